@@ -1,0 +1,6 @@
+"""CPU oracle for the SipMask hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package; the product (sipmask_amd) never does.  See oracle/ops.py header for
+what is pinned against reference golden vectors and what is "parity unpinned".
+"""

@@ -1,0 +1,308 @@
+"""CPU oracle: the SipMask detector graph as pure functions over a reference-named
+``state_dict`` (TEST INFRASTRUCTURE ONLY -- see oracle/ops.py header).
+
+Restates (fp32, torch-CPU ATen convs):
+  * ResNet caffe-style bottleneck backbone  M/mmdet/models/backbones/resnet.py:84-239,311-521
+  * FPN                                      M/mmdet/models/necks/fpn.py:137-178
+  * ConvModule conv->GN->ReLU                M/mmdet/ops/conv_module.py:34-132
+  * SipMaskHead.forward / get_bboxes_single  M/mmdet/models/anchor_heads/sipmask_head.py:241-287,543-633
+Parity unpinned: the reference has no test on this graph.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+ARCH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+FPN_STRIDES = (8, 16, 32, 64, 128)
+
+
+# ----------------------------------------------------------------------------
+# parameter construction (reference init, then the calibration overrides of
+# SURVEY section 8d so that synthetic weights exercise NMS / deform / masks)
+# ----------------------------------------------------------------------------
+
+
+def _kaiming(w, g):   # mmcv kaiming_init: fan_out, relu, normal
+    fan_out = w.shape[0] * w.shape[2] * w.shape[3]
+    return w.normal_(0, math.sqrt(2.0 / fan_out), generator=g)
+
+
+def _xavier_uniform(w, g):   # mmcv xavier_init(distribution='uniform'), fpn.py:131-135
+    fan_in = w.shape[1] * w.shape[2] * w.shape[3]
+    fan_out = w.shape[0] * w.shape[2] * w.shape[3]
+    a = math.sqrt(3.0) * math.sqrt(2.0 / (fan_in + fan_out))
+    return w.uniform_(-a, a, generator=g)
+
+
+def init_state_dict(depth=50, seed=0, calibrate=True, num_classes=81):
+    """Build a float32 state_dict with the reference's parameter names/shapes
+     and init rules (resnet.py:479-497, fpn.py:131-135,
+    sipmask_head.py:226-239), then apply the calibration overrides."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(name, co, ci, k, bias=False, init="kaiming", std=None):
+        w = torch.empty(co, ci, k, k)
+        if init == "kaiming":
+            _kaiming(w, g)
+        elif init == "xavier":
+            _xavier_uniform(w, g)
+        else:
+            w.normal_(0, std, generator=g)
+        sd[name + ".weight"] = w
+        if bias:
+            sd[name + ".bias"] = torch.zeros(co)
+
+    def bn(name, c, gamma=1.0):
+        sd[name + ".weight"] = torch.full((c,), gamma)
+        sd[name + ".bias"] = torch.zeros(c)
+        sd[name + ".running_mean"] = torch.zeros(c)
+        sd[name + ".running_var"] = torch.ones(c)
+        sd[name + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+    # ---- backbone
+    conv("backbone.conv1", 64, 3, 7)
+    bn("backbone.bn1", 64)
+    inplanes = 64
+    for li, nblocks in enumerate(ARCH[depth]):
+        planes = 64 * 2 ** li
+        for bi in range(nblocks):
+            p = "backbone.layer%d.%d" % (li + 1, bi)
+            conv(p + ".conv1", planes, inplanes, 1)
+            bn(p + ".bn1", planes)
+            conv(p + ".conv2", planes, planes, 3)
+            bn(p + ".bn2", planes)
+            conv(p + ".conv3", planes * 4, planes, 1)
+            # zero_init_residual sets bn3.weight = 0 (resnet.py:492-495); the
+            # calibration override sets it back to 1 so residual branches are live
+            bn(p + ".bn3", planes * 4, gamma=1.0 if calibrate else 0.0)
+            if bi == 0:
+                conv(p + ".downsample.0", planes * 4, inplanes, 1)
+                bn(p + ".downsample.1", planes * 4)
+            inplanes = planes * 4
+    # ---- neck (start_level=1, 3 laterals, 3 outputs, 2 extra)
+    for i, ci in enumerate((512, 1024, 2048)):
+        conv("neck.lateral_convs.%d.conv" % i, 256, ci, 1, bias=True, init="xavier")
+    for i in range(5):
+        conv("neck.fpn_convs.%d.conv" % i, 256, 256, 3, bias=True, init="xavier")
+    # ---- head
+    h = "bbox_head."
+    for i in range(3):
+        conv(h + "cls_convs.%d.conv" % i, 256, 256, 3, init="normal", std=0.01)
+        sd[h + "cls_convs.%d.gn.weight" % i] = torch.ones(256)
+        sd[h + "cls_convs.%d.gn.bias" % i] = torch.zeros(256)
+    for i in range(4):
+        conv(h + "reg_convs.%d.conv" % i, 256, 256, 3, init="normal", std=0.01)
+        sd[h + "reg_convs.%d.gn.weight" % i] = torch.ones(256)
+        sd[h + "reg_convs.%d.gn.bias" % i] = torch.zeros(256)
+    ncls = num_classes - 1
+    conv(h + "fcos_cls", ncls, 256, 3, bias=True, init="normal", std=0.01)
+    sd[h + "fcos_cls.bias"].fill_(float(-math.log((1 - 0.01) / 0.01)))
+    conv(h + "fcos_reg", 4, 256, 3, bias=True, init="normal", std=0.01)
+    conv(h + "fcos_centerness", 1, 256, 3, bias=True, init="normal", std=0.01)
+    for i in range(5):
+        sd[h + "scales.%d.scale" % i] = torch.tensor(1.0)
+    conv(h + "feat_align.conv_offset", 72, 4, 1, init="normal", std=0.2 if calibrate else 0.0)
+    if not calibrate:
+        sd[h + "feat_align.conv_offset.weight"].zero_()
+    conv(h + "feat_align.conv_adaption", 256, 256, 3, init="normal", std=0.01)
+    sd[h + "feat_align.norm.weight"] = torch.ones(256)
+    sd[h + "feat_align.norm.bias"] = torch.zeros(256)
+    conv(h + "sip_cof", 128, 256, 3, bias=True, init="normal", std=0.05 if calibrate else 0.001)
+    conv(h + "sip_mask_lat", 32, 512, 3, bias=True, init="normal", std=0.01)
+    conv(h + "sip_mask_lat0", 512, 768, 1, bias=True, init="normal", std=0.01)
+    if calibrate:
+        # random-normal tower weights at std 0.01 shrink the signal by ~0.5x per
+        # layer; give the synthetic net O(1) activations so boxes/masks are non-trivial
+        for i in range(3):
+            sd[h + "cls_convs.%d.conv.weight" % i].mul_(3.0)
+        for i in range(4):
+            sd[h + "reg_convs.%d.conv.weight" % i].mul_(3.0)
+        sd[h + "feat_align.conv_adaption.weight"].mul_(3.0)
+        sd[h + "fcos_reg.weight"].mul_(3.0)
+        sd[h + "fcos_reg.bias"].fill_(2.0)
+        sd[h + "fcos_cls.weight"].mul_(8.0)
+        sd[h + "sip_mask_lat.weight"].mul_(4.0)
+        sd[h + "sip_mask_lat0.weight"].mul_(4.0)
+        for i in range(5):
+            sd[h + "scales.%d.scale" % i] = torch.tensor(1.0 + 0.25 * i)
+    return sd
+
+
+def calibrate_cls_bias(sd, cls_logits_nobias, target=1000, score_thr=0.05):
+    """pick fcos_cls.bias by bisection so that about ``target``
+    class scores of one image exceed score_thr.  cls_logits_nobias: 1-D tensor of
+    all class logits of one image computed with bias 0."""
+    lo, hi = -20.0, 20.0
+    logit_thr = math.log(score_thr / (1 - score_thr))
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        n = int((cls_logits_nobias + mid > logit_thr).sum())
+        if n > target:
+            hi = mid
+        else:
+            lo = mid
+    sd["bbox_head.fcos_cls.bias"].fill_(0.5 * (lo + hi))
+    return 0.5 * (lo + hi)
+
+
+# ----------------------------------------------------------------------------
+# forward graph
+# ----------------------------------------------------------------------------
+
+
+def _bn(x, sd, p):
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
+                        sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+
+
+def backbone_forward(sd, x, depth=50, prefix="backbone."):
+    """resnet.py:501-512; caffe style => stride on conv1 of the block (:125-130)."""
+    x = F.conv2d(x, sd[prefix + "conv1.weight"], None, 2, 3)
+    x = F.relu(_bn(x, sd, prefix + "bn1"))
+    x = F.max_pool2d(x, 3, 2, 1)
+    outs = []
+    for li, nblocks in enumerate(ARCH[depth]):
+        for bi in range(nblocks):
+            p = "%slayer%d.%d" % (prefix, li + 1, bi)
+            stride = 2 if (bi == 0 and li > 0) else 1
+            idt = x
+            o = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], None, stride), sd, p + ".bn1"))
+            o = F.relu(_bn(F.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1), sd, p + ".bn2"))
+            o = _bn(F.conv2d(o, sd[p + ".conv3.weight"]), sd, p + ".bn3")
+            if bi == 0:
+                idt = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride), sd, p + ".downsample.1")
+            x = F.relu(o + idt)
+        outs.append(x)
+    return outs
+
+
+def fpn_forward(sd, feats, prefix="neck."):
+    """fpn.py:137-178 with start_level=1, add_extra_convs on outputs, relu before P7."""
+    ins = feats[1:]
+    lats = [F.conv2d(ins[i], sd[prefix + "lateral_convs.%d.conv.weight" % i],
+                     sd[prefix + "lateral_convs.%d.conv.bias" % i]) for i in range(3)]
+    for i in (2, 1):
+        lats[i - 1] = lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[2:], mode="nearest")
+    outs = [F.conv2d(lats[i], sd[prefix + "fpn_convs.%d.conv.weight" % i],
+                     sd[prefix + "fpn_convs.%d.conv.bias" % i], 1, 1) for i in range(3)]
+    outs.append(F.conv2d(outs[-1], sd[prefix + "fpn_convs.3.conv.weight"],
+                         sd[prefix + "fpn_convs.3.conv.bias"], 2, 1))
+    outs.append(F.conv2d(F.relu(outs[-1]), sd[prefix + "fpn_convs.4.conv.weight"],
+                         sd[prefix + "fpn_convs.4.conv.bias"], 2, 1))
+    return outs
+
+
+def _tower(sd, x, p):
+    x = F.conv2d(x, sd[p + ".conv.weight"], None, 1, 1)
+    return F.relu(F.group_norm(x, 32, sd[p + ".gn.weight"], sd[p + ".gn.bias"], 1e-5))
+
+
+def head_forward(sd, feats, prefix="bbox_head.", strides=FPN_STRIDES, return_aux=False):
+    """sipmask_head.py:241-287."""
+    h = prefix
+    cls_scores, bbox_preds, ctrs, cofs, fm = [], [], [], [], []
+    aux = dict(bbox_raw=[], offsets=[], cls_feat=[], reg_feat=[], aligned=[])
+    for li, (x, stride) in enumerate(zip(feats, strides)):
+        cf, rf = x, x
+        for i in range(3):
+            cf = _tower(sd, cf, h + "cls_convs.%d" % i)
+        for i in range(4):
+            rf = _tower(sd, rf, h + "reg_convs.%d" % i)
+        bbox_pred = sd[h + "scales.%d.scale" % li] * F.conv2d(rf, sd[h + "fcos_reg.weight"], sd[h + "fcos_reg.bias"], 1, 1)
+        offset = F.conv2d(bbox_pred, sd[h + "feat_align.conv_offset.weight"])
+        y = ops.deform_conv(cf, offset, sd[h + "feat_align.conv_adaption.weight"], 1, 1, 1, 4)
+        y = F.relu(F.group_norm(y, 32, sd[h + "feat_align.norm.weight"], sd[h + "feat_align.norm.bias"], 1e-5))
+        cls_scores.append(F.conv2d(y, sd[h + "fcos_cls.weight"], sd[h + "fcos_cls.bias"], 1, 1))
+        ctrs.append(F.conv2d(rf, sd[h + "fcos_centerness.weight"], sd[h + "fcos_centerness.bias"], 1, 1))
+        bbox_preds.append(bbox_pred.float() * stride)
+        cofs.append(F.conv2d(y, sd[h + "sip_cof.weight"], sd[h + "sip_cof.bias"], 1, 1))
+        if li < 3:
+            fm.append(rf if li == 0 else F.interpolate(rf, scale_factor=2 ** li, mode="bilinear", align_corners=False))
+        if return_aux:
+            aux["bbox_raw"].append(bbox_pred)
+            aux["offsets"].append(offset)
+            aux["cls_feat"].append(cf)
+            aux["reg_feat"].append(rf)
+            aux["aligned"].append(y)
+    fmc = torch.cat(fm, 1)
+    lat0 = F.relu(F.conv2d(fmc, sd[h + "sip_mask_lat0.weight"], sd[h + "sip_mask_lat0.bias"]))
+    lat = F.relu(F.conv2d(lat0, sd[h + "sip_mask_lat.weight"], sd[h + "sip_mask_lat.bias"], 1, 1))
+    feat_masks = F.interpolate(lat, scale_factor=4, mode="bilinear", align_corners=False)
+    if return_aux:
+        aux["basis_lowres"] = lat
+        return cls_scores, bbox_preds, ctrs, cofs, feat_masks, aux
+    return cls_scores, bbox_preds, ctrs, cofs, feat_masks
+
+
+def get_points(featmap_sizes, strides=FPN_STRIDES):
+    """sipmask_head.py:664-695: (x*s + s//2, y*s + s//2), row-major."""
+    pts = []
+    for (h, w), s in zip(featmap_sizes, strides):
+        xr = torch.arange(0, w * s, s, dtype=torch.float32)
+        yr = torch.arange(0, h * s, s, dtype=torch.float32)
+        y, x = torch.meshgrid(yr, xr, indexing="ij")
+        pts.append(torch.stack((x.reshape(-1), y.reshape(-1)), -1) + s // 2)
+    return pts
+
+
+def select_candidates(cls_scores, bbox_preds, ctrs, cofs, img_shape, nms_pre=1000,
+                      strides=FPN_STRIDES):
+    """sipmask_head.py:563-591 for ONE image (tensors [C,h,w] per level).
+    Returns mlvl_bboxes [K,4], mlvl_scores [K,C+1], mlvl_centerness [K],
+    mlvl_cofs [K,128], and (level, position) of every candidate."""
+    pts = get_points([c.shape[-2:] for c in cls_scores], strides)
+    B_, S_, C_, F_, lv, ps = [], [], [], [], [], []
+    for li, (cs, bp, ct, cf, p) in enumerate(zip(cls_scores, bbox_preds, ctrs, cofs, pts)):
+        ncls = cs.shape[0]
+        scores = cs.permute(1, 2, 0).reshape(-1, ncls).sigmoid()
+        ctr = ct.permute(1, 2, 0).reshape(-1).sigmoid()
+        bp = bp.permute(1, 2, 0).reshape(-1, 4)
+        cf = cf.permute(1, 2, 0).reshape(-1, 128)
+        pos = torch.arange(scores.shape[0])
+        if nms_pre > 0 and scores.shape[0] > nms_pre:
+            mx = (scores * ctr[:, None]).max(dim=1)[0]
+            idx = torch.from_numpy(ops.topk_desc(mx.numpy(), nms_pre))
+            p, bp, cf, scores, ctr, pos = p[idx], bp[idx], cf[idx], scores[idx], ctr[idx], pos[idx]
+        B_.append(ops.distance2bbox(p, bp, max_shape=img_shape))
+        S_.append(scores)
+        C_.append(ctr)
+        F_.append(cf)
+        lv.append(torch.full((scores.shape[0],), li, dtype=torch.long))
+        ps.append(pos)
+    scores = torch.cat(S_)
+    scores = torch.cat([scores.new_zeros(scores.shape[0], 1), scores], 1)
+    return torch.cat(B_), scores, torch.cat(C_), torch.cat(F_), torch.cat(lv), torch.cat(ps)
+
+
+def get_masks_single(cls_scores, bbox_preds, ctrs, cofs, feat_mask, img_shape, cfg,
+                     scale_factor=1.0, rescale=False):
+    """get_bboxes_single up to (not including) RLE: sipmask_head.py:543-633."""
+    mb, ms, mc, mf, lv, ps = select_candidates(cls_scores, bbox_preds, ctrs, cofs, img_shape,
+                                               cfg.get("nms_pre", -1))
+    if rescale:
+        mb = mb / float(scale_factor)
+    det, lab, keep = ops.multiclass_nms_idx(mb.numpy(), ms.numpy(), cfg["score_thr"],
+                                            cfg["nms"]["iou_thr"], cfg["max_per_img"],
+                                            score_factors=mc.numpy())
+    out = dict(det_bboxes=det, det_labels=lab, idxs_keep=keep, cand_boxes=mb, cand_scores=ms,
+               cand_ctr=mc, cand_cofs=mf, cand_level=lv, cand_pos=ps)
+    if det.shape[0] > 0:
+        det_cofs = mf[torch.from_numpy(keep)]
+        out.update(ops.mask_assemble(feat_mask, det_cofs, det, scale_factor, rescale))
+        out["det_cofs"] = det_cofs
+    return out
+
+
+def detector_forward(sd, img, depth=50):
+    feats = backbone_forward(sd, img, depth)
+    pyr = fpn_forward(sd, feats)
+    return head_forward(sd, pyr)
+
+
+DEFAULT_TEST_CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05,
+                        nms=dict(type="nms", iou_thr=0.5), max_per_img=100)

@@ -1,0 +1,180 @@
+"""Pins the CPU oracle: reference golden vectors for NMS/IoU, and internal
+cross-checks for the ops the reference never tests."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "nms_kat.json")))
+
+
+@pytest.mark.parametrize("mode", ["gpu", "cpu"])
+def test_nms_caffe2_5box(kat, mode):
+    # B/tests/test_nms.py:16-58 -- none of these cases sits on the threshold, so
+    # both the '>' (GPU) and '>=' (CPU) variants must reproduce the vectors
+    c = kat["caffe2_5box"]
+    dets = np.array(c["dets"], np.float32)
+    for thr, gt in zip(c["thresh"], c["keep"]):
+        np.testing.assert_array_equal(ops.nms(dets, thr, mode), np.array(gt))
+
+
+@pytest.mark.parametrize("mode", ["gpu", "cpu"])
+def test_nms_boxes53(kat, mode):
+    c = kat["boxes53"]   # B/tests/test_nms.py:60-221
+    dets = np.concatenate([np.array(c["boxes"], np.float32), np.array(c["scores"], np.float32)[:, None]], 1)
+    np.testing.assert_array_equal(ops.nms(dets, c["thresh"], mode), np.array(c["keep"]))
+
+
+def test_nms_doctests(kat):
+    for name in ("wrapper_doctest", "mmdet_test4"):
+        c = kat[name]
+        assert len(ops.nms(np.array(c["dets"], np.float32), c["thresh"])) == c["n_keep"]
+    assert ops.nms(np.zeros((0, 5), np.float32), 0.5).shape == (0,)
+
+
+def test_nms_threshold_edge():
+    # IoU(+1) of these two boxes is exactly 0.5: GPU ('>') keeps both, CPU ('>=') drops one
+    dets = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 4, 0.8]], np.float32)
+    assert list(ops.nms(dets, 0.5, "gpu")) == [0, 1]
+    assert list(ops.nms(dets, 0.5, "cpu")) == [0]
+
+
+def test_iou_doctest(kat):
+    c = kat["iou_doctest"]
+    iou = ops.bbox_overlaps(torch.tensor(c["bboxes1"], dtype=torch.float32), torch.tensor(c["bboxes2"], dtype=torch.float32))
+    np.testing.assert_allclose(iou.numpy(), np.array(c["iou"]), atol=5e-5)
+    e = torch.zeros(0, 4)
+    ne = torch.tensor([[0., 0, 10, 9]])
+    assert tuple(ops.bbox_overlaps(e, ne).shape) == (0, 1)
+    assert tuple(ops.bbox_overlaps(ne, e).shape) == (1, 0)
+
+
+def test_multiclass_nms_idx_structure():
+    rng = np.random.RandomState(0)
+    K, C = 300, 6
+    xy = rng.rand(K, 2).astype(np.float32) * 200
+    wh = rng.rand(K, 2).astype(np.float32) * 60 + 5
+    boxes = np.concatenate([xy, xy + wh], 1)
+    scores = np.concatenate([np.zeros((K, 1), np.float32), rng.rand(K, C).astype(np.float32) * 0.2], 1)
+    ctr = rng.rand(K).astype(np.float32)
+    det, lab, keep = ops.multiclass_nms_idx(boxes, scores, 0.05, 0.5, 100000, ctr)
+    # class blocks ascending, within a class candidate indices ascending
+    assert np.all(np.diff(lab) >= 0)
+    for c in range(C):
+        k = keep[lab == c]
+        assert np.all(np.diff(k) > 0)
+        # kept score = score * centerness of the source row, thresholded pre-centerness
+        np.testing.assert_array_equal(det[lab == c, 4], (scores[k, c + 1] * ctr[k]).astype(np.float32))
+        assert np.all(scores[k, c + 1] > 0.05)
+    np.testing.assert_array_equal(det[:, :4], boxes[keep])
+    det2, lab2, keep2 = ops.multiclass_nms_idx(boxes, scores, 0.05, 0.5, 20, ctr)
+    assert det2.shape[0] == 20 and np.all(np.diff(det2[:, 4]) <= 0)
+    det3, _, _ = ops.multiclass_nms_idx(boxes, scores, 0.9, 0.5, 20, ctr)
+    assert det3.shape == (0, 5)
+
+
+def test_deform_conv_zero_offset_equals_conv2d():
+    torch.manual_seed(0)
+    x = torch.randn(2, 8, 9, 11, dtype=torch.float64)
+    w = torch.randn(6, 8, 3, 3, dtype=torch.float64)
+    off = torch.zeros(2, 4 * 18, 9, 11, dtype=torch.float64)
+    y = ops.deform_conv(x, off, w, 1, 1, 1, 4)
+    torch.testing.assert_close(y, F.conv2d(x, w, None, 1, 1), rtol=1e-12, atol=1e-12)
+
+
+def test_deform_conv_integer_offset_equals_shifted_conv():
+    torch.manual_seed(1)
+    x = torch.randn(1, 4, 10, 12, dtype=torch.float64)
+    w = torch.randn(5, 4, 3, 3, dtype=torch.float64)
+    off = torch.zeros(1, 2 * 18, 10, 12, dtype=torch.float64)
+    off[:, 0::2] = 1.0      # every tap: +1 row
+    off[:, 1::2] = -2.0     # every tap: -2 cols
+    y = ops.deform_conv(x, off, w, 1, 1, 1, 2)
+    xs = torch.zeros_like(x)
+    xs[:, :, :-1, 2:] = x[:, :, 1:, :-2]       # xs[h,w] = x[h+1,w-2], zero outside
+    # borders differ by construction (conv zero-pads xs, deform reads x there)
+    torch.testing.assert_close(y[..., 2:-2, 3:-3], F.conv2d(xs, w, None, 1, 1)[..., 2:-2, 3:-3], rtol=1e-12, atol=1e-12)
+
+
+def test_deform_conv_fractional_border():
+    # a sample at h=-0.5 is valid (> -1) and only its high-row corners contribute
+    x = torch.ones(1, 1, 4, 4, dtype=torch.float64)
+    w = torch.zeros(1, 1, 3, 3, dtype=torch.float64)
+    w[0, 0, 1, 1] = 1.0
+    off = torch.zeros(1, 18, 4, 4, dtype=torch.float64)
+    off[0, 2 * 4] = -0.5   # centre tap, dh=-0.5
+    y = ops.deform_conv(x, off, w, 1, 1, 1, 1)
+    assert torch.allclose(y[0, 0, 0], torch.full((4,), 0.5, dtype=torch.float64))
+    assert torch.allclose(y[0, 0, 1:], torch.ones(3, 4, dtype=torch.float64))
+    off[0, 2 * 4] = -1.0   # h_im = -1 for row 0 -> not > -1 -> zero
+    y = ops.deform_conv(x, off, w, 1, 1, 1, 1)
+    assert torch.all(y[0, 0, 0] == 0)
+
+
+def test_crop_split_semantics():
+    rng = np.random.RandomState(0)
+    H, W, N = 12, 15, 5
+    data = rng.rand(4, H, W, N).astype(np.float32)
+    rois = np.array([[2.3, 1.2, 9.7, 8.8], [0, 0, 15, 12], [-3.5, -2, 4.2, 5.1], [5, 5, 5.05, 5.05], [10, 3, 30, 20]], np.float32)
+    out = ops.crop_split(data, rois, 2)
+    for n in range(N):
+        x1, y1, x2, y2 = rois[n]
+        for ph in range(H):
+            for pw in range(W):
+                if pw >= x1 and ph >= y1 and pw < x2 and ph < y2:
+                    rw = np.float32((np.float64(np.float32(x2 - x1)) + 0.1) / 2)
+                    rh = np.float32((np.float64(np.float32(y2 - y1)) + 0.1) / 2)
+                    iw = int(np.float32(np.float32(pw) - x1) / rw)
+                    ih = int(np.float32(np.float32(ph) - y1) / rh)
+                    assert out[ph, pw, n] == data[ih * 2 + iw, ph, pw, n]
+                else:
+                    assert out[ph, pw, n] == 0
+    # c=1 crop_split == crop_split_gt
+    g = ops.crop_split_gt(data[0], rois)
+    np.testing.assert_array_equal(g, ops.crop_split(data[:1], rois, 1))
+    # backward is the exact adjoint
+    go = rng.rand(H, W, N).astype(np.float32)
+    gi = ops.crop_split_backward(go, rois, 2)
+    assert np.isclose((gi.astype(np.float64) * data).sum(), (go.astype(np.float64) * out).sum())
+
+
+def test_focal_cuda_formula_matches_python_formula():
+    torch.manual_seed(0)
+    x = torch.randn(50, 7, dtype=torch.float64) * 4
+    t = torch.randint(0, 8, (50,))
+    a = ops.sigmoid_focal_loss_forward(x, t, 2.0, 0.25)
+    b = ops.py_sigmoid_focal_loss(x, t, 2.0, 0.25)
+    torch.testing.assert_close(a, b, rtol=1e-9, atol=1e-12)
+    xr = x.clone().requires_grad_(True)
+    ops.py_sigmoid_focal_loss(xr, t).sum().backward()
+    g = ops.sigmoid_focal_loss_backward(x, t, torch.ones_like(x))
+    torch.testing.assert_close(g, xr.grad, rtol=1e-8, atol=1e-10)
+
+
+def test_fast_nms_basic():
+    boxes = np.array([[0, 0, 10, 10], [1, 1, 10, 10], [20, 20, 30, 30]], np.float32)
+    scores = np.array([[0.9, 0.8, 0.7], [0.01, 0.02, 0.5]], np.float32)
+    cofs = np.arange(12, dtype=np.float32).reshape(3, 4)
+    b, c, m = ops.fast_nms(boxes, scores, cofs, 0.5, 200, 0.1)
+    # class 0 keeps box 0 and 2 (box 1 overlaps box 0 at IoU 0.81), class 1 keeps box 2
+    assert sorted(zip(c.tolist(), [round(float(v), 3) for v in b[:, 4]])) == [(0, 0.7), (0, 0.9), (1, 0.5)]
+
+
+def test_mask_assemble_consistency():
+    torch.manual_seed(0)
+    fm = torch.randn(32, 20, 28)
+    cof = torch.randn(3, 128) * 0.3
+    boxes = torch.tensor([[4.0, 6.0, 30.0, 32.0, 0.9], [0, 0, 55, 39, 0.8], [20.5, 3.2, 41.0, 22.9, 0.7]])
+    r = ops.mask_assemble(fm, cof, boxes, 1.0, False)
+    assert r["pos_masks"].shape == (3, 20, 28) and r["masks"].shape == (3, 40, 56)
+    # outside the half-resolution box the probabilities are exactly zero
+    assert float(r["pos_masks"][0, :3].abs().max()) == 0
+    assert set(np.unique(r["masks"].numpy())) <= {0, 1}
