@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Headline benchmark: img/s of SipMask-R50 800x1333 (padded 800x1344) inference, batch 4 per GPU,
+bf16 storage / f32 accumulate, on N MI355X of one node (one process per GPU, images sharded by
+batch, no data-path collective: BASELINE.json configs[1]).
+
+A "step" = one full pass of the hot path over one batch already resident in HBM:
+NCHW image -> ResNet-50 -> FPN -> SipMaskHead -> top-k / NMS -> fused mask assembly (uint8 masks).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
+the 3x3 256->256 tower implicit-GEMM over all 5 FPN levels) and `cpu_baseline` (the CPU oracle
+timed on the host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+IMG_H, IMG_W = 800, 1344           # 800x1333 padded to a multiple of 32 (cfg Pad size_divisor=32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE configs[1]: 4)")
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", type=str, default="", help="write the per-step HIP-event breakdown to this file")
+    return ap.parse_args()
+
+
+def cpu_baseline(det, seed=0):
+    """The CPU oracle (kind "port": the reference has no CPU path) on ONE 800x1344 image,
+    all host cores, 1 warm-up + 2 timed forwards of extract_feat -> head -> get_masks (no RLE)."""
+    from oracle import model as OM
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in det.state_dict().items()}
+    img = torch.randn(1, 3, IMG_H, IMG_W, generator=torch.Generator().manual_seed(seed))
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            cls, bb, ctr, cof, fm = OM.detector_forward(sd, img, det.backbone.depth)
+            OM.get_masks_single([c[0] for c in cls], [c[0] for c in bb], [c[0] for c in ctr], [c[0] for c in cof],
+                                fm[0], (IMG_H, 1333, 3), OM.DEFAULT_TEST_CFG)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[0]
+    return dict(value=round(1.0 / t, 4), unit="img/s", cores=cores, kind="port",
+                sample="1 image 3x800x1344 fp32, torch-CPU oracle (oneDNN convs + restated deform/NMS/mask ops), "
+                       "1 warm-up + best of 2 timed forwards (%.1f s each)" % t)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+
+    from sipmask_amd.synthetic import build_synthetic_detector, calibrate_cls_bias
+    B = args.batch
+    det = build_synthetic_detector(args.depth, seed=0)
+    g = torch.Generator().manual_seed(1234 + rank)
+    img = torch.randn(B, 3, IMG_H, IMG_W, generator=g).to(dev)       # synthetic, resident in HBM
+    shape = (IMG_H, 1333, 3)
+    eng = det.prepare(B, (IMG_H, IMG_W), shape)
+    bias = calibrate_cls_bias(det, eng, img, target_per_img=1000)
+    del eng
+    torch.cuda.empty_cache()
+    eng = det.prepare(B, (IMG_H, IMG_W), shape)
+
+    # ---- warm-up (eager), then optional graph capture
+    for _ in range(max(1, min(args.warmup, 2))):
+        eng.run(img)
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                eng.run(img)
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eng.run(img)
+        except Exception as e:  # capture problems must not invalidate the measurement: fall back to eager
+            print("[bench] graph capture failed (%s); running eagerly" % str(e)[:200], file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            eng.run(img)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ndet = eng.results()["ndet"].cpu().tolist()
+
+    # ---- per-step HIP-event breakdown (eager, on the launch stream) -> roofline of the dominant kernel
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in eng.steps]
+    reps = 3
+    acc = [0.0] * len(eng.steps)
+    eng.img = img
+    for r in range(reps):
+        for (label, fn), (e0, e1) in zip(eng.steps, ev):
+            e0.record()
+            fn()
+            e1.record()
+        torch.cuda.synchronize()
+        for i, (e0, e1) in enumerate(ev):
+            acc[i] += e0.elapsed_time(e1) / reps
+    conv_ms = {c.name: None for c in eng.convs}
+    for (label, _), ms in zip(eng.steps, acc):
+        if label.startswith("conv:"):
+            conv_ms[label[5:]] = ms
+    towers = [c for c in eng.convs if c.name.startswith("head.cls_convs") or c.name.startswith("head.reg_convs")]
+    tower_ms = sum(conv_ms[c.name] for c in towers) / len(towers)
+    tower_flops = towers[0].flops
+    all_conv_ms = sum(v for v in conv_ms.values())
+    all_conv_flops = eng.total_conv_flops()
+    fpn = [c for c in eng.convs if c.name.startswith("fpn.")]
+    fpn_tf = sum(c.flops for c in fpn) / (sum(conv_ms[c.name] for c in fpn) * 1e-3) / 1e12
+    achieved = tower_flops / (tower_ms * 1e-3) / 1e12
+    if args.breakdown and rank == 0:
+        with open(args.breakdown, "w") as f:
+            f.write("# per-step HIP event times (ms), eager launches, batch %d, mean of %d\n" % (B, reps))
+            for (label, _), ms in zip(eng.steps, acc):
+                f.write("%-44s %9.4f\n" % (label, ms))
+            f.write("# sum %.3f ms; convs %.3f ms = %.1f TFLOP/s over %.1f GFLOP\n" %
+                    (sum(acc), all_conv_ms, all_conv_flops / all_conv_ms / 1e9, all_conv_flops / 1e9))
+
+    if rank == 0:
+        total_imgs = B * args.steps * world
+        out = {
+            "metric": "img/s SipMask-R50 800x1333 inference (ResNet50+FPN+SipMaskHead+NMS+mask assembly)",
+            "value": round(total_imgs / elapsed, 3),
+            "unit": "img/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic (randn images, reference-init random weights + SURVEY 8d calibration overrides)",
+            "config": {"workload": "SipMask-R%d FPN inference, batch=%d/GPU, 3x800x1344 (800x1333 padded), bf16 "
+                                   "storage + f32 accumulate, score_thr .05, nms .5, max_per_img 100" % (args.depth, B),
+                       "global_batch": B * world, "parallelism": "dp%d (batch shard, no collective)" % world,
+                       "launch": "hipGraph replay" if graph is not None else "eager",
+                       "detections_per_image": ndet},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv_igemm_kernel<2,2,2,2> tower 3x3 256->256 over 5 FPN levels (M=%d,N=256,K=2304)"
+                                   % (B * 22400),
+                         "gflop_per_launch": round(tower_flops / 1e9, 2), "ms_per_launch": round(tower_ms, 4),
+                         "all_convs_tflops": round(all_conv_flops / (all_conv_ms * 1e-3) / 1e12, 2),
+                         "fpn_convs_tflops": round(fpn_tf, 2),
+                         "conv_gflop_per_step": round(all_conv_flops / 1e9, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(det)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,203 @@
+/*
+ * sipmask_hip.h -- C ABI of libsipmask_hip.so: the MI355X (gfx950) SipMask hot path.
+ *
+ * This header is the drop-in boundary: every entry point
+ * replaces one reference pybind11/ATen seam, takes raw DEVICE pointers + sizes +
+ * an explicit stream, allocates nothing, never synchronises, keeps no global
+ * state, and returns an int status (0 = ok, <0 = sm_status).  Citations are into
+ * /root/reference (M/ = SipMask-mmdetection/, B/ = SipMask-benchmark/).
+ *
+ * Data layout in HBM:
+ *   activations  "pyramid tensors": rows = sum_l B*H_l*W_l, each row C channels,
+ *                bf16 (or f32 where stated), NHWC inside a level, levels
+ *                concatenated (level l starts at row row0[l]).
+ *   conv weights [cout_pad][Kp] bf16, K = (kh,kw,cin) with cin fastest, Kp = K
+ *                rounded up to 64, rows zero padded to the cout tile.
+ */
+#ifndef SIPMASK_HIP_H
+#define SIPMASK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SM_ABI_VERSION 1
+#define SM_MAX_LEVELS 5
+
+typedef void* sm_stream_t; /* hipStream_t */
+
+typedef enum {
+  SM_OK = 0,
+  SM_ERR_BAD_SHAPE = -1,
+  SM_ERR_BAD_ARG = -2,
+  SM_ERR_LAUNCH = -3,
+  SM_ERR_UNSUPPORTED = -4,
+  SM_ERR_WORKSPACE = -5
+} sm_status;
+
+/* conv flags */
+#define SM_CONV_RELU 1u          /* y = max(y, 0) */
+#define SM_CONV_OUT_F32 2u       /* y stored as float32 instead of bf16 */
+#define SM_CONV_RES_ADD 4u       /* y += residual[row] (bf16, same rows/cstride as y) */
+#define SM_CONV_RES_NEAREST 8u   /* y += residual at nearest-neighbour source (FPN top-down,
+                                    M/mmdet/models/necks/fpn.py:149-152) */
+#define SM_CONV_IN_RELU 16u      /* x = max(x,0) applied on load (fpn.py:174-175 P7) */
+
+/* One (multi-level) 2-D convolution as an implicit GEMM.  Replaces the ATen/cuDNN
+ * conv calls under M/mmdet/models/backbones/resnet.py:206-229,
+ * M/mmdet/models/necks/fpn.py:141-175 and
+ * M/mmdet/models/anchor_heads/sipmask_head.py:253-285. */
+typedef struct {
+  int32_t nlev;                   /* 1..SM_MAX_LEVELS, all levels share the weights */
+  int32_t batch;
+  int32_t in_h[SM_MAX_LEVELS], in_w[SM_MAX_LEVELS];
+  int32_t out_h[SM_MAX_LEVELS], out_w[SM_MAX_LEVELS];
+  int64_t in_row0[SM_MAX_LEVELS];   /* first row of level l in x        */
+  int64_t out_row0[SM_MAX_LEVELS];  /* first row of level l in y / residual (RES_ADD) */
+  int32_t cin;                    /* multiple of 8 */
+  int32_t cout;                   /* real output channels */
+  int32_t cout_pad;               /* weight rows (multiple of the cout tile: 32, 64 or 128) */
+  int32_t kh, kw, stride, pad, dil;
+  int32_t in_cstride;             /* elements between consecutive rows of x   */
+  int32_t out_cstride, out_coff;  /* y row stride / first channel (concat slices) */
+  int32_t res_cstride;
+  int32_t res_h[SM_MAX_LEVELS], res_w[SM_MAX_LEVELS]; /* RES_NEAREST source size */
+  int64_t res_row0[SM_MAX_LEVELS];
+  uint32_t flags;
+  int32_t scale_nch;              /* channels < scale_nch are multiplied by level_scale */
+  float level_scale[SM_MAX_LEVELS]; /* Scale(), sipmask_head.py:261: y=(acc+bias)*scale */
+  int32_t deform_groups;          /* deform conv only: offset layout [row][G][kh*kw][2] f32 */
+} sm_conv_desc;
+
+int sm_version(void);
+const char* sm_strerror(int status);
+/* which cout tile (32/64/128) the library will use for this cout: weights must be
+ * padded to a multiple of it */
+int sm_conv_cout_tile(int cout);
+
+/* y = epilogue(conv(x, w) + bias).  x bf16 rows, w bf16 [cout_pad][Kp], bias f32[cout]
+ * or NULL, residual bf16 or NULL, y bf16/f32. */
+int sm_conv2d(const sm_conv_desc* d, const void* x, const void* w, const float* bias,
+              const void* residual, void* y, sm_stream_t stream);
+
+/* Deformable conv v1 forward, bilinear gather fused into the GEMM operand load
+ * (never materialises the column buffer).  Replaces deform_conv_forward_cuda,
+ * M/mmdet/ops/dcn/src/deform_conv_cuda.cpp:152-260 + deformable_im2col_gpu_kernel,
+ * M/mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:191-243.
+ * offset: f32 [rows][G*kh*kw*2] with the reference channel order (kernel.cu:216-223). */
+int sm_deform_conv2d(const sm_conv_desc* d, const void* x, const float* offset, const void* w,
+                     const float* bias, void* y, sm_stream_t stream);
+
+/* offset = W_off (72x4) . (level_scale * reg[row][0:4]) -- FeatureAlign.conv_offset (level_scale
+ * NULL = 1 when reg already carries Scale),
+ * sipmask_head.py:30-33,50.  reg: f32 rows with stride reg_cstride, out f32 [rows][nout]. */
+int sm_offset_linear(const float* reg, int reg_cstride, const float* w_off, int nout,
+                     const int64_t* row0, const int32_t* rows_per_level, const float* level_scale,
+                     int nlev, float* out, sm_stream_t stream);
+
+/* GroupNorm(groups) + optional ReLU over each (image, level), in place allowed.
+ * nn.GroupNorm in M/mmdet/ops/conv_module.py:116-120 / sipmask_head.py:42,52.
+ * stats: f32 workspace [batch*nlev*groups*2], zeroed by the call. */
+int sm_groupnorm(const void* x, void* y, const float* gamma, const float* beta, float* stats,
+                 int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels,
+                 int groups, float eps, int relu, sm_stream_t stream);
+
+/* 3x3 stride-2 pad-1 max pool (resnet.py:460), NHWC bf16. */
+int sm_maxpool3x3s2(const void* x, void* y, int batch, int h, int w, int c, sm_stream_t stream);
+
+/* NCHW f32 image -> NHWC bf16 with channels zero padded to cpad. */
+int sm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int batch, int c, int h, int w, int cpad,
+                             sm_stream_t stream);
+
+/* Bilinear (align_corners=False) integer-factor upsample of NHWC rows, written into a channel
+ * slice of y (F.interpolate at sipmask_head.py:279,285).  in: bf16 or f32; out same type. */
+int sm_upsample_bilinear(const void* x, void* y, int batch, int h, int w, int c, int factor,
+                         int in_cstride, int out_cstride, int out_coff, int is_f32,
+                         sm_stream_t stream);
+
+/* ---- detection post-processing (sipmask_head.py:543-605) ------------------------------- */
+
+typedef struct {
+  int32_t batch, nlev, num_classes; /* num_classes = 80 (without background) */
+  int32_t h[SM_MAX_LEVELS], w[SM_MAX_LEVELS], stride[SM_MAX_LEVELS];
+  int64_t row0[SM_MAX_LEVELS];   /* level start row in the head output tensors */
+  int32_t cls_cstride, cls_coff; /* class logits   f32 [rows][cls_cstride]  */
+  int32_t cof_cstride, cof_coff; /* coefficients   f32 [rows][cof_cstride], 128 wide */
+  int32_t reg_cstride;           /* f32 [rows][reg_cstride]: ch0-3 = bbox_pred (x Scale, NOT yet
+                                    x stride: the kernel applies bbox_pred.float()*stride,
+                                    sipmask_head.py:268), ch4 = centerness logit */
+  int32_t nms_pre;               /* cfg.nms_pre */
+  int32_t img_h, img_w;          /* img_shape for the clamp (transforms.py:219-223) */
+  int32_t kmax;                  /* candidate capacity per image = sum_l min(nms_pre, h*w) */
+  float scale_factor;            /* boxes are divided by it when rescale != 0 (sipmask_head.py:587-588) */
+  int32_t rescale;
+  int32_t reg_prescaled;         /* 1: reg ch0-3 already carry x stride (API path: bbox_preds as
+                                    returned by SipMaskHead.forward) */
+} sm_det_desc;
+
+/* workspace bytes for sm_det_select */
+int64_t sm_det_select_workspace(const sm_det_desc* d);
+/* per level: max_c sigmoid(cls)*sigmoid(ctr) -> top-k (value desc, index asc) -> gather +
+ * distance2bbox.  Outputs per image: boxes f32 [B][kmax][4], scores f32 [B][kmax][C]
+ * (sigmoid, no background column), ctr f32 [B][kmax], cofs f32 [B][kmax][128],
+ * cand_pos i32 [B][kmax] (position inside its level), ncand i32 [B]. */
+int sm_det_select(const sm_det_desc* d, const float* cls, const float* reg, const float* cof,
+                  float* boxes, float* scores, float* ctr, float* cofs, int32_t* cand_pos,
+                  int32_t* ncand, void* workspace, sm_stream_t stream);
+
+int64_t sm_multiclass_nms_workspace(int batch, int kmax, int num_classes);
+/* Batched device-resident multiclass_nms_idx, M/mmdet/core/post_processing/bbox_nms.py:79-146
+ * with the GPU NMS rule IoU(+1) > thr (M/mmdet/ops/nms/src/nms_kernel.cu:14-22,61).
+ * Outputs padded to max_num: det f32 [B][max_num][5], labels i64 [B][max_num],
+ * keep i64 [B][max_num] (candidate row), ndet i32 [B]. */
+int sm_multiclass_nms(const float* boxes, const float* scores, const float* ctr, const int32_t* ncand,
+                      int batch, int kmax, int num_classes, float score_thr, float iou_thr,
+                      int max_num, float* det, int64_t* labels, int64_t* keep, int32_t* ndet,
+                      void* workspace, sm_stream_t stream);
+
+/* Single-class greedy NMS with the reference op's contract, nms_cuda.nms:
+ * dets f32 [n][5] -> keep i64 [<=n] ascending original indices, *nkeep (device).
+ * M/mmdet/ops/nms/src/nms_kernel.cu:71-139.  workspace: sm_nms_workspace(n) bytes. */
+int64_t sm_nms_workspace(int n);
+int sm_nms(const float* dets, int n, float iou_thr, int64_t* keep, int32_t* nkeep, void* workspace,
+           sm_stream_t stream);
+
+/* Fused mask assembly: coef@basis -> sigmoid -> quadrant crop -> bilinear x up -> > thr.
+ * sipmask_head.py:609-633 + CropSplit M/mmdet/ops/crop/src/crop_split_cuda_kernel.cu:19-59.
+ * basis f32: [B][Hm][Wm][32] (basis_hwc=1) or [B][32][Hm][Wm] (basis_hwc=0);
+ * cofs f32 [B][kmax][128] gathered through keep[B][max_num]; det f32 [B][max_num][5].
+ * masks u8 [B][max_num][Ho][Wo] (rows >= ndet[b] untouched; Wo % 4 == 0);
+ * pos_masks f32 [B][max_num][Hm][Wm] (post sigmoid+crop, the CropSplit output) or NULL.
+ * crop box = (det[:4] * box_mul) / box_div  (sipmask_head.py:623: * scale_factor / 2);
+ * up_scale = the F.interpolate scale_factor (:630-632), Ho/Wo the resulting size. */
+int sm_mask_assemble(const float* basis, int basis_hwc, const float* cofs, const int64_t* keep,
+                     const float* det, const int32_t* ndet, int batch, int kmax, int max_num,
+                     int hm, int wm, int ho, int wo, float box_mul, float box_div, double up_scale,
+                     float mask_thr, uint8_t* masks, float* pos_masks, sm_stream_t stream);
+
+/* ---- training-side ops ---------------------------------------------------------------- */
+
+/* crop_split_cuda_forward/backward, M/mmdet/ops/crop/src/crop_split_cuda.cpp:14-36:
+ * data f32 [c*c][H][W][N], rois f32 [N][4], out f32 [H][W][N] (fully written). */
+int sm_crop_split_fwd(const float* data, const float* rois, float* out, int h, int w, int c, int n,
+                      sm_stream_t stream);
+int sm_crop_split_bwd(const float* grad_out, const float* rois, float* grad_in, int h, int w, int c,
+                      int n, sm_stream_t stream);
+/* crop_split_gt_cuda_forward, M/mmdet/ops/crop/src/crop_split_gt_cuda_kernel.cu:19-49 */
+int sm_crop_split_gt_fwd(const float* data, const float* rois, float* out, int h, int w, int n,
+                         sm_stream_t stream);
+
+/* sigmoid_focal_loss_cuda.forward/backward, M/mmdet/ops/sigmoid_focal_loss/src/
+ * sigmoid_focal_loss_cuda.cu:24-97.  logits f32 [n][c], targets i64 [n]. */
+int sm_sigmoid_focal_loss_fwd(const float* logits, const int64_t* targets, float* losses, int n, int c,
+                              float gamma, float alpha, sm_stream_t stream);
+int sm_sigmoid_focal_loss_bwd(const float* logits, const int64_t* targets, const float* d_losses,
+                              float* d_logits, int n, int c, float gamma, float alpha,
+                              sm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIPMASK_HIP_H */

@@ -1,0 +1,129 @@
+"""ctypes binding of libsipmask_hip.so (the C ABI declared in include/sipmask_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+returns a non-zero status a RuntimeError is raised.  Build with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C sipmask_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsipmask_hip.so")
+SM_MAX_LEVELS = 5
+
+SM_CONV_RELU = 1
+SM_CONV_OUT_F32 = 2
+SM_CONV_RES_ADD = 4
+SM_CONV_RES_NEAREST = 8
+SM_CONV_IN_RELU = 16
+
+_i32x5 = C.c_int32 * SM_MAX_LEVELS
+_i64x5 = C.c_int64 * SM_MAX_LEVELS
+_f32x5 = C.c_float * SM_MAX_LEVELS
+
+
+class ConvDesc(C.Structure):
+    """sm_conv_desc"""
+    _fields_ = [
+        ("nlev", C.c_int32), ("batch", C.c_int32),
+        ("in_h", _i32x5), ("in_w", _i32x5), ("out_h", _i32x5), ("out_w", _i32x5),
+        ("in_row0", _i64x5), ("out_row0", _i64x5),
+        ("cin", C.c_int32), ("cout", C.c_int32), ("cout_pad", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32),
+        ("in_cstride", C.c_int32), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
+        ("res_cstride", C.c_int32),
+        ("res_h", _i32x5), ("res_w", _i32x5), ("res_row0", _i64x5),
+        ("flags", C.c_uint32), ("scale_nch", C.c_int32), ("level_scale", _f32x5),
+        ("deform_groups", C.c_int32),
+    ]
+
+
+class DetDesc(C.Structure):
+    """sm_det_desc"""
+    _fields_ = [
+        ("batch", C.c_int32), ("nlev", C.c_int32), ("num_classes", C.c_int32),
+        ("h", _i32x5), ("w", _i32x5), ("stride", _i32x5), ("row0", _i64x5),
+        ("cls_cstride", C.c_int32), ("cls_coff", C.c_int32),
+        ("cof_cstride", C.c_int32), ("cof_coff", C.c_int32),
+        ("reg_cstride", C.c_int32), ("nms_pre", C.c_int32),
+        ("img_h", C.c_int32), ("img_w", C.c_int32), ("kmax", C.c_int32),
+        ("scale_factor", C.c_float), ("rescale", C.c_int32), ("reg_prescaled", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+
+# name -> (restype, argtypes); every symbol of include/sipmask_hip.h
+PROTOTYPES = {
+    "sm_version": (_I, []),
+    "sm_strerror": (C.c_char_p, [_I]),
+    "sm_conv_cout_tile": (_I, [_I]),
+    "sm_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    "sm_deform_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    "sm_offset_linear": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _P]),
+    "sm_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P]),
+    "sm_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "sm_nchw_f32_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "sm_upsample_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sm_det_select_workspace": (C.c_int64, [C.POINTER(DetDesc)]),
+    "sm_det_select": (_I, [C.POINTER(DetDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sm_multiclass_nms_workspace": (C.c_int64, [_I, _I, _I]),
+    "sm_multiclass_nms": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P]),
+    "sm_nms_workspace": (C.c_int64, [_I]),
+    "sm_nms": (_I, [_P, _I, _F, _P, _P, _P, _P]),
+    "sm_mask_assemble": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, C.c_double, _F, _P, _P, _P]),
+    "sm_crop_split_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "sm_crop_split_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "sm_crop_split_gt_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "sm_sigmoid_focal_loss_fwd": (_I, [_P, _P, _P, _I, _I, _F, _F, _P]),
+    "sm_sigmoid_focal_loss_bwd": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every prototype.  Raises RuntimeError when the
+    library has not been built -- there is no CPU / eager fallback in the product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "sipmask_amd: %s is missing; build it with `make -C sipmask_amd/csrc` "
+            "(the HIP extension is mandatory, there is no fallback path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().sm_strerror(status).decode()
+        raise RuntimeError("sipmask_hip %s failed: %s (%d)" % (what, msg, status))
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)"""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            # mirrors M/mmdet/ops/dcn/deform_conv.py:46-47 (NotImplementedError on CPU tensors)
+            raise NotImplementedError("sipmask_amd ops are HIP-only: got a %s tensor" % t.device)

@@ -1,0 +1,61 @@
+// Shared device helpers for libsipmask_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sipmask_hip.h"
+
+#define SM_LAUNCH_CHECK()                         \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return SM_ERR_LAUNCH;  \
+  } while (0)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+// round-to-nearest-even f32 -> bf16 bits (NaN preserved as quiet NaN)
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+
+__device__ __forceinline__ void unpack_bf16x8(const uint4& v, float* f) {
+  f[0] = bf16_bits_to_f32(v.x & 0xffffu);
+  f[1] = bf16_bits_to_f32(v.x >> 16);
+  f[2] = bf16_bits_to_f32(v.y & 0xffffu);
+  f[3] = bf16_bits_to_f32(v.y >> 16);
+  f[4] = bf16_bits_to_f32(v.z & 0xffffu);
+  f[5] = bf16_bits_to_f32(v.z >> 16);
+  f[6] = bf16_bits_to_f32(v.w & 0xffffu);
+  f[7] = bf16_bits_to_f32(v.w >> 16);
+}
+
+__device__ __forceinline__ uint4 pack_bf16x8(const float* f) {
+  uint4 v;
+  v.x = pack_bf16x2(f[0], f[1]);
+  v.y = pack_bf16x2(f[2], f[3]);
+  v.z = pack_bf16x2(f[4], f[5]);
+  v.w = pack_bf16x2(f[6], f[7]);
+  return v;
+}
+
+// order-preserving map float -> uint32 (larger float => larger key)
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+static inline hipStream_t sm_hip_stream(sm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int sm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,405 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): NHWC bf16 activations, K-major bf16
+// weights, v_mfma_f32_32x32x16_bf16 with f32 accumulation, fused epilogue.
+//
+// GEMM view:  D[cout][pos] = sum_k W[cout][k] * X[pos][k],  k = (kh, kw, cin) cin fastest.
+//   MFMA A operand = weight tile  (rows = cout), B operand = activation tile (cols = pos):
+//   with the 32x32 C/D layout (col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)) each
+//   lane then owns 4 CONSECUTIVE couts of one position -> 8-byte NHWC stores.
+// Tiles: BCO x BPOS x 64(K) per step, 256 threads = 4 wave64; both operands are staged
+//   global -> VGPR -> LDS (issue-early / write-late, guide T14) into a double buffer with
+//   a 16-byte-chunk XOR swizzle (slot = chunk ^ ((row>>1)&7)) so the ds_read_b128
+//   fragment reads of 128-byte rows are bank-conflict free.
+// Multi-level: the 5 FPN levels share tower weights, so one launch covers all levels
+//   (M tiles are enumerated per level; tiles never straddle a level).
+// DEFORM variant: the activation loader performs the deformable bilinear gather
+//   (deform_conv_cuda_kernel.cu:85-115,191-243) -- the column buffer never exists.
+#include "common.h"
+
+namespace {
+
+struct ConvKArgs {
+  const uint16_t* x;
+  const uint16_t* w;
+  const float* bias;
+  const uint16_t* res;
+  void* y;
+  const float* offset;
+  int nlev, batch;
+  int in_h[SM_MAX_LEVELS], in_w[SM_MAX_LEVELS], out_h[SM_MAX_LEVELS], out_w[SM_MAX_LEVELS];
+  long long in_row0[SM_MAX_LEVELS], out_row0[SM_MAX_LEVELS], res_row0[SM_MAX_LEVELS];
+  int res_h[SM_MAX_LEVELS], res_w[SM_MAX_LEVELS];
+  int tile0[SM_MAX_LEVELS + 1];
+  int cin, cout, kh, kw, stride, pad, dil;
+  int in_cstride, out_cstride, out_coff, res_cstride;
+  int Kp, nchunk, cpt, ntn, nk;
+  unsigned flags;
+  int scale_nch;
+  float level_scale[SM_MAX_LEVELS];
+  int dg, cpg8;  // deform groups, chunks (of 8 ch) per deform group
+};
+
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
+  uint32_t neg = (v >> 15) & 0x00010001u;
+  return v & ~(neg * 0xffffu);
+}
+
+template <int WCO, int WPOS, int TCO, int TPOS, bool DEFORM>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
+  constexpr int BCO = WCO * TCO * 32;
+  constexpr int BPOS = WPOS * TPOS * 32;
+  constexpr int NW = BCO / 32;   // 16-byte weight chunks per thread per K step
+  constexpr int NX = BPOS / 32;  // 16-byte activation chunks per thread per K step
+  constexpr int STAGE = (BCO + BPOS) * 128;
+  static_assert(WCO * WPOS == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wco = wave / WPOS;
+  const int wpos = wave % WPOS;
+  const int j = tid & 7;    // K chunk (8 bf16) inside the 64-wide K step
+  const int r0 = tid >> 3;  // tile row handled by this thread (+32*i)
+  const int wslot = (j ^ ((r0 >> 1) & 7)) * 16;
+
+  // ---- tile decode (wave-uniform)
+  const int nt = blockIdx.x % a.ntn;
+  const int mt = blockIdx.x / a.ntn;
+  int lev = 0;
+#pragma unroll
+  for (int l = 1; l < SM_MAX_LEVELS; ++l)
+    if (l < a.nlev && mt >= a.tile0[l]) lev = l;
+  const int H = a.in_h[lev], W = a.in_w[lev], Ho = a.out_h[lev], Wo = a.out_w[lev];
+  const int HoWo = Ho * Wo;
+  const int M = a.batch * HoWo;
+  const int m0 = (mt - a.tile0[lev]) * BPOS;
+  const long long in_row0 = a.in_row0[lev];
+
+  // ---- per-row gather bases (rows r0 + 32*i of the activation tile)
+  int rbase[NX], rhi[NX], rwi[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    int m = m0 + r0 + 32 * i;
+    if (m < M) {
+      int n = m / HoWo;
+      int rem = m - n * HoWo;
+      int ho = rem / Wo;
+      int wo = rem - ho * Wo;
+      rbase[i] = n * H * W;
+      rhi[i] = ho * a.stride - a.pad;
+      rwi[i] = wo * a.stride - a.pad;
+    } else {
+      rbase[i] = -1;
+      rhi[i] = 0;
+      rwi[i] = 0;
+    }
+  }
+  const uint16_t* wrow = a.w + (long long)(nt * BCO + r0) * a.Kp + j * 8;
+
+  uint4 wreg[NW], xreg[NX];
+
+  auto load_w = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      wreg[i] = *reinterpret_cast<const uint4*>(wrow + (long long)(32 * i) * a.Kp + kt * 64);
+  };
+
+  auto load_x = [&](int kt) {
+    const int kc = kt * 8 + j;
+    const int tap = kc / a.cpt;
+    const int c0 = (kc - tap * a.cpt) * 8;
+    const int kh = tap / a.kw;
+    const int kw = tap - kh * a.kw;
+    const bool kvalid = kc < a.nchunk;
+    const int dh = kh * a.dil, dw = kw * a.dil;
+    if constexpr (!DEFORM) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        int hi = rhi[i] + dh, wi = rwi[i] + dw;
+        bool ok = kvalid && rbase[i] >= 0 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ok) {
+          const uint16_t* p = a.x + (in_row0 + rbase[i] + hi * W + wi) * a.in_cstride + c0;
+          v = *reinterpret_cast<const uint4*>(p);
+        }
+        xreg[i] = v;
+      }
+      if (a.flags & SM_CONV_IN_RELU) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          xreg[i].x = relu_bf16x2(xreg[i].x);
+          xreg[i].y = relu_bf16x2(xreg[i].y);
+          xreg[i].z = relu_bf16x2(xreg[i].z);
+          xreg[i].w = relu_bf16x2(xreg[i].w);
+        }
+      }
+    } else {
+      // deformable bilinear gather; offset row = output row (stride-1 "same" conv)
+      const int g = (c0 >> 3) / a.cpg8;
+      const int ntap = a.kh * a.kw;
+      const long long orow0 = a.out_row0[lev] + m0 + r0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (kvalid && rbase[i] >= 0) {
+          const float* op = a.offset + (orow0 + 32 * i) * (long long)(a.dg * ntap * 2) + (g * ntap + tap) * 2;
+          const float2 o = *reinterpret_cast<const float2*>(op);
+          const float h_im = (float)(rhi[i] + dh) + o.x;
+          const float w_im = (float)(rwi[i] + dw) + o.y;
+          if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const uint16_t* base = a.x + (in_row0 + rbase[i]) * a.in_cstride + c0;
+            uint4 q1 = make_uint4(0, 0, 0, 0), q2 = q1, q3 = q1, q4 = q1;
+            if (h_low >= 0 && w_low >= 0)
+              q1 = *reinterpret_cast<const uint4*>(base + (long long)(h_low * W + w_low) * a.in_cstride);
+            if (h_low >= 0 && w_high <= W - 1)
+              q2 = *reinterpret_cast<const uint4*>(base + (long long)(h_low * W + w_high) * a.in_cstride);
+            if (h_high <= H - 1 && w_low >= 0)
+              q3 = *reinterpret_cast<const uint4*>(base + (long long)(h_high * W + w_low) * a.in_cstride);
+            if (h_high <= H - 1 && w_high <= W - 1)
+              q4 = *reinterpret_cast<const uint4*>(base + (long long)(h_high * W + w_high) * a.in_cstride);
+            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+            float f1[8], f2[8], f3[8], f4[8], r[8];
+            unpack_bf16x8(q1, f1);
+            unpack_bf16x8(q2, f2);
+            unpack_bf16x8(q3, f3);
+            unpack_bf16x8(q4, f4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = w1 * f1[e] + w2 * f2[e] + w3 * f3[e] + w4 * f4[e];
+            v = pack_bf16x8(r);
+          }
+        }
+        xreg[i] = v;
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    unsigned char* Wb = smem + buf * STAGE;
+    unsigned char* Xb = Wb + BCO * 128;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) *reinterpret_cast<uint4*>(Wb + (r0 + 32 * i) * 128 + wslot) = wreg[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) *reinterpret_cast<uint4*>(Xb + (r0 + 32 * i) * 128 + wslot) = xreg[i];
+  };
+
+  f32x16 acc[TCO][TPOS];
+#pragma unroll
+  for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TPOS; ++tp)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tc][tp][e] = 0.f;
+
+  const int l31 = lane & 31;
+  const int rsw = (l31 >> 1) & 7;
+  const int khalf = lane >> 5;
+  const int wrow_off = (wco * TCO * 32 + l31) * 128;
+  const int xrow_off = BCO * 128 + (wpos * TPOS * 32 + l31) * 128;
+
+  load_w(0);
+  load_x(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int nk = a.nk;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = (kt + 1) < nk;
+    if (more) {
+      load_w(kt + 1);
+      load_x(kt + 1);
+    }
+    const unsigned char* S = smem + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
+      bf16x8 wf[TCO], xf[TPOS];
+#pragma unroll
+      for (int t = 0; t < TCO; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(S + wrow_off + t * 32 * 128 + slot);
+#pragma unroll
+      for (int t = 0; t < TPOS; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(S + xrow_off + t * 32 * 128 + slot);
+#pragma unroll
+      for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TPOS; ++tp)
+          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: (acc + bias) * level_scale (+ residual) (relu) -> bf16 / f32
+  const float lscale = a.level_scale[lev];
+  const long long out_row0 = a.out_row0[lev];
+  const bool out_f32 = a.flags & SM_CONV_OUT_F32;
+#pragma unroll
+  for (int tp = 0; tp < TPOS; ++tp) {
+    const int m = m0 + wpos * TPOS * 32 + tp * 32 + l31;
+    if (m >= M) continue;
+    long long rrow = 0;
+    if (a.flags & SM_CONV_RES_ADD) {
+      rrow = out_row0 + m;
+    } else if (a.flags & SM_CONV_RES_NEAREST) {
+      int n = m / HoWo;
+      int rem = m - n * HoWo;
+      int ho = rem / Wo;
+      int wo = rem - ho * Wo;
+      const int rh = a.res_h[lev], rw = a.res_w[lev];
+      int sh = min((int)floorf((float)ho * ((float)rh / (float)Ho)), rh - 1);
+      int sw = min((int)floorf((float)wo * ((float)rw / (float)Wo)), rw - 1);
+      rrow = a.res_row0[lev] + ((long long)n * rh + sh) * rw + sw;
+    }
+#pragma unroll
+    for (int tc = 0; tc < TCO; ++tc) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = nt * BCO + wco * TCO * 32 + tc * 32 + 8 * q + 4 * khalf;
+        if (c >= a.cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[tc][tp][4 * q + e];
+          const int ce = c + e;
+          if (a.bias != nullptr && ce < a.cout) t += a.bias[ce];
+          if (ce < a.scale_nch) t *= lscale;
+          v[e] = t;
+        }
+        const bool full = (c + 3 < a.cout);
+        if (a.flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)) {
+          const uint16_t* rp = a.res + rrow * a.res_cstride + c;
+          if (full) {
+            uint2 rv = *reinterpret_cast<const uint2*>(rp);
+            v[0] += bf16_bits_to_f32(rv.x & 0xffffu);
+            v[1] += bf16_bits_to_f32(rv.x >> 16);
+            v[2] += bf16_bits_to_f32(rv.y & 0xffffu);
+            v[3] += bf16_bits_to_f32(rv.y >> 16);
+          } else {
+            for (int e = 0; e < 4; ++e)
+              if (c + e < a.cout) v[e] += bf16_bits_to_f32(rp[e]);
+          }
+        }
+        if (a.flags & SM_CONV_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        const long long o = (out_row0 + m) * a.out_cstride + a.out_coff + c;
+        if (out_f32) {
+          float* yp = reinterpret_cast<float*>(a.y) + o;
+          if (full && ((o & 3) == 0)) {
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            for (int e = 0; e < 4; ++e)
+              if (c + e < a.cout) yp[e] = v[e];
+          }
+        } else {
+          uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + o;
+          if (full && ((o & 3) == 0)) {
+            *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          } else {
+            for (int e = 0; e < 4; ++e)
+              if (c + e < a.cout) yp[e] = (uint16_t)f32_to_bf16_bits(v[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool DEFORM>
+int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,
+                const void* residual, void* y, hipStream_t stream) {
+  if (!d || !x || !w || !y) return SM_ERR_BAD_ARG;
+  if (d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return SM_ERR_BAD_SHAPE;
+  if (d->cin % 8 != 0 || d->cin < 8 || d->cout < 1) return SM_ERR_BAD_SHAPE;
+  if (d->in_cstride % 8 != 0) return SM_ERR_BAD_SHAPE;
+  if ((d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)) && !residual) return SM_ERR_BAD_ARG;
+  const int tile = sm_conv_cout_tile(d->cout);
+  if (d->cout_pad % tile != 0 || d->cout_pad < d->cout) return SM_ERR_BAD_SHAPE;
+  if (DEFORM) {
+    if (!offset || d->deform_groups < 1 || d->cin % (8 * d->deform_groups) != 0) return SM_ERR_BAD_ARG;
+    if (d->stride != 1) return SM_ERR_UNSUPPORTED;
+  }
+  ConvKArgs a;
+  a.x = (const uint16_t*)x;
+  a.w = (const uint16_t*)w;
+  a.bias = bias;
+  a.res = (const uint16_t*)residual;
+  a.y = y;
+  a.offset = offset;
+  a.nlev = d->nlev;
+  a.batch = d->batch;
+  const int bpos = (tile == 128) ? 128 : 256;
+  int t = 0;
+  for (int l = 0; l < SM_MAX_LEVELS; ++l) {
+    const bool on = l < d->nlev;
+    a.in_h[l] = on ? d->in_h[l] : 1;
+    a.in_w[l] = on ? d->in_w[l] : 1;
+    a.out_h[l] = on ? d->out_h[l] : 1;
+    a.out_w[l] = on ? d->out_w[l] : 1;
+    a.in_row0[l] = on ? d->in_row0[l] : 0;
+    a.out_row0[l] = on ? d->out_row0[l] : 0;
+    a.res_row0[l] = on ? d->res_row0[l] : 0;
+    a.res_h[l] = on ? d->res_h[l] : 1;
+    a.res_w[l] = on ? d->res_w[l] : 1;
+    a.level_scale[l] = on ? d->level_scale[l] : 1.f;
+    a.tile0[l] = t;
+    if (on) {
+      if (d->out_h[l] < 1 || d->out_w[l] < 1 || d->in_h[l] < 1 || d->in_w[l] < 1) return SM_ERR_BAD_SHAPE;
+      const int eh = (d->in_h[l] + 2 * d->pad - (d->dil * (d->kh - 1) + 1)) / d->stride + 1;
+      const int ew = (d->in_w[l] + 2 * d->pad - (d->dil * (d->kw - 1) + 1)) / d->stride + 1;
+      if (eh != d->out_h[l] || ew != d->out_w[l]) return SM_ERR_BAD_SHAPE;
+      t += sm_cdiv((long long)d->batch * d->out_h[l] * d->out_w[l], bpos);
+    }
+  }
+  a.tile0[SM_MAX_LEVELS] = t;
+  a.cin = d->cin;
+  a.cout = d->cout;
+  a.kh = d->kh;
+  a.kw = d->kw;
+  a.stride = d->stride;
+  a.pad = d->pad;
+  a.dil = d->dil;
+  a.in_cstride = d->in_cstride;
+  a.out_cstride = d->out_cstride;
+  a.out_coff = d->out_coff;
+  a.res_cstride = d->res_cstride;
+  const int K = d->kh * d->kw * d->cin;
+  a.Kp = (K + 63) / 64 * 64;
+  a.nchunk = K / 8;
+  a.cpt = d->cin / 8;
+  a.ntn = d->cout_pad / tile;
+  a.nk = a.Kp / 64;
+  a.flags = d->flags;
+  a.scale_nch = d->scale_nch;
+  a.dg = DEFORM ? d->deform_groups : 1;
+  a.cpg8 = DEFORM ? d->cin / (8 * d->deform_groups) : 1;
+  const long long nblk = (long long)t * a.ntn;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
+  dim3 grid((unsigned)nblk), block(256);
+  if (tile == 128)
+    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, DEFORM>), grid, block, 0, stream, a);
+  else if (tile == 64)
+    hipLaunchKernelGGL((conv_igemm_kernel<1, 4, 2, 2, DEFORM>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<1, 4, 1, 2, DEFORM>), grid, block, 0, stream, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+}  // namespace
+
+extern "C" int sm_conv_cout_tile(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
+
+extern "C" int sm_conv2d(const sm_conv_desc* d, const void* x, const void* w, const float* bias,
+                         const void* residual, void* y, sm_stream_t stream) {
+  return launch_conv<false>(d, x, nullptr, w, bias, residual, y, sm_hip_stream(stream));
+}
+
+extern "C" int sm_deform_conv2d(const sm_conv_desc* d, const void* x, const float* offset, const void* w,
+                                const float* bias, void* y, sm_stream_t stream) {
+  return launch_conv<true>(d, x, offset, w, bias, nullptr, y, sm_hip_stream(stream));
+}

@@ -1,0 +1,561 @@
+// Device-resident detection post-processing for SipMaskHead.get_bboxes
+// (M/mmdet/models/anchor_heads/sipmask_head.py:543-605):
+//   det_score  : max_c sigmoid(cls) * sigmoid(ctr) per position
+//   det_topk   : exact per-level top-k (value desc, index asc): 4x8-bit radix select in LDS,
+//                ordered tie compaction, bitonic sort of the <=2048 survivors
+//   det_gather : sigmoid scores / centerness / distance2bbox / coefficient gather
+//   nms_class  : one wave64 per (image, class): threshold -> sort -> greedy NMS where the
+//                64-bit suppression word of the reference kernel (nms_kernel.cu:24-68) maps 1:1
+//                onto wave64 ballots; no device->host copy, no host scan
+//   nms_final  : class-major concat + top max_num (bbox_nms.py:131-140)
+// Everything is integer/compare work on <= a few MB: latency bound, not bandwidth bound.
+#include "common.h"
+
+namespace {
+
+constexpr int TK_THREADS = 1024;
+constexpr int TK_CAP = 2048;
+
+struct TopkSmem {
+  unsigned long long sel[TK_CAP];
+  unsigned int hist[256];
+  unsigned int wsum[TK_THREADS / 64];
+  unsigned int prefix, krem, pos_gt, base_eq;
+};
+
+__device__ __forceinline__ unsigned long long compose_key(uint32_t okey, uint32_t idx) {
+  return ((unsigned long long)okey << 32) | (unsigned long long)(0xffffffffu - idx);
+}
+
+// bitonic sort, descending, P = power of two, all threads of the block participate
+__device__ void block_bitonic_desc(unsigned long long* a, int P) {
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+        const int pos = 2 * t - (t & (stride - 1));
+        const unsigned long long x = a[pos], y = a[pos + stride];
+        const bool desc = ((pos & size) == 0);
+        if ((x < y) == desc) {
+          a[pos] = y;
+          a[pos + stride] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Exact top-k of keys[0..n) for one block of TK_THREADS threads.  Result: sm.sel[0..k) sorted
+// by (key desc, index asc); low word = 0xffffffff - index.  Requires 1 <= k <= min(n, TK_CAP).
+__device__ void block_topk(const float* __restrict__ keys, int n, int k, TopkSmem& sm) {
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    sm.prefix = 0;
+    sm.krem = k;
+    sm.pos_gt = 0;
+    sm.base_eq = 0;
+  }
+  for (int round = 0; round < 4; ++round) {
+    const int shift = 24 - 8 * round;
+    if (tid < 256) sm.hist[tid] = 0;
+    __syncthreads();
+    const uint32_t prefix = sm.prefix;
+    for (int i = tid; i < n; i += TK_THREADS) {
+      const uint32_t u = float_to_ordered(keys[i]);
+      if (round == 0 || (u >> (shift + 8)) == prefix) atomicAdd(&sm.hist[(u >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned int cum = 0, krem = sm.krem;
+      int bin = 0;
+      for (int b = 255; b >= 0; --b) {
+        const unsigned int h = sm.hist[b];
+        if (cum + h >= krem) {
+          bin = b;
+          break;
+        }
+        cum += h;
+      }
+      sm.krem = krem - cum;
+      sm.prefix = (prefix << 8) | (unsigned int)bin;
+    }
+    __syncthreads();
+  }
+  const uint32_t T = sm.prefix;
+  const unsigned int krem = sm.krem;
+  const unsigned int cnt_gt = (unsigned int)k - krem;
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int base = 0; base < n; base += TK_THREADS) {
+    const int i = base + tid;
+    const bool valid = i < n;
+    const uint32_t u = valid ? float_to_ordered(keys[i]) : 0u;
+    const bool gt = valid && u > T;
+    const bool eq = valid && u == T;
+    if (gt) {
+      const unsigned int slot = atomicAdd(&sm.pos_gt, 1u);
+      sm.sel[slot] = compose_key(u, (uint32_t)i);
+    }
+    const unsigned long long bal = __ballot(eq);
+    const unsigned int wrank = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) sm.wsum[wv] = __popcll(bal);
+    __syncthreads();
+    unsigned int before = sm.base_eq, total = 0;
+#pragma unroll
+    for (int w = 0; w < TK_THREADS / 64; ++w) {
+      const unsigned int c = sm.wsum[w];
+      if (w < wv) before += c;
+      total += c;
+    }
+    if (eq) {
+      const unsigned int rank = before + wrank;
+      if (rank < krem) sm.sel[cnt_gt + rank] = compose_key(u, (uint32_t)i);
+    }
+    __syncthreads();
+    if (tid == 0) sm.base_eq += total;
+    __syncthreads();
+  }
+  int P = 1;
+  while (P < k) P <<= 1;
+  for (int i = k + tid; i < P; i += TK_THREADS) sm.sel[i] = 0ull;
+  block_bitonic_desc(sm.sel, P);
+}
+
+struct DetArgs {
+  int batch, nlev, C;
+  int h[SM_MAX_LEVELS], w[SM_MAX_LEVELS], stride[SM_MAX_LEVELS], hw[SM_MAX_LEVELS];
+  long long row0[SM_MAX_LEVELS];
+  int pos0[SM_MAX_LEVELS + 1];   // start of level l inside the per-image key array
+  int cand0[SM_MAX_LEVELS + 1];  // start of level l inside the per-image candidate list
+  int cls_cs, cls_co, cof_cs, cof_co, reg_cs;
+  int nms_pre, img_h, img_w, kmax;
+  float scale_factor;
+  int rescale, reg_prescaled;
+};
+
+__global__ void det_score_kernel(const float* __restrict__ cls, const float* __restrict__ reg,
+                                 float* __restrict__ keys, const DetArgs a) {
+  const int S = a.pos0[a.nlev];
+  const long long total = (long long)a.batch * S;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / S);
+    const int p = (int)(i - (long long)b * S);
+    int lev = 0;
+#pragma unroll
+    for (int l = 1; l < SM_MAX_LEVELS; ++l)
+      if (l < a.nlev && p >= a.pos0[l]) lev = l;
+    const long long row = a.row0[lev] + (long long)b * a.hw[lev] + (p - a.pos0[lev]);
+    const float* cp = cls + row * a.cls_cs + a.cls_co;
+    float mx = -INFINITY;
+    for (int c = 0; c < a.C; ++c) mx = fmaxf(mx, cp[c]);
+    // max_c(sigmoid(x_c) * s) == sigmoid(max_c x_c) * s : both maps are monotone
+    keys[i] = sigmoidf_acc(mx) * sigmoidf_acc(reg[row * a.reg_cs + 4]);
+  }
+}
+
+__global__ __launch_bounds__(TK_THREADS) void det_topk_kernel(const float* __restrict__ keys,
+                                                               int32_t* __restrict__ cand_pos, const DetArgs a) {
+  __shared__ TopkSmem sm;
+  const int lev = blockIdx.x, b = blockIdx.y;
+  const int n = a.hw[lev];
+  const int S = a.pos0[a.nlev];
+  int32_t* out = cand_pos + (long long)b * a.kmax + a.cand0[lev];
+  if (a.nms_pre <= 0 || n <= a.nms_pre) {  // sipmask_head.py:571: topk only when more than nms_pre
+    for (int i = threadIdx.x; i < n; i += TK_THREADS) out[i] = i;
+    return;
+  }
+  block_topk(keys + (long long)b * S + a.pos0[lev], n, a.nms_pre, sm);
+  for (int i = threadIdx.x; i < a.nms_pre; i += TK_THREADS)
+    out[i] = (int32_t)(0xffffffffu - (uint32_t)(sm.sel[i] & 0xffffffffull));
+}
+
+// one wave per candidate
+__global__ __launch_bounds__(64) void det_gather_kernel(const float* __restrict__ cls, const float* __restrict__ reg,
+                                                        const float* __restrict__ cof,
+                                                        const int32_t* __restrict__ cand_pos,
+                                                        float* __restrict__ boxes, float* __restrict__ scores,
+                                                        float* __restrict__ ctr, float* __restrict__ cofs,
+                                                        const DetArgs a) {
+  const int k = blockIdx.x, b = blockIdx.y;
+  int lev = 0;
+#pragma unroll
+  for (int l = 1; l < SM_MAX_LEVELS; ++l)
+    if (l < a.nlev && k >= a.cand0[l]) lev = l;
+  const int pos = cand_pos[(long long)b * a.kmax + k];
+  const long long row = a.row0[lev] + (long long)b * a.hw[lev] + pos;
+  const long long o = (long long)b * a.kmax + k;
+  const int lane = threadIdx.x;
+  for (int c = lane; c < a.C; c += 64) scores[o * a.C + c] = sigmoidf_acc(cls[row * a.cls_cs + a.cls_co + c]);
+  for (int c = lane; c < 128; c += 64) cofs[o * 128 + c] = cof[row * a.cof_cs + a.cof_co + c];
+  if (lane == 0) {
+    const float* rp = reg + row * a.reg_cs;
+    ctr[o] = sigmoidf_acc(rp[4]);
+    const int s = a.stride[lev];
+    const int py = pos / a.w[lev], px = pos - py * a.w[lev];
+    const float x = (float)(px * s) + (float)(s / 2), y = (float)(py * s) + (float)(s / 2);
+    const float xmax = (float)(a.img_w - 1), ymax = (float)(a.img_h - 1);
+    const float fs = a.reg_prescaled ? 1.f : (float)s;  // bbox_pred.float() * stride (sipmask_head.py:268)
+    float x1 = fminf(fmaxf(__fsub_rn(x, __fmul_rn(rp[0], fs)), 0.f), xmax);
+    float y1 = fminf(fmaxf(__fsub_rn(y, __fmul_rn(rp[1], fs)), 0.f), ymax);
+    float x2 = fminf(fmaxf(__fadd_rn(x, __fmul_rn(rp[2], fs)), 0.f), xmax);
+    float y2 = fminf(fmaxf(__fadd_rn(y, __fmul_rn(rp[3], fs)), 0.f), ymax);
+    if (a.rescale) {
+      x1 /= a.scale_factor;
+      y1 /= a.scale_factor;
+      x2 /= a.scale_factor;
+      y2 /= a.scale_factor;
+    }
+    *reinterpret_cast<float4*>(boxes + o * 4) = make_float4(x1, y1, x2, y2);
+  }
+}
+
+// ------------------------------------------------------------------------------- NMS
+// devIoU, nms_kernel.cu:14-22 (float32, +1 widths); written so the compiler cannot contract
+__device__ __forceinline__ float iou_plus1(const float4 a, const float4 b) {
+  const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
+  const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+  const float width = fmaxf(__fadd_rn(__fsub_rn(right, left), 1.f), 0.f);
+  const float height = fmaxf(__fadd_rn(__fsub_rn(bottom, top), 1.f), 0.f);
+  const float inter = __fmul_rn(width, height);
+  const float sa = __fmul_rn(__fadd_rn(__fsub_rn(a.z, a.x), 1.f), __fadd_rn(__fsub_rn(a.w, a.y), 1.f));
+  const float sb = __fmul_rn(__fadd_rn(__fsub_rn(b.z, b.x), 1.f), __fadd_rn(__fsub_rn(b.w, b.y), 1.f));
+  return __fdiv_rn(inter, __fsub_rn(__fadd_rn(sa, sb), inter));
+}
+
+// LDS carve for one wave: keys[P] (u64), kept_box[P] (float4), kept_idx[P] (u32)
+// Greedy NMS over the n sorted entries in keys (low word = 0xffffffff - candidate index).
+// box_of(idx) returns the box.  Returns number kept; kept_idx holds candidate indices in score order.
+template <typename BoxFn>
+__device__ int wave_greedy_nms(const unsigned long long* keys, int n, float thr, float4* kept_box,
+                               uint32_t* kept_idx, BoxFn box_of) {
+  const int lane = threadIdx.x;
+  int nkept = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    bool alive = i < n;
+    uint32_t idx = 0;
+    float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (alive) {
+      idx = 0xffffffffu - (uint32_t)(keys[i] & 0xffffffffull);
+      mine = box_of(idx);
+    }
+    for (int kk = 0; kk < nkept; ++kk) {
+      if (alive && iou_plus1(kept_box[kk], mine) > thr) alive = false;
+    }
+    // resolve inside the 64-box chunk in score order
+    for (int t = 0; t < 64; ++t) {
+      const unsigned long long bal = __ballot(alive);
+      if (!((bal >> t) & 1ull)) continue;   // wave-uniform
+      float4 bt;
+      bt.x = __shfl(mine.x, t);
+      bt.y = __shfl(mine.y, t);
+      bt.z = __shfl(mine.z, t);
+      bt.w = __shfl(mine.w, t);
+      if (alive && lane > t && iou_plus1(bt, mine) > thr) alive = false;
+    }
+    const unsigned long long bal = __ballot(alive);
+    if (alive) {
+      const int slot = nkept + __popcll(bal & ((1ull << lane) - 1ull));
+      kept_box[slot] = mine;
+      kept_idx[slot] = idx;
+    }
+    nkept += __popcll(bal);
+    __syncthreads();
+  }
+  return nkept;
+}
+
+// ascending sort of u32 values held in the low word of u64 scratch (single wave)
+__device__ void wave_sort_idx_asc(unsigned long long* scratch, const uint32_t* vals, int n) {
+  int P = 1;
+  while (P < n) P <<= 1;
+  for (int i = threadIdx.x; i < P; i += 64) scratch[i] = i < n ? (unsigned long long)(0xffffffffu - vals[i]) : 0ull;
+  block_bitonic_desc(scratch, P);  // descending in (max - idx) == ascending idx; zeros (padding) last
+}
+
+struct NmsArgs {
+  int batch, kmax, C, P, max_num;
+  float score_thr, iou_thr;
+};
+
+__global__ __launch_bounds__(64) void nms_class_kernel(const float* __restrict__ boxes,
+                                                       const float* __restrict__ scores,
+                                                       const float* __restrict__ ctr,
+                                                       const int32_t* __restrict__ ncand,
+                                                       int32_t* __restrict__ cls_keep,
+                                                       int32_t* __restrict__ cls_cnt, const NmsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(dsm);
+  float4* kept_box = reinterpret_cast<float4*>(dsm + (size_t)a.P * 8);
+  uint32_t* kept_idx = reinterpret_cast<uint32_t*>(dsm + (size_t)a.P * 24);
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int K = ncand[b];
+  const float* sc = scores + (long long)b * a.kmax * a.C + c;
+  const float* ct = ctr + (long long)b * a.kmax;
+  const float4* bx = reinterpret_cast<const float4*>(boxes) + (long long)b * a.kmax;
+  // 1. ordered compaction of candidates with raw class score > thr (bbox_nms.py:111)
+  int n = 0;
+  for (int base = 0; base < K; base += 64) {
+    const int i = base + lane;
+    float s = 0.f;
+    bool sel = false;
+    if (i < K) {
+      s = sc[(long long)i * a.C];
+      sel = s > a.score_thr;
+    }
+    const unsigned long long bal = __ballot(sel);
+    if (sel) {
+      const float sf = __fmul_rn(s, ct[i]);  // _scores *= score_factors (bbox_nms.py:121-122)
+      keys[n + __popcll(bal & ((1ull << lane) - 1ull))] = compose_key(float_to_ordered(sf), (uint32_t)i);
+    }
+    n += __popcll(bal);
+  }
+  int32_t* outk = cls_keep + ((long long)b * a.C + c) * a.kmax;
+  if (n == 0) {
+    if (lane == 0) cls_cnt[b * a.C + c] = 0;
+    return;
+  }
+  // 2. sort (score desc, index asc)
+  int P = 1;
+  while (P < n) P <<= 1;
+  for (int i = n + lane; i < P; i += 64) keys[i] = 0ull;
+  block_bitonic_desc(keys, P);
+  // 3. greedy NMS
+  const int nk = wave_greedy_nms(keys, n, a.iou_thr, kept_box, kept_idx, [&](uint32_t idx) { return bx[idx]; });
+  // 4. reference returns kept ORIGINAL indices ascending (nms_kernel.cu:135-138)
+  wave_sort_idx_asc(keys, kept_idx, nk);
+  for (int i = lane; i < nk; i += 64) outk[i] = (int32_t)(0xffffffffu - (uint32_t)keys[i]);
+  if (lane == 0) cls_cnt[b * a.C + c] = nk;
+}
+
+__global__ __launch_bounds__(TK_THREADS) void nms_final_kernel(const float* __restrict__ boxes,
+                                                               const float* __restrict__ scores,
+                                                               const float* __restrict__ ctr,
+                                                               const int32_t* __restrict__ cls_keep,
+                                                               const int32_t* __restrict__ cls_cnt,
+                                                               float* __restrict__ flat_key, float* __restrict__ det,
+                                                               int64_t* __restrict__ labels,
+                                                               int64_t* __restrict__ keep, int32_t* __restrict__ ndet,
+                                                               const NmsArgs a) {
+  __shared__ TopkSmem sm;
+  __shared__ int pre[257];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int t = 0;
+    for (int c = 0; c < a.C; ++c) {
+      pre[c] = t;
+      t += cls_cnt[b * a.C + c];
+    }
+    pre[a.C] = t;
+  }
+  __syncthreads();
+  const int total = pre[a.C];
+  float* fk = flat_key + (long long)b * a.C * a.kmax;
+  auto emit = [&](int slot, int p) {
+    // p = position in the class-major concatenation
+    int lo = 0, hi = a.C;  // find class c with pre[c] <= p < pre[c+1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (pre[mid] <= p) lo = mid; else hi = mid;
+    }
+    const int c = lo;
+    const int idx = cls_keep[((long long)b * a.C + c) * a.kmax + (p - pre[c])];
+    const long long o = (long long)b * a.max_num + slot;
+    const float4 bb = reinterpret_cast<const float4*>(boxes)[(long long)b * a.kmax + idx];
+    const float s = __fmul_rn(scores[((long long)b * a.kmax + idx) * a.C + c], ctr[(long long)b * a.kmax + idx]);
+    det[o * 5 + 0] = bb.x;
+    det[o * 5 + 1] = bb.y;
+    det[o * 5 + 2] = bb.z;
+    det[o * 5 + 3] = bb.w;
+    det[o * 5 + 4] = s;
+    labels[o] = c;
+    keep[o] = idx;
+  };
+  if (total <= a.max_num) {
+    for (int p = tid; p < total; p += TK_THREADS) emit(p, p);
+    if (tid == 0) ndet[b] = total;
+    return;
+  }
+  // more than max_num: sort by score desc (ties: position asc) and keep the top max_num
+  for (int p = tid; p < total; p += TK_THREADS) {
+    int lo = 0, hi = a.C;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (pre[mid] <= p) lo = mid; else hi = mid;
+    }
+    const int idx = cls_keep[((long long)b * a.C + lo) * a.kmax + (p - pre[lo])];
+    fk[p] = __fmul_rn(scores[((long long)b * a.kmax + idx) * a.C + lo], ctr[(long long)b * a.kmax + idx]);
+  }
+  __syncthreads();
+  block_topk(fk, total, a.max_num, sm);
+  for (int i = tid; i < a.max_num; i += TK_THREADS)
+    emit(i, (int)(0xffffffffu - (uint32_t)(sm.sel[i] & 0xffffffffull)));
+  if (tid == 0) ndet[b] = a.max_num;
+}
+
+// reference op contract: dets [n][5] -> ascending kept indices (nms_cuda.nms)
+__global__ __launch_bounds__(64) void nms_single_kernel(const float* __restrict__ dets, int n, float thr, int P,
+                                                        int64_t* __restrict__ keep, int32_t* __restrict__ nkeep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(dsm);
+  float4* kept_box = reinterpret_cast<float4*>(dsm + (size_t)P * 8);
+  uint32_t* kept_idx = reinterpret_cast<uint32_t*>(dsm + (size_t)P * 24);
+  const int lane = threadIdx.x;
+  for (int i = lane; i < P; i += 64)
+    keys[i] = i < n ? compose_key(float_to_ordered(dets[(long long)i * 5 + 4]), (uint32_t)i) : 0ull;
+  block_bitonic_desc(keys, P);
+  const int nk = wave_greedy_nms(keys, n, thr, kept_box, kept_idx, [&](uint32_t idx) {
+    const float* p = dets + (long long)idx * 5;
+    return make_float4(p[0], p[1], p[2], p[3]);
+  });
+  wave_sort_idx_asc(keys, kept_idx, nk);
+  for (int i = lane; i < nk; i += 64) keep[i] = (int64_t)(0xffffffffu - (uint32_t)keys[i]);
+  if (lane == 0) *nkeep = nk;
+}
+
+__global__ void fill_i32_kernel(int32_t* p, int n, int v) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = v;
+}
+
+int fill_det_args(const sm_det_desc* d, DetArgs& a) {
+  if (!d || d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1 || d->num_classes < 1) return SM_ERR_BAD_SHAPE;
+  if (d->nms_pre > TK_CAP) return SM_ERR_UNSUPPORTED;
+  a.batch = d->batch;
+  a.nlev = d->nlev;
+  a.C = d->num_classes;
+  int p = 0, k = 0;
+  for (int l = 0; l < SM_MAX_LEVELS; ++l) {
+    const bool on = l < d->nlev;
+    a.h[l] = on ? d->h[l] : 1;
+    a.w[l] = on ? d->w[l] : 1;
+    a.stride[l] = on ? d->stride[l] : 1;
+    a.hw[l] = on ? d->h[l] * d->w[l] : 0;
+    a.row0[l] = on ? d->row0[l] : 0;
+    a.pos0[l] = p;
+    a.cand0[l] = k;
+    if (on) {
+      p += a.hw[l];
+      k += (d->nms_pre > 0 && a.hw[l] > d->nms_pre) ? d->nms_pre : a.hw[l];
+    }
+  }
+  a.pos0[SM_MAX_LEVELS] = p;
+  a.cand0[SM_MAX_LEVELS] = k;
+  for (int l = d->nlev; l <= SM_MAX_LEVELS; ++l) {
+    a.pos0[l] = p;
+    a.cand0[l] = k;
+  }
+  if (k != d->kmax) return SM_ERR_BAD_SHAPE;
+  if (d->reg_cstride < 5 || d->reg_cstride % 4 != 0) return SM_ERR_BAD_SHAPE;
+  a.cls_cs = d->cls_cstride;
+  a.cls_co = d->cls_coff;
+  a.cof_cs = d->cof_cstride;
+  a.cof_co = d->cof_coff;
+  a.reg_cs = d->reg_cstride;
+  a.nms_pre = d->nms_pre;
+  a.img_h = d->img_h;
+  a.img_w = d->img_w;
+  a.kmax = d->kmax;
+  a.scale_factor = d->scale_factor;
+  a.rescale = d->rescale;
+  a.reg_prescaled = d->reg_prescaled;
+  return SM_OK;
+}
+
+int next_pow2(int v) {
+  int p = 64;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+extern "C" int64_t sm_det_select_workspace(const sm_det_desc* d) {
+  DetArgs a;
+  if (fill_det_args(d, a) != SM_OK) return -1;
+  return (int64_t)d->batch * a.pos0[d->nlev] * sizeof(float);
+}
+
+extern "C" int sm_det_select(const sm_det_desc* d, const float* cls, const float* reg, const float* cof, float* boxes,
+                             float* scores, float* ctr, float* cofs, int32_t* cand_pos, int32_t* ncand,
+                             void* workspace, sm_stream_t stream) {
+  if (!cls || !reg || !cof || !boxes || !scores || !ctr || !cofs || !cand_pos || !ncand || !workspace)
+    return SM_ERR_BAD_ARG;
+  DetArgs a;
+  int st = fill_det_args(d, a);
+  if (st != SM_OK) return st;
+  hipStream_t s = sm_hip_stream(stream);
+  float* keys = (float*)workspace;
+  const long long total = (long long)a.batch * a.pos0[a.nlev];
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(det_score_kernel, dim3(g), dim3(256), 0, s, cls, reg, keys, a);
+  hipLaunchKernelGGL(det_topk_kernel, dim3(a.nlev, a.batch), dim3(TK_THREADS), 0, s, keys, cand_pos, a);
+  hipLaunchKernelGGL(det_gather_kernel, dim3(a.kmax, a.batch), dim3(64), 0, s, cls, reg, cof, cand_pos, boxes, scores,
+                     ctr, cofs, a);
+  // every image has exactly kmax candidates (sum_l min(nms_pre, hw_l))
+  if (a.batch > 1024) return SM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(1024), 0, s, ncand, a.batch, a.kmax);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int64_t sm_multiclass_nms_workspace(int batch, int kmax, int num_classes) {
+  // cls_keep i32 [B][C][kmax] + flat_key f32 [B][C][kmax] + cls_cnt i32 [B][C]
+  return (int64_t)batch * num_classes * kmax * 8 + (int64_t)batch * num_classes * 4;
+}
+
+extern "C" int sm_multiclass_nms(const float* boxes, const float* scores, const float* ctr, const int32_t* ncand,
+                                 int batch, int kmax, int num_classes, float score_thr, float iou_thr, int max_num,
+                                 float* det, int64_t* labels, int64_t* keep, int32_t* ndet, void* workspace,
+                                 sm_stream_t stream) {
+  if (!boxes || !scores || !ctr || !ncand || !det || !labels || !keep || !ndet || !workspace) return SM_ERR_BAD_ARG;
+  if (batch < 1 || kmax < 1 || num_classes < 1 || num_classes > 256) return SM_ERR_BAD_SHAPE;
+  if (max_num < 1 || max_num > TK_CAP) return SM_ERR_UNSUPPORTED;
+  NmsArgs a;
+  a.batch = batch;
+  a.kmax = kmax;
+  a.C = num_classes;
+  a.P = next_pow2(kmax);
+  a.max_num = max_num;
+  a.score_thr = score_thr;
+  a.iou_thr = iou_thr;
+  const size_t lds = (size_t)a.P * 28;
+  if (lds > 160 * 1024) return SM_ERR_UNSUPPORTED;
+  hipStream_t s = sm_hip_stream(stream);
+  int32_t* cls_keep = (int32_t*)workspace;
+  float* flat_key = (float*)((char*)workspace + (size_t)batch * num_classes * kmax * 4);
+  int32_t* cls_cnt = (int32_t*)((char*)workspace + (size_t)batch * num_classes * kmax * 8);
+  if (hipFuncSetAttribute((const void*)nms_class_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+      hipSuccess)
+    return SM_ERR_LAUNCH;
+  hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(64), lds, s, boxes, scores, ctr, ncand, cls_keep,
+                     cls_cnt, a);
+  hipLaunchKernelGGL(nms_final_kernel, dim3(batch), dim3(TK_THREADS), 0, s, boxes, scores, ctr, cls_keep, cls_cnt,
+                     flat_key, det, labels, keep, ndet, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int64_t sm_nms_workspace(int n) { (void)n; return 16; }
+
+extern "C" int sm_nms(const float* dets, int n, float iou_thr, int64_t* keep, int32_t* nkeep, void* workspace,
+                      sm_stream_t stream) {
+  (void)workspace;
+  if (!dets || !keep || !nkeep || n < 0) return SM_ERR_BAD_ARG;
+  hipStream_t s = sm_hip_stream(stream);
+  if (n == 0) {
+    if (hipMemsetAsync(nkeep, 0, sizeof(int32_t), s) != hipSuccess) return SM_ERR_LAUNCH;
+    return SM_OK;
+  }
+  const int P = next_pow2(n);
+  const size_t lds = (size_t)P * 28;
+  if (lds > 160 * 1024) return SM_ERR_UNSUPPORTED;
+  if (hipFuncSetAttribute((const void*)nms_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+      hipSuccess)
+    return SM_ERR_LAUNCH;
+  hipLaunchKernelGGL(nms_single_kernel, dim3(1), dim3(64), lds, s, dets, n, iou_thr, P, keep, nkeep);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

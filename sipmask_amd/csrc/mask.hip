@@ -1,0 +1,222 @@
+// Fused SipMask mask assembly (sipmask_head.py:609-633) -- HBM bound:
+//   algorithmic bytes / image = basis read (Hm*Wm*32*4) + u8 masks written (N*Ho*Wo).
+// One block owns one TOxTO tile of output pixels for ALL detections of an image:
+//   * the source (mask-resolution) pixels that tile needs (<= 512) are owned by threads, whose
+//     32 basis values stay in VGPRs for the whole detection loop -> the basis is read once;
+//   * per detection: quadrant select (CropSplit index math, crop_split_cuda_kernel.cu:34-52)
+//     -> ONE 32-long dot product (only the selected quadrant is ever needed) -> sigmoid
+//     -> LDS tile -> bilinear (align_corners=False) -> > thr -> packed u8 stores (4 px / lane).
+// The reference materialises 4 x [Hm*Wm, N] sigmoid planes, the stacked copy, the crop, the
+// upsampled float masks and the thresholded copy: ~4 GB/image of traffic vs ~140 MB here.
+#include "common.h"
+
+namespace {
+
+constexpr int MA_THREADS = 256;
+constexpr int MA_PX = 2;              // source pixels owned per thread
+constexpr int MA_SRC_CAP = MA_THREADS * MA_PX;
+constexpr int MA_MAXDET = 128;        // detections cached per pass (LDS)
+
+struct MaskArgs {
+  const float* basis;
+  const float* cofs;
+  const int64_t* keep;
+  const float* det;
+  const int32_t* ndet;
+  uint8_t* masks;
+  float* pos_masks;
+  int kmax, max_num, hm, wm, ho, wo;
+  long long pix_stride, ch_stride;  // basis strides (elements)
+  float box_mul, box_div, inv_up, thr;
+};
+
+struct DetBox {
+  float x1, y1, x2, y2, rw, rh;
+};
+
+template <int TO>
+__global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArgs a) {
+  __shared__ float s_cof[128];
+  __shared__ DetBox s_box;
+  __shared__ float s_prob[MA_SRC_CAP];
+  const int b = blockIdx.z;
+  const int ox0 = blockIdx.x * TO, oy0 = blockIdx.y * TO;
+  const int tid = threadIdx.x;
+  const int nd = min(a.ndet[b], a.max_num);
+  if (nd <= 0) return;
+
+  // source window of this output tile
+  auto src_of = [&](int o) { return fmaxf(a.inv_up * ((float)o + 0.5f) - 0.5f, 0.f); };
+  const int oxe = min(ox0 + TO, a.wo) - 1, oye = min(oy0 + TO, a.ho) - 1;
+  const int sx0 = (int)src_of(ox0), sy0 = (int)src_of(oy0);
+  const int sx1 = min((int)src_of(oxe) + 1, a.wm - 1), sy1 = min((int)src_of(oye) + 1, a.hm - 1);
+  const int spw = sx1 - sx0 + 1, sph = sy1 - sy0 + 1;
+  const int nsrc = spw * sph;  // host guarantees <= MA_SRC_CAP
+
+  // owned source pixels + their basis vectors (registers)
+  float bas[MA_PX][32];
+  int gx[MA_PX], gy[MA_PX];
+#pragma unroll
+  for (int p = 0; p < MA_PX; ++p) {
+    const int li = tid + p * MA_THREADS;
+    gx[p] = -1;
+    gy[p] = -1;
+    if (li < nsrc) {
+      const int ly = li / spw, lx = li - ly * spw;
+      gx[p] = sx0 + lx;
+      gy[p] = sy0 + ly;
+      const float* bp = a.basis + (long long)b * a.hm * a.wm * 32 + ((long long)gy[p] * a.wm + gx[p]) * a.pix_stride;
+      if (a.ch_stride == 1) {
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(bp + k);
+          bas[p][k] = v.x;
+          bas[p][k + 1] = v.y;
+          bas[p][k + 2] = v.z;
+          bas[p][k + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) bas[p][k] = bp[(long long)k * a.ch_stride];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) bas[p][k] = 0.f;
+    }
+  }
+
+  // output pixels of this thread: TO*TO/256 groups of 4 consecutive x
+  constexpr int GROUPS = TO * TO / 4;                 // 4-pixel groups in the tile
+  constexpr int GPT = (GROUPS + MA_THREADS - 1) / MA_THREADS;
+
+  for (int n = 0; n < nd; ++n) {
+    __syncthreads();  // previous iteration finished reading s_prob / s_cof / s_box
+    const long long dn = (long long)b * a.max_num + n;
+    if (tid < 128) s_cof[tid] = a.cofs[((long long)b * a.kmax + a.keep[dn]) * 128 + tid];
+    if (tid == 128) {
+      const float* d = a.det + dn * 5;
+      DetBox bx;
+      bx.x1 = __fdiv_rn(__fmul_rn(d[0], a.box_mul), a.box_div);
+      bx.y1 = __fdiv_rn(__fmul_rn(d[1], a.box_mul), a.box_div);
+      bx.x2 = __fdiv_rn(__fmul_rn(d[2], a.box_mul), a.box_div);
+      bx.y2 = __fdiv_rn(__fmul_rn(d[3], a.box_mul), a.box_div);
+      // roi_w = (x2 - x1 + 0.1) / num_cell in double, rounded to float (kernel.cu:47-48)
+      bx.rw = (float)(((double)__fsub_rn(bx.x2, bx.x1) + 0.1) / 2.0);
+      bx.rh = (float)(((double)__fsub_rn(bx.y2, bx.y1) + 0.1) / 2.0);
+      s_box = bx;
+    }
+    __syncthreads();
+    const DetBox bx = s_box;
+    // tile / box overlap in source coordinates (uniform): any source pixel inside?
+    const bool hit = ((float)sx1 >= bx.x1) && ((float)sx0 < bx.x2) && ((float)sy1 >= bx.y1) && ((float)sy0 < bx.y2);
+    uint8_t* mrow = a.masks + dn * (long long)a.ho * a.wo;
+    if (!hit) {
+      // whole tile is zero
+#pragma unroll
+      for (int g = 0; g < GPT; ++g) {
+        const int gi = tid + g * MA_THREADS;
+        if (gi < GROUPS) {
+          const int oy = oy0 + gi / (TO / 4), ox = ox0 + (gi % (TO / 4)) * 4;
+          if (oy < a.ho && ox < a.wo) *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.wo + ox) = 0u;
+        }
+      }
+      if (a.pos_masks) {
+#pragma unroll
+        for (int p = 0; p < MA_PX; ++p)
+          if (gx[p] >= 0) a.pos_masks[dn * (long long)a.hm * a.wm + (long long)gy[p] * a.wm + gx[p]] = 0.f;
+      }
+      continue;
+    }
+#pragma unroll
+    for (int p = 0; p < MA_PX; ++p) {
+      const int li = tid + p * MA_THREADS;
+      if (li < nsrc) {
+        const float pw = (float)gx[p], ph = (float)gy[p];
+        float prob = 0.f;
+        if (pw >= bx.x1 && ph >= bx.y1 && pw < bx.x2 && ph < bx.y2) {
+          const int iw = (int)__fdiv_rn(__fsub_rn(pw, bx.x1), bx.rw);
+          const int ih = (int)__fdiv_rn(__fsub_rn(ph, bx.y1), bx.rh);
+          const float* cq = s_cof + ((ih * 2 + iw) & 3) * 32;
+          float acc = 0.f;
+#pragma unroll
+          for (int k = 0; k < 32; ++k) acc = fmaf(bas[p][k], cq[k], acc);
+          prob = sigmoidf_acc(acc);
+        }
+        s_prob[li] = prob;
+        if (a.pos_masks) a.pos_masks[dn * (long long)a.hm * a.wm + (long long)gy[p] * a.wm + gx[p]] = prob;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GPT; ++g) {
+      const int gi = tid + g * MA_THREADS;
+      if (gi >= GROUPS) continue;
+      const int oy = oy0 + gi / (TO / 4), oxb = ox0 + (gi % (TO / 4)) * 4;
+      if (oy >= a.ho || oxb >= a.wo) continue;
+      const float sy = src_of(oy);
+      const int y0 = (int)sy, y1 = min(y0 + 1, a.hm - 1);
+      const float ly = sy - (float)y0, hy = 1.f - ly;
+      const float* r0 = s_prob + (y0 - sy0) * spw - sx0;
+      const float* r1 = s_prob + (y1 - sy0) * spw - sx0;
+      uint32_t packed = 0u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ox = oxb + e;
+        if (ox < a.wo) {
+          const float sx = src_of(ox);
+          const int x0 = (int)sx, x1 = min(x0 + 1, a.wm - 1);
+          const float lx = sx - (float)x0, hx = 1.f - lx;
+          const float v = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+          packed |= (v > a.thr ? 1u : 0u) << (8 * e);
+        }
+      }
+      *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.wo + oxb) = packed;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int sm_mask_assemble(const float* basis, int basis_hwc, const float* cofs, const int64_t* keep,
+                                const float* det, const int32_t* ndet, int batch, int kmax, int max_num, int hm,
+                                int wm, int ho, int wo, float box_mul, float box_div, double up_scale, float mask_thr,
+                                uint8_t* masks, float* pos_masks, sm_stream_t stream) {
+  if (!basis || !cofs || !keep || !det || !ndet || !masks) return SM_ERR_BAD_ARG;
+  if (batch < 1 || hm < 1 || wm < 1 || ho < 1 || wo < 1 || wo % 4 != 0 || !(up_scale > 0)) return SM_ERR_BAD_SHAPE;
+  MaskArgs a;
+  a.basis = basis;
+  a.cofs = cofs;
+  a.keep = keep;
+  a.det = det;
+  a.ndet = ndet;
+  a.masks = masks;
+  a.pos_masks = pos_masks;
+  a.kmax = kmax;
+  a.max_num = max_num;
+  a.hm = hm;
+  a.wm = wm;
+  a.ho = ho;
+  a.wo = wo;
+  a.pix_stride = basis_hwc ? 32 : 1;
+  a.ch_stride = basis_hwc ? 1 : (long long)hm * wm;
+  a.box_mul = box_mul;
+  a.box_div = box_div;
+  a.inv_up = (float)(1.0 / up_scale);  // area_pixel_compute_scale with an explicit scale_factor
+  a.thr = mask_thr;
+  hipStream_t s = sm_hip_stream(stream);
+  // pick the output tile so that the source window (TO/up + 2)^2 fits the per-thread ownership
+  auto span = [&](int to) { return (int)((double)to / up_scale) + 3; };
+  int to = 32;
+  if (span(32) * span(32) > MA_SRC_CAP) to = 16;
+  if (to == 16 && span(16) * span(16) > MA_SRC_CAP) to = 8;
+  if (to == 8 && span(8) * span(8) > MA_SRC_CAP) return SM_ERR_UNSUPPORTED;
+  dim3 grid(sm_cdiv(wo, to), sm_cdiv(ho, to), batch), block(MA_THREADS);
+  if (to == 32)
+    hipLaunchKernelGGL(mask_assemble_kernel<32>, grid, block, 0, s, a);
+  else if (to == 16)
+    hipLaunchKernelGGL(mask_assemble_kernel<16>, grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL(mask_assemble_kernel<8>, grid, block, 0, s, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

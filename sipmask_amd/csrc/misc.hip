@@ -1,0 +1,344 @@
+// HBM-bound helper kernels around the conv GEMMs: layout conversion, max-pool, GroupNorm(+ReLU),
+// bilinear upsample, FeatureAlign offset projection.  All NHWC, 16-byte (8 x bf16) accesses.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- NCHW f32 -> NHWC bf16 (pad C)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int B, int C, int HW,
+                                    int cpad) {
+  const long long total = (long long)B * HW;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+       p += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(p / HW);
+    const int hw = (int)(p - (long long)n * HW);
+    const float* xp = x + (long long)n * C * HW + hw;
+    uint16_t* yp = y + p * cpad;
+    for (int c0 = 0; c0 < cpad; c0 += 8) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (c0 + e < C) ? xp[(long long)(c0 + e) * HW] : 0.f;
+      *reinterpret_cast<uint4*>(yp + c0) = pack_bf16x8(f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- maxpool 3x3 s2 p1
+__global__ void maxpool3x3s2_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int B, int H, int W,
+                                    int C, int Ho, int Wo) {
+  const int c8 = C / 8;
+  const long long total = (long long)B * Ho * Wo * c8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    long long p = i / c8;
+    const int wo = (int)(p % Wo);
+    p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hi = ho * 2 - 1 + dh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int wi = wo * 2 - 1 + dw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(x + (((long long)n * H + hi) * W + wi) * C + cc * 8);
+        float f[8];
+        unpack_bf16x8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], f[e]);
+      }
+    }
+    *reinterpret_cast<uint4*>(y + (((long long)n * Ho + ho) * Wo + wo) * C + cc * 8) = pack_bf16x8(m);
+  }
+}
+
+// ---------------------------------------------------------------- GroupNorm
+struct GnArgs {
+  int nlev, batch, C, groups, cpg;  // cpg = channels per group (multiple of 8)
+  int hw[SM_MAX_LEVELS];
+  long long row0[SM_MAX_LEVELS];
+  int blk0[SM_MAX_LEVELS + 1];  // first block of each level (per image)
+  float eps;
+  int relu;
+};
+
+constexpr int GN_ROWS_PER_BLOCK = 256;
+
+// Each block reduces GN_ROWS_PER_BLOCK rows of one (image, level); a thread owns one
+// 16-byte chunk column (8 channels, inside one group) and strides over rows.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ stats,
+                                                       const GnArgs a) {
+  const int n = blockIdx.y;
+  int lev = 0;
+#pragma unroll
+  for (int l = 1; l < SM_MAX_LEVELS; ++l)
+    if (l < a.nlev && (int)blockIdx.x >= a.blk0[l]) lev = l;
+  const int rb = (blockIdx.x - a.blk0[lev]) * GN_ROWS_PER_BLOCK;
+  const int HW = a.hw[lev];
+  const int c8 = a.C / 8;            // chunks per row
+  const int rows_per_iter = 256 / c8;  // C=256 -> 8 rows per iteration
+  const int cc = threadIdx.x % c8;
+  const int rr = threadIdx.x / c8;
+  const uint16_t* base = x + (a.row0[lev] + (long long)n * HW) * a.C;
+  float s = 0.f, ss = 0.f;
+  if (rr < rows_per_iter) {
+    const int rend = min(rb + GN_ROWS_PER_BLOCK, HW);
+    for (int r = rb + rr; r < rend; r += rows_per_iter) {
+      const uint4 v = *reinterpret_cast<const uint4*>(base + (long long)r * a.C + cc * 8);
+      float f[8];
+      unpack_bf16x8(v, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s += f[e];
+        ss += f[e] * f[e];
+      }
+    }
+  }
+  __shared__ float sh[2][256];
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = ss;
+  __syncthreads();
+  // one thread per group sums its chunks over all row-lanes
+  const int chunks_per_group = a.cpg / 8;
+  if ((int)threadIdx.x < a.groups) {
+    const int g = threadIdx.x;
+    float ts = 0.f, tss = 0.f;
+    for (int r = 0; r < rows_per_iter; ++r)
+      for (int k = 0; k < chunks_per_group; ++k) {
+        const int t = r * c8 + g * chunks_per_group + k;
+        ts += sh[0][t];
+        tss += sh[1][t];
+      }
+    float* st = stats + (((long long)n * a.nlev + lev) * a.groups + g) * 2;
+    atomicAdd(st, ts);
+    atomicAdd(st + 1, tss);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ stats, const GnArgs a) {
+  const int n = blockIdx.y;
+  int lev = 0;
+#pragma unroll
+  for (int l = 1; l < SM_MAX_LEVELS; ++l)
+    if (l < a.nlev && (int)blockIdx.x >= a.blk0[l]) lev = l;
+  const int rb = (blockIdx.x - a.blk0[lev]) * GN_ROWS_PER_BLOCK;
+  const int HW = a.hw[lev];
+  const int c8 = a.C / 8;
+  const int rows_per_iter = 256 / c8;
+  const int cc = threadIdx.x % c8;
+  const int rr = threadIdx.x / c8;
+  if (rr >= rows_per_iter) return;
+  const int g = (cc * 8) / a.cpg;
+  const float* st = stats + (((long long)n * a.nlev + lev) * a.groups + g) * 2;
+  const float cnt = (float)HW * (float)a.cpg;
+  const float mean = st[0] / cnt;
+  const float var = fmaxf(st[1] / cnt - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + a.eps);
+  float sc[8], sf[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float ga = gamma[cc * 8 + e] * rstd;
+    sc[e] = ga;
+    sf[e] = beta[cc * 8 + e] - mean * ga;
+  }
+  const long long off = (a.row0[lev] + (long long)n * HW) * a.C;
+  const int rend = min(rb + GN_ROWS_PER_BLOCK, HW);
+  for (int r = rb + rr; r < rend; r += rows_per_iter) {
+    const long long o = off + (long long)r * a.C + cc * 8;
+    const uint4 v = *reinterpret_cast<const uint4*>(x + o);
+    float f[8];
+    unpack_bf16x8(v, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = f[e] * sc[e] + sf[e];
+      f[e] = a.relu ? fmaxf(t, 0.f) : t;
+    }
+    *reinterpret_cast<uint4*>(y + o) = pack_bf16x8(f);
+  }
+}
+
+// ---------------------------------------------------------------- bilinear upsample (integer factor)
+template <bool F32>
+__global__ void upsample_bilinear_kernel(const void* __restrict__ xin, void* __restrict__ yout, int B, int H, int W,
+                                         int C, int factor, int in_cs, int out_cs, int out_coff) {
+  const int Ho = H * factor, Wo = W * factor;
+  constexpr int VEC = F32 ? 4 : 8;
+  const int cv = C / VEC;
+  const long long total = (long long)B * Ho * Wo * cv;
+  const float inv = 1.f / (float)factor;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cv);
+    long long p = i / cv;
+    const int wo = (int)(p % Wo);
+    p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    // area_pixel_compute_source_index(align_corners=False): max(0, (dst+0.5)*scale-0.5)
+    float sy = fmaxf(((float)ho + 0.5f) * inv - 0.5f, 0.f);
+    float sx = fmaxf(((float)wo + 0.5f) * inv - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const long long r00 = ((long long)n * H + y0) * W + x0, r01 = ((long long)n * H + y0) * W + x1;
+    const long long r10 = ((long long)n * H + y1) * W + x0, r11 = ((long long)n * H + y1) * W + x1;
+    const long long orow = ((long long)n * Ho + ho) * Wo + wo;
+    float a[VEC], b[VEC], c[VEC], d[VEC], r[VEC];
+    if constexpr (F32) {
+      const float* x = (const float*)xin;
+      *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(x + r00 * in_cs + cc * 4);
+      *reinterpret_cast<float4*>(b) = *reinterpret_cast<const float4*>(x + r01 * in_cs + cc * 4);
+      *reinterpret_cast<float4*>(c) = *reinterpret_cast<const float4*>(x + r10 * in_cs + cc * 4);
+      *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(x + r11 * in_cs + cc * 4);
+    } else {
+      const uint16_t* x = (const uint16_t*)xin;
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(x + r00 * in_cs + cc * 8), a);
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(x + r01 * in_cs + cc * 8), b);
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(x + r10 * in_cs + cc * 8), c);
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(x + r11 * in_cs + cc * 8), d);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) r[e] = hy * (hx * a[e] + lx * b[e]) + ly * (hx * c[e] + lx * d[e]);
+    if constexpr (F32) {
+      *reinterpret_cast<float4*>((float*)yout + orow * out_cs + out_coff + cc * 4) = *reinterpret_cast<float4*>(r);
+    } else {
+      *reinterpret_cast<uint4*>((uint16_t*)yout + orow * out_cs + out_coff + cc * 8) = pack_bf16x8(r);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- FeatureAlign.conv_offset (1x1, 4 -> nout)
+struct OffArgs {
+  int nlev, nout, reg_cs;
+  long long row0[SM_MAX_LEVELS];
+  int rows[SM_MAX_LEVELS];
+  float scale[SM_MAX_LEVELS];
+  long long total;
+};
+
+__global__ void offset_linear_kernel(const float* __restrict__ reg, const float* __restrict__ w,
+                                     float* __restrict__ out, const OffArgs a) {
+  // thread per (row, out channel); 4 MACs each
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.total * a.nout;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / a.nout;
+    const int o = (int)(i - r * a.nout);
+    int lev = 0;
+#pragma unroll
+    for (int l = 1; l < SM_MAX_LEVELS; ++l)
+      if (l < a.nlev && r >= a.row0[l]) lev = l;
+    const float4 v = *reinterpret_cast<const float4*>(reg + r * a.reg_cs);
+    const float4 ww = *reinterpret_cast<const float4*>(w + o * 4);
+    // bbox_pred (x Scale) feeds conv_offset: sipmask_head.py:261-263; level_scale is 1 when the
+    // producing conv already applied Scale in its epilogue
+    const float s = a.scale[lev];
+    out[i] = ww.x * (v.x * s) + ww.y * (v.y * s) + ww.z * (v.z * s) + ww.w * (v.w * s);
+  }
+}
+
+inline int grid_for(long long n, int block) {
+  long long g = (n + block - 1) / block;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int sm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int batch, int c, int h, int w, int cpad,
+                                        sm_stream_t stream) {
+  if (!x || !y || cpad % 8 != 0 || cpad < c || batch < 1) return SM_ERR_BAD_ARG;
+  const long long n = (long long)batch * h * w;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(n, 256)), dim3(256), 0, sm_hip_stream(stream), x,
+                     (uint16_t*)y, batch, c, h * w, cpad);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_maxpool3x3s2(const void* x, void* y, int batch, int h, int w, int c, sm_stream_t stream) {
+  if (!x || !y || c % 8 != 0) return SM_ERR_BAD_ARG;
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const long long n = (long long)batch * ho * wo * (c / 8);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(n, 256)), dim3(256), 0, sm_hip_stream(stream),
+                     (const uint16_t*)x, (uint16_t*)y, batch, h, w, c, ho, wo);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_groupnorm(const void* x, void* y, const float* gamma, const float* beta, float* stats, int batch,
+                            int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups, float eps,
+                            int relu, sm_stream_t stream) {
+  if (!x || !y || !gamma || !beta || !stats || !hw || !row0) return SM_ERR_BAD_ARG;
+  if (nlev < 1 || nlev > SM_MAX_LEVELS || channels % (8 * groups) != 0 || channels > 2048 || 256 % (channels / 8) != 0)
+    return SM_ERR_BAD_SHAPE;
+  if (groups > 256) return SM_ERR_BAD_SHAPE;
+  GnArgs a;
+  a.nlev = nlev;
+  a.batch = batch;
+  a.C = channels;
+  a.groups = groups;
+  a.cpg = channels / groups;
+  a.eps = eps;
+  a.relu = relu;
+  int t = 0;
+  for (int l = 0; l < SM_MAX_LEVELS; ++l) {
+    a.hw[l] = l < nlev ? hw[l] : 0;
+    a.row0[l] = l < nlev ? row0[l] : 0;
+    a.blk0[l] = t;
+    if (l < nlev) t += sm_cdiv(hw[l], GN_ROWS_PER_BLOCK);
+  }
+  a.blk0[SM_MAX_LEVELS] = t;
+  hipStream_t s = sm_hip_stream(stream);
+  if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(t, batch), dim3(256), 0, s, (const uint16_t*)x, stats, a);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(t, batch), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)y, gamma, beta,
+                     stats, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_upsample_bilinear(const void* x, void* y, int batch, int h, int w, int c, int factor,
+                                    int in_cstride, int out_cstride, int out_coff, int is_f32, sm_stream_t stream) {
+  if (!x || !y || factor < 1) return SM_ERR_BAD_ARG;
+  const int vec = is_f32 ? 4 : 8;
+  if (c % vec || in_cstride % vec || out_cstride % vec || out_coff % vec) return SM_ERR_BAD_SHAPE;
+  const long long n = (long long)batch * h * factor * w * factor * (c / vec);
+  if (is_f32)
+    hipLaunchKernelGGL(upsample_bilinear_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, sm_hip_stream(stream), x,
+                       y, batch, h, w, c, factor, in_cstride, out_cstride, out_coff);
+  else
+    hipLaunchKernelGGL(upsample_bilinear_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, sm_hip_stream(stream), x,
+                       y, batch, h, w, c, factor, in_cstride, out_cstride, out_coff);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_offset_linear(const float* reg, int reg_cstride, const float* w_off, int nout, const int64_t* row0,
+                                const int32_t* rows_per_level, const float* level_scale, int nlev, float* out,
+                                sm_stream_t stream) {
+  if (!reg || !w_off || !row0 || !rows_per_level || !out || nlev < 1 || nlev > SM_MAX_LEVELS) return SM_ERR_BAD_ARG;
+  if (reg_cstride % 4 != 0) return SM_ERR_BAD_SHAPE;
+  OffArgs a;
+  a.nlev = nlev;
+  a.nout = nout;
+  a.reg_cs = reg_cstride;
+  a.total = 0;
+  for (int l = 0; l < SM_MAX_LEVELS; ++l) {
+    a.row0[l] = l < nlev ? row0[l] : 0;
+    a.rows[l] = l < nlev ? rows_per_level[l] : 0;
+    a.scale[l] = (l < nlev && level_scale) ? level_scale[l] : 1.f;
+    if (l < nlev) a.total += rows_per_level[l];
+  }
+  hipLaunchKernelGGL(offset_linear_kernel, dim3(grid_for(a.total * nout, 256)), dim3(256), 0, sm_hip_stream(stream),
+                     reg, w_off, out, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

@@ -1,0 +1,82 @@
+"""SipMask single-stage detector -- drop-in for ``@DETECTORS`` ``SipMask``
+(M/mmdet/models/detectors/sipmask.py:5-16, single_stage.py:9-96, base.py:97-149).
+
+extract_feat + bbox_head + get_bboxes run as ONE static HIP launch plan (sipmask_amd/engine.py).
+"""
+import torch
+import torch.nn as nn
+
+from . import modules, sipmask_head  # noqa: F401  (register ResNet / FPN / SipMaskHead)
+from .registry import DETECTORS, build_backbone, build_head, build_neck
+
+
+@DETECTORS.register_module
+class SipMask(nn.Module):
+
+    def __init__(self, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(neck) if neck is not None else None
+        self.bbox_head = build_head(bbox_head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self._engines = {}
+        self.init_weights(pretrained=pretrained)
+
+    @property
+    def with_neck(self):
+        return self.neck is not None
+
+    def init_weights(self, pretrained=None):
+        self.backbone.init_weights(pretrained=pretrained if isinstance(pretrained, str) and
+                                   not pretrained.startswith("open-mmlab://") else None)
+        if self.with_neck:
+            self.neck.init_weights()
+        self.bbox_head.init_weights()
+        self._engines = {}
+
+    def prepare(self, batch, img_hw, img_shape=None):
+        """Build (or fetch) the static launch plan for this input geometry; weights are snapshotted,
+        BN folded, re-laid out as bf16 GEMM operands.  Call again after load_state_dict."""
+        from .engine import SipMaskEngine
+        key = (batch, tuple(img_hw), tuple(img_shape or ()))
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = SipMaskEngine(self.state_dict(), batch, img_hw, self.backbone.depth, self.test_cfg,
+                                self.bbox_head.num_classes, strides=self.bbox_head.strides, img_shape=img_shape)
+            self._engines = {key: eng}
+        return eng
+
+    def load_state_dict(self, *args, **kwargs):
+        self._engines = {}
+        return super().load_state_dict(*args, **kwargs)
+
+    def get_masks(self, img, img_metas=None):
+        """Batch-capable tensor-only inference (compare before RLE): dict of device tensors
+        det_bboxes [B,max,5], det_labels [B,max], idxs_keep [B,max], ndet [B], masks u8 [B,max,H,W]."""
+        shape = None if not img_metas else tuple(img_metas[0]['img_shape'])
+        eng = self.prepare(img.shape[0], tuple(img.shape[-2:]), shape)
+        return eng.run(img)
+
+    def simple_test(self, img, img_meta, rescale=False):
+        """single_stage.py:75-96: returns (bbox_results, segm_results) of image 0."""
+        if rescale and float(img_meta[0].get('scale_factor', 1.0)) != 1.0:
+            raise NotImplementedError("rescale with scale_factor != 1 is planned through SipMaskHead.get_masks")
+        r = self.get_masks(img, img_meta)
+        n = int(r["ndet"][0])
+        det, lab = r["det_bboxes"][0, :n], r["det_labels"][0, :n]
+        ncls = self.bbox_head.num_classes - 1
+        d, l, m = det.cpu().numpy(), lab.cpu().numpy(), r["masks"][0, :n].cpu().numpy()
+        shp = img_meta[0]['img_shape']
+        bbox_results = [d[l == i, :] for i in range(ncls)]
+        segm_results = [[m[j, :shp[0], :shp[1]] for j in range(n) if l[j] == i] for i in range(ncls)]
+        return bbox_results, segm_results
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        assert len(imgs) == 1, "aug test is not on the SipMask path"
+        assert imgs[0].size(0) == 1                      # base.py:118-119
+        return self.simple_test(imgs[0], img_metas[0], **kwargs)
+
+    def forward(self, img, img_meta, return_loss=True, **kwargs):
+        if return_loss:
+            raise NotImplementedError("forward_train lands with the backward kernels (SURVEY row a13/a17)")
+        return self.forward_test(img, img_meta, **kwargs)

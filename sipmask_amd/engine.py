@@ -1,0 +1,382 @@
+"""Inference engine: the SipMask hot path as a static plan of HIP kernel launches.
+
+``SipMaskEngine.prepare`` takes a reference-named ``state_dict``, folds the
+frozen BatchNorms into the conv weights (resnet.py:370,514-521: BN is always eval), re-lays the
+weights out as K-major bf16 GEMM operands, allocates every activation / workspace buffer once
+(288 GB of HBM: nothing is ever re-allocated) and records the launch list.  ``run`` replays the
+list on the current stream -- it is capture-safe, so callers may wrap it in a HIP graph.
+
+Layout: activations are NHWC bf16 "pyramid tensors" (all FPN levels of all images in one row
+matrix) so the 5 levels that share tower weights run as ONE implicit-GEMM launch.
+"""
+import math
+
+import torch
+
+from . import _lib
+from . import hip_ops as H
+from ._lib import SM_CONV_RELU, SM_CONV_OUT_F32, SM_CONV_RES_ADD, SM_CONV_RES_NEAREST, SM_CONV_IN_RELU
+
+ARCH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+BF16 = torch.bfloat16
+
+
+def _conv_out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def fold_bn(w, sd, p, eps=1e-5):
+    """conv (no bias) followed by eval-mode BN -> (w', b')."""
+    g, b = sd[p + ".weight"].float(), sd[p + ".bias"].float()
+    m, v = sd[p + ".running_mean"].float(), sd[p + ".running_var"].float()
+    s = g / torch.sqrt(v + eps)
+    return w.float() * s.view(-1, 1, 1, 1), b - m * s
+
+
+class _Conv:
+    """One prepared conv launch."""
+
+    def __init__(self, eng, name, w, bias, batch, in_sizes, in_row0, x, in_cstride, stride, pad, y, out_row0,
+                 out_cstride, out_coff=0, flags=0, cin_pad=None, residual=None, res_cstride=0, res_sizes=None,
+                 res_row0=None, scale_nch=0, level_scale=None, deform_groups=0, offset=None):
+        dev = eng.device
+        co, ci, k, _ = w.shape
+        cin = cin_pad or ci
+        self.name = name
+        self.w, co_pad = H.prep_conv_weight(w.to(dev), cin)
+        self.bias = None if bias is None else bias.float().to(dev).contiguous()
+        out_sizes = [(_conv_out(h, k, stride, pad), _conv_out(ww, k, stride, pad)) for h, ww in in_sizes]
+        self.out_sizes = out_sizes
+        self.desc = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, co_pad, k, stride, pad,
+                                     in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
+                                     scale_nch, level_scale, deform_groups)
+        self.x, self.y, self.residual, self.offset = x, y, residual, offset
+        self.flops = 2.0 * sum(batch * h * ww for h, ww in out_sizes) * co * ci * k * k
+
+    def __call__(self):
+        if self.offset is not None:
+            H.deform_conv2d(self.desc, self.x, self.offset, self.w, self.bias, self.y)
+        else:
+            H.conv2d(self.desc, self.x, self.w, self.bias, self.residual, self.y)
+
+
+class SipMaskEngine:
+    """Static launch plan for SipMask-R50/R101 inference at a fixed (batch, H, W)."""
+
+    def __init__(self, state_dict, batch, img_hw, depth=50, test_cfg=None, num_classes=81, device="cuda",
+                 strides=(8, 16, 32, 64, 128), img_shape=None, head_sizes=None):
+        _lib.load()   # fail loudly before anything else if the HIP library is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("SipMaskEngine needs a HIP device")
+        self.device = torch.device(device)
+        self.batch = batch
+        self.H, self.W = img_hw
+        assert self.H % 32 == 0 and self.W % 32 == 0, "pad images to a multiple of 32 (Pad size_divisor=32)"
+        self.depth = depth
+        self.ncls = num_classes - 1
+        self.strides = tuple(strides)
+        self.cfg = dict(nms_pre=1000, score_thr=0.05, nms=dict(type="nms", iou_thr=0.5), max_per_img=100)
+        if test_cfg:
+            self.cfg.update(test_cfg)
+        self.img_shape = img_shape or (self.H, self.W, 3)
+        self.steps = []        # (label, callable)
+        self.convs = []        # _Conv objects (for FLOP accounting / per-kernel timing)
+        self.head_start = 0
+        if head_sizes is None:
+            self._build(state_dict)
+        else:                  # head-only plan on caller-provided FPN features
+            sd = {k: v.detach() for k, v in state_dict.items()}
+            self.lv = H.Levels(batch, head_sizes)
+            self.pyr = self._buf(self.lv.rows, 256)
+            self._build_head(sd)
+            self._build_post()
+
+    @classmethod
+    def for_head(cls, state_dict, batch, sizes, num_classes=81, strides=(8, 16, 32, 64, 128), test_cfg=None,
+                 img_shape=None):
+        """Plan for SipMaskHead.forward / get_bboxes alone (features come from the caller)."""
+        h0, w0 = sizes[0]
+        img_hw = (h0 * strides[0], w0 * strides[0])
+        return cls(state_dict, batch, img_hw, 50, test_cfg, num_classes, "cuda", strides,
+                   img_shape or (img_hw[0], img_hw[1], 3), head_sizes=list(sizes))
+
+    def load_pyramid(self, feats):
+        """copy caller features (tuple of NCHW float tensors) into the bf16 pyramid tensor"""
+        lv = self.lv
+        for l, f in enumerate(feats):
+            h, w = lv.sizes[l]
+            assert tuple(f.shape) == (self.batch, 256, h, w), (tuple(f.shape), (self.batch, 256, h, w))
+            H.nchw_to_nhwc_bf16(f.detach().float().contiguous(), self.pyr[lv.row0[l]:lv.row0[l] + self.batch * h * w], 256)
+
+    def run_head(self, with_post=False):
+        for label, fn in self.steps[self.head_start:]:
+            if not with_post and label in ("det_select", "nms", "mask_assemble"):
+                continue
+            fn()
+
+    # -------------------------------------------------------------------------------- helpers
+    def _buf(self, rows, c, dtype=BF16):
+        return torch.empty(rows, c, dtype=dtype, device=self.device)
+
+    def _add(self, label, fn):
+        self.steps.append((label, fn))
+
+    def _add_conv(self, conv):
+        self.convs.append(conv)
+        self._add("conv:" + conv.name, conv)
+        return conv
+
+    # -------------------------------------------------------------------------------- plan
+    def _build(self, sd):
+        B, Himg, Wimg, dev = self.batch, self.H, self.W, self.device
+        sd = {k: v.detach() for k, v in sd.items()}
+        # ---- stem
+        self.img_nhwc = self._buf(B * Himg * Wimg, 8)
+        h1, w1 = _conv_out(Himg, 7, 2, 3), _conv_out(Wimg, 7, 2, 3)
+        w, b = fold_bn(sd["backbone.conv1.weight"], sd, "backbone.bn1")
+        stem = self._buf(B * h1 * w1, 64)
+        self._add("nhwc", lambda: H.nchw_to_nhwc_bf16(self.img, self.img_nhwc, 8))
+        self._add_conv(_Conv(self, "stem", w, b, B, [(Himg, Wimg)], [0], self.img_nhwc, 8, 2, 3, stem, [0], 64,
+                             flags=SM_CONV_RELU, cin_pad=8))
+        h2, w2 = _conv_out(h1, 3, 2, 1), _conv_out(w1, 3, 2, 1)
+        x = self._buf(B * h2 * w2, 64)
+        self._add("maxpool", (lambda s=stem, y=x: H.maxpool3x3s2(s, y, B, h1, w1, 64)))
+        # ---- residual stages (caffe style: stride on conv1, resnet.py:125-130)
+        cur, ch, cw, cc = x, h2, w2, 64
+        feats = []
+        for li, nblocks in enumerate(ARCH[self.depth]):
+            planes = 64 * 2 ** li
+            for bi in range(nblocks):
+                p = "backbone.layer%d.%d" % (li + 1, bi)
+                s = 2 if (bi == 0 and li > 0) else 1
+                oh, ow = _conv_out(ch, 1, s, 0), _conv_out(cw, 1, s, 0)
+                wa, ba = fold_bn(sd[p + ".conv1.weight"], sd, p + ".bn1")
+                t1 = self._buf(B * oh * ow, planes)
+                self._add_conv(_Conv(self, p + ".conv1", wa, ba, B, [(ch, cw)], [0], cur, cc, s, 0, t1, [0], planes,
+                                     flags=SM_CONV_RELU))
+                wb, bb = fold_bn(sd[p + ".conv2.weight"], sd, p + ".bn2")
+                t2 = self._buf(B * oh * ow, planes)
+                self._add_conv(_Conv(self, p + ".conv2", wb, bb, B, [(oh, ow)], [0], t1, planes, 1, 1, t2, [0], planes,
+                                     flags=SM_CONV_RELU))
+                if bi == 0:
+                    wd, bd = fold_bn(sd[p + ".downsample.0.weight"], sd, p + ".downsample.1")
+                    idt = self._buf(B * oh * ow, planes * 4)
+                    self._add_conv(_Conv(self, p + ".downsample", wd, bd, B, [(ch, cw)], [0], cur, cc, s, 0, idt, [0],
+                                         planes * 4))
+                else:
+                    idt = cur
+                wc, bc = fold_bn(sd[p + ".conv3.weight"], sd, p + ".bn3")
+                out = self._buf(B * oh * ow, planes * 4)
+                self._add_conv(_Conv(self, p + ".conv3", wc, bc, B, [(oh, ow)], [0], t2, planes, 1, 0, out, [0],
+                                     planes * 4, flags=SM_CONV_RELU | SM_CONV_RES_ADD, residual=idt,
+                                     res_cstride=planes * 4))
+                cur, ch, cw, cc = out, oh, ow, planes * 4
+            feats.append((cur, ch, cw, cc))
+        self.backbone_feats = feats
+        # ---- FPN (start_level=1): laterals with fused top-down nearest add (fpn.py:141-152)
+        sizes = [(f[1], f[2]) for f in feats[1:]]
+        p6 = (_conv_out(sizes[2][0], 3, 2, 1), _conv_out(sizes[2][1], 3, 2, 1))
+        p7 = (_conv_out(p6[0], 3, 2, 1), _conv_out(p6[1], 3, 2, 1))
+        self.lv = H.Levels(B, sizes + [p6, p7])
+        lv = self.lv
+        lats = [None] * 3
+        for i in (2, 1, 0):
+            f, fh, fw, fc = feats[i + 1]
+            lats[i] = self._buf(B * fh * fw, 256)
+            wl = sd["neck.lateral_convs.%d.conv.weight" % i]
+            bl = sd["neck.lateral_convs.%d.conv.bias" % i]
+            if i == 2:
+                self._add_conv(_Conv(self, "fpn.lat%d" % i, wl, bl, B, [(fh, fw)], [0], f, fc, 1, 0, lats[i], [0], 256))
+            else:
+                self._add_conv(_Conv(self, "fpn.lat%d" % i, wl, bl, B, [(fh, fw)], [0], f, fc, 1, 0, lats[i], [0], 256,
+                                     flags=SM_CONV_RES_NEAREST, residual=lats[i + 1], res_cstride=256,
+                                     res_sizes=[sizes[i + 1]], res_row0=[0]))
+        self.pyr = self._buf(lv.rows, 256)
+        for i in range(3):
+            self._add_conv(_Conv(self, "fpn.out%d" % i, sd["neck.fpn_convs.%d.conv.weight" % i],
+                                 sd["neck.fpn_convs.%d.conv.bias" % i], B, [sizes[i]], [0], lats[i], 256, 1, 1,
+                                 self.pyr, [lv.row0[i]], 256))
+        self._add_conv(_Conv(self, "fpn.p6", sd["neck.fpn_convs.3.conv.weight"], sd["neck.fpn_convs.3.conv.bias"], B,
+                             [sizes[2]], [lv.row0[2]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[3]], 256))
+        self._add_conv(_Conv(self, "fpn.p7", sd["neck.fpn_convs.4.conv.weight"], sd["neck.fpn_convs.4.conv.bias"], B,
+                             [p6], [lv.row0[3]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[4]], 256,
+                             flags=SM_CONV_IN_RELU))
+        self.head_start = len(self.steps)
+        self._build_head(sd)
+        self._build_post()
+
+    def _gn(self, label, x, gamma, beta):
+        g = gamma.float().to(self.device).contiguous()
+        b = beta.float().to(self.device).contiguous()
+        self._add("gn:" + label, lambda: H.groupnorm(x, x, g, b, self.gn_stats, self.lv, 256, 32, 1e-5, True))
+
+    def _build_head(self, sd, prefix="bbox_head."):
+        """SipMaskHead.forward, sipmask_head.py:241-287, on the pyramid tensor self.pyr."""
+        B, lv, dev, h = self.batch, self.lv, self.device, prefix
+        sizes, row0 = lv.sizes, lv.row0
+        self.gn_stats = torch.zeros(B * len(lv) * 32 * 2, dtype=torch.float32, device=dev)
+
+        def tower(kind, n):
+            x = self.pyr
+            for i in range(n):
+                y = self._buf(lv.rows, 256)
+                name = "%s_convs.%d" % (kind, i)
+                self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"], None, B, sizes, row0, x, 256,
+                                     1, 1, y, row0, 256))
+                self._gn(name, y, sd[h + name + ".gn.weight"], sd[h + name + ".gn.bias"])
+                x = y
+            return x
+
+        self.cls_feat = tower("cls", 3)
+        self.reg_feat = tower("reg", 4)
+        # fcos_reg (4, x Scale) + fcos_centerness (1) share reg_feat -> one 5-channel f32 conv
+        w_rc = torch.cat([sd[h + "fcos_reg.weight"], sd[h + "fcos_centerness.weight"]], 0)
+        b_rc = torch.cat([sd[h + "fcos_reg.bias"], sd[h + "fcos_centerness.bias"]], 0)
+        scales = [float(sd[h + "scales.%d.scale" % i]) for i in range(len(lv))]
+        self.reg_out = self._buf(lv.rows, 8, torch.float32)
+        self.reg_out.zero_()
+        self._add_conv(_Conv(self, "head.reg_ctr", w_rc, b_rc, B, sizes, row0, self.reg_feat, 256, 1, 1, self.reg_out,
+                             row0, 8, flags=SM_CONV_OUT_F32, scale_nch=4, level_scale=scales))
+        # FeatureAlign: offset = conv1x1(bbox_pred), y = relu(GN(deform_conv(cls_feat, offset)))
+        self.w_off = sd[h + "feat_align.conv_offset.weight"].float().view(72, 4).to(dev).contiguous()
+        self.offsets = self._buf(lv.rows, 72, torch.float32)
+        self._add("offset", lambda: H.offset_linear(self.reg_out, 8, self.w_off, lv, self.offsets))
+        self.aligned = self._buf(lv.rows, 256)
+        self._add_conv(_Conv(self, "head.feat_align", sd[h + "feat_align.conv_adaption.weight"], None, B, sizes, row0,
+                             self.cls_feat, 256, 1, 1, self.aligned, row0, 256, deform_groups=4, offset=self.offsets))
+        self._gn("feat_align", self.aligned, sd[h + "feat_align.norm.weight"], sd[h + "feat_align.norm.bias"])
+        # fcos_cls (80) + sip_cof (128) share the aligned feature -> one 208-channel f32 conv
+        w_cc = torch.cat([sd[h + "fcos_cls.weight"], sd[h + "sip_cof.weight"]], 0)
+        b_cc = torch.cat([sd[h + "fcos_cls.bias"], sd[h + "sip_cof.bias"]], 0)
+        self.ncc = self.ncls + 128
+        self.cls_cof = self._buf(lv.rows, self.ncc, torch.float32)
+        self._add_conv(_Conv(self, "head.cls_cof", w_cc, b_cc, B, sizes, row0, self.aligned, 256, 1, 1, self.cls_cof,
+                             row0, self.ncc, flags=SM_CONV_OUT_F32))
+        # mask basis branch (sipmask_head.py:275-285)
+        (h0, w0) = sizes[0]
+        self.cat = self._buf(B * h0 * w0, 768)
+        for l in range(3):
+            fh, fw = sizes[l]
+            src = self.reg_feat[row0[l]:row0[l] + B * fh * fw]
+            self._add("up:cat%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear(
+                s, self.cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, False)))
+        self.lat0 = self._buf(B * h0 * w0, 512)
+        self._add_conv(_Conv(self, "head.sip_mask_lat0", sd[h + "sip_mask_lat0.weight"], sd[h + "sip_mask_lat0.bias"],
+                             B, [(h0, w0)], [0], self.cat, 768, 1, 0, self.lat0, [0], 512, flags=SM_CONV_RELU))
+        self.basis_lo = self._buf(B * h0 * w0, 32, torch.float32)
+        self._add_conv(_Conv(self, "head.sip_mask_lat", sd[h + "sip_mask_lat.weight"], sd[h + "sip_mask_lat.bias"], B,
+                             [(h0, w0)], [0], self.lat0, 512, 1, 1, self.basis_lo, [0], 32,
+                             flags=SM_CONV_RELU | SM_CONV_OUT_F32))
+        self.hm, self.wm = 4 * h0, 4 * w0
+        self.basis = self._buf(B * self.hm * self.wm, 32, torch.float32)      # feat_masks, [B,Hm,Wm,32]
+        self._add("up:basis", lambda: H.upsample_bilinear(self.basis_lo, self.basis, B, h0, w0, 32, 4, 32, 32, 0, True))
+
+    def _build_post(self):
+        """get_bboxes (sipmask_head.py:500-633) for all images of the batch, device resident."""
+        B, lv, cfg = self.batch, self.lv, self.cfg
+        self.det_desc = H.make_det_desc(B, lv.sizes, self.strides, lv.row0, self.ncls, self.ncc, 0, self.ncc,
+                                        self.ncls, 8, cfg["nms_pre"], self.img_shape[0], self.img_shape[1])
+        self.sel = H.det_select_alloc(self.det_desc, self.device)
+        self.max_num = cfg["max_per_img"]
+        self.nms_out = H.multiclass_nms_alloc(B, self.det_desc.kmax, self.ncls, self.max_num, self.device)
+        self.ho, self.wo = 2 * self.hm, 2 * self.wm
+        self.masks = torch.zeros(B, self.max_num, self.ho, self.wo, dtype=torch.uint8, device=self.device)
+        self._add("det_select", lambda: H.det_select(self.det_desc, self.cls_cof, self.reg_out, self.cls_cof, self.sel))
+        self._add("nms", lambda: H.multiclass_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"],
+                                                  self.sel["ncand"], cfg["score_thr"], cfg["nms"]["iou_thr"],
+                                                  self.max_num, self.nms_out))
+        self._add("mask_assemble", lambda: H.mask_assemble(
+            self.basis, True, self.sel["cofs"], self.nms_out["keep"], self.nms_out["det"], self.nms_out["ndet"],
+            self.hm, self.wm, self.ho, self.wo, 1.0, 2.0, 2.0, 0.4, self.masks))
+
+    # -------------------------------------------------------------------------------- execution
+    def run(self, img):
+        """img: float32 NCHW [B,3,H,W] on the device.  Returns the result dict (device tensors)."""
+        assert img.shape == (self.batch, 3, self.H, self.W) and img.dtype == torch.float32 and img.is_cuda
+        self.img = img.contiguous()
+        for _, fn in self.steps:
+            fn()
+        return self.results()
+
+    def results(self):
+        o = self.nms_out
+        return dict(det_bboxes=o["det"], det_labels=o["labels"], idxs_keep=o["keep"], ndet=o["ndet"], masks=self.masks)
+
+    # -------------------------------------------------------------------------------- API views
+    def head_outputs(self):
+        """(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks) as NCHW views, as
+        SipMaskHead.forward returns them (sipmask_head.py:287)."""
+        B, lv = self.batch, self.lv
+        cls, bb, ctr, cof = [], [], [], []
+        for l, (h, w) in enumerate(lv.sizes):
+            r0, n = lv.row0[l], B * h * w
+            cc = self.cls_cof[r0:r0 + n].view(B, h, w, self.ncc).permute(0, 3, 1, 2)
+            rr = self.reg_out[r0:r0 + n].view(B, h, w, 8).permute(0, 3, 1, 2)
+            cls.append(cc[:, :self.ncls])
+            cof.append(cc[:, self.ncls:])
+            bb.append(rr[:, :4] * float(self.strides[l]))
+            ctr.append(rr[:, 4:5])
+        fm = self.basis.view(B, self.hm, self.wm, 32).permute(0, 3, 1, 2)
+        return cls, bb, ctr, cof, fm
+
+    def total_conv_flops(self):
+        return sum(c.flops for c in self.convs)
+
+
+class PostProcessor:
+    """SipMaskHead.get_bboxes on caller-provided head outputs (the API-faithful path used by the
+    parity tests: identical f32 inputs on both sides).  sipmask_head.py:500-633."""
+
+    def __init__(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg, strides,
+                 rescale=None):
+        _lib.load()
+        dev = cls_scores[0].device
+        _lib.require_cuda(cls_scores[0], feat_masks)
+        B = cls_scores[0].shape[0]
+        assert len(img_metas) == B
+        self.B, self.dev = B, dev
+        sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+        lv = H.Levels(B, sizes)
+        C = cls_scores[0].shape[1]
+        rows = lambda ts: torch.cat([t.detach().float().permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in ts])
+        self.cls = rows(cls_scores).contiguous()
+        self.cof = rows(cof_preds).contiguous()
+        self.reg = torch.cat([rows(bbox_preds), rows(centernesses),
+                              torch.zeros(lv.rows, 3, device=dev)], 1).contiguous()
+        self.basis = feat_masks.detach().float().contiguous()           # [B,32,Hm,Wm]
+        self.hm, self.wm = self.basis.shape[-2:]
+        meta = img_metas[0]
+        for m in img_metas[1:]:
+            if tuple(m['img_shape']) != tuple(meta['img_shape']) or m['scale_factor'] != meta['scale_factor']:
+                raise NotImplementedError("a batch must share img_shape / scale_factor (one launch plan)")
+        sf = float(meta['scale_factor'])
+        self.cfg = cfg
+        # quirk preserved (sipmask_head.py:621-623): crop boxes are multiplied by scale_factor unless
+        # rescale is None; boxes were divided by it only when rescale is truthy (:587-588)
+        self.box_mul = 1.0 if rescale is None else sf
+        self.up = 2.0 / (1.0 if rescale is None else sf)
+        self.ho, self.wo = int(self.hm * self.up), int(self.wm * self.up)
+        if self.wo % 4 != 0:
+            raise NotImplementedError("mask width must be a multiple of 4")
+        self.desc = H.make_det_desc(B, sizes, strides, lv.row0, C, C, 0, 128, 0, 8, cfg.get('nms_pre', -1),
+                                    meta['img_shape'][0], meta['img_shape'][1], sf, bool(rescale), True)
+        self.sel = H.det_select_alloc(self.desc, dev)
+        self.max_num = cfg['max_per_img']
+        self.out = H.multiclass_nms_alloc(B, self.desc.kmax, C, self.max_num, dev)
+
+    def run(self, want_pos_masks=False):
+        cfg = self.cfg
+        H.det_select(self.desc, self.cls, self.reg, self.cof, self.sel)
+        H.multiclass_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"], self.sel["ncand"], cfg['score_thr'],
+                         cfg['nms']['iou_thr'], self.max_num, self.out)
+        masks = torch.zeros(self.B, self.max_num, self.ho, self.wo, dtype=torch.uint8, device=self.dev)
+        self.pos_masks = (torch.zeros(self.B, self.max_num, self.hm, self.wm, device=self.dev)
+                          if want_pos_masks else None)
+        H.mask_assemble(self.basis, False, self.sel["cofs"], self.out["keep"], self.out["det"], self.out["ndet"],
+                        self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, 0.4, masks, self.pos_masks)
+        nd = self.out["ndet"].cpu().tolist()
+        res = []
+        for b in range(self.B):
+            n = nd[b]
+            res.append((self.out["det"][b, :n], self.out["labels"][b, :n], self.out["keep"][b, :n], masks[b, :n]))
+        return res

@@ -1,0 +1,206 @@
+"""Thin tensor -> C-ABI adapters (plumbing only: shape checks, pointers, the current stream).
+
+Everything numeric happens inside libsipmask_hip.so.  Shape / dtype / contiguity validation
+lives here so the error messages mirror the reference's Python-side checks
+(M/mmdet/ops/dcn/deform_conv.py:27-30,47,50-51; M/mmdet/ops/crop/src/crop_split_cuda.cpp:17).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, DetDesc, SM_MAX_LEVELS
+
+BF16 = torch.bfloat16
+
+
+def cout_tile(cout):
+    return 32 if cout <= 32 else (64 if cout <= 64 else 128)
+
+
+def prep_conv_weight(w, cin_pad=None):
+    """[co,ci,kh,kw] float -> bf16 [cout_pad][Kp]; K order (kh,kw,ci), ci fastest; Kp % 64 == 0."""
+    co, ci, kh, kw = w.shape
+    cin_pad = cin_pad or ((ci + 7) // 8 * 8)
+    tile = cout_tile(co)
+    co_pad = (co + tile - 1) // tile * tile
+    k = kh * kw * cin_pad
+    kp = (k + 63) // 64 * 64
+    out = torch.zeros(co_pad, kp, dtype=torch.float32, device=w.device)
+    wp = torch.zeros(co, kh, kw, cin_pad, dtype=torch.float32, device=w.device)
+    wp[..., :ci] = w.permute(0, 2, 3, 1).float()
+    out[:co, :k] = wp.reshape(co, k)
+    return out.to(BF16).contiguous(), co_pad
+
+
+class Levels:
+    """Row bookkeeping of a pyramid tensor: levels [(h,w)], batch -> row0 per level."""
+
+    def __init__(self, batch, sizes):
+        self.batch = batch
+        self.sizes = [(int(h), int(w)) for h, w in sizes]
+        self.row0 = []
+        r = 0
+        for h, w in self.sizes:
+            self.row0.append(r)
+            r += batch * h * w
+        self.rows = r
+
+    def __len__(self):
+        return len(self.sizes)
+
+
+def make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, cout, cout_pad, k, stride, pad,
+                   in_cstride, out_cstride, out_coff=0, flags=0, dil=1, res_cstride=0, res_sizes=None,
+                   res_row0=None, scale_nch=0, level_scale=None, deform_groups=0):
+    d = ConvDesc()
+    nlev = len(in_sizes)
+    assert 1 <= nlev <= SM_MAX_LEVELS
+    d.nlev, d.batch = nlev, batch
+    for l in range(nlev):
+        d.in_h[l], d.in_w[l] = in_sizes[l]
+        d.out_h[l], d.out_w[l] = out_sizes[l]
+        d.in_row0[l], d.out_row0[l] = in_row0[l], out_row0[l]
+        if res_sizes is not None:
+            d.res_h[l], d.res_w[l] = res_sizes[l]
+            d.res_row0[l] = res_row0[l]
+        d.level_scale[l] = 1.0 if level_scale is None else float(level_scale[l])
+    d.cin, d.cout, d.cout_pad = cin, cout, cout_pad
+    d.kh = d.kw = k
+    d.stride, d.pad, d.dil = stride, pad, dil
+    d.in_cstride, d.out_cstride, d.out_coff = in_cstride, out_cstride, out_coff
+    d.res_cstride = res_cstride
+    d.flags = flags
+    d.scale_nch = scale_nch
+    d.deform_groups = deform_groups
+    return d
+
+
+def conv2d(desc, x, w, bias, residual, y):
+    _lib.require_cuda(x, w, y)
+    lib = _lib.load()
+    _lib.check(lib.sm_conv2d(C.byref(desc), _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(residual),
+                             _lib.ptr(y), _lib.stream_ptr()), "sm_conv2d")
+    return y
+
+
+def deform_conv2d(desc, x, offset, w, bias, y):
+    _lib.require_cuda(x, offset, w, y)
+    lib = _lib.load()
+    _lib.check(lib.sm_deform_conv2d(C.byref(desc), _lib.ptr(x), _lib.ptr(offset), _lib.ptr(w), _lib.ptr(bias),
+                                    _lib.ptr(y), _lib.stream_ptr()), "sm_deform_conv2d")
+    return y
+
+
+def offset_linear(reg, reg_cstride, w_off, lv, out, level_scale=None):
+    lib = _lib.load()
+    nlev = len(lv)
+    row0 = (C.c_int64 * nlev)(*lv.row0)
+    rows = (C.c_int32 * nlev)(*[lv.batch * h * w for h, w in lv.sizes])
+    ls = None if level_scale is None else (C.c_float * nlev)(*[float(v) for v in level_scale])
+    _lib.check(lib.sm_offset_linear(_lib.ptr(reg), reg_cstride, _lib.ptr(w_off), w_off.shape[0], row0, rows, ls,
+                                    nlev, _lib.ptr(out), _lib.stream_ptr()), "sm_offset_linear")
+    return out
+
+
+def groupnorm(x, y, gamma, beta, stats, lv, channels, groups=32, eps=1e-5, relu=True):
+    lib = _lib.load()
+    nlev = len(lv)
+    hw = (C.c_int32 * nlev)(*[h * w for h, w in lv.sizes])
+    row0 = (C.c_int64 * nlev)(*lv.row0)
+    _lib.check(lib.sm_groupnorm(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
+                                lv.batch, nlev, hw, row0, channels, groups, eps, int(relu), _lib.stream_ptr()),
+               "sm_groupnorm")
+    return y
+
+
+def maxpool3x3s2(x, y, batch, h, w, c):
+    lib = _lib.load()
+    _lib.check(lib.sm_maxpool3x3s2(_lib.ptr(x), _lib.ptr(y), batch, h, w, c, _lib.stream_ptr()), "sm_maxpool3x3s2")
+    return y
+
+
+def nchw_to_nhwc_bf16(x, y, cpad):
+    lib = _lib.load()
+    _lib.require_cuda(x, y)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("expected a contiguous float32 NCHW tensor")
+    b, c, h, w = x.shape
+    _lib.check(lib.sm_nchw_f32_to_nhwc_bf16(_lib.ptr(x), _lib.ptr(y), b, c, h, w, cpad, _lib.stream_ptr()),
+               "sm_nchw_f32_to_nhwc_bf16")
+    return y
+
+
+def upsample_bilinear(x, y, batch, h, w, c, factor, in_cstride, out_cstride, out_coff, is_f32):
+    lib = _lib.load()
+    _lib.check(lib.sm_upsample_bilinear(_lib.ptr(x), _lib.ptr(y), batch, h, w, c, factor, in_cstride, out_cstride,
+                                        out_coff, int(is_f32), _lib.stream_ptr()), "sm_upsample_bilinear")
+    return y
+
+
+def make_det_desc(batch, sizes, strides, row0, num_classes, cls_cstride, cls_coff, cof_cstride, cof_coff,
+                  reg_cstride, nms_pre, img_h, img_w, scale_factor=1.0, rescale=False, reg_prescaled=False):
+    d = DetDesc()
+    d.batch, d.nlev, d.num_classes = batch, len(sizes), num_classes
+    kmax = 0
+    for l, (h, w) in enumerate(sizes):
+        d.h[l], d.w[l], d.stride[l], d.row0[l] = h, w, strides[l], row0[l]
+        kmax += min(nms_pre, h * w) if nms_pre > 0 else h * w
+    d.cls_cstride, d.cls_coff, d.cof_cstride, d.cof_coff = cls_cstride, cls_coff, cof_cstride, cof_coff
+    d.reg_cstride, d.nms_pre, d.img_h, d.img_w, d.kmax = reg_cstride, nms_pre, img_h, img_w, kmax
+    d.scale_factor, d.rescale = float(scale_factor), int(bool(rescale))
+    d.reg_prescaled = int(bool(reg_prescaled))
+    return d
+
+
+def det_select(desc, cls, reg, cof, out):
+    """out: dict with preallocated boxes/scores/ctr/cofs/cand_pos/ncand/ws tensors."""
+    lib = _lib.load()
+    _lib.check(lib.sm_det_select(C.byref(desc), _lib.ptr(cls), _lib.ptr(reg), _lib.ptr(cof), _lib.ptr(out["boxes"]),
+                                 _lib.ptr(out["scores"]), _lib.ptr(out["ctr"]), _lib.ptr(out["cofs"]),
+                                 _lib.ptr(out["cand_pos"]), _lib.ptr(out["ncand"]), _lib.ptr(out["ws_sel"]),
+                                 _lib.stream_ptr()), "sm_det_select")
+
+
+def det_select_alloc(desc, device):
+    lib = _lib.load()
+    b, k, c = desc.batch, desc.kmax, desc.num_classes
+    ws = lib.sm_det_select_workspace(C.byref(desc))
+    if ws < 0:
+        raise RuntimeError("sm_det_select_workspace: bad descriptor")
+    f32, i32 = torch.float32, torch.int32
+    return dict(boxes=torch.empty(b, k, 4, dtype=f32, device=device), scores=torch.empty(b, k, c, dtype=f32, device=device),
+                ctr=torch.empty(b, k, dtype=f32, device=device), cofs=torch.empty(b, k, 128, dtype=f32, device=device),
+                cand_pos=torch.empty(b, k, dtype=i32, device=device), ncand=torch.empty(b, dtype=i32, device=device),
+                ws_sel=torch.empty(max(int(ws), 16), dtype=torch.uint8, device=device))
+
+
+def multiclass_nms_alloc(batch, kmax, num_classes, max_num, device):
+    lib = _lib.load()
+    ws = lib.sm_multiclass_nms_workspace(batch, kmax, num_classes)
+    return dict(det=torch.zeros(batch, max_num, 5, dtype=torch.float32, device=device),
+                labels=torch.zeros(batch, max_num, dtype=torch.int64, device=device),
+                keep=torch.zeros(batch, max_num, dtype=torch.int64, device=device),
+                ndet=torch.zeros(batch, dtype=torch.int32, device=device),
+                ws_nms=torch.empty(int(ws), dtype=torch.uint8, device=device))
+
+
+def multiclass_nms(boxes, scores, ctr, ncand, score_thr, iou_thr, max_num, out):
+    lib = _lib.load()
+    b, k, c = scores.shape
+    _lib.check(lib.sm_multiclass_nms(_lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(ctr), _lib.ptr(ncand), b, k, c,
+                                     float(score_thr), float(iou_thr), int(max_num), _lib.ptr(out["det"]),
+                                     _lib.ptr(out["labels"]), _lib.ptr(out["keep"]), _lib.ptr(out["ndet"]),
+                                     _lib.ptr(out["ws_nms"]), _lib.stream_ptr()), "sm_multiclass_nms")
+
+
+def mask_assemble(basis, basis_hwc, cofs, keep, det, ndet, hm, wm, ho, wo, box_mul, box_div, up_scale, thr,
+                  masks, pos_masks=None):
+    lib = _lib.load()
+    b, kmax = cofs.shape[0], cofs.shape[1]
+    max_num = det.shape[1]
+    _lib.check(lib.sm_mask_assemble(_lib.ptr(basis), int(basis_hwc), _lib.ptr(cofs), _lib.ptr(keep), _lib.ptr(det),
+                                    _lib.ptr(ndet), b, kmax, max_num, hm, wm, ho, wo, float(box_mul), float(box_div),
+                                    float(up_scale), float(thr), _lib.ptr(masks), _lib.ptr(pos_masks),
+                                    _lib.stream_ptr()), "sm_mask_assemble")
+    return masks

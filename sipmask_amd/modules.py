@@ -1,0 +1,207 @@
+"""Parameter containers with the reference's names, constructor kwargs and init rules.
+
+These nn.Modules own the float32 parameters under exactly the reference ``state_dict`` keys
+ so published checkpoints load; they contain NO arithmetic.  All compute runs
+in the HIP engine (sipmask_amd/engine.py), which re-lays the weights out at ``prepare()`` time.
+
+  ConvModule   M/mmdet/ops/conv_module.py:34-132  (norm attr name 'gn'/'bn': M/mmdet/ops/norm.py:7,40)
+  ResNet       M/mmdet/models/backbones/resnet.py:311-521 (Bottleneck :84-239)
+  FPN          M/mmdet/models/necks/fpn.py:10-178
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .registry import BACKBONES, NECKS
+
+
+def kaiming_init(m, nonlinearity="relu"):
+    nn.init.kaiming_normal_(m.weight, a=0, mode="fan_out", nonlinearity=nonlinearity)
+    if getattr(m, "bias", None) is not None:
+        nn.init.constant_(m.bias, 0)
+
+
+def normal_init(m, mean=0, std=1, bias=0):
+    nn.init.normal_(m.weight, mean, std)
+    if getattr(m, "bias", None) is not None:
+        nn.init.constant_(m.bias, bias)
+
+
+def xavier_init(m, gain=1, bias=0):
+    nn.init.xavier_uniform_(m.weight, gain=gain)
+    if getattr(m, "bias", None) is not None:
+        nn.init.constant_(m.bias, bias)
+
+
+def bias_init_with_prob(prior_prob):
+    """M/mmdet/models/utils/weight_init.py:4-7"""
+    return float(-math.log((1 - prior_prob) / prior_prob))
+
+
+def _norm_layer(cfg, channels):
+    """(attr_name, module) like build_norm_layer: 'bn' / 'gn' prefixes, requires_grad handling."""
+    cfg = dict(cfg)
+    kind = cfg.pop("type")
+    requires_grad = cfg.pop("requires_grad", True)
+    if kind == "BN":
+        name, layer = "bn", nn.BatchNorm2d(channels, eps=cfg.get("eps", 1e-5))
+    elif kind == "GN":
+        name, layer = "gn", nn.GroupNorm(cfg["num_groups"], channels, eps=cfg.get("eps", 1e-5))
+    else:
+        raise KeyError("Unrecognized norm type {}".format(kind))
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return name, layer
+
+
+class ConvModule(nn.Module):
+    """conv -> norm -> act parameter holder; bias only when there is no norm (conv_module.py:63-65)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias="auto",
+                 conv_cfg=None, norm_cfg=None, act_cfg=dict(type="ReLU"), inplace=True,
+                 order=("conv", "norm", "act")):
+        super().__init__()
+        assert conv_cfg is None, "only plain Conv2d is on the SipMask path"
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == "auto":
+            bias = not self.with_norm
+        self.with_bias = bias
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias=bias)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = self.conv.kernel_size, self.conv.stride, self.conv.padding
+        self.norm_name = None
+        if self.with_norm:
+            self.norm_name, norm = _norm_layer(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        kaiming_init(self.conv)
+        if self.with_norm:
+            nn.init.constant_(self.norm.weight, 1)
+            nn.init.constant_(self.norm.bias, 0)
+
+    @property
+    def norm(self):
+        return getattr(self, self.norm_name)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, style="pytorch", norm_cfg=dict(type="BN")):
+        super().__init__()
+        assert style in ("pytorch", "caffe")
+        self.conv1_stride, self.conv2_stride = (1, stride) if style == "pytorch" else (stride, 1)
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=self.conv1_stride, bias=False)
+        self.add_module("bn1", _norm_layer(norm_cfg, planes)[1])
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=self.conv2_stride, padding=1, bias=False)
+        self.add_module("bn2", _norm_layer(norm_cfg, planes)[1])
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.add_module("bn3", _norm_layer(norm_cfg, planes * 4)[1])
+        self.downsample = downsample
+
+
+@BACKBONES.register_module
+class ResNet(nn.Module):
+    arch_settings = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth, in_channels=3, num_stages=4, strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1),
+                 out_indices=(0, 1, 2, 3), style="pytorch", frozen_stages=-1, conv_cfg=None,
+                 norm_cfg=dict(type="BN", requires_grad=True), norm_eval=True, dcn=None,
+                 stage_with_dcn=(False, False, False, False), with_cp=False, zero_init_residual=True):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError("invalid depth {} for resnet".format(depth))
+        if dcn is not None or conv_cfg is not None:
+            raise NotImplementedError("backbone DCN (SipMask++) is a 'next' row (SURVEY 8f-3)")
+        if style != "caffe" or tuple(strides) != (1, 2, 2, 2) or tuple(dilations) != (1, 1, 1, 1):
+            raise NotImplementedError("the engine implements the caffe-style stride layout of the sipmask configs")
+        self.depth, self.num_stages, self.out_indices = depth, num_stages, out_indices
+        self.style, self.frozen_stages, self.norm_eval = style, frozen_stages, norm_eval
+        self.zero_init_residual = zero_init_residual
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, stride=2, padding=3, bias=False)
+        self.add_module("bn1", _norm_layer(norm_cfg, 64)[1])
+        inplanes = 64
+        self.res_layers = []
+        for i, nblocks in enumerate(self.arch_settings[depth][:num_stages]):
+            planes = 64 * 2 ** i
+            blocks = []
+            for j in range(nblocks):
+                stride = strides[i] if j == 0 else 1
+                ds = None
+                if j == 0 and (stride != 1 or inplanes != planes * 4):
+                    ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                       _norm_layer(norm_cfg, planes * 4)[1])
+                blocks.append(Bottleneck(inplanes, planes, stride, ds, style, norm_cfg))
+                inplanes = planes * 4
+            name = "layer{}".format(i + 1)
+            self.add_module(name, nn.Sequential(*blocks))
+            self.res_layers.append(name)
+        self._freeze_stages()
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, "layer{}".format(i))
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def init_weights(self, pretrained=None):
+        if isinstance(pretrained, str):
+            sd = torch.load(pretrained, map_location="cpu")
+            self.load_state_dict(sd.get("state_dict", sd), strict=False)
+        elif pretrained is None:
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    kaiming_init(m)
+                elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                    nn.init.constant_(m.weight, 1)
+                    nn.init.constant_(m.bias, 0)
+            if self.zero_init_residual:
+                for m in self.modules():
+                    if isinstance(m, Bottleneck):
+                        nn.init.constant_(m.bn3.weight, 0)
+        else:
+            raise TypeError("pretrained must be a str or None")
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+
+
+@NECKS.register_module
+class FPN(nn.Module):
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 extra_convs_on_inputs=True, relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None,
+                 norm_cfg=None, act_cfg=None):
+        super().__init__()
+        assert isinstance(in_channels, list)
+        if norm_cfg is not None or conv_cfg is not None or end_level != -1:
+            raise NotImplementedError("FPN variants outside the sipmask configs")
+        if not (add_extra_convs and not extra_convs_on_inputs and relu_before_extra_convs):
+            raise NotImplementedError("the engine implements extra convs on outputs with ReLU (sipmask cfg :13-21)")
+        self.in_channels, self.out_channels, self.num_outs = in_channels, out_channels, num_outs
+        self.num_ins, self.start_level = len(in_channels), start_level
+        self.backbone_end_level = self.num_ins
+        self.lateral_convs, self.fpn_convs = nn.ModuleList(), nn.ModuleList()
+        for i in range(start_level, self.backbone_end_level):
+            self.lateral_convs.append(ConvModule(in_channels[i], out_channels, 1, act_cfg=act_cfg, inplace=False))
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1, act_cfg=act_cfg, inplace=False))
+        for i in range(num_outs - self.backbone_end_level + start_level):
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, stride=2, padding=1, act_cfg=act_cfg,
+                                             inplace=False))
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                xavier_init(m)

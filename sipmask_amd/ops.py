@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's ``mmdet.ops`` / ``mmdet.core.post_processing`` entry points
+for the SipMask hot path -- same names, argument meaning and error behaviour, HIP underneath.
+
+  DeformConv / deform_conv      M/mmdet/ops/dcn/deform_conv.py:16-96,189-255
+  CropSplit / crop_split        M/mmdet/ops/crop/crop_split.py:9-50
+  CropSplitGt / crop_split_gt   M/mmdet/ops/crop/crop_split_gt.py:9-38
+  nms                           M/mmdet/ops/nms/nms_wrapper.py:7-60
+  sigmoid_focal_loss            M/mmdet/ops/sigmoid_focal_loss/sigmoid_focal_loss.py:10-43
+  multiclass_nms_idx            M/mmdet/core/post_processing/bbox_nms.py:79-146
+  Scale                         M/mmdet/ops/scale.py:5-15
+
+There is no CPU implementation (as in the reference): CPU tensors raise
+NotImplementedError, a missing libsipmask_hip.so raises RuntimeError.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair, _single
+
+from . import _lib
+from . import hip_ops as H
+
+
+# ------------------------------------------------------------------------------- deform conv
+class DeformConvFunction(Function):
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                im2col_step=64):
+        if input is not None and input.dim() != 4:
+            raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(input.dim()))
+        if not input.is_cuda:
+            raise NotImplementedError
+        stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+        if groups != 1:
+            raise NotImplementedError("sipmask_amd DeformConv: groups != 1 is not on the SipMask path")
+        if stride != (1, 1) or stride[0] != stride[1] or padding[0] != padding[1] or dilation[0] != dilation[1]:
+            raise NotImplementedError("sipmask_amd DeformConv: only stride 1 and square pad/dilation")
+        b, c, h, w = input.shape
+        co, ci, kh, kw = weight.shape
+        if kh != kw:
+            raise NotImplementedError("square kernels only")
+        g = deformable_groups
+        ho = (h + 2 * padding[0] - (dilation[0] * (kh - 1) + 1)) // stride[0] + 1
+        wo = (w + 2 * padding[1] - (dilation[1] * (kw - 1) + 1)) // stride[1] + 1
+        if min(ho, wo) <= 0:
+            raise ValueError("convolution input is too small (output would be {}x{})".format(ho, wo))
+        if offset.shape != (b, g * 2 * kh * kw, ho, wo):
+            raise ValueError("invalid offset shape {} (expected {})".format(tuple(offset.shape),
+                                                                           (b, g * 2 * kh * kw, ho, wo)))
+        if c % 8 != 0 or c % (8 * g) != 0:
+            raise NotImplementedError("channels must be a multiple of 8*deformable_groups")
+        cur_im2col_step = min(im2col_step, b)
+        assert (b % cur_im2col_step) == 0, "im2col step must divide batchsize"
+        x = torch.empty(b * h * w, c, dtype=torch.bfloat16, device=input.device)
+        H.nchw_to_nhwc_bf16(input.detach().float().contiguous(), x, c)
+        off = offset.detach().float().permute(0, 2, 3, 1).contiguous().view(b * ho * wo, -1)
+        wq, co_pad = H.prep_conv_weight(weight.detach())
+        y = torch.empty(b * ho * wo, co, dtype=torch.float32, device=input.device)
+        d = H.make_conv_desc(b, [(h, w)], [(ho, wo)], [0], [0], c, co, co_pad, kh, 1, padding[0], c, co,
+                             flags=_lib.SM_CONV_OUT_F32, dil=dilation[0], deform_groups=g)
+        H.deform_conv2d(d, x, off, wq, None, y)
+        return y.view(b, ho, wo, co).permute(0, 3, 1, 2).to(input.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        raise NotImplementedError("sipmask_amd: deformable-conv backward (col2im / coord / weight grads, "
+                                  "deform_conv_cuda_kernel.cu:280-436) is scheduled for the training round")
+
+
+deform_conv = DeformConvFunction.apply
+
+
+class DeformConv(nn.Module):
+    """Same constructor / parameters / forward contract as M/mmdet/ops/dcn/deform_conv.py:189-255."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super(DeformConv, self).__init__()
+        assert not bias
+        assert in_channels % groups == 0, \
+            'in_channels {} cannot be divisible by groups {}'.format(in_channels, groups)
+        assert out_channels % groups == 0, \
+            'out_channels {} cannot be divisible by groups {}'.format(out_channels, groups)
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = _pair(stride)
+        self.padding = _pair(padding)
+        self.dilation = _pair(dilation)
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+        self.transposed = False
+        self.output_padding = _single(0)
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        # input smaller than the kernel: pad, run, crop (deform_conv.py:239-255)
+        input_pad = (x.size(2) < self.kernel_size[0] or x.size(3) < self.kernel_size[1])
+        if input_pad:
+            pad_h = max(self.kernel_size[0] - x.size(2), 0)
+            pad_w = max(self.kernel_size[1] - x.size(3), 0)
+            x = torch.nn.functional.pad(x, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+            offset = torch.nn.functional.pad(offset, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+        out = deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                          self.deformable_groups)
+        if input_pad:
+            out = out[:, :, :out.size(2) - pad_h, :out.size(3) - pad_w].contiguous()
+        return out
+
+
+# ------------------------------------------------------------------------------- crop split
+class CropSplitFunction(Function):
+
+    @staticmethod
+    def forward(ctx, data, rois, c):
+        _lib.require_cuda(data, rois)
+        if not data.is_contiguous():
+            raise RuntimeError("data must be contiguous")   # crop_split_cuda.cpp:17
+        if data.dtype != torch.float32:
+            raise NotImplementedError("sipmask_amd crop_split: float32 only")
+        height, width, n = data.shape[1], data.shape[2], data.shape[3]
+        ctx.c, ctx.height, ctx.width, ctx.n = c, height, width, n
+        ctx.save_for_backward(rois)
+        output = torch.empty(height, width, n, dtype=data.dtype, device=data.device)
+        lib = _lib.load()
+        _lib.check(lib.sm_crop_split_fwd(_lib.ptr(data), _lib.ptr(rois.float().contiguous()), _lib.ptr(output),
+                                         height, width, c, n, _lib.stream_ptr()), "sm_crop_split_fwd")
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        c, h, w, n = ctx.c, ctx.height, ctx.width, ctx.n
+        grad_input = torch.empty((c * c, h, w, n), dtype=grad_output.dtype, device=grad_output.device)
+        lib = _lib.load()
+        _lib.check(lib.sm_crop_split_bwd(_lib.ptr(grad_output.contiguous()), _lib.ptr(rois.float().contiguous()),
+                                         _lib.ptr(grad_input), h, w, c, n, _lib.stream_ptr()), "sm_crop_split_bwd")
+        return grad_input, None, None
+
+
+crop_split = CropSplitFunction.apply
+
+
+class CropSplit(nn.Module):
+
+    def __init__(self, c=2):
+        super(CropSplit, self).__init__()
+        self.c = c
+
+    def forward(self, data, rois):
+        return crop_split(data, rois, self.c)
+
+
+class CropSplitGtFunction(Function):
+    # no backward, as in the reference (crop_split_gt.py:11-27)
+
+    @staticmethod
+    def forward(ctx, data, rois, c):
+        _lib.require_cuda(data, rois)
+        if not data.is_contiguous():
+            raise RuntimeError("data must be contiguous")
+        height, width, n = data.shape
+        output = torch.empty(height, width, n, dtype=data.dtype, device=data.device)
+        lib = _lib.load()
+        _lib.check(lib.sm_crop_split_gt_fwd(_lib.ptr(data), _lib.ptr(rois.float().contiguous()), _lib.ptr(output),
+                                            height, width, n, _lib.stream_ptr()), "sm_crop_split_gt_fwd")
+        return output
+
+
+crop_split_gt = CropSplitGtFunction.apply
+
+
+class CropSplitGt(nn.Module):
+
+    def __init__(self, c=2):
+        super(CropSplitGt, self).__init__()
+        self.c = c
+
+    def forward(self, data, rois):
+        return crop_split_gt(data, rois, self.c)
+
+
+# ------------------------------------------------------------------------------- focal loss
+class SigmoidFocalLossFunction(Function):
+
+    @staticmethod
+    def forward(ctx, input, target, gamma=2.0, alpha=0.25):
+        _lib.require_cuda(input, target)
+        ctx.save_for_backward(input, target)
+        num_classes = input.shape[1]
+        ctx.num_classes, ctx.gamma, ctx.alpha = num_classes, gamma, alpha
+        x = input.float().contiguous()
+        loss = torch.empty_like(x)
+        lib = _lib.load()
+        _lib.check(lib.sm_sigmoid_focal_loss_fwd(_lib.ptr(x), _lib.ptr(target.long().contiguous()), _lib.ptr(loss),
+                                                 x.shape[0], num_classes, gamma, alpha, _lib.stream_ptr()),
+                   "sm_sigmoid_focal_loss_fwd")
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_loss):
+        input, target = ctx.saved_tensors
+        x = input.float().contiguous()
+        d_input = torch.empty_like(x)
+        lib = _lib.load()
+        _lib.check(lib.sm_sigmoid_focal_loss_bwd(_lib.ptr(x), _lib.ptr(target.long().contiguous()),
+                                                 _lib.ptr(d_loss.float().contiguous()), _lib.ptr(d_input),
+                                                 x.shape[0], ctx.num_classes, ctx.gamma, ctx.alpha,
+                                                 _lib.stream_ptr()), "sm_sigmoid_focal_loss_bwd")
+        return d_input, None, None, None
+
+
+sigmoid_focal_loss = SigmoidFocalLossFunction.apply
+
+
+# ------------------------------------------------------------------------------- NMS
+def nms(dets, iou_thr, device_id=None):
+    """Same contract as nms_wrapper.nms for GPU tensors: returns (dets[inds], inds), inds ascending.
+    Suppression rule IoU(+1) > iou_thr (the reference GPU kernel, nms_kernel.cu:61)."""
+    if not isinstance(dets, torch.Tensor):
+        raise TypeError('dets must be a Tensor, but got {}'.format(type(dets)))
+    if dets.shape[0] == 0:
+        return dets, dets.new_zeros(0, dtype=torch.long)
+    _lib.require_cuda(dets)
+    d = dets.float().contiguous()
+    n = d.shape[0]
+    keep = torch.empty(n, dtype=torch.int64, device=d.device)
+    nkeep = torch.zeros(1, dtype=torch.int32, device=d.device)
+    lib = _lib.load()
+    _lib.check(lib.sm_nms(_lib.ptr(d), n, float(iou_thr), _lib.ptr(keep), _lib.ptr(nkeep), None, _lib.stream_ptr()),
+               "sm_nms")
+    inds = keep[:int(nkeep.item())]
+    return dets[inds, :], inds
+
+
+def multiclass_nms_idx(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, score_factors=None):
+    """bbox_nms.py:79-146 on device for one image.  multi_scores [K, C+1] with a background column 0.
+    Returns (bboxes [N,5], labels [N] long, idxs [N] long)."""
+    _lib.require_cuda(multi_bboxes, multi_scores)
+    if multi_bboxes.shape[1] != 4:
+        raise NotImplementedError("class-specific boxes are not on the SipMask path")
+    cfg = dict(nms_cfg)
+    nms_type = cfg.pop('type', 'nms')
+    if nms_type != 'nms':
+        raise NotImplementedError("only greedy 'nms' (soft_nms is out of scope)")
+    iou_thr = cfg.get('iou_thr', 0.5)
+    k = multi_scores.shape[0]
+    c = multi_scores.shape[1] - 1
+    dev = multi_bboxes.device
+    if k == 0:
+        return (multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0,), dtype=torch.long),
+                multi_bboxes.new_zeros((0,), dtype=torch.long))
+    scores = multi_scores[:, 1:].float().contiguous().view(1, k, c)
+    boxes = multi_bboxes.float().contiguous().view(1, k, 4)
+    ctr = (torch.ones(1, k, device=dev) if score_factors is None else score_factors.float().contiguous().view(1, k))
+    ncand = torch.full((1,), k, dtype=torch.int32, device=dev)
+    cap = max_num if max_num > 0 else min(k * c, 2048)
+    out = H.multiclass_nms_alloc(1, k, c, cap, dev)
+    H.multiclass_nms(boxes, scores, ctr, ncand, score_thr, iou_thr, cap, out)
+    n = int(out["ndet"][0].item())
+    return out["det"][0, :n], out["labels"][0, :n], out["keep"][0, :n]
+
+
+class Scale(nn.Module):
+    """M/mmdet/ops/scale.py:5-15"""
+
+    def __init__(self, scale=1.0):
+        super(Scale, self).__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, x):
+        return x * self.scale

@@ -1,0 +1,95 @@
+"""End-to-end GPU parity: the bf16 HIP engine against the fp32 CPU oracle on the same seeded
+weights and image, stage by stage.  bf16 storage of ~60 stacked conv layers cannot meet 1e-3 on
+logits end to end (SURVEY section 7 "hard parts"); the stated bound here is a relative Frobenius
+error per stage, and the tight (bit-exact / 1e-5) parity lives in test_gpu_kernels.py where
+both sides see identical inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model as OM  # noqa: E402
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd.engine import SipMaskEngine
+    torch.manual_seed(0)
+    B, Hh, Ww = 2, 192, 256
+    sd = OM.init_state_dict(50, 0)
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(B, 3, Hh, Ww, generator=g)
+    feats = OM.backbone_forward(sd, img)
+    pyr = OM.fpn_forward(sd, feats)
+    # calibrate fcos_cls.bias so that a few hundred scores pass score_thr
+    out = OM.head_forward(sd, pyr)
+    allc = torch.cat([c[0].reshape(-1) for c in out[0]]) - sd["bbox_head.fcos_cls.bias"][0]
+    OM.calibrate_cls_bias(sd, allc, target=400)
+    out = OM.head_forward(sd, pyr, return_aux=True)
+    eng = SipMaskEngine(sd, B, (Hh, Ww), 50)
+    res = eng.run(img.cuda())
+    torch.cuda.synchronize()
+    return dict(sd=sd, img=img, feats=feats, pyr=pyr, out=out, eng=eng, res=res, B=B, hw=(Hh, Ww))
+
+
+def test_backbone_fpn_features(setup):
+    eng, B = setup["eng"], setup["B"]
+    for i, (buf, h, w, c) in enumerate(eng.backbone_feats):
+        got = buf.float().view(B, h, w, c).permute(0, 3, 1, 2)
+        r = _rel(got, setup["feats"][i])
+        assert r < 0.02, ("C%d" % (i + 2), r)
+    lv = eng.lv
+    for l, (h, w) in enumerate(lv.sizes):
+        got = eng.pyr[lv.row0[l]:lv.row0[l] + B * h * w].float().view(B, h, w, 256).permute(0, 3, 1, 2)
+        r = _rel(got, setup["pyr"][l])
+        assert r < 0.03, ("P%d" % (l + 3), r)
+
+
+def test_head_outputs(setup):
+    eng = setup["eng"]
+    cls, bb, ctr, cof, fm = eng.head_outputs()
+    ocls, obb, octr, ocof, ofm, aux = setup["out"]
+    for l in range(5):
+        assert cls[l].shape == ocls[l].shape and bb[l].shape == obb[l].shape
+        assert ctr[l].shape == octr[l].shape and cof[l].shape == ocof[l].shape
+        assert _rel(bb[l], obb[l]) < 0.05, ("bbox", l, _rel(bb[l], obb[l]))
+        assert _rel(cof[l], ocof[l]) < 0.15, ("cof", l, _rel(cof[l], ocof[l]))
+        # cls logits have a large constant bias; compare after removing it
+        b0 = float(setup["sd"]["bbox_head.fcos_cls.bias"][0])
+        assert _rel(cls[l] - b0, ocls[l] - b0) < 0.15, ("cls", l, _rel(cls[l] - b0, ocls[l] - b0))
+    assert fm.shape == ofm.shape
+    assert _rel(fm, ofm) < 0.08, _rel(fm, ofm)
+
+
+def test_postprocess_matches_oracle_on_engine_head_outputs(setup):
+    """Feed the ENGINE's own head outputs to the oracle post-processing: from there on both sides see
+    identical f32 inputs, so keep indices / labels must be bit-exact and masks identical away from
+    the 0.4 threshold."""
+    eng, res, B = setup["eng"], setup["res"], setup["B"]
+    cls, bb, ctr, cof, fm = [[t.cpu().float() for t in x] if isinstance(x, list) else x.cpu().float()
+                             for x in eng.head_outputs()]
+    Hh, Ww = setup["hw"]
+    total = 0
+    for b in range(B):
+        r = OM.get_masks_single([c[b] for c in cls], [x[b] for x in bb], [c[b] for c in ctr], [c[b] for c in cof],
+                                fm[b], (Hh, Ww, 3), OM.DEFAULT_TEST_CFG)
+        n = int(res["ndet"][b])
+        total += n
+        assert n == r["det_bboxes"].shape[0]
+        np.testing.assert_array_equal(res["idxs_keep"][b, :n].cpu().numpy(), r["idxs_keep"])
+        np.testing.assert_array_equal(res["det_labels"][b, :n].cpu().numpy(), r["det_labels"])
+        np.testing.assert_allclose(res["det_bboxes"][b, :n].cpu().numpy(), r["det_bboxes"], rtol=1e-6, atol=1e-6)
+        if n:
+            gm = res["masks"][b, :n].cpu()
+            diff = gm != r["masks"]
+            assert bool(((r["up"] - 0.4).abs()[diff] < 1e-4).all())
+            assert int(diff.sum()) <= max(5, int(1e-5 * diff.numel()))
+    assert total > 0, "calibration failed: no detections, NMS/mask path not exercised"

@@ -1,0 +1,390 @@
+"""GPU parity tests: every HIP kernel (through the C ABI) against the CPU oracle / a plain
+torch-fp32 reference on identical seeded inputs.  Tolerances are stated per test:
+  * integer / index outputs (NMS keep, top-k, labels, crop cells, masks away from the threshold): bit-exact
+  * bf16-input MFMA convs: inputs are pre-rounded to bf16 so the only error is f32 accumulation order
+    (|err| <= 2e-3 * scale) plus one bf16 rounding of the output where the output is bf16 (rel 2^-8)
+  * f32 elementwise kernels: 1e-5 relative (expf/logf ulp differences)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ops as O  # noqa: E402
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _run_conv(x, w, bias, stride, pad, relu=False, out_f32=False, residual=None, in_relu=False):
+    """x [B,C,H,W] f32 (bf16-representable), w [Co,Ci,k,k]; returns NCHW f32 on cpu."""
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    B, C, Hh, Ww = x.shape
+    Co, _, k, _ = w.shape
+    cpad = (C + 7) // 8 * 8
+    xh = torch.empty(B * Hh * Ww, cpad, dtype=torch.bfloat16, device=dev)
+    H.nchw_to_nhwc_bf16(x.to(dev).contiguous(), xh, cpad)
+    wq, co_pad = H.prep_conv_weight(w.to(dev), cpad)
+    Ho, Wo = (Hh + 2 * pad - k) // stride + 1, (Ww + 2 * pad - k) // stride + 1
+    flags = (_lib.SM_CONV_RELU if relu else 0) | (_lib.SM_CONV_OUT_F32 if out_f32 else 0)
+    flags |= _lib.SM_CONV_IN_RELU if in_relu else 0
+    res = None
+    if residual is not None:
+        flags |= _lib.SM_CONV_RES_ADD
+        res = residual.permute(0, 2, 3, 1).reshape(-1, Co).to(torch.bfloat16).to(dev).contiguous()
+    y = torch.empty(B * Ho * Wo, Co, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
+    d = H.make_conv_desc(B, [(Hh, Ww)], [(Ho, Wo)], [0], [0], cpad, Co, co_pad, k, stride, pad, cpad, Co,
+                         flags=flags, res_cstride=Co)
+    H.conv2d(d, xh, wq, None if bias is None else bias.to(dev), res, y)
+    torch.cuda.synchronize()
+    return y.float().view(B, Ho, Wo, Co).permute(0, 3, 1, 2).cpu()
+
+
+@pytest.mark.parametrize("cfg", [
+    # (B, Cin, H, W, Cout, k, stride, pad)
+    (2, 64, 17, 23, 128, 3, 1, 1),     # 128-tile, ragged M
+    (1, 256, 13, 21, 256, 3, 1, 1),    # tower shape
+    (2, 128, 20, 28, 64, 1, 1, 0),     # 64-tile, 1x1
+    (2, 64, 21, 19, 5, 3, 1, 1),       # 32-tile, cout tail (reg+ctr)
+    (2, 3, 37, 45, 64, 7, 2, 3),       # stem: cin padded 3->8, K padded to 448
+    (1, 512, 16, 12, 1024, 1, 2, 0),   # strided 1x1 (downsample)
+    (2, 256, 9, 11, 208, 3, 1, 1),     # cls+cof fused width
+    (1, 768, 10, 14, 512, 1, 1, 0),    # cin/8 not a power of two
+    (1, 256, 25, 42, 256, 3, 2, 1),    # P6: stride-2 3x3
+])
+def test_conv_igemm_vs_torch(cfg):
+    B, Ci, Hh, Ww, Co, k, s, p = cfg
+    g = torch.Generator().manual_seed(hash(cfg) % 1000)
+    x = _bf(torch.randn(B, Ci, Hh, Ww, generator=g))
+    w = _bf(torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(x, w, b, s, p)
+    y = _run_conv(x, w, b, s, p, out_f32=True)
+    # f32 accumulate of exactly representable products: error is summation order only
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=2e-4)
+    yb = _run_conv(x, w, b, s, p, relu=True)
+    torch.testing.assert_close(yb, F.relu(ref), rtol=2 ** -7, atol=2e-3)   # + one bf16 rounding
+
+
+def test_conv_residual_and_input_relu():
+    g = torch.Generator().manual_seed(3)
+    x = _bf(torch.randn(2, 64, 12, 10, generator=g))
+    w = _bf(torch.randn(256, 64, 1, 1, generator=g) / 8)
+    r = _bf(torch.randn(2, 256, 12, 10, generator=g))
+    y = _run_conv(x, w, None, 1, 0, relu=True, out_f32=True, residual=r)
+    torch.testing.assert_close(y, F.relu(F.conv2d(x, w) + r), rtol=1e-4, atol=2e-4)
+    w3 = _bf(torch.randn(64, 64, 3, 3, generator=g) / 24)
+    y = _run_conv(x, w3, None, 2, 1, out_f32=True, in_relu=True)
+    torch.testing.assert_close(y, F.conv2d(F.relu(x), w3, None, 2, 1), rtol=1e-4, atol=2e-4)
+
+
+def test_conv_multilevel_scale_and_nearest_residual():
+    """One launch over 3 levels with per-level Scale on the first 4 channels; and the FPN
+    top-down nearest-neighbour residual."""
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    B, C = 2, 64
+    sizes = [(12, 20), (6, 10), (3, 5)]
+    lv = H.Levels(B, sizes)
+    xs = [_bf(torch.randn(B, C, h, w, generator=g)) for h, w in sizes]
+    w = _bf(torch.randn(5, C, 3, 3, generator=g) / 24)
+    bias = torch.randn(5, generator=g)
+    scales = [1.5, 0.5, 2.0]
+    x = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, C) for t in xs]).to(torch.bfloat16).to(dev)
+    wq, co_pad = H.prep_conv_weight(w.to(dev))
+    y = torch.zeros(lv.rows, 8, dtype=torch.float32, device=dev)
+    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, C, 5, co_pad, 3, 1, 1, C, 8, flags=_lib.SM_CONV_OUT_F32,
+                         scale_nch=4, level_scale=scales)
+    H.conv2d(d, x, wq, bias.to(dev), None, y)
+    torch.cuda.synchronize()
+    for l, (h, wd) in enumerate(sizes):
+        ref = F.conv2d(xs[l], w, bias, 1, 1)
+        ref[:, :4] *= scales[l]
+        got = y[lv.row0[l]:lv.row0[l] + B * h * wd].view(B, h, wd, 8).permute(0, 3, 1, 2)[:, :5].cpu()
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=2e-4)
+    # nearest residual: lateral(C4) + up(lateral(C5)), fpn.py:149-152
+    coarse = _bf(torch.randn(B, 128, 7, 9, generator=g))
+    fine = _bf(torch.randn(B, C, 13, 18, generator=g))
+    wl = _bf(torch.randn(128, C, 1, 1, generator=g) / 8)
+    ref = F.conv2d(fine, wl) + F.interpolate(coarse, size=(13, 18), mode="nearest")
+    xf = fine.permute(0, 2, 3, 1).reshape(-1, C).to(torch.bfloat16).to(dev)
+    rc = coarse.permute(0, 2, 3, 1).reshape(-1, 128).to(torch.bfloat16).to(dev)
+    wq, co_pad = H.prep_conv_weight(wl.to(dev))
+    y = torch.zeros(B * 13 * 18, 128, dtype=torch.float32, device=dev)
+    d = H.make_conv_desc(B, [(13, 18)], [(13, 18)], [0], [0], C, 128, co_pad, 1, 1, 0, C, 128,
+                         flags=_lib.SM_CONV_OUT_F32 | _lib.SM_CONV_RES_NEAREST, res_cstride=128, res_sizes=[(7, 9)],
+                         res_row0=[0])
+    H.conv2d(d, xf, wq, None, rc, y)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.view(B, 13, 18, 128).permute(0, 3, 1, 2).cpu(), ref, rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 14, 19, 256), (1, 64, 9, 9, 40)])
+def test_deform_conv_vs_oracle(shape):
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    B, C, Hh, Ww, Co = shape
+    g = torch.Generator().manual_seed(11)
+    G = 4
+    x = _bf(torch.randn(B, C, Hh, Ww, generator=g))
+    w = _bf(torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    off = torch.randn(B, G * 18, Hh, Ww, generator=g) * 1.5
+    off[0, :, 0, 0] = 0.0            # exact-integer sample
+    off[0, 0::2, 1, 1] = -2.0        # h_im == -1 for the top taps -> must be excluded (> -1)
+    ref = O.deform_conv(x, off, w, 1, 1, 1, G)
+    xh = torch.empty(B * Hh * Ww, C, dtype=torch.bfloat16, device=dev)
+    H.nchw_to_nhwc_bf16(x.to(dev), xh, C)
+    offr = off.permute(0, 2, 3, 1).reshape(-1, G * 18).contiguous().to(dev)
+    wq, co_pad = H.prep_conv_weight(w.to(dev))
+    y = torch.empty(B * Hh * Ww, Co, dtype=torch.float32, device=dev)
+    d = H.make_conv_desc(B, [(Hh, Ww)], [(Hh, Ww)], [0], [0], C, Co, co_pad, 3, 1, 1, C, Co,
+                         flags=_lib.SM_CONV_OUT_F32, deform_groups=G)
+    H.deform_conv2d(d, xh, offr, wq, None, y)
+    torch.cuda.synchronize()
+    got = y.view(B, Hh, Ww, Co).permute(0, 3, 1, 2).cpu()
+    # the HIP kernel rounds each bilinear sample to bf16 before the MFMA: rel 2^-9 per sample,
+    # averaged over K=9*C products -> abs error ~ 2^-9 * |y| / sqrt(K) * few; bound generously
+    torch.testing.assert_close(got, ref, rtol=2e-2, atol=1.5e-2)
+    assert float((got - ref).abs().mean()) < 2e-3
+    # zero offsets: the gather is exact, so the result must match the plain conv tightly
+    H.deform_conv2d(d, xh, torch.zeros_like(offr), wq, None, y)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.view(B, Hh, Ww, Co).permute(0, 3, 1, 2).cpu(), F.conv2d(x, w, None, 1, 1),
+                               rtol=1e-4, atol=2e-4)
+
+
+def test_groupnorm_relu_multilevel():
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    B, C = 2, 256
+    sizes = [(20, 33), (10, 17), (5, 9), (3, 5), (2, 3)]
+    lv = H.Levels(B, sizes)
+    xs = [_bf(torch.randn(B, C, h, w, generator=g) * 3 + 0.5) for h, w in sizes]
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    x = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, C) for t in xs]).to(torch.bfloat16).to(dev)
+    stats = torch.zeros(B * 5 * 32 * 2, device=dev)
+    H.groupnorm(x, x, gamma.to(dev), beta.to(dev), stats, lv, C, 32, 1e-5, True)
+    torch.cuda.synchronize()
+    for l, (h, w) in enumerate(sizes):
+        ref = F.relu(F.group_norm(xs[l], 32, gamma, beta, 1e-5))
+        got = x[lv.row0[l]:lv.row0[l] + B * h * w].float().view(B, h, w, C).permute(0, 3, 1, 2).cpu()
+        torch.testing.assert_close(got, ref, rtol=2 ** -7, atol=1e-2)
+
+
+def test_maxpool_upsample_layout():
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    x = _bf(torch.randn(2, 64, 21, 30, generator=g))
+    xh = torch.empty(2 * 21 * 30, 64, dtype=torch.bfloat16, device=dev)
+    H.nchw_to_nhwc_bf16(x.to(dev), xh, 64)
+    torch.testing.assert_close(xh.float().view(2, 21, 30, 64).permute(0, 3, 1, 2).cpu(), x, rtol=0, atol=0)
+    y = torch.empty(2 * 11 * 15, 64, dtype=torch.bfloat16, device=dev)
+    H.maxpool3x3s2(xh, y, 2, 21, 30, 64)
+    torch.testing.assert_close(y.float().view(2, 11, 15, 64).permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 3, 2, 1),
+                               rtol=0, atol=0)
+    for f in (1, 2, 4):
+        out = torch.zeros(2 * 21 * f * 30 * f, 128, dtype=torch.bfloat16, device=dev)
+        H.upsample_bilinear(xh, out, 2, 21, 30, 64, f, 64, 128, 64, False)
+        ref = x if f == 1 else F.interpolate(x, scale_factor=f, mode="bilinear", align_corners=False)
+        got = out.float().view(2, 21 * f, 30 * f, 128).permute(0, 3, 1, 2).cpu()
+        torch.testing.assert_close(got[:, 64:], ref, rtol=2 ** -7, atol=1e-2)
+        assert float(got[:, :64].abs().max()) == 0
+    xf = torch.randn(1, 32, 9, 13, generator=g)
+    src = xf.permute(0, 2, 3, 1).reshape(-1, 32).contiguous().to(dev)
+    out = torch.empty(36 * 52, 32, device=dev)
+    H.upsample_bilinear(src, out, 1, 9, 13, 32, 4, 32, 32, 0, True)
+    torch.testing.assert_close(out.view(1, 36, 52, 32).permute(0, 3, 1, 2).cpu(),
+                               F.interpolate(xf, scale_factor=4, mode="bilinear", align_corners=False),
+                               rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------- NMS
+def _kat(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "nms_kat.json")))
+
+
+def test_nms_golden_vectors(golden_dir):
+    """The reference's own keep-index vectors (B/tests/test_nms.py) through sm_nms: bit-exact."""
+    from sipmask_amd import ops as P
+    dev = _dev()
+    kat = _kat(golden_dir)
+    c = kat["caffe2_5box"]
+    dets = torch.tensor(c["dets"], dtype=torch.float32, device=dev)
+    for thr, gt in zip(c["thresh"], c["keep"]):
+        kept, inds = P.nms(dets, thr)
+        assert inds.cpu().tolist() == gt
+        assert torch.equal(kept, dets[inds])
+    c = kat["boxes53"]
+    dets = torch.cat([torch.tensor(c["boxes"]), torch.tensor(c["scores"])[:, None]], 1).float().to(dev)
+    assert P.nms(dets, c["thresh"])[1].cpu().tolist() == c["keep"]
+    for name in ("wrapper_doctest", "mmdet_test4"):
+        c = kat[name]
+        assert len(P.nms(torch.tensor(c["dets"], dtype=torch.float32, device=dev), c["thresh"])[1]) == c["n_keep"]
+    e = torch.zeros(0, 5, device=dev)
+    assert P.nms(e, 0.5)[1].numel() == 0
+    # exact-threshold pair: GPU rule is '>' (nms_kernel.cu:61) so both survive
+    d2 = torch.tensor([[0, 0, 9, 9, 0.9], [0, 0, 9, 4, 0.8]], dtype=torch.float32, device=dev)
+    assert P.nms(d2, 0.5)[1].cpu().tolist() == [0, 1]
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 700, 3000])
+def test_nms_random_vs_oracle(n):
+    from sipmask_amd import ops as P
+    dev = _dev()
+    rng = np.random.RandomState(n)
+    xy = rng.rand(n, 2).astype(np.float32) * 300
+    wh = rng.rand(n, 2).astype(np.float32) * 80 + 2
+    sc = rng.rand(n).astype(np.float32)
+    sc[: n // 3] = np.round(sc[: n // 3], 1)          # many exact score ties
+    dets = np.concatenate([xy, xy + wh, sc[:, None]], 1).astype(np.float32)
+    ref = O.nms(dets, 0.5, "gpu")
+    got = P.nms(torch.from_numpy(dets).to(dev), 0.5)[1].cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("case", [(500, 80, 100, 0.05), (3350, 80, 100, 0.05), (300, 7, 20, 0.3), (200, 3, 100, 0.99),
+                                  (900, 80, 2000, 0.02)])
+def test_multiclass_nms_idx_vs_oracle(case):
+    from sipmask_amd import ops as P
+    dev = _dev()
+    K, C, max_num, thr = case
+    rng = np.random.RandomState(K + C)
+    xy = rng.rand(K, 2).astype(np.float32) * 600
+    wh = rng.rand(K, 2).astype(np.float32) * 120 + 4
+    boxes = np.concatenate([xy, xy + wh], 1)
+    scores = (rng.rand(K, C + 1).astype(np.float32) ** 6)
+    scores[:, 0] = 0
+    scores[: K // 4] = np.round(scores[: K // 4], 2)    # ties
+    ctr = rng.rand(K).astype(np.float32)
+    rb, rl, rk = O.multiclass_nms_idx(boxes, scores, thr, 0.5, max_num, ctr)
+    b, l, k = P.multiclass_nms_idx(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), thr,
+                                   dict(type="nms", iou_thr=0.5), max_num, torch.from_numpy(ctr).to(dev))
+    np.testing.assert_array_equal(k.cpu().numpy(), rk)       # bit-exact keep indices
+    np.testing.assert_array_equal(l.cpu().numpy(), rl)
+    np.testing.assert_array_equal(b.cpu().numpy(), rb)       # boxes copied, score = f32 product: exact
+
+
+def test_det_select_vs_oracle():
+    """score -> per-level top-k -> gather/decode (sipmask_head.py:563-591) for a 2-image batch."""
+    from sipmask_amd import hip_ops as H
+    from oracle import model as OM
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    B, C = 2, 80
+    sizes = [(40, 50), (20, 25), (10, 13), (5, 7), (3, 4)]
+    strides = (8, 16, 32, 64, 128)
+    lv = H.Levels(B, sizes)
+    cls = [torch.randn(B, C, h, w, generator=g) * 2 - 3 for h, w in sizes]
+    bbp = [torch.randn(B, 4, h, w, generator=g) * 2 + 3 for h, w in sizes]      # x Scale, before x stride
+    ctr = [torch.randn(B, 1, h, w, generator=g) for h, w in sizes]
+    cof = [torch.randn(B, 128, h, w, generator=g) for h, w in sizes]
+    rows = lambda ts: torch.cat([t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in ts])
+    cls_cof = torch.cat([rows(cls), rows(cof)], 1).contiguous().to(dev)
+    reg = torch.cat([rows(bbp), rows(ctr), torch.zeros(lv.rows, 3)], 1).contiguous().to(dev)
+    img_h, img_w = 320, 400
+    d = H.make_det_desc(B, sizes, strides, lv.row0, C, C + 128, 0, C + 128, C, 8, 1000, img_h, img_w)
+    out = H.det_select_alloc(d, dev)
+    H.det_select(d, cls_cof, reg, cls_cof, out)
+    torch.cuda.synchronize()
+    for b in range(B):
+        mb, ms, mc, mf, lvl, pos = OM.select_candidates([c[b] for c in cls], [x[b] * s for x, s in zip(bbp, strides)],
+                                                        [c[b] for c in ctr], [c[b] for c in cof], (img_h, img_w, 3), 1000,
+                                                        strides)
+        assert int(out["ncand"][b]) == mb.shape[0] == d.kmax
+        got_pos = out["cand_pos"][b].cpu()
+        mism = (got_pos != pos.int())
+        # the only legal differences are swaps between scores that differ by <= 1 ulp of expf
+        assert int(mism.sum()) <= 4, int(mism.sum())
+        ok = ~mism
+        torch.testing.assert_close(out["boxes"][b].cpu()[ok], mb[ok], rtol=0, atol=0)
+        torch.testing.assert_close(out["scores"][b].cpu()[ok], ms[ok][:, 1:], rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(out["ctr"][b].cpu()[ok], mc[ok], rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(out["cofs"][b].cpu()[ok], mf[ok], rtol=0, atol=0)
+
+
+def test_mask_assemble_vs_oracle():
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    B, Hm, Wm, kmax, max_num = 2, 52, 76, 40, 12
+    basis = torch.randn(B, 32, Hm, Wm, generator=g)
+    cofs = torch.randn(B, kmax, 128, generator=g) * 0.4
+    nd = [9, 0]
+    det = torch.zeros(B, max_num, 5)
+    xy = torch.rand(nd[0], 2, generator=g) * torch.tensor([2.0 * Wm * 0.7, 2.0 * Hm * 0.7])
+    wh = torch.rand(nd[0], 2, generator=g) * 60 + 3
+    det[0, :nd[0], :2] = xy
+    det[0, :nd[0], 2:4] = xy + wh
+    det[0, 0, :4] = torch.tensor([0.0, 0.0, 2.0 * Wm - 1, 2.0 * Hm - 1])     # full image
+    det[0, 1, :4] = torch.tensor([10.3, 7.7, 10.9, 8.2])                      # sub-pixel box
+    keep = torch.randint(0, kmax, (B, max_num), generator=g)
+    for hwc in (True, False):
+        bas = (basis.permute(0, 2, 3, 1) if hwc else basis).contiguous().to(dev)
+        masks = torch.full((B, max_num, 2 * Hm, 2 * Wm), 7, dtype=torch.uint8, device=dev)
+        posm = torch.full((B, max_num, Hm, Wm), -1.0, device=dev)
+        H.mask_assemble(bas, hwc, cofs.to(dev), keep.to(dev), det.to(dev), torch.tensor(nd, dtype=torch.int32, device=dev),
+                        Hm, Wm, 2 * Hm, 2 * Wm, 1.0, 2.0, 2.0, 0.4, masks, posm)
+        torch.cuda.synchronize()
+        r = O.mask_assemble(basis[0], cofs[0][keep[0, :nd[0]]], det[0, :nd[0]], 1.0, False)
+        got_p = posm[0, :nd[0]].cpu()
+        # mask "logits"/probabilities: stated tolerance 1e-3 (north_star); achieved ~1e-6
+        torch.testing.assert_close(got_p, r["pos_masks"], rtol=0, atol=1e-5)
+        assert bool(((got_p == 0) == (r["pos_masks"] == 0)).all())          # crop support identical
+        gm = masks[0, :nd[0]].cpu()
+        diff = gm != r["masks"]
+        assert bool(((r["up"] - 0.4).abs()[diff] < 1e-5).all())             # only threshold-adjacent pixels may flip
+        assert int(diff.sum()) <= 5
+        assert bool((masks[0, nd[0]:] == 7).all()) and bool((masks[1] == 7).all())   # rows >= ndet untouched
+
+
+def test_crop_split_and_gt_vs_oracle():
+    from sipmask_amd import ops as P
+    dev = _dev()
+    rng = np.random.RandomState(0)
+    Hh, Ww, N = 37, 45, 11
+    data = rng.rand(4, Hh, Ww, N).astype(np.float32)
+    xy = rng.rand(N, 2).astype(np.float32) * 30 - 5
+    rois = np.concatenate([xy, xy + rng.rand(N, 2).astype(np.float32) * 40 + 0.05], 1).astype(np.float32)
+    t = torch.from_numpy(data).to(dev).requires_grad_(True)
+    r = torch.from_numpy(rois).to(dev)
+    out = P.CropSplit(2)(t, r)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.crop_split(data, rois, 2))
+    go = rng.rand(Hh, Ww, N).astype(np.float32)
+    out.backward(torch.from_numpy(go).to(dev))
+    np.testing.assert_array_equal(t.grad.cpu().numpy(), O.crop_split_backward(go, rois, 2))
+    gt = P.CropSplitGt(2)(torch.from_numpy(data[0]).to(dev), r)
+    np.testing.assert_array_equal(gt.cpu().numpy(), O.crop_split_gt(data[0], rois))
+    with pytest.raises(NotImplementedError):
+        P.CropSplit(2)(torch.from_numpy(data), torch.from_numpy(rois))      # CPU tensors: no CPU path
+
+
+def test_sigmoid_focal_loss_vs_oracle():
+    from sipmask_amd import ops as P
+    dev = _dev()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(777, 80, generator=g) * 4
+    t = torch.randint(0, 81, (777,), generator=g)
+    xr = x.clone().to(dev).requires_grad_(True)
+    loss = P.sigmoid_focal_loss(xr, t.to(dev), 2.0, 0.25)
+    ref = O.sigmoid_focal_loss_forward(x.double(), t, 2.0, 0.25)
+    torch.testing.assert_close(loss.detach().cpu().double(), ref, rtol=2e-5, atol=1e-7)
+    dl = torch.rand(777, 80, generator=g)
+    loss.backward(dl.to(dev))
+    refg = O.sigmoid_focal_loss_backward(x.double(), t, dl.double(), 2.0, 0.25)
+    torch.testing.assert_close(xr.grad.cpu().double(), refg, rtol=2e-5, atol=1e-7)
