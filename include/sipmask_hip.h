@@ -44,6 +44,7 @@ typedef enum {
 #define SM_CONV_RES_NEAREST 8u   /* y += residual at nearest-neighbour source (FPN top-down,
                                     M/mmdet/models/necks/fpn.py:149-152) */
 #define SM_CONV_IN_RELU 16u      /* x = max(x,0) applied on load (fpn.py:174-175 P7) */
+#define SM_CONV_DBG_LINEAR_TILES 0x40000000u /* A/B switch: disable the XCD-aware tile remap */
 
 /* One (multi-level) 2-D convolution as an implicit GEMM.  Replaces the ATen/cuDNN
  * conv calls under M/mmdet/models/backbones/resnet.py:206-229,
@@ -140,8 +141,8 @@ typedef struct {
 /* workspace bytes for sm_det_select */
 int64_t sm_det_select_workspace(const sm_det_desc* d);
 /* per level: max_c sigmoid(cls)*sigmoid(ctr) -> top-k (value desc, index asc) -> gather +
- * distance2bbox.  Outputs per image: boxes f32 [B][kmax][4], scores f32 [B][kmax][C]
- * (sigmoid, no background column), ctr f32 [B][kmax], cofs f32 [B][kmax][128],
+ * distance2bbox.  Outputs per image: boxes f32 [B][kmax][4], scores f32 [B][C][kmax] (CLASS-MAJOR)
+ * (sigmoid, no background column; class-major so per-class NMS streams it), ctr f32 [B][kmax], cofs f32 [B][kmax][128],
  * cand_pos i32 [B][kmax] (position inside its level), ncand i32 [B]. */
 int sm_det_select(const sm_det_desc* d, const float* cls, const float* reg, const float* cof,
                   float* boxes, float* scores, float* ctr, float* cofs, int32_t* cand_pos,

@@ -14,6 +14,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // native 16-byte register (see conv_igemm.hip)
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
 
@@ -38,6 +39,26 @@ __device__ __forceinline__ void unpack_bf16x8(const uint4& v, float* f) {
   f[5] = bf16_bits_to_f32(v.z >> 16);
   f[6] = bf16_bits_to_f32(v.w & 0xffffu);
   f[7] = bf16_bits_to_f32(v.w >> 16);
+}
+
+__device__ __forceinline__ void unpack_bf16x8(const u32x4& v, float* f) {
+  f[0] = bf16_bits_to_f32(v.x & 0xffffu);
+  f[1] = bf16_bits_to_f32(v.x >> 16);
+  f[2] = bf16_bits_to_f32(v.y & 0xffffu);
+  f[3] = bf16_bits_to_f32(v.y >> 16);
+  f[4] = bf16_bits_to_f32(v.z & 0xffffu);
+  f[5] = bf16_bits_to_f32(v.z >> 16);
+  f[6] = bf16_bits_to_f32(v.w & 0xffffu);
+  f[7] = bf16_bits_to_f32(v.w >> 16);
+}
+
+__device__ __forceinline__ u32x4 pack_bf16x8_v(const float* f) {
+  u32x4 v;
+  v.x = pack_bf16x2(f[0], f[1]);
+  v.y = pack_bf16x2(f[2], f[3]);
+  v.z = pack_bf16x2(f[4], f[5]);
+  v.w = pack_bf16x2(f[6], f[7]);
+  return v;
 }
 
 __device__ __forceinline__ uint4 pack_bf16x8(const float* f) {

@@ -13,6 +13,8 @@
 //   (M tiles are enumerated per level; tiles never straddle a level).
 // DEFORM variant: the activation loader performs the deformable bilinear gather
 //   (deform_conv_cuda_kernel.cu:85-115,191-243) -- the column buffer never exists.
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -43,6 +45,35 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
   return v & ~(neg * 0xffffu);
 }
 
+// Staging registers: native clang vectors (u32x4), NOT HIP's uint4 class -- an assignment
+// `uint4 r = *global_ptr` is emitted as llvm.memcpy(private <- global), which SROA cannot
+// promote, so the staging array lands in scratch memory (scratch_store/scratch_load plus an
+// immediate vmcnt wait inside the K loop: -25% on the tower convs).  Named members with
+// compile-time accessors keep every register statically addressed.
+struct Stage8 {
+  u32x4 r0, r1, r2, r3, r4, r5, r6, r7;
+  template <int I>
+  __device__ __forceinline__ u32x4& at() {
+    if constexpr (I == 0) return r0;
+    else if constexpr (I == 1) return r1;
+    else if constexpr (I == 2) return r2;
+    else if constexpr (I == 3) return r3;
+    else if constexpr (I == 4) return r4;
+    else if constexpr (I == 5) return r5;
+    else if constexpr (I == 6) return r6;
+    else return r7;
+  }
+};
+
+template <int N, typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
 template <int WCO, int WPOS, int TCO, int TPOS, bool DEFORM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
   constexpr int BCO = WCO * TCO * 32;
@@ -50,8 +81,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
   constexpr int NW = BCO / 32;   // 16-byte weight chunks per thread per K step
   constexpr int NX = BPOS / 32;  // 16-byte activation chunks per thread per K step
   constexpr int STAGE = (BCO + BPOS) * 128;
+  constexpr int EPI_LD = BCO + 4;                  // padded f32 row of the epilogue staging tile
+  constexpr int EPI_BYTES = BPOS * EPI_LD * 4;
+  constexpr int SMEM_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
   static_assert(WCO * WPOS == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -62,9 +96,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
   const int r0 = tid >> 3;  // tile row handled by this thread (+32*i)
   const int wslot = (j ^ ((r0 >> 1) & 7)) * 16;
 
-  // ---- tile decode (wave-uniform)
-  const int nt = blockIdx.x % a.ntn;
-  const int mt = blockIdx.x / a.ntn;
+  // ---- tile decode (wave-uniform).  Blocks are dispatched round-robin over the 8 XCDs
+  // (block b -> XCD b%8, observed); give every XCD one CONTIGUOUS range of tiles so that the
+  // 3x3 halo rows and both cout tiles of a position tile hit the same 4 MiB L2 (guide T1,
+  // bijective form).  Placement only affects speed, never correctness.
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, xq = nblk >> 3, xr = nblk & 7;
+  const int tlin = (a.flags & SM_CONV_DBG_LINEAR_TILES)
+                       ? (int)blockIdx.x
+                       : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)(blockIdx.x >> 3);
+  const int nt = tlin % a.ntn;
+  const int mt = tlin / a.ntn;
   int lev = 0;
 #pragma unroll
   for (int l = 1; l < SM_MAX_LEVELS; ++l)
@@ -96,14 +138,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
   }
   const uint16_t* wrow = a.w + (long long)(nt * BCO + r0) * a.Kp + j * 8;
 
-  uint4 wreg[NW], xreg[NX];
+  Stage8 wreg, xreg;
+  // deformable gather state between "issue" (before the MFMAs) and "finish" (after them)
+  constexpr bool DSPLIT = DEFORM && (NX <= 4);
+  Stage8 cqa, cqb;                 // 16 corner chunks (rows i, corners 0..3) when DSPLIT
+  float cw[DSPLIT ? NX : 1][4];    // corner weights (0 where the corner / sample is invalid)
+  uint32_t xmask[NX];              // plain conv: all-ones where the tap is inside the image
+  const uint32_t relu_m = (a.flags & SM_CONV_IN_RELU) ? 0xffffu : 0u;
 
   auto load_w = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < NW; ++i)
-      wreg[i] = *reinterpret_cast<const uint4*>(wrow + (long long)(32 * i) * a.Kp + kt * 64);
+    static_for<NW>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      wreg.template at<i>() = *reinterpret_cast<const u32x4*>(wrow + (long long)(32 * i) * a.Kp + kt * 64);
+    });
   };
 
+  // All global loads below are UNCONDITIONAL (clamped address + select): a load inside an
+  // exec-masked branch makes hipcc wait vmcnt(0) at the join, which serialises the row loads.
   auto load_x = [&](int kt) {
     const int kc = kt * 8 + j;
     const int tap = kc / a.cpt;
@@ -113,77 +164,133 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     const bool kvalid = kc < a.nchunk;
     const int dh = kh * a.dil, dw = kw * a.dil;
     if constexpr (!DEFORM) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        int hi = rhi[i] + dh, wi = rwi[i] + dw;
-        bool ok = kvalid && rbase[i] >= 0 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (ok) {
-          const uint16_t* p = a.x + (in_row0 + rbase[i] + hi * W + wi) * a.in_cstride + c0;
-          v = *reinterpret_cast<const uint4*>(p);
-        }
-        xreg[i] = v;
-      }
-      if (a.flags & SM_CONV_IN_RELU) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-          xreg[i].x = relu_bf16x2(xreg[i].x);
-          xreg[i].y = relu_bf16x2(xreg[i].y);
-          xreg[i].z = relu_bf16x2(xreg[i].z);
-          xreg[i].w = relu_bf16x2(xreg[i].w);
-        }
-      }
+      // branch-free: select on the 32-bit row index, AND-masks for zero padding and input ReLU
+      const int irow0 = (int)in_row0;
+      static_for<NX>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int hi = rhi[i] + dh, wi = rwi[i] + dw;
+        const bool ok = kvalid && rbase[i] >= 0 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        const int prow = ok ? (irow0 + rbase[i] + hi * W + wi) : 0;
+        const int pc0 = ok ? c0 : 0;
+        // raw load now; the padding / ReLU masks are applied in finish_x() AFTER the MFMAs, so
+        // the wait for this load sits behind the matrix work instead of in front of it
+        xreg.template at<i>() = *reinterpret_cast<const u32x4*>(a.x + (long long)prow * a.in_cstride + pc0);
+        xmask[i] = ok ? 0xffffffffu : 0u;
+      });
     } else {
-      // deformable bilinear gather; offset row = output row (stride-1 "same" conv)
+      // deformable bilinear gather (deform_conv_cuda_kernel.cu:85-115,216-229); the offset row is
+      // the output row (stride-1 "same" conv).  Phase 1: offsets of all rows, phase 2: all corner
+      // loads, phase 3 (finish_x, after the MFMAs when DSPLIT): blend to bf16.
       const int g = (c0 >> 3) / a.cpg8;
       const int ntap = a.kh * a.kw;
       const long long orow0 = a.out_row0[lev] + m0 + r0;
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (kvalid && rbase[i] >= 0) {
-          const float* op = a.offset + (orow0 + 32 * i) * (long long)(a.dg * ntap * 2) + (g * ntap + tap) * 2;
-          const float2 o = *reinterpret_cast<const float2*>(op);
-          const float h_im = (float)(rhi[i] + dh) + o.x;
-          const float w_im = (float)(rwi[i] + dw) + o.y;
-          if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-            const int h_high = h_low + 1, w_high = w_low + 1;
-            const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-            const float hh = 1.f - lh, hw = 1.f - lw;
-            const uint16_t* base = a.x + (in_row0 + rbase[i]) * a.in_cstride + c0;
-            uint4 q1 = make_uint4(0, 0, 0, 0), q2 = q1, q3 = q1, q4 = q1;
-            if (h_low >= 0 && w_low >= 0)
-              q1 = *reinterpret_cast<const uint4*>(base + (long long)(h_low * W + w_low) * a.in_cstride);
-            if (h_low >= 0 && w_high <= W - 1)
-              q2 = *reinterpret_cast<const uint4*>(base + (long long)(h_low * W + w_high) * a.in_cstride);
-            if (h_high <= H - 1 && w_low >= 0)
-              q3 = *reinterpret_cast<const uint4*>(base + (long long)(h_high * W + w_low) * a.in_cstride);
-            if (h_high <= H - 1 && w_high <= W - 1)
-              q4 = *reinterpret_cast<const uint4*>(base + (long long)(h_high * W + w_high) * a.in_cstride);
-            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-            float f1[8], f2[8], f3[8], f4[8], r[8];
-            unpack_bf16x8(q1, f1);
-            unpack_bf16x8(q2, f2);
-            unpack_bf16x8(q3, f3);
-            unpack_bf16x8(q4, f4);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) r[e] = w1 * f1[e] + w2 * f2[e] + w3 * f3[e] + w4 * f4[e];
-            v = pack_bf16x8(r);
+      float2 off[NX];
+      static_for<NX>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const bool ok = kvalid && rbase[i] >= 0;
+        const long long oo = ok ? (orow0 + 32 * i) * (long long)(a.dg * ntap * 2) + (g * ntap + tap) * 2 : 0ll;
+        off[i] = *reinterpret_cast<const float2*>(a.offset + oo);
+      });
+      static_for<NX>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const bool ok = kvalid && rbase[i] >= 0;
+        const float h_im = (float)(rhi[i] + dh) + off[i].x;
+        const float w_im = (float)(rwi[i] + dw) + off[i].y;
+        const bool inr = ok && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h_low = inr ? (int)hf : 0, w_low = inr ? (int)wf : 0;
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - hf, lw = w_im - wf;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool t_ok = h_low >= 0, b_ok = h_high <= H - 1, l_ok = w_low >= 0, r_ok = w_high <= W - 1;
+        const float w1 = (inr && t_ok && l_ok) ? hh * hw : 0.f;
+        const float w2 = (inr && t_ok && r_ok) ? hh * lw : 0.f;
+        const float w3 = (inr && b_ok && l_ok) ? lh * hw : 0.f;
+        const float w4 = (inr && b_ok && r_ok) ? lh * lw : 0.f;
+        const int hl = min(max(h_low, 0), H - 1), hh_ = min(max(h_high, 0), H - 1);
+        const int wl = min(max(w_low, 0), W - 1), wh_ = min(max(w_high, 0), W - 1);
+        const uint16_t* base = a.x + (in_row0 + (ok ? rbase[i] : 0)) * a.in_cstride + (ok ? c0 : 0);
+        const u32x4 q1 = *reinterpret_cast<const u32x4*>(base + (long long)(hl * W + wl) * a.in_cstride);
+        const u32x4 q2 = *reinterpret_cast<const u32x4*>(base + (long long)(hl * W + wh_) * a.in_cstride);
+        const u32x4 q3 = *reinterpret_cast<const u32x4*>(base + (long long)(hh_ * W + wl) * a.in_cstride);
+        const u32x4 q4 = *reinterpret_cast<const u32x4*>(base + (long long)(hh_ * W + wh_) * a.in_cstride);
+        if constexpr (DSPLIT) {
+          cw[i][0] = w1;
+          cw[i][1] = w2;
+          cw[i][2] = w3;
+          cw[i][3] = w4;
+          if constexpr (i < 2) {
+            cqa.template at<4 * i + 0>() = q1;
+            cqa.template at<4 * i + 1>() = q2;
+            cqa.template at<4 * i + 2>() = q3;
+            cqa.template at<4 * i + 3>() = q4;
+          } else {
+            cqb.template at<4 * (i - 2) + 0>() = q1;
+            cqb.template at<4 * (i - 2) + 1>() = q2;
+            cqb.template at<4 * (i - 2) + 2>() = q3;
+            cqb.template at<4 * (i - 2) + 3>() = q4;
           }
+        } else {
+          float f1[8], f2[8], f3[8], f4[8], r[8];
+          unpack_bf16x8(q1, f1);
+          unpack_bf16x8(q2, f2);
+          unpack_bf16x8(q3, f3);
+          unpack_bf16x8(q4, f4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[e] = w1 * f1[e] + w2 * f2[e] + w3 * f3[e] + w4 * f4[e];
+          xreg.template at<i>() = pack_bf16x8_v(r);
         }
-        xreg[i] = v;
-      }
+      });
+    }
+  };
+
+  auto finish_x = [&]() {
+    if constexpr (!DEFORM) {
+      static_for<NX>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        u32x4 v = xreg.template at<i>();
+        const uint32_t m = xmask[i];
+        v.x = (v.x & ~(((v.x >> 15) & 0x00010001u) * relu_m)) & m;
+        v.y = (v.y & ~(((v.y >> 15) & 0x00010001u) * relu_m)) & m;
+        v.z = (v.z & ~(((v.z >> 15) & 0x00010001u) * relu_m)) & m;
+        v.w = (v.w & ~(((v.w >> 15) & 0x00010001u) * relu_m)) & m;
+        xreg.template at<i>() = v;
+      });
+    }
+    if constexpr (DSPLIT) {
+      static_for<NX>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        float f1[8], f2[8], f3[8], f4[8], r[8];
+        if constexpr (i < 2) {
+          unpack_bf16x8(cqa.template at<4 * i + 0>(), f1);
+          unpack_bf16x8(cqa.template at<4 * i + 1>(), f2);
+          unpack_bf16x8(cqa.template at<4 * i + 2>(), f3);
+          unpack_bf16x8(cqa.template at<4 * i + 3>(), f4);
+        } else {
+          unpack_bf16x8(cqb.template at<4 * (i - 2) + 0>(), f1);
+          unpack_bf16x8(cqb.template at<4 * (i - 2) + 1>(), f2);
+          unpack_bf16x8(cqb.template at<4 * (i - 2) + 2>(), f3);
+          unpack_bf16x8(cqb.template at<4 * (i - 2) + 3>(), f4);
+        }
+        const float w1 = cw[i][0], w2 = cw[i][1], w3 = cw[i][2], w4 = cw[i][3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = w1 * f1[e] + w2 * f2[e] + w3 * f3[e] + w4 * f4[e];
+        xreg.template at<i>() = pack_bf16x8_v(r);
+      });
     }
   };
 
   auto store_tile = [&](int buf) {
     unsigned char* Wb = smem + buf * STAGE;
     unsigned char* Xb = Wb + BCO * 128;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) *reinterpret_cast<uint4*>(Wb + (r0 + 32 * i) * 128 + wslot) = wreg[i];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) *reinterpret_cast<uint4*>(Xb + (r0 + 32 * i) * 128 + wslot) = xreg[i];
+    static_for<NW>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      *reinterpret_cast<u32x4*>(Wb + (r0 + 32 * i) * 128 + wslot) = wreg.template at<i>();
+    });
+    static_for<NX>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      *reinterpret_cast<u32x4*>(Xb + (r0 + 32 * i) * 128 + wslot) = xreg.template at<i>();
+    });
   };
 
   f32x16 acc[TCO][TPOS];
@@ -202,6 +309,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 
   load_w(0);
   load_x(0);
+  finish_x();
   store_tile(0);
   __syncthreads();
 
@@ -228,81 +336,111 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         for (int tp = 0; tp < TPOS; ++tp)
           acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
     }
-    if (more) store_tile(buf ^ 1);
+    if (more) {
+      finish_x();
+      store_tile(buf ^ 1);
+    }
     __syncthreads();
   }
 
-  // ---- epilogue: (acc + bias) * level_scale (+ residual) (relu) -> bf16 / f32
+  // ---- epilogue: (acc + bias) * level_scale -> f32 tile in LDS -> coalesced 16-byte row
+  // segments (+ residual) (relu) -> bf16 / f32.  The MFMA C layout gives a lane 4 couts of one
+  // position (8-byte pieces scattered over 32 rows per store); staging through LDS turns the
+  // stores (and the residual loads) into full 128-byte lines.
   const float lscale = a.level_scale[lev];
   const long long out_row0 = a.out_row0[lev];
   const bool out_f32 = a.flags & SM_CONV_OUT_F32;
+  float* E = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int tp = 0; tp < TPOS; ++tp) {
-    const int m = m0 + wpos * TPOS * 32 + tp * 32 + l31;
-    if (m >= M) continue;
-    long long rrow = 0;
-    if (a.flags & SM_CONV_RES_ADD) {
-      rrow = out_row0 + m;
-    } else if (a.flags & SM_CONV_RES_NEAREST) {
-      int n = m / HoWo;
-      int rem = m - n * HoWo;
-      int ho = rem / Wo;
-      int wo = rem - ho * Wo;
-      const int rh = a.res_h[lev], rw = a.res_w[lev];
-      int sh = min((int)floorf((float)ho * ((float)rh / (float)Ho)), rh - 1);
-      int sw = min((int)floorf((float)wo * ((float)rw / (float)Wo)), rw - 1);
-      rrow = a.res_row0[lev] + ((long long)n * rh + sh) * rw + sw;
+  for (int tc = 0; tc < TCO; ++tc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cl = wco * TCO * 32 + tc * 32 + 8 * q + 4 * khalf;  // cout inside the tile
+      const int c = nt * BCO + cl;
+      float bv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = (a.bias != nullptr && c + e < a.cout) ? a.bias[c + e] : 0.f;
+#pragma unroll
+      for (int tp = 0; tp < TPOS; ++tp) {
+        const int pl = wpos * TPOS * 32 + tp * 32 + l31;
+        float4 v;
+        v.x = acc[tc][tp][4 * q + 0] + bv[0];
+        v.y = acc[tc][tp][4 * q + 1] + bv[1];
+        v.z = acc[tc][tp][4 * q + 2] + bv[2];
+        v.w = acc[tc][tp][4 * q + 3] + bv[3];
+        if (c + 0 < a.scale_nch) v.x *= lscale;
+        if (c + 1 < a.scale_nch) v.y *= lscale;
+        if (c + 2 < a.scale_nch) v.z *= lscale;
+        if (c + 3 < a.scale_nch) v.w *= lscale;
+        *reinterpret_cast<float4*>(E + pl * EPI_LD + cl) = v;
+      }
     }
-#pragma unroll
-    for (int tc = 0; tc < TCO; ++tc) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = nt * BCO + wco * TCO * 32 + tc * 32 + 8 * q + 4 * khalf;
-        if (c >= a.cout) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = acc[tc][tp][4 * q + e];
-          const int ce = c + e;
-          if (a.bias != nullptr && ce < a.cout) t += a.bias[ce];
-          if (ce < a.scale_nch) t *= lscale;
-          v[e] = t;
-        }
-        const bool full = (c + 3 < a.cout);
-        if (a.flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)) {
-          const uint16_t* rp = a.res + rrow * a.res_cstride + c;
-          if (full) {
-            uint2 rv = *reinterpret_cast<const uint2*>(rp);
-            v[0] += bf16_bits_to_f32(rv.x & 0xffffu);
-            v[1] += bf16_bits_to_f32(rv.x >> 16);
-            v[2] += bf16_bits_to_f32(rv.y & 0xffffu);
-            v[3] += bf16_bits_to_f32(rv.y >> 16);
-          } else {
-            for (int e = 0; e < 4; ++e)
-              if (c + e < a.cout) v[e] += bf16_bits_to_f32(rp[e]);
-          }
-        }
-        if (a.flags & SM_CONV_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        const long long o = (out_row0 + m) * a.out_cstride + a.out_coff + c;
-        if (out_f32) {
-          float* yp = reinterpret_cast<float*>(a.y) + o;
-          if (full && ((o & 3) == 0)) {
-            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            for (int e = 0; e < 4; ++e)
-              if (c + e < a.cout) yp[e] = v[e];
-          }
+  }
+  __syncthreads();
+  constexpr int CPR = BCO / 8;          // 8-cout chunks per tile row
+  constexpr int RPP = 256 / CPR;        // rows per pass
+  const int ec = tid % CPR, er = tid / CPR;
+  const int c0 = nt * BCO + ec * 8;
+  const bool has_res = a.flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST);
+  const bool vec_ok = (c0 + 7 < a.cout) && ((a.out_cstride & 7) == 0) && ((a.out_coff & 7) == 0) &&
+                      (!has_res || (a.res_cstride & 7) == 0);
+  if (c0 < a.cout) {
+#pragma unroll 2
+    for (int r = er; r < BPOS; r += RPP) {
+      const int m = m0 + r;
+      if (m >= M) break;
+      const float4 lo = *reinterpret_cast<const float4*>(E + r * EPI_LD + ec * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(E + r * EPI_LD + ec * 8 + 4);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      if (has_res) {
+        long long rrow;
+        if (a.flags & SM_CONV_RES_ADD) {
+          rrow = out_row0 + m;
         } else {
-          uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + o;
-          if (full && ((o & 3) == 0)) {
-            *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-          } else {
-            for (int e = 0; e < 4; ++e)
-              if (c + e < a.cout) yp[e] = (uint16_t)f32_to_bf16_bits(v[e]);
-          }
+          const int n = m / HoWo;
+          const int rem = m - n * HoWo;
+          const int ho = rem / Wo;
+          const int wo = rem - ho * Wo;
+          const int rh = a.res_h[lev], rw = a.res_w[lev];
+          const int sh = min((int)floorf((float)ho * ((float)rh / (float)Ho)), rh - 1);
+          const int sw = min((int)floorf((float)wo * ((float)rw / (float)Wo)), rw - 1);
+          rrow = a.res_row0[lev] + ((long long)n * rh + sh) * rw + sw;
+        }
+        const uint16_t* rp = a.res + rrow * a.res_cstride + c0;
+        if (vec_ok) {
+          float f[8];
+          unpack_bf16x8(*reinterpret_cast<const u32x4*>(rp), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += f[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (c0 + e < a.cout) v[e] += bf16_bits_to_f32(rp[e]);
+        }
+      }
+      if (a.flags & SM_CONV_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      const long long o = (out_row0 + m) * a.out_cstride + a.out_coff + c0;
+      if (out_f32) {
+        float* yp = reinterpret_cast<float*>(a.y) + o;
+        if (vec_ok) {
+          *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (c0 + e < a.cout) yp[e] = v[e];
+        }
+      } else {
+        uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + o;
+        if (vec_ok) {
+          *reinterpret_cast<u32x4*>(yp) = pack_bf16x8_v(v);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (c0 + e < a.cout) yp[e] = (uint16_t)f32_to_bf16_bits(v[e]);
         }
       }
     }

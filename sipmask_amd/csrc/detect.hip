@@ -170,25 +170,27 @@ __global__ __launch_bounds__(TK_THREADS) void det_topk_kernel(const float* __res
     out[i] = (int32_t)(0xffffffffu - (uint32_t)(sm.sel[i] & 0xffffffffull));
 }
 
-// one wave per candidate
+// one wave per 64 consecutive candidates of an image.  Scores are written CLASS-MAJOR
+// ([B][C][kmax]) so that the per-class NMS waves stream them with coalesced loads.
 __global__ __launch_bounds__(64) void det_gather_kernel(const float* __restrict__ cls, const float* __restrict__ reg,
                                                         const float* __restrict__ cof,
                                                         const int32_t* __restrict__ cand_pos,
                                                         float* __restrict__ boxes, float* __restrict__ scores,
                                                         float* __restrict__ ctr, float* __restrict__ cofs,
                                                         const DetArgs a) {
-  const int k = blockIdx.x, b = blockIdx.y;
-  int lev = 0;
+  __shared__ long long s_row[64];
+  const int b = blockIdx.y, lane = threadIdx.x;
+  const int k = blockIdx.x * 64 + lane;
+  const bool valid = k < a.kmax;
+  long long row = 0;
+  if (valid) {
+    int lev = 0;
 #pragma unroll
-  for (int l = 1; l < SM_MAX_LEVELS; ++l)
-    if (l < a.nlev && k >= a.cand0[l]) lev = l;
-  const int pos = cand_pos[(long long)b * a.kmax + k];
-  const long long row = a.row0[lev] + (long long)b * a.hw[lev] + pos;
-  const long long o = (long long)b * a.kmax + k;
-  const int lane = threadIdx.x;
-  for (int c = lane; c < a.C; c += 64) scores[o * a.C + c] = sigmoidf_acc(cls[row * a.cls_cs + a.cls_co + c]);
-  for (int c = lane; c < 128; c += 64) cofs[o * 128 + c] = cof[row * a.cof_cs + a.cof_co + c];
-  if (lane == 0) {
+    for (int l = 1; l < SM_MAX_LEVELS; ++l)
+      if (l < a.nlev && k >= a.cand0[l]) lev = l;
+    const int pos = cand_pos[(long long)b * a.kmax + k];
+    row = a.row0[lev] + (long long)b * a.hw[lev] + pos;
+    const long long o = (long long)b * a.kmax + k;
     const float* rp = reg + row * a.reg_cs;
     ctr[o] = sigmoidf_acc(rp[4]);
     const int s = a.stride[lev];
@@ -207,6 +209,20 @@ __global__ __launch_bounds__(64) void det_gather_kernel(const float* __restrict_
       y2 /= a.scale_factor;
     }
     *reinterpret_cast<float4*>(boxes + o * 4) = make_float4(x1, y1, x2, y2);
+    // class scores: lane = candidate (coalesced class-major stores; the 64 source rows stay in L1)
+    const float* cp = cls + row * a.cls_cs + a.cls_co;
+    float* sp = scores + (long long)b * a.C * a.kmax + k;
+    for (int c = 0; c < a.C; ++c) sp[(long long)c * a.kmax] = sigmoidf_acc(cp[c]);
+  }
+  s_row[lane] = valid ? row : -1;
+  __syncthreads();
+  // coefficients: lanes sweep the 128 channels of one candidate at a time (coalesced both sides)
+  for (int j = 0; j < 64; ++j) {
+    const long long r = s_row[j];
+    if (r < 0) break;
+    const long long o = (long long)b * a.kmax + blockIdx.x * 64 + j;
+    cofs[o * 128 + lane] = cof[r * a.cof_cs + a.cof_co + lane];
+    cofs[o * 128 + 64 + lane] = cof[r * a.cof_cs + a.cof_co + 64 + lane];
   }
 }
 
@@ -223,54 +239,83 @@ __device__ __forceinline__ float iou_plus1(const float4 a, const float4 b) {
   return __fdiv_rn(inter, __fsub_rn(__fadd_rn(sa, sb), inter));
 }
 
-// LDS carve for one wave: keys[P] (u64), kept_box[P] (float4), kept_idx[P] (u32)
-// Greedy NMS over the n sorted entries in keys (low word = 0xffffffff - candidate index).
-// box_of(idx) returns the box.  Returns number kept; kept_idx holds candidate indices in score order.
+constexpr int NMS_THREADS = 256;   // 4 waves per (image, class)
+
+// LDS carve (dynamic): keys[P] (u64), kept_box[P] (float4), kept_idx[P] (u32); static: NmsSmem.
+struct NmsSmem {
+  unsigned long long rowm[64];                    // intra-chunk suppression rows (bits > t only)
+  unsigned long long alive_w[NMS_THREADS / 64];   // per-wave "not suppressed by a kept box" masks
+  unsigned int n;
+};
+
+// Greedy NMS over the n sorted entries in keys (low word = 0xffffffff - candidate index), all
+// NMS_THREADS threads of the block.  Semantics = the reference's bitmask kernel + host scan
+// (nms_kernel.cu:24-68,113-138): box i is kept iff no EARLIER KEPT box has IoU(+1) > thr.
+// Work split per 64-box chunk (score order): (a) each wave tests the chunk against a slice of
+// the kept list, (b) each wave builds 16 rows of the 64x64 intra-chunk suppression matrix with
+// ballots (the reference's 64-bit mask word == one wave64 ballot), (c) a scalar 64-step
+// resolve on those rows, (d) kept boxes appended.  Returns the number kept (score order).
 template <typename BoxFn>
-__device__ int wave_greedy_nms(const unsigned long long* keys, int n, float thr, float4* kept_box,
-                               uint32_t* kept_idx, BoxFn box_of) {
-  const int lane = threadIdx.x;
+__device__ int block_greedy_nms(const unsigned long long* keys, int n, float thr, float4* kept_box,
+                                uint32_t* kept_idx, NmsSmem& sm, BoxFn box_of) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int NW = NMS_THREADS / 64;
   int nkept = 0;
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
-    bool alive = i < n;
+    const bool valid = i < n;
     uint32_t idx = 0;
     float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (alive) {
+    if (valid) {
       idx = 0xffffffffu - (uint32_t)(keys[i] & 0xffffffffull);
       mine = box_of(idx);
     }
-    for (int kk = 0; kk < nkept; ++kk) {
+    // (a) suppression by already-kept boxes, kept list striped over the waves
+    bool alive = valid;
+    for (int kk = wv; kk < nkept; kk += NW) {
       if (alive && iou_plus1(kept_box[kk], mine) > thr) alive = false;
     }
-    // resolve inside the 64-box chunk in score order
-    for (int t = 0; t < 64; ++t) {
-      const unsigned long long bal = __ballot(alive);
-      if (!((bal >> t) & 1ull)) continue;   // wave-uniform
+    const unsigned long long aw = __ballot(alive);
+    if (lane == 0) sm.alive_w[wv] = aw;
+    // (b) rows t = wv, wv+NW, ... of the intra-chunk matrix: bit j set iff j > t and IoU(t, j) > thr
+    for (int t = wv; t < 64; t += NW) {
       float4 bt;
       bt.x = __shfl(mine.x, t);
       bt.y = __shfl(mine.y, t);
       bt.z = __shfl(mine.z, t);
       bt.w = __shfl(mine.w, t);
-      if (alive && lane > t && iou_plus1(bt, mine) > thr) alive = false;
+      const bool hit = valid && lane > t && (base + t) < n && iou_plus1(bt, mine) > thr;
+      const unsigned long long row = __ballot(hit);
+      if (lane == 0) sm.rowm[t] = row;
     }
-    const unsigned long long bal = __ballot(alive);
-    if (alive) {
-      const int slot = nkept + __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();
+    // (c) scalar resolve (every wave redundantly; all operands are wave-uniform)
+    unsigned long long am = sm.alive_w[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) am &= sm.alive_w[w];
+    const unsigned long long myrow = sm.rowm[lane];
+    for (int t = 0; t < 64; ++t) {
+      const unsigned long long rt = __shfl(myrow, t);
+      if ((am >> t) & 1ull) am &= ~rt;
+    }
+    // (d) append the survivors in score order
+    if (wv == 0 && ((am >> lane) & 1ull)) {
+      const int slot = nkept + __popcll(am & ((1ull << lane) - 1ull));
       kept_box[slot] = mine;
       kept_idx[slot] = idx;
     }
-    nkept += __popcll(bal);
+    nkept += __popcll(am);
     __syncthreads();
   }
   return nkept;
 }
 
-// ascending sort of u32 values held in the low word of u64 scratch (single wave)
-__device__ void wave_sort_idx_asc(unsigned long long* scratch, const uint32_t* vals, int n) {
+// ascending sort of u32 values through the u64 scratch (whole block)
+__device__ void block_sort_idx_asc(unsigned long long* scratch, const uint32_t* vals, int n) {
   int P = 1;
   while (P < n) P <<= 1;
-  for (int i = threadIdx.x; i < P; i += 64) scratch[i] = i < n ? (unsigned long long)(0xffffffffu - vals[i]) : 0ull;
+  for (int i = threadIdx.x; i < P; i += blockDim.x)
+    scratch[i] = i < n ? (unsigned long long)(0xffffffffu - vals[i]) : 0ull;
   block_bitonic_desc(scratch, P);  // descending in (max - idx) == ascending idx; zeros (padding) last
 }
 
@@ -279,55 +324,58 @@ struct NmsArgs {
   float score_thr, iou_thr;
 };
 
-__global__ __launch_bounds__(64) void nms_class_kernel(const float* __restrict__ boxes,
-                                                       const float* __restrict__ scores,
-                                                       const float* __restrict__ ctr,
-                                                       const int32_t* __restrict__ ncand,
-                                                       int32_t* __restrict__ cls_keep,
-                                                       int32_t* __restrict__ cls_cnt, const NmsArgs a) {
+__global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __restrict__ boxes,
+                                                                const float* __restrict__ scores,
+                                                                const float* __restrict__ ctr,
+                                                                const int32_t* __restrict__ ncand,
+                                                                int32_t* __restrict__ cls_keep,
+                                                                int32_t* __restrict__ cls_cnt, const NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  __shared__ NmsSmem sm;
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(dsm);
   float4* kept_box = reinterpret_cast<float4*>(dsm + (size_t)a.P * 8);
   uint32_t* kept_idx = reinterpret_cast<uint32_t*>(dsm + (size_t)a.P * 24);
   const int c = blockIdx.x, b = blockIdx.y;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int K = ncand[b];
-  const float* sc = scores + (long long)b * a.kmax * a.C + c;
+  const float* sc = scores + ((long long)b * a.C + c) * a.kmax;   // class-major: contiguous over candidates
   const float* ct = ctr + (long long)b * a.kmax;
   const float4* bx = reinterpret_cast<const float4*>(boxes) + (long long)b * a.kmax;
-  // 1. ordered compaction of candidates with raw class score > thr (bbox_nms.py:111)
-  int n = 0;
-  for (int base = 0; base < K; base += 64) {
-    const int i = base + lane;
-    float s = 0.f;
-    bool sel = false;
-    if (i < K) {
-      s = sc[(long long)i * a.C];
-      sel = s > a.score_thr;
-    }
+  if (tid == 0) sm.n = 0;
+  __syncthreads();
+  // 1. compaction of candidates with raw class score > thr (bbox_nms.py:111).  The order of
+  //    insertion is irrelevant: the sort key (score, index) is a total order.
+  for (int base = 0; base < K; base += NMS_THREADS) {
+    const int i = base + tid;
+    const float s = (i < K) ? sc[i] : 0.f;
+    const bool sel = (i < K) && (s > a.score_thr);
     const unsigned long long bal = __ballot(sel);
+    unsigned int wbase = 0;
+    if (lane == 0 && bal) wbase = atomicAdd(&sm.n, (unsigned int)__popcll(bal));
+    wbase = __shfl(wbase, 0);
     if (sel) {
       const float sf = __fmul_rn(s, ct[i]);  // _scores *= score_factors (bbox_nms.py:121-122)
-      keys[n + __popcll(bal & ((1ull << lane) - 1ull))] = compose_key(float_to_ordered(sf), (uint32_t)i);
+      keys[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = compose_key(float_to_ordered(sf), (uint32_t)i);
     }
-    n += __popcll(bal);
   }
+  __syncthreads();
+  const int n = (int)sm.n;
   int32_t* outk = cls_keep + ((long long)b * a.C + c) * a.kmax;
   if (n == 0) {
-    if (lane == 0) cls_cnt[b * a.C + c] = 0;
+    if (tid == 0) cls_cnt[b * a.C + c] = 0;
     return;
   }
   // 2. sort (score desc, index asc)
   int P = 1;
   while (P < n) P <<= 1;
-  for (int i = n + lane; i < P; i += 64) keys[i] = 0ull;
+  for (int i = n + tid; i < P; i += NMS_THREADS) keys[i] = 0ull;
   block_bitonic_desc(keys, P);
   // 3. greedy NMS
-  const int nk = wave_greedy_nms(keys, n, a.iou_thr, kept_box, kept_idx, [&](uint32_t idx) { return bx[idx]; });
+  const int nk = block_greedy_nms(keys, n, a.iou_thr, kept_box, kept_idx, sm, [&](uint32_t idx) { return bx[idx]; });
   // 4. reference returns kept ORIGINAL indices ascending (nms_kernel.cu:135-138)
-  wave_sort_idx_asc(keys, kept_idx, nk);
-  for (int i = lane; i < nk; i += 64) outk[i] = (int32_t)(0xffffffffu - (uint32_t)keys[i]);
-  if (lane == 0) cls_cnt[b * a.C + c] = nk;
+  block_sort_idx_asc(keys, kept_idx, nk);
+  for (int i = tid; i < nk; i += NMS_THREADS) outk[i] = (int32_t)(0xffffffffu - (uint32_t)keys[i]);
+  if (tid == 0) cls_cnt[b * a.C + c] = nk;
 }
 
 __global__ __launch_bounds__(TK_THREADS) void nms_final_kernel(const float* __restrict__ boxes,
@@ -342,11 +390,14 @@ __global__ __launch_bounds__(TK_THREADS) void nms_final_kernel(const float* __re
   __shared__ TopkSmem sm;
   __shared__ int pre[257];
   const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ int cnt_s[256];
+  if (tid < a.C) cnt_s[tid] = cls_cnt[b * a.C + tid];
+  __syncthreads();
   if (tid == 0) {
     int t = 0;
     for (int c = 0; c < a.C; ++c) {
       pre[c] = t;
-      t += cls_cnt[b * a.C + c];
+      t += cnt_s[c];
     }
     pre[a.C] = t;
   }
@@ -364,7 +415,7 @@ __global__ __launch_bounds__(TK_THREADS) void nms_final_kernel(const float* __re
     const int idx = cls_keep[((long long)b * a.C + c) * a.kmax + (p - pre[c])];
     const long long o = (long long)b * a.max_num + slot;
     const float4 bb = reinterpret_cast<const float4*>(boxes)[(long long)b * a.kmax + idx];
-    const float s = __fmul_rn(scores[((long long)b * a.kmax + idx) * a.C + c], ctr[(long long)b * a.kmax + idx]);
+    const float s = __fmul_rn(scores[((long long)b * a.C + c) * a.kmax + idx], ctr[(long long)b * a.kmax + idx]);
     det[o * 5 + 0] = bb.x;
     det[o * 5 + 1] = bb.y;
     det[o * 5 + 2] = bb.z;
@@ -386,7 +437,7 @@ __global__ __launch_bounds__(TK_THREADS) void nms_final_kernel(const float* __re
       if (pre[mid] <= p) lo = mid; else hi = mid;
     }
     const int idx = cls_keep[((long long)b * a.C + lo) * a.kmax + (p - pre[lo])];
-    fk[p] = __fmul_rn(scores[((long long)b * a.kmax + idx) * a.C + lo], ctr[(long long)b * a.kmax + idx]);
+    fk[p] = __fmul_rn(scores[((long long)b * a.C + lo) * a.kmax + idx], ctr[(long long)b * a.kmax + idx]);
   }
   __syncthreads();
   block_topk(fk, total, a.max_num, sm);
@@ -396,23 +447,25 @@ __global__ __launch_bounds__(TK_THREADS) void nms_final_kernel(const float* __re
 }
 
 // reference op contract: dets [n][5] -> ascending kept indices (nms_cuda.nms)
-__global__ __launch_bounds__(64) void nms_single_kernel(const float* __restrict__ dets, int n, float thr, int P,
-                                                        int64_t* __restrict__ keep, int32_t* __restrict__ nkeep) {
+__global__ __launch_bounds__(NMS_THREADS) void nms_single_kernel(const float* __restrict__ dets, int n, float thr,
+                                                                 int P, int64_t* __restrict__ keep,
+                                                                 int32_t* __restrict__ nkeep) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  __shared__ NmsSmem sm;
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(dsm);
   float4* kept_box = reinterpret_cast<float4*>(dsm + (size_t)P * 8);
   uint32_t* kept_idx = reinterpret_cast<uint32_t*>(dsm + (size_t)P * 24);
-  const int lane = threadIdx.x;
-  for (int i = lane; i < P; i += 64)
+  const int tid = threadIdx.x;
+  for (int i = tid; i < P; i += NMS_THREADS)
     keys[i] = i < n ? compose_key(float_to_ordered(dets[(long long)i * 5 + 4]), (uint32_t)i) : 0ull;
   block_bitonic_desc(keys, P);
-  const int nk = wave_greedy_nms(keys, n, thr, kept_box, kept_idx, [&](uint32_t idx) {
+  const int nk = block_greedy_nms(keys, n, thr, kept_box, kept_idx, sm, [&](uint32_t idx) {
     const float* p = dets + (long long)idx * 5;
     return make_float4(p[0], p[1], p[2], p[3]);
   });
-  wave_sort_idx_asc(keys, kept_idx, nk);
-  for (int i = lane; i < nk; i += 64) keep[i] = (int64_t)(0xffffffffu - (uint32_t)keys[i]);
-  if (lane == 0) *nkeep = nk;
+  block_sort_idx_asc(keys, kept_idx, nk);
+  for (int i = tid; i < nk; i += NMS_THREADS) keep[i] = (int64_t)(0xffffffffu - (uint32_t)keys[i]);
+  if (tid == 0) *nkeep = nk;
 }
 
 __global__ void fill_i32_kernel(int32_t* p, int n, int v) {
@@ -492,7 +545,7 @@ extern "C" int sm_det_select(const sm_det_desc* d, const float* cls, const float
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(det_score_kernel, dim3(g), dim3(256), 0, s, cls, reg, keys, a);
   hipLaunchKernelGGL(det_topk_kernel, dim3(a.nlev, a.batch), dim3(TK_THREADS), 0, s, keys, cand_pos, a);
-  hipLaunchKernelGGL(det_gather_kernel, dim3(a.kmax, a.batch), dim3(64), 0, s, cls, reg, cof, cand_pos, boxes, scores,
+  hipLaunchKernelGGL(det_gather_kernel, dim3((a.kmax + 63) / 64, a.batch), dim3(64), 0, s, cls, reg, cof, cand_pos, boxes, scores,
                      ctr, cofs, a);
   // every image has exactly kmax candidates (sum_l min(nms_pre, hw_l))
   if (a.batch > 1024) return SM_ERR_UNSUPPORTED;
@@ -530,7 +583,7 @@ extern "C" int sm_multiclass_nms(const float* boxes, const float* scores, const 
   if (hipFuncSetAttribute((const void*)nms_class_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return SM_ERR_LAUNCH;
-  hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(64), lds, s, boxes, scores, ctr, ncand, cls_keep,
+  hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(NMS_THREADS), lds, s, boxes, scores, ctr, ncand, cls_keep,
                      cls_cnt, a);
   hipLaunchKernelGGL(nms_final_kernel, dim3(batch), dim3(TK_THREADS), 0, s, boxes, scores, ctr, cls_keep, cls_cnt,
                      flat_key, det, labels, keep, ndet, a);
@@ -555,7 +608,7 @@ extern "C" int sm_nms(const float* dets, int n, float iou_thr, int64_t* keep, in
   if (hipFuncSetAttribute((const void*)nms_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return SM_ERR_LAUNCH;
-  hipLaunchKernelGGL(nms_single_kernel, dim3(1), dim3(64), lds, s, dets, n, iou_thr, P, keep, nkeep);
+  hipLaunchKernelGGL(nms_single_kernel, dim3(1), dim3(NMS_THREADS), lds, s, dets, n, iou_thr, P, keep, nkeep);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

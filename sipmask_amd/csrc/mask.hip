@@ -1,11 +1,14 @@
 // Fused SipMask mask assembly (sipmask_head.py:609-633) -- HBM bound:
 //   algorithmic bytes / image = basis read (Hm*Wm*32*4) + u8 masks written (N*Ho*Wo).
-// One block owns one TOxTO tile of output pixels for ALL detections of an image:
+// One block owns one TOW x TOH tile of output pixels for ALL detections of an image:
 //   * the source (mask-resolution) pixels that tile needs (<= 512) are owned by threads, whose
 //     32 basis values stay in VGPRs for the whole detection loop -> the basis is read once;
+//   * the detections' boxes and 4x32 coefficients are staged ONCE in LDS (no dependent global
+//     load inside the detection loop);
 //   * per detection: quadrant select (CropSplit index math, crop_split_cuda_kernel.cu:34-52)
 //     -> ONE 32-long dot product (only the selected quadrant is ever needed) -> sigmoid
-//     -> LDS tile -> bilinear (align_corners=False) -> > thr -> packed u8 stores (4 px / lane).
+//     -> LDS tile -> bilinear (align_corners=False) -> > thr -> packed u8 stores; TOW = 128
+//     makes every store instruction cover whole 128-byte lines.
 // The reference materialises 4 x [Hm*Wm, N] sigmoid planes, the stacked copy, the crop, the
 // upsampled float masks and the thresholded copy: ~4 GB/image of traffic vs ~140 MB here.
 #include "common.h"
@@ -13,9 +16,9 @@
 namespace {
 
 constexpr int MA_THREADS = 256;
-constexpr int MA_PX = 2;              // source pixels owned per thread
+constexpr int MA_PX = 2;  // source pixels owned per thread
 constexpr int MA_SRC_CAP = MA_THREADS * MA_PX;
-constexpr int MA_MAXDET = 128;        // detections cached per pass (LDS)
+constexpr int MA_DETS = 64;  // detections staged in LDS per pass (64 * 128 * 4 B = 32 KiB)
 
 struct MaskArgs {
   const float* basis;
@@ -34,20 +37,20 @@ struct DetBox {
   float x1, y1, x2, y2, rw, rh;
 };
 
-template <int TO>
+template <int TOW, int TOH>
 __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArgs a) {
-  __shared__ float s_cof[128];
-  __shared__ DetBox s_box;
+  __shared__ __attribute__((aligned(16))) float s_cof[MA_DETS * 128];
+  __shared__ DetBox s_box[MA_DETS];
   __shared__ float s_prob[MA_SRC_CAP];
   const int b = blockIdx.z;
-  const int ox0 = blockIdx.x * TO, oy0 = blockIdx.y * TO;
+  const int ox0 = blockIdx.x * TOW, oy0 = blockIdx.y * TOH;
   const int tid = threadIdx.x;
   const int nd = min(a.ndet[b], a.max_num);
   if (nd <= 0) return;
 
   // source window of this output tile
   auto src_of = [&](int o) { return fmaxf(a.inv_up * ((float)o + 0.5f) - 0.5f, 0.f); };
-  const int oxe = min(ox0 + TO, a.wo) - 1, oye = min(oy0 + TO, a.ho) - 1;
+  const int oxe = min(ox0 + TOW, a.wo) - 1, oye = min(oy0 + TOH, a.ho) - 1;
   const int sx0 = (int)src_of(ox0), sy0 = (int)src_of(oy0);
   const int sx1 = min((int)src_of(oxe) + 1, a.wm - 1), sy1 = min((int)src_of(oye) + 1, a.hm - 1);
   const int spw = sx1 - sx0 + 1, sph = sy1 - sy0 + 1;
@@ -85,16 +88,15 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
     }
   }
 
-  // output pixels of this thread: TO*TO/256 groups of 4 consecutive x
-  constexpr int GROUPS = TO * TO / 4;                 // 4-pixel groups in the tile
+  constexpr int GROUPS = TOW * TOH / 4;  // 4-pixel (one u32) groups in the tile
   constexpr int GPT = (GROUPS + MA_THREADS - 1) / MA_THREADS;
 
-  for (int n = 0; n < nd; ++n) {
-    __syncthreads();  // previous iteration finished reading s_prob / s_cof / s_box
-    const long long dn = (long long)b * a.max_num + n;
-    if (tid < 128) s_cof[tid] = a.cofs[((long long)b * a.kmax + a.keep[dn]) * 128 + tid];
-    if (tid == 128) {
-      const float* d = a.det + dn * 5;
+  for (int n0 = 0; n0 < nd; n0 += MA_DETS) {
+    const int nn = min(MA_DETS, nd - n0);
+    __syncthreads();  // previous pass finished with s_cof / s_box / s_prob
+    // stage this pass's detections: boxes (CropSplit geometry) + coefficients, coalesced
+    if (tid < nn) {
+      const float* d = a.det + ((long long)b * a.max_num + n0 + tid) * 5;
       DetBox bx;
       bx.x1 = __fdiv_rn(__fmul_rn(d[0], a.box_mul), a.box_div);
       bx.y1 = __fdiv_rn(__fmul_rn(d[1], a.box_mul), a.box_div);
@@ -103,74 +105,84 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
       // roi_w = (x2 - x1 + 0.1) / num_cell in double, rounded to float (kernel.cu:47-48)
       bx.rw = (float)(((double)__fsub_rn(bx.x2, bx.x1) + 0.1) / 2.0);
       bx.rh = (float)(((double)__fsub_rn(bx.y2, bx.y1) + 0.1) / 2.0);
-      s_box = bx;
+      s_box[tid] = bx;
+    }
+    for (int i = tid; i < nn * 32; i += MA_THREADS) {  // 32 float4 per detection
+      const int dd = i >> 5, q4 = i & 31;
+      const long long src = ((long long)b * a.kmax + a.keep[(long long)b * a.max_num + n0 + dd]) * 128;
+      *reinterpret_cast<float4*>(s_cof + dd * 128 + q4 * 4) = *reinterpret_cast<const float4*>(a.cofs + src + q4 * 4);
     }
     __syncthreads();
-    const DetBox bx = s_box;
-    // tile / box overlap in source coordinates (uniform): any source pixel inside?
-    const bool hit = ((float)sx1 >= bx.x1) && ((float)sx0 < bx.x2) && ((float)sy1 >= bx.y1) && ((float)sy0 < bx.y2);
-    uint8_t* mrow = a.masks + dn * (long long)a.ho * a.wo;
-    if (!hit) {
-      // whole tile is zero
+
+    for (int n = 0; n < nn; ++n) {
+      const long long dn = (long long)b * a.max_num + n0 + n;
+      const DetBox bx = s_box[n];
+      // tile / box overlap in source coordinates (block-uniform, conservative)
+      const bool hit = ((float)sx1 >= bx.x1) && ((float)sx0 < bx.x2) && ((float)sy1 >= bx.y1) && ((float)sy0 < bx.y2);
+      uint8_t* mrow = a.masks + dn * (long long)a.ho * a.wo;
+      if (!hit) {
+        // the whole tile is zero: no LDS traffic, no barrier
+#pragma unroll
+        for (int g = 0; g < GPT; ++g) {
+          const int gi = tid + g * MA_THREADS;
+          if (gi < GROUPS) {
+            const int oy = oy0 + gi / (TOW / 4), ox = ox0 + (gi % (TOW / 4)) * 4;
+            if (oy < a.ho && ox < a.wo) *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.wo + ox) = 0u;
+          }
+        }
+        if (a.pos_masks) {
+#pragma unroll
+          for (int p = 0; p < MA_PX; ++p)
+            if (gx[p] >= 0) a.pos_masks[dn * (long long)a.hm * a.wm + (long long)gy[p] * a.wm + gx[p]] = 0.f;
+        }
+        continue;
+      }
+#pragma unroll
+      for (int p = 0; p < MA_PX; ++p) {
+        const int li = tid + p * MA_THREADS;
+        if (li < nsrc) {
+          const float pw = (float)gx[p], ph = (float)gy[p];
+          float prob = 0.f;
+          if (pw >= bx.x1 && ph >= bx.y1 && pw < bx.x2 && ph < bx.y2) {
+            const int iw = (int)__fdiv_rn(__fsub_rn(pw, bx.x1), bx.rw);
+            const int ih = (int)__fdiv_rn(__fsub_rn(ph, bx.y1), bx.rh);
+            const float* cq = s_cof + n * 128 + ((ih * 2 + iw) & 3) * 32;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) acc = fmaf(bas[p][k], cq[k], acc);
+            prob = sigmoidf_acc(acc);
+          }
+          s_prob[li] = prob;
+          if (a.pos_masks) a.pos_masks[dn * (long long)a.hm * a.wm + (long long)gy[p] * a.wm + gx[p]] = prob;
+        }
+      }
+      __syncthreads();
 #pragma unroll
       for (int g = 0; g < GPT; ++g) {
         const int gi = tid + g * MA_THREADS;
-        if (gi < GROUPS) {
-          const int oy = oy0 + gi / (TO / 4), ox = ox0 + (gi % (TO / 4)) * 4;
-          if (oy < a.ho && ox < a.wo) *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.wo + ox) = 0u;
+        if (gi >= GROUPS) continue;
+        const int oy = oy0 + gi / (TOW / 4), oxb = ox0 + (gi % (TOW / 4)) * 4;
+        if (oy >= a.ho || oxb >= a.wo) continue;
+        const float sy = src_of(oy);
+        const int y0 = (int)sy, y1 = min(y0 + 1, a.hm - 1);
+        const float ly = sy - (float)y0, hy = 1.f - ly;
+        const float* r0 = s_prob + (y0 - sy0) * spw - sx0;
+        const float* r1 = s_prob + (y1 - sy0) * spw - sx0;
+        uint32_t packed = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ox = oxb + e;
+          if (ox < a.wo) {
+            const float sx = src_of(ox);
+            const int x0 = (int)sx, x1 = min(x0 + 1, a.wm - 1);
+            const float lx = sx - (float)x0, hx = 1.f - lx;
+            const float v = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+            packed |= (v > a.thr ? 1u : 0u) << (8 * e);
+          }
         }
+        *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.wo + oxb) = packed;
       }
-      if (a.pos_masks) {
-#pragma unroll
-        for (int p = 0; p < MA_PX; ++p)
-          if (gx[p] >= 0) a.pos_masks[dn * (long long)a.hm * a.wm + (long long)gy[p] * a.wm + gx[p]] = 0.f;
-      }
-      continue;
-    }
-#pragma unroll
-    for (int p = 0; p < MA_PX; ++p) {
-      const int li = tid + p * MA_THREADS;
-      if (li < nsrc) {
-        const float pw = (float)gx[p], ph = (float)gy[p];
-        float prob = 0.f;
-        if (pw >= bx.x1 && ph >= bx.y1 && pw < bx.x2 && ph < bx.y2) {
-          const int iw = (int)__fdiv_rn(__fsub_rn(pw, bx.x1), bx.rw);
-          const int ih = (int)__fdiv_rn(__fsub_rn(ph, bx.y1), bx.rh);
-          const float* cq = s_cof + ((ih * 2 + iw) & 3) * 32;
-          float acc = 0.f;
-#pragma unroll
-          for (int k = 0; k < 32; ++k) acc = fmaf(bas[p][k], cq[k], acc);
-          prob = sigmoidf_acc(acc);
-        }
-        s_prob[li] = prob;
-        if (a.pos_masks) a.pos_masks[dn * (long long)a.hm * a.wm + (long long)gy[p] * a.wm + gx[p]] = prob;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < GPT; ++g) {
-      const int gi = tid + g * MA_THREADS;
-      if (gi >= GROUPS) continue;
-      const int oy = oy0 + gi / (TO / 4), oxb = ox0 + (gi % (TO / 4)) * 4;
-      if (oy >= a.ho || oxb >= a.wo) continue;
-      const float sy = src_of(oy);
-      const int y0 = (int)sy, y1 = min(y0 + 1, a.hm - 1);
-      const float ly = sy - (float)y0, hy = 1.f - ly;
-      const float* r0 = s_prob + (y0 - sy0) * spw - sx0;
-      const float* r1 = s_prob + (y1 - sy0) * spw - sx0;
-      uint32_t packed = 0u;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int ox = oxb + e;
-        if (ox < a.wo) {
-          const float sx = src_of(ox);
-          const int x0 = (int)sx, x1 = min(x0 + 1, a.wm - 1);
-          const float lx = sx - (float)x0, hx = 1.f - lx;
-          const float v = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
-          packed |= (v > a.thr ? 1u : 0u) << (8 * e);
-        }
-      }
-      *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.wo + oxb) = packed;
+      __syncthreads();  // s_prob is rewritten by the next overlapping detection
     }
   }
 }
@@ -204,19 +216,25 @@ extern "C" int sm_mask_assemble(const float* basis, int basis_hwc, const float* 
   a.inv_up = (float)(1.0 / up_scale);  // area_pixel_compute_scale with an explicit scale_factor
   a.thr = mask_thr;
   hipStream_t s = sm_hip_stream(stream);
-  // pick the output tile so that the source window (TO/up + 2)^2 fits the per-thread ownership
-  auto span = [&](int to) { return (int)((double)to / up_scale) + 3; };
-  int to = 32;
-  if (span(32) * span(32) > MA_SRC_CAP) to = 16;
-  if (to == 16 && span(16) * span(16) > MA_SRC_CAP) to = 8;
-  if (to == 8 && span(8) * span(8) > MA_SRC_CAP) return SM_ERR_UNSUPPORTED;
-  dim3 grid(sm_cdiv(wo, to), sm_cdiv(ho, to), batch), block(MA_THREADS);
-  if (to == 32)
-    hipLaunchKernelGGL(mask_assemble_kernel<32>, grid, block, 0, s, a);
-  else if (to == 16)
-    hipLaunchKernelGGL(mask_assemble_kernel<16>, grid, block, 0, s, a);
-  else
-    hipLaunchKernelGGL(mask_assemble_kernel<8>, grid, block, 0, s, a);
-  SM_LAUNCH_CHECK();
-  return SM_OK;
+  // pick the widest output tile whose source window (TOW/up + 3) x (TOH/up + 3) fits the
+  // per-thread ownership (512 source pixels); wide tiles = full-line mask stores
+  auto fits = [&](int tw, int th) {
+    return ((int)((double)tw / up_scale) + 3) * ((int)((double)th / up_scale) + 3) <= MA_SRC_CAP;
+  };
+  dim3 block(MA_THREADS);
+#define SM_MASK_TRY(TW, TH)                                                                                  \
+  if (fits(TW, TH)) {                                                                                        \
+    hipLaunchKernelGGL((mask_assemble_kernel<TW, TH>), dim3(sm_cdiv(wo, TW), sm_cdiv(ho, TH), batch), block, \
+                       0, s, a);                                                                             \
+    SM_LAUNCH_CHECK();                                                                                       \
+    return SM_OK;                                                                                            \
+  }
+  SM_MASK_TRY(128, 8)
+  SM_MASK_TRY(64, 8)
+  SM_MASK_TRY(32, 8)
+  SM_MASK_TRY(16, 8)
+  SM_MASK_TRY(8, 8)
+  SM_MASK_TRY(8, 4)
+#undef SM_MASK_TRY
+  return SM_ERR_UNSUPPORTED;
 }

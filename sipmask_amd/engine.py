@@ -52,6 +52,11 @@ class _Conv:
                                      scale_nch, level_scale, deform_groups)
         self.x, self.y, self.residual, self.offset = x, y, residual, offset
         self.flops = 2.0 * sum(batch * h * ww for h, ww in out_sizes) * co * ci * k * k
+        # algorithmic HBM bytes: x read once + y written once (+ residual read) + weights
+        in_rows = sum(batch * h * ww for h, ww in in_sizes)
+        out_rows = sum(batch * h * ww for h, ww in out_sizes)
+        self.bytes = (in_rows * cin * 2 + out_rows * co * (4 if flags & SM_CONV_OUT_F32 else 2) +
+                      (out_rows * co * 2 if residual is not None else 0) + self.w.numel() * 2)
 
     def __call__(self):
         if self.offset is not None:

@@ -169,7 +169,7 @@ def det_select_alloc(desc, device):
     if ws < 0:
         raise RuntimeError("sm_det_select_workspace: bad descriptor")
     f32, i32 = torch.float32, torch.int32
-    return dict(boxes=torch.empty(b, k, 4, dtype=f32, device=device), scores=torch.empty(b, k, c, dtype=f32, device=device),
+    return dict(boxes=torch.empty(b, k, 4, dtype=f32, device=device), scores=torch.empty(b, c, k, dtype=f32, device=device),
                 ctr=torch.empty(b, k, dtype=f32, device=device), cofs=torch.empty(b, k, 128, dtype=f32, device=device),
                 cand_pos=torch.empty(b, k, dtype=i32, device=device), ncand=torch.empty(b, dtype=i32, device=device),
                 ws_sel=torch.empty(max(int(ws), 16), dtype=torch.uint8, device=device))
@@ -187,7 +187,7 @@ def multiclass_nms_alloc(batch, kmax, num_classes, max_num, device):
 
 def multiclass_nms(boxes, scores, ctr, ncand, score_thr, iou_thr, max_num, out):
     lib = _lib.load()
-    b, k, c = scores.shape
+    b, c, k = scores.shape          # class-major [B][C][kmax]
     _lib.check(lib.sm_multiclass_nms(_lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(ctr), _lib.ptr(ncand), b, k, c,
                                      float(score_thr), float(iou_thr), int(max_num), _lib.ptr(out["det"]),
                                      _lib.ptr(out["labels"]), _lib.ptr(out["keep"]), _lib.ptr(out["ndet"]),

@@ -265,7 +265,7 @@ def multiclass_nms_idx(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-
     if k == 0:
         return (multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0,), dtype=torch.long),
                 multi_bboxes.new_zeros((0,), dtype=torch.long))
-    scores = multi_scores[:, 1:].float().contiguous().view(1, k, c)
+    scores = multi_scores[:, 1:].float().t().contiguous().view(1, c, k)     # class-major for the kernel
     boxes = multi_bboxes.float().contiguous().view(1, k, 4)
     ctr = (torch.ones(1, k, device=dev) if score_factors is None else score_factors.float().contiguous().view(1, k))
     ncand = torch.full((1,), k, dtype=torch.int32, device=dev)

@@ -313,7 +313,7 @@ def test_det_select_vs_oracle():
         assert int(mism.sum()) <= 4, int(mism.sum())
         ok = ~mism
         torch.testing.assert_close(out["boxes"][b].cpu()[ok], mb[ok], rtol=0, atol=0)
-        torch.testing.assert_close(out["scores"][b].cpu()[ok], ms[ok][:, 1:], rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(out["scores"][b].cpu().t()[ok], ms[ok][:, 1:], rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(out["ctr"][b].cpu()[ok], mc[ok], rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(out["cofs"][b].cpu()[ok], mf[ok], rtol=0, atol=0)
 
