@@ -74,8 +74,12 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int WCO, int WPOS, int TCO, int TPOS, bool DEFORM>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
+// 16 zero bytes in device memory: the source of every zero-padding / K-padding chunk in the
+// LDS-DMA loader (an LDS-DMA load cannot be masked, but it can be pointed at zeros)
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <int WCO, int WPOS, int TCO, int TPOS, bool DEFORM, bool DMA>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   constexpr int BCO = WCO * TCO * 32;
   constexpr int BPOS = WPOS * TPOS * 32;
   constexpr int NW = BCO / 32;   // 16-byte weight chunks per thread per K step
@@ -92,7 +96,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
   const int wave = tid >> 6;
   const int wco = wave / WPOS;
   const int wpos = wave % WPOS;
-  const int j = tid & 7;    // K chunk (8 bf16) inside the 64-wide K step
+  // K chunk (8 bf16) of this thread inside the 64-wide K step.  Register path: logical chunk
+  // tid&7, written to the swizzled LDS slot.  LDS-DMA path: the hardware writes lane L of a wave
+  // to (wave-uniform base + 16*L), i.e. PHYSICAL slot tid&7 of row tid>>3, so the thread must
+  // FETCH the logical chunk that belongs there: the swizzle moves to the source side (guide rule 21).
+  const int j = DMA ? ((tid & 7) ^ (((tid >> 3) >> 1) & 7)) : (tid & 7);
   const int r0 = tid >> 3;  // tile row handled by this thread (+32*i)
   const int wslot = (j ^ ((r0 >> 1) & 7)) * 16;
 
@@ -136,45 +144,83 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
       rwi[i] = 0;
     }
   }
+  // element offset of each row's (kh=0,kw=0) tap; rows beyond M get a row coordinate that fails
+  // every bounds test, so no separate validity flag is needed in the K loop
+  long long xoff[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    if (rbase[i] < 0) rhi[i] = -0x40000000;
+    xoff[i] = (in_row0 + (rbase[i] < 0 ? 0 : rbase[i]) + (long long)rhi[i] * W + rwi[i]) * a.in_cstride;
+  }
   const uint16_t* wrow = a.w + (long long)(nt * BCO + r0) * a.Kp + j * 8;
+  const long long wstride = 32ll * a.Kp;
+  // loader K state (this thread's 16-byte chunk j of the current K step), advanced incrementally:
+  // no integer division inside the K loop when a tap holds >= 8 chunks (every layer but the stem)
+  int ld_cc, ld_kh, ld_kw, ld_kc = j;
+  {
+    const int tap0 = j / a.cpt;
+    ld_cc = j - tap0 * a.cpt;
+    ld_kh = tap0 / a.kw;
+    ld_kw = tap0 - ld_kh * a.kw;
+  }
+  const uint16_t* ld_wp = wrow;
+  auto advance_k = [&]() {
+    ld_kc += 8;
+    ld_wp += 64;
+    if (a.cpt >= 8) {
+      ld_cc += 8;
+      if (ld_cc >= a.cpt) {
+        ld_cc -= a.cpt;
+        if (++ld_kw == a.kw) {
+          ld_kw = 0;
+          ++ld_kh;
+        }
+      }
+    } else {
+      const int tap = ld_kc / a.cpt;
+      ld_cc = ld_kc - tap * a.cpt;
+      ld_kh = tap / a.kw;
+      ld_kw = tap - ld_kh * a.kw;
+    }
+  };
 
-  Stage8 wreg, xreg;
+  // two staging register sets: plain convs keep TWO K tiles of global loads in flight (tile kt+1
+  // and kt+2 while tile kt is on the MFMAs); the deformable variant uses set A only
+  Stage8 wregA, xregA, wregB, xregB;
   // deformable gather state between "issue" (before the MFMAs) and "finish" (after them)
   constexpr bool DSPLIT = DEFORM && (NX <= 4);
   Stage8 cqa, cqb;                 // 16 corner chunks (rows i, corners 0..3) when DSPLIT
   float cw[DSPLIT ? NX : 1][4];    // corner weights (0 where the corner / sample is invalid)
-  uint32_t xmask[NX];              // plain conv: all-ones where the tap is inside the image
+  uint32_t xmaskA[NX], xmaskB[NX];  // plain conv: all-ones where the tap is inside the image
   const uint32_t relu_m = (a.flags & SM_CONV_IN_RELU) ? 0xffffu : 0u;
 
-  auto load_w = [&](int kt) {
+  // NOTE: load_w / load_x consume the loader K state; call them as a pair, in K order, then advance_k()
+  auto load_w = [&](int, Stage8& wreg) {
     static_for<NW>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      wreg.template at<i>() = *reinterpret_cast<const u32x4*>(wrow + (long long)(32 * i) * a.Kp + kt * 64);
+      wreg.template at<i>() = *reinterpret_cast<const u32x4*>(ld_wp + i * wstride);
     });
   };
 
   // All global loads below are UNCONDITIONAL (clamped address + select): a load inside an
   // exec-masked branch makes hipcc wait vmcnt(0) at the join, which serialises the row loads.
-  auto load_x = [&](int kt) {
-    const int kc = kt * 8 + j;
-    const int tap = kc / a.cpt;
-    const int c0 = (kc - tap * a.cpt) * 8;
-    const int kh = tap / a.kw;
-    const int kw = tap - kh * a.kw;
+  auto load_x = [&](int, Stage8& xreg, uint32_t (&xmask)[NX]) {
+    const int kc = ld_kc;
+    const int tap = ld_kh * a.kw + ld_kw;
+    const int c0 = ld_cc * 8;
     const bool kvalid = kc < a.nchunk;
-    const int dh = kh * a.dil, dw = kw * a.dil;
+    const int dh = ld_kh * a.dil, dw = ld_kw * a.dil;
     if constexpr (!DEFORM) {
       // branch-free: select on the 32-bit row index, AND-masks for zero padding and input ReLU
-      const int irow0 = (int)in_row0;
+      const long long toff = (long long)((dh * W + dw) * a.in_cstride + c0);   // same for all rows
       static_for<NX>([&](auto I) {
         constexpr int i = decltype(I)::value;
         const int hi = rhi[i] + dh, wi = rwi[i] + dw;
-        const bool ok = kvalid && rbase[i] >= 0 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-        const int prow = ok ? (irow0 + rbase[i] + hi * W + wi) : 0;
-        const int pc0 = ok ? c0 : 0;
+        const bool ok = kvalid && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        const long long eo = ok ? xoff[i] + toff : 0ll;
         // raw load now; the padding / ReLU masks are applied in finish_x() AFTER the MFMAs, so
         // the wait for this load sits behind the matrix work instead of in front of it
-        xreg.template at<i>() = *reinterpret_cast<const u32x4*>(a.x + (long long)prow * a.in_cstride + pc0);
+        xreg.template at<i>() = *reinterpret_cast<const u32x4*>(a.x + eo);
         xmask[i] = ok ? 0xffffffffu : 0u;
       });
     } else {
@@ -187,13 +233,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
       float2 off[NX];
       static_for<NX>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        const bool ok = kvalid && rbase[i] >= 0;
+        const bool ok = kvalid && rhi[i] > -0x20000000;
         const long long oo = ok ? (orow0 + 32 * i) * (long long)(a.dg * ntap * 2) + (g * ntap + tap) * 2 : 0ll;
         off[i] = *reinterpret_cast<const float2*>(a.offset + oo);
       });
       static_for<NX>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        const bool ok = kvalid && rbase[i] >= 0;
+        const bool ok = kvalid && rhi[i] > -0x20000000;
         const float h_im = (float)(rhi[i] + dh) + off[i].x;
         const float w_im = (float)(rwi[i] + dw) + off[i].y;
         const bool inr = ok && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
@@ -244,16 +290,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     }
   };
 
-  auto finish_x = [&]() {
+  auto finish_x = [&](Stage8& xreg, uint32_t (&xmask)[NX]) {
     if constexpr (!DEFORM) {
       static_for<NX>([&](auto I) {
         constexpr int i = decltype(I)::value;
         u32x4 v = xreg.template at<i>();
         const uint32_t m = xmask[i];
-        v.x = (v.x & ~(((v.x >> 15) & 0x00010001u) * relu_m)) & m;
-        v.y = (v.y & ~(((v.y >> 15) & 0x00010001u) * relu_m)) & m;
-        v.z = (v.z & ~(((v.z >> 15) & 0x00010001u) * relu_m)) & m;
-        v.w = (v.w & ~(((v.w >> 15) & 0x00010001u) * relu_m)) & m;
+        if (relu_m) {   // block-uniform; only the FPN P7 conv takes it
+          v.x &= ~(((v.x >> 15) & 0x00010001u) * relu_m);
+          v.y &= ~(((v.y >> 15) & 0x00010001u) * relu_m);
+          v.z &= ~(((v.z >> 15) & 0x00010001u) * relu_m);
+          v.w &= ~(((v.w >> 15) & 0x00010001u) * relu_m);
+        }
+        v.x &= m;
+        v.y &= m;
+        v.z &= m;
+        v.w &= m;
         xreg.template at<i>() = v;
       });
     }
@@ -280,7 +332,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     }
   };
 
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, Stage8& wreg, Stage8& xreg) {
     unsigned char* Wb = smem + buf * STAGE;
     unsigned char* Xb = Wb + BCO * 128;
     static_for<NW>([&](auto I) {
@@ -307,20 +359,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
   const int wrow_off = (wco * TCO * 32 + l31) * 128;
   const int xrow_off = BCO * 128 + (wpos * TPOS * 32 + l31) * 128;
 
-  load_w(0);
-  load_x(0);
-  finish_x();
-  store_tile(0);
-  __syncthreads();
-
-  const int nk = a.nk;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const bool more = (kt + 1) < nk;
-    if (more) {
-      load_w(kt + 1);
-      load_x(kt + 1);
-    }
+  auto compute = [&](int buf) {
     const unsigned char* S = smem + buf * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -336,12 +375,109 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         for (int tp = 0; tp < TPOS; ++tp)
           acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
     }
-    if (more) {
-      finish_x();
-      store_tile(buf ^ 1);
+  };
+
+  const int nk = a.nk;
+  if constexpr (DMA) {
+    // ---- LDS-DMA main loop: global_load_lds_dwordx4 straight into the swizzled LDS image, no
+    // staging VGPRs, no ds_write pass, no mask pass.  Two LDS stages; the __syncthreads() that ends
+    // a K step also drains the DMA queue (hipcc emits vmcnt(0) in front of the barrier).
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    const int wave_row = (tid >> 6) * 8;   // first tile row written by this wave (+32*i)
+    auto dma_tile = [&](int buf) {
+      unsigned char* Wb = smem + buf * STAGE;
+      unsigned char* Xb = Wb + BCO * 128;
+      const int c0 = ld_cc * 8;
+      const bool kvalid = ld_kc < a.nchunk;
+      const int dh = ld_kh * a.dil, dw = ld_kw * a.dil;
+      const long long toff = (long long)((dh * W + dw) * a.in_cstride + c0);
+      static_for<NW>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        __builtin_amdgcn_global_load_lds((glb_void*)(ld_wp + i * wstride), (lds_void*)(Wb + (wave_row + 32 * i) * 128),
+                                         16, 0, 0);
+      });
+      static_for<NX>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int hi = rhi[i] + dh, wi = rwi[i] + dw;
+        const bool ok = kvalid && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        const uint16_t* src = ok ? (a.x + xoff[i] + toff) : reinterpret_cast<const uint16_t*>(g_zero16);
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Xb + (wave_row + 32 * i) * 128), 16, 0, 0);
+      });
+      advance_k();
+    };
+    dma_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) dma_tile(buf ^ 1);
+      compute(buf);
+      __syncthreads();
+    }
+  } else {
+  load_w(0, wregA);
+  load_x(0, xregA, xmaskA);
+  advance_k();
+  finish_x(xregA, xmaskA);
+  store_tile(0, wregA, xregA);
+  // Depth-2 register prefetch was measured NEUTRAL on MI355X (tower 616 vs 618 TF/s, layer3/4
+  // 3x3 unchanged): the K loop is VALU/issue bound, not load-latency bound; it costs 36 VGPRs,
+  // so it is compiled out.  Kept for future A/B.
+  constexpr bool PF2 = false;
+  if constexpr (PF2) {
+    // register-prefetch depth 2: sets A/B alternate, statically named (loop unrolled by two)
+    if (nk > 1) {
+      load_w(1, wregA);
+      load_x(1, xregA, xmaskA);
+      advance_k();
     }
     __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      // even step: LDS[0] = tile kt, set A = tile kt+1 (in flight), issue tile kt+2 -> set B
+      if (kt + 2 < nk) {
+        load_w(kt + 2, wregB);
+        load_x(kt + 2, xregB, xmaskB);
+        advance_k();
+      }
+      compute(0);
+      if (kt + 1 < nk) {
+        finish_x(xregA, xmaskA);
+        store_tile(1, wregA, xregA);
+      }
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      // odd step: LDS[1] = tile kt+1, set B = tile kt+2 (in flight), issue tile kt+3 -> set A
+      if (kt + 3 < nk) {
+        load_w(kt + 3, wregA);
+        load_x(kt + 3, xregA, xmaskA);
+        advance_k();
+      }
+      compute(1);
+      if (kt + 2 < nk) {
+        finish_x(xregB, xmaskB);
+        store_tile(0, wregB, xregB);
+      }
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      const bool more = (kt + 1) < nk;
+      if (more) {
+        load_w(kt + 1, wregA);
+        load_x(kt + 1, xregA, xmaskA);
+        advance_k();
+      }
+      compute(buf);
+      if (more) {
+        finish_x(xregA, xmaskA);
+        store_tile(buf ^ 1, wregA, xregA);
+      }
+      __syncthreads();
+    }
   }
+  }  // !DMA
 
   // ---- epilogue: (acc + bias) * level_scale -> f32 tile in LDS -> coalesced 16-byte row
   // segments (+ residual) (relu) -> bf16 / f32.  The MFMA C layout gives a lane 4 couts of one
@@ -518,12 +654,19 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   const long long nblk = (long long)t * a.ntn;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
   dim3 grid((unsigned)nblk), block(256);
-  if (tile == 128)
-    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, DEFORM>), grid, block, 0, stream, a);
-  else if (tile == 64)
-    hipLaunchKernelGGL((conv_igemm_kernel<1, 4, 2, 2, DEFORM>), grid, block, 0, stream, a);
-  else
-    hipLaunchKernelGGL((conv_igemm_kernel<1, 4, 1, 2, DEFORM>), grid, block, 0, stream, a);
+  // LDS-DMA loader for plain convs; the register-staged loader where VALU must touch the operand
+  // (deformable gather, input ReLU) or when the A/B debug flag asks for it
+  const bool dma = !DEFORM && !(d->flags & (SM_CONV_IN_RELU | SM_CONV_DBG_REG_STAGING));
+  if (tile == 128) {
+    if (dma) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, DEFORM, false>), grid, block, 0, stream, a);
+  } else if (tile == 64) {
+    if (dma) hipLaunchKernelGGL((conv_igemm_kernel<1, 4, 2, 2, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<1, 4, 2, 2, DEFORM, false>), grid, block, 0, stream, a);
+  } else {
+    if (dma) hipLaunchKernelGGL((conv_igemm_kernel<1, 4, 1, 2, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<1, 4, 1, 2, DEFORM, false>), grid, block, 0, stream, a);
+  }
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
