@@ -122,23 +122,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ndet = eng.results()["ndet"].cpu().tolist()
+    from sipmask_amd.dist_shard import timed_steps, gather_counts
+    # barrier + torch.cuda.synchronize() on both sides, MAX over ranks (tested with gloo in tests/test_dist_shard.py)
+    elapsed = timed_steps(step, args.steps, sync_fn=torch.cuda.synchronize, device=dev)
+    ndet = gather_counts(eng.results()["ndet"].to(torch.int64), device=dev).cpu().tolist()
 
     # ---- per-step HIP-event breakdown (eager, on the launch stream) -> roofline of the dominant kernel
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in eng.steps]

@@ -385,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
     const int wave_row = (tid >> 6) * 8;   // first tile row written by this wave (+32*i)
+    const unsigned long long zero_page = (unsigned long long)g_zero16;
     auto dma_tile = [&](int buf) {
       unsigned char* Wb = smem + buf * STAGE;
       unsigned char* Xb = Wb + BCO * 128;
@@ -401,7 +402,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
         constexpr int i = decltype(I)::value;
         const int hi = rhi[i] + dh, wi = rwi[i] + dw;
         const bool ok = kvalid && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-        const uint16_t* src = ok ? (a.x + xoff[i] + toff) : reinterpret_cast<const uint16_t*>(g_zero16);
+        // bitwise select of the 64-bit address: a ?: between the tensor and the zero page makes
+        // hipcc emit TWO exec-masked DMA instructions (one per source) instead of one
+        const unsigned long long pm = ok ? ~0ull : 0ull;
+        const unsigned long long src = ((unsigned long long)(a.x + xoff[i] + toff) & pm) | (zero_page & ~pm);
         __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Xb + (wave_row + 32 * i) * 128), 16, 0, 0);
       });
       advance_k();
@@ -582,6 +586,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
     }
   }
 }
+
+
+// NOTE (round 1 experiment, removed): a 256-cout x 128-position, 8-wave, 3-stage LDS-DMA variant
+// with counted vmcnt(6) + raw s_barrier measured 736 TF/s on the tower conv vs 716-757 for two
+// 128x128 blocks per CU, and lost on small-M layers (half as many blocks): the K loop is not
+// bound by prefetch depth or L2->LDS bytes.  See DESIGN.md section 6.
 
 template <bool DEFORM>
 int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,

@@ -1,0 +1,69 @@
+"""Batch sharding for multi-GPU inference: one process per GPU, each rank owns a disjoint slice of the images,
+NO data-path collective (the reference does the same with DistributedSampler(shuffle=False) + per-GPU forward,
+M/tools/test.py:120-149).  The only collectives are a barrier + a MAX all-reduce around a timed region and an
+all-gather of small host-side results (reference: M/mmdet/apis/test.py:75-147 collects pickles).
+Backend-agnostic (RCCL via "nccl" on GPUs; "gloo" in the CPU tests).
+"""
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n_items, rank, world_size):
+    """Contiguous slice [lo, hi) of n_items owned by ``rank``; sizes differ by at most one and
+    lower ranks get the extra items (the order DistributedSampler(shuffle=False) would give after
+    a sort by rank)."""
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def timed_steps(step_fn, steps, sync_fn=None, device=None):
+    """Run ``step_fn`` ``steps`` times between two (barrier + device sync) fences and return the MAX
+    elapsed seconds over ranks -- the bench.py contract."""
+    rank, ws = world()
+
+    def fence():
+        if sync_fn is not None:
+            sync_fn()
+        if ws > 1:
+            dist.barrier()
+            if sync_fn is not None:
+                sync_fn()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if ws > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device or "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def gather_counts(local_counts, device=None):
+    """All-gather a small 1-D int tensor per rank (e.g. detections per image) onto every rank,
+    concatenated in rank order = global image order of shard_range."""
+    rank, ws = world()
+    t = torch.as_tensor(local_counts, dtype=torch.int64, device=device or "cpu").reshape(-1)
+    if ws == 1:
+        return t
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(sizes, n)
+    mx = int(max(int(s.item()) for s in sizes))
+    pad = torch.zeros(mx, dtype=torch.int64, device=t.device)
+    pad[:t.numel()] = t
+    bufs = [torch.zeros_like(pad) for _ in range(ws)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:int(s.item())] for b, s in zip(bufs, sizes)])
