@@ -1,0 +1,117 @@
+"""GPU tests of the reference-facing API (registry-built modules): SipMaskHead.forward / get_masks /
+get_bboxes on caller tensors, SipMask.simple_test, DeformConv module -- against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model as OM  # noqa: E402
+from oracle import ops as O  # noqa: E402
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def det():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd.synthetic import build_synthetic_detector
+    d = build_synthetic_detector(50, seed=3)
+    with torch.no_grad():
+        d.bbox_head.fcos_cls.bias.fill_(-7.5)
+    return d
+
+
+def test_head_forward_api_matches_oracle(det):
+    """SipMaskHead.forward(feats) on caller-provided FPN features (bf16-representable)."""
+    g = torch.Generator().manual_seed(0)
+    sizes = [(24, 32), (12, 16), (6, 8), (3, 4), (2, 2)]
+    feats = [torch.randn(2, 256, h, w, generator=g).to(torch.bfloat16).float() for h, w in sizes]
+    sd = {"bbox_head." + k: v.detach().cpu() for k, v in det.bbox_head.state_dict().items()}
+    ref = OM.head_forward(sd, feats)
+    out = det.bbox_head([f.cuda() for f in feats])
+    torch.cuda.synchronize()
+    names = ("cls", "bbox", "ctr", "cof")
+    tol = dict(cls=0.08, bbox=0.03, ctr=0.08, cof=0.08)
+    for name, got_l, ref_l in zip(names, out[:4], ref[:4]):
+        for l in range(5):
+            assert got_l[l].shape == ref_l[l].shape
+            b0 = -7.5 if name == "cls" else 0.0
+            assert _rel(got_l[l] - b0, ref_l[l] - b0) < tol[name], (name, l, _rel(got_l[l] - b0, ref_l[l] - b0))
+    assert out[4].shape == ref[4].shape and _rel(out[4], ref[4]) < 0.05
+
+
+def test_get_masks_api_bit_exact_vs_oracle(det):
+    """get_masks on caller tensors (identical f32 inputs on both sides): keep indices / labels
+    bit-exact, boxes equal, masks identical away from the 0.4 threshold.  Also rescale=True."""
+    g = torch.Generator().manual_seed(5)
+    B, C = 2, 80
+    sizes = [(32, 40), (16, 20), (8, 10), (4, 5), (2, 3)]
+    strides = (8, 16, 32, 64, 128)
+    cls = [torch.randn(B, C, h, w, generator=g) * 2 - 4.5 for h, w in sizes]
+    bb = [(torch.randn(B, 4, h, w, generator=g) * 1.5 + 3) * s for (h, w), s in zip(sizes, strides)]
+    ctr = [torch.randn(B, 1, h, w, generator=g) for h, w in sizes]
+    cof = [torch.randn(B, 128, h, w, generator=g) * 0.3 for h, w in sizes]
+    fm = torch.randn(B, 32, 128, 160, generator=g)
+    cfg = dict(OM.DEFAULT_TEST_CFG)
+    for rescale, sf in ((False, 1.0), (True, 1.0)):
+        metas = [dict(img_shape=(256, 320, 3), ori_shape=(256, 320, 3), scale_factor=sf) for _ in range(B)]
+        res = det.bbox_head.get_masks([t.cuda() for t in cls], [t.cuda() for t in bb], [t.cuda() for t in ctr],
+                                      [t.cuda() for t in cof], fm.cuda(), metas, cfg, rescale=rescale)
+        tot = 0
+        for b in range(B):
+            r = OM.get_masks_single([c[b] for c in cls], [x[b] for x in bb], [c[b] for c in ctr], [c[b] for c in cof],
+                                    fm[b], (256, 320, 3), cfg, sf, rescale)
+            d, l, k, m = res[b]
+            tot += d.shape[0]
+            np.testing.assert_array_equal(k.cpu().numpy(), r["idxs_keep"])
+            np.testing.assert_array_equal(l.cpu().numpy(), r["det_labels"])
+            np.testing.assert_allclose(d.cpu().numpy(), r["det_bboxes"], rtol=1e-6, atol=1e-6)
+            if d.shape[0]:
+                diff = m.cpu() != r["masks"]
+                assert bool(((r["up"] - 0.4).abs()[diff] < 1e-4).all()) and int(diff.sum()) <= 5
+        assert tot > 10
+    out = det.bbox_head.get_bboxes([t.cuda() for t in cls], [t.cuda() for t in bb], [t.cuda() for t in ctr],
+                                   [t.cuda() for t in cof], fm.cuda(), metas, cfg, rescale=False)
+    assert len(out) == B and len(out[0][2]) == C
+    assert sum(len(s) for s in out[0][2]) == out[0][0].shape[0]
+
+
+def test_simple_test_end_to_end(det):
+    img = torch.randn(1, 3, 160, 192, generator=torch.Generator().manual_seed(2)).cuda()
+    meta = [dict(img_shape=(160, 190, 3), ori_shape=(160, 190, 3), pad_shape=(160, 192, 3), scale_factor=1.0, flip=False)]
+    bbox_results, segm_results = det.simple_test(img, meta)
+    assert len(bbox_results) == 80 and len(segm_results) == 80
+    n = sum(b.shape[0] for b in bbox_results)
+    assert n == sum(len(s) for s in segm_results)
+    for b in bbox_results:
+        assert b.shape[1] == 5
+    for s in segm_results:
+        for m in s:
+            assert m.shape == (160, 190) and m.dtype == np.uint8
+    # forward(return_loss=False) takes the reference's nested-list protocol
+    r2 = det([img], [meta], return_loss=False)
+    assert len(r2[0]) == 80
+
+
+def test_deform_conv_module_api():
+    from sipmask_amd.ops import DeformConv
+    torch.manual_seed(0)
+    m = DeformConv(64, 32, 3, padding=1, deformable_groups=4).cuda()
+    x = torch.randn(2, 64, 10, 12).to(torch.bfloat16).float()
+    off = torch.randn(2, 72, 10, 12) * 0.7
+    with torch.no_grad():
+        m.weight.copy_(m.weight.to(torch.bfloat16).float())
+    y = m(x.cuda(), off.cuda())
+    ref = O.deform_conv(x, off, m.weight.detach().cpu(), 1, 1, 1, 4)
+    assert y.shape == ref.shape
+    torch.testing.assert_close(y.cpu(), ref, rtol=2e-2, atol=1.5e-2)
+    with pytest.raises(ValueError):
+        m(x.cuda(), off[:, :36].cuda())          # wrong offset channel count, as deform_conv.py:108-111
+    # input smaller than the kernel: pad / run / crop path (deform_conv.py:239-255)
+    xs = torch.randn(1, 64, 2, 2).cuda()
+    assert m(xs, torch.zeros(1, 72, 2, 2).cuda()).shape == (1, 32, 2, 2)
