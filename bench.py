@@ -152,6 +152,14 @@ def main():
     fpn = [c for c in eng.convs if c.name.startswith("fpn.")]
     fpn_tf = sum(c.flops for c in fpn) / (sum(conv_ms[c.name] for c in fpn) * 1e-3) / 1e12
     achieved = tower_flops / (tower_ms * 1e-3) / 1e12
+    # HBM traffic of the dominant kernel: PMC passes cannot run inside this process; the number
+    # comes from the committed rocprofv3 summary of the same kernel/shape (profiles/), per launch
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_tower_conv.json")
+    if os.path.exists(pmc_file) and B == 4:
+        pmc = json.load(open(pmc_file))
+        traffic = round(pmc["hbm_bytes_per_launch"] / 1e6, 1)
+        traffic_src = "profiles/r01_pmc_tower_conv.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), MB per launch"
     if args.breakdown and rank == 0:
         with open(args.breakdown, "w") as f:
             f.write("# per-step HIP event times (ms), eager launches, batch %d, mean of %d\n" % (B, reps))
@@ -187,7 +195,8 @@ def main():
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "detections_per_image": ndet},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_mb_per_launch": round(towers[0].bytes / 1e6, 1),
                          "kernel": "conv_igemm_kernel<2,2,2,2> tower 3x3 256->256 over 5 FPN levels (M=%d,N=256,K=2304)"
                                    % (B * 22400),
                          "gflop_per_launch": round(tower_flops / 1e9, 2), "ms_per_launch": round(tower_ms, 4),
