@@ -593,6 +593,275 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
 // 128x128 blocks per CU, and lost on small-M layers (half as many blocks): the K loop is not
 // bound by prefetch depth or L2->LDS bytes.  See DESIGN.md section 6.
 
+
+// =====================================================================================
+// LDS-DMA kernel with 32-wide K steps: the same 4-wave tiles, but an LDS footprint small enough
+// (2 x (BCO+BPOS) x 64 B stages, epilogue staged in two half-tile passes) for FOUR blocks per CU.
+// Rationale (ablation): with K=64 steps the MFMA-only loop runs at ~1140
+// TF/s and the DMA-only loop at ~1000 TF/s-equivalent, yet together they reach only ~760: phases
+// of the two co-resident blocks barely overlap.  More, smaller blocks per CU give more phase
+// diversity (the CU always has some wave in its MFMA phase) at the price of twice the barriers.
+// LDS rows are 64 bytes; swizzle slot = chunk ^ ((row>>2)&3) keeps ds_read_b128 conflict free.
+// =====================================================================================
+template <int WCO, int WPOS, int TCO, int TPOS>
+__global__ __launch_bounds__(256, 4) void conv_dma32_kernel(const ConvKArgs a) {
+  constexpr int BCO = WCO * TCO * 32;
+  constexpr int BPOS = WPOS * TPOS * 32;
+  constexpr int NW = (BCO + 63) / 64;   // DMA instructions per thread per K step (weights)
+  constexpr int NX = BPOS / 64;  // (activations)
+  constexpr int STAGE = (BCO + BPOS) * 64;
+  constexpr int EPI_LD = BCO + 4;
+  constexpr int HROWS = BPOS / 2;                  // positions per epilogue pass
+  constexpr int EPI_BYTES = HROWS * EPI_LD * 4;
+  constexpr int SMEM_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+  static_assert(WCO * WPOS == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wco = wave / WPOS;
+  const int wpos = wave % WPOS;
+  // a wave-instruction covers 16 rows x 4 chunks; lane L -> row L>>2 (of the group), physical
+  // slot L&3, so it fetches logical chunk (L&3) ^ ((row>>2)&3) = (L&3) ^ ((L>>4)&3)
+  const int j = (lane & 3) ^ ((lane >> 4) & 3);
+  const int r0 = tid >> 2;   // tile row (+64*i)
+
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, xq = nblk >> 3, xr = nblk & 7;
+  const int tlin = (a.flags & SM_CONV_DBG_LINEAR_TILES)
+                       ? (int)blockIdx.x
+                       : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)(blockIdx.x >> 3);
+  const int nt = tlin % a.ntn;
+  const int mt = tlin / a.ntn;
+  int lev = 0;
+#pragma unroll
+  for (int l = 1; l < SM_MAX_LEVELS; ++l)
+    if (l < a.nlev && mt >= a.tile0[l]) lev = l;
+  const int H = a.in_h[lev], W = a.in_w[lev], Ho = a.out_h[lev], Wo = a.out_w[lev];
+  const int HoWo = Ho * Wo;
+  const int M = a.batch * HoWo;
+  const int m0 = (mt - a.tile0[lev]) * BPOS;
+  const long long in_row0 = a.in_row0[lev];
+
+  int rhi[NX], rwi[NX];
+  long long xoff[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int m = m0 + r0 + 64 * i;
+    if (m < M) {
+      const int n = m / HoWo;
+      const int rem = m - n * HoWo;
+      const int ho = rem / Wo;
+      const int wo = rem - ho * Wo;
+      rhi[i] = ho * a.stride - a.pad;
+      rwi[i] = wo * a.stride - a.pad;
+      xoff[i] = (in_row0 + (long long)n * H * W + (long long)rhi[i] * W + rwi[i]) * a.in_cstride;
+    } else {
+      rhi[i] = -0x40000000;
+      rwi[i] = 0;
+      xoff[i] = 0;
+    }
+  }
+  const uint16_t* ld_wp = a.w + (long long)(nt * BCO + r0) * a.Kp + j * 8;
+  const long long wstride = 64ll * a.Kp;
+  int ld_kc = j, ld_cc, ld_kh, ld_kw;
+  {
+    const int tap0 = j / a.cpt;
+    ld_cc = j - tap0 * a.cpt;
+    ld_kh = tap0 / a.kw;
+    ld_kw = tap0 - ld_kh * a.kw;
+  }
+  const unsigned long long zero_page = (unsigned long long)g_zero16;
+  const int wave_row = wave * 16;   // first tile row written by this wave (+64*i)
+  auto dma_tile = [&](int buf) {
+    unsigned char* Wb = smem + buf * STAGE;
+    unsigned char* Xb = Wb + BCO * 64;
+    const bool kvalid = ld_kc < a.nchunk;
+    const int dh = ld_kh * a.dil, dw = ld_kw * a.dil;
+    const long long toff = (long long)((dh * W + dw) * a.in_cstride + ld_cc * 8);
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      if (BCO >= 64 || wave_row < BCO)   // 32-cout tile: only waves 0,1 own weight rows (wave-uniform)
+        __builtin_amdgcn_global_load_lds((glb_void*)(ld_wp + i * wstride), (lds_void*)(Wb + (wave_row + 64 * i) * 64), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int hi = rhi[i] + dh, wi = rwi[i] + dw;
+      const bool ok = kvalid && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      const unsigned long long pm = ok ? ~0ull : 0ull;
+      const unsigned long long src = ((unsigned long long)(a.x + xoff[i] + toff) & pm) | (zero_page & ~pm);
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Xb + (wave_row + 64 * i) * 64), 16, 0, 0);
+    }
+    ld_kc += 4;
+    ld_wp += 32;
+    if (a.cpt >= 4) {
+      ld_cc += 4;
+      if (ld_cc >= a.cpt) {
+        ld_cc -= a.cpt;
+        if (++ld_kw == a.kw) {
+          ld_kw = 0;
+          ++ld_kh;
+        }
+      }
+    } else {
+      const int tap = ld_kc / a.cpt;
+      ld_cc = ld_kc - tap * a.cpt;
+      ld_kh = tap / a.kw;
+      ld_kw = tap - ld_kh * a.kw;
+    }
+  };
+
+  f32x16 acc[TCO][TPOS];
+#pragma unroll
+  for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TPOS; ++tp)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tc][tp][e] = 0.f;
+
+  const int l31 = lane & 31;
+  const int rsw = (l31 >> 2) & 3;
+  const int khalf = lane >> 5;
+  const int wrow_off = (wco * TCO * 32 + l31) * 64;
+  const int xrow_off = BCO * 64 + (wpos * TPOS * 32 + l31) * 64;
+  auto compute = [&](int buf) {
+    const unsigned char* S = smem + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
+      bf16x8 wf[TCO], xf[TPOS];
+#pragma unroll
+      for (int t = 0; t < TCO; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(S + wrow_off + t * 32 * 64 + slot);
+#pragma unroll
+      for (int t = 0; t < TPOS; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(S + xrow_off + t * 32 * 64 + slot);
+#pragma unroll
+      for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TPOS; ++tp)
+          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+    }
+  };
+
+  const int nk = a.nk * 2;   // Kp is a multiple of 64
+  dma_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) dma_tile(buf ^ 1);
+    compute(buf);
+    __syncthreads();
+  }
+
+  // ---- epilogue in two half-tile passes (positions [p*HROWS, (p+1)*HROWS))
+  const float lscale = a.level_scale[lev];
+  const long long out_row0 = a.out_row0[lev];
+  const bool out_f32 = a.flags & SM_CONV_OUT_F32;
+  float* E = reinterpret_cast<float*>(smem);
+  constexpr int CPR = BCO / 8;
+  constexpr int RPP = 256 / CPR;
+  const int ec = tid % CPR, er = tid / CPR;
+  const int c0 = nt * BCO + ec * 8;
+  const bool has_res = a.flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST);
+  const bool vec_ok = (c0 + 7 < a.cout) && ((a.out_cstride & 7) == 0) && ((a.out_coff & 7) == 0) &&
+                      (!has_res || (a.res_cstride & 7) == 0);
+  const int wave_p0 = wpos * TPOS * 32;            // first position (in the tile) of this wave
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (p) __syncthreads();                          // pass 0 readers are done with E
+    if (wave_p0 / HROWS == p) {
+#pragma unroll
+      for (int tc = 0; tc < TCO; ++tc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cl = wco * TCO * 32 + tc * 32 + 8 * q + 4 * khalf;
+          const int c = nt * BCO + cl;
+          float bv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[e] = (a.bias != nullptr && c + e < a.cout) ? a.bias[c + e] : 0.f;
+#pragma unroll
+          for (int tp = 0; tp < TPOS; ++tp) {
+            const int pl = wave_p0 % HROWS + tp * 32 + l31;
+            float4 v;
+            v.x = acc[tc][tp][4 * q + 0] + bv[0];
+            v.y = acc[tc][tp][4 * q + 1] + bv[1];
+            v.z = acc[tc][tp][4 * q + 2] + bv[2];
+            v.w = acc[tc][tp][4 * q + 3] + bv[3];
+            if (c + 0 < a.scale_nch) v.x *= lscale;
+            if (c + 1 < a.scale_nch) v.y *= lscale;
+            if (c + 2 < a.scale_nch) v.z *= lscale;
+            if (c + 3 < a.scale_nch) v.w *= lscale;
+            *reinterpret_cast<float4*>(E + pl * EPI_LD + cl) = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (c0 < a.cout) {
+#pragma unroll 2
+      for (int r = er; r < HROWS; r += RPP) {
+        const int m = m0 + p * HROWS + r;
+        if (m >= M) break;
+        const float4 lo = *reinterpret_cast<const float4*>(E + r * EPI_LD + ec * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(E + r * EPI_LD + ec * 8 + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (has_res) {
+          long long rrow;
+          if (a.flags & SM_CONV_RES_ADD) {
+            rrow = out_row0 + m;
+          } else {
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int ho = rem / Wo;
+            const int wo = rem - ho * Wo;
+            const int rh = a.res_h[lev], rw = a.res_w[lev];
+            const int sh = min((int)floorf((float)ho * ((float)rh / (float)Ho)), rh - 1);
+            const int sw = min((int)floorf((float)wo * ((float)rw / (float)Wo)), rw - 1);
+            rrow = a.res_row0[lev] + ((long long)n * rh + sh) * rw + sw;
+          }
+          const uint16_t* rp = a.res + rrow * a.res_cstride + c0;
+          if (vec_ok) {
+            float f[8];
+            unpack_bf16x8(*reinterpret_cast<const u32x4*>(rp), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += f[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (c0 + e < a.cout) v[e] += bf16_bits_to_f32(rp[e]);
+          }
+        }
+        if (a.flags & SM_CONV_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        const long long o = (out_row0 + m) * a.out_cstride + a.out_coff + c0;
+        if (out_f32) {
+          float* yp = reinterpret_cast<float*>(a.y) + o;
+          if (vec_ok) {
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (c0 + e < a.cout) yp[e] = v[e];
+          }
+        } else {
+          uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + o;
+          if (vec_ok) {
+            *reinterpret_cast<u32x4*>(yp) = pack_bf16x8_v(v);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (c0 + e < a.cout) yp[e] = (uint16_t)f32_to_bf16_bits(v[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <bool DEFORM>
 int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,
                 const void* residual, void* y, hipStream_t stream) {
@@ -667,6 +936,17 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   // LDS-DMA loader for plain convs; the register-staged loader where VALU must touch the operand
   // (deformable gather, input ReLU) or when the A/B debug flag asks for it
   const bool dma = !DEFORM && !(d->flags & (SM_CONV_IN_RELU | SM_CONV_DBG_REG_STAGING));
+  // K-step width: measured on MI355X (profiles/r01_conv_microbench.txt) the 32-wide / 4-blocks-per-CU
+  // kernel wins for K <= 1152 (all 1x1 convs, the 3x3 convs of layer1/2, the stem: +5..+28 %) and
+  // loses for K >= 2304 (towers, FPN, layer3/4 3x3: -8..-20 %)
+  const bool k32 = (d->flags & SM_CONV_DBG_K32) || (!(d->flags & SM_CONV_DBG_K64) && a.Kp <= 1152);
+  if (dma && k32) {
+    if (tile == 128) hipLaunchKernelGGL((conv_dma32_kernel<2, 2, 2, 2>), grid, block, 0, stream, a);
+    else if (tile == 64) hipLaunchKernelGGL((conv_dma32_kernel<1, 4, 2, 2>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv_dma32_kernel<1, 4, 1, 2>), grid, block, 0, stream, a);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+  }
   if (tile == 128) {
     if (dma) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, DEFORM, false>), grid, block, 0, stream, a);

@@ -28,7 +28,7 @@ def _bf(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def _run_conv(x, w, bias, stride, pad, relu=False, out_f32=False, residual=None, in_relu=False):
+def _run_conv(x, w, bias, stride, pad, relu=False, out_f32=False, residual=None, in_relu=False, extra_flags=0):
     """x [B,C,H,W] f32 (bf16-representable), w [Co,Ci,k,k]; returns NCHW f32 on cpu."""
     from sipmask_amd import hip_ops as H, _lib
     dev = _dev()
@@ -41,6 +41,7 @@ def _run_conv(x, w, bias, stride, pad, relu=False, out_f32=False, residual=None,
     Ho, Wo = (Hh + 2 * pad - k) // stride + 1, (Ww + 2 * pad - k) // stride + 1
     flags = (_lib.SM_CONV_RELU if relu else 0) | (_lib.SM_CONV_OUT_F32 if out_f32 else 0)
     flags |= _lib.SM_CONV_IN_RELU if in_relu else 0
+    flags |= extra_flags
     res = None
     if residual is not None:
         flags |= _lib.SM_CONV_RES_ADD
@@ -77,6 +78,26 @@ def test_conv_igemm_vs_torch(cfg):
     torch.testing.assert_close(y, ref, rtol=1e-4, atol=2e-4)
     yb = _run_conv(x, w, b, s, p, relu=True)
     torch.testing.assert_close(yb, F.relu(ref), rtol=2 ** -7, atol=2e-3)   # + one bf16 rounding
+
+
+@pytest.mark.parametrize("variant", [0x20000000, 0x10000000, 0x08000000])
+def test_conv_loader_variants(variant):
+    """The A/B loader variants (register staging 0x2..., forced 32-wide K steps 0x1..., forced 64-wide
+    0x08...) must give the same
+    results as the default LDS-DMA kernel on every tile shape, incl. residual and ragged tiles."""
+    g = torch.Generator().manual_seed(17)
+    for (B, Ci, Hh, Ww, Co, k, s, p) in [(2, 64, 17, 23, 128, 3, 1, 1), (2, 128, 20, 28, 64, 1, 1, 0),
+                                          (2, 64, 21, 19, 5, 3, 1, 1), (2, 3, 37, 45, 64, 7, 2, 3),
+                                          (1, 768, 10, 14, 512, 1, 1, 0), (1, 256, 25, 42, 256, 3, 2, 1)]:
+        x = _bf(torch.randn(B, Ci, Hh, Ww, generator=g))
+        w = _bf(torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5)
+        b = torch.randn(Co, generator=g)
+        ref = F.conv2d(x, w, b, s, p)
+        r = _bf(torch.randn_like(ref))
+        y = _run_conv(x, w, b, s, p, relu=True, out_f32=True, residual=r, extra_flags=variant)
+        torch.testing.assert_close(y, F.relu(ref + r), rtol=1e-4, atol=2e-4)
+        yb = _run_conv(x, w, b, s, p, extra_flags=variant)
+        torch.testing.assert_close(yb, ref, rtol=2 ** -7, atol=2e-3)
 
 
 def test_conv_residual_and_input_relu():
