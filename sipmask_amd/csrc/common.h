@@ -26,8 +26,12 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
   return u >> 16;
 }
 
+// two f32 -> packed bf16x2 (round to nearest even): one v_cvt_pk_bf16_f32 on gfx950 (no clang
+// builtin; NaN stays NaN) instead of ~8 integer VALU ops per pair
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
 
 __device__ __forceinline__ void unpack_bf16x8(const uint4& v, float* f) {
