@@ -885,7 +885,47 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   a.offset = offset;
   a.nlev = d->nlev;
   a.batch = d->batch;
-  const int bpos = (tile == 128) ? 128 : 256;
+  // LDS-DMA loader for plain convs; the register-staged loader where VALU must touch the operand
+  // (deformable gather, input ReLU) or when the A/B debug flag asks for it
+  const bool dma = !DEFORM && !(d->flags & (SM_CONV_IN_RELU | SM_CONV_DBG_REG_STAGING));
+  const int K = d->kh * d->kw * d->cin;
+  a.Kp = (K + 63) / 64 * 64;
+  // K-step width: measured on MI355X (profiles/r01_conv_microbench.txt) the 32-wide / 4-blocks-per-CU
+  // kernel wins for K <= 1152 (all 1x1 convs, the 3x3 convs of layer1/2, the stem: +5..+28 %) and
+  // loses for K >= 2304 (towers, FPN, layer3/4 3x3: -8..-20 %)
+  const bool k32 = dma && ((d->flags & SM_CONV_DBG_K32) || (!(d->flags & SM_CONV_DBG_K64) && a.Kp <= 1152));
+  // ---- tile selection.  The cout tile is fixed by the weight padding contract (32/64/128) but may
+  // be split further (128 -> 64); the position tile shrinks until the launch has enough blocks to
+  // occupy the chip (256 CUs x 2 or 4 resident blocks): small-M layers (layer3/4, P5-P7, the
+  // 32-channel predictors) are latency bound and want blocks, not reuse.
+  struct Cfg { int bco, bpos; };
+  Cfg cands[3];
+  int ncand = 0;
+  if (!dma) {
+    cands[ncand++] = {tile, tile == 128 ? 128 : 256};
+  } else if (tile == 128) {
+    cands[ncand++] = {128, 128};
+    cands[ncand++] = {128, 64};
+    cands[ncand++] = {64, 64};
+  } else if (tile == 64) {
+    cands[ncand++] = {64, 256};
+    cands[ncand++] = {64, 128};
+    cands[ncand++] = {64, 64};
+  } else {
+    cands[ncand++] = {32, 256};
+    cands[ncand++] = {32, 128};
+  }
+  const long long want = (d->flags & SM_CONV_DBG_BIG_TILES) ? 0 : (k32 ? 768 : 512);
+  int bco = cands[0].bco, bpos = cands[0].bpos;
+  for (int c = 0; c < ncand; ++c) {
+    long long nb = 0;
+    for (int l = 0; l < d->nlev; ++l)
+      nb += sm_cdiv((long long)d->batch * d->out_h[l] * d->out_w[l], cands[c].bpos);
+    nb *= d->cout_pad / cands[c].bco;
+    bco = cands[c].bco;
+    bpos = cands[c].bpos;
+    if (nb >= want) break;
+  }
   int t = 0;
   for (int l = 0; l < SM_MAX_LEVELS; ++l) {
     const bool on = l < d->nlev;
@@ -920,11 +960,9 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   a.out_cstride = d->out_cstride;
   a.out_coff = d->out_coff;
   a.res_cstride = d->res_cstride;
-  const int K = d->kh * d->kw * d->cin;
-  a.Kp = (K + 63) / 64 * 64;
   a.nchunk = K / 8;
   a.cpt = d->cin / 8;
-  a.ntn = d->cout_pad / tile;
+  a.ntn = d->cout_pad / bco;
   a.nk = a.Kp / 64;
   a.flags = d->flags;
   a.scale_nch = d->scale_nch;
@@ -933,30 +971,29 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   const long long nblk = (long long)t * a.ntn;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
   dim3 grid((unsigned)nblk), block(256);
-  // LDS-DMA loader for plain convs; the register-staged loader where VALU must touch the operand
-  // (deformable gather, input ReLU) or when the A/B debug flag asks for it
-  const bool dma = !DEFORM && !(d->flags & (SM_CONV_IN_RELU | SM_CONV_DBG_REG_STAGING));
-  // K-step width: measured on MI355X (profiles/r01_conv_microbench.txt) the 32-wide / 4-blocks-per-CU
-  // kernel wins for K <= 1152 (all 1x1 convs, the 3x3 convs of layer1/2, the stem: +5..+28 %) and
-  // loses for K >= 2304 (towers, FPN, layer3/4 3x3: -8..-20 %)
-  const bool k32 = (d->flags & SM_CONV_DBG_K32) || (!(d->flags & SM_CONV_DBG_K64) && a.Kp <= 1152);
-  if (dma && k32) {
-    if (tile == 128) hipLaunchKernelGGL((conv_dma32_kernel<2, 2, 2, 2>), grid, block, 0, stream, a);
-    else if (tile == 64) hipLaunchKernelGGL((conv_dma32_kernel<1, 4, 2, 2>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv_dma32_kernel<1, 4, 1, 2>), grid, block, 0, stream, a);
-    SM_LAUNCH_CHECK();
-    return SM_OK;
-  }
-  if (tile == 128) {
-    if (dma) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, DEFORM, false>), grid, block, 0, stream, a);
-  } else if (tile == 64) {
-    if (dma) hipLaunchKernelGGL((conv_igemm_kernel<1, 4, 2, 2, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<1, 4, 2, 2, DEFORM, false>), grid, block, 0, stream, a);
+#define SM_LAUNCH(KERNEL) hipLaunchKernelGGL((KERNEL), grid, block, 0, stream, a)
+  if (!dma) {
+    if (tile == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, DEFORM, false>));
+    else if (tile == 64) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 2, DEFORM, false>));
+    else SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 2, DEFORM, false>));
+  } else if (k32) {
+    if (bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2>));
+    else if (bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1>));
+    else if (bco == 64 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 2>));
+    else if (bco == 64 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 1>));
+    else if (bco == 64 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 1, 1>));
+    else if (bco == 32 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 2>));
+    else SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 1>));
   } else {
-    if (dma) hipLaunchKernelGGL((conv_igemm_kernel<1, 4, 1, 2, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<1, 4, 1, 2, DEFORM, false>), grid, block, 0, stream, a);
+    if (bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true>));
+    else if (bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true>));
+    else if (bco == 64 && bpos == 256) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 2, false, true>));
+    else if (bco == 64 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 1, false, true>));
+    else if (bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true>));
+    else if (bco == 32 && bpos == 256) SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 2, false, true>));
+    else SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 1, false, true>));
   }
+#undef SM_LAUNCH
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
