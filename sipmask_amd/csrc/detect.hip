@@ -48,8 +48,15 @@ __device__ void block_bitonic_desc(unsigned long long* a, int P) {
 
 // Exact top-k of keys[0..n) for one block of TK_THREADS threads.  Result: sm.sel[0..k) sorted
 // by (key desc, index asc); low word = 0xffffffff - index.  Requires 1 <= k <= min(n, TK_CAP).
-__device__ void block_topk(const float* __restrict__ keys, int n, int k, TopkSmem& sm) {
+__device__ void block_topk(const float* __restrict__ gkeys, int n, int k, TopkSmem& sm, float* lds_keys = nullptr) {
   const int tid = threadIdx.x;
+  // the keys are scanned 5 times (4 radix rounds + compaction): stage them in LDS when they fit
+  const float* keys = gkeys;
+  if (lds_keys != nullptr) {
+    for (int i = tid; i < n; i += TK_THREADS) lds_keys[i] = gkeys[i];
+    keys = lds_keys;
+    __syncthreads();
+  }
   if (tid == 0) {
     sm.prefix = 0;
     sm.krem = k;
@@ -131,6 +138,7 @@ struct DetArgs {
   int nms_pre, img_h, img_w, kmax;
   float scale_factor;
   int rescale, reg_prescaled;
+  int topk_cache_floats;   // dynamic LDS floats available to det_topk_kernel (0 = scan global memory)
 };
 
 __global__ void det_score_kernel(const float* __restrict__ cls, const float* __restrict__ reg,
@@ -157,6 +165,7 @@ __global__ void det_score_kernel(const float* __restrict__ cls, const float* __r
 __global__ __launch_bounds__(TK_THREADS) void det_topk_kernel(const float* __restrict__ keys,
                                                                int32_t* __restrict__ cand_pos, const DetArgs a) {
   __shared__ TopkSmem sm;
+  extern __shared__ __attribute__((aligned(16))) float topk_cache[];
   const int lev = blockIdx.x, b = blockIdx.y;
   const int n = a.hw[lev];
   const int S = a.pos0[a.nlev];
@@ -165,24 +174,26 @@ __global__ __launch_bounds__(TK_THREADS) void det_topk_kernel(const float* __res
     for (int i = threadIdx.x; i < n; i += TK_THREADS) out[i] = i;
     return;
   }
-  block_topk(keys + (long long)b * S + a.pos0[lev], n, a.nms_pre, sm);
+  block_topk(keys + (long long)b * S + a.pos0[lev], n, a.nms_pre, sm, a.topk_cache_floats >= n ? topk_cache : nullptr);
   for (int i = threadIdx.x; i < a.nms_pre; i += TK_THREADS)
     out[i] = (int32_t)(0xffffffffu - (uint32_t)(sm.sel[i] & 0xffffffffull));
 }
 
-// one wave per 64 consecutive candidates of an image.  Scores are written CLASS-MAJOR
-// ([B][C][kmax]) so that the per-class NMS waves stream them with coalesced loads.
-__global__ __launch_bounds__(64) void det_gather_kernel(const float* __restrict__ cls, const float* __restrict__ reg,
-                                                        const float* __restrict__ cof,
-                                                        const int32_t* __restrict__ cand_pos,
-                                                        float* __restrict__ boxes, float* __restrict__ scores,
-                                                        float* __restrict__ ctr, float* __restrict__ cofs,
-                                                        const DetArgs a) {
+// 256 threads per 64 consecutive candidates of an image: thread = (candidate, class quarter).
+// Scores are written CLASS-MAJOR ([B][C][kmax]) so that the per-class NMS blocks stream them
+// with coalesced loads.
+__global__ __launch_bounds__(256) void det_gather_kernel(const float* __restrict__ cls, const float* __restrict__ reg,
+                                                         const float* __restrict__ cof,
+                                                         const int32_t* __restrict__ cand_pos,
+                                                         float* __restrict__ boxes, float* __restrict__ scores,
+                                                         float* __restrict__ ctr, float* __restrict__ cofs,
+                                                         const DetArgs a) {
   __shared__ long long s_row[64];
-  const int b = blockIdx.y, lane = threadIdx.x;
-  const int k = blockIdx.x * 64 + lane;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int lc = tid & 63, part = tid >> 6;
+  const int k = blockIdx.x * 64 + lc;
   const bool valid = k < a.kmax;
-  long long row = 0;
+  long long row = -1;
   if (valid) {
     int lev = 0;
 #pragma unroll
@@ -191,38 +202,42 @@ __global__ __launch_bounds__(64) void det_gather_kernel(const float* __restrict_
     const int pos = cand_pos[(long long)b * a.kmax + k];
     row = a.row0[lev] + (long long)b * a.hw[lev] + pos;
     const long long o = (long long)b * a.kmax + k;
-    const float* rp = reg + row * a.reg_cs;
-    ctr[o] = sigmoidf_acc(rp[4]);
-    const int s = a.stride[lev];
-    const int py = pos / a.w[lev], px = pos - py * a.w[lev];
-    const float x = (float)(px * s) + (float)(s / 2), y = (float)(py * s) + (float)(s / 2);
-    const float xmax = (float)(a.img_w - 1), ymax = (float)(a.img_h - 1);
-    const float fs = a.reg_prescaled ? 1.f : (float)s;  // bbox_pred.float() * stride (sipmask_head.py:268)
-    float x1 = fminf(fmaxf(__fsub_rn(x, __fmul_rn(rp[0], fs)), 0.f), xmax);
-    float y1 = fminf(fmaxf(__fsub_rn(y, __fmul_rn(rp[1], fs)), 0.f), ymax);
-    float x2 = fminf(fmaxf(__fadd_rn(x, __fmul_rn(rp[2], fs)), 0.f), xmax);
-    float y2 = fminf(fmaxf(__fadd_rn(y, __fmul_rn(rp[3], fs)), 0.f), ymax);
-    if (a.rescale) {
-      x1 /= a.scale_factor;
-      y1 /= a.scale_factor;
-      x2 /= a.scale_factor;
-      y2 /= a.scale_factor;
+    if (part == 0) {
+      const float* rp = reg + row * a.reg_cs;
+      ctr[o] = sigmoidf_acc(rp[4]);
+      const int s = a.stride[lev];
+      const int py = pos / a.w[lev], px = pos - py * a.w[lev];
+      const float x = (float)(px * s) + (float)(s / 2), y = (float)(py * s) + (float)(s / 2);
+      const float xmax = (float)(a.img_w - 1), ymax = (float)(a.img_h - 1);
+      const float fs = a.reg_prescaled ? 1.f : (float)s;  // bbox_pred.float() * stride (sipmask_head.py:268)
+      float x1 = fminf(fmaxf(__fsub_rn(x, __fmul_rn(rp[0], fs)), 0.f), xmax);
+      float y1 = fminf(fmaxf(__fsub_rn(y, __fmul_rn(rp[1], fs)), 0.f), ymax);
+      float x2 = fminf(fmaxf(__fadd_rn(x, __fmul_rn(rp[2], fs)), 0.f), xmax);
+      float y2 = fminf(fmaxf(__fadd_rn(y, __fmul_rn(rp[3], fs)), 0.f), ymax);
+      if (a.rescale) {
+        x1 /= a.scale_factor;
+        y1 /= a.scale_factor;
+        x2 /= a.scale_factor;
+        y2 /= a.scale_factor;
+      }
+      *reinterpret_cast<float4*>(boxes + o * 4) = make_float4(x1, y1, x2, y2);
+      s_row[lc] = row;
     }
-    *reinterpret_cast<float4*>(boxes + o * 4) = make_float4(x1, y1, x2, y2);
-    // class scores: lane = candidate (coalesced class-major stores; the 64 source rows stay in L1)
+    // class scores: lanes = candidates (coalesced class-major stores; the source rows stay in L1)
     const float* cp = cls + row * a.cls_cs + a.cls_co;
     float* sp = scores + (long long)b * a.C * a.kmax + k;
-    for (int c = 0; c < a.C; ++c) sp[(long long)c * a.kmax] = sigmoidf_acc(cp[c]);
+    for (int c = part; c < a.C; c += 4) sp[(long long)c * a.kmax] = sigmoidf_acc(cp[c]);
+  } else if (part == 0) {
+    s_row[lc] = -1;
   }
-  s_row[lane] = valid ? row : -1;
   __syncthreads();
-  // coefficients: lanes sweep the 128 channels of one candidate at a time (coalesced both sides)
-  for (int j = 0; j < 64; ++j) {
-    const long long r = s_row[j];
-    if (r < 0) break;
-    const long long o = (long long)b * a.kmax + blockIdx.x * 64 + j;
-    cofs[o * 128 + lane] = cof[r * a.cof_cs + a.cof_co + lane];
-    cofs[o * 128 + 64 + lane] = cof[r * a.cof_cs + a.cof_co + 64 + lane];
+  // coefficients: 128 threads sweep the 128 channels of one candidate (coalesced both sides)
+  const int ch = tid & 127;
+  for (int jj = tid >> 7; jj < 64; jj += 2) {
+    const long long r = s_row[jj];
+    if (r < 0) continue;
+    const long long o = (long long)b * a.kmax + blockIdx.x * 64 + jj;
+    cofs[o * 128 + ch] = cof[r * a.cof_cs + a.cof_co + ch];
   }
 }
 
@@ -239,7 +254,7 @@ __device__ __forceinline__ float iou_plus1(const float4 a, const float4 b) {
   return __fdiv_rn(inter, __fsub_rn(__fadd_rn(sa, sb), inter));
 }
 
-constexpr int NMS_THREADS = 256;   // 4 waves per (image, class)
+constexpr int NMS_THREADS = 1024;  // 16 waves per (image, class): heavy classes (thousands of boxes) set the tail
 
 // LDS carve (dynamic): keys[P] (u64), kept_box[P] (float4), kept_idx[P] (u32); static: NmsSmem.
 struct NmsSmem {
@@ -513,6 +528,7 @@ int fill_det_args(const sm_det_desc* d, DetArgs& a) {
   a.scale_factor = d->scale_factor;
   a.rescale = d->rescale;
   a.reg_prescaled = d->reg_prescaled;
+  a.topk_cache_floats = 0;
   return SM_OK;
 }
 
@@ -544,8 +560,17 @@ extern "C" int sm_det_select(const sm_det_desc* d, const float* cls, const float
   int g = (int)((total + 255) / 256);
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(det_score_kernel, dim3(g), dim3(256), 0, s, cls, reg, keys, a);
-  hipLaunchKernelGGL(det_topk_kernel, dim3(a.nlev, a.batch), dim3(TK_THREADS), 0, s, keys, cand_pos, a);
-  hipLaunchKernelGGL(det_gather_kernel, dim3((a.kmax + 63) / 64, a.batch), dim3(64), 0, s, cls, reg, cof, cand_pos, boxes, scores,
+  int maxn = 0;
+  for (int l = 0; l < a.nlev; ++l) maxn = a.hw[l] > maxn ? a.hw[l] : maxn;
+  size_t cache_bytes = (size_t)maxn * sizeof(float);
+  if (cache_bytes > 128 * 1024) cache_bytes = 0;   // TopkSmem (17 KiB) + cache must fit 160 KiB
+  a.topk_cache_floats = (int)(cache_bytes / sizeof(float));
+  if (cache_bytes > 48 * 1024 &&
+      hipFuncSetAttribute((const void*)det_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cache_bytes) !=
+          hipSuccess)
+    return SM_ERR_LAUNCH;
+  hipLaunchKernelGGL(det_topk_kernel, dim3(a.nlev, a.batch), dim3(TK_THREADS), cache_bytes, s, keys, cand_pos, a);
+  hipLaunchKernelGGL(det_gather_kernel, dim3((a.kmax + 63) / 64, a.batch), dim3(256), 0, s, cls, reg, cof, cand_pos, boxes, scores,
                      ctr, cofs, a);
   // every image has exactly kmax candidates (sum_l min(nms_pre, hw_l))
   if (a.batch > 1024) return SM_ERR_UNSUPPORTED;
