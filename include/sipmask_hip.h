@@ -95,6 +95,13 @@ int sm_conv2d(const sm_conv_desc* d, const void* x, const void* w, const float* 
 int sm_deform_conv2d(const sm_conv_desc* d, const void* x, const float* offset, const void* w,
                      const float* bias, void* y, sm_stream_t stream);
 
+/* sm_conv2d / sm_deform_conv2d (offset != NULL) with the GroupNorm statistics of the output fused in the
+ * epilogue: gn_stats f32 [batch][nlev][cout/8][2] = (sum, sum of squares) per (image, level, group of 8
+ * channels), zeroed by the call.  Feed it to sm_groupnorm_apply.  Needs cout % 8 == 0, bf16 output. */
+int sm_conv2d_gn_stats(const sm_conv_desc* d, const void* x, const float* offset, const void* w,
+                       const float* bias, const void* residual, void* y, float* gn_stats,
+                       sm_stream_t stream);
+
 /* offset = W_off (72x4) . (level_scale * reg[row][0:4]) -- FeatureAlign.conv_offset (level_scale
  * NULL = 1 when reg already carries Scale),
  * sipmask_head.py:30-33,50.  reg: f32 rows with stride reg_cstride, out f32 [rows][nout]. */
@@ -108,6 +115,11 @@ int sm_offset_linear(const float* reg, int reg_cstride, const float* w_off, int 
 int sm_groupnorm(const void* x, void* y, const float* gamma, const float* beta, float* stats,
                  int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels,
                  int groups, float eps, int relu, sm_stream_t stream);
+
+/* the normalisation half of sm_groupnorm, given precomputed statistics (same stats layout) */
+int sm_groupnorm_apply(const void* x, void* y, const float* gamma, const float* beta, const float* stats,
+                       int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels,
+                       int groups, float eps, int relu, sm_stream_t stream);
 
 /* 3x3 stride-2 pad-1 max pool (resnet.py:460), NHWC bf16. */
 int sm_maxpool3x3s2(const void* x, void* y, int batch, int h, int w, int c, sm_stream_t stream);

@@ -38,6 +38,7 @@ struct ConvKArgs {
   int scale_nch;
   float level_scale[SM_MAX_LEVELS];
   int dg, cpg8;  // deform groups, chunks (of 8 ch) per deform group
+  float* gn_stats;  // optional fused GroupNorm statistics [batch][nlev][cout/8][2] (sum, sum of squares)
 };
 
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
@@ -87,7 +88,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   constexpr int STAGE = (BCO + BPOS) * 128;
   constexpr int EPI_LD = BCO + 4;                  // padded f32 row of the epilogue staging tile
   constexpr int EPI_BYTES = BPOS * EPI_LD * 4;
-  constexpr int SMEM_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+  constexpr int GN_SEG = 4;                        // images a tile may span before falling back to global atomics
+  constexpr int GN_BYTES = GN_SEG * (BCO / 8) * 2 * 4;
+  constexpr int SMEM_MAIN = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+  constexpr int SMEM_BYTES = SMEM_MAIN + GN_BYTES;  // ONE LDS object (a second one de-pipelines the DMA loop)
   static_assert(WCO * WPOS == 4, "4 waves");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
@@ -491,6 +495,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   const long long out_row0 = a.out_row0[lev];
   const bool out_f32 = a.flags & SM_CONV_OUT_F32;
   float* E = reinterpret_cast<float*>(smem);
+  float* gn_bins = reinterpret_cast<float*>(smem + SMEM_MAIN);   // [GN_SEG][BCO/8][2]
+  if (a.gn_stats != nullptr && tid < GN_SEG * (BCO / 8) * 2) gn_bins[tid] = 0.f;
 #pragma unroll
   for (int tc = 0; tc < TCO; ++tc) {
 #pragma unroll
@@ -524,6 +530,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   const bool has_res = a.flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST);
   const bool vec_ok = (c0 + 7 < a.cout) && ((a.out_cstride & 7) == 0) && ((a.out_coff & 7) == 0) &&
                       (!has_res || (a.res_cstride & 7) == 0);
+  // fused GroupNorm statistics (8 channels per group == this thread's 8 couts): accumulate over the
+  // thread's rows while the image index is unchanged, flush into LDS bins, one global atomic per bin
+  const bool gn = a.gn_stats != nullptr;
+  const int gn_groups = a.cout >> 3;
+  const int gn_n0 = m0 / HoWo;               // first image touched by this tile
+  int gn_n = gn_n0, gn_bound = (gn_n0 + 1) * HoWo;
+  float gn_s = 0.f, gn_ss = 0.f;
+  auto gn_flush = [&]() {
+    if (gn_s != 0.f || gn_ss != 0.f) {
+      const int seg = gn_n - gn_n0;
+      if (seg < GN_SEG) {
+        atomicAdd(&gn_bins[(seg * (BCO / 8) + ec) * 2 + 0], gn_s);
+        atomicAdd(&gn_bins[(seg * (BCO / 8) + ec) * 2 + 1], gn_ss);
+      } else {
+        float* st = a.gn_stats + (((long long)gn_n * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
+        atomicAdd(st, gn_s);
+        atomicAdd(st + 1, gn_ss);
+      }
+    }
+    gn_s = 0.f;
+    gn_ss = 0.f;
+  };
   if (c0 < a.cout) {
 #pragma unroll 2
     for (int r = er; r < BPOS; r += RPP) {
@@ -558,6 +586,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
             if (c0 + e < a.cout) v[e] += bf16_bits_to_f32(rp[e]);
         }
       }
+      if (gn) {
+        while (m >= gn_bound) {   // crossed into the next image
+          gn_flush();
+          ++gn_n;
+          gn_bound += HoWo;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          gn_s += v[e];
+          gn_ss += v[e] * v[e];
+        }
+      }
       if (a.flags & SM_CONV_RELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -583,6 +623,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
             if (c0 + e < a.cout) yp[e] = (uint16_t)f32_to_bf16_bits(v[e]);
         }
       }
+    }
+  }
+  if (gn) {
+    gn_flush();
+    __syncthreads();
+    if (tid < GN_SEG * (BCO / 8) * 2) {
+      const float v = gn_bins[tid];
+      const int seg = tid / ((BCO / 8) * 2), rem = tid - seg * ((BCO / 8) * 2);
+      const int g = (nt * BCO >> 3) + (rem >> 1);
+      if (v != 0.f && g < gn_groups && gn_n0 + seg < a.batch)
+        atomicAdd(a.gn_stats + (((long long)(gn_n0 + seg) * a.nlev + lev) * gn_groups + g) * 2 + (rem & 1), v);
     }
   }
 }
@@ -864,7 +915,7 @@ __global__ __launch_bounds__(256, 4) void conv_dma32_kernel(const ConvKArgs a) {
 
 template <bool DEFORM>
 int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,
-                const void* residual, void* y, hipStream_t stream) {
+                const void* residual, void* y, hipStream_t stream, float* gn_stats = nullptr) {
   if (!d || !x || !w || !y) return SM_ERR_BAD_ARG;
   if (d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return SM_ERR_BAD_SHAPE;
   if (d->cin % 8 != 0 || d->cin < 8 || d->cout < 1) return SM_ERR_BAD_SHAPE;
@@ -883,6 +934,12 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   a.res = (const uint16_t*)residual;
   a.y = y;
   a.offset = offset;
+  a.gn_stats = gn_stats;
+  if (gn_stats != nullptr) {
+    if (d->cout % 8 != 0 || (d->flags & SM_CONV_OUT_F32)) return SM_ERR_UNSUPPORTED;
+    if (hipMemsetAsync(gn_stats, 0, sizeof(float) * 2 * d->batch * d->nlev * (d->cout / 8), stream) != hipSuccess)
+      return SM_ERR_LAUNCH;
+  }
   a.nlev = d->nlev;
   a.batch = d->batch;
   // LDS-DMA loader for plain convs; the register-staged loader where VALU must touch the operand
@@ -893,7 +950,8 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   // K-step width: measured on MI355X (profiles/r01_conv_microbench.txt) the 32-wide / 4-blocks-per-CU
   // kernel wins for K <= 1152 (all 1x1 convs, the 3x3 convs of layer1/2, the stem: +5..+28 %) and
   // loses for K >= 2304 (towers, FPN, layer3/4 3x3: -8..-20 %)
-  const bool k32 = dma && ((d->flags & SM_CONV_DBG_K32) || (!(d->flags & SM_CONV_DBG_K64) && a.Kp <= 1152));
+  const bool k32 = dma && gn_stats == nullptr &&
+                   ((d->flags & SM_CONV_DBG_K32) || (!(d->flags & SM_CONV_DBG_K64) && a.Kp <= 1152));
   // ---- tile selection.  The cout tile is fixed by the weight padding contract (32/64/128) but may
   // be split further (128 -> 64); the position tile shrinks until the launch has enough blocks to
   // occupy the chip (256 CUs x 2 or 4 resident blocks): small-M layers (layer3/4, P5-P7, the
@@ -1005,6 +1063,15 @@ extern "C" int sm_conv_cout_tile(int cout) { return cout <= 32 ? 32 : (cout <= 6
 extern "C" int sm_conv2d(const sm_conv_desc* d, const void* x, const void* w, const float* bias,
                          const void* residual, void* y, sm_stream_t stream) {
   return launch_conv<false>(d, x, nullptr, w, bias, residual, y, sm_hip_stream(stream));
+}
+
+extern "C" int sm_conv2d_gn_stats(const sm_conv_desc* d, const void* x, const float* offset, const void* w,
+                                  const float* bias, const void* residual, void* y, float* gn_stats,
+                                  sm_stream_t stream) {
+  if (!gn_stats) return SM_ERR_BAD_ARG;
+  if (offset != nullptr)
+    return launch_conv<true>(d, x, offset, w, bias, nullptr, y, sm_hip_stream(stream), gn_stats);
+  return launch_conv<false>(d, x, nullptr, w, bias, residual, y, sm_hip_stream(stream), gn_stats);
 }
 
 extern "C" int sm_deform_conv2d(const sm_conv_desc* d, const void* x, const float* offset, const void* w,

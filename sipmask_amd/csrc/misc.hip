@@ -273,14 +273,11 @@ extern "C" int sm_maxpool3x3s2(const void* x, void* y, int batch, int h, int w, 
   return SM_OK;
 }
 
-extern "C" int sm_groupnorm(const void* x, void* y, const float* gamma, const float* beta, float* stats, int batch,
-                            int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups, float eps,
-                            int relu, sm_stream_t stream) {
-  if (!x || !y || !gamma || !beta || !stats || !hw || !row0) return SM_ERR_BAD_ARG;
+static int gn_fill_args(GnArgs& a, int& t, int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels,
+                        int groups, float eps, int relu) {
   if (nlev < 1 || nlev > SM_MAX_LEVELS || channels % (8 * groups) != 0 || channels > 2048 || 256 % (channels / 8) != 0)
     return SM_ERR_BAD_SHAPE;
   if (groups > 256) return SM_ERR_BAD_SHAPE;
-  GnArgs a;
   a.nlev = nlev;
   a.batch = batch;
   a.C = channels;
@@ -288,7 +285,7 @@ extern "C" int sm_groupnorm(const void* x, void* y, const float* gamma, const fl
   a.cpg = channels / groups;
   a.eps = eps;
   a.relu = relu;
-  int t = 0;
+  t = 0;
   for (int l = 0; l < SM_MAX_LEVELS; ++l) {
     a.hw[l] = l < nlev ? hw[l] : 0;
     a.row0[l] = l < nlev ? row0[l] : 0;
@@ -296,11 +293,36 @@ extern "C" int sm_groupnorm(const void* x, void* y, const float* gamma, const fl
     if (l < nlev) t += sm_cdiv(hw[l], GN_ROWS_PER_BLOCK);
   }
   a.blk0[SM_MAX_LEVELS] = t;
+  return SM_OK;
+}
+
+extern "C" int sm_groupnorm(const void* x, void* y, const float* gamma, const float* beta, float* stats, int batch,
+                            int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups, float eps,
+                            int relu, sm_stream_t stream) {
+  if (!x || !y || !gamma || !beta || !stats || !hw || !row0) return SM_ERR_BAD_ARG;
+  GnArgs a;
+  int t;
+  const int st = gn_fill_args(a, t, batch, nlev, hw, row0, channels, groups, eps, relu);
+  if (st != SM_OK) return st;
   hipStream_t s = sm_hip_stream(stream);
   if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(t, batch), dim3(256), 0, s, (const uint16_t*)x, stats, a);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(t, batch), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)y, gamma, beta,
                      stats, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_groupnorm_apply(const void* x, void* y, const float* gamma, const float* beta, const float* stats,
+                                  int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups,
+                                  float eps, int relu, sm_stream_t stream) {
+  if (!x || !y || !gamma || !beta || !stats || !hw || !row0) return SM_ERR_BAD_ARG;
+  GnArgs a;
+  int t;
+  const int st = gn_fill_args(a, t, batch, nlev, hw, row0, channels, groups, eps, relu);
+  if (st != SM_OK) return st;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(t, batch), dim3(256), 0, sm_hip_stream(stream), (const uint16_t*)x,
+                     (uint16_t*)y, gamma, beta, stats, a);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

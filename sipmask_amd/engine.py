@@ -51,6 +51,7 @@ class _Conv:
                                      in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
                                      scale_nch, level_scale, deform_groups)
         self.x, self.y, self.residual, self.offset = x, y, residual, offset
+        self.gn_stats = None      # set -> GroupNorm statistics of y are accumulated in the conv epilogue
         self.flops = 2.0 * sum(batch * h * ww for h, ww in out_sizes) * co * ci * k * k
         # algorithmic HBM bytes: x read once + y written once (+ residual read) + weights
         in_rows = sum(batch * h * ww for h, ww in in_sizes)
@@ -59,7 +60,9 @@ class _Conv:
                       (out_rows * co * 2 if residual is not None else 0) + self.w.numel() * 2)
 
     def __call__(self):
-        if self.offset is not None:
+        if self.gn_stats is not None:
+            H.conv2d_gn_stats(self.desc, self.x, self.offset, self.w, self.bias, self.residual, self.y, self.gn_stats)
+        elif self.offset is not None:
             H.deform_conv2d(self.desc, self.x, self.offset, self.w, self.bias, self.y)
         else:
             H.conv2d(self.desc, self.x, self.w, self.bias, self.residual, self.y)
@@ -210,10 +213,16 @@ class SipMaskEngine:
         self._build_head(sd)
         self._build_post()
 
-    def _gn(self, label, x, gamma, beta):
+    def _gn(self, label, x, gamma, beta, conv=None):
+        """GroupNorm(32)+ReLU in place.  With ``conv`` (the launch that produced x) the statistics pass is
+        fused into that conv's epilogue and only the normalisation kernel remains."""
         g = gamma.float().to(self.device).contiguous()
         b = beta.float().to(self.device).contiguous()
-        self._add("gn:" + label, lambda: H.groupnorm(x, x, g, b, self.gn_stats, self.lv, 256, 32, 1e-5, True))
+        if conv is not None:
+            conv.gn_stats = self.gn_stats
+            self._add("gn:" + label, lambda: H.groupnorm_apply(x, x, g, b, self.gn_stats, self.lv, 256, 32, 1e-5, True))
+        else:
+            self._add("gn:" + label, lambda: H.groupnorm(x, x, g, b, self.gn_stats, self.lv, 256, 32, 1e-5, True))
 
     def _build_head(self, sd, prefix="bbox_head."):
         """SipMaskHead.forward, sipmask_head.py:241-287, on the pyramid tensor self.pyr."""
@@ -226,9 +235,9 @@ class SipMaskEngine:
             for i in range(n):
                 y = self._buf(lv.rows, 256)
                 name = "%s_convs.%d" % (kind, i)
-                self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"], None, B, sizes, row0, x, 256,
-                                     1, 1, y, row0, 256))
-                self._gn(name, y, sd[h + name + ".gn.weight"], sd[h + name + ".gn.bias"])
+                c = self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"], None, B, sizes, row0, x,
+                                         256, 1, 1, y, row0, 256))
+                self._gn(name, y, sd[h + name + ".gn.weight"], sd[h + name + ".gn.bias"], conv=c)
                 x = y
             return x
 
@@ -247,9 +256,10 @@ class SipMaskEngine:
         self.offsets = self._buf(lv.rows, 72, torch.float32)
         self._add("offset", lambda: H.offset_linear(self.reg_out, 8, self.w_off, lv, self.offsets))
         self.aligned = self._buf(lv.rows, 256)
-        self._add_conv(_Conv(self, "head.feat_align", sd[h + "feat_align.conv_adaption.weight"], None, B, sizes, row0,
-                             self.cls_feat, 256, 1, 1, self.aligned, row0, 256, deform_groups=4, offset=self.offsets))
-        self._gn("feat_align", self.aligned, sd[h + "feat_align.norm.weight"], sd[h + "feat_align.norm.bias"])
+        c = self._add_conv(_Conv(self, "head.feat_align", sd[h + "feat_align.conv_adaption.weight"], None, B, sizes,
+                                 row0, self.cls_feat, 256, 1, 1, self.aligned, row0, 256, deform_groups=4,
+                                 offset=self.offsets))
+        self._gn("feat_align", self.aligned, sd[h + "feat_align.norm.weight"], sd[h + "feat_align.norm.bias"], conv=c)
         # fcos_cls (80) + sip_cof (128) share the aligned feature -> one 208-channel f32 conv
         w_cc = torch.cat([sd[h + "fcos_cls.weight"], sd[h + "sip_cof.weight"]], 0)
         b_cc = torch.cat([sd[h + "fcos_cls.bias"], sd[h + "sip_cof.bias"]], 0)

@@ -92,6 +92,26 @@ def deform_conv2d(desc, x, offset, w, bias, y):
     return y
 
 
+def conv2d_gn_stats(desc, x, offset, w, bias, residual, y, stats):
+    """conv (deformable when offset is given) with the output's GroupNorm statistics fused in the epilogue"""
+    lib = _lib.load()
+    _lib.check(lib.sm_conv2d_gn_stats(C.byref(desc), _lib.ptr(x), _lib.ptr(offset), _lib.ptr(w), _lib.ptr(bias),
+                                      _lib.ptr(residual), _lib.ptr(y), _lib.ptr(stats), _lib.stream_ptr()),
+               "sm_conv2d_gn_stats")
+    return y
+
+
+def groupnorm_apply(x, y, gamma, beta, stats, lv, channels, groups=32, eps=1e-5, relu=True):
+    lib = _lib.load()
+    nlev = len(lv)
+    hw = (C.c_int32 * nlev)(*[h * w for h, w in lv.sizes])
+    row0 = (C.c_int64 * nlev)(*lv.row0)
+    _lib.check(lib.sm_groupnorm_apply(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
+                                      lv.batch, nlev, hw, row0, channels, groups, eps, int(relu), _lib.stream_ptr()),
+               "sm_groupnorm_apply")
+    return y
+
+
 def offset_linear(reg, reg_cstride, w_off, lv, out, level_scale=None):
     lib = _lib.load()
     nlev = len(lv)

@@ -154,6 +154,42 @@ def test_conv_multilevel_scale_and_nearest_residual():
     torch.testing.assert_close(y.view(B, 13, 18, 128).permute(0, 3, 1, 2).cpu(), ref, rtol=1e-4, atol=2e-4)
 
 
+def test_conv_fused_groupnorm_statistics():
+    """sm_conv2d_gn_stats: per (image, level, group of 8 channels) sum / sum of squares of the conv
+    output accumulated in the epilogue, incl. tiles that span several images (tiny levels)."""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(8)
+    B, C, Co = 3, 64, 256
+    sizes = [(21, 30), (9, 11), (3, 5), (2, 2)]
+    lv = H.Levels(B, sizes)
+    xs = [_bf(torch.randn(B, C, h, w, generator=g)) for h, w in sizes]
+    w = _bf(torch.randn(Co, C, 3, 3, generator=g) / 24)
+    x = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, C) for t in xs]).to(torch.bfloat16).to(dev)
+    wq, co_pad = H.prep_conv_weight(w.to(dev))
+    y = torch.zeros(lv.rows, Co, dtype=torch.bfloat16, device=dev)
+    stats = torch.full((B, len(sizes), Co // 8, 2), 123.0, device=dev)
+    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, C, Co, co_pad, 3, 1, 1, C, Co)
+    H.conv2d_gn_stats(d, x, None, wq, None, None, y, stats)
+    torch.cuda.synchronize()
+    for l, (h, wd) in enumerate(sizes):
+        ref = F.conv2d(xs[l], w, None, 1, 1).double()                       # [B,Co,h,w]
+        rs = ref.view(B, Co // 8, 8 * h * wd)
+        got = stats[:, l].cpu().double()
+        torch.testing.assert_close(got[..., 0], rs.sum(-1), rtol=1e-4, atol=2e-3)
+        torch.testing.assert_close(got[..., 1], (rs * rs).sum(-1), rtol=1e-4, atol=2e-3)
+        out = y[lv.row0[l]:lv.row0[l] + B * h * wd].float().view(B, h, wd, Co).permute(0, 3, 1, 2).cpu()
+        torch.testing.assert_close(out, ref.float(), rtol=2 ** -7, atol=2e-3)
+    # normalisation with those statistics == GroupNorm(32) + ReLU
+    gamma, beta = torch.randn(Co, generator=g), torch.randn(Co, generator=g)
+    H.groupnorm_apply(y, y, gamma.to(dev), beta.to(dev), stats.view(-1), lv, Co, 32, 1e-5, True)
+    torch.cuda.synchronize()
+    for l, (h, wd) in enumerate(sizes):
+        ref = F.relu(F.group_norm(F.conv2d(xs[l], w, None, 1, 1), 32, gamma, beta, 1e-5))
+        out = y[lv.row0[l]:lv.row0[l] + B * h * wd].float().view(B, h, wd, Co).permute(0, 3, 1, 2).cpu()
+        torch.testing.assert_close(out, ref, rtol=2e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize("shape", [(2, 256, 14, 19, 256), (1, 64, 9, 9, 40)])
 def test_deform_conv_vs_oracle(shape):
     from sipmask_amd import hip_ops as H, _lib
