@@ -174,6 +174,34 @@ int sm_multiclass_nms(const float* boxes, const float* scores, const float* ctr,
                       int max_num, float* det, int64_t* labels, int64_t* keep, int32_t* ndet,
                       void* workspace, sm_stream_t stream);
 
+/* Batched SipMaskHead.fast_nms (ssd_flag configs and SipMask-VIS), sipmask_head.py:868-910: per class the
+ * top_k boxes by score*centerness, IoU WITHOUT +1 (jaccard :912-960), keep j iff max_{i<j} IoU(i,j) <= iou_thr
+ * and score > score_thr; the survivors of all classes sorted by score, top max_num.  Same inputs, outputs and
+ * workspace (sm_multiclass_nms_workspace) as sm_multiclass_nms; scores are multiplied by ctr inside. */
+int sm_fast_nms(const float* boxes, const float* scores, const float* ctr, const int32_t* ncand, int batch,
+                int kmax, int num_classes, float score_thr, float iou_thr, int top_k, int max_num, float* det,
+                int64_t* labels, int64_t* keep, int32_t* ndet, void* workspace, sm_stream_t stream);
+
+/* Device-side COCO RLE of the assembled masks: replaces the per-detection D2H + paste + pycocotools
+ * mask_util.encode loop of sipmask_head.py:645-657 (algorithm: cocoapi common/maskApi.c rleEncode + rleToString).
+ * masks u8 0/1 [batch][max_num][ho][wo]; detection i of image b is encoded iff i < ndet[b].  The mask's
+ * top-left min(mask, canvas) window is pasted on a zero canvas_h x canvas_w canvas (:648-653, RLE 'size').
+ * rect (nullable) int32 [batch][max_num][4] = x0,y0,x1,y1 (exclusive) outside which the caller guarantees zeros
+ * (CropSplit zeroes everything outside the box), so only the box is read.
+ * Outputs: counts u32 [batch][max_num][max_runs] (uncompressed run lengths), nruns[d] (or -needed when
+ * max_runs is too small), nchars[d], and all compressed strings packed back to back: detection d's 'counts'
+ * bytes are packed[offsets[d] .. offsets[d+1]) (offsets has batch*max_num+1 entries; if offsets[last] exceeds
+ * packed_cap nothing past the capacity was written and the caller must retry with a larger buffer). */
+int64_t sm_rle_workspace(int batch, int max_num, int canvas_w, int max_runs);
+/* rect hint for sm_rle_encode from the detections sm_mask_assemble used (same box_mul/box_div/up_scale):
+ * a conservative output-pixel rectangle per detection outside which the assembled mask is zero. */
+int sm_mask_rects(const float* det, int batch, int max_num, float box_mul, float box_div, double up_scale,
+                  int32_t* rect, sm_stream_t stream);
+int sm_rle_encode(const uint8_t* masks, const int32_t* ndet, const int32_t* rect, int batch, int max_num, int ho,
+                  int wo, int canvas_h, int canvas_w, int max_runs, uint32_t* counts, int32_t* nruns,
+                  int32_t* nchars, uint8_t* packed, int64_t packed_cap, int64_t* offsets, void* workspace,
+                  sm_stream_t stream);
+
 /* Single-class greedy NMS with the reference op's contract, nms_cuda.nms:
  * dets f32 [n][5] -> keep i64 [<=n] ascending original indices, *nkeep (device).
  * M/mmdet/ops/nms/src/nms_kernel.cu:71-139.  workspace: sm_nms_workspace(n) bytes. */

@@ -419,3 +419,95 @@ def mask_assemble(feat_mask, det_cofs, det_boxes, scale_factor=1.0, rescale=None
                        mode="bilinear", align_corners=False).squeeze(0)
     masks = (up > mask_thr).to(torch.uint8)
     return dict(pos_masks=pos, logits=logits, up=up, masks=masks, rois=rois)
+
+
+# ----------------------------------------------------------------------------
+# COCO run-length encoding (result packing, sipmask_head.py:645-657)
+# ----------------------------------------------------------------------------
+# The reference calls pycocotools.mask.encode (sipmask_head.py:655), a third-party dependency that is NOT under
+# /root/reference and is not pinned by it (requirements name no version; the READMEs install cocoapi from git).
+# The functions below restate the published algorithm of cocoapi `common/maskApi.c` (rleEncode, rleToString,
+# rleFrString, rleDecode).  PARITY UNPINNED: there is no pycocotools in this image to generate golden strings;
+# the tests pin the restatement through encode -> string -> parse -> decode round trips only.
+
+
+def rle_counts(mask):
+    """maskApi.c rleEncode: column-major scan, alternating run lengths starting with the zeros run
+    (which is 0 when the mask starts with a 1).  mask [H,W] of 0/1 -> list of ints."""
+    m = np.asarray(mask, np.uint8)
+    v = m.T.reshape(-1)                                  # column-major (Fortran order, sipmask_head.py:656)
+    n = v.size
+    if n == 0:
+        return [0]
+    change = np.flatnonzero(v[1:] != v[:-1]) + 1          # positions where the value flips
+    lead = [0] if v[0] != 0 else []                       # rleEncode starts with p=0: a mask that starts with 1
+    edges = np.concatenate([[0], lead, change, [n]])      # gets a leading zero-length run of zeros
+    cnts = np.diff(edges)
+    return [int(c) for c in cnts]
+
+
+def rle_to_string(cnts):
+    """maskApi.c rleToString: counts i>2 are stored as the difference to counts[i-2]; each value is emitted as
+    5-bit groups, least significant first, bit 0x20 = 'more', sign carried by bit 0x10 of the last group; +48."""
+    out = bytearray()
+    for i, c in enumerate(cnts):
+        x = int(c)
+        if i > 2:
+            x -= int(cnts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1f
+            x >>= 5                                        # arithmetic shift (Python ints: floor), as `long`
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            out.append(ch + 48)
+    return bytes(out)
+
+
+def rle_from_string(s):
+    """maskApi.c rleFrString (the inverse of rle_to_string)."""
+    cnts = []
+    p = 0
+    s = bytes(s)
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = s[p] - 48
+            x |= (c & 0x1f) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(cnts) > 2:
+            x += cnts[-2]
+        cnts.append(x)
+    return cnts
+
+
+def rle_decode(cnts, h, w):
+    """maskApi.c rleDecode -> [H,W] uint8."""
+    v = np.zeros(h * w, np.uint8)
+    p, val = 0, 0
+    for c in cnts:
+        v[p:p + c] = val
+        p += c
+        val ^= 1
+    return v.reshape(w, h).T.copy()
+
+
+def rle_encode(mask):
+    """pycocotools.mask.encode for one [H,W] mask -> {'size': [H,W], 'counts': bytes}."""
+    m = np.asarray(mask, np.uint8)
+    return dict(size=[int(m.shape[0]), int(m.shape[1])], counts=rle_to_string(rle_counts(m)))
+
+
+def paste_and_encode(mask, canvas_hw):
+    """sipmask_head.py:648-656: paste the top-left min(mask, canvas) window onto a zero canvas, encode."""
+    m = np.asarray(mask, np.uint8)
+    H, W = int(canvas_hw[0]), int(canvas_hw[1])
+    im = np.zeros((H, W), np.uint8)
+    h, w = min(m.shape[0], H), min(m.shape[1], W)
+    im[:h, :w] = m[:h, :w]
+    return rle_encode(im)

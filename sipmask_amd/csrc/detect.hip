@@ -337,6 +337,8 @@ __device__ void block_sort_idx_asc(unsigned long long* scratch, const uint32_t* 
 struct NmsArgs {
   int batch, kmax, C, P, max_num;
   float score_thr, iou_thr;
+  int always_sort;   // fast_nms: the final list is always sorted by score (sipmask_head.py:902)
+  int top_k;         // fast_nms: boxes kept per class before the IoU test (:871)
 };
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __restrict__ boxes,
@@ -439,11 +441,16 @@ __global__ __launch_bounds__(TK_THREADS) void nms_final_kernel(const float* __re
     labels[o] = c;
     keep[o] = idx;
   };
-  if (total <= a.max_num) {
+  if (total <= a.max_num && !a.always_sort) {
     for (int p = tid; p < total; p += TK_THREADS) emit(p, p);
     if (tid == 0) ndet[b] = total;
     return;
   }
+  if (total == 0) {
+    if (tid == 0) ndet[b] = 0;
+    return;
+  }
+  const int nout = min(total, a.max_num);
   // more than max_num: sort by score desc (ties: position asc) and keep the top max_num
   for (int p = tid; p < total; p += TK_THREADS) {
     int lo = 0, hi = a.C;
@@ -455,10 +462,74 @@ __global__ __launch_bounds__(TK_THREADS) void nms_final_kernel(const float* __re
     fk[p] = __fmul_rn(scores[((long long)b * a.C + lo) * a.kmax + idx], ctr[(long long)b * a.kmax + idx]);
   }
   __syncthreads();
-  block_topk(fk, total, a.max_num, sm);
-  for (int i = tid; i < a.max_num; i += TK_THREADS)
+  block_topk(fk, total, nout, sm);
+  for (int i = tid; i < nout; i += TK_THREADS)
     emit(i, (int)(0xffffffffu - (uint32_t)(sm.sel[i] & 0xffffffffull)));
-  if (tid == 0) ndet[b] = a.max_num;
+  if (tid == 0) ndet[b] = nout;
+}
+
+// ------------------------------------------------------------------------------- fast_nms
+// jaccard WITHOUT the +1 (sipmask_head.py:912-960), float32, same operation order
+__device__ __forceinline__ float iou_plain(const float4 a, const float4 b) {
+  const float w = fmaxf(__fsub_rn(fminf(a.z, b.z), fmaxf(a.x, b.x)), 0.f);
+  const float h = fmaxf(__fsub_rn(fminf(a.w, b.w), fmaxf(a.y, b.y)), 0.f);
+  const float inter = __fmul_rn(w, h);
+  const float aa = __fmul_rn(__fsub_rn(a.z, a.x), __fsub_rn(a.w, a.y));
+  const float ab = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
+  return __fdiv_rn(inter, __fsub_rn(__fadd_rn(aa, ab), inter));
+}
+
+// SipMaskHead.fast_nms (sipmask_head.py:868-910), one block per (image, class): top_k boxes by
+// score*centerness (desc, index asc), keep j iff max_{i<j} IoU(i,j) <= thr (a NaN IoU -- degenerate
+// boxes -- propagates through torch.max and fails the test) and score > score_thr.  Kept
+// candidates are written in rank order; nms_final_kernel (always_sort) does the global top-N.
+__global__ __launch_bounds__(TK_THREADS) void fast_nms_class_kernel(const float* __restrict__ boxes,
+                                                                    const float* __restrict__ scores,
+                                                                    const float* __restrict__ ctr,
+                                                                    const int32_t* __restrict__ ncand,
+                                                                    float* __restrict__ keybuf,
+                                                                    int32_t* __restrict__ cls_keep,
+                                                                    int32_t* __restrict__ cls_cnt, const NmsArgs a) {
+  __shared__ TopkSmem sm;
+  __shared__ float4 s_box[TK_CAP];
+  __shared__ unsigned int s_keep[TK_CAP];
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int K = ncand[b];
+  const float* sc = scores + ((long long)b * a.C + c) * a.kmax;
+  const float* ct = ctr + (long long)b * a.kmax;
+  float* kb = keybuf + ((long long)b * a.C + c) * a.kmax;
+  for (int i = tid; i < K; i += TK_THREADS) kb[i] = __fmul_rn(sc[i], ct[i]);   // mlvl_scores * centerness (:604)
+  __syncthreads();
+  const int k = min(a.top_k, K);
+  int32_t* outk = cls_keep + ((long long)b * a.C + c) * a.kmax;
+  if (k <= 0) {
+    if (tid == 0) cls_cnt[b * a.C + c] = 0;
+    return;
+  }
+  block_topk(kb, K, k, sm);
+  const float4* bx = reinterpret_cast<const float4*>(boxes) + (long long)b * a.kmax;
+  for (int i = tid; i < k; i += TK_THREADS) s_box[i] = bx[0xffffffffu - (uint32_t)(sm.sel[i] & 0xffffffffull)];
+  __syncthreads();
+  for (int j = tid; j < k; j += TK_THREADS) {
+    const float4 mine = s_box[j];
+    float mx = 0.f;   // triu_(diagonal=1) leaves zeros below the diagonal, so the column max starts at 0
+    bool nan = false;
+    for (int i = 0; i < j; ++i) {
+      const float v = iou_plain(s_box[i], mine);
+      nan |= (v != v);
+      mx = fmaxf(mx, v);
+    }
+    const uint32_t idx = 0xffffffffu - (uint32_t)(sm.sel[j] & 0xffffffffull);
+    const bool kp = !nan && (mx <= a.iou_thr) && (kb[idx] > a.score_thr);
+    s_keep[j] = kp ? 1u : 0u;
+  }
+  __syncthreads();
+  if (tid == 0) {   // k <= 2048: a serial compaction in rank order is cheap
+    int n = 0;
+    for (int j = 0; j < k; ++j)
+      if (s_keep[j]) outk[n++] = (int32_t)(0xffffffffu - (uint32_t)(sm.sel[j] & 0xffffffffull));
+    cls_cnt[b * a.C + c] = n;
+  }
 }
 
 // reference op contract: dets [n][5] -> ascending kept indices (nms_cuda.nms)
@@ -599,6 +670,8 @@ extern "C" int sm_multiclass_nms(const float* boxes, const float* scores, const 
   a.max_num = max_num;
   a.score_thr = score_thr;
   a.iou_thr = iou_thr;
+  a.always_sort = 0;
+  a.top_k = 0;
   const size_t lds = (size_t)a.P * 28;
   if (lds > 160 * 1024) return SM_ERR_UNSUPPORTED;
   hipStream_t s = sm_hip_stream(stream);
@@ -610,6 +683,36 @@ extern "C" int sm_multiclass_nms(const float* boxes, const float* scores, const 
     return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(NMS_THREADS), lds, s, boxes, scores, ctr, ncand, cls_keep,
                      cls_cnt, a);
+  hipLaunchKernelGGL(nms_final_kernel, dim3(batch), dim3(TK_THREADS), 0, s, boxes, scores, ctr, cls_keep, cls_cnt,
+                     flat_key, det, labels, keep, ndet, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_fast_nms(const float* boxes, const float* scores, const float* ctr, const int32_t* ncand, int batch,
+                           int kmax, int num_classes, float score_thr, float iou_thr, int top_k, int max_num,
+                           float* det, int64_t* labels, int64_t* keep, int32_t* ndet, void* workspace,
+                           sm_stream_t stream) {
+  if (!boxes || !scores || !ctr || !ncand || !det || !labels || !keep || !ndet || !workspace) return SM_ERR_BAD_ARG;
+  if (batch < 1 || kmax < 1 || num_classes < 1 || num_classes > 256) return SM_ERR_BAD_SHAPE;
+  if (max_num < 1 || max_num > TK_CAP || top_k < 1 || top_k > TK_CAP) return SM_ERR_UNSUPPORTED;
+  NmsArgs a;
+  a.batch = batch;
+  a.kmax = kmax;
+  a.C = num_classes;
+  a.P = 0;
+  a.max_num = max_num;
+  a.score_thr = score_thr;
+  a.iou_thr = iou_thr;
+  a.always_sort = 1;
+  a.top_k = top_k;
+  hipStream_t s = sm_hip_stream(stream);
+  // same workspace layout as sm_multiclass_nms: cls_keep | flat_key | cls_cnt
+  int32_t* cls_keep = (int32_t*)workspace;
+  float* flat_key = (float*)((char*)workspace + (size_t)batch * num_classes * kmax * 4);
+  int32_t* cls_cnt = (int32_t*)((char*)workspace + (size_t)batch * num_classes * kmax * 8);
+  hipLaunchKernelGGL(fast_nms_class_kernel, dim3(num_classes, batch), dim3(TK_THREADS), 0, s, boxes, scores, ctr, ncand,
+                     flat_key, cls_keep, cls_cnt, a);
   hipLaunchKernelGGL(nms_final_kernel, dim3(batch), dim3(TK_THREADS), 0, s, boxes, scores, ctr, cls_keep, cls_cnt,
                      flat_key, det, labels, keep, ndet, a);
   SM_LAUNCH_CHECK();

@@ -1,0 +1,380 @@
+// Device-side COCO run-length encoding of the assembled instance masks.
+//
+// Replaces the reference's per-detection `masks[i].cpu().numpy()` + paste + `mask_util.encode` loop
+// (sipmask_head.py:645-657): the masks stay in HBM, one block per detection produces the column-major run
+// lengths (cocoapi maskApi.c rleEncode) and the compressed ASCII string (maskApi.c rleToString), and a second
+// kernel packs all strings of the batch into one buffer, so the host does two small D2H copies per batch
+// instead of one ~1 MB copy per detection.
+//
+// HBM-bound byte work: a detection's canvas is H*W bytes read twice (count pass + emit pass); with the optional
+// `rect` hint (the detection box plus a margin: CropSplit zeroes everything outside the box) only the box is
+// read.  Threads own 4 adjacent columns (one dword per row) of a row slice, so a wave reads 256 contiguous
+// bytes per row; transitions are found with one XOR per dword against the previous row.
+#include "common.h"
+
+namespace {
+
+constexpr int RLE_THREADS = 1024;
+constexpr int RLE_UNITS = 4096;       // target number of (column group, row slice) units per detection
+constexpr int RLE_MAX_SLICES = 32;
+
+struct RleArgs {
+  int batch, max_num;
+  int ho, wo;          // mask tensor [B][max_num][ho][wo]
+  int H, W;            // canvas (RLE 'size'): ori_shape or img_shape (sipmask_head.py:648-653)
+  int hc, wc;          // copied window = min(mask, canvas) (:649,652)
+  int max_runs, cap;
+  long long packed_cap;
+};
+
+__device__ __forceinline__ int block_excl_scan(int v, int* s_wave, int* total) {
+  // exclusive scan of one int per thread over the block (wave64 shuffles + one LDS hop)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  __syncthreads();                     // s_wave may still be read from a previous call
+  if (lane == 63) s_wave[wid] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < RLE_THREADS / 64; ++w) {
+    const int t = s_wave[w];
+    if (w < wid) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+// number of characters rleToString emits for the (delta coded) value x
+__device__ __forceinline__ int rle_nchars(long long x) {
+  int n = 0;
+  bool more = true;
+  while (more) {
+    const int c = (int)(x & 0x1f);
+    x >>= 5;
+    more = (c & 0x10) ? (x != -1) : (x != 0);
+    ++n;
+  }
+  return n;
+}
+
+struct RleRegion {
+  int tx0, ty0, tx1, ty1;   // rectangle outside which the canvas is zero (clamped to the copied window)
+  int x0, y0, sx1, sy1;     // scanned rectangle: one extra row/column so the 1->0 edge after the box is seen
+  int G, S, R;              // column groups (4 columns each), row slices, rows per slice
+};
+
+template <bool ALIGNED>
+__device__ __forceinline__ uint32_t rle_row(const uint8_t* __restrict__ m, const RleArgs& a, const RleRegion& rg, int y,
+                                            int xg, uint32_t vmask) {
+  if (y < rg.ty0 || y >= rg.ty1 || vmask == 0u) return 0u;
+  const uint8_t* p = m + (long long)y * a.wo + xg;
+  uint32_t v;
+  if (ALIGNED) {
+    v = *reinterpret_cast<const uint32_t*>(p);
+  } else {
+    v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((vmask >> (8 * j)) & 1u) v |= (uint32_t)p[j] << (8 * j);
+  }
+  return v & vmask;
+}
+
+__device__ __forceinline__ uint32_t rle_val(const uint8_t* __restrict__ m, const RleArgs& a, const RleRegion& rg, int y,
+                                            int x) {
+  if (x < rg.tx0 || x >= rg.tx1 || y < rg.ty0 || y >= rg.ty1) return 0u;
+  return m[(long long)y * a.wo + x] & 1u;
+}
+
+// value vector that precedes row `ys` of the 4 columns at xg in column-major order
+template <bool ALIGNED>
+__device__ __forceinline__ uint32_t rle_prev(const uint8_t* __restrict__ m, const RleArgs& a, const RleRegion& rg, int ys,
+                                             int xg, uint32_t vmask) {
+  if (ys > rg.y0) return rle_row<ALIGNED>(m, a, rg, ys - 1, xg, vmask);
+  if (rg.y0 > 0) return 0u;            // the row above the hinted rectangle is zero
+  uint32_t v = 0;                      // row 0: the predecessor is the last canvas row of the previous column
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int x = xg + j - 1;
+    if (x >= 0 && xg + j < rg.sx1) v |= rle_val(m, a, rg, a.H - 1, x) << (8 * j);
+  }
+  return v;
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(RLE_THREADS) void rle_encode_kernel(const uint8_t* __restrict__ masks,
+                                                                 const int32_t* __restrict__ ndet,
+                                                                 const int32_t* __restrict__ rect,
+                                                                 uint32_t* __restrict__ pos_ws, int32_t* __restrict__ unit_ws,
+                                                                 uint32_t* __restrict__ counts, int32_t* __restrict__ nruns,
+                                                                 int32_t* __restrict__ nchars, const RleArgs a) {
+  __shared__ int s_wave[RLE_THREADS / 64];
+  __shared__ long long s_red[RLE_THREADS / 64];
+  const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int det = b * a.max_num + i;
+  if (i >= ndet[b]) {
+    if (tid == 0) {
+      nruns[det] = 0;
+      nchars[det] = 0;
+    }
+    return;
+  }
+  const uint8_t* m = masks + (long long)det * a.ho * a.wo;
+  uint32_t* pos = pos_ws + (long long)det * a.max_runs;
+  int32_t* unit = unit_ws + (long long)det * a.cap;
+  uint32_t* cnt_out = counts + (long long)det * a.max_runs;
+  const uint32_t N = (uint32_t)a.H * (uint32_t)a.W;
+
+  RleRegion rg;
+  rg.tx0 = 0, rg.ty0 = 0, rg.tx1 = a.wc, rg.ty1 = a.hc;
+  if (rect) {
+    rg.tx0 = max(rect[det * 4 + 0], 0);
+    rg.ty0 = max(rect[det * 4 + 1], 0);
+    rg.tx1 = min(rect[det * 4 + 2], a.wc);
+    rg.ty1 = min(rect[det * 4 + 3], a.hc);
+  }
+  int T = 0;
+  const bool empty = rg.tx1 <= rg.tx0 || rg.ty1 <= rg.ty0;
+  if (!empty) {
+    rg.x0 = rg.tx0 & ~3;
+    rg.y0 = rg.ty1 == a.H ? 0 : rg.ty0;   // a box touching the last row flips at row 0 of the next column
+    rg.sx1 = min(rg.tx1 + 1, a.W);
+    rg.sy1 = min(rg.ty1 + 1, a.H);
+    rg.G = (rg.sx1 - rg.x0 + 3) >> 2;
+    const int Hr = rg.sy1 - rg.y0;
+    int S = max(1, min(RLE_UNITS / rg.G, RLE_MAX_SLICES));
+    S = min(S, Hr);
+    rg.R = (Hr + S - 1) / S;
+    rg.S = (Hr + rg.R - 1) / rg.R;
+    const int U = rg.G * rg.S;
+    const int nidx = 4 * U;             // <= cap by construction (sm_rle_workspace)
+
+    // ---- pass 1: transitions per (column, slice)
+    for (int u = tid; u < U; u += RLE_THREADS) {
+      const int g = u / rg.S, s = u - g * rg.S;
+      const int xg = rg.x0 + 4 * g;
+      uint32_t vmask = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (xg + j >= rg.tx0 && xg + j < rg.tx1) vmask |= 1u << (8 * j);
+      const int ys = rg.y0 + s * rg.R, ye = min(ys + rg.R, rg.sy1);
+      uint32_t prev = rle_prev<ALIGNED>(m, a, rg, ys, xg, vmask);
+      int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll 4
+      for (int y = ys; y < ye; ++y) {
+        const uint32_t cur = rle_row<ALIGNED>(m, a, rg, y, xg, vmask);
+        const uint32_t d = cur ^ prev;
+        c0 += d & 1u;
+        c1 += (d >> 8) & 1u;
+        c2 += (d >> 16) & 1u;
+        c3 += d >> 24;
+        prev = cur;
+      }
+      unit[(4 * g + 0) * rg.S + s] = c0;
+      unit[(4 * g + 1) * rg.S + s] = c1;
+      unit[(4 * g + 2) * rg.S + s] = c2;
+      unit[(4 * g + 3) * rg.S + s] = c3;
+    }
+    __syncthreads();
+
+    // ---- exclusive scan of the unit counts in column-major order (in place)
+    const int per = (nidx + RLE_THREADS - 1) / RLE_THREADS;
+    const int lo = min(tid * per, nidx), hi = min(lo + per, nidx);
+    int sum = 0;
+    for (int k = lo; k < hi; ++k) sum += unit[k];
+    int run = block_excl_scan(sum, s_wave, &T);
+    for (int k = lo; k < hi; ++k) {
+      const int c = unit[k];
+      unit[k] = run;
+      run += c;
+    }
+    __syncthreads();
+  }
+  const int nr = T + 1;
+  if (nr > a.max_runs) {                // overflow: report the needed size, the host raises
+    if (tid == 0) {
+      nruns[det] = -nr;
+      nchars[det] = 0;
+    }
+    return;
+  }
+  if (!empty) {
+    // ---- pass 2: positions (column-major linear index) of every transition
+    const int U = rg.G * rg.S;
+    for (int u = tid; u < U; u += RLE_THREADS) {
+      const int g = u / rg.S, s = u - g * rg.S;
+      const int xg = rg.x0 + 4 * g;
+      uint32_t vmask = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (xg + j >= rg.tx0 && xg + j < rg.tx1) vmask |= 1u << (8 * j);
+      const int ys = rg.y0 + s * rg.R, ye = min(ys + rg.R, rg.sy1);
+      uint32_t prev = rle_prev<ALIGNED>(m, a, rg, ys, xg, vmask);
+      int o0 = unit[(4 * g + 0) * rg.S + s], o1 = unit[(4 * g + 1) * rg.S + s];
+      int o2 = unit[(4 * g + 2) * rg.S + s], o3 = unit[(4 * g + 3) * rg.S + s];
+      const uint32_t colbase = (uint32_t)xg * (uint32_t)a.H;
+#pragma unroll 4
+      for (int y = ys; y < ye; ++y) {
+        const uint32_t cur = rle_row<ALIGNED>(m, a, rg, y, xg, vmask);
+        const uint32_t d = cur ^ prev;
+        if (d) {
+          if (d & 1u) pos[o0++] = colbase + (uint32_t)y;
+          if (d & 0x100u) pos[o1++] = colbase + (uint32_t)a.H + (uint32_t)y;
+          if (d & 0x10000u) pos[o2++] = colbase + 2u * (uint32_t)a.H + (uint32_t)y;
+          if (d & 0x1000000u) pos[o3++] = colbase + 3u * (uint32_t)a.H + (uint32_t)y;
+        }
+        prev = cur;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- run lengths (rleEncode) and the length of their rleToString image
+  auto cnt = [&](int r) -> long long {
+    const uint32_t lo = r == 0 ? 0u : pos[r - 1];
+    const uint32_t hi = r == T ? N : pos[r];
+    return (long long)(hi - lo);
+  };
+  long long nch = 0;
+  for (int r = tid; r < nr; r += RLE_THREADS) {
+    const long long c = cnt(r);
+    cnt_out[r] = (uint32_t)c;
+    nch += rle_nchars(r > 2 ? c - cnt(r - 2) : c);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) nch += __shfl_down(nch, d, 64);
+  if ((tid & 63) == 0) s_red[tid >> 6] = nch;
+  __syncthreads();
+  if (tid == 0) {
+    long long t = 0;
+    for (int w = 0; w < RLE_THREADS / 64; ++w) t += s_red[w];
+    nruns[det] = nr;
+    nchars[det] = (int32_t)t;
+  }
+}
+
+// rleToString of every detection into one packed buffer; offsets[d] .. offsets[d+1] is detection d's string
+__global__ __launch_bounds__(RLE_THREADS) void rle_pack_kernel(const uint32_t* __restrict__ counts,
+                                                               const int32_t* __restrict__ nruns,
+                                                               const int32_t* __restrict__ nchars,
+                                                               uint8_t* __restrict__ packed, int64_t* __restrict__ offsets,
+                                                               const RleArgs a) {
+  __shared__ int s_wave[RLE_THREADS / 64];
+  __shared__ long long s_red[RLE_THREADS / 64];
+  const int det = blockIdx.y * a.max_num + blockIdx.x, tid = threadIdx.x;
+  const int ndets = a.batch * a.max_num;
+  long long off = 0;
+  for (int d = tid; d < det; d += RLE_THREADS) off += nchars[d];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) off += __shfl_down(off, d, 64);
+  if ((tid & 63) == 0) s_red[tid >> 6] = off;
+  __syncthreads();
+  off = 0;
+  for (int w = 0; w < RLE_THREADS / 64; ++w) off += s_red[w];
+  const int mine = nchars[det];
+  if (tid == 0) {
+    offsets[det] = off;
+    if (det == ndets - 1) offsets[ndets] = off + mine;
+  }
+  const int nr = nruns[det];
+  if (nr <= 0 || off + mine > a.packed_cap) return;     // the host checks offsets[ndets] against the capacity
+  const uint32_t* c = counts + (long long)det * a.max_runs;
+  uint8_t* out = packed + off;
+  int carry = 0;
+  for (int base = 0; base < nr; base += RLE_THREADS) {
+    const int r = base + tid;
+    long long x = 0;
+    int n = 0;
+    if (r < nr) {
+      x = (long long)c[r];
+      if (r > 2) x -= (long long)c[r - 2];
+      n = rle_nchars(x);
+    }
+    int tot;
+    int o = carry + block_excl_scan(n, s_wave, &tot);
+    for (int k = 0; k < n; ++k) {
+      int ch = (int)(x & 0x1f);
+      x >>= 5;
+      if (k + 1 < n) ch |= 0x20;
+      out[o++] = (uint8_t)(ch + 48);
+    }
+    carry += tot;
+  }
+}
+
+// Conservative output-pixel rectangle outside which sm_mask_assemble wrote zeros: the crop keeps half-resolution
+// pixels inside box*mul/div (crop_split_cuda_kernel.cu:45), bilinear x`up` reads two neighbours per axis.
+__global__ void mask_rects_kernel(const float* __restrict__ det, int n, float mul, float div, float up,
+                                  int32_t* __restrict__ rect) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  const float* b = det + (long long)d * 5;
+  const float x1 = b[0] * mul / div, y1 = b[1] * mul / div, x2 = b[2] * mul / div, y2 = b[3] * mul / div;
+  auto lo = [&](float v) { return (int)fmaxf(fminf(floorf((v - 1.f) * up) - 2.f, 1e9f), -1e9f); };
+  auto hi = [&](float v) { return (int)fmaxf(fminf(ceilf((v + 1.f) * up) + 2.f, 1e9f), -1e9f); };
+  rect[d * 4 + 0] = lo(x1);
+  rect[d * 4 + 1] = lo(y1);
+  rect[d * 4 + 2] = hi(x2);
+  rect[d * 4 + 3] = hi(y2);
+}
+
+int rle_cap(int W) {
+  const int gmax = (W + 1 + 3 + 3) / 4;
+  return max(4 * RLE_UNITS + 4 * RLE_MAX_SLICES * 4, 4 * gmax);
+}
+
+}  // namespace
+
+extern "C" int64_t sm_rle_workspace(int batch, int max_num, int canvas_w, int max_runs) {
+  if (batch < 1 || max_num < 1 || canvas_w < 1 || max_runs < 1) return 0;
+  const int64_t nd = (int64_t)batch * max_num;
+  return nd * max_runs * 4 + nd * (int64_t)rle_cap(canvas_w) * 4 + 256;
+}
+
+extern "C" int sm_mask_rects(const float* det, int batch, int max_num, float box_mul, float box_div, double up_scale,
+                             int32_t* rect, sm_stream_t stream) {
+  if (!det || !rect) return SM_ERR_BAD_ARG;
+  if (batch < 1 || max_num < 1 || !(up_scale > 0) || !(box_div != 0.f)) return SM_ERR_BAD_SHAPE;
+  const int n = batch * max_num;
+  hipLaunchKernelGGL(mask_rects_kernel, dim3((n + 255) / 256), dim3(256), 0, sm_hip_stream(stream), det, n, box_mul,
+                     box_div, (float)up_scale, rect);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_rle_encode(const uint8_t* masks, const int32_t* ndet, const int32_t* rect, int batch, int max_num,
+                             int ho, int wo, int canvas_h, int canvas_w, int max_runs, uint32_t* counts, int32_t* nruns,
+                             int32_t* nchars, uint8_t* packed, int64_t packed_cap, int64_t* offsets, void* workspace,
+                             sm_stream_t stream) {
+  if (!masks || !ndet || !counts || !nruns || !nchars || !packed || !offsets || !workspace) return SM_ERR_BAD_ARG;
+  if (batch < 1 || max_num < 1 || ho < 1 || wo < 1 || canvas_h < 1 || canvas_w < 1 || max_runs < 2 || packed_cap < 1)
+    return SM_ERR_BAD_SHAPE;
+  if ((int64_t)canvas_h * canvas_w >= (1ll << 32)) return SM_ERR_UNSUPPORTED;
+  RleArgs a;
+  a.batch = batch, a.max_num = max_num;
+  a.ho = ho, a.wo = wo;
+  a.H = canvas_h, a.W = canvas_w;
+  a.hc = min(ho, canvas_h), a.wc = min(wo, canvas_w);
+  a.max_runs = max_runs;
+  a.cap = rle_cap(canvas_w);
+  a.packed_cap = packed_cap;
+  const int64_t nd = (int64_t)batch * max_num;
+  uint32_t* pos_ws = (uint32_t*)workspace;
+  int32_t* unit_ws = (int32_t*)((char*)workspace + nd * max_runs * 4);
+  hipStream_t s = sm_hip_stream(stream);
+  const bool aligned = (wo % 4 == 0) && (((uintptr_t)masks & 3) == 0);
+  if (aligned)
+    hipLaunchKernelGGL(rle_encode_kernel<true>, dim3(max_num, batch), dim3(RLE_THREADS), 0, s, masks, ndet, rect, pos_ws,
+                       unit_ws, counts, nruns, nchars, a);
+  else
+    hipLaunchKernelGGL(rle_encode_kernel<false>, dim3(max_num, batch), dim3(RLE_THREADS), 0, s, masks, ndet, rect, pos_ws,
+                       unit_ws, counts, nruns, nchars, a);
+  hipLaunchKernelGGL(rle_pack_kernel, dim3(max_num, batch), dim3(RLE_THREADS), 0, s, counts, nruns, nchars, packed, offsets,
+                     a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

@@ -58,17 +58,19 @@ class SipMask(nn.Module):
         return eng.run(img)
 
     def simple_test(self, img, img_meta, rescale=False):
-        """single_stage.py:75-96: returns (bbox_results, segm_results) of image 0."""
+        """single_stage.py:75-96: returns (bbox_results, segm_results) of image 0; segm_results[label] is the
+        list of COCO RLE dicts of that class (sipmask_head.py:655-657), encoded on device."""
         if rescale and float(img_meta[0].get('scale_factor', 1.0)) != 1.0:
             raise NotImplementedError("rescale with scale_factor != 1 is planned through SipMaskHead.get_masks")
-        r = self.get_masks(img, img_meta)
+        shape = tuple(img_meta[0]['img_shape'])
+        eng = self.prepare(img.shape[0], tuple(img.shape[-2:]), shape)
+        r = eng.run(img)
+        rle = eng.encode_rle(shape[:2])[0]
         n = int(r["ndet"][0])
-        det, lab = r["det_bboxes"][0, :n], r["det_labels"][0, :n]
+        d, l = r["det_bboxes"][0, :n].cpu().numpy(), r["det_labels"][0, :n].cpu().numpy()
         ncls = self.bbox_head.num_classes - 1
-        d, l, m = det.cpu().numpy(), lab.cpu().numpy(), r["masks"][0, :n].cpu().numpy()
-        shp = img_meta[0]['img_shape']
-        bbox_results = [d[l == i, :] for i in range(ncls)]
-        segm_results = [[m[j, :shp[0], :shp[1]] for j in range(n) if l[j] == i] for i in range(ncls)]
+        bbox_results = [d[l == i, :] for i in range(ncls)]                       # bbox2result, transforms.py:181-199
+        segm_results = [[rle[j] for j in range(n) if l[j] == i] for i in range(ncls)]
         return bbox_results, segm_results
 
     def forward_test(self, imgs, img_metas, **kwargs):

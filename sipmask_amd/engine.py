@@ -317,6 +317,27 @@ class SipMaskEngine:
         o = self.nms_out
         return dict(det_bboxes=o["det"], det_labels=o["labels"], idxs_keep=o["keep"], ndet=o["ndet"], masks=self.masks)
 
+    def encode_rle(self, canvas_hw=None, fetch=True, max_runs=8192):
+        """Result packing on device (sipmask_head.py:645-657 without the per-mask D2H): run-length encodes the
+        masks of the last run() on the current stream, restricted to each detection's box (sm_mask_rects).
+        Returns per image the list of RLE dicts (fetch=True: two small D2H copies) or the device buffers."""
+        canvas_hw = tuple(canvas_hw or self.img_shape[:2])
+        if getattr(self, "_rle", None) is None or self._rle["canvas_w"] != canvas_hw[1] or \
+                self._rle["max_runs"] < max_runs:
+            self._rle = H.rle_alloc(self.batch, self.max_num, canvas_hw[1], self.device, max_runs=max_runs)
+        H.mask_rects(self.nms_out["det"], 1.0, 2.0, 2.0, self._rle["rect"])
+        H.rle_encode(self.masks, self.nms_out["ndet"], canvas_hw, self._rle, self._rle["rect"])
+        if not fetch:
+            return self._rle
+        nd = self.nms_out["ndet"].cpu().tolist()
+        try:
+            return H.rle_fetch(self._rle, self.batch, self.max_num, nd, canvas_hw)
+        except RuntimeError:
+            need = int(-self._rle["nruns"].min().item()) + 1
+            if need <= max_runs:
+                raise
+            return self.encode_rle(canvas_hw, True, need)
+
     # -------------------------------------------------------------------------------- API views
     def head_outputs(self):
         """(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks) as NCHW views, as
@@ -389,9 +410,17 @@ class PostProcessor:
                           if want_pos_masks else None)
         H.mask_assemble(self.basis, False, self.sel["cofs"], self.out["keep"], self.out["det"], self.out["ndet"],
                         self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, 0.4, masks, self.pos_masks)
+        self.masks = masks
         nd = self.out["ndet"].cpu().tolist()
         res = []
         for b in range(self.B):
             n = nd[b]
             res.append((self.out["det"][b, :n], self.out["labels"][b, :n], self.out["keep"][b, :n], masks[b, :n]))
         return res
+
+    def encode_rle(self, canvas_hw):
+        """RLE dicts of the masks of the last run(), per image (sipmask_head.py:645-657), encoded on device."""
+        from . import ops as P
+        rect = torch.zeros(self.B * self.max_num, 4, dtype=torch.int32, device=self.dev)
+        H.mask_rects(self.out["det"], self.box_mul, 2.0, self.up, rect)
+        return P.encode_masks(self.masks, self.out["ndet"], canvas_hw, rect)

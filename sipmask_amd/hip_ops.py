@@ -214,6 +214,15 @@ def multiclass_nms(boxes, scores, ctr, ncand, score_thr, iou_thr, max_num, out):
                                      _lib.ptr(out["ws_nms"]), _lib.stream_ptr()), "sm_multiclass_nms")
 
 
+def fast_nms(boxes, scores, ctr, ncand, score_thr, iou_thr, top_k, max_num, out):
+    lib = _lib.load()
+    b, c, k = scores.shape
+    _lib.check(lib.sm_fast_nms(_lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(ctr), _lib.ptr(ncand), b, k, c,
+                               float(score_thr), float(iou_thr), int(top_k), int(max_num), _lib.ptr(out["det"]),
+                               _lib.ptr(out["labels"]), _lib.ptr(out["keep"]), _lib.ptr(out["ndet"]),
+                               _lib.ptr(out["ws_nms"]), _lib.stream_ptr()), "sm_fast_nms")
+
+
 def mask_assemble(basis, basis_hwc, cofs, keep, det, ndet, hm, wm, ho, wo, box_mul, box_div, up_scale, thr,
                   masks, pos_masks=None):
     lib = _lib.load()
@@ -224,3 +233,58 @@ def mask_assemble(basis, basis_hwc, cofs, keep, det, ndet, hm, wm, ho, wo, box_m
                                     float(up_scale), float(thr), _lib.ptr(masks), _lib.ptr(pos_masks),
                                     _lib.stream_ptr()), "sm_mask_assemble")
     return masks
+
+
+# ------------------------------------------------------------------------------- device RLE (result packing)
+def rle_alloc(batch, max_num, canvas_w, device, max_runs=8192, packed_cap=None):
+    lib = _lib.load()
+    nd = batch * max_num
+    if packed_cap is None:
+        packed_cap = nd * max_runs              # ~1-2 characters per run in practice; checked after the launch
+    ws = lib.sm_rle_workspace(batch, max_num, canvas_w, max_runs)
+    return dict(counts=torch.empty(nd, max_runs, dtype=torch.int32, device=device),
+                nruns=torch.zeros(nd, dtype=torch.int32, device=device),
+                nchars=torch.zeros(nd, dtype=torch.int32, device=device),
+                packed=torch.empty(int(packed_cap), dtype=torch.uint8, device=device),
+                offsets=torch.zeros(nd + 1, dtype=torch.int64, device=device),
+                rect=torch.zeros(nd, 4, dtype=torch.int32, device=device),
+                ws=torch.empty(int(ws), dtype=torch.uint8, device=device), max_runs=max_runs, canvas_w=canvas_w)
+
+
+def mask_rects(det, box_mul, box_div, up_scale, rect):
+    lib = _lib.load()
+    b, n = det.shape[0], det.shape[1]
+    _lib.check(lib.sm_mask_rects(_lib.ptr(det), b, n, float(box_mul), float(box_div), float(up_scale),
+                                 _lib.ptr(rect), _lib.stream_ptr()), "sm_mask_rects")
+    return rect
+
+
+def rle_encode(masks, ndet, canvas_hw, out, rect=None):
+    """masks u8 [B][max_num][ho][wo] -> run lengths + packed rleToString bytes, all on device (no sync)."""
+    lib = _lib.load()
+    b, n, ho, wo = masks.shape
+    assert out["canvas_w"] == int(canvas_hw[1])
+    _lib.check(lib.sm_rle_encode(_lib.ptr(masks), _lib.ptr(ndet), _lib.ptr(rect), b, n, ho, wo, int(canvas_hw[0]),
+                                 int(canvas_hw[1]), int(out["max_runs"]), _lib.ptr(out["counts"]),
+                                 _lib.ptr(out["nruns"]), _lib.ptr(out["nchars"]), _lib.ptr(out["packed"]),
+                                 int(out["packed"].numel()), _lib.ptr(out["offsets"]), _lib.ptr(out["ws"]),
+                                 _lib.stream_ptr()), "sm_rle_encode")
+
+
+def rle_fetch(out, batch, max_num, ndet, canvas_hw):
+    """Two D2H copies for the whole batch (offsets+run counts, then the packed strings) ->
+    per image a list of {'size': [H, W], 'counts': bytes} (the pycocotools RLE dict, sipmask_head.py:655)."""
+    nruns = out["nruns"].cpu().numpy()
+    offs = out["offsets"].cpu().numpy()
+    if (nruns < 0).any():
+        raise RuntimeError("sm_rle_encode: max_runs=%d too small, a mask needs %d runs" % (out["max_runs"], -nruns.min()))
+    total = int(offs[-1])
+    if total > out["packed"].numel():
+        raise RuntimeError("sm_rle_encode: packed capacity %d < %d" % (out["packed"].numel(), total))
+    blob = out["packed"][:total].cpu().numpy().tobytes()
+    size = [int(canvas_hw[0]), int(canvas_hw[1])]
+    res = []
+    for b in range(batch):
+        res.append([dict(size=list(size), counts=blob[offs[b * max_num + i]:offs[b * max_num + i + 1]])
+                    for i in range(int(ndet[b]))])
+    return res

@@ -276,6 +276,48 @@ def multiclass_nms_idx(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-
     return out["det"][0, :n], out["labels"][0, :n], out["keep"][0, :n]
 
 
+def fast_nms(boxes, scores, masks, iou_threshold=0.5, top_k=200, score_thr=0.1, max_num=100):
+    """SipMaskHead.fast_nms (sipmask_head.py:868-910) on device for one image.  boxes [K,4], scores [C,K]
+    (already multiplied by centerness, :603), masks [K,D] (the coefficient rows).  Returns
+    (boxes [N,5], classes [N] long, masks [N,D]); ties in a class are ranked by candidate index."""
+    _lib.require_cuda(boxes, scores, masks)
+    c, k = scores.shape
+    dev = boxes.device
+    if k == 0:
+        return boxes.new_zeros((0, 5)), boxes.new_zeros((0,), dtype=torch.long), masks[:0]
+    out = H.multiclass_nms_alloc(1, k, c, max_num, dev)
+    H.fast_nms(boxes.float().contiguous().view(1, k, 4), scores.float().contiguous().view(1, c, k),
+               torch.ones(1, k, device=dev), torch.full((1,), k, dtype=torch.int32, device=dev), score_thr,
+               iou_threshold, top_k, max_num, out)
+    n = int(out["ndet"][0].item())
+    keep = out["keep"][0, :n]
+    return out["det"][0, :n], out["labels"][0, :n], masks[keep]
+
+
+def encode_masks(masks, ndet, canvas_hw, rect=None, max_runs=8192):
+    """Device replacement of the reference's per-detection `mask.cpu()` + paste + `mask_util.encode` loop
+    (sipmask_head.py:645-657).  masks u8 [B, max_num, ho, wo] (0/1), ndet int32 [B].  Returns, per image, the
+    list of RLE dicts {'size': [H, W], 'counts': bytes} of its first ndet[b] detections.  The run buffer is
+    grown and the launch repeated if a mask has more than max_runs runs."""
+    _lib.require_cuda(masks, ndet)
+    if masks.dtype != torch.uint8:
+        raise TypeError("masks must be uint8 0/1")
+    b, n = masks.shape[0], masks.shape[1]
+    nd = ndet.cpu().numpy()
+    while True:
+        out = H.rle_alloc(b, n, int(canvas_hw[1]), masks.device, max_runs=max_runs)
+        H.rle_encode(masks.contiguous(), ndet, canvas_hw, out, rect)
+        nr = out["nruns"].min().item()
+        if nr < 0:
+            max_runs = int(-nr) + 1
+            continue
+        need = int(out["offsets"][-1].item())
+        if need > out["packed"].numel():
+            out = H.rle_alloc(b, n, int(canvas_hw[1]), masks.device, max_runs=max_runs, packed_cap=need)
+            H.rle_encode(masks.contiguous(), ndet, canvas_hw, out, rect)
+        return H.rle_fetch(out, b, n, nd, canvas_hw)
+
+
 class Scale(nn.Module):
     """M/mmdet/ops/scale.py:5-15"""
 

@@ -131,22 +131,22 @@ class SipMaskHead(nn.Module):
         return post.run()
 
     def get_bboxes(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg, rescale=None):
-        """Reference packaging (sipmask_head.py:645-662): list of (det_bboxes, det_labels, cls_segms).
-        pycocotools is not part of this path, so cls_segms holds the binary uint8 masks (the array the
-        reference hands to mask_util.encode at :655) bucketed by label, instead of RLE dicts."""
+        """Reference packaging (sipmask_head.py:645-662): list of (det_bboxes, det_labels, cls_segms) with
+        cls_segms[label] = list of COCO RLE dicts {'size': [H, W], 'counts': bytes}.  The masks are pasted on the
+        ori_shape / img_shape canvas and run-length encoded ON DEVICE (sm_rle_encode), so the per-detection
+        `mask.cpu()` + `mask_util.encode` loop of the reference becomes two small D2H copies per batch."""
+        from .engine import PostProcessor
+        post = PostProcessor(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg,
+                             self.strides, rescale)
+        res = post.run()
+        meta = img_metas[0]
+        shp = meta['ori_shape'] if rescale else meta['img_shape']
+        rles = post.encode_rle(shp[:2])
         out = []
-        for img_id, (det, labels, _, masks) in enumerate(
-                self.get_masks(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg, rescale)):
-            meta = img_metas[img_id]
-            shp = meta['ori_shape'] if rescale else meta['img_shape']
+        for (det, labels, _, _), rle in zip(res, rles):
             cls_segms = [[] for _ in range(self.num_classes - 1)]
-            m = masks.cpu().numpy()
-            lab = labels.cpu().numpy()
-            for i in range(det.shape[0]):
-                im_mask = np.zeros((shp[0], shp[1]), dtype=np.uint8)
-                hh, ww = min(m.shape[1], shp[0]), min(m.shape[2], shp[1])
-                im_mask[:hh, :ww] = m[i, :hh, :ww]
-                cls_segms[int(lab[i])].append(im_mask)
+            for lab, r in zip(labels.cpu().tolist(), rle):
+                cls_segms[lab].append(r)
             out.append((det, labels, cls_segms))
         return out
 

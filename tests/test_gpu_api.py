@@ -79,6 +79,19 @@ def test_get_masks_api_bit_exact_vs_oracle(det):
                                    [t.cuda() for t in cof], fm.cuda(), metas, cfg, rescale=False)
     assert len(out) == B and len(out[0][2]) == C
     assert sum(len(s) for s in out[0][2]) == out[0][0].shape[0]
+    # the RLE dicts (encoded on device) decode to exactly the masks get_masks returned (rescale=False pass)
+    res = det.bbox_head.get_masks([t.cuda() for t in cls], [t.cuda() for t in bb], [t.cuda() for t in ctr],
+                                  [t.cuda() for t in cof], fm.cuda(), metas, cfg, rescale=False)
+    for b in range(B):
+        d, l, k, m = res[b]
+        m, l = m.cpu().numpy(), l.cpu().tolist()
+        seen = [0] * C
+        for i in range(d.shape[0]):
+            r = out[b][2][l[i]][seen[l[i]]]
+            seen[l[i]] += 1
+            assert r["size"] == [256, 320]
+            assert r["counts"] == O.paste_and_encode(m[i], (256, 320))["counts"]
+            np.testing.assert_array_equal(O.rle_decode(O.rle_from_string(r["counts"]), 256, 320), m[i][:256, :320])
 
 
 def test_simple_test_end_to_end(det):
@@ -90,9 +103,15 @@ def test_simple_test_end_to_end(det):
     assert n == sum(len(s) for s in segm_results)
     for b in bbox_results:
         assert b.shape[1] == 5
-    for s in segm_results:
-        for m in s:
-            assert m.shape == (160, 190) and m.dtype == np.uint8
+    eng = det.prepare(1, (160, 192), (160, 190, 3))          # the plan simple_test just ran: same masks
+    masks = eng.masks[0].cpu().numpy()
+    labels = eng.nms_out["labels"][0].cpu().tolist()
+    seen = [0] * 80
+    for i in range(n):
+        r = segm_results[labels[i]][seen[labels[i]]]
+        seen[labels[i]] += 1
+        assert r["size"] == [160, 190] and isinstance(r["counts"], bytes)
+        np.testing.assert_array_equal(O.rle_decode(O.rle_from_string(r["counts"]), 160, 190), masks[i][:160, :190])
     # forward(return_loss=False) takes the reference's nested-list protocol
     r2 = det([img], [meta], return_loss=False)
     assert len(r2[0]) == 80

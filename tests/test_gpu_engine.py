@@ -93,3 +93,25 @@ def test_postprocess_matches_oracle_on_engine_head_outputs(setup):
             assert bool(((r["up"] - 0.4).abs()[diff] < 1e-4).all())
             assert int(diff.sum()) <= max(5, int(1e-5 * diff.numel()))
     assert total > 0, "calibration failed: no detections, NMS/mask path not exercised"
+
+
+def test_r101_backbone_features():
+    """BASELINE config #3 (SipMask-R101): same engine, depth 101 (layer3 has 23 blocks)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd.engine import SipMaskEngine
+    sd = OM.init_state_dict(101, 0)
+    img = torch.randn(1, 3, 128, 160, generator=torch.Generator().manual_seed(3))
+    eng = SipMaskEngine(sd, 1, (128, 160), 101)
+    eng.run(img.cuda())
+    torch.cuda.synchronize()
+    feats = OM.backbone_forward(sd, img, 101)
+    pyr = OM.fpn_forward(sd, feats)
+    assert len([c for c in eng.convs if c.name.startswith("backbone.layer3.")]) == 23 * 3 + 1
+    for i, (buf, h, w, c) in enumerate(eng.backbone_feats):
+        got = buf.float().view(1, h, w, c).permute(0, 3, 1, 2)
+        assert _rel(got, feats[i]) < 0.03, (i, _rel(got, feats[i]))
+    lv = eng.lv
+    h, w = lv.sizes[0]
+    got = eng.pyr[:h * w].float().view(1, h, w, 256).permute(0, 3, 1, 2)
+    assert _rel(got, pyr[0]) < 0.04

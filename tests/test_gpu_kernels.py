@@ -337,6 +337,126 @@ def test_multiclass_nms_idx_vs_oracle(case):
     np.testing.assert_array_equal(b.cpu().numpy(), rb)       # boxes copied, score = f32 product: exact
 
 
+@pytest.mark.parametrize("case", [(700, 80, 0.1), (150, 5, 0.0), (1, 3, 0.1), (3000, 20, 0.3)])
+def test_fast_nms_vs_oracle(case):
+    """SipMaskHead.fast_nms (ssd_flag configs, sipmask_head.py:868-910): same boxes, classes, coefficient rows."""
+    from sipmask_amd import ops as P
+    dev = _dev()
+    K, C, thr = case
+    rng = np.random.RandomState(K * 3 + C)
+    xy = rng.rand(K, 2).astype(np.float32) * 300
+    wh = rng.rand(K, 2).astype(np.float32) * 120 + 4
+    boxes = np.concatenate([xy, xy + wh], 1)
+    if K > 10:
+        boxes[5] = boxes[4]                               # exact duplicates
+        boxes[7, 2:] = boxes[7, :2]                       # two degenerate (zero-area) boxes: their mutual IoU is
+        boxes[9, 2:] = boxes[9, :2]                       # 0/0 = NaN, which torch.max propagates (-> not kept)
+    scores = (rng.rand(C, K).astype(np.float32) ** 3)
+    scores[:, : K // 4] = np.round(scores[:, : K // 4], 2)   # ties
+    cofs = rng.randn(K, 128).astype(np.float32)
+    rb, rl, rm = O.fast_nms(boxes, scores, cofs, 0.5, 200, thr, 100)
+    b, l, m = P.fast_nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev),
+                         torch.from_numpy(cofs).to(dev), 0.5, 200, thr)
+    np.testing.assert_array_equal(l.cpu().numpy(), rl)
+    np.testing.assert_array_equal(b.cpu().numpy(), rb)
+    np.testing.assert_array_equal(m.cpu().numpy(), rm)
+
+
+@pytest.mark.parametrize("case", [
+    # (ho, wo, canvas_h, canvas_w, kind)
+    (64, 96, 64, 96, "blobs"), (64, 96, 60, 91, "blobs"), (50, 75, 64, 96, "blobs"), (37, 53, 37, 53, "noise"),
+    (200, 336, 200, 333, "boxes"), (800, 1344, 800, 1333, "boxes"), (16, 16, 16, 16, "edge")])
+def test_rle_encode_vs_oracle(case):
+    """Device COCO RLE (sm_rle_encode) == the oracle's restatement of maskApi.c on pasted masks: run lengths and
+    compressed strings, with and without the box hint, aligned and unaligned rows, canvas smaller/larger."""
+    from sipmask_amd import hip_ops as H, ops as P
+    dev = _dev()
+    ho, wo, ch, cw, kind = case
+    rng = np.random.RandomState(ho * 7 + wo)
+    B, n = 2, 6
+    m = np.zeros((B, n, ho, wo), np.uint8)
+    rect = np.zeros((B, n, 4), np.int32)
+    for b in range(B):
+        for i in range(n):
+            x0, x1 = sorted(rng.randint(0, wo + 1, 2))
+            y0, y1 = sorted(rng.randint(0, ho + 1, 2))
+            if kind == "edge":      # boxes touching the borders, single rows/columns, empty and full masks
+                x0, y0, x1, y1 = [(0, 0, wo, ho), (0, 0, 1, ho), (wo - 1, 0, wo, ho), (0, ho - 1, wo, ho),
+                                  (3, 3, 3, 3), (5, 0, 9, ho)][i]
+            if kind == "noise":
+                m[b, i] = rng.rand(ho, wo) < 0.5
+                x0, y0, x1, y1 = 0, 0, wo, ho
+            elif kind == "blobs":
+                yy, xx = np.mgrid[:ho, :wo]
+                blob = ((yy - (y0 + y1) / 2) ** 2 * 1.3 + (xx - (x0 + x1) / 2) ** 2) < (max(x1 - x0, 2) / 2) ** 2
+                m[b, i, y0:y1, x0:x1] = (blob & (rng.rand(ho, wo) < 0.97))[y0:y1, x0:x1]
+            else:
+                m[b, i, y0:y1, x0:x1] = 1
+                if i % 2:
+                    m[b, i, y0:y1, x0:x1] &= (rng.rand(y1 - y0, x1 - x0) < 0.9)
+            rect[b, i] = [x0 - rng.randint(0, 3), y0 - rng.randint(0, 3), x1 + rng.randint(0, 3), y1 + rng.randint(0, 3)]
+    ndet = np.array([n, n - 2], np.int32)
+    mt, nt, rt = torch.from_numpy(m).to(dev), torch.from_numpy(ndet).to(dev), torch.from_numpy(rect).to(dev)
+    def pasted(x):
+        im = np.zeros((ch, cw), np.uint8)
+        im[:min(ho, ch), :min(wo, cw)] = x[:ch, :cw]
+        return im
+    need = max(len(O.rle_counts(pasted(m[b, i]))) for b in range(B) for i in range(n))
+    for hint in (None, rt):
+        out = H.rle_alloc(B, n, cw, dev, max_runs=need + 1)
+        H.rle_encode(mt, nt, (ch, cw), out, hint)
+        got = H.rle_fetch(out, B, n, ndet, (ch, cw))
+        nruns = out["nruns"].cpu().numpy().reshape(B, n)
+        counts = out["counts"].cpu().numpy().view(np.uint32).reshape(B, n, -1)
+        for b in range(B):
+            assert len(got[b]) == ndet[b]
+            for i in range(n):
+                if i >= ndet[b]:
+                    assert nruns[b, i] == 0
+                    continue
+                ref = O.paste_and_encode(m[b, i], (ch, cw))
+                im = np.zeros((ch, cw), np.uint8)
+                im[:min(ho, ch), :min(wo, cw)] = m[b, i][:ch, :cw]
+                rc = O.rle_counts(im)
+                assert nruns[b, i] == len(rc)
+                np.testing.assert_array_equal(counts[b, i, :len(rc)], np.array(rc, np.uint32))
+                assert got[b][i]["counts"] == ref["counts"], (b, i)
+                assert got[b][i]["size"] == [ch, cw]
+    # the convenience wrapper grows max_runs when a mask needs more
+    res = P.encode_masks(mt, nt, (ch, cw), max_runs=8)
+    for b in range(B):
+        for i in range(ndet[b]):
+            assert res[b][i]["counts"] == O.paste_and_encode(m[b, i], (ch, cw))["counts"]
+
+
+def test_mask_rects_cover_assembled_masks():
+    """sm_mask_rects is a safe hint: every non-zero pixel sm_mask_assemble writes lies inside the rectangle."""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    B, K, n, hm, wm = 1, 40, 40, 64, 96
+    basis = torch.randn(B, 32, hm, wm, generator=g).to(dev)
+    cofs = (torch.randn(B, K, 128, generator=g) * 0.5).to(dev)
+    xy = torch.rand(B, n, 2, generator=g) * torch.tensor([2.0 * wm, 2.0 * hm]) - 10
+    wh = torch.rand(B, n, 2, generator=g) * 60 + 1
+    det = torch.cat([xy, xy + wh, torch.rand(B, n, 1, generator=g)], 2).to(dev)
+    keep = torch.arange(n).view(1, n).to(dev)
+    ndet = torch.tensor([n], dtype=torch.int32, device=dev)
+    for up, mul in ((2.0, 1.0), (2.0 / 0.75, 0.75)):
+        ho, wo = int(hm * up), int(wm * up)
+        wo -= wo % 4
+        masks = torch.zeros(B, n, ho, wo, dtype=torch.uint8, device=dev)
+        H.mask_assemble(basis, False, cofs, keep, det, ndet, hm, wm, ho, wo, mul, 2.0, up, 0.4, masks)
+        rect = torch.zeros(B * n, 4, dtype=torch.int32, device=dev)
+        H.mask_rects(det, mul, 2.0, up, rect)
+        r, m = rect.cpu().numpy(), masks.cpu().numpy()
+        assert m.sum() > 0
+        for i in range(n):
+            ys, xs = np.nonzero(m[0, i])
+            if len(ys):
+                assert xs.min() >= r[i, 0] and xs.max() < r[i, 2] and ys.min() >= r[i, 1] and ys.max() < r[i, 3], (i, r[i])
+
+
 def test_det_select_vs_oracle():
     """score -> per-level top-k -> gather/decode (sipmask_head.py:563-591) for a 2-image batch."""
     from sipmask_amd import hip_ops as H

@@ -178,3 +178,36 @@ def test_mask_assemble_consistency():
     # outside the half-resolution box the probabilities are exactly zero
     assert float(r["pos_masks"][0, :3].abs().max()) == 0
     assert set(np.unique(r["masks"].numpy())) <= {0, 1}
+
+
+def test_rle_restatement_round_trip():
+    """COCO RLE (maskApi.c rleEncode / rleToString / rleFrString / rleDecode restated; pycocotools is absent, so
+    this pins self-consistency only): brute-force run lengths, string round trip, decode == mask, paste rule."""
+    rng = np.random.RandomState(0)
+    for t in range(120):
+        h, w = rng.randint(1, 40), rng.randint(1, 40)
+        m = (rng.rand(h, w) < rng.rand()).astype(np.uint8)
+        if t % 7 == 0:
+            m[:] = 0
+        if t % 11 == 0:
+            m[:] = 1
+        c = ops.rle_counts(m)
+        ref, p, cc = [], 0, 0
+        for x in m.T.reshape(-1):              # maskApi.c rleEncode, literally
+            if x != p:
+                ref.append(cc)
+                cc, p = 0, x
+            cc += 1
+        ref.append(cc)
+        assert c == ref and sum(c) == h * w
+        s = ops.rle_to_string(c)
+        assert all(48 <= ch < 48 + 64 for ch in s)
+        assert ops.rle_from_string(s) == c
+        np.testing.assert_array_equal(ops.rle_decode(c, h, w), m)
+    assert ops.rle_encode(np.array([[0, 1], [1, 1]]))["counts"] == b"13"
+    assert ops.rle_counts(np.array([[1, 0], [1, 1]])) == [0, 2, 1, 1]
+    # large runs need several 5-bit groups; negative deltas carry the sign bit
+    c = [100000, 3, 5, 2, 70000]
+    assert ops.rle_from_string(ops.rle_to_string(c)) == c
+    r = ops.paste_and_encode(np.ones((4, 6), np.uint8), (3, 8))
+    assert r["size"] == [3, 8] and ops.rle_from_string(r["counts"]) == [0, 18, 6]
