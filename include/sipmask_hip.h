@@ -148,7 +148,8 @@ typedef struct {
   int32_t nms_pre;               /* cfg.nms_pre */
   int32_t img_h, img_w;          /* img_shape for the clamp (transforms.py:219-223) */
   int32_t kmax;                  /* candidate capacity per image = sum_l min(nms_pre, h*w) */
-  float scale_factor;            /* boxes are divided by it when rescale != 0 (sipmask_head.py:587-588) */
+  float scale_factor[4];         /* x1,y1,x2,y2 are divided by these when rescale != 0 (sipmask_head.py:587-588;
+                                  * a keep_ratio=False pipeline gives [w,h,w,h] scales, a scalar is repeated) */
   int32_t rescale;
   int32_t reg_prescaled;         /* 1: reg ch0-3 already carry x stride (API path: bbox_preds as
                                     returned by SipMaskHead.forward) */
@@ -195,8 +196,8 @@ int sm_fast_nms(const float* boxes, const float* scores, const float* ctr, const
 int64_t sm_rle_workspace(int batch, int max_num, int canvas_w, int max_runs);
 /* rect hint for sm_rle_encode from the detections sm_mask_assemble used (same box_mul/box_div/up_scale):
  * a conservative output-pixel rectangle per detection outside which the assembled mask is zero. */
-int sm_mask_rects(const float* det, int batch, int max_num, float box_mul, float box_div, double up_scale,
-                  int32_t* rect, sm_stream_t stream);
+int sm_mask_rects(const float* det, int batch, int max_num, float box_mul_x, float box_mul_y, float box_div,
+                  double up_scale_h, double up_scale_w, int32_t* rect, sm_stream_t stream);
 int sm_rle_encode(const uint8_t* masks, const int32_t* ndet, const int32_t* rect, int batch, int max_num, int ho,
                   int wo, int canvas_h, int canvas_w, int max_runs, uint32_t* counts, int32_t* nruns,
                   int32_t* nchars, uint8_t* packed, int64_t packed_cap, int64_t* offsets, void* workspace,
@@ -213,14 +214,18 @@ int sm_nms(const float* dets, int n, float iou_thr, int64_t* keep, int32_t* nkee
  * sipmask_head.py:609-633 + CropSplit M/mmdet/ops/crop/src/crop_split_cuda_kernel.cu:19-59.
  * basis f32: [B][Hm][Wm][32] (basis_hwc=1) or [B][32][Hm][Wm] (basis_hwc=0);
  * cofs f32 [B][kmax][128] gathered through keep[B][max_num]; det f32 [B][max_num][5].
- * masks u8 [B][max_num][Ho][Wo] (rows >= ndet[b] untouched; Wo % 4 == 0);
+ * masks u8 [B][max_num][Ho][mask_pitch] (rows >= ndet[b] untouched; mask_pitch % 4 == 0, >= Wo; the pad
+ * columns of a written dword are zeroed);
  * pos_masks f32 [B][max_num][Hm][Wm] (post sigmoid+crop, the CropSplit output) or NULL.
- * crop box = (det[:4] * box_mul) / box_div  (sipmask_head.py:623: * scale_factor / 2);
- * up_scale = the F.interpolate scale_factor (:630-632), Ho/Wo the resulting size. */
+ * crop box = (det[:4] * box_mul_{x,y}) / box_div  (sipmask_head.py:623: * scale_factor / 2, per coordinate for
+ * the [w,h,w,h] scale factors of keep_ratio=False pipelines);
+ * up_scale_{h,w} = the F.interpolate scale_factor (:629-632; ssd_flag: 2 / scale_factor[3:1:-1]), Ho/Wo the
+ * resulting size. */
 int sm_mask_assemble(const float* basis, int basis_hwc, const float* cofs, const int64_t* keep,
                      const float* det, const int32_t* ndet, int batch, int kmax, int max_num,
-                     int hm, int wm, int ho, int wo, float box_mul, float box_div, double up_scale,
-                     float mask_thr, uint8_t* masks, float* pos_masks, sm_stream_t stream);
+                     int hm, int wm, int ho, int wo, int mask_pitch, float box_mul_x, float box_mul_y, float box_div,
+                     double up_scale_h, double up_scale_w, float mask_thr, uint8_t* masks, float* pos_masks,
+                     sm_stream_t stream);
 
 /* ---- training-side ops ---------------------------------------------------------------- */
 

@@ -38,10 +38,12 @@ def _xavier_uniform(w, g):   # mmcv xavier_init(distribution='uniform'), fpn.py:
     return w.uniform_(-a, a, generator=g)
 
 
-def init_state_dict(depth=50, seed=0, calibrate=True, num_classes=81):
+def init_state_dict(depth=50, seed=0, calibrate=True, num_classes=81, stacked_convs=4, norm=True):
     """Build a float32 state_dict with the reference's parameter names/shapes
      and init rules (resnet.py:479-497, fpn.py:131-135,
-    sipmask_head.py:226-239), then apply the calibration overrides."""
+    sipmask_head.py:226-239), then apply the calibration overrides.
+    stacked_convs / norm: the SSD configs use stacked_convs=2, norm_cfg=None (towers get conv biases instead of
+    GN, sipmask_head.py:161-185 `bias=self.norm_cfg is None`; FeatureAlign flag_norm=False, :196)."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
 
@@ -91,14 +93,14 @@ def init_state_dict(depth=50, seed=0, calibrate=True, num_classes=81):
         conv("neck.fpn_convs.%d.conv" % i, 256, 256, 3, bias=True, init="xavier")
     # ---- head
     h = "bbox_head."
-    for i in range(3):
-        conv(h + "cls_convs.%d.conv" % i, 256, 256, 3, init="normal", std=0.01)
-        sd[h + "cls_convs.%d.gn.weight" % i] = torch.ones(256)
-        sd[h + "cls_convs.%d.gn.bias" % i] = torch.zeros(256)
-    for i in range(4):
-        conv(h + "reg_convs.%d.conv" % i, 256, 256, 3, init="normal", std=0.01)
-        sd[h + "reg_convs.%d.gn.weight" % i] = torch.ones(256)
-        sd[h + "reg_convs.%d.gn.bias" % i] = torch.zeros(256)
+    for kind, n in (("cls", stacked_convs - 1), ("reg", stacked_convs)):
+        for i in range(n):
+            conv(h + "%s_convs.%d.conv" % (kind, i), 256, 256, 3, bias=not norm, init="normal", std=0.01)
+            if norm:
+                sd[h + "%s_convs.%d.gn.weight" % (kind, i)] = torch.ones(256)
+                sd[h + "%s_convs.%d.gn.bias" % (kind, i)] = torch.zeros(256)
+            elif calibrate:        # exercise the bias path of the norm-free towers
+                sd[h + "%s_convs.%d.conv.bias" % (kind, i)].normal_(0, 0.05, generator=g)
     ncls = num_classes - 1
     conv(h + "fcos_cls", ncls, 256, 3, bias=True, init="normal", std=0.01)
     sd[h + "fcos_cls.bias"].fill_(float(-math.log((1 - 0.01) / 0.01)))
@@ -118,10 +120,10 @@ def init_state_dict(depth=50, seed=0, calibrate=True, num_classes=81):
     if calibrate:
         # random-normal tower weights at std 0.01 shrink the signal by ~0.5x per
         # layer; give the synthetic net O(1) activations so boxes/masks are non-trivial
-        for i in range(3):
-            sd[h + "cls_convs.%d.conv.weight" % i].mul_(3.0)
-        for i in range(4):
-            sd[h + "reg_convs.%d.conv.weight" % i].mul_(3.0)
+        for i in range(stacked_convs - 1):
+            sd[h + "cls_convs.%d.conv.weight" % i].mul_(3.0 if norm else 1.5)
+        for i in range(stacked_convs):
+            sd[h + "reg_convs.%d.conv.weight" % i].mul_(3.0 if norm else 1.5)
         sd[h + "feat_align.conv_adaption.weight"].mul_(3.0)
         sd[h + "fcos_reg.weight"].mul_(3.0)
         sd[h + "fcos_reg.bias"].fill_(2.0)
@@ -198,25 +200,37 @@ def fpn_forward(sd, feats, prefix="neck."):
 
 
 def _tower(sd, x, p):
-    x = F.conv2d(x, sd[p + ".conv.weight"], None, 1, 1)
-    return F.relu(F.group_norm(x, 32, sd[p + ".gn.weight"], sd[p + ".gn.bias"], 1e-5))
+    """ConvModule conv -> (GN32) -> ReLU, conv_module.py:34-132; bias iff there is no norm."""
+    x = F.conv2d(x, sd[p + ".conv.weight"], sd.get(p + ".conv.bias"), 1, 1)
+    if p + ".gn.weight" in sd:
+        x = F.group_norm(x, 32, sd[p + ".gn.weight"], sd[p + ".gn.bias"], 1e-5)
+    return F.relu(x)
+
+
+def tower_depths(sd, prefix="bbox_head."):
+    """(#cls convs, #reg convs, norm?) as laid down by _init_layers (sipmask_head.py:159-185)."""
+    n = lambda kind: sum(1 for k in sd if k.startswith(prefix + kind + "_convs.") and k.endswith(".conv.weight"))
+    return n("cls"), n("reg"), (prefix + "reg_convs.0.gn.weight") in sd
 
 
 def head_forward(sd, feats, prefix="bbox_head.", strides=FPN_STRIDES, return_aux=False):
     """sipmask_head.py:241-287."""
     h = prefix
     cls_scores, bbox_preds, ctrs, cofs, fm = [], [], [], [], []
+    ncls_convs, nreg_convs, flag_norm = tower_depths(sd, h)
     aux = dict(bbox_raw=[], offsets=[], cls_feat=[], reg_feat=[], aligned=[])
     for li, (x, stride) in enumerate(zip(feats, strides)):
         cf, rf = x, x
-        for i in range(3):
+        for i in range(ncls_convs):
             cf = _tower(sd, cf, h + "cls_convs.%d" % i)
-        for i in range(4):
+        for i in range(nreg_convs):
             rf = _tower(sd, rf, h + "reg_convs.%d" % i)
         bbox_pred = sd[h + "scales.%d.scale" % li] * F.conv2d(rf, sd[h + "fcos_reg.weight"], sd[h + "fcos_reg.bias"], 1, 1)
         offset = F.conv2d(bbox_pred, sd[h + "feat_align.conv_offset.weight"])
         y = ops.deform_conv(cf, offset, sd[h + "feat_align.conv_adaption.weight"], 1, 1, 1, 4)
-        y = F.relu(F.group_norm(y, 32, sd[h + "feat_align.norm.weight"], sd[h + "feat_align.norm.bias"], 1e-5))
+        if flag_norm:                             # FeatureAlign.forward, sipmask_head.py:49-55
+            y = F.group_norm(y, 32, sd[h + "feat_align.norm.weight"], sd[h + "feat_align.norm.bias"], 1e-5)
+        y = F.relu(y)
         cls_scores.append(F.conv2d(y, sd[h + "fcos_cls.weight"], sd[h + "fcos_cls.bias"], 1, 1))
         ctrs.append(F.conv2d(rf, sd[h + "fcos_centerness.weight"], sd[h + "fcos_centerness.bias"], 1, 1))
         bbox_preds.append(bbox_pred.float() * stride)
@@ -280,20 +294,28 @@ def select_candidates(cls_scores, bbox_preds, ctrs, cofs, img_shape, nms_pre=100
 
 
 def get_masks_single(cls_scores, bbox_preds, ctrs, cofs, feat_mask, img_shape, cfg,
-                     scale_factor=1.0, rescale=False):
-    """get_bboxes_single up to (not including) RLE: sipmask_head.py:543-633."""
+                     scale_factor=1.0, rescale=False, ssd_flag=False):
+    """get_bboxes_single up to (not including) RLE: sipmask_head.py:543-633.
+    scale_factor: scalar, or the [w,h,w,h] array of a keep_ratio=False pipeline (ssd_flag configs)."""
     mb, ms, mc, mf, lv, ps = select_candidates(cls_scores, bbox_preds, ctrs, cofs, img_shape,
                                                cfg.get("nms_pre", -1))
     if rescale:
-        mb = mb / float(scale_factor)
-    det, lab, keep = ops.multiclass_nms_idx(mb.numpy(), ms.numpy(), cfg["score_thr"],
-                                            cfg["nms"]["iou_thr"], cfg["max_per_img"],
-                                            score_factors=mc.numpy())
-    out = dict(det_bboxes=det, det_labels=lab, idxs_keep=keep, cand_boxes=mb, cand_scores=ms,
-               cand_ctr=mc, cand_cofs=mf, cand_level=lv, cand_pos=ps)
-    if det.shape[0] > 0:
+        mb = mb / torch.as_tensor(scale_factor, dtype=torch.float32)            # :587-588
+    out = dict(cand_boxes=mb, cand_scores=ms, cand_ctr=mc, cand_cofs=mf, cand_level=lv, cand_pos=ps)
+    if not ssd_flag:
+        det, lab, keep = ops.multiclass_nms_idx(mb.numpy(), ms.numpy(), cfg["score_thr"],
+                                                cfg["nms"]["iou_thr"], cfg["max_per_img"],
+                                                score_factors=mc.numpy())
         det_cofs = mf[torch.from_numpy(keep)]
-        out.update(ops.mask_assemble(feat_mask, det_cofs, det, scale_factor, rescale))
+        out.update(det_bboxes=det, det_labels=lab, idxs_keep=keep)
+    else:                                                                          # :603-605
+        sc = (ms * mc.view(-1, 1))[:, 1:].t().contiguous()
+        det, lab, det_cofs = ops.fast_nms(mb.numpy(), sc.numpy(), mf.numpy(), cfg["nms"]["iou_thr"], 200,
+                                          cfg["score_thr"])
+        det_cofs = torch.from_numpy(det_cofs)
+        out.update(det_bboxes=det, det_labels=lab)
+    if det.shape[0] > 0:
+        out.update(ops.mask_assemble(feat_mask, det_cofs, det, scale_factor, rescale, ssd_flag=ssd_flag))
         out["det_cofs"] = det_cofs
     return out
 

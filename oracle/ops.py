@@ -398,8 +398,9 @@ def py_sigmoid_focal_loss(pred, target, gamma=2.0, alpha=0.25):
 
 
 def mask_assemble(feat_mask, det_cofs, det_boxes, scale_factor=1.0, rescale=None,
-                  mask_thr=0.4, up_scale=2):
-    """M/mmdet/models/anchor_heads/sipmask_head.py:609-633 for ssd_flag=False.
+                  mask_thr=0.4, up_scale=2, ssd_flag=False):
+    """M/mmdet/models/anchor_heads/sipmask_head.py:609-633.  ssd_flag: scale_factor is the [w,h,w,h] array of a
+    keep_ratio=False pipeline and the upsampling is per axis, `scale / scale_factor[3:1:-1]` (:629-630).
 
     feat_mask [32,Hm,Wm] f32, det_cofs [N,128], det_boxes [N,>=4].
     Returns dict(pos_masks [N,Hm,Wm] f32 after sigmoid+crop,
@@ -411,12 +412,18 @@ def mask_assemble(feat_mask, det_cofs, det_boxes, scale_factor=1.0, rescale=None
     img = feat_mask.permute(1, 2, 0)
     logits = torch.stack([img @ det_cofs[:, 32 * q:32 * (q + 1)].t() for q in range(4)], 0)
     probs = torch.sigmoid(logits)
+    sf = np.asarray(scale_factor, np.float32).reshape(-1)
     if rescale is None:                       # sipmask_head.py:621-622
-        scale_factor = 1.0
-    rois = det_boxes[:, :4] * float(scale_factor) / up_scale
+        sf = sf * 0 + 1.0
+    rois = det_boxes[:, :4] * torch.from_numpy(sf) / up_scale             # scalar or per coordinate (:623)
     pos = torch.from_numpy(crop_split(probs.numpy(), rois.numpy(), 2)).permute(2, 0, 1).contiguous()
-    up = F.interpolate(pos.unsqueeze(0), scale_factor=up_scale / float(scale_factor),
-                       mode="bilinear", align_corners=False).squeeze(0)
+    if ssd_flag:
+        ups = (float(up_scale / sf[3]), float(up_scale / sf[2]))           # scale / scale_factor[3:1:-1]
+    else:
+        assert sf.size == 1, "the non-SSD path divides by a scalar scale_factor (:632)"
+        # a python float in img_meta (keep_ratio=True): the division happens in double
+        ups = up_scale / (1.0 if rescale is None else float(np.asarray(scale_factor, np.float64).reshape(-1)[0]))
+    up = F.interpolate(pos.unsqueeze(0), scale_factor=ups, mode="bilinear", align_corners=False).squeeze(0)
     masks = (up > mask_thr).to(torch.uint8)
     return dict(pos_masks=pos, logits=logits, up=up, masks=masks, rois=rois)
 

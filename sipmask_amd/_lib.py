@@ -49,7 +49,7 @@ class DetDesc(C.Structure):
         ("cof_cstride", C.c_int32), ("cof_coff", C.c_int32),
         ("reg_cstride", C.c_int32), ("nms_pre", C.c_int32),
         ("img_h", C.c_int32), ("img_w", C.c_int32), ("kmax", C.c_int32),
-        ("scale_factor", C.c_float), ("rescale", C.c_int32), ("reg_prescaled", C.c_int32),
+        ("scale_factor", C.c_float * 4), ("rescale", C.c_int32), ("reg_prescaled", C.c_int32),
     ]
 
 
@@ -77,11 +77,12 @@ PROTOTYPES = {
     "sm_multiclass_nms": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P]),
     "sm_fast_nms": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sm_rle_workspace": (C.c_int64, [_I, _I, _I, _I]),
-    "sm_mask_rects": (_I, [_P, _I, _I, _F, _F, C.c_double, _P, _P]),
+    "sm_mask_rects": (_I, [_P, _I, _I, _F, _F, _F, C.c_double, C.c_double, _P, _P]),
     "sm_rle_encode": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "sm_nms_workspace": (C.c_int64, [_I]),
     "sm_nms": (_I, [_P, _I, _F, _P, _P, _P, _P]),
-    "sm_mask_assemble": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, C.c_double, _F, _P, _P, _P]),
+    "sm_mask_assemble": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, C.c_double, C.c_double, _F,
+                              _P, _P, _P]),
     "sm_crop_split_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sm_crop_split_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sm_crop_split_gt_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -136,7 +136,7 @@ struct DetArgs {
   int cand0[SM_MAX_LEVELS + 1];  // start of level l inside the per-image candidate list
   int cls_cs, cls_co, cof_cs, cof_co, reg_cs;
   int nms_pre, img_h, img_w, kmax;
-  float scale_factor;
+  float scale_factor[4];
   int rescale, reg_prescaled;
   int topk_cache_floats;   // dynamic LDS floats available to det_topk_kernel (0 = scan global memory)
 };
@@ -215,10 +215,10 @@ __global__ __launch_bounds__(256) void det_gather_kernel(const float* __restrict
       float x2 = fminf(fmaxf(__fadd_rn(x, __fmul_rn(rp[2], fs)), 0.f), xmax);
       float y2 = fminf(fmaxf(__fadd_rn(y, __fmul_rn(rp[3], fs)), 0.f), ymax);
       if (a.rescale) {
-        x1 /= a.scale_factor;
-        y1 /= a.scale_factor;
-        x2 /= a.scale_factor;
-        y2 /= a.scale_factor;
+        x1 /= a.scale_factor[0];
+        y1 /= a.scale_factor[1];
+        x2 /= a.scale_factor[2];
+        y2 /= a.scale_factor[3];
       }
       *reinterpret_cast<float4*>(boxes + o * 4) = make_float4(x1, y1, x2, y2);
       s_row[lc] = row;
@@ -596,7 +596,7 @@ int fill_det_args(const sm_det_desc* d, DetArgs& a) {
   a.img_h = d->img_h;
   a.img_w = d->img_w;
   a.kmax = d->kmax;
-  a.scale_factor = d->scale_factor;
+  for (int i = 0; i < 4; ++i) a.scale_factor[i] = d->scale_factor[i];
   a.rescale = d->rescale;
   a.reg_prescaled = d->reg_prescaled;
   a.topk_cache_floats = 0;

@@ -28,9 +28,9 @@ struct MaskArgs {
   const int32_t* ndet;
   uint8_t* masks;
   float* pos_masks;
-  int kmax, max_num, hm, wm, ho, wo;
+  int kmax, max_num, hm, wm, ho, wo, pitch;   // wo = logical width, pitch = row pitch of masks (multiple of 4)
   long long pix_stride, ch_stride;  // basis strides (elements)
-  float box_mul, box_div, inv_up, thr;
+  float box_mul_x, box_mul_y, box_div, inv_up_x, inv_up_y, thr;
 };
 
 struct DetBox {
@@ -49,10 +49,11 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
   if (nd <= 0) return;
 
   // source window of this output tile
-  auto src_of = [&](int o) { return fmaxf(a.inv_up * ((float)o + 0.5f) - 0.5f, 0.f); };
+  auto src_x = [&](int o) { return fmaxf(a.inv_up_x * ((float)o + 0.5f) - 0.5f, 0.f); };
+  auto src_y = [&](int o) { return fmaxf(a.inv_up_y * ((float)o + 0.5f) - 0.5f, 0.f); };
   const int oxe = min(ox0 + TOW, a.wo) - 1, oye = min(oy0 + TOH, a.ho) - 1;
-  const int sx0 = (int)src_of(ox0), sy0 = (int)src_of(oy0);
-  const int sx1 = min((int)src_of(oxe) + 1, a.wm - 1), sy1 = min((int)src_of(oye) + 1, a.hm - 1);
+  const int sx0 = (int)src_x(ox0), sy0 = (int)src_y(oy0);
+  const int sx1 = min((int)src_x(oxe) + 1, a.wm - 1), sy1 = min((int)src_y(oye) + 1, a.hm - 1);
   const int spw = sx1 - sx0 + 1, sph = sy1 - sy0 + 1;
   const int nsrc = spw * sph;  // host guarantees <= MA_SRC_CAP
 
@@ -98,10 +99,10 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
     if (tid < nn) {
       const float* d = a.det + ((long long)b * a.max_num + n0 + tid) * 5;
       DetBox bx;
-      bx.x1 = __fdiv_rn(__fmul_rn(d[0], a.box_mul), a.box_div);
-      bx.y1 = __fdiv_rn(__fmul_rn(d[1], a.box_mul), a.box_div);
-      bx.x2 = __fdiv_rn(__fmul_rn(d[2], a.box_mul), a.box_div);
-      bx.y2 = __fdiv_rn(__fmul_rn(d[3], a.box_mul), a.box_div);
+      bx.x1 = __fdiv_rn(__fmul_rn(d[0], a.box_mul_x), a.box_div);
+      bx.y1 = __fdiv_rn(__fmul_rn(d[1], a.box_mul_y), a.box_div);
+      bx.x2 = __fdiv_rn(__fmul_rn(d[2], a.box_mul_x), a.box_div);
+      bx.y2 = __fdiv_rn(__fmul_rn(d[3], a.box_mul_y), a.box_div);
       // roi_w = (x2 - x1 + 0.1) / num_cell in double, rounded to float (kernel.cu:47-48)
       bx.rw = (float)(((double)__fsub_rn(bx.x2, bx.x1) + 0.1) / 2.0);
       bx.rh = (float)(((double)__fsub_rn(bx.y2, bx.y1) + 0.1) / 2.0);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
       const DetBox bx = s_box[n];
       // tile / box overlap in source coordinates (block-uniform, conservative)
       const bool hit = ((float)sx1 >= bx.x1) && ((float)sx0 < bx.x2) && ((float)sy1 >= bx.y1) && ((float)sy0 < bx.y2);
-      uint8_t* mrow = a.masks + dn * (long long)a.ho * a.wo;
+      uint8_t* mrow = a.masks + dn * (long long)a.ho * a.pitch;
       if (!hit) {
         // the whole tile is zero: no LDS traffic, no barrier
 #pragma unroll
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
           const int gi = tid + g * MA_THREADS;
           if (gi < GROUPS) {
             const int oy = oy0 + gi / (TOW / 4), ox = ox0 + (gi % (TOW / 4)) * 4;
-            if (oy < a.ho && ox < a.wo) *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.wo + ox) = 0u;
+            if (oy < a.ho && ox < a.wo) *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.pitch + ox) = 0u;
           }
         }
         if (a.pos_masks) {
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
         if (gi >= GROUPS) continue;
         const int oy = oy0 + gi / (TOW / 4), oxb = ox0 + (gi % (TOW / 4)) * 4;
         if (oy >= a.ho || oxb >= a.wo) continue;
-        const float sy = src_of(oy);
+        const float sy = src_y(oy);
         const int y0 = (int)sy, y1 = min(y0 + 1, a.hm - 1);
         const float ly = sy - (float)y0, hy = 1.f - ly;
         const float* r0 = s_prob + (y0 - sy0) * spw - sx0;
@@ -173,14 +174,14 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
         for (int e = 0; e < 4; ++e) {
           const int ox = oxb + e;
           if (ox < a.wo) {
-            const float sx = src_of(ox);
+            const float sx = src_x(ox);
             const int x0 = (int)sx, x1 = min(x0 + 1, a.wm - 1);
             const float lx = sx - (float)x0, hx = 1.f - lx;
             const float v = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
             packed |= (v > a.thr ? 1u : 0u) << (8 * e);
           }
         }
-        *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.wo + oxb) = packed;
+        *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.pitch + oxb) = packed;
       }
       __syncthreads();  // s_prob is rewritten by the next overlapping detection
     }
@@ -191,10 +192,12 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
 
 extern "C" int sm_mask_assemble(const float* basis, int basis_hwc, const float* cofs, const int64_t* keep,
                                 const float* det, const int32_t* ndet, int batch, int kmax, int max_num, int hm,
-                                int wm, int ho, int wo, float box_mul, float box_div, double up_scale, float mask_thr,
+                                int wm, int ho, int wo, int mask_pitch, float box_mul_x, float box_mul_y, float box_div, double up_scale_h,
+                                double up_scale_w, float mask_thr,
                                 uint8_t* masks, float* pos_masks, sm_stream_t stream) {
   if (!basis || !cofs || !keep || !det || !ndet || !masks) return SM_ERR_BAD_ARG;
-  if (batch < 1 || hm < 1 || wm < 1 || ho < 1 || wo < 1 || wo % 4 != 0 || !(up_scale > 0)) return SM_ERR_BAD_SHAPE;
+  if (batch < 1 || hm < 1 || wm < 1 || ho < 1 || wo < 1 || mask_pitch % 4 != 0 || mask_pitch < wo || !(up_scale_h > 0) || !(up_scale_w > 0))
+    return SM_ERR_BAD_SHAPE;
   MaskArgs a;
   a.basis = basis;
   a.cofs = cofs;
@@ -209,17 +212,20 @@ extern "C" int sm_mask_assemble(const float* basis, int basis_hwc, const float* 
   a.wm = wm;
   a.ho = ho;
   a.wo = wo;
+  a.pitch = mask_pitch;
   a.pix_stride = basis_hwc ? 32 : 1;
   a.ch_stride = basis_hwc ? 1 : (long long)hm * wm;
-  a.box_mul = box_mul;
+  a.box_mul_x = box_mul_x;
+  a.box_mul_y = box_mul_y;
   a.box_div = box_div;
-  a.inv_up = (float)(1.0 / up_scale);  // area_pixel_compute_scale with an explicit scale_factor
+  a.inv_up_x = (float)(1.0 / up_scale_w);  // area_pixel_compute_scale with an explicit scale_factor
+  a.inv_up_y = (float)(1.0 / up_scale_h);
   a.thr = mask_thr;
   hipStream_t s = sm_hip_stream(stream);
   // pick the widest output tile whose source window (TOW/up + 3) x (TOH/up + 3) fits the
   // per-thread ownership (512 source pixels); wide tiles = full-line mask stores
   auto fits = [&](int tw, int th) {
-    return ((int)((double)tw / up_scale) + 3) * ((int)((double)th / up_scale) + 3) <= MA_SRC_CAP;
+    return ((int)((double)tw / up_scale_w) + 3) * ((int)((double)th / up_scale_h) + 3) <= MA_SRC_CAP;
   };
   dim3 block(MA_THREADS);
 #define SM_MASK_TRY(TW, TH)                                                                                  \

@@ -34,15 +34,20 @@ class SipMask(nn.Module):
         self.bbox_head.init_weights()
         self._engines = {}
 
-    def prepare(self, batch, img_hw, img_shape=None):
+    def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False):
         """Build (or fetch) the static launch plan for this input geometry; weights are snapshotted,
-        BN folded, re-laid out as bf16 GEMM operands.  Call again after load_state_dict."""
+        BN folded, re-laid out as bf16 GEMM operands.  Call again after load_state_dict.
+        scale_factor / rescale: img_meta['scale_factor'] and the rescale flag of simple_test (boxes and masks
+        in original-image coordinates, sipmask_head.py:587-588,621-632)."""
+        import numpy as np
         from .engine import SipMaskEngine
-        key = (batch, tuple(img_hw), tuple(img_shape or ()))
+        key = (batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
+               rescale)
         eng = self._engines.get(key)
         if eng is None:
             eng = SipMaskEngine(self.state_dict(), batch, img_hw, self.backbone.depth, self.test_cfg,
-                                self.bbox_head.num_classes, strides=self.bbox_head.strides, img_shape=img_shape)
+                                self.bbox_head.num_classes, strides=self.bbox_head.strides, img_shape=img_shape,
+                                ssd_flag=self.bbox_head.ssd_flag, scale_factor=scale_factor, rescale=rescale)
             self._engines = {key: eng}
         return eng
 
@@ -60,12 +65,12 @@ class SipMask(nn.Module):
     def simple_test(self, img, img_meta, rescale=False):
         """single_stage.py:75-96: returns (bbox_results, segm_results) of image 0; segm_results[label] is the
         list of COCO RLE dicts of that class (sipmask_head.py:655-657), encoded on device."""
-        if rescale and float(img_meta[0].get('scale_factor', 1.0)) != 1.0:
-            raise NotImplementedError("rescale with scale_factor != 1 is planned through SipMaskHead.get_masks")
-        shape = tuple(img_meta[0]['img_shape'])
-        eng = self.prepare(img.shape[0], tuple(img.shape[-2:]), shape)
+        meta = img_meta[0]
+        shape = tuple(meta['img_shape'])
+        eng = self.prepare(img.shape[0], tuple(img.shape[-2:]), shape, meta.get('scale_factor', 1.0), bool(rescale))
         r = eng.run(img)
-        rle = eng.encode_rle(shape[:2])[0]
+        canvas = tuple(meta['ori_shape'])[:2] if rescale else shape[:2]              # sipmask_head.py:648-653
+        rle = eng.encode_rle(canvas)[0]
         n = int(r["ndet"][0])
         d, l = r["det_bboxes"][0, :n].cpu().numpy(), r["det_labels"][0, :n].cpu().numpy()
         ncls = self.bbox_head.num_classes - 1

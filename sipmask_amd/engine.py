@@ -72,7 +72,8 @@ class SipMaskEngine:
     """Static launch plan for SipMask-R50/R101 inference at a fixed (batch, H, W)."""
 
     def __init__(self, state_dict, batch, img_hw, depth=50, test_cfg=None, num_classes=81, device="cuda",
-                 strides=(8, 16, 32, 64, 128), img_shape=None, head_sizes=None):
+                 strides=(8, 16, 32, 64, 128), img_shape=None, head_sizes=None, ssd_flag=False, scale_factor=1.0,
+                 rescale=False):
         _lib.load()   # fail loudly before anything else if the HIP library is missing
         if not torch.cuda.is_available():
             raise RuntimeError("SipMaskEngine needs a HIP device")
@@ -87,6 +88,8 @@ class SipMaskEngine:
         if test_cfg:
             self.cfg.update(test_cfg)
         self.img_shape = img_shape or (self.H, self.W, 3)
+        # ssd_flag configs: fast_nms + per-axis mask upsampling (sipmask_head.py:594-605,629-630)
+        self.ssd_flag, self.scale_factor, self.rescale = bool(ssd_flag), scale_factor, rescale
         self.steps = []        # (label, callable)
         self.convs = []        # _Conv objects (for FLOP accounting / per-kernel timing)
         self.head_start = 0
@@ -101,12 +104,12 @@ class SipMaskEngine:
 
     @classmethod
     def for_head(cls, state_dict, batch, sizes, num_classes=81, strides=(8, 16, 32, 64, 128), test_cfg=None,
-                 img_shape=None):
+                 img_shape=None, ssd_flag=False):
         """Plan for SipMaskHead.forward / get_bboxes alone (features come from the caller)."""
         h0, w0 = sizes[0]
         img_hw = (h0 * strides[0], w0 * strides[0])
         return cls(state_dict, batch, img_hw, 50, test_cfg, num_classes, "cuda", strides,
-                   img_shape or (img_hw[0], img_hw[1], 3), head_sizes=list(sizes))
+                   img_shape or (img_hw[0], img_hw[1], 3), head_sizes=list(sizes), ssd_flag=ssd_flag)
 
     def load_pyramid(self, feats):
         """copy caller features (tuple of NCHW float tensors) into the bf16 pyramid tensor"""
@@ -230,19 +233,29 @@ class SipMaskEngine:
         sizes, row0 = lv.sizes, lv.row0
         self.gn_stats = torch.zeros(B * len(lv) * 32 * 2, dtype=torch.float32, device=dev)
 
+        # tower depth / norm as laid down by _init_layers (sipmask_head.py:159-185): stacked_convs-1 cls convs,
+        # stacked_convs reg convs; norm_cfg=None (SSD configs) -> conv bias + ReLU, no GroupNorm
+        depth = lambda kind: sum(1 for k in sd if k.startswith(h + kind + "_convs.") and k.endswith(".conv.weight"))
+        self.flag_norm = (h + "reg_convs.0.gn.weight") in sd
+
         def tower(kind, n):
             x = self.pyr
             for i in range(n):
                 y = self._buf(lv.rows, 256)
                 name = "%s_convs.%d" % (kind, i)
-                c = self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"], None, B, sizes, row0, x,
-                                         256, 1, 1, y, row0, 256))
-                self._gn(name, y, sd[h + name + ".gn.weight"], sd[h + name + ".gn.bias"], conv=c)
+                if self.flag_norm:
+                    c = self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"], None, B, sizes, row0,
+                                             x, 256, 1, 1, y, row0, 256))
+                    self._gn(name, y, sd[h + name + ".gn.weight"], sd[h + name + ".gn.bias"], conv=c)
+                else:
+                    self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"],
+                                         sd.get(h + name + ".conv.bias"), B, sizes, row0, x, 256, 1, 1, y, row0, 256,
+                                         flags=SM_CONV_RELU))
                 x = y
             return x
 
-        self.cls_feat = tower("cls", 3)
-        self.reg_feat = tower("reg", 4)
+        self.cls_feat = tower("cls", depth("cls"))
+        self.reg_feat = tower("reg", depth("reg"))
         # fcos_reg (4, x Scale) + fcos_centerness (1) share reg_feat -> one 5-channel f32 conv
         w_rc = torch.cat([sd[h + "fcos_reg.weight"], sd[h + "fcos_centerness.weight"]], 0)
         b_rc = torch.cat([sd[h + "fcos_reg.bias"], sd[h + "fcos_centerness.bias"]], 0)
@@ -258,8 +271,10 @@ class SipMaskEngine:
         self.aligned = self._buf(lv.rows, 256)
         c = self._add_conv(_Conv(self, "head.feat_align", sd[h + "feat_align.conv_adaption.weight"], None, B, sizes,
                                  row0, self.cls_feat, 256, 1, 1, self.aligned, row0, 256, deform_groups=4,
-                                 offset=self.offsets))
-        self._gn("feat_align", self.aligned, sd[h + "feat_align.norm.weight"], sd[h + "feat_align.norm.bias"], conv=c)
+                                 offset=self.offsets, flags=0 if self.flag_norm else SM_CONV_RELU))
+        if self.flag_norm:                                 # FeatureAlign.forward, sipmask_head.py:49-55
+            self._gn("feat_align", self.aligned, sd[h + "feat_align.norm.weight"], sd[h + "feat_align.norm.bias"],
+                     conv=c)
         # fcos_cls (80) + sip_cof (128) share the aligned feature -> one 208-channel f32 conv
         w_cc = torch.cat([sd[h + "fcos_cls.weight"], sd[h + "sip_cof.weight"]], 0)
         b_cc = torch.cat([sd[h + "fcos_cls.bias"], sd[h + "sip_cof.bias"]], 0)
@@ -290,19 +305,28 @@ class SipMaskEngine:
         """get_bboxes (sipmask_head.py:500-633) for all images of the batch, device resident."""
         B, lv, cfg = self.batch, self.lv, self.cfg
         self.det_desc = H.make_det_desc(B, lv.sizes, self.strides, lv.row0, self.ncls, self.ncc, 0, self.ncc,
-                                        self.ncls, 8, cfg["nms_pre"], self.img_shape[0], self.img_shape[1])
+                                        self.ncls, 8, cfg["nms_pre"], self.img_shape[0], self.img_shape[1],
+                                        self.scale_factor, bool(self.rescale))
         self.sel = H.det_select_alloc(self.det_desc, self.device)
-        self.max_num = cfg["max_per_img"]
+        # fast_nms keeps a hard-coded 100 (sipmask_head.py:903), not cfg.max_per_img
+        self.max_num = 100 if self.ssd_flag else cfg["max_per_img"]
         self.nms_out = H.multiclass_nms_alloc(B, self.det_desc.kmax, self.ncls, self.max_num, self.device)
-        self.ho, self.wo = 2 * self.hm, 2 * self.wm
-        self.masks = torch.zeros(B, self.max_num, self.ho, self.wo, dtype=torch.uint8, device=self.device)
+        self.box_mul, self.up, (self.ho, self.wo) = H.post_geometry(self.hm, self.wm, self.scale_factor, self.rescale,
+                                                                    self.ssd_flag)
+        self.pitch = (self.wo + 3) // 4 * 4
+        self.masks = torch.zeros(B, self.max_num, self.ho, self.pitch, dtype=torch.uint8, device=self.device)
         self._add("det_select", lambda: H.det_select(self.det_desc, self.cls_cof, self.reg_out, self.cls_cof, self.sel))
-        self._add("nms", lambda: H.multiclass_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"],
-                                                  self.sel["ncand"], cfg["score_thr"], cfg["nms"]["iou_thr"],
-                                                  self.max_num, self.nms_out))
+        if self.ssd_flag:
+            self._add("nms", lambda: H.fast_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"],
+                                                self.sel["ncand"], cfg["score_thr"], cfg["nms"]["iou_thr"], 200,
+                                                self.max_num, self.nms_out))
+        else:
+            self._add("nms", lambda: H.multiclass_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"],
+                                                      self.sel["ncand"], cfg["score_thr"], cfg["nms"]["iou_thr"],
+                                                      self.max_num, self.nms_out))
         self._add("mask_assemble", lambda: H.mask_assemble(
             self.basis, True, self.sel["cofs"], self.nms_out["keep"], self.nms_out["det"], self.nms_out["ndet"],
-            self.hm, self.wm, self.ho, self.wo, 1.0, 2.0, 2.0, 0.4, self.masks))
+            self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, 0.4, self.masks))
 
     # -------------------------------------------------------------------------------- execution
     def run(self, img):
@@ -315,7 +339,8 @@ class SipMaskEngine:
 
     def results(self):
         o = self.nms_out
-        return dict(det_bboxes=o["det"], det_labels=o["labels"], idxs_keep=o["keep"], ndet=o["ndet"], masks=self.masks)
+        return dict(det_bboxes=o["det"], det_labels=o["labels"], idxs_keep=o["keep"], ndet=o["ndet"],
+                    masks=self.masks[..., :self.wo])
 
     def encode_rle(self, canvas_hw=None, fetch=True, max_runs=8192):
         """Result packing on device (sipmask_head.py:645-657 without the per-mask D2H): run-length encodes the
@@ -325,7 +350,7 @@ class SipMaskEngine:
         if getattr(self, "_rle", None) is None or self._rle["canvas_w"] != canvas_hw[1] or \
                 self._rle["max_runs"] < max_runs:
             self._rle = H.rle_alloc(self.batch, self.max_num, canvas_hw[1], self.device, max_runs=max_runs)
-        H.mask_rects(self.nms_out["det"], 1.0, 2.0, 2.0, self._rle["rect"])
+        H.mask_rects(self.nms_out["det"], self.box_mul, 2.0, self.up, self._rle["rect"])
         H.rle_encode(self.masks, self.nms_out["ndet"], canvas_hw, self._rle, self._rle["rect"])
         if not fetch:
             return self._rle
@@ -364,7 +389,7 @@ class PostProcessor:
     parity tests: identical f32 inputs on both sides).  sipmask_head.py:500-633."""
 
     def __init__(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg, strides,
-                 rescale=None):
+                 rescale=None, ssd_flag=False):
         _lib.load()
         dev = cls_scores[0].device
         _lib.require_cuda(cls_scores[0], feat_masks)
@@ -381,31 +406,32 @@ class PostProcessor:
                               torch.zeros(lv.rows, 3, device=dev)], 1).contiguous()
         self.basis = feat_masks.detach().float().contiguous()           # [B,32,Hm,Wm]
         self.hm, self.wm = self.basis.shape[-2:]
+        import numpy as np
         meta = img_metas[0]
         for m in img_metas[1:]:
-            if tuple(m['img_shape']) != tuple(meta['img_shape']) or m['scale_factor'] != meta['scale_factor']:
+            if tuple(m['img_shape']) != tuple(meta['img_shape']) or \
+                    not np.array_equal(np.asarray(m['scale_factor']), np.asarray(meta['scale_factor'])):
                 raise NotImplementedError("a batch must share img_shape / scale_factor (one launch plan)")
-        sf = float(meta['scale_factor'])
-        self.cfg = cfg
-        # quirk preserved (sipmask_head.py:621-623): crop boxes are multiplied by scale_factor unless
-        # rescale is None; boxes were divided by it only when rescale is truthy (:587-588)
-        self.box_mul = 1.0 if rescale is None else sf
-        self.up = 2.0 / (1.0 if rescale is None else sf)
-        self.ho, self.wo = int(self.hm * self.up), int(self.wm * self.up)
-        if self.wo % 4 != 0:
-            raise NotImplementedError("mask width must be a multiple of 4")
+        sf = meta['scale_factor']
+        self.cfg, self.ssd_flag = cfg, bool(ssd_flag)
+        self.box_mul, self.up, (self.ho, self.wo) = H.post_geometry(self.hm, self.wm, sf, rescale, self.ssd_flag)
+        self.pitch = (self.wo + 3) // 4 * 4
         self.desc = H.make_det_desc(B, sizes, strides, lv.row0, C, C, 0, 128, 0, 8, cfg.get('nms_pre', -1),
                                     meta['img_shape'][0], meta['img_shape'][1], sf, bool(rescale), True)
         self.sel = H.det_select_alloc(self.desc, dev)
-        self.max_num = cfg['max_per_img']
+        self.max_num = 100 if self.ssd_flag else cfg['max_per_img']
         self.out = H.multiclass_nms_alloc(B, self.desc.kmax, C, self.max_num, dev)
 
     def run(self, want_pos_masks=False):
         cfg = self.cfg
         H.det_select(self.desc, self.cls, self.reg, self.cof, self.sel)
-        H.multiclass_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"], self.sel["ncand"], cfg['score_thr'],
-                         cfg['nms']['iou_thr'], self.max_num, self.out)
-        masks = torch.zeros(self.B, self.max_num, self.ho, self.wo, dtype=torch.uint8, device=self.dev)
+        if self.ssd_flag:
+            H.fast_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"], self.sel["ncand"], cfg['score_thr'],
+                       cfg['nms']['iou_thr'], 200, self.max_num, self.out)
+        else:
+            H.multiclass_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"], self.sel["ncand"],
+                             cfg['score_thr'], cfg['nms']['iou_thr'], self.max_num, self.out)
+        masks = torch.zeros(self.B, self.max_num, self.ho, self.pitch, dtype=torch.uint8, device=self.dev)
         self.pos_masks = (torch.zeros(self.B, self.max_num, self.hm, self.wm, device=self.dev)
                           if want_pos_masks else None)
         H.mask_assemble(self.basis, False, self.sel["cofs"], self.out["keep"], self.out["det"], self.out["ndet"],
@@ -415,7 +441,8 @@ class PostProcessor:
         res = []
         for b in range(self.B):
             n = nd[b]
-            res.append((self.out["det"][b, :n], self.out["labels"][b, :n], self.out["keep"][b, :n], masks[b, :n]))
+            res.append((self.out["det"][b, :n], self.out["labels"][b, :n], self.out["keep"][b, :n],
+                        masks[b, :n, :, :self.wo]))
         return res
 
     def encode_rle(self, canvas_hw):

@@ -158,6 +158,45 @@ def upsample_bilinear(x, y, batch, h, w, c, factor, in_cstride, out_cstride, out
     return y
 
 
+def scale4(scale_factor):
+    """img_meta['scale_factor'] -> [w, h, w, h] floats: a scalar (keep_ratio=True, transforms.py Resize) is
+    repeated, a 4-array (keep_ratio=False) is taken as is."""
+    import numpy as np
+    a = np.asarray(scale_factor, dtype=np.float32).reshape(-1)
+    if a.size == 1:
+        a = np.repeat(a, 4)
+    if a.size != 4:
+        raise ValueError("scale_factor must be a scalar or 4 values, got %r" % (scale_factor,))
+    return [float(v) for v in a]
+
+
+def _pair(v):
+    return (float(v[0]), float(v[1])) if isinstance(v, (tuple, list)) else (float(v), float(v))
+
+
+def post_geometry(hm, wm, scale_factor, rescale, ssd_flag=False):
+    """Crop / upsample geometry of get_bboxes_single (sipmask_head.py:621-632) ->
+    (box_mul (x, y), up_scale (h, w), (ho, wo)).  Quirk preserved: crop boxes are multiplied by scale_factor unless
+    rescale is None, while they were divided by it only when rescale is truthy (:587-588)."""
+    import numpy as np
+    a = np.asarray(scale_factor).reshape(-1)
+    if rescale is None:
+        mul, up = (1.0, 1.0), (2.0, 2.0)
+    elif a.size == 1:
+        v = float(a[0])                                   # python float in img_meta: double arithmetic
+        mul, up = (v, v), (2.0 / v, 2.0 / v)
+    else:
+        if not ssd_flag:
+            raise ValueError("a 4-element scale_factor needs ssd_flag=True (F.interpolate gets 2 factors, :629-630)")
+        s4 = np.asarray(scale_factor, np.float32).reshape(4)
+        if s4[0] != s4[2] or s4[1] != s4[3]:
+            raise NotImplementedError("scale_factor must be [w, h, w, h]")
+        mul = (float(s4[0]), float(s4[1]))
+        up = (float(np.float32(2) / s4[3]), float(np.float32(2) / s4[2]))   # 2 / scale_factor[3:1:-1] in float32
+    import math
+    return mul, up, (int(math.floor(hm * up[0])), int(math.floor(wm * up[1])))
+
+
 def make_det_desc(batch, sizes, strides, row0, num_classes, cls_cstride, cls_coff, cof_cstride, cof_coff,
                   reg_cstride, nms_pre, img_h, img_w, scale_factor=1.0, rescale=False, reg_prescaled=False):
     d = DetDesc()
@@ -168,7 +207,9 @@ def make_det_desc(batch, sizes, strides, row0, num_classes, cls_cstride, cls_cof
         kmax += min(nms_pre, h * w) if nms_pre > 0 else h * w
     d.cls_cstride, d.cls_coff, d.cof_cstride, d.cof_coff = cls_cstride, cls_coff, cof_cstride, cof_coff
     d.reg_cstride, d.nms_pre, d.img_h, d.img_w, d.kmax = reg_cstride, nms_pre, img_h, img_w, kmax
-    d.scale_factor, d.rescale = float(scale_factor), int(bool(rescale))
+    for i, v in enumerate(scale4(scale_factor)):
+        d.scale_factor[i] = v
+    d.rescale = int(bool(rescale))
     d.reg_prescaled = int(bool(reg_prescaled))
     return d
 
@@ -225,12 +266,16 @@ def fast_nms(boxes, scores, ctr, ncand, score_thr, iou_thr, top_k, max_num, out)
 
 def mask_assemble(basis, basis_hwc, cofs, keep, det, ndet, hm, wm, ho, wo, box_mul, box_div, up_scale, thr,
                   masks, pos_masks=None):
+    """box_mul: scalar or (x, y); up_scale: scalar or (h, w) -- per axis for keep_ratio=False pipelines.
+    masks u8 [B, max_num, ho, pitch] with pitch % 4 == 0 and pitch >= wo (the logical width)."""
     lib = _lib.load()
+    (mx, my), (uh, uw) = _pair(box_mul), _pair(up_scale)
     b, kmax = cofs.shape[0], cofs.shape[1]
     max_num = det.shape[1]
     _lib.check(lib.sm_mask_assemble(_lib.ptr(basis), int(basis_hwc), _lib.ptr(cofs), _lib.ptr(keep), _lib.ptr(det),
-                                    _lib.ptr(ndet), b, kmax, max_num, hm, wm, ho, wo, float(box_mul), float(box_div),
-                                    float(up_scale), float(thr), _lib.ptr(masks), _lib.ptr(pos_masks),
+                                    _lib.ptr(ndet), b, kmax, max_num, hm, wm, ho, wo, int(masks.shape[-1]), mx, my,
+                                    float(box_div),
+                                    uh, uw, float(thr), _lib.ptr(masks), _lib.ptr(pos_masks),
                                     _lib.stream_ptr()), "sm_mask_assemble")
     return masks
 
@@ -254,7 +299,8 @@ def rle_alloc(batch, max_num, canvas_w, device, max_runs=8192, packed_cap=None):
 def mask_rects(det, box_mul, box_div, up_scale, rect):
     lib = _lib.load()
     b, n = det.shape[0], det.shape[1]
-    _lib.check(lib.sm_mask_rects(_lib.ptr(det), b, n, float(box_mul), float(box_div), float(up_scale),
+    (mx, my), (uh, uw) = _pair(box_mul), _pair(up_scale)
+    _lib.check(lib.sm_mask_rects(_lib.ptr(det), b, n, mx, my, float(box_div), uh, uw,
                                  _lib.ptr(rect), _lib.stream_ptr()), "sm_mask_rects")
     return rect
 

@@ -44,8 +44,8 @@ class SipMaskHead(nn.Module):
                  loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
                  conv_cfg=None, norm_cfg=dict(type='GN', num_groups=32, requires_grad=True)):
         super().__init__()
-        if ssd_flag or rescoring_flag:
-            raise NotImplementedError("ssd_flag (fast_nms) / rescoring (SipMask++) are 'next' rows (SURVEY 8f)")
+        if rescoring_flag:
+            raise NotImplementedError("rescoring_flag (SipMask++ mask-IoU branch) is a 'next' row (SURVEY 8f)")
         self.num_classes = num_classes
         self.cls_out_channels = num_classes - 1
         self.in_channels, self.feat_channels, self.stacked_convs = in_channels, feat_channels, stacked_convs
@@ -105,11 +105,9 @@ class SipMaskHead(nn.Module):
         key = (batch, tuple(sizes), tuple(img_shape or ()), repr(cfg))
         eng = self._engines.get(key)
         if eng is None:
-            if self.norm_cfg is None:
-                raise NotImplementedError("norm_cfg=None towers are not planned into the HIP engine yet")
             sd = {"bbox_head." + k: v for k, v in self.state_dict().items()}
             eng = SipMaskEngine.for_head(sd, batch, sizes, num_classes=self.num_classes, strides=self.strides,
-                                         test_cfg=cfg, img_shape=img_shape)
+                                         test_cfg=cfg, img_shape=img_shape, ssd_flag=self.ssd_flag)
             self._engines = {key: eng}     # one cached plan; weights are snapshotted at build time
         return eng
 
@@ -127,7 +125,7 @@ class SipMaskHead(nn.Module):
         (det_bboxes [N,5], det_labels [N], idxs_keep [N], masks uint8 [N,Ho,Wo])."""
         from .engine import PostProcessor
         post = PostProcessor(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg,
-                             self.strides, rescale)
+                             self.strides, rescale, self.ssd_flag)
         return post.run()
 
     def get_bboxes(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg, rescale=None):
@@ -137,7 +135,7 @@ class SipMaskHead(nn.Module):
         `mask.cpu()` + `mask_util.encode` loop of the reference becomes two small D2H copies per batch."""
         from .engine import PostProcessor
         post = PostProcessor(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg,
-                             self.strides, rescale)
+                             self.strides, rescale, self.ssd_flag)
         res = post.run()
         meta = img_metas[0]
         shp = meta['ori_shape'] if rescale else meta['img_shape']

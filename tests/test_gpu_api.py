@@ -134,3 +134,115 @@ def test_deform_conv_module_api():
     # input smaller than the kernel: pad / run / crop path (deform_conv.py:239-255)
     xs = torch.randn(1, 64, 2, 2).cuda()
     assert m(xs, torch.zeros(1, 72, 2, 2).cuda()).shape == (1, 32, 2, 2)
+
+
+# --------------------------------------------------------------------------- SSD configs (ssd_flag=True)
+@pytest.fixture(scope="module")
+def ssd_det():
+    """configs/sipmask/sipmask_r50_caffe_fpn_ssd_6x.py: stacked_convs=2, norm_cfg=None, ssd_flag=True,
+    test score_thr 0.1; weights = the oracle's seeded init for that layout (same parameter names)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd.registry import build_detector
+    from sipmask_amd.synthetic import model_cfg
+    cfg = model_cfg(50)
+    cfg['bbox_head'].update(stacked_convs=2, ssd_flag=True, norm_cfg=None)
+    d = build_detector(cfg, train_cfg=None, test_cfg=dict(nms_pre=1000, min_bbox_size=0, score_thr=0.1,
+                                                          nms=dict(type='nms', iou_thr=0.5), max_per_img=100))
+    sd = OM.init_state_dict(50, seed=11, calibrate=True, stacked_convs=2, norm=False)
+    sd["bbox_head.fcos_cls.bias"].fill_(-5.5)
+    missing = d.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return d
+
+
+def test_ssd_head_forward_matches_oracle(ssd_det):
+    """norm-free 1+2 conv towers (bias + ReLU fused in the conv epilogue), FeatureAlign without GroupNorm."""
+    g = torch.Generator().manual_seed(1)
+    sizes = [(20, 20), (10, 10), (5, 5), (3, 3), (2, 2)]
+    feats = [torch.randn(2, 256, h, w, generator=g).to(torch.bfloat16).float() for h, w in sizes]
+    sd = {"bbox_head." + k: v.detach().cpu() for k, v in ssd_det.bbox_head.state_dict().items()}
+    assert OM.tower_depths(sd) == (1, 2, False)
+    ref = OM.head_forward(sd, feats)
+    out = ssd_det.bbox_head([f.cuda() for f in feats])
+    torch.cuda.synchronize()
+    for name, got_l, ref_l in zip(("cls", "bbox", "ctr", "cof"), out[:4], ref[:4]):
+        for l in range(5):
+            assert got_l[l].shape == ref_l[l].shape
+            b0 = -5.5 if name == "cls" else 0.0
+            assert _rel(got_l[l] - b0, ref_l[l] - b0) < 0.05, (name, l, _rel(got_l[l] - b0, ref_l[l] - b0))
+    assert _rel(out[4], ref[4]) < 0.05
+
+
+def test_ssd_get_masks_vs_oracle(ssd_det):
+    """ssd_flag post-processing on caller tensors (identical f32 inputs): fast_nms instead of multiclass NMS,
+    [w,h,w,h] scale factors, per-axis mask upsampling (sipmask_head.py:594-605,621-632)."""
+    g = torch.Generator().manual_seed(6)
+    B, C = 2, 80
+    sizes = [(20, 20), (10, 10), (5, 5), (3, 3), (2, 2)]
+    strides = (8, 16, 32, 64, 128)
+    cls = [torch.randn(B, C, h, w, generator=g) * 2 - 3.5 for h, w in sizes]
+    bb = [(torch.randn(B, 4, h, w, generator=g) * 1.5 + 3) * s for (h, w), s in zip(sizes, strides)]
+    ctr = [torch.randn(B, 1, h, w, generator=g) + 1 for h, w in sizes]
+    cof = [torch.randn(B, 128, h, w, generator=g) * 0.3 for h, w in sizes]
+    fm = torch.randn(B, 32, 80, 80, generator=g)
+    cfg = dict(OM.DEFAULT_TEST_CFG, score_thr=0.1)
+    ori = (141, 188, 3)                                       # resized (keep_ratio=False) to 160x160
+    sf = np.array([160 / 188, 160 / 141, 160 / 188, 160 / 141], dtype=np.float32)
+    tot = 0
+    for rescale in (True, False):
+        metas = [dict(img_shape=(160, 160, 3), ori_shape=ori, scale_factor=sf) for _ in range(B)]
+        res = ssd_det.bbox_head.get_masks([t.cuda() for t in cls], [t.cuda() for t in bb], [t.cuda() for t in ctr],
+                                          [t.cuda() for t in cof], fm.cuda(), metas, cfg, rescale=rescale)
+        for b in range(B):
+            r = OM.get_masks_single([c[b] for c in cls], [x[b] for x in bb], [c[b] for c in ctr], [c[b] for c in cof],
+                                    fm[b], (160, 160, 3), cfg, sf, rescale, ssd_flag=True)
+            d, l, k, m = res[b]
+            tot += d.shape[0]
+            np.testing.assert_array_equal(l.cpu().numpy(), r["det_labels"])
+            np.testing.assert_allclose(d.cpu().numpy(), r["det_bboxes"], rtol=1e-6, atol=1e-6)
+            if d.shape[0]:
+                assert tuple(m.shape) == tuple(r["masks"].shape), (m.shape, r["masks"].shape)
+                diff = m.cpu() != r["masks"]
+                assert bool(((r["up"] - 0.4).abs()[diff] < 1e-4).all()) and int(diff.sum()) <= 5
+    assert tot > 10
+    out = ssd_det.bbox_head.get_bboxes([t.cuda() for t in cls], [t.cuda() for t in bb], [t.cuda() for t in ctr],
+                                       [t.cuda() for t in cof], fm.cuda(), metas, cfg, rescale=True)
+    metas_r = metas
+    res = ssd_det.bbox_head.get_masks([t.cuda() for t in cls], [t.cuda() for t in bb], [t.cuda() for t in ctr],
+                                      [t.cuda() for t in cof], fm.cuda(), metas_r, cfg, rescale=True)
+    for b in range(B):
+        d, l, k, m = res[b]
+        m, l = m.cpu().numpy(), l.cpu().tolist()
+        seen = [0] * C
+        for i in range(d.shape[0]):
+            rle = out[b][2][l[i]][seen[l[i]]]
+            seen[l[i]] += 1
+            assert rle["size"] == [141, 188]
+            assert rle["counts"] == O.paste_and_encode(m[i], (141, 188))["counts"]
+
+
+def test_ssd_simple_test_rescale(ssd_det):
+    """Whole SSD-style detector (544-like square input, keep_ratio=False) with rescale=True: boxes and RLE masks
+    come back in original-image coordinates; the RLE decodes to the engine's own masks."""
+    img = torch.randn(1, 3, 160, 160, generator=torch.Generator().manual_seed(4)).cuda()
+    sf = np.array([160 / 188, 160 / 141, 160 / 188, 160 / 141], dtype=np.float32)
+    meta = [dict(img_shape=(160, 160, 3), ori_shape=(141, 188, 3), pad_shape=(160, 160, 3), scale_factor=sf, flip=False)]
+    bbox_results, segm_results = ssd_det.simple_test(img, meta, rescale=True)
+    n = sum(b.shape[0] for b in bbox_results)
+    assert n == sum(len(s) for s in segm_results) and 0 < n <= 100
+    eng = ssd_det.prepare(1, (160, 160), (160, 160, 3), sf, True)
+    assert eng.ssd_flag and not eng.flag_norm and (eng.ho, eng.wo) == (140, 187)   # floor(80 * 2 / scale)
+    masks = eng.masks[0].cpu().numpy()
+    labels = eng.nms_out["labels"][0].cpu().tolist()
+    seen = [0] * 80
+    for i in range(n):
+        r = segm_results[labels[i]][seen[labels[i]]]
+        seen[labels[i]] += 1
+        assert r["size"] == [141, 188]
+        dec = O.rle_decode(O.rle_from_string(r["counts"]), 141, 188)
+        np.testing.assert_array_equal(dec[:140, :187], masks[i][:, :187])          # pasted top-left (:649-654)
+        assert dec[140:].sum() == 0 and dec[:, 187:].sum() == 0
+    # scores sorted descending overall (fast_nms sorts the survivors, sipmask_head.py:902)
+    sc = eng.nms_out["det"][0, :n, 4].cpu().numpy()
+    assert (np.diff(sc) <= 0).all()
