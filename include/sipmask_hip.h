@@ -95,6 +95,21 @@ int sm_conv2d(const sm_conv_desc* d, const void* x, const void* w, const float* 
 int sm_deform_conv2d(const sm_conv_desc* d, const void* x, const float* offset, const void* w,
                      const float* bias, void* y, sm_stream_t stream);
 
+/* Deformable conv v1 backward: replaces deform_conv_backward_input_cuda + deform_conv_backward_parameters_cuda
+ * (M/mmdet/ops/dcn/src/deform_conv_cuda.cpp:262-490; kernels deform_conv_cuda_kernel.cu:279-433).
+ * d is the FORWARD descriptor (x geometry in in_*, gout/offset geometry in out_*, out_cstride = gout row stride).
+ * x bf16 rows, offset f32 [rows][G*kh*kw*2], gout bf16 rows [.][cout];
+ * w_t: the weight as the operand of the grad-column GEMM, bf16 [Kpad][cout] with K = (kh,kw,cin) -- i.e. the
+ *      tensor weight.permute(2,3,1,0).reshape(K, cout, 1, 1) laid out like a 1x1 sm_conv2d weight (needed for
+ *      grad_x / grad_offset only);
+ * outputs (each nullable = skipped): grad_x f32 [in rows][cin] (zeroed by the call), grad_offset f32 like offset,
+ * grad_w_t f32 [K][cout] = dW^T (overwritten; dW[co][c][i][j] = grad_w_t[(i*kw+j)*cin + c][co]).
+ * Needs cin % 64 == 0, (cin/G) % 64 == 0, cout % 8 == 0, stride 1. */
+int64_t sm_deform_conv2d_bwd_workspace(const sm_conv_desc* d);
+int sm_deform_conv2d_bwd(const sm_conv_desc* d, const void* x, const float* offset, const void* w_t,
+                         const void* gout, float* grad_x, float* grad_offset, float* grad_w_t, void* workspace,
+                         sm_stream_t stream);
+
 /* sm_conv2d / sm_deform_conv2d (offset != NULL) with the GroupNorm statistics of the output fused in the
  * epilogue: gn_stats f32 [batch][nlev][cout/8][2] = (sum, sum of squares) per (image, level, group of 8
  * channels), zeroed by the call.  Feed it to sm_groupnorm_apply.  Needs cout % 8 == 0, bf16 output. */

@@ -286,6 +286,62 @@ def deform_conv(x, offset, weight, stride=1, padding=1, dilation=1, deformable_g
     return out.view(B, Co, Ho, Wo)
 
 
+def deform_conv_backward(x, offset, weight, grad_out, stride=1, padding=1, dilation=1, deformable_groups=1):
+    """DeformConvFunction.backward (M/mmdet/ops/dcn/deform_conv.py:60-96) -> (grad_input, grad_offset, grad_weight).
+
+    * columns = weight^T @ grad_output (deform_conv_cuda.cpp:262-374);
+    * grad_input: every column element is scattered to the in-bounds bilinear corners of its sampling point with
+      get_gradient_weight (deform_conv_cuda_kernel.cu:117-142, scatter loop :279-343);
+    * grad_offset[b, g, 2t+{0,1}] = sum_{c in group g} col * get_coordinate_weight (:144-188, :375-433; a sample
+      outside (-1,H)x(-1,W) contributes 0, :423-426);
+    * grad_weight = grad_output @ im2col(x, offset)^T, scale 1 (deform_conv_cuda.cpp:376-490, deform_conv.py:92).
+    Works for float32 or float64."""
+    B, C, H, W = x.shape
+    Co, Ci, kh, kw = weight.shape
+    G = deformable_groups
+    cpg = C // G
+    Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+    dt = x.dtype
+    gcol = torch.einsum("ocij,bohw->bcijhw", weight, grad_out).reshape(B, G, cpg, kh * kw, Ho, Wo)
+    ho = torch.arange(Ho, dtype=dt).view(1, Ho, 1) * stride - padding
+    wo = torch.arange(Wo, dtype=dt).view(1, 1, Wo) * stride - padding
+    xf = x.reshape(B, G, cpg, H * W)
+    off = offset.view(B, G, kh * kw, 2, Ho, Wo)
+    gx = x.new_zeros(B, G, cpg, H * W)
+    goff = offset.new_zeros(B, G, kh * kw, 2, Ho, Wo)
+    cols = x.new_zeros(B, G, cpg, kh * kw, Ho, Wo)
+    for g in range(G):
+        for t in range(kh * kw):
+            i, j = t // kw, t % kw
+            h_im = ho + i * dilation + off[:, g, t, 0]
+            w_im = wo + j * dilation + off[:, g, t, 1]
+            valid = (h_im > -1) & (w_im > -1) & (h_im < H) & (w_im < W)
+            hl, wl = torch.floor(h_im), torch.floor(w_im)
+            lh, lw = h_im - hl, w_im - wl
+            hl, wl = hl.long(), wl.long()
+            hh_, wh_ = hl + 1, wl + 1
+            top = gcol[:, g, :, t]                                            # [B,cpg,Ho,Wo]
+            corners = ((hl, wl, (hl >= 0) & (wl >= 0), (1 - lh) * (1 - lw), -(1 - lw), -(1 - lh)),
+                       (hl, wh_, (hl >= 0) & (wh_ <= W - 1), (1 - lh) * lw, -lw, (1 - lh)),
+                       (hh_, wl, (hh_ <= H - 1) & (wl >= 0), lh * (1 - lw), (1 - lw), -lh),
+                       (hh_, wh_, (hh_ <= H - 1) & (wh_ <= W - 1), lh * lw, lw, lh))
+            dh = x.new_zeros(B, cpg, Ho, Wo)
+            dw = x.new_zeros(B, cpg, Ho, Wo)
+            for hi, wi, ok, wgt, ch, cw in corners:
+                ok = (ok & valid).view(B, 1, Ho, Wo).to(dt)
+                lin = (hi.clamp(0, H - 1) * W + wi.clamp(0, W - 1)).view(B, 1, Ho * Wo).expand(B, cpg, Ho * Wo)
+                v = torch.gather(xf[:, g], 2, lin).view(B, cpg, Ho, Wo) * ok
+                gx[:, g].scatter_add_(2, lin, (top * wgt.unsqueeze(1) * ok).reshape(B, cpg, Ho * Wo))
+                cols[:, g, :, t] += wgt.unsqueeze(1) * v
+                dh += ch.unsqueeze(1) * v
+                dw += cw.unsqueeze(1) * v
+            goff[:, g, t, 0] = (top * dh).sum(1)
+            goff[:, g, t, 1] = (top * dw).sum(1)
+    gw = torch.einsum("bohw,bcthw->oct", grad_out, cols.reshape(B, C, kh * kw, Ho, Wo)).reshape(Co, C, kh, kw)
+    return gx.view(B, C, H, W), goff.view(B, G * 2 * kh * kw, Ho, Wo), gw
+
+
 # ----------------------------------------------------------------------------
 # crop_split / crop_split_gt  (CUDA-kernel semantics, NOT the python fallback)
 # ----------------------------------------------------------------------------

@@ -1,0 +1,354 @@
+// Deformable conv v1 backward (training side of FeatureAlign).
+//
+// Replaces deform_conv_backward_input_cuda / deform_conv_backward_parameters_cuda
+// (M/mmdet/ops/dcn/src/deform_conv_cuda.cpp:262-490) and their kernels deformable_col2im_gpu_kernel,
+// deformable_col2im_coord_gpu_kernel, deformable_im2col_gpu_kernel (deform_conv_cuda_kernel.cu:191-433).
+//
+// Both GEMMs run on the MFMA implicit-GEMM kernel of conv_igemm.hip as 1x1 convolutions:
+//   grad columns  gcol[p][k]  = sum_co gout[p][co] * W[co][k]         (A = gout rows, B = W^T prepared by the host)
+//   grad weight   dW^T[k][co] = sum_p  col^T[k][p] * gout^T[co][p]    (position chunks; operands transposed here)
+// and the data-dependent parts are HBM-bound gather/scatter kernels:
+//   * col2im: one wave per (position, tap, 64 channels): the 64 lanes scatter their column gradient to the 4
+//     bilinear corners of grad_x (f32 NHWC, hardware float atomics on contiguous 256-B segments) and reduce the
+//     offset gradient over the channels of the deformable group with wave shuffles;
+//   * im2col^T / gout^T: produce the K-major operands of the weight-gradient GEMM.
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int DB_MAX_CHUNK = 32768;   // positions per weight-gradient GEMM (bounds the col^T workspace)
+
+struct DBArgs {
+  const uint16_t* x;
+  const float* offset;
+  const uint16_t* gout;
+  int nlev, batch;
+  int in_h[SM_MAX_LEVELS], in_w[SM_MAX_LEVELS], out_h[SM_MAX_LEVELS], out_w[SM_MAX_LEVELS];
+  long long in_row0[SM_MAX_LEVELS], out_row0[SM_MAX_LEVELS];
+  int cin, cout, kh, kw, stride, pad, dil, in_cstride, gout_cstride, G;
+  long long P;   // total output positions (all levels, all images), compact order = level, image, y, x
+};
+
+struct Pos {
+  int l, b, oy, ox;
+  long long orow;   // row of this position in gout / offset
+};
+
+__device__ __forceinline__ Pos locate(const DBArgs& a, long long p) {
+  Pos r;
+  r.l = 0;
+  for (int l = 0; l < a.nlev; ++l) {
+    const long long n = (long long)a.batch * a.out_h[l] * a.out_w[l];
+    if (p < n || l == a.nlev - 1) {
+      r.l = l;
+      break;
+    }
+    p -= n;
+  }
+  const int hw = a.out_h[r.l] * a.out_w[r.l];
+  r.b = (int)(p / hw);
+  const int rem = (int)(p - (long long)r.b * hw);
+  r.oy = rem / a.out_w[r.l];
+  r.ox = rem - r.oy * a.out_w[r.l];
+  r.orow = a.out_row0[r.l] + p;
+  return r;
+}
+
+struct Sample {
+  bool valid;
+  int hl, wl;
+  float lh, lw;
+};
+
+// sampling point of (position, tap, deformable group): deform_conv_cuda_kernel.cu:216-229
+__device__ __forceinline__ Sample sample_of(const DBArgs& a, const Pos& ps, int tap, int g) {
+  const int kk = a.kh * a.kw;
+  const int i = tap / a.kw, j = tap - i * a.kw;
+  const float* o = a.offset + ps.orow * (long long)(a.G * kk * 2) + (g * kk + tap) * 2;
+  const float h_im = (float)(ps.oy * a.stride - a.pad + i * a.dil) + o[0];
+  const float w_im = (float)(ps.ox * a.stride - a.pad + j * a.dil) + o[1];
+  Sample s;
+  s.valid = h_im > -1.f && w_im > -1.f && h_im < (float)a.in_h[ps.l] && w_im < (float)a.in_w[ps.l];
+  const float fh = floorf(h_im), fw = floorf(w_im);
+  s.hl = (int)fh;
+  s.wl = (int)fw;
+  s.lh = h_im - fh;
+  s.lw = w_im - fw;
+  return s;
+}
+
+// ---------------------------------------------------------------- grad_input + grad_offset
+__global__ __launch_bounds__(256) void deform_col2im_kernel(const DBArgs a, const float* __restrict__ gcol,
+                                                            float* __restrict__ gx, float* __restrict__ goff,
+                                                            long long nunits) {
+  const int lane = threadIdx.x & 63;
+  const int kk = a.kh * a.kw;
+  const int nq = a.cin >> 6;
+  const int cpg = a.cin / a.G;
+  const long long K = (long long)kk * a.cin;
+  for (long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); u < nunits; u += (long long)gridDim.x * 4) {
+    const int q = (int)(u % nq);
+    const int tap = (int)((u / nq) % kk);
+    const long long p = u / ((long long)nq * kk);
+    const Pos ps = locate(a, p);
+    const int c = q * 64 + lane;
+    const int g = (q * 64) / cpg;
+    const Sample s = sample_of(a, ps, tap, g);
+    if (!s.valid) continue;   // wave-uniform: contributes nothing (kernel.cu:423-426; no in-bounds neighbour :324-327)
+    const float top = gcol[p * K + (long long)tap * a.cin + c];
+    const int H = a.in_h[ps.l], W = a.in_w[ps.l];
+    const long long base = a.in_row0[ps.l] + (long long)ps.b * H * W;
+    float dh = 0.f, dw = 0.f;
+    // corners: (hl,wl) (hl,wh) (hh,wl) (hh,wh); weights get_gradient_weight :117-142,
+    // coordinate weights get_coordinate_weight :144-188
+    const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int hc = s.hl + (k >> 1), wc = s.wl + (k & 1);
+      if (hc < 0 || hc > H - 1 || wc < 0 || wc > W - 1) continue;
+      const float wy = (k >> 1) ? s.lh : hh, wx = (k & 1) ? s.lw : hw;
+      const long long row = base + (long long)hc * W + wc;
+      const float v = bf16_bits_to_f32((uint32_t)a.x[row * a.in_cstride + c]);
+      if (gx) unsafeAtomicAdd(gx + row * a.cin + c, top * (wy * wx));
+      dh += ((k >> 1) ? wx : -wx) * v;
+      dw += ((k & 1) ? wy : -wy) * v;
+    }
+    if (goff) {
+      float th = top * dh, tw = top * dw;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        th += __shfl_down(th, d, 64);
+        tw += __shfl_down(tw, d, 64);
+      }
+      if (lane == 0) {
+        float* o = goff + ps.orow * (long long)(a.G * kk * 2) + (g * kk + tap) * 2;
+        if (cpg == 64) {
+          o[0] = th;
+          o[1] = tw;
+        } else {
+          unsafeAtomicAdd(o, th);
+          unsafeAtomicAdd(o + 1, tw);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- operands of the weight-gradient GEMM
+// col^T[k][pl] (bf16, k = tap*cin + c) for positions p0 .. p0+n of the compact order; columns n..Lp are zero
+__global__ __launch_bounds__(256) void deform_im2col_t_kernel(const DBArgs a, long long p0, int n, int Lp,
+                                                              uint16_t* __restrict__ colT) {
+  const int kk = a.kh * a.kw;
+  const int nc8 = a.cin >> 3;
+  const int cpg = a.cin / a.G;
+  const long long total = (long long)kk * nc8 * Lp;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int pl = (int)(t % Lp);
+    const int c8 = (int)((t / Lp) % nc8);
+    const int tap = (int)(t / ((long long)Lp * nc8));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (pl < n) {
+      const Pos ps = locate(a, p0 + pl);
+      const Sample s = sample_of(a, ps, tap, (c8 * 8) / cpg);
+      if (s.valid) {
+        const int H = a.in_h[ps.l], W = a.in_w[ps.l];
+        const long long base = a.in_row0[ps.l] + (long long)ps.b * H * W;
+        const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int hc = s.hl + (k >> 1), wc = s.wl + (k & 1);
+          if (hc < 0 || hc > H - 1 || wc < 0 || wc > W - 1) continue;
+          const float wgt = ((k >> 1) ? s.lh : hh) * ((k & 1) ? s.lw : hw);
+          const u32x4 raw = *reinterpret_cast<const u32x4*>(a.x + (base + (long long)hc * W + wc) * a.in_cstride + c8 * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] += wgt * __uint_as_float(raw[e] << 16);
+            v[2 * e + 1] += wgt * __uint_as_float(raw[e] & 0xffff0000u);
+          }
+        }
+      }
+    }
+    uint16_t* o = colT + ((long long)tap * a.cin + c8 * 8) * Lp + pl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[(long long)e * Lp] = (uint16_t)f32_to_bf16_bits(v[e]);
+  }
+}
+
+// gout^T[co][pl] (bf16) for the same positions; rows cout..cout_pad and columns n..Lp are zero
+__global__ __launch_bounds__(256) void gout_t_kernel(const DBArgs a, long long p0, int n, int Lp, int cout_pad,
+                                                     uint16_t* __restrict__ goutT) {
+  const long long total = (long long)cout_pad * Lp;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int pl = (int)(t % Lp);
+    const int co = (int)(t / Lp);
+    uint16_t v = 0;
+    if (pl < n && co < a.cout) {
+      const Pos ps = locate(a, p0 + pl);
+      v = a.gout[ps.orow * a.gout_cstride + co];
+    }
+    goutT[t] = v;
+  }
+}
+
+__global__ void axpy_kernel(float* __restrict__ acc, const float* __restrict__ x, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    acc[i] += x[i];
+}
+
+struct Plan {
+  long long P, K;
+  int chunk, Lp, cout_pad2;       // weight-gradient GEMM: positions per chunk, padded length, padded cout
+  int kpad1;                      // grad-column GEMM: K padded to its cout tile
+  size_t off_gcol, off_colT, off_goutT, off_dtmp, total;
+};
+
+bool make_plan(const sm_conv_desc* d, Plan* pl) {
+  pl->P = 0;
+  for (int l = 0; l < d->nlev; ++l) pl->P += (long long)d->batch * d->out_h[l] * d->out_w[l];
+  pl->K = (long long)d->kh * d->kw * d->cin;
+  pl->chunk = (int)std::min<long long>(pl->P, DB_MAX_CHUNK);
+  pl->Lp = (pl->chunk + 63) / 64 * 64;
+  const int t2 = sm_conv_cout_tile(d->cout);
+  pl->cout_pad2 = (d->cout + t2 - 1) / t2 * t2;
+  const int t1 = sm_conv_cout_tile((int)pl->K);
+  pl->kpad1 = (int)((pl->K + t1 - 1) / t1 * t1);
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o += (bytes + 255) / 256 * 256;
+    return at;
+  };
+  pl->off_gcol = take((size_t)pl->P * pl->K * 4);
+  pl->off_colT = take((size_t)pl->K * pl->Lp * 2);
+  pl->off_goutT = take((size_t)pl->cout_pad2 * pl->Lp * 2);
+  pl->off_dtmp = take((size_t)pl->K * d->cout * 4);
+  pl->total = o;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int64_t sm_deform_conv2d_bwd_workspace(const sm_conv_desc* d) {
+  if (!d || d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return 0;
+  Plan pl;
+  make_plan(d, &pl);
+  return (int64_t)pl.total;
+}
+
+extern "C" int sm_deform_conv2d_bwd(const sm_conv_desc* d, const void* x, const float* offset, const void* w_t,
+                                    const void* gout, float* grad_x, float* grad_offset, float* grad_w_t,
+                                    void* workspace, sm_stream_t stream) {
+  if (!d || !x || !offset || !gout || !workspace) return SM_ERR_BAD_ARG;
+  if (d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return SM_ERR_BAD_SHAPE;
+  if (d->deform_groups < 1 || d->cin % 64 != 0 || (d->cin / d->deform_groups) % 64 != 0 || d->cout % 8 != 0)
+    return SM_ERR_UNSUPPORTED;
+  if (d->stride != 1) return SM_ERR_UNSUPPORTED;
+  if ((grad_x || grad_offset) && !w_t) return SM_ERR_BAD_ARG;
+  hipStream_t s = sm_hip_stream(stream);
+  Plan pl;
+  make_plan(d, &pl);
+  char* ws = (char*)workspace;
+  DBArgs a;
+  a.x = (const uint16_t*)x;
+  a.offset = offset;
+  a.gout = (const uint16_t*)gout;
+  a.nlev = d->nlev;
+  a.batch = d->batch;
+  long long in_rows = 0;
+  for (int l = 0; l < d->nlev; ++l) {
+    a.in_h[l] = d->in_h[l], a.in_w[l] = d->in_w[l], a.out_h[l] = d->out_h[l], a.out_w[l] = d->out_w[l];
+    a.in_row0[l] = d->in_row0[l], a.out_row0[l] = d->out_row0[l];
+    in_rows = std::max<long long>(in_rows, d->in_row0[l] + (long long)d->batch * d->in_h[l] * d->in_w[l]);
+  }
+  // the compact position order must coincide with the rows of gout/offset inside a level (it does by
+  // construction: row = out_row0[l] + (b*oh + y)*ow + x); levels may sit anywhere
+  a.cin = d->cin, a.cout = d->cout, a.kh = d->kh, a.kw = d->kw, a.stride = d->stride, a.pad = d->pad, a.dil = d->dil;
+  a.in_cstride = d->in_cstride, a.gout_cstride = d->out_cstride, a.G = d->deform_groups;
+  a.P = pl.P;
+  const int kk = d->kh * d->kw;
+
+  if (grad_x || grad_offset) {
+    // ---- grad columns = gout @ W  as a 1x1 conv  (cin := cout, cout := K)
+    sm_conv_desc g1;
+    memset(&g1, 0, sizeof(g1));
+    g1.nlev = d->nlev;
+    g1.batch = d->batch;
+    long long prow = 0;
+    for (int l = 0; l < d->nlev; ++l) {
+      g1.in_h[l] = g1.out_h[l] = d->out_h[l];
+      g1.in_w[l] = g1.out_w[l] = d->out_w[l];
+      g1.in_row0[l] = d->out_row0[l];
+      g1.out_row0[l] = prow;
+      prow += (long long)d->batch * d->out_h[l] * d->out_w[l];
+    }
+    g1.cin = d->cout;
+    g1.cout = (int)pl.K;
+    g1.cout_pad = pl.kpad1;
+    g1.kh = g1.kw = 1, g1.stride = 1, g1.pad = 0, g1.dil = 1;
+    g1.in_cstride = d->out_cstride;
+    g1.out_cstride = (int)pl.K;
+    g1.flags = SM_CONV_OUT_F32;
+    float* gcol = (float*)(ws + pl.off_gcol);
+    int st = sm_conv2d(&g1, gout, w_t, nullptr, nullptr, gcol, stream);
+    if (st != SM_OK) return st;
+    if (grad_x && hipMemsetAsync(grad_x, 0, (size_t)in_rows * d->cin * 4, s) != hipSuccess) return SM_ERR_LAUNCH;
+    if (grad_offset) {   // positions sampling outside the image are skipped by the kernel: their gradient is 0
+      long long orows = 0;
+      for (int l = 0; l < d->nlev; ++l)
+        orows = std::max<long long>(orows, d->out_row0[l] + (long long)d->batch * d->out_h[l] * d->out_w[l]);
+      if (hipMemsetAsync(grad_offset, 0, (size_t)orows * d->deform_groups * kk * 2 * 4, s) != hipSuccess)
+        return SM_ERR_LAUNCH;
+    }
+    const long long nunits = pl.P * kk * (d->cin / 64);
+    const int blocks = (int)std::min<long long>((nunits + 3) / 4, 256 * 64);
+    hipLaunchKernelGGL(deform_col2im_kernel, dim3(blocks), dim3(256), 0, s, a, gcol, grad_x, grad_offset, nunits);
+    SM_LAUNCH_CHECK();
+  }
+  if (grad_w_t) {
+    // ---- dW^T[k][co] = sum over position chunks of col^T @ gout (1x1 conv: rows := K, cin := chunk length)
+    uint16_t* colT = (uint16_t*)(ws + pl.off_colT);
+    uint16_t* goutT = (uint16_t*)(ws + pl.off_goutT);
+    float* dtmp = (float*)(ws + pl.off_dtmp);
+    const long long nout = pl.K * d->cout;
+    bool first = true;
+    for (long long p0 = 0; p0 < pl.P; p0 += pl.chunk) {
+      const int n = (int)std::min<long long>(pl.chunk, pl.P - p0);
+      const int Lp = (n + 63) / 64 * 64;
+      const long long t1 = (long long)kk * (d->cin / 8) * Lp;
+      hipLaunchKernelGGL(deform_im2col_t_kernel, dim3((int)std::min<long long>((t1 + 255) / 256, 256 * 64)), dim3(256), 0, s, a,
+                         p0, n, Lp, colT);
+      const long long t2 = (long long)pl.cout_pad2 * Lp;
+      hipLaunchKernelGGL(gout_t_kernel, dim3((int)std::min<long long>((t2 + 255) / 256, 256 * 64)), dim3(256), 0, s, a, p0, n,
+                         Lp, pl.cout_pad2, goutT);
+      SM_LAUNCH_CHECK();
+      sm_conv_desc g2;
+      memset(&g2, 0, sizeof(g2));
+      g2.nlev = 1;
+      g2.batch = 1;
+      g2.in_h[0] = g2.out_h[0] = 1;
+      g2.in_w[0] = g2.out_w[0] = (int)pl.K;
+      g2.cin = Lp;
+      g2.cout = d->cout;
+      g2.cout_pad = pl.cout_pad2;
+      g2.kh = g2.kw = 1, g2.stride = 1, g2.pad = 0, g2.dil = 1;
+      g2.in_cstride = Lp;
+      g2.out_cstride = d->cout;
+      g2.flags = SM_CONV_OUT_F32;
+      int st = sm_conv2d(&g2, colT, goutT, nullptr, nullptr, first ? (void*)grad_w_t : (void*)dtmp, stream);
+      if (st != SM_OK) return st;
+      if (!first) {
+        hipLaunchKernelGGL(axpy_kernel, dim3((int)std::min<long long>((nout + 255) / 256, 4096)), dim3(256), 0, s, grad_w_t, dtmp,
+                           nout);
+        SM_LAUNCH_CHECK();
+      }
+      first = false;
+    }
+  }
+  return SM_OK;
+}

@@ -123,6 +123,15 @@ def offset_linear(reg, reg_cstride, w_off, lv, out, level_scale=None):
     return out
 
 
+def deform_conv2d_bwd(desc, x, offset, w_t, gout, grad_x, grad_offset, grad_w_t):
+    """grad_x f32 [rows][cin], grad_offset f32 like offset, grad_w_t f32 [K][cout]; None = skip."""
+    lib = _lib.load()
+    ws = torch.empty(int(lib.sm_deform_conv2d_bwd_workspace(C.byref(desc))), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.sm_deform_conv2d_bwd(C.byref(desc), _lib.ptr(x), _lib.ptr(offset), _lib.ptr(w_t), _lib.ptr(gout),
+                                        _lib.ptr(grad_x), _lib.ptr(grad_offset), _lib.ptr(grad_w_t), _lib.ptr(ws),
+                                        _lib.stream_ptr()), "sm_deform_conv2d_bwd")
+
+
 def groupnorm(x, y, gamma, beta, stats, lv, channels, groups=32, eps=1e-5, relu=True):
     lib = _lib.load()
     nlev = len(lv)

@@ -63,13 +63,44 @@ class DeformConvFunction(Function):
         d = H.make_conv_desc(b, [(h, w)], [(ho, wo)], [0], [0], c, co, co_pad, kh, 1, padding[0], c, co,
                              flags=_lib.SM_CONV_OUT_F32, dil=dilation[0], deform_groups=g)
         H.deform_conv2d(d, x, off, wq, None, y)
+        if input.requires_grad or offset.requires_grad or weight.requires_grad:
+            ctx.save_for_backward(x, off, weight)
+            ctx.geom = (b, c, h, w, co, kh, ho, wo, padding[0], dilation[0], g, input.dtype)
         return y.view(b, ho, wo, co).permute(0, 3, 1, 2).to(input.dtype)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        raise NotImplementedError("sipmask_amd: deformable-conv backward (col2im / coord / weight grads, "
-                                  "deform_conv_cuda_kernel.cu:280-436) is scheduled for the training round")
+        """deform_conv.py:60-96: (grad_input, grad_offset, grad_weight) through sm_deform_conv2d_bwd.
+        Mixed precision like the forward: bf16 operands (x, weight, grad_output), f32 accumulation."""
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        x, off, weight = ctx.saved_tensors
+        b, c, h, w, co, k, ho, wo, pad, dil, g, dt = ctx.geom
+        dev = grad_output.device
+        if c % 64 != 0 or (c // g) % 64 != 0 or co % 8 != 0:
+            raise NotImplementedError("deform conv backward needs 64 | channels per deformable group and 8 | out_channels")
+        go = torch.empty(b * ho * wo, co, dtype=torch.bfloat16, device=dev)
+        H.nchw_to_nhwc_bf16(grad_output.detach().float().contiguous(), go, co)
+        d = H.make_conv_desc(b, [(h, w)], [(ho, wo)], [0], [0], c, co, co, k, 1, pad, c, co,
+                             dil=dil, deform_groups=g)
+        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need_w = ctx.needs_input_grad[2]
+        K = k * k * c
+        w_t = None
+        if need_in:      # W^T as the operand of the grad-column GEMM: a 1x1 conv weight [K][co]
+            w_t, _ = H.prep_conv_weight(weight.detach().permute(2, 3, 1, 0).reshape(K, co, 1, 1).contiguous(), co)
+        gx = torch.empty(b * h * w, c, dtype=torch.float32, device=dev) if need_in else None
+        goff = torch.empty_like(off) if need_in else None
+        gw_t = torch.empty(K, co, dtype=torch.float32, device=dev) if need_w else None
+        H.deform_conv2d_bwd(d, x, off, w_t, go, gx, goff, gw_t)
+        grad_input = grad_offset = grad_weight = None
+        if need_in:
+            grad_input = gx.view(b, h, w, c).permute(0, 3, 1, 2).to(dt)
+            grad_offset = goff.view(b, ho, wo, -1).permute(0, 3, 1, 2).contiguous()
+        if need_w:
+            grad_weight = gw_t.view(k, k, c, co).permute(3, 2, 0, 1).contiguous().to(weight.dtype)
+        return (grad_input, grad_offset, grad_weight, None, None, None, None, None, None)
 
 
 deform_conv = DeformConvFunction.apply

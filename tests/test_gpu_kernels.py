@@ -457,6 +457,41 @@ def test_mask_rects_cover_assembled_masks():
                 assert xs.min() >= r[i, 0] and xs.max() < r[i, 2] and ys.min() >= r[i, 1] and ys.max() < r[i, 3], (i, r[i])
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 10, 12, 32, 1, 1), (1, 256, 13, 21, 256, 4, 1), (2, 128, 9, 7, 64, 1, 2),
+                                 (1, 256, 40, 50, 256, 4, 1), (2, 64, 150, 120, 16, 1, 1)])   # last: 2 wgrad chunks
+def test_deform_conv_backward_vs_oracle(cfg):
+    """DeformConvFunction.backward (sm_deform_conv2d_bwd) against the oracle restatement of the reference's
+    col2im / col2im_coord / parameter-gradient kernels on bf16-representable x, weight, grad_output.
+    Tolerances (relative to the tensor's max): grad_input / grad_offset 2e-3 (f32 accumulation order + atomics),
+    grad_weight 1e-2 (the sampled columns are rounded to bf16 before the MFMA, as in the forward)."""
+    from sipmask_amd import ops as P
+    dev = _dev()
+    B, C, Hh, Ww, Co, G, dil = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = _bf(torch.randn(B, C, Hh, Ww, generator=g))
+    w = _bf(torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    off = torch.randn(B, G * 18, Hh, Ww, generator=g) * 1.5
+    off[:, :, 0, 0] = 0.0                                   # integer sampling points (lh = lw = 0)
+    off[:, :, -1, -1] = 30.0                                # far outside: no contribution, zero offset gradient
+    go = _bf(torch.randn(B, Co, Hh, Ww, generator=g))
+    rx, roff, rw = O.deform_conv_backward(x, off, w, go, 1, dil, dil, G)
+    xd, od, wd = x.to(dev).requires_grad_(), off.to(dev).requires_grad_(), w.to(dev).requires_grad_()
+    y = P.deform_conv(xd, od, wd, 1, dil, dil, 1, G)
+    y.backward(go.to(dev))
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max() / b.abs().max())
+    assert rel(xd.grad, rx) < 2e-3, rel(xd.grad, rx)
+    assert rel(od.grad, roff) < 2e-3, rel(od.grad, roff)
+    assert rel(wd.grad, rw) < 1e-2, rel(wd.grad, rw)
+    assert float(od.grad[:, :, -1, -1].abs().max()) == 0.0
+    # only the weight gradient requested (backward_parameters alone, deform_conv.py:86-94)
+    wd2 = w.to(dev).requires_grad_()
+    P.deform_conv(x.to(dev), off.to(dev), wd2, 1, dil, dil, 1, G).backward(go.to(dev))
+    assert rel(wd2.grad, rw) < 1e-2
+
+
 def test_det_select_vs_oracle():
     """score -> per-level top-k -> gather/decode (sipmask_head.py:563-591) for a 2-image batch."""
     from sipmask_amd import hip_ops as H
