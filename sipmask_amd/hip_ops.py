@@ -343,3 +343,18 @@ def rle_fetch(out, batch, max_num, ndet, canvas_hw):
         res.append([dict(size=list(size), counts=blob[offs[b * max_num + i]:offs[b * max_num + i + 1]])
                     for i in range(int(ndet[b]))])
     return res
+
+
+# ------------------------------------------------------------------------------- fused mask loss (training)
+def mask_loss_fwd(basis, cof, rois, gt, idx_gt, out):
+    lib = _lib.load()
+    _lib.check(lib.sm_mask_loss_fwd(_lib.ptr(basis), 0, _lib.ptr(cof), _lib.ptr(rois), _lib.ptr(gt), _lib.ptr(idx_gt),
+                                    cof.shape[0], basis.shape[1], basis.shape[2], _lib.ptr(out), _lib.stream_ptr()),
+               "sm_mask_loss_fwd")
+
+
+def mask_loss_bwd(basis, cof, rois, gt, idx_gt, grad_sum, grad_cof, grad_basis):
+    lib = _lib.load()
+    _lib.check(lib.sm_mask_loss_bwd(_lib.ptr(basis), 0, _lib.ptr(cof), _lib.ptr(rois), _lib.ptr(gt), _lib.ptr(idx_gt),
+                                    cof.shape[0], basis.shape[1], basis.shape[2], _lib.ptr(grad_sum),
+                                    _lib.ptr(grad_cof), _lib.ptr(grad_basis), _lib.stream_ptr()), "sm_mask_loss_bwd")

@@ -259,6 +259,46 @@ class SigmoidFocalLossFunction(Function):
 sigmoid_focal_loss = SigmoidFocalLossFunction.apply
 
 
+# ------------------------------------------------------------------------------- fused mask loss
+class MaskLossFunction(Function):
+    """Per-detection sum of the mask BCE (sipmask_head.py:443-461) without the [4,Hm,Wm,N] volumes:
+    S[n] = sum_pixels BCE(CropSplit(sigmoid(basis.cof_q))[..,n], CropSplitGt(gt[idx_gt[n]])[..,n]).
+    feat_mask [32,Hm,Wm] f32, cof_pred [N,128], rois [N,4] (basis-grid boxes), gt_masks u8/bool/float 0-1
+    [G,Hm,Wm], idx_gt long [N].  Differentiable in feat_mask and cof_pred."""
+
+    @staticmethod
+    def forward(ctx, feat_mask, cof_pred, rois, gt_masks, idx_gt):
+        if not feat_mask.is_cuda:
+            raise NotImplementedError
+        basis = feat_mask.detach().float().contiguous()
+        cof = cof_pred.detach().float().contiguous()
+        rois = rois.detach().float().contiguous()
+        gt = gt_masks.detach().to(torch.uint8).contiguous()
+        idx = idx_gt.detach().long().contiguous()
+        n = cof.shape[0]
+        if basis.dim() != 3 or basis.shape[0] != 32 or cof.shape[1] != 128 or rois.shape != (n, 4) or \
+                gt.shape[1:] != basis.shape[1:] or idx.shape != (n,):
+            raise ValueError("mask_loss: inconsistent shapes")
+        out = torch.zeros(n, dtype=torch.float32, device=basis.device)
+        H.mask_loss_fwd(basis, cof, rois, gt, idx, out)
+        ctx.save_for_backward(basis, cof, rois, gt, idx)
+        ctx.dtypes = (feat_mask.dtype, cof_pred.dtype)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_sum):
+        basis, cof, rois, gt, idx = ctx.saved_tensors
+        gb = torch.empty_like(basis) if ctx.needs_input_grad[0] else None
+        gc = torch.zeros_like(cof) if ctx.needs_input_grad[1] else None
+        H.mask_loss_bwd(basis, cof, rois, gt, idx, grad_sum.detach().float().contiguous(), gc, gb)
+        return (None if gb is None else gb.to(ctx.dtypes[0]), None if gc is None else gc.to(ctx.dtypes[1]),
+                None, None, None)
+
+
+mask_loss = MaskLossFunction.apply
+
+
 # ------------------------------------------------------------------------------- NMS
 def nms(dets, iou_thr, device_id=None):
     """Same contract as nms_wrapper.nms for GPU tensors: returns (dets[inds], inds), inds ascending.

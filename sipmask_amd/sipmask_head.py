@@ -148,5 +148,69 @@ class SipMaskHead(nn.Module):
             out.append((det, labels, cls_segms))
         return out
 
-    def loss(self, *args, **kwargs):
-        raise NotImplementedError("SipMaskHead.loss (training step, SURVEY row a13) lands with the backward kernels")
+    def loss(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, gt_bboxes, gt_labels, img_metas, cfg,
+             gt_bboxes_ignore=None, gt_masks_list=None):
+        """sipmask_head.py:289-498 (rescoring_flag=False): dict(loss_cls, loss_bbox, loss_centerness, loss_mask).
+
+        Same arguments as the reference.  Target assignment is tensor code (targets.py); the classification
+        loss runs on the HIP sigmoid-focal-loss kernel and the mask loss on the fused HIP kernels
+        (ops.mask_loss: no [4,Hm,Wm,N] probability volumes, CropSplit/CropSplitGt/BCE/reduction in one pass),
+        both differentiable, so `sum(losses).backward()` reaches the head outputs."""
+        from . import targets as T
+        from .ops import mask_loss
+        if gt_masks_list is None:
+            raise ValueError("SipMaskHead.loss needs gt_masks_list (with_mask=True in the train pipeline)")
+        assert len(cls_scores) == len(bbox_preds) == len(centernesses)
+        dev = cls_scores[0].device
+        sizes = [tuple(f.shape[-2:]) for f in cls_scores]
+        points = T.level_points(sizes, self.strides, bbox_preds[0].dtype, dev)
+        nums = [p.shape[0] for p in points]
+        num_imgs, C = cls_scores[0].size(0), self.cls_out_channels
+        lab_lvl, tgt_lvl, lab_img, tgt_img, gt_inds = T.fcos_target(
+            points, self.strides, self.regress_ranges, gt_bboxes, gt_labels, self.center_sampling,
+            self.center_sample_radius)
+        rows = lambda ts, c: torch.cat([t.permute(0, 2, 3, 1).reshape(-1, c) for t in ts])
+        f_cls, f_box, f_ctr = rows(cls_scores, C), rows(bbox_preds, 4), rows(centernesses, 1).reshape(-1)
+        f_lab, f_tgt = torch.cat(lab_lvl), torch.cat(tgt_lvl)
+        f_pts = torch.cat([p.repeat(num_imgs, 1) for p in points])
+        f_str = torch.cat([p.new_full((n * num_imgs, 1), float(s)) for p, n, s in zip(points, nums, self.strides)])
+        pos = f_lab.nonzero().reshape(-1)
+        num_pos = len(pos)
+        loss_cls = self.loss_cls(f_cls, f_lab, avg_factor=num_pos + num_imgs)             # :364-366
+        p_box, p_ctr = f_box[pos], f_ctr[pos]
+        if num_pos > 0:
+            p_tgt = f_tgt[pos]
+            ctr_t = T.centerness_target(p_tgt)
+            dec_p = T.distance2bbox(f_pts[pos], p_box / f_str[pos])
+            dec_t = T.distance2bbox(f_pts[pos], p_tgt / f_str[pos])
+            loss_bbox = self.loss_bbox(dec_p, dec_t, weight=ctr_t, avg_factor=ctr_t.sum())   # :379-383
+            loss_centerness = self.loss_centerness(p_ctr, ctr_t)
+        else:
+            loss_bbox, loss_centerness = p_box.sum(), p_ctr.sum()
+        # ---- mask loss (:395-461), one fused launch pair per image
+        img_cls = torch.cat([c.permute(0, 2, 3, 1).reshape(num_imgs, -1, C) for c in cls_scores], 1)
+        img_cof = torch.cat([c.permute(0, 2, 3, 1).reshape(num_imgs, -1, 128) for c in cof_preds], 1)
+        img_box = torch.cat([b.detach().permute(0, 2, 3, 1).reshape(num_imgs, -1, 4) for b in bbox_preds], 1)
+        cat_pts = torch.cat(points)
+        loss_mask = 0
+        for i in range(num_imgs):
+            labels = torch.cat([l.flatten() for l in lab_img[i]])
+            pi = (labels > 0).nonzero().view(-1)
+            bdt = T.distance2bbox(cat_pts[pi], img_box[i][pi]) / 2                        # det_bboxes[i] / 2
+            area = (bdt[:, 2] - bdt[:, 0]) * (bdt[:, 3] - bdt[:, 1])
+            keep = area > 1.0
+            bdt, idx, pk = bdt[keep], gt_inds[i][keep], pi[keep]
+            if bdt.shape[0] == 0:
+                loss_mask = loss_mask + area.sum() * 0
+                continue
+            with torch.no_grad():
+                score = img_cls[i, pk, labels[pk] - 1].sigmoid()
+                weighting = score * T.aligned_iou(gt_bboxes[i][idx] / 2, bdt)
+                weighting = weighting / (weighting.sum() + 0.0001) * len(weighting)
+                hm, wm = feat_masks[i].shape[1:]
+                gt_new = T.prepare_gt_masks(gt_masks_list[i][:gt_labels[i].shape[0]], hm, wm, dev)
+            bce = mask_loss(feat_masks[i], img_cof[i][pk], bdt, gt_new, idx)             # [N] per-detection sums
+            pre = bce / (bdt[:, 2] - bdt[:, 0]) / (bdt[:, 3] - bdt[:, 1]) / bdt.shape[0]
+            loss_mask = loss_mask + torch.sum(pre * weighting)
+        loss_mask = loss_mask / num_imgs
+        return dict(loss_cls=loss_cls, loss_bbox=loss_bbox, loss_centerness=loss_centerness, loss_mask=loss_mask)

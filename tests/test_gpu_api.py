@@ -246,3 +246,88 @@ def test_ssd_simple_test_rescale(ssd_det):
     # scores sorted descending overall (fast_nms sorts the survivors, sipmask_head.py:902)
     sc = eng.nms_out["det"][0, :n, 4].cpu().numpy()
     assert (np.diff(sc) <= 0).all()
+
+
+# --------------------------------------------------------------------------- training: SipMaskHead.loss
+def _synthetic_gt(g, num_imgs, img_h, img_w, n_gt):
+    from numpy.random import RandomState
+    rng = RandomState(int(torch.randint(0, 10000, (1,), generator=g)))
+    boxes, labels, masks = [], [], []
+    for _ in range(num_imgs):
+        xy = rng.rand(n_gt, 2) * np.array([img_w * 0.6, img_h * 0.6])
+        wh = rng.rand(n_gt, 2) * np.array([img_w * 0.5, img_h * 0.5]) + 10
+        b = np.concatenate([xy, np.minimum(xy + wh, [img_w - 1, img_h - 1])], 1).astype(np.float32)
+        m = np.zeros((n_gt, img_h, img_w), np.uint8)
+        yy, xx = np.mgrid[:img_h, :img_w]
+        for k in range(n_gt):
+            cx, cy, rx, ry = (b[k, 0] + b[k, 2]) / 2, (b[k, 1] + b[k, 3]) / 2, (b[k, 2] - b[k, 0]) / 2, (b[k, 3] - b[k, 1]) / 2
+            m[k] = (((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) <= 1.0
+        boxes.append(torch.from_numpy(b))
+        labels.append(torch.from_numpy(rng.randint(1, 81, n_gt).astype(np.int64)))
+        masks.append(m)
+    return boxes, labels, masks
+
+
+def test_mask_loss_kernels_vs_oracle():
+    """sm_mask_loss_fwd/bwd == CropSplit(sigmoid(basis.cof)) / CropSplitGt / BCE / sum of the reference
+    (sipmask_head.py:443-461) and its autograd gradients.  f32 both sides: 1e-4 relative (expf/logf ulps,
+    summation order)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd.ops import mask_loss
+    from oracle import loss as OL
+    g = torch.Generator().manual_seed(12)
+    hm, wm, n, G = 48, 72, 37, 5
+    fm = torch.randn(32, hm, wm, generator=g)
+    cof = torch.randn(n, 128, generator=g) * 0.4
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([wm * 0.8, hm * 0.8]) - 4
+    wh = torch.rand(n, 2, generator=g) * torch.tensor([wm * 0.6, hm * 0.6]) + 1.5
+    boxes = torch.cat([xy, xy + wh], 1)
+    boxes[3] = torch.tensor([5.0, 7.0, 9.0, 12.0])           # integer corners: exact >=, < tests
+    boxes[4] = torch.tensor([-20.0, -20.0, 200.0, 200.0])    # covers the whole grid
+    gtm = (torch.rand(G, hm, wm, generator=g) < 0.5).float()
+    idx = torch.randint(0, G, (n,), generator=g)
+    wgt = torch.rand(n, generator=g)
+    fr, cr = fm.clone().requires_grad_(), cof.clone().requires_grad_()
+    lref, pre = OL.mask_loss_single(fr, cr, boxes, gtm, idx, wgt)
+    lref.backward()
+    fd, cd = fm.cuda().requires_grad_(), cof.cuda().requires_grad_()
+    bd = boxes.cuda()
+    bce = mask_loss(fd, cd, bd, gtm.cuda().to(torch.uint8), idx.cuda())
+    pre_d = bce / (bd[:, 2] - bd[:, 0]) / (bd[:, 3] - bd[:, 1]) / n
+    torch.testing.assert_close(pre_d.detach().cpu(), pre.detach(), rtol=1e-4, atol=1e-6)
+    (pre_d * wgt.cuda()).sum().backward()
+    torch.testing.assert_close(cd.grad.cpu(), cr.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(fd.grad.cpu(), fr.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_head_loss_vs_oracle(det):
+    """SipMaskHead.loss on caller-provided head outputs: the four losses and their gradients w.r.t. every head
+    output against the CPU oracle's autograd (f32 both sides, 2e-4 relative to each tensor's max)."""
+    from oracle import loss as OL
+    g = torch.Generator().manual_seed(21)
+    B, C = 2, 80
+    sizes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    strides = (8, 16, 32, 64, 128)
+    mk = lambda c, sc, sh: [(torch.randn(B, c, h, w, generator=g) * sc + sh) for h, w in sizes]
+    cls, ctr, cof = mk(C, 1.5, -3.0), mk(1, 1.0, 0.0), mk(128, 0.3, 0.0)
+    bb = [(torch.rand(B, 4, h, w, generator=g) * 3 + 0.5) * s for (h, w), s in zip(sizes, strides)]
+    fm = torch.randn(B, 32, 64, 80, generator=g)
+    gtb, gtl, gtm = _synthetic_gt(g, B, 128, 160, 5)
+    leaves_r = [[t.clone().requires_grad_() for t in ts] for ts in (cls, bb, ctr, cof)] + [fm.clone().requires_grad_()]
+    ref, aux = OL.head_loss(leaves_r[0], leaves_r[1], leaves_r[2], leaves_r[3], leaves_r[4], gtb, gtl, gtm)
+    assert aux["num_pos"] > 20
+    sum(ref.values()).backward()
+    leaves_d = [[t.cuda().requires_grad_() for t in ts] for ts in (cls, bb, ctr, cof)] + [fm.cuda().requires_grad_()]
+    metas = [dict(img_shape=(128, 160, 3), pad_shape=(128, 160, 3), scale_factor=1.0) for _ in range(B)]
+    out = det.bbox_head.loss(leaves_d[0], leaves_d[1], leaves_d[2], leaves_d[3], leaves_d[4],
+                             [b.cuda() for b in gtb], [l.cuda() for l in gtl], metas, None, gt_masks_list=gtm)
+    assert set(out) == {"loss_cls", "loss_bbox", "loss_centerness", "loss_mask"}
+    for k in out:
+        assert abs(float(out[k]) - float(ref[k])) <= 2e-4 * max(1.0, abs(float(ref[k]))), (k, float(out[k]), float(ref[k]))
+    sum(out.values()).backward()
+    flat = lambda L: [t for ts in L[:4] for t in ts] + [L[4]]
+    for a, b in zip(flat(leaves_d), flat(leaves_r)):
+        assert b.grad is not None and a.grad is not None
+        scale = float(b.grad.abs().max()) + 1e-12
+        assert float((a.grad.cpu() - b.grad).abs().max()) <= 2e-4 * scale + 1e-7, (tuple(a.shape), scale)
