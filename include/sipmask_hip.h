@@ -275,6 +275,23 @@ int sm_mask_loss_bwd(const float* basis, int basis_hwc, const float* cof, const 
                      const int64_t* idx_gt, int n, int hm, int wm, const float* grad_sum, float* grad_cof,
                      float* grad_basis, sm_stream_t stream);
 
+/* ---- SipMask-VIS tracking (V/ = SipMask-VIS/, V/mmdet/models/anchor_heads/sipmask_head.py) -------------- */
+
+/* extract_box_feature_center_single (:768-781) for every detection of the batch: out[b][i][:] = the embedding at
+ * floor((x1+x2)/2/stride), floor((y1+y2)/2/stride) of track_feats f32 [batch][h][w][channels] (NHWC), boxes first
+ * multiplied by box_mul (res_det_bboxes *= scale_factor, :612-614).  Rows i >= ndet[b] are zeroed. */
+int sm_track_gather(const float* track_feats, const float* det, const int32_t* ndet, int batch, int max_num, int h,
+                    int w, int channels, float box_mul, float stride, float* out, sm_stream_t stream);
+
+/* Matching scores of one frame against the tracked objects (:623-640, compute_comp_scores :544-562):
+ * comp f32 [n][t+1] = log_softmax([0, det_feats . prev_feats^T]) + coeff_score*log(det score)
+ *                     + coeff_iou*IoU(+1)(det, prev) + coeff_label*[labels equal]   (column 0 = new object:
+ * IoU 0, label term 1), plus the row arg max (first maximum) and its value.  det f32 [n][5], prev_boxes [t][5]. */
+int sm_track_match(const float* det_feats, const float* prev_feats, const float* det, const int64_t* det_labels,
+                   const float* prev_boxes, const int64_t* prev_labels, int n, int t, int channels,
+                   float coeff_score, float coeff_iou, float coeff_label, float* comp, int32_t* match_id,
+                   float* match_score, sm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

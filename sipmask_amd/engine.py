@@ -73,7 +73,7 @@ class SipMaskEngine:
 
     def __init__(self, state_dict, batch, img_hw, depth=50, test_cfg=None, num_classes=81, device="cuda",
                  strides=(8, 16, 32, 64, 128), img_shape=None, head_sizes=None, ssd_flag=False, scale_factor=1.0,
-                 rescale=False):
+                 rescale=False, vis=False):
         _lib.load()   # fail loudly before anything else if the HIP library is missing
         if not torch.cuda.is_available():
             raise RuntimeError("SipMaskEngine needs a HIP device")
@@ -90,6 +90,10 @@ class SipMaskEngine:
         self.img_shape = img_shape or (self.H, self.W, 3)
         # ssd_flag configs: fast_nms + per-axis mask upsampling (sipmask_head.py:594-605,629-630)
         self.ssd_flag, self.scale_factor, self.rescale = bool(ssd_flag), scale_factor, rescale
+        # SipMask-VIS head (V/mmdet/models/anchor_heads/sipmask_head.py): track branch, always fast_nms with
+        # cfg.max_per_img, mask threshold 0.5, crop/upsample scaled only when rescale (:734-764)
+        self.vis = bool(vis)
+        self.mask_thr = 0.5 if self.vis else 0.4
         self.steps = []        # (label, callable)
         self.convs = []        # _Conv objects (for FLOP accounting / per-kernel timing)
         self.head_start = 0
@@ -104,12 +108,12 @@ class SipMaskEngine:
 
     @classmethod
     def for_head(cls, state_dict, batch, sizes, num_classes=81, strides=(8, 16, 32, 64, 128), test_cfg=None,
-                 img_shape=None, ssd_flag=False):
+                 img_shape=None, ssd_flag=False, vis=False):
         """Plan for SipMaskHead.forward / get_bboxes alone (features come from the caller)."""
         h0, w0 = sizes[0]
         img_hw = (h0 * strides[0], w0 * strides[0])
         return cls(state_dict, batch, img_hw, 50, test_cfg, num_classes, "cuda", strides,
-                   img_shape or (img_hw[0], img_hw[1], 3), head_sizes=list(sizes), ssd_flag=ssd_flag)
+                   img_shape or (img_hw[0], img_hw[1], 3), head_sizes=list(sizes), ssd_flag=ssd_flag, vis=vis)
 
     def load_pyramid(self, feats):
         """copy caller features (tuple of NCHW float tensors) into the bf16 pyramid tensor"""
@@ -121,7 +125,7 @@ class SipMaskEngine:
 
     def run_head(self, with_post=False):
         for label, fn in self.steps[self.head_start:]:
-            if not with_post and label in ("det_select", "nms", "mask_assemble"):
+            if not with_post and label in ("det_select", "nms", "mask_assemble", "track_gather"):
                 continue
             fn()
 
@@ -300,6 +304,38 @@ class SipMaskEngine:
         self.hm, self.wm = 4 * h0, 4 * w0
         self.basis = self._buf(B * self.hm * self.wm, 32, torch.float32)      # feat_masks, [B,Hm,Wm,32]
         self._add("up:basis", lambda: H.upsample_bilinear(self.basis_lo, self.basis, B, h0, w0, 32, 4, 32, 32, 0, True))
+        # VIS track branch (V/...:265-284,310-311): track_convs on levels 0-2 (one 3-level launch per conv) ->
+        # bilinear x1/x2/x4 -> cat 768 -> 1x1 -> 512-channel embedding map at stride 8, f32
+        self.track_feats = None
+        ntrack = sum(1 for k in sd if k.startswith(h + "track_convs.") and k.endswith(".conv.weight"))
+        if ntrack:
+            lv3 = H.Levels(B, sizes[:3])
+            assert list(lv3.row0) == list(row0[:3])
+            x = self.pyr
+            for i in range(ntrack):
+                y = self._buf(lv3.rows, 256)
+                name = "track_convs.%d" % i
+                c = self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"],
+                                         None if self.flag_norm else sd.get(h + name + ".conv.bias"), B, sizes[:3],
+                                         row0[:3], x, 256, 1, 1, y, row0[:3], 256,
+                                         flags=0 if self.flag_norm else SM_CONV_RELU))
+                if self.flag_norm:
+                    g = sd[h + name + ".gn.weight"].float().to(dev).contiguous()
+                    bta = sd[h + name + ".gn.bias"].float().to(dev).contiguous()
+                    c.gn_stats = self.gn_stats
+                    self._add("gn:" + name, (lambda y=y, g=g, bta=bta: H.groupnorm_apply(
+                        y, y, g, bta, self.gn_stats, lv3, 256, 32, 1e-5, True)))
+                x = y
+            self.track_cat = self._buf(B * h0 * w0, 768)
+            for l in range(3):
+                fh, fw = sizes[l]
+                src = x[row0[l]:row0[l] + B * fh * fw]
+                self._add("up:track%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear(
+                    s, self.track_cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, False)))
+            self.track_feats = self._buf(B * h0 * w0, 512, torch.float32)
+            self._add_conv(_Conv(self, "head.sipmask_track", sd[h + "sipmask_track.weight"], sd[h + "sipmask_track.bias"],
+                                 B, [(h0, w0)], [0], self.track_cat, 768, 1, 0, self.track_feats, [0], 512,
+                                 flags=SM_CONV_OUT_F32))
 
     def _build_post(self):
         """get_bboxes (sipmask_head.py:500-633) for all images of the batch, device resident."""
@@ -308,15 +344,16 @@ class SipMaskEngine:
                                         self.ncls, 8, cfg["nms_pre"], self.img_shape[0], self.img_shape[1],
                                         self.scale_factor, bool(self.rescale))
         self.sel = H.det_select_alloc(self.det_desc, self.device)
-        # fast_nms keeps a hard-coded 100 (sipmask_head.py:903), not cfg.max_per_img
-        self.max_num = 100 if self.ssd_flag else cfg["max_per_img"]
+        # the M/ fast_nms keeps a hard-coded 100 (sipmask_head.py:903), the VIS one cfg.max_per_img (V/...:985)
+        self.max_num = 100 if (self.ssd_flag and not self.vis) else cfg["max_per_img"]
         self.nms_out = H.multiclass_nms_alloc(B, self.det_desc.kmax, self.ncls, self.max_num, self.device)
-        self.box_mul, self.up, (self.ho, self.wo) = H.post_geometry(self.hm, self.wm, self.scale_factor, self.rescale,
+        geo_rescale = (True if self.rescale else None) if self.vis else self.rescale
+        self.box_mul, self.up, (self.ho, self.wo) = H.post_geometry(self.hm, self.wm, self.scale_factor, geo_rescale,
                                                                     self.ssd_flag)
         self.pitch = (self.wo + 3) // 4 * 4
         self.masks = torch.zeros(B, self.max_num, self.ho, self.pitch, dtype=torch.uint8, device=self.device)
         self._add("det_select", lambda: H.det_select(self.det_desc, self.cls_cof, self.reg_out, self.cls_cof, self.sel))
-        if self.ssd_flag:
+        if self.ssd_flag or self.vis:
             self._add("nms", lambda: H.fast_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"],
                                                 self.sel["ncand"], cfg["score_thr"], cfg["nms"]["iou_thr"], 200,
                                                 self.max_num, self.nms_out))
@@ -326,7 +363,15 @@ class SipMaskEngine:
                                                       self.max_num, self.nms_out))
         self._add("mask_assemble", lambda: H.mask_assemble(
             self.basis, True, self.sel["cofs"], self.nms_out["keep"], self.nms_out["det"], self.nms_out["ndet"],
-            self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, 0.4, self.masks))
+            self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, self.masks))
+        if self.track_feats is not None:
+            # det_roi_feats (V/...:612-616): embeddings at the box centres, boxes back in network coordinates
+            import numpy as np
+            sfv = float(np.asarray(self.scale_factor, np.float64).reshape(-1)[0])
+            self.det_feats = torch.zeros(B, self.max_num, 512, dtype=torch.float32, device=self.device)
+            self._add("track_gather", lambda: H.track_gather(
+                self.track_feats, self.nms_out["det"], self.nms_out["ndet"], lv.sizes[0][0], lv.sizes[0][1],
+                sfv if self.rescale else 1.0, self.det_feats))
 
     # -------------------------------------------------------------------------------- execution
     def run(self, img):
@@ -339,8 +384,11 @@ class SipMaskEngine:
 
     def results(self):
         o = self.nms_out
-        return dict(det_bboxes=o["det"], det_labels=o["labels"], idxs_keep=o["keep"], ndet=o["ndet"],
-                    masks=self.masks[..., :self.wo])
+        r = dict(det_bboxes=o["det"], det_labels=o["labels"], idxs_keep=o["keep"], ndet=o["ndet"],
+                 masks=self.masks[..., :self.wo])
+        if self.track_feats is not None:
+            r["det_feats"] = self.det_feats
+        return r
 
     def encode_rle(self, canvas_hw=None, fetch=True, max_runs=8192):
         """Result packing on device (sipmask_head.py:645-657 without the per-mask D2H): run-length encodes the
@@ -389,7 +437,7 @@ class PostProcessor:
     parity tests: identical f32 inputs on both sides).  sipmask_head.py:500-633."""
 
     def __init__(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg, strides,
-                 rescale=None, ssd_flag=False):
+                 rescale=None, ssd_flag=False, vis=False):
         _lib.load()
         dev = cls_scores[0].device
         _lib.require_cuda(cls_scores[0], feat_masks)
@@ -413,19 +461,21 @@ class PostProcessor:
                     not np.array_equal(np.asarray(m['scale_factor']), np.asarray(meta['scale_factor'])):
                 raise NotImplementedError("a batch must share img_shape / scale_factor (one launch plan)")
         sf = meta['scale_factor']
-        self.cfg, self.ssd_flag = cfg, bool(ssd_flag)
-        self.box_mul, self.up, (self.ho, self.wo) = H.post_geometry(self.hm, self.wm, sf, rescale, self.ssd_flag)
+        self.cfg, self.ssd_flag, self.vis = cfg, bool(ssd_flag), bool(vis)
+        self.mask_thr = 0.5 if self.vis else 0.4                      # V/...:764 vs sipmask_head.py:633
+        geo_rescale = (True if rescale else None) if self.vis else rescale
+        self.box_mul, self.up, (self.ho, self.wo) = H.post_geometry(self.hm, self.wm, sf, geo_rescale, self.ssd_flag)
         self.pitch = (self.wo + 3) // 4 * 4
         self.desc = H.make_det_desc(B, sizes, strides, lv.row0, C, C, 0, 128, 0, 8, cfg.get('nms_pre', -1),
                                     meta['img_shape'][0], meta['img_shape'][1], sf, bool(rescale), True)
         self.sel = H.det_select_alloc(self.desc, dev)
-        self.max_num = 100 if self.ssd_flag else cfg['max_per_img']
+        self.max_num = 100 if (self.ssd_flag and not self.vis) else cfg['max_per_img']
         self.out = H.multiclass_nms_alloc(B, self.desc.kmax, C, self.max_num, dev)
 
     def run(self, want_pos_masks=False):
         cfg = self.cfg
         H.det_select(self.desc, self.cls, self.reg, self.cof, self.sel)
-        if self.ssd_flag:
+        if self.ssd_flag or self.vis:
             H.fast_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"], self.sel["ncand"], cfg['score_thr'],
                        cfg['nms']['iou_thr'], 200, self.max_num, self.out)
         else:
@@ -435,7 +485,8 @@ class PostProcessor:
         self.pos_masks = (torch.zeros(self.B, self.max_num, self.hm, self.wm, device=self.dev)
                           if want_pos_masks else None)
         H.mask_assemble(self.basis, False, self.sel["cofs"], self.out["keep"], self.out["det"], self.out["ndet"],
-                        self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, 0.4, masks, self.pos_masks)
+                        self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, masks,
+                        self.pos_masks)
         self.masks = masks
         nd = self.out["ndet"].cpu().tolist()
         res = []

@@ -358,3 +358,28 @@ def mask_loss_bwd(basis, cof, rois, gt, idx_gt, grad_sum, grad_cof, grad_basis):
     _lib.check(lib.sm_mask_loss_bwd(_lib.ptr(basis), 0, _lib.ptr(cof), _lib.ptr(rois), _lib.ptr(gt), _lib.ptr(idx_gt),
                                     cof.shape[0], basis.shape[1], basis.shape[2], _lib.ptr(grad_sum),
                                     _lib.ptr(grad_cof), _lib.ptr(grad_basis), _lib.stream_ptr()), "sm_mask_loss_bwd")
+
+
+# ------------------------------------------------------------------------------- VIS tracking
+def track_gather(track_feats, det, ndet, h, w, box_mul, out, stride=8.0):
+    """track_feats f32 [B*h*w, C] (NHWC rows); det [B, max_num, 5]; out [B, max_num, C]."""
+    lib = _lib.load()
+    b, n, c = det.shape[0], det.shape[1], track_feats.shape[-1]
+    _lib.check(lib.sm_track_gather(_lib.ptr(track_feats), _lib.ptr(det), _lib.ptr(ndet), b, n, h, w, c, float(box_mul),
+                                   float(stride), _lib.ptr(out), _lib.stream_ptr()), "sm_track_gather")
+    return out
+
+
+def track_match(det_feats, prev_feats, det, det_labels, prev_boxes, prev_labels, coeff):
+    """-> (comp [n, t+1], match_id int32 [n], match_score [n])"""
+    lib = _lib.load()
+    n, c = det_feats.shape
+    t = prev_feats.shape[0]
+    comp = torch.empty(n, t + 1, dtype=torch.float32, device=det_feats.device)
+    mid = torch.zeros(n, dtype=torch.int32, device=det_feats.device)
+    msc = torch.zeros(n, dtype=torch.float32, device=det_feats.device)
+    _lib.check(lib.sm_track_match(_lib.ptr(det_feats), _lib.ptr(prev_feats), _lib.ptr(det), _lib.ptr(det_labels),
+                                  _lib.ptr(prev_boxes), _lib.ptr(prev_labels), n, t, c, float(coeff[0]),
+                                  float(coeff[1]), float(coeff[2]), _lib.ptr(comp), _lib.ptr(mid), _lib.ptr(msc),
+                                  _lib.stream_ptr()), "sm_track_match")
+    return comp, mid, msc

@@ -1,0 +1,165 @@
+"""SipMask-VIS head and detector -- mirrors V/mmdet/models/anchor_heads/sipmask_head.py
+(`V/` = SipMask-VIS/): the SipMask head plus a track branch, fast_nms post-processing and frame-to-frame
+identity matching.
+
+In the reference tree the class is also called ``SipMaskHead``; both variants live in this one package, so it is
+registered here as ``SipMaskVISHead`` / ``SipMaskVIS`` (inside the V/ tree: ``HEADS.register_module(cls, force=True)``
+under the old name).  Parameter names are the reference's (``track_convs.{i}.{conv,gn}``, ``sipmask_track``), so V/
+checkpoints load as they are.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip_ops as H
+from .detector import SipMask
+from .modules import ConvModule
+from .registry import DETECTORS, HEADS
+from .sipmask_head import SipMaskHead
+
+
+@HEADS.register_module
+class SipMaskVISHead(SipMaskHead):
+    """V/mmdet/models/anchor_heads/sipmask_head.py:122-172 (constructor: no ssd/rescoring flags, match_coeff :165)."""
+
+    def __init__(self, num_classes, in_channels, **kwargs):
+        kwargs.pop('ssd_flag', None)
+        kwargs.pop('rescoring_flag', None)
+        super().__init__(num_classes, in_channels, **kwargs)
+        self.match_coeff = [1.0, 2.0, 10]
+        self.track_convs = nn.ModuleList()                              # :219-231
+        for i in range(self.stacked_convs - 1):
+            chn = self.in_channels if i == 0 else self.feat_channels
+            self.track_convs.append(ConvModule(chn, self.feat_channels, 3, stride=1, padding=1, conv_cfg=self.conv_cfg,
+                                               norm_cfg=self.norm_cfg, bias=self.norm_cfg is None))
+        self.sipmask_track = nn.Conv2d(self.feat_channels * 3, 512, 1, padding=0)
+        for m in self.track_convs:
+            nn.init.normal_(m.conv.weight, std=0.01)                    # :249-250
+        self.reset_tracker()
+
+    # ------------------------------------------------------------------ tracker state (:169-171)
+    def reset_tracker(self):
+        self.prev_roi_feats = self.prev_bboxes = self.prev_det_labels = None
+
+    def _engine(self, batch, sizes, img_shape=None, cfg=None):
+        from .engine import SipMaskEngine
+        key = (batch, tuple(sizes), tuple(img_shape or ()), repr(cfg))
+        eng = self._engines.get(key)
+        if eng is None:
+            sd = {"bbox_head." + k: v for k, v in self.state_dict().items()}
+            eng = SipMaskEngine.for_head(sd, batch, sizes, num_classes=self.num_classes, strides=self.strides,
+                                         test_cfg=cfg, img_shape=img_shape, vis=True)
+            self._engines = {key: eng}
+        return eng
+
+    def forward(self, feats, feats_x=None, flag_train=False):
+        """V/...:252-317, test path: (cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, track_feats,
+        track_feats) with track_feats [B,512,h/8,w/8]."""
+        if flag_train:
+            raise NotImplementedError("the VIS training path (reference-frame branch, loss_track) is not built")
+        b = feats[0].shape[0]
+        sizes = [tuple(f.shape[-2:]) for f in feats]
+        eng = self._engine(b, sizes)
+        eng.load_pyramid(feats)
+        eng.run_head()
+        h0, w0 = sizes[0]
+        tf = eng.track_feats.view(b, h0, w0, 512).permute(0, 3, 1, 2)
+        return eng.head_outputs() + (tf, tf)
+
+    # ------------------------------------------------------------------ matching (:618-667)
+    def match(self, det_bboxes, det_labels, det_roi_feats, is_first):
+        """Identity assignment of one frame.  det_bboxes [N,5], det_labels [N], det_roi_feats [N,512] on the
+        device.  Returns det_obj_ids (numpy int32 [N]; -1 = duplicate claim that lost, as in the reference).
+        The scores come from sm_track_match; the sequential memory update is the reference's host loop."""
+        n = det_bboxes.shape[0]
+        if is_first or self.prev_bboxes is None:
+            self.prev_bboxes, self.prev_roi_feats = det_bboxes.clone(), det_roi_feats.clone()
+            self.prev_det_labels = det_labels.clone()
+            return np.arange(n)
+        comp, mid, _ = H.track_match(det_roi_feats.contiguous(), self.prev_roi_feats.contiguous(),
+                                     det_bboxes.contiguous(), det_labels.contiguous(), self.prev_bboxes.contiguous(),
+                                     self.prev_det_labels.contiguous(), self.match_coeff)
+        match_ids = mid.cpu().numpy()
+        comp_h = comp.cpu().numpy()
+        ids = -np.ones(n, dtype=np.int32)
+        best = -100.0 * np.ones(self.prev_bboxes.size(0))
+        new = []
+        for i, m in enumerate(match_ids):
+            if m == 0:
+                ids[i] = self.prev_roi_feats.size(0) + len(new)
+                new.append(i)
+            else:
+                o = int(m) - 1
+                if comp_h[i, m] > best[o]:
+                    ids[i], best[o] = o, comp_h[i, m]
+                    self.prev_roi_feats[o] = det_roi_feats[i]
+                    self.prev_bboxes[o] = det_bboxes[i]
+        if new:
+            idx = torch.as_tensor(new, device=det_bboxes.device)
+            self.prev_roi_feats = torch.cat((self.prev_roi_feats, det_roi_feats[idx]), 0)
+            self.prev_bboxes = torch.cat((self.prev_bboxes, det_bboxes[idx]), 0)
+            self.prev_det_labels = torch.cat((self.prev_det_labels, det_labels[idx]), 0)
+        return ids
+
+    def get_bboxes(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, track_feats, track_feats_ref,
+                   img_metas, cfg, rescale=None):
+        """V/...:565-684 for ONE image (the reference asserts the same): [[det_bboxes, det_labels, obj_segms,
+        det_obj_ids]] with obj_segms {obj_id: COCO RLE dict} encoded on device."""
+        from .engine import PostProcessor
+        assert len(img_metas) == 1, "only support one image at a time (V/...:621)"
+        meta = img_metas[0]
+        post = PostProcessor(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg,
+                             self.strides, rescale, vis=True)
+        det, labels, _, _ = post.run()[0]
+        if det.shape[0] == 0:
+            return [[det, labels, [[] for _ in range(self.num_classes - 1)], []]]
+        sf = float(np.asarray(meta['scale_factor'], np.float64).reshape(-1)[0]) if rescale else 1.0
+        b, c, h0, w0 = track_feats.shape
+        rows = track_feats.detach().float().permute(0, 2, 3, 1).reshape(-1, c).contiguous()
+        feats = torch.zeros(1, post.max_num, c, dtype=torch.float32, device=det.device)
+        H.track_gather(rows, post.out["det"], post.out["ndet"], h0, w0, sf, feats)
+        ids = self.match(det, labels, feats[0, :det.shape[0]], meta['is_first'])
+        rle = post.encode_rle(tuple(meta['ori_shape'])[:2])[0]
+        obj_segms = {}
+        for i in range(det.shape[0]):
+            if ids[i] >= 0:
+                obj_segms[int(ids[i])] = rle[i]
+        return [[det, labels, obj_segms, ids]]
+
+
+@DETECTORS.register_module
+class SipMaskVIS(SipMask):
+    """V/mmdet/models/detectors/single_stage.py:69-82: simple_test on one frame -> (bbox_results, segm_results) keyed
+    by object id; the whole frame (backbone ... mask assembly, embedding gather) is one static launch plan."""
+
+    def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False):
+        from .engine import SipMaskEngine
+        key = (batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
+               rescale)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = SipMaskEngine(self.state_dict(), batch, img_hw, self.backbone.depth, self.test_cfg,
+                                self.bbox_head.num_classes, strides=self.bbox_head.strides, img_shape=img_shape,
+                                scale_factor=scale_factor, rescale=rescale, vis=True)
+            self._engines = {key: eng}
+        return eng
+
+    def simple_test(self, img, img_meta, rescale=False):
+        assert img.shape[0] == 1, "only support one image at a time (V/...:621)"
+        meta = img_meta[0]
+        eng = self.prepare(1, tuple(img.shape[-2:]), tuple(meta['img_shape']), meta.get('scale_factor', 1.0),
+                           bool(rescale))
+        r = eng.run(img)
+        n = int(r["ndet"][0])
+        if n == 0:
+            return dict(), [[] for _ in range(self.bbox_head.num_classes - 1)]
+        det, labels = r["det_bboxes"][0, :n], r["det_labels"][0, :n]
+        ids = self.bbox_head.match(det, labels, r["det_feats"][0, :n], meta['is_first'])
+        rle = eng.encode_rle(tuple(meta['ori_shape'])[:2])[0]
+        d, l = det.cpu().numpy(), labels.cpu().numpy()
+        bbox_results, segm_results = {}, {}                       # bbox2result_with_id, V/...transforms.py:182-202
+        for i in range(n):
+            if ids[i] >= 0:
+                bbox_results[int(ids[i])] = {'bbox': d[i], 'label': l[i]}
+                segm_results[int(ids[i])] = rle[i]
+        return bbox_results, segm_results

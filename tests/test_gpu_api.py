@@ -324,7 +324,8 @@ def test_head_loss_vs_oracle(det):
                              [b.cuda() for b in gtb], [l.cuda() for l in gtl], metas, None, gt_masks_list=gtm)
     assert set(out) == {"loss_cls", "loss_bbox", "loss_centerness", "loss_mask"}
     for k in out:
-        assert abs(float(out[k]) - float(ref[k])) <= 2e-4 * max(1.0, abs(float(ref[k]))), (k, float(out[k]), float(ref[k]))
+        a, b = float(out[k].detach()), float(ref[k].detach())
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (k, a, b)
     sum(out.values()).backward()
     flat = lambda L: [t for ts in L[:4] for t in ts] + [L[4]]
     for a, b in zip(flat(leaves_d), flat(leaves_r)):

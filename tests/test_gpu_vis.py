@@ -1,0 +1,165 @@
+"""GPU tests of the SipMask-VIS path: tracking kernels, the track branch of the head, fast_nms
+post-processing with the VIS conventions and the frame-to-frame identity assignment, against oracle/vis.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model as OM  # noqa: E402
+from oracle import ops as O  # noqa: E402
+from oracle import vis as OV  # noqa: E402
+
+VIS_TEST_CFG = dict(nms_pre=200, min_bbox_size=0, score_thr=0.03, nms=dict(type='nms', iou_thr=0.5), max_per_img=10)
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def vdet():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd import vis_head  # noqa: F401  (registers SipMaskVIS / SipMaskVISHead)
+    from sipmask_amd.registry import build_detector
+    from sipmask_amd.synthetic import model_cfg
+    cfg = model_cfg(50)
+    cfg['type'] = 'SipMaskVIS'
+    cfg['bbox_head'].update(type='SipMaskVISHead', num_classes=41, stacked_convs=3)
+    d = build_detector(cfg, train_cfg=None, test_cfg=dict(VIS_TEST_CFG))
+    sd = OV.init_vis_state_dict(seed=5)
+    sd["bbox_head.fcos_cls.bias"].fill_(-4.0)
+    d.load_state_dict(sd, strict=True)
+    return d
+
+
+def test_track_kernels_vs_oracle():
+    from sipmask_amd import hip_ops as H
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(8)
+    B, n, h, w, C, T = 2, 7, 12, 20, 512, 13
+    tf = torch.randn(B, C, h, w, generator=g)
+    xy = torch.rand(B, n, 2, generator=g) * torch.tensor([w * 8 * 0.7, h * 8 * 0.7])
+    det = torch.cat([xy, xy + torch.rand(B, n, 2, generator=g) * 40 + 2, torch.rand(B, n, 1, generator=g) * 0.9 + 0.05], 2)
+    det[0, 0, :4] = torch.tensor([0.0, 0.0, w * 8 - 1.0, h * 8 - 1.0])
+    det[0, 1, :4] = torch.tensor([w * 8 - 9.0, h * 8 - 9.0, w * 8 - 1.0, h * 8 - 1.0])      # last cell
+    ndet = torch.tensor([n, n - 3], dtype=torch.int32)
+    rows = tf.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(dev)
+    for mul in (1.0, 0.75):
+        out = torch.full((B, n, C), 7.0, device=dev)
+        H.track_gather(rows, det.to(dev), ndet.to(dev), h, w, mul, out)
+        for b in range(B):
+            ref = OV.extract_box_feature_center(tf[b], det[b, :ndet[b], :4] * mul)
+            np.testing.assert_array_equal(out[b, :ndet[b]].cpu().numpy(), ref.numpy())
+            assert float(out[b, ndet[b]:].abs().max() if ndet[b] < n else 0.0) == 0.0
+    # matching scores
+    df = torch.randn(n, C, generator=g) * 0.2
+    pf = torch.randn(T, C, generator=g) * 0.2
+    pf[3] = df[2] * 1.5                     # a clear match
+    pb = torch.cat([torch.rand(T, 2, generator=g) * 100, torch.rand(T, 2, generator=g) * 100 + 100,
+                    torch.rand(T, 1, generator=g)], 1)
+    pb[3, :4] = det[0, 2, :4]
+    dl = torch.randint(0, 40, (n,), generator=g)
+    pl = torch.randint(0, 40, (T,), generator=g)
+    pl[3] = dl[2]
+    ref = OV.comp_scores(df, pf, det[0], dl, pb, pl)
+    comp, mid, msc = H.track_match(df.to(dev), pf.to(dev), det[0].contiguous().to(dev), dl.to(dev), pb.to(dev), pl.to(dev),
+                                   OV.MATCH_COEFF)
+    torch.testing.assert_close(comp.cpu(), ref, rtol=1e-5, atol=1e-4)
+    np.testing.assert_array_equal(mid.cpu().numpy(), ref.max(1)[1].numpy().astype(np.int32))
+    torch.testing.assert_close(msc.cpu(), ref.max(1)[0], rtol=1e-5, atol=1e-4)
+    assert int(mid[2]) == 4
+
+
+def test_vis_head_forward_track_branch(vdet):
+    g = torch.Generator().manual_seed(2)
+    sizes = [(24, 40), (12, 20), (6, 10), (3, 5), (2, 3)]
+    feats = [torch.randn(1, 256, h, w, generator=g).to(torch.bfloat16).float() for h, w in sizes]
+    sd = {"bbox_head." + k: v.detach().cpu() for k, v in vdet.bbox_head.state_dict().items()}
+    assert OM.tower_depths(sd) == (2, 3, True)
+    ref = OM.head_forward(sd, feats)
+    tref = OV.track_forward(sd, feats)
+    out = vdet.bbox_head([f.cuda() for f in feats], None, False)
+    assert len(out) == 7 and tuple(out[5].shape) == (1, 512, 24, 40)
+    assert _rel(out[5], tref) < 0.03, _rel(out[5], tref)
+    for got_l, ref_l, b0 in zip(out[:4], ref[:4], (-4.0, 0.0, 0.0, 0.0)):
+        for l in range(5):
+            assert _rel(got_l[l] - b0, ref_l[l] - b0) < 0.08
+    assert _rel(out[4], ref[4]) < 0.05
+
+
+def test_vis_get_bboxes_sequence_vs_oracle(vdet):
+    """Three frames through SipMaskVISHead.get_bboxes on caller tensors (identical f32 inputs both sides):
+    boxes/labels/masks of every frame and the object ids of the whole sequence equal the oracle's."""
+    head = vdet.bbox_head
+    head.reset_tracker()
+    tracker = OV.Tracker()
+    g = torch.Generator().manual_seed(31)
+    C = 40
+    sizes = [(24, 40), (12, 20), (6, 10), (3, 5), (2, 3)]
+    strides = (8, 16, 32, 64, 128)
+    base_cls = [torch.randn(1, C, h, w, generator=g) * 2 - 3.0 for h, w in sizes]
+    base_bb = [(torch.randn(1, 4, h, w, generator=g) * 1.5 + 3) * s for (h, w), s in zip(sizes, strides)]
+    base_ctr = [torch.randn(1, 1, h, w, generator=g) + 1 for h, w in sizes]
+    base_cof = [torch.randn(1, 128, h, w, generator=g) * 0.3 for h, w in sizes]
+    fm = torch.randn(1, 32, 96, 160, generator=g)
+    tf = torch.randn(1, 512, 24, 40, generator=g) * 0.15
+    cfg = dict(VIS_TEST_CFG)
+    sf = 0.75
+    seen_ids = []
+    for frame in range(3):
+        noise = lambda ts, sc: [t + torch.randn(t.shape, generator=g) * sc for t in ts]
+        cls, bb, ctr, cof = noise(base_cls, 0.05), noise(base_bb, 0.3), noise(base_ctr, 0.02), noise(base_cof, 0.01)
+        tfn = tf + torch.randn(tf.shape, generator=g) * 0.01
+        meta = [dict(img_shape=(192, 320, 3), ori_shape=(256, 427, 3), scale_factor=sf, is_first=(frame == 0))]
+        res = head.get_bboxes([t.cuda() for t in cls], [t.cuda() for t in bb], [t.cuda() for t in ctr],
+                              [t.cuda() for t in cof], fm.cuda(), tfn.cuda(), tfn.cuda(), meta, cfg, rescale=True)
+        det, labels, obj_segms, ids = res[0]
+        r = OV.get_masks_single_vis([c[0] for c in cls], [x[0] for x in bb], [c[0] for c in ctr], [c[0] for c in cof],
+                                    fm[0], (192, 320, 3), cfg, sf, True)
+        np.testing.assert_array_equal(labels.cpu().numpy(), r["det_labels"])
+        np.testing.assert_allclose(det.cpu().numpy(), r["det_bboxes"], rtol=1e-6, atol=1e-6)
+        feats = OV.extract_box_feature_center(tfn[0], torch.from_numpy(r["det_bboxes"][:, :4]) * sf)
+        rid = tracker.step(r["det_bboxes"], r["det_labels"], feats, frame == 0)
+        np.testing.assert_array_equal(np.asarray(ids), rid)
+        seen_ids.append(set(int(i) for i in ids if i >= 0))
+        # RLE of the kept objects decode to the oracle's masks (pasted on the original-size canvas)
+        order = {int(ids[i]): i for i in range(len(ids)) if ids[i] >= 0}
+        for oid, i in order.items():
+            dec = O.rle_decode(O.rle_from_string(obj_segms[oid]["counts"]), 256, 427)
+            m = r["masks"][i].numpy()
+            hh, ww = min(256, m.shape[0]), min(427, m.shape[1])
+            diff = dec[:hh, :ww] != m[:hh, :ww]
+            assert int(diff.sum()) <= 3 and bool(((r["up"][i][:hh, :ww] - 0.5).abs()[torch.from_numpy(diff)] < 1e-4).all())
+    assert len(seen_ids[0]) >= 3 and len(seen_ids[0] & seen_ids[1] & seen_ids[2]) >= 2     # identities persist
+
+
+def test_vis_detector_sequence(vdet):
+    """SipMaskVIS.simple_test over a 3-frame clip: ids from the engine's own detections/embeddings equal the oracle
+    tracker run on the same tensors; results are keyed by object id with RLE masks."""
+    vdet.bbox_head.reset_tracker()
+    tracker = OV.Tracker()
+    g = torch.Generator().manual_seed(4)
+    img0 = torch.randn(1, 3, 192, 320, generator=g)
+    kept = []
+    for frame in range(3):
+        img = (img0 + torch.randn(img0.shape, generator=g) * 0.02).cuda()
+        meta = [dict(img_shape=(192, 320, 3), ori_shape=(192, 320, 3), pad_shape=(192, 320, 3), scale_factor=1.0,
+                     is_first=(frame == 0))]
+        bbox_results, segm_results = vdet.simple_test(img, meta, rescale=True)
+        eng = vdet.prepare(1, (192, 320), (192, 320, 3), 1.0, True)
+        assert eng.vis and eng.track_feats is not None and eng.mask_thr == 0.5
+        n = int(eng.nms_out["ndet"][0])
+        assert 0 < n <= 10
+        det = eng.nms_out["det"][0, :n].cpu()
+        lab = eng.nms_out["labels"][0, :n].cpu()
+        rid = tracker.step(det.numpy(), lab.numpy(), eng.det_feats[0, :n].cpu(), frame == 0)
+        assert set(bbox_results) == set(int(i) for i in rid if i >= 0) == set(segm_results)
+        for i, oid in enumerate(rid):
+            if oid >= 0 and list(rid).count(oid) == 1:
+                np.testing.assert_array_equal(bbox_results[int(oid)]['bbox'], det[i].numpy())
+                assert segm_results[int(oid)]["size"] == [192, 320]
+        kept.append(set(bbox_results))
+    assert len(kept[0] & kept[2]) >= 1
