@@ -79,8 +79,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // LDS-DMA loader (an LDS-DMA load cannot be masked, but it can be pointed at zeros)
 __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
-template <int WCO, int WPOS, int TCO, int TPOS, bool DEFORM, bool DMA>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
+// PROD = 1: warp-specialised variant of the LDS-DMA kernel -- 8 waves, waves 0-3 only issue MFMAs + fragment
+// reads (consumers), waves 4-7 only issue the LDS-DMA loads (producers), so a wave never stalls its MFMA stream
+// on the DMA issue port (the two phases of the 4-wave kernel barely overlap: DESIGN.md section 6).
+template <int WCO, int WPOS, int TCO, int TPOS, bool DEFORM, bool DMA, int PROD = 0>
+__global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const ConvKArgs a) {
+  static_assert(!PROD || (DMA && !DEFORM), "producer/consumer split exists for the LDS-DMA path only");
+  constexpr int THREADS = 256 * (1 + PROD);
   constexpr int BCO = WCO * TCO * 32;
   constexpr int BPOS = WPOS * TPOS * 32;
   constexpr int NW = BCO / 32;   // 16-byte weight chunks per thread per K step
@@ -95,7 +100,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   static_assert(WCO * WPOS == 4, "4 waves");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
-  const int tid = threadIdx.x;
+  const int gtid = threadIdx.x;                       // 0..THREADS-1 (epilogue work split)
+  const bool is_prod = PROD && gtid >= 256;           // wave-uniform role
+  const bool is_cons = !PROD || gtid < 256;
+  const int tid = gtid & 255;                          // index inside the role group: loader row/chunk, MFMA wave
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wco = wave / WPOS;
@@ -414,13 +422,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
       });
       advance_k();
     };
-    dma_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) dma_tile(buf ^ 1);
-      compute(buf);
+    if constexpr (PROD) {
+      if (is_prod) dma_tile(0);
       __syncthreads();
+      for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (is_prod) {
+          if (kt + 1 < nk) dma_tile(buf ^ 1);
+        } else {
+          compute(buf);
+        }
+        __syncthreads();
+      }
+    } else {
+      dma_tile(0);
+      __syncthreads();
+      for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) dma_tile(buf ^ 1);
+        compute(buf);
+        __syncthreads();
+      }
     }
   } else {
   load_w(0, wregA);
@@ -496,7 +518,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   const bool out_f32 = a.flags & SM_CONV_OUT_F32;
   float* E = reinterpret_cast<float*>(smem);
   float* gn_bins = reinterpret_cast<float*>(smem + SMEM_MAIN);   // [GN_SEG][BCO/8][2]
-  if (a.gn_stats != nullptr && tid < GN_SEG * (BCO / 8) * 2) gn_bins[tid] = 0.f;
+  if (a.gn_stats != nullptr && gtid < GN_SEG * (BCO / 8) * 2) gn_bins[gtid] = 0.f;
+  if (is_cons) {
 #pragma unroll
   for (int tc = 0; tc < TCO; ++tc) {
 #pragma unroll
@@ -522,10 +545,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
       }
     }
   }
+  }  // is_cons
   __syncthreads();
   constexpr int CPR = BCO / 8;          // 8-cout chunks per tile row
-  constexpr int RPP = 256 / CPR;        // rows per pass
-  const int ec = tid % CPR, er = tid / CPR;
+  constexpr int RPP = THREADS / CPR;    // rows per pass (all waves of the block store)
+  const int ec = gtid % CPR, er = gtid / CPR;
   const int c0 = nt * BCO + ec * 8;
   const bool has_res = a.flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST);
   const bool vec_ok = (c0 + 7 < a.cout) && ((a.out_cstride & 7) == 0) && ((a.out_coff & 7) == 0) &&
@@ -628,9 +652,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   if (gn) {
     gn_flush();
     __syncthreads();
-    if (tid < GN_SEG * (BCO / 8) * 2) {
-      const float v = gn_bins[tid];
-      const int seg = tid / ((BCO / 8) * 2), rem = tid - seg * ((BCO / 8) * 2);
+    if (gtid < GN_SEG * (BCO / 8) * 2) {
+      const float v = gn_bins[gtid];
+      const int seg = gtid / ((BCO / 8) * 2), rem = gtid - seg * ((BCO / 8) * 2);
       const int g = (nt * BCO >> 3) + (rem >> 1);
       if (v != 0.f && g < gn_groups && gn_n0 + seg < a.batch)
         atomicAdd(a.gn_stats + (((long long)(gn_n0 + seg) * a.nlev + lev) * gn_groups + g) * 2 + (rem & 1), v);
@@ -1042,8 +1066,14 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else if (bco == 64 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 1, 1>));
     else if (bco == 32 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 2>));
     else SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 1>));
-  } else {
-    if (bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true>));
+  } else if constexpr (!DEFORM) {
+    const bool ws = (d->flags & SM_CONV_DBG_WARP_SPEC) != 0;
+    if (ws) block = dim3(512);
+    if (ws && bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 1>));
+    else if (ws && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 1>));
+    else if (ws && bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true, 1>));
+    else if (ws) return SM_ERR_UNSUPPORTED;
+    else if (bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true>));
     else if (bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true>));
     else if (bco == 64 && bpos == 256) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 2, false, true>));
     else if (bco == 64 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 1, false, true>));
