@@ -243,6 +243,12 @@ int sm_mask_assemble(const float* basis, int basis_hwc, const float* cofs, const
                      double up_scale_h, double up_scale_w, float mask_thr, uint8_t* masks, float* pos_masks,
                      sm_stream_t stream);
 
+/* SipMask++ rescoring tail (sipmask_head.py:638-641): mask_scores[b][i] = max over the hw positions of
+ * feat[(b*max_num+i)*hw + p][labels[b][i]] (feat = relu(mask_scoring(convs_scoring(pos_masks))), f32 NHWC rows)
+ * times det[b][i][4]; 0 for i >= ndet[b]. */
+int sm_mask_rescore(const float* feat, const int64_t* labels, const float* det, const int32_t* ndet, int batch,
+                    int max_num, int hw, int channels, float* mask_scores, sm_stream_t stream);
+
 /* ---- training-side ops ---------------------------------------------------------------- */
 
 /* crop_split_cuda_forward/backward, M/mmdet/ops/crop/src/crop_split_cuda.cpp:14-36:

@@ -38,7 +38,8 @@ def _xavier_uniform(w, g):   # mmcv xavier_init(distribution='uniform'), fpn.py:
     return w.uniform_(-a, a, generator=g)
 
 
-def init_state_dict(depth=50, seed=0, calibrate=True, num_classes=81, stacked_convs=4, norm=True):
+def init_state_dict(depth=50, seed=0, calibrate=True, num_classes=81, stacked_convs=4, norm=True,
+                    stage_with_dcn=(False, False, False, False), rescoring=False):
     """Build a float32 state_dict with the reference's parameter names/shapes
      and init rules (resnet.py:479-497, fpn.py:131-135,
     sipmask_head.py:226-239), then apply the calibration overrides.
@@ -77,6 +78,12 @@ def init_state_dict(depth=50, seed=0, calibrate=True, num_classes=81, stacked_co
             conv(p + ".conv1", planes, inplanes, 1)
             bn(p + ".bn1", planes)
             conv(p + ".conv2", planes, planes, 3)
+            if stage_with_dcn[li] and bi % 3 == 0:      # SipMask++: DCN in block 0 and every 3rd (resnet.py:270-291)
+                # conv_offset is zero-initialised (deform_conv.py:289-291); the calibration gives it small
+                # non-zero values so the sampling really moves
+                conv(p + ".conv2.conv_offset", 18, planes, 3, bias=True, init="normal", std=0.02 if calibrate else 0.0)
+                if not calibrate:
+                    sd[p + ".conv2.conv_offset.weight"].zero_()
             bn(p + ".bn2", planes)
             conv(p + ".conv3", planes * 4, planes, 1)
             # zero_init_residual sets bn3.weight = 0 (resnet.py:492-495); the
@@ -117,6 +124,13 @@ def init_state_dict(depth=50, seed=0, calibrate=True, num_classes=81, stacked_co
     conv(h + "sip_cof", 128, 256, 3, bias=True, init="normal", std=0.05 if calibrate else 0.001)
     conv(h + "sip_mask_lat", 32, 512, 3, bias=True, init="normal", std=0.01)
     conv(h + "sip_mask_lat0", 512, 768, 1, bias=True, init="normal", std=0.01)
+    if rescoring:                                   # SipMask++ mask scoring branch, sipmask_head.py:200-219
+        chans = [1, 16, 16, 16, 32, 64, 128]
+        for i in range(6):
+            conv(h + "convs_scoring.%d.conv" % i, chans[i + 1], chans[i], 3, bias=True, init="kaiming")
+        conv(h + "mask_scoring", num_classes - 1, 128, 1, bias=True, init="normal", std=0.001 if not calibrate else 0.05)
+        if calibrate:
+            sd[h + "mask_scoring.bias"].normal_(0.3, 0.1, generator=g)
     if calibrate:
         # random-normal tower weights at std 0.01 shrink the signal by ~0.5x per
         # layer; give the synthetic net O(1) activations so boxes/masks are non-trivial
@@ -174,7 +188,13 @@ def backbone_forward(sd, x, depth=50, prefix="backbone."):
             stride = 2 if (bi == 0 and li > 0) else 1
             idt = x
             o = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], None, stride), sd, p + ".bn1"))
-            o = F.relu(_bn(F.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1), sd, p + ".bn2"))
+            if (p + ".conv2.conv_offset.weight") in sd:     # DeformConvPack, M/mmdet/ops/dcn/deform_conv.py:293-296
+                w_off = sd[p + ".conv2.conv_offset.weight"]
+                off = F.conv2d(o, w_off, sd[p + ".conv2.conv_offset.bias"], 1, 1)
+                o = ops.deform_conv(o, off, sd[p + ".conv2.weight"], 1, 1, 1, w_off.shape[0] // 18)
+            else:
+                o = F.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1)
+            o = F.relu(_bn(o, sd, p + ".bn2"))
             o = _bn(F.conv2d(o, sd[p + ".conv3.weight"]), sd, p + ".bn3")
             if bi == 0:
                 idt = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride), sd, p + ".downsample.1")
@@ -318,6 +338,20 @@ def get_masks_single(cls_scores, bbox_preds, ctrs, cofs, feat_mask, img_shape, c
         out.update(ops.mask_assemble(feat_mask, det_cofs, det, scale_factor, rescale, ssd_flag=ssd_flag))
         out["det_cofs"] = det_cofs
     return out
+
+
+def mask_rescoring(sd, pos_masks, det_labels, det_scores, prefix="bbox_head."):
+    """SipMask++ rescoring, sipmask_head.py:635-641: six ConvModule(3x3, stride 2, no padding, bias, ReLU) on each
+    cropped probability mask, 1x1 mask_scoring + ReLU, global max pool, the detection's class channel, times the
+    box score.  pos_masks [N,Hm,Wm] (CropSplit output), det_labels [N] long, det_scores [N] -> [N]."""
+    h = prefix
+    x = torch.as_tensor(pos_masks, dtype=torch.float32).unsqueeze(1)
+    for i in range(6):
+        x = F.relu(F.conv2d(x, sd[h + "convs_scoring.%d.conv.weight" % i], sd[h + "convs_scoring.%d.conv.bias" % i], 2, 0))
+    x = F.relu(F.conv2d(x, sd[h + "mask_scoring.weight"], sd[h + "mask_scoring.bias"]))
+    x = F.max_pool2d(x, kernel_size=x.shape[2:]).squeeze(-1).squeeze(-1)
+    lab = torch.as_tensor(det_labels, dtype=torch.long)
+    return x[torch.arange(x.shape[0]), lab] * torch.as_tensor(det_scores, dtype=torch.float32)
 
 
 def detector_forward(sd, img, depth=50):

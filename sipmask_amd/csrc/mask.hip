@@ -188,7 +188,36 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
   }
 }
 
+// SipMask++ mask rescoring tail (sipmask_head.py:638-641): global max-pool of relu(mask_scoring(...)) over the
+// last feature map, the detection's own class channel, times the box score.  One wave per detection.
+__global__ __launch_bounds__(64) void mask_rescore_kernel(const float* __restrict__ feat, const int64_t* __restrict__ labels,
+                                                          const float* __restrict__ det, const int32_t* __restrict__ ndet,
+                                                          int max_num, int hw, int C, float* __restrict__ out) {
+  const int i = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const long long n = (long long)b * max_num + i;
+  if (i >= ndet[b]) {
+    if (lane == 0) out[n] = 0.f;
+    return;
+  }
+  const int c = (int)labels[n];
+  float m = -INFINITY;
+  for (int p = lane; p < hw; p += 64) m = fmaxf(m, feat[(n * hw + p) * C + c]);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if (lane == 0) out[n] = __fmul_rn(m, det[n * 5 + 4]);
+}
+
 }  // namespace
+
+extern "C" int sm_mask_rescore(const float* feat, const int64_t* labels, const float* det, const int32_t* ndet, int batch,
+                               int max_num, int hw, int channels, float* mask_scores, sm_stream_t stream) {
+  if (!feat || !labels || !det || !ndet || !mask_scores) return SM_ERR_BAD_ARG;
+  if (batch < 1 || max_num < 1 || hw < 1 || channels < 1) return SM_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(mask_rescore_kernel, dim3(max_num, batch), dim3(64), 0, sm_hip_stream(stream), feat, labels, det, ndet,
+                     max_num, hw, channels, mask_scores);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
 
 extern "C" int sm_mask_assemble(const float* basis, int basis_hwc, const float* cofs, const int64_t* keep,
                                 const float* det, const int32_t* ndet, int batch, int kmax, int max_num, int hm,

@@ -76,6 +76,9 @@ class SipMask(nn.Module):
         ncls = self.bbox_head.num_classes - 1
         bbox_results = [d[l == i, :] for i in range(ncls)]                       # bbox2result, transforms.py:181-199
         segm_results = [[rle[j] for j in range(n) if l[j] == i] for i in range(ncls)]
+        if "mask_scores" in r:                   # SipMask++: (cls_segms, mask_scores), sipmask_head.py:659-660
+            ms = r["mask_scores"][0, :n].cpu().numpy()
+            segm_results = (segm_results, [ms[l == i] for i in range(ncls)])
         return bbox_results, segm_results
 
     def forward_test(self, imgs, img_metas, **kwargs):

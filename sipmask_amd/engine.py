@@ -68,6 +68,44 @@ class _Conv:
             H.conv2d(self.desc, self.x, self.w, self.bias, self.residual, self.y)
 
 
+class MaskRescorer:
+    """SipMask++ mask-scoring branch (sipmask_head.py:200-219,635-641) as a launch list over the N = batch*max_num
+    cropped probability masks: f32 [N,Hm,Wm] -> bf16 NHWC (1 channel padded to 8) -> six 3x3 stride-2 convs (+bias,
+    ReLU) -> 1x1 mask_scoring (+ReLU, f32) -> global max over the last map at the detection's class x box score."""
+
+    def __init__(self, sd, prefix, batch, max_num, hm, wm, device):
+        self.device = torch.device(device)
+        n = batch * max_num
+        self.batch, self.max_num, self.hm, self.wm = batch, max_num, hm, wm
+        self.pos_masks = torch.zeros(batch, max_num, hm, wm, dtype=torch.float32, device=self.device)
+        self.x0 = torch.empty(n * hm * wm, 8, dtype=BF16, device=self.device)
+        self.convs = []
+        x, h, w, c = self.x0, hm, wm, 8
+        for i in range(6):
+            wgt, b = sd[prefix + "convs_scoring.%d.conv.weight" % i], sd[prefix + "convs_scoring.%d.conv.bias" % i]
+            oh, ow = _conv_out(h, 3, 2, 0), _conv_out(w, 3, 2, 0)
+            if min(oh, ow) < 1:
+                raise ValueError("mask grid %dx%d is too small for the six stride-2 scoring convs" % (hm, wm))
+            co = wgt.shape[0]
+            y = torch.empty(n * oh * ow, co, dtype=BF16, device=self.device)
+            self.convs.append(_Conv(self, "rescore.convs_scoring.%d" % i, wgt, b, n, [(h, w)], [0], x, c, 2, 0, y, [0], co,
+                                    flags=SM_CONV_RELU, cin_pad=8 if i == 0 else None))
+            x, h, w, c = y, oh, ow, co
+        wgt, b = sd[prefix + "mask_scoring.weight"], sd[prefix + "mask_scoring.bias"]
+        self.hw, self.ncls = h * w, wgt.shape[0]
+        self.feat = torch.empty(n * h * w, self.ncls, dtype=torch.float32, device=self.device)
+        self.convs.append(_Conv(self, "rescore.mask_scoring", wgt, b, n, [(h, w)], [0], x, c, 1, 0, self.feat, [0],
+                                self.ncls, flags=SM_CONV_RELU | SM_CONV_OUT_F32))
+        self.scores = torch.zeros(batch, max_num, dtype=torch.float32, device=self.device)
+
+    def run(self, labels, det, ndet):
+        n = self.batch * self.max_num
+        H.nchw_to_nhwc_bf16(self.pos_masks.view(n, 1, self.hm, self.wm), self.x0, 8)
+        for c in self.convs:
+            c()
+        return H.mask_rescore(self.feat, labels, det, ndet, self.hw, self.scores)
+
+
 class SipMaskEngine:
     """Static launch plan for SipMask-R50/R101 inference at a fixed (batch, H, W)."""
 
@@ -125,7 +163,7 @@ class SipMaskEngine:
 
     def run_head(self, with_post=False):
         for label, fn in self.steps[self.head_start:]:
-            if not with_post and label in ("det_select", "nms", "mask_assemble", "track_gather"):
+            if not with_post and label in ("det_select", "nms", "mask_assemble", "track_gather", "rescore"):
                 continue
             fn()
 
@@ -171,8 +209,19 @@ class SipMaskEngine:
                                      flags=SM_CONV_RELU))
                 wb, bb = fold_bn(sd[p + ".conv2.weight"], sd, p + ".bn2")
                 t2 = self._buf(B * oh * ow, planes)
-                self._add_conv(_Conv(self, p + ".conv2", wb, bb, B, [(oh, ow)], [0], t1, planes, 1, 1, t2, [0], planes,
-                                     flags=SM_CONV_RELU))
+                if (p + ".conv2.conv_offset.weight") in sd:
+                    # SipMask++ backbone DCN (DeformConvPack, deform_conv.py:258-296): offsets from an ordinary
+                    # 3x3 conv (f32), then the deformable conv with bn2 folded in (it is linear in the weight)
+                    w_off, b_off = sd[p + ".conv2.conv_offset.weight"], sd[p + ".conv2.conv_offset.bias"]
+                    dg = w_off.shape[0] // 18
+                    off = self._buf(B * oh * ow, 18 * dg, torch.float32)
+                    self._add_conv(_Conv(self, p + ".conv2.conv_offset", w_off, b_off, B, [(oh, ow)], [0], t1, planes, 1,
+                                         1, off, [0], 18 * dg, flags=SM_CONV_OUT_F32))
+                    self._add_conv(_Conv(self, p + ".conv2", wb, bb, B, [(oh, ow)], [0], t1, planes, 1, 1, t2, [0],
+                                         planes, flags=SM_CONV_RELU, deform_groups=dg, offset=off))
+                else:
+                    self._add_conv(_Conv(self, p + ".conv2", wb, bb, B, [(oh, ow)], [0], t1, planes, 1, 1, t2, [0],
+                                         planes, flags=SM_CONV_RELU))
                 if bi == 0:
                     wd, bd = fold_bn(sd[p + ".downsample.0.weight"], sd, p + ".downsample.1")
                     idt = self._buf(B * oh * ow, planes * 4)
@@ -234,6 +283,7 @@ class SipMaskEngine:
     def _build_head(self, sd, prefix="bbox_head."):
         """SipMaskHead.forward, sipmask_head.py:241-287, on the pyramid tensor self.pyr."""
         B, lv, dev, h = self.batch, self.lv, self.device, prefix
+        self._sd, self._sd_keys = sd, set(sd.keys())
         sizes, row0 = lv.sizes, lv.row0
         self.gn_stats = torch.zeros(B * len(lv) * 32 * 2, dtype=torch.float32, device=dev)
 
@@ -361,9 +411,16 @@ class SipMaskEngine:
             self._add("nms", lambda: H.multiclass_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"],
                                                       self.sel["ncand"], cfg["score_thr"], cfg["nms"]["iou_thr"],
                                                       self.max_num, self.nms_out))
+        self.rescorer = None
+        if ("bbox_head.convs_scoring.0.conv.weight") in self._sd_keys:
+            self.rescorer = MaskRescorer(self._sd, "bbox_head.", B, self.max_num, self.hm, self.wm, self.device)
+        pos = None if self.rescorer is None else self.rescorer.pos_masks
         self._add("mask_assemble", lambda: H.mask_assemble(
             self.basis, True, self.sel["cofs"], self.nms_out["keep"], self.nms_out["det"], self.nms_out["ndet"],
-            self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, self.masks))
+            self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, self.masks, pos))
+        if self.rescorer is not None:
+            self._add("rescore", lambda: self.rescorer.run(self.nms_out["labels"], self.nms_out["det"],
+                                                           self.nms_out["ndet"]))
         if self.track_feats is not None:
             # det_roi_feats (V/...:612-616): embeddings at the box centres, boxes back in network coordinates
             import numpy as np
@@ -388,6 +445,8 @@ class SipMaskEngine:
                  masks=self.masks[..., :self.wo])
         if self.track_feats is not None:
             r["det_feats"] = self.det_feats
+        if self.rescorer is not None:
+            r["mask_scores"] = self.rescorer.scores
         return r
 
     def encode_rle(self, canvas_hw=None, fetch=True, max_runs=8192):
@@ -437,7 +496,7 @@ class PostProcessor:
     parity tests: identical f32 inputs on both sides).  sipmask_head.py:500-633."""
 
     def __init__(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg, strides,
-                 rescale=None, ssd_flag=False, vis=False):
+                 rescale=None, ssd_flag=False, vis=False, rescore_sd=None):
         _lib.load()
         dev = cls_scores[0].device
         _lib.require_cuda(cls_scores[0], feat_masks)
@@ -471,6 +530,8 @@ class PostProcessor:
         self.sel = H.det_select_alloc(self.desc, dev)
         self.max_num = 100 if (self.ssd_flag and not self.vis) else cfg['max_per_img']
         self.out = H.multiclass_nms_alloc(B, self.desc.kmax, C, self.max_num, dev)
+        # SipMask++: rescore_sd = the head's state_dict (keys convs_scoring.*, mask_scoring.*)
+        self.rescorer = None if rescore_sd is None else MaskRescorer(rescore_sd, "", B, self.max_num, self.hm, self.wm, dev)
 
     def run(self, want_pos_masks=False):
         cfg = self.cfg
@@ -482,12 +543,19 @@ class PostProcessor:
             H.multiclass_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"], self.sel["ncand"],
                              cfg['score_thr'], cfg['nms']['iou_thr'], self.max_num, self.out)
         masks = torch.zeros(self.B, self.max_num, self.ho, self.pitch, dtype=torch.uint8, device=self.dev)
-        self.pos_masks = (torch.zeros(self.B, self.max_num, self.hm, self.wm, device=self.dev)
-                          if want_pos_masks else None)
+        if self.rescorer is not None:
+            self.pos_masks = self.rescorer.pos_masks
+            self.pos_masks.zero_()
+        else:
+            self.pos_masks = (torch.zeros(self.B, self.max_num, self.hm, self.wm, device=self.dev)
+                              if want_pos_masks else None)
         H.mask_assemble(self.basis, False, self.sel["cofs"], self.out["keep"], self.out["det"], self.out["ndet"],
                         self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, masks,
                         self.pos_masks)
         self.masks = masks
+        self.mask_scores = None
+        if self.rescorer is not None:
+            self.mask_scores = self.rescorer.run(self.out["labels"], self.out["det"], self.out["ndet"])
         nd = self.out["ndet"].cpu().tolist()
         res = []
         for b in range(self.B):

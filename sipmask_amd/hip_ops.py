@@ -383,3 +383,12 @@ def track_match(det_feats, prev_feats, det, det_labels, prev_boxes, prev_labels,
                                   float(coeff[1]), float(coeff[2]), _lib.ptr(comp), _lib.ptr(mid), _lib.ptr(msc),
                                   _lib.stream_ptr()), "sm_track_match")
     return comp, mid, msc
+
+
+def mask_rescore(feat, labels, det, ndet, hw, out):
+    """feat f32 [B*max_num*hw, C]; labels [B, max_num]; det [B, max_num, 5]; out f32 [B, max_num]."""
+    lib = _lib.load()
+    b, n = det.shape[0], det.shape[1]
+    _lib.check(lib.sm_mask_rescore(_lib.ptr(feat), _lib.ptr(labels), _lib.ptr(det), _lib.ptr(ndet), b, n, int(hw),
+                                   feat.shape[-1], _lib.ptr(out), _lib.stream_ptr()), "sm_mask_rescore")
+    return out

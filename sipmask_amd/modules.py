@@ -85,16 +85,38 @@ class ConvModule(nn.Module):
         return getattr(self, self.norm_name)
 
 
+class DeformConvPack(nn.Module):
+    """Parameter container of M/mmdet/ops/dcn/deform_conv.py:258-296 (conv type 'DCN'): ``weight`` of the
+    deformable conv and the ordinary ``conv_offset`` conv (zero-initialised, :289-291) that predicts its offsets."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, deformable_groups=1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.deformable_groups = in_channels, out_channels, deformable_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        self.conv_offset = nn.Conv2d(in_channels, deformable_groups * 2 * kernel_size * kernel_size, kernel_size,
+                                     stride=stride, padding=padding, bias=True)
+        nn.init.zeros_(self.conv_offset.weight)
+        nn.init.zeros_(self.conv_offset.bias)
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None, style="pytorch", norm_cfg=dict(type="BN")):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, style="pytorch", norm_cfg=dict(type="BN"),
+                 dcn=None):
         super().__init__()
         assert style in ("pytorch", "caffe")
         self.conv1_stride, self.conv2_stride = (1, stride) if style == "pytorch" else (stride, 1)
         self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=self.conv1_stride, bias=False)
         self.add_module("bn1", _norm_layer(norm_cfg, planes)[1])
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=self.conv2_stride, padding=1, bias=False)
+        self.with_dcn = dcn is not None
+        if self.with_dcn:                                     # resnet.py:145-168
+            if dcn.get('type', 'DCN') != 'DCN' or dcn.get('fallback_on_stride', False):
+                raise NotImplementedError("only conv type 'DCN' (deformable conv v1) is on the SipMask++ path")
+            self.conv2 = DeformConvPack(planes, planes, 3, self.conv2_stride, 1, dcn.get('deformable_groups', 1))
+        else:
+            self.conv2 = nn.Conv2d(planes, planes, 3, stride=self.conv2_stride, padding=1, bias=False)
         self.add_module("bn2", _norm_layer(norm_cfg, planes)[1])
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
         self.add_module("bn3", _norm_layer(norm_cfg, planes * 4)[1])
@@ -112,8 +134,9 @@ class ResNet(nn.Module):
         super().__init__()
         if depth not in self.arch_settings:
             raise KeyError("invalid depth {} for resnet".format(depth))
-        if dcn is not None or conv_cfg is not None:
-            raise NotImplementedError("backbone DCN (SipMask++) is a 'next' row (SURVEY 8f-3)")
+        if conv_cfg is not None:
+            raise NotImplementedError("conv_cfg other than the default Conv is not on the SipMask path")
+        self.dcn, self.stage_with_dcn = dcn, tuple(stage_with_dcn)
         if style != "caffe" or tuple(strides) != (1, 2, 2, 2) or tuple(dilations) != (1, 1, 1, 1):
             raise NotImplementedError("the engine implements the caffe-style stride layout of the sipmask configs")
         self.depth, self.num_stages, self.out_indices = depth, num_stages, out_indices
@@ -132,7 +155,9 @@ class ResNet(nn.Module):
                 if j == 0 and (stride != 1 or inplanes != planes * 4):
                     ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
                                        _norm_layer(norm_cfg, planes * 4)[1])
-                blocks.append(Bottleneck(inplanes, planes, stride, ds, style, norm_cfg))
+                # SipMask++ edit of make_res_layer (resnet.py:270-291): DCN in block 0 and every 3rd block after it
+                bdcn = dcn if (dcn is not None and self.stage_with_dcn[i] and j % 3 == 0) else None
+                blocks.append(Bottleneck(inplanes, planes, stride, ds, style, norm_cfg, bdcn))
                 inplanes = planes * 4
             name = "layer{}".format(i + 1)
             self.add_module(name, nn.Sequential(*blocks))

@@ -44,8 +44,6 @@ class SipMaskHead(nn.Module):
                  loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
                  conv_cfg=None, norm_cfg=dict(type='GN', num_groups=32, requires_grad=True)):
         super().__init__()
-        if rescoring_flag:
-            raise NotImplementedError("rescoring_flag (SipMask++ mask-IoU branch) is a 'next' row (SURVEY 8f)")
         self.num_classes = num_classes
         self.cls_out_channels = num_classes - 1
         self.in_channels, self.feat_channels, self.stacked_convs = in_channels, feat_channels, stacked_convs
@@ -80,6 +78,12 @@ class SipMaskHead(nn.Module):
         self.sip_cof = nn.Conv2d(self.feat_channels, self.nc * 4, 3, padding=1)
         self.sip_mask_lat = nn.Conv2d(512, self.nc, 3, padding=1)
         self.sip_mask_lat0 = nn.Conv2d(768, 512, 1, padding=0)
+        if self.rescoring_flag:                                        # SipMask++ mask scoring branch (:200-219)
+            chans = [1, 16, 16, 16, 32, 64, 128]
+            self.convs_scoring = nn.Sequential(*[ConvModule(chans[i], chans[i + 1], 3, stride=2, padding=0, bias=True)
+                                                 for i in range(6)])
+            self.mask_scoring = nn.Conv2d(128, self.num_classes - 1, 1)
+            normal_init(self.mask_scoring, std=0.001)
         self.relu = nn.ReLU(inplace=True)
         self.crop_cuda = CropSplit(2)
         self.crop_gt_cuda = CropSplitGt(2)
@@ -125,8 +129,11 @@ class SipMaskHead(nn.Module):
         (det_bboxes [N,5], det_labels [N], idxs_keep [N], masks uint8 [N,Ho,Wo])."""
         from .engine import PostProcessor
         post = PostProcessor(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg,
-                             self.strides, rescale, self.ssd_flag)
-        return post.run()
+                             self.strides, rescale, self.ssd_flag, rescore_sd=self._rescore_sd())
+        res = post.run()
+        if self.rescoring_flag:      # 5th element: mask_scores [N] = predicted mask IoU x box score (:638-641)
+            res = [r + (post.mask_scores[b, :r[0].shape[0]],) for b, r in enumerate(res)]
+        return res
 
     def get_bboxes(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg, rescale=None):
         """Reference packaging (sipmask_head.py:645-662): list of (det_bboxes, det_labels, cls_segms) with
@@ -135,18 +142,30 @@ class SipMaskHead(nn.Module):
         `mask.cpu()` + `mask_util.encode` loop of the reference becomes two small D2H copies per batch."""
         from .engine import PostProcessor
         post = PostProcessor(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg,
-                             self.strides, rescale, self.ssd_flag)
+                             self.strides, rescale, self.ssd_flag, rescore_sd=self._rescore_sd())
         res = post.run()
         meta = img_metas[0]
         shp = meta['ori_shape'] if rescale else meta['img_shape']
         rles = post.encode_rle(shp[:2])
         out = []
-        for (det, labels, _, _), rle in zip(res, rles):
+        for b, ((det, labels, _, _), rle) in enumerate(zip(res, rles)):
             cls_segms = [[] for _ in range(self.num_classes - 1)]
-            for lab, r in zip(labels.cpu().tolist(), rle):
+            lab_h = labels.cpu().tolist()
+            for lab, r in zip(lab_h, rle):
                 cls_segms[lab].append(r)
-            out.append((det, labels, cls_segms))
+            if self.rescoring_flag:      # (cls_segms, mask_scores) bucketed by class, sipmask_head.py:641-643,659-660
+                ms = post.mask_scores[b, :det.shape[0]].cpu().numpy()
+                la = np.asarray(lab_h, dtype=np.int64)
+                out.append((det, labels, (cls_segms, [ms[la == i] for i in range(self.num_classes - 1)])))
+            else:
+                out.append((det, labels, cls_segms))
         return out
+
+    def _rescore_sd(self):
+        if not self.rescoring_flag:
+            return None
+        return {k: v.detach() for k, v in self.state_dict().items()
+                if k.startswith("convs_scoring.") or k.startswith("mask_scoring.")}
 
     def loss(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, gt_bboxes, gt_labels, img_metas, cfg,
              gt_bboxes_ignore=None, gt_masks_list=None):

@@ -332,3 +332,44 @@ def test_head_loss_vs_oracle(det):
         assert b.grad is not None and a.grad is not None
         scale = float(b.grad.abs().max()) + 1e-12
         assert float((a.grad.cpu() - b.grad).abs().max()) <= 2e-4 * scale + 1e-7, (tuple(a.shape), scale)
+
+
+def test_sipmask_pp_api_rescoring():
+    """rescoring_flag=True through the reference-facing API: get_masks returns the per-detection mask scores,
+    get_bboxes returns (cls_segms, mask_scores) bucketed by class (sipmask_head.py:641-643,659-660)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd.registry import build_head
+    from sipmask_amd import sipmask_head  # noqa: F401
+    head = build_head(dict(type='SipMaskHead', num_classes=81, in_channels=256, stacked_convs=2, ssd_flag=True,
+                           norm_cfg=None, rescoring_flag=True, feat_channels=256, strides=[8, 16, 32, 64, 128],
+                           center_sampling=True, center_sample_radius=1.5))
+    sd = {k[len("bbox_head."):]: v for k, v in OM.init_state_dict(50, 9, stacked_convs=2, norm=False,
+                                                                    rescoring=True).items() if k.startswith("bbox_head.")}
+    head.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(6)
+    B, C = 1, 80
+    sizes = [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)]
+    strides = (8, 16, 32, 64, 128)
+    cls = [torch.randn(B, C, h, w, generator=g) * 2 - 3.5 for h, w in sizes]
+    bb = [(torch.randn(B, 4, h, w, generator=g) * 1.5 + 3) * s for (h, w), s in zip(sizes, strides)]
+    ctr = [torch.randn(B, 1, h, w, generator=g) + 1 for h, w in sizes]
+    cof = [torch.randn(B, 128, h, w, generator=g) * 0.3 for h, w in sizes]
+    fm = torch.randn(B, 32, 128, 128, generator=g)
+    cfg = dict(OM.DEFAULT_TEST_CFG, score_thr=0.1)
+    sf = np.array([1.0, 1.0, 1.0, 1.0], dtype=np.float32)
+    metas = [dict(img_shape=(256, 256, 3), ori_shape=(256, 256, 3), scale_factor=sf)]
+    args = ([t.cuda() for t in cls], [t.cuda() for t in bb], [t.cuda() for t in ctr], [t.cuda() for t in cof], fm.cuda(),
+            metas, cfg)
+    det, lab, keep, masks, ms = head.get_masks(*args, rescale=False)[0]
+    r = OM.get_masks_single([c[0] for c in cls], [x[0] for x in bb], [c[0] for c in ctr], [c[0] for c in cof], fm[0],
+                            (256, 256, 3), cfg, sf, False, ssd_flag=True)
+    np.testing.assert_array_equal(lab.cpu().numpy(), r["det_labels"])
+    ref = OM.mask_rescoring({"bbox_head." + k: v for k, v in sd.items()}, r["pos_masks"], r["det_labels"],
+                            r["det_bboxes"][:, 4])
+    assert float((ms.cpu() - ref).abs().max()) < 0.03 * float(ref.max())
+    out = head.get_bboxes(*args, rescale=False)
+    cls_segms, mask_scores = out[0][2]
+    assert len(cls_segms) == 80 and len(mask_scores) == 80
+    assert [len(s) for s in cls_segms] == [len(m) for m in mask_scores]
+    assert sum(len(s) for s in cls_segms) == det.shape[0]

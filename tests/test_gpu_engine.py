@@ -115,3 +115,37 @@ def test_r101_backbone_features():
     h, w = lv.sizes[0]
     got = eng.pyr[:h * w].float().view(1, h, w, 256).permute(0, 3, 1, 2)
     assert _rel(got, pyr[0]) < 0.04
+
+
+def test_sipmask_pp_dcn_backbone_and_rescoring():
+    """SipMask++ (configs/sipmask/sipmask++_r101_caffe_fpn_ssd_6x.py, at R50 depth for test time): DeformConvPack
+    in block 0 and every 3rd block of stages 2-4, SSD head layout, mask rescoring branch.  Stage parity of the
+    backbone, and the rescoring chain on the engine's own cropped masks / detections against the oracle
+    (bf16 convs vs f32: 3 % of the largest score)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd.engine import SipMaskEngine
+    dcn = (False, True, True, True)
+    sd = OM.init_state_dict(50, 2, stacked_convs=2, norm=False, stage_with_dcn=dcn, rescoring=True)
+    sd["bbox_head.fcos_cls.bias"].fill_(-3.0)
+    img = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(5))
+    cfg = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.1, nms=dict(type='nms', iou_thr=0.5), max_per_img=100)
+    eng = SipMaskEngine(sd, 1, (256, 256), 50, cfg, ssd_flag=True)
+    r = eng.run(img.cuda())
+    torch.cuda.synchronize()
+    ndcn = len([c for c in eng.convs if c.name.endswith("conv2.conv_offset")])
+    assert ndcn == 2 + 2 + 1 and eng.rescorer is not None
+    feats = OM.backbone_forward(sd, img, 50)
+    for i, (buf, h, w, c) in enumerate(eng.backbone_feats):
+        got = buf.float().view(1, h, w, c).permute(0, 3, 1, 2)
+        assert _rel(got, feats[i]) < 0.03, (i, _rel(got, feats[i]))
+    n = int(r["ndet"][0])
+    assert n > 3
+    pos = eng.rescorer.pos_masks[0, :n].cpu()
+    lab = r["det_labels"][0, :n].cpu()
+    sc = r["det_bboxes"][0, :n, 4].cpu()
+    ref = OM.mask_rescoring(sd, pos, lab, sc)
+    got = r["mask_scores"][0, :n].cpu()
+    assert float(ref.max()) > 0
+    assert float((got - ref).abs().max()) < 0.03 * float(ref.max()), (got, ref)
+    assert float(r["mask_scores"][0, n:].abs().max()) == 0.0 if n < eng.max_num else True
