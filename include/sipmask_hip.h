@@ -111,6 +111,18 @@ int sm_deform_conv2d_bwd(const sm_conv_desc* d, const void* x, const float* offs
                          const void* gout, float* grad_x, float* grad_offset, float* grad_w_t, void* workspace,
                          sm_stream_t stream);
 
+/* Backward of a plain convolution (training row a17; the ATen/cuDNN conv backward under resnet.py / fpn.py /
+ * sipmask_head.py).  d is the FORWARD descriptor, x / gout bf16 rows as in sm_deform_conv2d_bwd.
+ *   grad_w_t  f32 [K][cout] = dW^T, K = (kh,kw,cin)                       (im2col^T + gout^T + MFMA GEMM)
+ *   grad_bias f32 [cout]
+ *   grad_x    f32 [in rows][cin]: with w_dgrad (stride 1) one forward implicit GEMM over gout --
+ *             w_dgrad = the weight flipped in (kh,kw) and transposed to [cin][cout][kh][kw], laid out like an
+ *             sm_conv2d weight; otherwise (strided convs) grad columns + col2im with w_t as in
+ *             sm_deform_conv2d_bwd (needs cin % 64 == 0).
+ * Every output is nullable.  Workspace: sm_deform_conv2d_bwd_workspace(d). */
+int sm_conv2d_bwd(const sm_conv_desc* d, const void* x, const void* w_t, const void* w_dgrad, const void* gout,
+                  float* grad_x, float* grad_w_t, float* grad_bias, void* workspace, sm_stream_t stream);
+
 /* sm_conv2d / sm_deform_conv2d (offset != NULL) with the GroupNorm statistics of the output fused in the
  * epilogue: gn_stats f32 [batch][nlev][cout/8][2] = (sum, sum of squares) per (image, level, group of 8
  * channels), zeroed by the call.  Feed it to sm_groupnorm_apply.  Needs cout % 8 == 0, bf16 output. */

@@ -68,9 +68,14 @@ struct Sample {
 __device__ __forceinline__ Sample sample_of(const DBArgs& a, const Pos& ps, int tap, int g) {
   const int kk = a.kh * a.kw;
   const int i = tap / a.kw, j = tap - i * a.kw;
-  const float* o = a.offset + ps.orow * (long long)(a.G * kk * 2) + (g * kk + tap) * 2;
-  const float h_im = (float)(ps.oy * a.stride - a.pad + i * a.dil) + o[0];
-  const float w_im = (float)(ps.ox * a.stride - a.pad + j * a.dil) + o[1];
+  float o0 = 0.f, o1 = 0.f;             // a plain convolution is the offset-free special case
+  if (a.offset != nullptr) {
+    const float* o = a.offset + ps.orow * (long long)(a.G * kk * 2) + (g * kk + tap) * 2;
+    o0 = o[0];
+    o1 = o[1];
+  }
+  const float h_im = (float)(ps.oy * a.stride - a.pad + i * a.dil) + o0;
+  const float w_im = (float)(ps.ox * a.stride - a.pad + j * a.dil) + o1;
   Sample s;
   s.valid = h_im > -1.f && w_im > -1.f && h_im < (float)a.in_h[ps.l] && w_im < (float)a.in_w[ps.l];
   const float fh = floorf(h_im), fw = floorf(w_im);
@@ -201,6 +206,34 @@ __global__ void axpy_kernel(float* __restrict__ acc, const float* __restrict__ x
     acc[i] += x[i];
 }
 
+// grad_bias[co] = sum over all positions of gout[p][co]: one block per 8 channels, rows strided over the threads
+__global__ __launch_bounds__(256) void bias_grad_kernel(const DBArgs a, float* __restrict__ gbias) {
+  __shared__ float s_red[256][8];
+  const int c0 = blockIdx.x * 8, tid = threadIdx.x;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (long long p = tid; p < a.P; p += 256) {
+    const Pos ps = locate(a, p);
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(a.gout + ps.orow * a.gout_cstride + c0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[2 * e] += __uint_as_float(raw[e] << 16);
+      acc[2 * e + 1] += __uint_as_float(raw[e] & 0xffff0000u);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s_red[tid][e] = acc[e];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s_red[tid][e] += s_red[tid + st][e];
+    __syncthreads();
+  }
+  if (tid < 8 && c0 + tid < a.cout) gbias[c0 + tid] = s_red[0][tid];
+}
+
 struct Plan {
   long long P, K;
   int chunk, Lp, cout_pad2;       // weight-gradient GEMM: positions per chunk, padded length, padded cout
@@ -241,15 +274,19 @@ extern "C" int64_t sm_deform_conv2d_bwd_workspace(const sm_conv_desc* d) {
   return (int64_t)pl.total;
 }
 
-extern "C" int sm_deform_conv2d_bwd(const sm_conv_desc* d, const void* x, const float* offset, const void* w_t,
-                                    const void* gout, float* grad_x, float* grad_offset, float* grad_w_t,
-                                    void* workspace, sm_stream_t stream) {
-  if (!d || !x || !offset || !gout || !workspace) return SM_ERR_BAD_ARG;
+static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offset, const void* w_t, const void* w_dgrad,
+                         const void* gout, float* grad_x, float* grad_offset, float* grad_w_t, float* grad_bias,
+                         void* workspace, sm_stream_t stream) {
+  if (!d || !x || !gout || !workspace) return SM_ERR_BAD_ARG;
   if (d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return SM_ERR_BAD_SHAPE;
-  if (d->deform_groups < 1 || d->cin % 64 != 0 || (d->cin / d->deform_groups) % 64 != 0 || d->cout % 8 != 0)
-    return SM_ERR_UNSUPPORTED;
-  if (d->stride != 1) return SM_ERR_UNSUPPORTED;
-  if ((grad_x || grad_offset) && !w_t) return SM_ERR_BAD_ARG;
+  const int G = offset ? d->deform_groups : 1;
+  if (d->cin % 8 != 0 || d->cout % 8 != 0 || d->out_cstride % 8 != 0 || d->in_cstride % 8 != 0) return SM_ERR_UNSUPPORTED;
+  if (offset && (G < 1 || d->stride != 1)) return SM_ERR_UNSUPPORTED;
+  // fast input gradient of a plain stride-1 conv: one forward implicit GEMM over gout with the flipped,
+  // transposed weights (w_dgrad); everything else goes through grad columns + col2im
+  const bool fast_dgrad = grad_x && !offset && w_dgrad && d->stride == 1;
+  const bool col_path = (grad_x && !fast_dgrad) || grad_offset;
+  if (col_path && (!w_t || d->cin % 64 != 0 || (d->cin / G) % 64 != 0)) return w_t ? SM_ERR_UNSUPPORTED : SM_ERR_BAD_ARG;
   hipStream_t s = sm_hip_stream(stream);
   Plan pl;
   make_plan(d, &pl);
@@ -269,11 +306,40 @@ extern "C" int sm_deform_conv2d_bwd(const sm_conv_desc* d, const void* x, const 
   // the compact position order must coincide with the rows of gout/offset inside a level (it does by
   // construction: row = out_row0[l] + (b*oh + y)*ow + x); levels may sit anywhere
   a.cin = d->cin, a.cout = d->cout, a.kh = d->kh, a.kw = d->kw, a.stride = d->stride, a.pad = d->pad, a.dil = d->dil;
-  a.in_cstride = d->in_cstride, a.gout_cstride = d->out_cstride, a.G = d->deform_groups;
+  a.in_cstride = d->in_cstride, a.gout_cstride = d->out_cstride, a.G = G;
   a.P = pl.P;
   const int kk = d->kh * d->kw;
 
-  if (grad_x || grad_offset) {
+  if (grad_bias) {
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((d->cout + 7) / 8), dim3(256), 0, s, a, grad_bias);
+    SM_LAUNCH_CHECK();
+  }
+  if (fast_dgrad) {
+    // dX = conv(gout, flip(W)^T) with pad' = dil*(k-1) - pad: same rows as x, f32
+    sm_conv_desc g0;
+    memset(&g0, 0, sizeof(g0));
+    g0.nlev = d->nlev;
+    g0.batch = d->batch;
+    for (int l = 0; l < d->nlev; ++l) {
+      g0.in_h[l] = d->out_h[l], g0.in_w[l] = d->out_w[l];
+      g0.out_h[l] = d->in_h[l], g0.out_w[l] = d->in_w[l];
+      g0.in_row0[l] = d->out_row0[l];
+      g0.out_row0[l] = d->in_row0[l];
+    }
+    g0.cin = d->cout;
+    g0.cout = d->cin;
+    const int t0 = sm_conv_cout_tile(d->cin);
+    g0.cout_pad = (d->cin + t0 - 1) / t0 * t0;
+    g0.kh = d->kh, g0.kw = d->kw, g0.stride = 1, g0.dil = d->dil;
+    g0.pad = d->dil * (d->kh - 1) - d->pad;
+    if (g0.pad < 0 || d->kh != d->kw) return SM_ERR_UNSUPPORTED;
+    g0.in_cstride = d->out_cstride;
+    g0.out_cstride = d->cin;
+    g0.flags = SM_CONV_OUT_F32;
+    const int st = sm_conv2d(&g0, gout, w_dgrad, nullptr, nullptr, grad_x, stream);
+    if (st != SM_OK) return st;
+  }
+  if (col_path) {
     // ---- grad columns = gout @ W  as a 1x1 conv  (cin := cout, cout := K)
     sm_conv_desc g1;
     memset(&g1, 0, sizeof(g1));
@@ -297,17 +363,18 @@ extern "C" int sm_deform_conv2d_bwd(const sm_conv_desc* d, const void* x, const 
     float* gcol = (float*)(ws + pl.off_gcol);
     int st = sm_conv2d(&g1, gout, w_t, nullptr, nullptr, gcol, stream);
     if (st != SM_OK) return st;
-    if (grad_x && hipMemsetAsync(grad_x, 0, (size_t)in_rows * d->cin * 4, s) != hipSuccess) return SM_ERR_LAUNCH;
+    float* gx_col = fast_dgrad ? nullptr : grad_x;
+    if (gx_col && hipMemsetAsync(gx_col, 0, (size_t)in_rows * d->cin * 4, s) != hipSuccess) return SM_ERR_LAUNCH;
     if (grad_offset) {   // positions sampling outside the image are skipped by the kernel: their gradient is 0
       long long orows = 0;
       for (int l = 0; l < d->nlev; ++l)
         orows = std::max<long long>(orows, d->out_row0[l] + (long long)d->batch * d->out_h[l] * d->out_w[l]);
-      if (hipMemsetAsync(grad_offset, 0, (size_t)orows * d->deform_groups * kk * 2 * 4, s) != hipSuccess)
+      if (hipMemsetAsync(grad_offset, 0, (size_t)orows * G * kk * 2 * 4, s) != hipSuccess)
         return SM_ERR_LAUNCH;
     }
     const long long nunits = pl.P * kk * (d->cin / 64);
     const int blocks = (int)std::min<long long>((nunits + 3) / 4, 256 * 64);
-    hipLaunchKernelGGL(deform_col2im_kernel, dim3(blocks), dim3(256), 0, s, a, gcol, grad_x, grad_offset, nunits);
+    hipLaunchKernelGGL(deform_col2im_kernel, dim3(blocks), dim3(256), 0, s, a, gcol, gx_col, grad_offset, nunits);
     SM_LAUNCH_CHECK();
   }
   if (grad_w_t) {
@@ -351,4 +418,17 @@ extern "C" int sm_deform_conv2d_bwd(const sm_conv_desc* d, const void* x, const 
     }
   }
   return SM_OK;
+}
+
+extern "C" int sm_deform_conv2d_bwd(const sm_conv_desc* d, const void* x, const float* offset, const void* w_t,
+                                    const void* gout, float* grad_x, float* grad_offset, float* grad_w_t,
+                                    void* workspace, sm_stream_t stream) {
+  if (!offset) return SM_ERR_BAD_ARG;
+  if (d && (d->cin % 64 != 0 || d->deform_groups < 1 || (d->cin / d->deform_groups) % 64 != 0)) return SM_ERR_UNSUPPORTED;
+  return conv_bwd_impl(d, x, offset, w_t, nullptr, gout, grad_x, grad_offset, grad_w_t, nullptr, workspace, stream);
+}
+
+extern "C" int sm_conv2d_bwd(const sm_conv_desc* d, const void* x, const void* w_t, const void* w_dgrad, const void* gout,
+                             float* grad_x, float* grad_w_t, float* grad_bias, void* workspace, sm_stream_t stream) {
+  return conv_bwd_impl(d, x, nullptr, w_t, w_dgrad, gout, grad_x, nullptr, grad_w_t, grad_bias, workspace, stream);
 }

@@ -132,6 +132,15 @@ def deform_conv2d_bwd(desc, x, offset, w_t, gout, grad_x, grad_offset, grad_w_t)
                                         _lib.stream_ptr()), "sm_deform_conv2d_bwd")
 
 
+def conv2d_bwd(desc, x, w_t, w_dgrad, gout, grad_x, grad_w_t, grad_bias):
+    """Plain conv backward (see sm_conv2d_bwd).  Outputs may be None."""
+    lib = _lib.load()
+    ws = torch.empty(int(lib.sm_deform_conv2d_bwd_workspace(C.byref(desc))), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.sm_conv2d_bwd(C.byref(desc), _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(w_dgrad), _lib.ptr(gout),
+                                 _lib.ptr(grad_x), _lib.ptr(grad_w_t), _lib.ptr(grad_bias), _lib.ptr(ws),
+                                 _lib.stream_ptr()), "sm_conv2d_bwd")
+
+
 def groupnorm(x, y, gamma, beta, stats, lv, channels, groups=32, eps=1e-5, relu=True):
     lib = _lib.load()
     nlev = len(lv)

@@ -152,6 +152,62 @@ class DeformConv(nn.Module):
         return out
 
 
+# ------------------------------------------------------------------------------- plain conv (fwd + bwd)
+class Conv2dFunction(Function):
+    """F.conv2d(input, weight, bias, stride, padding, dilation) on the HIP implicit-GEMM kernels, forward and
+    backward (bf16 operands, f32 accumulation) -- the building block of the training step.
+    NCHW float tensors in and out, square kernels, groups=1."""
+
+    @staticmethod
+    def forward(ctx, input, weight, bias=None, stride=1, padding=0, dilation=1):
+        if not input.is_cuda:
+            raise NotImplementedError
+        b, c, h, w = input.shape
+        co, ci, k, k2 = weight.shape
+        if k != k2 or ci != c or c % 8 != 0 or co % 8 != 0:
+            raise NotImplementedError("square kernels, channels a multiple of 8")
+        ho = (h + 2 * padding - (dilation * (k - 1) + 1)) // stride + 1
+        wo = (w + 2 * padding - (dilation * (k - 1) + 1)) // stride + 1
+        x = torch.empty(b * h * w, c, dtype=torch.bfloat16, device=input.device)
+        H.nchw_to_nhwc_bf16(input.detach().float().contiguous(), x, c)
+        wq, co_pad = H.prep_conv_weight(weight.detach())
+        y = torch.empty(b * ho * wo, co, dtype=torch.float32, device=input.device)
+        d = H.make_conv_desc(b, [(h, w)], [(ho, wo)], [0], [0], c, co, co_pad, k, stride, padding, c, co,
+                             flags=_lib.SM_CONV_OUT_F32, dil=dilation)
+        H.conv2d(d, x, wq, None if bias is None else bias.detach().float().contiguous(), None, y)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (b, c, h, w, co, k, ho, wo, stride, padding, dilation, input.dtype, bias is not None)
+        return y.view(b, ho, wo, co).permute(0, 3, 1, 2).to(input.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        x, weight = ctx.saved_tensors
+        b, c, h, w, co, k, ho, wo, stride, pad, dil, dt, has_bias = ctx.geom
+        dev = grad_output.device
+        go = torch.empty(b * ho * wo, co, dtype=torch.bfloat16, device=dev)
+        H.nchw_to_nhwc_bf16(grad_output.detach().float().contiguous(), go, co)
+        d = H.make_conv_desc(b, [(h, w)], [(ho, wo)], [0], [0], c, co, co, k, stride, pad, c, co, dil=dil)
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
+        K = k * k * c
+        wdet = weight.detach()
+        w_t = w_dg = None
+        if need_x and stride == 1:       # flipped + transposed weight: dX is a forward conv over grad_output
+            w_dg, _ = H.prep_conv_weight(wdet.flip(2, 3).permute(1, 0, 2, 3).contiguous(), co)
+        elif need_x:                     # strided: grad columns + col2im
+            w_t, _ = H.prep_conv_weight(wdet.permute(2, 3, 1, 0).reshape(K, co, 1, 1).contiguous(), co)
+        gx = torch.empty(b * h * w, c, dtype=torch.float32, device=dev) if need_x else None
+        gw_t = torch.empty(K, co, dtype=torch.float32, device=dev) if need_w else None
+        gb = torch.empty(co, dtype=torch.float32, device=dev) if need_b else None
+        H.conv2d_bwd(d, x, w_t, w_dg, go, gx, gw_t, gb)
+        return (None if gx is None else gx.view(b, h, w, c).permute(0, 3, 1, 2).to(dt),
+                None if gw_t is None else gw_t.view(k, k, c, co).permute(3, 2, 0, 1).contiguous().to(weight.dtype),
+                gb, None, None, None)
+
+
+conv2d = Conv2dFunction.apply
+
+
 # ------------------------------------------------------------------------------- crop split
 class CropSplitFunction(Function):
 

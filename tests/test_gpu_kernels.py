@@ -492,6 +492,41 @@ def test_deform_conv_backward_vs_oracle(cfg):
     assert rel(wd2.grad, rw) < 1e-2
 
 
+@pytest.mark.parametrize("cfg", [
+    # (B, Cin, H, W, Cout, k, stride, pad, dil)
+    (2, 64, 13, 17, 128, 3, 1, 1, 1),      # tower-like: fast dgrad (flipped-weight forward conv)
+    (1, 256, 25, 42, 256, 3, 1, 1, 1),
+    (2, 128, 12, 10, 64, 1, 1, 0, 1),      # 1x1
+    (2, 64, 16, 20, 256, 1, 2, 0, 1),      # strided 1x1 (caffe-style conv1 / downsample): col2im dgrad
+    (1, 256, 25, 42, 256, 3, 2, 1, 1),     # P6: stride-2 3x3
+    (1, 64, 14, 14, 64, 3, 1, 2, 2),       # dilated
+    (2, 64, 150, 120, 16, 3, 1, 1, 1),     # two wgrad chunks
+])
+def test_conv2d_backward_vs_torch(cfg):
+    """sm_conv2d_bwd through ops.conv2d (autograd) against torch's CPU conv backward on bf16-representable x, w,
+    grad_output: grad_input / grad_bias 2e-3, grad_weight 1e-2 of the tensor max (im2col operand is bf16)."""
+    from sipmask_amd import ops as P
+    dev = _dev()
+    B, C, Hh, Ww, Co, k, s_, p_, dl = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = _bf(torch.randn(B, C, Hh, Ww, generator=g)).requires_grad_()
+    w = _bf(torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5).requires_grad_()
+    bias = torch.randn(Co, generator=g).requires_grad_()
+    y = F.conv2d(x, w, bias, s_, p_, dl)
+    go = _bf(torch.randn(y.shape, generator=g))
+    y.backward(go)
+    xd, wd, bd = (t.detach().to(dev).requires_grad_() for t in (x, w, bias))
+    yd = P.conv2d(xd, wd, bd, s_, p_, dl)
+    torch.testing.assert_close(yd.detach().cpu(), y.detach(), rtol=1e-4, atol=2e-4)
+    yd.backward(go.to(dev))
+
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max() / b.abs().max())
+    assert rel(xd.grad, x.grad) < 2e-3, rel(xd.grad, x.grad)
+    assert rel(bd.grad, bias.grad) < 2e-3, rel(bd.grad, bias.grad)
+    assert rel(wd.grad, w.grad) < 1e-2, rel(wd.grad, w.grad)
+
+
 def test_det_select_vs_oracle():
     """score -> per-level top-k -> gather/decode (sipmask_head.py:563-591) for a 2-image batch."""
     from sipmask_amd import hip_ops as H
