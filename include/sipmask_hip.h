@@ -294,6 +294,27 @@ int sm_mask_loss_bwd(const float* basis, int basis_hwc, const float* cof, const 
                      const int64_t* idx_gt, int n, int hm, int wm, const float* grad_sum, float* grad_cof,
                      float* grad_basis, sm_stream_t stream);
 
+/* ---- training-path layers on f32 NCHW tensors ------------------------------------------ */
+
+/* nn.GroupNorm (+ReLU) as used by the head's ConvModules / FeatureAlign (conv_module.py:116-120,
+ * sipmask_head.py:42,52).  stats f32 [batch][groups][2] = (mean, rstd) saved for the backward. */
+int sm_groupnorm_nchw_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int batch,
+                          int channels, int hw, int groups, float eps, int relu, sm_stream_t stream);
+/* dy is masked by (y > 0) when relu.  dx / dgamma / dbeta nullable; dgamma, dbeta are overwritten. */
+int sm_groupnorm_nchw_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* stats,
+                          float* dx, float* dgamma, float* dbeta, int batch, int channels, int hw, int groups,
+                          int relu, sm_stream_t stream);
+/* F.interpolate(bilinear, align_corners=False, integer scale_factor) on `planes` = N*C planes of h x w, and its
+ * adjoint (dx overwritten). */
+int sm_upsample_bilinear_nchw_fwd(const float* x, float* y, int64_t planes, int h, int w, int factor,
+                                  sm_stream_t stream);
+int sm_upsample_bilinear_nchw_bwd(const float* dy, float* dx, int64_t planes, int h, int w, int factor,
+                                  sm_stream_t stream);
+/* torch.optim.SGD update with momentum and weight decay (the reference's optimizer, M/mmdet/apis/train.py:92-133):
+ * g += wd*p; buf = first_step ? g : momentum*buf + g; p -= lr*buf. */
+int sm_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                float weight_decay, int first_step, sm_stream_t stream);
+
 /* ---- SipMask-VIS tracking (V/ = SipMask-VIS/, V/mmdet/models/anchor_heads/sipmask_head.py) -------------- */
 
 /* extract_box_feature_center_single (:768-781) for every detection of the batch: out[b][i][:] = the embedding at

@@ -246,7 +246,9 @@ def head_forward(sd, feats, prefix="bbox_head.", strides=FPN_STRIDES, return_aux
         for i in range(nreg_convs):
             rf = _tower(sd, rf, h + "reg_convs.%d" % i)
         bbox_pred = sd[h + "scales.%d.scale" % li] * F.conv2d(rf, sd[h + "fcos_reg.weight"], sd[h + "fcos_reg.bias"], 1, 1)
-        offset = F.conv2d(bbox_pred, sd[h + "feat_align.conv_offset.weight"])
+        # FeatureAlign.forward: offset = self.conv_offset(shape.detach()) (sipmask_head.py:50) -- no gradient
+        # flows from the deformable conv's offsets back into the box branch
+        offset = F.conv2d(bbox_pred.detach(), sd[h + "feat_align.conv_offset.weight"])
         y = ops.deform_conv(cf, offset, sd[h + "feat_align.conv_adaption.weight"], 1, 1, 1, 4)
         if flag_norm:                             # FeatureAlign.forward, sipmask_head.py:49-55
             y = F.group_norm(y, 32, sd[h + "feat_align.norm.weight"], sd[h + "feat_align.norm.bias"], 1e-5)

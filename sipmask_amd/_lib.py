@@ -84,6 +84,11 @@ PROTOTYPES = {
     "sm_track_match": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P]),
     "sm_mask_rescore": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "sm_conv2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sm_groupnorm_nchw_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "sm_groupnorm_nchw_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sm_upsample_bilinear_nchw_fwd": (_I, [_P, _P, C.c_int64, _I, _I, _I, _P]),
+    "sm_upsample_bilinear_nchw_bwd": (_I, [_P, _P, C.c_int64, _I, _I, _I, _P]),
+    "sm_sgd_step": (_I, [_P, _P, _P, C.c_int64, _F, _F, _F, _I, _P]),
     "sm_rle_workspace": (C.c_int64, [_I, _I, _I, _I]),
     "sm_mask_rects": (_I, [_P, _I, _I, _F, _F, _F, C.c_double, C.c_double, _P, _P]),
     "sm_rle_encode": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),

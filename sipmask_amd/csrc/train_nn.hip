@@ -1,0 +1,223 @@
+// Training-path layers of the SipMask head that are not GEMMs: GroupNorm(+ReLU) forward/backward,
+// bilinear upsampling forward/backward (align_corners=False, integer factor) and the SGD-momentum update, on f32
+// NCHW tensors as autograd hands them over.  All HBM-bound: a GroupNorm group is one contiguous run of
+// (C/G)*H*W floats in NCHW, so every (image, group) is one block streaming contiguous memory.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TN_THREADS = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < TN_THREADS / 64; ++w) t += s_red[w];
+  return t;
+}
+
+// nn.GroupNorm (+ optional ReLU): y = gamma * (x - mean) * rstd + beta.  One block per (n, group).
+// stats[n][g] = (mean, rstd) is kept for the backward.
+__global__ __launch_bounds__(TN_THREADS) void gn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ stats, int C, int HW, int G, float eps,
+                                                            int relu) {
+  __shared__ float s_red[TN_THREADS / 64];
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G;
+  const long long base = ((long long)n * C + (long long)g * cpg) * HW;
+  const int m = cpg * HW;
+  float s = 0.f;
+  for (int i = tid; i < m; i += TN_THREADS) s += x[base + i];
+  const float mean = block_sum(s, s_red) / (float)m;
+  float ss = 0.f;
+  for (int i = tid; i < m; i += TN_THREADS) {
+    const float d = x[base + i] - mean;
+    ss += d * d;
+  }
+  const float var = block_sum(ss, s_red) / (float)m;      // biased variance, two-pass (as ATen's CPU kernel)
+  const float rstd = rsqrtf(var + eps);
+  if (tid == 0) {
+    stats[((long long)n * G + g) * 2 + 0] = mean;
+    stats[((long long)n * G + g) * 2 + 1] = rstd;
+  }
+  for (int i = tid; i < m; i += TN_THREADS) {
+    const int c = g * cpg + i / HW;
+    float v = (x[base + i] - mean) * rstd * gamma[c] + beta[c];
+    if (relu) v = fmaxf(v, 0.f);
+    y[base + i] = v;
+  }
+}
+
+// backward of the above: dy is first masked by (y > 0) when relu.  dgamma/dbeta are accumulated with atomics
+// (zeroed by the host wrapper); dx = rstd * (gamma*dy - mean_g(gamma*dy) - xhat * mean_g(gamma*dy*xhat)).
+__global__ __launch_bounds__(TN_THREADS) void gn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                            const float* __restrict__ stats, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
+                                                            int HW, int G, int relu) {
+  __shared__ float s_red[TN_THREADS / 64];
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G;
+  const long long base = ((long long)n * C + (long long)g * cpg) * HW;
+  const int m = cpg * HW;
+  const float mean = stats[((long long)n * G + g) * 2 + 0], rstd = stats[((long long)n * G + g) * 2 + 1];
+  float s1 = 0.f, s2 = 0.f;
+  // per-channel sums for dgamma / dbeta: channels are visited one after another (HW elements each)
+  for (int cl = 0; cl < cpg; ++cl) {
+    const int c = g * cpg + cl;
+    float a = 0.f, b = 0.f;
+    for (int i = tid; i < HW; i += TN_THREADS) {
+      const long long o = base + (long long)cl * HW + i;
+      float d = dy[o];
+      if (relu && !(y[o] > 0.f)) d = 0.f;
+      const float xh = (x[o] - mean) * rstd;
+      a += d * xh;
+      b += d;
+    }
+    const float ta = block_sum(a, s_red), tb = block_sum(b, s_red);
+    if (tid == 0) {
+      if (dgamma) unsafeAtomicAdd(dgamma + c, ta);
+      if (dbeta) unsafeAtomicAdd(dbeta + c, tb);
+    }
+    s1 += gamma[c] * tb;     // every thread holds the block totals
+    s2 += gamma[c] * ta;
+  }
+  if (!dx) return;
+  const float m1 = s1 / (float)m, m2 = s2 / (float)m;
+  for (int i = tid; i < m; i += TN_THREADS) {
+    const int c = g * cpg + i / HW;
+    const long long o = base + i;
+    float d = dy[o];
+    if (relu && !(y[o] > 0.f)) d = 0.f;
+    const float xh = (x[o] - mean) * rstd;
+    dx[o] = rstd * (gamma[c] * d - m1 - xh * m2);
+  }
+}
+
+// F.interpolate(mode='bilinear', align_corners=False, scale_factor=f) on NCHW f32, one thread per output pixel
+__device__ __forceinline__ void bil_src(int o, int n_in, float inv, int& i0, int& i1, float& l) {
+  const float s = fmaxf(inv * ((float)o + 0.5f) - 0.5f, 0.f);
+  i0 = min((int)s, n_in - 1);
+  i1 = min(i0 + 1, n_in - 1);
+  l = s - (float)i0;
+}
+
+__global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes, int h, int w,
+                                    int f) {
+  const int ho = h * f, wo = w * f;
+  const long long total = planes * ho * wo;
+  const float inv = 1.f / (float)f;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(t % wo), oy = (int)((t / wo) % ho);
+    const long long p = t / ((long long)wo * ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bil_src(oy, h, inv, y0, y1, ly);
+    bil_src(ox, w, inv, x0, x1, lx);
+    const float* s = x + p * h * w;
+    y[t] = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) +
+           ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+  }
+}
+
+// adjoint of the above: dx zeroed by the host, 4 float atomics per output pixel
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long planes, int h, int w,
+                                    int f) {
+  const int ho = h * f, wo = w * f;
+  const long long total = planes * ho * wo;
+  const float inv = 1.f / (float)f;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(t % wo), oy = (int)((t / wo) % ho);
+    const long long p = t / ((long long)wo * ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bil_src(oy, h, inv, y0, y1, ly);
+    bil_src(ox, w, inv, x0, x1, lx);
+    const float g = dy[t];
+    float* d = dx + p * h * w;
+    unsafeAtomicAdd(d + y0 * w + x0, g * (1.f - ly) * (1.f - lx));
+    unsafeAtomicAdd(d + y0 * w + x1, g * (1.f - ly) * lx);
+    unsafeAtomicAdd(d + y1 * w + x0, g * ly * (1.f - lx));
+    unsafeAtomicAdd(d + y1 * w + x1, g * ly * lx);
+  }
+}
+
+// torch.optim.SGD step (momentum, weight decay, dampening 0, no nesterov): g += wd*p; buf = mom*buf + g (buf = g on
+// the first step); p -= lr*buf.  The reference's optimizer: cfg optimizer=dict(type='SGD', lr=.01, momentum=.9,
+// weight_decay=1e-4) with paramwise bias_lr_mult=2, bias_decay_mult=0 (M/mmdet/apis/train.py:92-133).
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n, float lr,
+                           float momentum, float wd, int first) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] + wd * p[i];
+    const float b = first ? gi : momentum * buf[i] + gi;
+    buf[i] = b;
+    p[i] -= lr * b;
+  }
+}
+
+inline int grid_1d(long long n) { return (int)std::min<long long>((n + 255) / 256, 256 * 32); }
+
+}  // namespace
+
+extern "C" int sm_groupnorm_nchw_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                                     int batch, int channels, int hw, int groups, float eps, int relu,
+                                     sm_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !stats) return SM_ERR_BAD_ARG;
+  if (batch < 1 || channels < 1 || hw < 1 || groups < 1 || channels % groups != 0) return SM_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(gn_fwd_kernel, dim3(groups, batch), dim3(TN_THREADS), 0, sm_hip_stream(stream), x, gamma, beta, y,
+                     stats, channels, hw, groups, eps, relu);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_groupnorm_nchw_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+                                     const float* stats, float* dx, float* dgamma, float* dbeta, int batch,
+                                     int channels, int hw, int groups, int relu, sm_stream_t stream) {
+  if (!x || !dy || !gamma || !stats || (relu && !y)) return SM_ERR_BAD_ARG;
+  if (batch < 1 || channels < 1 || hw < 1 || groups < 1 || channels % groups != 0) return SM_ERR_BAD_SHAPE;
+  hipStream_t s = sm_hip_stream(stream);
+  if (dgamma && hipMemsetAsync(dgamma, 0, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (dbeta && hipMemsetAsync(dbeta, 0, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
+  hipLaunchKernelGGL(gn_bwd_kernel, dim3(groups, batch), dim3(TN_THREADS), 0, s, x, y, dy, gamma, stats, dx, dgamma, dbeta,
+                     channels, hw, groups, relu);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_upsample_bilinear_nchw_fwd(const float* x, float* y, int64_t planes, int h, int w, int factor,
+                                             sm_stream_t stream) {
+  if (!x || !y) return SM_ERR_BAD_ARG;
+  if (planes < 1 || h < 1 || w < 1 || factor < 1) return SM_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_1d(planes * h * w * factor * factor)), dim3(256), 0,
+                     sm_hip_stream(stream), x, y, (long long)planes, h, w, factor);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_upsample_bilinear_nchw_bwd(const float* dy, float* dx, int64_t planes, int h, int w, int factor,
+                                             sm_stream_t stream) {
+  if (!dy || !dx) return SM_ERR_BAD_ARG;
+  if (planes < 1 || h < 1 || w < 1 || factor < 1) return SM_ERR_BAD_SHAPE;
+  hipStream_t s = sm_hip_stream(stream);
+  if (hipMemsetAsync(dx, 0, sizeof(float) * planes * h * w, s) != hipSuccess) return SM_ERR_LAUNCH;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_1d(planes * h * w * factor * factor)), dim3(256), 0, s, dy, dx,
+                     (long long)planes, h, w, factor);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                           float weight_decay, int first_step, sm_stream_t stream) {
+  if (!param || !grad || !momentum_buf) return SM_ERR_BAD_ARG;
+  if (n < 1) return SM_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_1d(n)), dim3(256), 0, sm_hip_stream(stream), param, grad, momentum_buf,
+                     (long long)n, lr, momentum, weight_decay, first_step);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

@@ -401,3 +401,51 @@ def mask_rescore(feat, labels, det, ndet, hw, out):
     _lib.check(lib.sm_mask_rescore(_lib.ptr(feat), _lib.ptr(labels), _lib.ptr(det), _lib.ptr(ndet), b, n, int(hw),
                                    feat.shape[-1], _lib.ptr(out), _lib.stream_ptr()), "sm_mask_rescore")
     return out
+
+
+# ------------------------------------------------------------------------------- training-path NCHW layers
+def groupnorm_nchw_fwd(x, gamma, beta, groups, eps, relu):
+    lib = _lib.load()
+    b, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (b * c)
+    y = torch.empty_like(x)
+    stats = torch.empty(b, groups, 2, dtype=torch.float32, device=x.device)
+    _lib.check(lib.sm_groupnorm_nchw_fwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), _lib.ptr(stats), b, c,
+                                         hw, groups, float(eps), int(relu), _lib.stream_ptr()), "sm_groupnorm_nchw_fwd")
+    return y, stats
+
+
+def groupnorm_nchw_bwd(x, y, dy, gamma, stats, groups, relu, need_dx=True, need_dw=True):
+    lib = _lib.load()
+    b, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (b * c)
+    dx = torch.empty_like(x) if need_dx else None
+    dg = torch.empty(c, dtype=torch.float32, device=x.device) if need_dw else None
+    db = torch.empty(c, dtype=torch.float32, device=x.device) if need_dw else None
+    _lib.check(lib.sm_groupnorm_nchw_bwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(dy), _lib.ptr(gamma), _lib.ptr(stats),
+                                         _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), b, c, hw, groups, int(relu),
+                                         _lib.stream_ptr()), "sm_groupnorm_nchw_bwd")
+    return dx, dg, db
+
+
+def upsample_nchw(x, factor, backward=False):
+    """x f32 [N,C,h,w] -> [N,C,h*f,w*f]; backward=True: x is dy [N,C,h*f,w*f] -> dx [N,C,h,w]."""
+    lib = _lib.load()
+    n, c = x.shape[0], x.shape[1]
+    if not backward:
+        h, w = x.shape[2], x.shape[3]
+        y = torch.empty(n, c, h * factor, w * factor, dtype=torch.float32, device=x.device)
+        _lib.check(lib.sm_upsample_bilinear_nchw_fwd(_lib.ptr(x), _lib.ptr(y), n * c, h, w, factor, _lib.stream_ptr()),
+                   "sm_upsample_bilinear_nchw_fwd")
+        return y
+    h, w = x.shape[2] // factor, x.shape[3] // factor
+    dx = torch.empty(n, c, h, w, dtype=torch.float32, device=x.device)
+    _lib.check(lib.sm_upsample_bilinear_nchw_bwd(_lib.ptr(x), _lib.ptr(dx), n * c, h, w, factor, _lib.stream_ptr()),
+               "sm_upsample_bilinear_nchw_bwd")
+    return dx
+
+
+def sgd_step(param, grad, buf, lr, momentum, weight_decay, first_step):
+    lib = _lib.load()
+    _lib.check(lib.sm_sgd_step(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(buf), param.numel(), float(lr), float(momentum),
+                               float(weight_decay), int(first_step), _lib.stream_ptr()), "sm_sgd_step")

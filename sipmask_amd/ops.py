@@ -208,6 +208,52 @@ class Conv2dFunction(Function):
 conv2d = Conv2dFunction.apply
 
 
+class GroupNormFunction(Function):
+    """F.group_norm (+ fused ReLU) forward/backward on the HIP NCHW kernels (f32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps=1e-5, relu=False):
+        if not x.is_cuda:
+            raise NotImplementedError
+        xc = x.detach().float().contiguous()
+        g, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y, stats = H.groupnorm_nchw_fwd(xc, g, b, groups, eps, relu)
+        ctx.save_for_backward(xc, y, g, stats)
+        ctx.cfg = (groups, relu, x.dtype)
+        return y.to(x.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, y, g, stats = ctx.saved_tensors
+        groups, relu, dt = ctx.cfg
+        dx, dg, db = H.groupnorm_nchw_bwd(x, y, dy.detach().float().contiguous(), g, stats, groups, relu,
+                                          ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return (None if dx is None else dx.to(dt), dg, db, None, None, None)
+
+
+group_norm = GroupNormFunction.apply
+
+
+class UpsampleBilinearFunction(Function):
+    """F.interpolate(x, scale_factor=f, mode='bilinear', align_corners=False) for integer f, fwd/bwd in HIP."""
+
+    @staticmethod
+    def forward(ctx, x, factor):
+        if not x.is_cuda:
+            raise NotImplementedError
+        ctx.factor, ctx.dt = int(factor), x.dtype
+        return H.upsample_nchw(x.detach().float().contiguous(), int(factor)).to(x.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return H.upsample_nchw(dy.detach().float().contiguous(), ctx.factor, backward=True).to(ctx.dt), None
+
+
+upsample_bilinear = UpsampleBilinearFunction.apply
+
+
 # ------------------------------------------------------------------------------- crop split
 class CropSplitFunction(Function):
 

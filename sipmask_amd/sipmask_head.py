@@ -115,8 +115,57 @@ class SipMaskHead(nn.Module):
             self._engines = {key: eng}     # one cached plan; weights are snapshotted at build time
         return eng
 
+    # ------------------------------------------------------------------ forward, training mode (autograd)
+    def _tower_train(self, x, convs):
+        from . import ops as P
+        for m in convs:
+            if m.with_norm:
+                x = P.group_norm(P.conv2d(x, m.conv.weight, None, 1, 1), m.norm.weight, m.norm.bias, 32, 1e-5, True)
+            else:
+                x = torch.relu(P.conv2d(x, m.conv.weight, m.conv.bias, 1, 1))
+        return x
+
+    def forward_train(self, feats):
+        """SipMaskHead.forward (sipmask_head.py:241-287) as a differentiable graph of HIP autograd ops
+        (ops.conv2d, ops.deform_conv, ops.group_norm, ops.upsample_bilinear; bf16 operands / f32 accumulation in
+        the GEMMs, f32 elsewhere), so that `loss(...)` -> `.backward()` produces parameter gradients on the HIP
+        kernels.  Layer by layer with NCHW<->NHWC conversions in every conv: correct, not yet fast (the fused static
+        plan is inference-only)."""
+        from . import ops as P
+        cls_scores, bbox_preds, centernesses, cof_preds, fm = [], [], [], [], []
+        # fcos_reg (4) + fcos_centerness (1) as ONE 8-channel conv (3 zero channels): the GEMM wants cout % 8 == 0
+        zw = self.fcos_reg.weight.new_zeros(3, *self.fcos_reg.weight.shape[1:])
+        w_rc = torch.cat([self.fcos_reg.weight, self.fcos_centerness.weight, zw], 0)
+        b_rc = torch.cat([self.fcos_reg.bias, self.fcos_centerness.bias, self.fcos_reg.bias.new_zeros(3)], 0)
+        for li, (x, scale, stride) in enumerate(zip(feats, self.scales, self.strides)):
+            cls_feat = self._tower_train(x, self.cls_convs)
+            reg_feat = self._tower_train(x, self.reg_convs)
+            rc = P.conv2d(reg_feat, w_rc, b_rc, 1, 1)
+            bbox_pred = scale(rc[:, :4])
+            centernesses.append(rc[:, 4:5])
+            # FeatureAlign (:49-55): the 1x1 offset conv reads the DETACHED box prediction (4 -> 72 channels: far
+            # below one MFMA tile, left to ATen), then the deformable conv (+GN) + ReLU
+            offset = torch.nn.functional.conv2d(bbox_pred.detach(), self.feat_align.conv_offset.weight)
+            y = P.deform_conv(cls_feat, offset, self.feat_align.conv_adaption.weight, 1, 1, 1, 1, 4)
+            if self.feat_align.flag_norm:
+                y = P.group_norm(y, self.feat_align.norm.weight, self.feat_align.norm.bias, 32, 1e-5, True)
+            else:
+                y = torch.relu(y)
+            cls_scores.append(P.conv2d(y, self.fcos_cls.weight, self.fcos_cls.bias, 1, 1))
+            bbox_preds.append(bbox_pred.float() * stride)
+            cof_preds.append(P.conv2d(y, self.sip_cof.weight, self.sip_cof.bias, 1, 1))
+            if li < 3:
+                fm.append(reg_feat if li == 0 else P.upsample_bilinear(reg_feat, 2 ** li))
+        lat0 = torch.relu(P.conv2d(torch.cat(fm, 1), self.sip_mask_lat0.weight, self.sip_mask_lat0.bias, 1, 0))
+        lat = torch.relu(P.conv2d(lat0, self.sip_mask_lat.weight, self.sip_mask_lat.bias, 1, 1))
+        return cls_scores, bbox_preds, centernesses, cof_preds, P.upsample_bilinear(lat, 4)
+
     def forward(self, feats):
-        """feats: tuple of 5 NCHW float tensors -> (cls_scores, bbox_preds, centernesses, cof_preds, feat_masks)."""
+        """feats: tuple of 5 NCHW float tensors -> (cls_scores, bbox_preds, centernesses, cof_preds, feat_masks).
+        In training mode with autograd enabled the differentiable path (forward_train) is taken; otherwise the
+        fused static launch plan."""
+        if self.training and torch.is_grad_enabled():
+            return self.forward_train(feats)
         b = feats[0].shape[0]
         sizes = [tuple(f.shape[-2:]) for f in feats]
         eng = self._engine(b, sizes)

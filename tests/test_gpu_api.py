@@ -23,7 +23,7 @@ def det():
     d = build_synthetic_detector(50, seed=3)
     with torch.no_grad():
         d.bbox_head.fcos_cls.bias.fill_(-7.5)
-    return d
+    return d.eval()        # inference fixtures: the reference tests under model.eval() as well
 
 
 def test_head_forward_api_matches_oracle(det):
@@ -153,7 +153,7 @@ def ssd_det():
     sd["bbox_head.fcos_cls.bias"].fill_(-5.5)
     missing = d.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
-    return d
+    return d.eval()
 
 
 def test_ssd_head_forward_matches_oracle(ssd_det):
@@ -373,3 +373,59 @@ def test_sipmask_pp_api_rescoring():
     assert len(cls_segms) == 80 and len(mask_scores) == 80
     assert [len(s) for s in cls_segms] == [len(m) for m in mask_scores]
     assert sum(len(s) for s in cls_segms) == det.shape[0]
+
+
+def test_head_training_step_vs_oracle():
+    """forward_train -> loss -> backward on the HIP autograd ops (conv / deformable conv / GroupNorm / bilinear
+    upsampling forward+backward kernels, fused mask loss, focal loss) for the whole SipMaskHead: losses and the
+    gradient of EVERY head parameter against torch-CPU autograd through the oracle (f32).  This is the WIRING test:
+    every op has its own tight parity test (conv / deform-conv backward 2e-3..1e-2, GroupNorm / upsampling / mask
+    loss 1e-4); here activations and back-propagated gradients are re-rounded to bf16 at each of up to 6 stacked
+    GEMMs, so the bound per parameter tensor is cosine similarity > 0.98 and relative Frobenius error < 0.2
+    (a mis-wired branch shows up as ~1.0: that is how the missing detach() in the oracle was found), 1e-2 on the
+    loss values."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import loss as OL
+    from sipmask_amd.registry import build_head
+    from sipmask_amd import sipmask_head  # noqa: F401
+    head = build_head(dict(type='SipMaskHead', num_classes=81, in_channels=256, stacked_convs=4, feat_channels=256,
+                           strides=[8, 16, 32, 64, 128], center_sampling=True, center_sample_radius=1.5)).cuda()
+    full = OM.init_state_dict(50, seed=13, calibrate=True)
+    sd = {k[len("bbox_head."):]: v for k, v in full.items() if k.startswith("bbox_head.")}
+    sd["fcos_cls.bias"].fill_(-3.0)
+    head.load_state_dict(sd, strict=True)
+    head.train()
+    g = torch.Generator().manual_seed(3)
+    B = 2
+    sizes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    feats = [torch.randn(B, 256, h, w, generator=g).to(torch.bfloat16).float() for h, w in sizes]
+    gtb, gtl, gtm = _synthetic_gt(g, B, 128, 160, 4)
+    # ---- oracle: f32 CPU autograd through head_forward + head_loss
+    osd = {"bbox_head." + k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    oout = OM.head_forward(osd, feats)
+    oloss, aux = OL.head_loss(oout[0], oout[1], oout[2], oout[3], oout[4], gtb, gtl, gtm)
+    assert aux["num_pos"] > 10
+    sum(oloss.values()).backward()
+    # ---- HIP path
+    out = head([f.cuda() for f in feats])
+    metas = [dict(img_shape=(128, 160, 3), pad_shape=(128, 160, 3), scale_factor=1.0) for _ in range(B)]
+    loss = head.loss(*out, [b.cuda() for b in gtb], [l.cuda() for l in gtl], metas, None, gt_masks_list=gtm)
+    for k in loss:
+        a, b = float(loss[k].detach()), float(oloss[k].detach())
+        assert abs(a - b) <= 1e-2 * max(1.0, abs(b)), (k, a, b)
+    sum(loss.values()).backward()
+    bad = []
+    for name, p in head.named_parameters():
+        ref = osd["bbox_head." + name].grad
+        if name.startswith("feat_align.norm") and ref is None:
+            continue
+        assert p.grad is not None, name
+        if ref is None or float(ref.norm()) == 0.0:
+            continue
+        got = p.grad.cpu().float()
+        err = float((got - ref).norm() / ref.norm())
+        cos = float((got * ref).sum() / (got.norm() * ref.norm() + 1e-30))
+        if err > 0.2 or cos < 0.98:
+            bad.append((name, err, cos))
+    assert not bad, sorted(bad, key=lambda t: -t[1])[:40]

@@ -527,6 +527,49 @@ def test_conv2d_backward_vs_torch(cfg):
     assert rel(wd.grad, w.grad) < 1e-2, rel(wd.grad, w.grad)
 
 
+def test_training_layers_vs_torch():
+    """ops.group_norm (+ReLU) and ops.upsample_bilinear, forward and backward, against torch CPU autograd (f32:
+    1e-4 relative to the tensor max), and sm_sgd_step against the torch.optim.SGD update rule."""
+    from sipmask_amd import ops as P, hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    for relu in (True, False):
+        x = torch.randn(2, 64, 9, 11, generator=g).requires_grad_()
+        w = (torch.rand(64, generator=g) + 0.5).requires_grad_()
+        b = torch.randn(64, generator=g).requires_grad_()
+        y = F.group_norm(x, 32, w, b, 1e-5)
+        y = F.relu(y) if relu else y
+        go = torch.randn(y.shape, generator=g)
+        y.backward(go)
+        xd, wd, bd = (t.detach().to(dev).requires_grad_() for t in (x, w, b))
+        yd = P.group_norm(xd, wd, bd, 32, 1e-5, relu)
+        torch.testing.assert_close(yd.detach().cpu(), y.detach(), rtol=1e-4, atol=1e-5)
+        yd.backward(go.to(dev))
+        for a, r in ((xd.grad, x.grad), (wd.grad, w.grad), (bd.grad, b.grad)):
+            assert float((a.cpu() - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-6
+    for f in (2, 4):
+        x = torch.randn(2, 5, 7, 9, generator=g).requires_grad_()
+        y = F.interpolate(x, scale_factor=f, mode="bilinear", align_corners=False)
+        go = torch.randn(y.shape, generator=g)
+        y.backward(go)
+        xd = x.detach().to(dev).requires_grad_()
+        yd = P.upsample_bilinear(xd, f)
+        torch.testing.assert_close(yd.detach().cpu(), y.detach(), rtol=1e-5, atol=1e-6)
+        yd.backward(go.to(dev))
+        torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-5)
+    # SGD with momentum + weight decay, two steps
+    p0 = torch.randn(1000, generator=g)
+    pr = p0.clone().requires_grad_()
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    pd, buf = p0.clone().to(dev), torch.zeros(1000, device=dev)
+    for step in range(2):
+        gr = torch.randn(1000, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        H.sgd_step(pd, gr.to(dev), buf, 0.01, 0.9, 1e-4, step == 0)
+    torch.testing.assert_close(pd.cpu(), pr.detach(), rtol=1e-6, atol=1e-7)
+
+
 def test_det_select_vs_oracle():
     """score -> per-level top-k -> gather/decode (sipmask_head.py:563-591) for a 2-image batch."""
     from sipmask_amd import hip_ops as H

@@ -32,7 +32,7 @@ def vdet():
     sd = OV.init_vis_state_dict(seed=5)
     sd["bbox_head.fcos_cls.bias"].fill_(-4.0)
     d.load_state_dict(sd, strict=True)
-    return d
+    return d.eval()
 
 
 def test_track_kernels_vs_oracle():
