@@ -429,3 +429,38 @@ def test_head_training_step_vs_oracle():
         if err > 0.2 or cos < 0.98:
             bad.append((name, err, cos))
     assert not bad, sorted(bad, key=lambda t: -t[1])[:40]
+
+
+def test_head_train_step_sgd_updates():
+    """dist_train.head_train_step (single rank): HIP forward_train + loss + backward + HipSGD.  The first update
+    obeys the SGD rule with mmdet's paramwise options (bias: lr x2, no weight decay); a few steps on a fixed batch
+    reduce the loss."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd.registry import build_head
+    from sipmask_amd import sipmask_head  # noqa: F401
+    from sipmask_amd.dist_train import HipSGD, head_train_step
+    head = build_head(dict(type='SipMaskHead', num_classes=81, in_channels=256, stacked_convs=4, feat_channels=256,
+                           strides=[8, 16, 32, 64, 128], center_sampling=True, center_sample_radius=1.5)).cuda()
+    sd = {k[len("bbox_head."):]: v for k, v in OM.init_state_dict(50, seed=17, calibrate=True).items()
+          if k.startswith("bbox_head.")}
+    sd["fcos_cls.bias"].fill_(-3.0)
+    head.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    sizes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    feats = [torch.randn(B, 256, h, w, generator=g).cuda() for h, w in sizes]
+    gtb, gtl, gtm = _synthetic_gt(g, B, 128, 160, 4)
+    gtb, gtl = [b.cuda() for b in gtb], [l.cuda() for l in gtl]
+    metas = [dict(img_shape=(128, 160, 3), pad_shape=(128, 160, 3), scale_factor=1.0) for _ in range(B)]
+    opt = HipSGD(head.named_parameters(), lr=0.002, momentum=0.9, weight_decay=1e-4)
+    w0 = head.sip_cof.weight.detach().clone()
+    b0 = head.sip_cof.bias.detach().clone()
+    first = head_train_step(head, feats, gtb, gtl, gtm, metas, opt)
+    gw, gb = head.sip_cof.weight.grad.clone(), head.sip_cof.bias.grad.clone()
+    torch.testing.assert_close(head.sip_cof.weight.detach(), w0 - 0.002 * (gw + 1e-4 * w0), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(head.sip_cof.bias.detach(), b0 - 0.004 * gb, rtol=1e-5, atol=1e-7)
+    losses = [sum(first.values())]
+    for _ in range(4):
+        losses.append(sum(head_train_step(head, feats, gtb, gtl, gtm, metas, opt).values()))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
