@@ -86,7 +86,22 @@ class SipMask(nn.Module):
         assert imgs[0].size(0) == 1                      # base.py:118-119
         return self.simple_test(imgs[0], img_metas[0], **kwargs)
 
+    def extract_feat_train(self, img):
+        """extract_feat (single_stage.py:41-47) as a differentiable graph of HIP autograd ops."""
+        x = self.backbone.forward_train(img)
+        return self.neck.forward_train(x) if self.with_neck else x
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None):
+        """single_stage.py:49-73: losses of one batch.  Backbone (BN frozen, stages <= frozen_stages without a
+        graph), FPN and head run layer by layer on the HIP forward/backward ops; `.backward()` on the summed losses
+        fills every trainable parameter's .grad."""
+        self.bbox_head.train()
+        x = self.extract_feat_train(img)
+        outs = self.bbox_head(x)
+        return self.bbox_head.loss(*outs, gt_bboxes, gt_labels, img_metas, self.train_cfg,
+                                   gt_bboxes_ignore=gt_bboxes_ignore, gt_masks_list=gt_masks)
+
     def forward(self, img, img_meta, return_loss=True, **kwargs):
         if return_loss:
-            raise NotImplementedError("forward_train lands with the backward kernels (SURVEY row a13/a17)")
+            return self.forward_train(img, img_meta, **kwargs)
         return self.forward_test(img, img_meta, **kwargs)

@@ -121,3 +121,16 @@ def head_train_step(head, feats, gt_bboxes, gt_labels, gt_masks, img_metas, opti
         bucketer.finish()
     optimizer.step()
     return {k: float(v.detach()) for k, v in losses.items()}
+
+
+def detector_train_step(det, img, img_metas, gt_bboxes, gt_labels, gt_masks, optimizer, bucketer=None):
+    """One data-parallel training step of the whole detector (BASELINE config #4): SipMask.forward_train (HIP
+    autograd ops for backbone stages 2-4, FPN and head; BN and stage 1 frozen as in the config) -> backward with the
+    bucketed all-reduce overlapped -> SGD.  Returns the loss dict (floats)."""
+    optimizer.zero_grad()
+    losses = det.forward_train(img, img_metas, gt_bboxes, gt_labels, gt_masks=gt_masks)
+    sum(losses.values()).backward()
+    if bucketer is not None:
+        bucketer.finish()
+    optimizer.step()
+    return {k: float(v.detach()) for k, v in losses.items()}

@@ -122,6 +122,44 @@ class Bottleneck(nn.Module):
         self.add_module("bn3", _norm_layer(norm_cfg, planes * 4)[1])
         self.downsample = downsample
 
+    def forward_train(self, x):
+        """resnet.py:205-239 on the HIP autograd ops; the (eval-mode, frozen) BatchNorms are folded into the conv
+        weights inside the graph, so their affine parameters would still receive gradients if they required them."""
+        from . import ops as P
+        out = torch.relu(_conv_bn(x, self.conv1, self.bn1, self.conv1_stride, 0))
+        if self.with_dcn:
+            wo, bo = _pad_cout8(self.conv2.conv_offset.weight, self.conv2.conv_offset.bias)
+            off = P.conv2d(out, wo, bo, 1, 1)[:, :self.conv2.conv_offset.weight.shape[0]]
+            w, b = _fold(self.conv2.weight, self.bn2)
+            out = P.deform_conv(out, off.contiguous(), w, 1, 1, 1, 1, self.conv2.deformable_groups) + b.view(1, -1, 1, 1)
+            out = torch.relu(out)
+        else:
+            out = torch.relu(_conv_bn(out, self.conv2, self.bn2, self.conv2_stride, 1))
+        out = _conv_bn(out, self.conv3, self.bn3, 1, 0)
+        idt = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1],
+                                                         self.downsample[0].stride[0], 0)
+        return torch.relu(out + idt)
+
+
+def _fold(weight, bn):
+    """eval-mode BatchNorm folded into the preceding conv: differentiable in weight (and in bn.weight/bias)."""
+    s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return weight * s.view(-1, 1, 1, 1), bn.bias - bn.running_mean * s
+
+
+def _conv_bn(x, conv, bn, stride, pad):
+    from . import ops as P
+    w, b = _fold(conv.weight, bn)
+    return P.conv2d(x, w, b, stride, pad)
+
+
+def _pad_cout8(w, b):
+    """zero rows up to a multiple of 8 output channels (the GEMM kernels want cout % 8 == 0)"""
+    extra = (-w.shape[0]) % 8
+    if extra == 0:
+        return w, b
+    return torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, extra)), torch.nn.functional.pad(b, (0, extra))
+
 
 @BACKBONES.register_module
 class ResNet(nn.Module):
@@ -163,6 +201,27 @@ class ResNet(nn.Module):
             self.add_module(name, nn.Sequential(*blocks))
             self.res_layers.append(name)
         self._freeze_stages()
+
+    def forward_train(self, x):
+        """resnet.py:501-512 as a differentiable graph (BN always in eval mode: norm_eval, cfg requires_grad=False).
+        Frozen stages run without building a graph.  x: [B,3,H,W] float on the device."""
+        from . import ops as P
+        outs = []
+        with torch.no_grad():
+            x8 = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 5))                      # 3 -> 8 input channels
+            w, b = _fold(torch.nn.functional.pad(self.conv1.weight, (0, 0, 0, 0, 0, 5)), self.bn1)
+            x = torch.relu(P.conv2d(x8, w, b, 2, 3))
+            x = torch.nn.functional.max_pool2d(x, 3, 2, 1)
+        for i, name in enumerate(self.res_layers):
+            frozen = (i + 1) <= self.frozen_stages
+            with torch.set_grad_enabled(torch.is_grad_enabled() and not frozen):
+                for blk in getattr(self, name):
+                    x = blk.forward_train(x)
+            if frozen:
+                x = x.detach()
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
 
     def _freeze_stages(self):
         if self.frozen_stages >= 0:
@@ -225,6 +284,20 @@ class FPN(nn.Module):
         for i in range(num_outs - self.backbone_end_level + start_level):
             self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, stride=2, padding=1, act_cfg=act_cfg,
                                              inplace=False))
+
+    def forward_train(self, inputs):
+        """fpn.py:137-178 (start_level, extra convs on the outputs, ReLU before P7) on the HIP conv autograd op."""
+        from . import ops as P
+        lats = [P.conv2d(inputs[i + self.start_level], lc.conv.weight, lc.conv.bias, 1, 0)
+                for i, lc in enumerate(self.lateral_convs)]
+        for i in range(len(lats) - 1, 0, -1):
+            lats[i - 1] = lats[i - 1] + torch.nn.functional.interpolate(lats[i], size=lats[i - 1].shape[2:], mode='nearest')
+        outs = [P.conv2d(lats[i], self.fpn_convs[i].conv.weight, self.fpn_convs[i].conv.bias, 1, 1)
+                for i in range(len(lats))]
+        for i in range(len(lats), len(self.fpn_convs)):
+            src = outs[-1] if i == len(lats) else torch.relu(outs[-1])
+            outs.append(P.conv2d(src, self.fpn_convs[i].conv.weight, self.fpn_convs[i].conv.bias, 2, 1))
+        return tuple(outs)
 
     def init_weights(self):
         for m in self.modules():
