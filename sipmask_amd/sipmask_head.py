@@ -143,9 +143,10 @@ class SipMaskHead(nn.Module):
             rc = P.conv2d(reg_feat, w_rc, b_rc, 1, 1)
             bbox_pred = scale(rc[:, :4])
             centernesses.append(rc[:, 4:5])
-            # FeatureAlign (:49-55): the 1x1 offset conv reads the DETACHED box prediction (4 -> 72 channels: far
-            # below one MFMA tile, left to ATen), then the deformable conv (+GN) + ReLU
-            offset = torch.nn.functional.conv2d(bbox_pred.detach(), self.feat_align.conv_offset.weight)
+            # FeatureAlign (:49-55): the 1x1 offset conv reads the DETACHED box prediction; 4 -> 72 channels is far
+            # below one MFMA tile, so it is a plain [72,4] matmul per position (library GEMM; as an ATen conv its
+            # weight gradient fell into MIOpen's naive wrw kernel: 28 % of the first profiled training step)
+            offset = torch.einsum('oc,bchw->bohw', self.feat_align.conv_offset.weight.flatten(1), bbox_pred.detach())
             y = P.deform_conv(cls_feat, offset, self.feat_align.conv_adaption.weight, 1, 1, 1, 1, 4)
             if self.feat_align.flag_norm:
                 y = P.group_norm(y, self.feat_align.norm.weight, self.feat_align.norm.bias, 32, 1e-5, True)
