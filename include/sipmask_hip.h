@@ -44,6 +44,8 @@ typedef enum {
 #define SM_CONV_RES_NEAREST 8u   /* y += residual at nearest-neighbour source (FPN top-down,
                                     M/mmdet/models/necks/fpn.py:149-152) */
 #define SM_CONV_IN_RELU 16u      /* x = max(x,0) applied on load (fpn.py:174-175 P7) */
+#define SM_CONV_RELU_NCH 32u     /* y = max(y, 0) on channels < scale_nch only (the maskrcnn-benchmark variant's
+                                    relu(scale(bbox_pred)), SipMask-benchmark/.../sipmask/sipmask.py:155-157) */
 #define SM_CONV_DBG_LINEAR_TILES 0x40000000u /* A/B switch: disable the XCD-aware tile remap */
 #define SM_CONV_DBG_REG_STAGING 0x20000000u  /* A/B switch: register-staged loader instead of LDS-DMA */
 #define SM_CONV_DBG_K32 0x10000000u          /* A/B switch: force 32-wide K steps, 4 blocks per CU */
@@ -230,6 +232,19 @@ int sm_rle_encode(const uint8_t* masks, const int32_t* ndet, const int32_t* rect
                   int wo, int canvas_h, int canvas_w, int max_runs, uint32_t* counts, int32_t* nruns,
                   int32_t* nchars, uint8_t* packed, int64_t packed_cap, int64_t* offsets, void* workspace,
                   sm_stream_t stream);
+
+/* Candidate selection of the maskrcnn-benchmark variant (B/ = SipMask-benchmark/,
+ * B/fcos_core/modeling/rpn/sipmask/inference.py:66-138): per level, every (location, class) pair with
+ * sigmoid(cls) > pre_nms_thresh competes with key sigmoid(cls)*sigmoid(ctr); the best min(count, d->nms_pre)
+ * pairs of each level are decoded (clip_to_image) and gathered.  d->kmax = sum_l min(nms_pre, h_l*w_l*C);
+ * level l owns the slots [cand0_l, cand0_l + nms_pre), unused slots stay empty (zero box, no score).
+ * Outputs: boxes [B][kmax][4], scores [B][C][kmax] class-major DENSE with sqrt(key) at (class of the pair, slot)
+ * and 0 elsewhere (so sm_multiclass_nms with score_thr 0 and ctr = 1 is boxlist_ml_nms: same-label NMS,
+ * B/fcos_core/csrc/cuda/ml_nms.cu), cofs [B][kmax][128], lvl_cnt int32 [B][SM_MAX_LEVELS], ncand[b] = kmax. */
+int64_t sm_pairs_select_workspace(const sm_det_desc* d);
+int sm_pairs_select(const sm_det_desc* d, float pre_nms_thresh, const float* cls, const float* reg, const float* cof,
+                    float* boxes, float* scores, float* cofs, int32_t* lvl_cnt, int32_t* ncand, void* workspace,
+                    sm_stream_t stream);
 
 /* Single-class greedy NMS with the reference op's contract, nms_cuda.nms:
  * dets f32 [n][5] -> keep i64 [<=n] ascending original indices, *nkeep (device).

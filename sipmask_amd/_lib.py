@@ -18,6 +18,7 @@ SM_CONV_OUT_F32 = 2
 SM_CONV_RES_ADD = 4
 SM_CONV_RES_NEAREST = 8
 SM_CONV_IN_RELU = 16
+SM_CONV_RELU_NCH = 32
 
 _i32x5 = C.c_int32 * SM_MAX_LEVELS
 _i64x5 = C.c_int64 * SM_MAX_LEVELS
@@ -89,6 +90,8 @@ PROTOTYPES = {
     "sm_upsample_bilinear_nchw_fwd": (_I, [_P, _P, C.c_int64, _I, _I, _I, _P]),
     "sm_upsample_bilinear_nchw_bwd": (_I, [_P, _P, C.c_int64, _I, _I, _I, _P]),
     "sm_sgd_step": (_I, [_P, _P, _P, C.c_int64, _F, _F, _F, _I, _P]),
+    "sm_pairs_select_workspace": (C.c_int64, [_P]),
+    "sm_pairs_select": (_I, [_P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_rle_workspace": (C.c_int64, [_I, _I, _I, _I]),
     "sm_mask_rects": (_I, [_P, _I, _I, _F, _F, _F, C.c_double, C.c_double, _P, _P]),
     "sm_rle_encode": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),

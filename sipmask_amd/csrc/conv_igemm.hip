@@ -625,6 +625,10 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
       if (a.flags & SM_CONV_RELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (a.flags & SM_CONV_RELU_NCH) {   // ReLU on the Scale()d channels only (B/ bbox_pred, sipmask.py:157)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (c0 + e < a.scale_nch) v[e] = fmaxf(v[e], 0.f);
       }
       const long long o = (out_row0 + m) * a.out_cstride + a.out_coff + c0;
       if (out_f32) {
@@ -910,6 +914,10 @@ __global__ __launch_bounds__(256, 4) void conv_dma32_kernel(const ConvKArgs a) {
         if (a.flags & SM_CONV_RELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (a.flags & SM_CONV_RELU_NCH) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (c0 + e < a.scale_nch) v[e] = fmaxf(v[e], 0.f);
         }
         const long long o = (out_row0 + m) * a.out_cstride + a.out_coff + c0;
         if (out_f32) {

@@ -241,6 +241,102 @@ __global__ __launch_bounds__(256) void det_gather_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------- (location, class) pairs
+// Candidate selection of the maskrcnn-benchmark variant (B/ = SipMask-benchmark/,
+// B/fcos_core/modeling/rpn/sipmask/inference.py:66-138): per level every (location, class) pair with
+// sigmoid(cls) > pre_nms_thresh is a candidate, ranked by sigmoid(cls)*sigmoid(ctr); the best pre_nms_top_n of
+// a level survive; the reported score is the square root.  keys [B][S*C] f32: the product, or -1 for a pair
+// below the threshold.
+__global__ void pair_score_kernel(const float* __restrict__ cls, const float* __restrict__ reg, float* __restrict__ keys,
+                                  const DetArgs a, float thr) {
+  const int S = a.pos0[a.nlev];
+  const long long total = (long long)a.batch * S * a.C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % a.C);
+    const long long bp = i / a.C;
+    const int b = (int)(bp / S);
+    const int p = (int)(bp - (long long)b * S);
+    int lev = 0;
+#pragma unroll
+    for (int l = 1; l < SM_MAX_LEVELS; ++l)
+      if (l < a.nlev && p >= a.pos0[l]) lev = l;
+    const long long row = a.row0[lev] + (long long)b * a.hw[lev] + (p - a.pos0[lev]);
+    const float pc = sigmoidf_acc(cls[row * a.cls_cs + a.cls_co + c]);
+    keys[i] = pc > thr ? __fmul_rn(pc, sigmoidf_acc(reg[row * a.reg_cs + 4])) : -1.f;
+  }
+}
+
+// one block per (level, image): k = min(#candidates, pre_nms_top_n) best pairs of the level (key desc, pair
+// index asc), written to the level's slot range of the per-image candidate list; lvl_cnt[b][l] = k
+__global__ __launch_bounds__(TK_THREADS) void pair_topk_kernel(const float* __restrict__ keys,
+                                                                int32_t* __restrict__ cand_pair,
+                                                                int32_t* __restrict__ lvl_cnt, const DetArgs a) {
+  __shared__ TopkSmem sm;
+  __shared__ int s_cnt;
+  const int lev = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int S = a.pos0[a.nlev];
+  const int n = a.hw[lev] * a.C;
+  const float* kl = keys + ((long long)b * S + a.pos0[lev]) * a.C;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int i = tid; i < n; i += TK_THREADS) c += kl[i] >= 0.f ? 1 : 0;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+  if ((tid & 63) == 0 && c) atomicAdd(&s_cnt, c);
+  __syncthreads();
+  const int k = min(s_cnt, a.nms_pre);
+  if (tid == 0) lvl_cnt[b * SM_MAX_LEVELS + lev] = k;
+  if (k <= 0) return;
+  __syncthreads();
+  block_topk(kl, n, k, sm);
+  int32_t* out = cand_pair + (long long)b * a.kmax + a.cand0[lev];
+  for (int i = tid; i < k; i += TK_THREADS) out[i] = (int32_t)(0xffffffffu - (uint32_t)(sm.sel[i] & 0xffffffffull));
+}
+
+// decode + gather of the selected pairs.  Slot k of an image belongs to level l iff cand0[l] <= k < cand0[l+1];
+// slots past the level's count stay empty: zero box, no score (the dense class-major score matrix is zeroed
+// by the host wrapper, and the NMS takes only scores > 0).
+__global__ __launch_bounds__(128) void pair_gather_kernel(const float* __restrict__ cls, const float* __restrict__ reg,
+                                                          const float* __restrict__ cof, const float* __restrict__ keys,
+                                                          const int32_t* __restrict__ cand_pair,
+                                                          const int32_t* __restrict__ lvl_cnt, float* __restrict__ boxes,
+                                                          float* __restrict__ scores, float* __restrict__ cofs,
+                                                          const DetArgs a) {
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  int lev = 0;
+#pragma unroll
+  for (int l = 1; l < SM_MAX_LEVELS; ++l)
+    if (l < a.nlev && k >= a.cand0[l]) lev = l;
+  const long long o = (long long)b * a.kmax + k;
+  if (k - a.cand0[lev] >= lvl_cnt[b * SM_MAX_LEVELS + lev]) {
+    if (tid < 4) boxes[o * 4 + tid] = 0.f;
+    cofs[o * 128 + tid] = 0.f;
+    return;
+  }
+  const int S = a.pos0[a.nlev];
+  const int pair = cand_pair[o];
+  const int pos = pair / a.C, c = pair - pos * a.C;
+  const long long row = a.row0[lev] + (long long)b * a.hw[lev] + pos;
+  if (tid == 0) {
+    const float* rp = reg + row * a.reg_cs;
+    const int s = a.stride[lev];
+    const int py = pos / a.w[lev], px = pos - py * a.w[lev];
+    const float x = (float)(px * s) + (float)(s / 2), y = (float)(py * s) + (float)(s / 2);
+    const float xmax = (float)(a.img_w - 1), ymax = (float)(a.img_h - 1);   // clip_to_image, TO_REMOVE = 1
+    const float fs = a.reg_prescaled ? 1.f : (float)s;                       // bbox_pred * fpn_strides[l] (sipmask.py:161)
+    const float x1 = fminf(fmaxf(__fsub_rn(x, __fmul_rn(rp[0], fs)), 0.f), xmax);
+    const float y1 = fminf(fmaxf(__fsub_rn(y, __fmul_rn(rp[1], fs)), 0.f), ymax);
+    const float x2 = fminf(fmaxf(__fadd_rn(x, __fmul_rn(rp[2], fs)), 0.f), xmax);
+    const float y2 = fminf(fmaxf(__fadd_rn(y, __fmul_rn(rp[3], fs)), 0.f), ymax);
+    *reinterpret_cast<float4*>(boxes + o * 4) = make_float4(x1, y1, x2, y2);
+    const float key = keys[((long long)b * S + a.pos0[lev] + pos) * a.C + c];
+    scores[((long long)b * a.C + c) * a.kmax + k] = __fsqrt_rn(key);          // torch.sqrt(per_box_cls), inference.py:133
+  }
+  cofs[o * 128 + tid] = cof[row * a.cof_cs + a.cof_co + tid];
+}
+
 // ------------------------------------------------------------------------------- NMS
 // devIoU, nms_kernel.cu:14-22 (float32, +1 widths); written so the compiler cannot contract
 __device__ __forceinline__ float iou_plus1(const float4 a, const float4 b) {
@@ -339,6 +435,7 @@ struct NmsArgs {
   float score_thr, iou_thr;
   int always_sort;   // fast_nms: the final list is always sorted by score (sipmask_head.py:902)
   int top_k;         // fast_nms: boxes kept per class before the IoU test (:871)
+  unsigned char* ext_kept;   // optional [B][C][P] x 20 bytes: kept boxes + indices outside LDS (P > 4096)
 };
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __restrict__ boxes,
@@ -353,6 +450,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __r
   float4* kept_box = reinterpret_cast<float4*>(dsm + (size_t)a.P * 8);
   uint32_t* kept_idx = reinterpret_cast<uint32_t*>(dsm + (size_t)a.P * 24);
   const int c = blockIdx.x, b = blockIdx.y;
+  if (a.ext_kept != nullptr) {   // candidate lists too long for keys + kept boxes in LDS: kept list in HBM/L2
+    unsigned char* e = a.ext_kept + ((size_t)b * a.C + c) * (size_t)a.P * 20;
+    kept_box = reinterpret_cast<float4*>(e);
+    kept_idx = reinterpret_cast<uint32_t*>(e + (size_t)a.P * 16);
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int K = ncand[b];
   const float* sc = scores + ((long long)b * a.C + c) * a.kmax;   // class-major: contiguous over candidates
@@ -650,9 +752,72 @@ extern "C" int sm_det_select(const sm_det_desc* d, const float* cls, const float
   return SM_OK;
 }
 
+// per-level candidate capacity of the pair selection: min(pre_nms_top_n, hw*C)
+static int fill_pair_args(const sm_det_desc* d, DetArgs& a) {
+  if (!d || d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1 || d->num_classes < 1) return SM_ERR_BAD_SHAPE;
+  if (d->nms_pre < 1 || d->nms_pre > TK_CAP) return SM_ERR_UNSUPPORTED;
+  sm_det_desc t = *d;
+  int k = 0;
+  for (int l = 0; l < d->nlev; ++l) {
+    const long long npair = (long long)d->h[l] * d->w[l] * d->num_classes;
+    k += (int)(npair < d->nms_pre ? npair : d->nms_pre);
+  }
+  if (k != d->kmax) return SM_ERR_BAD_SHAPE;
+  // fill_det_args derives kmax from min(nms_pre, hw): give it what it expects, then restore the pair layout
+  int kk = 0;
+  for (int l = 0; l < d->nlev; ++l) kk += (d->h[l] * d->w[l] > d->nms_pre) ? d->nms_pre : d->h[l] * d->w[l];
+  t.kmax = kk;
+  const int st = fill_det_args(&t, a);
+  if (st != SM_OK) return st;
+  int c0 = 0;
+  for (int l = 0; l <= SM_MAX_LEVELS; ++l) {
+    a.cand0[l] = c0;
+    if (l < d->nlev) {
+      const long long npair = (long long)d->h[l] * d->w[l] * d->num_classes;
+      c0 += (int)(npair < d->nms_pre ? npair : d->nms_pre);
+    }
+  }
+  a.kmax = d->kmax;
+  return SM_OK;
+}
+
+extern "C" int64_t sm_pairs_select_workspace(const sm_det_desc* d) {
+  DetArgs a;
+  if (fill_pair_args(d, a) != SM_OK) return -1;
+  return (int64_t)d->batch * a.pos0[d->nlev] * d->num_classes * sizeof(float) + (int64_t)d->batch * d->kmax * 4 + 256;
+}
+
+extern "C" int sm_pairs_select(const sm_det_desc* d, float pre_nms_thresh, const float* cls, const float* reg,
+                               const float* cof, float* boxes, float* scores, float* cofs, int32_t* lvl_cnt,
+                               int32_t* ncand, void* workspace, sm_stream_t stream) {
+  if (!cls || !reg || !cof || !boxes || !scores || !cofs || !lvl_cnt || !ncand || !workspace) return SM_ERR_BAD_ARG;
+  DetArgs a;
+  const int st = fill_pair_args(d, a);
+  if (st != SM_OK) return st;
+  if (a.batch > 1024) return SM_ERR_UNSUPPORTED;
+  hipStream_t s = sm_hip_stream(stream);
+  float* keys = (float*)workspace;
+  const size_t key_bytes = (size_t)a.batch * a.pos0[a.nlev] * a.C * sizeof(float);
+  int32_t* cand_pair = (int32_t*)((char*)workspace + (key_bytes + 255) / 256 * 256);
+  const long long total = (long long)a.batch * a.pos0[a.nlev] * a.C;
+  int g = (int)((total + 255) / 256);
+  if (g > 16384) g = 16384;
+  if (hipMemsetAsync(scores, 0, (size_t)a.batch * a.C * a.kmax * sizeof(float), s) != hipSuccess) return SM_ERR_LAUNCH;
+  hipLaunchKernelGGL(pair_score_kernel, dim3(g), dim3(256), 0, s, cls, reg, keys, a, pre_nms_thresh);
+  hipLaunchKernelGGL(pair_topk_kernel, dim3(a.nlev, a.batch), dim3(TK_THREADS), 0, s, keys, cand_pair, lvl_cnt, a);
+  hipLaunchKernelGGL(pair_gather_kernel, dim3(a.kmax, a.batch), dim3(128), 0, s, cls, reg, cof, keys, cand_pair, lvl_cnt,
+                     boxes, scores, cofs, a);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(1024), 0, s, ncand, a.batch, a.kmax);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
 extern "C" int64_t sm_multiclass_nms_workspace(int batch, int kmax, int num_classes) {
   // cls_keep i32 [B][C][kmax] + flat_key f32 [B][C][kmax] + cls_cnt i32 [B][C]
-  return (int64_t)batch * num_classes * kmax * 8 + (int64_t)batch * num_classes * 4;
+  int64_t n = (int64_t)batch * num_classes * kmax * 8 + (int64_t)batch * num_classes * 4;
+  const int64_t P = next_pow2(kmax);
+  if (P * 28 > 150 * 1024) n = (n + 255) / 256 * 256 + (int64_t)batch * num_classes * P * 20;   // external kept lists
+  return n;
 }
 
 extern "C" int sm_multiclass_nms(const float* boxes, const float* scores, const float* ctr, const int32_t* ncand,
@@ -672,12 +837,17 @@ extern "C" int sm_multiclass_nms(const float* boxes, const float* scores, const 
   a.iou_thr = iou_thr;
   a.always_sort = 0;
   a.top_k = 0;
-  const size_t lds = (size_t)a.P * 28;
-  if (lds > 160 * 1024) return SM_ERR_UNSUPPORTED;
+  a.ext_kept = nullptr;
+  size_t lds = (size_t)a.P * 28;
   hipStream_t s = sm_hip_stream(stream);
   int32_t* cls_keep = (int32_t*)workspace;
   float* flat_key = (float*)((char*)workspace + (size_t)batch * num_classes * kmax * 4);
   int32_t* cls_cnt = (int32_t*)((char*)workspace + (size_t)batch * num_classes * kmax * 8);
+  if (lds > 150 * 1024) {        // long candidate lists (the 5 x 1000 pairs of the B/ variant): keys only in LDS
+    lds = (size_t)a.P * 8;
+    if (lds > 150 * 1024) return SM_ERR_UNSUPPORTED;
+    a.ext_kept = (unsigned char*)workspace + (((size_t)batch * num_classes * kmax * 8 + (size_t)batch * num_classes * 4 + 255) / 256) * 256;
+  }
   if (hipFuncSetAttribute((const void*)nms_class_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return SM_ERR_LAUNCH;
@@ -706,6 +876,7 @@ extern "C" int sm_fast_nms(const float* boxes, const float* scores, const float*
   a.iou_thr = iou_thr;
   a.always_sort = 1;
   a.top_k = top_k;
+  a.ext_kept = nullptr;
   hipStream_t s = sm_hip_stream(stream);
   // same workspace layout as sm_multiclass_nms: cls_keep | flat_key | cls_cnt
   int32_t* cls_keep = (int32_t*)workspace;

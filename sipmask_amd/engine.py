@@ -111,7 +111,7 @@ class SipMaskEngine:
 
     def __init__(self, state_dict, batch, img_hw, depth=50, test_cfg=None, num_classes=81, device="cuda",
                  strides=(8, 16, 32, 64, 128), img_shape=None, head_sizes=None, ssd_flag=False, scale_factor=1.0,
-                 rescale=False, vis=False):
+                 rescale=False, vis=False, benchmark=None):
         _lib.load()   # fail loudly before anything else if the HIP library is missing
         if not torch.cuda.is_available():
             raise RuntimeError("SipMaskEngine needs a HIP device")
@@ -132,6 +132,9 @@ class SipMaskEngine:
         # cfg.max_per_img, mask threshold 0.5, crop/upsample scaled only when rescale (:734-764)
         self.vis = bool(vis)
         self.mask_thr = 0.5 if self.vis else 0.4
+        # maskrcnn-benchmark variant (B/ = SipMask-benchmark/): dict(pre_nms_thresh, pre_nms_top_n, nms_thresh,
+        # post_top_n) -> relu(scale(bbox_pred)), (location, class)-pair candidates, same-label NMS
+        self.benchmark = dict(benchmark) if benchmark else None
         self.steps = []        # (label, callable)
         self.convs = []        # _Conv objects (for FLOP accounting / per-kernel timing)
         self.head_start = 0
@@ -146,12 +149,12 @@ class SipMaskEngine:
 
     @classmethod
     def for_head(cls, state_dict, batch, sizes, num_classes=81, strides=(8, 16, 32, 64, 128), test_cfg=None,
-                 img_shape=None, ssd_flag=False, vis=False):
+                 img_shape=None, ssd_flag=False, vis=False, benchmark=None):
         """Plan for SipMaskHead.forward / get_bboxes alone (features come from the caller)."""
         h0, w0 = sizes[0]
         img_hw = (h0 * strides[0], w0 * strides[0])
         return cls(state_dict, batch, img_hw, 50, test_cfg, num_classes, "cuda", strides,
-                   img_shape or (img_hw[0], img_hw[1], 3), head_sizes=list(sizes), ssd_flag=ssd_flag, vis=vis)
+                   img_shape or (img_hw[0], img_hw[1], 3), head_sizes=list(sizes), ssd_flag=ssd_flag, vis=vis, benchmark=benchmark)
 
     def load_pyramid(self, feats):
         """copy caller features (tuple of NCHW float tensors) into the bf16 pyramid tensor"""
@@ -297,9 +300,9 @@ class SipMaskEngine:
             for i in range(n):
                 y = self._buf(lv.rows, 256)
                 name = "%s_convs.%d" % (kind, i)
-                if self.flag_norm:
-                    c = self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"], None, B, sizes, row0,
-                                             x, 256, 1, 1, y, row0, 256))
+                if self.flag_norm:     # a conv bias in front of GN exists in the B/ variant only (sipmask.py:70-79)
+                    c = self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"],
+                                             sd.get(h + name + ".conv.bias"), B, sizes, row0, x, 256, 1, 1, y, row0, 256))
                     self._gn(name, y, sd[h + name + ".gn.weight"], sd[h + name + ".gn.bias"], conv=c)
                 else:
                     self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"],
@@ -317,13 +320,15 @@ class SipMaskEngine:
         self.reg_out = self._buf(lv.rows, 8, torch.float32)
         self.reg_out.zero_()
         self._add_conv(_Conv(self, "head.reg_ctr", w_rc, b_rc, B, sizes, row0, self.reg_feat, 256, 1, 1, self.reg_out,
-                             row0, 8, flags=SM_CONV_OUT_F32, scale_nch=4, level_scale=scales))
+                             row0, 8, flags=SM_CONV_OUT_F32 | (_lib.SM_CONV_RELU_NCH if self.benchmark else 0),
+                             scale_nch=4, level_scale=scales))
         # FeatureAlign: offset = conv1x1(bbox_pred), y = relu(GN(deform_conv(cls_feat, offset)))
         self.w_off = sd[h + "feat_align.conv_offset.weight"].float().view(72, 4).to(dev).contiguous()
         self.offsets = self._buf(lv.rows, 72, torch.float32)
         self._add("offset", lambda: H.offset_linear(self.reg_out, 8, self.w_off, lv, self.offsets))
         self.aligned = self._buf(lv.rows, 256)
-        c = self._add_conv(_Conv(self, "head.feat_align", sd[h + "feat_align.conv_adaption.weight"], None, B, sizes,
+        c = self._add_conv(_Conv(self, "head.feat_align", sd[h + "feat_align.conv_adaption.weight"],
+                                 sd.get(h + "feat_align.conv_adaption.bias"), B, sizes,
                                  row0, self.cls_feat, 256, 1, 1, self.aligned, row0, 256, deform_groups=4,
                                  offset=self.offsets, flags=0 if self.flag_norm else SM_CONV_RELU))
         if self.flag_norm:                                 # FeatureAlign.forward, sipmask_head.py:49-55
@@ -387,8 +392,37 @@ class SipMaskEngine:
                                  B, [(h0, w0)], [0], self.track_cat, 768, 1, 0, self.track_feats, [0], 512,
                                  flags=SM_CONV_OUT_F32))
 
+    def _build_post_benchmark(self):
+        """SipMaskPostProcessor (B/fcos_core/modeling/rpn/sipmask/inference.py:66-236) for a batch whose images share
+        one size: pair selection -> same-label NMS -> top post_top_n -> fused mask assembly."""
+        B, lv, bm = self.batch, self.lv, self.benchmark
+        npre = int(bm["pre_nms_top_n"])
+        kmax = sum(min(npre, h * w * self.ncls) for h, w in lv.sizes)
+        self.det_desc = H.make_det_desc(B, lv.sizes, self.strides, lv.row0, self.ncls, self.ncc, 0, self.ncc,
+                                        self.ncls, 8, npre, self.img_shape[0], self.img_shape[1], kmax=kmax)
+        self.sel = H.pairs_select_alloc(self.det_desc, self.device)
+        self.max_num = int(bm["post_top_n"])
+        self.nms_out = H.multiclass_nms_alloc(B, kmax, self.ncls, self.max_num, self.device)
+        self.box_mul, self.up, (self.ho, self.wo) = H.post_geometry(self.hm, self.wm, self.scale_factor, None)
+        sf = float(self.scale_factor)
+        self.up = (2.0 / sf, 2.0 / sf)                # crop boxes / 2, upsample 2 / scale_factor (inference.py:205-208)
+        import math
+        self.ho, self.wo = int(math.floor(self.hm * self.up[0])), int(math.floor(self.wm * self.up[1]))
+        self.pitch = (self.wo + 3) // 4 * 4
+        self.masks = torch.zeros(B, self.max_num, self.ho, self.pitch, dtype=torch.uint8, device=self.device)
+        self.rescorer, self.track_feats = None, None
+        self._add("det_select", lambda: H.pairs_select(self.det_desc, bm["pre_nms_thresh"], self.cls_cof, self.reg_out,
+                                                       self.cls_cof, self.sel))
+        self._add("nms", lambda: H.multiclass_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"],
+                                                  self.sel["ncand"], 0.0, bm["nms_thresh"], self.max_num, self.nms_out))
+        self._add("mask_assemble", lambda: H.mask_assemble(
+            self.basis, True, self.sel["cofs"], self.nms_out["keep"], self.nms_out["det"], self.nms_out["ndet"],
+            self.hm, self.wm, self.ho, self.wo, 1.0, 2.0, self.up, 0.4, self.masks))
+
     def _build_post(self):
         """get_bboxes (sipmask_head.py:500-633) for all images of the batch, device resident."""
+        if self.benchmark:
+            return self._build_post_benchmark()
         B, lv, cfg = self.batch, self.lv, self.cfg
         self.det_desc = H.make_det_desc(B, lv.sizes, self.strides, lv.row0, self.ncls, self.ncc, 0, self.ncc,
                                         self.ncls, 8, cfg["nms_pre"], self.img_shape[0], self.img_shape[1],

@@ -216,19 +216,21 @@ def post_geometry(hm, wm, scale_factor, rescale, ssd_flag=False):
 
 
 def make_det_desc(batch, sizes, strides, row0, num_classes, cls_cstride, cls_coff, cof_cstride, cof_coff,
-                  reg_cstride, nms_pre, img_h, img_w, scale_factor=1.0, rescale=False, reg_prescaled=False):
+                  reg_cstride, nms_pre, img_h, img_w, scale_factor=1.0, rescale=False, reg_prescaled=False, kmax=None):
     d = DetDesc()
     d.batch, d.nlev, d.num_classes = batch, len(sizes), num_classes
-    kmax = 0
+    ksum = 0
     for l, (h, w) in enumerate(sizes):
         d.h[l], d.w[l], d.stride[l], d.row0[l] = h, w, strides[l], row0[l]
-        kmax += min(nms_pre, h * w) if nms_pre > 0 else h * w
+        ksum += min(nms_pre, h * w) if nms_pre > 0 else h * w
     d.cls_cstride, d.cls_coff, d.cof_cstride, d.cof_coff = cls_cstride, cls_coff, cof_cstride, cof_coff
-    d.reg_cstride, d.nms_pre, d.img_h, d.img_w, d.kmax = reg_cstride, nms_pre, img_h, img_w, kmax
+    d.reg_cstride, d.nms_pre, d.img_h, d.img_w, d.kmax = reg_cstride, nms_pre, img_h, img_w, ksum
     for i, v in enumerate(scale4(scale_factor)):
         d.scale_factor[i] = v
     d.rescale = int(bool(rescale))
     d.reg_prescaled = int(bool(reg_prescaled))
+    if kmax is not None:          # pair selection (sm_pairs_select): sum_l min(nms_pre, h*w*C)
+        d.kmax = int(kmax)
     return d
 
 
@@ -271,6 +273,29 @@ def multiclass_nms(boxes, scores, ctr, ncand, score_thr, iou_thr, max_num, out):
                                      float(score_thr), float(iou_thr), int(max_num), _lib.ptr(out["det"]),
                                      _lib.ptr(out["labels"]), _lib.ptr(out["keep"]), _lib.ptr(out["ndet"]),
                                      _lib.ptr(out["ws_nms"]), _lib.stream_ptr()), "sm_multiclass_nms")
+
+
+def pairs_select_alloc(desc, device):
+    lib = _lib.load()
+    b, k, c = desc.batch, desc.kmax, desc.num_classes
+    ws = lib.sm_pairs_select_workspace(C.byref(desc))
+    if ws < 0:
+        raise ValueError("invalid pair-selection descriptor")
+    return dict(boxes=torch.zeros(b, k, 4, dtype=torch.float32, device=device),
+                scores=torch.zeros(b, c, k, dtype=torch.float32, device=device),
+                ctr=torch.ones(b, k, dtype=torch.float32, device=device),
+                cofs=torch.zeros(b, k, 128, dtype=torch.float32, device=device),
+                lvl_cnt=torch.zeros(b, SM_MAX_LEVELS, dtype=torch.int32, device=device),
+                ncand=torch.zeros(b, dtype=torch.int32, device=device),
+                ws=torch.empty(int(ws), dtype=torch.uint8, device=device))
+
+
+def pairs_select(desc, pre_nms_thresh, cls, reg, cof, out):
+    lib = _lib.load()
+    _lib.check(lib.sm_pairs_select(C.byref(desc), float(pre_nms_thresh), _lib.ptr(cls), _lib.ptr(reg), _lib.ptr(cof),
+                                   _lib.ptr(out["boxes"]), _lib.ptr(out["scores"]), _lib.ptr(out["cofs"]),
+                                   _lib.ptr(out["lvl_cnt"]), _lib.ptr(out["ncand"]), _lib.ptr(out["ws"]),
+                                   _lib.stream_ptr()), "sm_pairs_select")
 
 
 def fast_nms(boxes, scores, ctr, ncand, score_thr, iou_thr, top_k, max_num, out):
