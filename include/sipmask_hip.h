@@ -309,6 +309,15 @@ int sm_mask_loss_bwd(const float* basis, int basis_hwc, const float* cof, const 
                      const int64_t* idx_gt, int n, int hm, int wm, const float* grad_sum, float* grad_cof,
                      float* grad_basis, sm_stream_t stream);
 
+/* ---- input pipeline ------------------------------------------------------------------------- */
+
+/* Resize (cv2.INTER_LINEAR geometry, result rounded to uint8 as cv2.resize returns it) -> Normalize ((x - mean) / std,
+ * optional BGR->RGB first) -> Pad (zeros) -> float CHW, one launch per image.  Replaces the CPU transforms of
+ * M/mmdet/datasets/pipelines/transforms.py (Resize :24-175, Normalize :362-403, Pad :405-455) + ImageToTensor.
+ * src uint8 HWC [src_h][src_w][3] on the device; out_chw f32 [3][pad_h][pad_w]; mean/std host float[3]. */
+int sm_preprocess_u8(const uint8_t* src, int src_h, int src_w, int new_h, int new_w, int pad_h, int pad_w,
+                     const float* mean, const float* std, int to_rgb, float* out_chw, sm_stream_t stream);
+
 /* ---- training-path layers on f32 NCHW tensors ------------------------------------------ */
 
 /* nn.GroupNorm (+ReLU) as used by the head's ConvModules / FeatureAlign (conv_module.py:116-120,

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "sm_sgd_step": (_I, [_P, _P, _P, C.c_int64, _F, _F, _F, _I, _P]),
     "sm_pairs_select_workspace": (C.c_int64, [_P]),
     "sm_pairs_select": (_I, [_P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sm_preprocess_u8": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "sm_rle_workspace": (C.c_int64, [_I, _I, _I, _I]),
     "sm_mask_rects": (_I, [_P, _I, _I, _F, _F, _F, C.c_double, C.c_double, _P, _P]),
     "sm_rle_encode": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),

@@ -570,6 +570,38 @@ def test_training_layers_vs_torch():
     torch.testing.assert_close(pd.cpu(), pr.detach(), rtol=1e-6, atol=1e-7)
 
 
+def test_input_pipeline_vs_oracle():
+    """sm_preprocess_u8 (resize keep-ratio + normalise + pad + CHW) == the numpy restatement: identical except
+    where the float interpolation lands within rounding distance of .5 (<= 1 grey level on < 0.1 % of the pixels)."""
+    from sipmask_amd.input_pipeline import prepare_batch
+    from oracle import pipeline as OP
+    dev = _dev()
+    rng = np.random.RandomState(3)
+    imgs = [rng.randint(0, 256, (480, 640, 3)).astype(np.uint8), rng.randint(0, 256, (375, 500, 3)).astype(np.uint8),
+            rng.randint(0, 256, (900, 1400, 3)).astype(np.uint8)]
+    # smooth content as well (noise exercises the rounding edge, gradients the geometry)
+    yy, xx = np.mgrid[:480, :640]
+    imgs[0][..., 1] = ((yy * 0.3 + xx * 0.2) % 256).astype(np.uint8)
+    batch, metas = prepare_batch([torch.from_numpy(i).to(dev) for i in imgs], img_scale=(1333, 800))
+    hp, wp = batch.shape[-2:]
+    assert hp % 32 == 0 and wp % 32 == 0
+    for i, im in enumerate(imgs):
+        ref, meta = OP.prepare(im, (1333, 800))
+        assert metas[i]["img_shape"] == meta["img_shape"] and metas[i]["ori_shape"] == meta["ori_shape"]
+        assert abs(metas[i]["scale_factor"] - meta["scale_factor"]) < 1e-12
+        nh, nw = meta["img_shape"][:2]
+        got = batch[i].cpu().numpy()
+        d = np.abs(got[:, :nh, :nw] - ref[:, :nh, :nw])
+        assert d.max() <= 1.0 + 1e-4 and (d > 1e-3).mean() < 1e-3, (d.max(), (d > 1e-3).mean())
+        assert np.abs(got[:, nh:, :]).sum() == 0 and np.abs(got[:, :, nw:]).sum() == 0       # Pad with zeros
+    # SSD-style keep_ratio=False: scale factors [w, h, w, h]
+    b2, m2 = prepare_batch([torch.from_numpy(imgs[1]).to(dev)], img_scale=(544, 544), keep_ratio=False)
+    assert tuple(b2.shape) == (1, 3, 544, 544) and m2[0]["scale_factor"].shape == (4,)
+    r2 = OP.resize_bilinear_u8(imgs[1], 544, 544).astype(np.float32) - np.array([102.9801, 115.9465, 122.7717], np.float32)
+    d = np.abs(b2[0].cpu().numpy() - r2.transpose(2, 0, 1))
+    assert d.max() <= 1.0 + 1e-4 and (d > 1e-3).mean() < 1e-3
+
+
 def test_det_select_vs_oracle():
     """score -> per-level top-k -> gather/decode (sipmask_head.py:563-591) for a 2-image batch."""
     from sipmask_amd import hip_ops as H
