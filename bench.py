@@ -217,7 +217,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_mb_per_launch": round(towers[0].bytes / 1e6, 1),
-                         "kernel": "conv_igemm_kernel<2,2,2,2,false,true> (LDS-DMA, 128x128 tile, 64-wide K steps, GroupNorm "
+                         "kernel": "conv_igemm_kernel<2,2,2,2,false,true,0> (LDS-DMA, 128x128 tile, 64-wide K steps, GroupNorm "
                                    "statistics fused) = tower 3x3 256->256 over 5 FPN levels (M=%d,N=256,K=2304)"
                                    % (B * 22400),
                          "gflop_per_launch": round(tower_flops / 1e9, 2), "ms_per_launch": round(tower_ms, 4),
