@@ -51,6 +51,7 @@ typedef enum {
 #define SM_CONV_DBG_K32 0x10000000u          /* A/B switch: force 32-wide K steps, 4 blocks per CU */
 #define SM_CONV_DBG_K64 0x08000000u          /* A/B switch: force 64-wide K steps, 2 blocks per CU */
 #define SM_CONV_DBG_BIG_TILES 0x04000000u    /* A/B switch: never shrink tiles for occupancy */
+#define SM_CONV_DBG_LDS_EPILOGUE 0x01000000u /* A/B switch: LDS-staged epilogue in the 32-wide-K kernel (default: registers) */
 #define SM_CONV_DBG_WARP_SPEC 0x02000000u    /* A/B switch: 8-wave producer/consumer variant of the 64-wide-K kernel */
 
 /* One (multi-level) 2-D convolution as an implicit GEMM.  Replaces the ATen/cuDNN

@@ -833,10 +833,90 @@ __global__ __launch_bounds__(256, 4) void conv_dma32_kernel(const ConvKArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue in two half-tile passes (positions [p*HROWS, (p+1)*HROWS))
   const float lscale = a.level_scale[lev];
   const long long out_row0 = a.out_row0[lev];
   const bool out_f32 = a.flags & SM_CONV_OUT_F32;
+  // ---- register epilogue (guide T21): the MFMA C layout leaves lanes i / i+32 with adjacent 4-cout groups of one
+  // position; one v_permlane32_swap per dword turns each pair of groups into 8 consecutive couts per lane, i.e.
+  // ONE 16-byte bf16 store (and one 16-byte residual load) per lane -- no LDS round trip, no barrier.  These
+  // launches (1x1 convs, K <= 1152) run 2-36 K steps per tile, so the LDS-staged epilogue was most of their time.
+  const bool has_res0 = a.flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST);
+  const bool reg_epi = !(a.flags & SM_CONV_DBG_LDS_EPILOGUE) && (a.cout & 7) == 0 && (a.out_cstride & 7) == 0 &&
+                       (a.out_coff & 7) == 0 && (!has_res0 || (a.res_cstride & 7) == 0);
+  if (reg_epi) {
+#pragma unroll
+    for (int tp = 0; tp < TPOS; ++tp) {
+      const int m = m0 + wpos * TPOS * 32 + tp * 32 + l31;
+      long long rrow = 0;
+      if (has_res0 && m < M) {
+        if (a.flags & SM_CONV_RES_ADD) {
+          rrow = out_row0 + m;
+        } else {
+          const int n = m / HoWo;
+          const int rem = m - n * HoWo;
+          const int ho = rem / Wo;
+          const int wo = rem - ho * Wo;
+          const int rh = a.res_h[lev], rw = a.res_w[lev];
+          const int sh = min((int)floorf((float)ho * ((float)rh / (float)Ho)), rh - 1);
+          const int sw = min((int)floorf((float)wo * ((float)rw / (float)Wo)), rw - 1);
+          rrow = a.res_row0[lev] + ((long long)n * rh + sh) * rw + sw;
+        }
+      }
+#pragma unroll
+      for (int tc = 0; tc < TCO; ++tc) {
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t lo = __float_as_uint(acc[tc][tp][4 * (2 * qp) + e]);
+            const uint32_t hi = __float_as_uint(acc[tc][tp][4 * (2 * qp + 1) + e]);
+            const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+            v[e] = __uint_as_float(r[0]);       // lanes 0-31: own group 2qp      | lanes 32-63: lower half's group 2qp+1
+            v[4 + e] = __uint_as_float(r[1]);   // lanes 0-31: upper's group 2qp  | lanes 32-63: own group 2qp+1
+          }
+          const int c0 = nt * BCO + wco * TCO * 32 + tc * 32 + 8 * (2 * qp + khalf);
+          if (m >= M || c0 >= a.cout) continue;
+          if (a.bias != nullptr) {
+            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + c0);
+            const float4 b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 4);
+            v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w;
+            v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
+          }
+          if (c0 < a.scale_nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (c0 + e < a.scale_nch) v[e] *= lscale;
+          }
+          if (has_res0) {
+            float f[8];
+            unpack_bf16x8(*reinterpret_cast<const u32x4*>(a.res + rrow * a.res_cstride + c0), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += f[e];
+          }
+          if (a.flags & SM_CONV_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (a.flags & SM_CONV_RELU_NCH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (c0 + e < a.scale_nch) v[e] = fmaxf(v[e], 0.f);
+          }
+          const long long o = (out_row0 + m) * a.out_cstride + a.out_coff + c0;
+          if (out_f32) {
+            float* yp = reinterpret_cast<float*>(a.y) + o;
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(a.y) + o) = pack_bf16x8_v(v);
+          }
+        }
+      }
+    }
+    return;
+  }
+  // ---- LDS-staged epilogue in two half-tile passes (positions [p*HROWS, (p+1)*HROWS)): unaligned channel
+  // counts / strides, or the A/B debug flag
   float* E = reinterpret_cast<float*>(smem);
   constexpr int CPR = BCO / 8;
   constexpr int RPP = 256 / CPR;

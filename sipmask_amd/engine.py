@@ -18,6 +18,7 @@ from . import hip_ops as H
 from ._lib import SM_CONV_RELU, SM_CONV_OUT_F32, SM_CONV_RES_ADD, SM_CONV_RES_NEAREST, SM_CONV_IN_RELU
 
 ARCH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+_DEBUG_CONV_FLAGS = int(__import__("os").environ.get("SIPMASK_CONV_DEBUG_FLAGS", "0"), 0)
 BF16 = torch.bfloat16
 
 
@@ -47,6 +48,7 @@ class _Conv:
         self.bias = None if bias is None else bias.float().to(dev).contiguous()
         out_sizes = [(_conv_out(h, k, stride, pad), _conv_out(ww, k, stride, pad)) for h, ww in in_sizes]
         self.out_sizes = out_sizes
+        flags |= _DEBUG_CONV_FLAGS          # A/B switches of include/sipmask_hip.h for whole-plan experiments
         self.desc = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, co_pad, k, stride, pad,
                                      in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
                                      scale_nch, level_scale, deform_groups)
