@@ -519,6 +519,145 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
   float* E = reinterpret_cast<float*>(smem);
   float* gn_bins = reinterpret_cast<float*>(smem + SMEM_MAIN);   // [GN_SEG][BCO/8][2]
   if (a.gn_stats != nullptr && gtid < GN_SEG * (BCO / 8) * 2) gn_bins[gtid] = 0.f;
+  // ---- register epilogue (same scheme as conv_dma32_kernel: v_permlane32_swap -> 8 consecutive couts per lane ->
+  // 16-byte loads/stores, no LDS round trip).  GroupNorm statistics: after the swap a lane's 8 couts are exactly
+  // one 8-channel group, so (sum, sum of squares) reduce over the 32 positions of the half-wave with shuffles and
+  // land in the LDS bins with one atomic per half-wave (per-lane atomics when a tile straddles two images).
+  const bool has_res0 = a.flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST);
+  const bool reg_epi = !PROD && !(a.flags & SM_CONV_DBG_LDS_EPILOGUE) && (a.cout & 7) == 0 && (a.out_cstride & 7) == 0 &&
+                       (a.out_coff & 7) == 0 && (!has_res0 || (a.res_cstride & 7) == 0);
+  if (reg_epi) {
+    const bool gn = a.gn_stats != nullptr;
+    const int gn_groups = a.cout >> 3;
+    const int gn_n0 = m0 / HoWo;
+    if (gn) __syncthreads();                       // bins zeroed
+#pragma unroll
+    for (int tp = 0; tp < TPOS; ++tp) {
+      const int m = m0 + wpos * TPOS * 32 + tp * 32 + l31;
+      const bool mvalid = m < M;
+      const int n_img = mvalid ? m / HoWo : -1;
+      long long rrow = 0;
+      if (has_res0 && mvalid) {
+        if (a.flags & SM_CONV_RES_ADD) {
+          rrow = out_row0 + m;
+        } else {
+          const int rem = m - n_img * HoWo;
+          const int ho = rem / Wo;
+          const int wo = rem - ho * Wo;
+          const int rh = a.res_h[lev], rw = a.res_w[lev];
+          const int sh = min((int)floorf((float)ho * ((float)rh / (float)Ho)), rh - 1);
+          const int sw = min((int)floorf((float)wo * ((float)rw / (float)Wo)), rw - 1);
+          rrow = a.res_row0[lev] + ((long long)n_img * rh + sh) * rw + sw;
+        }
+      }
+      // is the whole wave inside one image?  (then the statistics reduce with shuffles)
+      const int n_first = __builtin_amdgcn_readfirstlane(n_img);
+      const bool uniform_img = gn && __all(n_img == n_first || n_img < 0) && n_first >= 0;
+#pragma unroll
+      for (int tc = 0; tc < TCO; ++tc) {
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t lo = __float_as_uint(acc[tc][tp][4 * (2 * qp) + e]);
+            const uint32_t hi = __float_as_uint(acc[tc][tp][4 * (2 * qp + 1) + e]);
+            const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+            v[e] = __uint_as_float(r[0]);
+            v[4 + e] = __uint_as_float(r[1]);
+          }
+          const int cl = wco * TCO * 32 + tc * 32 + 8 * (2 * qp + khalf);   // cout inside the tile
+          const int c0 = nt * BCO + cl;
+          const bool live = mvalid && c0 < a.cout;
+          if (live) {
+            if (a.bias != nullptr) {
+              const float4 b0 = *reinterpret_cast<const float4*>(a.bias + c0);
+              const float4 b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 4);
+              v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w;
+              v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
+            }
+            if (c0 < a.scale_nch) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (c0 + e < a.scale_nch) v[e] *= lscale;
+            }
+            if (has_res0) {
+              float f[8];
+              unpack_bf16x8(*reinterpret_cast<const u32x4*>(a.res + rrow * a.res_cstride + c0), f);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += f[e];
+            }
+          }
+          if (gn) {                                 // wave-uniform branch: shuffles below need every lane
+            float gs = 0.f, gss = 0.f;
+            if (live) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                gs += v[e];
+                gss += v[e] * v[e];
+              }
+            }
+            if (uniform_img) {
+#pragma unroll
+              for (int d = 16; d > 0; d >>= 1) {   // within the half-wave: xor < 32 never crosses halves
+                gs += __shfl_xor(gs, d, 64);
+                gss += __shfl_xor(gss, d, 64);
+              }
+              if (l31 == 0 && c0 < a.cout) {
+                const int seg = n_first - gn_n0;
+                if (seg < GN_SEG) {
+                  atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 0], gs);
+                  atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 1], gss);
+                } else {
+                  float* st = a.gn_stats + (((long long)n_first * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
+                  atomicAdd(st, gs);
+                  atomicAdd(st + 1, gss);
+                }
+              }
+            } else if (live) {
+              const int seg = n_img - gn_n0;
+              if (seg < GN_SEG) {
+                atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 0], gs);
+                atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 1], gss);
+              } else {
+                float* st = a.gn_stats + (((long long)n_img * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
+                atomicAdd(st, gs);
+                atomicAdd(st + 1, gss);
+              }
+            }
+          }
+          if (!live) continue;
+          if (a.flags & SM_CONV_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (a.flags & SM_CONV_RELU_NCH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (c0 + e < a.scale_nch) v[e] = fmaxf(v[e], 0.f);
+          }
+          const long long o = (out_row0 + m) * a.out_cstride + a.out_coff + c0;
+          if (out_f32) {
+            float* yp = reinterpret_cast<float*>(a.y) + o;
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(a.y) + o) = pack_bf16x8_v(v);
+          }
+        }
+      }
+    }
+    if (gn) {                                       // flush the bins (same as the LDS-staged path)
+      __syncthreads();
+      if (gtid < GN_SEG * (BCO / 8) * 2) {
+        const float v = gn_bins[gtid];
+        const int seg = gtid / ((BCO / 8) * 2), rem = gtid - seg * ((BCO / 8) * 2);
+        const int g = (nt * BCO >> 3) + (rem >> 1);
+        if (v != 0.f && g < gn_groups && gn_n0 + seg < a.batch)
+          atomicAdd(a.gn_stats + (((long long)(gn_n0 + seg) * a.nlev + lev) * gn_groups + g) * 2 + (rem & 1), v);
+      }
+    }
+    return;
+  }
   if (is_cons) {
 #pragma unroll
   for (int tc = 0; tc < TCO; ++tc) {

@@ -81,7 +81,7 @@ def test_conv_igemm_vs_torch(cfg):
 
 
 @pytest.mark.parametrize("variant", [0x20000000, 0x10000000, 0x08000000, 0x04000000, 0x14000000, 0x0c000000,
-                                     0x01000000, 0x11000000])   # last two: LDS-staged epilogue of the K32 kernel
+                                     0x01000000, 0x11000000, 0x09000000])   # last three: LDS-staged epilogue (A/B)
 def test_conv_loader_variants(variant):
     """The A/B loader variants (register staging 0x2..., forced 32-wide K steps 0x1..., forced 64-wide
     0x08...) must give the same
