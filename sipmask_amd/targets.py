@@ -94,7 +94,8 @@ def prepare_gt_masks(gt_masks, hm, wm, device):
     on the [hm,wm] basis grid -> > 0.5, as uint8 on `device` (the gt operand of the fused mask loss)."""
     import numpy as np
     import torch.nn.functional as F
-    g = torch.from_numpy(np.array(gt_masks, dtype=np.float32)).to(device)
+    # ship the masks as uint8 (4x fewer PCIe bytes, no float conversion on the host), widen on the device
+    g = torch.from_numpy(np.ascontiguousarray(gt_masks, dtype=np.uint8)).to(device, non_blocking=True).float()
     g = F.interpolate(g.unsqueeze(0), scale_factor=0.5, mode='bilinear', align_corners=False).squeeze(0)
     out = g.new_zeros(g.shape[0], hm, wm)
     h, w = min(hm, g.shape[1]), min(wm, g.shape[2])
