@@ -10,7 +10,6 @@ Parity unpinned: the reference has no test on this graph.
 """
 import math
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

@@ -21,7 +21,6 @@ Parity pinning:
 Path prefixes used in citations: M/ = SipMask-mmdetection/, B/ = SipMask-benchmark/,
 V/ = SipMask-VIS/ under /root/reference.
 """
-import math
 
 import numpy as np
 import torch

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .model import _tower, tower_depths, select_candidates, FPN_STRIDES, init_state_dict
+from .model import _tower, select_candidates, init_state_dict
 
 MATCH_COEFF = (1.0, 2.0, 10.0)      # :165
 
