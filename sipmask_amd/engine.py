@@ -138,6 +138,11 @@ class SipMaskEngine:
         # post_top_n) -> relu(scale(bbox_pred)), (location, class)-pair candidates, same-label NMS
         self.benchmark = dict(benchmark) if benchmark else None
         self.steps = []        # (label, callable)
+        self.lanes = []        # per step: 0 (main stream), n > 0 (side stream n) or ("join", n...)
+        self._side_streams = {}
+        # independent branches (bottleneck downsample, FPN output convs of the coarse levels) on side streams: their
+        # launches are 20-130 blocks, far below the 512 resident blocks of the chip
+        self.multi_stream = __import__("os").environ.get("SIPMASK_MULTI_STREAM", "1") != "0"
         self.convs = []        # _Conv objects (for FLOP accounting / per-kernel timing)
         self.head_start = 0
         if head_sizes is None:
@@ -167,22 +172,64 @@ class SipMaskEngine:
             H.nchw_to_nhwc_bf16(f.detach().float().contiguous(), self.pyr[lv.row0[l]:lv.row0[l] + self.batch * h * w], 256)
 
     def run_head(self, with_post=False):
-        for label, fn in self.steps[self.head_start:]:
-            if not with_post and label in ("det_select", "nms", "mask_assemble", "track_gather", "rescore"):
-                continue
-            fn()
+        post = ("det_select", "nms", "mask_assemble", "track_gather", "rescore")
+        sel = [i for i in range(self.head_start, len(self.steps)) if with_post or self.steps[i][0] not in post]
+        self._run_steps([self.steps[i] for i in sel], [self.lanes[i] for i in sel])
 
     # -------------------------------------------------------------------------------- helpers
     def _buf(self, rows, c, dtype=BF16):
         return torch.empty(rows, c, dtype=dtype, device=self.device)
 
-    def _add(self, label, fn):
+    def _add(self, label, fn, lane=0):
+        """lane 0 = the caller's stream; lanes > 0 are side HIP streams for branches that do not depend on what
+        lane 0 does next (they fork at their first step and are joined by an explicit _join)."""
         self.steps.append((label, fn))
+        self.lanes.append(lane)
 
-    def _add_conv(self, conv):
+    def _add_conv(self, conv, lane=0):
         self.convs.append(conv)
-        self._add("conv:" + conv.name, conv)
+        self._add("conv:" + conv.name, conv, lane)
         return conv
+
+    def _join(self, *lanes):
+        """lane 0 waits for the side lanes (their results are read by the following steps)"""
+        self.steps.append(("join", lambda: None))
+        self.lanes.append(("join",) + tuple(lanes))
+
+    def _run_steps(self, steps, lanes):
+        """Launch the plan.  Side lanes are torch streams: a lane forks (waits for everything lane 0 has queued so
+        far) at its first step after a join, so a step on a side lane may read anything produced before it in plan
+        order on lane 0; capture-safe (the side streams join the capture through wait_stream)."""
+        if not self.multi_stream:
+            for _, fn in steps:
+                fn()
+            return
+        main = torch.cuda.current_stream()
+        active = set()
+        for (label, fn), lane in zip(steps, lanes):
+            if isinstance(lane, tuple):                      # join
+                for ln in lane[1:]:
+                    if ln in active:
+                        main.wait_stream(self._side(ln))
+                        active.discard(ln)
+                continue
+            if lane == 0:
+                fn()
+                continue
+            side = self._side(lane)
+            if lane not in active:
+                side.wait_stream(main)
+                active.add(lane)
+            with torch.cuda.stream(side):
+                fn()
+        for ln in list(active):                              # never leave a lane dangling
+            main.wait_stream(self._side(ln))
+
+    def _side(self, lane):
+        st = self._side_streams.get(lane)
+        if st is None:
+            st = self._side_streams[lane] = torch.cuda.Stream(device=self.device)
+        return st
 
     # -------------------------------------------------------------------------------- plan
     def _build(self, sd):
@@ -208,6 +255,14 @@ class SipMaskEngine:
                 p = "backbone.layer%d.%d" % (li + 1, bi)
                 s = 2 if (bi == 0 and li > 0) else 1
                 oh, ow = _conv_out(ch, 1, s, 0), _conv_out(cw, 1, s, 0)
+                if bi == 0:       # the shortcut conv reads the block input only: it forks onto a side lane BEFORE
+                    # conv1/conv2 are queued and is joined right before conv3 adds it
+                    wd, bd = fold_bn(sd[p + ".downsample.0.weight"], sd, p + ".downsample.1")
+                    idt = self._buf(B * oh * ow, planes * 4)
+                    self._add_conv(_Conv(self, p + ".downsample", wd, bd, B, [(ch, cw)], [0], cur, cc, s, 0, idt, [0],
+                                         planes * 4), lane=1)
+                else:
+                    idt = cur
                 wa, ba = fold_bn(sd[p + ".conv1.weight"], sd, p + ".bn1")
                 t1 = self._buf(B * oh * ow, planes)
                 self._add_conv(_Conv(self, p + ".conv1", wa, ba, B, [(ch, cw)], [0], cur, cc, s, 0, t1, [0], planes,
@@ -228,12 +283,7 @@ class SipMaskEngine:
                     self._add_conv(_Conv(self, p + ".conv2", wb, bb, B, [(oh, ow)], [0], t1, planes, 1, 1, t2, [0],
                                          planes, flags=SM_CONV_RELU))
                 if bi == 0:
-                    wd, bd = fold_bn(sd[p + ".downsample.0.weight"], sd, p + ".downsample.1")
-                    idt = self._buf(B * oh * ow, planes * 4)
-                    self._add_conv(_Conv(self, p + ".downsample", wd, bd, B, [(ch, cw)], [0], cur, cc, s, 0, idt, [0],
-                                         planes * 4))
-                else:
-                    idt = cur
+                    self._join(1)
                 wc, bc = fold_bn(sd[p + ".conv3.weight"], sd, p + ".bn3")
                 out = self._buf(B * oh * ow, planes * 4)
                 self._add_conv(_Conv(self, p + ".conv3", wc, bc, B, [(oh, ow)], [0], t2, planes, 1, 0, out, [0],
@@ -249,6 +299,15 @@ class SipMaskEngine:
         self.lv = H.Levels(B, sizes + [p6, p7])
         lv = self.lv
         lats = [None] * 3
+        self.pyr = self._buf(lv.rows, 256)
+
+        def out_conv(i, lane):
+            self._add_conv(_Conv(self, "fpn.out%d" % i, sd["neck.fpn_convs.%d.conv.weight" % i],
+                                 sd["neck.fpn_convs.%d.conv.bias" % i], B, [sizes[i]], [0], lats[i], 256, 1, 1,
+                                 self.pyr, [lv.row0[i]], 256), lane)
+        # plan order = dependency order on lane 0 (lat2 -> lat1 -> lat0 -> out0); the coarse outputs only need
+        # their own lateral, so they leave for side lanes as soon as it is queued: lane 1 = out2 -> P6 -> P7 (66, 20
+        # and 8 blocks), lane 2 = out1 (264 blocks), both overlapped with lat1 / lat0 / out0 on lane 0
         for i in (2, 1, 0):
             f, fh, fw, fc = feats[i + 1]
             lats[i] = self._buf(B * fh * fw, 256)
@@ -256,34 +315,36 @@ class SipMaskEngine:
             bl = sd["neck.lateral_convs.%d.conv.bias" % i]
             if i == 2:
                 self._add_conv(_Conv(self, "fpn.lat%d" % i, wl, bl, B, [(fh, fw)], [0], f, fc, 1, 0, lats[i], [0], 256))
+                out_conv(2, 1)
+                self._add_conv(_Conv(self, "fpn.p6", sd["neck.fpn_convs.3.conv.weight"], sd["neck.fpn_convs.3.conv.bias"],
+                                     B, [sizes[2]], [lv.row0[2]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[3]], 256), 1)
+                self._add_conv(_Conv(self, "fpn.p7", sd["neck.fpn_convs.4.conv.weight"], sd["neck.fpn_convs.4.conv.bias"],
+                                     B, [p6], [lv.row0[3]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[4]], 256,
+                                     flags=SM_CONV_IN_RELU), 1)
             else:
                 self._add_conv(_Conv(self, "fpn.lat%d" % i, wl, bl, B, [(fh, fw)], [0], f, fc, 1, 0, lats[i], [0], 256,
                                      flags=SM_CONV_RES_NEAREST, residual=lats[i + 1], res_cstride=256,
                                      res_sizes=[sizes[i + 1]], res_row0=[0]))
-        self.pyr = self._buf(lv.rows, 256)
-        for i in range(3):
-            self._add_conv(_Conv(self, "fpn.out%d" % i, sd["neck.fpn_convs.%d.conv.weight" % i],
-                                 sd["neck.fpn_convs.%d.conv.bias" % i], B, [sizes[i]], [0], lats[i], 256, 1, 1,
-                                 self.pyr, [lv.row0[i]], 256))
-        self._add_conv(_Conv(self, "fpn.p6", sd["neck.fpn_convs.3.conv.weight"], sd["neck.fpn_convs.3.conv.bias"], B,
-                             [sizes[2]], [lv.row0[2]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[3]], 256))
-        self._add_conv(_Conv(self, "fpn.p7", sd["neck.fpn_convs.4.conv.weight"], sd["neck.fpn_convs.4.conv.bias"], B,
-                             [p6], [lv.row0[3]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[4]], 256,
-                             flags=SM_CONV_IN_RELU))
+                if i == 1:
+                    out_conv(1, 2)
+        out_conv(0, 0)
+        self._join(1, 2)
         self.head_start = len(self.steps)
         self._build_head(sd)
         self._build_post()
 
-    def _gn(self, label, x, gamma, beta, conv=None):
+    def _gn(self, label, x, gamma, beta, conv=None, lane=0, stats=None):
         """GroupNorm(32)+ReLU in place.  With ``conv`` (the launch that produced x) the statistics pass is
-        fused into that conv's epilogue and only the normalisation kernel remains."""
+        fused into that conv's epilogue and only the normalisation kernel remains.  Concurrent lanes need their own
+        statistics buffer."""
         g = gamma.float().to(self.device).contiguous()
         b = beta.float().to(self.device).contiguous()
+        st = self.gn_stats if stats is None else stats
         if conv is not None:
-            conv.gn_stats = self.gn_stats
-            self._add("gn:" + label, lambda: H.groupnorm_apply(x, x, g, b, self.gn_stats, self.lv, 256, 32, 1e-5, True))
+            conv.gn_stats = st
+            self._add("gn:" + label, lambda: H.groupnorm_apply(x, x, g, b, st, self.lv, 256, 32, 1e-5, True), lane)
         else:
-            self._add("gn:" + label, lambda: H.groupnorm(x, x, g, b, self.gn_stats, self.lv, 256, 32, 1e-5, True))
+            self._add("gn:" + label, lambda: H.groupnorm(x, x, g, b, st, self.lv, 256, 32, 1e-5, True), lane)
 
     def _build_head(self, sd, prefix="bbox_head."):
         """SipMaskHead.forward, sipmask_head.py:241-287, on the pyramid tensor self.pyr."""
@@ -297,24 +358,50 @@ class SipMaskEngine:
         depth = lambda kind: sum(1 for k in sd if k.startswith(h + kind + "_convs.") and k.endswith(".conv.weight"))
         self.flag_norm = (h + "reg_convs.0.gn.weight") in sd
 
-        def tower(kind, n):
+        def tower(kind, n, lane=0, stats=None):
             x = self.pyr
             for i in range(n):
                 y = self._buf(lv.rows, 256)
                 name = "%s_convs.%d" % (kind, i)
                 if self.flag_norm:     # a conv bias in front of GN exists in the B/ variant only (sipmask.py:70-79)
                     c = self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"],
-                                             sd.get(h + name + ".conv.bias"), B, sizes, row0, x, 256, 1, 1, y, row0, 256))
-                    self._gn(name, y, sd[h + name + ".gn.weight"], sd[h + name + ".gn.bias"], conv=c)
+                                             sd.get(h + name + ".conv.bias"), B, sizes, row0, x, 256, 1, 1, y, row0, 256),
+                                       lane)
+                    self._gn(name, y, sd[h + name + ".gn.weight"], sd[h + name + ".gn.bias"], conv=c, lane=lane,
+                             stats=stats)
                 else:
                     self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"],
                                          sd.get(h + name + ".conv.bias"), B, sizes, row0, x, 256, 1, 1, y, row0, 256,
-                                         flags=SM_CONV_RELU))
+                                         flags=SM_CONV_RELU), lane)
                 x = y
             return x
 
-        self.cls_feat = tower("cls", depth("cls"))
+        # the classification tower only meets the box branch at FeatureAlign: it runs on a side lane (own GroupNorm
+        # statistics buffer) next to the regression tower; a 1404-block launch leaves the last of its 2.74 rounds
+        # of resident blocks 38 % empty, which the other tower's blocks fill
+        self.gn_stats_cls = torch.zeros_like(self.gn_stats)
+        self.cls_feat = tower("cls", depth("cls"), lane=1, stats=self.gn_stats_cls)
         self.reg_feat = tower("reg", depth("reg"))
+        # mask basis branch (sipmask_head.py:275-285): needs reg_feat only and is consumed by mask assembly only, so it
+        # runs on lane 2 next to reg_ctr / FeatureAlign / cls_cof and the low-occupancy det_select + NMS (joined in
+        # _build_post right before mask assembly)
+        (h0, w0) = sizes[0]
+        self.cat = self._buf(B * h0 * w0, 768)
+        for l in range(3):
+            fh, fw = sizes[l]
+            src = self.reg_feat[row0[l]:row0[l] + B * fh * fw]
+            self._add("up:cat%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear(
+                s, self.cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, False)), 2)
+        self.lat0 = self._buf(B * h0 * w0, 512)
+        self._add_conv(_Conv(self, "head.sip_mask_lat0", sd[h + "sip_mask_lat0.weight"], sd[h + "sip_mask_lat0.bias"],
+                             B, [(h0, w0)], [0], self.cat, 768, 1, 0, self.lat0, [0], 512, flags=SM_CONV_RELU), 2)
+        self.basis_lo = self._buf(B * h0 * w0, 32, torch.float32)
+        self._add_conv(_Conv(self, "head.sip_mask_lat", sd[h + "sip_mask_lat.weight"], sd[h + "sip_mask_lat.bias"], B,
+                             [(h0, w0)], [0], self.lat0, 512, 1, 1, self.basis_lo, [0], 32,
+                             flags=SM_CONV_RELU | SM_CONV_OUT_F32), 2)
+        self.hm, self.wm = 4 * h0, 4 * w0
+        self.basis = self._buf(B * self.hm * self.wm, 32, torch.float32)      # feat_masks, [B,Hm,Wm,32]
+        self._add("up:basis", lambda: H.upsample_bilinear(self.basis_lo, self.basis, B, h0, w0, 32, 4, 32, 32, 0, True), 2)
         # fcos_reg (4, x Scale) + fcos_centerness (1) share reg_feat -> one 5-channel f32 conv
         w_rc = torch.cat([sd[h + "fcos_reg.weight"], sd[h + "fcos_centerness.weight"]], 0)
         b_rc = torch.cat([sd[h + "fcos_reg.bias"], sd[h + "fcos_centerness.bias"]], 0)
@@ -329,6 +416,7 @@ class SipMaskEngine:
         self.offsets = self._buf(lv.rows, 72, torch.float32)
         self._add("offset", lambda: H.offset_linear(self.reg_out, 8, self.w_off, lv, self.offsets))
         self.aligned = self._buf(lv.rows, 256)
+        self._join(1)
         c = self._add_conv(_Conv(self, "head.feat_align", sd[h + "feat_align.conv_adaption.weight"],
                                  sd.get(h + "feat_align.conv_adaption.bias"), B, sizes,
                                  row0, self.cls_feat, 256, 1, 1, self.aligned, row0, 256, deform_groups=4,
@@ -343,24 +431,6 @@ class SipMaskEngine:
         self.cls_cof = self._buf(lv.rows, self.ncc, torch.float32)
         self._add_conv(_Conv(self, "head.cls_cof", w_cc, b_cc, B, sizes, row0, self.aligned, 256, 1, 1, self.cls_cof,
                              row0, self.ncc, flags=SM_CONV_OUT_F32))
-        # mask basis branch (sipmask_head.py:275-285)
-        (h0, w0) = sizes[0]
-        self.cat = self._buf(B * h0 * w0, 768)
-        for l in range(3):
-            fh, fw = sizes[l]
-            src = self.reg_feat[row0[l]:row0[l] + B * fh * fw]
-            self._add("up:cat%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear(
-                s, self.cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, False)))
-        self.lat0 = self._buf(B * h0 * w0, 512)
-        self._add_conv(_Conv(self, "head.sip_mask_lat0", sd[h + "sip_mask_lat0.weight"], sd[h + "sip_mask_lat0.bias"],
-                             B, [(h0, w0)], [0], self.cat, 768, 1, 0, self.lat0, [0], 512, flags=SM_CONV_RELU))
-        self.basis_lo = self._buf(B * h0 * w0, 32, torch.float32)
-        self._add_conv(_Conv(self, "head.sip_mask_lat", sd[h + "sip_mask_lat.weight"], sd[h + "sip_mask_lat.bias"], B,
-                             [(h0, w0)], [0], self.lat0, 512, 1, 1, self.basis_lo, [0], 32,
-                             flags=SM_CONV_RELU | SM_CONV_OUT_F32))
-        self.hm, self.wm = 4 * h0, 4 * w0
-        self.basis = self._buf(B * self.hm * self.wm, 32, torch.float32)      # feat_masks, [B,Hm,Wm,32]
-        self._add("up:basis", lambda: H.upsample_bilinear(self.basis_lo, self.basis, B, h0, w0, 32, 4, 32, 32, 0, True))
         # VIS track branch (V/...:265-284,310-311): track_convs on levels 0-2 (one 3-level launch per conv) ->
         # bilinear x1/x2/x4 -> cat 768 -> 1x1 -> 512-channel embedding map at stride 8, f32
         self.track_feats = None
@@ -417,6 +487,7 @@ class SipMaskEngine:
                                                        self.cls_cof, self.sel))
         self._add("nms", lambda: H.multiclass_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"],
                                                   self.sel["ncand"], 0.0, bm["nms_thresh"], self.max_num, self.nms_out))
+        self._join(2)
         self._add("mask_assemble", lambda: H.mask_assemble(
             self.basis, True, self.sel["cofs"], self.nms_out["keep"], self.nms_out["det"], self.nms_out["ndet"],
             self.hm, self.wm, self.ho, self.wo, 1.0, 2.0, self.up, 0.4, self.masks))
@@ -447,6 +518,7 @@ class SipMaskEngine:
             self._add("nms", lambda: H.multiclass_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"],
                                                       self.sel["ncand"], cfg["score_thr"], cfg["nms"]["iou_thr"],
                                                       self.max_num, self.nms_out))
+        self._join(2)
         self.rescorer = None
         if ("bbox_head.convs_scoring.0.conv.weight") in self._sd_keys:
             self.rescorer = MaskRescorer(self._sd, "bbox_head.", B, self.max_num, self.hm, self.wm, self.device)
@@ -471,8 +543,7 @@ class SipMaskEngine:
         """img: float32 NCHW [B,3,H,W] on the device.  Returns the result dict (device tensors)."""
         assert img.shape == (self.batch, 3, self.H, self.W) and img.dtype == torch.float32 and img.is_cuda
         self.img = img.contiguous()
-        for _, fn in self.steps:
-            fn()
+        self._run_steps(self.steps, self.lanes)
         return self.results()
 
     def results(self):
