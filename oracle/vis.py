@@ -124,3 +124,24 @@ class Tracker:
                     self.prev_roi_feats[o] = det_feats[i]
                     self.prev_bboxes[o] = det_boxes[i]
         return ids
+
+
+def track_loss(track_feats, track_feats_ref, mask_aux, ref_bboxes_list, gt_pids_list, jitter):
+    """loss_match of V/...:470-498,536 given the per-image positives of the mask loss (oracle.loss.head_loss aux):
+    mean over images of cross_entropy([0, f_key . f_ref^T], gt_pids[idx_gt])."""
+    total = 0
+    for i, aux in enumerate(mask_aux):
+        if aux is None:
+            continue
+        ref = ref_bboxes_list[i]
+        off = jitter[i]
+        cxcy = (ref[:, 2:4] + ref[:, :2]) / 2
+        wh = (ref[:, 2:4] - ref[:, :2]).abs()
+        ncxcy, nwh = cxcy + wh * off[:, :2], wh * (1 + off[:, 2:])
+        new_boxes = torch.cat([ncxcy - nwh / 2, ncxcy + nwh / 2], 1)
+        fk = extract_box_feature_center(track_feats[i], aux["bbox_dt"] * 2)
+        fr = extract_box_feature_center(track_feats_ref[i], new_boxes)
+        prod = fk @ fr.t()
+        prod_ext = torch.cat([prod.new_zeros(prod.shape[0], 1), prod], 1)
+        total = total + F.cross_entropy(prod_ext, gt_pids_list[i][aux["idx_gt"]], reduction="mean")
+    return total / len(mask_aux)

@@ -218,7 +218,7 @@ class SipMaskHead(nn.Module):
                 if k.startswith("convs_scoring.") or k.startswith("mask_scoring.")}
 
     def loss(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, gt_bboxes, gt_labels, img_metas, cfg,
-             gt_bboxes_ignore=None, gt_masks_list=None):
+             gt_bboxes_ignore=None, gt_masks_list=None, _per_image=None):
         """sipmask_head.py:289-498 (rescoring_flag=False): dict(loss_cls, loss_bbox, loss_centerness, loss_mask).
 
         Same arguments as the reference.  Target assignment is tensor code (targets.py); the classification
@@ -278,6 +278,8 @@ class SipMaskHead(nn.Module):
                 weighting = weighting / (weighting.sum() + 0.0001) * len(weighting)
                 hm, wm = feat_masks[i].shape[1:]
                 gt_new = T.prepare_gt_masks(gt_masks_list[i][:gt_labels[i].shape[0]], hm, wm, dev)
+            if _per_image is not None:       # hook for heads that add per-image terms (VIS track loss)
+                _per_image(i, bdt, idx)
             bce = mask_loss(feat_masks[i], img_cof[i][pk], bdt, gt_new, idx)             # [N] per-detection sums
             pre = bce / (bdt[:, 2] - bdt[:, 0]) / (bdt[:, 3] - bdt[:, 1]) / bdt.shape[0]
             loss_mask = loss_mask + torch.sum(pre * weighting)

@@ -52,11 +52,62 @@ class SipMaskVISHead(SipMaskHead):
             self._engines = {key: eng}
         return eng
 
+    def _track_train(self, feats):
+        from . import ops as P
+        outs = []
+        for li, x in enumerate(feats[:3]):                               # V/...:273-284
+            t = self._tower_train(x, self.track_convs)
+            outs.append(t if li == 0 else P.upsample_bilinear(t, 2 ** li))
+        return P.conv2d(torch.cat(outs, 1), self.sipmask_track.weight, self.sipmask_track.bias, 1, 0)
+
+    def forward_train(self, feats, feats_x=None):
+        """V/...:252-315 with flag_train=True: the five head outputs plus the track embeddings of the key frame and
+        of the reference frame, all on the differentiable HIP autograd ops."""
+        out = SipMaskHead.forward_train(self, feats)
+        tf = self._track_train(feats)
+        return out + (tf, self._track_train(feats_x) if feats_x is not None else tf)
+
+    def loss(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, track_feats, track_feats_ref, gt_bboxes,
+             gt_labels, img_metas, cfg, gt_bboxes_ignore=None, gt_masks_list=None, ref_bboxes_list=None, gt_pids_list=None,
+             jitter=None):
+        """V/...:320-543: the SipMask losses plus loss_match / match_acc.  For every image the embeddings at the
+        positive points' predicted boxes (key frame) are matched against the embeddings at the jittered reference
+        boxes with a softmax over [new object, ref_1..ref_n] (:470-498).  jitter: optional list of [n_ref,4] offsets
+        in [-0.05, 0.05] replacing the reference's uniform_ draw (tests)."""
+        import torch.nn.functional as F
+        acc = dict(loss=0, correct=0.0, n=0)
+        num_imgs = cls_scores[0].size(0)
+
+        def center_feats(tf, boxes):                                   # extract_box_feature_center_single :768-781
+            cx = torch.floor((boxes[:, 2] + boxes[:, 0]) / 2.0 / 8).long().clamp(0, tf.shape[2] - 1)
+            cy = torch.floor((boxes[:, 3] + boxes[:, 1]) / 2.0 / 8).long().clamp(0, tf.shape[1] - 1)
+            return tf.permute(1, 2, 0)[cy, cx, :]
+
+        def per_image(i, bdt, idx):
+            ref = ref_bboxes_list[i]
+            off = jitter[i].to(ref) if jitter is not None else ref.new_empty(ref.shape[0], 4).uniform_(-0.05, 0.05)
+            cxcy = (ref[:, 2:4] + ref[:, :2]) / 2
+            wh = (ref[:, 2:4] - ref[:, :2]).abs()
+            ncxcy, nwh = cxcy + wh * off[:, :2], wh * (1 + off[:, 2:])
+            new_boxes = torch.cat([ncxcy - nwh / 2, ncxcy + nwh / 2], 1)
+            prod = center_feats(track_feats[i], bdt * 2) @ center_feats(track_feats_ref[i], new_boxes).t()
+            prod_ext = torch.cat([prod.new_zeros(prod.shape[0], 1), prod], 1)
+            cur = gt_pids_list[i][idx]
+            acc["loss"] = acc["loss"] + F.cross_entropy(prod_ext, cur, reduction='mean')
+            acc["correct"] += float((prod_ext.argmax(1) == cur).float().mean()) * 100.0 * len(idx)   # accuracy() in %
+            acc["n"] += len(idx)
+
+        losses = SipMaskHead.loss(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, gt_bboxes, gt_labels,
+                                  img_metas, cfg, gt_bboxes_ignore, gt_masks_list, _per_image=per_image)
+        losses["loss_match"] = acc["loss"] / num_imgs
+        losses["match_acc"] = torch.as_tensor(acc["correct"] / max(acc["n"], 1))
+        return losses
+
     def forward(self, feats, feats_x=None, flag_train=False):
-        """V/...:252-317, test path: (cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, track_feats,
-        track_feats) with track_feats [B,512,h/8,w/8]."""
+        """V/...:252-317: (cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, track_feats, track_feats_ref)
+        with track_feats [B,512,h/8,w/8]; flag_train=True takes the differentiable path."""
         if flag_train:
-            raise NotImplementedError("the VIS training path (reference-frame branch, loss_track) is not built")
+            return self.forward_train(feats, feats_x)
         b = feats[0].shape[0]
         sizes = [tuple(f.shape[-2:]) for f in feats]
         eng = self._engine(b, sizes)

@@ -163,3 +163,66 @@ def test_vis_detector_sequence(vdet):
                 assert segm_results[int(oid)]["size"] == [192, 320]
         kept.append(set(bbox_results))
     assert len(kept[0] & kept[2]) >= 1
+
+
+def test_vis_training_losses_vs_oracle():
+    """SipMaskVISHead.forward(feats, feats_x, flag_train=True) + loss: the SipMask losses plus loss_match against the
+    oracle (same jitter offsets injected on both sides); gradients reach the track branch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import loss as OL
+    from sipmask_amd import vis_head  # noqa: F401
+    from sipmask_amd.registry import build_head
+    head = build_head(dict(type='SipMaskVISHead', num_classes=41, in_channels=256, stacked_convs=3, feat_channels=256,
+                           strides=[8, 16, 32, 64, 128], center_sampling=True, center_sample_radius=1.5)).cuda()
+    sd = {k[len("bbox_head."):]: v for k, v in OV.init_vis_state_dict(seed=8).items() if k.startswith("bbox_head.")}
+    sd["fcos_cls.bias"].fill_(-3.0)
+    head.load_state_dict(sd, strict=True)
+    head.train()
+    g = torch.Generator().manual_seed(12)
+    B = 2
+    sizes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    feats = [torch.randn(B, 256, h, w, generator=g).to(torch.bfloat16).float() for h, w in sizes]
+    feats_x = [f + 0.05 * torch.randn(f.shape, generator=g) for f in feats]
+    feats_x = [f.to(torch.bfloat16).float() for f in feats_x]
+    rng = np.random.RandomState(5)
+    gtb, gtl, gtm, refb, pids, jit = [], [], [], [], [], []
+    yy, xx = np.mgrid[:128, :160]
+    for _ in range(B):
+        n = 4
+        xy = rng.rand(n, 2) * np.array([90.0, 70.0])
+        wh = rng.rand(n, 2) * np.array([60.0, 50.0]) + 12
+        b = np.concatenate([xy, np.minimum(xy + wh, [159, 127])], 1).astype(np.float32)
+        m = np.zeros((n, 128, 160), np.uint8)
+        for k in range(n):
+            m[k, int(b[k, 1]):int(b[k, 3]) + 1, int(b[k, 0]):int(b[k, 2]) + 1] = 1
+        gtb.append(torch.from_numpy(b))
+        gtl.append(torch.from_numpy(rng.randint(1, 41, n).astype(np.int64)))
+        gtm.append(m)
+        nref = 3
+        refb.append(torch.from_numpy((b[:nref] + rng.randn(nref, 4).astype(np.float32) * 2).clip(0, 120)))
+        pids.append(torch.from_numpy(np.array([1, 2, 3, 0], np.int64)))        # 0 = not in the reference frame
+        jit.append(torch.from_numpy((rng.rand(nref, 4).astype(np.float32) - 0.5) * 0.1))
+    # ---- oracle
+    osd = {"bbox_head." + k: v.clone() for k, v in sd.items()}
+    oout = OM.head_forward(osd, feats)
+    otf, otr = OV.track_forward(osd, feats), OV.track_forward(osd, feats_x)
+    oloss, aux = OL.head_loss(oout[0], oout[1], oout[2], oout[3], oout[4], gtb, gtl, gtm)
+    omatch = OV.track_loss(otf, otr, aux["mask_aux"], refb, pids, jit)
+    # ---- HIP
+    out = head([f.cuda() for f in feats], [f.cuda() for f in feats_x], True)
+    assert len(out) == 7 and tuple(out[5].shape) == (B, 512, 16, 20)
+    assert _rel(out[5].detach(), otf) < 0.03 and _rel(out[6].detach(), otr) < 0.03
+    metas = [dict(img_shape=(128, 160, 3), pad_shape=(128, 160, 3), scale_factor=1.0) for _ in range(B)]
+    loss = head.loss(*out, [b.cuda() for b in gtb], [l.cuda() for l in gtl], metas, None, gt_masks_list=gtm,
+                     ref_bboxes_list=[r.cuda() for r in refb], gt_pids_list=[p.cuda() for p in pids], jitter=jit)
+    assert set(loss) == {"loss_cls", "loss_bbox", "loss_centerness", "loss_mask", "loss_match", "match_acc"}
+    for k in oloss:
+        a, b = float(loss[k].detach()), float(oloss[k].detach())
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (k, a, b)
+    a, b = float(loss["loss_match"].detach()), float(omatch)
+    assert abs(a - b) <= 3e-2 * max(1.0, abs(b)), (a, b)
+    sum(v for k, v in loss.items() if k != "match_acc").backward()
+    for name in ("track_convs.0.conv.weight", "track_convs.1.gn.weight", "sipmask_track.weight", "sipmask_track.bias"):
+        gr = dict(head.named_parameters())[name].grad
+        assert gr is not None and float(gr.abs().sum()) > 0, name
