@@ -73,6 +73,8 @@ def cpu_baseline(det, seed=0):
 
 def main():
     args = parse()
+    if args.tower_only:      # profiling aid: keep every dispatch sequential so that rocprofv3's per-kernel average is
+        os.environ["SIPMASK_MULTI_STREAM"] = "0"     # the isolated kernel, not two towers sharing the chip
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
