@@ -78,6 +78,9 @@ typedef struct {
   int32_t scale_nch;              /* channels < scale_nch are multiplied by level_scale */
   float level_scale[SM_MAX_LEVELS]; /* Scale(), sipmask_head.py:261: y=(acc+bias)*scale */
   int32_t deform_groups;          /* deform conv only: offset layout [row][G][kh*kw][2] f32 */
+  int64_t w_batch_stride;         /* elements between the weight matrices of consecutive images; 0 = one shared
+                                   * weight (every convolution).  != 0 turns the launch into `batch` independent
+                                   * GEMMs (split-K weight gradients); needs out_h*out_w % position tile == 0 */
 } sm_conv_desc;
 
 int sm_version(void);

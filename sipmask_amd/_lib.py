@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
         ("res_cstride", C.c_int32),
         ("res_h", _i32x5), ("res_w", _i32x5), ("res_row0", _i64x5),
         ("flags", C.c_uint32), ("scale_nch", C.c_int32), ("level_scale", _f32x5),
-        ("deform_groups", C.c_int32),
+        ("deform_groups", C.c_int32), ("w_batch_stride", C.c_int64),
     ]
 
 

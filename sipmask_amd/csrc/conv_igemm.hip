@@ -39,6 +39,7 @@ struct ConvKArgs {
   float level_scale[SM_MAX_LEVELS];
   int dg, cpg8;  // deform groups, chunks (of 8 ch) per deform group
   float* gn_stats;  // optional fused GroupNorm statistics [batch][nlev][cout/8][2] (sum, sum of squares)
+  long long w_bstride;  // elements between the weight matrices of consecutive images (0 = shared): batched / split-K GEMMs
 };
 
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
     if (rbase[i] < 0) rhi[i] = -0x40000000;
     xoff[i] = (in_row0 + (rbase[i] < 0 ? 0 : rbase[i]) + (long long)rhi[i] * W + rwi[i]) * a.in_cstride;
   }
-  const uint16_t* wrow = a.w + (long long)(nt * BCO + r0) * a.Kp + j * 8;
+  const uint16_t* wrow = a.w + (long long)(nt * BCO + r0) * a.Kp + j * 8 + (a.w_bstride != 0 ? (long long)(m0 / HoWo) * a.w_bstride : 0ll);
   const long long wstride = 32ll * a.Kp;
   // loader K state (this thread's 16-byte chunk j of the current K step), advanced incrementally:
   // no integer division inside the K loop when a tap holds >= 8 chunks (every layer but the stem)
@@ -883,7 +884,7 @@ __global__ __launch_bounds__(256, 4) void conv_dma32_kernel(const ConvKArgs a) {
       xoff[i] = 0;
     }
   }
-  const uint16_t* ld_wp = a.w + (long long)(nt * BCO + r0) * a.Kp + j * 8;
+  const uint16_t* ld_wp = a.w + (long long)(nt * BCO + r0) * a.Kp + j * 8 + (a.w_bstride != 0 ? (long long)(m0 / HoWo) * a.w_bstride : 0ll);
   const long long wstride = 64ll * a.Kp;
   int ld_kc = j, ld_cc, ld_kh, ld_kw;
   {
@@ -1181,6 +1182,7 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   ConvKArgs a;
   a.x = (const uint16_t*)x;
   a.w = (const uint16_t*)w;
+  a.w_bstride = d->w_batch_stride;
   a.bias = bias;
   a.res = (const uint16_t*)residual;
   a.y = y;

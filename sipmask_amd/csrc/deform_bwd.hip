@@ -6,7 +6,8 @@
 //
 // Both GEMMs run on the MFMA implicit-GEMM kernel of conv_igemm.hip as 1x1 convolutions:
 //   grad columns  gcol[p][k]  = sum_co gout[p][co] * W[co][k]         (A = gout rows, B = W^T prepared by the host)
-//   grad weight   dW^T[k][co] = sum_p  col^T[k][p] * gout^T[co][p]    (position chunks; operands transposed here)
+//   grad weight   dW^T[k][co] = sum_p  col^T[k][p] * gout^T[co][p]    (split-K: S position slices as ONE batched launch,
+//                                                                   operands transposed here, partials reduced after)
 // and the data-dependent parts are HBM-bound gather/scatter kernels:
 //   * col2im: one wave per (position, tap, 64 channels): the 64 lanes scatter their column gradient to the 4
 //     bilinear corners of grad_x (f32 NHWC, hardware float atomics on contiguous 256-B segments) and reduce the
@@ -20,7 +21,7 @@
 
 namespace {
 
-constexpr int DB_MAX_CHUNK = 32768;   // positions per weight-gradient GEMM (bounds the col^T workspace)
+constexpr int DB_SLICE = 8192;   // positions per split-K slice of the weight-gradient GEMM
 
 struct DBArgs {
   const uint16_t* x;
@@ -145,16 +146,22 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const DBArgs a, cons
 
 // ---------------------------------------------------------------- operands of the weight-gradient GEMM
 // col^T[k][pl] (bf16, k = tap*cin + c) for positions p0 .. p0+n of the compact order; columns n..Lp are zero
-__global__ __launch_bounds__(256) void deform_im2col_t_kernel(const DBArgs a, long long p0, int n, int Lp,
+// col^T, slice-major: colT[s][k][pl] (bf16, k = tap*cin + c, rows K..Kpad of a slice are never read as real data:
+// the host zero-fills them once) for position p = s*L + pl; positions >= P are zero.
+__global__ __launch_bounds__(256) void deform_im2col_t_kernel(const DBArgs a, int S, int L, int Kpad,
                                                               uint16_t* __restrict__ colT) {
   const int kk = a.kh * a.kw;
   const int nc8 = a.cin >> 3;
   const int cpg = a.cin / a.G;
-  const long long total = (long long)kk * nc8 * Lp;
+  const long long SL = (long long)S * L;
+  const long long total = (long long)kk * nc8 * SL;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-    const int pl = (int)(t % Lp);
-    const int c8 = (int)((t / Lp) % nc8);
-    const int tap = (int)(t / ((long long)Lp * nc8));
+    const long long gp = t % SL;
+    const int sl = (int)(gp / L), pl = (int)(gp - (long long)sl * L);
+    const int c8 = (int)((t / SL) % nc8);
+    const int tap = (int)(t / (SL * nc8));
+    const int n = gp < a.P ? pl + 1 : 0;      // "pl < n" below == position exists
+    const long long p0 = gp - pl;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -179,31 +186,39 @@ __global__ __launch_bounds__(256) void deform_im2col_t_kernel(const DBArgs a, lo
         }
       }
     }
-    uint16_t* o = colT + ((long long)tap * a.cin + c8 * 8) * Lp + pl;
+    uint16_t* o = colT + ((long long)sl * Kpad + (long long)tap * a.cin + c8 * 8) * L + pl;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[(long long)e * Lp] = (uint16_t)f32_to_bf16_bits(v[e]);
+    for (int e = 0; e < 8; ++e) o[(long long)e * L] = (uint16_t)f32_to_bf16_bits(v[e]);
   }
 }
 
-// gout^T[co][pl] (bf16) for the same positions; rows cout..cout_pad and columns n..Lp are zero
-__global__ __launch_bounds__(256) void gout_t_kernel(const DBArgs a, long long p0, int n, int Lp, int cout_pad,
+// gout^T, slice-major: goutT[s][co][pl] (bf16); rows cout..cout_pad and positions >= P are zero
+__global__ __launch_bounds__(256) void gout_t_kernel(const DBArgs a, int S, int L, int cout_pad,
                                                      uint16_t* __restrict__ goutT) {
-  const long long total = (long long)cout_pad * Lp;
+  const long long total = (long long)S * cout_pad * L;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-    const int pl = (int)(t % Lp);
-    const int co = (int)(t / Lp);
+    const int pl = (int)(t % L);
+    const int co = (int)((t / L) % cout_pad);
+    const int sl = (int)(t / ((long long)L * cout_pad));
+    const long long gp = (long long)sl * L + pl;
     uint16_t v = 0;
-    if (pl < n && co < a.cout) {
-      const Pos ps = locate(a, p0 + pl);
+    if (gp < a.P && co < a.cout) {
+      const Pos ps = locate(a, gp);
       v = a.gout[ps.orow * a.gout_cstride + co];
     }
     goutT[t] = v;
   }
 }
 
-__global__ void axpy_kernel(float* __restrict__ acc, const float* __restrict__ x, long long n) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    acc[i] += x[i];
+// grad_w_t[k][co] = sum over the S slices of part[s][k][co] (rows k < K of each Kpad-row slice)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int S, long long K, int Kpad,
+                                    int cout) {
+  const long long n = K * cout;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += part[(long long)s * Kpad * cout + i];
+    out[i] = acc;
+  }
 }
 
 // grad_bias[co] = sum over all positions of gout[p][co]: one block per 8 channels, rows strided over the threads
@@ -236,17 +251,20 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const DBArgs a, float* _
 
 struct Plan {
   long long P, K;
-  int chunk, Lp, cout_pad2;       // weight-gradient GEMM: positions per chunk, padded length, padded cout
+  int S, L, Kpad, cout_pad2;      // weight-gradient GEMM: S slices of L positions, K rows padded per slice
   int kpad1;                      // grad-column GEMM: K padded to its cout tile
-  size_t off_gcol, off_colT, off_goutT, off_dtmp, total;
+  size_t off_gcol, off_colT, off_goutT, off_part, total;
 };
 
 bool make_plan(const sm_conv_desc* d, Plan* pl) {
   pl->P = 0;
   for (int l = 0; l < d->nlev; ++l) pl->P += (long long)d->batch * d->out_h[l] * d->out_w[l];
   pl->K = (long long)d->kh * d->kw * d->cin;
-  pl->chunk = (int)std::min<long long>(pl->P, DB_MAX_CHUNK);
-  pl->Lp = (pl->chunk + 63) / 64 * 64;
+  // split-K: one batched GEMM over S slices of the position axis (enough blocks to fill the chip even though the
+  // result is only K x cout), partial sums reduced afterwards
+  pl->L = (int)std::min<long long>((pl->P + 63) / 64 * 64, DB_SLICE);
+  pl->S = (int)((pl->P + pl->L - 1) / pl->L);
+  pl->Kpad = (int)((pl->K + 255) / 256 * 256);   // every position tile (<= 256 rows) stays inside one slice
   const int t2 = sm_conv_cout_tile(d->cout);
   pl->cout_pad2 = (d->cout + t2 - 1) / t2 * t2;
   const int t1 = sm_conv_cout_tile((int)pl->K);
@@ -258,9 +276,9 @@ bool make_plan(const sm_conv_desc* d, Plan* pl) {
     return at;
   };
   pl->off_gcol = take((size_t)pl->P * pl->K * 4);
-  pl->off_colT = take((size_t)pl->K * pl->Lp * 2);
-  pl->off_goutT = take((size_t)pl->cout_pad2 * pl->Lp * 2);
-  pl->off_dtmp = take((size_t)pl->K * d->cout * 4);
+  pl->off_colT = take((size_t)pl->S * pl->Kpad * pl->L * 2);
+  pl->off_goutT = take((size_t)pl->S * pl->cout_pad2 * pl->L * 2);
+  pl->off_part = take((size_t)pl->S * pl->Kpad * d->cout * 4);
   pl->total = o;
   return true;
 }
@@ -378,44 +396,41 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
     SM_LAUNCH_CHECK();
   }
   if (grad_w_t) {
-    // ---- dW^T[k][co] = sum over position chunks of col^T @ gout (1x1 conv: rows := K, cin := chunk length)
+    // ---- dW^T[k][co] = sum_s col^T_s @ gout_s: ONE launch of the implicit-GEMM kernel as a batch of S 1x1
+    // "convolutions" (image s: Kpad rows, cin = L, its own weight matrix gout^T_s via w_batch_stride), then a reduce
     uint16_t* colT = (uint16_t*)(ws + pl.off_colT);
     uint16_t* goutT = (uint16_t*)(ws + pl.off_goutT);
-    float* dtmp = (float*)(ws + pl.off_dtmp);
+    float* part = (float*)(ws + pl.off_part);
+    if (pl.Kpad != pl.K &&
+        hipMemsetAsync(colT, 0, (size_t)pl.S * pl.Kpad * pl.L * 2, s) != hipSuccess)   // padding rows of every slice
+      return SM_ERR_LAUNCH;
+    const long long t1 = (long long)kk * (d->cin / 8) * pl.S * pl.L;
+    hipLaunchKernelGGL(deform_im2col_t_kernel, dim3((int)std::min<long long>((t1 + 255) / 256, 256 * 64)), dim3(256), 0, s, a,
+                       pl.S, pl.L, pl.Kpad, colT);
+    const long long t2 = (long long)pl.S * pl.cout_pad2 * pl.L;
+    hipLaunchKernelGGL(gout_t_kernel, dim3((int)std::min<long long>((t2 + 255) / 256, 256 * 64)), dim3(256), 0, s, a, pl.S,
+                       pl.L, pl.cout_pad2, goutT);
+    SM_LAUNCH_CHECK();
+    sm_conv_desc g2;
+    memset(&g2, 0, sizeof(g2));
+    g2.nlev = 1;
+    g2.batch = pl.S;
+    g2.in_h[0] = g2.out_h[0] = 1;
+    g2.in_w[0] = g2.out_w[0] = pl.Kpad;
+    g2.cin = pl.L;
+    g2.cout = d->cout;
+    g2.cout_pad = pl.cout_pad2;
+    g2.kh = g2.kw = 1, g2.stride = 1, g2.pad = 0, g2.dil = 1;
+    g2.in_cstride = pl.L;
+    g2.out_cstride = d->cout;
+    g2.flags = SM_CONV_OUT_F32;
+    g2.w_batch_stride = (long long)pl.cout_pad2 * pl.L;
+    const int st = sm_conv2d(&g2, colT, goutT, nullptr, nullptr, part, stream);
+    if (st != SM_OK) return st;
     const long long nout = pl.K * d->cout;
-    bool first = true;
-    for (long long p0 = 0; p0 < pl.P; p0 += pl.chunk) {
-      const int n = (int)std::min<long long>(pl.chunk, pl.P - p0);
-      const int Lp = (n + 63) / 64 * 64;
-      const long long t1 = (long long)kk * (d->cin / 8) * Lp;
-      hipLaunchKernelGGL(deform_im2col_t_kernel, dim3((int)std::min<long long>((t1 + 255) / 256, 256 * 64)), dim3(256), 0, s, a,
-                         p0, n, Lp, colT);
-      const long long t2 = (long long)pl.cout_pad2 * Lp;
-      hipLaunchKernelGGL(gout_t_kernel, dim3((int)std::min<long long>((t2 + 255) / 256, 256 * 64)), dim3(256), 0, s, a, p0, n,
-                         Lp, pl.cout_pad2, goutT);
-      SM_LAUNCH_CHECK();
-      sm_conv_desc g2;
-      memset(&g2, 0, sizeof(g2));
-      g2.nlev = 1;
-      g2.batch = 1;
-      g2.in_h[0] = g2.out_h[0] = 1;
-      g2.in_w[0] = g2.out_w[0] = (int)pl.K;
-      g2.cin = Lp;
-      g2.cout = d->cout;
-      g2.cout_pad = pl.cout_pad2;
-      g2.kh = g2.kw = 1, g2.stride = 1, g2.pad = 0, g2.dil = 1;
-      g2.in_cstride = Lp;
-      g2.out_cstride = d->cout;
-      g2.flags = SM_CONV_OUT_F32;
-      int st = sm_conv2d(&g2, colT, goutT, nullptr, nullptr, first ? (void*)grad_w_t : (void*)dtmp, stream);
-      if (st != SM_OK) return st;
-      if (!first) {
-        hipLaunchKernelGGL(axpy_kernel, dim3((int)std::min<long long>((nout + 255) / 256, 4096)), dim3(256), 0, s, grad_w_t, dtmp,
-                           nout);
-        SM_LAUNCH_CHECK();
-      }
-      first = false;
-    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long long>((nout + 255) / 256, 4096)), dim3(256), 0, s, part,
+                       grad_w_t, pl.S, pl.K, pl.Kpad, d->cout);
+    SM_LAUNCH_CHECK();
   }
   return SM_OK;
 }
