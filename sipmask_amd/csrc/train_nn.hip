@@ -126,25 +126,36 @@ __global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
-// adjoint of the above: dx zeroed by the host, 4 float atomics per output pixel
+// adjoint of the above in gather form (deterministic, no atomics): input pixel (y, x) collects from the <= 3f x 3f
+// output pixels whose interpolation touches it, with the forward's own index/weight function (so clamped borders,
+// where both taps land on the same source pixel, get weight 1 as in the forward)
 __global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long planes, int h, int w,
                                     int f) {
   const int ho = h * f, wo = w * f;
-  const long long total = planes * ho * wo;
+  const long long total = planes * h * w;
   const float inv = 1.f / (float)f;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-    const int ox = (int)(t % wo), oy = (int)((t / wo) % ho);
-    const long long p = t / ((long long)wo * ho);
-    int y0, y1, x0, x1;
-    float ly, lx;
-    bil_src(oy, h, inv, y0, y1, ly);
-    bil_src(ox, w, inv, x0, x1, lx);
-    const float g = dy[t];
-    float* d = dx + p * h * w;
-    unsafeAtomicAdd(d + y0 * w + x0, g * (1.f - ly) * (1.f - lx));
-    unsafeAtomicAdd(d + y0 * w + x1, g * (1.f - ly) * lx);
-    unsafeAtomicAdd(d + y1 * w + x0, g * ly * (1.f - lx));
-    unsafeAtomicAdd(d + y1 * w + x1, g * ly * lx);
+    const int x = (int)(t % w), y = (int)((t / w) % h);
+    const long long p = t / ((long long)w * h);
+    const float* g = dy + p * ho * wo;
+    float acc = 0.f;
+    for (int oy = max(0, f * y - f); oy < min(ho, f * y + 2 * f); ++oy) {
+      int y0, y1;
+      float ly;
+      bil_src(oy, h, inv, y0, y1, ly);
+      const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int ox = max(0, f * x - f); ox < min(wo, f * x + 2 * f); ++ox) {
+        int x0, x1;
+        float lx;
+        bil_src(ox, w, inv, x0, x1, lx);
+        const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+        if (wx != 0.f) row += wx * g[(long long)oy * wo + ox];
+      }
+      acc += wy * row;
+    }
+    dx[t] = acc;
   }
 }
 
@@ -204,9 +215,7 @@ extern "C" int sm_upsample_bilinear_nchw_bwd(const float* dy, float* dx, int64_t
                                              sm_stream_t stream) {
   if (!dy || !dx) return SM_ERR_BAD_ARG;
   if (planes < 1 || h < 1 || w < 1 || factor < 1) return SM_ERR_BAD_SHAPE;
-  hipStream_t s = sm_hip_stream(stream);
-  if (hipMemsetAsync(dx, 0, sizeof(float) * planes * h * w, s) != hipSuccess) return SM_ERR_LAUNCH;
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_1d(planes * h * w * factor * factor)), dim3(256), 0, s, dy, dx,
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_1d(planes * h * w)), dim3(256), 0, sm_hip_stream(stream), dy, dx,
                      (long long)planes, h, w, factor);
   SM_LAUNCH_CHECK();
   return SM_OK;

@@ -24,6 +24,20 @@ from . import _lib
 from . import hip_ops as H
 
 
+def _rows_bf16(t, c):
+    """NCHW float tensor -> bf16 NHWC rows [B*H*W, c].  A channels_last-strided tensor (what the conv ops below
+    return: an NHWC buffer viewed as NCHW) is just cast -- no transposition; an NCHW-contiguous one goes through
+    the transposing kernel."""
+    b, _, h, w = t.shape
+    t = t.detach()
+    nhwc = t.permute(0, 2, 3, 1)
+    if nhwc.is_contiguous():
+        return nhwc.reshape(b * h * w, c).to(torch.bfloat16)
+    x = torch.empty(b * h * w, c, dtype=torch.bfloat16, device=t.device)
+    H.nchw_to_nhwc_bf16(t.float().contiguous(), x, c)
+    return x
+
+
 # ------------------------------------------------------------------------------- deform conv
 class DeformConvFunction(Function):
 
@@ -55,8 +69,7 @@ class DeformConvFunction(Function):
             raise NotImplementedError("channels must be a multiple of 8*deformable_groups")
         cur_im2col_step = min(im2col_step, b)
         assert (b % cur_im2col_step) == 0, "im2col step must divide batchsize"
-        x = torch.empty(b * h * w, c, dtype=torch.bfloat16, device=input.device)
-        H.nchw_to_nhwc_bf16(input.detach().float().contiguous(), x, c)
+        x = _rows_bf16(input, c)
         off = offset.detach().float().permute(0, 2, 3, 1).contiguous().view(b * ho * wo, -1)
         wq, co_pad = H.prep_conv_weight(weight.detach())
         y = torch.empty(b * ho * wo, co, dtype=torch.float32, device=input.device)
@@ -80,8 +93,7 @@ class DeformConvFunction(Function):
         dev = grad_output.device
         if c % 64 != 0 or (c // g) % 64 != 0 or co % 8 != 0:
             raise NotImplementedError("deform conv backward needs 64 | channels per deformable group and 8 | out_channels")
-        go = torch.empty(b * ho * wo, co, dtype=torch.bfloat16, device=dev)
-        H.nchw_to_nhwc_bf16(grad_output.detach().float().contiguous(), go, co)
+        go = _rows_bf16(grad_output, co)
         d = H.make_conv_desc(b, [(h, w)], [(ho, wo)], [0], [0], c, co, co, k, 1, pad, c, co,
                              dil=dil, deform_groups=g)
         need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
@@ -168,8 +180,7 @@ class Conv2dFunction(Function):
             raise NotImplementedError("square kernels, channels a multiple of 8")
         ho = (h + 2 * padding - (dilation * (k - 1) + 1)) // stride + 1
         wo = (w + 2 * padding - (dilation * (k - 1) + 1)) // stride + 1
-        x = torch.empty(b * h * w, c, dtype=torch.bfloat16, device=input.device)
-        H.nchw_to_nhwc_bf16(input.detach().float().contiguous(), x, c)
+        x = _rows_bf16(input, c)
         wq, co_pad = H.prep_conv_weight(weight.detach())
         y = torch.empty(b * ho * wo, co, dtype=torch.float32, device=input.device)
         d = H.make_conv_desc(b, [(h, w)], [(ho, wo)], [0], [0], c, co, co_pad, k, stride, padding, c, co,
@@ -185,8 +196,7 @@ class Conv2dFunction(Function):
         x, weight = ctx.saved_tensors
         b, c, h, w, co, k, ho, wo, stride, pad, dil, dt, has_bias = ctx.geom
         dev = grad_output.device
-        go = torch.empty(b * ho * wo, co, dtype=torch.bfloat16, device=dev)
-        H.nchw_to_nhwc_bf16(grad_output.detach().float().contiguous(), go, co)
+        go = _rows_bf16(grad_output, co)
         d = H.make_conv_desc(b, [(h, w)], [(ho, wo)], [0], [0], c, co, co, k, stride, pad, c, co, dil=dil)
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
         K = k * k * c
