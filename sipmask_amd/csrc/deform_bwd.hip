@@ -192,6 +192,72 @@ __global__ __launch_bounds__(256) void deform_im2col_t_kernel(const DBArgs a, in
   }
 }
 
+// Tiled transposition for the offset-free case (every plain convolution): a block moves a 64-position x 64-channel
+// tile per tap through LDS, so the reads are full 128-byte channel runs of the NHWC rows and the writes are 16-byte
+// position runs of the K-major col^T rows (the generic kernel above gathers 16 B per lane from 64 different rows).
+// MODE 0: col^T of x (taps, zero padding outside the image); MODE 1: gout^T (one "tap", no shift, rows >= cout zero).
+template <int MODE>
+__global__ __launch_bounds__(256) void transpose_tile_kernel(const DBArgs a, int S, int L, int rows_per_slice, int nch,
+                                                             uint16_t* __restrict__ out) {
+  __shared__ uint16_t tile[64][72];                  // [position][channel], 144-byte pitch: conflict-free both ways
+  const int tid = threadIdx.x;
+  const long long gp0 = (long long)blockIdx.x * 64;  // first position (global index over S*L) of the tile
+  const int c0 = blockIdx.y * 64;                    // first channel
+  const int sl = (int)(gp0 / L), pl0 = (int)(gp0 - (long long)sl * L);
+  const int ntap = MODE == 0 ? a.kh * a.kw : 1;
+  // load role: thread -> (position tid>>2... two passes), 16-byte channel chunk
+  const int lp = tid >> 3, lc = (tid & 7) * 8;       // 32 positions per pass, 8 chunks of 8 channels
+  // store role: thread -> (channel tid>>2... two passes), 16-byte position chunk
+  const int sc = tid >> 3, sp = (tid & 7) * 8;
+  Pos ps[2];
+  bool pv[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const long long gp = gp0 + lp + 32 * h;
+    pv[h] = gp < a.P;
+    if (pv[h]) ps[h] = locate(a, gp);
+  }
+  for (int tap = 0; tap < ntap; ++tap) {
+    const int ti = MODE == 0 ? tap / a.kw : 0, tj = MODE == 0 ? tap - ti * a.kw : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (pv[h] && c0 + lc < nch) {
+        if (MODE == 0) {
+          const int iy = ps[h].oy * a.stride - a.pad + ti * a.dil, ix = ps[h].ox * a.stride - a.pad + tj * a.dil;
+          const int Hh = a.in_h[ps[h].l], Ww = a.in_w[ps[h].l];
+          if (iy >= 0 && iy < Hh && ix >= 0 && ix < Ww) {
+            const long long row = a.in_row0[ps[h].l] + ((long long)ps[h].b * Hh + iy) * Ww + ix;
+            v = *reinterpret_cast<const u32x4*>(a.x + row * a.in_cstride + c0 + lc);
+          }
+        } else {
+          v = *reinterpret_cast<const u32x4*>(a.gout + ps[h].orow * a.gout_cstride + c0 + lc);
+        }
+      }
+      *reinterpret_cast<u32x4*>(&tile[lp + 32 * h][lc]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = sc + 32 * h;
+      if (c0 + c < rows_per_slice - (MODE == 0 ? tap * 0 : 0)) {
+        uint16_t r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = tile[sp + e][c];
+        u32x4 w;
+        w[0] = r[0] | ((uint32_t)r[1] << 16);
+        w[1] = r[2] | ((uint32_t)r[3] << 16);
+        w[2] = r[4] | ((uint32_t)r[5] << 16);
+        w[3] = r[6] | ((uint32_t)r[7] << 16);
+        const long long krow = MODE == 0 ? (long long)tap * a.cin + c0 + c : (long long)(c0 + c);
+        const bool ok = MODE == 0 ? (c0 + c < a.cin) : (c0 + c < rows_per_slice);
+        if (ok) *reinterpret_cast<u32x4*>(out + ((long long)sl * rows_per_slice + krow) * L + pl0 + sp) = w;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // gout^T, slice-major: goutT[s][co][pl] (bf16); rows cout..cout_pad and positions >= P are zero
 __global__ __launch_bounds__(256) void gout_t_kernel(const DBArgs a, int S, int L, int cout_pad,
                                                      uint16_t* __restrict__ goutT) {
@@ -404,12 +470,18 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
     if (pl.Kpad != pl.K &&
         hipMemsetAsync(colT, 0, (size_t)pl.S * pl.Kpad * pl.L * 2, s) != hipSuccess)   // padding rows of every slice
       return SM_ERR_LAUNCH;
-    const long long t1 = (long long)kk * (d->cin / 8) * pl.S * pl.L;
-    hipLaunchKernelGGL(deform_im2col_t_kernel, dim3((int)std::min<long long>((t1 + 255) / 256, 256 * 64)), dim3(256), 0, s, a,
-                       pl.S, pl.L, pl.Kpad, colT);
-    const long long t2 = (long long)pl.S * pl.cout_pad2 * pl.L;
-    hipLaunchKernelGGL(gout_t_kernel, dim3((int)std::min<long long>((t2 + 255) / 256, 256 * 64)), dim3(256), 0, s, a, pl.S,
-                       pl.L, pl.cout_pad2, goutT);
+    const int ptiles = (int)((long long)pl.S * pl.L / 64);      // L is a multiple of 64
+    if (offset == nullptr) {
+      hipLaunchKernelGGL(transpose_tile_kernel<0>, dim3(ptiles, (d->cin + 63) / 64), dim3(256), 0, s, a, pl.S, pl.L, pl.Kpad,
+                         d->cin, colT);
+    } else {
+      const long long t1 = (long long)kk * (d->cin / 8) * pl.S * pl.L;
+      hipLaunchKernelGGL(deform_im2col_t_kernel, dim3((int)std::min<long long>((t1 + 255) / 256, 256 * 64)), dim3(256), 0, s,
+                         a, pl.S, pl.L, pl.Kpad, colT);
+    }
+    // gout^T: rows cout..cout_pad2 of every slice must be zero (they are weight rows of the GEMM)
+    hipLaunchKernelGGL(transpose_tile_kernel<1>, dim3(ptiles, (pl.cout_pad2 + 63) / 64), dim3(256), 0, s, a, pl.S, pl.L,
+                       pl.cout_pad2, d->cout, goutT);
     SM_LAUNCH_CHECK();
     sm_conv_desc g2;
     memset(&g2, 0, sizeof(g2));
