@@ -21,63 +21,88 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
   return t;
 }
 
-// nn.GroupNorm (+ optional ReLU): y = gamma * (x - mean) * rstd + beta.  One block per (n, group).
-// stats[n][g] = (mean, rstd) is kept for the backward.
-__global__ __launch_bounds__(TN_THREADS) void gn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ y,
-                                                            float* __restrict__ stats, int C, int HW, int G, float eps,
-                                                            int relu) {
+// nn.GroupNorm (+ optional ReLU): y = gamma * (x - mean) * rstd + beta, in two fully parallel phases.  A group of an
+// image is one contiguous run of m = (C/G)*H*W floats in NCHW; phase 1 reduces it with `nsplit` blocks per group
+// (partial sums of x - pivot and (x - pivot)^2, pivot = the group's first element, so the variance does not lose
+// precision to a large mean), phase 2 is elementwise.  One block per group would leave the chip idle: 32 groups x
+// 4 images = 128 blocks for 256 CUs, each streaming megabytes.
+__global__ __launch_bounds__(TN_THREADS) void gn_reduce_kernel(const float* __restrict__ x, float* __restrict__ part, int C,
+                                                               int HW, int G, int nsplit) {
   __shared__ float s_red[TN_THREADS / 64];
-  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int g = blockIdx.x, n = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
   const int cpg = C / G;
   const long long base = ((long long)n * C + (long long)g * cpg) * HW;
   const int m = cpg * HW;
-  float s = 0.f;
-  for (int i = tid; i < m; i += TN_THREADS) s += x[base + i];
-  const float mean = block_sum(s, s_red) / (float)m;
-  float ss = 0.f;
-  for (int i = tid; i < m; i += TN_THREADS) {
-    const float d = x[base + i] - mean;
+  const int per = (m + nsplit - 1) / nsplit;
+  const int lo = sp * per, hi = min(lo + per, m);
+  const float pivot = x[base];
+  float s = 0.f, ss = 0.f;
+  for (int i = lo + tid; i < hi; i += TN_THREADS) {
+    const float d = x[base + i] - pivot;
+    s += d;
     ss += d * d;
   }
-  const float var = block_sum(ss, s_red) / (float)m;      // biased variance, two-pass (as ATen's CPU kernel)
-  const float rstd = rsqrtf(var + eps);
+  s = block_sum(s, s_red);
+  ss = block_sum(ss, s_red);
   if (tid == 0) {
-    stats[((long long)n * G + g) * 2 + 0] = mean;
-    stats[((long long)n * G + g) * 2 + 1] = rstd;
-  }
-  for (int i = tid; i < m; i += TN_THREADS) {
-    const int c = g * cpg + i / HW;
-    float v = (x[base + i] - mean) * rstd * gamma[c] + beta[c];
-    if (relu) v = fmaxf(v, 0.f);
-    y[base + i] = v;
+    unsafeAtomicAdd(part + ((long long)n * G + g) * 2 + 0, s);
+    unsafeAtomicAdd(part + ((long long)n * G + g) * 2 + 1, ss);
   }
 }
 
-// backward of the above: dy is first masked by (y > 0) when relu.  dgamma/dbeta are accumulated with atomics
-// (zeroed by the host wrapper); dx = rstd * (gamma*dy - mean_g(gamma*dy) - xhat * mean_g(gamma*dy*xhat)).
-__global__ __launch_bounds__(TN_THREADS) void gn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                            const float* __restrict__ dy, const float* __restrict__ gamma,
-                                                            const float* __restrict__ stats, float* __restrict__ dx,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
-                                                            int HW, int G, int relu) {
+// part (sum, sum of squares of x - pivot) -> stats (mean, rstd); one thread per (n, g)
+__global__ void gn_finish_kernel(const float* __restrict__ x, const float* __restrict__ part, float* __restrict__ stats,
+                                 int NG, int C, int HW, int G, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NG) return;
+  const int n = i / G, g = i - n * G;
+  const int cpg = C / G;
+  const float m = (float)cpg * (float)HW;
+  const float pivot = x[((long long)n * C + (long long)g * cpg) * HW];
+  const float ms = part[i * 2] / m;
+  const float var = fmaxf(part[i * 2 + 1] / m - ms * ms, 0.f);
+  stats[i * 2] = pivot + ms;
+  stats[i * 2 + 1] = rsqrtf(var + eps);
+}
+
+__global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ stats, float* __restrict__ y, long long total, int C, int HW,
+                                int G, int relu) {
+  const int cpg = C / G;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW) % C);
+    const long long ng = (i / ((long long)C * HW)) * G + c / cpg;
+    float v = (x[i] - stats[ng * 2]) * stats[ng * 2 + 1] * gamma[c] + beta[c];
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = v;
+  }
+}
+
+// backward: dy is first masked by (y > 0) when relu.  Phase 1 (nsplit blocks per (n, group)): per-channel
+// sums a_c = sum dy*xhat, b_c = sum dy -> atomics into dgamma / dbeta and into the group's (sum gamma*b, sum gamma*a);
+// phase 2 elementwise: dx = rstd * (gamma*dy - mean_g(gamma*dy) - xhat * mean_g(gamma*dy*xhat)).
+__global__ __launch_bounds__(TN_THREADS) void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                   const float* __restrict__ dy,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ stats, float* __restrict__ part,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                   int C, int HW, int G, int relu, int nsplit) {
   __shared__ float s_red[TN_THREADS / 64];
-  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int g = blockIdx.x, n = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
   const int cpg = C / G;
   const long long base = ((long long)n * C + (long long)g * cpg) * HW;
-  const int m = cpg * HW;
   const float mean = stats[((long long)n * G + g) * 2 + 0], rstd = stats[((long long)n * G + g) * 2 + 1];
+  const int per = (HW + nsplit - 1) / nsplit;
+  const int lo = sp * per, hi = min(lo + per, HW);
   float s1 = 0.f, s2 = 0.f;
-  // per-channel sums for dgamma / dbeta: channels are visited one after another (HW elements each)
   for (int cl = 0; cl < cpg; ++cl) {
     const int c = g * cpg + cl;
     float a = 0.f, b = 0.f;
-    for (int i = tid; i < HW; i += TN_THREADS) {
+    for (int i = lo + tid; i < hi; i += TN_THREADS) {
       const long long o = base + (long long)cl * HW + i;
       float d = dy[o];
       if (relu && !(y[o] > 0.f)) d = 0.f;
-      const float xh = (x[o] - mean) * rstd;
-      a += d * xh;
+      a += d * ((x[o] - mean) * rstd);
       b += d;
     }
     const float ta = block_sum(a, s_red), tb = block_sum(b, s_red);
@@ -85,18 +110,29 @@ __global__ __launch_bounds__(TN_THREADS) void gn_bwd_kernel(const float* __restr
       if (dgamma) unsafeAtomicAdd(dgamma + c, ta);
       if (dbeta) unsafeAtomicAdd(dbeta + c, tb);
     }
-    s1 += gamma[c] * tb;     // every thread holds the block totals
+    s1 += gamma[c] * tb;
     s2 += gamma[c] * ta;
   }
-  if (!dx) return;
-  const float m1 = s1 / (float)m, m2 = s2 / (float)m;
-  for (int i = tid; i < m; i += TN_THREADS) {
-    const int c = g * cpg + i / HW;
-    const long long o = base + i;
-    float d = dy[o];
-    if (relu && !(y[o] > 0.f)) d = 0.f;
-    const float xh = (x[o] - mean) * rstd;
-    dx[o] = rstd * (gamma[c] * d - m1 - xh * m2);
+  if (tid == 0) {
+    unsafeAtomicAdd(part + ((long long)n * G + g) * 2 + 0, s1);
+    unsafeAtomicAdd(part + ((long long)n * G + g) * 2 + 1, s2);
+  }
+}
+
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                    const float* __restrict__ gamma, const float* __restrict__ stats,
+                                    const float* __restrict__ part, float* __restrict__ dx, long long total, int C, int HW,
+                                    int G, int relu) {
+  const int cpg = C / G;
+  const float inv_m = 1.f / ((float)cpg * (float)HW);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW) % C);
+    const long long ng = (i / ((long long)C * HW)) * G + c / cpg;
+    float d = dy[i];
+    if (relu && !(y[i] > 0.f)) d = 0.f;
+    const float rstd = stats[ng * 2 + 1];
+    const float xh = (x[i] - stats[ng * 2]) * rstd;
+    dx[i] = rstd * (gamma[c] * d - part[ng * 2] * inv_m - xh * part[ng * 2 + 1] * inv_m);
   }
 }
 
@@ -176,13 +212,30 @@ inline int grid_1d(long long n) { return (int)std::min<long long>((n + 255) / 25
 
 }  // namespace
 
+static int gn_nsplit(int batch, int groups, long long m) {
+  // enough blocks for the chip (>= ~1024), at least ~16 K elements per block
+  long long want = (1024 + (long long)batch * groups - 1) / ((long long)batch * groups);
+  long long cap = (m + 16383) / 16384;
+  long long ns = want < cap ? want : cap;
+  return (int)(ns < 1 ? 1 : (ns > 64 ? 64 : ns));
+}
+
 extern "C" int sm_groupnorm_nchw_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
                                      int batch, int channels, int hw, int groups, float eps, int relu,
                                      sm_stream_t stream) {
   if (!x || !gamma || !beta || !y || !stats) return SM_ERR_BAD_ARG;
   if (batch < 1 || channels < 1 || hw < 1 || groups < 1 || channels % groups != 0) return SM_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(gn_fwd_kernel, dim3(groups, batch), dim3(TN_THREADS), 0, sm_hip_stream(stream), x, gamma, beta, y,
-                     stats, channels, hw, groups, eps, relu);
+  hipStream_t s = sm_hip_stream(stream);
+  const int ng = batch * groups;
+  const long long m = (long long)(channels / groups) * hw;
+  const int ns = gn_nsplit(batch, groups, m);
+  // the (mean, rstd) buffer doubles as the partial-sum buffer of phase 1
+  if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * ng, s) != hipSuccess) return SM_ERR_LAUNCH;
+  hipLaunchKernelGGL(gn_reduce_kernel, dim3(groups, batch, ns), dim3(TN_THREADS), 0, s, x, stats, channels, hw, groups, ns);
+  hipLaunchKernelGGL(gn_finish_kernel, dim3((ng + 63) / 64), dim3(64), 0, s, x, stats, stats, ng, channels, hw, groups, eps);
+  const long long total = (long long)batch * channels * hw;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_1d(total)), dim3(256), 0, s, x, gamma, beta, stats, y, total, channels, hw,
+                     groups, relu);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -192,11 +245,24 @@ extern "C" int sm_groupnorm_nchw_bwd(const float* x, const float* y, const float
                                      int channels, int hw, int groups, int relu, sm_stream_t stream) {
   if (!x || !dy || !gamma || !stats || (relu && !y)) return SM_ERR_BAD_ARG;
   if (batch < 1 || channels < 1 || hw < 1 || groups < 1 || channels % groups != 0) return SM_ERR_BAD_SHAPE;
+  if (batch * groups > 4096) return SM_ERR_UNSUPPORTED;
   hipStream_t s = sm_hip_stream(stream);
   if (dgamma && hipMemsetAsync(dgamma, 0, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
   if (dbeta && hipMemsetAsync(dbeta, 0, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
-  hipLaunchKernelGGL(gn_bwd_kernel, dim3(groups, batch), dim3(TN_THREADS), 0, s, x, y, dy, gamma, stats, dx, dgamma, dbeta,
-                     channels, hw, groups, relu);
+  // group sums (sum gamma*dy, sum gamma*dy*xhat): a small scratch inside the library (one per stream would be the
+  // caller's job; the plan issues GroupNorm backward launches in order on one stream)
+  static float* part = nullptr;
+  if (!part && hipMalloc((void**)&part, sizeof(float) * 2 * 4096) != hipSuccess) return SM_ERR_WORKSPACE;
+  const int ng = batch * groups;
+  if (hipMemsetAsync(part, 0, sizeof(float) * 2 * ng, s) != hipSuccess) return SM_ERR_LAUNCH;
+  const int ns = gn_nsplit(batch, groups, hw);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(groups, batch, ns), dim3(TN_THREADS), 0, s, x, y, dy, gamma, stats, part,
+                     dgamma, dbeta, channels, hw, groups, relu, ns);
+  if (dx) {
+    const long long total = (long long)batch * channels * hw;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_1d(total)), dim3(256), 0, s, x, y, dy, gamma, stats, part, dx, total,
+                       channels, hw, groups, relu);
+  }
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
