@@ -19,7 +19,8 @@ GRID = "359424"
 
 
 def one(pattern):
-    return sorted(glob.glob(os.path.join(SRC, pattern)))[-1]
+    # gpurun_out/ accumulates the files of every call: take the newest match
+    return max(glob.glob(os.path.join(SRC, pattern)), key=os.path.getmtime)
 
 
 def with_header(src, dst, header):
