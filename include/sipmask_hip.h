@@ -328,10 +328,11 @@ int sm_preprocess_u8(const uint8_t* src, int src_h, int src_w, int new_h, int ne
  * sipmask_head.py:42,52).  stats f32 [batch][groups][2] = (mean, rstd) saved for the backward. */
 int sm_groupnorm_nchw_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int batch,
                           int channels, int hw, int groups, float eps, int relu, sm_stream_t stream);
-/* dy is masked by (y > 0) when relu.  dx / dgamma / dbeta nullable; dgamma, dbeta are overwritten. */
+/* dy is masked by (y > 0) when relu.  dx / dgamma / dbeta nullable; dgamma, dbeta are overwritten.
+ * scratch: f32 [batch][groups][2] (group sums between the reduction phase and the elementwise phase). */
 int sm_groupnorm_nchw_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* stats,
-                          float* dx, float* dgamma, float* dbeta, int batch, int channels, int hw, int groups,
-                          int relu, sm_stream_t stream);
+                          float* dx, float* dgamma, float* dbeta, float* scratch, int batch, int channels, int hw,
+                          int groups, int relu, sm_stream_t stream);
 /* F.interpolate(bilinear, align_corners=False, integer scale_factor) on `planes` = N*C planes of h x w, and its
  * adjoint (dx overwritten). */
 int sm_upsample_bilinear_nchw_fwd(const float* x, float* y, int64_t planes, int h, int w, int factor,

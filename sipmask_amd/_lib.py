@@ -86,7 +86,7 @@ PROTOTYPES = {
     "sm_mask_rescore": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "sm_conv2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_groupnorm_nchw_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
-    "sm_groupnorm_nchw_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sm_groupnorm_nchw_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sm_upsample_bilinear_nchw_fwd": (_I, [_P, _P, C.c_int64, _I, _I, _I, _P]),
     "sm_upsample_bilinear_nchw_bwd": (_I, [_P, _P, C.c_int64, _I, _I, _I, _P]),
     "sm_sgd_step": (_I, [_P, _P, _P, C.c_int64, _F, _F, _F, _I, _P]),

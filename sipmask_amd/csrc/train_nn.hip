@@ -241,26 +241,22 @@ extern "C" int sm_groupnorm_nchw_fwd(const float* x, const float* gamma, const f
 }
 
 extern "C" int sm_groupnorm_nchw_bwd(const float* x, const float* y, const float* dy, const float* gamma,
-                                     const float* stats, float* dx, float* dgamma, float* dbeta, int batch,
-                                     int channels, int hw, int groups, int relu, sm_stream_t stream) {
-  if (!x || !dy || !gamma || !stats || (relu && !y)) return SM_ERR_BAD_ARG;
+                                     const float* stats, float* dx, float* dgamma, float* dbeta, float* scratch,
+                                     int batch, int channels, int hw, int groups, int relu, sm_stream_t stream) {
+  if (!x || !dy || !gamma || !stats || !scratch || (relu && !y)) return SM_ERR_BAD_ARG;
   if (batch < 1 || channels < 1 || hw < 1 || groups < 1 || channels % groups != 0) return SM_ERR_BAD_SHAPE;
-  if (batch * groups > 4096) return SM_ERR_UNSUPPORTED;
   hipStream_t s = sm_hip_stream(stream);
   if (dgamma && hipMemsetAsync(dgamma, 0, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
   if (dbeta && hipMemsetAsync(dbeta, 0, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
-  // group sums (sum gamma*dy, sum gamma*dy*xhat): a small scratch inside the library (one per stream would be the
-  // caller's job; the plan issues GroupNorm backward launches in order on one stream)
-  static float* part = nullptr;
-  if (!part && hipMalloc((void**)&part, sizeof(float) * 2 * 4096) != hipSuccess) return SM_ERR_WORKSPACE;
+  // scratch f32 [batch][groups][2]: the group sums (sum gamma*dy, sum gamma*dy*xhat) between the two phases
   const int ng = batch * groups;
-  if (hipMemsetAsync(part, 0, sizeof(float) * 2 * ng, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (hipMemsetAsync(scratch, 0, sizeof(float) * 2 * ng, s) != hipSuccess) return SM_ERR_LAUNCH;
   const int ns = gn_nsplit(batch, groups, hw);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(groups, batch, ns), dim3(TN_THREADS), 0, s, x, y, dy, gamma, stats, part,
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(groups, batch, ns), dim3(TN_THREADS), 0, s, x, y, dy, gamma, stats, scratch,
                      dgamma, dbeta, channels, hw, groups, relu, ns);
   if (dx) {
     const long long total = (long long)batch * channels * hw;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_1d(total)), dim3(256), 0, s, x, y, dy, gamma, stats, part, dx, total,
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_1d(total)), dim3(256), 0, s, x, y, dy, gamma, stats, scratch, dx, total,
                        channels, hw, groups, relu);
   }
   SM_LAUNCH_CHECK();

@@ -447,9 +447,10 @@ def groupnorm_nchw_bwd(x, y, dy, gamma, stats, groups, relu, need_dx=True, need_
     dx = torch.empty_like(x) if need_dx else None
     dg = torch.empty(c, dtype=torch.float32, device=x.device) if need_dw else None
     db = torch.empty(c, dtype=torch.float32, device=x.device) if need_dw else None
+    scratch = torch.empty(b, groups, 2, dtype=torch.float32, device=x.device)
     _lib.check(lib.sm_groupnorm_nchw_bwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(dy), _lib.ptr(gamma), _lib.ptr(stats),
-                                         _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), b, c, hw, groups, int(relu),
-                                         _lib.stream_ptr()), "sm_groupnorm_nchw_bwd")
+                                         _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(scratch), b, c, hw, groups,
+                                         int(relu), _lib.stream_ptr()), "sm_groupnorm_nchw_bwd")
     return dx, dg, db
 
 
