@@ -97,3 +97,63 @@ def test_oracle_mask_loss_equals_numpy_crop_ops():
     ref = ref / (boxes[:, 2] - boxes[:, 0]) / (boxes[:, 3] - boxes[:, 1]) / n
     torch.testing.assert_close(pre, ref, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(loss, (ref * wgt).sum(), rtol=1e-5, atol=1e-6)
+
+
+def test_benchmark_checkpoint_name_conversion():
+    """B/ (maskrcnn-benchmark) parameter names -> mmdet names (pure host logic)."""
+    from oracle import fcos_core as OB
+    from oracle import model as OM
+    from sipmask_amd.benchmark_variant import convert_state_dict
+    head = OB.init_head_state_dict(seed=1)
+    conv = convert_state_dict({"module." + k: v for k, v in head.items()})
+    assert len(conv) == len(head)
+    assert OM.tower_depths(conv) == (3, 4, True)
+    assert torch.equal(conv["bbox_head.cls_convs.2.gn.weight"], head["rpn.head.cls_tower.7.weight"])
+    assert torch.equal(conv["bbox_head.reg_convs.3.conv.bias"], head["rpn.head.bbox_tower.9.bias"])
+    assert torch.equal(conv["bbox_head.fcos_cls.weight"], head["rpn.head.cls_logits.weight"])
+    assert conv["bbox_head.scales.4.scale"].shape == ()
+    trunk = {"backbone.body.stem.conv1.weight": torch.zeros(1), "backbone.body.layer3.5.bn2.running_var": torch.zeros(1),
+             "backbone.body.layer2.0.downsample.0.weight": torch.zeros(1), "backbone.fpn.fpn_inner2.weight": torch.zeros(1),
+             "backbone.fpn.fpn_layer4.bias": torch.zeros(1), "backbone.fpn.top_blocks.p6.weight": torch.zeros(1),
+             "backbone.fpn.top_blocks.p7.bias": torch.zeros(1), "rpn.anchor_generator.cell_anchors.0": torch.zeros(1)}
+    assert set(convert_state_dict(trunk)) == {
+        "backbone.conv1.weight", "backbone.layer3.5.bn2.running_var", "backbone.layer2.0.downsample.0.weight",
+        "neck.lateral_convs.0.conv.weight", "neck.fpn_convs.2.conv.bias", "neck.fpn_convs.3.conv.weight",
+        "neck.fpn_convs.4.conv.bias"}
+
+
+def test_oracle_ml_nms_equals_per_label_nms():
+    """B/ ml_nms == the golden-pinned greedy NMS run per label (different labels never suppress each other)."""
+    from oracle import fcos_core as OB
+    rng = np.random.RandomState(2)
+    n = 300
+    xy = rng.rand(n, 2).astype(np.float32) * 200
+    boxes = np.concatenate([xy, xy + rng.rand(n, 2).astype(np.float32) * 60 + 5], 1)
+    scores = rng.rand(n).astype(np.float32)
+    labels = rng.randint(1, 6, n)
+    keep = OB.ml_nms(boxes, scores, labels, 0.6)
+    ref = []
+    for c in range(1, 6):
+        idx = np.nonzero(labels == c)[0]
+        k = O.nms(np.concatenate([boxes[idx], scores[idx, None]], 1), 0.6, mode="gpu")
+        ref.extend(idx[k].tolist())
+    assert sorted(ref) == keep.tolist()
+
+
+def test_oracle_input_pipeline_properties():
+    """numpy restatement of Resize/Normalize/Pad: size rule, identity resize, constant images, zero padding."""
+    from oracle import pipeline as OP
+    from sipmask_amd.input_pipeline import rescale_size
+    for (h, w) in ((480, 640), (375, 500), (900, 1400), (800, 1333), (1333, 800)):
+        assert rescale_size(h, w, (1333, 800)) == OP.rescale_size(h, w, (1333, 800))
+        nh, nw, f = OP.rescale_size(h, w, (1333, 800))
+        assert max(nh, nw) <= 1333 and min(nh, nw) <= 800 and (max(nh, nw) == 1333 or min(nh, nw) == 800)
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(OP.resize_bilinear_u8(img, 37, 53), img)              # same size: identity
+    const = np.full((20, 30, 3), 77, np.uint8)
+    assert (OP.resize_bilinear_u8(const, 47, 61) == 77).all()                            # constants stay constant
+    out, meta = OP.prepare(const, (100, 60), mean=(70, 70, 70), std=(1, 1, 1))
+    nh, nw = meta["img_shape"][:2]
+    assert out.shape[1] % 32 == 0 and out.shape[2] % 32 == 0
+    assert (out[:, :nh, :nw] == 7).all() and (out[:, nh:, :] == 0).all() and (out[:, :, nw:] == 0).all()
