@@ -181,7 +181,7 @@ def main():
     if os.path.exists(pmc_file) and B == 4:
         pmc = json.load(open(pmc_file))
         traffic = round(pmc["hbm_bytes_per_launch"] / 1e6, 1)
-        traffic_src = "profiles/r01_pmc_tower_conv.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), MB per launch"
+        traffic_src = "profiles/r01_pmc_tower_conv.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), MB per launch; measured on the same tile/loader bytes before the K-loop rewrite"
     if args.breakdown and rank == 0:
         with open(args.breakdown, "w") as f:
             f.write("# per-step HIP event times (ms), eager launches, batch %d, mean of %d\n" % (B, reps))
@@ -219,7 +219,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_mb_per_launch": round(towers[0].bytes / 1e6, 1),
-                         "kernel": "conv_igemm_kernel<2,2,2,2,false,true,0> (LDS-DMA, 128x128 tile, 64-wide K steps, GroupNorm "
+                         "kernel": "conv_igemm_kernel<2,2,2,2,false,true,0,3> (LDS-DMA, 128x128 tile, 64-wide K steps, flat loader + pipelined fragment reads, GroupNorm "
                                    "statistics fused) = tower 3x3 256->256 over 5 FPN levels (M=%d,N=256,K=2304)"
                                    % (B * 22400),
                          "gflop_per_launch": round(tower_flops / 1e9, 2), "ms_per_launch": round(tower_ms, 4),

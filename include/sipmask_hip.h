@@ -52,6 +52,10 @@ typedef enum {
 #define SM_CONV_DBG_K64 0x08000000u          /* A/B switch: force 64-wide K steps, 2 blocks per CU */
 #define SM_CONV_DBG_BIG_TILES 0x04000000u    /* A/B switch: never shrink tiles for occupancy */
 #define SM_CONV_DBG_LDS_EPILOGUE 0x01000000u /* A/B switch: LDS-staged epilogue in the 32-wide-K kernel (default: registers) */
+#define SM_CONV_DBG_WIDE_POS 0x00800000u     /* A/B switch: 128-cout x 256-position tiles (64x128 per wave) where the register epilogue applies */
+#define SM_CONV_DBG_TILE256 0x00400000u      /* A/B switch: 256x256 tiles on 8 waves, 1 block per CU (64-wide K steps, cout_pad % 256 == 0) */
+#define SM_CONV_DBG_FLAT_LOOP 0x00200000u    /* A/B switch: flat LDS-DMA loader + peeled K loop WITHOUT the pipelined fragment reads of the default loop */
+#define SM_CONV_DBG_LEGACY_LOOP 0x00100000u  /* A/B switch: the original K loop (branchy loader, one fragment register set) on the 128/64-cout tiles */
 #define SM_CONV_DBG_WARP_SPEC 0x02000000u    /* A/B switch: 8-wave producer/consumer variant of the 64-wide-K kernel */
 
 /* One (multi-level) 2-D convolution as an implicit GEMM.  Replaces the ATen/cuDNN

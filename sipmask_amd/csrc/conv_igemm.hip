@@ -83,28 +83,38 @@ __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u
 // PROD = 1: warp-specialised variant of the LDS-DMA kernel -- 8 waves, waves 0-3 only issue MFMAs + fragment
 // reads (consumers), waves 4-7 only issue the LDS-DMA loads (producers), so a wave never stalls its MFMA stream
 // on the DMA issue port (the two phases of the 4-wave kernel barely overlap: DESIGN.md section 6).
-template <int WCO, int WPOS, int TCO, int TPOS, bool DEFORM, bool DMA, int PROD = 0>
-__global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const ConvKArgs a) {
+// OPT (LDS-DMA path, cin >= 64 only): bit 0 = control-flow-free loader + peeled K loop (one basic block per K step),
+// bit 1 = fragment reads of K sub-step kk+1 issued under the MFMAs of kk (second register set).
+template <int WCO, int WPOS, int TCO, int TPOS, bool DEFORM, bool DMA, int PROD = 0, int OPT = 0>
+__global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2 : 1) void conv_igemm_kernel(const ConvKArgs a) {
   static_assert(!PROD || (DMA && !DEFORM), "producer/consumer split exists for the LDS-DMA path only");
-  constexpr int THREADS = 256 * (1 + PROD);
+  constexpr int NTHR = 64 * WCO * WPOS;            // threads of one role group: 4 waves, or 8 for the 256x256 tile
+  constexpr int THREADS = NTHR * (1 + PROD);
+  constexpr int LROWS = NTHR / 8;                  // tile rows one loader pass covers (8 16-byte chunks per 64-wide K row)
   constexpr int BCO = WCO * TCO * 32;
   constexpr int BPOS = WPOS * TPOS * 32;
-  constexpr int NW = BCO / 32;   // 16-byte weight chunks per thread per K step
-  constexpr int NX = BPOS / 32;  // 16-byte activation chunks per thread per K step
+  constexpr int NW = BCO / LROWS;   // 16-byte weight chunks per thread per K step
+  constexpr int NX = BPOS / LROWS;  // 16-byte activation chunks per thread per K step
   constexpr int STAGE = (BCO + BPOS) * 128;
   constexpr int EPI_LD = BCO + 4;                  // padded f32 row of the epilogue staging tile
   constexpr int EPI_BYTES = BPOS * EPI_LD * 4;
   constexpr int GN_SEG = 4;                        // images a tile may span before falling back to global atomics
   constexpr int GN_BYTES = GN_SEG * (BCO / 8) * 2 * 4;
-  constexpr int SMEM_MAIN = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+  // tiles above 128x128 exist with the register epilogue only (the launcher checks its alignment conditions): their
+  // f32 staging tile would not fit beside nothing, and they are picked for the reuse, not for odd shapes
+  constexpr bool REG_ONLY = BCO * BPOS > 128 * 128;
+  constexpr int SMEM_MAIN = (REG_ONLY || 2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
   constexpr int SMEM_BYTES = SMEM_MAIN + GN_BYTES;  // ONE LDS object (a second one de-pipelines the DMA loop)
-  static_assert(WCO * WPOS == 4, "4 waves");
+  static_assert(WCO * WPOS == 4 || (WCO * WPOS == 8 && !PROD), "4 waves, or 8 without the producer split");
+  static_assert(NW <= 8 && NX <= 8, "Stage8 holds 8 chunks");
+  static_assert(OPT == 0 || (DMA && !PROD), "OPT variants exist for the plain LDS-DMA loop only");
+  static_assert(WCO * WPOS == 4 || OPT == 3, "the 8-wave tile is built on the flat, pipelined loop");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   const int gtid = threadIdx.x;                       // 0..THREADS-1 (epilogue work split)
-  const bool is_prod = PROD && gtid >= 256;           // wave-uniform role
-  const bool is_cons = !PROD || gtid < 256;
-  const int tid = gtid & 255;                          // index inside the role group: loader row/chunk, MFMA wave
+  const bool is_prod = PROD && gtid >= NTHR;          // wave-uniform role
+  const bool is_cons = !PROD || gtid < NTHR;
+  const int tid = PROD ? (gtid & (NTHR - 1)) : gtid;   // index inside the role group: loader row/chunk, MFMA wave
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wco = wave / WPOS;
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
   // to (wave-uniform base + 16*L), i.e. PHYSICAL slot tid&7 of row tid>>3, so the thread must
   // FETCH the logical chunk that belongs there: the swizzle moves to the source side (guide rule 21).
   const int j = DMA ? ((tid & 7) ^ (((tid >> 3) >> 1) & 7)) : (tid & 7);
-  const int r0 = tid >> 3;  // tile row handled by this thread (+32*i)
+  const int r0 = tid >> 3;  // tile row handled by this thread (+LROWS*i)
   const int wslot = (j ^ ((r0 >> 1) & 7)) * 16;
 
   // ---- tile decode (wave-uniform).  Blocks are dispatched round-robin over the 8 XCDs
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
   int rbase[NX], rhi[NX], rwi[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    int m = m0 + r0 + 32 * i;
+    int m = m0 + r0 + LROWS * i;
     if (m < M) {
       int n = m / HoWo;
       int rem = m - n * HoWo;
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
     xoff[i] = (in_row0 + (rbase[i] < 0 ? 0 : rbase[i]) + (long long)rhi[i] * W + rwi[i]) * a.in_cstride;
   }
   const uint16_t* wrow = a.w + (long long)(nt * BCO + r0) * a.Kp + j * 8 + (a.w_bstride != 0 ? (long long)(m0 / HoWo) * a.w_bstride : 0ll);
-  const long long wstride = 32ll * a.Kp;
+  const long long wstride = (long long)LROWS * a.Kp;
   // loader K state (this thread's 16-byte chunk j of the current K step), advanced incrementally:
   // no integer division inside the K loop when a tap holds >= 8 chunks (every layer but the stem)
   int ld_cc, ld_kh, ld_kw, ld_kc = j;
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
       static_for<NX>([&](auto I) {
         constexpr int i = decltype(I)::value;
         const bool ok = kvalid && rhi[i] > -0x20000000;
-        const long long oo = ok ? (orow0 + 32 * i) * (long long)(a.dg * ntap * 2) + (g * ntap + tap) * 2 : 0ll;
+        const long long oo = ok ? (orow0 + LROWS * i) * (long long)(a.dg * ntap * 2) + (g * ntap + tap) * 2 : 0ll;
         off[i] = *reinterpret_cast<const float2*>(a.offset + oo);
       });
       static_for<NX>([&](auto I) {
@@ -350,11 +360,11 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
     unsigned char* Xb = Wb + BCO * 128;
     static_for<NW>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      *reinterpret_cast<u32x4*>(Wb + (r0 + 32 * i) * 128 + wslot) = wreg.template at<i>();
+      *reinterpret_cast<u32x4*>(Wb + (r0 + LROWS * i) * 128 + wslot) = wreg.template at<i>();
     });
     static_for<NX>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      *reinterpret_cast<u32x4*>(Xb + (r0 + 32 * i) * 128 + wslot) = xreg.template at<i>();
+      *reinterpret_cast<u32x4*>(Xb + (r0 + LROWS * i) * 128 + wslot) = xreg.template at<i>();
     });
   };
 
@@ -372,8 +382,47 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
   const int wrow_off = (wco * TCO * 32 + l31) * 128;
   const int xrow_off = BCO * 128 + (wpos * TPOS * 32 + l31) * 128;
 
+  // OPT bit 1: fragments of K sub-step kk+1 are read into a second register set while the MFMAs of kk run
+  // (hipcc otherwise re-uses one set: read -> lgkmcnt(0) -> 4 MFMAs, the LDS latency exposed every 128 MFMA cycles);
+  // the sched_group_barrier ladder pins "1 MFMA, 1 ds_read" pairs so the reads issue in the MFMA shadows.
+  constexpr bool FRAG_PIPE = (OPT & 2) != 0;
+  constexpr bool FLAT_LOOP = (OPT & 1) != 0;
   auto compute = [&](int buf) {
     const unsigned char* S = smem + buf * STAGE;
+    if constexpr (FRAG_PIPE) {
+      bf16x8 wf[2][TCO], xf[2][TPOS];
+      auto rd = [&](int kk, int set) {
+        const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
+#pragma unroll
+        for (int t = 0; t < TCO; ++t) wf[set][t] = *reinterpret_cast<const bf16x8*>(S + wrow_off + t * 32 * 128 + slot);
+#pragma unroll
+        for (int t = 0; t < TPOS; ++t) xf[set][t] = *reinterpret_cast<const bf16x8*>(S + xrow_off + t * 32 * 128 + slot);
+      };
+      rd(0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, TCO + TPOS, 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) rd(kk + 1, (kk + 1) & 1);
+#pragma unroll
+        for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+          for (int tp = 0; tp < TPOS; ++tp)
+            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][tc], xf[kk & 1][tp], acc[tc][tp], 0, 0, 0);
+        // ladder: one fragment read of kk+1 behind each MFMA of kk
+        constexpr int NFR = TCO + TPOS, NMF = TCO * TPOS, NPAIR = NFR < NMF ? NFR : NMF;
+        if (kk < 3) {
+#pragma unroll
+          for (int i = 0; i < NPAIR; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          if constexpr (NFR > NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, NFR - NPAIR, 0);
+          if constexpr (NMF > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NPAIR, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+        }
+      }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
@@ -388,6 +437,7 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
         for (int tp = 0; tp < TPOS; ++tp)
           acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
     }
+    }
   };
 
   const int nk = a.nk;
@@ -397,7 +447,7 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
     // a K step also drains the DMA queue (hipcc emits vmcnt(0) in front of the barrier).
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
-    const int wave_row = (tid >> 6) * 8;   // first tile row written by this wave (+32*i)
+    const int wave_row = (tid >> 6) * 8;   // first tile row written by this wave (+LROWS*i)
     const unsigned long long zero_page = (unsigned long long)g_zero16;
     auto dma_tile = [&](int buf) {
       unsigned char* Wb = smem + buf * STAGE;
@@ -408,7 +458,7 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
       const long long toff = (long long)((dh * W + dw) * a.in_cstride + c0);
       static_for<NW>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        __builtin_amdgcn_global_load_lds((glb_void*)(ld_wp + i * wstride), (lds_void*)(Wb + (wave_row + 32 * i) * 128),
+        __builtin_amdgcn_global_load_lds((glb_void*)(ld_wp + i * wstride), (lds_void*)(Wb + (wave_row + LROWS * i) * 128),
                                          16, 0, 0);
       });
       static_for<NX>([&](auto I) {
@@ -419,11 +469,55 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
         // hipcc emit TWO exec-masked DMA instructions (one per source) instead of one
         const unsigned long long pm = ok ? ~0ull : 0ull;
         const unsigned long long src = ((unsigned long long)(a.x + xoff[i] + toff) & pm) | (zero_page & ~pm);
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Xb + (wave_row + 32 * i) * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Xb + (wave_row + LROWS * i) * 128), 16, 0, 0);
       });
       advance_k();
     };
-    if constexpr (PROD) {
+    // OPT bit 0: the same loader without control flow (bitwise bounds test, no division path: the launcher only
+    // picks these variants for cin >= 64), and the K loop peeled so that one K step -- DMA issue, fragment reads, MFMAs --
+    // is ONE basic block the scheduler can interleave.
+    const int wave_row_s = __builtin_amdgcn_readfirstlane(tid >> 6) * 8;   // in an SGPR: the M0 values become SALU work
+    auto dma_tile_flat = [&](int buf) {
+      unsigned char* Wb = smem + buf * STAGE + wave_row_s * 128;
+      unsigned char* Xb = Wb + BCO * 128;
+      const bool kvalid = ld_kc < a.nchunk;
+      const int dh = ld_kh * a.dil, dw = ld_kw * a.dil;
+      const long long toff = (long long)((dh * W + dw) * a.in_cstride + ld_cc * 8);
+      static_for<NW>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        __builtin_amdgcn_global_load_lds((glb_void*)(ld_wp + i * wstride), (lds_void*)(Wb + LROWS * i * 128),
+                                         16, 0, 0);
+      });
+      static_for<NX>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int hi = rhi[i] + dh, wi = rwi[i] + dw;
+        const bool ok = kvalid & ((unsigned)hi < (unsigned)H) & ((unsigned)wi < (unsigned)W);
+        const unsigned long long pm = ok ? ~0ull : 0ull;
+        const unsigned long long src = ((unsigned long long)(a.x + xoff[i] + toff) & pm) | (zero_page & ~pm);
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Xb + LROWS * i * 128), 16, 0, 0);
+      });
+      ld_kc += 8;
+      ld_wp += 64;
+      ld_cc += 8;
+      const int wrap = ld_cc >= a.cpt ? 1 : 0;
+      ld_cc -= wrap * a.cpt;
+      ld_kw += wrap;
+      const int wrap2 = ld_kw == a.kw ? 1 : 0;
+      ld_kw -= wrap2 * a.kw;
+      ld_kh += wrap2;
+    };
+    if constexpr (FLAT_LOOP) {
+      dma_tile_flat(0);
+      __syncthreads();
+      for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int buf = kt & 1;
+        dma_tile_flat(buf ^ 1);
+        compute(buf);
+        __syncthreads();
+      }
+      compute((nk - 1) & 1);
+      if constexpr (!REG_ONLY) __syncthreads();   // the LDS-staged epilogue overwrites the stages other waves may still read
+    } else if constexpr (PROD) {
       if (is_prod) dma_tile(0);
       __syncthreads();
       for (int kt = 0; kt < nk; ++kt) {
@@ -659,6 +753,7 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
     }
     return;
   }
+  if constexpr (REG_ONLY) return;
   if (is_cons) {
 #pragma unroll
   for (int tc = 0; tc < TCO; ++tc) {
@@ -822,8 +917,8 @@ __global__ __launch_bounds__(256 * (1 + PROD), 2) void conv_igemm_kernel(const C
 // diversity (the CU always has some wave in its MFMA phase) at the price of twice the barriers.
 // LDS rows are 64 bytes; swizzle slot = chunk ^ ((row>>2)&3) keeps ds_read_b128 conflict free.
 // =====================================================================================
-template <int WCO, int WPOS, int TCO, int TPOS>
-__global__ __launch_bounds__(256, 4) void conv_dma32_kernel(const ConvKArgs a) {
+template <int WCO, int WPOS, int TCO, int TPOS, int MINB = 4>
+__global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a) {
   constexpr int BCO = WCO * TCO * 32;
   constexpr int BPOS = WPOS * TPOS * 32;
   constexpr int NW = (BCO + 63) / 64;   // DMA instructions per thread per K step (weights)
@@ -832,7 +927,8 @@ __global__ __launch_bounds__(256, 4) void conv_dma32_kernel(const ConvKArgs a) {
   constexpr int EPI_LD = BCO + 4;
   constexpr int HROWS = BPOS / 2;                  // positions per epilogue pass
   constexpr int EPI_BYTES = HROWS * EPI_LD * 4;
-  constexpr int SMEM_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+  constexpr bool REG_ONLY = BCO * BPOS > 128 * 128;   // register epilogue only (see conv_igemm_kernel)
+  constexpr int SMEM_BYTES = (REG_ONLY || 2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
   static_assert(WCO * WPOS == 4, "4 waves");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   typedef __attribute__((address_space(3))) void lds_void;
@@ -1055,6 +1151,7 @@ __global__ __launch_bounds__(256, 4) void conv_dma32_kernel(const ConvKArgs a) {
     }
     return;
   }
+  if constexpr (REG_ONLY) return;
   // ---- LDS-staged epilogue in two half-tile passes (positions [p*HROWS, (p+1)*HROWS)): unaligned channel
   // counts / strides, or the A/B debug flag
   float* E = reinterpret_cast<float*>(smem);
@@ -1210,14 +1307,20 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   // occupy the chip (256 CUs x 2 or 4 resident blocks): small-M layers (layer3/4, P5-P7, the
   // 32-channel predictors) are latency bound and want blocks, not reuse.
   struct Cfg { int bco, bpos; };
-  Cfg cands[3];
+  Cfg cands[4];
   int ncand = 0;
   if (!dma) {
     cands[ncand++] = {tile, tile == 128 ? 128 : 256};
   } else if (tile == 128) {
+    // 128 couts x 256 positions (64x128 per wave: 0.75 fragment reads and 0.75 DMA bytes per MFMA of the 128x128
+    // tile); register epilogue only, so only where its alignment conditions hold.  Behind an A/B flag.
+    const bool has_res = d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST);
+    const bool reg_ok = !(d->flags & SM_CONV_DBG_LDS_EPILOGUE) && (d->cout & 7) == 0 && (d->out_cstride & 7) == 0 &&
+                        (d->out_coff & 7) == 0 && (!has_res || (d->res_cstride & 7) == 0);
+    if ((d->flags & SM_CONV_DBG_WIDE_POS) && reg_ok) cands[ncand++] = {128, 256};
     cands[ncand++] = {128, 128};
     cands[ncand++] = {128, 64};
-    cands[ncand++] = {64, 64};
+    if (ncand < 4) cands[ncand++] = {64, 64};
   } else if (tile == 64) {
     cands[ncand++] = {64, 256};
     cands[ncand++] = {64, 128};
@@ -1228,6 +1331,26 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   }
   const long long want = (d->flags & SM_CONV_DBG_BIG_TILES) ? 0 : (k32 ? 768 : 512);
   int bco = cands[0].bco, bpos = cands[0].bpos;
+  // 256x256 tile on 8 waves, one block per CU (A/B flag): half the LDS-DMA pieces and 3/4 of the fragment reads per
+  // MFMA of the 128x128 tile.  Register epilogue only; 64-wide K steps only.
+  bool tile256 = false;
+  if (dma && !k32 && tile == 128 && (d->flags & SM_CONV_DBG_TILE256) && d->cout_pad % 256 == 0 && d->cin >= 64) {
+    const bool has_res = d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST);
+    tile256 = !(d->flags & (SM_CONV_DBG_LDS_EPILOGUE | SM_CONV_DBG_WARP_SPEC)) && (d->cout & 7) == 0 &&
+              (d->out_cstride & 7) == 0 && (d->out_coff & 7) == 0 && (!has_res || (d->res_cstride & 7) == 0);
+  }
+  if (tile256 && !(d->flags & SM_CONV_DBG_BIG_TILES)) {
+    // one block per CU: the launch must fill its rounds of 256 blocks reasonably (a 263-block launch runs two rounds)
+    long long nb = 0;
+    for (int l = 0; l < d->nlev; ++l) nb += sm_cdiv((long long)d->batch * d->out_h[l] * d->out_w[l], 256);
+    nb *= d->cout_pad / 256;
+    const long long rounds = (nb + 255) / 256;
+    tile256 = nb >= 230 && nb * 100 >= rounds * 256 * 65;
+  }
+  if (tile256) {
+    bco = bpos = 256;
+    ncand = 0;
+  }
   for (int c = 0; c < ncand; ++c) {
     long long nb = 0;
     for (int l = 0; l < d->nlev; ++l)
@@ -1288,7 +1411,8 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else if (tile == 64) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 2, DEFORM, false>));
     else SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 2, DEFORM, false>));
   } else if (k32) {
-    if (bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2>));
+    if (bco == 128 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 4, 2>));
+    else if (bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2>));
     else if (bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1>));
     else if (bco == 64 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 2>));
     else if (bco == 64 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 1>));
@@ -1297,11 +1421,23 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 1>));
   } else if constexpr (!DEFORM) {
     const bool ws = (d->flags & SM_CONV_DBG_WARP_SPEC) != 0;
+    // K-loop variant of the 128/64-cout tiles: flat loader + peeled K loop + pipelined fragment reads (OPT 3) whenever
+    // cin >= 64 (no division path in the flat loader); measured +10..15 % on every 3x3 conv with K >= 2304
+    // (profiles/r01_conv_kloop_variants.txt).  A/B flags: FLAT_LOOP = OPT 1, LEGACY_LOOP = OPT 0.
+    const int opt = (ws || d->cin < 64 || (d->flags & SM_CONV_DBG_LEGACY_LOOP)) ? 0 : ((d->flags & SM_CONV_DBG_FLAT_LOOP) ? 1 : 3);
     if (ws) block = dim3(512);
     if (ws && bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 1>));
     else if (ws && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 1>));
     else if (ws && bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true, 1>));
     else if (ws) return SM_ERR_UNSUPPORTED;
+    else if (bco == 256) { block = dim3(512); SM_LAUNCH((conv_igemm_kernel<2, 4, 4, 2, false, true, 0, 3>)); }
+    else if (opt == 3 && bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 0, 3>));
+    else if (opt == 3 && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 0, 3>));
+    else if (opt == 3 && bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true, 0, 3>));
+    else if (opt == 1 && bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 0, 1>));
+    else if (opt == 1 && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 0, 1>));
+    else if (opt == 1 && bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true, 0, 1>));
+    else if (bco == 128 && bpos == 256) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 4, false, true>));
     else if (bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true>));
     else if (bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true>));
     else if (bco == 64 && bpos == 256) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 2, false, true>));

@@ -81,7 +81,10 @@ def test_conv_igemm_vs_torch(cfg):
 
 
 @pytest.mark.parametrize("variant", [0x20000000, 0x10000000, 0x08000000, 0x04000000, 0x14000000, 0x0c000000,
-                                     0x01000000, 0x11000000, 0x09000000])   # last three: LDS-staged epilogue (A/B)
+                                     0x01000000, 0x11000000, 0x09000000,    # these three: LDS-staged epilogue (A/B)
+                                     0x0c800000, 0x14800000,                # 128x256 tiles, 64- / 32-wide K steps
+                                     0x08200000, 0x08100000, 0x0c100000,    # flat K loop without fragment pipeline / legacy K loop
+                                     0x0c400000, 0x09200000])               # 256x256 8-wave tiles (forced); flat loop + LDS epilogue
 def test_conv_loader_variants(variant):
     """The A/B loader variants (register staging 0x2..., forced 32-wide K steps 0x1..., forced 64-wide
     0x08...) must give the same
@@ -155,7 +158,8 @@ def test_conv_multilevel_scale_and_nearest_residual():
     torch.testing.assert_close(y.view(B, 13, 18, 128).permute(0, 3, 1, 2).cpu(), ref, rtol=1e-4, atol=2e-4)
 
 
-def test_conv_fused_groupnorm_statistics():
+@pytest.mark.parametrize("extra", [0, 0x04800000, 0x00100000, 0x04400000])   # default / 128x256 / legacy K loop / 256x256 (forced)
+def test_conv_fused_groupnorm_statistics(extra):
     """sm_conv2d_gn_stats: per (image, level, group of 8 channels) sum / sum of squares of the conv
     output accumulated in the epilogue, incl. tiles that span several images (tiny levels)."""
     from sipmask_amd import hip_ops as H
@@ -170,7 +174,7 @@ def test_conv_fused_groupnorm_statistics():
     wq, co_pad = H.prep_conv_weight(w.to(dev))
     y = torch.zeros(lv.rows, Co, dtype=torch.bfloat16, device=dev)
     stats = torch.full((B, len(sizes), Co // 8, 2), 123.0, device=dev)
-    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, C, Co, co_pad, 3, 1, 1, C, Co)
+    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, C, Co, co_pad, 3, 1, 1, C, Co, flags=extra)
     H.conv2d_gn_stats(d, x, None, wq, None, None, y, stats)
     torch.cuda.synchronize()
     for l, (h, wd) in enumerate(sizes):

@@ -53,7 +53,7 @@ tower_live = [l for l in open(os.path.join(SRC, "tower.log")) if l.startswith("{
 old = json.load(open(os.path.join(DST, "r01_pmc_tower_conv.json")))
 fetch, write = cnt["FETCH_SIZE"][1] * 1024 * 2, cnt["WRITE_SIZE"][1] * 1024
 js = {
-    "kernel": "conv_igemm_kernel<2,2,2,2,false,true,0> with fused GroupNorm statistics = tower 3x3 256->256 over 5 FPN "
+    "kernel": "conv_igemm_kernel<2,2,2,2,false,true,0,3> with fused GroupNorm statistics = tower 3x3 256->256 over 5 FPN "
               "levels, B=4 (M=89600,N=256,K=2304), grid 1404 x 256 threads",
     "command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --tower-only 10   "
                "(tools/profile_round.sh; separate passes for FETCH_SIZE and WRITE_SIZE; dispatches selected by kernel "

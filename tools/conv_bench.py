@@ -36,14 +36,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--only", type=str, default="", help="substring filter on the shape name")
+    ap.add_argument("--only", type=str, default="", help="comma separated substring filters on the shape name")
     ap.add_argument("--variants", type=str, default="0,%d" % 0x40000000, help="comma separated extra flag words")
     args = ap.parse_args()
     dev = torch.device("cuda")
-    variants = [int(v) for v in args.variants.split(",")]
+    variants = [int(v, 0) for v in args.variants.split(",")]
     cases = []
     for name, sizes, cin, cout, k, s, p, flags, res in SHAPES:
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split(",")):
             continue
         lv = H.Levels(B, sizes)
         osz = [((h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1) for h, w in sizes]
