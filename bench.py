@@ -181,7 +181,7 @@ def main():
     if os.path.exists(pmc_file) and B == 4:
         pmc = json.load(open(pmc_file))
         traffic = round(pmc["hbm_bytes_per_launch"] / 1e6, 1)
-        traffic_src = "profiles/r01_pmc_tower_conv.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), MB per launch; measured on the same tile/loader bytes before the K-loop rewrite"
+        traffic_src = "profiles/r01_pmc_tower_conv.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), MB per launch"
     if args.breakdown and rank == 0:
         with open(args.breakdown, "w") as f:
             f.write("# per-step HIP event times (ms), eager launches, batch %d, mean of %d\n" % (B, reps))

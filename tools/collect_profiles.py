@@ -36,7 +36,8 @@ with_header(one("tower/*/*_kernel_stats.csv"), os.path.join(DST, TAG + "_rocprof
             "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --tower-only 50   (dominant kernel "
             "alone; the tower-shaped dispatches have grid 359424, their trace statistics are in r01_pmc_tower_conv.json)")
 shutil.copy(os.path.join(SRC, "step_breakdown.txt"), os.path.join(DST, "r01_step_breakdown_hip_events.txt"))
-shutil.copy(os.path.join(SRC, "conv_microbench.txt"), os.path.join(DST, "r01_conv_microbench.txt"))
+if os.path.getmtime(os.path.join(SRC, "conv_microbench.txt")) >= os.path.getmtime(os.path.join(SRC, "bench_full.json")):   # same call only
+    shutil.copy(os.path.join(SRC, "conv_microbench.txt"), os.path.join(DST, "r01_conv_microbench.txt"))
 line = [l for l in open(os.path.join(SRC, "bench_full.json")) if l.startswith("{")][-1]
 open(os.path.join(DST, "r01_bench_line.json"), "w").write(line)
 bench = json.loads(line)
