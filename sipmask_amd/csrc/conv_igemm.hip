@@ -917,7 +917,9 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
 // diversity (the CU always has some wave in its MFMA phase) at the price of twice the barriers.
 // LDS rows are 64 bytes; swizzle slot = chunk ^ ((row>>2)&3) keeps ds_read_b128 conflict free.
 // =====================================================================================
-template <int WCO, int WPOS, int TCO, int TPOS, int MINB = 4>
+// OPT = 3 (A/B flag SM_CONV_DBG_K32_OPT, cin >= 32): the K-loop treatment of conv_igemm_kernel's OPT 3 -- flat loader,
+// peeled loop, fragments of the second K sub-step read under the MFMAs of the first.
+template <int WCO, int WPOS, int TCO, int TPOS, int MINB = 4, int OPT = 0>
 __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a) {
   constexpr int BCO = WCO * TCO * 32;
   constexpr int BPOS = WPOS * TPOS * 32;
@@ -1060,6 +1062,81 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
   };
 
   const int nk = a.nk * 2;   // Kp is a multiple of 64
+  if constexpr (OPT != 0) {
+    const int wave_row_s = __builtin_amdgcn_readfirstlane(wave) * 16;
+    auto dma_tile_flat = [&](int buf) {
+      unsigned char* Wb = smem + buf * STAGE + wave_row_s * 64;
+      unsigned char* Xb = Wb + BCO * 64;
+      const bool kvalid = ld_kc < a.nchunk;
+      const int dh = ld_kh * a.dil, dw = ld_kw * a.dil;
+      const long long toff = (long long)((dh * W + dw) * a.in_cstride + ld_cc * 8);
+#pragma unroll
+      for (int i = 0; i < NW; ++i)
+        if (BCO >= 64 || wave_row_s < BCO)
+          __builtin_amdgcn_global_load_lds((glb_void*)(ld_wp + i * wstride), (lds_void*)(Wb + 64 * i * 64), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int hi = rhi[i] + dh, wi = rwi[i] + dw;
+        const bool ok = kvalid & ((unsigned)hi < (unsigned)H) & ((unsigned)wi < (unsigned)W);
+        const unsigned long long pm = ok ? ~0ull : 0ull;
+        const unsigned long long src = ((unsigned long long)(a.x + xoff[i] + toff) & pm) | (zero_page & ~pm);
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Xb + 64 * i * 64), 16, 0, 0);
+      }
+      ld_kc += 4;
+      ld_wp += 32;
+      ld_cc += 4;
+      const int wrap = ld_cc >= a.cpt ? 1 : 0;
+      ld_cc -= wrap * a.cpt;
+      ld_kw += wrap;
+      const int wrap2 = ld_kw == a.kw ? 1 : 0;
+      ld_kw -= wrap2 * a.kw;
+      ld_kh += wrap2;
+    };
+    auto compute_p = [&](int buf) {
+      const unsigned char* S = smem + buf * STAGE;
+      bf16x8 wf[2][TCO], xf[2][TPOS];
+      auto rd = [&](int kk, int set) {
+        const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
+#pragma unroll
+        for (int t = 0; t < TCO; ++t) wf[set][t] = *reinterpret_cast<const bf16x8*>(S + wrow_off + t * 32 * 64 + slot);
+#pragma unroll
+        for (int t = 0; t < TPOS; ++t) xf[set][t] = *reinterpret_cast<const bf16x8*>(S + xrow_off + t * 32 * 64 + slot);
+      };
+      constexpr int NFR = TCO + TPOS, NMF = TCO * TPOS, NPAIR = NFR < NMF ? NFR : NMF;
+      rd(0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);
+      rd(1, 1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+          for (int tp = 0; tp < TPOS; ++tp)
+            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][tc], xf[kk][tp], acc[tc][tp], 0, 0, 0);
+        if (kk == 0) {
+#pragma unroll
+          for (int i = 0; i < NPAIR; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          if constexpr (NFR > NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, NFR - NPAIR, 0);
+          if constexpr (NMF > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NPAIR, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+        }
+      }
+    };
+    dma_tile_flat(0);
+    __syncthreads();
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      const int buf = kt & 1;
+      dma_tile_flat(buf ^ 1);
+      compute_p(buf);
+      __syncthreads();
+    }
+    compute_p((nk - 1) & 1);
+    if constexpr (!REG_ONLY) __syncthreads();   // the LDS-staged epilogue re-uses the stages
+  } else {
   dma_tile(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
@@ -1067,6 +1144,7 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
     if (kt + 1 < nk) dma_tile(buf ^ 1);
     compute(buf);
     __syncthreads();
+  }
   }
 
   const float lscale = a.level_scale[lev];
@@ -1411,7 +1489,15 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else if (tile == 64) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 2, DEFORM, false>));
     else SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 2, DEFORM, false>));
   } else if (k32) {
-    if (bco == 128 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 4, 2>));
+    const bool o3 = (d->flags & SM_CONV_DBG_K32_OPT) && d->cin >= 32;
+    if (o3 && bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2, 4, 3>));
+    else if (o3 && bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1, 4, 3>));
+    else if (o3 && bco == 64 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 2, 4, 3>));
+    else if (o3 && bco == 64 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 1, 4, 3>));
+    else if (o3 && bco == 64 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 1, 1, 4, 3>));
+    else if (o3 && bco == 32 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 2, 4, 3>));
+    else if (o3 && bco == 32) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 1, 4, 3>));
+    else if (bco == 128 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 4, 2>));
     else if (bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2>));
     else if (bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1>));
     else if (bco == 64 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 2>));
