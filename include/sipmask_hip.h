@@ -94,6 +94,22 @@ const char* sm_strerror(int status);
  * padded to a multiple of it */
 int sm_conv_cout_tile(int cout);
 
+/* What the library will launch for a conv descriptor: pure host logic, callable without a GPU (the `-m "not gpu"`
+ * tests pin the selection rules with it; sm_conv2d & co. execute exactly this plan).  No reference counterpart: the
+ * reference leaves algorithm choice to cuDNN. */
+typedef struct sm_conv_plan {
+  int32_t lds_dma;    /* 1 = LDS-DMA loader, 0 = register-staged loader (deformable gather, input ReLU) */
+  int32_t k_step;     /* 32 or 64 bf16 per K step */
+  int32_t k_padded;   /* K rounded up to 64 (the weight row pitch) */
+  int32_t tile_cout;  /* block tile */
+  int32_t tile_pos;
+  int32_t threads;    /* 256, or 512 for the 8-wave tiles */
+  int32_t k_loop;     /* 0 legacy loop, 1 flat loader + peeled loop, 3 = 1 + pipelined fragment reads */
+  int32_t warp_spec;  /* producer/consumer A/B variant */
+  int64_t blocks;     /* grid size */
+} sm_conv_plan;
+int sm_conv_plan_query(const sm_conv_desc* d, int deformable, int with_gn_stats, sm_conv_plan* out);
+
 /* y = epilogue(conv(x, w) + bias).  x bf16 rows, w bf16 [cout_pad][Kp], bias f32[cout]
  * or NULL, residual bf16 or NULL, y bf16/f32. */
 int sm_conv2d(const sm_conv_desc* d, const void* x, const void* w, const float* bias,

@@ -41,6 +41,15 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ConvPlan(C.Structure):
+    """sm_conv_plan"""
+    _fields_ = [
+        ("lds_dma", C.c_int32), ("k_step", C.c_int32), ("k_padded", C.c_int32), ("tile_cout", C.c_int32),
+        ("tile_pos", C.c_int32), ("threads", C.c_int32), ("k_loop", C.c_int32), ("warp_spec", C.c_int32),
+        ("blocks", C.c_int64),
+    ]
+
+
 class DetDesc(C.Structure):
     """sm_det_desc"""
     _fields_ = [
@@ -63,6 +72,7 @@ PROTOTYPES = {
     "sm_version": (_I, []),
     "sm_strerror": (C.c_char_p, [_I]),
     "sm_conv_cout_tile": (_I, [_I]),
+    "sm_conv_plan_query": (_I, [C.POINTER(ConvDesc), _I, _I, C.POINTER(ConvPlan)]),
     "sm_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "sm_deform_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "sm_conv2d_gn_stats": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -1340,46 +1340,36 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
   }
 }
 
-template <bool DEFORM>
-int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,
-                const void* residual, void* y, hipStream_t stream, float* gn_stats = nullptr) {
-  if (!d || !x || !w || !y) return SM_ERR_BAD_ARG;
+// ---- launch planning: pure host logic (no device access), exported as sm_conv_plan_query so that the selection
+// rules are testable without a GPU.  launch_conv() below executes exactly this plan.
+int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p) {
+  if (!d || !p) return SM_ERR_BAD_ARG;
   if (d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return SM_ERR_BAD_SHAPE;
   if (d->cin % 8 != 0 || d->cin < 8 || d->cout < 1) return SM_ERR_BAD_SHAPE;
   if (d->in_cstride % 8 != 0) return SM_ERR_BAD_SHAPE;
-  if ((d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)) && !residual) return SM_ERR_BAD_ARG;
   const int tile = sm_conv_cout_tile(d->cout);
   if (d->cout_pad % tile != 0 || d->cout_pad < d->cout) return SM_ERR_BAD_SHAPE;
-  if (DEFORM) {
-    if (!offset || d->deform_groups < 1 || d->cin % (8 * d->deform_groups) != 0) return SM_ERR_BAD_ARG;
+  if (deform) {
+    if (d->deform_groups < 1 || d->cin % (8 * d->deform_groups) != 0) return SM_ERR_BAD_ARG;
     if (d->stride != 1) return SM_ERR_UNSUPPORTED;
   }
-  ConvKArgs a;
-  a.x = (const uint16_t*)x;
-  a.w = (const uint16_t*)w;
-  a.w_bstride = d->w_batch_stride;
-  a.bias = bias;
-  a.res = (const uint16_t*)residual;
-  a.y = y;
-  a.offset = offset;
-  a.gn_stats = gn_stats;
-  if (gn_stats != nullptr) {
-    if (d->cout % 8 != 0 || (d->flags & SM_CONV_OUT_F32)) return SM_ERR_UNSUPPORTED;
-    if (hipMemsetAsync(gn_stats, 0, sizeof(float) * 2 * d->batch * d->nlev * (d->cout / 8), stream) != hipSuccess)
-      return SM_ERR_LAUNCH;
+  if (with_gn && (d->cout % 8 != 0 || (d->flags & SM_CONV_OUT_F32))) return SM_ERR_UNSUPPORTED;
+  for (int l = 0; l < d->nlev; ++l) {
+    if (d->out_h[l] < 1 || d->out_w[l] < 1 || d->in_h[l] < 1 || d->in_w[l] < 1) return SM_ERR_BAD_SHAPE;
+    const int eh = (d->in_h[l] + 2 * d->pad - (d->dil * (d->kh - 1) + 1)) / d->stride + 1;
+    const int ew = (d->in_w[l] + 2 * d->pad - (d->dil * (d->kw - 1) + 1)) / d->stride + 1;
+    if (eh != d->out_h[l] || ew != d->out_w[l]) return SM_ERR_BAD_SHAPE;
   }
-  a.nlev = d->nlev;
-  a.batch = d->batch;
   // LDS-DMA loader for plain convs; the register-staged loader where VALU must touch the operand
   // (deformable gather, input ReLU) or when the A/B debug flag asks for it
-  const bool dma = !DEFORM && !(d->flags & (SM_CONV_IN_RELU | SM_CONV_DBG_REG_STAGING));
+  const bool dma = !deform && !(d->flags & (SM_CONV_IN_RELU | SM_CONV_DBG_REG_STAGING));
   const int K = d->kh * d->kw * d->cin;
-  a.Kp = (K + 63) / 64 * 64;
+  const int Kp = (K + 63) / 64 * 64;
   // K-step width: measured on MI355X (profiles/r01_conv_microbench.txt) the 32-wide / 4-blocks-per-CU
   // kernel wins for K <= 1152 (all 1x1 convs, the 3x3 convs of layer1/2, the stem: +5..+28 %) and
   // loses for K >= 2304 (towers, FPN, layer3/4 3x3: -8..-20 %)
-  const bool k32 = dma && gn_stats == nullptr &&
-                   ((d->flags & SM_CONV_DBG_K32) || (!(d->flags & SM_CONV_DBG_K64) && a.Kp <= 1152));
+  const bool k32 = dma && !with_gn &&
+                   ((d->flags & SM_CONV_DBG_K32) || (!(d->flags & SM_CONV_DBG_K64) && Kp <= 1152));
   // ---- tile selection.  The cout tile is fixed by the weight padding contract (32/64/128) but may
   // be split further (128 -> 64); the position tile shrinks until the launch has enough blocks to
   // occupy the chip (256 CUs x 2 or 4 resident blocks): small-M layers (layer3/4, P5-P7, the
@@ -1387,14 +1377,15 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   struct Cfg { int bco, bpos; };
   Cfg cands[4];
   int ncand = 0;
+  const bool has_res = d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST);
+  // alignment conditions of the register epilogue (the tiles above 128x128 have no other)
+  const bool reg_ok = !(d->flags & SM_CONV_DBG_LDS_EPILOGUE) && (d->cout & 7) == 0 && (d->out_cstride & 7) == 0 &&
+                      (d->out_coff & 7) == 0 && (!has_res || (d->res_cstride & 7) == 0);
   if (!dma) {
     cands[ncand++] = {tile, tile == 128 ? 128 : 256};
   } else if (tile == 128) {
     // 128 couts x 256 positions (64x128 per wave: 0.75 fragment reads and 0.75 DMA bytes per MFMA of the 128x128
-    // tile); register epilogue only, so only where its alignment conditions hold.  Behind an A/B flag.
-    const bool has_res = d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST);
-    const bool reg_ok = !(d->flags & SM_CONV_DBG_LDS_EPILOGUE) && (d->cout & 7) == 0 && (d->out_cstride & 7) == 0 &&
-                        (d->out_coff & 7) == 0 && (!has_res || (d->res_cstride & 7) == 0);
+    // tile), behind an A/B flag
     if ((d->flags & SM_CONV_DBG_WIDE_POS) && reg_ok) cands[ncand++] = {128, 256};
     cands[ncand++] = {128, 128};
     cands[ncand++] = {128, 64};
@@ -1409,14 +1400,11 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   }
   const long long want = (d->flags & SM_CONV_DBG_BIG_TILES) ? 0 : (k32 ? 768 : 512);
   int bco = cands[0].bco, bpos = cands[0].bpos;
+  const bool ws = dma && !k32 && (d->flags & SM_CONV_DBG_WARP_SPEC) != 0;
   // 256x256 tile on 8 waves, one block per CU (A/B flag): half the LDS-DMA pieces and 3/4 of the fragment reads per
   // MFMA of the 128x128 tile.  Register epilogue only; 64-wide K steps only.
-  bool tile256 = false;
-  if (dma && !k32 && tile == 128 && (d->flags & SM_CONV_DBG_TILE256) && d->cout_pad % 256 == 0 && d->cin >= 64) {
-    const bool has_res = d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST);
-    tile256 = !(d->flags & (SM_CONV_DBG_LDS_EPILOGUE | SM_CONV_DBG_WARP_SPEC)) && (d->cout & 7) == 0 &&
-              (d->out_cstride & 7) == 0 && (d->out_coff & 7) == 0 && (!has_res || (d->res_cstride & 7) == 0);
-  }
+  bool tile256 = dma && !k32 && !ws && tile == 128 && (d->flags & SM_CONV_DBG_TILE256) && d->cout_pad % 256 == 0 &&
+                 d->cin >= 64 && reg_ok;
   if (tile256 && !(d->flags & SM_CONV_DBG_BIG_TILES)) {
     // one block per CU: the launch must fill its rounds of 256 blocks reasonably (a 263-block launch runs two rounds)
     long long nb = 0;
@@ -1438,6 +1426,65 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     bpos = cands[c].bpos;
     if (nb >= want) break;
   }
+  long long t = 0;
+  for (int l = 0; l < d->nlev; ++l) t += sm_cdiv((long long)d->batch * d->out_h[l] * d->out_w[l], bpos);
+  const long long nblk = t * (d->cout_pad / bco);
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
+  // K-loop variant.  64-wide K, 128/64-cout tiles of the tile-128 family: flat loader + peeled K loop + pipelined
+  // fragment reads (OPT 3) whenever cin >= 64 (no division path in the flat loader); measured +10..15 % on every 3x3
+  // conv with K >= 2304 (profiles/r01_conv_kloop_variants.txt).  A/B flags: FLAT_LOOP = OPT 1, LEGACY_LOOP = OPT 0.
+  // 32-wide K: OPT 3 behind SM_CONV_DBG_K32_OPT (cin >= 32).
+  int opt = 0;
+  if (dma && k32) {
+    const bool has_o3 = !(bco == 128 && bpos == 256);
+    opt = ((d->flags & SM_CONV_DBG_K32_OPT) && d->cin >= 32 && has_o3) ? 3 : 0;
+  } else if (dma && !ws) {
+    const bool has_opt = (bco == 128 && (bpos == 128 || bpos == 64)) || (bco == 64 && bpos == 64);
+    if (bco == 256) opt = 3;
+    else if (has_opt && d->cin >= 64 && !(d->flags & SM_CONV_DBG_LEGACY_LOOP)) opt = (d->flags & SM_CONV_DBG_FLAT_LOOP) ? 1 : 3;
+  }
+  if (ws && !((bco == 128 && (bpos == 128 || bpos == 64)) || (bco == 64 && bpos == 64))) return SM_ERR_UNSUPPORTED;
+  p->lds_dma = dma ? 1 : 0;
+  p->k_step = k32 ? 32 : 64;
+  p->k_padded = Kp;
+  p->tile_cout = bco;
+  p->tile_pos = bpos;
+  p->threads = (bco == 256 || ws) ? 512 : 256;
+  p->k_loop = opt;
+  p->warp_spec = ws ? 1 : 0;
+  p->blocks = nblk;
+  return SM_OK;
+}
+
+template <bool DEFORM>
+int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,
+                const void* residual, void* y, hipStream_t stream, float* gn_stats = nullptr) {
+  if (!d || !x || !w || !y) return SM_ERR_BAD_ARG;
+  if (DEFORM && !offset) return SM_ERR_BAD_ARG;
+  sm_conv_plan plan;
+  const int prc = plan_conv(d, DEFORM, gn_stats != nullptr, &plan);
+  if (prc != SM_OK) return prc;
+  if ((d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)) && !residual) return SM_ERR_BAD_ARG;
+  const int tile = sm_conv_cout_tile(d->cout);
+  const bool dma = plan.lds_dma != 0, k32 = plan.k_step == 32, ws = plan.warp_spec != 0;
+  const int bco = plan.tile_cout, bpos = plan.tile_pos, opt = plan.k_loop;
+  ConvKArgs a;
+  a.x = (const uint16_t*)x;
+  a.w = (const uint16_t*)w;
+  a.w_bstride = d->w_batch_stride;
+  a.bias = bias;
+  a.res = (const uint16_t*)residual;
+  a.y = y;
+  a.offset = offset;
+  a.gn_stats = gn_stats;
+  if (gn_stats != nullptr) {
+    if (hipMemsetAsync(gn_stats, 0, sizeof(float) * 2 * d->batch * d->nlev * (d->cout / 8), stream) != hipSuccess)
+      return SM_ERR_LAUNCH;
+  }
+  a.nlev = d->nlev;
+  a.batch = d->batch;
+  const int K = d->kh * d->kw * d->cin;
+  a.Kp = plan.k_padded;
   int t = 0;
   for (int l = 0; l < SM_MAX_LEVELS; ++l) {
     const bool on = l < d->nlev;
@@ -1452,13 +1499,7 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     a.res_w[l] = on ? d->res_w[l] : 1;
     a.level_scale[l] = on ? d->level_scale[l] : 1.f;
     a.tile0[l] = t;
-    if (on) {
-      if (d->out_h[l] < 1 || d->out_w[l] < 1 || d->in_h[l] < 1 || d->in_w[l] < 1) return SM_ERR_BAD_SHAPE;
-      const int eh = (d->in_h[l] + 2 * d->pad - (d->dil * (d->kh - 1) + 1)) / d->stride + 1;
-      const int ew = (d->in_w[l] + 2 * d->pad - (d->dil * (d->kw - 1) + 1)) / d->stride + 1;
-      if (eh != d->out_h[l] || ew != d->out_w[l]) return SM_ERR_BAD_SHAPE;
-      t += sm_cdiv((long long)d->batch * d->out_h[l] * d->out_w[l], bpos);
-    }
+    if (on) t += sm_cdiv((long long)d->batch * d->out_h[l] * d->out_w[l], bpos);
   }
   a.tile0[SM_MAX_LEVELS] = t;
   a.cin = d->cin;
@@ -1489,7 +1530,7 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else if (tile == 64) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 2, DEFORM, false>));
     else SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 2, DEFORM, false>));
   } else if (k32) {
-    const bool o3 = (d->flags & SM_CONV_DBG_K32_OPT) && d->cin >= 32;
+    const bool o3 = opt == 3;
     if (o3 && bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2, 4, 3>));
     else if (o3 && bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1, 4, 3>));
     else if (o3 && bco == 64 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 2, 4, 3>));
@@ -1506,11 +1547,6 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else if (bco == 32 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 2>));
     else SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 1>));
   } else if constexpr (!DEFORM) {
-    const bool ws = (d->flags & SM_CONV_DBG_WARP_SPEC) != 0;
-    // K-loop variant of the 128/64-cout tiles: flat loader + peeled K loop + pipelined fragment reads (OPT 3) whenever
-    // cin >= 64 (no division path in the flat loader); measured +10..15 % on every 3x3 conv with K >= 2304
-    // (profiles/r01_conv_kloop_variants.txt).  A/B flags: FLAT_LOOP = OPT 1, LEGACY_LOOP = OPT 0.
-    const int opt = (ws || d->cin < 64 || (d->flags & SM_CONV_DBG_LEGACY_LOOP)) ? 0 : ((d->flags & SM_CONV_DBG_FLAT_LOOP) ? 1 : 3);
     if (ws) block = dim3(512);
     if (ws && bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 1>));
     else if (ws && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 1>));
@@ -1540,6 +1576,10 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
 }  // namespace
 
 extern "C" int sm_conv_cout_tile(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
+
+extern "C" int sm_conv_plan_query(const sm_conv_desc* d, int deformable, int with_gn_stats, sm_conv_plan* out) {
+  return plan_conv(d, deformable != 0, with_gn_stats != 0, out);
+}
 
 extern "C" int sm_conv2d(const sm_conv_desc* d, const void* x, const void* w, const float* bias,
                          const void* residual, void* y, sm_stream_t stream) {

@@ -76,6 +76,14 @@ def make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, cout, cou
     return d
 
 
+def conv_plan(desc, deformable=False, with_gn_stats=False):
+    """What the library will launch for `desc` (sm_conv_plan_query: host logic only, works without a GPU)."""
+    lib = _lib.load()
+    p = _lib.ConvPlan()
+    _lib.check(lib.sm_conv_plan_query(C.byref(desc), int(deformable), int(with_gn_stats), C.byref(p)), "sm_conv_plan_query")
+    return {f: int(getattr(p, f)) for f, _ in _lib.ConvPlan._fields_}
+
+
 def conv2d(desc, x, w, bias, residual, y):
     _lib.require_cuda(x, w, y)
     lib = _lib.load()

@@ -32,12 +32,90 @@ def test_struct_layout_matches_header():
     import subprocess, tempfile
     from sipmask_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = '#include <stdio.h>\n#include "sipmask_hip.h"\nint main(){printf("%zu %zu\\n", sizeof(sm_conv_desc), sizeof(sm_det_desc));return 0;}\n'
+    src = '#include <stdio.h>\n#include "sipmask_hip.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(sm_conv_desc), sizeof(sm_det_desc), sizeof(sm_conv_plan));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
-        a, b = subprocess.check_output([os.path.join(d, "t")]).split()
+        a, b, c = subprocess.check_output([os.path.join(d, "t")]).split()
     assert int(a) == ctypes.sizeof(_lib.ConvDesc) and int(b) == ctypes.sizeof(_lib.DetDesc)
+    assert int(c) == ctypes.sizeof(_lib.ConvPlan)
+
+
+def _plan(sizes, cin, cout, k, stride=1, pad=None, flags=0, B=4, gn=False, deform=False, out_f32=False, res=False):
+    from sipmask_amd import hip_ops as H, _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libsipmask_hip.so not built (run __graft_entry__.build())")
+    pad = k // 2 if pad is None else pad
+    lib = _lib.load()
+    tile = lib.sm_conv_cout_tile(cout)
+    cout_pad = (cout + tile - 1) // tile * tile
+    osz = [((h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1) for h, w in sizes]
+    lv, lo = H.Levels(B, sizes), H.Levels(B, osz)
+    fl = flags | (_lib.SM_CONV_OUT_F32 if out_f32 else 0) | (_lib.SM_CONV_RES_ADD if res else 0)
+    d = H.make_conv_desc(B, sizes, osz, lv.row0, lo.row0, cin, cout, cout_pad, k, stride, pad, cin, cout, flags=fl,
+                         res_cstride=cout if res else 0, deform_groups=4 if deform else 0)
+    return H.conv_plan(d, deformable=deform, with_gn_stats=gn)
+
+
+PYR = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]          # batch 4 @ 800x1344
+
+
+def test_conv_launch_plan_rules():
+    """sm_conv_plan_query: the launcher's selection rules on the shapes of the R50 plan.
+    Host logic only -- no GPU involved."""
+    # tower conv with fused GN statistics: 128x128 tiles, 64-wide K, pipelined K loop, 1404 blocks
+    p = _plan(PYR, 256, 256, 3, gn=True)
+    assert (p["lds_dma"], p["k_step"], p["tile_cout"], p["tile_pos"], p["threads"], p["k_loop"]) == (1, 64, 128, 128, 256, 3)
+    assert p["blocks"] == 1404 and p["k_padded"] == 2304
+    # K <= 1152 -> 32-wide K steps (but never with fused GN statistics); its pipelined loop is opt-in
+    p = _plan([(200, 336)], 64, 64, 3)
+    assert (p["k_step"], p["tile_cout"], p["k_loop"], p["k_padded"]) == (32, 64, 0, 576)
+    assert _plan([(200, 336)], 64, 64, 3, flags=0x00080000)["k_loop"] == 3
+    assert _plan([(200, 336)], 64, 64, 3, gn=True)["k_step"] == 64
+    p = _plan([(800, 1344)], 8, 64, 7, stride=2, pad=3)                           # stem: cin 3 padded to 8, K 392 -> 448
+    assert (p["k_step"], p["k_padded"], p["k_loop"]) == (32, 448, 0)
+    # small-M layers shrink the tiles until the launch has >= 512 blocks (or run out of candidates)
+    p = _plan([(25, 42)], 512, 512, 3)                                            # layer4 3x3: M = 4200
+    assert (p["k_step"], p["tile_cout"], p["tile_pos"]) == (64, 64, 64) and p["blocks"] == 66 * 8
+    p = _plan([(50, 84)], 256, 256, 3)                                            # layer3 3x3: M = 16800
+    assert (p["tile_cout"], p["tile_pos"]) == (128, 64) and p["blocks"] == 263 * 2 and p["k_loop"] == 3
+    # operands VALU must touch are register-staged: deformable gather, input ReLU
+    p = _plan(PYR, 256, 256, 3, deform=True)
+    assert (p["lds_dma"], p["tile_cout"], p["tile_pos"], p["k_loop"]) == (0, 128, 128, 0)
+    assert _plan([(13, 21)], 256, 256, 3, stride=2, flags=16)["lds_dma"] == 0    # SM_CONV_IN_RELU (P7)
+    # A/B flags: legacy / flat loop, forced K widths
+    assert _plan(PYR, 256, 256, 3, flags=0x00100000)["k_loop"] == 0
+    assert _plan(PYR, 256, 256, 3, flags=0x00200000)["k_loop"] == 1
+    assert _plan(PYR, 256, 256, 3, flags=0x10000000)["k_step"] == 32
+    assert _plan([(200, 336)], 64, 64, 3, flags=0x08000000)["k_step"] == 64
+    # 256x256 8-wave tiles (opt-in): only where the rounds of 256 blocks are >= 65 % filled
+    p = _plan(PYR, 256, 256, 3, flags=0x00400000, gn=True)
+    assert (p["tile_cout"], p["tile_pos"], p["threads"], p["k_loop"], p["blocks"]) == (256, 256, 512, 3, 353)
+    p = _plan(PYR[:1], 256, 256, 3, flags=0x00400000)                             # fpn.out0: 263 blocks = 2 rounds, 51 %
+    assert (p["tile_cout"], p["tile_pos"], p["threads"]) == (128, 128, 256)
+    assert _plan(PYR[:1], 256, 256, 3, flags=0x04400000)["tile_cout"] == 256     # ... unless forced (BIG_TILES)
+    assert _plan(PYR, 256, 208, 3, flags=0x00400000, out_f32=True)["tile_cout"] == 256   # cls+cof: cout_pad 256
+    assert _plan(PYR, 256, 4, 3, flags=0x00400000)["tile_cout"] == 32            # 32-cout family untouched
+    # 128x256 tiles (opt-in) need the register epilogue's alignment
+    assert _plan(PYR, 256, 256, 3, flags=0x00800000)["tile_pos"] == 256
+    assert _plan(PYR, 256, 256, 3, flags=0x01800000)["tile_pos"] == 128          # + LDS_EPILOGUE flag: not eligible
+
+
+def test_conv_launch_plan_rejects_bad_descriptors():
+    from sipmask_amd import hip_ops as H, _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libsipmask_hip.so not built (run __graft_entry__.build())")
+    lv = H.Levels(2, [(10, 12)])
+    ok = dict(batch=2, in_sizes=[(10, 12)], out_sizes=[(10, 12)], in_row0=lv.row0, out_row0=lv.row0, cin=64, cout=128,
+              cout_pad=128, k=3, stride=1, pad=1, in_cstride=64, out_cstride=128)
+    assert H.conv_plan(H.make_conv_desc(**ok))["blocks"] > 0
+    for bad in (dict(cin=60), dict(out_sizes=[(9, 12)]), dict(cout_pad=96), dict(in_cstride=60), dict(batch=0)):
+        with pytest.raises(RuntimeError):
+            H.conv_plan(H.make_conv_desc(**dict(ok, **bad)))
+    with pytest.raises(RuntimeError):                                              # GN statistics need bf16 output
+        H.conv_plan(H.make_conv_desc(**dict(ok, flags=_lib.SM_CONV_OUT_F32)), with_gn_stats=True)
+    with pytest.raises(RuntimeError):                                              # deformable conv is stride 1
+        H.conv_plan(H.make_conv_desc(**dict(ok, stride=2, out_sizes=[(5, 6)], deform_groups=1)), deformable=True)
 
 
 def test_registry_contract():
