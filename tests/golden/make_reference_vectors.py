@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""Runs the REFERENCE's own Python code (tests/golden/ref_loader.py explains how) on exact, re-creatable inputs
+(oracle/fixtures.py) and stores its outputs in tests/golden/ref_vectors.npz.  Run in the build container only:
+
+    python tests/golden/make_reference_vectors.py
+
+tests/test_reference_vectors.py then checks the oracle against these outputs (no /root/reference needed).
+Key prefixes: A_ head forward, B_ get_bboxes, C_ loss / targets, D_ small functions, E_ fast_nms.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_loader as R  # noqa: E402
+from oracle import fixtures as FX  # noqa: E402
+from oracle import model as OM  # noqa: E402
+
+NUM_CLASSES = 9          # 8 foreground classes: keeps the fixtures small, exercises the same code
+OUT = {}
+
+
+class Cfg(dict):
+    """attribute access like mmcv.Config"""
+    __getattr__ = dict.__getitem__
+
+
+TEST_CFG = Cfg(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=Cfg(type="nms", iou_thr=0.5), max_per_img=100)
+
+
+def sample_idx(n, k=48):
+    return np.unique(np.linspace(0, n - 1, k).astype(np.int64))
+
+
+def summarize(name, t):
+    a = t.detach().cpu().numpy().astype(np.float32).reshape(-1)
+    OUT[name + ".sum"] = np.float64(a.astype(np.float64).sum())
+    OUT[name + ".abssum"] = np.float64(np.abs(a.astype(np.float64)).sum())
+    OUT[name + ".samples"] = a[sample_idx(a.size)]
+    OUT[name + ".shape"] = np.asarray(t.shape, np.int64)
+
+
+def build_head(ns, stacked_convs=4, norm=True, ssd_flag=False, center_sampling=True):
+    kw = dict(num_classes=NUM_CLASSES, in_channels=256, stacked_convs=stacked_convs, feat_channels=256,
+              strides=[8, 16, 32, 64, 128], center_sampling=center_sampling, center_sample_radius=1.5, ssd_flag=ssd_flag)
+    if not norm:
+        kw["norm_cfg"] = None
+    head = ns.head.SipMaskHead(**kw)
+    tmpl = {k[len("bbox_head."):]: v for k, v in
+            OM.init_state_dict(50, 0, num_classes=NUM_CLASSES, stacked_convs=stacked_convs, norm=norm).items()
+            if k.startswith("bbox_head.")}
+    assert set(tmpl) == set(head.state_dict()), sorted(set(tmpl) ^ set(head.state_dict()))
+    head.load_state_dict(FX.head_state_dict(tmpl))
+    head.eval()
+    return head
+
+
+def pack_masks(segms, labels, H, W):
+    """the stubbed mask_util.encode returns the pasted uint8 mask: re-order the per-class lists into detection order"""
+    cnt, out = {}, []
+    for lab in labels.tolist():
+        k = cnt.get(lab, 0)
+        cnt[lab] = k + 1
+        m = np.asarray(segms[lab][k])[:, :, 0]
+        assert m.shape == (H, W), m.shape
+        out.append(np.packbits(m.astype(np.uint8).reshape(-1)))
+    return np.stack(out) if out else np.zeros((0, (H * W + 7) // 8), np.uint8)
+
+
+def _accept_ndarray_scale_factor():
+    """sipmask_head.py:630 passes a numpy array as F.interpolate's scale_factor (fine for the PyTorch of its time);
+    today's F.interpolate wants python floats -- convert, change nothing else"""
+    import torch.nn.functional as F
+    orig = F.interpolate
+
+    def interpolate(input, size=None, scale_factor=None, *a, **k):
+        if isinstance(scale_factor, np.ndarray):
+            scale_factor = [float(v) for v in scale_factor]
+        return orig(input, size, scale_factor, *a, **k)
+
+    F.interpolate = interpolate
+    R.STAND_INS["F.interpolate(scale_factor=ndarray)"] = "numpy scale factors converted to python floats (API change of PyTorch)"
+
+
+def main():
+    torch.manual_seed(0)
+    _accept_ndarray_scale_factor()
+    ns = R.mmdet_tree(R.M, "M")
+    H, W = FX.IMG_HW
+
+    # ---- A: SipMaskHead.forward (sipmask_head.py:241-287), GN head and the SSD-style head (stacked_convs=2, no norm)
+    for tag, kw in (("A_forward_gn", dict()), ("A_forward_ssd", dict(stacked_convs=2, norm=False, ssd_flag=True))):
+        head = build_head(ns, **kw)
+        feats = FX.pyramid_feats(11, 2)
+        with torch.no_grad():
+            cls, box, ctr, cof, fm = head(feats)
+        for l in range(5):
+            summarize("%s.cls%d" % (tag, l), cls[l])
+            summarize("%s.box%d" % (tag, l), box[l])
+            summarize("%s.ctr%d" % (tag, l), ctr[l])
+            summarize("%s.cof%d" % (tag, l), cof[l])
+        summarize(tag + ".feat_mask", fm)
+
+    # ---- B: get_bboxes / get_bboxes_single (sipmask_head.py:501-663) on synthetic head outputs
+    head = build_head(ns)
+    cases = [("B_default", None, 1.0, False, (H, W, 3)),
+             ("B_rescale", True, 1.5, False, (64, 85, 3)),
+             ("B_ssd", True, np.array([1.25, 1.5, 1.25, 1.5], np.float32), True, (64, 102, 3))]
+    for tag, rescale, sf, ssd, ori in cases:
+        head.ssd_flag = ssd
+        outs = FX.head_outputs(21, 2, NUM_CLASSES - 1)
+        metas = [dict(img_shape=(H, W, 3), ori_shape=ori, scale_factor=sf)] * 2
+        with torch.no_grad():
+            res = head.get_bboxes(*outs, metas, TEST_CFG, rescale=rescale)
+        for b, (det, lab, segms) in enumerate(res):
+            OUT["%s.det%d" % (tag, b)] = det.numpy().astype(np.float32)
+            OUT["%s.lab%d" % (tag, b)] = lab.numpy().astype(np.int64)
+            mh, mw = (ori[0], ori[1]) if rescale else (H, W)
+            OUT["%s.masks%d" % (tag, b)] = pack_masks(segms, lab, mh, mw)
+            OUT["%s.mask_hw" % tag] = np.asarray([mh, mw], np.int64)
+    head.ssd_flag = False
+
+    # ---- C: loss (sipmask_head.py:290-498) with fcos_target / centerness_target (:731-866)
+    for tag, cs in (("C_loss_cs", True), ("C_loss_nocs", False)):
+        head = build_head(ns, center_sampling=cs)
+        head.center_sample_radius = 1.5
+        head.radius = 1.5
+        cls, box, ctr, cof, fm = FX.head_outputs(31, 2, NUM_CLASSES - 1)
+        cof = [c * 0.25 for c in cof]
+        gtb, gtl, gtm = FX.ground_truth(32, 2, NUM_CLASSES - 1)
+        fms = fm * 0.25
+        metas = [dict(img_shape=(H, W, 3))] * 2
+        losses = head.loss(cls, box, ctr, cof, fms, gtb, gtl, metas, None, gt_masks_list=gtm)
+        for k, v in losses.items():
+            OUT["%s.%s" % (tag, k)] = np.float64(float(v))
+        pts, _ = head.get_points([c.shape[-2:] for c in cls], torch.float32, "cpu")
+        labels, bbox_targets, label_list, bbox_targets_list, gt_inds = head.fcos_target(pts, gtb, gtl)
+        OUT[tag + ".labels"] = torch.cat(labels).numpy().astype(np.int64)            # level-major, images inside a level
+        OUT[tag + ".bbox_targets"] = torch.cat(bbox_targets).numpy().astype(np.float32)
+        for b in range(2):
+            OUT["%s.gt_inds%d" % (tag, b)] = gt_inds[b].numpy().astype(np.int64)
+        OUT[tag + ".points"] = torch.cat(pts).numpy().astype(np.float32)
+
+    # ---- D: small functions
+    head = build_head(ns)
+    a = torch.from_numpy(np.concatenate([FX.exact(41, (40, 2), 0, 2 ** 11, 2.0 ** -4),
+                                         FX.exact(42, (40, 2), 0, 2 ** 11, 2.0 ** -4)], 1))
+    a = torch.cat([torch.min(a[:, :2], a[:, 2:]), torch.max(a[:, :2], a[:, 2:])], 1)
+    b = torch.from_numpy(np.concatenate([FX.exact(43, (40, 2), 0, 2 ** 11, 2.0 ** -4),
+                                         FX.exact(44, (40, 2), 0, 2 ** 11, 2.0 ** -4)], 1))
+    b = torch.cat([torch.min(b[:, :2], b[:, 2:]), torch.max(b[:, :2], b[:, 2:])], 1)
+    OUT["D_overlaps.full"] = ns.geometry.bbox_overlaps(a, b).numpy()
+    OUT["D_overlaps.aligned"] = ns.geometry.bbox_overlaps(a, b, is_aligned=True).numpy()
+    pts = torch.from_numpy(FX.exact(45, (64, 2), 0, 2 ** 11, 2.0 ** -4))
+    dist = torch.from_numpy(FX.exact(46, (64, 4), -64, 2 ** 11, 2.0 ** -4))
+    OUT["D_distance2bbox.plain"] = ns.transforms.distance2bbox(pts, dist).numpy()
+    OUT["D_distance2bbox.clamped"] = ns.transforms.distance2bbox(pts, dist, max_shape=(96, 128, 3)).numpy()
+    t = torch.from_numpy(FX.exact(47, (50, 4), 1, 2 ** 10, 2.0 ** -4))
+    OUT["D_centerness_target"] = head.centerness_target(t).numpy()
+    # the reference's python crop_split (:58-105, the commented-out alternative of the CUDA op) on box-aligned cases
+    data = torch.from_numpy(FX.exact(48, (4, 24, 32, 12), 0, 2 ** 10, 2.0 ** -10))
+    rois = torch.from_numpy(FX.exact(49, (12, 4), 0, 96, 0.25))
+    rois = torch.cat([torch.min(rois[:, :2], rois[:, 2:]), torch.max(rois[:, :2], rois[:, 2:]) + 2.0], 1)
+    OUT["D_py_crop_split"] = ns.head.crop_split(data[0], data[1], data[2], data[3], rois).numpy()
+
+    # ---- E: fast_nms (sipmask_head.py:868-960)
+    boxes = torch.from_numpy(np.concatenate([FX.exact(51, (300, 2), 0, 2 ** 11, 2.0 ** -4),
+                                             FX.exact(52, (300, 2), 0, 2 ** 11, 2.0 ** -4)], 1))
+    boxes = torch.cat([torch.min(boxes[:, :2], boxes[:, 2:]), torch.max(boxes[:, :2], boxes[:, 2:]) + 1.0], 1)
+    scores = torch.from_numpy(FX.exact_unique(53, (8, 300)))
+    cofs = torch.from_numpy(FX.exact(54, (300, 128)))
+    d, l, m = head.fast_nms(boxes, scores, cofs, iou_threshold=0.5, top_k=200, score_thr=0.6)
+    OUT["E_fast_nms.det"] = d.numpy()
+    OUT["E_fast_nms.lab"] = l.numpy().astype(np.int64)
+    OUT["E_fast_nms.cof_rowsum"] = m.numpy().astype(np.float64).sum(1)
+
+    OUT["meta"] = np.asarray(json.dumps(dict(
+        generator="tests/golden/make_reference_vectors.py", reference="JialeCao001/SipMask @ v1 (/root/reference)",
+        torch=torch.__version__, num_classes=NUM_CLASSES, stand_ins=R.STAND_INS)))
+    path = os.path.join(HERE, "ref_vectors.npz")
+    np.savez_compressed(path, **OUT)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(OUT), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+"""The oracle against outputs of the REFERENCE's own Python code (tests/golden/ref_vectors.npz).
+
+The fixtures were produced in the build container by tests/golden/make_reference_vectors.py, which executes the
+reference's source files (SipMaskHead.forward / get_bboxes / loss / fcos_target / fast_nms, mmdet's distance2bbox,
+bbox_overlaps, multiclass_nms_idx, the loss modules) with stand-ins only for the compiled extensions and absent
+third-party packages (listed in the fixture's `meta`).  Inputs are re-created exactly by oracle/fixtures.py, so these
+tests need neither the reference nor a GPU.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as FX
+from oracle import loss as OL
+from oracle import model as OM
+from oracle import ops as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NUM_CLASSES = 9
+CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type="nms", iou_thr=0.5), max_per_img=100)
+
+
+@pytest.fixture(scope="module")
+def ref():
+    z = np.load(os.path.join(HERE, "golden", "ref_vectors.npz"))
+    meta = json.loads(str(z["meta"]))
+    assert meta["num_classes"] == NUM_CLASSES and "mmdet.ops.DeformConv" in meta["stand_ins"]
+    return z
+
+
+def _head_sd(stacked_convs=4, norm=True):
+    tmpl = {k: v for k, v in OM.init_state_dict(50, 0, num_classes=NUM_CLASSES, stacked_convs=stacked_convs, norm=norm).items()
+            if k.startswith("bbox_head.")}
+    sd = FX.head_state_dict({k[len("bbox_head."):]: v for k, v in tmpl.items()})
+    return {"bbox_head." + k: v for k, v in sd.items()}
+
+
+def _check_summary(ref, name, t):
+    a = t.detach().numpy().astype(np.float32).reshape(-1)
+    assert tuple(ref[name + ".shape"]) == tuple(t.shape), name
+    idx = np.unique(np.linspace(0, a.size - 1, 48).astype(np.int64))
+    scale = float(ref[name + ".abssum"]) / a.size + 1e-12
+    np.testing.assert_allclose(a[idx], ref[name + ".samples"], rtol=1e-4, atol=1e-4 * scale, err_msg=name)
+    np.testing.assert_allclose(np.abs(a.astype(np.float64)).sum(), float(ref[name + ".abssum"]), rtol=1e-5, err_msg=name)
+    np.testing.assert_allclose(a.astype(np.float64).sum(), float(ref[name + ".sum"]), rtol=1e-4,
+                               atol=1e-6 * float(ref[name + ".abssum"]), err_msg=name)
+
+
+@pytest.mark.parametrize("tag,kw", [("A_forward_gn", dict()), ("A_forward_ssd", dict(stacked_convs=2, norm=False))])
+def test_head_forward_matches_reference_forward(ref, tag, kw):
+    """SipMaskHead.forward, sipmask_head.py:241-287 (towers, Scale, FeatureAlign, predictors, mask basis)"""
+    sd = _head_sd(**kw)
+    feats = FX.pyramid_feats(11, 2)
+    with torch.no_grad():
+        cls, box, ctr, cof, fm = OM.head_forward(sd, feats)
+    for l in range(5):
+        _check_summary(ref, "%s.cls%d" % (tag, l), cls[l])
+        _check_summary(ref, "%s.box%d" % (tag, l), box[l])
+        _check_summary(ref, "%s.ctr%d" % (tag, l), ctr[l])
+        _check_summary(ref, "%s.cof%d" % (tag, l), cof[l])
+    _check_summary(ref, tag + ".feat_mask", fm)
+
+
+@pytest.mark.parametrize("tag,rescale,sf,ssd", [("B_default", None, 1.0, False), ("B_rescale", True, 1.5, False),
+                                                ("B_ssd", True, np.array([1.25, 1.5, 1.25, 1.5], np.float32), True)])
+def test_postprocessing_matches_reference_get_bboxes(ref, tag, rescale, sf, ssd):
+    """get_bboxes_single, sipmask_head.py:543-663: candidate selection, multiclass_nms_idx / fast_nms, mask assembly,
+    paste into the (original) image canvas.  Boxes to 1e-5, labels and EVERY mask pixel exact."""
+    H, W = FX.IMG_HW
+    cls, box, ctr, cof, fm = FX.head_outputs(21, 2, NUM_CLASSES - 1)
+    mh, mw = [int(v) for v in ref[tag + ".mask_hw"]]
+    ndet = 0
+    for b in range(2):
+        r = OM.get_masks_single([c[b] for c in cls], [x[b] for x in box], [c[b] for c in ctr], [c[b] for c in cof], fm[b],
+                                (H, W, 3), CFG, scale_factor=sf, rescale=rescale, ssd_flag=ssd)
+        det, lab = ref["%s.det%d" % (tag, b)], ref["%s.lab%d" % (tag, b)]
+        assert r["det_bboxes"].shape == det.shape
+        np.testing.assert_array_equal(r["det_labels"], lab)
+        np.testing.assert_allclose(r["det_bboxes"], det, rtol=1e-5, atol=1e-5)
+        want = np.unpackbits(ref["%s.masks%d" % (tag, b)], axis=1)[:, :mh * mw].reshape(-1, mh, mw)
+        got = np.zeros_like(want)
+        m = r["masks"].numpy()
+        hh, ww = min(mh, m.shape[1]), min(mw, m.shape[2])
+        got[:, :hh, :ww] = m[:, :hh, :ww]                      # the paste of sipmask_head.py:645-653
+        assert int((got != want).sum()) == 0, (tag, b, int((got != want).sum()))
+        ndet += det.shape[0]
+    assert ndet > 50
+
+
+@pytest.mark.parametrize("tag,cs", [("C_loss_cs", True), ("C_loss_nocs", False)])
+def test_loss_and_targets_match_reference(ref, tag, cs):
+    """SipMaskHead.loss (:290-498), fcos_target / fcos_target_single (:731-857), centerness_target (:859-866)"""
+    cls, box, ctr, cof, fm = FX.head_outputs(31, 2, NUM_CLASSES - 1)
+    cof = [c * 0.25 for c in cof]
+    gtb, gtl, gtm = FX.ground_truth(32, 2, NUM_CLASSES - 1)
+    losses, aux = OL.head_loss(cls, box, ctr, cof, fm * 0.25, gtb, gtl, gtm, center_sampling=cs)
+    np.testing.assert_array_equal(aux["labels"].numpy(), ref[tag + ".labels"])
+    np.testing.assert_array_equal(aux["bbox_targets"].numpy(), ref[tag + ".bbox_targets"])
+    for b in range(2):
+        np.testing.assert_array_equal(aux["per_img"][b][2].numpy(), ref["%s.gt_inds%d" % (tag, b)])
+    pts = torch.cat(OM.get_points([c.shape[-2:] for c in cls])).numpy()
+    np.testing.assert_array_equal(pts, ref[tag + ".points"])
+    assert int((ref[tag + ".labels"] > 0).sum()) > 10
+    for k in ("loss_cls", "loss_bbox", "loss_centerness", "loss_mask"):
+        np.testing.assert_allclose(float(losses[k]), float(ref["%s.%s" % (tag, k)]), rtol=2e-5, err_msg=k)
+
+
+def _boxes(s1, s2, n, grow=0.0):
+    a = torch.from_numpy(np.concatenate([FX.exact(s1, (n, 2), 0, 2 ** 11, 2.0 ** -4), FX.exact(s2, (n, 2), 0, 2 ** 11, 2.0 ** -4)], 1))
+    return torch.cat([torch.min(a[:, :2], a[:, 2:]), torch.max(a[:, :2], a[:, 2:]) + grow], 1)
+
+
+def test_small_functions_match_reference(ref):
+    a, b = _boxes(41, 42, 40), _boxes(43, 44, 40)
+    np.testing.assert_allclose(np.asarray(O.bbox_overlaps(a, b)), ref["D_overlaps.full"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(np.asarray(O.bbox_overlaps(a, b, is_aligned=True)), ref["D_overlaps.aligned"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(OL._aligned_iou(a, b).numpy(), ref["D_overlaps.aligned"], rtol=1e-6, atol=1e-7)
+    pts = torch.from_numpy(FX.exact(45, (64, 2), 0, 2 ** 11, 2.0 ** -4))
+    dist = torch.from_numpy(FX.exact(46, (64, 4), -64, 2 ** 11, 2.0 ** -4))
+    np.testing.assert_array_equal(np.asarray(O.distance2bbox(pts, dist)), ref["D_distance2bbox.plain"])
+    np.testing.assert_array_equal(np.asarray(O.distance2bbox(pts, dist, max_shape=(96, 128, 3))), ref["D_distance2bbox.clamped"])
+    np.testing.assert_array_equal(OL._d2b(pts, dist).numpy(), ref["D_distance2bbox.plain"])
+    t = torch.from_numpy(FX.exact(47, (50, 4), 1, 2 ** 10, 2.0 ** -4))
+    np.testing.assert_allclose(OL.centerness_target(t).numpy(), ref["D_centerness_target"], rtol=1e-6)
+
+
+def test_cuda_semantics_crop_split_vs_reference_python_crop_split(ref):
+    """The reference keeps a python crop_split (sipmask_head.py:58-105) next to the CUDA op it actually calls; the oracle
+    restates the CUDA kernel.  The two rules (python: pixel < (x1+x2)/2; CUDA: int((x - x1) / ((x2 - x1 + 0.1) / 2)))
+    can only disagree on the one pixel row / column next to a box centre, so on 12 quarter-pixel boxes the restated
+    kernel must reproduce the reference's python result except for a handful of such pixels."""
+    data = FX.exact(48, (4, 24, 32, 12), 0, 2 ** 10, 2.0 ** -10)
+    rois = torch.from_numpy(FX.exact(49, (12, 4), 0, 96, 0.25))
+    rois = torch.cat([torch.min(rois[:, :2], rois[:, 2:]), torch.max(rois[:, :2], rois[:, 2:]) + 2.0], 1).numpy()
+    got = O.crop_split(data, rois, 2)
+    want = ref["D_py_crop_split"]
+    assert (want != 0).sum() > 900
+    diff = (got != want)
+    assert int(diff.sum()) <= 8 and int((diff.sum((0, 1)) == 0).sum()) >= 10, diff.sum((0, 1))
+    for n in np.nonzero(diff.sum((0, 1)))[0]:                       # only next to the centre lines of that box
+        ys, xs = np.nonzero(diff[:, :, n])
+        cx, cy = (rois[n, 0] + rois[n, 2]) / 2, (rois[n, 1] + rois[n, 3]) / 2
+        assert all(abs(x - cx) <= 1 or abs(y - cy) <= 1 for x, y in zip(xs, ys))
+
+
+def test_fast_nms_matches_reference(ref):
+    """SipMaskHead.fast_nms + jaccard + intersect, sipmask_head.py:868-960"""
+    boxes = _boxes(51, 52, 300, grow=1.0).numpy()
+    scores = FX.exact_unique(53, (8, 300))
+    cofs = FX.exact(54, (300, 128))
+    det, lab, m = O.fast_nms(boxes, scores, cofs, 0.5, 200, 0.6, max_out=100)
+    np.testing.assert_array_equal(lab, ref["E_fast_nms.lab"])
+    np.testing.assert_allclose(det, ref["E_fast_nms.det"], rtol=1e-6)
+    np.testing.assert_allclose(m.astype(np.float64).sum(1), ref["E_fast_nms.cof_rowsum"], rtol=1e-6)
+    assert det.shape[0] > 20
