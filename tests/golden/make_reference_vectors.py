@@ -86,6 +86,106 @@ def _accept_ndarray_scale_factor():
     R.STAND_INS["F.interpolate(scale_factor=ndarray)"] = "numpy scale factors converted to python floats (API change of PyTorch)"
 
 
+VIS_CLASSES = 5
+VIS_CFG = Cfg(nms_pre=200, min_bbox_size=0, score_thr=0.1, nms=Cfg(type="nms", iou_thr=0.5), max_per_img=10)
+
+
+def vis_sections():
+    """SipMask-VIS head (V/mmdet/models/anchor_heads/sipmask_head.py): forward with the track branch (:252-317),
+    get_bboxes with fast_nms and the frame-to-frame matching (:565-684, :544-562, :768-781)"""
+    from oracle import vis as OV
+    ns = R.mmdet_tree_vis()
+    H, W = FX.IMG_HW
+    head = ns.head.SipMaskHead(num_classes=VIS_CLASSES, in_channels=256, stacked_convs=3, feat_channels=256,
+                               strides=[8, 16, 32, 64, 128], center_sampling=True, center_sample_radius=1.5)
+    tmpl = {k[len("bbox_head."):]: v for k, v in OV.init_vis_state_dict(0, num_classes=VIS_CLASSES).items()
+            if k.startswith("bbox_head.")}
+    assert set(tmpl) == set(head.state_dict())
+    head.load_state_dict(FX.head_state_dict(tmpl, seed=300))
+    head.eval()
+    feats = FX.pyramid_feats(61, 1)
+    with torch.no_grad():
+        cls, box, ctr, cof, fm, tf, _ = head(feats, feats, flag_train=False)
+    for l in range(5):
+        summarize("F_vis_forward.cls%d" % l, cls[l])
+        summarize("F_vis_forward.box%d" % l, box[l])
+        summarize("F_vis_forward.cof%d" % l, cof[l])
+    summarize("F_vis_forward.feat_mask", fm)
+    summarize("F_vis_forward.track", tf)
+    # a 4-frame clip; the reference keeps the tracker memory on the head object
+    for case, rescale, sf, ori in (("G_vis_clip", False, 1.0, (H, W, 3)), ("G_vis_clip_rescale", True, 1.5, (64, 85, 3))):
+        head.prev_bboxes = head.prev_roi_feats = head.prev_det_labels = None
+        for f in range(4):
+            cls, box, ctr, cof, fm = FX.head_outputs(71 + (f // 2), 1, VIS_CLASSES - 1)    # frames 0,1 and 2,3 share detections
+            box = [b + 0.5 * f for b in box]
+            tf = FX.texact(81 + f, (1, 512, H // 8, W // 8), -2 ** 9, 2 ** 9, 2.0 ** -10)
+            meta = [dict(img_shape=(H, W, 3), ori_shape=ori, scale_factor=sf, is_first=(f == 0))]
+            with torch.no_grad():
+                res = head.get_bboxes(cls, box, ctr, cof, fm, tf, tf, meta, VIS_CFG, rescale=rescale)
+            det, lab, segms, ids = res[0]
+            tag = "%s.f%d" % (case, f)
+            OUT[tag + ".det"] = det.numpy().astype(np.float32)
+            OUT[tag + ".lab"] = lab.numpy().astype(np.int64)
+            OUT[tag + ".ids"] = np.asarray(ids, np.int64)
+            keys = sorted(int(k) for k in segms)
+            OUT[tag + ".mask_ids"] = np.asarray(keys, np.int64)
+            OUT[tag + ".masks"] = (np.stack([np.packbits(np.asarray(segms[k])[:, :, 0].reshape(-1)) for k in keys])
+                                   if keys else np.zeros((0, 1), np.uint8))
+        OUT[case + ".mask_hw"] = np.asarray(ori[:2], np.int64)
+        OUT[case + ".memory_boxes"] = head.prev_bboxes.numpy().astype(np.float32)
+        OUT[case + ".memory_labels"] = head.prev_det_labels.numpy().astype(np.int64)
+
+
+def benchmark_sections():
+    """maskrcnn-benchmark variant (B/fcos_core/modeling/rpn/sipmask): head forward in eval mode (sipmask.py:145-190),
+    SipMaskPostProcessor.forward (inference.py:66-236) incl. compute_locations (sipmask.py:261-285)"""
+    import types
+    from oracle import fcos_core as OB
+    ns = R.fcos_tree()
+    H, W = FX.IMG_HW
+    cfg = R.fcos_cfg(num_classes=NUM_CLASSES)
+    head = ns.sipmask.SipMaskHead(cfg, 256)
+    tmpl = {k[len("rpn.head."):]: v for k, v in OB.init_head_state_dict(0, num_classes=NUM_CLASSES).items()}
+    assert set(tmpl) == set(head.state_dict())
+    sd = FX.head_state_dict(tmpl, seed=500)
+    sd["bbox_pred.bias"] = sd["bbox_pred.bias"] + 1.0          # keep relu(bbox_pred) alive
+    head.load_state_dict(sd)
+    head.eval()
+    feats = FX.pyramid_feats(91, 2)
+    with torch.no_grad():
+        logits, reg, ctr, cof, fm = head(feats)
+    for l in range(5):
+        summarize("H_b_forward.cls%d" % l, logits[l])
+        summarize("H_b_forward.box%d" % l, reg[l])
+        summarize("H_b_forward.ctr%d" % l, ctr[l])
+        summarize("H_b_forward.cof%d" % l, cof[l])
+    summarize("H_b_forward.feat_mask", fm)
+
+    # inference.py:75-91 calls .view() on the result of permute().reshape().sigmoid(); elementwise results were
+    # contiguous in the PyTorch of its time and keep the (non-viewable) input strides today -> same values, contiguous
+    _sig = torch.Tensor.sigmoid
+    torch.Tensor.sigmoid = lambda self: _sig(self).contiguous()
+    R.STAND_INS["Tensor.sigmoid (B/ section)"] = "result made contiguous (memory-format drift of PyTorch; values unchanged)"
+    post = ns.inference.SipMaskPostProcessor(pre_nms_thresh=0.05, pre_nms_top_n=1000, nms_thresh=0.6, fpn_post_nms_top_n=100,
+                                             min_size=0, num_classes=NUM_CLASSES)
+    fake = types.SimpleNamespace(fpn_strides=[8, 16, 32, 64, 128])
+    fake.compute_locations_per_level = lambda h, w, s, d: ns.sipmask.SipMaskModule.compute_locations_per_level(fake, h, w, s, d)
+    cls, box, ctr, cof, fm = FX.head_outputs(95, 2, NUM_CLASSES - 1)
+    locations = ns.sipmask.SipMaskModule.compute_locations(fake, cls)
+    OUT["I_b_post.locations"] = torch.cat(locations).numpy()
+    for tag, ori_wh in (("I_b_post_same", (W, H)), ("I_b_post_rescale", (85, 64))):
+        with torch.no_grad():
+            res = post(locations, cls, box, ctr, cof, fm, [(H, W), (H, W)], img_metas=[ori_wh, ori_wh])
+        for b, bl in enumerate(res):
+            OUT["%s.bbox%d" % (tag, b)] = bl.bbox.numpy().astype(np.float32)
+            OUT["%s.scores%d" % (tag, b)] = bl.get_field("scores").numpy().astype(np.float32)
+            OUT["%s.labels%d" % (tag, b)] = bl.get_field("labels").numpy().astype(np.int64)
+            m = bl.get_field("mask").numpy()[:, 0]
+            OUT["%s.masks%d" % (tag, b)] = np.packbits(m.reshape(m.shape[0], -1).astype(np.uint8), axis=1)
+        OUT[tag + ".mask_hw"] = np.asarray([ori_wh[1], ori_wh[0]], np.int64)
+    torch.Tensor.sigmoid = _sig
+
+
 def main():
     torch.manual_seed(0)
     _accept_ndarray_scale_factor()
@@ -177,6 +277,9 @@ def main():
     OUT["E_fast_nms.det"] = d.numpy()
     OUT["E_fast_nms.lab"] = l.numpy().astype(np.int64)
     OUT["E_fast_nms.cof_rowsum"] = m.numpy().astype(np.float64).sum(1)
+
+    vis_sections()
+    benchmark_sections()
 
     OUT["meta"] = np.asarray(json.dumps(dict(
         generator="tests/golden/make_reference_vectors.py", reference="JialeCao001/SipMask @ v1 (/root/reference)",

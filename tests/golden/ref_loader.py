@@ -219,3 +219,136 @@ def mmdet_tree(root=M, tag="M"):
     head = load("mmdet.models.anchor_heads.sipmask_head", os.path.join(p, "models/anchor_heads/sipmask_head.py"))
     return types.SimpleNamespace(geometry=geometry, transforms=transforms, bbox_nms=bbox_nms, focal=focal, iou=iou, ce=ce,
                                  head=head, build_loss=build_loss, tag=tag)
+
+
+def mmdet_tree_vis(root=V):
+    """The SipMask-VIS tree (older mmdet layout: ConvModule / Scale live in mmdet/models/utils, the head imports
+    `cross_entropy` and `accuracy` from ..losses).  Same stand-ins as mmdet_tree(); additionally
+    torch.cuda.current_device() answers "cpu" (the VIS head builds two dummy tensors on `torch.cuda.current_device()`)."""
+    for k in [k for k in sys.modules if k == "mmdet" or k.startswith("mmdet.") or k.startswith("mmcv") or
+              k.startswith("pycocotools")]:
+        del sys.modules[k]
+    _mmcv()
+    torch.cuda.current_device = lambda: "cpu"
+    STAND_INS["torch.cuda.current_device"] = "no GPU in the build container: answers 'cpu' (V/ sipmask_head.py:548-552,626)"
+    stub("pycocotools", mask=stub("pycocotools.mask", encode=lambda a: [a]))
+    p = os.path.join(root, "mmdet")
+    stub("mmdet")
+    stub("mmdet.core")
+    stub("mmdet.core.bbox")
+    stub("mmdet.core.utils")
+    stub("mmdet.core.post_processing")
+    geometry = load("mmdet.core.bbox.geometry", os.path.join(p, "core/bbox/geometry.py"))
+    transforms = load("mmdet.core.bbox.transforms", os.path.join(p, "core/bbox/transforms.py"))
+    misc = load("mmdet.core.utils.misc", os.path.join(p, "core/utils/misc.py"))
+    ops = stub("mmdet.ops", DeformConv=_DeformConv, CropSplit=_CropSplit, CropSplitGt=_CropSplitGt, sigmoid_focal_loss=None)
+    stub("mmdet.ops.nms", nms_wrapper=stub("mmdet.ops.nms.nms_wrapper", nms=_nms_stub))
+    bbox_nms = load("mmdet.core.post_processing.bbox_nms", os.path.join(p, "core/post_processing/bbox_nms.py"))
+    core = sys.modules["mmdet.core"]
+    core.distance2bbox, core.bbox_overlaps = transforms.distance2bbox, geometry.bbox_overlaps
+    core.force_fp32, core.auto_fp16, core.multi_apply = _force_fp32, _force_fp32, misc.multi_apply
+    core.multiclass_nms, core.multiclass_nms_idx = bbox_nms.multiclass_nms, bbox_nms.multiclass_nms_idx
+    stub("mmdet.models")
+    reg = stub("mmdet.models.registry", HEADS=_Registry(), LOSSES=_Registry())
+    utils = stub("mmdet.models.utils")
+    for leaf in ("conv_ws", "norm", "scale", "weight_init", "conv_module"):
+        load("mmdet.models.utils." + leaf, os.path.join(p, "models/utils", leaf + ".py"))
+    utils.ConvModule = sys.modules["mmdet.models.utils.conv_module"].ConvModule
+    utils.Scale = sys.modules["mmdet.models.utils.scale"].Scale
+    utils.bias_init_with_prob = sys.modules["mmdet.models.utils.weight_init"].bias_init_with_prob
+    losses = stub("mmdet.models.losses")
+    load("mmdet.models.losses.utils", os.path.join(p, "models/losses/utils.py"))
+    focal = load("mmdet.models.losses.focal_loss", os.path.join(p, "models/losses/focal_loss.py"))
+
+    def _sfl(pred, target, gamma, alpha):
+        onehot = torch.zeros_like(pred)
+        idx = target.nonzero().view(-1)
+        onehot[idx, target[idx] - 1] = 1
+        return focal.py_sigmoid_focal_loss(pred, onehot, gamma=gamma, alpha=alpha, reduction="none")
+
+    focal._sigmoid_focal_loss = _sfl
+    load("mmdet.models.losses.iou_loss", os.path.join(p, "models/losses/iou_loss.py"))
+    ce = load("mmdet.models.losses.cross_entropy_loss", os.path.join(p, "models/losses/cross_entropy_loss.py"))
+    acc = load("mmdet.models.losses.accuracy", os.path.join(p, "models/losses/accuracy.py"))
+    losses.cross_entropy, losses.accuracy = ce.cross_entropy, acc.accuracy
+
+    def build_loss(cfg):
+        cfg = dict(cfg)
+        return reg.LOSSES.module_dict[cfg.pop("type")](**cfg)
+
+    stub("mmdet.models.builder", build_loss=build_loss)
+    stub("mmdet.models.anchor_heads")
+    head = load("mmdet.models.anchor_heads.sipmask_head", os.path.join(p, "models/anchor_heads/sipmask_head.py"))
+    return types.SimpleNamespace(geometry=geometry, transforms=transforms, bbox_nms=bbox_nms, head=head, tag="V")
+
+
+class _DeformConvB(nn.Module):
+    """constructor signature of B/fcos_core/layers/dcn/deform_conv_module.py:DeformConv (bias supported there)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super().__init__()
+        assert groups == 1
+        self.weight = nn.Parameter(torch.zeros(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.stride, self.padding, self.dilation, self.dg = stride, padding, dilation, deformable_groups
+
+    def forward(self, x, offset):
+        y = O.deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.dg)
+        return y if self.bias is None else y + self.bias.view(1, -1, 1, 1)
+
+
+def _ml_nms_stub(boxes, scores, labels, thr):
+    """B/fcos_core/csrc/cuda/ml_nms.cu through _C.ml_nms -> kept indices (increasing)"""
+    from oracle import fcos_core as OB
+    keep = OB.ml_nms(boxes.detach().numpy().astype(np.float32), scores.detach().numpy().astype(np.float32),
+                     labels.detach().numpy().astype(np.int64), thr)
+    return torch.as_tensor(np.asarray(keep, dtype=np.int64))
+
+
+def _ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def fcos_cfg(num_classes=81, **over):
+    """cfg.MODEL.SIPMASK.* / cfg.TEST.* with the values of B/fcos_core/config/defaults.py:292-314 overridden by
+    B/configs/sipmask/sipmask_R_50_FPN_1x.yaml:13-22"""
+    sip = dict(NUM_CLASSES=num_classes, FPN_STRIDES=[8, 16, 32, 64, 128], PRIOR_PROB=0.01, INFERENCE_TH=0.05, NMS_TH=0.6,
+               PRE_NMS_TOP_N=1000, LOSS_ALPHA=0.25, LOSS_GAMMA=2.0, NUM_CONVS=4, CENTER_SAMPLING_RADIUS=1.5,
+               IOU_LOSS_TYPE="giou", NORM_REG_TARGETS=True, CENTERNESS_ON_REG=True, USE_DCN_IN_TOWER=False)
+    sip.update(over)
+    return _ns(MODEL=_ns(SIPMASK=_ns(**sip)), TEST=_ns(DETECTIONS_PER_IMG=100, BBOX_AUG=_ns(ENABLED=False)))
+
+
+def fcos_tree(root=B):
+    """The maskrcnn-benchmark variant (B/fcos_core).  Stand-ins: _C.nms / _C.ml_nms (compiled) -> oracle NMS per label,
+    DeformConv / CropSplit / CropSplitGt (compiled) -> oracle ops; everything else is the reference's Python."""
+    for k in [k for k in sys.modules if k == "fcos_core" or k.startswith("fcos_core.") or k.startswith("pycocotools")]:
+        del sys.modules[k]
+    STAND_INS["fcos_core._C.ml_nms"] = ("compiled extension: replaced by oracle.fcos_core.ml_nms = the golden-pinned greedy "
+                                        "NMS run per label (tests/test_targets.py::test_oracle_ml_nms_equals_per_label_nms)")
+    stub("pycocotools", mask=stub("pycocotools.mask", encode=lambda a: [a]))
+    p = os.path.join(root, "fcos_core")
+    stub("fcos_core", _C=_ns(nms=lambda d, s, t: _nms_stub(torch.cat([d, s[:, None]], 1), t)[1], ml_nms=_ml_nms_stub))
+    sys.modules["fcos_core._C"] = sys.modules["fcos_core"]._C
+    layers = stub("fcos_core.layers", nms=sys.modules["fcos_core"]._C.nms, ml_nms=_ml_nms_stub, DeformConv=_DeformConvB,
+                  CropSplit=_CropSplit, CropSplitGt=_CropSplitGt, DFConv2d=None)
+    layers.Scale = load("fcos_core.layers.scale", os.path.join(p, "layers/scale.py")).Scale
+    layers.IOULoss = load("fcos_core.layers.iou_loss", os.path.join(p, "layers/iou_loss.py")).IOULoss
+    layers.SigmoidFocalLoss = load("fcos_core.layers.sigmoid_focal_loss", os.path.join(p, "layers/sigmoid_focal_loss.py")).SigmoidFocalLoss
+    stub("fcos_core.structures")
+    load("fcos_core.structures.bounding_box", os.path.join(p, "structures/bounding_box.py"))
+    load("fcos_core.structures.boxlist_ops", os.path.join(p, "structures/boxlist_ops.py"))
+    stub("fcos_core.modeling")
+    load("fcos_core.modeling.box_coder", os.path.join(p, "modeling/box_coder.py"))
+    load("fcos_core.modeling.utils", os.path.join(p, "modeling/utils.py"))
+    load("fcos_core.modeling.matcher", os.path.join(p, "modeling/matcher.py"))
+    stub("fcos_core.modeling.rpn")
+    load("fcos_core.modeling.rpn.utils", os.path.join(p, "modeling/rpn/utils.py"))
+    load("fcos_core.modeling.rpn.inference", os.path.join(p, "modeling/rpn/inference.py"))
+    stub("fcos_core.modeling.rpn.sipmask")
+    inf = load("fcos_core.modeling.rpn.sipmask.inference", os.path.join(p, "modeling/rpn/sipmask/inference.py"))
+    loss = load("fcos_core.modeling.rpn.sipmask.loss", os.path.join(p, "modeling/rpn/sipmask/loss.py"))
+    sip = load("fcos_core.modeling.rpn.sipmask.sipmask", os.path.join(p, "modeling/rpn/sipmask/sipmask.py"))
+    return types.SimpleNamespace(inference=inf, loss=loss, sipmask=sip, tag="B",
+                                 BoxList=sys.modules["fcos_core.structures.bounding_box"].BoxList)

@@ -156,3 +156,112 @@ def test_fast_nms_matches_reference(ref):
     np.testing.assert_allclose(det, ref["E_fast_nms.det"], rtol=1e-6)
     np.testing.assert_allclose(m.astype(np.float64).sum(1), ref["E_fast_nms.cof_rowsum"], rtol=1e-6)
     assert det.shape[0] > 20
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SipMask-VIS head (V/mmdet/models/anchor_heads/sipmask_head.py)
+# ---------------------------------------------------------------------------------------------------------------
+VIS_CLASSES = 5
+VIS_CFG = dict(nms_pre=200, min_bbox_size=0, score_thr=0.1, nms=dict(type="nms", iou_thr=0.5), max_per_img=10)
+
+
+def test_vis_forward_matches_reference(ref):
+    """forward(flag_train=False), V/...:252-317: the M/ head with 3-deep towers plus track_convs -> sipmask_track"""
+    from oracle import vis as OV
+    tmpl = {k[len("bbox_head."):]: v for k, v in OV.init_vis_state_dict(0, num_classes=VIS_CLASSES).items()
+            if k.startswith("bbox_head.")}
+    sd = {"bbox_head." + k: v for k, v in FX.head_state_dict(tmpl, seed=300).items()}
+    feats = FX.pyramid_feats(61, 1)
+    with torch.no_grad():
+        cls, box, ctr, cof, fm = OM.head_forward(sd, feats)
+        tf = OV.track_forward(sd, feats)
+    for l in range(5):
+        _check_summary(ref, "F_vis_forward.cls%d" % l, cls[l])
+        _check_summary(ref, "F_vis_forward.box%d" % l, box[l])
+        _check_summary(ref, "F_vis_forward.cof%d" % l, cof[l])
+    _check_summary(ref, "F_vis_forward.feat_mask", fm)
+    _check_summary(ref, "F_vis_forward.track", tf)
+
+
+@pytest.mark.parametrize("case,rescale,sf", [("G_vis_clip", False, 1.0), ("G_vis_clip_rescale", True, 1.5)])
+def test_vis_clip_matches_reference_get_bboxes(ref, case, rescale, sf):
+    """get_bboxes over a 4-frame clip, V/...:565-684: fast_nms detections, centre features, comprehensive matching
+    scores, identity assignment and the update of the tracker memory; masks pasted per object id."""
+    from oracle import vis as OV
+    H, W = FX.IMG_HW
+    mh, mw = [int(v) for v in ref[case + ".mask_hw"]]
+    trk = OV.Tracker()
+    total = 0
+    for f in range(4):
+        cls, box, ctr, cof, fm = FX.head_outputs(71 + (f // 2), 1, VIS_CLASSES - 1)
+        box = [b + 0.5 * f for b in box]
+        tf = FX.texact(81 + f, (1, 512, H // 8, W // 8), -2 ** 9, 2 ** 9, 2.0 ** -10)
+        r = OV.get_masks_single_vis([c[0] for c in cls], [x[0] for x in box], [c[0] for c in ctr], [c[0] for c in cof], fm[0],
+                                    (H, W, 3), VIS_CFG, scale_factor=sf, rescale=rescale)
+        tag = "%s.f%d" % (case, f)
+        det = r["det_bboxes"]
+        np.testing.assert_array_equal(r["det_labels"], ref[tag + ".lab"])
+        np.testing.assert_allclose(det, ref[tag + ".det"], rtol=1e-5, atol=1e-5)
+        boxes = torch.from_numpy(det[:, :4].copy()) * (sf if rescale else 1.0)
+        feat = OV.extract_box_feature_center(tf[0], boxes)
+        ids = trk.step(det, r["det_labels"], feat, is_first=(f == 0))
+        np.testing.assert_array_equal(np.asarray(ids, np.int64), ref[tag + ".ids"])
+        # the reference keeps, per object id, the mask of the LAST detection carrying it (dict overwrite, :672-680)
+        want_ids = ref[tag + ".mask_ids"]
+        want = np.unpackbits(ref[tag + ".masks"], axis=1)[:, :mh * mw].reshape(-1, mh, mw)
+        m = r["masks"].numpy()
+        for j, oid in enumerate(want_ids):
+            i = int(np.nonzero(np.asarray(ids) == oid)[0][-1])
+            got = np.zeros((mh, mw), np.uint8)
+            hh, ww = min(mh, m.shape[1]), min(mw, m.shape[2])
+            got[:hh, :ww] = m[i, :hh, :ww]
+            assert int((got != want[j]).sum()) == 0, (tag, oid)
+        assert sorted(set(int(i) for i in ids if i >= 0)) == [int(v) for v in want_ids]
+        total += det.shape[0]
+    np.testing.assert_allclose(trk.prev_bboxes.numpy(), ref[case + ".memory_boxes"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(trk.prev_det_labels.numpy(), ref[case + ".memory_labels"])
+    assert total >= 20 and int(ref[case + ".f3.ids"].max()) >= 3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# maskrcnn-benchmark variant (B/fcos_core/modeling/rpn/sipmask)
+# ---------------------------------------------------------------------------------------------------------------
+def test_benchmark_head_forward_matches_reference(ref):
+    """SipMaskHead.forward in eval mode, B/...sipmask.py:145-190 (NORM_REG_TARGETS, CENTERNESS_ON_REG as in the yaml)"""
+    from oracle import fcos_core as OB
+    tmpl = {k[len("rpn.head."):]: v for k, v in OB.init_head_state_dict(0, num_classes=NUM_CLASSES).items()}
+    sd = FX.head_state_dict(tmpl, seed=500)
+    sd["bbox_pred.bias"] = sd["bbox_pred.bias"] + 1.0
+    sd = {"rpn.head." + k: v for k, v in sd.items()}
+    feats = FX.pyramid_feats(91, 2)
+    with torch.no_grad():
+        logits, reg, ctr, cof, fm = OB.head_forward(sd, feats)
+    for l in range(5):
+        _check_summary(ref, "H_b_forward.cls%d" % l, logits[l])
+        _check_summary(ref, "H_b_forward.box%d" % l, reg[l])
+        _check_summary(ref, "H_b_forward.ctr%d" % l, ctr[l])
+        _check_summary(ref, "H_b_forward.cof%d" % l, cof[l])
+    _check_summary(ref, "H_b_forward.feat_mask", fm)
+
+
+@pytest.mark.parametrize("tag,ori_wh", [("I_b_post_same", (128, 96)), ("I_b_post_rescale", (85, 64))])
+def test_benchmark_postprocessor_matches_reference(ref, tag, ori_wh):
+    """SipMaskPostProcessor.forward, B/...inference.py:66-236: (location, class) candidates, sqrt scores, clip, ml_nms,
+    kthvalue cut, mask assembly at 2 / scale_factor, paste; and compute_locations (sipmask.py:261-285)"""
+    from oracle import fcos_core as OB
+    H, W = FX.IMG_HW
+    cls, box, ctr, cof, fm = FX.head_outputs(95, 2, NUM_CLASSES - 1)
+    pts = torch.cat(OM.get_points([c.shape[-2:] for c in cls])).numpy()
+    np.testing.assert_array_equal(pts, ref["I_b_post.locations"])
+    mh, mw = [int(v) for v in ref[tag + ".mask_hw"]]
+    n = 0
+    for b in range(2):
+        r = OB.postprocess_single([c[b] for c in cls], [x[b] for x in box], [c[b] for c in ctr], [c[b] for c in cof], fm[b],
+                                  (H, W), ori_wh)
+        np.testing.assert_array_equal(r["labels"].numpy(), ref["%s.labels%d" % (tag, b)])
+        np.testing.assert_allclose(r["bbox"].numpy(), ref["%s.bbox%d" % (tag, b)], rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(r["scores"].numpy(), ref["%s.scores%d" % (tag, b)], rtol=1e-6)
+        want = np.unpackbits(ref["%s.masks%d" % (tag, b)], axis=1)[:, :mh * mw].reshape(-1, mh, mw)
+        assert int((r["mask"].numpy() != want).sum()) == 0
+        n += want.shape[0]
+    assert n > 50
