@@ -2,7 +2,9 @@
 
 Restates B/fcos_core/modeling/rpn/sipmask/sipmask.py:142-190 (head forward, test mode), inference.py:66-236
 (SipMaskPostProcessor), B/fcos_core/csrc/cuda/ml_nms.cu (same-label greedy NMS, IoU with +1) on B/-named parameters.
-PARITY UNPINNED: the reference has no test for this path.
+Pinning: no reference test, but head_forward and postprocess_single reproduce B/'s own SipMaskHead.forward (eval) and
+SipMaskPostProcessor.forward run in the build container (tests/golden/ref_vectors.npz sections H_ / I_; stand-ins for
+_C.ml_nms, DeformConv, CropSplit: tests/golden/ref_loader.py).
 """
 import numpy as np
 import torch

@@ -2,9 +2,10 @@
 
 Restates M/mmdet/models/anchor_heads/sipmask_head.py:289-498 (loss), :731-866 (fcos_target, centerness_target)
 with plain differentiable torch-CPU ops, so tests can take both the loss values and, through autograd, the
-gradients w.r.t. the head outputs.  PARITY UNPINNED: the reference holds no test or golden value for its loss;
-the restatement is pinned only by its own invariants (tests/test_oracle_ops.py) and by the HIP path agreeing
-with it.  The CropSplit / CropSplitGt index math comes from oracle.ops (_crop_cells, CUDA-kernel semantics).
+gradients w.r.t. the head outputs.  Pinning: the reference holds no test or golden value for its loss, but its own `SipMaskHead.loss` / `fcos_target`
+run in the build container (with and without center sampling) give the committed values of
+tests/golden/ref_vectors.npz section C_, which head_loss reproduces (labels, targets and gt indices exactly, the four
+loss values to 2e-5; tests/test_reference_vectors.py).  The CropSplit / CropSplitGt index math comes from oracle.ops (_crop_cells, CUDA-kernel semantics).
 """
 import numpy as np
 import torch

@@ -6,7 +6,10 @@ Restates (fp32, torch-CPU ATen convs):
   * FPN                                      M/mmdet/models/necks/fpn.py:137-178
   * ConvModule conv->GN->ReLU                M/mmdet/ops/conv_module.py:34-132
   * SipMaskHead.forward / get_bboxes_single  M/mmdet/models/anchor_heads/sipmask_head.py:241-287,543-633
-Parity unpinned: the reference has no test on this graph.
+Pinning: the reference has no test on this graph; head_forward and get_masks_single reproduce the
+reference's own SipMaskHead.forward / get_bboxes run in the build container (tests/golden/ref_vectors.npz, sections A_
+and B_; stand-ins only for DeformConv, CropSplit and NMS, see tests/golden/ref_loader.py).  The backbone and FPN
+restatements stay parity unpinned (their reference modules need mmcv's checkpoint / norm helpers throughout).
 """
 import math
 

@@ -12,11 +12,20 @@ Parity pinning:
     ``/root/reference/SipMask-benchmark/tests/test_nms.py:16-58,60-221``) and the
     doctest vectors of ``SipMask-mmdetection/mmdet/ops/nms/nms_wrapper.py:25-34``
     and ``mmdet/core/bbox/geometry.py:22-44``.
-  * Everything else (deform conv, crop_split, mask assembly, multiclass_nms_idx,
-    fast_nms, focal loss) has NO reference test => **parity unpinned**; the
-    restatement is validated by internal cross-checks in tests/test_oracle_*.py
-    (deform(offset=0) == conv2d, integer-offset == shifted conv, crop_split(c=1)
-    == crop_split_gt, CUDA focal formula == python focal formula, fp64 gradcheck).
+  * The reference has no test for anything else, but most of it is plain PyTorch that runs here: outputs of the
+    reference's OWN code (SipMaskHead.forward / get_bboxes / loss / fcos_target / fast_nms of M/, the VIS head with
+    its tracker, B/'s head and SipMaskPostProcessor, mmdet's distance2bbox / bbox_overlaps / multiclass_nms_idx / loss
+    modules) are committed as ``tests/golden/ref_vectors.npz`` (made by ``tests/golden/make_reference_vectors.py``;
+    ``tests/golden/ref_loader.py`` lists the stand-ins for the compiled / absent pieces) and
+    ``tests/test_reference_vectors.py`` holds this package to them: distance2bbox, bbox_overlaps, multiclass_nms_idx,
+    fast_nms, mask_assemble, the python-formula focal loss and the whole graphs in model.py / loss.py / vis.py /
+    fcos_core.py are pinned that way.
+  * Still **parity unpinned** (compiled CUDA extension or absent third-party code on the reference side, nothing to
+    run or compare with): deform_conv / deform_conv_backward, the CUDA crop_split / crop_split_gt kernels (their
+    restatement agrees with the reference's python ``crop_split`` except on the pixel row/column next to a box centre,
+    see the test), the CUDA focal-loss kernel (== the python formula), COCO RLE, the input pipeline.  Those are
+    validated by internal cross-checks in tests/test_oracle_*.py (deform(offset=0) == conv2d, integer-offset ==
+    shifted conv, crop_split(c=1) == crop_split_gt, CUDA focal formula == python focal formula, fp64 gradcheck).
 
 Path prefixes used in citations: M/ = SipMask-mmdetection/, B/ = SipMask-benchmark/,
 V/ = SipMask-VIS/ under /root/reference.

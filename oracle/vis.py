@@ -5,7 +5,9 @@
   get_bboxes_single (always fast_nms)      :686-766, fast_nms :951-993
   extract_box_feature_center_single        :768-781
   frame-to-frame matching                  :565-684 (compute_comp_scores :544-562)
-PARITY UNPINNED: the reference holds no test for this path.
+Pinning: no reference test, but track_forward, get_masks_single_vis, extract_box_feature_center and Tracker reproduce
+the VIS head's own forward / get_bboxes over a 4-frame clip run in the build container (tests/golden/ref_vectors.npz
+sections F_ / G_: detections, object ids, memory and every mask pixel).  track_loss stays parity unpinned.
 """
 import numpy as np
 import torch
