@@ -51,6 +51,33 @@ def head_state_dict(template, seed=100):
     return out
 
 
+def trunk_state_dict(template, seed=700):
+    """backbone / neck tensors re-filled with exact values: conv weights are integers in [-512, 512) times the power of
+    two that brings their spread closest to sqrt(2 / fan_in); BN statistics positive; DCN offset convs small"""
+    out = {}
+    for i, (k, v) in enumerate(sorted(template.items())):
+        shp = tuple(v.shape)
+        if k.endswith("num_batches_tracked"):
+            out[k] = torch.zeros(shp, dtype=v.dtype)
+            continue
+        if k.endswith("running_var"):
+            t = 0.5 + exact(seed + i, shp, 0, 256, 2.0 ** -8)
+        elif k.endswith("running_mean"):
+            t = exact(seed + i, shp, -32, 32, 2.0 ** -8)
+        elif v.dim() == 1 and k.endswith("weight"):
+            t = 1.0 + exact(seed + i, shp, -16, 16, 2.0 ** -8)
+        elif v.dim() == 1:
+            t = exact(seed + i, shp, -16, 16, 2.0 ** -8)
+        elif "conv_offset" in k:
+            t = exact(seed + i, shp, -64, 64, 2.0 ** -14)
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            e = int(np.round(np.log2(np.sqrt(2.0 / fan_in) / 295.0)))
+            t = exact(seed + i, shp, -512, 512, 2.0 ** e)
+        out[k] = torch.from_numpy(np.asarray(t, dtype=np.float32).reshape(shp))
+    return out
+
+
 def pyramid_feats(seed, batch, channels=256, sizes=PYRAMID):
     return [texact(seed + l, (batch, channels, h, w)) for l, (h, w) in enumerate(sizes)]
 

@@ -44,14 +44,16 @@ def summarize(name, t):
     OUT[name + ".shape"] = np.asarray(t.shape, np.int64)
 
 
-def build_head(ns, stacked_convs=4, norm=True, ssd_flag=False, center_sampling=True):
+def build_head(ns, stacked_convs=4, norm=True, ssd_flag=False, center_sampling=True, rescoring=False):
     kw = dict(num_classes=NUM_CLASSES, in_channels=256, stacked_convs=stacked_convs, feat_channels=256,
-              strides=[8, 16, 32, 64, 128], center_sampling=center_sampling, center_sample_radius=1.5, ssd_flag=ssd_flag)
+              strides=[8, 16, 32, 64, 128], center_sampling=center_sampling, center_sample_radius=1.5, ssd_flag=ssd_flag,
+              rescoring_flag=rescoring)
     if not norm:
         kw["norm_cfg"] = None
     head = ns.head.SipMaskHead(**kw)
     tmpl = {k[len("bbox_head."):]: v for k, v in
-            OM.init_state_dict(50, 0, num_classes=NUM_CLASSES, stacked_convs=stacked_convs, norm=norm).items()
+            OM.init_state_dict(50, 0, num_classes=NUM_CLASSES, stacked_convs=stacked_convs, norm=norm,
+                               rescoring=rescoring).items()
             if k.startswith("bbox_head.")}
     assert set(tmpl) == set(head.state_dict()), sorted(set(tmpl) ^ set(head.state_dict()))
     head.load_state_dict(FX.head_state_dict(tmpl))
@@ -84,6 +86,38 @@ def _accept_ndarray_scale_factor():
 
     F.interpolate = interpolate
     R.STAND_INS["F.interpolate(scale_factor=ndarray)"] = "numpy scale factors converted to python floats (API change of PyTorch)"
+
+
+def trunk_sections(ns):
+    """ResNet-50 caffe style (M/mmdet/models/backbones/resnet.py), plain and with DCN in stages 2-4 (the SipMask++
+    configs), and the FPN of the SipMask configs (M/mmdet/models/necks/fpn.py), eval mode"""
+    img = FX.texact(601, (1, 3, 64, 96), -2 ** 11, 2 ** 11, 2.0 ** -10)
+    for tag, dcn in (("J_backbone", None), ("J_backbone_dcn", (False, True, True, True))):
+        kw = dict(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                  norm_cfg=dict(type="BN", requires_grad=False), norm_eval=True, style="caffe")
+        if dcn:
+            kw.update(dcn=dict(type="DCN", deformable_groups=1, fallback_on_stride=False), stage_with_dcn=dcn)
+        net = ns.resnet.ResNet(**kw)
+        full = OM.init_state_dict(50, 0, stage_with_dcn=dcn) if dcn else OM.init_state_dict(50, 0)
+        tmpl = {k[len("backbone."):]: v for k, v in full.items() if k.startswith("backbone.")}
+        assert set(tmpl) == set(net.state_dict())
+        net.load_state_dict(FX.trunk_state_dict(tmpl))
+        net.eval()
+        with torch.no_grad():
+            feats = net(img)
+        for i, f in enumerate(feats):
+            summarize("%s.c%d" % (tag, i + 2), f)
+        if dcn is None:
+            neck = ns.fpn.FPN(in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=1, add_extra_convs=True,
+                              extra_convs_on_inputs=False, num_outs=5, relu_before_extra_convs=True)
+            ntmpl = {k[len("neck."):]: v for k, v in full.items() if k.startswith("neck.")}
+            assert set(ntmpl) == set(neck.state_dict())
+            neck.load_state_dict(FX.trunk_state_dict(ntmpl, seed=900))
+            neck.eval()
+            with torch.no_grad():
+                pyr = neck(feats)
+            for i, f in enumerate(pyr):
+                summarize("J_fpn.p%d" % (i + 3), f)
 
 
 VIS_CLASSES = 5
@@ -223,6 +257,23 @@ def main():
             OUT["%s.masks%d" % (tag, b)] = pack_masks(segms, lab, mh, mw)
             OUT["%s.mask_hw" % tag] = np.asarray([mh, mw], np.int64)
     head.ssd_flag = False
+    # SipMask++ mask rescoring (:635-643): the SSD-style head with rescoring_flag, scores per detection
+    head = build_head(ns, stacked_convs=2, norm=False, ssd_flag=True, rescoring=True)
+    big = [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)]         # the six stride-2 convs need a >= 127 px basis map
+    outs = FX.head_outputs(25, 1, NUM_CLASSES - 1, sizes=big)
+    sf = np.array([1.25, 1.5, 1.25, 1.5], np.float32)
+    metas = [dict(img_shape=(256, 256, 3), ori_shape=(170, 204, 3), scale_factor=sf)]
+    with torch.no_grad():
+        res = head.get_bboxes(*outs, metas, TEST_CFG, rescale=True)
+    for b, (det, lab, (segms, mscores)) in enumerate(res):
+        cnt, ms = {}, []
+        for l in lab.tolist():
+            k = cnt.get(l, 0)
+            cnt[l] = k + 1
+            ms.append(float(mscores[l][k]))
+        OUT["B_rescoring.det%d" % b] = det.numpy().astype(np.float32)
+        OUT["B_rescoring.lab%d" % b] = lab.numpy().astype(np.int64)
+        OUT["B_rescoring.mask_scores%d" % b] = np.asarray(ms, np.float32)
 
     # ---- C: loss (sipmask_head.py:290-498) with fcos_target / centerness_target (:731-866)
     for tag, cs in (("C_loss_cs", True), ("C_loss_nocs", False)):
@@ -278,6 +329,7 @@ def main():
     OUT["E_fast_nms.lab"] = l.numpy().astype(np.int64)
     OUT["E_fast_nms.cof_rowsum"] = m.numpy().astype(np.float64).sum(1)
 
+    trunk_sections(ns)
     vis_sections()
     benchmark_sections()
 

@@ -34,7 +34,8 @@ STAND_INS = {
                                "the fixture holds the reference's mask, not its RLE)",
     "mmdet.ops.nms.nms_wrapper.nms": "compiled extension: replaced by oracle.ops.nms(mode='gpu'), which reproduces the "
                                      "reference's own NMS golden vectors (tests/golden/nms_kat.json)",
-    "mmdet.ops.DeformConv": "compiled CUDA extension: replaced by oracle.ops.deform_conv (parity unpinned for that op)",
+    "mmdet.ops.DeformConv": "compiled CUDA extension: replaced by oracle.ops.deform_conv (parity unpinned for that op); "
+                            "DeformConvPack = the same behind its conv_offset conv, as deform_conv.py:258-296 defines it",
     "mmdet.ops.CropSplit / CropSplitGt": "compiled CUDA extension: replaced by oracle.ops.crop_split / crop_split_gt "
                                           "(cross-checked in the fixtures against the reference's python crop_split)",
     "mmdet.ops.sigmoid_focal_loss": "compiled CUDA extension: replaced by the reference's own py_sigmoid_focal_loss "
@@ -96,6 +97,21 @@ class _DeformConv(nn.Module):
 
     def forward(self, x, offset):
         return O.deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.dg)
+
+
+class _DeformConvPack(_DeformConv):
+    """M/mmdet/ops/dcn/deform_conv.py:258-296 restated around the stand-in: conv_offset (a plain conv with the layer's own
+    kernel / stride / padding, bias) feeds the deformable conv"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, deformable_groups, bias)
+        k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        self.conv_offset = nn.Conv2d(in_channels, deformable_groups * 2 * k * k, kernel_size=k, stride=stride,
+                                     padding=padding, bias=True)
+
+    def forward(self, x):
+        return super().forward(x, self.conv_offset(x))
 
 
 class _CropSplit(nn.Module):
@@ -175,13 +191,17 @@ def mmdet_tree(root=M, tag="M"):
     if hasattr(bbox_nms, "multiclass_nms_idx"):
         core.multiclass_nms_idx = bbox_nms.multiclass_nms_idx
     # mmdet.ops: the pure-Python layers run as written, the compiled ones are stand-ins
-    stub("mmdet.ops.dcn", DeformConvPack=None, ModulatedDeformConvPack=None, DeformConv=_DeformConv)
+    stub("mmdet.ops.dcn", DeformConvPack=_DeformConvPack, ModulatedDeformConvPack=None, DeformConv=_DeformConv)
     for leaf in ("activation", "conv_ws", "norm", "scale"):
         if os.path.exists(os.path.join(p, "ops", leaf + ".py")):
             load("mmdet.ops." + leaf, os.path.join(p, "ops", leaf + ".py"))
     for leaf in ("conv", "conv_module"):
         if os.path.exists(os.path.join(p, "ops", leaf + ".py")):
             load("mmdet.ops." + leaf, os.path.join(p, "ops", leaf + ".py"))
+    if "mmdet.ops.conv" in sys.modules:
+        ops.build_conv_layer = sys.modules["mmdet.ops.conv"].build_conv_layer
+        ops.build_norm_layer = sys.modules["mmdet.ops.norm"].build_norm_layer
+        ops.ContextBlock = ops.GeneralizedAttention = None
     if "mmdet.ops.conv_module" in sys.modules:
         ops.ConvModule = sys.modules["mmdet.ops.conv_module"].ConvModule
     if "mmdet.ops.scale" in sys.modules:
@@ -206,6 +226,7 @@ def mmdet_tree(root=M, tag="M"):
     focal._sigmoid_focal_loss = _sfl
     iou = load("mmdet.models.losses.iou_loss", os.path.join(p, "models/losses/iou_loss.py"))
     ce = load("mmdet.models.losses.cross_entropy_loss", os.path.join(p, "models/losses/cross_entropy_loss.py"))
+    load("mmdet.models.losses.mse_loss", os.path.join(p, "models/losses/mse_loss.py"))
 
     def build_loss(cfg):
         cfg = dict(cfg)
@@ -217,8 +238,15 @@ def mmdet_tree(root=M, tag="M"):
          Scale=getattr(ops, "Scale", None), build_norm_layer=None, build_conv_layer=None)
     stub("mmdet.models.anchor_heads")
     head = load("mmdet.models.anchor_heads.sipmask_head", os.path.join(p, "models/anchor_heads/sipmask_head.py"))
+    # backbone and neck (M/ only): ResNet needs mmcv.runner.load_checkpoint and mmdet.utils.get_root_logger at import time
+    stub("mmcv.runner", load_checkpoint=None)
+    stub("mmdet.utils", get_root_logger=None)
+    stub("mmdet.models.backbones")
+    stub("mmdet.models.necks")
+    resnet = load("mmdet.models.backbones.resnet", os.path.join(p, "models/backbones/resnet.py"))
+    fpn = load("mmdet.models.necks.fpn", os.path.join(p, "models/necks/fpn.py"))
     return types.SimpleNamespace(geometry=geometry, transforms=transforms, bbox_nms=bbox_nms, focal=focal, iou=iou, ce=ce,
-                                 head=head, build_loss=build_loss, tag=tag)
+                                 head=head, build_loss=build_loss, resnet=resnet, fpn=fpn, tag=tag)
 
 
 def mmdet_tree_vis(root=V):

@@ -265,3 +265,45 @@ def test_benchmark_postprocessor_matches_reference(ref, tag, ori_wh):
         assert int((r["mask"].numpy() != want).sum()) == 0
         n += want.shape[0]
     assert n > 50
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# backbone and neck (M/mmdet/models/backbones/resnet.py, M/mmdet/models/necks/fpn.py)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,dcn", [("J_backbone", None), ("J_backbone_dcn", (False, True, True, True))])
+def test_backbone_and_fpn_match_reference(ref, tag, dcn):
+    """ResNet-50 caffe (frozen BN, eval) plain / with DeformConvPack in stages 2-4, and the SipMask FPN
+    (start_level=1, extra convs on outputs, relu before the extra convs)"""
+    full = OM.init_state_dict(50, 0, stage_with_dcn=dcn) if dcn else OM.init_state_dict(50, 0)
+    tmpl = {k[len("backbone."):]: v for k, v in full.items() if k.startswith("backbone.")}
+    sd = {"backbone." + k: v for k, v in FX.trunk_state_dict(tmpl).items()}
+    ntmpl = {k[len("neck."):]: v for k, v in full.items() if k.startswith("neck.")}
+    sd.update({"neck." + k: v for k, v in FX.trunk_state_dict(ntmpl, seed=900).items()})
+    img = FX.texact(601, (1, 3, 64, 96), -2 ** 11, 2 ** 11, 2.0 ** -10)
+    with torch.no_grad():
+        feats = OM.backbone_forward(sd, img, 50)
+        for i, f in enumerate(feats):
+            _check_summary(ref, "%s.c%d" % (tag, i + 2), f)
+        if dcn is None:
+            for i, f in enumerate(OM.fpn_forward(sd, feats)):
+                _check_summary(ref, "J_fpn.p%d" % (i + 3), f)
+
+
+def test_mask_rescoring_matches_reference(ref):
+    """SipMask++ rescoring inside get_bboxes_single (sipmask_head.py:635-643) on the SSD-style head: six stride-2
+    ConvModules + mask_scoring on every cropped probability mask, class channel, times the box score"""
+    tmpl = {k: v for k, v in OM.init_state_dict(50, 0, num_classes=NUM_CLASSES, stacked_convs=2, norm=False,
+                                                rescoring=True).items() if k.startswith("bbox_head.")}
+    sd = {"bbox_head." + k: v for k, v in FX.head_state_dict({k[len("bbox_head."):]: v for k, v in tmpl.items()}).items()}
+    big = [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)]
+    cls, box, ctr, cof, fm = FX.head_outputs(25, 1, NUM_CLASSES - 1, sizes=big)
+    sf = np.array([1.25, 1.5, 1.25, 1.5], np.float32)
+    r = OM.get_masks_single([c[0] for c in cls], [x[0] for x in box], [c[0] for c in ctr], [c[0] for c in cof], fm[0],
+                            (256, 256, 3), CFG, scale_factor=sf, rescale=True, ssd_flag=True)
+    np.testing.assert_array_equal(r["det_labels"], ref["B_rescoring.lab0"])
+    np.testing.assert_allclose(r["det_bboxes"], ref["B_rescoring.det0"], rtol=1e-5, atol=1e-5)
+    with torch.no_grad():
+        ms = OM.mask_rescoring(sd, r["pos_masks"], r["det_labels"], r["det_bboxes"][:, 4])
+    want = ref["B_rescoring.mask_scores0"]
+    assert want.shape[0] > 20 and float(np.abs(want).max()) > 0
+    np.testing.assert_allclose(ms.numpy(), want, rtol=1e-4, atol=1e-6 * float(np.abs(want).max()))
