@@ -108,7 +108,7 @@ def mask_loss_single(feat_mask, cof_pred, bbox_dt, gt_mask_new, idx_gt, weightin
 
 def head_loss(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, gt_bboxes, gt_labels, gt_masks_list,
               strides=FPN_STRIDES, regress_ranges=REGRESS_RANGES, center_sampling=True, radius=1.5,
-              gamma=2.0, alpha=0.25):
+              gamma=2.0, alpha=0.25, stride_norm=True):
     """SipMaskHead.loss, sipmask_head.py:289-498 (rescoring_flag=False), default loss configs
     (FocalLoss gamma 2 alpha .25, IoULoss, sigmoid CrossEntropyLoss; all loss_weight 1)."""
     sizes = [tuple(c.shape[-2:]) for c in cls_scores]
@@ -136,8 +136,11 @@ def head_loss(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, gt_bb
     if num_pos > 0:
         p_tgt = f_tgt[pos]
         ctr_t = centerness_target(p_tgt)
-        dec_p = _d2b(f_pts[pos], p_box / f_str[pos])
-        dec_t = _d2b(f_pts[pos], p_tgt / f_str[pos])
+        # M/ decodes stride-normalised distances (:372-375); the VIS head decodes them in pixels (V/...:409-411) -- with
+        # the +1 IoU convention the two give different losses
+        div = f_str[pos] if stride_norm else 1.0
+        dec_p = _d2b(f_pts[pos], p_box / div)
+        dec_t = _d2b(f_pts[pos], p_tgt / div)
         iou_l = -_aligned_iou(dec_p, dec_t).clamp(min=1e-6).log()
         loss_bbox = (iou_l * ctr_t).sum() / ctr_t.sum()
         loss_ctr = F.binary_cross_entropy_with_logits(p_ctr, ctr_t, reduction="none").mean()

@@ -35,6 +35,7 @@ class FeatureAlign(nn.Module):
 
 @HEADS.register_module
 class SipMaskHead(nn.Module):
+    bbox_loss_stride_norm = True      # loss_bbox on stride-normalised boxes (M/ sipmask_head.py:372-375)
 
     def __init__(self, num_classes, in_channels, feat_channels=256, stacked_convs=4, strides=(4, 8, 16, 32, 64),
                  regress_ranges=((-1, 64), (64, 128), (128, 256), (256, 512), (512, INF)), center_sampling=False,
@@ -250,8 +251,11 @@ class SipMaskHead(nn.Module):
         if num_pos > 0:
             p_tgt = f_tgt[pos]
             ctr_t = T.centerness_target(p_tgt)
-            dec_p = T.distance2bbox(f_pts[pos], p_box / f_str[pos])
-            dec_t = T.distance2bbox(f_pts[pos], p_tgt / f_str[pos])
+            # M/ :372-375 decodes stride-normalised distances; the VIS head (V/...:409-411) decodes pixels: with the
+            # +1 IoU convention that is a different loss, so the subclass switches it off
+            div = f_str[pos] if self.bbox_loss_stride_norm else 1.0
+            dec_p = T.distance2bbox(f_pts[pos], p_box / div)
+            dec_t = T.distance2bbox(f_pts[pos], p_tgt / div)
             loss_bbox = self.loss_bbox(dec_p, dec_t, weight=ctr_t, avg_factor=ctr_t.sum())   # :379-383
             loss_centerness = self.loss_centerness(p_ctr, ctr_t)
         else:

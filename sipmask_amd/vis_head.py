@@ -21,6 +21,7 @@ from .sipmask_head import SipMaskHead
 @HEADS.register_module
 class SipMaskVISHead(SipMaskHead):
     """V/mmdet/models/anchor_heads/sipmask_head.py:122-172 (constructor: no ssd/rescoring flags, match_coeff :165)."""
+    bbox_loss_stride_norm = False     # V/...:409-411 decodes the positive boxes in pixels for loss_bbox
 
     def __init__(self, num_classes, in_channels, **kwargs):
         kwargs.pop('ssd_flag', None)

@@ -169,6 +169,38 @@ def vis_sections():
         OUT[case + ".memory_boxes"] = head.prev_bboxes.numpy().astype(np.float32)
         OUT[case + ".memory_labels"] = head.prev_det_labels.numpy().astype(np.int64)
 
+    # loss with the matching term (V/...:320-541).  The reference jitters the reference-frame boxes with
+    # Tensor.uniform_ from the global RNG (:470-473): record what it drew, the oracle takes the jitter as an input.
+    cls, box, ctr, cof, fm = FX.head_outputs(111, 2, VIS_CLASSES - 1)
+    box = [torch.cat([b[:, :2], b[:, :2]], 1) for b in box]    # l = r, t = b: predicted centres stay on the track map
+    cof = [c * 0.25 for c in cof]
+    gtb, gtl, gtm = FX.ground_truth(112, 2, VIS_CLASSES - 1)
+    tf = FX.texact(113, (2, 512, H // 8, W // 8), -2 ** 9, 2 ** 9, 2.0 ** -10)
+    tfr = FX.texact(114, (2, 512, H // 8, W // 8), -2 ** 9, 2 ** 9, 2.0 ** -10)
+    refb = [b + 2.0 for b in gtb]
+    pids = [torch.from_numpy(np.random.RandomState(115 + i).randint(0, len(b) + 1, size=len(b)).astype(np.int64))
+            for i, b in enumerate(gtb)]
+    drawn = []
+    orig_uniform = torch.Tensor.uniform_
+
+    def recording_uniform(self, *a, **k):
+        r = orig_uniform(self, *a, **k)
+        drawn.append(r.clone().numpy())
+        return r
+
+    torch.Tensor.uniform_ = recording_uniform
+    torch.manual_seed(7)
+    try:
+        losses = head.loss(cls, box, ctr, cof, fm * 0.25, tf, tfr, gtb, gtl, [dict(img_shape=(H, W, 3))] * 2, None,
+                           gt_masks_list=gtm, ref_bboxes_list=refb, gt_pids_list=pids)
+    finally:
+        torch.Tensor.uniform_ = orig_uniform
+    for k, v in losses.items():
+        OUT["K_vis_loss.%s" % k] = np.float64(float(v))
+    assert len(drawn) == 2
+    for i, d in enumerate(drawn):
+        OUT["K_vis_loss.jitter%d" % i] = d.astype(np.float32)
+
 
 def benchmark_sections():
     """maskrcnn-benchmark variant (B/fcos_core/modeling/rpn/sipmask): head forward in eval mode (sipmask.py:145-190),

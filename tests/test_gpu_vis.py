@@ -207,7 +207,7 @@ def test_vis_training_losses_vs_oracle():
     osd = {"bbox_head." + k: v.clone() for k, v in sd.items()}
     oout = OM.head_forward(osd, feats)
     otf, otr = OV.track_forward(osd, feats), OV.track_forward(osd, feats_x)
-    oloss, aux = OL.head_loss(oout[0], oout[1], oout[2], oout[3], oout[4], gtb, gtl, gtm)
+    oloss, aux = OL.head_loss(oout[0], oout[1], oout[2], oout[3], oout[4], gtb, gtl, gtm, stride_norm=False)   # V/...:409-411
     omatch = OV.track_loss(otf, otr, aux["mask_aux"], refb, pids, jit)
     # ---- HIP
     out = head([f.cuda() for f in feats], [f.cuda() for f in feats_x], True)

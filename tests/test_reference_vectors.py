@@ -307,3 +307,26 @@ def test_mask_rescoring_matches_reference(ref):
     want = ref["B_rescoring.mask_scores0"]
     assert want.shape[0] > 20 and float(np.abs(want).max()) > 0
     np.testing.assert_allclose(ms.numpy(), want, rtol=1e-4, atol=1e-6 * float(np.abs(want).max()))
+
+
+def test_vis_loss_with_matching_term_matches_reference(ref):
+    """V/ SipMaskHead.loss (:320-541): the M/ terms plus loss_match over jittered reference-frame boxes (the jitter the
+    reference drew from torch's global RNG is part of the fixture)"""
+    from oracle import vis as OV
+    H, W = FX.IMG_HW
+    cls, box, ctr, cof, fm = FX.head_outputs(111, 2, VIS_CLASSES - 1)
+    box = [torch.cat([b[:, :2], b[:, :2]], 1) for b in box]
+    cof = [c * 0.25 for c in cof]
+    gtb, gtl, gtm = FX.ground_truth(112, 2, VIS_CLASSES - 1)
+    tf = FX.texact(113, (2, 512, H // 8, W // 8), -2 ** 9, 2 ** 9, 2.0 ** -10)
+    tfr = FX.texact(114, (2, 512, H // 8, W // 8), -2 ** 9, 2 ** 9, 2.0 ** -10)
+    refb = [b + 2.0 for b in gtb]
+    pids = [torch.from_numpy(np.random.RandomState(115 + i).randint(0, len(b) + 1, size=len(b)).astype(np.int64))
+            for i, b in enumerate(gtb)]
+    jitter = [torch.from_numpy(ref["K_vis_loss.jitter%d" % i]) for i in range(2)]
+    losses, aux = OL.head_loss(cls, box, ctr, cof, fm * 0.25, gtb, gtl, gtm, center_sampling=True, stride_norm=False)
+    for k in ("loss_cls", "loss_bbox", "loss_centerness", "loss_mask"):
+        np.testing.assert_allclose(float(losses[k]), float(ref["K_vis_loss.%s" % k]), rtol=2e-5, err_msg=k)
+    lm = OV.track_loss(tf, tfr, aux["mask_aux"], refb, pids, jitter)
+    assert float(ref["K_vis_loss.loss_match"]) > 0
+    np.testing.assert_allclose(float(lm), float(ref["K_vis_loss.loss_match"]), rtol=2e-5)
