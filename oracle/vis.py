@@ -7,7 +7,7 @@
   frame-to-frame matching                  :565-684 (compute_comp_scores :544-562)
 Pinning: no reference test, but track_forward, get_masks_single_vis, extract_box_feature_center and Tracker reproduce
 the VIS head's own forward / get_bboxes over a 4-frame clip run in the build container (tests/golden/ref_vectors.npz
-sections F_ / G_: detections, object ids, memory and every mask pixel).  track_loss stays parity unpinned.
+sections F_ / G_: detections, object ids, memory and every mask pixel), track_loss its loss_match (section K_).
 """
 import numpy as np
 import torch
