@@ -88,7 +88,7 @@ def prepare_gt_masks(gt_masks, hm, wm):
     return out.gt(0.5).float()
 
 
-def mask_loss_single(feat_mask, cof_pred, bbox_dt, gt_mask_new, idx_gt, weighting):
+def mask_loss_single(feat_mask, cof_pred, bbox_dt, gt_mask_new, idx_gt, weighting, return_pred=False):
     """:438-461 for one image.  feat_mask [32,Hm,Wm], cof_pred [N,128], bbox_dt [N,4] (basis-grid boxes),
     gt_mask_new [G,Hm,Wm], idx_gt [N], weighting [N] -> scalar."""
     hm, wm = feat_mask.shape[1:]
@@ -103,12 +103,14 @@ def mask_loss_single(feat_mask, cof_pred, bbox_dt, gt_mask_new, idx_gt, weightin
     w = bbox_dt[:, 2] - bbox_dt[:, 0]
     h = bbox_dt[:, 3] - bbox_dt[:, 1]
     pre = pre / w / h / n
+    if return_pred:
+        return torch.sum(pre * weighting.detach()), pre, pred
     return torch.sum(pre * weighting.detach()), pre
 
 
 def head_loss(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, gt_bboxes, gt_labels, gt_masks_list,
               strides=FPN_STRIDES, regress_ranges=REGRESS_RANGES, center_sampling=True, radius=1.5,
-              gamma=2.0, alpha=0.25, stride_norm=True):
+              gamma=2.0, alpha=0.25, stride_norm=True, rescoring_sd=None):
     """SipMaskHead.loss, sipmask_head.py:289-498 (rescoring_flag=False), default loss configs
     (FocalLoss gamma 2 alpha .25, IoULoss, sigmoid CrossEntropyLoss; all loss_weight 1)."""
     sizes = [tuple(c.shape[-2:]) for c in cls_scores]
@@ -150,6 +152,7 @@ def head_loss(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, gt_bb
     img_cls = torch.cat([c.permute(0, 2, 3, 1).reshape(num_imgs, -1, C) for c in cls_scores], 1)
     img_cof = torch.cat([c.permute(0, 2, 3, 1).reshape(num_imgs, -1, 128) for c in cof_preds], 1)
     loss_mask = 0
+    loss_iou, num_iou = 0, 0.1                                                    # :411-413
     aux = []
     for i in range(num_imgs):
         labels, targets, idx_gt = per_img[i]
@@ -171,9 +174,25 @@ def head_loss(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, gt_bb
             wgt = wgt / (wgt.sum() + 0.0001) * len(wgt)
         hm, wm = feat_masks[i].shape[1:]
         gtm = prepare_gt_masks(gt_masks_list[i][:gt_labels[i].shape[0]], hm, wm)
-        li, pre = mask_loss_single(feat_masks[i], cof, bdt, gtm, idx, wgt)
+        li, pre, pred = mask_loss_single(feat_masks[i], cof, bdt, gtm, idx, wgt, return_pred=True)
         loss_mask = loss_mask + li
         aux.append(dict(pos_inds=pi[keep], bbox_dt=bdt, idx_gt=idx, weighting=wgt, pre_loss=pre, gt_mask=gtm))
+        if rescoring_sd is not None:                                              # SipMask++ rescoring loss (:463-483)
+            from .model import mask_rescoring
+            pm = pred.detach().permute(2, 0, 1)                                   # [N,Hm,Wm] cropped probabilities
+            pos_labels = labels[pi[keep]] - 1
+            pred_iou = mask_rescoring(rescoring_sd, pm, pos_labels, torch.ones(pm.shape[0]))
+            with torch.no_grad():
+                gsel = gtm[idx]                                                   # UNcropped gt masks of the positives
+                mp = (pm > 0.4).float()
+                inter = (mp * gsel).sum((1, 2))
+                gt_area = gsel.sum((1, 2))
+                iou_t = inter / (mp.sum((1, 2)) + gt_area - inter + 0.1)
+                iou_w = ((iou_t > 0.1) & (iou_t <= 1.0) & (gt_area >= 100)).float()
+            loss_iou = loss_iou + (((pred_iou - iou_t) ** 2) * iou_w).sum()      # MSELoss(reduction='sum') with weights
+            num_iou = num_iou + iou_w.sum()
     loss_mask = loss_mask / num_imgs
-    return dict(loss_cls=loss_cls, loss_bbox=loss_bbox, loss_centerness=loss_ctr, loss_mask=loss_mask), \
-        dict(labels=f_lab, bbox_targets=f_tgt, per_img=per_img, mask_aux=aux, num_pos=num_pos)
+    out = dict(loss_cls=loss_cls, loss_bbox=loss_bbox, loss_centerness=loss_ctr, loss_mask=loss_mask)
+    if rescoring_sd is not None:
+        out["loss_iou"] = loss_iou * 10 / num_iou
+    return out, dict(labels=f_lab, bbox_targets=f_tgt, per_img=per_img, mask_aux=aux, num_pos=num_pos)

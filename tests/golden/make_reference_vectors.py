@@ -328,6 +328,17 @@ def main():
             OUT["%s.gt_inds%d" % (tag, b)] = gt_inds[b].numpy().astype(np.int64)
         OUT[tag + ".points"] = torch.cat(pts).numpy().astype(np.float32)
 
+    # ---- C2: SipMask++ loss with the rescoring term loss_iou (:463-491), SSD-style head, 128x128 basis map
+    head = build_head(ns, stacked_convs=2, norm=False, ssd_flag=True, rescoring=True)
+    big = [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)]
+    cls, box, ctr, cof, fm = FX.head_outputs(35, 2, NUM_CLASSES - 1, sizes=big)
+    cof = [c * 0.25 for c in cof]
+    gtb, gtl, gtm = FX.ground_truth(36, 2, NUM_CLASSES - 1, img_hw=(256, 256), max_gt=4)
+    gtb = [b * 1.0 for b in gtb]
+    losses = head.loss(cls, box, ctr, cof, fm * 0.25, gtb, gtl, [dict(img_shape=(256, 256, 3))] * 2, None, gt_masks_list=gtm)
+    for k, v in losses.items():
+        OUT["C_loss_rescoring.%s" % k] = np.float64(float(v))
+
     # ---- D: small functions
     head = build_head(ns)
     a = torch.from_numpy(np.concatenate([FX.exact(41, (40, 2), 0, 2 ** 11, 2.0 ** -4),

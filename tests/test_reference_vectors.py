@@ -330,3 +330,20 @@ def test_vis_loss_with_matching_term_matches_reference(ref):
     lm = OV.track_loss(tf, tfr, aux["mask_aux"], refb, pids, jitter)
     assert float(ref["K_vis_loss.loss_match"]) > 0
     np.testing.assert_allclose(float(lm), float(ref["K_vis_loss.loss_match"]), rtol=2e-5)
+
+
+def test_loss_with_rescoring_term_matches_reference(ref):
+    """SipMask++ training: SipMaskHead.loss with rescoring_flag (sipmask_head.py:463-491) -- loss_iou = weighted squared
+    error between the rescoring branch's prediction on the cropped masks and the mask IoU with the (uncropped) gt"""
+    tmpl = {k[len("bbox_head."):]: v for k, v in OM.init_state_dict(50, 0, num_classes=NUM_CLASSES, stacked_convs=2, norm=False,
+                                                                    rescoring=True).items() if k.startswith("bbox_head.")}
+    sd = {"bbox_head." + k: v for k, v in FX.head_state_dict(tmpl).items()}
+    big = [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)]
+    cls, box, ctr, cof, fm = FX.head_outputs(35, 2, NUM_CLASSES - 1, sizes=big)
+    cof = [c * 0.25 for c in cof]
+    gtb, gtl, gtm = FX.ground_truth(36, 2, NUM_CLASSES - 1, img_hw=(256, 256), max_gt=4)
+    with torch.no_grad():
+        losses, _ = OL.head_loss(cls, box, ctr, cof, fm * 0.25, gtb, gtl, gtm, rescoring_sd=sd)
+    assert float(ref["C_loss_rescoring.loss_iou"]) > 0
+    for k in ("loss_cls", "loss_bbox", "loss_centerness", "loss_mask", "loss_iou"):
+        np.testing.assert_allclose(float(losses[k]), float(ref["C_loss_rescoring.%s" % k]), rtol=5e-5, err_msg=k)
