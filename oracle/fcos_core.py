@@ -3,8 +3,8 @@
 Restates B/fcos_core/modeling/rpn/sipmask/sipmask.py:142-190 (head forward, test mode), inference.py:66-236
 (SipMaskPostProcessor), B/fcos_core/csrc/cuda/ml_nms.cu (same-label greedy NMS, IoU with +1) on B/-named parameters.
 Pinning: no reference test, but head_forward and postprocess_single reproduce B/'s own SipMaskHead.forward (eval) and
-SipMaskPostProcessor.forward run in the build container (tests/golden/ref_vectors.npz sections H_ / I_; stand-ins for
-_C.ml_nms, DeformConv, CropSplit: tests/golden/ref_loader.py).
+SipMaskPostProcessor.forward run in the build container, and loss() its SipMaskLossComputation (tests/golden/
+ref_vectors.npz sections H_ / I_ / L_; stand-ins for _C.ml_nms / _C.nms, DeformConv, CropSplit: tests/golden/ref_loader.py).
 """
 import numpy as np
 import torch
@@ -145,3 +145,90 @@ def postprocess_single(logits, bbox_reg, ctrs, cofs, feat_mask, image_size, ori_
         canvas[:, :hh, :ww] = masks[:, :hh, :ww]
         out.update(mask=canvas, up=up)
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# training loss of the variant (SipMaskLossComputation, B/fcos_core/modeling/rpn/sipmask/loss.py:109-487)
+# ----------------------------------------------------------------------------------------------------------------
+def focal_loss_sum(logits, labels, gamma=2.0, alpha=0.25):
+    """SigmoidFocalLoss.forward -> .sum(), B/fcos_core/layers/sigmoid_focal_loss.py:40-69 (the python formula; labels are
+    1-based, 0 = background)"""
+    C = logits.shape[1]
+    cls = torch.arange(1, C + 1, dtype=labels.dtype).unsqueeze(0)
+    t = labels.unsqueeze(1)
+    p = torch.sigmoid(logits)
+    term1 = (1 - p) ** gamma * torch.log(p)
+    term2 = p ** gamma * torch.log(1 - p)
+    return (-(t == cls).float() * term1 * alpha - ((t != cls) * (t >= 0)).float() * term2 * (1 - alpha)).sum()
+
+
+def giou_loss_sum(pred, target, weight):
+    """IOULoss('giou'), B/fcos_core/layers/iou_loss.py:8-53, on (l, t, r, b) distances"""
+    pa = (pred[:, 0] + pred[:, 2]) * (pred[:, 1] + pred[:, 3])
+    ta = (target[:, 0] + target[:, 2]) * (target[:, 1] + target[:, 3])
+    wi = torch.min(pred[:, 0], target[:, 0]) + torch.min(pred[:, 2], target[:, 2])
+    hi = torch.min(pred[:, 3], target[:, 3]) + torch.min(pred[:, 1], target[:, 1])
+    gw = torch.max(pred[:, 0], target[:, 0]) + torch.max(pred[:, 2], target[:, 2])
+    gh = torch.max(pred[:, 3], target[:, 3]) + torch.max(pred[:, 1], target[:, 1])
+    ac = gw * gh + 1e-7
+    inter = wi * hi
+    union = ta + pa - inter
+    ious = (inter + 1.0) / (union + 1.0)
+    losses = 1 - (ious - (ac - union) / ac)
+    return (losses * weight).sum() if weight.sum() > 0 else losses.sum()
+
+
+def loss(logits, bbox_reg, ctrs, cofs, feat_masks, gt_bboxes, gt_labels, gt_masks_list, strides=FPN_STRIDES,
+         radius=1.5, gamma=2.0, alpha=0.25):
+    """SipMaskLossComputation.__call__ (:330-487) with the yaml's settings: NORM_REG_TARGETS (bbox_reg are the
+    TRAINING-mode outputs relu(scale * conv), regression targets divided by the level stride), center sampling 1.5,
+    GIoU.  Returns dict(loss_cls, loss_reg, loss_centerness, loss_mask) and the per-level labels."""
+    from .loss import fcos_target_single, centerness_target, prepare_gt_masks, mask_loss_single, _aligned_iou, REGRESS_RANGES
+    sizes = [tuple(c.shape[-2:]) for c in logits]
+    points = get_points(sizes, strides)
+    nums = [p.shape[0] for p in points]
+    N, C = logits[0].shape[0], logits[0].shape[1]
+    cat_points = torch.cat(points)
+    cat_rr = torch.cat([points[i].new_tensor(REGRESS_RANGES[i])[None].expand_as(points[i]) for i in range(len(points))])
+    per_img = [fcos_target_single(gt_bboxes[i], gt_labels[i], cat_points, cat_rr, nums, strides, True, radius) for i in range(N)]
+    flat = lambda ts, c: torch.cat([t.permute(0, 2, 3, 1).reshape(-1, c) for t in ts])
+    f_cls, f_reg, f_ctr = flat(logits, C), flat(bbox_reg, 4), flat(ctrs, 1).reshape(-1)
+    f_lab = torch.cat([torch.cat([per_img[i][0].split(nums)[l] for i in range(N)]) for l in range(len(nums))])
+    f_tgt = torch.cat([torch.cat([per_img[i][1].split(nums)[l] for i in range(N)]) / strides[l] for l in range(len(nums))])
+    pos = (f_lab > 0).nonzero().squeeze(1)
+    num_pos = max(float(pos.numel()), 1.0)
+    loss_cls = focal_loss_sum(f_cls, f_lab, gamma, alpha) / num_pos
+    if pos.numel() > 0:
+        ct = centerness_target(f_tgt[pos])
+        loss_reg = giou_loss_sum(f_reg[pos], f_tgt[pos], ct) / ct.sum()
+        loss_ctr = F.binary_cross_entropy_with_logits(f_ctr[pos], ct, reduction="sum") / num_pos
+    else:
+        loss_reg, loss_ctr = f_reg[pos].sum(), f_ctr[pos].sum()
+    img_cls = torch.cat([c.permute(0, 2, 3, 1).reshape(N, -1, C) for c in logits], 1)
+    img_cof = torch.cat([c.permute(0, 2, 3, 1).reshape(N, -1, 128) for c in cofs], 1)
+    loss_mask = 0
+    for i in range(N):
+        labels, _, idx_gt = per_img[i]
+        d = torch.cat([bbox_reg[l][i].permute(1, 2, 0).reshape(-1, 4).detach() * strides[l] for l in range(len(points))])
+        boxes = torch.stack([cat_points[:, 0] - d[:, 0], cat_points[:, 1] - d[:, 1],
+                             cat_points[:, 0] + d[:, 2], cat_points[:, 1] + d[:, 3]], 1) / 2
+        pi = (labels > 0).nonzero().view(-1)
+        bdt, cof = boxes[pi], img_cof[i][pi]
+        area = (bdt[:, 2] - bdt[:, 0]) * (bdt[:, 3] - bdt[:, 1])
+        keep = area > 1.0
+        bdt, idx, cof = bdt[keep], idx_gt[keep], cof[keep]
+        if bdt.shape[0] == 0:
+            continue
+        score = img_cls[i, pi, labels[pi] - 1].sigmoid().detach()[keep]
+        wgt = score * _aligned_iou(gt_bboxes[i][idx] / 2, bdt)
+        wgt = wgt / wgt.sum() * len(wgt)                                             # no epsilon here (:452)
+        k = torch.from_numpy(np.asarray(ops.nms(torch.cat([bdt, score[:, None]], 1).numpy(), 0.9, mode="gpu"), np.int64))  # :453
+        bdt, wgt, idx, cof = bdt[k], wgt[k], idx[k], cof[k]
+        hm, wm = feat_masks[i].shape[1:]
+        gtm = prepare_gt_masks(gt_masks_list[i], hm, wm)
+        li, _ = mask_loss_single(feat_masks[i], cof, bdt, gtm, idx, wgt)
+        loss_mask = loss_mask + li
+    loss_mask = loss_mask / N
+    if float(loss_mask) > 1.0:                                                        # :483-484
+        loss_mask = loss_mask * 0.5
+    return dict(loss_cls=loss_cls, loss_reg=loss_reg, loss_centerness=loss_ctr, loss_mask=loss_mask), f_lab

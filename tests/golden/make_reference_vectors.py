@@ -251,6 +251,34 @@ def benchmark_sections():
         OUT[tag + ".mask_hw"] = np.asarray([ori_wh[1], ori_wh[0]], np.int64)
     torch.Tensor.sigmoid = _sig
 
+    # training loss of the variant (loss.py:330-487).  The CPU branch of SigmoidFocalLoss indexes gamma[0] / alpha[0]
+    # (sigmoid_focal_loss.py:43-44), so the cfg carries them as one-element lists; targets are BoxLists whose "masks"
+    # field only has to offer get_mask_tensor() (the real SegmentationMask needs cv2 / pycocotools).
+    cfg = R.fcos_cfg(num_classes=NUM_CLASSES, LOSS_GAMMA=[2.0], LOSS_ALPHA=[0.25])
+    R.STAND_INS["fcos_core SegmentationMask"] = "absent deps: a holder with get_mask_tensor() returning the uint8 masks"
+    evaluator = ns.loss.SipMaskLossComputation(cfg)
+    cls, box, ctr, cof, fm = FX.head_outputs(97, 2, NUM_CLASSES - 1)
+    box = [b / s for b, s in zip(box, FX.STRIDES)]             # training mode: stride-normalised distances
+    cof = [c * 0.25 for c in cof]
+    gtb, gtl, gtm = FX.ground_truth(98, 2, NUM_CLASSES - 1)
+
+    class _Masks:
+        def __init__(self, m):
+            self.m = torch.from_numpy(m)
+
+        def get_mask_tensor(self):
+            return self.m
+
+    targets = []
+    for b in range(2):
+        bl = ns.BoxList(gtb[b], (W, H), mode="xyxy")
+        bl.add_field("labels", gtl[b])
+        bl.add_field("masks", _Masks(gtm[b]))
+        targets.append(bl)
+    lc, lr, lct, lm = evaluator(locations, cls, box, ctr, cof, fm * 0.25, targets)
+    for k, v in (("loss_cls", lc), ("loss_reg", lr), ("loss_centerness", lct), ("loss_mask", lm)):
+        OUT["L_b_loss.%s" % k] = np.float64(float(v))
+
 
 def main():
     torch.manual_seed(0)

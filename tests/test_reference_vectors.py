@@ -347,3 +347,42 @@ def test_loss_with_rescoring_term_matches_reference(ref):
     assert float(ref["C_loss_rescoring.loss_iou"]) > 0
     for k in ("loss_cls", "loss_bbox", "loss_centerness", "loss_mask", "loss_iou"):
         np.testing.assert_allclose(float(losses[k]), float(ref["C_loss_rescoring.%s" % k]), rtol=5e-5, err_msg=k)
+
+
+def test_benchmark_loss_matches_reference(ref):
+    """SipMaskLossComputation.__call__, B/...loss.py:330-487 (targets with center sampling, focal / GIoU / centerness
+    terms normalised as in the yaml config, mask loss with the 0.9 NMS filter and the halving above 1.0)"""
+    from oracle import fcos_core as OB
+    cls, box, ctr, cof, fm = FX.head_outputs(97, 2, NUM_CLASSES - 1)
+    box = [b / s for b, s in zip(box, FX.STRIDES)]
+    cof = [c * 0.25 for c in cof]
+    gtb, gtl, gtm = FX.ground_truth(98, 2, NUM_CLASSES - 1)
+    losses, labels = OB.loss(cls, box, ctr, cof, fm * 0.25, gtb, gtl, gtm)
+    assert int((labels > 0).sum()) > 10
+    for k in ("loss_cls", "loss_reg", "loss_centerness", "loss_mask"):
+        np.testing.assert_allclose(float(losses[k]), float(ref["L_b_loss.%s" % k]), rtol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("tag,cs", [("C_loss_cs", True), ("C_loss_nocs", False)])
+def test_product_target_assignment_matches_reference(ref, tag, cs):
+    """the PRODUCT's host-side target code (sipmask_amd/targets.py, pure torch, runs without a GPU) against the
+    reference's fcos_target / get_points / centerness_target / distance2bbox outputs directly"""
+    from sipmask_amd import targets as T
+    cls = FX.head_outputs(31, 2, NUM_CLASSES - 1)[0]
+    gtb, gtl, _ = FX.ground_truth(32, 2, NUM_CLASSES - 1)
+    sizes = [tuple(c.shape[-2:]) for c in cls]
+    pts = T.level_points(sizes, FX.STRIDES)
+    np.testing.assert_array_equal(torch.cat(pts).numpy(), ref[tag + ".points"])
+    lab_lvl, tgt_lvl, lab_img, tgt_img, gt_inds = T.fcos_target(pts, FX.STRIDES, OL.REGRESS_RANGES, gtb, gtl, cs, 1.5)
+    np.testing.assert_array_equal(torch.cat(lab_lvl).numpy(), ref[tag + ".labels"])
+    np.testing.assert_array_equal(torch.cat(tgt_lvl).numpy(), ref[tag + ".bbox_targets"])
+    for b in range(2):
+        np.testing.assert_array_equal(gt_inds[b].numpy(), ref["%s.gt_inds%d" % (tag, b)])
+    t = torch.from_numpy(FX.exact(47, (50, 4), 1, 2 ** 10, 2.0 ** -4))
+    np.testing.assert_allclose(T.centerness_target(t).numpy(), ref["D_centerness_target"], rtol=1e-6)
+    p = torch.from_numpy(FX.exact(45, (64, 2), 0, 2 ** 11, 2.0 ** -4))
+    d = torch.from_numpy(FX.exact(46, (64, 4), -64, 2 ** 11, 2.0 ** -4))
+    np.testing.assert_array_equal(T.distance2bbox(p, d).numpy(), ref["D_distance2bbox.plain"])
+    np.testing.assert_array_equal(T.distance2bbox(p, d, max_shape=(96, 128, 3)).numpy(), ref["D_distance2bbox.clamped"])
+    a, b = _boxes(41, 42, 40), _boxes(43, 44, 40)
+    np.testing.assert_allclose(T.aligned_iou(a, b).numpy(), ref["D_overlaps.aligned"], rtol=1e-6, atol=1e-7)
