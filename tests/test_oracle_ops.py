@@ -211,3 +211,39 @@ def test_rle_restatement_round_trip():
     assert ops.rle_from_string(ops.rle_to_string(c)) == c
     r = ops.paste_and_encode(np.ones((4, 6), np.uint8), (3, 8))
     assert r["size"] == [3, 8] and ops.rle_from_string(r["counts"]) == [0, 18, 6]
+
+
+def _ref_nms_cpu():
+    """the reference's own C++ CPU NMS (M/mmdet/ops/nms/src/nms_cpu.cpp), built by oracle/build_ref.py into oracle/_ref/"""
+    import glob
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = glob.glob(os.path.join(here, "oracle", "_ref", "ref_nms_cpu*.so"))
+    if not so:
+        pytest.skip("oracle/_ref not built (python oracle/build_ref.py; needs /root/reference)")
+    import torch  # noqa: F401  (libtorch must be loaded before the extension)
+    spec = importlib.util.spec_from_file_location("ref_nms_cpu", so[0])
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_oracle_cpu_nms_equals_the_compiled_reference_extension(kat):
+    """oracle.ops.nms(mode="cpu") against the reference's compiled nms_cpu.cpp: random boxes at several thresholds
+    (incl. exact-threshold overlaps: the CPU rule is `IoU >= thr`), and the reference's golden cases"""
+    import torch
+    ref = _ref_nms_cpu()
+    rng = np.random.RandomState(3)
+    for n, thr in ((1, 0.5), (17, 0.3), (300, 0.5), (300, 0.7), (1200, 0.45)):
+        xy = rng.randint(0, 200, (n, 2)).astype(np.float32)
+        wh = rng.randint(4, 60, (n, 2)).astype(np.float32)
+        sc = (rng.permutation(4096)[:n].astype(np.float32) + 1) / 4097.0           # no score ties
+        dets = np.concatenate([xy, xy + wh, sc[:, None]], 1).astype(np.float32)
+        want = ref.nms(torch.from_numpy(dets), float(thr)).numpy()                   # kept indices, increasing
+        got = np.sort(np.asarray(ops.nms(dets, thr, mode="cpu")))
+        np.testing.assert_array_equal(got, want)
+    # two boxes overlapping at exactly IoU 0.5 (+1 convention): suppressed by the CPU rule, kept by the GPU rule
+    d = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 19, 0.8]], np.float32)
+    assert ref.nms(torch.from_numpy(d), 0.5).numpy().tolist() == [0]
+    assert sorted(ops.nms(d, 0.5, mode="cpu")) == [0] and sorted(ops.nms(d, 0.5, mode="gpu")) == [0, 1]
