@@ -27,6 +27,24 @@ def test_library_exports_every_declared_symbol():
     assert [lib.sm_conv_cout_tile(c) for c in (5, 32, 33, 64, 65, 208, 2048)] == [32, 32, 64, 64, 128, 128, 128]
 
 
+def test_ctypes_prototypes_match_header_arities():
+    """every entry point: the number (and pointer/scalar kind) of arguments bound in _lib.PROTOTYPES equals the header's"""
+    from sipmask_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "sipmask_hip.h")).read(), flags=re.S)
+    decls = list(re.finditer(r"\b(sm_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S))
+    assert len(decls) == len(_lib.PROTOTYPES)
+    for m in decls:
+        name, args = m.group(1), m.group(2).strip()
+        params = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        bound = _lib.PROTOTYPES[name][1]
+        assert len(params) == len(bound), (name, len(params), len(bound))
+        for prm, ct in zip(params, bound):
+            is_ptr = "*" in prm or prm.split()[0] == "sm_stream_t"
+            ct_ptr = ct is ctypes.c_void_p or ct is ctypes.c_char_p or hasattr(ct, "contents")
+            assert is_ptr == ct_ptr, (name, prm, ct)
+
+
 def test_struct_layout_matches_header():
     """ctypes mirrors of sm_conv_desc / sm_det_desc must have the C sizes (gcc, same ABI)."""
     import subprocess, tempfile
