@@ -202,3 +202,39 @@ def test_ops_fail_loudly_without_gpu():
         from sipmask_amd.engine import SipMaskEngine
         with pytest.raises(RuntimeError):
             SipMaskEngine(OM.init_state_dict(50, 0), 1, (64, 64))
+
+
+@pytest.mark.parametrize("variant,nconv", [("r50", 73), ("ssd", 69), ("vis", 74), ("benchmark", 73), ("dcn", 74)])
+def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nconv):
+    """The static launch plan is host logic: tools/plan_dump.py builds the engine of every front-end variant on the CPU
+    (nothing is launched) and asks sm_conv_plan_query for each prepared conv descriptor."""
+    import importlib.util
+    from sipmask_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libsipmask_hip.so not built (run __graft_entry__.build())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("plan_dump", os.path.join(root, "tools", "plan_dump.py"))
+    pd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pd)
+    avail = torch.cuda.is_available
+    eng = pd.build_on_cpu(variant, batch=2, hw=(256, 320))
+    assert torch.cuda.is_available is avail                       # the patch is undone
+    rows = {r["name"]: r for r in pd.conv_rows(eng)}
+    assert len(rows) == nconv == len(eng.convs)
+    assert all(r["plan"]["blocks"] > 0 and 0 < r["fill"] <= 1 for r in rows.values())
+    assert len(eng.steps) == len(eng.lanes)
+    joined = set()
+    for lane in eng.lanes:                                           # every side lane that is used gets joined
+        if isinstance(lane, tuple):
+            joined.update(lane[1:])
+    assert {l for l in eng.lanes if isinstance(l, int) and l > 0} <= joined
+    fa = rows["head.feat_align"]["plan"]
+    assert fa["lds_dma"] == 0 and fa["k_step"] == 64                # deformable gather: register-staged loader
+    assert rows["fpn.p7"]["plan"]["lds_dma"] == 0                   # input ReLU (fpn.py:174-175)
+    tower = rows["head.reg_convs.0"]["plan"]
+    assert (tower["k_step"], tower["k_loop"]) == (64, 3)
+    if variant == "dcn":
+        assert sum(1 for n in rows if n.endswith("conv2.conv_offset")) == 5
+        assert all(rows[n[:-len(".conv_offset")]]["plan"]["lds_dma"] == 0 for n in rows if n.endswith("conv2.conv_offset"))
+    if variant == "vis":
+        assert "head.sipmask_track" in rows or any(n.startswith("head.track") for n in rows)
