@@ -228,6 +228,26 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
         if isinstance(lane, tuple):
             joined.update(lane[1:])
     assert {l for l in eng.lanes if isinstance(l, int) and l > 0} <= joined
+    # every descriptor stays inside the buffers it was prepared for (rows per level, channel strides, weight matrix)
+    for c in eng.convs:
+        d = c.desc
+        K = d.kh * d.kw * d.cin
+        assert tuple(c.w.shape) == (d.cout_pad, (K + 63) // 64 * 64), c.name
+        assert c.x.dim() == 2 and c.y.dim() == 2 and d.in_cstride <= c.x.shape[1] and d.cin <= d.in_cstride, c.name
+        assert d.out_coff + d.cout <= d.out_cstride <= c.y.shape[1], c.name
+        for l in range(d.nlev):
+            assert d.in_row0[l] + d.batch * d.in_h[l] * d.in_w[l] <= c.x.shape[0], (c.name, l)
+            assert d.out_row0[l] + d.batch * d.out_h[l] * d.out_w[l] <= c.y.shape[0], (c.name, l)
+            if c.residual is not None and (d.flags & 8):            # SM_CONV_RES_NEAREST
+                assert d.res_row0[l] + d.batch * d.res_h[l] * d.res_w[l] <= c.residual.shape[0], (c.name, l)
+            elif c.residual is not None:
+                assert d.out_row0[l] + d.batch * d.out_h[l] * d.out_w[l] <= c.residual.shape[0] and \
+                    d.res_cstride <= c.residual.shape[1], (c.name, l)
+        if c.offset is not None:
+            rows_out = sum(d.batch * d.out_h[l] * d.out_w[l] for l in range(d.nlev))
+            assert c.offset.numel() >= rows_out * d.deform_groups * d.kh * d.kw * 2, c.name
+        if c.bias is not None:
+            assert c.bias.numel() >= d.cout, c.name
     fa = rows["head.feat_align"]["plan"]
     assert fa["lds_dma"] == 0 and fa["k_step"] == 64                # deformable gather: register-staged loader
     assert rows["fpn.p7"]["plan"]["lds_dma"] == 0                   # input ReLU (fpn.py:174-175)
