@@ -57,7 +57,10 @@ def conv_rows(eng):
         per_cu = 1 if p["threads"] == 512 else (4 if p["k_step"] == 32 else 2)
         slots = 256 * per_cu
         rounds = -(-p["blocks"] // slots)
-        rows.append(dict(name=c.name, plan=p, gflop=c.flops / 1e9, mb=c.bytes / 1e6, fill=p["blocks"] / (rounds * slots)))
+        # fill = how full the rounds of resident blocks are; with several blocks per CU the leftover blocks of a
+        # barely started round run alone and faster, so a low fill costs less than its face value (waves = blocks/slots)
+        rows.append(dict(name=c.name, plan=p, gflop=c.flops / 1e9, mb=c.bytes / 1e6, fill=p["blocks"] / (rounds * slots),
+                         waves=p["blocks"] / slots))
     return rows
 
 
@@ -72,16 +75,16 @@ def main():
     rows = {r["name"]: r for r in conv_rows(eng)}
     print("# %s, batch %d, %dx%d: %d steps, %d conv launches, %.1f conv GFLOP per step" % (
         args.variant, args.batch, args.hw[0], args.hw[1], len(eng.steps), len(eng.convs), sum(r["gflop"] for r in rows.values())))
-    print("# lane | step | tile (cout x pos) | K step | loop | blocks | fill of the rounds of resident blocks | GFLOP | algorithmic MB")
+    print("# lane | step | tile (cout x pos) | K step | loop | blocks | blocks / resident slots (256 CUs x 1, 2 or 4) | GFLOP | algorithmic MB")
     for (label, _), lane in zip(eng.steps, eng.lanes):
         ln = "join " + ",".join(str(x) for x in lane[1:]) if isinstance(lane, tuple) else str(lane)
         if label.startswith("conv:"):
             r = rows[label[5:]]
             p = r["plan"]
-            print("%-8s %-34s %3dx%-3d K%-2d %-9s %6d  %3.0f %%  %8.2f %8.1f" % (
+            print("%-8s %-34s %3dx%-3d K%-2d %-9s %6d  %5.2f  %8.2f %8.1f" % (
                 ln, label, p["tile_cout"], p["tile_pos"], p["k_step"],
                 {0: "legacy", 1: "flat", 3: "pipelined"}[p["k_loop"]] if p["lds_dma"] else "reg-stage", p["blocks"],
-                100 * r["fill"], r["gflop"], r["mb"]))
+                r["waves"], r["gflop"], r["mb"]))
         elif label != "join":
             print("%-8s %s" % (ln, label))
         else:
