@@ -4,6 +4,9 @@ mmdetection tree (M/mmdet/ops/nms/src/nms_cpu.cpp: one C++ file against the torc
 oracle/_ref/ (git-ignored); the sources are compiled from where they lie under /root/reference, nothing is copied.
 TEST INFRASTRUCTURE ONLY: tests/test_oracle_ops.py uses it (when present) to check oracle.ops.nms(mode="cpu").
 Everything else compiled in the reference is CUDA (nvcc, PyTorch-1.1 THC API) and cannot be built here.
+NEVER pass a reference .cu file to torch.utils.cpp_extension.load(): on a ROCm build it hipifies IN PLACE, i.e. writes
+*_hip_kernel.hip next to the source inside the read-only /root/reference tree.  Plain .cpp sources are compiled from
+where they lie and only oracle/_ref/ is written.
 
     python oracle/build_ref.py            # no-op when /root/reference is absent (GPU box)
 """

@@ -18,6 +18,10 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+# /root/reference is read-only by contract.  Executing its source files through importlib would otherwise drop
+# __pycache__/*.pyc next to them (root bypasses the mount's permission bits); this switch must precede every load().
+sys.dont_write_bytecode = True
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import ops as O  # noqa: E402
