@@ -57,6 +57,7 @@ typedef enum {
 #define SM_CONV_DBG_FLAT_LOOP 0x00200000u    /* A/B switch: flat LDS-DMA loader + peeled K loop WITHOUT the pipelined fragment reads of the default loop */
 #define SM_CONV_DBG_LEGACY_LOOP 0x00100000u  /* A/B switch: the original K loop (branchy loader, one fragment register set) on the 128/64-cout tiles */
 #define SM_CONV_DBG_K32_OPT 0x00080000u      /* A/B switch: flat loader + peeled loop + pipelined fragment reads in the 32-wide-K kernel (cin >= 32) */
+#define SM_CONV_DBG_HAND_PLACED 0x00040000u  /* A/B switch (with TILE256): hand-placed K step, LDS-DMA pieces between the MFMAs */
 #define SM_CONV_DBG_WARP_SPEC 0x02000000u    /* A/B switch: 8-wave producer/consumer variant of the 64-wide-K kernel */
 
 /* One (multi-level) 2-D convolution as an implicit GEMM.  Replaces the ATen/cuDNN

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   static_assert(WCO * WPOS == 4 || (WCO * WPOS == 8 && !PROD), "4 waves, or 8 without the producer split");
   static_assert(NW <= 8 && NX <= 8, "Stage8 holds 8 chunks");
   static_assert(OPT == 0 || (DMA && !PROD), "OPT variants exist for the plain LDS-DMA loop only");
-  static_assert(WCO * WPOS == 4 || OPT == 3, "the 8-wave tile is built on the flat, pipelined loop");
+  static_assert(WCO * WPOS == 4 || (OPT & 3) == 3, "the 8-wave tile is built on the flat, pipelined loop");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   const int gtid = threadIdx.x;                       // 0..THREADS-1 (epilogue work split)
@@ -517,7 +517,78 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
       ld_kw -= wrap2 * a.kw;
       ld_kh += wrap2;
     };
-    if constexpr (FLAT_LOOP) {
+    // OPT bit 2 (experiment): the K step written out with every instruction placed by hand -- MFMA m of sub-step kk is
+    // followed by fragment read m of kk+1 and, in the first two sub-steps, by one LDS-DMA piece of the NEXT tile every
+    // DMA_EVERY MFMAs; sched_barrier(0) after each slot pins the order.  The address VALU of a piece then runs in the
+    // shadow of the MFMA issued just before it instead of in front of the whole K step (where, in the 8-wave tile,
+    // both waves of a SIMD do it at the same time with the matrix pipe idle).
+    constexpr bool HAND_PLACED = (OPT & 4) != 0;
+    auto k_step_placed = [&](int buf, bool with_dma) {
+      const unsigned char* S = smem + buf * STAGE;
+      unsigned char* Wb = smem + (buf ^ 1) * STAGE + wave_row_s * 128;
+      unsigned char* Xb = Wb + BCO * 128;
+      constexpr int NFR = TCO + TPOS, NMF = TCO * TPOS, NP = NW + NX;
+      constexpr int DMA_EVERY = (2 * NMF) / NP > 0 ? (2 * NMF) / NP : 1;
+      static_assert(!HAND_PLACED || NFR <= NMF, "one fragment read per MFMA slot");
+      bf16x8 wf[2][TCO], xf[2][TPOS];
+      const bool kvalid = ld_kc < a.nchunk;
+      const int dh = ld_kh * a.dil, dw = ld_kw * a.dil;
+      const long long toff = (long long)((dh * W + dw) * a.in_cstride + ld_cc * 8);
+      auto rd1 = [&](int kk, int set, int f) {                       // fragment f of sub-step kk -> register set
+        const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
+        if (f < TCO) wf[set][f] = *reinterpret_cast<const bf16x8*>(S + wrow_off + f * 32 * 128 + slot);
+        else xf[set][f - TCO] = *reinterpret_cast<const bf16x8*>(S + xrow_off + (f - TCO) * 32 * 128 + slot);
+      };
+      static_for<NFR>([&](auto F) { rd1(0, 0, decltype(F)::value); });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<4>([&](auto KK) {
+        constexpr int kk = decltype(KK)::value;
+        static_for<NMF>([&](auto MM) {
+          constexpr int m = decltype(MM)::value;
+          constexpr int tc = m / TPOS, tp = m % TPOS;
+          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][tc], xf[kk & 1][tp], acc[tc][tp], 0, 0, 0);
+          if constexpr (kk < 3 && m < NFR) rd1(kk + 1, (kk + 1) & 1, m);
+          constexpr int slot_idx = kk * NMF + m;
+          if constexpr (kk < 2 && (slot_idx % DMA_EVERY) == DMA_EVERY - 1 && slot_idx / DMA_EVERY < NP) {
+            constexpr int pc = slot_idx / DMA_EVERY;
+            if (with_dma) {                                           // block-uniform: false in the peeled last K step only
+              if constexpr (pc < NW) {
+                __builtin_amdgcn_global_load_lds((glb_void*)(ld_wp + pc * wstride), (lds_void*)(Wb + LROWS * pc * 128), 16, 0, 0);
+              } else {
+                constexpr int i = pc - NW;
+                const int hi = rhi[i] + dh, wi = rwi[i] + dw;
+                const bool ok = kvalid & ((unsigned)hi < (unsigned)H) & ((unsigned)wi < (unsigned)W);
+                const unsigned long long pm = ok ? ~0ull : 0ull;
+                const unsigned long long src = ((unsigned long long)(a.x + xoff[i] + toff) & pm) | (zero_page & ~pm);
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Xb + LROWS * i * 128), 16, 0, 0);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      if (with_dma) {
+        ld_kc += 8;
+        ld_wp += 64;
+        ld_cc += 8;
+        const int wrap = ld_cc >= a.cpt ? 1 : 0;
+        ld_cc -= wrap * a.cpt;
+        ld_kw += wrap;
+        const int wrap2 = ld_kw == a.kw ? 1 : 0;
+        ld_kw -= wrap2 * a.kw;
+        ld_kh += wrap2;
+      }
+    };
+    if constexpr (HAND_PLACED) {
+      dma_tile_flat(0);
+      __syncthreads();
+      for (int kt = 0; kt + 1 < nk; ++kt) {
+        k_step_placed(kt & 1, true);
+        __syncthreads();
+      }
+      k_step_placed((nk - 1) & 1, false);
+      if constexpr (!REG_ONLY) __syncthreads();
+    } else if constexpr (FLAT_LOOP) {
       dma_tile_flat(0);
       __syncthreads();
       for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -1576,6 +1647,7 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else if (ws && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 1>));
     else if (ws && bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true, 1>));
     else if (ws) return SM_ERR_UNSUPPORTED;
+    else if (bco == 256 && (d->flags & SM_CONV_DBG_HAND_PLACED)) { block = dim3(512); SM_LAUNCH((conv_igemm_kernel<2, 4, 4, 2, false, true, 0, 7>)); }
     else if (bco == 256) { block = dim3(512); SM_LAUNCH((conv_igemm_kernel<2, 4, 4, 2, false, true, 0, 3>)); }
     else if (opt == 3 && bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 0, 3>));
     else if (opt == 3 && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 0, 3>));
