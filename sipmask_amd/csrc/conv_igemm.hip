@@ -1649,6 +1649,7 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else if (ws) return SM_ERR_UNSUPPORTED;
     else if (bco == 256 && (d->flags & SM_CONV_DBG_HAND_PLACED)) { block = dim3(512); SM_LAUNCH((conv_igemm_kernel<2, 4, 4, 2, false, true, 0, 7>)); }
     else if (bco == 256) { block = dim3(512); SM_LAUNCH((conv_igemm_kernel<2, 4, 4, 2, false, true, 0, 3>)); }
+    else if (opt == 3 && bco == 128 && bpos == 128 && (d->flags & SM_CONV_DBG_HAND_PLACED)) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 0, 7>));
     else if (opt == 3 && bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 0, 3>));
     else if (opt == 3 && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 0, 3>));
     else if (opt == 3 && bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true, 0, 3>));

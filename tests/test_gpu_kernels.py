@@ -86,7 +86,7 @@ def test_conv_igemm_vs_torch(cfg):
                                      0x08200000, 0x08100000, 0x0c100000,    # flat K loop without fragment pipeline / legacy K loop
                                      0x0c400000, 0x09200000,                # 256x256 8-wave tiles (forced); flat loop + LDS epilogue
                                      0x10080000, 0x14080000, 0x11080000,    # 32-wide-K kernel with the flat/pipelined loop
-                                     0x0c440000])                           # 256x256 tiles with the hand-placed K step
+                                     0x0c440000, 0x08040000])               # hand-placed K step: 256x256 tiles / 128x128 tiles
 def test_conv_loader_variants(variant):
     """The A/B loader variants (register staging 0x2..., forced 32-wide K steps 0x1..., forced 64-wide
     0x08...) must give the same
