@@ -27,6 +27,24 @@ def test_library_exports_every_declared_symbol():
     assert [lib.sm_conv_cout_tile(c) for c in (5, 32, 33, 64, 65, 208, 2048)] == [32, 32, 64, 64, 128, 128, 128]
 
 
+def test_ctypes_prototypes_match_header_arities():
+    """every entry point: the number (and pointer/scalar kind) of arguments bound in _lib.PROTOTYPES equals the header's"""
+    from sipmask_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "sipmask_hip.h")).read(), flags=re.S)
+    decls = list(re.finditer(r"\b(sm_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S))
+    assert len(decls) == len(_lib.PROTOTYPES)
+    for m in decls:
+        name, args = m.group(1), m.group(2).strip()
+        params = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        bound = _lib.PROTOTYPES[name][1]
+        assert len(params) == len(bound), (name, len(params), len(bound))
+        for prm, ct in zip(params, bound):
+            is_ptr = "*" in prm or prm.split()[0] == "sm_stream_t"
+            ct_ptr = ct is ctypes.c_void_p or ct is ctypes.c_char_p or hasattr(ct, "contents")
+            assert is_ptr == ct_ptr, (name, prm, ct)
+
+
 def test_struct_layout_matches_header():
     """ctypes mirrors of sm_conv_desc / sm_det_desc must have the C sizes (gcc, same ABI)."""
     import subprocess, tempfile
@@ -184,3 +202,59 @@ def test_ops_fail_loudly_without_gpu():
         from sipmask_amd.engine import SipMaskEngine
         with pytest.raises(RuntimeError):
             SipMaskEngine(OM.init_state_dict(50, 0), 1, (64, 64))
+
+
+@pytest.mark.parametrize("variant,nconv", [("r50", 73), ("ssd", 69), ("vis", 74), ("benchmark", 73), ("dcn", 74)])
+def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nconv):
+    """The static launch plan is host logic: tools/plan_dump.py builds the engine of every front-end variant on the CPU
+    (nothing is launched) and asks sm_conv_plan_query for each prepared conv descriptor."""
+    import importlib.util
+    from sipmask_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libsipmask_hip.so not built (run __graft_entry__.build())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("plan_dump", os.path.join(root, "tools", "plan_dump.py"))
+    pd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pd)
+    avail = torch.cuda.is_available
+    eng = pd.build_on_cpu(variant, batch=2, hw=(256, 320))
+    assert torch.cuda.is_available is avail                       # the patch is undone
+    rows = {r["name"]: r for r in pd.conv_rows(eng)}
+    assert len(rows) == nconv == len(eng.convs)
+    assert all(r["plan"]["blocks"] > 0 and 0 < r["fill"] <= 1 for r in rows.values())
+    assert len(eng.steps) == len(eng.lanes)
+    joined = set()
+    for lane in eng.lanes:                                           # every side lane that is used gets joined
+        if isinstance(lane, tuple):
+            joined.update(lane[1:])
+    assert {l for l in eng.lanes if isinstance(l, int) and l > 0} <= joined
+    # every descriptor stays inside the buffers it was prepared for (rows per level, channel strides, weight matrix)
+    for c in eng.convs:
+        d = c.desc
+        K = d.kh * d.kw * d.cin
+        assert tuple(c.w.shape) == (d.cout_pad, (K + 63) // 64 * 64), c.name
+        assert c.x.dim() == 2 and c.y.dim() == 2 and d.in_cstride <= c.x.shape[1] and d.cin <= d.in_cstride, c.name
+        assert d.out_coff + d.cout <= d.out_cstride <= c.y.shape[1], c.name
+        for l in range(d.nlev):
+            assert d.in_row0[l] + d.batch * d.in_h[l] * d.in_w[l] <= c.x.shape[0], (c.name, l)
+            assert d.out_row0[l] + d.batch * d.out_h[l] * d.out_w[l] <= c.y.shape[0], (c.name, l)
+            if c.residual is not None and (d.flags & 8):            # SM_CONV_RES_NEAREST
+                assert d.res_row0[l] + d.batch * d.res_h[l] * d.res_w[l] <= c.residual.shape[0], (c.name, l)
+            elif c.residual is not None:
+                assert d.out_row0[l] + d.batch * d.out_h[l] * d.out_w[l] <= c.residual.shape[0] and \
+                    d.res_cstride <= c.residual.shape[1], (c.name, l)
+        if c.offset is not None:
+            rows_out = sum(d.batch * d.out_h[l] * d.out_w[l] for l in range(d.nlev))
+            assert c.offset.numel() >= rows_out * d.deform_groups * d.kh * d.kw * 2, c.name
+        if c.bias is not None:
+            assert c.bias.numel() >= d.cout, c.name
+    fa = rows["head.feat_align"]["plan"]
+    assert fa["lds_dma"] == 0 and fa["k_step"] == 64                # deformable gather: register-staged loader
+    assert rows["fpn.p7"]["plan"]["lds_dma"] == 0                   # input ReLU (fpn.py:174-175)
+    tower = rows["head.reg_convs.0"]["plan"]
+    assert (tower["k_step"], tower["k_loop"]) == (64, 3)
+    if variant == "dcn":
+        assert sum(1 for n in rows if n.endswith("conv2.conv_offset")) == 5
+        assert all(rows[n[:-len(".conv_offset")]]["plan"]["lds_dma"] == 0 for n in rows if n.endswith("conv2.conv_offset"))
+    if variant == "vis":
+        assert "head.sipmask_track" in rows or any(n.startswith("head.track") for n in rows)
