@@ -101,7 +101,7 @@ def main():
 
     if args.tower_only:
         eng.run(img)
-        tower = [c for c in eng.convs if c.name.startswith("head.cls_convs")][0]
+        tower = [c for c in eng.convs if c.name.startswith("head.cls_convs") or c.name.startswith("head.tower")][0]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
             tower()
@@ -167,6 +167,9 @@ def main():
         if label.startswith("conv:"):
             conv_ms[label[5:]] = ms
     towers = [c for c in eng.convs if c.name.startswith("head.cls_convs") or c.name.startswith("head.reg_convs")]
+    grouped = [c for c in eng.convs if c.name.startswith("head.tower")]      # SIPMASK_GROUPED_TOWERS=1: cls+reg per launch
+    if grouped:
+        towers = grouped
     tower_ms = sum(conv_ms[c.name] for c in towers) / len(towers)
     tower_flops = towers[0].flops
     all_conv_ms = sum(v for v in conv_ms.values())

@@ -57,6 +57,7 @@ typedef enum {
 #define SM_CONV_DBG_FLAT_LOOP 0x00200000u    /* A/B switch: flat LDS-DMA loader + peeled K loop WITHOUT the pipelined fragment reads of the default loop */
 #define SM_CONV_DBG_LEGACY_LOOP 0x00100000u  /* A/B switch: the original K loop (branchy loader, one fragment register set) on the 128/64-cout tiles */
 #define SM_CONV_DBG_K32_OPT 0x00080000u      /* A/B switch: flat loader + peeled loop + pipelined fragment reads in the 32-wide-K kernel (cin >= 32) */
+#define SM_CONV_DBG_HAND_PLACED 0x00040000u  /* A/B switch (with TILE256): hand-placed K step, LDS-DMA pieces between the MFMAs */
 #define SM_CONV_DBG_WARP_SPEC 0x02000000u    /* A/B switch: 8-wave producer/consumer variant of the 64-wide-K kernel */
 
 /* One (multi-level) 2-D convolution as an implicit GEMM.  Replaces the ATen/cuDNN
@@ -86,6 +87,13 @@ typedef struct {
   int64_t w_batch_stride;         /* elements between the weight matrices of consecutive images; 0 = one shared
                                    * weight (every convolution).  != 0 turns the launch into `batch` independent
                                    * GEMMs (split-K weight gradients); needs out_h*out_w % position tile == 0 */
+  /* group dimension (64-wide-K LDS-DMA convs only): `ngroups` > 1 runs that many problems of identical shape in ONE
+   * launch -- e.g. the cls and reg tower convs of one depth (sipmask_head.py:252-257), which otherwise are two
+   * 1404-block launches.  Group g reads x rows shifted by g*x_group_rows (0 = all groups share the input), writes y
+   * rows (and reads a RES_ADD residual) shifted by g*y_group_rows, uses weights at w + g*w_group_stride elements,
+   * bias at g*bias_group_stride floats and GroupNorm statistics at g*gn_group_stride floats.  0 or 1 = no groups. */
+  int32_t ngroups;
+  int64_t x_group_rows, y_group_rows, w_group_stride, bias_group_stride, gn_group_stride;
 } sm_conv_desc;
 
 int sm_version(void);

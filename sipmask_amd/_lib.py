@@ -38,6 +38,8 @@ class ConvDesc(C.Structure):
         ("res_h", _i32x5), ("res_w", _i32x5), ("res_row0", _i64x5),
         ("flags", C.c_uint32), ("scale_nch", C.c_int32), ("level_scale", _f32x5),
         ("deform_groups", C.c_int32), ("w_batch_stride", C.c_int64),
+        ("ngroups", C.c_int32), ("x_group_rows", C.c_int64), ("y_group_rows", C.c_int64), ("w_group_stride", C.c_int64),
+        ("bias_group_stride", C.c_int64), ("gn_group_stride", C.c_int64),
     ]
 
 

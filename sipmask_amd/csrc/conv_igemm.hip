@@ -40,6 +40,11 @@ struct ConvKArgs {
   int dg, cpg8;  // deform groups, chunks (of 8 ch) per deform group
   float* gn_stats;  // optional fused GroupNorm statistics [batch][nlev][cout/8][2] (sum, sum of squares)
   long long w_bstride;  // elements between the weight matrices of consecutive images (0 = shared): batched / split-K GEMMs
+  // group dimension (64-wide-K LDS-DMA kernel only): ngroups problems of identical shape in one launch, e.g. the cls
+  // and reg tower convs of one depth.  Tiles [g*tpg, (g+1)*tpg) belong to group g; its operands sit at fixed offsets.
+  int ngroups, tpg;
+  long long x_grows, y_grows;        // rows between the groups' inputs (0 = shared) / outputs (and RES_ADD residuals)
+  long long w_gstride, b_gstride, gn_gstride;   // elements between the groups' weights / biases / GN statistics
 };
 
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   static_assert(WCO * WPOS == 4 || (WCO * WPOS == 8 && !PROD), "4 waves, or 8 without the producer split");
   static_assert(NW <= 8 && NX <= 8, "Stage8 holds 8 chunks");
   static_assert(OPT == 0 || (DMA && !PROD), "OPT variants exist for the plain LDS-DMA loop only");
-  static_assert(WCO * WPOS == 4 || OPT == 3, "the 8-wave tile is built on the flat, pipelined loop");
+  static_assert(WCO * WPOS == 4 || (OPT & 3) == 3, "the 8-wave tile is built on the flat, pipelined loop");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   const int gtid = threadIdx.x;                       // 0..THREADS-1 (epilogue work split)
@@ -136,8 +141,13 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   const int tlin = (a.flags & SM_CONV_DBG_LINEAR_TILES)
                        ? (int)blockIdx.x
                        : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)(blockIdx.x >> 3);
-  const int nt = tlin % a.ntn;
-  const int mt = tlin / a.ntn;
+  // group decode (wave-uniform): which problem instance this tile belongs to
+  const int grp = a.ngroups > 1 ? tlin / a.tpg : 0;
+  const int tl_g = tlin - grp * a.tpg;
+  const int nt = tl_g % a.ntn;
+  const int mt = tl_g / a.ntn;
+  const float* const biasp = a.bias != nullptr ? a.bias + grp * a.b_gstride : nullptr;
+  float* const gnp = a.gn_stats != nullptr ? a.gn_stats + grp * a.gn_gstride : nullptr;
   int lev = 0;
 #pragma unroll
   for (int l = 1; l < SM_MAX_LEVELS; ++l)
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   const int HoWo = Ho * Wo;
   const int M = a.batch * HoWo;
   const int m0 = (mt - a.tile0[lev]) * BPOS;
-  const long long in_row0 = a.in_row0[lev];
+  const long long in_row0 = a.in_row0[lev] + grp * a.x_grows;
 
   // ---- per-row gather bases (rows r0 + 32*i of the activation tile)
   int rbase[NX], rhi[NX], rwi[NX];
@@ -175,7 +185,8 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
     if (rbase[i] < 0) rhi[i] = -0x40000000;
     xoff[i] = (in_row0 + (rbase[i] < 0 ? 0 : rbase[i]) + (long long)rhi[i] * W + rwi[i]) * a.in_cstride;
   }
-  const uint16_t* wrow = a.w + (long long)(nt * BCO + r0) * a.Kp + j * 8 + (a.w_bstride != 0 ? (long long)(m0 / HoWo) * a.w_bstride : 0ll);
+  const uint16_t* wrow = a.w + grp * a.w_gstride + (long long)(nt * BCO + r0) * a.Kp + j * 8 +
+                         (a.w_bstride != 0 ? (long long)(m0 / HoWo) * a.w_bstride : 0ll);
   const long long wstride = (long long)LROWS * a.Kp;
   // loader K state (this thread's 16-byte chunk j of the current K step), advanced incrementally:
   // no integer division inside the K loop when a tap holds >= 8 chunks (every layer but the stem)
@@ -506,7 +517,78 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
       ld_kw -= wrap2 * a.kw;
       ld_kh += wrap2;
     };
-    if constexpr (FLAT_LOOP) {
+    // OPT bit 2 (experiment): the K step written out with every instruction placed by hand -- MFMA m of sub-step kk is
+    // followed by fragment read m of kk+1 and, in the first two sub-steps, by one LDS-DMA piece of the NEXT tile every
+    // DMA_EVERY MFMAs; sched_barrier(0) after each slot pins the order.  The address VALU of a piece then runs in the
+    // shadow of the MFMA issued just before it instead of in front of the whole K step (where, in the 8-wave tile,
+    // both waves of a SIMD do it at the same time with the matrix pipe idle).
+    constexpr bool HAND_PLACED = (OPT & 4) != 0;
+    auto k_step_placed = [&](int buf, bool with_dma) {
+      const unsigned char* S = smem + buf * STAGE;
+      unsigned char* Wb = smem + (buf ^ 1) * STAGE + wave_row_s * 128;
+      unsigned char* Xb = Wb + BCO * 128;
+      constexpr int NFR = TCO + TPOS, NMF = TCO * TPOS, NP = NW + NX;
+      constexpr int DMA_EVERY = (2 * NMF) / NP > 0 ? (2 * NMF) / NP : 1;
+      static_assert(!HAND_PLACED || NFR <= NMF, "one fragment read per MFMA slot");
+      bf16x8 wf[2][TCO], xf[2][TPOS];
+      const bool kvalid = ld_kc < a.nchunk;
+      const int dh = ld_kh * a.dil, dw = ld_kw * a.dil;
+      const long long toff = (long long)((dh * W + dw) * a.in_cstride + ld_cc * 8);
+      auto rd1 = [&](int kk, int set, int f) {                       // fragment f of sub-step kk -> register set
+        const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
+        if (f < TCO) wf[set][f] = *reinterpret_cast<const bf16x8*>(S + wrow_off + f * 32 * 128 + slot);
+        else xf[set][f - TCO] = *reinterpret_cast<const bf16x8*>(S + xrow_off + (f - TCO) * 32 * 128 + slot);
+      };
+      static_for<NFR>([&](auto F) { rd1(0, 0, decltype(F)::value); });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<4>([&](auto KK) {
+        constexpr int kk = decltype(KK)::value;
+        static_for<NMF>([&](auto MM) {
+          constexpr int m = decltype(MM)::value;
+          constexpr int tc = m / TPOS, tp = m % TPOS;
+          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][tc], xf[kk & 1][tp], acc[tc][tp], 0, 0, 0);
+          if constexpr (kk < 3 && m < NFR) rd1(kk + 1, (kk + 1) & 1, m);
+          constexpr int slot_idx = kk * NMF + m;
+          if constexpr (kk < 2 && (slot_idx % DMA_EVERY) == DMA_EVERY - 1 && slot_idx / DMA_EVERY < NP) {
+            constexpr int pc = slot_idx / DMA_EVERY;
+            if (with_dma) {                                           // block-uniform: false in the peeled last K step only
+              if constexpr (pc < NW) {
+                __builtin_amdgcn_global_load_lds((glb_void*)(ld_wp + pc * wstride), (lds_void*)(Wb + LROWS * pc * 128), 16, 0, 0);
+              } else {
+                constexpr int i = pc - NW;
+                const int hi = rhi[i] + dh, wi = rwi[i] + dw;
+                const bool ok = kvalid & ((unsigned)hi < (unsigned)H) & ((unsigned)wi < (unsigned)W);
+                const unsigned long long pm = ok ? ~0ull : 0ull;
+                const unsigned long long src = ((unsigned long long)(a.x + xoff[i] + toff) & pm) | (zero_page & ~pm);
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Xb + LROWS * i * 128), 16, 0, 0);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      if (with_dma) {
+        ld_kc += 8;
+        ld_wp += 64;
+        ld_cc += 8;
+        const int wrap = ld_cc >= a.cpt ? 1 : 0;
+        ld_cc -= wrap * a.cpt;
+        ld_kw += wrap;
+        const int wrap2 = ld_kw == a.kw ? 1 : 0;
+        ld_kw -= wrap2 * a.kw;
+        ld_kh += wrap2;
+      }
+    };
+    if constexpr (HAND_PLACED) {
+      dma_tile_flat(0);
+      __syncthreads();
+      for (int kt = 0; kt + 1 < nk; ++kt) {
+        k_step_placed(kt & 1, true);
+        __syncthreads();
+      }
+      k_step_placed((nk - 1) & 1, false);
+      if constexpr (!REG_ONLY) __syncthreads();
+    } else if constexpr (FLAT_LOOP) {
       dma_tile_flat(0);
       __syncthreads();
       for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -609,11 +691,11 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   // position (8-byte pieces scattered over 32 rows per store); staging through LDS turns the
   // stores (and the residual loads) into full 128-byte lines.
   const float lscale = a.level_scale[lev];
-  const long long out_row0 = a.out_row0[lev];
+  const long long out_row0 = a.out_row0[lev] + grp * a.y_grows;
   const bool out_f32 = a.flags & SM_CONV_OUT_F32;
   float* E = reinterpret_cast<float*>(smem);
   float* gn_bins = reinterpret_cast<float*>(smem + SMEM_MAIN);   // [GN_SEG][BCO/8][2]
-  if (a.gn_stats != nullptr && gtid < GN_SEG * (BCO / 8) * 2) gn_bins[gtid] = 0.f;
+  if (gnp != nullptr && gtid < GN_SEG * (BCO / 8) * 2) gn_bins[gtid] = 0.f;
   // ---- register epilogue (same scheme as conv_dma32_kernel: v_permlane32_swap -> 8 consecutive couts per lane ->
   // 16-byte loads/stores, no LDS round trip).  GroupNorm statistics: after the swap a lane's 8 couts are exactly
   // one 8-channel group, so (sum, sum of squares) reduce over the 32 positions of the half-wave with shuffles and
@@ -622,7 +704,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   const bool reg_epi = !PROD && !(a.flags & SM_CONV_DBG_LDS_EPILOGUE) && (a.cout & 7) == 0 && (a.out_cstride & 7) == 0 &&
                        (a.out_coff & 7) == 0 && (!has_res0 || (a.res_cstride & 7) == 0);
   if (reg_epi) {
-    const bool gn = a.gn_stats != nullptr;
+    const bool gn = gnp != nullptr;
     const int gn_groups = a.cout >> 3;
     const int gn_n0 = m0 / HoWo;
     if (gn) __syncthreads();                       // bins zeroed
@@ -665,9 +747,9 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
           const int c0 = nt * BCO + cl;
           const bool live = mvalid && c0 < a.cout;
           if (live) {
-            if (a.bias != nullptr) {
-              const float4 b0 = *reinterpret_cast<const float4*>(a.bias + c0);
-              const float4 b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 4);
+            if (biasp != nullptr) {
+              const float4 b0 = *reinterpret_cast<const float4*>(biasp + c0);
+              const float4 b1 = *reinterpret_cast<const float4*>(biasp + c0 + 4);
               v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w;
               v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
             }
@@ -704,7 +786,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
                   atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 0], gs);
                   atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 1], gss);
                 } else {
-                  float* st = a.gn_stats + (((long long)n_first * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
+                  float* st = gnp + (((long long)n_first * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
                   atomicAdd(st, gs);
                   atomicAdd(st + 1, gss);
                 }
@@ -715,7 +797,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
                 atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 0], gs);
                 atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 1], gss);
               } else {
-                float* st = a.gn_stats + (((long long)n_img * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
+                float* st = gnp + (((long long)n_img * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
                 atomicAdd(st, gs);
                 atomicAdd(st + 1, gss);
               }
@@ -748,7 +830,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
         const int seg = gtid / ((BCO / 8) * 2), rem = gtid - seg * ((BCO / 8) * 2);
         const int g = (nt * BCO >> 3) + (rem >> 1);
         if (v != 0.f && g < gn_groups && gn_n0 + seg < a.batch)
-          atomicAdd(a.gn_stats + (((long long)(gn_n0 + seg) * a.nlev + lev) * gn_groups + g) * 2 + (rem & 1), v);
+          atomicAdd(gnp + (((long long)(gn_n0 + seg) * a.nlev + lev) * gn_groups + g) * 2 + (rem & 1), v);
       }
     }
     return;
@@ -763,7 +845,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
       const int c = nt * BCO + cl;
       float bv[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bv[e] = (a.bias != nullptr && c + e < a.cout) ? a.bias[c + e] : 0.f;
+      for (int e = 0; e < 4; ++e) bv[e] = (biasp != nullptr && c + e < a.cout) ? biasp[c + e] : 0.f;
 #pragma unroll
       for (int tp = 0; tp < TPOS; ++tp) {
         const int pl = wpos * TPOS * 32 + tp * 32 + l31;
@@ -791,7 +873,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
                       (!has_res || (a.res_cstride & 7) == 0);
   // fused GroupNorm statistics (8 channels per group == this thread's 8 couts): accumulate over the
   // thread's rows while the image index is unchanged, flush into LDS bins, one global atomic per bin
-  const bool gn = a.gn_stats != nullptr;
+  const bool gn = gnp != nullptr;
   const int gn_groups = a.cout >> 3;
   const int gn_n0 = m0 / HoWo;               // first image touched by this tile
   int gn_n = gn_n0, gn_bound = (gn_n0 + 1) * HoWo;
@@ -803,7 +885,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
         atomicAdd(&gn_bins[(seg * (BCO / 8) + ec) * 2 + 0], gn_s);
         atomicAdd(&gn_bins[(seg * (BCO / 8) + ec) * 2 + 1], gn_ss);
       } else {
-        float* st = a.gn_stats + (((long long)gn_n * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
+        float* st = gnp + (((long long)gn_n * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
         atomicAdd(st, gn_s);
         atomicAdd(st + 1, gn_ss);
       }
@@ -896,7 +978,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
       const int seg = gtid / ((BCO / 8) * 2), rem = gtid - seg * ((BCO / 8) * 2);
       const int g = (nt * BCO >> 3) + (rem >> 1);
       if (v != 0.f && g < gn_groups && gn_n0 + seg < a.batch)
-        atomicAdd(a.gn_stats + (((long long)(gn_n0 + seg) * a.nlev + lev) * gn_groups + g) * 2 + (rem & 1), v);
+        atomicAdd(gnp + (((long long)(gn_n0 + seg) * a.nlev + lev) * gn_groups + g) * 2 + (rem & 1), v);
     }
   }
 }
@@ -1365,10 +1447,11 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p)
   const bool dma = !deform && !(d->flags & (SM_CONV_IN_RELU | SM_CONV_DBG_REG_STAGING));
   const int K = d->kh * d->kw * d->cin;
   const int Kp = (K + 63) / 64 * 64;
+  const int ngroups = d->ngroups > 1 ? d->ngroups : 1;
   // K-step width: measured on MI355X (profiles/r01_conv_microbench.txt) the 32-wide / 4-blocks-per-CU
   // kernel wins for K <= 1152 (all 1x1 convs, the 3x3 convs of layer1/2, the stem: +5..+28 %) and
   // loses for K >= 2304 (towers, FPN, layer3/4 3x3: -8..-20 %)
-  const bool k32 = dma && !with_gn &&
+  const bool k32 = dma && !with_gn && ngroups == 1 &&
                    ((d->flags & SM_CONV_DBG_K32) || (!(d->flags & SM_CONV_DBG_K64) && Kp <= 1152));
   // ---- tile selection.  The cout tile is fixed by the weight padding contract (32/64/128) but may
   // be split further (128 -> 64); the position tile shrinks until the launch has enough blocks to
@@ -1410,6 +1493,7 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p)
     long long nb = 0;
     for (int l = 0; l < d->nlev; ++l) nb += sm_cdiv((long long)d->batch * d->out_h[l] * d->out_w[l], 256);
     nb *= d->cout_pad / 256;
+    nb *= ngroups;
     const long long rounds = (nb + 255) / 256;
     tile256 = nb >= 230 && nb * 100 >= rounds * 256 * 65;
   }
@@ -1428,8 +1512,10 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p)
   }
   long long t = 0;
   for (int l = 0; l < d->nlev; ++l) t += sm_cdiv((long long)d->batch * d->out_h[l] * d->out_w[l], bpos);
-  const long long nblk = t * (d->cout_pad / bco);
+  const long long nblk = t * (d->cout_pad / bco) * ngroups;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
+  // groups exist in the 64-wide-K LDS-DMA kernel only (its tile decode carries the group offsets)
+  if (ngroups > 1 && (!dma || k32 || ws || (d->flags & SM_CONV_RES_NEAREST) || d->w_batch_stride != 0)) return SM_ERR_UNSUPPORTED;
   // K-loop variant.  64-wide K, 128/64-cout tiles of the tile-128 family: flat loader + peeled K loop + pipelined
   // fragment reads (OPT 3) whenever cin >= 64 (no division path in the flat loader); measured +10..15 % on every 3x3
   // conv with K >= 2304 (profiles/r01_conv_kloop_variants.txt).  A/B flags: FLAT_LOOP = OPT 1, LEGACY_LOOP = OPT 0.
@@ -1478,7 +1564,9 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   a.offset = offset;
   a.gn_stats = gn_stats;
   if (gn_stats != nullptr) {
-    if (hipMemsetAsync(gn_stats, 0, sizeof(float) * 2 * d->batch * d->nlev * (d->cout / 8), stream) != hipSuccess)
+    const int ng = d->ngroups > 1 ? d->ngroups : 1;
+    if (ng > 1 && d->gn_group_stride != 2ll * d->batch * d->nlev * (d->cout / 8)) return SM_ERR_BAD_ARG;   // contiguous
+    if (hipMemsetAsync(gn_stats, 0, sizeof(float) * 2 * d->batch * d->nlev * (d->cout / 8) * ng, stream) != hipSuccess)
       return SM_ERR_LAUNCH;
   }
   a.nlev = d->nlev;
@@ -1521,8 +1609,15 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   a.scale_nch = d->scale_nch;
   a.dg = DEFORM ? d->deform_groups : 1;
   a.cpg8 = DEFORM ? d->cin / (8 * d->deform_groups) : 1;
-  const long long nblk = (long long)t * a.ntn;
-  if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
+  a.ngroups = d->ngroups > 1 ? d->ngroups : 1;
+  a.tpg = t * a.ntn;
+  a.x_grows = d->x_group_rows;
+  a.y_grows = d->y_group_rows;
+  a.w_gstride = d->w_group_stride;
+  a.b_gstride = d->bias_group_stride;
+  a.gn_gstride = d->gn_group_stride;
+  const long long nblk = (long long)t * a.ntn * a.ngroups;
+  if (nblk != plan.blocks) return SM_ERR_BAD_SHAPE;       // plan_conv and this function must agree
   dim3 grid((unsigned)nblk), block(256);
 #define SM_LAUNCH(KERNEL) hipLaunchKernelGGL((KERNEL), grid, block, 0, stream, a)
   if (!dma) {
@@ -1552,7 +1647,9 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else if (ws && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 1>));
     else if (ws && bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true, 1>));
     else if (ws) return SM_ERR_UNSUPPORTED;
+    else if (bco == 256 && (d->flags & SM_CONV_DBG_HAND_PLACED)) { block = dim3(512); SM_LAUNCH((conv_igemm_kernel<2, 4, 4, 2, false, true, 0, 7>)); }
     else if (bco == 256) { block = dim3(512); SM_LAUNCH((conv_igemm_kernel<2, 4, 4, 2, false, true, 0, 3>)); }
+    else if (opt == 3 && bco == 128 && bpos == 128 && (d->flags & SM_CONV_DBG_HAND_PLACED)) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 0, 7>));
     else if (opt == 3 && bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 0, 3>));
     else if (opt == 3 && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 0, 3>));
     else if (opt == 3 && bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true, 0, 3>));

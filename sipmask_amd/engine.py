@@ -19,6 +19,11 @@ from ._lib import SM_CONV_RELU, SM_CONV_OUT_F32, SM_CONV_RES_ADD, SM_CONV_RES_NE
 
 ARCH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 _DEBUG_CONV_FLAGS = int(__import__("os").environ.get("SIPMASK_CONV_DEBUG_FLAGS", "0"), 0)
+_GROUPED_TOWERS = __import__("os").environ.get("SIPMASK_GROUPED_TOWERS", "0") == "1"    # experiment, see _build_head
+
+
+def _lib_flag(name):
+    return {"SM_CONV_DBG_TILE256": 0x00400000}[name]
 BF16 = torch.bfloat16
 
 
@@ -68,6 +73,32 @@ class _Conv:
             H.deform_conv2d(self.desc, self.x, self.offset, self.w, self.bias, self.y)
         else:
             H.conv2d(self.desc, self.x, self.w, self.bias, self.residual, self.y)
+
+
+class _GroupedConv(_Conv):
+    """G convs of identical shape (own weights, own outputs, shared or own inputs) as ONE launch through the group
+    dimension of sm_conv_desc: weights stacked [G][cout_pad][Kp], y = [G * rows, cout], GroupNorm statistics
+    [G][batch][nlev][cout/8][2].  Used for the cls / reg tower convs of one depth (sipmask_head.py:252-257)."""
+
+    def __init__(self, eng, name, ws, biases, batch, in_sizes, in_row0, x, x_group_rows, in_cstride, y, y_group_rows,
+                 out_row0, out_cstride, flags=0):
+        G = len(ws)
+        _Conv.__init__(self, eng, name, ws[0], biases[0], batch, in_sizes, in_row0, x, in_cstride, 1, 1, y, out_row0,
+                       out_cstride, flags=flags)
+        dev = eng.device
+        packed = [self.w] + [H.prep_conv_weight(w.to(dev), in_cstride)[0] for w in ws[1:]]
+        assert all(p.shape == packed[0].shape for p in packed)
+        self.w = torch.stack(packed).contiguous()
+        if biases[0] is not None:
+            self.bias = torch.stack([b.float().to(dev) for b in biases]).contiguous()
+        d = self.desc
+        d.ngroups = G
+        d.x_group_rows, d.y_group_rows = x_group_rows, y_group_rows
+        d.w_group_stride = packed[0].numel()
+        d.bias_group_stride = 0 if biases[0] is None else biases[0].numel()
+        d.gn_group_stride = 2 * batch * len(in_sizes) * (ws[0].shape[0] // 8)
+        self.flops *= G
+        self.bytes = self.bytes * G - (0 if x_group_rows else (G - 1) * sum(batch * h * ww for h, ww in in_sizes) * in_cstride * 2)
 
 
 class MaskRescorer:
@@ -380,8 +411,41 @@ class SipMaskEngine:
         # statistics buffer) next to the regression tower; a 1404-block launch leaves the last of its 2.74 rounds
         # of resident blocks 38 % empty, which the other tower's blocks fill
         self.gn_stats_cls = torch.zeros_like(self.gn_stats)
-        self.cls_feat = tower("cls", depth("cls"), lane=1, stats=self.gn_stats_cls)
-        self.reg_feat = tower("reg", depth("reg"))
+        if _GROUPED_TOWERS and self.flag_norm and depth("cls") >= 1:
+            # cls and reg tower convs of one depth as ONE grouped launch (2 x 353 tiles of 256x256 fill the 256 CUs'
+            # rounds to 92 %), each followed by the two towers' GroupNorm passes on two lanes
+            n_sh = min(depth("cls"), depth("reg"))
+            S = self.gn_stats.numel()
+            stats2 = torch.zeros(2 * S, dtype=torch.float32, device=dev)
+            x, xg = self.pyr, 0
+            for i in range(n_sh):
+                y = self._buf(2 * lv.rows, 256)
+                names = ["cls_convs.%d" % i, "reg_convs.%d" % i]
+                c = self._add_conv(_GroupedConv(self, "head.tower%d" % i, [sd[h + n + ".conv.weight"] for n in names],
+                                                [sd.get(h + n + ".conv.bias") for n in names], B, sizes, row0, x, xg, 256, y,
+                                                lv.rows, row0, 256, flags=_lib_flag("SM_CONV_DBG_TILE256")))
+                c.gn_stats = stats2
+                for g, n in enumerate(names):
+                    yv, st = y[g * lv.rows:(g + 1) * lv.rows], stats2[g * S:(g + 1) * S]
+                    gam = sd[h + n + ".gn.weight"].float().to(dev).contiguous()
+                    bet = sd[h + n + ".gn.bias"].float().to(dev).contiguous()
+                    self._add("gn:" + n, (lambda yv=yv, gam=gam, bet=bet, st=st: H.groupnorm_apply(
+                        yv, yv, gam, bet, st, self.lv, 256, 32, 1e-5, True)), 1 if g == 0 else 0)
+                self._join(1)
+                x, xg = y, lv.rows
+            self.cls_feat, x = x[:lv.rows], x[lv.rows:]
+            for i in range(n_sh, depth("reg")):                    # the reg tower is one conv deeper
+                y = self._buf(lv.rows, 256)
+                name = "reg_convs.%d" % i
+                c = self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"], sd.get(h + name + ".conv.bias"),
+                                         B, sizes, row0, x, 256, 1, 1, y, row0, 256))
+                self._gn(name, y, sd[h + name + ".gn.weight"], sd[h + name + ".gn.bias"], conv=c)
+                x = y
+            self.reg_feat = x
+            assert depth("cls") == n_sh, "a cls tower deeper than the reg tower does not occur in the reference configs"
+        else:
+            self.cls_feat = tower("cls", depth("cls"), lane=1, stats=self.gn_stats_cls)
+            self.reg_feat = tower("reg", depth("reg"))
         # mask basis branch (sipmask_head.py:275-285): needs reg_feat only and is consumed by mask assembly only, so it
         # runs on lane 2 next to reg_ctr / FeatureAlign / cls_cof and the low-occupancy det_select + NMS (joined in
         # _build_post right before mask assembly)

@@ -52,7 +52,8 @@ class Levels:
 
 def make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, cout, cout_pad, k, stride, pad,
                    in_cstride, out_cstride, out_coff=0, flags=0, dil=1, res_cstride=0, res_sizes=None,
-                   res_row0=None, scale_nch=0, level_scale=None, deform_groups=0):
+                   res_row0=None, scale_nch=0, level_scale=None, deform_groups=0, ngroups=1, x_group_rows=0, y_group_rows=0,
+                   w_group_stride=0, bias_group_stride=0, gn_group_stride=0):
     d = ConvDesc()
     nlev = len(in_sizes)
     assert 1 <= nlev <= SM_MAX_LEVELS
@@ -73,6 +74,9 @@ def make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, cout, cou
     d.flags = flags
     d.scale_nch = scale_nch
     d.deform_groups = deform_groups
+    d.ngroups = ngroups
+    d.x_group_rows, d.y_group_rows, d.w_group_stride = x_group_rows, y_group_rows, w_group_stride
+    d.bias_group_stride, d.gn_group_stride = bias_group_stride, gn_group_stride
     return d
 
 

@@ -85,7 +85,8 @@ def test_conv_igemm_vs_torch(cfg):
                                      0x0c800000, 0x14800000,                # 128x256 tiles, 64- / 32-wide K steps
                                      0x08200000, 0x08100000, 0x0c100000,    # flat K loop without fragment pipeline / legacy K loop
                                      0x0c400000, 0x09200000,                # 256x256 8-wave tiles (forced); flat loop + LDS epilogue
-                                     0x10080000, 0x14080000, 0x11080000])   # 32-wide-K kernel with the flat/pipelined loop
+                                     0x10080000, 0x14080000, 0x11080000,    # 32-wide-K kernel with the flat/pipelined loop
+                                     0x0c440000, 0x08040000])               # hand-placed K step: 256x256 tiles / 128x128 tiles
 def test_conv_loader_variants(variant):
     """The A/B loader variants (register staging 0x2..., forced 32-wide K steps 0x1..., forced 64-wide
     0x08...) must give the same
@@ -194,6 +195,43 @@ def test_conv_fused_groupnorm_statistics(extra):
         ref = F.relu(F.group_norm(F.conv2d(xs[l], w, None, 1, 1), 32, gamma, beta, 1e-5))
         out = y[lv.row0[l]:lv.row0[l] + B * h * wd].float().view(B, h, wd, Co).permute(0, 3, 1, 2).cpu()
         torch.testing.assert_close(out, ref, rtol=2e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("extra,shared_x", [(0, True), (0, False), (0x04400000, True), (0x04400000, False), (0x04440000, False)])
+def test_grouped_conv_with_groupnorm_statistics(extra, shared_x):
+    """group dimension of sm_conv_desc: two convs of identical shape (own weights, own outputs and GN statistics,
+    shared or own inputs) in ONE launch == the two launches, on the default tiles and on the 256x256 8-wave tile"""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    B, C, Co, G = 2, 64, 256, 2
+    sizes = [(19, 27), (9, 11), (3, 5)]
+    lv = H.Levels(B, sizes)
+    xs = [[_bf(torch.randn(B, C, h, w, generator=g)) for h, w in sizes] for _ in range(1 if shared_x else G)]
+    ws = [_bf(torch.randn(Co, C, 3, 3, generator=g) / 24) for _ in range(G)]
+    flat = lambda t: torch.cat([a.permute(0, 2, 3, 1).reshape(-1, C) for a in t])
+    x = torch.cat([flat(t) for t in xs]).to(torch.bfloat16).to(dev)
+    packed = [H.prep_conv_weight(w.to(dev)) for w in ws]
+    wq, co_pad = torch.stack([p[0] for p in packed]).contiguous(), packed[0][1]
+    y = torch.zeros(G * lv.rows, Co, dtype=torch.bfloat16, device=dev)
+    S = 2 * B * len(sizes) * (Co // 8)
+    stats = torch.full((G * S,), 7.0, device=dev)
+    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, C, Co, co_pad, 3, 1, 1, C, Co, flags=extra, ngroups=G,
+                         x_group_rows=0 if shared_x else lv.rows, y_group_rows=lv.rows, w_group_stride=packed[0][0].numel(),
+                         gn_group_stride=S)
+    H.conv2d_gn_stats(d, x, None, wq, None, None, y, stats)
+    torch.cuda.synchronize()
+    for gi in range(G):
+        src = xs[0] if shared_x else xs[gi]
+        st = stats[gi * S:(gi + 1) * S].view(B, len(sizes), Co // 8, 2).cpu().double()
+        for l, (h, wd) in enumerate(sizes):
+            ref = F.conv2d(src[l], ws[gi], None, 1, 1).double()
+            r0 = gi * lv.rows + lv.row0[l]
+            out = y[r0:r0 + B * h * wd].float().view(B, h, wd, Co).permute(0, 3, 1, 2).cpu()
+            torch.testing.assert_close(out, ref.float(), rtol=2 ** -7, atol=2e-3)
+            rs = ref.view(B, Co // 8, 8 * h * wd)
+            torch.testing.assert_close(st[:, l, :, 0], rs.sum(-1), rtol=1e-4, atol=2e-3)
+            torch.testing.assert_close(st[:, l, :, 1], (rs * rs).sum(-1), rtol=1e-4, atol=2e-3)
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 14, 19, 256), (1, 64, 9, 9, 40)])

@@ -220,7 +220,8 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     eng = pd.build_on_cpu(variant, batch=2, hw=(256, 320))
     assert torch.cuda.is_available is avail                       # the patch is undone
     rows = {r["name"]: r for r in pd.conv_rows(eng)}
-    assert len(rows) == nconv == len(eng.convs)
+    grouped = os.environ.get("SIPMASK_GROUPED_TOWERS", "0") == "1"     # wip/grouped-towers: cls+reg convs per depth fuse
+    assert len(rows) == len(eng.convs) and (grouped or len(rows) == nconv)
     assert all(r["plan"]["blocks"] > 0 and 0 < r["fill"] <= 1 for r in rows.values())
     assert len(eng.steps) == len(eng.lanes)
     joined = set()
@@ -232,12 +233,15 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     for c in eng.convs:
         d = c.desc
         K = d.kh * d.kw * d.cin
-        assert tuple(c.w.shape) == (d.cout_pad, (K + 63) // 64 * 64), c.name
+        G = max(int(d.ngroups), 1)
+        assert tuple(c.w.shape)[-2:] == (d.cout_pad, (K + 63) // 64 * 64) and c.w.numel() == G * d.cout_pad * ((K + 63) // 64 * 64), c.name
+        if G > 1:
+            assert d.w_group_stride == d.cout_pad * ((K + 63) // 64 * 64) and c.gn_stats.numel() == G * d.gn_group_stride, c.name
         assert c.x.dim() == 2 and c.y.dim() == 2 and d.in_cstride <= c.x.shape[1] and d.cin <= d.in_cstride, c.name
         assert d.out_coff + d.cout <= d.out_cstride <= c.y.shape[1], c.name
         for l in range(d.nlev):
-            assert d.in_row0[l] + d.batch * d.in_h[l] * d.in_w[l] <= c.x.shape[0], (c.name, l)
-            assert d.out_row0[l] + d.batch * d.out_h[l] * d.out_w[l] <= c.y.shape[0], (c.name, l)
+            assert (G - 1) * d.x_group_rows + d.in_row0[l] + d.batch * d.in_h[l] * d.in_w[l] <= c.x.shape[0], (c.name, l)
+            assert (G - 1) * d.y_group_rows + d.out_row0[l] + d.batch * d.out_h[l] * d.out_w[l] <= c.y.shape[0], (c.name, l)
             if c.residual is not None and (d.flags & 8):            # SM_CONV_RES_NEAREST
                 assert d.res_row0[l] + d.batch * d.res_h[l] * d.res_w[l] <= c.residual.shape[0], (c.name, l)
             elif c.residual is not None:
@@ -251,7 +255,7 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     fa = rows["head.feat_align"]["plan"]
     assert fa["lds_dma"] == 0 and fa["k_step"] == 64                # deformable gather: register-staged loader
     assert rows["fpn.p7"]["plan"]["lds_dma"] == 0                   # input ReLU (fpn.py:174-175)
-    tower = rows["head.reg_convs.0"]["plan"]
+    tower = rows["head.tower0" if grouped and "head.tower0" in rows else "head.reg_convs.0"]["plan"]
     assert (tower["k_step"], tower["k_loop"]) == (64, 3)
     if variant == "dcn":
         assert sum(1 for n in rows if n.endswith("conv2.conv_offset")) == 5
