@@ -197,6 +197,26 @@ int sm_upsample_bilinear(const void* x, void* y, int batch, int h, int w, int c,
                          int in_cstride, int out_cstride, int out_coff, int is_f32,
                          sm_stream_t stream);
 
+/* ---- exact-f32 plan: the parity mode of the hot path -------------------------------------------------------
+ * The reference computes the whole path in fp32 (M/mmdet/models/anchor_heads/sipmask_head.py:241-287,609-633;
+ * resnet.py:206-229; fpn.py:141-175).  These entry points run the same launch plan with f32 activations and
+ * weights on v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate) so that box / mask logits can be held
+ * to the reference within accumulation-order rounding; the bf16 entry points above stay the throughput path.
+ * Layout as above with f32 elements: activations f32 rows (cin, in_cstride multiples of 4), weights f32
+ * [cout_pad][Kp], K = (kh,kw,cin) cin fastest, Kp = K rounded up to 16, rows padded to sm_conv_cout_tile(cout).
+ * sm_conv2d_f32: offset != NULL selects the deformable variant (bilinear samples formed in f32 exactly as
+ * deform_conv_cuda_kernel.cu:85-115); residual f32 rows; y f32 (SM_CONV_OUT_F32 is implied). */
+int sm_conv2d_f32(const sm_conv_desc* d, const float* x, const float* offset, const float* w, const float* bias,
+                  const float* residual, float* y, sm_stream_t stream);
+/* NCHW f32 image -> NHWC f32 with channels zero padded to cpad (multiple of 4). */
+int sm_nchw_f32_to_nhwc_f32(const float* x, float* y, int batch, int c, int h, int w, int cpad, sm_stream_t stream);
+/* 3x3 stride-2 pad-1 max pool on NHWC f32 (resnet.py:460). */
+int sm_maxpool3x3s2_f32(const float* x, float* y, int batch, int h, int w, int c, sm_stream_t stream);
+/* sm_groupnorm on f32 rows; stats: DOUBLE workspace [batch*nlev*groups*2] (sum, sum of squares), zeroed by the call. */
+int sm_groupnorm_f32(const float* x, float* y, const float* gamma, const float* beta, double* stats, int batch,
+                     int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups, float eps, int relu,
+                     sm_stream_t stream);
+
 /* ---- detection post-processing (sipmask_head.py:543-605) ------------------------------- */
 
 typedef struct {

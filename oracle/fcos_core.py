@@ -108,9 +108,9 @@ def postprocess_single(logits, bbox_reg, ctrs, cofs, feat_mask, image_size, ori_
     B_, S_, L_, F_ = [], [], [], []
     for cls, reg, ctr, cof, loc in zip(logits, bbox_reg, ctrs, cofs, pts):
         C = cls.shape[0]
-        p = cls.permute(1, 2, 0).reshape(-1, C).sigmoid()
+        p = ops.sigmoid_ref(cls.permute(1, 2, 0).reshape(-1, C))
         r = reg.permute(1, 2, 0).reshape(-1, 4)
-        c = ctr.permute(1, 2, 0).reshape(-1).sigmoid()
+        c = ops.sigmoid_ref(ctr.permute(1, 2, 0).reshape(-1))
         f = cof.permute(1, 2, 0).reshape(-1, 128)
         cand = p > pre_nms_thresh
         n = min(int(cand.sum()), pre_nms_top_n)

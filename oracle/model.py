@@ -297,8 +297,8 @@ def select_candidates(cls_scores, bbox_preds, ctrs, cofs, img_shape, nms_pre=100
     B_, S_, C_, F_, lv, ps = [], [], [], [], [], []
     for li, (cs, bp, ct, cf, p) in enumerate(zip(cls_scores, bbox_preds, ctrs, cofs, pts)):
         ncls = cs.shape[0]
-        scores = cs.permute(1, 2, 0).reshape(-1, ncls).sigmoid()
-        ctr = ct.permute(1, 2, 0).reshape(-1).sigmoid()
+        scores = ops.sigmoid_ref(cs.permute(1, 2, 0).reshape(-1, ncls))      # see ops.sigmoid_ref: f64, rounded once
+        ctr = ops.sigmoid_ref(ct.permute(1, 2, 0).reshape(-1))
         bp = bp.permute(1, 2, 0).reshape(-1, 4)
         cf = cf.permute(1, 2, 0).reshape(-1, 128)
         pos = torch.arange(scores.shape[0])

@@ -55,6 +55,20 @@ def topk_desc(values, k):
     return order[:k]
 
 
+def sigmoid_ref(x):
+    """The ranking sigmoid of get_bboxes_single (M/mmdet/models/anchor_heads/sipmask_head.py:566-567,
+    `cls_score...sigmoid()`, `centerness...sigmoid()`), evaluated in float64 and rounded ONCE to float32.
+    The reference calls torch's f32 sigmoid, whose expf is not bit-defined across CPU / CUDA / ROCm libraries
+    (1 ulp apart), and every integer decision downstream (top-k order, score > score_thr, NMS order) hangs off
+    these values.  A float64 evaluation rounded to float32 is reproducible between any two < 1-ulp double exp()
+    implementations (except within ~2^-52 of an f32 rounding boundary), so the HIP kernels (common.h:
+    sigmoid_rank) and this oracle produce the same bits; it differs from torch.sigmoid by at most 1 f32 ulp
+    (tests/test_reference_vectors.py holds both against the reference's own outputs)."""
+    t = torch.as_tensor(x)
+    v = t.detach().to(torch.float64)
+    return (1.0 / (1.0 + torch.exp(-v))).to(torch.float32)
+
+
 # ----------------------------------------------------------------------------
 # boxes
 # ----------------------------------------------------------------------------

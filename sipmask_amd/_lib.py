@@ -78,6 +78,10 @@ PROTOTYPES = {
     "sm_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "sm_deform_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "sm_conv2d_gn_stats": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sm_conv2d_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "sm_nchw_f32_to_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "sm_maxpool3x3s2_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "sm_groupnorm_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P]),
     "sm_groupnorm_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P]),
     "sm_offset_linear": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _P]),
     "sm_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P]),

@@ -82,5 +82,13 @@ __device__ __forceinline__ uint32_t float_to_ordered(float f) {
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Ranking sigmoid of the detection path: evaluated in DOUBLE and rounded once to f32.  Every integer decision of
+// get_bboxes_single (top-k order, score > score_thr, NMS order; sipmask_head.py:563-605) hangs off these values, and
+// f32 expf differs by an ulp between libraries (torch-CPU / CUDA / ocml), which is enough to swap two near-equal keys.
+// A double evaluation agrees between any two <1-ulp double exp() implementations after the rounding to f32 except
+// when the double result lies within ~2^-52 of an f32 rounding boundary (p ~ 2^-28 per value), so the oracle
+// (oracle/ops.py: sigmoid_ref) and this kernel produce the same f32 bits and the comparisons downstream are exact.
+__device__ __forceinline__ float sigmoid_rank(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
+
 static inline hipStream_t sm_hip_stream(sm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int sm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -158,7 +158,7 @@ __global__ void det_score_kernel(const float* __restrict__ cls, const float* __r
     float mx = -INFINITY;
     for (int c = 0; c < a.C; ++c) mx = fmaxf(mx, cp[c]);
     // max_c(sigmoid(x_c) * s) == sigmoid(max_c x_c) * s : both maps are monotone
-    keys[i] = sigmoidf_acc(mx) * sigmoidf_acc(reg[row * a.reg_cs + 4]);
+    keys[i] = __fmul_rn(sigmoid_rank(mx), sigmoid_rank(reg[row * a.reg_cs + 4]));
   }
 }
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void det_gather_kernel(const float* __restrict
     const long long o = (long long)b * a.kmax + k;
     if (part == 0) {
       const float* rp = reg + row * a.reg_cs;
-      ctr[o] = sigmoidf_acc(rp[4]);
+      ctr[o] = sigmoid_rank(rp[4]);
       const int s = a.stride[lev];
       const int py = pos / a.w[lev], px = pos - py * a.w[lev];
       const float x = (float)(px * s) + (float)(s / 2), y = (float)(py * s) + (float)(s / 2);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void det_gather_kernel(const float* __restrict
     // class scores: lanes = candidates (coalesced class-major stores; the source rows stay in L1)
     const float* cp = cls + row * a.cls_cs + a.cls_co;
     float* sp = scores + (long long)b * a.C * a.kmax + k;
-    for (int c = part; c < a.C; c += 4) sp[(long long)c * a.kmax] = sigmoidf_acc(cp[c]);
+    for (int c = part; c < a.C; c += 4) sp[(long long)c * a.kmax] = sigmoid_rank(cp[c]);
   } else if (part == 0) {
     s_row[lc] = -1;
   }
@@ -262,8 +262,8 @@ __global__ void pair_score_kernel(const float* __restrict__ cls, const float* __
     for (int l = 1; l < SM_MAX_LEVELS; ++l)
       if (l < a.nlev && p >= a.pos0[l]) lev = l;
     const long long row = a.row0[lev] + (long long)b * a.hw[lev] + (p - a.pos0[lev]);
-    const float pc = sigmoidf_acc(cls[row * a.cls_cs + a.cls_co + c]);
-    keys[i] = pc > thr ? __fmul_rn(pc, sigmoidf_acc(reg[row * a.reg_cs + 4])) : -1.f;
+    const float pc = sigmoid_rank(cls[row * a.cls_cs + a.cls_co + c]);
+    keys[i] = pc > thr ? __fmul_rn(pc, sigmoid_rank(reg[row * a.reg_cs + 4])) : -1.f;
   }
 }
 

@@ -244,6 +244,146 @@ __global__ void offset_linear_kernel(const float* __restrict__ reg, const float*
   }
 }
 
+// ================================================================ exact-f32 plan (parity mode, conv_f32.hip)
+// NCHW f32 -> NHWC f32 (channels zero padded to cpad, multiple of 4)
+__global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW,
+                                        int cpad) {
+  const long long total = (long long)B * HW;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+       p += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(p / HW);
+    const int hw = (int)(p - (long long)n * HW);
+    const float* xp = x + (long long)n * C * HW + hw;
+    float* yp = y + p * cpad;
+    for (int c0 = 0; c0 < cpad; c0 += 4) {
+      float4 v;
+      v.x = (c0 + 0 < C) ? xp[(long long)(c0 + 0) * HW] : 0.f;
+      v.y = (c0 + 1 < C) ? xp[(long long)(c0 + 1) * HW] : 0.f;
+      v.z = (c0 + 2 < C) ? xp[(long long)(c0 + 2) * HW] : 0.f;
+      v.w = (c0 + 3 < C) ? xp[(long long)(c0 + 3) * HW] : 0.f;
+      *reinterpret_cast<float4*>(yp + c0) = v;
+    }
+  }
+}
+
+__global__ void maxpool3x3s2_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C,
+                                        int Ho, int Wo) {
+  const int c4 = C / 4;
+  const long long total = (long long)B * Ho * Wo * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c4);
+    long long p = i / c4;
+    const int wo = (int)(p % Wo);
+    p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hi = ho * 2 - 1 + dh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int wi = wo * 2 - 1 + dw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + (((long long)n * H + hi) * W + wi) * C + cc * 4);
+        m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y), m.z = fmaxf(m.z, v.z), m.w = fmaxf(m.w, v.w);
+      }
+    }
+    *reinterpret_cast<float4*>(y + (((long long)n * Ho + ho) * Wo + wo) * C + cc * 4) = m;
+  }
+}
+
+// GroupNorm on f32 rows: statistics accumulated in DOUBLE (sum, sum of squares per (image, level, group)), so the
+// E[x^2] - mean^2 form loses nothing against the reference's f32 two-pass moments.  A thread owns one 16-byte chunk
+// column (4 channels inside one group) and strides over rows.
+__global__ __launch_bounds__(256) void gn_stats_f32_kernel(const float* __restrict__ x, double* __restrict__ stats,
+                                                           const GnArgs a) {
+  const int n = blockIdx.y;
+  int lev = 0;
+#pragma unroll
+  for (int l = 1; l < SM_MAX_LEVELS; ++l)
+    if (l < a.nlev && (int)blockIdx.x >= a.blk0[l]) lev = l;
+  const int rb = (blockIdx.x - a.blk0[lev]) * GN_ROWS_PER_BLOCK;
+  const int HW = a.hw[lev];
+  const int c4 = a.C / 4;
+  const int rows_per_iter = 256 / c4;
+  const int cc = threadIdx.x % c4;
+  const int rr = threadIdx.x / c4;
+  const float* base = x + (a.row0[lev] + (long long)n * HW) * a.C;
+  double s = 0.0, ss = 0.0;
+  if (rr < rows_per_iter) {
+    const int rend = min(rb + GN_ROWS_PER_BLOCK, HW);
+    for (int r = rb + rr; r < rend; r += rows_per_iter) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (long long)r * a.C + cc * 4);
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  }
+  __shared__ double sh[2][256];
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = ss;
+  __syncthreads();
+  const int chunks_per_group = a.cpg / 4;
+  if ((int)threadIdx.x < a.groups) {
+    const int g = threadIdx.x;
+    double ts = 0.0, tss = 0.0;
+    for (int r = 0; r < rows_per_iter; ++r)
+      for (int k = 0; k < chunks_per_group; ++k) {
+        const int t = r * c4 + g * chunks_per_group + k;
+        ts += sh[0][t];
+        tss += sh[1][t];
+      }
+    double* st = stats + (((long long)n * a.nlev + lev) * a.groups + g) * 2;
+    atomicAdd(st, ts);
+    atomicAdd(st + 1, tss);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_f32_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const double* __restrict__ stats, const GnArgs a) {
+  const int n = blockIdx.y;
+  int lev = 0;
+#pragma unroll
+  for (int l = 1; l < SM_MAX_LEVELS; ++l)
+    if (l < a.nlev && (int)blockIdx.x >= a.blk0[l]) lev = l;
+  const int rb = (blockIdx.x - a.blk0[lev]) * GN_ROWS_PER_BLOCK;
+  const int HW = a.hw[lev];
+  const int c4 = a.C / 4;
+  const int rows_per_iter = 256 / c4;
+  const int cc = threadIdx.x % c4;
+  const int rr = threadIdx.x / c4;
+  if (rr >= rows_per_iter) return;
+  const int g = (cc * 4) / a.cpg;
+  const double* st = stats + (((long long)n * a.nlev + lev) * a.groups + g) * 2;
+  const double cnt = (double)HW * (double)a.cpg;
+  const double mean_d = st[0] / cnt;
+  const double var_d = fmax(st[1] / cnt - mean_d * mean_d, 0.0);
+  // (x - mean) * rstd * gamma + beta, as at::native group_norm evaluates it
+  const float mean = (float)mean_d;
+  const float rstd = (float)(1.0 / sqrt(var_d + (double)a.eps));
+  float ga[4], be[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ga[e] = gamma[cc * 4 + e];
+    be[e] = beta[cc * 4 + e];
+  }
+  const long long off = (a.row0[lev] + (long long)n * HW) * a.C;
+  const int rend = min(rb + GN_ROWS_PER_BLOCK, HW);
+  for (int r = rb + rr; r < rend; r += rows_per_iter) {
+    const long long o = off + (long long)r * a.C + cc * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = (f[e] - mean) * rstd * ga[e] + be[e];
+      f[e] = a.relu ? fmaxf(t, 0.f) : t;
+    }
+    *reinterpret_cast<float4*>(y + o) = make_float4(f[0], f[1], f[2], f[3]);
+  }
+}
+
 inline int grid_for(long long n, int block) {
   long long g = (n + block - 1) / block;
   if (g > 256 * 16) g = 256 * 16;
@@ -274,8 +414,8 @@ extern "C" int sm_maxpool3x3s2(const void* x, void* y, int batch, int h, int w, 
 }
 
 static int gn_fill_args(GnArgs& a, int& t, int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels,
-                        int groups, float eps, int relu) {
-  if (nlev < 1 || nlev > SM_MAX_LEVELS || channels % (8 * groups) != 0 || channels > 2048 || 256 % (channels / 8) != 0)
+                        int groups, float eps, int relu, int vec = 8) {
+  if (nlev < 1 || nlev > SM_MAX_LEVELS || channels % (vec * groups) != 0 || channels > 256 * vec || 256 % (channels / vec) != 0)
     return SM_ERR_BAD_SHAPE;
   if (groups > 256) return SM_ERR_BAD_SHAPE;
   a.nlev = nlev;
@@ -361,6 +501,44 @@ extern "C" int sm_offset_linear(const float* reg, int reg_cstride, const float* 
   }
   hipLaunchKernelGGL(offset_linear_kernel, dim3(grid_for(a.total * nout, 256)), dim3(256), 0, sm_hip_stream(stream),
                      reg, w_off, out, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+/* ---- exact-f32 plan (parity mode): the f32 twins of the layout / pool / GroupNorm kernels ------------------- */
+
+extern "C" int sm_nchw_f32_to_nhwc_f32(const float* x, float* y, int batch, int c, int h, int w, int cpad,
+                                       sm_stream_t stream) {
+  if (!x || !y || cpad % 4 != 0 || cpad < c || batch < 1) return SM_ERR_BAD_ARG;
+  const long long n = (long long)batch * h * w;
+  hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, sm_hip_stream(stream), x, y, batch, c,
+                     h * w, cpad);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_maxpool3x3s2_f32(const float* x, float* y, int batch, int h, int w, int c, sm_stream_t stream) {
+  if (!x || !y || c % 4 != 0) return SM_ERR_BAD_ARG;
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const long long n = (long long)batch * ho * wo * (c / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, sm_hip_stream(stream), x, y, batch, h,
+                     w, c, ho, wo);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_groupnorm_f32(const float* x, float* y, const float* gamma, const float* beta, double* stats, int batch,
+                                int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups, float eps,
+                                int relu, sm_stream_t stream) {
+  if (!x || !y || !gamma || !beta || !stats || !hw || !row0) return SM_ERR_BAD_ARG;
+  GnArgs a;
+  int t;
+  const int st = gn_fill_args(a, t, batch, nlev, hw, row0, channels, groups, eps, relu, 4);
+  if (st != SM_OK) return st;
+  hipStream_t s = sm_hip_stream(stream);
+  if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
+  hipLaunchKernelGGL(gn_stats_f32_kernel, dim3(t, batch), dim3(256), 0, s, x, stats, a);
+  hipLaunchKernelGGL(gn_apply_f32_kernel, dim3(t, batch), dim3(256), 0, s, x, y, gamma, beta, stats, a);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -34,20 +34,23 @@ class SipMask(nn.Module):
         self.bbox_head.init_weights()
         self._engines = {}
 
-    def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False):
+    def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False, precision="bf16"):
         """Build (or fetch) the static launch plan for this input geometry; weights are snapshotted,
         BN folded, re-laid out as bf16 GEMM operands.  Call again after load_state_dict.
         scale_factor / rescale: img_meta['scale_factor'] and the rescale flag of simple_test (boxes and masks
-        in original-image coordinates, sipmask_head.py:587-588,621-632)."""
+        in original-image coordinates, sipmask_head.py:587-588,621-632).  precision: "bf16" = the throughput plan,
+        "f32" = the parity plan (exact-f32 MFMA convs, every tensor f32: held to the fp32 reference within
+        accumulation-order rounding)."""
         import numpy as np
         from .engine import SipMaskEngine
         key = (batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
-               rescale)
+               rescale, precision)
         eng = self._engines.get(key)
         if eng is None:
             eng = SipMaskEngine(self.state_dict(), batch, img_hw, self.backbone.depth, self.test_cfg,
                                 self.bbox_head.num_classes, strides=self.bbox_head.strides, img_shape=img_shape,
-                                ssd_flag=self.bbox_head.ssd_flag, scale_factor=scale_factor, rescale=rescale)
+                                ssd_flag=self.bbox_head.ssd_flag, scale_factor=scale_factor, rescale=rescale,
+                                precision=precision)
             self._engines = {key: eng}
         return eng
 

@@ -19,11 +19,13 @@ from ._lib import SM_CONV_RELU, SM_CONV_OUT_F32, SM_CONV_RES_ADD, SM_CONV_RES_NE
 
 ARCH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 _DEBUG_CONV_FLAGS = int(__import__("os").environ.get("SIPMASK_CONV_DEBUG_FLAGS", "0"), 0)
-_GROUPED_TOWERS = __import__("os").environ.get("SIPMASK_GROUPED_TOWERS", "0") == "1"    # experiment, see _build_head
+# cls + reg tower convs of one depth as ONE grouped 256x256-tile launch (measured round 2: 0.2225 ms per pair =
+# 950 TFLOP/s vs 2 x 0.1346 ms = 785 TFLOP/s as two launches; profiles/r02_*); SIPMASK_GROUPED_TOWERS=0 = A/B
+_GROUPED_TOWERS = __import__("os").environ.get("SIPMASK_GROUPED_TOWERS", "1") == "1"
 
 
 def _lib_flag(name):
-    return {"SM_CONV_DBG_TILE256": 0x00400000}[name]
+    return {"SM_CONV_DBG_TILE256": 0x00400000, "SM_CONV_DBG_HAND_PLACED": 0x00040000}[name]
 BF16 = torch.bfloat16
 
 
@@ -49,7 +51,13 @@ class _Conv:
         co, ci, k, _ = w.shape
         cin = cin_pad or ci
         self.name = name
-        self.w, co_pad = H.prep_conv_weight(w.to(dev), cin)
+        # exact-f32 plan (parity mode): f32 operands on v_mfma_f32_32x32x2_f32, every conv output f32
+        self.f32 = getattr(eng, "precision", "bf16") == "f32"
+        if self.f32:
+            cin = cin_pad = ci if ci % 4 == 0 else (ci + 3) // 4 * 4
+            self.w, co_pad = H.prep_conv_weight_f32(w.to(dev), cin)
+        else:
+            self.w, co_pad = H.prep_conv_weight(w.to(dev), cin)
         self.bias = None if bias is None else bias.float().to(dev).contiguous()
         out_sizes = [(_conv_out(h, k, stride, pad), _conv_out(ww, k, stride, pad)) for h, ww in in_sizes]
         self.out_sizes = out_sizes
@@ -63,11 +71,14 @@ class _Conv:
         # algorithmic HBM bytes: x read once + y written once (+ residual read) + weights
         in_rows = sum(batch * h * ww for h, ww in in_sizes)
         out_rows = sum(batch * h * ww for h, ww in out_sizes)
-        self.bytes = (in_rows * cin * 2 + out_rows * co * (4 if flags & SM_CONV_OUT_F32 else 2) +
-                      (out_rows * co * 2 if residual is not None else 0) + self.w.numel() * 2)
+        es = 4 if self.f32 else 2
+        self.bytes = (in_rows * cin * es + out_rows * co * (4 if (flags & SM_CONV_OUT_F32 or self.f32) else 2) +
+                      (out_rows * co * es if residual is not None else 0) + self.w.numel() * es)
 
     def __call__(self):
-        if self.gn_stats is not None:
+        if self.f32:
+            H.conv2d_f32(self.desc, self.x, self.offset, self.w, self.bias, self.residual, self.y)
+        elif self.gn_stats is not None:
             H.conv2d_gn_stats(self.desc, self.x, self.offset, self.w, self.bias, self.residual, self.y, self.gn_stats)
         elif self.offset is not None:
             H.deform_conv2d(self.desc, self.x, self.offset, self.w, self.bias, self.y)
@@ -144,8 +155,14 @@ class SipMaskEngine:
 
     def __init__(self, state_dict, batch, img_hw, depth=50, test_cfg=None, num_classes=81, device="cuda",
                  strides=(8, 16, 32, 64, 128), img_shape=None, head_sizes=None, ssd_flag=False, scale_factor=1.0,
-                 rescale=False, vis=False, benchmark=None):
+                 rescale=False, vis=False, benchmark=None, precision="bf16"):
         _lib.load()   # fail loudly before anything else if the HIP library is missing
+        if precision not in ("bf16", "f32"):
+            raise ValueError("precision must be 'bf16' (throughput plan) or 'f32' (parity plan), got %r" % (precision,))
+        # "f32": every activation / weight float32, convs on the exact-f32 MFMA kernel (csrc/conv_f32.hip), GroupNorm
+        # statistics in double -- the plan that is held to the fp32 reference within accumulation-order rounding
+        self.precision = precision
+        self.act_dtype = torch.float32 if precision == "f32" else BF16
         if not torch.cuda.is_available():
             raise RuntimeError("SipMaskEngine needs a HIP device")
         self.device = torch.device(device)
@@ -187,12 +204,13 @@ class SipMaskEngine:
 
     @classmethod
     def for_head(cls, state_dict, batch, sizes, num_classes=81, strides=(8, 16, 32, 64, 128), test_cfg=None,
-                 img_shape=None, ssd_flag=False, vis=False, benchmark=None):
+                 img_shape=None, ssd_flag=False, vis=False, benchmark=None, precision="bf16"):
         """Plan for SipMaskHead.forward / get_bboxes alone (features come from the caller)."""
         h0, w0 = sizes[0]
         img_hw = (h0 * strides[0], w0 * strides[0])
         return cls(state_dict, batch, img_hw, 50, test_cfg, num_classes, "cuda", strides,
-                   img_shape or (img_hw[0], img_hw[1], 3), head_sizes=list(sizes), ssd_flag=ssd_flag, vis=vis, benchmark=benchmark)
+                   img_shape or (img_hw[0], img_hw[1], 3), head_sizes=list(sizes), ssd_flag=ssd_flag, vis=vis, benchmark=benchmark,
+                   precision=precision)
 
     def load_pyramid(self, feats):
         """copy caller features (tuple of NCHW float tensors) into the bf16 pyramid tensor"""
@@ -200,7 +218,8 @@ class SipMaskEngine:
         for l, f in enumerate(feats):
             h, w = lv.sizes[l]
             assert tuple(f.shape) == (self.batch, 256, h, w), (tuple(f.shape), (self.batch, 256, h, w))
-            H.nchw_to_nhwc_bf16(f.detach().float().contiguous(), self.pyr[lv.row0[l]:lv.row0[l] + self.batch * h * w], 256)
+            to_rows = H.nchw_to_nhwc_f32 if self.precision == "f32" else H.nchw_to_nhwc_bf16
+            to_rows(f.detach().float().contiguous(), self.pyr[lv.row0[l]:lv.row0[l] + self.batch * h * w], 256)
 
     def run_head(self, with_post=False):
         post = ("det_select", "nms", "mask_assemble", "track_gather", "rescore")
@@ -208,8 +227,9 @@ class SipMaskEngine:
         self._run_steps([self.steps[i] for i in sel], [self.lanes[i] for i in sel])
 
     # -------------------------------------------------------------------------------- helpers
-    def _buf(self, rows, c, dtype=BF16):
-        return torch.empty(rows, c, dtype=dtype, device=self.device)
+    def _buf(self, rows, c, dtype=None):
+        """activation buffer; dtype None = the plan's activation type (bf16, or f32 in the parity plan)"""
+        return torch.empty(rows, c, dtype=dtype or self.act_dtype, device=self.device)
 
     def _add(self, label, fn, lane=0):
         """lane 0 = the caller's stream; lanes > 0 are side HIP streams for branches that do not depend on what
@@ -267,16 +287,20 @@ class SipMaskEngine:
         B, Himg, Wimg, dev = self.batch, self.H, self.W, self.device
         sd = {k: v.detach() for k, v in sd.items()}
         # ---- stem
-        self.img_nhwc = self._buf(B * Himg * Wimg, 8)
+        f32 = self.precision == "f32"
+        cpad = 4 if f32 else 8
+        self.img_nhwc = self._buf(B * Himg * Wimg, cpad)
         h1, w1 = _conv_out(Himg, 7, 2, 3), _conv_out(Wimg, 7, 2, 3)
         w, b = fold_bn(sd["backbone.conv1.weight"], sd, "backbone.bn1")
         stem = self._buf(B * h1 * w1, 64)
-        self._add("nhwc", lambda: H.nchw_to_nhwc_bf16(self.img, self.img_nhwc, 8))
-        self._add_conv(_Conv(self, "stem", w, b, B, [(Himg, Wimg)], [0], self.img_nhwc, 8, 2, 3, stem, [0], 64,
-                             flags=SM_CONV_RELU, cin_pad=8))
+        to_rows = H.nchw_to_nhwc_f32 if f32 else H.nchw_to_nhwc_bf16
+        self._add("nhwc", lambda: to_rows(self.img, self.img_nhwc, cpad))
+        self._add_conv(_Conv(self, "stem", w, b, B, [(Himg, Wimg)], [0], self.img_nhwc, cpad, 2, 3, stem, [0], 64,
+                             flags=SM_CONV_RELU, cin_pad=cpad))
         h2, w2 = _conv_out(h1, 3, 2, 1), _conv_out(w1, 3, 2, 1)
         x = self._buf(B * h2 * w2, 64)
-        self._add("maxpool", (lambda s=stem, y=x: H.maxpool3x3s2(s, y, B, h1, w1, 64)))
+        pool = H.maxpool3x3s2_f32 if f32 else H.maxpool3x3s2
+        self._add("maxpool", (lambda s=stem, y=x: pool(s, y, B, h1, w1, 64)))
         # ---- residual stages (caffe style: stride on conv1, resnet.py:125-130)
         cur, ch, cw, cc = x, h2, w2, 64
         feats = []
@@ -371,11 +395,22 @@ class SipMaskEngine:
         g = gamma.float().to(self.device).contiguous()
         b = beta.float().to(self.device).contiguous()
         st = self.gn_stats if stats is None else stats
+        if self.precision == "f32":          # statistics pass in double + normalise pass (no fused epilogue statistics)
+            st64 = self.gn_stats64 if stats is None else self._gn_stats64_for(stats)
+            self._add("gn:" + label, lambda: H.groupnorm_f32(x, x, g, b, st64, self.lv, 256, 32, 1e-5, True), lane)
+            return
         if conv is not None:
             conv.gn_stats = st
             self._add("gn:" + label, lambda: H.groupnorm_apply(x, x, g, b, st, self.lv, 256, 32, 1e-5, True), lane)
         else:
             self._add("gn:" + label, lambda: H.groupnorm(x, x, g, b, st, self.lv, 256, 32, 1e-5, True), lane)
+
+    def _gn_stats64_for(self, stats):
+        """the double-precision twin of a per-lane statistics buffer (f32 plan)"""
+        k = stats.data_ptr()
+        if k not in self._gn64:
+            self._gn64[k] = torch.zeros(stats.numel(), dtype=torch.float64, device=self.device)
+        return self._gn64[k]
 
     def _build_head(self, sd, prefix="bbox_head."):
         """SipMaskHead.forward, sipmask_head.py:241-287, on the pyramid tensor self.pyr."""
@@ -383,6 +418,8 @@ class SipMaskEngine:
         self._sd, self._sd_keys = sd, set(sd.keys())
         sizes, row0 = lv.sizes, lv.row0
         self.gn_stats = torch.zeros(B * len(lv) * 32 * 2, dtype=torch.float32, device=dev)
+        self.gn_stats64 = torch.zeros(B * len(lv) * 32 * 2, dtype=torch.float64, device=dev)
+        self._gn64 = {}
 
         # tower depth / norm as laid down by _init_layers (sipmask_head.py:159-185): stacked_convs-1 cls convs,
         # stacked_convs reg convs; norm_cfg=None (SSD configs) -> conv bias + ReLU, no GroupNorm
@@ -411,7 +448,7 @@ class SipMaskEngine:
         # statistics buffer) next to the regression tower; a 1404-block launch leaves the last of its 2.74 rounds
         # of resident blocks 38 % empty, which the other tower's blocks fill
         self.gn_stats_cls = torch.zeros_like(self.gn_stats)
-        if _GROUPED_TOWERS and self.flag_norm and depth("cls") >= 1:
+        if _GROUPED_TOWERS and self.precision != "f32" and self.flag_norm and depth("cls") >= 1:
             # cls and reg tower convs of one depth as ONE grouped launch (2 x 353 tiles of 256x256 fill the 256 CUs'
             # rounds to 92 %), each followed by the two towers' GroupNorm passes on two lanes
             n_sh = min(depth("cls"), depth("reg"))
@@ -423,7 +460,8 @@ class SipMaskEngine:
                 names = ["cls_convs.%d" % i, "reg_convs.%d" % i]
                 c = self._add_conv(_GroupedConv(self, "head.tower%d" % i, [sd[h + n + ".conv.weight"] for n in names],
                                                 [sd.get(h + n + ".conv.bias") for n in names], B, sizes, row0, x, xg, 256, y,
-                                                lv.rows, row0, 256, flags=_lib_flag("SM_CONV_DBG_TILE256")))
+                                                lv.rows, row0, 256,
+                                                flags=_lib_flag("SM_CONV_DBG_TILE256") | _lib_flag("SM_CONV_DBG_HAND_PLACED")))
                 c.gn_stats = stats2
                 for g, n in enumerate(names):
                     yv, st = y[g * lv.rows:(g + 1) * lv.rows], stats2[g * S:(g + 1) * S]
@@ -455,7 +493,7 @@ class SipMaskEngine:
             fh, fw = sizes[l]
             src = self.reg_feat[row0[l]:row0[l] + B * fh * fw]
             self._add("up:cat%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear(
-                s, self.cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, False)), 2)
+                s, self.cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, self.precision == "f32")), 2)
         self.lat0 = self._buf(B * h0 * w0, 512)
         self._add_conv(_Conv(self, "head.sip_mask_lat0", sd[h + "sip_mask_lat0.weight"], sd[h + "sip_mask_lat0.bias"],
                              B, [(h0, w0)], [0], self.cat, 768, 1, 0, self.lat0, [0], 512, flags=SM_CONV_RELU), 2)
@@ -510,7 +548,12 @@ class SipMaskEngine:
                                          None if self.flag_norm else sd.get(h + name + ".conv.bias"), B, sizes[:3],
                                          row0[:3], x, 256, 1, 1, y, row0[:3], 256,
                                          flags=0 if self.flag_norm else SM_CONV_RELU))
-                if self.flag_norm:
+                if self.flag_norm and self.precision == "f32":
+                    g = sd[h + name + ".gn.weight"].float().to(dev).contiguous()
+                    bta = sd[h + name + ".gn.bias"].float().to(dev).contiguous()
+                    self._add("gn:" + name, (lambda y=y, g=g, bta=bta: H.groupnorm_f32(
+                        y, y, g, bta, self.gn_stats64, lv3, 256, 32, 1e-5, True)))
+                elif self.flag_norm:
                     g = sd[h + name + ".gn.weight"].float().to(dev).contiguous()
                     bta = sd[h + name + ".gn.bias"].float().to(dev).contiguous()
                     c.gn_stats = self.gn_stats
@@ -522,7 +565,7 @@ class SipMaskEngine:
                 fh, fw = sizes[l]
                 src = x[row0[l]:row0[l] + B * fh * fw]
                 self._add("up:track%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear(
-                    s, self.track_cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, False)))
+                    s, self.track_cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, self.precision == "f32")))
             self.track_feats = self._buf(B * h0 * w0, 512, torch.float32)
             self._add_conv(_Conv(self, "head.sipmask_track", sd[h + "sipmask_track.weight"], sd[h + "sipmask_track.bias"],
                                  B, [(h0, w0)], [0], self.track_cat, 768, 1, 0, self.track_feats, [0], 512,

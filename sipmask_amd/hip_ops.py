@@ -188,6 +188,66 @@ def upsample_bilinear(x, y, batch, h, w, c, factor, in_cstride, out_cstride, out
     return y
 
 
+# ---- exact-f32 plan (parity mode): f32 activations / weights, v_mfma_f32_32x32x2_f32 (csrc/conv_f32.hip)
+
+def prep_conv_weight_f32(w, cin_pad=None):
+    """[co,ci,kh,kw] float -> f32 [cout_pad][Kp]; K order (kh,kw,ci), ci fastest (padded to a multiple of 4); Kp % 16 == 0."""
+    co, ci, kh, kw = w.shape
+    cin_pad = cin_pad or ((ci + 3) // 4 * 4)
+    tile = cout_tile(co)
+    co_pad = (co + tile - 1) // tile * tile
+    k = kh * kw * cin_pad
+    kp = (k + 15) // 16 * 16
+    out = torch.zeros(co_pad, kp, dtype=torch.float32, device=w.device)
+    wp = torch.zeros(co, kh, kw, cin_pad, dtype=torch.float32, device=w.device)
+    wp[..., :ci] = w.permute(0, 2, 3, 1).float()
+    out[:co, :k] = wp.reshape(co, k)
+    return out.contiguous(), co_pad
+
+
+def conv2d_f32(desc, x, offset, w, bias, residual, y):
+    """sm_conv2d_f32: offset given -> deformable conv; every tensor float32"""
+    _lib.require_cuda(x, w, y)
+    for t in (x, offset, w, bias, residual, y):
+        if t is not None and t.dtype != torch.float32:
+            raise ValueError("sm_conv2d_f32 takes float32 tensors, got %s" % t.dtype)
+    lib = _lib.load()
+    _lib.check(lib.sm_conv2d_f32(C.byref(desc), _lib.ptr(x), _lib.ptr(offset), _lib.ptr(w), _lib.ptr(bias),
+                                 _lib.ptr(residual), _lib.ptr(y), _lib.stream_ptr()), "sm_conv2d_f32")
+    return y
+
+
+def groupnorm_f32(x, y, gamma, beta, stats, lv, channels, groups=32, eps=1e-5, relu=True):
+    """stats: float64 workspace [batch*nlev*groups*2]"""
+    lib = _lib.load()
+    if stats.dtype != torch.float64:
+        raise ValueError("sm_groupnorm_f32 needs a float64 statistics workspace")
+    nlev = len(lv)
+    hw = (C.c_int32 * nlev)(*[h * w for h, w in lv.sizes])
+    row0 = (C.c_int64 * nlev)(*lv.row0)
+    _lib.check(lib.sm_groupnorm_f32(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
+                                    lv.batch, nlev, hw, row0, channels, groups, eps, int(relu), _lib.stream_ptr()),
+               "sm_groupnorm_f32")
+    return y
+
+
+def maxpool3x3s2_f32(x, y, batch, h, w, c):
+    lib = _lib.load()
+    _lib.check(lib.sm_maxpool3x3s2_f32(_lib.ptr(x), _lib.ptr(y), batch, h, w, c, _lib.stream_ptr()), "sm_maxpool3x3s2_f32")
+    return y
+
+
+def nchw_to_nhwc_f32(x, y, cpad):
+    lib = _lib.load()
+    _lib.require_cuda(x, y)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("expected a contiguous float32 NCHW tensor")
+    b, c, h, w = x.shape
+    _lib.check(lib.sm_nchw_f32_to_nhwc_f32(_lib.ptr(x), _lib.ptr(y), b, c, h, w, cpad, _lib.stream_ptr()),
+               "sm_nchw_f32_to_nhwc_f32")
+    return y
+
+
 def scale4(scale_factor):
     """img_meta['scale_factor'] -> [w, h, w, h] floats: a scalar (keep_ratio=True, transforms.py Resize) is
     repeated, a 4-array (keep_ratio=False) is taken as is."""

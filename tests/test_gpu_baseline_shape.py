@@ -1,0 +1,60 @@
+"""Parity AT THE BASELINE SHAPES (BASELINE.json configs[1] R50 batch 4 and configs[2] R101 batch 1, 3x800x1344):
+the benchmarked launch plan itself -- M = 89 600 head rows, 1 404-block multi-level tile decode, 2.3 GB of buffers,
+multi-stream lanes -- against the fp32 CPU oracle, stage by stage (tools/parity_baseline.py does the work and is
+also the script that writes profiles/r02_parity_*.json).
+
+  * f32 plan (the parity mode): mask logits within 1e-3 ABSOLUTE of the oracle (north_star's tolerance), from the
+    same image AND from identical fp32 FPN features; every stage within 2e-4 of its largest value.
+  * bf16 plan (the throughput mode): stated bound = relative Frobenius error per stage (bf16 storage of ~60 stacked
+    convs): backbone/FPN < 2 %, head outputs < 4 %, mask logits < 5 %; its exactness claims live in the kernel
+    tests (identical inputs) and in test_gpu_engine.py (post-processing on the engine's own head outputs)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+@pytest.mark.parametrize("depth,batch", [(50, 4), (101, 1)])
+def test_f32_plan_at_baseline_shape(depth, batch):
+    _need_gpu()
+    import parity_baseline as PB
+    rep = PB.run(depth, batch, "f32", features_too=(depth == 50), verbose=False)
+    for sec in ("image", "features"):
+        if sec not in rep:
+            continue
+        for k, v in rep[sec].items():
+            if k == "mask_logits":
+                assert v["max_abs"] <= 1e-3, (sec, k, v)
+                assert v["cof_max_abs"] <= 1e-4 * max(1.0, v["ref_max_abs"]), (sec, k, v)
+            else:
+                assert v["max_abs"] <= 2e-4 * v["ref_max_abs"], (sec, k, v)
+    # detections: f32 rounding may swap two near-equal ranking keys; the kept sets must agree almost everywhere
+    for d in rep["detections"]:
+        assert abs(d["ndet_engine"] - d["ndet_oracle"]) <= 2, d
+        assert d["common"] >= d["ndet_oracle"] - 3, d
+        assert d["common_mask_pixels_beyond_1e-3_of_thr"] == 0, d
+
+
+def test_bf16_plan_at_baseline_shape():
+    _need_gpu()
+    import parity_baseline as PB
+    rep = PB.run(50, 4, "bf16", features_too=True, verbose=False)
+    img, feat = rep["image"], rep["features"]
+    for k in ("C2", "C3", "C4", "C5", "P3", "P4", "P5", "P6", "P7"):
+        assert img[k]["rel_fro"] < 0.02, (k, img[k])
+    for k in ("cls_logits", "bbox_pred", "centerness", "cof", "basis"):
+        assert img[k]["rel_fro"] < 0.04, (k, img[k])
+        assert feat[k]["rel_fro"] < 0.02, (k, feat[k])
+    assert img["mask_logits"]["rel_fro"] < 0.05 and feat["mask_logits"]["rel_fro"] < 0.025
+    for d in rep["detections"]:
+        assert d["ndet_engine"] > 0 and d["ndet_oracle"] > 0
