@@ -15,6 +15,7 @@ import re
 import torch
 
 from .engine import SipMaskEngine
+from .plan_cache import PlanCache
 
 DEFAULTS = dict(num_classes=81, fpn_strides=(8, 16, 32, 64, 128), inference_th=0.05, pre_nms_top_n=1000, nms_th=0.6,
                 detections_per_img=100, norm_reg_targets=True, centerness_on_reg=True, num_convs=4)
@@ -87,21 +88,20 @@ class SipMaskBenchmark:
         sd = state_dict if any(k.startswith("bbox_head.") for k in state_dict) else convert_state_dict(state_dict)
         self.sd = {k: v.detach() for k, v in sd.items()}
         self.depth, self.device = depth, device
-        self._engines = {}
+        self._engines = PlanCache()
 
     def prepare(self, batch, img_hw, image_size, ori_wh):
         key = (batch, tuple(img_hw), tuple(image_size), tuple(ori_wh))
-        eng = self._engines.get(key)
-        if eng is None:
+        def build():
             c = self.cfg
             h, w = image_size
             sf = min(h / ori_wh[1], w / ori_wh[0])          # inference.py:198 (np.minimum of the two ratios)
-            eng = SipMaskEngine(self.sd, batch, img_hw, self.depth, None, c["num_classes"], self.device,
-                                tuple(c["fpn_strides"]), (int(h), int(w), 3), scale_factor=sf,
-                                benchmark=dict(pre_nms_thresh=c["inference_th"], pre_nms_top_n=c["pre_nms_top_n"],
-                                               nms_thresh=c["nms_th"], post_top_n=c["detections_per_img"]))
-            self._engines = {key: eng}
-        return eng
+            return SipMaskEngine(self.sd, batch, img_hw, self.depth, None, c["num_classes"], self.device,
+                                 tuple(c["fpn_strides"]), (int(h), int(w), 3), scale_factor=sf,
+                                 benchmark=dict(pre_nms_thresh=c["inference_th"], pre_nms_top_n=c["pre_nms_top_n"],
+                                                nms_thresh=c["nms_th"], post_top_n=c["detections_per_img"]))
+        # self.sd holds the caller's tensors: an in-place update of any of them invalidates the plans
+        return self._engines.get(key, list(self.sd.values()), build)
 
     def __call__(self, images, image_sizes, img_metas):
         b = images.shape[0]

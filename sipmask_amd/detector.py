@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from . import modules, sipmask_head  # noqa: F401  (register ResNet / FPN / SipMaskHead)
+from .plan_cache import PlanCache, module_tensors
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
 
@@ -19,7 +20,7 @@ class SipMask(nn.Module):
         self.neck = build_neck(neck) if neck is not None else None
         self.bbox_head = build_head(bbox_head)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
-        self._engines = {}
+        self._engines = PlanCache()
         self.init_weights(pretrained=pretrained)
 
     @property
@@ -32,7 +33,7 @@ class SipMask(nn.Module):
         if self.with_neck:
             self.neck.init_weights()
         self.bbox_head.init_weights()
-        self._engines = {}
+        self._engines.clear()
 
     def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False, precision="bf16"):
         """Build (or fetch) the static launch plan for this input geometry; weights are snapshotted,
@@ -45,18 +46,12 @@ class SipMask(nn.Module):
         from .engine import SipMaskEngine
         key = (batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
                rescale, precision)
-        eng = self._engines.get(key)
-        if eng is None:
-            eng = SipMaskEngine(self.state_dict(), batch, img_hw, self.backbone.depth, self.test_cfg,
-                                self.bbox_head.num_classes, strides=self.bbox_head.strides, img_shape=img_shape,
-                                ssd_flag=self.bbox_head.ssd_flag, scale_factor=scale_factor, rescale=rescale,
-                                precision=precision)
-            self._engines = {key: eng}
-        return eng
-
-    def load_state_dict(self, *args, **kwargs):
-        self._engines = {}
-        return super().load_state_dict(*args, **kwargs)
+        # plans are valid for the weights they were built from: PlanCache drops them when any parameter / buffer has
+        # been updated in place since (optimizer.step, load_state_dict, mmcv load_checkpoint)
+        return self._engines.get(key, module_tensors(self), lambda: SipMaskEngine(
+            self.state_dict(), batch, img_hw, self.backbone.depth, self.test_cfg, self.bbox_head.num_classes,
+            strides=self.bbox_head.strides, img_shape=img_shape, ssd_flag=self.bbox_head.ssd_flag,
+            scale_factor=scale_factor, rescale=rescale, precision=precision))
 
     def get_masks(self, img, img_metas=None):
         """Batch-capable tensor-only inference (compare before RLE): dict of device tensors

@@ -67,3 +67,36 @@ def gather_counts(local_counts, device=None):
     bufs = [torch.zeros_like(pad) for _ in range(ws)]
     dist.all_gather(bufs, pad)
     return torch.cat([b[:int(s.item())] for b, s in zip(bufs, sizes)])
+
+
+# ---- SipMask-VIS: shard by VIDEO, never by frame ---------------------------------------------------------------
+# The tracker state (prev_roi_feats / prev_bboxes / prev_det_labels, V/mmdet/models/anchor_heads/sipmask_head.py:
+# 169-171) is sequential inside a video and reset at its first frame (`is_first`, :620-667), so the unit of work
+# that can move between GPUs is a whole video (V/tools/test_video.py runs the frames of a video in order).
+
+def shard_videos(frame_counts, world_size):
+    """Assign whole videos to ranks, balancing the number of FRAMES: longest-processing-time greedy (videos sorted by
+    length, each to the least loaded rank; ties -> lower rank), deterministic on every rank without communication.
+    Returns world_size lists of video indices, each in ascending (dataset) order."""
+    loads = [0] * world_size
+    owned = [[] for _ in range(world_size)]
+    order = sorted(range(len(frame_counts)), key=lambda i: (-int(frame_counts[i]), i))
+    for i in order:
+        r = min(range(world_size), key=lambda q: (loads[q], q))
+        owned[r].append(i)
+        loads[r] += int(frame_counts[i])
+    return [sorted(v) for v in owned]
+
+
+def run_videos(videos, frame_fn, reset_fn, rank=None, world_size=None):
+    """Run this rank's share of ``videos`` (list of frame lists): ``reset_fn()`` at every video start (is_first),
+    then ``frame_fn(video_index, frame_index, frame)`` strictly in frame order.  Returns {video index: [results]}.
+    No collective: results are merged on the host afterwards (gather_counts / the reference's pickle collection)."""
+    if rank is None:
+        rank, world_size = world()
+    mine = shard_videos([len(v) for v in videos], world_size)[rank]
+    out = {}
+    for vi in mine:
+        reset_fn()
+        out[vi] = [frame_fn(vi, fi, fr) for fi, fr in enumerate(videos[vi])]
+    return out

@@ -14,7 +14,14 @@ import torch.distributed as dist
 class GradBucketer:
     """Flat f32 gradient buckets filled in reverse parameter order (the order backward produces them); a bucket's
     asynchronous all-reduce starts from the post-accumulate hook of its last parameter; finish() waits, averages
-    and scatters the result back into .grad (views, no copy back when grads alias the flat buffer)."""
+    and scatters the result back into .grad (views, no copy back when grads alias the flat buffer).
+
+    Collective ORDER is fixed: bucket k is launched only after buckets 0..k-1 have been launched, on every rank.
+    Which parameters receive a gradient can differ between ranks (an image batch without positives gives
+    loss_mask = area.sum()*0 with no graph, so sip_cof / sip_mask_lat get no gradient on that rank only): a rank
+    whose bucket never fills defers it -- and every later bucket -- to finish(), which launches the rest in index
+    order, so all ranks issue the same sequence of equally sized all-reduces (no RCCL hang, no mispaired buffers).
+    Parameters without a gradient contribute zeros, as DDP(find_unused_parameters=True) would."""
 
     def __init__(self, params, bucket_bytes=64 << 20, process_group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -34,6 +41,7 @@ class GradBucketer:
         for bi, b in enumerate(self.buckets):
             for i, p in enumerate(b["params"]):
                 self._where[id(p)] = (bi, i)
+        self._next = 0                    # first bucket whose all-reduce has not been launched this step
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _close(self, ps):
@@ -45,20 +53,27 @@ class GradBucketer:
             o += p.numel()
         self.buckets.append(dict(flat=flat, params=list(ps), offsets=offs, pending=len(ps), work=None))
 
+    def _launch_ready(self, force=False):
+        """launch, in index order, every bucket that is full (all of them when force)"""
+        while self._next < len(self.buckets) and (force or self.buckets[self._next]["pending"] == 0):
+            b = self.buckets[self._next]
+            if self.world > 1:
+                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._next += 1
+
     def _on_grad(self, p):
         bi, i = self._where[id(p)]
         b = self.buckets[bi]
         b["flat"][b["offsets"][i]:b["offsets"][i] + p.numel()].copy_(p.grad.reshape(-1))
         b["pending"] -= 1
-        if b["pending"] == 0 and self.world > 1:
-            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if b["pending"] == 0:
+            self._launch_ready()
 
     def finish(self):
         """Wait for every bucket, turn sums into means, write them back.  Parameters that received no gradient this
         step contribute zeros (as DDP with find_unused_parameters would)."""
-        for b in self.buckets:
-            if b["pending"] > 0 and self.world > 1:        # some parameter had no grad: reduce what there is
-                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._launch_ready(force=True)                     # buckets with a missing gradient: reduce what there is
+        self._next = 0
         for b in self.buckets:
             if b["work"] is not None:
                 b["work"].wait()
@@ -106,6 +121,9 @@ class HipSGD:
             if first:
                 it["buf"] = torch.zeros_like(p, dtype=torch.float32)
             H.sgd_step(p.data, p.grad.detach().float().contiguous(), it["buf"], it["lr"], self.momentum, it["wd"], first)
+            # the kernel wrote through the raw pointer: tell autograd / the launch-plan caches (plan_cache.py) that
+            # this parameter changed
+            torch.autograd.graph.increment_version(p)
 
 
 def head_train_step(head, feats, gt_bboxes, gt_labels, gt_masks, img_metas, optimizer, bucketer=None, train_cfg=None):

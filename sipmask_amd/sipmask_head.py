@@ -10,6 +10,7 @@ import torch.nn as nn
 from . import hip_ops as H
 from .modules import ConvModule, bias_init_with_prob, normal_init
 from .ops import CropSplit, CropSplitGt, DeformConv, Scale
+from .plan_cache import PlanCache, module_tensors
 from .registry import HEADS, build_loss
 
 INF = 1e8
@@ -58,7 +59,7 @@ class SipMaskHead(nn.Module):
         self.center_sampling, self.center_sample_radius = center_sampling, center_sample_radius
         self.ssd_flag, self.rescoring_flag = ssd_flag, rescoring_flag
         self.nc = 32
-        self._engines = {}
+        self._engines = PlanCache()
         self._init_layers()
 
     def _init_layers(self):
@@ -102,19 +103,17 @@ class SipMaskHead(nn.Module):
         normal_init(self.sip_mask_lat, std=0.01)
         normal_init(self.sip_mask_lat0, std=0.01)
         self.feat_align.init_weights()
-        self._engines = {}
+        self._engines.clear()
 
     # ------------------------------------------------------------------ forward (HIP engine, head mode)
     def _engine(self, batch, sizes, img_shape=None, cfg=None):
         from .engine import SipMaskEngine
         key = (batch, tuple(sizes), tuple(img_shape or ()), repr(cfg))
-        eng = self._engines.get(key)
-        if eng is None:
+        def build():
             sd = {"bbox_head." + k: v for k, v in self.state_dict().items()}
-            eng = SipMaskEngine.for_head(sd, batch, sizes, num_classes=self.num_classes, strides=self.strides,
-                                         test_cfg=cfg, img_shape=img_shape, ssd_flag=self.ssd_flag)
-            self._engines = {key: eng}     # one cached plan; weights are snapshotted at build time
-        return eng
+            return SipMaskEngine.for_head(sd, batch, sizes, num_classes=self.num_classes, strides=self.strides,
+                                          test_cfg=cfg, img_shape=img_shape, ssd_flag=self.ssd_flag)
+        return self._engines.get(key, module_tensors(self), build)   # rebuilt when any weight has changed since
 
     # ------------------------------------------------------------------ forward, training mode (autograd)
     def _tower_train(self, x, convs):

@@ -75,5 +75,35 @@ def calibrate_cls_bias(det, engine, img, target_per_img=1000, score_thr=0.05):
     b = 0.5 * (lo + hi)
     with torch.no_grad():
         det.bbox_head.fcos_cls.bias.fill_(b)
-    det._engines = {}
     return b
+
+
+# V/configs/sipmask/sipmask_r50_caffe_fpn_gn_1x.py (V/ = SipMask-VIS/): 41 classes, stacked_convs=3, test_cfg :51-56
+VIS_TEST_CFG = dict(nms_pre=200, min_bbox_size=0, score_thr=0.03, nms=dict(type='nms', iou_thr=0.5), max_per_img=10)
+
+
+def build_synthetic_vis_detector(seed=0):
+    """BASELINE config #5: SipMask-VIS R50 (track head), reference init + the same calibration overrides."""
+    from . import vis_head  # noqa: F401  (registers SipMaskVIS / SipMaskVISHead)
+    torch.manual_seed(seed)
+    cfg = model_cfg(50)
+    cfg['type'] = 'SipMaskVIS'
+    cfg['bbox_head'].update(type='SipMaskVISHead', num_classes=41, stacked_convs=3)
+    det = build_detector(cfg, train_cfg=None, test_cfg=dict(VIS_TEST_CFG))
+    h = det.bbox_head
+    with torch.no_grad():
+        for n, p in det.backbone.named_parameters():
+            if n.endswith("bn3.weight"):
+                p.fill_(1.0)
+        torch.nn.init.normal_(h.feat_align.conv_offset.weight, std=0.2)
+        for m in list(h.cls_convs) + list(h.reg_convs) + list(h.track_convs):
+            m.conv.weight.mul_(3.0)
+        h.feat_align.conv_adaption.weight.mul_(3.0)
+        h.fcos_reg.weight.mul_(3.0)
+        h.fcos_reg.bias.fill_(2.0)
+        h.fcos_cls.weight.mul_(8.0)
+        torch.nn.init.normal_(h.sip_cof.weight, std=0.05)
+        h.sip_mask_lat.weight.mul_(4.0)
+        h.sip_mask_lat0.weight.mul_(4.0)
+    det.eval()
+    return det

@@ -14,6 +14,7 @@ import torch.nn as nn
 from . import hip_ops as H
 from .detector import SipMask
 from .modules import ConvModule
+from .plan_cache import module_tensors
 from .registry import DETECTORS, HEADS
 from .sipmask_head import SipMaskHead
 
@@ -45,13 +46,11 @@ class SipMaskVISHead(SipMaskHead):
     def _engine(self, batch, sizes, img_shape=None, cfg=None):
         from .engine import SipMaskEngine
         key = (batch, tuple(sizes), tuple(img_shape or ()), repr(cfg))
-        eng = self._engines.get(key)
-        if eng is None:
+        def build():
             sd = {"bbox_head." + k: v for k, v in self.state_dict().items()}
-            eng = SipMaskEngine.for_head(sd, batch, sizes, num_classes=self.num_classes, strides=self.strides,
-                                         test_cfg=cfg, img_shape=img_shape, vis=True)
-            self._engines = {key: eng}
-        return eng
+            return SipMaskEngine.for_head(sd, batch, sizes, num_classes=self.num_classes, strides=self.strides,
+                                          test_cfg=cfg, img_shape=img_shape, vis=True)
+        return self._engines.get(key, module_tensors(self), build)
 
     def _track_train(self, feats):
         from . import ops as P
@@ -188,13 +187,9 @@ class SipMaskVIS(SipMask):
         from .engine import SipMaskEngine
         key = (batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
                rescale)
-        eng = self._engines.get(key)
-        if eng is None:
-            eng = SipMaskEngine(self.state_dict(), batch, img_hw, self.backbone.depth, self.test_cfg,
-                                self.bbox_head.num_classes, strides=self.bbox_head.strides, img_shape=img_shape,
-                                scale_factor=scale_factor, rescale=rescale, vis=True)
-            self._engines = {key: eng}
-        return eng
+        return self._engines.get(key, module_tensors(self), lambda: SipMaskEngine(
+            self.state_dict(), batch, img_hw, self.backbone.depth, self.test_cfg, self.bbox_head.num_classes,
+            strides=self.bbox_head.strides, img_shape=img_shape, scale_factor=scale_factor, rescale=rescale, vis=True))
 
     def simple_test(self, img, img_meta, rescale=False):
         assert img.shape[0] == 1, "only support one image at a time (V/...:621)"

@@ -97,3 +97,130 @@ def test_bucketed_gradient_allreduce_gloo_world2():
             mean = (np.asarray(a) + np.asarray(b)) / 2
             np.testing.assert_allclose(np.asarray(x0), mean, rtol=1e-6, atol=1e-7)
             np.testing.assert_allclose(np.asarray(x1), mean, rtol=1e-6, atol=1e-7)
+
+
+def _uneven_worker(rank, world, port, out):
+    """rank 1 has a branch that receives NO gradient (the 'image batch without positives' case: loss_mask has no
+    graph on that rank, so sip_cof / sip_mask_lat get no .grad there while the other rank's do)"""
+    import torch.nn as nn
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sipmask_amd.dist_train import GradBucketer
+    torch.manual_seed(0)
+    trunk = nn.Linear(16, 32)
+    head_a = nn.Linear(32, 40)            # always used
+    head_b = nn.Linear(32, 24)            # the "mask branch": used on rank 0 only
+    params = list(trunk.parameters()) + list(head_a.parameters()) + list(head_b.parameters())
+    b = GradBucketer(params, bucket_bytes=1024)                 # 1 KB buckets: several, of different sizes
+    sizes = [bk["flat"].numel() for bk in b.buckets]
+    g = torch.Generator().manual_seed(7 + rank)
+    res = []
+    for step in range(2):
+        for p in params:
+            p.grad = None
+        x = torch.randn(4, 16, generator=g)
+        h = torch.relu(trunk(x))
+        loss = head_a(h).square().sum()
+        if rank == 0:
+            loss = loss + head_b(h).square().sum()
+        loss.backward()
+        local = [(None if p.grad is None else p.grad.clone()) for p in params]
+        b.finish()
+        res.append(([None if t is None else t.numpy().tolist() for t in local],
+                    [p.grad.clone().numpy().tolist() for p in params]))
+    out[rank] = (sizes, res)
+    dist.destroy_process_group()
+
+
+def test_bucket_order_is_rank_independent_when_a_rank_misses_gradients():
+    """with per-bucket launches straight from the hooks, a rank without gradients for one bucket would issue
+    its all-reduces in a different order than its peers (mismatched sizes -> hang / wrong sums).  Buckets are now
+    launched strictly in index order; missing gradients count as zeros (mean over ranks)."""
+    import numpy as np
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_uneven_worker, args=(2, port, out), nprocs=2, join=True)
+        (s0, r0), (s1, r1) = out[0], out[1]
+    assert s0 == s1 and len(s0) >= 3 and len(set(s0)) > 1        # several buckets of different sizes
+    for step in range(2):
+        l0, m0 = r0[step]
+        l1, m1 = r1[step]
+        for a, c, x0, x1 in zip(l0, l1, m0, m1):
+            za = np.zeros_like(np.asarray(x0)) if a is None else np.asarray(a)
+            zc = np.zeros_like(np.asarray(x0)) if c is None else np.asarray(c)
+            mean = (za + zc) / 2
+            np.testing.assert_allclose(np.asarray(x0), mean, rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(np.asarray(x1), mean, rtol=1e-6, atol=1e-7)
+        assert any(c is None for c in l1) and all(a is not None for a in l0)
+
+
+def _video_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sipmask_amd.dist_shard import run_videos
+    videos = [list(range(n)) for n in (8, 3, 5, 9, 2)]           # 5 videos of different lengths
+    state = {"prev": None, "resets": 0}
+
+    def reset():
+        state["prev"], state["resets"] = None, state["resets"] + 1
+
+    def frame(vi, fi, fr):
+        # a stand-in tracker: needs the previous frame of THE SAME video (sequential state), reset at frame 0
+        assert (fi == 0) == (state["prev"] is None) and (fi == 0 or state["prev"] == (vi, fi - 1))
+        state["prev"] = (vi, fi)
+        return vi * 100 + fr
+
+    res = run_videos(videos, frame, reset)
+    frames = sum(len(v) for v in res.values())
+    all_frames = gather_counts([frames])
+    out[rank] = ({k: v for k, v in res.items()}, state["resets"], all_frames.tolist())
+    dist.destroy_process_group()
+
+
+def test_vis_clips_are_sharded_by_video_world2():
+    """BASELINE config #5 / SURVEY 8(e): VIS shards whole videos (tracker state is sequential inside a clip,
+    V/mmdet/models/anchor_heads/sipmask_head.py:169-171,620-667): every video on exactly one rank, frames in order,
+    tracker reset per video, frame counts balanced."""
+    from sipmask_amd.dist_shard import shard_videos
+    assert shard_videos([8, 3, 5, 9, 2], 2) == [[1, 3, 4], [0, 2]]          # 14 vs 13 frames
+    assert shard_videos([4, 4, 4], 1) == [[0, 1, 2]]
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_video_worker, args=(2, port, out), nprocs=2, join=True)
+        (r0, n0, f0), (r1, n1, f1) = out[0], out[1]
+    assert sorted(list(r0) + list(r1)) == [0, 1, 2, 3, 4] and not (set(r0) & set(r1))
+    assert n0 == len(r0) and n1 == len(r1)
+    for res in (r0, r1):
+        for vi, frames in res.items():
+            assert frames == [vi * 100 + f for f in range(len(frames))]
+    assert f0 == f1 == [14, 13]
+
+
+def test_bench_self_launches_its_ranks_cpu_stub():
+    """`python bench.py --gpus 2` with no launcher must become 2 ranks (it silently measured one GPU).
+    SIPMASK_BENCH_STUB=1 swaps the GPU work for a sleeping step and RCCL for gloo; everything else -- re-exec under
+    torch.distributed.run, rendezvous on 127.0.0.1, barrier-fenced timing, rank-0 JSON line -- is the real path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SIPMASK_BENCH_STUB="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == [0, 1] and d["steps"] == 3
+    assert d["ms_per_step"] >= 20.0 - 1.0          # MAX over ranks: rank 1 sleeps 20 ms per step
+    # and a mismatching launcher is an error, not a silent 1-GPU run
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env1, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
