@@ -303,11 +303,10 @@ def run_train(args, rank, world, dev):
     elapsed = timed_steps(step, args.steps, sync_fn=torch.cuda.synchronize, device=dev)
     # whole-step MFMA fraction: forward + data-gradient + weight-gradient GEMMs of every trained conv ~ 3x the
     # inference conv FLOPs of the trained part (stem + layer1 run without a graph: 1x)
-    from sipmask_amd.engine import SipMaskEngine   # FLOP accounting only (host logic)
     fwd_gflop = 450.9 * B                           # conv FLOPs per image
     train_gflop = fwd_gflop * 3.0 - 2.0 * (2.5 + 14.3) * 2 * B
     ms = elapsed / args.steps * 1e3
-    achieved = train_gflop / ms / 1e3
+    achieved = train_gflop / ms                     # GFLOP per ms = TFLOP/s
     out = {
         "metric": "img/s SipMask-R%d training step (forward_train + loss + backward + gradient all-reduce + SGD)" % args.depth,
         "value": round(B * args.steps * world / elapsed, 3),
@@ -349,9 +348,33 @@ def run_vis(args, rank, world, dev):
     mine = shard_videos([VIS_T] * clips_per_step, world)[rank]
     frames_dev = {vi: [f.to(dev) for f in clip_frames[vi]] for vi in mine}
     counts = []
+    # one frame = ~100 small launches at batch 1: replay them as ONE hipGraph per frame (static input buffer)
+    static = torch.zeros(1, 3, VIS_H, VIS_W, device=dev)
+    graph = None
+    if not args.no_graph:
+        try:
+            eng.run(static)
+            torch.cuda.synchronize()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                eng.run(static)
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eng.run(static)
+        except Exception as e:
+            print("[bench] graph capture failed (%s); running eagerly" % str(e)[:200], file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
 
     def frame_fn(vi, fi, frame):
-        r = eng.run(frame)
+        if graph is not None:
+            static.copy_(frame)
+            graph.replay()
+            r = eng.results()
+        else:
+            r = eng.run(frame)
         n = int(r["ndet"][0])                        # the tracker needs the count on the host (as the reference does)
         if n:
             det.bbox_head.match(r["det_bboxes"][0, :n], r["det_labels"][0, :n], r["det_feats"][0, :n], fi == 0)
@@ -379,6 +402,7 @@ def run_vis(args, rank, world, dev):
         "config": {"workload": "SipMask-VIS R50, clips of %d frames 3x%dx%d (640x360 padded), 1 clip per GPU per step, frames "
                                "in order (tracker state), batch 1 per frame as the reference asserts" % (VIS_T, VIS_H, VIS_W),
                    "global_batch": clips_per_step, "parallelism": "dp%d (sharded by video, no collective)" % world,
+                   "launch": "hipGraph replay per frame" if graph is not None else "eager",
                    "detections_last_step_this_rank": counts},
         "roofline": {"bound": "mfma", "achieved": round(flops / ms_frame / 1e9, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(flops / ms_frame / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,

@@ -58,6 +58,7 @@ typedef enum {
 #define SM_CONV_DBG_LEGACY_LOOP 0x00100000u  /* A/B switch: the original K loop (branchy loader, one fragment register set) on the 128/64-cout tiles */
 #define SM_CONV_DBG_K32_OPT 0x00080000u      /* A/B switch: flat loader + peeled loop + pipelined fragment reads in the 32-wide-K kernel (cin >= 32) */
 #define SM_CONV_DBG_HAND_PLACED 0x00040000u  /* A/B switch (with TILE256): hand-placed K step, LDS-DMA pieces between the MFMAs */
+#define SM_CONV_DBG_RES_PREFETCH 0x00020000u /* A/B switch: 32-wide-K kernel loads the residual rows BEFORE the K loop (HBM-bound 1x1 + residual convs) */
 #define SM_CONV_DBG_WARP_SPEC 0x02000000u    /* A/B switch: 8-wave producer/consumer variant of the 64-wide-K kernel */
 
 /* One (multi-level) 2-D convolution as an implicit GEMM.  Replaces the ATen/cuDNN
@@ -322,6 +323,20 @@ int sm_mask_assemble(const float* basis, int basis_hwc, const float* cofs, const
                      int hm, int wm, int ho, int wo, int mask_pitch, float box_mul_x, float box_mul_y, float box_div,
                      double up_scale_h, double up_scale_w, float mask_thr, uint8_t* masks, float* pos_masks,
                      sm_stream_t stream);
+
+/* sm_mask_assemble for a launch plan that owns its buffers: the basis is given at its CONV resolution (basis_lo f32
+ * [B][lo_h][lo_w][32], the relu(sip_mask_lat) output BEFORE the bilinear x`factor` of sipmask_head.py:285; Hm = lo_h *
+ * factor) and interpolated after the coefficient dot product (bilinear interpolation is linear: equal to the reference
+ * order up to f32 rounding), and only the 128x8-pixel tiles of each detection's box rectangle are written, plus zeros
+ * over the tiles the same slot covered in the previous call.  `state` int32 [batch*max_num][4] carries those tile
+ * ranges between calls: zero it together with `masks` when the buffer is created, never touch either in between.
+ * After the call `masks` holds exactly what sm_mask_assemble would have written (zeros outside the rectangles). */
+int64_t sm_mask_assemble_lo_workspace(int batch, int max_num);
+int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, int factor, const float* cofs, const int64_t* keep,
+                        const float* det, const int32_t* ndet, int batch, int kmax, int max_num, int ho, int wo,
+                        int mask_pitch, float box_mul_x, float box_mul_y, float box_div, double up_scale_h,
+                        double up_scale_w, float mask_thr, uint8_t* masks, int32_t* state, void* workspace,
+                        sm_stream_t stream);
 
 /* SipMask++ rescoring tail (sipmask_head.py:638-641): mask_scores[b][i] = max over the hw positions of
  * feat[(b*max_num+i)*hw + p][labels[b][i]] (feat = relu(mask_scoring(convs_scoring(pos_masks))), f32 NHWC rows)

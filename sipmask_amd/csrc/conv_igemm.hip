@@ -1001,7 +1001,10 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
 // =====================================================================================
 // OPT = 3 (A/B flag SM_CONV_DBG_K32_OPT, cin >= 32): the K-loop treatment of conv_igemm_kernel's OPT 3 -- flat loader,
 // peeled loop, fragments of the second K sub-step read under the MFMAs of the first.
-template <int WCO, int WPOS, int TCO, int TPOS, int MINB = 4, int OPT = 0>
+// RESPF (A/B flag SM_CONV_DBG_RES_PREFETCH): the same-row residual of the register epilogue is loaded BEFORE the K
+// loop, so its HBM latency overlaps the operand DMA and the MFMAs instead of following them (the 1x1 + residual convs
+// of layer1/2 run 2 K steps per tile: load -> MFMA -> residual load -> store was four serial latencies per block).
+template <int WCO, int WPOS, int TCO, int TPOS, int MINB = 4, int OPT = 0, bool RESPF = false>
 __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a) {
   constexpr int BCO = WCO * TCO * 32;
   constexpr int BPOS = WPOS * TPOS * 32;
@@ -1143,6 +1146,23 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
     }
   };
 
+  // ---- residual prefetch (RESPF): the register epilogue's 16-byte residual pieces, addressed exactly as below
+  u32x4 resv[RESPF ? TPOS : 1][RESPF ? TCO : 1][2];
+  if constexpr (RESPF) {
+#pragma unroll
+    for (int tp = 0; tp < TPOS; ++tp) {
+      const int m = m0 + wpos * TPOS * 32 + tp * 32 + (lane & 31);
+      const long long rrow = a.out_row0[lev] + (m < M ? m : 0);
+#pragma unroll
+      for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          const int c0 = nt * BCO + wco * TCO * 32 + tc * 32 + 8 * (2 * qp + (lane >> 5));
+          const int cc = c0 < a.cout ? c0 : 0;
+          resv[tp][tc][qp] = *reinterpret_cast<const u32x4*>(a.res + rrow * a.res_cstride + cc);
+        }
+    }
+  }
   const int nk = a.nk * 2;   // Kp is a multiple of 64
   if constexpr (OPT != 0) {
     const int wave_row_s = __builtin_amdgcn_readfirstlane(wave) * 16;
@@ -1286,7 +1306,8 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
           }
           if (has_res0) {
             float f[8];
-            unpack_bf16x8(*reinterpret_cast<const u32x4*>(a.res + rrow * a.res_cstride + c0), f);
+            if constexpr (RESPF) unpack_bf16x8(resv[tp][tc][qp], f);
+            else unpack_bf16x8(*reinterpret_cast<const u32x4*>(a.res + rrow * a.res_cstride + c0), f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += f[e];
           }
@@ -1626,6 +1647,9 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 2, DEFORM, false>));
   } else if (k32) {
     const bool o3 = opt == 3;
+    // residual prefetch: same-row residual + the register epilogue's alignment conditions (the kernel's reg_epi test)
+    const bool respf = (d->flags & SM_CONV_DBG_RES_PREFETCH) && (d->flags & SM_CONV_RES_ADD) && !(d->flags & SM_CONV_DBG_LDS_EPILOGUE) &&
+                       (d->cout & 7) == 0 && (d->out_cstride & 7) == 0 && (d->out_coff & 7) == 0 && (d->res_cstride & 7) == 0;
     if (o3 && bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2, 4, 3>));
     else if (o3 && bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1, 4, 3>));
     else if (o3 && bco == 64 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 2, 4, 3>));
@@ -1634,6 +1658,8 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else if (o3 && bco == 32 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 2, 4, 3>));
     else if (o3 && bco == 32) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 1, 4, 3>));
     else if (bco == 128 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 4, 2>));
+    else if (respf && bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2, 4, 0, true>));
+    else if (respf && bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1, 4, 0, true>));
     else if (bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2>));
     else if (bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1>));
     else if (bco == 64 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 2>));

@@ -27,11 +27,22 @@ __device__ __forceinline__ unsigned long long compose_key(uint32_t okey, uint32_
   return ((unsigned long long)okey << 32) | (unsigned long long)(0xffffffffu - idx);
 }
 
-// bitonic sort, descending, P = power of two, all threads of the block participate
-__device__ void block_bitonic_desc(unsigned long long* a, int P) {
+// bitonic sort, descending, P = power of two, all threads of the block participate.
+// Pair t of a compare-exchange step touches pos = 2t - (t & (stride-1)) and pos + stride: for stride <= 64 the 64
+// pairs of a wave lie inside the wave's own 128-element block [128w, 128w+128) (and [128(w+nw), ...) on the next
+// trip of the t loop), so consecutive steps with stride <= 64 need no block barrier -- LDS / L1 accesses of ONE wave
+// are ordered, a wave-level fence is enough.  Only steps with stride >= 128 exchange data between waves: P = 1024
+// takes 9 block barriers instead of 55 (the sort was most of det_topk / nms_class for the heavy classes).
+__device__ void block_bitonic_desc(unsigned long long* a, int P, bool in_lds = true) {
+  bool cross = true;      // the data this step reads may have been written by another wave
   for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      __syncthreads();
+      if (stride >= 128 || cross) __syncthreads();
+      else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      cross = stride >= 128 || !in_lds;   // global scratch (heavy NMS classes): block barrier after every step
       for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
         const int pos = 2 * t - (t & (stride - 1));
         const unsigned long long x = a[pos], y = a[pos + stride];
@@ -68,6 +79,8 @@ __device__ void block_topk(const float* __restrict__ gkeys, int n, int k, TopkSm
     if (tid < 256) sm.hist[tid] = 0;
     __syncthreads();
     const uint32_t prefix = sm.prefix;
+    // (a wave-aggregated update -- one ballot + one atomic per distinct digit -- was measured SLOWER here, 0.131 vs
+    // 0.111 ms for det_select: same-address LDS atomics of one wave are already combined by the hardware)
     for (int i = tid; i < n; i += TK_THREADS) {
       const uint32_t u = float_to_ordered(keys[i]);
       if (round == 0 || (u >> (shift + 8)) == prefix) atomicAdd(&sm.hist[(u >> shift) & 255u], 1u);
@@ -350,6 +363,25 @@ __device__ __forceinline__ float iou_plus1(const float4 a, const float4 b) {
   return __fdiv_rn(inter, __fsub_rn(__fadd_rn(sa, sb), inter));
 }
 
+// IoU(+1)(a, b) > thr with the exact semantics of `iou_plus1(a, b) > thr` (f32 division, round to nearest) at a third
+// of its cost: inter - thr * union decides directly unless it is within 1e-5 * union of zero (a quotient within
+// 1e-5 of thr; the division's own rounding moves it by 6e-8), and only those borderline pairs -- and non-finite
+// boxes -- pay for the division.
+__device__ __forceinline__ bool iou_plus1_gt(const float4 a, const float4 b, float thr) {
+  const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
+  const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+  const float width = fmaxf(__fadd_rn(__fsub_rn(right, left), 1.f), 0.f);
+  const float height = fmaxf(__fadd_rn(__fsub_rn(bottom, top), 1.f), 0.f);
+  const float inter = __fmul_rn(width, height);
+  const float sa = __fmul_rn(__fadd_rn(__fsub_rn(a.z, a.x), 1.f), __fadd_rn(__fsub_rn(a.w, a.y), 1.f));
+  const float sb = __fmul_rn(__fadd_rn(__fsub_rn(b.z, b.x), 1.f), __fadd_rn(__fsub_rn(b.w, b.y), 1.f));
+  const float uni = __fsub_rn(__fadd_rn(sa, sb), inter);
+  const float t = fmaf(-thr, uni, inter);
+  if (fabsf(t) > 1e-5f * fabsf(uni) && fabsf(uni) < 3e38f) return t > 0.f;     // NaN / inf fall through
+  return __fdiv_rn(inter, uni) > thr;
+}
+
+constexpr int NMS_P_LDS = 2048;   // LDS working-set capacity per (image, class): 56 KB -> 2 blocks per CU
 constexpr int NMS_THREADS = 1024;  // 16 waves per (image, class): heavy classes (thousands of boxes) set the tail
 
 // LDS carve (dynamic): keys[P] (u64), kept_box[P] (float4), kept_idx[P] (u32); static: NmsSmem.
@@ -357,6 +389,7 @@ struct NmsSmem {
   unsigned long long rowm[64];                    // intra-chunk suppression rows (bits > t only)
   unsigned long long alive_w[NMS_THREADS / 64];   // per-wave "not suppressed by a kept box" masks
   unsigned int n;
+  int nkept;
 };
 
 // Greedy NMS over the n sorted entries in keys (low word = 0xffffffff - candidate index), all
@@ -384,7 +417,7 @@ __device__ int block_greedy_nms(const unsigned long long* keys, int n, float thr
     // (a) suppression by already-kept boxes, kept list striped over the waves
     bool alive = valid;
     for (int kk = wv; kk < nkept; kk += NW) {
-      if (alive && iou_plus1(kept_box[kk], mine) > thr) alive = false;
+      if (alive && iou_plus1_gt(kept_box[kk], mine, thr)) alive = false;
     }
     const unsigned long long aw = __ballot(alive);
     if (lane == 0) sm.alive_w[wv] = aw;
@@ -395,39 +428,42 @@ __device__ int block_greedy_nms(const unsigned long long* keys, int n, float thr
       bt.y = __shfl(mine.y, t);
       bt.z = __shfl(mine.z, t);
       bt.w = __shfl(mine.w, t);
-      const bool hit = valid && lane > t && (base + t) < n && iou_plus1(bt, mine) > thr;
+      const bool hit = valid && lane > t && (base + t) < n && iou_plus1_gt(bt, mine, thr);
       const unsigned long long row = __ballot(hit);
       if (lane == 0) sm.rowm[t] = row;
     }
     __syncthreads();
-    // (c) scalar resolve (every wave redundantly; all operands are wave-uniform)
-    unsigned long long am = sm.alive_w[0];
+    // (c) scalar resolve + (d) append, by wave 0 alone (the 64 dependent steps are serial anyway; 16 waves doing them
+    // redundantly only fought for the issue slots of the 4 SIMDs)
+    if (wv == 0) {
+      unsigned long long am = sm.alive_w[0];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) am &= sm.alive_w[w];
-    const unsigned long long myrow = sm.rowm[lane];
-    for (int t = 0; t < 64; ++t) {
-      const unsigned long long rt = __shfl(myrow, t);
-      if ((am >> t) & 1ull) am &= ~rt;
+      for (int w = 1; w < NW; ++w) am &= sm.alive_w[w];
+      const unsigned long long myrow = sm.rowm[lane];
+      for (int t = 0; t < 64; ++t) {
+        const unsigned long long rt = __shfl(myrow, t);
+        if ((am >> t) & 1ull) am &= ~rt;
+      }
+      if ((am >> lane) & 1ull) {
+        const int slot = nkept + __popcll(am & ((1ull << lane) - 1ull));
+        kept_box[slot] = mine;
+        kept_idx[slot] = idx;
+      }
+      if (lane == 0) sm.nkept = nkept + __popcll(am);
     }
-    // (d) append the survivors in score order
-    if (wv == 0 && ((am >> lane) & 1ull)) {
-      const int slot = nkept + __popcll(am & ((1ull << lane) - 1ull));
-      kept_box[slot] = mine;
-      kept_idx[slot] = idx;
-    }
-    nkept += __popcll(am);
     __syncthreads();
+    nkept = sm.nkept;
   }
   return nkept;
 }
 
 // ascending sort of u32 values through the u64 scratch (whole block)
-__device__ void block_sort_idx_asc(unsigned long long* scratch, const uint32_t* vals, int n) {
+__device__ void block_sort_idx_asc(unsigned long long* scratch, const uint32_t* vals, int n, bool in_lds = true) {
   int P = 1;
   while (P < n) P <<= 1;
   for (int i = threadIdx.x; i < P; i += blockDim.x)
     scratch[i] = i < n ? (unsigned long long)(0xffffffffu - vals[i]) : 0ull;
-  block_bitonic_desc(scratch, P);  // descending in (max - idx) == ascending idx; zeros (padding) last
+  block_bitonic_desc(scratch, P, in_lds);  // descending in (max - idx) == ascending idx; zeros (padding) last
 }
 
 struct NmsArgs {
@@ -435,9 +471,13 @@ struct NmsArgs {
   float score_thr, iou_thr;
   int always_sort;   // fast_nms: the final list is always sorted by score (sipmask_head.py:902)
   int top_k;         // fast_nms: boxes kept per class before the IoU test (:871)
-  unsigned char* ext_kept;   // optional [B][C][P] x 20 bytes: kept boxes + indices outside LDS (P > 4096)
+  int P_lds;         // per-class capacity of the LDS working set (keys + kept boxes + indices, 28 bytes per entry)
+  unsigned char* ext;   // [B][C][P] x 28 bytes in HBM/L2: working set of a class with more than P_lds candidates
 };
 
+// One block per (image, class).  A class typically passes score_thr with a few dozen candidates, rarely with
+// thousands, so the LDS working set is sized for P_lds entries (2 blocks per CU: all classes of a batch are resident
+// at once) and the rare heavy class works out of its global scratch slice instead (same code, slower memory).
 __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __restrict__ boxes,
                                                                 const float* __restrict__ scores,
                                                                 const float* __restrict__ ctr,
@@ -446,15 +486,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __r
                                                                 int32_t* __restrict__ cls_cnt, const NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   __shared__ NmsSmem sm;
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(dsm);
-  float4* kept_box = reinterpret_cast<float4*>(dsm + (size_t)a.P * 8);
-  uint32_t* kept_idx = reinterpret_cast<uint32_t*>(dsm + (size_t)a.P * 24);
   const int c = blockIdx.x, b = blockIdx.y;
-  if (a.ext_kept != nullptr) {   // candidate lists too long for keys + kept boxes in LDS: kept list in HBM/L2
-    unsigned char* e = a.ext_kept + ((size_t)b * a.C + c) * (size_t)a.P * 20;
-    kept_box = reinterpret_cast<float4*>(e);
-    kept_idx = reinterpret_cast<uint32_t*>(e + (size_t)a.P * 16);
-  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int K = ncand[b];
   const float* sc = scores + ((long long)b * a.C + c) * a.kmax;   // class-major: contiguous over candidates
@@ -462,8 +494,34 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __r
   const float4* bx = reinterpret_cast<const float4*>(boxes) + (long long)b * a.kmax;
   if (tid == 0) sm.n = 0;
   __syncthreads();
-  // 1. compaction of candidates with raw class score > thr (bbox_nms.py:111).  The order of
-  //    insertion is irrelevant: the sort key (score, index) is a total order.
+  // 0. how many candidates pass the raw class score threshold (bbox_nms.py:111)?  decides LDS vs global scratch
+  {
+    unsigned int cnt = 0;
+    for (int i = tid; i < K; i += NMS_THREADS) cnt += (sc[i] > a.score_thr) ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+    if (lane == 0 && cnt) atomicAdd(&sm.n, cnt);
+  }
+  __syncthreads();
+  const int n = (int)sm.n;
+  __syncthreads();
+  int32_t* outk = cls_keep + ((long long)b * a.C + c) * a.kmax;
+  if (n == 0) {
+    if (tid == 0) cls_cnt[b * a.C + c] = 0;
+    return;
+  }
+  if (tid == 0) sm.n = 0;
+  int P = 1;
+  while (P < n) P <<= 1;
+  const bool in_lds = P <= a.P_lds;
+  unsigned char* ws = in_lds ? dsm : a.ext + ((size_t)b * a.C + c) * (size_t)a.P * 28;
+  const size_t cap = in_lds ? (size_t)a.P_lds : (size_t)a.P;
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws);
+  float4* kept_box = reinterpret_cast<float4*>(ws + cap * 8);
+  uint32_t* kept_idx = reinterpret_cast<uint32_t*>(ws + cap * 24);
+  __syncthreads();
+  // 1. compaction of candidates with raw class score > thr.  The order of insertion is irrelevant: the sort key
+  //    (score, index) is a total order.
   for (int base = 0; base < K; base += NMS_THREADS) {
     const int i = base + tid;
     const float s = (i < K) ? sc[i] : 0.f;
@@ -477,22 +535,14 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __r
       keys[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = compose_key(float_to_ordered(sf), (uint32_t)i);
     }
   }
-  __syncthreads();
-  const int n = (int)sm.n;
-  int32_t* outk = cls_keep + ((long long)b * a.C + c) * a.kmax;
-  if (n == 0) {
-    if (tid == 0) cls_cnt[b * a.C + c] = 0;
-    return;
-  }
-  // 2. sort (score desc, index asc)
-  int P = 1;
-  while (P < n) P <<= 1;
   for (int i = n + tid; i < P; i += NMS_THREADS) keys[i] = 0ull;
-  block_bitonic_desc(keys, P);
+  __syncthreads();
+  // 2. sort (score desc, index asc)
+  block_bitonic_desc(keys, P, in_lds);
   // 3. greedy NMS
   const int nk = block_greedy_nms(keys, n, a.iou_thr, kept_box, kept_idx, sm, [&](uint32_t idx) { return bx[idx]; });
   // 4. reference returns kept ORIGINAL indices ascending (nms_kernel.cu:135-138)
-  block_sort_idx_asc(keys, kept_idx, nk);
+  block_sort_idx_asc(keys, kept_idx, nk, in_lds);
   for (int i = tid; i < nk; i += NMS_THREADS) outk[i] = (int32_t)(0xffffffffu - (uint32_t)keys[i]);
   if (tid == 0) cls_cnt[b * a.C + c] = nk;
 }
@@ -816,7 +866,7 @@ extern "C" int64_t sm_multiclass_nms_workspace(int batch, int kmax, int num_clas
   // cls_keep i32 [B][C][kmax] + flat_key f32 [B][C][kmax] + cls_cnt i32 [B][C]
   int64_t n = (int64_t)batch * num_classes * kmax * 8 + (int64_t)batch * num_classes * 4;
   const int64_t P = next_pow2(kmax);
-  if (P * 28 > 150 * 1024) n = (n + 255) / 256 * 256 + (int64_t)batch * num_classes * P * 20;   // external kept lists
+  if (P > NMS_P_LDS) n = (n + 255) / 256 * 256 + (int64_t)batch * num_classes * P * 28;   // scratch of heavy classes
   return n;
 }
 
@@ -837,17 +887,15 @@ extern "C" int sm_multiclass_nms(const float* boxes, const float* scores, const 
   a.iou_thr = iou_thr;
   a.always_sort = 0;
   a.top_k = 0;
-  a.ext_kept = nullptr;
-  size_t lds = (size_t)a.P * 28;
+  a.P_lds = a.P < NMS_P_LDS ? a.P : NMS_P_LDS;
+  a.ext = nullptr;
+  const size_t lds = (size_t)a.P_lds * 28;
   hipStream_t s = sm_hip_stream(stream);
   int32_t* cls_keep = (int32_t*)workspace;
   float* flat_key = (float*)((char*)workspace + (size_t)batch * num_classes * kmax * 4);
   int32_t* cls_cnt = (int32_t*)((char*)workspace + (size_t)batch * num_classes * kmax * 8);
-  if (lds > 150 * 1024) {        // long candidate lists (the 5 x 1000 pairs of the B/ variant): keys only in LDS
-    lds = (size_t)a.P * 8;
-    if (lds > 150 * 1024) return SM_ERR_UNSUPPORTED;
-    a.ext_kept = (unsigned char*)workspace + (((size_t)batch * num_classes * kmax * 8 + (size_t)batch * num_classes * 4 + 255) / 256) * 256;
-  }
+  if (a.P > NMS_P_LDS)           // classes with more than NMS_P_LDS candidates work out of their global scratch slice
+    a.ext = (unsigned char*)workspace + (((size_t)batch * num_classes * kmax * 8 + (size_t)batch * num_classes * 4 + 255) / 256) * 256;
   if (hipFuncSetAttribute((const void*)nms_class_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return SM_ERR_LAUNCH;
@@ -876,7 +924,8 @@ extern "C" int sm_fast_nms(const float* boxes, const float* scores, const float*
   a.iou_thr = iou_thr;
   a.always_sort = 1;
   a.top_k = top_k;
-  a.ext_kept = nullptr;
+  a.P_lds = 0;
+  a.ext = nullptr;
   hipStream_t s = sm_hip_stream(stream);
   // same workspace layout as sm_multiclass_nms: cls_keep | flat_key | cls_cnt
   int32_t* cls_keep = (int32_t*)workspace;

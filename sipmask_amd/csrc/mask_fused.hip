@@ -1,0 +1,308 @@
+// Mask assembly of the launch plan (sipmask_head.py:275-285 tail + :609-633), detection-centric:
+//
+//   feat_masks = bilinear x4 (relu(sip_mask_lat(...)))            (:285)   [B,32,Hm,Wm]  -- never materialised here
+//   logits_q   = feat_masks . cof_q                               (:616-619)
+//   pos        = CropSplit(sigmoid(logits))                       (:620-624, crop_split_cuda_kernel.cu:34-52)
+//   masks      = bilinear x(2/scale_factor)(pos) > 0.4            (:629-633)
+//
+// Two observations remove almost all of the HBM traffic of sm_mask_assemble (568 MB per 4-image step):
+//  (1) bilinear interpolation is linear, so  (bilinear x4 basis_lo) . cof  ==  bilinear x4 (basis_lo . cof)  up to f32
+//      rounding: the 32-channel basis is only ever read at its conv resolution (h0 x w0 = Hm/4 x Wm/4, 8.6 MB per
+//      4 images instead of 137 MB written by the x4 upsample kernel and read again here), 4 low-resolution quadrant
+//      logit planes per tile are formed in LDS and interpolated;
+//  (2) a mask is zero outside its (conservative) box rectangle, and the masks buffer is owned by the launch plan: only
+//      the tiles of each detection's rectangle are written, plus zeros over the tiles its slot covered in the
+//      PREVIOUS call (per-slot tile ranges kept in a small device-side state buffer).  The buffer contents after the
+//      call are exactly those of sm_mask_assemble (zeros elsewhere); the bytes written drop from N*Ho*Wo to ~2x the
+//      box areas.
+// Work decomposition: a plan kernel turns (detections, previous ranges) into a prefix sum of 128x8-pixel output tiles;
+// a fixed grid of blocks walks that list (binary search in an LDS copy of the prefix).
+#include "common.h"
+
+namespace {
+
+constexpr int MF_THREADS = 256;
+constexpr int MF_TW = 128, MF_TH = 8;    // output tile (pixels): stores cover whole 128-byte lines
+constexpr int MF_SRC_CAP = 640;          // mask-resolution source pixels per tile
+constexpr int MF_LO_CAP = 160;           // low-resolution pixels per tile
+constexpr int MF_MAX_ENTRIES = 4096;     // 2 * batch * max_num work-list entries (prefix copy lives in LDS)
+
+struct MaskFArgs {
+  const float* basis_lo;   // [B][lo_h][lo_w][32]
+  const float* cofs;
+  const int64_t* keep;
+  const float* det;
+  const int32_t* ndet;
+  uint8_t* masks;
+  int32_t* state;          // [B*max_num][4] tile range written by the previous call (tx0, ty0, tx1, ty1), exclusive end
+  int32_t* ranges;         // workspace [B*max_num][8]: new range, previous range
+  int32_t* prefix;         // workspace [2*B*max_num + 1]
+  int batch, kmax, max_num, lo_h, lo_w, factor, hm, wm, ho, wo, pitch;
+  float box_mul_x, box_mul_y, box_div, up_x, up_y, inv_up_x, inv_up_y, inv_f, thr;
+};
+
+// ---- plan: per slot the tile range of the new rectangle (mask_rects_kernel's conservative rule, rle.hip) and of the
+// previous call's; entry 2d = new tiles, 2d+1 = previous tiles; exclusive prefix sum of the tile counts.
+__global__ __launch_bounds__(1024) void mask_plan_kernel(const MaskFArgs a) {
+  __shared__ int s_part[1024 / 64];
+  __shared__ int s_carry;
+  const int nslot = a.batch * a.max_num;
+  const int n2 = 2 * nslot;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ntx = (a.wo + MF_TW - 1) / MF_TW, nty = (a.ho + MF_TH - 1) / MF_TH;
+  if (tid == 0) {
+    s_carry = 0;
+    a.prefix[0] = 0;
+  }
+  __syncthreads();
+  for (int base = 0; base < n2; base += 1024) {
+    const int e = base + tid;
+    int cnt = 0;
+    if (e < n2) {
+      const int d = e >> 1;
+      int r[4];
+      if (e & 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = a.state[d * 4 + k];
+      } else {
+        const int b = d / a.max_num, i = d - b * a.max_num;
+        r[0] = r[1] = r[2] = r[3] = 0;
+        if (i < min(a.ndet[b], a.max_num)) {
+          const float* bx = a.det + (long long)d * 5;
+          const float x1 = bx[0] * a.box_mul_x / a.box_div, y1 = bx[1] * a.box_mul_y / a.box_div;
+          const float x2 = bx[2] * a.box_mul_x / a.box_div, y2 = bx[3] * a.box_mul_y / a.box_div;
+          auto lo = [&](float v, float up) { return (int)fmaxf(fminf(floorf((v - 1.f) * up) - 2.f, 1e9f), -1e9f); };
+          auto hi = [&](float v, float up) { return (int)fmaxf(fminf(ceilf((v + 1.f) * up) + 2.f, 1e9f), -1e9f); };
+          const int px0 = max(lo(x1, a.up_x), 0), py0 = max(lo(y1, a.up_y), 0);
+          const int px1 = min(hi(x2, a.up_x), a.wo), py1 = min(hi(y2, a.up_y), a.ho);
+          if (px1 > px0 && py1 > py0) {
+            r[0] = px0 / MF_TW;
+            r[1] = py0 / MF_TH;
+            r[2] = min((px1 + MF_TW - 1) / MF_TW, ntx);
+            r[3] = min((py1 + MF_TH - 1) / MF_TH, nty);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a.ranges[d * 8 + (e & 1) * 4 + k] = r[k];
+      cnt = max(r[2] - r[0], 0) * max(r[3] - r[1], 0);
+    }
+    // block-wide inclusive scan of cnt (wave shuffles + per-wave partials)
+    int v = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(v, o, 64);
+      if (lane >= o) v += t;
+    }
+    if (lane == 63) s_part[wv] = v;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wv; ++w) woff += s_part[w];
+    const int carry = s_carry;
+    if (e < n2) a.prefix[e + 1] = carry + woff + v;
+    __syncthreads();
+    if (tid == 1023) s_carry = carry + woff + v;
+    __syncthreads();
+  }
+  // the new ranges become the state of the next call (read above, so no race inside this single block)
+  for (int d = tid; d < nslot; d += 1024) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.state[d * 4 + k] = a.ranges[d * 8 + k];
+  }
+}
+
+struct FBox {
+  float x1, y1, x2, y2, rw, rh;
+};
+
+__global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs a) {
+  __shared__ int s_prefix[MF_MAX_ENTRIES + 1];
+  __shared__ __attribute__((aligned(16))) float s_cof[128];
+  __shared__ float s_lo[4][MF_LO_CAP];
+  __shared__ float s_prob[MF_SRC_CAP];
+  const int tid = threadIdx.x;
+  const int n2 = 2 * a.batch * a.max_num;
+  for (int i = tid; i <= n2; i += MF_THREADS) s_prefix[i] = a.prefix[i];
+  __syncthreads();
+  const int total = s_prefix[n2];
+  auto src_x = [&](int o) { return fmaxf(a.inv_up_x * ((float)o + 0.5f) - 0.5f, 0.f); };
+  auto src_y = [&](int o) { return fmaxf(a.inv_up_y * ((float)o + 0.5f) - 0.5f, 0.f); };
+  auto lo_c = [&](int g) { return fmaxf(a.inv_f * ((float)g + 0.5f) - 0.5f, 0.f); };   // mask-res -> conv-res coordinate
+
+  for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    // entry e with prefix[e] <= w < prefix[e+1]
+    int lo = 0, hi = n2;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_prefix[mid] <= w) lo = mid; else hi = mid;
+    }
+    const int e = lo, d = e >> 1, kind = e & 1;
+    const int* rg = a.ranges + d * 8;
+    const int r0 = rg[kind * 4 + 0], r1 = rg[kind * 4 + 1], r2 = rg[kind * 4 + 2];
+    const int t = w - s_prefix[e];
+    const int tx = r0 + t % (r2 - r0), ty = r1 + t / (r2 - r0);
+    const int ox0 = tx * MF_TW, oy0 = ty * MF_TH;
+    uint8_t* mrow = a.masks + (long long)d * a.ho * a.pitch;
+    constexpr int GROUPS = MF_TW * MF_TH / 4;
+    if (kind == 1) {
+      // a tile the slot covered last time: zero it unless this call's rectangle rewrites it anyway
+      if (!(tx >= rg[0] && tx < rg[2] && ty >= rg[1] && ty < rg[3])) {
+        for (int gi = tid; gi < GROUPS; gi += MF_THREADS) {
+          const int oy = oy0 + gi / (MF_TW / 4), ox = ox0 + (gi % (MF_TW / 4)) * 4;
+          if (oy < a.ho && ox < a.wo) *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.pitch + ox) = 0u;
+        }
+      }
+      continue;
+    }
+    const int b = d / a.max_num;
+    __syncthreads();   // previous tile of this block is done with the LDS tiles
+    if (tid < 32) {
+      const long long src = ((long long)b * a.kmax + a.keep[d]) * 128;
+      *reinterpret_cast<float4*>(s_cof + tid * 4) = *reinterpret_cast<const float4*>(a.cofs + src + tid * 4);
+    }
+    FBox bx;
+    {
+      const float* dd = a.det + (long long)d * 5;
+      bx.x1 = __fdiv_rn(__fmul_rn(dd[0], a.box_mul_x), a.box_div);
+      bx.y1 = __fdiv_rn(__fmul_rn(dd[1], a.box_mul_y), a.box_div);
+      bx.x2 = __fdiv_rn(__fmul_rn(dd[2], a.box_mul_x), a.box_div);
+      bx.y2 = __fdiv_rn(__fmul_rn(dd[3], a.box_mul_y), a.box_div);
+      bx.rw = (float)(((double)__fsub_rn(bx.x2, bx.x1) + 0.1) / 2.0);   // crop_split_cuda_kernel.cu:47-48
+      bx.rh = (float)(((double)__fsub_rn(bx.y2, bx.y1) + 0.1) / 2.0);
+    }
+    // mask-resolution source window of the tile (as sm_mask_assemble) and the conv-resolution window under it
+    const int oxe = min(ox0 + MF_TW, a.wo) - 1, oye = min(oy0 + MF_TH, a.ho) - 1;
+    const int sx0 = (int)src_x(ox0), sy0 = (int)src_y(oy0);
+    const int sx1 = min((int)src_x(oxe) + 1, a.wm - 1), sy1 = min((int)src_y(oye) + 1, a.hm - 1);
+    const int spw = sx1 - sx0 + 1, sph = sy1 - sy0 + 1;
+    const int nsrc = spw * sph;
+    const int lx0 = (int)lo_c(sx0), ly0 = (int)lo_c(sy0);
+    const int lx1 = min((int)lo_c(sx1) + 1, a.lo_w - 1), ly1 = min((int)lo_c(sy1) + 1, a.lo_h - 1);
+    const int lpw = lx1 - lx0 + 1, lph = ly1 - ly0 + 1;
+    const int nlo = lpw * lph;
+    __syncthreads();   // s_cof
+    // (1) the 4 quadrant logits at conv resolution: one 32-long dot product per (quadrant, pixel)
+    for (int i = tid; i < 4 * nlo; i += MF_THREADS) {
+      const int q = i / nlo, p = i - q * nlo;
+      const int py = p / lpw, px = p - py * lpw;
+      const float* bp = a.basis_lo + (((long long)b * a.lo_h + (ly0 + py)) * a.lo_w + (lx0 + px)) * 32;
+      const float* cq = s_cof + q * 32;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; k += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(bp + k);
+        acc = fmaf(v.x, cq[k], acc);
+        acc = fmaf(v.y, cq[k + 1], acc);
+        acc = fmaf(v.z, cq[k + 2], acc);
+        acc = fmaf(v.w, cq[k + 3], acc);
+      }
+      s_lo[q][p] = acc;
+    }
+    __syncthreads();
+    // (2) mask-resolution probabilities: quadrant select (CropSplit), bilinear xfactor of that quadrant's logits
+    //     (upsample_bilinear_kernel's formula, misc.hip), sigmoid
+    for (int li = tid; li < nsrc; li += MF_THREADS) {
+      const int yy = li / spw, xx = li - yy * spw;
+      const int gx = sx0 + xx, gy = sy0 + yy;
+      const float pw = (float)gx, ph = (float)gy;
+      float prob = 0.f;
+      if (pw >= bx.x1 && ph >= bx.y1 && pw < bx.x2 && ph < bx.y2) {
+        const int iw = (int)__fdiv_rn(__fsub_rn(pw, bx.x1), bx.rw);
+        const int ih = (int)__fdiv_rn(__fsub_rn(ph, bx.y1), bx.rh);
+        const float* L = s_lo[(ih * 2 + iw) & 3];
+        const float fy = lo_c(gy), fx = lo_c(gx);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = min(y0 + 1, a.lo_h - 1), x1 = min(x0 + 1, a.lo_w - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* q0 = L + (y0 - ly0) * lpw - lx0;
+        const float* q1 = L + (y1 - ly0) * lpw - lx0;
+        const float logit = hy * (hx * q0[x0] + lx * q0[x1]) + ly * (hx * q1[x0] + lx * q1[x1]);
+        prob = sigmoidf_acc(logit);
+      }
+      s_prob[li] = prob;
+    }
+    __syncthreads();
+    // (3) image-resolution bilinear + threshold, 4 pixels per 32-bit store
+    for (int gi = tid; gi < GROUPS; gi += MF_THREADS) {
+      const int oy = oy0 + gi / (MF_TW / 4), oxb = ox0 + (gi % (MF_TW / 4)) * 4;
+      if (oy >= a.ho || oxb >= a.wo) continue;
+      const float sy = src_y(oy);
+      const int y0 = (int)sy, y1 = min(y0 + 1, a.hm - 1);
+      const float ly = sy - (float)y0, hy = 1.f - ly;
+      const float* p0 = s_prob + (y0 - sy0) * spw - sx0;
+      const float* p1 = s_prob + (y1 - sy0) * spw - sx0;
+      uint32_t packed = 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ox = oxb + k;
+        if (ox < a.wo) {
+          const float sx = src_x(ox);
+          const int x0 = (int)sx, x1 = min(x0 + 1, a.wm - 1);
+          const float lx = sx - (float)x0, hx = 1.f - lx;
+          const float v = hy * (hx * p0[x0] + lx * p0[x1]) + ly * (hx * p1[x0] + lx * p1[x1]);
+          packed |= (v > a.thr ? 1u : 0u) << (8 * k);
+        }
+      }
+      *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.pitch + oxb) = packed;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t sm_mask_assemble_lo_workspace(int batch, int max_num) {
+  if (batch < 1 || max_num < 1) return 0;
+  const int64_t nslot = (int64_t)batch * max_num;
+  return nslot * 8 * 4 + (2 * nslot + 1) * 4 + 64;
+}
+
+extern "C" int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, int factor, const float* cofs,
+                                   const int64_t* keep, const float* det, const int32_t* ndet, int batch, int kmax,
+                                   int max_num, int ho, int wo, int mask_pitch, float box_mul_x, float box_mul_y,
+                                   float box_div, double up_scale_h, double up_scale_w, float mask_thr, uint8_t* masks,
+                                   int32_t* state, void* workspace, sm_stream_t stream) {
+  if (!basis_lo || !cofs || !keep || !det || !ndet || !masks || !state || !workspace) return SM_ERR_BAD_ARG;
+  if (batch < 1 || max_num < 1 || lo_h < 1 || lo_w < 1 || factor < 1 || ho < 1 || wo < 1 || mask_pitch % 4 != 0 ||
+      mask_pitch < wo || !(up_scale_h > 0) || !(up_scale_w > 0) || !(box_div != 0.f))
+    return SM_ERR_BAD_SHAPE;
+  if (2 * batch * max_num > MF_MAX_ENTRIES) return SM_ERR_UNSUPPORTED;
+  // the tile's source windows must fit the LDS tiles
+  const int spw = (int)((double)MF_TW / up_scale_w) + 3, sph = (int)((double)MF_TH / up_scale_h) + 3;
+  if (spw * sph > MF_SRC_CAP || (spw / factor + 3) * (sph / factor + 3) > MF_LO_CAP) return SM_ERR_UNSUPPORTED;
+  MaskFArgs a;
+  a.basis_lo = basis_lo;
+  a.cofs = cofs;
+  a.keep = keep;
+  a.det = det;
+  a.ndet = ndet;
+  a.masks = masks;
+  a.state = state;
+  a.ranges = (int32_t*)workspace;
+  a.prefix = a.ranges + (size_t)batch * max_num * 8;
+  a.batch = batch;
+  a.kmax = kmax;
+  a.max_num = max_num;
+  a.lo_h = lo_h;
+  a.lo_w = lo_w;
+  a.factor = factor;
+  a.hm = lo_h * factor;
+  a.wm = lo_w * factor;
+  a.ho = ho;
+  a.wo = wo;
+  a.pitch = mask_pitch;
+  a.box_mul_x = box_mul_x;
+  a.box_mul_y = box_mul_y;
+  a.box_div = box_div;
+  a.up_x = (float)up_scale_w;
+  a.up_y = (float)up_scale_h;
+  a.inv_up_x = (float)(1.0 / up_scale_w);
+  a.inv_up_y = (float)(1.0 / up_scale_h);
+  a.inv_f = 1.f / (float)factor;
+  a.thr = mask_thr;
+  hipStream_t s = sm_hip_stream(stream);
+  hipLaunchKernelGGL(mask_plan_kernel, dim3(1), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(mask_fused_kernel, dim3(2048), dim3(MF_THREADS), 0, s, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

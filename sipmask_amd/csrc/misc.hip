@@ -150,17 +150,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
   }
   const long long off = (a.row0[lev] + (long long)n * HW) * a.C;
   const int rend = min(rb + GN_ROWS_PER_BLOCK, HW);
-  for (int r = rb + rr; r < rend; r += rows_per_iter) {
-    const long long o = off + (long long)r * a.C + cc * 8;
-    const uint4 v = *reinterpret_cast<const uint4*>(x + o);
-    float f[8];
-    unpack_bf16x8(v, f);
+  // 4 rows per iteration, all loads issued before the first use: a pure streaming pass wants bytes in flight
+  // (one 16-byte load per thread per iteration measured 2.8 TB/s on the 46 MB tower tensor)
+  constexpr int UN = 4;
+  for (int r = rb + rr; r < rend; r += rows_per_iter * UN) {
+    uint4 v[UN];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t = f[e] * sc[e] + sf[e];
-      f[e] = a.relu ? fmaxf(t, 0.f) : t;
+    for (int u = 0; u < UN; ++u) {
+      const int ru = min(r + u * rows_per_iter, rend - 1);        // clamped duplicate load, store masked below
+      v[u] = *reinterpret_cast<const uint4*>(x + off + (long long)ru * a.C + cc * 8);
     }
-    *reinterpret_cast<uint4*>(y + o) = pack_bf16x8(f);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int ru = r + u * rows_per_iter;
+      if (ru >= rend) break;
+      float f[8];
+      unpack_bf16x8(v[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = f[e] * sc[e] + sf[e];
+        f[e] = a.relu ? fmaxf(t, 0.f) : t;
+      }
+      *reinterpret_cast<uint4*>(y + off + (long long)ru * a.C + cc * 8) = pack_bf16x8(f);
+    }
   }
 }
 

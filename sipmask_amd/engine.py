@@ -405,6 +405,27 @@ class SipMaskEngine:
         else:
             self._add("gn:" + label, lambda: H.groupnorm(x, x, g, b, st, self.lv, 256, 32, 1e-5, True), lane)
 
+    # feat_masks: materialised lazily
+    _needs_basis = False
+
+    def _upsample_basis(self):
+        h0, w0 = self._basis_h0w0
+        if self._basis is None:
+            self._basis = self._buf(self.batch * self.hm * self.wm, 32, torch.float32)
+        H.upsample_bilinear(self.basis_lo, self._basis, self.batch, h0, w0, 32, 4, 32, 32, 0, True)
+        return self._basis
+
+    def _basis_step(self):
+        if self._needs_basis:
+            self._upsample_basis()
+
+    @property
+    def basis(self):
+        """feat_masks as rows [B*Hm*Wm, 32] f32, up to date with the last run"""
+        if self._needs_basis and self._basis is not None:
+            return self._basis
+        return self._upsample_basis()
+
     def _gn_stats64_for(self, stats):
         """the double-precision twin of a per-lane statistics buffer (f32 plan)"""
         k = stats.data_ptr()
@@ -502,8 +523,12 @@ class SipMaskEngine:
                              [(h0, w0)], [0], self.lat0, 512, 1, 1, self.basis_lo, [0], 32,
                              flags=SM_CONV_RELU | SM_CONV_OUT_F32), 2)
         self.hm, self.wm = 4 * h0, 4 * w0
-        self.basis = self._buf(B * self.hm * self.wm, 32, torch.float32)      # feat_masks, [B,Hm,Wm,32]
-        self._add("up:basis", lambda: H.upsample_bilinear(self.basis_lo, self.basis, B, h0, w0, 32, 4, 32, 32, 0, True), 2)
+        # feat_masks [B,Hm,Wm,32] = bilinear x4 of basis_lo (sipmask_head.py:285).  The plan's own mask assembly
+        # interpolates AFTER the coefficient dot product (sm_mask_assemble_lo), so the 137 MB tensor is only
+        # materialised for the API view (head_outputs) and for the plans that still consume it (_needs_basis)
+        self._basis = None
+        self._basis_h0w0 = (h0, w0)
+        self._add("up:basis", lambda: self._basis_step(), 2)
         # fcos_reg (4, x Scale) + fcos_centerness (1) share reg_feat -> one 5-channel f32 conv
         w_rc = torch.cat([sd[h + "fcos_reg.weight"], sd[h + "fcos_centerness.weight"]], 0)
         b_rc = torch.cat([sd[h + "fcos_reg.bias"], sd[h + "fcos_centerness.bias"]], 0)
@@ -590,6 +615,8 @@ class SipMaskEngine:
         self.pitch = (self.wo + 3) // 4 * 4
         self.masks = torch.zeros(B, self.max_num, self.ho, self.pitch, dtype=torch.uint8, device=self.device)
         self.rescorer, self.track_feats = None, None
+        self._needs_basis = True
+        self._basis = self._buf(B * self.hm * self.wm, 32, torch.float32)
         self._add("det_select", lambda: H.pairs_select(self.det_desc, bm["pre_nms_thresh"], self.cls_cof, self.reg_out,
                                                        self.cls_cof, self.sel))
         self._add("nms", lambda: H.multiclass_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"],
@@ -615,7 +642,20 @@ class SipMaskEngine:
         self.box_mul, self.up, (self.ho, self.wo) = H.post_geometry(self.hm, self.wm, self.scale_factor, geo_rescale,
                                                                     self.ssd_flag)
         self.pitch = (self.wo + 3) // 4 * 4
-        self.masks = torch.zeros(B, self.max_num, self.ho, self.pitch, dtype=torch.uint8, device=self.device)
+        self.rescorer = None
+        if ("bbox_head.convs_scoring.0.conv.weight") in self._sd_keys:
+            self.rescorer = MaskRescorer(self._sd, "bbox_head.", B, self.max_num, self.hm, self.wm, self.device)
+        # the rescoring branch consumes the cropped probability maps at mask resolution (pos_masks), which only
+        # sm_mask_assemble produces; every other plan assembles masks from the conv-resolution basis
+        self.fused_masks = self.rescorer is None and __import__("os").environ.get("SIPMASK_FUSED_MASKS", "1") != "0"
+        self._needs_basis = not self.fused_masks
+        if self._needs_basis:
+            self._basis = self._buf(B * self.hm * self.wm, 32, torch.float32)     # allocated at build (capture-safe)
+        if self.fused_masks:
+            self.mask_buf = H.mask_assemble_lo_alloc(B, self.max_num, self.ho, self.wo, self.device)
+            self.masks = self.mask_buf["masks"]
+        else:
+            self.masks = torch.zeros(B, self.max_num, self.ho, self.pitch, dtype=torch.uint8, device=self.device)
         self._add("det_select", lambda: H.det_select(self.det_desc, self.cls_cof, self.reg_out, self.cls_cof, self.sel))
         if self.ssd_flag or self.vis:
             self._add("nms", lambda: H.fast_nms(self.sel["boxes"], self.sel["scores"], self.sel["ctr"],
@@ -626,13 +666,16 @@ class SipMaskEngine:
                                                       self.sel["ncand"], cfg["score_thr"], cfg["nms"]["iou_thr"],
                                                       self.max_num, self.nms_out))
         self._join(2)
-        self.rescorer = None
-        if ("bbox_head.convs_scoring.0.conv.weight") in self._sd_keys:
-            self.rescorer = MaskRescorer(self._sd, "bbox_head.", B, self.max_num, self.hm, self.wm, self.device)
         pos = None if self.rescorer is None else self.rescorer.pos_masks
-        self._add("mask_assemble", lambda: H.mask_assemble(
-            self.basis, True, self.sel["cofs"], self.nms_out["keep"], self.nms_out["det"], self.nms_out["ndet"],
-            self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, self.masks, pos))
+        if self.fused_masks:
+            h0, w0 = self._basis_h0w0
+            self._add("mask_assemble", lambda: H.mask_assemble_lo(
+                self.basis_lo, h0, w0, 4, self.sel["cofs"], self.nms_out["keep"], self.nms_out["det"],
+                self.nms_out["ndet"], self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, self.mask_buf))
+        else:
+            self._add("mask_assemble", lambda: H.mask_assemble(
+                self._basis, True, self.sel["cofs"], self.nms_out["keep"], self.nms_out["det"], self.nms_out["ndet"],
+                self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, self.masks, pos))
         if self.rescorer is not None:
             self._add("rescore", lambda: self.rescorer.run(self.nms_out["labels"], self.nms_out["det"],
                                                            self.nms_out["ndet"]))

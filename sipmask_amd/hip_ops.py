@@ -395,6 +395,30 @@ def mask_assemble(basis, basis_hwc, cofs, keep, det, ndet, hm, wm, ho, wo, box_m
     return masks
 
 
+def mask_assemble_lo_alloc(batch, max_num, ho, wo, device):
+    """buffers owned by the plan for sm_mask_assemble_lo: the u8 masks (zeroed once), the per-slot tile-range state
+    (zeroed with them) and the work-list workspace"""
+    lib = _lib.load()
+    pitch = (wo + 3) // 4 * 4
+    return dict(masks=torch.zeros(batch, max_num, ho, pitch, dtype=torch.uint8, device=device),
+                state=torch.zeros(batch * max_num, 4, dtype=torch.int32, device=device),
+                ws=torch.empty(int(lib.sm_mask_assemble_lo_workspace(batch, max_num)), dtype=torch.uint8, device=device))
+
+
+def mask_assemble_lo(basis_lo, lo_h, lo_w, factor, cofs, keep, det, ndet, ho, wo, box_mul, box_div, up_scale, thr, buf):
+    """fused-upsample, rectangle-tracked mask assembly (see sm_mask_assemble_lo); buf from mask_assemble_lo_alloc"""
+    lib = _lib.load()
+    (mx, my), (uh, uw) = _pair(box_mul), _pair(up_scale)
+    b, kmax = cofs.shape[0], cofs.shape[1]
+    max_num = det.shape[1]
+    masks = buf["masks"]
+    _lib.check(lib.sm_mask_assemble_lo(_lib.ptr(basis_lo), lo_h, lo_w, factor, _lib.ptr(cofs), _lib.ptr(keep), _lib.ptr(det),
+                                       _lib.ptr(ndet), b, kmax, max_num, ho, wo, int(masks.shape[-1]), mx, my, float(box_div),
+                                       uh, uw, float(thr), _lib.ptr(masks), _lib.ptr(buf["state"]), _lib.ptr(buf["ws"]),
+                                       _lib.stream_ptr()), "sm_mask_assemble_lo")
+    return masks
+
+
 # ------------------------------------------------------------------------------- device RLE (result packing)
 def rle_alloc(batch, max_num, canvas_w, device, max_runs=8192, packed_cap=None):
     lib = _lib.load()

@@ -86,7 +86,8 @@ def test_conv_igemm_vs_torch(cfg):
                                      0x08200000, 0x08100000, 0x0c100000,    # flat K loop without fragment pipeline / legacy K loop
                                      0x0c400000, 0x09200000,                # 256x256 8-wave tiles (forced); flat loop + LDS epilogue
                                      0x10080000, 0x14080000, 0x11080000,    # 32-wide-K kernel with the flat/pipelined loop
-                                     0x0c440000, 0x08040000])               # hand-placed K step: 256x256 tiles / 128x128 tiles
+                                     0x0c440000, 0x08040000,                # hand-placed K step: 256x256 tiles / 128x128 tiles
+                                     0x00020000, 0x10020000, 0x14020000])   # residual prefetch before the K loop (32-wide-K kernel)
 def test_conv_loader_variants(variant):
     """The A/B loader variants (register staging 0x2..., forced 32-wide K steps 0x1..., forced 64-wide
     0x08...) must give the same
@@ -715,6 +716,46 @@ def test_mask_assemble_vs_oracle():
         assert bool(((r["up"] - 0.4).abs()[diff] < 1e-5).all())             # only threshold-adjacent pixels may flip
         assert int(diff.sum()) <= 5
         assert bool((masks[0, nd[0]:] == 7).all()) and bool((masks[1] == 7).all())   # rows >= ndet untouched
+
+
+def test_mask_assemble_lo_vs_oracle_and_rectangle_tracking():
+    """sm_mask_assemble_lo: basis at conv resolution (the x4 bilinear of sipmask_head.py:285 applied AFTER the coefficient
+    dot product), only the detections' rectangles written, the previous call's rectangles cleared.  Against the oracle
+    fed with F.interpolate(basis_lo, x4): masks may differ only where the upsampled probability is within 1e-5 of
+    the threshold (the reassociation changes logits by f32 rounding), and after every call the WHOLE buffer -- slots
+    beyond ndet, pixels outside the boxes, rectangles of the previous call -- must be what the oracle says."""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(33)
+    B, h0, w0, kmax, max_num = 2, 13, 21, 60, 9
+    Hm, Wm = 4 * h0, 4 * w0
+    Ho, Wo = 2 * Hm, 2 * Wm
+    basis_lo = torch.relu(torch.randn(B, 32, h0, w0, generator=g))
+    feat = F.interpolate(basis_lo, scale_factor=4, mode="bilinear", align_corners=False)
+    cofs = torch.randn(B, kmax, 128, generator=g) * 0.5
+    lo_rows = basis_lo.permute(0, 2, 3, 1).contiguous().to(dev)
+    buf = H.mask_assemble_lo_alloc(B, max_num, Ho, Wo, dev)
+    for it, nd in enumerate(([7, 3], [2, 9], [0, 1])):                 # detections move, counts shrink and grow
+        xy = torch.rand(B, max_num, 2, generator=g) * torch.tensor([Wo * 0.7, Ho * 0.7])
+        wh = torch.rand(B, max_num, 2, generator=g) * torch.tensor([Wo * 0.5, Ho * 0.5]) + 3
+        det = torch.cat([xy, xy + wh, torch.rand(B, max_num, 1, generator=g)], 2)
+        if it == 0:
+            det[0, 0, :4] = torch.tensor([-20.0, -10.0, Wo + 30.0, Ho + 5.0])         # larger than the image
+            det[0, 1, :4] = torch.tensor([10.3, 7.7, 10.9, 8.2])                      # sub-pixel box
+        keep = torch.randint(0, kmax, (B, max_num), generator=g)
+        H.mask_assemble_lo(lo_rows, h0, w0, 4, cofs.to(dev), keep.to(dev), det.to(dev),
+                           torch.tensor(nd, dtype=torch.int32, device=dev), Ho, Wo, 1.0, 2.0, 2.0, 0.4, buf)
+        torch.cuda.synchronize()
+        got = buf["masks"][..., :Wo].cpu()
+        for b in range(B):
+            n = nd[b]
+            assert int(got[b, n:].sum()) == 0                          # stale slots cleared
+            if n == 0:
+                continue
+            r = O.mask_assemble(feat[b], cofs[b][keep[b, :n]], det[b, :n], 1.0, False)
+            diff = got[b, :n] != r["masks"]
+            assert bool(((r["up"] - 0.4).abs()[diff] < 1e-5).all()), (it, b)
+            assert int(diff.sum()) <= 5
 
 
 def test_crop_split_and_gt_vs_oracle():

@@ -220,8 +220,12 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     eng = pd.build_on_cpu(variant, batch=2, hw=(256, 320))
     assert torch.cuda.is_available is avail                       # the patch is undone
     rows = {r["name"]: r for r in pd.conv_rows(eng)}
-    grouped = os.environ.get("SIPMASK_GROUPED_TOWERS", "0") == "1"     # wip/grouped-towers: cls+reg convs per depth fuse
-    assert len(rows) == len(eng.convs) and (grouped or len(rows) == nconv)
+    # the cls and reg tower convs of one depth run as ONE grouped launch (default; SIPMASK_GROUPED_TOWERS=0 = A/B):
+    # every "head.towerN" launch stands for two of the nconv convolutions
+    ngrouped = sum(1 for n in rows if n.startswith("head.tower"))
+    grouped = ngrouped > 0
+    assert grouped == (os.environ.get("SIPMASK_GROUPED_TOWERS", "1") == "1" and eng.flag_norm)   # GN heads only
+    assert len(rows) == len(eng.convs) and len(rows) == nconv - ngrouped
     assert all(r["plan"]["blocks"] > 0 and 0 < r["fill"] <= 1 for r in rows.values())
     assert len(eng.steps) == len(eng.lanes)
     joined = set()
