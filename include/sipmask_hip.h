@@ -59,6 +59,7 @@ typedef enum {
 #define SM_CONV_DBG_K32_OPT 0x00080000u      /* A/B switch: flat loader + peeled loop + pipelined fragment reads in the 32-wide-K kernel (cin >= 32) */
 #define SM_CONV_DBG_HAND_PLACED 0x00040000u  /* A/B switch (with TILE256): hand-placed K step, LDS-DMA pieces between the MFMAs */
 #define SM_CONV_DBG_RES_PREFETCH 0x00020000u /* A/B switch: 32-wide-K kernel loads the residual rows BEFORE the K loop (HBM-bound 1x1 + residual convs) */
+#define SM_CONV_DBG_NO_SPLITK 0x00010000u   /* A/B switch: sm_conv2d_ws never splits K */
 #define SM_CONV_DBG_WARP_SPEC 0x02000000u    /* A/B switch: 8-wave producer/consumer variant of the 64-wide-K kernel */
 
 /* One (multi-level) 2-D convolution as an implicit GEMM.  Replaces the ATen/cuDNN
@@ -115,7 +116,9 @@ typedef struct sm_conv_plan {
   int32_t threads;    /* 256, or 512 for the 8-wave tiles */
   int32_t k_loop;     /* 0 legacy loop, 1 flat loader + peeled loop, 3 = 1 + pipelined fragment reads */
   int32_t warp_spec;  /* producer/consumer A/B variant */
-  int64_t blocks;     /* grid size */
+  int64_t blocks;     /* grid size (without split-K) */
+  int32_t split_k;    /* K slices per tile sm_conv2d_ws would use given a workspace (1 = no split) */
+  int64_t workspace_bytes; /* f32 partial slabs [split_k][rows][cout_pad] needed for that; 0 when split_k == 1 */
 } sm_conv_plan;
 int sm_conv_plan_query(const sm_conv_desc* d, int deformable, int with_gn_stats, sm_conv_plan* out);
 
@@ -123,6 +126,13 @@ int sm_conv_plan_query(const sm_conv_desc* d, int deformable, int with_gn_stats,
  * or NULL, residual bf16 or NULL, y bf16/f32. */
 int sm_conv2d(const sm_conv_desc* d, const void* x, const void* w, const float* bias,
               const void* residual, void* y, sm_stream_t stream);
+
+/* sm_conv2d with a caller-provided workspace: launches that leave most of the chip idle (few tiles, long K loops: the
+ * 3x3 / 1x1 convs of layer4, FPN lateral 2, ... at M = B*25*42) are split along K into sm_conv_plan.split_k slices per
+ * tile (f32 partial slabs in the workspace) followed by a reduce + epilogue kernel.  workspace may be NULL / too small:
+ * then this is sm_conv2d.  The summation order differs from sm_conv2d's by the slicing only (f32). */
+int sm_conv2d_ws(const sm_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                 void* workspace, int64_t workspace_bytes, sm_stream_t stream);
 
 /* Deformable conv v1 forward, bilinear gather fused into the GEMM operand load
  * (never materialises the column buffer).  Replaces deform_conv_forward_cuda,

@@ -48,7 +48,7 @@ class ConvPlan(C.Structure):
     _fields_ = [
         ("lds_dma", C.c_int32), ("k_step", C.c_int32), ("k_padded", C.c_int32), ("tile_cout", C.c_int32),
         ("tile_pos", C.c_int32), ("threads", C.c_int32), ("k_loop", C.c_int32), ("warp_spec", C.c_int32),
-        ("blocks", C.c_int64),
+        ("blocks", C.c_int64), ("split_k", C.c_int32), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -76,6 +76,7 @@ PROTOTYPES = {
     "sm_conv_cout_tile": (_I, [_I]),
     "sm_conv_plan_query": (_I, [C.POINTER(ConvDesc), _I, _I, C.POINTER(ConvPlan)]),
     "sm_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    "sm_conv2d_ws": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "sm_deform_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "sm_conv2d_gn_stats": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_conv2d_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),

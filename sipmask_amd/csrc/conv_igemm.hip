@@ -45,6 +45,11 @@ struct ConvKArgs {
   int ngroups, tpg;
   long long x_grows, y_grows;        // rows between the groups' inputs (0 = shared) / outputs (and RES_ADD residuals)
   long long w_gstride, b_gstride, gn_gstride;   // elements between the groups' weights / biases / GN statistics
+  // split-K (64-wide-K LDS-DMA kernel, flat loop): ksplit > 1 -> block b works on K steps [ks*nk/S, (ks+1)*nk/S) of tile
+  // b / S and stores its raw f32 accumulators to part[ks][row][cout_pad]; splitk_reduce_kernel applies the epilogue
+  int ksplit;
+  float* part;
+  long long part_rows;   // rows of one partial slab
 };
 
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
@@ -138,9 +143,13 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   // bijective form).  Placement only affects speed, never correctness.
   const int nblk = gridDim.x;
   const int xcd = blockIdx.x & 7, xq = nblk >> 3, xr = nblk & 7;
-  const int tlin = (a.flags & SM_CONV_DBG_LINEAR_TILES)
-                       ? (int)blockIdx.x
-                       : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)(blockIdx.x >> 3);
+  const int tlin_s = (a.flags & SM_CONV_DBG_LINEAR_TILES)
+                         ? (int)blockIdx.x
+                         : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)(blockIdx.x >> 3);
+  // split-K: consecutive blocks are the K slices of one tile
+  const int ks = a.ksplit > 1 ? tlin_s % a.ksplit : 0;
+  const int tlin = a.ksplit > 1 ? tlin_s / a.ksplit : tlin_s;
+  const int kt0 = a.ksplit > 1 ? (int)((long long)ks * a.nk / a.ksplit) : 0;
   // group decode (wave-uniform): which problem instance this tile belongs to
   const int grp = a.ngroups > 1 ? tlin / a.tpg : 0;
   const int tl_g = tlin - grp * a.tpg;
@@ -190,14 +199,14 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   const long long wstride = (long long)LROWS * a.Kp;
   // loader K state (this thread's 16-byte chunk j of the current K step), advanced incrementally:
   // no integer division inside the K loop when a tap holds >= 8 chunks (every layer but the stem)
-  int ld_cc, ld_kh, ld_kw, ld_kc = j;
+  int ld_cc, ld_kh, ld_kw, ld_kc = j + 8 * kt0;
   {
-    const int tap0 = j / a.cpt;
-    ld_cc = j - tap0 * a.cpt;
+    const int tap0 = ld_kc / a.cpt;
+    ld_cc = ld_kc - tap0 * a.cpt;
     ld_kh = tap0 / a.kw;
     ld_kw = tap0 - ld_kh * a.kw;
   }
-  const uint16_t* ld_wp = wrow;
+  const uint16_t* ld_wp = wrow + 64 * kt0;
   auto advance_k = [&]() {
     ld_kc += 8;
     ld_wp += 64;
@@ -451,7 +460,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
     }
   };
 
-  const int nk = a.nk;
+  const int nk = a.ksplit > 1 ? (int)((long long)(ks + 1) * a.nk / a.ksplit) - kt0 : a.nk;
   if constexpr (DMA) {
     // ---- LDS-DMA main loop: global_load_lds_dwordx4 straight into the swizzled LDS image, no
     // staging VGPRs, no ds_write pass, no mask pass.  Two LDS stages; the __syncthreads() that ends
@@ -703,6 +712,37 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   const bool has_res0 = a.flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST);
   const bool reg_epi = !PROD && !(a.flags & SM_CONV_DBG_LDS_EPILOGUE) && (a.cout & 7) == 0 && (a.out_cstride & 7) == 0 &&
                        (a.out_coff & 7) == 0 && (!has_res0 || (a.res_cstride & 7) == 0);
+  if (a.ksplit > 1) {
+    // split-K slice: raw accumulators -> part[ks][out row][cout_pad] in the register-epilogue layout (8 consecutive
+    // couts per lane, two 16-byte stores); the launcher only splits launches that meet reg_epi's conditions
+    const int cpad = a.ntn * BCO;
+    float* pp = a.part + (long long)ks * a.part_rows * cpad;
+#pragma unroll
+    for (int tp = 0; tp < TPOS; ++tp) {
+      const int m = m0 + wpos * TPOS * 32 + tp * 32 + l31;
+#pragma unroll
+      for (int tc = 0; tc < TCO; ++tc) {
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t lo = __float_as_uint(acc[tc][tp][4 * (2 * qp) + e]);
+            const uint32_t hi = __float_as_uint(acc[tc][tp][4 * (2 * qp + 1) + e]);
+            const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+            v[e] = __uint_as_float(r[0]);
+            v[4 + e] = __uint_as_float(r[1]);
+          }
+          if (m >= M) continue;
+          const int c0 = nt * BCO + wco * TCO * 32 + tc * 32 + 8 * (2 * qp + khalf);
+          float* q = pp + (long long)m * cpad + c0;
+          *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+      }
+    }
+    return;
+  }
   if (reg_epi) {
     const bool gn = gnp != nullptr;
     const int gn_groups = a.cout >> 3;
@@ -1443,9 +1483,59 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
   }
 }
 
+// ---- split-K epilogue: sum the S partial slabs, then bias / same-row residual / ReLU / store (single-level launches)
+struct SplitKEpi {
+  const float* part;
+  const float* bias;
+  const uint16_t* res;
+  void* y;
+  long long rows, part_rows, out_row0;
+  int S, cout, cpad, out_cstride, out_coff, res_cstride;
+  unsigned flags;
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitKEpi e) {
+  const int c8 = e.cout >> 3;
+  const long long total = e.rows * c8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long m = i / c8;
+    const int c0 = (int)(i - m * c8) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < e.S; ++s) {
+      const float* q = e.part + ((long long)s * e.part_rows + m) * e.cpad + c0;
+      const float4 a0 = *reinterpret_cast<const float4*>(q), a1 = *reinterpret_cast<const float4*>(q + 4);
+      v[0] += a0.x, v[1] += a0.y, v[2] += a0.z, v[3] += a0.w;
+      v[4] += a1.x, v[5] += a1.y, v[6] += a1.z, v[7] += a1.w;
+    }
+    if (e.bias != nullptr) {
+      const float4 b0 = *reinterpret_cast<const float4*>(e.bias + c0), b1 = *reinterpret_cast<const float4*>(e.bias + c0 + 4);
+      v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w;
+      v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
+    }
+    if (e.flags & SM_CONV_RES_ADD) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const u32x4*>(e.res + (e.out_row0 + m) * e.res_cstride + c0), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += f[k];
+    }
+    if (e.flags & SM_CONV_RELU) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    const long long o = (e.out_row0 + m) * e.out_cstride + e.out_coff + c0;
+    if (e.flags & SM_CONV_OUT_F32) {
+      float* yp = reinterpret_cast<float*>(e.y) + o;
+      *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(e.y) + o) = pack_bf16x8_v(v);
+    }
+  }
+}
+
 // ---- launch planning: pure host logic (no device access), exported as sm_conv_plan_query so that the selection
 // rules are testable without a GPU.  launch_conv() below executes exactly this plan.
-int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p) {
+int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p, bool allow_split = true) {
   if (!d || !p) return SM_ERR_BAD_ARG;
   if (d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return SM_ERR_BAD_SHAPE;
   if (d->cin % 8 != 0 || d->cin < 8 || d->cout < 1) return SM_ERR_BAD_SHAPE;
@@ -1503,6 +1593,14 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p)
     cands[ncand++] = {32, 128};
   }
   const long long want = (d->flags & SM_CONV_DBG_BIG_TILES) ? 0 : (k32 ? 768 : 512);
+  // split-K (sm_conv2d_ws): the flat-loop 64-wide-K kernel on single-level launches with the register epilogue's
+  // alignment and a plain epilogue (bias / same-row residual / ReLU)
+  const int nk64 = Kp / 64;
+  int split = 1;
+  const bool sk_base = allow_split && dma && !k32 && !with_gn && ngroups == 1 && d->nlev == 1 && reg_ok &&
+                       !(d->flags & (SM_CONV_RES_NEAREST | SM_CONV_RELU_NCH | SM_CONV_DBG_NO_SPLITK | SM_CONV_DBG_HAND_PLACED |
+                                     SM_CONV_DBG_WARP_SPEC | SM_CONV_DBG_LEGACY_LOOP | SM_CONV_DBG_FLAT_LOOP | SM_CONV_DBG_TILE256)) &&
+                       d->scale_nch == 0 && d->w_batch_stride == 0;
   int bco = cands[0].bco, bpos = cands[0].bpos;
   const bool ws = dma && !k32 && (d->flags & SM_CONV_DBG_WARP_SPEC) != 0;
   // 256x256 tile on 8 waves, one block per CU (A/B flag): half the LDS-DMA pieces and 3/4 of the fragment reads per
@@ -1530,6 +1628,19 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p)
     bco = cands[c].bco;
     bpos = cands[c].bpos;
     if (nb >= want) break;
+    // split-K instead of shrinking the tile further.  Measured (round 2, B=4 R50, HIP events incl. the reduce launch):
+    // it only pays for launches of a few blocks with very long K loops -- layer4 3x3 (132 tiles of 128x128, 72 K
+    // steps) 0.0595 -> 0.0530 ms, fpn.out2 0.0339 -> 0.0250 ms -- and LOSES where the unsplit launch already fills
+    // the chip with smaller tiles (layer3 3x3: 526 tiles of 128x64 0.0415 ms vs 2 x 264 tiles of 128x128 + reduce
+    // 0.0536 ms; 1x1 convs with K = 2048 likewise): the reduce kernel's launch boundary costs what the shorter K loop
+    // saves.  Hence the narrow rule: <= 160 tiles and >= 36 K steps.
+    if (sk_base && cands[c].bco == 128 && cands[c].bpos <= 128 && d->cin >= 64 && nb <= 160 && nk64 >= 36) {
+      int S = nk64 / 8 < 4 ? nk64 / 8 : 4;
+      if (S > 1) {
+        split = S;
+        break;
+      }
+    }
   }
   long long t = 0;
   for (int l = 0; l < d->nlev; ++l) t += sm_cdiv((long long)d->batch * d->out_h[l] * d->out_w[l], bpos);
@@ -1560,16 +1671,24 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p)
   p->k_loop = opt;
   p->warp_spec = ws ? 1 : 0;
   p->blocks = nblk;
+  // split-K: S slices per tile (chosen with the tile above), partial slabs [S][rows][cout_pad] f32 in the workspace
+  p->split_k = (split > 1 && opt == 3) ? split : 1;
+  p->workspace_bytes = 0;
+  if (p->split_k > 1)
+    p->workspace_bytes = (long long)p->split_k * d->batch * d->out_h[0] * d->out_w[0] * d->cout_pad * 4;
   return SM_OK;
 }
 
 template <bool DEFORM>
 int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,
-                const void* residual, void* y, hipStream_t stream, float* gn_stats = nullptr) {
+                const void* residual, void* y, hipStream_t stream, float* gn_stats = nullptr, void* workspace = nullptr,
+                long long workspace_bytes = 0) {
   if (!d || !x || !w || !y) return SM_ERR_BAD_ARG;
   if (DEFORM && !offset) return SM_ERR_BAD_ARG;
   sm_conv_plan plan;
-  const int prc = plan_conv(d, DEFORM, gn_stats != nullptr, &plan);
+  int prc = plan_conv(d, DEFORM, gn_stats != nullptr, &plan, !DEFORM && workspace != nullptr);
+  if (prc == SM_OK && plan.split_k > 1 && workspace_bytes < plan.workspace_bytes)      // workspace too small: no split
+    prc = plan_conv(d, DEFORM, gn_stats != nullptr, &plan, false);
   if (prc != SM_OK) return prc;
   if ((d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)) && !residual) return SM_ERR_BAD_ARG;
   const int tile = sm_conv_cout_tile(d->cout);
@@ -1630,6 +1749,10 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   a.scale_nch = d->scale_nch;
   a.dg = DEFORM ? d->deform_groups : 1;
   a.cpg8 = DEFORM ? d->cin / (8 * d->deform_groups) : 1;
+  const int S = plan.split_k > 1 ? plan.split_k : 1;
+  a.ksplit = S;
+  a.part = (float*)workspace;
+  a.part_rows = (long long)d->batch * d->out_h[0] * d->out_w[0];
   a.ngroups = d->ngroups > 1 ? d->ngroups : 1;
   a.tpg = t * a.ntn;
   a.x_grows = d->x_group_rows;
@@ -1637,8 +1760,8 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   a.w_gstride = d->w_group_stride;
   a.b_gstride = d->bias_group_stride;
   a.gn_gstride = d->gn_group_stride;
-  const long long nblk = (long long)t * a.ntn * a.ngroups;
-  if (nblk != plan.blocks) return SM_ERR_BAD_SHAPE;       // plan_conv and this function must agree
+  const long long nblk = (long long)t * a.ntn * a.ngroups * S;
+  if (nblk != plan.blocks * S) return SM_ERR_BAD_SHAPE;   // plan_conv and this function must agree
   dim3 grid((unsigned)nblk), block(256);
 #define SM_LAUNCH(KERNEL) hipLaunchKernelGGL((KERNEL), grid, block, 0, stream, a)
   if (!dma) {
@@ -1692,6 +1815,26 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 1, false, true>));
   }
 #undef SM_LAUNCH
+  if (S > 1) {
+    SplitKEpi e;
+    e.part = a.part;
+    e.bias = bias;
+    e.res = (const uint16_t*)residual;
+    e.y = y;
+    e.rows = (long long)d->batch * d->out_h[0] * d->out_w[0];
+    e.part_rows = a.part_rows;
+    e.out_row0 = d->out_row0[0];
+    e.S = S;
+    e.cout = d->cout;
+    e.cpad = d->cout_pad;
+    e.out_cstride = d->out_cstride;
+    e.out_coff = d->out_coff;
+    e.res_cstride = d->res_cstride;
+    e.flags = d->flags;
+    const long long items = e.rows * (d->cout >> 3);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256)), dim3(256), 0,
+                       stream, e);
+  }
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -1707,6 +1850,11 @@ extern "C" int sm_conv_plan_query(const sm_conv_desc* d, int deformable, int wit
 extern "C" int sm_conv2d(const sm_conv_desc* d, const void* x, const void* w, const float* bias,
                          const void* residual, void* y, sm_stream_t stream) {
   return launch_conv<false>(d, x, nullptr, w, bias, residual, y, sm_hip_stream(stream));
+}
+
+extern "C" int sm_conv2d_ws(const sm_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                            void* y, void* workspace, int64_t workspace_bytes, sm_stream_t stream) {
+  return launch_conv<false>(d, x, nullptr, w, bias, residual, y, sm_hip_stream(stream), nullptr, workspace, workspace_bytes);
 }
 
 extern "C" int sm_conv2d_gn_stats(const sm_conv_desc* d, const void* x, const float* offset, const void* w,

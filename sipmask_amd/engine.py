@@ -24,6 +24,9 @@ _DEBUG_CONV_FLAGS = int(__import__("os").environ.get("SIPMASK_CONV_DEBUG_FLAGS",
 _GROUPED_TOWERS = __import__("os").environ.get("SIPMASK_GROUPED_TOWERS", "1") == "1"
 
 
+_SPLIT_K = __import__("os").environ.get("SIPMASK_SPLIT_K", "1") != "0"     # A/B: split-K for under-filled launches
+
+
 def _lib_flag(name):
     return {"SM_CONV_DBG_TILE256": 0x00400000, "SM_CONV_DBG_HAND_PLACED": 0x00040000}[name]
 BF16 = torch.bfloat16
@@ -67,6 +70,13 @@ class _Conv:
                                      scale_nch, level_scale, deform_groups)
         self.x, self.y, self.residual, self.offset = x, y, residual, offset
         self.gn_stats = None      # set -> GroupNorm statistics of y are accumulated in the conv epilogue
+        # split-K workspace (own buffer per conv: launches on different lanes may run concurrently); sized by the
+        # library's plan, allocated once at build -- 288 GB of HBM
+        self.ws = None
+        if not self.f32 and offset is None and _SPLIT_K:
+            pl = H.conv_plan(self.desc)
+            if pl["split_k"] > 1:
+                self.ws = torch.empty(pl["workspace_bytes"], dtype=torch.uint8, device=dev)
         self.flops = 2.0 * sum(batch * h * ww for h, ww in out_sizes) * co * ci * k * k
         # algorithmic HBM bytes: x read once + y written once (+ residual read) + weights
         in_rows = sum(batch * h * ww for h, ww in in_sizes)
@@ -82,6 +92,8 @@ class _Conv:
             H.conv2d_gn_stats(self.desc, self.x, self.offset, self.w, self.bias, self.residual, self.y, self.gn_stats)
         elif self.offset is not None:
             H.deform_conv2d(self.desc, self.x, self.offset, self.w, self.bias, self.y)
+        elif self.ws is not None:
+            H.conv2d_ws(self.desc, self.x, self.w, self.bias, self.residual, self.y, self.ws)
         else:
             H.conv2d(self.desc, self.x, self.w, self.bias, self.residual, self.y)
 

@@ -96,6 +96,16 @@ def conv2d(desc, x, w, bias, residual, y):
     return y
 
 
+def conv2d_ws(desc, x, w, bias, residual, y, workspace):
+    """sm_conv2d with a split-K workspace (uint8 tensor or None): see conv_plan(desc)["split_k"] / ["workspace_bytes"]"""
+    _lib.require_cuda(x, w, y)
+    lib = _lib.load()
+    _lib.check(lib.sm_conv2d_ws(C.byref(desc), _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(y),
+                                _lib.ptr(workspace), 0 if workspace is None else workspace.numel(), _lib.stream_ptr()),
+               "sm_conv2d_ws")
+    return y
+
+
 def deform_conv2d(desc, x, offset, w, bias, y):
     _lib.require_cuda(x, offset, w, y)
     lib = _lib.load()

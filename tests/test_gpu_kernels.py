@@ -107,6 +107,49 @@ def test_conv_loader_variants(variant):
         torch.testing.assert_close(yb, ref, rtol=2 ** -7, atol=2e-3)
 
 
+@pytest.mark.parametrize("cfg", [
+    (2, 512, 25, 42, 512, 3, 1, 1),     # layer4 conv2 at B=2: 3x3, K = 4608 (72 K steps), M = 2100
+    (4, 512, 25, 42, 512, 3, 1, 1),     # the same at B=4 (132 tiles of 128x128 x 4 slices)
+    (1, 256, 50, 84, 256, 3, 1, 1),     # layer3 conv2 at B=1 (K = 2304: 36 K steps)
+    (1, 256, 13, 21, 256, 3, 1, 1),     # FPN output conv on a tiny map
+])
+def test_conv_split_k_vs_torch(cfg):
+    """sm_conv2d_ws: under-filled launches with long K loops run as S K-slices per (larger) tile + a reduce/epilogue
+    kernel; same tolerance as the unsplit kernel (f32 accumulation, different summation order), with bias, same-row
+    residual and ReLU in the reduce kernel, bf16 and f32 outputs; without a workspace the call is sm_conv2d."""
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    B, Ci, Hh, Ww, Co, k, st, p = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = _bf(torch.randn(B, Ci, Hh, Ww, generator=g))
+    w = _bf(torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(x, w, b, st, p)
+    r = _bf(torch.randn_like(ref))
+    xh = torch.empty(B * Hh * Ww, Ci, dtype=torch.bfloat16, device=dev)
+    H.nchw_to_nhwc_bf16(x.to(dev).contiguous(), xh, Ci)
+    wq, co_pad = H.prep_conv_weight(w.to(dev), Ci)
+    res = r.permute(0, 2, 3, 1).reshape(-1, Co).to(torch.bfloat16).to(dev).contiguous()
+    for out_f32 in (True, False):
+        flags = _lib.SM_CONV_RELU | _lib.SM_CONV_RES_ADD | (_lib.SM_CONV_OUT_F32 if out_f32 else 0)
+        d = H.make_conv_desc(B, [(Hh, Ww)], [(Hh, Ww)], [0], [0], Ci, Co, co_pad, k, st, p, Ci, Co, flags=flags, res_cstride=Co)
+        pl = H.conv_plan(d)
+        assert pl["split_k"] > 1 and pl["workspace_bytes"] > 0, pl
+        ws = torch.empty(pl["workspace_bytes"], dtype=torch.uint8, device=dev)
+        y = torch.full((B * Hh * Ww, Co), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
+        H.conv2d_ws(d, xh, wq, b.to(dev), res, y, ws)
+        torch.cuda.synchronize()
+        got = y.float().view(B, Hh, Ww, Co).permute(0, 3, 1, 2).cpu()
+        if out_f32:
+            torch.testing.assert_close(got, F.relu(ref + r), rtol=1e-4, atol=2e-4)
+        else:
+            torch.testing.assert_close(got, F.relu(ref + r), rtol=2 ** -7, atol=2e-3)
+        y2 = torch.empty_like(y)
+        H.conv2d_ws(d, xh, wq, b.to(dev), res, y2, None)                 # no workspace: the unsplit plan
+        torch.cuda.synchronize()
+        torch.testing.assert_close(y2.float(), y.float(), rtol=2 ** -7 if not out_f32 else 1e-4, atol=2e-3 if not out_f32 else 2e-4)
+
+
 def test_conv_residual_and_input_relu():
     g = torch.Generator().manual_seed(3)
     x = _bf(torch.randn(2, 64, 12, 10, generator=g))

@@ -93,8 +93,14 @@ def test_conv_launch_plan_rules():
     p = _plan([(800, 1344)], 8, 64, 7, stride=2, pad=3)                           # stem: cin 3 padded to 8, K 392 -> 448
     assert (p["k_step"], p["k_padded"], p["k_loop"]) == (32, 448, 0)
     # small-M layers shrink the tiles until the launch has >= 512 blocks (or run out of candidates)
-    p = _plan([(25, 42)], 512, 512, 3)                                            # layer4 3x3: M = 4200
-    assert (p["k_step"], p["tile_cout"], p["tile_pos"]) == (64, 64, 64) and p["blocks"] == 66 * 8
+    p = _plan([(25, 42)], 512, 512, 3, flags=0x00010000)                          # layer4 3x3: M = 4200 (split-K off)
+    assert (p["k_step"], p["tile_cout"], p["tile_pos"]) == (64, 64, 64) and p["blocks"] == 66 * 8 and p["split_k"] == 1
+    # ... unless a workspace is offered (sm_conv2d_ws): <= 160 tiles with >= 36 K steps keep the large tile and are cut
+    # into K slices instead (f32 partial slabs + reduce kernel)
+    p = _plan([(25, 42)], 512, 512, 3)
+    assert (p["tile_cout"], p["tile_pos"], p["blocks"], p["split_k"]) == (128, 128, 33 * 4, 4)
+    assert p["workspace_bytes"] == 4 * 4200 * 512 * 4
+    assert _plan([(25, 42)], 2048, 512, 1)["split_k"] == 1                        # 1x1, 32 K steps: measured slower split
     p = _plan([(50, 84)], 256, 256, 3)                                            # layer3 3x3: M = 16800
     assert (p["tile_cout"], p["tile_pos"]) == (128, 64) and p["blocks"] == 263 * 2 and p["k_loop"] == 3
     # operands VALU must touch are register-staged: deformable gather, input ReLU
