@@ -44,6 +44,8 @@ def parse(argv=None):
     ap.add_argument("--precision", choices=("bf16", "f32"), default="bf16")
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE configs[1]: 4)")
     ap.add_argument("--depth", type=int, default=None, help="backbone depth (overrides the config's)")
+    ap.add_argument("--lanes", type=int, default=1, help="run the batch as this many independent sub-batches on concurrent "
+                    "HIP streams inside the graph (their launch chains overlap each other's kernel boundaries and tails)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-step HIP-event breakdown to this file")
@@ -138,9 +140,38 @@ def run_inference(args, rank, world, dev):
                           "algorithmic_mb": round(tower.bytes / 1e6, 1)}))
         return None
 
+    # ---- optional: the batch as `lanes` independent sub-batches, each with its own plan, on concurrent streams
+    run_all = lambda: eng.run(img)
+    subs = []
+    if args.lanes > 1:
+        assert B % args.lanes == 0
+        from sipmask_amd.engine import SipMaskEngine
+        sd = det.state_dict()
+        bs = B // args.lanes
+        for i in range(args.lanes):
+            e = SipMaskEngine(sd, bs, (IMG_H, IMG_W), args.depth, det.test_cfg, det.bbox_head.num_classes,
+                              strides=det.bbox_head.strides, img_shape=shape, precision=args.precision)
+            subs.append((e, img[i * bs:(i + 1) * bs].contiguous(), torch.cuda.Stream()))
+
+        # sub-batch 0 runs on the caller's stream with its own side lanes (the plan's usual fork/join pattern); the
+        # others run as linear chains on one forked stream each: side lanes forked from a forked stream crash
+        # hipStreamEndCapture on ROCm 7.2 (segfault in capture_end, seen with 2 x 3 streams)
+        for e, x, st in subs[1:]:
+            e.multi_stream = False
+
+        def run_all():
+            main = torch.cuda.current_stream()
+            for e, x, st in subs[1:]:
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    e.run(x)
+            subs[0][0].run(subs[0][1])
+            for e, x, st in subs[1:]:
+                main.wait_stream(st)
+
     # ---- warm-up (eager), then optional graph capture
     for _ in range(max(1, min(args.warmup, 2))):
-        eng.run(img)
+        run_all()
     torch.cuda.synchronize()
     graph = None
     if not args.no_graph:
@@ -148,11 +179,11 @@ def run_inference(args, rank, world, dev):
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                eng.run(img)
+                run_all()
             torch.cuda.current_stream().wait_stream(s)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                eng.run(img)
+                run_all()
         except Exception as e:  # capture problems must not invalidate the measurement: fall back to eager
             print("[bench] graph capture failed (%s); running eagerly" % str(e)[:200], file=sys.stderr)
             graph = None
@@ -162,13 +193,14 @@ def run_inference(args, rank, world, dev):
         if graph is not None:
             graph.replay()
         else:
-            eng.run(img)
+            run_all()
 
     for _ in range(args.warmup):
         step()
     # barrier + torch.cuda.synchronize() on both sides, MAX over ranks (tested with gloo in tests/test_dist_shard.py)
     elapsed = timed_steps(step, args.steps, sync_fn=torch.cuda.synchronize, device=dev)
-    ndet = gather_counts(eng.results()["ndet"].to(torch.int64), device=dev).cpu().tolist()
+    nd_local = eng.results()["ndet"] if not subs else torch.cat([e.results()["ndet"] for e, _, _ in subs])
+    ndet = gather_counts(nd_local.to(torch.int64), device=dev).cpu().tolist()
 
     # ---- per-step HIP-event breakdown (eager, on the launch stream) -> roofline of the dominant kernel
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in eng.steps]
@@ -243,7 +275,8 @@ def run_inference(args, rank, world, dev):
                                "nms .5, max_per_img 100" % (args.depth, B, "f32 storage + exact-f32 MFMA (parity plan)" if f32
                                                             else "bf16 storage + f32 accumulate"),
                    "global_batch": B * world, "parallelism": "dp%d (batch shard, no collective)" % world,
-                   "launch": "hipGraph replay" if graph is not None else "eager",
+                   "launch": ("hipGraph replay" if graph is not None else "eager") +
+                             ("" if args.lanes == 1 else ", %d sub-batches of %d on concurrent streams" % (args.lanes, B // args.lanes)),
                    "detections_per_image": ndet},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,

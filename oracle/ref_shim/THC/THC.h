@@ -1,0 +1,1 @@
+// empty on purpose: see ../host_shim.h (oracle/ref_shim, test infrastructure)
