@@ -59,6 +59,7 @@ typedef enum {
 #define SM_CONV_DBG_K32_OPT 0x00080000u      /* A/B switch: flat loader + peeled loop + pipelined fragment reads in the 32-wide-K kernel (cin >= 32) */
 #define SM_CONV_DBG_HAND_PLACED 0x00040000u  /* A/B switch (with TILE256): hand-placed K step, LDS-DMA pieces between the MFMAs */
 #define SM_CONV_DBG_RES_PREFETCH 0x00020000u /* A/B switch: 32-wide-K kernel loads the residual rows BEFORE the K loop (HBM-bound 1x1 + residual convs) */
+#define SM_CONV_DBG_DEFORM_128 0x00008000u  /* A/B switch: deformable conv on the 128-cout x 128-position 4-wave tile (default: 256 x 128 on 8 waves) */
 #define SM_CONV_DBG_NO_SPLITK 0x00010000u   /* A/B switch: sm_conv2d_ws never splits K */
 #define SM_CONV_DBG_WARP_SPEC 0x02000000u    /* A/B switch: 8-wave producer/consumer variant of the 64-wide-K kernel */
 

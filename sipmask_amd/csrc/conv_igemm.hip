@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   static_assert(WCO * WPOS == 4 || (WCO * WPOS == 8 && !PROD), "4 waves, or 8 without the producer split");
   static_assert(NW <= 8 && NX <= 8, "Stage8 holds 8 chunks");
   static_assert(OPT == 0 || (DMA && !PROD), "OPT variants exist for the plain LDS-DMA loop only");
-  static_assert(WCO * WPOS == 4 || (OPT & 3) == 3, "the 8-wave tile is built on the flat, pipelined loop");
+  static_assert(WCO * WPOS == 4 || (OPT & 3) == 3 || !DMA, "the 8-wave LDS-DMA tile is built on the flat, pipelined loop");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   const int gtid = threadIdx.x;                       // 0..THREADS-1 (epilogue work split)
@@ -233,7 +233,13 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   // deformable gather state between "issue" (before the MFMAs) and "finish" (after them)
   constexpr bool DSPLIT = DEFORM && (NX <= 4);
   Stage8 cqa, cqb;                 // 16 corner chunks (rows i, corners 0..3) when DSPLIT
-  float cw[DSPLIT ? NX : 1][4];    // corner weights (0 where the corner / sample is invalid)
+  // PF2 (A/B, compiled out): TWO K steps of corner loads in flight for deformable tiles with <= 2 rows per thread (set
+  // 0 in cqa, set 1 in cqb).  Measured on the 8-wave 256 x 128 FeatureAlign tile: 0.330 ms vs 0.275 ms without -- the
+  // K step is bound by the loader's VALU (setup + blend) and its registers, not by gather latency.
+  constexpr bool PF2 = false && DEFORM && NX <= 2;
+  float cw[2][DSPLIT ? NX : 1][4];    // corner weights per set (0 where the corner / sample is invalid)
+  using CS0 = std::integral_constant<int, 0>;
+  using CS1 = std::integral_constant<int, 1>;
   uint32_t xmaskA[NX], xmaskB[NX];  // plain conv: all-ones where the tap is inside the image
   const uint32_t relu_m = (a.flags & SM_CONV_IN_RELU) ? 0xffffu : 0u;
 
@@ -245,9 +251,28 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
     });
   };
 
+  // deformable offsets, prefetched one K step ahead (see load_x)
+  float2 off_pf[DEFORM ? NX : 1];
+  bool off_ready = false;
+  auto issue_off = [&](int kc, int kh_, int kw_, int cc_, float2 (&dst)[DEFORM ? NX : 1]) {
+    if constexpr (DEFORM) {
+      const int ntap = a.kh * a.kw;
+      const int tap = kh_ * a.kw + kw_;
+      const int g = cc_ / a.cpg8;
+      const bool kvalid = kc < a.nchunk;
+      const long long orow0 = a.out_row0[lev] + m0 + r0;
+      static_for<NX>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const bool ok = kvalid && rhi[i] > -0x20000000;
+        const long long oo = ok ? (orow0 + LROWS * i) * (long long)(a.dg * ntap * 2) + (g * ntap + tap) * 2 : 0ll;
+        dst[i] = *reinterpret_cast<const float2*>(a.offset + oo);
+      });
+    }
+  };
   // All global loads below are UNCONDITIONAL (clamped address + select): a load inside an
   // exec-masked branch makes hipcc wait vmcnt(0) at the join, which serialises the row loads.
-  auto load_x = [&](int, Stage8& xreg, uint32_t (&xmask)[NX]) {
+  auto load_x = [&](int, Stage8& xreg, uint32_t (&xmask)[NX], auto CS) {
+    constexpr int cs = decltype(CS)::value;
     const int kc = ld_kc;
     const int tap = ld_kh * a.kw + ld_kw;
     const int c0 = ld_cc * 8;
@@ -270,16 +295,35 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
       // deformable bilinear gather (deform_conv_cuda_kernel.cu:85-115,216-229); the offset row is
       // the output row (stride-1 "same" conv).  Phase 1: offsets of all rows, phase 2: all corner
       // loads, phase 3 (finish_x, after the MFMAs when DSPLIT): blend to bf16.
-      const int g = (c0 >> 3) / a.cpg8;
       const int ntap = a.kh * a.kw;
       const long long orow0 = a.out_row0[lev] + m0 + r0;
+      // the offsets of THIS K step were requested one step ago (off_pf); request the next step's now, so that the
+      // dependent chain of a step is corner loads -> blend only (offset load -> address -> corner load -> blend was two
+      // exposed memory latencies per K step at one block per CU)
       float2 off[NX];
-      static_for<NX>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        const bool ok = kvalid && rhi[i] > -0x20000000;
-        const long long oo = ok ? (orow0 + LROWS * i) * (long long)(a.dg * ntap * 2) + (g * ntap + tap) * 2 : 0ll;
-        off[i] = *reinterpret_cast<const float2*>(a.offset + oo);
-      });
+      if (!off_ready) {
+        issue_off(kc, ld_kh, ld_kw, ld_cc, off_pf);
+        off_ready = true;
+      }
+      static_for<NX>([&](auto I) { off[decltype(I)::value] = off_pf[decltype(I)::value]; });
+      {
+        int ncc = ld_cc + 8, nkh = ld_kh, nkw = ld_kw;
+        if (a.cpt >= 8) {
+          if (ncc >= a.cpt) {
+            ncc -= a.cpt;
+            if (++nkw == a.kw) {
+              nkw = 0;
+              ++nkh;
+            }
+          }
+        } else {
+          const int ntp = (kc + 8) / a.cpt;
+          ncc = (kc + 8) - ntp * a.cpt;
+          nkh = ntp / a.kw;
+          nkw = ntp - nkh * a.kw;
+        }
+        issue_off(kc + 8, nkh, nkw, ncc, off_pf);
+      }
       static_for<NX>([&](auto I) {
         constexpr int i = decltype(I)::value;
         const bool ok = kvalid && rhi[i] > -0x20000000;
@@ -304,11 +348,16 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
         const u32x4 q3 = *reinterpret_cast<const u32x4*>(base + (long long)(hh_ * W + wl) * a.in_cstride);
         const u32x4 q4 = *reinterpret_cast<const u32x4*>(base + (long long)(hh_ * W + wh_) * a.in_cstride);
         if constexpr (DSPLIT) {
-          cw[i][0] = w1;
-          cw[i][1] = w2;
-          cw[i][2] = w3;
-          cw[i][3] = w4;
-          if constexpr (i < 2) {
+          cw[cs][i][0] = w1;
+          cw[cs][i][1] = w2;
+          cw[cs][i][2] = w3;
+          cw[cs][i][3] = w4;
+          if constexpr (PF2 && cs == 1) {
+            cqb.template at<4 * i + 0>() = q1;
+            cqb.template at<4 * i + 1>() = q2;
+            cqb.template at<4 * i + 2>() = q3;
+            cqb.template at<4 * i + 3>() = q4;
+          } else if constexpr (i < 2) {
             cqa.template at<4 * i + 0>() = q1;
             cqa.template at<4 * i + 1>() = q2;
             cqa.template at<4 * i + 2>() = q3;
@@ -333,7 +382,8 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
     }
   };
 
-  auto finish_x = [&](Stage8& xreg, uint32_t (&xmask)[NX]) {
+  auto finish_x = [&](Stage8& xreg, uint32_t (&xmask)[NX], auto CS) {
+    constexpr int cs = decltype(CS)::value;
     if constexpr (!DEFORM) {
       static_for<NX>([&](auto I) {
         constexpr int i = decltype(I)::value;
@@ -356,7 +406,12 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
       static_for<NX>([&](auto I) {
         constexpr int i = decltype(I)::value;
         float f1[8], f2[8], f3[8], f4[8], r[8];
-        if constexpr (i < 2) {
+        if constexpr (PF2 && cs == 1) {
+          unpack_bf16x8(cqb.template at<4 * i + 0>(), f1);
+          unpack_bf16x8(cqb.template at<4 * i + 1>(), f2);
+          unpack_bf16x8(cqb.template at<4 * i + 2>(), f3);
+          unpack_bf16x8(cqb.template at<4 * i + 3>(), f4);
+        } else if constexpr (i < 2) {
           unpack_bf16x8(cqa.template at<4 * i + 0>(), f1);
           unpack_bf16x8(cqa.template at<4 * i + 1>(), f2);
           unpack_bf16x8(cqa.template at<4 * i + 2>(), f3);
@@ -367,7 +422,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
           unpack_bf16x8(cqb.template at<4 * (i - 2) + 2>(), f3);
           unpack_bf16x8(cqb.template at<4 * (i - 2) + 3>(), f4);
         }
-        const float w1 = cw[i][0], w2 = cw[i][1], w3 = cw[i][2], w4 = cw[i][3];
+        const float w1 = cw[cs][i][0], w2 = cw[cs][i][1], w3 = cw[cs][i][2], w4 = cw[cs][i][3];
 #pragma unroll
         for (int e = 0; e < 8; ++e) r[e] = w1 * f1[e] + w2 * f2[e] + w3 * f3[e] + w4 * f4[e];
         xreg.template at<i>() = pack_bf16x8_v(r);
@@ -632,19 +687,17 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
     }
   } else {
   load_w(0, wregA);
-  load_x(0, xregA, xmaskA);
+  load_x(0, xregA, xmaskA, CS0{});
   advance_k();
-  finish_x(xregA, xmaskA);
+  finish_x(xregA, xmaskA, CS0{});
   store_tile(0, wregA, xregA);
-  // Depth-2 register prefetch was measured NEUTRAL on MI355X (tower 616 vs 618 TF/s, layer3/4
-  // 3x3 unchanged): the K loop is VALU/issue bound, not load-latency bound; it costs 36 VGPRs,
-  // so it is compiled out.  Kept for future A/B.
-  constexpr bool PF2 = false;
+  // Depth-2 register prefetch was measured NEUTRAL for the plain register-staged convs (tower 616 vs 618 TF/s, layer3/4
+  // 3x3 unchanged) and NEGATIVE for the 8-wave deformable tile (PF2 above): compiled out.
   if constexpr (PF2) {
     // register-prefetch depth 2: sets A/B alternate, statically named (loop unrolled by two)
     if (nk > 1) {
       load_w(1, wregA);
-      load_x(1, xregA, xmaskA);
+      load_x(1, xregA, xmaskA, CS0{});
       advance_k();
     }
     __syncthreads();
@@ -652,12 +705,12 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
       // even step: LDS[0] = tile kt, set A = tile kt+1 (in flight), issue tile kt+2 -> set B
       if (kt + 2 < nk) {
         load_w(kt + 2, wregB);
-        load_x(kt + 2, xregB, xmaskB);
+        load_x(kt + 2, xregB, xmaskB, CS1{});
         advance_k();
       }
       compute(0);
       if (kt + 1 < nk) {
-        finish_x(xregA, xmaskA);
+        finish_x(xregA, xmaskA, CS0{});
         store_tile(1, wregA, xregA);
       }
       __syncthreads();
@@ -665,12 +718,12 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
       // odd step: LDS[1] = tile kt+1, set B = tile kt+2 (in flight), issue tile kt+3 -> set A
       if (kt + 3 < nk) {
         load_w(kt + 3, wregA);
-        load_x(kt + 3, xregA, xmaskA);
+        load_x(kt + 3, xregA, xmaskA, CS0{});
         advance_k();
       }
       compute(1);
       if (kt + 2 < nk) {
-        finish_x(xregB, xmaskB);
+        finish_x(xregB, xmaskB, CS1{});
         store_tile(0, wregB, xregB);
       }
       __syncthreads();
@@ -682,12 +735,12 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
       const bool more = (kt + 1) < nk;
       if (more) {
         load_w(kt + 1, wregA);
-        load_x(kt + 1, xregA, xmaskA);
+        load_x(kt + 1, xregA, xmaskA, CS0{});
         advance_k();
       }
       compute(buf);
       if (more) {
-        finish_x(xregA, xmaskA);
+        finish_x(xregA, xmaskA, CS0{});
         store_tile(buf ^ 1, wregA, xregA);
       }
       __syncthreads();
@@ -1576,7 +1629,14 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p,
   const bool reg_ok = !(d->flags & SM_CONV_DBG_LDS_EPILOGUE) && (d->cout & 7) == 0 && (d->out_cstride & 7) == 0 &&
                       (d->out_coff & 7) == 0 && (!has_res || (d->res_cstride & 7) == 0);
   if (!dma) {
-    cands[ncand++] = {tile, tile == 128 ? 128 : 256};
+    // deformable conv: the bilinear gather (offset load, corner weights, 4 corner loads and a VALU blend per 8-channel
+    // chunk) is the loader's cost and it is paid once per BLOCK tile row, whatever the cout extent: a 256-cout x
+    // 128-position tile on 8 waves halves the gather work per MFMA of the 128 x 128 tile (the FeatureAlign conv was
+    // VALU-bound in the loader: ~520 loader VALU per thread per K step against 512 MFMA cycles)
+    if (deform && tile == 128 && d->cout_pad % 256 == 0 && reg_ok && !(d->flags & SM_CONV_DBG_DEFORM_128))
+      cands[ncand++] = {256, 128};
+    else
+      cands[ncand++] = {tile, tile == 128 ? 128 : 256};
   } else if (tile == 128) {
     // 128 couts x 256 positions (64x128 per wave: 0.75 fragment reads and 0.75 DMA bytes per MFMA of the 128x128
     // tile), behind an A/B flag
@@ -1765,7 +1825,8 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   dim3 grid((unsigned)nblk), block(256);
 #define SM_LAUNCH(KERNEL) hipLaunchKernelGGL((KERNEL), grid, block, 0, stream, a)
   if (!dma) {
-    if (tile == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, DEFORM, false>));
+    if (DEFORM && bco == 256) { block = dim3(512); SM_LAUNCH((conv_igemm_kernel<4, 2, 2, 2, DEFORM, false>)); }
+    else if (tile == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, DEFORM, false>));
     else if (tile == 64) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 2, DEFORM, false>));
     else SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 2, DEFORM, false>));
   } else if (k32) {

@@ -104,8 +104,10 @@ def test_conv_launch_plan_rules():
     p = _plan([(50, 84)], 256, 256, 3)                                            # layer3 3x3: M = 16800
     assert (p["tile_cout"], p["tile_pos"]) == (128, 64) and p["blocks"] == 263 * 2 and p["k_loop"] == 3
     # operands VALU must touch are register-staged: deformable gather, input ReLU
-    p = _plan(PYR, 256, 256, 3, deform=True)
-    assert (p["lds_dma"], p["tile_cout"], p["tile_pos"], p["k_loop"]) == (0, 128, 128, 0)
+    p = _plan(PYR, 256, 256, 3, deform=True)                                       # 256-cout x 128-position tile on 8 waves
+    assert (p["lds_dma"], p["tile_cout"], p["tile_pos"], p["k_loop"], p["threads"]) == (0, 256, 128, 0, 512)
+    p = _plan(PYR, 256, 256, 3, deform=True, flags=0x00008000)                     # A/B: the 4-wave 128 x 128 tile
+    assert (p["lds_dma"], p["tile_cout"], p["tile_pos"], p["threads"]) == (0, 128, 128, 256)
     assert _plan([(13, 21)], 256, 256, 3, stride=2, flags=16)["lds_dma"] == 0    # SM_CONV_IN_RELU (P7)
     # A/B flags: legacy / flat loop, forced K widths
     assert _plan(PYR, 256, 256, 3, flags=0x00100000)["k_loop"] == 0
