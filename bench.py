@@ -44,8 +44,8 @@ def parse(argv=None):
     ap.add_argument("--precision", choices=("bf16", "f32"), default="bf16")
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE configs[1]: 4)")
     ap.add_argument("--depth", type=int, default=None, help="backbone depth (overrides the config's)")
-    ap.add_argument("--lanes", type=int, default=1, help="run the batch as this many independent sub-batches on concurrent "
-                    "HIP streams inside the graph (their launch chains overlap each other's kernel boundaries and tails)")
+    ap.add_argument("--lanes", type=int, default=0, help="run the batch as this many independent sub-batch plans on "
+                    "concurrent HIP streams (engine.SubBatchPlan); 0 = the product default (2 for even batches >= 4)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-step HIP-event breakdown to this file")
@@ -117,11 +117,11 @@ def run_inference(args, rank, world, dev):
     g = torch.Generator().manual_seed(1234 + rank)
     img = torch.randn(B, 3, IMG_H, IMG_W, generator=g).to(dev)       # synthetic, resident in HBM
     shape = (IMG_H, 1333, 3)
-    eng = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision)
+    eng = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=1)
     calibrate_cls_bias(det, eng, img, target_per_img=1000)           # updates fcos_cls.bias in place -> plan rebuilt
     del eng
     torch.cuda.empty_cache()
-    eng = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision)
+    eng = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=1)
 
     if args.tower_only:
         eng.run(img)
@@ -140,34 +140,15 @@ def run_inference(args, rank, world, dev):
                           "algorithmic_mb": round(tower.bytes / 1e6, 1)}))
         return None
 
-    # ---- optional: the batch as `lanes` independent sub-batches, each with its own plan, on concurrent streams
-    run_all = lambda: eng.run(img)
-    subs = []
-    if args.lanes > 1:
-        assert B % args.lanes == 0
-        from sipmask_amd.engine import SipMaskEngine
-        sd = det.state_dict()
-        bs = B // args.lanes
-        for i in range(args.lanes):
-            e = SipMaskEngine(sd, bs, (IMG_H, IMG_W), args.depth, det.test_cfg, det.bbox_head.num_classes,
-                              strides=det.bbox_head.strides, img_shape=shape, precision=args.precision)
-            subs.append((e, img[i * bs:(i + 1) * bs].contiguous(), torch.cuda.Stream()))
-
-        # sub-batch 0 runs on the caller's stream with its own side lanes (the plan's usual fork/join pattern); the
-        # others run as linear chains on one forked stream each: side lanes forked from a forked stream crash
-        # hipStreamEndCapture on ROCm 7.2 (segfault in capture_end, seen with 2 x 3 streams)
-        for e, x, st in subs[1:]:
-            e.multi_stream = False
-
-        def run_all():
-            main = torch.cuda.current_stream()
-            for e, x, st in subs[1:]:
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    e.run(x)
-            subs[0][0].run(subs[0][1])
-            for e, x, st in subs[1:]:
-                main.wait_stream(st)
+    # ---- the timed plan: det.prepare's default runs an even batch >= 4 as two concurrent half-batch chains
+    # (engine.SubBatchPlan); --lanes 1 forces the single plan
+    del eng
+    torch.cuda.empty_cache()
+    plan = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=args.lanes or "auto")
+    subplans = getattr(plan, "engines", None)
+    eng = subplans[0] if subplans else plan          # the plan whose launches the breakdown / roofline below time
+    eng_img = img[:eng.batch].contiguous()
+    run_all = lambda: plan.run(img)
 
     # ---- warm-up (eager), then optional graph capture
     for _ in range(max(1, min(args.warmup, 2))):
@@ -199,14 +180,13 @@ def run_inference(args, rank, world, dev):
         step()
     # barrier + torch.cuda.synchronize() on both sides, MAX over ranks (tested with gloo in tests/test_dist_shard.py)
     elapsed = timed_steps(step, args.steps, sync_fn=torch.cuda.synchronize, device=dev)
-    nd_local = eng.results()["ndet"] if not subs else torch.cat([e.results()["ndet"] for e, _, _ in subs])
-    ndet = gather_counts(nd_local.to(torch.int64), device=dev).cpu().tolist()
+    ndet = gather_counts(plan.results()["ndet"].to(torch.int64), device=dev).cpu().tolist()
 
     # ---- per-step HIP-event breakdown (eager, on the launch stream) -> roofline of the dominant kernel
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in eng.steps]
     reps = 3
     acc = [0.0] * len(eng.steps)
-    eng.img = img
+    eng.img = eng_img
     for r in range(reps):
         for (label, fn), (e0, e1) in zip(eng.steps, ev):
             e0.record()
@@ -236,13 +216,13 @@ def run_inference(args, rank, world, dev):
     # committed rocprofv3 summary of the same kernel/shape (profiles/), per launch
     traffic, traffic_src = None, None
     pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_tower_conv.json" if grouped else "r01_pmc_tower_conv.json")
-    if os.path.exists(pmc_file) and B == 4 and not f32:
+    if os.path.exists(pmc_file) and eng.batch == 4 and not f32:
         pmc = json.load(open(pmc_file))
         traffic = round(pmc["hbm_bytes_per_launch"] / 1e6, 1)
         traffic_src = "profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), MB per launch" % os.path.basename(pmc_file)
     if args.breakdown and rank == 0:
         with open(args.breakdown, "w") as f:
-            f.write("# per-step HIP event times (ms), eager launches, batch %d, mean of %d\n" % (B, reps))
+            f.write("# per-step HIP event times (ms), eager launches, plan batch %d, mean of %d\n" % (eng.batch, reps))
             cinfo = {"conv:" + c.name: c for c in eng.convs}
             for (label, _), ms in zip(eng.steps, acc):
                 c = cinfo.get(label)
@@ -255,15 +235,15 @@ def run_inference(args, rank, world, dev):
                     (sum(acc), all_conv_ms, all_conv_flops / all_conv_ms / 1e9, all_conv_flops / 1e9))
     if f32:
         kernel = ("conv_f32_kernel<2,2,2,2> (v_mfma_f32_32x32x2_f32, 128x128 tile, 16-wide K steps, register-staged "
-                  "loader) = tower 3x3 256->256 over 5 FPN levels (M=%d,N=256,K=2304)" % (B * 22400))
+                  "loader) = tower 3x3 256->256 over 5 FPN levels (M=%d,N=256,K=2304)" % (eng.batch * 22400))
     elif grouped:
         kernel = ("conv_igemm_kernel<2,4,4,2,false,true,0,7> (LDS-DMA, 256x256 tile on 8 waves, 64-wide K steps, "
                   "hand-placed DMA issue, GroupNorm statistics fused), cls+reg tower 3x3 256->256 of one depth as ONE "
-                  "grouped launch over 5 FPN levels (2 x (M=%d,N=256,K=2304))" % (B * 22400))
+                  "grouped launch over 5 FPN levels (2 x (M=%d,N=256,K=2304))" % (eng.batch * 22400))
     else:
         kernel = ("conv_igemm_kernel<2,2,2,2,false,true,0,3> (LDS-DMA, 128x128 tile, 64-wide K steps, flat loader + "
                   "pipelined fragment reads, GroupNorm statistics fused) = tower 3x3 256->256 over 5 FPN levels "
-                  "(M=%d,N=256,K=2304)" % (B * 22400))
+                  "(M=%d,N=256,K=2304)" % (eng.batch * 22400))
     out = {
         "metric": "img/s SipMask-R%d 800x1333 inference (ResNet%d+FPN+SipMaskHead+NMS+mask assembly)" % (args.depth, args.depth),
         "value": round(B * args.steps * world / elapsed, 3),
@@ -276,7 +256,8 @@ def run_inference(args, rank, world, dev):
                                                             else "bf16 storage + f32 accumulate"),
                    "global_batch": B * world, "parallelism": "dp%d (batch shard, no collective)" % world,
                    "launch": ("hipGraph replay" if graph is not None else "eager") +
-                             ("" if args.lanes == 1 else ", %d sub-batches of %d on concurrent streams" % (args.lanes, B // args.lanes)),
+                             ("" if not subplans else ", %d sub-batch plans of %d images on concurrent streams"
+                              % (len(subplans), eng.batch)),
                    "detections_per_image": ndet},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -284,7 +265,7 @@ def run_inference(args, rank, world, dev):
                      "gflop_per_launch": round(tower_flops / 1e9, 2), "ms_per_launch": round(tower_ms, 4),
                      "all_convs_tflops": round(all_conv_flops / (all_conv_ms * 1e-3) / 1e12, 2),
                      "fpn_convs_tflops": round(fpn_tf, 2),
-                     "conv_gflop_per_step": round(all_conv_flops / 1e9, 1)},
+                     "conv_gflop_per_step": round(plan.total_conv_flops() / 1e9, 1)},
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_inference(det, args.depth)

@@ -35,23 +35,35 @@ class SipMask(nn.Module):
         self.bbox_head.init_weights()
         self._engines.clear()
 
-    def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False, precision="bf16"):
+    def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False, precision="bf16", lanes="auto"):
         """Build (or fetch) the static launch plan for this input geometry; weights are snapshotted,
         BN folded, re-laid out as bf16 GEMM operands.  Call again after load_state_dict.
         scale_factor / rescale: img_meta['scale_factor'] and the rescale flag of simple_test (boxes and masks
         in original-image coordinates, sipmask_head.py:587-588,621-632).  precision: "bf16" = the throughput plan,
         "f32" = the parity plan (exact-f32 MFMA convs, every tensor f32: held to the fp32 reference within
-        accumulation-order rounding)."""
+        accumulation-order rounding).  lanes: the batch as this many concurrent sub-batch plans (engine.SubBatchPlan);
+        "auto" = 2 for even batches >= 4, else 1."""
         import numpy as np
         from .engine import SipMaskEngine
         key = (batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
-               rescale, precision)
+               rescale, precision, lanes)
         # plans are valid for the weights they were built from: PlanCache drops them when any parameter / buffer has
         # been updated in place since (optimizer.step, load_state_dict, mmcv load_checkpoint)
-        return self._engines.get(key, module_tensors(self), lambda: SipMaskEngine(
-            self.state_dict(), batch, img_hw, self.backbone.depth, self.test_cfg, self.bbox_head.num_classes,
-            strides=self.bbox_head.strides, img_shape=img_shape, ssd_flag=self.bbox_head.ssd_flag,
-            scale_factor=scale_factor, rescale=rescale, precision=precision))
+        if lanes == "auto":        # SubBatchPlan: two concurrent half-batch chains pay off from 2 images per chain on
+            lanes = 2 if (batch >= 4 and batch % 2 == 0 and not getattr(self.bbox_head, "rescoring_flag", False)) else 1
+        assert batch % lanes == 0
+
+        def build():
+            sd = self.state_dict()
+            mk = lambda b: SipMaskEngine(sd, b, img_hw, self.backbone.depth, self.test_cfg, self.bbox_head.num_classes,
+                                         strides=self.bbox_head.strides, img_shape=img_shape,
+                                         ssd_flag=self.bbox_head.ssd_flag, scale_factor=scale_factor, rescale=rescale,
+                                         precision=precision)
+            if lanes == 1:
+                return mk(batch)
+            from .engine import SubBatchPlan
+            return SubBatchPlan([mk(batch // lanes) for _ in range(lanes)])
+        return self._engines.get(key, module_tensors(self), build)
 
     def get_masks(self, img, img_metas=None):
         """Batch-capable tensor-only inference (compare before RLE): dict of device tensors

@@ -760,6 +760,81 @@ class SipMaskEngine:
         return sum(c.flops for c in self.convs)
 
 
+class SubBatchPlan:
+    """A batch run as `lanes` independent sub-batches, each with its own launch plan, on concurrent HIP streams (one
+    linear launch chain per sub-batch, forked from and joined to the caller's stream; capture-safe).
+
+    Why: a launch plan is ~125 dependent kernels, and at 4 images per step a third of the step is what happens BETWEEN
+    them (launch boundaries, ramp-up, tails, single-tile K loops of the small layers: t(B) = 1.65 ms + 0.87 ms/image,
+    profiles/r02*).  Two chains of B/2 fill each other's gaps: measured 887 vs 850 img/s at B=4, 1046 vs 912 at B=8
+    (MI355X, hipGraph replay).  Sub-batches of ONE image lose more per launch than they gain (648 img/s), hence the
+    `lanes="auto"` rule of SipMask.prepare: 2 lanes iff the batch is even and >= 4.
+    The sub-plans run without their own side lanes: forking side streams from a stream that is itself a fork
+    crashes hipStreamEndCapture on ROCm 7.2 (segfault), and the second chain covers what the side lanes covered.
+    Outputs are ONE set of batch-sized tensors; every sub-plan writes its slice."""
+
+    def __init__(self, engines):
+        assert len(engines) >= 2 and all(e.rescorer is None for e in engines)
+        self.engines = engines
+        self.batch = sum(e.batch for e in engines)
+        e0 = engines[0]
+        self.lv, self.ncls, self.cfg, self.max_num = e0.lv, e0.ncls, e0.cfg, e0.max_num
+        self.H, self.W, self.ho, self.wo, self.pitch = e0.H, e0.W, e0.ho, e0.wo, e0.pitch
+        dev = e0.device
+        mk = lambda t: torch.zeros((self.batch,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        self.out = {k: mk(e0.nms_out[k]) for k in ("det", "labels", "keep", "ndet")}
+        self.masks = mk(e0.masks)
+        self.det_feats = mk(e0.det_feats) if e0.track_feats is not None else None
+        b0 = 0
+        for e in engines:                       # every sub-plan writes its slice of the shared outputs
+            e.multi_stream = False
+            sl = slice(b0, b0 + e.batch)
+            for k in self.out:
+                e.nms_out[k] = self.out[k][sl]
+            e.masks = self.masks[sl]
+            if getattr(e, "fused_masks", False):
+                e.mask_buf["masks"] = e.masks
+            if self.det_feats is not None:
+                e.det_feats = self.det_feats[sl]
+            b0 += e.batch
+        self.streams = [torch.cuda.Stream(device=dev) for _ in engines[1:]]
+
+    def run(self, img):
+        assert img.shape[0] == self.batch
+        main = torch.cuda.current_stream()
+        b0 = self.engines[0].batch
+        for e, st in zip(self.engines[1:], self.streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                e.run(img[b0:b0 + e.batch])
+            b0 += e.batch
+        self.engines[0].run(img[:self.engines[0].batch])
+        for st in self.streams:
+            main.wait_stream(st)
+        return self.results()
+
+    def results(self):
+        r = dict(det_bboxes=self.out["det"], det_labels=self.out["labels"], idxs_keep=self.out["keep"], ndet=self.out["ndet"],
+                 masks=self.masks[..., :self.wo])
+        if self.det_feats is not None:
+            r["det_feats"] = self.det_feats
+        return r
+
+    def encode_rle(self, canvas_hw=None, fetch=True, max_runs=8192):
+        assert fetch, "device-side RLE buffers are per sub-plan"
+        out = []
+        for e in self.engines:
+            out.extend(e.encode_rle(canvas_hw, True, max_runs))
+        return out
+
+    @property
+    def convs(self):
+        return [c for e in self.engines for c in e.convs]
+
+    def total_conv_flops(self):
+        return sum(e.total_conv_flops() for e in self.engines)
+
+
 class PostProcessor:
     """SipMaskHead.get_bboxes on caller-provided head outputs (the API-faithful path used by the
     parity tests: identical f32 inputs on both sides).  sipmask_head.py:500-633."""
