@@ -236,6 +236,11 @@ def run_inference(args, rank, world, dev):
     if f32:
         kernel = ("conv_f32_kernel<2,2,2,2> (v_mfma_f32_32x32x2_f32, 128x128 tile, 16-wide K steps, register-staged "
                   "loader) = tower 3x3 256->256 over 5 FPN levels (M=%d,N=256,K=2304)" % (eng.batch * 22400))
+    elif getattr(towers[0], "patch", False):
+        kernel = ("conv3x3_patch_kernel (input patch + 2 taps of weights resident in LDS via LDS-DMA, 256x256 tile on 8 "
+                  "waves, GroupNorm statistics fused)%s = tower 3x3 256->256 over 5 FPN levels (%sM=%d,N=256,K=2304)"
+                  % (", cls+reg towers of one depth as ONE grouped launch" if grouped else "", "2 x " if grouped else "",
+                     eng.batch * 22400))
     elif grouped:
         kernel = ("conv_igemm_kernel<2,4,4,2,false,true,0,7> (LDS-DMA, 256x256 tile on 8 waves, 64-wide K steps, "
                   "hand-placed DMA issue, GroupNorm statistics fused), cls+reg tower 3x3 256->256 of one depth as ONE "

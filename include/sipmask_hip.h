@@ -135,6 +135,19 @@ int sm_conv2d(const sm_conv_desc* d, const void* x, const void* w, const float* 
 int sm_conv2d_ws(const sm_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
                  void* workspace, int64_t workspace_bytes, sm_stream_t stream);
 
+/* 3x3 / stride 1 / pad 1 convolution with the input patch resident in LDS (csrc/conv3x3_patch.hip): the throughput
+ * kernel for the large 3x3 layers (tower convs -- also as the grouped cls+reg launch --, fcos_cls + sip_cof, FPN
+ * output convs).  Same descriptor, activations and epilogue semantics as sm_conv2d / sm_conv2d_gn_stats (bias,
+ * per-level Scale on scale_nch channels, ReLU, bf16 / f32 output, fused GroupNorm statistics when gn_stats != NULL,
+ * multi-level, group dimension; no residual), but the weights come in the kernel's own K order:
+ *   w_patch bf16 [cout_pad][cin/32][9][32]  (32-channel chunk, tap kh*3+kw, channel), cout_pad a multiple of 256.
+ * sm_conv3x3_patch_supported: 1 if the descriptor is eligible (3x3 s1 p1, cin % 64 == 0, cout_pad % 256 == 0, 8-aligned
+ * output, level widths <= 253); sm_conv3x3_patch_tiles: its grid size (256-position x 256-cout tiles). */
+int sm_conv3x3_patch_supported(const sm_conv_desc* d);
+int64_t sm_conv3x3_patch_tiles(const sm_conv_desc* d);
+int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void* w_patch, const float* bias, void* y,
+                     float* gn_stats, sm_stream_t stream);
+
 /* Deformable conv v1 forward, bilinear gather fused into the GEMM operand load
  * (never materialises the column buffer).  Replaces deform_conv_forward_cuda,
  * M/mmdet/ops/dcn/src/deform_conv_cuda.cpp:152-260 + deformable_im2col_gpu_kernel,

@@ -1,0 +1,409 @@
+// 3x3 / stride 1 / pad 1 convolution with the INPUT PATCH resident in LDS (gfx950).
+//
+// Why a second conv kernel.  conv_igemm.hip walks K = (tap, cin) and DMAs, per 64-wide K step, a fresh [positions x 64]
+// activation tile: every input pixel crosses L2 -> LDS nine times (once per tap).  Its 256x256 tile moves 128 FLOP per
+// L2->LDS byte and the LDS-DMA path (~56 B/clk/CU, MI355X_MICROARCH.md) then caps it near half of the MFMA rate; the
+// measured ceiling was 970 TFLOP/s on the tower convs.  Here the loop order is (32-channel
+// chunk, tap): the block DMAs ONE patch -- its 256 output positions plus the 3x3 halo, 32 channels deep -- and the nine
+// taps read it from LDS at nine row shifts.  Activation bytes per K step drop ~4x (weights now dominate: 203 FLOP per
+// DMA byte for W = 168), and the DMA instruction count per MFMA from 8/32 to ~5/32.
+//
+// Geometry.  Positions are tiled in PADDED-FLAT coordinates per image: q = oh * (W+2) + (ow+1), i.e. every image row
+// carries one zero column on each side.  A tile is 256 consecutive q of one image (the two pad columns are dummy
+// outputs: 1.2 % at W = 168), so a tap (kh, kw) is the constant row shift kh*(W+2) + kw inside the patch and the 32
+// positions of an MFMA tile read 32 CONSECUTIVE patch rows: the XOR swizzle of the 64-byte rows stays conflict free
+// for any shift (rows distinct mod 16 per ds_read_b128 lane group).  Patch rows = 256 + 2*(W+2) + 2 (598 for W = 168).
+// LDS: 2 patch buffers (chunk c computes while chunk c+1 lands) + 2 weight stages of 2 taps x 256 couts x 64 B.
+// Weights come in their own layout [cout_pad][cin/32][9][32] (K order = chunk, tap, channel), one DMA piece = 16 cout
+// rows x 64 B.  8 waves (2 cout x 4 pos), wave tile 128 couts x 64 positions, 1 block per CU, one barrier per 2 taps.
+// Epilogue: conv_igemm's register epilogue (v_permlane32_swap -> 8 consecutive couts per lane), bias, per-level Scale,
+// ReLU, bf16 / f32 stores, fused GroupNorm statistics; multi-level launches and the group dimension (cls + reg towers).
+#include <utility>
+
+#include "common.h"
+
+namespace {
+
+struct PatchArgs {
+  const uint16_t* x;
+  const uint16_t* w;
+  const float* bias;
+  void* y;
+  float* gn_stats;
+  int nlev, batch;
+  int h[SM_MAX_LEVELS], w_[SM_MAX_LEVELS];
+  long long in_row0[SM_MAX_LEVELS], out_row0[SM_MAX_LEVELS];
+  int tile0[SM_MAX_LEVELS + 1];   // first position tile of each level (inside one group)
+  int tpi[SM_MAX_LEVELS];         // position tiles per image of the level
+  int cin, cout, nc, ntn;         // nc = cin / 32, ntn = cout_pad / 256
+  int in_cstride, out_cstride, out_coff;
+  long long Kp;                   // weight row pitch (elements) = 9 * cin
+  unsigned flags;
+  int scale_nch;
+  float level_scale[SM_MAX_LEVELS];
+  int prow_cap;                   // rows of one patch buffer (multiple of 16)
+  int ngroups, tpg;
+  long long x_grows, y_grows, w_gstride, b_gstride, gn_gstride;
+};
+
+template <int N, typename F, int... Is>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+  sfor_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16p[4] = {0u, 0u, 0u, 0u};
+
+constexpr int PT_BCO = 256, PT_BPOS = 256, PT_THREADS = 512;
+constexpr int PT_WSTAGE = 2 * PT_BCO * 64;        // one weight stage: 2 taps x 256 couts x 64 B
+constexpr int PT_MAXPP = 6;                       // patch DMA pieces per wave (<= 768 patch rows)
+
+__global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_kernel(const PatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [W stage 0][W stage 1][patch 0][patch 1]
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  constexpr int TCO = 4, TPOS = 2;                // wave tile: 4 x 2 MFMA tiles of 32 x 32
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave >> 2, wpos = wave & 3;
+  const int l31 = lane & 31, khalf = lane >> 5;
+
+  // ---- tile decode (wave-uniform); XCD-contiguous tile ranges as in conv_igemm.hip
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, xq = nblk >> 3, xr = nblk & 7;
+  const int tlin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)(blockIdx.x >> 3);
+  const int grp = a.ngroups > 1 ? tlin / a.tpg : 0;
+  const int tl_g = tlin - grp * a.tpg;
+  const int nt = tl_g % a.ntn;
+  const int mt = tl_g / a.ntn;
+  int lev = 0;
+#pragma unroll
+  for (int l = 1; l < SM_MAX_LEVELS; ++l)
+    if (l < a.nlev && mt >= a.tile0[l]) lev = l;
+  const int H = a.h[lev], W = a.w_[lev], Wp = W + 2;
+  const int ti = mt - a.tile0[lev];
+  const int n = ti / a.tpi[lev];
+  const int q0 = (ti - n * a.tpi[lev]) * PT_BPOS;
+  const long long img_row0 = a.in_row0[lev] + grp * a.x_grows + (long long)n * H * W;
+
+  const int PB = a.prow_cap * 64;                 // bytes of one patch buffer
+  unsigned char* const Wb0 = smem;
+  unsigned char* const Pb0 = smem + 2 * PT_WSTAGE;
+
+  // ---- loader state.  A DMA piece is 16 rows x 64 B: lane L -> row (L >> 2), physical slot (L & 3), so it fetches
+  // the logical 16-byte chunk (L & 3) ^ ((row >> 2) & 3) of that row (swizzle on the source side, guide rule 21).
+  const int lrow = lane >> 2;
+  const int npieces = (PT_BPOS + 2 * Wp + 2 + 15) >> 4;
+  const unsigned long long zero_page = (unsigned long long)g_zero16p;
+  // patch: this wave owns pieces wave, wave + 8, ...; per piece the lane's source offset (elements) or -1 (zero page)
+  int poff[PT_MAXPP];
+#pragma unroll
+  for (int i = 0; i < PT_MAXPP; ++i) {
+    const int piece = wave + 8 * i;
+    const int r = piece * 16 + lrow;                           // patch row
+    const int qi = q0 - Wp - 1 + r;                            // padded-flat input index
+    const int ih = qi >= 0 ? qi / Wp : -1;
+    const int iwp = qi - ih * Wp;
+    const bool ok = piece < npieces && ih >= 0 && ih < H && iwp >= 1 && iwp <= W;
+    const int chunk = (lane & 3) ^ ((r >> 2) & 3);
+    poff[i] = ok ? (int)((ih * W + iwp - 1) * a.in_cstride + chunk * 8) : -1;
+  }
+  const uint16_t* const xbase = a.x + img_row0 * a.in_cstride;
+  // weights: a stage = 2 halves (taps) x 16 pieces; this wave owns pieces wave*4 .. wave*4+3 (half = piece >> 4)
+  const uint16_t* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const int half = piece >> 4, row = (piece & 15) * 16 + lrow;
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    wsrc[i] = a.w + grp * a.w_gstride + (long long)(nt * PT_BCO + row) * a.Kp + half * 32 + chunk * 8;
+  }
+  auto dma_w = [&](int stage, int buf) {            // weight stage `stage` (K steps 2*stage, 2*stage+1) -> Wb[buf]
+    unsigned char* dst = Wb0 + buf * PT_WSTAGE;
+    sfor<4>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      const int piece = wave * 4 + i;
+      __builtin_amdgcn_global_load_lds((glb_void*)(wsrc[i] + (long long)stage * 64),
+                                       (lds_void*)(dst + (piece >> 4) * (PT_BCO * 64) + (piece & 15) * 1024), 16, 0, 0);
+    });
+  };
+  auto dma_patch_piece = [&](auto I, int chunk_c, int buf) {     // piece I of this wave, channel chunk c -> Pb[buf]
+    constexpr int i = decltype(I)::value;
+    const int piece = wave + 8 * i;
+    if (piece < npieces) {                                       // wave-uniform
+      const unsigned long long pm = poff[i] >= 0 ? ~0ull : 0ull;
+      const unsigned long long src = ((unsigned long long)(xbase + poff[i] + chunk_c * 32) & pm) | (zero_page & ~pm);
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Pb0 + buf * PB + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TCO][TPOS];
+#pragma unroll
+  for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TPOS; ++tp)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tc][tp][e] = 0.f;
+
+  const int rsw = (l31 >> 2) & 3;
+  const int wrow_off = (wco * 128 + l31) * 64;
+  const int prow0 = wpos * 64 + l31;              // patch row of this lane's position at tap (0,0), tp = 0
+
+  // one tap: 2 K sub-steps of 16, 8 MFMAs each; both sub-steps' fragments are requested up front and hipcc schedules the
+  // stage (2 taps = 24 reads + 32 MFMAs, one basic block).  A/B (round 2): the same stage with the reads of sub-step
+  // u+1 pinned under the MFMAs of u and the DMA issues pinned behind every second MFMA (sched_barrier(0) per slot)
+  // needed 256 VGPRs + 19 spills and ran 764 vs 835 TFLOP/s on the B=2 tower launch -- not kept.
+  auto tap = [&](const unsigned char* Wh, const unsigned char* P, int shift) {
+    bf16x8 wf[2][TCO], xf[2][TPOS];
+    int pr[TPOS], psw[TPOS];
+#pragma unroll
+    for (int t = 0; t < TPOS; ++t) {
+      pr[t] = prow0 + t * 32 + shift;
+      psw[t] = (pr[t] >> 2) & 3;
+    }
+    auto rd = [&](int kk, int set) {
+#pragma unroll
+      for (int t = 0; t < TCO; ++t)
+        wf[set][t] = *reinterpret_cast<const bf16x8*>(Wh + wrow_off + t * 32 * 64 + (((kk * 2 + khalf) ^ rsw) * 16));
+#pragma unroll
+      for (int t = 0; t < TPOS; ++t)
+        xf[set][t] = *reinterpret_cast<const bf16x8*>(P + pr[t] * 64 + (((kk * 2 + khalf) ^ psw[t]) * 16));
+    };
+    rd(0, 0);
+    rd(1, 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TPOS; ++tp)
+          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][tc], xf[kk][tp], acc[tc][tp], 0, 0, 0);
+  };
+
+  // ---- main loop over channel-chunk PAIRS: 18 taps = 9 weight stages per iteration.
+  // patch(c) lives in Pb[c & 1]; patch(c0+1) is DMAed during stages 0-2 (before tap 9 needs it in stage 4), patch(c0+2)
+  // during stages 5-7 (after tap 8, the last reader of Pb[0], finished in stage 4); weight stage s+1 during stage s.
+  const int npair = a.nc >> 1;
+  const int nstage = npair * 9;
+  sfor<PT_MAXPP>([&](auto I) { dma_patch_piece(I, 0, 0); });
+  dma_w(0, 0);
+  __syncthreads();
+  for (int cp = 0; cp < npair; ++cp) {
+    const int c0 = 2 * cp;
+    sfor<9>([&](auto SP) {
+      constexpr int sp = decltype(SP)::value;
+      const int st = cp * 9 + sp;                                  // global stage index (parity = W buffer)
+      if (st + 1 < nstage) dma_w(st + 1, (st + 1) & 1);
+      if constexpr (sp < 3) {                                      // patch of the pair's second chunk
+        dma_patch_piece(std::integral_constant<int, 2 * sp>{}, c0 + 1, 1);
+        dma_patch_piece(std::integral_constant<int, 2 * sp + 1>{}, c0 + 1, 1);
+      } else if constexpr (sp >= 5 && sp < 8) {                    // patch of the NEXT pair's first chunk
+        if (cp + 1 < npair) {
+          dma_patch_piece(std::integral_constant<int, 2 * (sp - 5)>{}, c0 + 2, 0);
+          dma_patch_piece(std::integral_constant<int, 2 * (sp - 5) + 1>{}, c0 + 2, 0);
+        }
+      }
+      const unsigned char* Wst = Wb0 + (st & 1) * PT_WSTAGE;
+      sfor<2>([&](auto HH) {
+        constexpr int hh = decltype(HH)::value;
+        constexpr int s = 2 * sp + hh;                             // tap index inside the pair, 0..17
+        constexpr int cc = s / 9, t = s % 9, kh = t / 3, kw = t % 3;
+        tap(Wst + hh * (PT_BCO * 64), Pb0 + cc * PB, kh * Wp + kw);
+      });
+      __syncthreads();                                             // drains the DMA queue (vmcnt(0)) and fences the buffers
+    });
+  }
+
+  // ---- epilogue (register epilogue of conv_igemm.hip): lanes i / i+32 swap 4-cout groups -> 8 consecutive couts
+  const float lscale = a.level_scale[lev];
+  const float* const biasp = a.bias != nullptr ? a.bias + grp * a.b_gstride : nullptr;
+  float* const gnp = a.gn_stats != nullptr ? a.gn_stats + grp * a.gn_gstride : nullptr;
+  const bool out_f32 = a.flags & SM_CONV_OUT_F32;
+  const long long out_img_row0 = a.out_row0[lev] + grp * a.y_grows + (long long)n * H * W;
+  float* gn_bins = reinterpret_cast<float*>(smem);                  // [256/8][2]; the K loop's last barrier freed the LDS
+  const bool gn = gnp != nullptr;
+  if (gn) {
+    if (tid < 64) gn_bins[tid] = 0.f;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tp = 0; tp < TPOS; ++tp) {
+    const int q = q0 + wpos * 64 + tp * 32 + l31;
+    const int oh = q / Wp;
+    const int owp = q - oh * Wp;
+    const bool pvalid = oh < H && owp >= 1 && owp <= W;
+    const long long orow = out_img_row0 + (long long)oh * W + owp - 1;
+#pragma unroll
+    for (int tc = 0; tc < TCO; ++tc) {
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t lo = __float_as_uint(acc[tc][tp][4 * (2 * qp) + e]);
+          const uint32_t hi = __float_as_uint(acc[tc][tp][4 * (2 * qp + 1) + e]);
+          const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+          v[e] = __uint_as_float(r[0]);
+          v[4 + e] = __uint_as_float(r[1]);
+        }
+        const int cl = wco * 128 + tc * 32 + 8 * (2 * qp + khalf);
+        const int c0 = nt * PT_BCO + cl;
+        const bool live = pvalid && c0 < a.cout;
+        if (live) {
+          if (biasp != nullptr) {
+            const float4 b0 = *reinterpret_cast<const float4*>(biasp + c0);
+            const float4 b1 = *reinterpret_cast<const float4*>(biasp + c0 + 4);
+            v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w;
+            v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
+          }
+          if (c0 < a.scale_nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (c0 + e < a.scale_nch) v[e] *= lscale;
+          }
+        }
+        if (gn) {                                   // wave-uniform: the shuffles need every lane
+          float gs = 0.f, gss = 0.f;
+          if (live) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              gs += v[e];
+              gss += v[e] * v[e];
+            }
+          }
+#pragma unroll
+          for (int d = 16; d > 0; d >>= 1) {        // within the half-wave (xor < 32 never crosses halves)
+            gs += __shfl_xor(gs, d, 64);
+            gss += __shfl_xor(gss, d, 64);
+          }
+          if (l31 == 0 && c0 < a.cout) {
+            atomicAdd(&gn_bins[(cl >> 3) * 2 + 0], gs);
+            atomicAdd(&gn_bins[(cl >> 3) * 2 + 1], gss);
+          }
+        }
+        if (!live) continue;
+        if (a.flags & SM_CONV_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (a.flags & SM_CONV_RELU_NCH) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (c0 + e < a.scale_nch) v[e] = fmaxf(v[e], 0.f);
+        }
+        const long long o = orow * a.out_cstride + a.out_coff + c0;
+        if (out_f32) {
+          float* yp = reinterpret_cast<float*>(a.y) + o;
+          *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(a.y) + o) = pack_bf16x8_v(v);
+        }
+      }
+    }
+  }
+  if (gn) {                                          // the whole tile lies in image n of level lev
+    __syncthreads();
+    if (tid < 64) {
+      const float v = gn_bins[tid];
+      const int g = (nt * PT_BCO >> 3) + (tid >> 1);
+      if (v != 0.f && g < (a.cout >> 3))
+        atomicAdd(gnp + (((long long)n * a.nlev + lev) * (a.cout >> 3) + g) * 2 + (tid & 1), v);
+    }
+  }
+}
+
+int patch_check(const sm_conv_desc* d) {
+  if (!d) return SM_ERR_BAD_ARG;
+  if (d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return SM_ERR_BAD_SHAPE;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dil != 1) return SM_ERR_UNSUPPORTED;
+  if (d->cin % 64 != 0 || d->cin < 64 || d->in_cstride % 8 != 0) return SM_ERR_UNSUPPORTED;
+  if (d->cout < 1 || d->cout_pad % PT_BCO != 0 || d->cout_pad < d->cout) return SM_ERR_UNSUPPORTED;
+  if ((d->cout & 7) || (d->out_cstride & 7) || (d->out_coff & 7)) return SM_ERR_UNSUPPORTED;
+  if (d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST | SM_CONV_IN_RELU)) return SM_ERR_UNSUPPORTED;
+  if (d->w_batch_stride != 0) return SM_ERR_UNSUPPORTED;
+  for (int l = 0; l < d->nlev; ++l) {
+    if (d->in_h[l] != d->out_h[l] || d->in_w[l] != d->out_w[l] || d->in_h[l] < 1 || d->in_w[l] < 1) return SM_ERR_BAD_SHAPE;
+    if (PT_BPOS + 2 * (d->in_w[l] + 2) + 2 > 16 * 8 * PT_MAXPP) return SM_ERR_UNSUPPORTED;   // patch rows the loader covers
+    if ((long long)d->in_h[l] * d->in_w[l] * d->in_cstride >= (1ll << 31)) return SM_ERR_UNSUPPORTED;   // 32-bit patch offsets
+  }
+  return SM_OK;
+}
+
+}  // namespace
+
+extern "C" int sm_conv3x3_patch_supported(const sm_conv_desc* d) { return patch_check(d) == SM_OK ? 1 : 0; }
+
+extern "C" int64_t sm_conv3x3_patch_tiles(const sm_conv_desc* d) {
+  if (patch_check(d) != SM_OK) return 0;
+  long long t = 0;
+  for (int l = 0; l < d->nlev; ++l)
+    t += (long long)d->batch * sm_cdiv((long long)d->in_h[l] * (d->in_w[l] + 2), PT_BPOS);
+  return t * (d->cout_pad / PT_BCO) * (d->ngroups > 1 ? d->ngroups : 1);
+}
+
+extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void* w_patch, const float* bias, void* y,
+                                float* gn_stats, sm_stream_t stream) {
+  if (!x || !w_patch || !y) return SM_ERR_BAD_ARG;
+  const int rc = patch_check(d);
+  if (rc != SM_OK) return rc;
+  if (gn_stats != nullptr && (d->flags & SM_CONV_OUT_F32)) return SM_ERR_UNSUPPORTED;
+  PatchArgs a;
+  a.x = (const uint16_t*)x;
+  a.w = (const uint16_t*)w_patch;
+  a.bias = bias;
+  a.y = y;
+  a.gn_stats = gn_stats;
+  a.nlev = d->nlev;
+  a.batch = d->batch;
+  int t = 0, maxw = 1;
+  for (int l = 0; l < SM_MAX_LEVELS; ++l) {
+    const bool on = l < d->nlev;
+    a.h[l] = on ? d->in_h[l] : 1;
+    a.w_[l] = on ? d->in_w[l] : 1;
+    a.in_row0[l] = on ? d->in_row0[l] : 0;
+    a.out_row0[l] = on ? d->out_row0[l] : 0;
+    a.level_scale[l] = on ? d->level_scale[l] : 1.f;
+    a.tile0[l] = t;
+    a.tpi[l] = on ? sm_cdiv((long long)d->in_h[l] * (d->in_w[l] + 2), PT_BPOS) : 1;
+    if (on) {
+      t += d->batch * a.tpi[l];
+      if (d->in_w[l] > maxw) maxw = d->in_w[l];
+    }
+  }
+  a.tile0[SM_MAX_LEVELS] = t;
+  a.cin = d->cin;
+  a.cout = d->cout;
+  a.nc = d->cin / 32;
+  a.ntn = d->cout_pad / PT_BCO;
+  a.in_cstride = d->in_cstride;
+  a.out_cstride = d->out_cstride;
+  a.out_coff = d->out_coff;
+  a.Kp = 9ll * d->cin;
+  a.flags = d->flags;
+  a.scale_nch = d->scale_nch;
+  a.prow_cap = (PT_BPOS + 2 * (maxw + 2) + 2 + 15) / 16 * 16;
+  a.ngroups = d->ngroups > 1 ? d->ngroups : 1;
+  a.tpg = t * a.ntn;
+  a.x_grows = d->x_group_rows;
+  a.y_grows = d->y_group_rows;
+  a.w_gstride = d->w_group_stride;
+  a.b_gstride = d->bias_group_stride;
+  a.gn_gstride = d->gn_group_stride;
+  hipStream_t s = sm_hip_stream(stream);
+  if (gn_stats != nullptr) {
+    if (hipMemsetAsync(gn_stats, 0, sizeof(float) * 2 * a.ngroups * d->batch * d->nlev * (d->cout / 8), s) != hipSuccess)
+      return SM_ERR_LAUNCH;
+  }
+  const size_t lds = 2 * (size_t)PT_WSTAGE + 2 * (size_t)a.prow_cap * 64;
+  if (lds > 160 * 1024) return SM_ERR_UNSUPPORTED;
+  if (hipFuncSetAttribute((const void*)conv3x3_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return SM_ERR_LAUNCH;
+  const long long nblk = (long long)t * a.ntn * a.ngroups;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(conv3x3_patch_kernel, dim3((unsigned)nblk), dim3(PT_THREADS), lds, s, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

@@ -25,6 +25,7 @@ _GROUPED_TOWERS = __import__("os").environ.get("SIPMASK_GROUPED_TOWERS", "1") ==
 
 
 _SPLIT_K = __import__("os").environ.get("SIPMASK_SPLIT_K", "1") != "0"     # A/B: split-K for under-filled launches
+_PATCH_CONV = __import__("os").environ.get("SIPMASK_PATCH_CONV", "1") != "0"   # A/B: patch-resident 3x3 kernel
 
 
 def _lib_flag(name):
@@ -70,10 +71,27 @@ class _Conv:
                                      scale_nch, level_scale, deform_groups)
         self.x, self.y, self.residual, self.offset = x, y, residual, offset
         self.gn_stats = None      # set -> GroupNorm statistics of y are accumulated in the conv epilogue
+        # large 3x3 / stride-1 convs run on the patch-resident kernel (csrc/conv3x3_patch.hip): own weight layout, cout
+        # padded to 256.  `groups` launches of this shape share one grid (tower pairs): the tile rule sees all of them.
+        self.patch = False
+        if (not self.f32 and offset is None and residual is None and _PATCH_CONV and k == 3 and stride == 1 and pad == 1
+                and ci % 64 == 0 and cin == ci):
+            dp = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, (co + 255) // 256 * 256, k, stride,
+                                  pad, in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
+                                  scale_nch, level_scale, deform_groups)
+            if H.conv3x3_patch_supported(dp):
+                tiles = H.conv3x3_patch_tiles(dp) * getattr(self, "_patch_groups", 1)
+                rounds = (tiles + 255) // 256
+                # one 256x256 tile per CU: take the kernel when the launch is a reasonable share of a round of 256 CUs
+                # and multi-round launches fill their rounds (measured: profiles/r02*_patch_conv_microbench.txt)
+                if tiles >= 100 and (rounds == 1 or tiles >= 0.65 * rounds * 256):
+                    self.patch = True
+                    self.w, _ = H.prep_conv_weight_patch(w.to(dev))
+                    self.desc = dp
         # split-K workspace (own buffer per conv: launches on different lanes may run concurrently); sized by the
         # library's plan, allocated once at build -- 288 GB of HBM
         self.ws = None
-        if not self.f32 and offset is None and _SPLIT_K:
+        if not self.f32 and offset is None and _SPLIT_K and not self.patch:
             pl = H.conv_plan(self.desc)
             if pl["split_k"] > 1:
                 self.ws = torch.empty(pl["workspace_bytes"], dtype=torch.uint8, device=dev)
@@ -88,6 +106,8 @@ class _Conv:
     def __call__(self):
         if self.f32:
             H.conv2d_f32(self.desc, self.x, self.offset, self.w, self.bias, self.residual, self.y)
+        elif self.patch:
+            H.conv3x3_patch(self.desc, self.x, self.w, self.bias, self.y, self.gn_stats)
         elif self.gn_stats is not None:
             H.conv2d_gn_stats(self.desc, self.x, self.offset, self.w, self.bias, self.residual, self.y, self.gn_stats)
         elif self.offset is not None:
@@ -106,10 +126,13 @@ class _GroupedConv(_Conv):
     def __init__(self, eng, name, ws, biases, batch, in_sizes, in_row0, x, x_group_rows, in_cstride, y, y_group_rows,
                  out_row0, out_cstride, flags=0):
         G = len(ws)
+        self._patch_groups = G
         _Conv.__init__(self, eng, name, ws[0], biases[0], batch, in_sizes, in_row0, x, in_cstride, 1, 1, y, out_row0,
                        out_cstride, flags=flags)
         dev = eng.device
-        packed = [self.w] + [H.prep_conv_weight(w.to(dev), in_cstride)[0] for w in ws[1:]]
+        prep = (lambda w: H.prep_conv_weight_patch(w.to(dev))[0]) if self.patch else \
+            (lambda w: H.prep_conv_weight(w.to(dev), in_cstride)[0])
+        packed = [self.w] + [prep(w) for w in ws[1:]]
         assert all(p.shape == packed[0].shape for p in packed)
         self.w = torch.stack(packed).contiguous()
         if biases[0] is not None:

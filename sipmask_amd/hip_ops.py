@@ -33,6 +33,33 @@ def prep_conv_weight(w, cin_pad=None):
     return out.to(BF16).contiguous(), co_pad
 
 
+def prep_conv_weight_patch(w):
+    """[co,ci,3,3] float -> bf16 [cout_pad][ci/32][9][32] for sm_conv3x3_patch (K order: 32-channel chunk, tap, channel);
+    cout_pad a multiple of 256, ci a multiple of 64."""
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (3, 3) and ci % 64 == 0
+    co_pad = (co + 255) // 256 * 256
+    out = torch.zeros(co_pad, ci // 32, 9, 32, dtype=torch.float32, device=w.device)
+    out[:co] = w.float().permute(0, 2, 3, 1).reshape(co, 9, ci // 32, 32).permute(0, 2, 1, 3)
+    return out.reshape(co_pad, 9 * ci).to(BF16).contiguous(), co_pad
+
+
+def conv3x3_patch_supported(desc):
+    return bool(_lib.load().sm_conv3x3_patch_supported(C.byref(desc)))
+
+
+def conv3x3_patch_tiles(desc):
+    return int(_lib.load().sm_conv3x3_patch_tiles(C.byref(desc)))
+
+
+def conv3x3_patch(desc, x, w_patch, bias, y, gn_stats=None):
+    _lib.require_cuda(x, w_patch, y)
+    lib = _lib.load()
+    _lib.check(lib.sm_conv3x3_patch(C.byref(desc), _lib.ptr(x), _lib.ptr(w_patch), _lib.ptr(bias), _lib.ptr(y),
+                                    _lib.ptr(gn_stats), _lib.stream_ptr()), "sm_conv3x3_patch")
+    return y
+
+
 class Levels:
     """Row bookkeeping of a pyramid tensor: levels [(h,w)], batch -> row0 per level."""
 

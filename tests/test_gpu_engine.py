@@ -179,10 +179,12 @@ def test_sub_batch_plan_matches_single_plan():
             assert _rel(b, a) < 2e-3, (i, l, _rel(b, a))
     n1, n2 = r1["ndet"].cpu(), r2["ndet"].cpu()
     assert int(n1.sum()) > 0 and bool(((n1 - n2).abs() <= 2).all())
-    for b in range(4):
-        n = int(min(n1[b], n2[b]))
-        same = (r1["det_labels"][b, :n] == r2["det_labels"][b, :n]).float().mean() if n else torch.tensor(1.0)
-        assert float(same) > 0.9
+    from collections import Counter
+    for b in range(4):                                   # same detections up to near-tie swaps: compare label multisets
+        c1 = Counter(r1["det_labels"][b, :int(n1[b])].cpu().tolist())
+        c2 = Counter(r2["det_labels"][b, :int(n2[b])].cpu().tolist())
+        common = sum((c1 & c2).values())
+        assert common >= 0.9 * max(int(n1[b]), 1), (b, common, int(n1[b]))
     # a second run with other images reuses the plans and the shared output tensors
     r3 = two.run(torch.flip(img, dims=[0]))
     torch.cuda.synchronize()

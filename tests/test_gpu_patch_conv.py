@@ -1,0 +1,96 @@
+"""GPU parity of the patch-resident 3x3 conv kernel (csrc/conv3x3_patch.hip, sm_conv3x3_patch) against torch fp32
+F.conv2d on bf16-representable inputs: f32 outputs within accumulation order (rtol 1e-4 / atol 2e-4), bf16 outputs
+plus one rounding; multi-level launches (tiles never straddle an image), ragged widths (pad columns are dummy outputs),
+per-level Scale, ReLU, fused GroupNorm statistics, the group dimension (cls + reg towers in one launch)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _rows(ts):
+    return torch.cat([t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in ts])
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, Cin, Cout, sizes
+    (2, 256, 256, [(25, 42), (13, 21), (7, 11), (4, 6), (2, 3)]),     # tower-like pyramid
+    (1, 64, 208, [(19, 37)]),                                          # cout tail inside a 256 tile, odd width
+    (2, 128, 512, [(9, 250)]),                                         # two cout tiles, widest supported rows
+    (1, 256, 256, [(100, 168)]),                                       # FPN level-0 geometry (67 tiles)
+])
+def test_patch_conv_vs_torch(cfg):
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    B, Ci, Co, sizes = cfg
+    g = torch.Generator().manual_seed(Ci + Co + len(sizes))
+    lv = H.Levels(B, sizes)
+    xs = [_bf(torch.randn(B, Ci, h, w, generator=g)) for h, w in sizes]
+    w = _bf(torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5)
+    bias = torch.randn(Co, generator=g)
+    x = _rows(xs).to(torch.bfloat16).to(dev)
+    wq, co_pad = H.prep_conv_weight_patch(w.to(dev))
+    scales = [1.0 + 0.25 * l for l in range(len(sizes))]
+    for out_f32, relu in ((True, False), (False, True)):
+        flags = (_lib.SM_CONV_OUT_F32 if out_f32 else 0) | (_lib.SM_CONV_RELU if relu else 0)
+        d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, Ci, Co, co_pad, 3, 1, 1, Ci, Co, flags=flags,
+                             scale_nch=4, level_scale=scales)
+        assert H.conv3x3_patch_supported(d)
+        y = torch.full((lv.rows, Co), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
+        H.conv3x3_patch(d, x, wq, bias.to(dev), y)
+        torch.cuda.synchronize()
+        for l, (h, wd) in enumerate(sizes):
+            ref = F.conv2d(xs[l], w, bias, 1, 1)
+            ref[:, :4] *= scales[l]
+            if relu:
+                ref = F.relu(ref)
+            got = y[lv.row0[l]:lv.row0[l] + B * h * wd].float().view(B, h, wd, Co).permute(0, 3, 1, 2).cpu()
+            if out_f32:
+                torch.testing.assert_close(got, ref, rtol=1e-4, atol=2e-4)
+            else:
+                torch.testing.assert_close(got, ref, rtol=2 ** -7, atol=2e-3)
+
+
+@pytest.mark.parametrize("shared_x", [True, False])
+def test_patch_conv_grouped_with_groupnorm_statistics(shared_x):
+    """two problem instances (the cls and reg tower convs of one depth) in ONE launch + fused GN statistics"""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(3 + shared_x)
+    B, C, G = 2, 256, 2
+    sizes = [(20, 33), (10, 17), (5, 9)]
+    lv = H.Levels(B, sizes)
+    xs = [[_bf(torch.randn(B, C, h, w, generator=g)) for h, w in sizes] for _ in range(1 if shared_x else G)]
+    ws = [_bf(torch.randn(C, C, 3, 3, generator=g) / 48) for _ in range(G)]
+    x = torch.cat([_rows(t) for t in xs]).to(torch.bfloat16).to(dev)
+    packed = [H.prep_conv_weight_patch(w.to(dev))[0] for w in ws]
+    wq = torch.stack(packed).contiguous()
+    y = torch.zeros(G * lv.rows, C, dtype=torch.bfloat16, device=dev)
+    S = 2 * B * len(sizes) * (C // 8)
+    stats = torch.full((G * S,), 7.0, device=dev)
+    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, C, C, 256, 3, 1, 1, C, C, ngroups=G,
+                         x_group_rows=0 if shared_x else lv.rows, y_group_rows=lv.rows, w_group_stride=packed[0].numel(),
+                         bias_group_stride=0, gn_group_stride=S)
+    H.conv3x3_patch(d, x, wq, None, y, stats)
+    torch.cuda.synchronize()
+    for gi in range(G):
+        src = xs[0] if shared_x else xs[gi]
+        st = stats[gi * S:(gi + 1) * S].view(B, len(sizes), C // 8, 2).cpu()
+        for l, (h, wd) in enumerate(sizes):
+            ref = F.conv2d(src[l], ws[gi], None, 1, 1)
+            got = y[gi * lv.rows + lv.row0[l]: gi * lv.rows + lv.row0[l] + B * h * wd].float().view(B, h, wd, C).permute(0, 3, 1, 2).cpu()
+            torch.testing.assert_close(got, ref, rtol=2 ** -7, atol=2e-3)
+            r8 = ref.view(B, C // 8, 8, h * wd)
+            torch.testing.assert_close(st[:, l, :, 0], r8.sum((2, 3)), rtol=2e-3, atol=0.5)
+            torch.testing.assert_close(st[:, l, :, 1], (r8 * r8).sum((2, 3)), rtol=2e-3, atol=0.5)
