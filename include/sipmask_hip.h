@@ -388,6 +388,17 @@ int sm_sigmoid_focal_loss_bwd(const float* logits, const int64_t* targets, const
                               float* d_logits, int n, int c, float gamma, float alpha,
                               sm_stream_t stream);
 
+/* FCOS target assignment for a batch, SipMaskHead.fcos_target / fcos_target_single (sipmask_head.py:731-857), device
+ * resident: points f32 [S][2] (all levels concatenated), point_stride / range_lo / range_hi f32 [S] (stride and
+ * regress range of each point's level), gt_boxes f32 [B][gmax][4], gt_labels i64 [B][gmax], ngt i32 [B].
+ * center_sampling / radius as in the head's config.  Outputs: labels i64 [B][S] (0 = background), bbox_targets f32
+ * [B][S][4] = (l,t,r,b) against the chosen box, gt_index i32 [B][S] = index of that box (-1 when the image has none).
+ * Bit-identical to the reference's broadcast tensor code (same f32 operations, first index on area ties). */
+int sm_fcos_target(const float* points, const float* point_stride, const float* range_lo, const float* range_hi,
+                   const float* gt_boxes, const int64_t* gt_labels, const int32_t* ngt, int batch, int npoints, int gmax,
+                   int center_sampling, float radius, int64_t* labels, float* bbox_targets, int32_t* gt_index,
+                   sm_stream_t stream);
+
 /* Fused SipMask mask loss (sipmask_head.py:443-461): for detection n, the sum over the pixels of its crop box
  * of F.binary_cross_entropy(CropSplit(sigmoid(basis . cof_q))[.., n], CropSplitGt(gt[idx_gt[n]])[.., n]) --
  * without materialising the 4 x [Hm,Wm,N] probability volumes.  basis f32 [32][Hm][Wm] (basis_hwc=0) or
@@ -431,6 +442,13 @@ int sm_upsample_bilinear_nchw_bwd(const float* dy, float* dx, int64_t planes, in
  * g += wd*p; buf = first_step ? g : momentum*buf + g; p -= lr*buf. */
 int sm_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
                 float weight_decay, int first_step, sm_stream_t stream);
+
+/* sm_sgd_step for ALL parameter tensors in one launch.  items (device): array of
+ *   struct { float* param; const float* grad; float* momentum_buf; int64_t n; float lr; float weight_decay; }   (40 bytes)
+ * blocks (device) int32 [nblocks][2] = (item index, chunk index): thread block b updates elements
+ * [chunk * 4096, min((chunk + 1) * 4096, n)) of its item. */
+int sm_sgd_multi(const void* items, const int32_t* blocks, int nblocks, float momentum, int first_step,
+                 sm_stream_t stream);
 
 /* ---- SipMask-VIS tracking (V/ = SipMask-VIS/, V/mmdet/models/anchor_heads/sipmask_head.py) -------------- */
 

@@ -110,6 +110,7 @@ PROTOTYPES = {
     "sm_upsample_bilinear_nchw_fwd": (_I, [_P, _P, C.c_int64, _I, _I, _I, _P]),
     "sm_upsample_bilinear_nchw_bwd": (_I, [_P, _P, C.c_int64, _I, _I, _I, _P]),
     "sm_sgd_step": (_I, [_P, _P, _P, C.c_int64, _F, _F, _F, _I, _P]),
+    "sm_sgd_multi": (_I, [_P, _P, _I, _F, _I, _P]),
     "sm_pairs_select_workspace": (C.c_int64, [_P]),
     "sm_pairs_select": (_I, [_P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_preprocess_u8": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
@@ -123,6 +124,7 @@ PROTOTYPES = {
     "sm_mask_assemble_lo_workspace": (C.c_int64, [_I, _I]),
     "sm_mask_assemble_lo": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, C.c_double, C.c_double,
                                  _F, _P, _P, _P, _P]),
+    "sm_fcos_target": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
     "sm_crop_split_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sm_crop_split_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sm_crop_split_gt_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -208,6 +208,30 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
   }
 }
 
+// the same update for EVERY parameter tensor in one launch: items[] = per-tensor pointers and hyper-parameters,
+// blocks[] = (item, chunk) per thread block (chunks of SGD_CHUNK elements)
+constexpr int SGD_CHUNK = 4096;
+struct SgdItem {
+  float* p;
+  const float* g;
+  float* buf;
+  long long n;
+  float lr, wd;
+};
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdItem* __restrict__ items, const int2* __restrict__ blocks,
+                                                        float momentum, int first) {
+  const int2 bk = blocks[blockIdx.x];
+  const SgdItem it = items[bk.x];
+  const long long i0 = (long long)bk.y * SGD_CHUNK;
+  const long long i1 = i0 + SGD_CHUNK < it.n ? i0 + SGD_CHUNK : it.n;
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float gi = it.g[i] + it.wd * it.p[i];
+    const float b = first ? gi : momentum * it.buf[i] + gi;
+    it.buf[i] = b;
+    it.p[i] -= it.lr * b;
+  }
+}
+
 inline int grid_1d(long long n) { return (int)std::min<long long>((n + 255) / 256, 256 * 32); }
 
 }  // namespace
@@ -289,6 +313,16 @@ extern "C" int sm_sgd_step(float* param, const float* grad, float* momentum_buf,
   if (n < 1) return SM_OK;
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_1d(n)), dim3(256), 0, sm_hip_stream(stream), param, grad, momentum_buf,
                      (long long)n, lr, momentum, weight_decay, first_step);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_sgd_multi(const void* items, const int32_t* blocks, int nblocks, float momentum, int first_step,
+                            sm_stream_t stream) {
+  if (!items || !blocks) return SM_ERR_BAD_ARG;
+  if (nblocks < 1) return SM_OK;
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3(nblocks), dim3(256), 0, sm_hip_stream(stream), (const SgdItem*)items,
+                     (const int2*)blocks, momentum, first_step);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

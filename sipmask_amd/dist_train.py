@@ -1,6 +1,7 @@
 """Data-parallel training plumbing for the SipMask head: bucketed gradient all-reduce over
 torch.distributed (backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests) overlapped with backward, and
-the reference's SGD (M/mmdet/apis/train.py:92-139, cfg optimizer :108-113) on the HIP update kernel.
+the reference's SGD (M/mmdet/apis/train.py:92-139, cfg optimizer :108-113) on the HIP update kernel (one fused
+multi-tensor launch per step).
 
 The reference wraps the model in MMDistributedDataParallel and lets torch DDP reduce 25 MB buckets.  Here the buckets
 are sized for xGMI: it is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is per-link bound and
@@ -92,9 +93,16 @@ class GradBucketer:
             h.remove()
 
 
+class _SgdItem(__import__("ctypes").Structure):
+    """sm_sgd_multi's item (include/sipmask_hip.h)"""
+    _fields_ = [("p", __import__("ctypes").c_void_p), ("g", __import__("ctypes").c_void_p),
+                ("buf", __import__("ctypes").c_void_p), ("n", __import__("ctypes").c_int64),
+                ("lr", __import__("ctypes").c_float), ("wd", __import__("ctypes").c_float)]
+
+
 class HipSGD:
     """torch.optim.SGD(momentum, weight_decay) with mmdet's paramwise options (bias_lr_mult, bias_decay_mult:
-    M/mmdet/apis/train.py:92-133), the update on sm_sgd_step (one launch per parameter tensor)."""
+    M/mmdet/apis/train.py:92-133), the update as ONE sm_sgd_multi launch over all parameter tensors."""
 
     def __init__(self, named_params, lr=0.01, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0):
         self.items = []
@@ -105,6 +113,7 @@ class HipSGD:
             self.items.append(dict(p=p, lr=lr * (bias_lr_mult if is_bias else 1.0),
                                    wd=weight_decay * (bias_decay_mult if is_bias else 1.0), buf=None))
         self.momentum = momentum
+        self._steps, self._blocks, self._keep = 0, None, None
 
     def zero_grad(self):
         for it in self.items:
@@ -112,18 +121,40 @@ class HipSGD:
 
     @torch.no_grad()
     def step(self):
-        from . import hip_ops as H
-        for it in self.items:
-            p = it["p"]
-            if p.grad is None:
-                continue
-            first = it["buf"] is None
-            if first:
-                it["buf"] = torch.zeros_like(p, dtype=torch.float32)
-            H.sgd_step(p.data, p.grad.detach().float().contiguous(), it["buf"], it["lr"], self.momentum, it["wd"], first)
-            # the kernel wrote through the raw pointer: tell autograd / the launch-plan caches (plan_cache.py) that
-            # this parameter changed
-            torch.autograd.graph.increment_version(p)
+        """ONE launch for every parameter tensor (sm_sgd_multi): the per-tensor pointers go to the device as a small
+        table (40 bytes per tensor, rebuilt per step because autograd hands out fresh .grad tensors), the
+        (tensor, 4096-element chunk) list per thread block is built once."""
+        import ctypes as C
+        from . import _lib
+        live = [it for it in self.items if it["p"].grad is not None]
+        if not live:
+            return
+        dev = live[0]["p"].device
+        first = self._steps == 0
+        for it in live:
+            if it["buf"] is None:
+                it["buf"] = torch.zeros_like(it["p"], dtype=torch.float32)
+        key = tuple(id(it) for it in live)
+        if self._blocks is None or self._blocks[0] != key:
+            bl = []
+            for i, it in enumerate(live):
+                bl.extend((i, c) for c in range((it["p"].numel() + 4095) // 4096))
+            self._blocks = (key, torch.tensor(bl, dtype=torch.int32, device=dev).contiguous(), len(bl))
+        grads = [it["p"].grad.detach().float().contiguous() for it in live]     # keep alive until the launch is queued
+        tab = (_SgdItem * len(live))()
+        for t, it, g in zip(tab, live, grads):
+            t.p, t.g, t.buf, t.n = it["p"].data_ptr(), g.data_ptr(), it["buf"].data_ptr(), it["p"].numel()
+            t.lr, t.wd = it["lr"], it["wd"]
+        items = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
+        lib = _lib.load()
+        _lib.check(lib.sm_sgd_multi(_lib.ptr(items), _lib.ptr(self._blocks[1]), self._blocks[2], float(self.momentum),
+                                    int(first), _lib.stream_ptr()), "sm_sgd_multi")
+        self._steps += 1
+        self._keep = (items, grads)          # until the next step: the launch above is asynchronous
+        for it in live:
+            # the kernel wrote through raw pointers: tell autograd / the launch-plan caches (plan_cache.py) that this
+            # parameter changed
+            torch.autograd.graph.increment_version(it["p"])
 
 
 def head_train_step(head, feats, gt_bboxes, gt_labels, gt_masks, img_metas, optimizer, bucketer=None, train_cfg=None):

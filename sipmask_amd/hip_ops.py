@@ -513,6 +513,22 @@ def rle_fetch(out, batch, max_num, ndet, canvas_hw):
 
 
 # ------------------------------------------------------------------------------- fused mask loss (training)
+def fcos_target(points, pstride, lo, hi, gt_boxes, gt_labels, ngt, center_sampling, radius):
+    """sm_fcos_target: gt_boxes [B,gmax,4] f32, gt_labels [B,gmax] i64, ngt [B] i32 -> labels [B,S] i64, targets [B,S,4],
+    gt_index [B,S] i32"""
+    lib = _lib.load()
+    _lib.require_cuda(points, gt_boxes)
+    b, gmax = gt_boxes.shape[0], gt_boxes.shape[1]
+    s = points.shape[0]
+    labels = torch.empty(b, s, dtype=torch.int64, device=points.device)
+    targets = torch.empty(b, s, 4, dtype=torch.float32, device=points.device)
+    gidx = torch.empty(b, s, dtype=torch.int32, device=points.device)
+    _lib.check(lib.sm_fcos_target(_lib.ptr(points), _lib.ptr(pstride), _lib.ptr(lo), _lib.ptr(hi), _lib.ptr(gt_boxes),
+                                  _lib.ptr(gt_labels), _lib.ptr(ngt), b, s, gmax, int(bool(center_sampling)), float(radius),
+                                  _lib.ptr(labels), _lib.ptr(targets), _lib.ptr(gidx), _lib.stream_ptr()), "sm_fcos_target")
+    return labels, targets, gidx
+
+
 def mask_loss_fwd(basis, cof, rois, gt, idx_gt, out):
     lib = _lib.load()
     _lib.check(lib.sm_mask_loss_fwd(_lib.ptr(basis), 0, _lib.ptr(cof), _lib.ptr(rois), _lib.ptr(gt), _lib.ptr(idx_gt),

@@ -45,6 +45,25 @@ def assign_image(points, point_stride, lo, hi, gt_bboxes, gt_labels, center_samp
     return labels, ltrb[torch.arange(P, device=points.device), idx], idx[labels > 0]
 
 
+def _assign_batch_device(points, pstride, lo, hi, gt_bboxes_list, gt_labels_list, center_sampling, radius):
+    """the whole batch's assignment in ONE launch of sm_fcos_target (no [S,G,4] broadcast tensors, no per-image
+    loop of ATen ops); same return values as [assign_image(...) for every image]"""
+    from . import hip_ops as H
+    B = len(gt_bboxes_list)
+    gmax = max(1, max(int(b.shape[0]) for b in gt_bboxes_list))
+    dev = points.device
+    boxes = torch.zeros(B, gmax, 4, dtype=torch.float32, device=dev)
+    labs = torch.zeros(B, gmax, dtype=torch.int64, device=dev)
+    for i, (b, l) in enumerate(zip(gt_bboxes_list, gt_labels_list)):
+        if b.shape[0]:
+            boxes[i, :b.shape[0]] = b.float()
+            labs[i, :b.shape[0]] = l
+    ngt = torch.tensor([int(b.shape[0]) for b in gt_bboxes_list], dtype=torch.int32, device=dev)
+    labels, targets, gidx = H.fcos_target(points.contiguous(), pstride.contiguous(), lo.contiguous(), hi.contiguous(), boxes,
+                                          labs, ngt, center_sampling, radius)
+    return [(labels[i], targets[i], gidx[i][labels[i] > 0].long()) for i in range(B)]
+
+
 def fcos_target(points, strides, regress_ranges, gt_bboxes_list, gt_labels_list, center_sampling=True, radius=1.5):
     """fcos_target (:731-771).  Returns (labels per level [cat over images], bbox_targets per level,
     per-image labels split by level, per-image targets split by level, per-image gt_ind)."""
@@ -52,8 +71,11 @@ def fcos_target(points, strides, regress_ranges, gt_bboxes_list, gt_labels_list,
     cat = torch.cat(points)
     mk = lambda vals: torch.cat([p.new_full((p.shape[0],), float(v)) for p, v in zip(points, vals)])
     pstride, lo, hi = mk(strides), mk([r[0] for r in regress_ranges]), mk([r[1] for r in regress_ranges])
-    per = [assign_image(cat, pstride, lo, hi, b, l, center_sampling, radius)
-           for b, l in zip(gt_bboxes_list, gt_labels_list)]
+    if cat.is_cuda:
+        per = _assign_batch_device(cat, pstride, lo, hi, gt_bboxes_list, gt_labels_list, center_sampling, radius)
+    else:
+        per = [assign_image(cat, pstride, lo, hi, b, l, center_sampling, radius)
+               for b, l in zip(gt_bboxes_list, gt_labels_list)]
     lab_img = [p[0].split(nums, 0) for p in per]
     tgt_img = [p[1].split(nums, 0) for p in per]
     lab_lvl = [torch.cat([li[l] for li in lab_img]) for l in range(len(nums))]

@@ -577,3 +577,68 @@ def test_detector_forward_train_vs_oracle():
     sum(loss.values()).backward()
     compare(trunk + ("bbox_head.cls_convs.0.conv.weight", "bbox_head.reg_convs.3.gn.weight", "bbox_head.sip_cof.weight",
                      "bbox_head.feat_align.conv_offset.weight", "bbox_head.sip_mask_lat0.weight"), osd, 0.9, 0.5)
+
+
+def test_fcos_target_kernel_vs_tensor_formulation():
+    """sm_fcos_target (one launch for the batch) against targets.assign_image, the broadcast tensor code that
+    tests/test_targets.py holds to the reference's own fcos_target outputs: labels, (l,t,r,b) targets and the indices of
+    the positives must be IDENTICAL, with and without centre sampling, incl. an image without ground truth, boxes that
+    tie in area and points no box claims."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd import targets as T
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(12)
+    sizes = [(40, 56), (20, 28), (10, 14), (5, 7), (3, 4)]
+    strides = (8, 16, 32, 64, 128)
+    ranges = ((-1, 64), (64, 128), (128, 256), (256, 512), (512, 1e8))
+    pts = T.level_points(sizes, strides, device=dev)
+    gtb, gtl = [], []
+    for n in (7, 0, 23, 1):
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([300.0, 200.0])
+        wh = torch.rand(n, 2, generator=g) * torch.tensor([250.0, 180.0]) + 4
+        b = torch.cat([xy, xy + wh], 1)
+        if n >= 7:
+            b[3] = b[2]                                  # identical boxes: equal areas -> the FIRST index wins
+            b[5, 2:] = b[5, :2] + (b[4, 2:] - b[4, :2])  # another equal-area pair at a different place
+        gtb.append(b.to(dev))
+        gtl.append(torch.randint(1, 81, (n,), generator=g).to(dev))
+    for cs in (True, False):
+        lab_lvl, tgt_lvl, lab_img, tgt_img, gt_inds = T.fcos_target(pts, strides, ranges, gtb, gtl, cs, 1.5)
+        cat = torch.cat(pts)
+        mk = lambda vals: torch.cat([p.new_full((p.shape[0],), float(v)) for p, v in zip(pts, vals)])
+        for i in range(4):
+            rl, rt, ri = T.assign_image(cat, mk(strides), mk([r[0] for r in ranges]), mk([r[1] for r in ranges]), gtb[i],
+                                        gtl[i], cs, 1.5)
+            assert torch.equal(torch.cat(lab_img[i]), rl)
+            assert torch.equal(torch.cat(tgt_img[i]), rt)
+            assert torch.equal(gt_inds[i], ri)
+        assert int(sum((l > 0).sum() for l in lab_lvl)) > 0
+
+
+def test_hip_sgd_multi_tensor_matches_torch_sgd():
+    """HipSGD (one sm_sgd_multi launch for all tensors, mmdet's paramwise bias options) against torch.optim.SGD with the
+    same per-parameter groups over 3 steps."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.nn as nn
+    from sipmask_amd.dist_train import HipSGD
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(3, 17, 3), nn.ReLU(), nn.Conv2d(17, 33, 3), nn.ReLU(), nn.Conv2d(33, 5, 1)).cuda()
+    ref = nn.Sequential(nn.Conv2d(3, 17, 3), nn.ReLU(), nn.Conv2d(17, 33, 3), nn.ReLU(), nn.Conv2d(33, 5, 1)).cuda()
+    ref.load_state_dict(net.state_dict())
+    net[4].bias.requires_grad_(False)
+    ref[4].bias.requires_grad_(False)
+    opt = HipSGD(net.named_parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    groups = [dict(params=[p], lr=0.01 * (2.0 if n.endswith(".bias") else 1.0), weight_decay=0.0 if n.endswith(".bias") else 1e-4)
+              for n, p in ref.named_parameters() if p.requires_grad]
+    topt = torch.optim.SGD(groups, lr=0.01, momentum=0.9)
+    x = torch.randn(4, 3, 20, 20, device="cuda")
+    for step in range(3):
+        for m, o in ((net, opt), (ref, topt)):
+            o.zero_grad()
+            m(x).square().mean().backward()
+            o.step()
+        for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            torch.testing.assert_close(p, q, rtol=1e-5, atol=1e-7, msg=lambda m_: "%s step %d: %s" % (n, step, m_))
+    assert net[0].weight._version >= 3
