@@ -183,13 +183,51 @@ class SipMaskVIS(SipMask):
     """V/mmdet/models/detectors/single_stage.py:69-82: simple_test on one frame -> (bbox_results, segm_results) keyed
     by object id; the whole frame (backbone ... mask assembly, embedding gather) is one static launch plan."""
 
-    def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False):
-        from .engine import SipMaskEngine
+    def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False, lanes=1):
+        from .engine import SipMaskEngine, SubBatchPlan
         key = (batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
-               rescale)
-        return self._engines.get(key, module_tensors(self), lambda: SipMaskEngine(
-            self.state_dict(), batch, img_hw, self.backbone.depth, self.test_cfg, self.bbox_head.num_classes,
-            strides=self.bbox_head.strides, img_shape=img_shape, scale_factor=scale_factor, rescale=rescale, vis=True))
+               rescale, lanes)
+
+        def build():
+            sd = self.state_dict()
+            mk = lambda b: SipMaskEngine(sd, b, img_hw, self.backbone.depth, self.test_cfg, self.bbox_head.num_classes,
+                                         strides=self.bbox_head.strides, img_shape=img_shape, scale_factor=scale_factor,
+                                         rescale=rescale, vis=True)
+            return mk(batch) if lanes == 1 else SubBatchPlan([mk(batch // lanes) for _ in range(lanes)])
+        return self._engines.get(key, module_tensors(self), build)
+
+    def clip_test(self, imgs, img_metas, rescale=False, encode=True):
+        """A whole clip at once.  Everything up to the identity matching is independent per frame (backbone, FPN, head,
+        track embeddings, fast_nms, mask assembly: V/...:565-616), so the T frames run as ONE batch through the launch
+        plan (two half-clip chains for even T >= 4); only `match` (V/...:616-667) is sequential, and it runs here in
+        frame order on the batched results -- the same ids as T calls of simple_test, without T latency-bound
+        batch-1 passes.  imgs [T,3,H,W]; img_metas: T dicts (is_first resets the tracker).  Returns the T
+        (bbox_results, segm_results) pairs of simple_test (segm_results empty dicts when encode=False)."""
+        T = imgs.shape[0]
+        m0 = img_metas[0]
+        lanes = 2 if (T >= 4 and T % 2 == 0) else 1
+        eng = self.prepare(T, tuple(imgs.shape[-2:]), tuple(m0['img_shape']), m0.get('scale_factor', 1.0), bool(rescale),
+                           lanes=lanes)
+        r = eng.run(imgs)
+        nd = r["ndet"].cpu().tolist()                              # ONE device->host sync per clip
+        rles = eng.encode_rle(tuple(m0['ori_shape'])[:2]) if encode else None
+        out = []
+        for t in range(T):
+            n = int(nd[t])
+            if n == 0:
+                out.append((dict(), [[] for _ in range(self.bbox_head.num_classes - 1)]))
+                continue
+            det, labels = r["det_bboxes"][t, :n], r["det_labels"][t, :n]
+            ids = self.bbox_head.match(det, labels, r["det_feats"][t, :n], img_metas[t]['is_first'])
+            d, l = det.cpu().numpy(), labels.cpu().numpy()
+            bbox_results, segm_results = {}, {}
+            for i in range(n):
+                if ids[i] >= 0:
+                    bbox_results[int(ids[i])] = {'bbox': d[i], 'label': l[i]}
+                    if encode:
+                        segm_results[int(ids[i])] = rles[t][i]
+            out.append((bbox_results, segm_results))
+        return out
 
     def simple_test(self, img, img_meta, rescale=False):
         assert img.shape[0] == 1, "only support one image at a time (V/...:621)"

@@ -165,6 +165,29 @@ def test_vis_detector_sequence(vdet):
     assert len(kept[0] & kept[2]) >= 1
 
 
+def test_vis_clip_test_equals_frame_by_frame(vdet):
+    """SipMaskVIS.clip_test (the clip's frames as one batch through the plan, matching in frame order afterwards) gives
+    the identities and boxes of frame-by-frame simple_test calls."""
+    g = torch.Generator().manual_seed(9)
+    img0 = torch.randn(1, 3, 192, 320, generator=g)
+    frames = torch.cat([img0 + torch.randn(img0.shape, generator=g) * 0.02 for _ in range(4)]).cuda()
+    metas = [dict(img_shape=(192, 320, 3), ori_shape=(192, 320, 3), pad_shape=(192, 320, 3), scale_factor=1.0,
+                  is_first=(t == 0)) for t in range(4)]
+    vdet.bbox_head.reset_tracker()
+    seq = [vdet.simple_test(frames[t:t + 1], [metas[t]], rescale=True) for t in range(4)]
+    vdet.bbox_head.reset_tracker()
+    clip = vdet.clip_test(frames, metas, rescale=True)
+    assert sum(len(b) for b, _ in seq) > 0
+    for t in range(4):
+        (b1, s1), (b2, s2) = seq[t], clip[t]
+        common = set(b1) & set(b2)
+        assert len(common) >= max(len(b1), len(b2)) - 1, (t, sorted(b1), sorted(b2))      # near-tie swaps at most
+        for oid in common:
+            if b1[oid]['label'] == b2[oid]['label']:
+                np.testing.assert_allclose(b1[oid]['bbox'], b2[oid]['bbox'], rtol=2e-2, atol=0.5)
+                assert s2[oid]["size"] == s1[oid]["size"]
+
+
 def test_vis_training_losses_vs_oracle():
     """SipMaskVISHead.forward(feats, feats_x, flag_train=True) + loss: the SipMask losses plus loss_match against the
     oracle (same jitter offsets injected on both sides); gradients reach the track branch."""
