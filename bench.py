@@ -123,8 +123,17 @@ def run_inference(args, rank, world, dev):
     torch.cuda.empty_cache()
     eng = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=1)
 
-    if args.tower_only:
-        eng.run(img)
+    # ---- the timed plan: det.prepare's default runs an even batch >= 4 as two concurrent half-batch chains
+    # (engine.SubBatchPlan); --lanes 1 forces the single plan
+    del eng
+    torch.cuda.empty_cache()
+    plan = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=args.lanes or "auto")
+    subplans = getattr(plan, "engines", None)
+    eng = subplans[0] if subplans else plan          # the plan whose launches the breakdown / roofline below time
+    eng_img = img[:eng.batch].contiguous()
+    run_all = lambda: plan.run(img)
+    if args.tower_only:      # the dominant kernel of the SAME plan the breakdown below times, alone and back to back
+        eng.run(eng_img)
         tower = [c for c in eng.convs if c.name.startswith("head.cls_convs") or c.name.startswith("head.tower")][0]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
@@ -135,20 +144,11 @@ def run_inference(args, rank, world, dev):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.tower_only
-        print(json.dumps({"kernel": tower.name, "launches": args.tower_only, "ms_per_launch": round(ms, 4),
+        print(json.dumps({"kernel": tower.name, "plan_batch": eng.batch, "patch_kernel": bool(getattr(tower, "patch", False)),
+                          "launches": args.tower_only, "ms_per_launch": round(ms, 4),
                           "tflops": round(tower.flops / ms / 1e9, 1), "gflop": round(tower.flops / 1e9, 2),
                           "algorithmic_mb": round(tower.bytes / 1e6, 1)}))
         return None
-
-    # ---- the timed plan: det.prepare's default runs an even batch >= 4 as two concurrent half-batch chains
-    # (engine.SubBatchPlan); --lanes 1 forces the single plan
-    del eng
-    torch.cuda.empty_cache()
-    plan = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=args.lanes or "auto")
-    subplans = getattr(plan, "engines", None)
-    eng = subplans[0] if subplans else plan          # the plan whose launches the breakdown / roofline below time
-    eng_img = img[:eng.batch].contiguous()
-    run_all = lambda: plan.run(img)
 
     # ---- warm-up (eager), then optional graph capture
     for _ in range(max(1, min(args.warmup, 2))):
@@ -215,9 +215,9 @@ def run_inference(args, rank, world, dev):
     # HBM traffic of the dominant kernel: PMC passes cannot run inside this process; the number comes from the
     # committed rocprofv3 summary of the same kernel/shape (profiles/), per launch
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_tower_conv.json" if grouped else "r01_pmc_tower_conv.json")
-    if os.path.exists(pmc_file) and eng.batch == 4 and not f32:
-        pmc = json.load(open(pmc_file))
+    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_tower_conv.json")
+    pmc = json.load(open(pmc_file)) if os.path.exists(pmc_file) else None
+    if pmc and pmc.get("plan_batch") == eng.batch and pmc.get("launch") == towers[0].name and not f32:
         traffic = round(pmc["hbm_bytes_per_launch"] / 1e6, 1)
         traffic_src = "profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), MB per launch" % os.path.basename(pmc_file)
     if args.breakdown and rank == 0:
