@@ -47,6 +47,9 @@ def parse(argv=None):
     ap.add_argument("--lanes", type=int, default=0, help="run the batch as this many independent sub-batch plans on "
                     "concurrent HIP streams (engine.SubBatchPlan); 0 = the product default (2 for even batches >= 4)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--sub-graphs", type=int, default=0, choices=[0, 1, 2],
+                    help="with 2 sub-plans: one hipGraph per sub-plan on concurrent streams (1 = sub-plans keep their "
+                         "internal side lanes, 2 = single-lane sub-plans) instead of one graph around both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-step HIP-event breakdown to this file")
     ap.add_argument("--tower-only", type=int, default=0, metavar="N",
@@ -155,7 +158,11 @@ def run_inference(args, rank, world, dev):
         run_all()
     torch.cuda.synchronize()
     graph = None
-    if not args.no_graph:
+    sub_graphs = False
+    if args.sub_graphs and not args.no_graph and hasattr(plan, "capture"):
+        plan.capture(img, multi_stream=(args.sub_graphs == 1))
+        sub_graphs = True
+    elif not args.no_graph:
         try:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -171,7 +178,9 @@ def run_inference(args, rank, world, dev):
             torch.cuda.synchronize()
 
     def step():
-        if graph is not None:
+        if sub_graphs:
+            plan.replay()
+        elif graph is not None:
             graph.replay()
         else:
             run_all()
@@ -195,7 +204,7 @@ def run_inference(args, rank, world, dev):
         torch.cuda.synchronize()
         for i, (e0, e1) in enumerate(ev):
             acc[i] += e0.elapsed_time(e1) / reps
-    conv_ms = {c.name: None for c in eng.convs}
+    conv_ms = {c.name: None for c in eng.convs + eng.fused}
     for (label, _), ms in zip(eng.steps, acc):
         if label.startswith("conv:"):
             conv_ms[label[5:]] = ms
@@ -223,7 +232,7 @@ def run_inference(args, rank, world, dev):
     if args.breakdown and rank == 0:
         with open(args.breakdown, "w") as f:
             f.write("# per-step HIP event times (ms), eager launches, plan batch %d, mean of %d\n" % (eng.batch, reps))
-            cinfo = {"conv:" + c.name: c for c in eng.convs}
+            cinfo = {"conv:" + c.name: c for c in eng.convs + eng.fused}
             for (label, _), ms in zip(eng.steps, acc):
                 c = cinfo.get(label)
                 if c is not None:

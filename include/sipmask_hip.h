@@ -135,6 +135,18 @@ int sm_conv2d(const sm_conv_desc* d, const void* x, const void* w, const float* 
 int sm_conv2d_ws(const sm_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
                  void* workspace, int64_t workspace_bytes, sm_stream_t stream);
 
+/* ResNet bottleneck tail as ONE launch (Bottleneck.forward, M/mmdet/models/backbones/resnet.py:167-200, caffe style,
+   BN folded by the caller):  t2 = relu(conv3x3(x; w2) + b2);  y = relu(conv1x1(t2; w3) + b3 + identity);  and, when
+   w1_next is given, the NEXT block's  t1_next = relu(conv1x1(y; w1_next) + b1_next)  -- t2 (and y as conv1's input)
+   never leave the CU.  channels = C in {64, 128} (layer1 / layer2); x [B*h*w][C], identity / y [B*h*w][4C],
+   t1_next [B*h*w][C], all bf16 NHWC rows; w2 [C][9C] with K = (kh, kw, cin), w3 [4C][C], w1_next [C][4C] bf16 (the
+   sm_conv2d weight layout for these shapes); biases f32.  Arithmetic (K order, rounding points) is that of the
+   separate sm_conv2d launches, so results are bit-identical to them. */
+int sm_bottleneck_tail_supported(int channels);
+int sm_bottleneck_tail(int batch, int h, int w, int channels, const void* x, const void* w2, const float* b2,
+                       const void* w3, const float* b3, const void* identity, void* y, const void* w1_next,
+                       const float* b1_next, void* t1_next, sm_stream_t stream);
+
 /* 3x3 / stride 1 / pad 1 convolution with the input patch resident in LDS (csrc/conv3x3_patch.hip): the throughput
  * kernel for the large 3x3 layers (tower convs -- also as the grouped cls+reg launch --, fcos_cls + sip_cof, FPN
  * output convs).  Same descriptor, activations and epilogue semantics as sm_conv2d / sm_conv2d_gn_stats (bias,
@@ -196,6 +208,11 @@ int sm_conv2d_gn_stats(const sm_conv_desc* d, const void* x, const float* offset
 int sm_offset_linear(const float* reg, int reg_cstride, const float* w_off, int nout,
                      const int64_t* row0, const int32_t* rows_per_level, const float* level_scale,
                      int nlev, float* out, sm_stream_t stream);
+
+/* y = relu(x) over n bf16 elements (n % 8 == 0): halves with the sign bit set become +0 (so a negative NaN becomes 0
+   where torch.relu would keep it; activations on this path are finite).  Replaces the `F.relu(outs[-1])` in front of
+   the P7 conv (M/mmdet/models/necks/fpn.py:166-170) so that conv takes the LDS-DMA operand path. */
+int sm_relu_bf16(const void* x, void* y, int64_t n, sm_stream_t stream);
 
 /* GroupNorm(groups) + optional ReLU over each (image, level), in place allowed.
  * nn.GroupNorm in M/mmdet/ops/conv_module.py:116-120 / sipmask_head.py:42,52.

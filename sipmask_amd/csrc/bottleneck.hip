@@ -1,0 +1,359 @@
+// ResNet bottleneck tail as ONE launch (gfx950): conv2 (3x3 / stride 1 / pad 1, C -> C, folded-BN bias, ReLU) chained
+// with conv3 (1x1, C -> 4C, folded-BN bias, + identity, ReLU); optionally the NEXT block's conv1 (1x1, 4C -> C, bias,
+// ReLU) chained behind it.  Reference: Bottleneck.forward, M/mmdet/models/backbones/resnet.py:167-200 (caffe style: the
+// stride sits on conv1, so conv2 is always stride 1), BN frozen (resnet.py:370,514-521) and folded by the caller.
+//
+// Why.  layer1 / layer2 are bandwidth-shaped: conv3 moves 155 MB per B=2 launch for 4.4 GFLOP, and the C-channel tensor
+// between conv2 and conv3 (and the 4C-channel tensor between conv3 and the next conv1) goes out to HBM and comes back
+// for nothing.  Here a block computes the conv2 tile for 128 positions x ALL C channels; the MFMA C layout after the
+// v_permlane32_swap step of the register epilogue (lane (p, h) holds 8 consecutive channels 16*kk + 8*h of position p)
+// IS the B-operand layout of v_mfma_f32_32x32x16_bf16 for K step kk, so the bias+ReLU'd, bf16-rounded conv2 tile feeds
+// conv3's MFMAs straight from registers: no LDS round trip, no barrier, and bit-identical arithmetic to the two-launch
+// path (same K order, same rounding points).  The same holds between conv3's output and the next conv1.
+// Every wave owns 32 positions for the whole chain; the 1x1 weights stream through LDS in 16 KB slices (LDS-DMA,
+// ping-pong between a dedicated buffer and the finished K loop's stages), 128-byte rows with the conv_igemm swizzle.
+#include "common.h"
+
+namespace {
+
+struct BtArgs {
+  const uint16_t* x;     // conv2 input  [M][C]
+  const uint16_t* w2;    // [C][9C]      (kh, kw, cin) with cin fastest
+  const float* b2;
+  const uint16_t* w3;    // [4C][C]
+  const float* b3;
+  const uint16_t* res;   // identity     [M][4C]
+  uint16_t* y;           // block output [M][4C]
+  const uint16_t* w1n;   // next conv1   [C][4C] or null
+  const float* b1n;
+  uint16_t* t1n;         // next conv1 output [M][C]
+  int batch, H, W, M;
+};
+
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16b[4] = {0u, 0u, 0u, 0u};
+
+constexpr int BT_BPOS = 128;
+constexpr int BT_SLICE_BYTES = 16384;
+
+template <int C2, bool CHAIN1>
+__global__ __launch_bounds__(256, 3) void bottleneck_tail_kernel(const BtArgs a) {
+  constexpr int TCO = C2 / 32;                  // MFMA tiles along the conv2 couts (all of them in one wave)
+  constexpr int NW = C2 / 64;                   // weight DMA instructions per thread per K step
+  constexpr int NX = BT_BPOS / 64;
+  constexpr int STAGE = (C2 + BT_BPOS) * 64;    // one K step of 32: [C2 weight rows | 128 position rows] x 64 B
+  constexpr int KP2 = 9 * C2;
+  constexpr int CPT = C2 / 8;                   // 16-byte chunks per tap
+  constexpr int NK = 9 * C2 / 32;
+  constexpr int C4 = 4 * C2;
+  constexpr int SL = BT_SLICE_BYTES / (C2 * 2); // conv3 couts per slice (128 | 64)
+  constexpr int NPASS = C4 / SL;
+  constexpr int NSUB = C2 / 64;                 // 128-byte-row sub-tiles (64 k each) of a conv3 weight slice
+  constexpr int CT = SL / 32;                   // MFMA tiles along the slice's couts
+  constexpr int KK3 = C2 / 16;                  // K steps of 16 in conv3
+  // chained conv1 of the next block: per pass a K slice of SL input channels, weights [C2 rows][SL k]
+  constexpr int NSUB1 = SL / 64;
+  constexpr int W1_BYTES = CHAIN1 ? BT_SLICE_BYTES : 0;
+  static_assert(2 * STAGE >= BT_SLICE_BYTES, "the finished stages hold one weight slice");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // bt_lds_bytes(C2, CHAIN1)
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  unsigned char* const bufA = smem + 2 * STAGE;
+  unsigned char* const bufB = smem;
+  unsigned char* const w1buf = smem + 2 * STAGE + BT_SLICE_BYTES;     // [2][16 KB] (CHAIN1)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int m0 = blockIdx.x * BT_BPOS;
+  const int H = a.H, W = a.W, HW = H * W, M = a.M;
+
+  // ---- weight slices of the 1x1 convs: 16 KB = 128 flat rows of 128 B, lane L of a wave instruction -> row L>>3,
+  // physical slot L&7, i.e. it fetches logical chunk (L&7) ^ ((row>>1)&7)
+  auto dma_w3_slice = [&](int p, unsigned char* buf) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int fr = (r * 4 + wave) * 8 + (lane >> 3);
+      const int sub = fr / SL, row = fr - sub * SL;
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      const uint16_t* src = a.w3 + (long long)(p * SL + row) * C2 + sub * 64 + chunk * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(buf + (r * 4 + wave) * 1024), 16, 0, 0);
+    }
+  };
+  auto dma_w1_slice = [&](int p, unsigned char* buf) {       // rows = next conv1 couts (C2), k = [p*SL, (p+1)*SL)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int fr = (r * 4 + wave) * 8 + (lane >> 3);
+      const int sub = fr / C2, row = fr - sub * C2;
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      const uint16_t* src = a.w1n + (long long)row * C4 + p * SL + sub * 64 + chunk * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(buf + (r * 4 + wave) * 1024), 16, 0, 0);
+    }
+  };
+  dma_w3_slice(0, bufA);                         // independent of everything: lands under the K loop
+  if constexpr (CHAIN1) dma_w1_slice(0, w1buf);
+
+  // ---- conv2: implicit GEMM, 32-wide K steps, LDS-DMA double buffer (the conv_dma32_kernel scheme, one level)
+  const int j = (lane & 3) ^ ((lane >> 4) & 3);
+  const int r0 = tid >> 2;
+  int rhi[NX], rwi[NX];
+  long long xoff[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int m = m0 + r0 + 64 * i;
+    if (m < M) {
+      const int n = m / HW;
+      const int rem = m - n * HW;
+      const int ho = rem / W;
+      const int wo = rem - ho * W;
+      rhi[i] = ho - 1;
+      rwi[i] = wo - 1;
+      xoff[i] = ((long long)n * HW + (long long)rhi[i] * W + rwi[i]) * C2;
+    } else {
+      rhi[i] = -0x40000000;
+      rwi[i] = 0;
+      xoff[i] = 0;
+    }
+  }
+  const uint16_t* ld_wp = a.w2 + (long long)r0 * KP2 + j * 8;
+  int ld_cc = j, ld_kh = 0, ld_kw = 0;           // CPT >= 8 > j
+  const unsigned long long zero_page = (unsigned long long)g_zero16b;
+  const int wave_row = wave * 16;
+  auto dma_tile = [&](int buf) {
+    unsigned char* Wb = smem + buf * STAGE + wave_row * 64;
+    unsigned char* Xb = Wb + C2 * 64;
+    const long long toff = (long long)((ld_kh * W + ld_kw) * C2 + ld_cc * 8);
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(ld_wp + (long long)i * 64 * KP2), (lds_void*)(Wb + 64 * i * 64), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int hi = rhi[i] + ld_kh, wi = rwi[i] + ld_kw;
+      const bool ok = ((unsigned)hi < (unsigned)H) & ((unsigned)wi < (unsigned)W);
+      const unsigned long long pm = ok ? ~0ull : 0ull;
+      const unsigned long long src = ((unsigned long long)(a.x + xoff[i] + toff) & pm) | (zero_page & ~pm);
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Xb + 64 * i * 64), 16, 0, 0);
+    }
+    ld_wp += 32;
+    ld_cc += 4;
+    const int wrap = ld_cc >= CPT ? 1 : 0;
+    ld_cc -= wrap * CPT;
+    ld_kw += wrap;
+    const int wrap2 = ld_kw == 3 ? 1 : 0;
+    ld_kw -= wrap2 * 3;
+    ld_kh += wrap2;
+  };
+
+  f32x16 acc[TCO];
+#pragma unroll
+  for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[tc][e] = 0.f;
+  const int rsw = (l31 >> 2) & 3;
+  const int wrow_off = l31 * 64;
+  const int xrow_off = C2 * 64 + (wave * 32 + l31) * 64;
+  auto compute = [&](int buf) {
+    const unsigned char* S = smem + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
+      bf16x8 wf[TCO];
+#pragma unroll
+      for (int t = 0; t < TCO; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(S + wrow_off + t * 32 * 64 + slot);
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(S + xrow_off + slot);
+#pragma unroll
+      for (int tc = 0; tc < TCO; ++tc) acc[tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tc], xf, acc[tc], 0, 0, 0);
+    }
+  };
+  dma_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt + 1 < NK; ++kt) {
+    const int buf = kt & 1;
+    dma_tile(buf ^ 1);
+    compute(buf);
+    __syncthreads();
+  }
+  compute((NK - 1) & 1);
+
+  // ---- conv2 epilogue in registers: bias, ReLU, bf16 -> the B fragments of conv3 (K step kk = 2*tc + qp)
+  bf16x8 tfr[KK3];
+#pragma unroll
+  for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t lo = __float_as_uint(acc[tc][4 * (2 * qp) + e]);
+        const uint32_t hi = __float_as_uint(acc[tc][4 * (2 * qp + 1) + e]);
+        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+        v[e] = __uint_as_float(r[0]);
+        v[4 + e] = __uint_as_float(r[1]);
+      }
+      const int c0 = tc * 32 + 16 * qp + 8 * khalf;
+      const float4 b0 = *reinterpret_cast<const float4*>(a.b2 + c0);
+      const float4 b1 = *reinterpret_cast<const float4*>(a.b2 + c0 + 4);
+      v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w;
+      v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      tfr[2 * tc + qp] = __builtin_bit_cast(bf16x8, pack_bf16x8_v(v));
+    }
+
+  // ---- conv3 (+ chained conv1) in passes of SL couts
+  const int m = m0 + wave * 32 + l31;
+  const bool mok = m < M;
+  const long long orow = (long long)(mok ? m : 0) * C4;
+  f32x16 acc1[CHAIN1 ? TCO : 1];
+  if constexpr (CHAIN1) {
+#pragma unroll
+    for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc1[tc][e] = 0.f;
+  }
+  const int asw = (l31 >> 1) & 7;                // A-fragment swizzle: rows ct*32 + l31, 32 | row base
+#pragma unroll 1
+  for (int p = 0; p < NPASS; ++p) {
+    unsigned char* const buf = (p & 1) ? bufB : bufA;
+    __syncthreads();                             // slice p has landed; the other buffer's readers (pass p-1) are done
+    if (p + 1 < NPASS) {
+      dma_w3_slice(p + 1, (p & 1) ? bufA : bufB);
+      if constexpr (CHAIN1) dma_w1_slice(p + 1, w1buf + ((p + 1) & 1) * BT_SLICE_BYTES);
+    }
+    u32x4 rv[CT][2];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp)
+        rv[ct][qp] = *reinterpret_cast<const u32x4*>(a.res + orow + p * SL + ct * 32 + 16 * qp + 8 * khalf);
+    f32x16 acc3[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc3[ct][e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KK3; ++kk) {
+      const int sub = kk >> 2;
+      const int slot = ((((kk & 3) * 2 + khalf) ^ asw)) * 16;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(buf + (sub * SL + ct * 32 + l31) * 128 + slot);
+        acc3[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, tfr[kk], acc3[ct], 0, 0, 0);
+      }
+    }
+    bf16x8 yfr[CT * 2];                          // this pass's outputs as B fragments of the chained conv1
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t lo = __float_as_uint(acc3[ct][4 * (2 * qp) + e]);
+          const uint32_t hi = __float_as_uint(acc3[ct][4 * (2 * qp + 1) + e]);
+          const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+          v[e] = __uint_as_float(r[0]);
+          v[4 + e] = __uint_as_float(r[1]);
+        }
+        const int c0 = p * SL + ct * 32 + 16 * qp + 8 * khalf;
+        const float4 b0 = *reinterpret_cast<const float4*>(a.b3 + c0);
+        const float4 b1 = *reinterpret_cast<const float4*>(a.b3 + c0 + 4);
+        v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w;
+        v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
+        float f[8];
+        unpack_bf16x8(rv[ct][qp], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + f[e], 0.f);
+        const u32x4 packed = pack_bf16x8_v(v);
+        if (mok) *reinterpret_cast<u32x4*>(a.y + orow + c0) = packed;
+        yfr[ct * 2 + qp] = __builtin_bit_cast(bf16x8, packed);
+      }
+    if constexpr (CHAIN1) {
+      const unsigned char* wb = w1buf + (p & 1) * BT_SLICE_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < SL / 16; ++kk) {       // k = p*SL + 16*kk (+ 8*khalf) <-> yfr[kk]
+        const int sub = kk >> 2;
+        const int slot = ((((kk & 3) * 2 + khalf) ^ asw)) * 16;
+#pragma unroll
+        for (int tc = 0; tc < TCO; ++tc) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + (sub * C2 + tc * 32 + l31) * 128 + slot);
+          acc1[tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, yfr[kk], acc1[tc], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if constexpr (CHAIN1) {
+#pragma unroll
+    for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t lo = __float_as_uint(acc1[tc][4 * (2 * qp) + e]);
+          const uint32_t hi = __float_as_uint(acc1[tc][4 * (2 * qp + 1) + e]);
+          const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+          v[e] = __uint_as_float(r[0]);
+          v[4 + e] = __uint_as_float(r[1]);
+        }
+        const int c0 = tc * 32 + 16 * qp + 8 * khalf;
+        const float4 b0 = *reinterpret_cast<const float4*>(a.b1n + c0);
+        const float4 b1 = *reinterpret_cast<const float4*>(a.b1n + c0 + 4);
+        v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w;
+        v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        if (mok) *reinterpret_cast<u32x4*>(a.t1n + (long long)m * C2 + c0) = pack_bf16x8_v(v);
+      }
+  }
+}
+
+constexpr int bt_lds_bytes(int c2, bool chain) { return 2 * (c2 + BT_BPOS) * 64 + BT_SLICE_BYTES + (chain ? 2 * BT_SLICE_BYTES : 0); }
+
+template <int C2, bool CHAIN1>
+int bt_launch(const BtArgs& a, dim3 grid, hipStream_t s) {
+  constexpr int lds = bt_lds_bytes(C2, CHAIN1);
+  static bool attr_set = false;                 // > 64 KB of dynamic LDS needs the opt-in once per kernel
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail_kernel<C2, CHAIN1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return SM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bottleneck_tail_kernel<C2, CHAIN1>), grid, dim3(256), lds, s, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+}  // namespace
+
+extern "C" int sm_bottleneck_tail_supported(int channels) { return (channels == 64 || channels == 128) ? 1 : 0; }
+
+extern "C" int sm_bottleneck_tail(int batch, int h, int w, int channels, const void* x, const void* w2, const float* b2,
+                                  const void* w3, const float* b3, const void* identity, void* y, const void* w1_next,
+                                  const float* b1_next, void* t1_next, sm_stream_t stream) {
+  if (!x || !w2 || !b2 || !w3 || !b3 || !identity || !y || batch < 1 || h < 1 || w < 1) return SM_ERR_BAD_ARG;
+  if (channels != 64 && channels != 128) return SM_ERR_UNSUPPORTED;
+  const bool chain = w1_next != nullptr;
+  if (chain && (!b1_next || !t1_next)) return SM_ERR_BAD_ARG;
+  const long long M = (long long)batch * h * w;
+  if (M * 4 * channels >= (1ll << 31) * 8) return SM_ERR_BAD_SHAPE;
+  BtArgs a;
+  a.x = (const uint16_t*)x;
+  a.w2 = (const uint16_t*)w2;
+  a.b2 = b2;
+  a.w3 = (const uint16_t*)w3;
+  a.b3 = b3;
+  a.res = (const uint16_t*)identity;
+  a.y = (uint16_t*)y;
+  a.w1n = (const uint16_t*)w1_next;
+  a.b1n = b1_next;
+  a.t1n = (uint16_t*)t1_next;
+  a.batch = batch;
+  a.H = h;
+  a.W = w;
+  a.M = (int)M;
+  const dim3 grid(sm_cdiv(M, BT_BPOS));
+  hipStream_t s = sm_hip_stream(stream);
+  if (channels == 64) return chain ? bt_launch<64, true>(a, grid, s) : bt_launch<64, false>(a, grid, s);
+  return chain ? bt_launch<128, true>(a, grid, s) : bt_launch<128, false>(a, grid, s);
+}

@@ -64,6 +64,7 @@ struct GnArgs {
   int blk0[SM_MAX_LEVELS + 1];  // first block of each level (per image)
   float eps;
   int relu;
+  int rpb;  // rows of one (image, level) per block
 };
 
 constexpr int GN_ROWS_PER_BLOCK = 256;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
 #pragma unroll
   for (int l = 1; l < SM_MAX_LEVELS; ++l)
     if (l < a.nlev && (int)blockIdx.x >= a.blk0[l]) lev = l;
-  const int rb = (blockIdx.x - a.blk0[lev]) * GN_ROWS_PER_BLOCK;
+  const int rb = (blockIdx.x - a.blk0[lev]) * a.rpb;
   const int HW = a.hw[lev];
   const int c8 = a.C / 8;            // chunks per row
   const int rows_per_iter = 256 / c8;  // C=256 -> 8 rows per iteration
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
   const uint16_t* base = x + (a.row0[lev] + (long long)n * HW) * a.C;
   float s = 0.f, ss = 0.f;
   if (rr < rows_per_iter) {
-    const int rend = min(rb + GN_ROWS_PER_BLOCK, HW);
+    const int rend = min(rb + a.rpb, HW);
     for (int r = rb + rr; r < rend; r += rows_per_iter) {
       const uint4 v = *reinterpret_cast<const uint4*>(base + (long long)r * a.C + cc * 8);
       float f[8];
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
 #pragma unroll
   for (int l = 1; l < SM_MAX_LEVELS; ++l)
     if (l < a.nlev && (int)blockIdx.x >= a.blk0[l]) lev = l;
-  const int rb = (blockIdx.x - a.blk0[lev]) * GN_ROWS_PER_BLOCK;
+  const int rb = (blockIdx.x - a.blk0[lev]) * a.rpb;
   const int HW = a.hw[lev];
   const int c8 = a.C / 8;
   const int rows_per_iter = 256 / c8;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
     sf[e] = beta[cc * 8 + e] - mean * ga;
   }
   const long long off = (a.row0[lev] + (long long)n * HW) * a.C;
-  const int rend = min(rb + GN_ROWS_PER_BLOCK, HW);
+  const int rend = min(rb + a.rpb, HW);
   // 4 rows per iteration, all loads issued before the first use: a pure streaming pass wants bytes in flight
   // (one 16-byte load per thread per iteration measured 2.8 TB/s on the 46 MB tower tensor)
   constexpr int UN = 4;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void gn_stats_f32_kernel(const float* __restri
 #pragma unroll
   for (int l = 1; l < SM_MAX_LEVELS; ++l)
     if (l < a.nlev && (int)blockIdx.x >= a.blk0[l]) lev = l;
-  const int rb = (blockIdx.x - a.blk0[lev]) * GN_ROWS_PER_BLOCK;
+  const int rb = (blockIdx.x - a.blk0[lev]) * a.rpb;
   const int HW = a.hw[lev];
   const int c4 = a.C / 4;
   const int rows_per_iter = 256 / c4;
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void gn_stats_f32_kernel(const float* __restri
   const float* base = x + (a.row0[lev] + (long long)n * HW) * a.C;
   double s = 0.0, ss = 0.0;
   if (rr < rows_per_iter) {
-    const int rend = min(rb + GN_ROWS_PER_BLOCK, HW);
+    const int rend = min(rb + a.rpb, HW);
     for (int r = rb + rr; r < rend; r += rows_per_iter) {
       const float4 v = *reinterpret_cast<const float4*>(base + (long long)r * a.C + cc * 4);
       s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void gn_apply_f32_kernel(const float* __restri
 #pragma unroll
   for (int l = 1; l < SM_MAX_LEVELS; ++l)
     if (l < a.nlev && (int)blockIdx.x >= a.blk0[l]) lev = l;
-  const int rb = (blockIdx.x - a.blk0[lev]) * GN_ROWS_PER_BLOCK;
+  const int rb = (blockIdx.x - a.blk0[lev]) * a.rpb;
   const int HW = a.hw[lev];
   const int c4 = a.C / 4;
   const int rows_per_iter = 256 / c4;
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256) void gn_apply_f32_kernel(const float* __restri
     be[e] = beta[cc * 4 + e];
   }
   const long long off = (a.row0[lev] + (long long)n * HW) * a.C;
-  const int rend = min(rb + GN_ROWS_PER_BLOCK, HW);
+  const int rend = min(rb + a.rpb, HW);
   for (int r = rb + rr; r < rend; r += rows_per_iter) {
     const long long o = off + (long long)r * a.C + cc * 4;
     const float4 v = *reinterpret_cast<const float4*>(x + o);
@@ -426,7 +427,7 @@ extern "C" int sm_maxpool3x3s2(const void* x, void* y, int batch, int h, int w, 
 }
 
 static int gn_fill_args(GnArgs& a, int& t, int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels,
-                        int groups, float eps, int relu, int vec = 8) {
+                        int groups, float eps, int relu, int vec = 8, bool streaming = false) {
   if (nlev < 1 || nlev > SM_MAX_LEVELS || channels % (vec * groups) != 0 || channels > 256 * vec || 256 % (channels / vec) != 0)
     return SM_ERR_BAD_SHAPE;
   if (groups > 256) return SM_ERR_BAD_SHAPE;
@@ -437,12 +438,20 @@ static int gn_fill_args(GnArgs& a, int& t, int batch, int nlev, const int32_t* h
   a.cpg = channels / groups;
   a.eps = eps;
   a.relu = relu;
+  // a block walks GN_ROWS_PER_BLOCK rows; the pure streaming pass (apply only) wants >= ~4 blocks per CU in flight,
+  // so small tensors (a B=2 sub-plan: 176 blocks of 256 rows for the whole tower tensor) get shorter blocks
+  a.rpb = GN_ROWS_PER_BLOCK;
+  if (streaming) {
+    long long blocks = 0;
+    for (int l = 0; l < nlev; ++l) blocks += (long long)batch * sm_cdiv(hw[l], GN_ROWS_PER_BLOCK);
+    if (blocks < 1024) a.rpb = blocks < 512 ? 32 : 64;
+  }
   t = 0;
   for (int l = 0; l < SM_MAX_LEVELS; ++l) {
     a.hw[l] = l < nlev ? hw[l] : 0;
     a.row0[l] = l < nlev ? row0[l] : 0;
     a.blk0[l] = t;
-    if (l < nlev) t += sm_cdiv(hw[l], GN_ROWS_PER_BLOCK);
+    if (l < nlev) t += sm_cdiv(hw[l], a.rpb);
   }
   a.blk0[SM_MAX_LEVELS] = t;
   return SM_OK;
@@ -471,7 +480,7 @@ extern "C" int sm_groupnorm_apply(const void* x, void* y, const float* gamma, co
   if (!x || !y || !gamma || !beta || !stats || !hw || !row0) return SM_ERR_BAD_ARG;
   GnArgs a;
   int t;
-  const int st = gn_fill_args(a, t, batch, nlev, hw, row0, channels, groups, eps, relu);
+  const int st = gn_fill_args(a, t, batch, nlev, hw, row0, channels, groups, eps, relu, 8, true);
   if (st != SM_OK) return st;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(t, batch), dim3(256), 0, sm_hip_stream(stream), (const uint16_t*)x,
                      (uint16_t*)y, gamma, beta, stats, a);
@@ -513,6 +522,32 @@ extern "C" int sm_offset_linear(const float* reg, int reg_cstride, const float* 
   }
   hipLaunchKernelGGL(offset_linear_kernel, dim3(grid_for(a.total * nout, 256)), dim3(256), 0, sm_hip_stream(stream),
                      reg, w_off, out, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+/* ReLU of a bf16 row matrix into a second buffer.  FPN: P7 = conv(relu(P6)) (fpn.py:166-170) while P6 itself is a
+   pyramid level; with the ReLU'd copy as the conv's input the 4-tile P7 launch takes the LDS-DMA operand path instead
+   of the register-staged loader the SM_CONV_IN_RELU flag forces (0.056 -> 0.02 ms). */
+namespace {
+__global__ void relu_bf16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, long long n16) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n16) return;
+  u32x4 v = x[i];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t neg = (v[e] >> 15) & 0x00010001u;      // sign bit of each half
+    v[e] &= ~(neg * 0xffffu);                              // negative (and -0) halves -> +0
+  }
+  y[i] = v;
+}
+}  // namespace
+
+extern "C" int sm_relu_bf16(const void* x, void* y, int64_t n, sm_stream_t stream) {
+  if (!x || !y || n < 0 || (n & 7) != 0) return SM_ERR_BAD_ARG;
+  if (n == 0) return SM_OK;
+  hipLaunchKernelGGL(relu_bf16_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, sm_hip_stream(stream),
+                     (const u32x4*)x, (u32x4*)y, (long long)(n / 8));
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -58,7 +58,7 @@ class SipMask(nn.Module):
             mk = lambda b: SipMaskEngine(sd, b, img_hw, self.backbone.depth, self.test_cfg, self.bbox_head.num_classes,
                                          strides=self.bbox_head.strides, img_shape=img_shape,
                                          ssd_flag=self.bbox_head.ssd_flag, scale_factor=scale_factor, rescale=rescale,
-                                         precision=precision)
+                                         precision=precision, sub_plan=lanes > 1)
             if lanes == 1:
                 return mk(batch)
             from .engine import SubBatchPlan

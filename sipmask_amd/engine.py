@@ -26,6 +26,9 @@ _GROUPED_TOWERS = __import__("os").environ.get("SIPMASK_GROUPED_TOWERS", "1") ==
 
 _SPLIT_K = __import__("os").environ.get("SIPMASK_SPLIT_K", "1") != "0"     # A/B: split-K for under-filled launches
 _PATCH_CONV = __import__("os").environ.get("SIPMASK_PATCH_CONV", "1") != "0"   # A/B: patch-resident 3x3 kernel
+# bottleneck fusion in layer1 / layer2: 0 = separate launches, 1 = conv2+conv3, 2 = conv2+conv3+next conv1
+_FUSE_BOTTLENECK = int(__import__("os").environ.get("SIPMASK_FUSE_BOTTLENECK", "2"))
+_RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"   # A/B: relu(P6) copy vs input-ReLU flag
 
 
 def _lib_flag(name):
@@ -84,14 +87,16 @@ class _Conv:
                 rounds = (tiles + 255) // 256
                 # one 256x256 tile per CU: take the kernel when the launch is a reasonable share of a round of 256 CUs
                 # and multi-round launches fill their rounds (measured: profiles/r02*_patch_conv_microbench.txt)
-                if tiles >= 100 and (rounds == 1 or tiles >= 0.65 * rounds * 256):
+                # ... and the couts fill most of the 256-wide tile (sip_mask_lat, 128 -> 32: 0.061 ms on the 32 x 256
+                # implicit-GEMM tile, 0.101 ms here with 7/8 of the MFMAs on padding)
+                if tiles >= 100 and (rounds == 1 or tiles >= 0.65 * rounds * 256) and co * 4 >= 3 * ((co + 255) // 256 * 256):
                     self.patch = True
                     self.w, _ = H.prep_conv_weight_patch(w.to(dev))
                     self.desc = dp
         # split-K workspace (own buffer per conv: launches on different lanes may run concurrently); sized by the
         # library's plan, allocated once at build -- 288 GB of HBM
         self.ws = None
-        if not self.f32 and offset is None and _SPLIT_K and not self.patch:
+        if not self.f32 and offset is None and getattr(eng, "split_k", _SPLIT_K) and not self.patch:
             pl = H.conv_plan(self.desc)
             if pl["split_k"] > 1:
                 self.ws = torch.empty(pl["workspace_bytes"], dtype=torch.uint8, device=dev)
@@ -116,6 +121,34 @@ class _Conv:
             H.conv2d_ws(self.desc, self.x, self.w, self.bias, self.residual, self.y, self.ws)
         else:
             H.conv2d(self.desc, self.x, self.w, self.bias, self.residual, self.y)
+
+
+class _BottleneckTail:
+    """conv2 + conv3 (+ the next block's conv1) of a ResNet bottleneck as ONE launch (csrc/bottleneck.hip;
+    resnet.py:167-200): the C-channel tensor between conv2 and conv3, and the read of the block output by the next
+    conv1, never touch HBM.  Same arithmetic as the separate launches (bit-identical outputs)."""
+
+    def __init__(self, name, batch, hw, planes, x, w2, b2, w3, b3, identity, y, next1=None):
+        dev = x.device
+        self.name, self.batch, self.hw, self.planes = name, batch, hw, planes
+        prep = lambda w: H.prep_conv_weight(w.to(dev), w.shape[1])[0][:w.shape[0]].contiguous()
+        fb = lambda b: b.float().to(dev).contiguous()
+        self.x, self.identity, self.y = x, identity, y
+        self.w2, self.b2, self.w3, self.b3 = prep(w2), fb(b2), prep(w3), fb(b3)
+        self.w1n = self.b1n = self.t1n = None
+        rows = batch * hw[0] * hw[1]
+        self.flops = 2.0 * rows * planes * planes * 9 + 2.0 * rows * planes * 4 * planes
+        # algorithmic bytes of the fused launch: x in, identity in, y out (+ next t1 out) + weights
+        self.bytes = rows * planes * 2 + 2 * rows * 4 * planes * 2 + (self.w2.numel() + self.w3.numel()) * 2
+        if next1 is not None:
+            w1, b1, t1n = next1
+            self.w1n, self.b1n, self.t1n = prep(w1), fb(b1), t1n
+            self.flops += 2.0 * rows * 4 * planes * planes
+            self.bytes += rows * planes * 2 + self.w1n.numel() * 2
+
+    def __call__(self):
+        H.bottleneck_tail(self.batch, self.hw[0], self.hw[1], self.planes, self.x, self.w2, self.b2, self.w3, self.b3,
+                          self.identity, self.y, self.w1n, self.b1n, self.t1n)
 
 
 class _GroupedConv(_Conv):
@@ -190,8 +223,11 @@ class SipMaskEngine:
 
     def __init__(self, state_dict, batch, img_hw, depth=50, test_cfg=None, num_classes=81, device="cuda",
                  strides=(8, 16, 32, 64, 128), img_shape=None, head_sizes=None, ssd_flag=False, scale_factor=1.0,
-                 rescale=False, vis=False, benchmark=None, precision="bf16"):
+                 rescale=False, vis=False, benchmark=None, precision="bf16", sub_plan=False):
         _lib.load()   # fail loudly before anything else if the HIP library is missing
+        # sub_plan: this engine is one chain of a SubBatchPlan -- the other chain fills the CUs a short launch leaves
+        # idle, so split-K (an extra reduce launch to fill them) only costs: 966 vs 962 img/s (profiles/r02e_ab_subplans.json)
+        self.split_k = _SPLIT_K and not sub_plan
         if precision not in ("bf16", "f32"):
             raise ValueError("precision must be 'bf16' (throughput plan) or 'f32' (parity plan), got %r" % (precision,))
         # "f32": every activation / weight float32, convs on the exact-f32 MFMA kernel (csrc/conv_f32.hip), GroupNorm
@@ -227,6 +263,7 @@ class SipMaskEngine:
         # launches are 20-130 blocks, far below the 512 resident blocks of the chip
         self.multi_stream = __import__("os").environ.get("SIPMASK_MULTI_STREAM", "1") != "0"
         self.convs = []        # _Conv objects (for FLOP accounting / per-kernel timing)
+        self.fused = []        # _BottleneckTail launches (several convs each; counted in total_conv_flops)
         self.head_start = 0
         if head_sizes is None:
             self._build(state_dict)
@@ -339,6 +376,7 @@ class SipMaskEngine:
         # ---- residual stages (caffe style: stride on conv1, resnet.py:125-130)
         cur, ch, cw, cc = x, h2, w2, 64
         feats = []
+        chained_t1 = None
         for li, nblocks in enumerate(ARCH[self.depth]):
             planes = 64 * 2 ** li
             for bi in range(nblocks):
@@ -353,13 +391,34 @@ class SipMaskEngine:
                                          planes * 4), lane=1)
                 else:
                     idt = cur
+                has_dcn = (p + ".conv2.conv_offset.weight") in sd
+                fuse = _FUSE_BOTTLENECK if (not f32 and planes in (64, 128) and not has_dcn) else 0
                 wa, ba = fold_bn(sd[p + ".conv1.weight"], sd, p + ".bn1")
-                t1 = self._buf(B * oh * ow, planes)
-                self._add_conv(_Conv(self, p + ".conv1", wa, ba, B, [(ch, cw)], [0], cur, cc, s, 0, t1, [0], planes,
-                                     flags=SM_CONV_RELU))
+                if chained_t1 is not None:       # the previous block's fused launch already produced this conv1
+                    t1, chained_t1 = chained_t1, None
+                else:
+                    t1 = self._buf(B * oh * ow, planes)
+                    self._add_conv(_Conv(self, p + ".conv1", wa, ba, B, [(ch, cw)], [0], cur, cc, s, 0, t1, [0], planes,
+                                         flags=SM_CONV_RELU))
                 wb, bb = fold_bn(sd[p + ".conv2.weight"], sd, p + ".bn2")
+                wc, bc = fold_bn(sd[p + ".conv3.weight"], sd, p + ".bn3")
+                out = self._buf(B * oh * ow, planes * 4)
+                if fuse:
+                    if bi == 0:
+                        self._join(1)
+                    next1 = None
+                    pn = "backbone.layer%d.%d" % (li + 1, bi + 1)
+                    if fuse >= 2 and bi + 1 < nblocks and (pn + ".conv2.conv_offset.weight") not in sd:
+                        wn, bn = fold_bn(sd[pn + ".conv1.weight"], sd, pn + ".bn1")
+                        chained_t1 = self._buf(B * oh * ow, planes)
+                        next1 = (wn, bn, chained_t1)
+                    tail = _BottleneckTail(p + ".tail", B, (oh, ow), planes, t1, wb, bb, wc, bc, idt, out, next1)
+                    self.fused.append(tail)
+                    self._add("conv:" + tail.name, tail)
+                    cur, ch, cw, cc = out, oh, ow, planes * 4
+                    continue
                 t2 = self._buf(B * oh * ow, planes)
-                if (p + ".conv2.conv_offset.weight") in sd:
+                if has_dcn:
                     # SipMask++ backbone DCN (DeformConvPack, deform_conv.py:258-296): offsets from an ordinary
                     # 3x3 conv (f32), then the deformable conv with bn2 folded in (it is linear in the weight)
                     w_off, b_off = sd[p + ".conv2.conv_offset.weight"], sd[p + ".conv2.conv_offset.bias"]
@@ -374,8 +433,6 @@ class SipMaskEngine:
                                          planes, flags=SM_CONV_RELU))
                 if bi == 0:
                     self._join(1)
-                wc, bc = fold_bn(sd[p + ".conv3.weight"], sd, p + ".bn3")
-                out = self._buf(B * oh * ow, planes * 4)
                 self._add_conv(_Conv(self, p + ".conv3", wc, bc, B, [(oh, ow)], [0], t2, planes, 1, 0, out, [0],
                                      planes * 4, flags=SM_CONV_RELU | SM_CONV_RES_ADD, residual=idt,
                                      res_cstride=planes * 4))
@@ -408,9 +465,19 @@ class SipMaskEngine:
                 out_conv(2, 1)
                 self._add_conv(_Conv(self, "fpn.p6", sd["neck.fpn_convs.3.conv.weight"], sd["neck.fpn_convs.3.conv.bias"],
                                      B, [sizes[2]], [lv.row0[2]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[3]], 256), 1)
-                self._add_conv(_Conv(self, "fpn.p7", sd["neck.fpn_convs.4.conv.weight"], sd["neck.fpn_convs.4.conv.bias"],
-                                     B, [p6], [lv.row0[3]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[4]], 256,
-                                     flags=SM_CONV_IN_RELU), 1)
+                if self.precision == "f32" or not _RELU_COPY_P7:
+                    self._add_conv(_Conv(self, "fpn.p7", sd["neck.fpn_convs.4.conv.weight"], sd["neck.fpn_convs.4.conv.bias"],
+                                         B, [p6], [lv.row0[3]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[4]], 256,
+                                         flags=SM_CONV_IN_RELU), 1)
+                else:
+                    # relu(P6) as its own 100-KB tensor: the P7 launch is a handful of tiles with 36 K steps, and the
+                    # input-ReLU flag would put it on the register-staged loader (one exposed load latency per K step)
+                    n6 = B * p6[0] * p6[1]
+                    self.p6_relu = self._buf(n6, 256)
+                    p6_rows = self.pyr[lv.row0[3]:lv.row0[3] + n6]
+                    self._add("relu:p6", lambda: H.relu_bf16(p6_rows, self.p6_relu), 1)
+                    self._add_conv(_Conv(self, "fpn.p7", sd["neck.fpn_convs.4.conv.weight"], sd["neck.fpn_convs.4.conv.bias"],
+                                         B, [p6], [0], self.p6_relu, 256, 2, 1, self.pyr, [lv.row0[4]], 256), 1)
             else:
                 self._add_conv(_Conv(self, "fpn.lat%d" % i, wl, bl, B, [(fh, fw)], [0], f, fc, 1, 0, lats[i], [0], 256,
                                      flags=SM_CONV_RES_NEAREST, residual=lats[i + 1], res_cstride=256,
@@ -780,7 +847,7 @@ class SipMaskEngine:
         return cls, bb, ctr, cof, fm
 
     def total_conv_flops(self):
-        return sum(c.flops for c in self.convs)
+        return sum(c.flops for c in self.convs) + sum(c.flops for c in self.fused)
 
 
 class SubBatchPlan:
@@ -832,6 +899,35 @@ class SubBatchPlan:
                 e.run(img[b0:b0 + e.batch])
             b0 += e.batch
         self.engines[0].run(img[:self.engines[0].batch])
+        for st in self.streams:
+            main.wait_stream(st)
+        return self.results()
+
+    def capture(self, img, multi_stream=True):
+        """ONE hipGraph PER SUB-PLAN instead of one around run(): a sub-plan captured on its own may keep its internal
+        side lanes (no fork of a fork inside one capture), and replay() launches the graphs on concurrent streams.
+        `img` must stay where it is (the graphs read its slices)."""
+        assert img.shape[0] == self.batch
+        self.graphs, b0 = [], 0
+        for e in self.engines:
+            e.multi_stream = bool(multi_stream)
+            sub = img[b0:b0 + e.batch]
+            e.run(sub)                                   # eager once with this lane setting (side streams get created)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                e.run(sub)
+            self.graphs.append(g)
+            b0 += e.batch
+        return self
+
+    def replay(self):
+        main = torch.cuda.current_stream()
+        for g, st in zip(self.graphs[1:], self.streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                g.replay()
+        self.graphs[0].replay()
         for st in self.streams:
             main.wait_stream(st)
         return self.results()

@@ -172,6 +172,35 @@ def offset_linear(reg, reg_cstride, w_off, lv, out, level_scale=None):
     return out
 
 
+def bottleneck_tail(batch, h, w, channels, x, w2, b2, w3, b3, identity, y, w1_next=None, b1_next=None, t1_next=None):
+    """conv2 + conv3 (+ the next block's conv1) of a ResNet bottleneck as one launch (resnet.py:167-200); weights in
+    the prep_conv_weight layout ([cout][K], K = (kh, kw, cin)), bf16 rows, f32 biases"""
+    lib = _lib.load()
+    _lib.require_cuda(x, w2, b2, w3, b3, identity, y)
+    C4 = 4 * channels
+    assert tuple(w2.shape) == (channels, 9 * channels) and tuple(w3.shape) == (C4, channels), (w2.shape, w3.shape)
+    assert x.shape[1] == channels and identity.shape[1] == C4 and y.shape[1] == C4
+    assert min(x.shape[0], identity.shape[0], y.shape[0]) >= batch * h * w
+    if w1_next is not None:
+        assert tuple(w1_next.shape) == (channels, C4) and t1_next.shape[1] == channels and t1_next.shape[0] >= batch * h * w
+    _lib.check(lib.sm_bottleneck_tail(batch, h, w, channels, _lib.ptr(x), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(w3),
+                                      _lib.ptr(b3), _lib.ptr(identity), _lib.ptr(y),
+                                      None if w1_next is None else _lib.ptr(w1_next),
+                                      None if w1_next is None else _lib.ptr(b1_next),
+                                      None if w1_next is None else _lib.ptr(t1_next), _lib.stream_ptr()),
+               "sm_bottleneck_tail")
+    return y
+
+
+def relu_bf16(x, y):
+    """y = relu(x), bf16, same shape (fpn.py:166-170: the ReLU in front of the P7 conv)"""
+    lib = _lib.load()
+    _lib.require_cuda(x, y)
+    assert x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and x.numel() == y.numel()
+    _lib.check(lib.sm_relu_bf16(_lib.ptr(x), _lib.ptr(y), x.numel(), _lib.stream_ptr()), "sm_relu_bf16")
+    return y
+
+
 def deform_conv2d_bwd(desc, x, offset, w_t, gout, grad_x, grad_offset, grad_w_t):
     """grad_x f32 [rows][cin], grad_offset f32 like offset, grad_w_t f32 [K][cout]; None = skip."""
     lib = _lib.load()

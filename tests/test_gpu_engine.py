@@ -189,3 +189,44 @@ def test_sub_batch_plan_matches_single_plan():
     r3 = two.run(torch.flip(img, dims=[0]))
     torch.cuda.synchronize()
     assert r3["ndet"].data_ptr() == r2["ndet"].data_ptr()
+    # one hipGraph per sub-plan (each with its internal side lanes), replayed on concurrent streams: same results as
+    # the eager chains on the same (static) images
+    static = img.clone()
+    ref = {k: v.clone() for k, v in two.run(static).items()}
+    torch.cuda.synchronize()
+    two.capture(static, multi_stream=True)
+    for k in two.out:
+        two.out[k].zero_()
+    r4 = two.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(r4["ndet"], ref["ndet"]) and int(r4["ndet"].sum()) > 0
+    for b in range(4):
+        n = int(ref["ndet"][b])
+        assert Counter(r4["det_labels"][b, :n].cpu().tolist()) == Counter(ref["det_labels"][b, :n].cpu().tolist())
+    for e in two.engines:
+        e.multi_stream = False
+
+
+def test_fused_bottleneck_plan_is_bit_identical(monkeypatch):
+    """The launch plan with fused bottleneck tails in layer1 / layer2 (conv2+conv3, and conv2+conv3+next conv1) gives the
+    same bits as the plan of separate conv launches: C2..C5 features and the detections."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import sipmask_amd.engine as E
+    sd = OM.init_state_dict(50, 0)
+    sd["bbox_head.fcos_cls.bias"].fill_(-2.5)
+    img = torch.randn(2, 3, 160, 224, generator=torch.Generator().manual_seed(9)).cuda()
+    outs = {}
+    for mode in (0, 1, 2):
+        monkeypatch.setattr(E, "_FUSE_BOTTLENECK", mode)
+        eng = E.SipMaskEngine(sd, 2, (160, 224), 50)
+        assert len(eng.fused) == (0 if mode == 0 else 7)
+        assert sum(t.w1n is not None for t in eng.fused) == (5 if mode == 2 else 0)
+        r = eng.run(img)
+        torch.cuda.synchronize()
+        outs[mode] = ([f[0].clone() for f in eng.backbone_feats], r["ndet"].clone(), r["det_bboxes"].clone())
+    for mode in (1, 2):
+        for a, b in zip(outs[0][0], outs[mode][0]):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), mode
+        assert torch.equal(outs[0][1], outs[mode][1]) and torch.equal(outs[0][2], outs[mode][2])
+    assert int(outs[0][1].sum()) > 0

@@ -836,3 +836,82 @@ def test_sigmoid_focal_loss_vs_oracle():
     loss.backward(dl.to(dev))
     refg = O.sigmoid_focal_loss_backward(x.double(), t, dl.double(), 2.0, 0.25)
     torch.testing.assert_close(xr.grad.cpu().double(), refg, rtol=2e-5, atol=1e-7)
+
+
+def test_relu_bf16_and_p7_on_the_dma_path():
+    """sm_relu_bf16 is exact relu on bf16 (sign bit always cleared: -0 -> +0), and the P7 conv fed with relu(P6) (LDS-DMA operand
+    path, split-K) equals the same conv with the input-ReLU flag (register-staged loader): fpn.py:166-170."""
+    from sipmask_amd import hip_ops as H
+    from sipmask_amd._lib import SM_CONV_IN_RELU
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2 * 13 * 21, 256, generator=g).to(torch.bfloat16)
+    x[0, :8] = torch.tensor([-0.0, 0.0, -1.0, 1.0, -3e-38, 3e-38, -65280.0, 65280.0], dtype=torch.bfloat16)
+    xd = x.to(dev)
+    y = H.relu_bf16(xd, torch.empty_like(xd))
+    yc = y.cpu()
+    assert torch.equal(yc.float(), torch.relu(x.float())) and not bool((yc.view(torch.int16) < 0).any())   # -0 -> +0
+    w = (torch.randn(256, 256, 3, 3, generator=g) / 48).to(torch.bfloat16).float()
+    wp, cop = H.prep_conv_weight(w.to(dev), 256)
+    outs = []
+    for flags, src in ((SM_CONV_IN_RELU, xd), (0, y)):
+        d = H.make_conv_desc(2, [(13, 21)], [(7, 11)], [0], [0], 256, 256, cop, 3, 2, 1, 256, 256, 0, flags)
+        o = torch.zeros(2 * 7 * 11, 256, dtype=torch.bfloat16, device=dev)
+        pl = H.conv_plan(d)
+        if pl["split_k"] > 1:
+            H.conv2d_ws(d, src, wp, None, None, o, torch.empty(pl["workspace_bytes"], dtype=torch.uint8, device=dev))
+        else:
+            H.conv2d(d, src, wp, None, None, o)
+        outs.append(o.float().cpu())
+    ref = torch.nn.functional.conv2d(torch.relu(x.float()).view(2, 13, 21, 256).permute(0, 3, 1, 2), w, None, 2, 1)
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, 256)
+    for o in outs:
+        torch.testing.assert_close(o, ref, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=2 ** -6)
+
+
+@pytest.mark.parametrize("C,chain", [(64, False), (64, True), (128, False), (128, True)])
+def test_bottleneck_tail_bit_identical_to_separate_convs(C, chain):
+    """sm_bottleneck_tail (conv2 3x3 + conv3 1x1 + identity [+ the next block's conv1] in one launch; resnet.py:167-200)
+    against the same three convs as separate sm_conv2d launches: same K order and rounding points -> identical bf16
+    bits; against torch fp32 on the bf16-rounded intermediates -> accumulation-order tolerance.  M = 2*13*19 = 494 rows
+    (not a multiple of the 128-position tile), borders everywhere."""
+    from sipmask_amd import hip_ops as H
+    from sipmask_amd._lib import SM_CONV_RELU, SM_CONV_RES_ADD
+    dev = _dev()
+    B, h, w = 2, 13, 19
+    M = B * h * w
+    g = torch.Generator().manual_seed(C + chain)
+    bf = lambda t: t.to(torch.bfloat16)
+    x = bf(torch.randn(M, C, generator=g)).to(dev)
+    idt = bf(torch.randn(M, 4 * C, generator=g)).to(dev)
+    w2 = bf(torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)).float()
+    w3 = bf(torch.randn(4 * C, C, 1, 1, generator=g) / C ** 0.5).float()
+    w1 = bf(torch.randn(C, 4 * C, 1, 1, generator=g) / (2 * C ** 0.5)).float()
+    b2, b3, b1 = (torch.randn(n, generator=g).to(dev) * 0.1 for n in (C, 4 * C, C))
+    # separate launches
+    def conv(src, wt, bias, cin, cout, k, flags, res=None):
+        wp, cop = H.prep_conv_weight(wt.to(dev), cin)
+        d = H.make_conv_desc(B, [(h, w)], [(h, w)], [0], [0], cin, cout, cop, k, 1, k // 2, cin, cout, 0, flags, 1,
+                             cout if res is not None else 0)
+        o = torch.zeros(M, cout, dtype=torch.bfloat16, device=dev)
+        H.conv2d(d, src, wp, bias, res, o)
+        return o
+    t2 = conv(x, w2, b2, C, C, 3, SM_CONV_RELU)
+    y_ref = conv(t2, w3, b3, C, 4 * C, 1, SM_CONV_RELU | SM_CONV_RES_ADD, idt)
+    t1_ref = conv(y_ref, w1, b1, 4 * C, C, 1, SM_CONV_RELU)
+    # fused
+    prep = lambda wt: H.prep_conv_weight(wt.to(dev), wt.shape[1])[0][:wt.shape[0]].contiguous()
+    y = torch.zeros(M + 7, 4 * C, dtype=torch.bfloat16, device=dev)
+    t1n = torch.zeros(M + 7, C, dtype=torch.bfloat16, device=dev)
+    H.bottleneck_tail(B, h, w, C, x, prep(w2), b2, prep(w3), b3, idt, y, *( (prep(w1), b1, t1n) if chain else ()))
+    torch.cuda.synchronize()
+    assert torch.equal(y[:M].view(torch.int16), y_ref.view(torch.int16))
+    assert not bool(y[M:].any()) and not bool(t1n[M:].any())            # nothing written past M
+    if chain:
+        assert torch.equal(t1n[:M].view(torch.int16), t1_ref.view(torch.int16))
+    # torch fp32 on the same rounding points
+    xi = x.float().cpu().view(B, h, w, C).permute(0, 3, 1, 2)
+    r2 = bf(torch.relu(torch.nn.functional.conv2d(xi, w2, b2.cpu(), 1, 1))).float()
+    r3 = torch.relu(torch.nn.functional.conv2d(r2, w3, b3.cpu()) + idt.float().cpu().view(B, h, w, 4 * C).permute(0, 3, 1, 2))
+    torch.testing.assert_close(y[:M].float().cpu(), r3.permute(0, 2, 3, 1).reshape(M, 4 * C), rtol=1e-2, atol=2e-2)

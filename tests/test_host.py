@@ -233,7 +233,11 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     ngrouped = sum(1 for n in rows if n.startswith("head.tower"))
     grouped = ngrouped > 0
     assert grouped == (os.environ.get("SIPMASK_GROUPED_TOWERS", "1") == "1" and eng.flag_norm)   # GN heads only
-    assert len(rows) == len(eng.convs) and len(rows) == nconv - ngrouped
+    # fused bottleneck tails (layer1 / layer2, plain conv2): conv2 + conv3 (+ the next block's conv1) per launch
+    nfused = sum(2 + (t.w1n is not None) for t in eng.fused)
+    if variant in ("r50", "vis", "benchmark", "ssd") and os.environ.get("SIPMASK_FUSE_BOTTLENECK", "2") == "2":
+        assert len(eng.fused) == 7 and nfused == 7 * 2 + 5
+    assert len(rows) == len(eng.convs) and len(rows) == nconv - ngrouped - nfused
     assert all(r["plan"]["blocks"] > 0 and 0 < r["fill"] <= 1 for r in rows.values())
     assert len(eng.steps) == len(eng.lanes)
     joined = set()
@@ -266,7 +270,8 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
             assert c.bias.numel() >= d.cout, c.name
     fa = rows["head.feat_align"]["plan"]
     assert fa["lds_dma"] == 0 and fa["k_step"] == 64                # deformable gather: register-staged loader
-    assert rows["fpn.p7"]["plan"]["lds_dma"] == 0                   # input ReLU (fpn.py:174-175)
+    # P7 = conv(relu(P6)) (fpn.py:166-170): the plan feeds it a ReLU'd copy so it keeps the LDS-DMA path
+    assert rows["fpn.p7"]["plan"]["lds_dma"] == 1 and any(lbl == "relu:p6" for lbl, _ in eng.steps)
     tower = rows["head.tower0" if grouped and "head.tower0" in rows else "head.reg_convs.0"]["plan"]
     assert (tower["k_step"], tower["k_loop"]) == (64, 3)
     if variant == "dcn":
