@@ -26,8 +26,10 @@ _GROUPED_TOWERS = __import__("os").environ.get("SIPMASK_GROUPED_TOWERS", "1") ==
 
 _SPLIT_K = __import__("os").environ.get("SIPMASK_SPLIT_K", "1") != "0"     # A/B: split-K for under-filled launches
 _PATCH_CONV = __import__("os").environ.get("SIPMASK_PATCH_CONV", "1") != "0"   # A/B: patch-resident 3x3 kernel
-# bottleneck fusion in layer1 / layer2: 0 = separate launches, 1 = conv2+conv3, 2 = conv2+conv3+next conv1
-_FUSE_BOTTLENECK = int(__import__("os").environ.get("SIPMASK_FUSE_BOTTLENECK", "2"))
+# bottleneck fusion in layer1 / layer2: 0 = separate launches, 1 = conv2+conv3, 2 = conv2+conv3+next conv1.  Measured
+# (profiles/r02f_ab_bottleneck_fusion.json, same box): 963 / 998 / 984 img/s -- the chained conv1 needs 72-80 KB of LDS
+# (2 blocks per CU instead of 3-4) and loses under two concurrent sub-plans what it saves per launch
+_FUSE_BOTTLENECK = int(__import__("os").environ.get("SIPMASK_FUSE_BOTTLENECK", "1"))
 _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"   # A/B: relu(P6) copy vs input-ReLU flag
 
 

@@ -151,14 +151,18 @@ def test_sipmask_pp_dcn_backbone_and_rescoring():
     assert float(r["mask_scores"][0, n:].abs().max()) == 0.0 if n < eng.max_num else True
 
 
-def test_sub_batch_plan_matches_single_plan():
+def test_sub_batch_plan_matches_single_plan(monkeypatch):
     """SipMask.prepare(lanes=2) (engine.SubBatchPlan: two concurrent half-batch launch chains writing slices of one
     set of outputs) against the single plan of the same batch: same kernels on the same images, so head outputs agree
     to accumulation order (GroupNorm statistics are atomic sums) and the detections are the same sets."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    import sipmask_amd.engine as E
     from sipmask_amd.engine import SubBatchPlan
     from sipmask_amd.synthetic import build_synthetic_detector
+    # sub-plans run without split-K (engine.py: sub_plan); the single plan of this comparison must sum in the same
+    # order, or bf16 rounding flips in layer3/4 grow to ~1 % by the head outputs
+    monkeypatch.setattr(E, "_SPLIT_K", False)
     det = build_synthetic_detector(50, seed=0)
     with torch.no_grad():
         det.bbox_head.fcos_cls.bias.fill_(-2.0)

@@ -235,8 +235,8 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     assert grouped == (os.environ.get("SIPMASK_GROUPED_TOWERS", "1") == "1" and eng.flag_norm)   # GN heads only
     # fused bottleneck tails (layer1 / layer2, plain conv2): conv2 + conv3 (+ the next block's conv1) per launch
     nfused = sum(2 + (t.w1n is not None) for t in eng.fused)
-    if variant in ("r50", "vis", "benchmark", "ssd") and os.environ.get("SIPMASK_FUSE_BOTTLENECK", "2") == "2":
-        assert len(eng.fused) == 7 and nfused == 7 * 2 + 5
+    if variant in ("r50", "vis", "benchmark", "ssd") and os.environ.get("SIPMASK_FUSE_BOTTLENECK", "1") == "1":
+        assert len(eng.fused) == 7 and nfused == 7 * 2
     assert len(rows) == len(eng.convs) and len(rows) == nconv - ngrouped - nfused
     assert all(r["plan"]["blocks"] > 0 and 0 < r["fill"] <= 1 for r in rows.values())
     assert len(eng.steps) == len(eng.lanes)
