@@ -60,6 +60,10 @@ typedef enum {
 #define SM_CONV_DBG_HAND_PLACED 0x00040000u  /* A/B switch (with TILE256): hand-placed K step, LDS-DMA pieces between the MFMAs */
 #define SM_CONV_DBG_RES_PREFETCH 0x00020000u /* A/B switch: 32-wide-K kernel loads the residual rows BEFORE the K loop (HBM-bound 1x1 + residual convs) */
 #define SM_CONV_DBG_DEFORM_128 0x00008000u  /* A/B switch: deformable conv on the 128-cout x 128-position 4-wave tile (default: 256 x 128 on 8 waves) */
+#define SM_CONV_DBG_PATCH_UNIFORM 0x00004000u  /* A/B switch (sm_conv3x3_patch): every tile 256 positions (the round-2 launch shape) */
+#define SM_CONV_DBG_PATCH_SMALL128 0x00002000u /* A/B switch (sm_conv3x3_patch): only 128-position tiles finish a launch */
+#define SM_CONV_DBG_PATCH_SMALL192 0x00001000u /* A/B switch (sm_conv3x3_patch): only 192-position tiles finish a launch */
+#define SM_CONV_DBG_PATCH_PIPE 0x00000800u     /* A/B switch (sm_conv3x3_patch): fragment reads of sub-step i+1 pinned under the MFMAs of sub-step i */
 #define SM_CONV_DBG_NO_SPLITK 0x00010000u   /* A/B switch: sm_conv2d_ws never splits K */
 #define SM_CONV_DBG_WARP_SPEC 0x02000000u    /* A/B switch: 8-wave producer/consumer variant of the 64-wide-K kernel */
 
@@ -154,9 +158,14 @@ int sm_bottleneck_tail(int batch, int h, int w, int channels, const void* x, con
  * multi-level, group dimension; no residual), but the weights come in the kernel's own K order:
  *   w_patch bf16 [cout_pad][cin/32][9][32]  (32-channel chunk, tap kh*3+kw, channel), cout_pad a multiple of 256.
  * sm_conv3x3_patch_supported: 1 if the descriptor is eligible (3x3 s1 p1, cin % 64 == 0, cout_pad % 256 == 0, 8-aligned
- * output, level widths <= 253); sm_conv3x3_patch_tiles: its grid size (256-position x 256-cout tiles). */
+ * output, level widths <= 253); sm_conv3x3_patch_tiles: its grid size.
+ * Launch shape: one block per CU, so a launch of equal tiles pays for a whole last round however empty it is.  Every
+ * (level, image) segment is therefore cut into 256-position tiles followed by 128- or 192-position tiles, chosen by a
+ * list-scheduling estimate over the 256 CUs (sm_conv3x3_patch_plan: out = {big tiles, small tiles, small tile
+ * positions, estimated makespan in 1/1000 of a 256-position tile time}); pure host logic, no GPU needed. */
 int sm_conv3x3_patch_supported(const sm_conv_desc* d);
 int64_t sm_conv3x3_patch_tiles(const sm_conv_desc* d);
+int sm_conv3x3_patch_plan(const sm_conv_desc* d, int64_t* out4);
 int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void* w_patch, const float* bias, void* y,
                      float* gn_stats, sm_stream_t stream);
 

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "sm_conv2d_ws": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "sm_conv3x3_patch_supported": (_I, [C.POINTER(ConvDesc)]),
     "sm_conv3x3_patch_tiles": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "sm_conv3x3_patch_plan": (_I, [C.POINTER(ConvDesc), _P]),
     "sm_conv3x3_patch": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "sm_deform_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "sm_conv2d_gn_stats": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),

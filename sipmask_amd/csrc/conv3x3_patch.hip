@@ -33,8 +33,13 @@ struct PatchArgs {
   int nlev, batch;
   int h[SM_MAX_LEVELS], w_[SM_MAX_LEVELS];
   long long in_row0[SM_MAX_LEVELS], out_row0[SM_MAX_LEVELS];
-  int tile0[SM_MAX_LEVELS + 1];   // first position tile of each level (inside one group)
-  int tpi[SM_MAX_LEVELS];         // position tiles per image of the level
+  // Two PARTS per launch: part 0 = 256-position tiles, part 1 = the remainder of every (level, image) segment in
+  // smaller tiles (128 or 192 positions), dispatched after the big ones -- see plan_parts().
+  int tile0[2][SM_MAX_LEVELS + 1];   // first position tile of each level (inside one group)
+  int tpi[2][SM_MAX_LEVELS];         // position tiles per image of the level
+  int qbase[2][SM_MAX_LEVELS];       // first padded-flat position the part covers in a segment
+  int nblk[2];                       // blocks of each part (all groups, all cout tiles)
+  int small_pos;                     // 128 or 192
   int cin, cout, nc, ntn;         // nc = cin / 32, ntn = cout_pad / 256
   int in_cstride, out_cstride, out_coff;
   long long Kp;                   // weight row pitch (elements) = 9 * cin
@@ -42,7 +47,7 @@ struct PatchArgs {
   int scale_nch;
   float level_scale[SM_MAX_LEVELS];
   int prow_cap;                   // rows of one patch buffer (multiple of 16)
-  int ngroups, tpg;
+  int ngroups, tpg[2];
   long long x_grows, y_grows, w_gstride, b_gstride, gn_gstride;
 };
 
@@ -61,32 +66,33 @@ constexpr int PT_BCO = 256, PT_BPOS = 256, PT_THREADS = 512;
 constexpr int PT_WSTAGE = 2 * PT_BCO * 64;        // one weight stage: 2 taps x 256 couts x 64 B
 constexpr int PT_MAXPP = 6;                       // patch DMA pieces per wave (<= 768 patch rows)
 
-__global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_kernel(const PatchArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [W stage 0][W stage 1][patch 0][patch 1]
+// One tile: 256 couts x (WPOS * TPOS * 32) positions on 8 waves laid out WCO (cout) x WPOS (position), each wave
+// TCO x TPOS MFMA tiles of 32 x 32.  <2,4,4,2> is the 256-position tile; <4,2,2,3> / <4,2,2,2> are the 192- / 128-
+// position tiles that finish a launch whose last round of 256-tiles would leave most CUs idle.
+template <int WCO, int WPOS, int TCO, int TPOS, bool PIPE>
+__device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, const int tlin, unsigned char* const smem) {
+  static_assert(WCO * WPOS == 8 && WCO * TCO * 32 == PT_BCO, "8 waves, 256 couts");
+  constexpr int BPOS = WPOS * TPOS * 32;
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
-  constexpr int TCO = 4, TPOS = 2;                // wave tile: 4 x 2 MFMA tiles of 32 x 32
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wco = wave >> 2, wpos = wave & 3;
+  const int wco = wave / WPOS, wpos = wave % WPOS;
   const int l31 = lane & 31, khalf = lane >> 5;
 
-  // ---- tile decode (wave-uniform); XCD-contiguous tile ranges as in conv_igemm.hip
-  const int nblk = gridDim.x;
-  const int xcd = blockIdx.x & 7, xq = nblk >> 3, xr = nblk & 7;
-  const int tlin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)(blockIdx.x >> 3);
-  const int grp = a.ngroups > 1 ? tlin / a.tpg : 0;
-  const int tl_g = tlin - grp * a.tpg;
+  // ---- tile decode (wave-uniform)
+  const int grp = a.ngroups > 1 ? tlin / a.tpg[part] : 0;
+  const int tl_g = tlin - grp * a.tpg[part];
   const int nt = tl_g % a.ntn;
   const int mt = tl_g / a.ntn;
   int lev = 0;
 #pragma unroll
   for (int l = 1; l < SM_MAX_LEVELS; ++l)
-    if (l < a.nlev && mt >= a.tile0[l]) lev = l;
+    if (l < a.nlev && mt >= a.tile0[part][l]) lev = l;
   const int H = a.h[lev], W = a.w_[lev], Wp = W + 2;
-  const int ti = mt - a.tile0[lev];
-  const int n = ti / a.tpi[lev];
-  const int q0 = (ti - n * a.tpi[lev]) * PT_BPOS;
+  const int ti = mt - a.tile0[part][lev];
+  const int n = ti / a.tpi[part][lev];
+  const int q0 = a.qbase[part][lev] + (ti - n * a.tpi[part][lev]) * BPOS;
   const long long img_row0 = a.in_row0[lev] + grp * a.x_grows + (long long)n * H * W;
 
   const int PB = a.prow_cap * 64;                 // bytes of one patch buffer
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_kernel(const Patc
   // ---- loader state.  A DMA piece is 16 rows x 64 B: lane L -> row (L >> 2), physical slot (L & 3), so it fetches
   // the logical 16-byte chunk (L & 3) ^ ((row >> 2) & 3) of that row (swizzle on the source side, guide rule 21).
   const int lrow = lane >> 2;
-  const int npieces = (PT_BPOS + 2 * Wp + 2 + 15) >> 4;
+  const int npieces = (BPOS + 2 * Wp + 2 + 15) >> 4;
   const unsigned long long zero_page = (unsigned long long)g_zero16p;
   // patch: this wave owns pieces wave, wave + 8, ...; per piece the lane's source offset (elements) or -1 (zero page)
   int poff[PT_MAXPP];
@@ -149,8 +155,8 @@ __global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_kernel(const Patc
       for (int e = 0; e < 16; ++e) acc[tc][tp][e] = 0.f;
 
   const int rsw = (l31 >> 2) & 3;
-  const int wrow_off = (wco * 128 + l31) * 64;
-  const int prow0 = wpos * 64 + l31;              // patch row of this lane's position at tap (0,0), tp = 0
+  const int wrow_off = (wco * (TCO * 32) + l31) * 64;
+  const int prow0 = wpos * (TPOS * 32) + l31;              // patch row of this lane's position at tap (0,0), tp = 0
 
   // one tap: 2 K sub-steps of 16, 8 MFMAs each; both sub-steps' fragments are requested up front and hipcc schedules the
   // stage (2 taps = 24 reads + 32 MFMAs, one basic block).  A/B (round 2): the same stage with the reads of sub-step
@@ -207,12 +213,60 @@ __global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_kernel(const Patc
         }
       }
       const unsigned char* Wst = Wb0 + (st & 1) * PT_WSTAGE;
+      if constexpr (PIPE) {
+        // software-pipelined stage: 4 sub-steps (tap hh, K half kk) of TCO*TPOS MFMAs; the fragments of sub-step i+1 are
+        // read into the other register set behind the MFMAs of sub-step i ("1 MFMA, 1 ds_read" ladder), so only the
+        // first sub-step after the barrier waits for the LDS.  hipcc's own schedule (the else branch) re-uses one set per
+        // tap: read -> lgkmcnt(0) -> 2-4 MFMAs, eight exposed LDS round trips per stage.
+        constexpr int NFR = TCO + TPOS, NMF = TCO * TPOS, NPAIR = NFR < NMF ? NFR : NMF;
+        bf16x8 wf[2][TCO], xf[2][TPOS];
+        auto rd = [&](auto IC, int set) {
+          constexpr int i = decltype(IC)::value;
+          constexpr int hh = i >> 1, kk = i & 1;
+          constexpr int s = 2 * sp + hh;
+          constexpr int cc = s / 9, t9 = s % 9, kh = t9 / 3, kw = t9 % 3;
+          const unsigned char* Wh = Wst + hh * (PT_BCO * 64);
+          const unsigned char* P = Pb0 + cc * PB;
+          const int shift = kh * Wp + kw;
+#pragma unroll
+          for (int t = 0; t < TCO; ++t)
+            wf[set][t] = *reinterpret_cast<const bf16x8*>(Wh + wrow_off + t * 32 * 64 + (((kk * 2 + khalf) ^ rsw) * 16));
+#pragma unroll
+          for (int t = 0; t < TPOS; ++t) {
+            const int pr = prow0 + t * 32 + shift;
+            xf[set][t] = *reinterpret_cast<const bf16x8*>(P + pr * 64 + (((kk * 2 + khalf) ^ ((pr >> 2) & 3)) * 16));
+          }
+        };
+        rd(std::integral_constant<int, 0>{}, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);
+        sfor<4>([&](auto IC) {
+          constexpr int i = decltype(IC)::value;
+          if constexpr (i < 3) rd(std::integral_constant<int, i + 1>{}, (i + 1) & 1);
+#pragma unroll
+          for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+            for (int tp = 0; tp < TPOS; ++tp)
+              acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 1][tc], xf[i & 1][tp], acc[tc][tp], 0, 0, 0);
+          if constexpr (i < 3) {
+#pragma unroll
+            for (int j = 0; j < NPAIR; ++j) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if constexpr (NFR > NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, NFR - NPAIR, 0);
+            if constexpr (NMF > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NPAIR, 0);
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+          }
+        });
+      } else {
       sfor<2>([&](auto HH) {
         constexpr int hh = decltype(HH)::value;
         constexpr int s = 2 * sp + hh;                             // tap index inside the pair, 0..17
         constexpr int cc = s / 9, t = s % 9, kh = t / 3, kw = t % 3;
         tap(Wst + hh * (PT_BCO * 64), Pb0 + cc * PB, kh * Wp + kw);
       });
+      }
       __syncthreads();                                             // drains the DMA queue (vmcnt(0)) and fences the buffers
     });
   }
@@ -231,7 +285,7 @@ __global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_kernel(const Patc
   }
 #pragma unroll
   for (int tp = 0; tp < TPOS; ++tp) {
-    const int q = q0 + wpos * 64 + tp * 32 + l31;
+    const int q = q0 + wpos * (TPOS * 32) + tp * 32 + l31;
     const int oh = q / Wp;
     const int owp = q - oh * Wp;
     const bool pvalid = oh < H && owp >= 1 && owp <= W;
@@ -249,7 +303,7 @@ __global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_kernel(const Patc
           v[e] = __uint_as_float(r[0]);
           v[4 + e] = __uint_as_float(r[1]);
         }
-        const int cl = wco * 128 + tc * 32 + 8 * (2 * qp + khalf);
+        const int cl = wco * (TCO * 32) + tc * 32 + 8 * (2 * qp + khalf);
         const int c0 = nt * PT_BCO + cl;
         const bool live = pvalid && c0 < a.cout;
         if (live) {
@@ -315,6 +369,29 @@ __global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_kernel(const Patc
   }
 }
 
+
+// XCD-contiguous tile ranges (blockIdx round-robins over the 8 XCDs), as in conv_igemm.hip
+__device__ __forceinline__ int xcd_tile(int b, int nblk) {
+  const int xcd = b & 7, xq = nblk >> 3, xr = nblk & 7;
+  return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
+}
+
+// blocks [0, nblk[0]) are 256-position tiles, blocks [nblk[0], nblk[0] + nblk[1]) the SMALL-position tiles: the
+// dispatcher hands out blocks in index order, so a CU that retires a big tile picks up a small one.
+template <int SMALL, bool PIPE>
+__global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_kernel(const PatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [W stage 0][W stage 1][patch 0][patch 1]
+  const int b = blockIdx.x;
+  if (b < a.nblk[0]) {
+    patch_tile<2, 4, 4, 2, PIPE>(a, 0, xcd_tile(b, a.nblk[0]), smem);
+  } else {
+    if constexpr (SMALL == 128)
+      patch_tile<4, 2, 2, 2, PIPE>(a, 1, xcd_tile(b - a.nblk[0], a.nblk[1]), smem);
+    else
+      patch_tile<4, 2, 2, 3, PIPE>(a, 1, xcd_tile(b - a.nblk[0], a.nblk[1]), smem);
+  }
+}
+
 int patch_check(const sm_conv_desc* d) {
   if (!d) return SM_ERR_BAD_ARG;
   if (d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return SM_ERR_BAD_SHAPE;
@@ -332,16 +409,111 @@ int patch_check(const sm_conv_desc* d) {
   return SM_OK;
 }
 
+
+// ---- launch shape.  Every (level, image[, group, cout tile]) segment of L = H * (W + 2) padded-flat positions gets
+// k256[l] tiles of 256 positions followed by tiles of `small` positions for the rest.  One block per CU: a launch of T
+// equal tiles takes ceil(T / CUS) tile times however empty the last round is (the B=2 tower launch: 368 tiles = two
+// rounds for 1.44 rounds of work).  The planner tries "r full rounds of big tiles, remainder small" for every r and both
+// small sizes and keeps the cheapest by a list-scheduling estimate (cost of a tile = positions + a fixed 24-position
+// equivalent for prologue / epilogue).
+constexpr int PT_CUS = 256;
+
+struct PatchShape {
+  int k256[SM_MAX_LEVELS];
+  int small;        // 128 / 192
+  long long nbig, nsmall;
+};
+
+long long seg_len(const sm_conv_desc* d, int l) { return (long long)d->in_h[l] * (d->in_w[l] + 2); }
+
+double shape_cost(long long nbig, long long nsmall, int small) {
+  // list schedule on PT_CUS CUs: big tiles round-robin first, then every small tile to the earliest-free CU
+  const double cb = 256 + 24, cs = small + 24;
+  const long long rb = nbig / PT_CUS, eb = nbig % PT_CUS;      // eb CUs carry one more big tile
+  double t_a = rb * cb, t_b = (rb + 1) * cb;                   // class a: PT_CUS - eb CUs, class b: eb CUs
+  const long long n_a = PT_CUS - eb, n_b = eb;
+  double end = nbig ? (eb ? t_b : t_a) : 0.0;
+  long long left = nsmall;
+  while (left > 0) {
+    const bool use_a = n_b == 0 || t_a <= t_b;
+    double& t = use_a ? t_a : t_b;
+    const long long n = use_a ? n_a : n_b;
+    left -= left < n ? left : n;
+    t += cs;
+    end = end > t ? end : t;
+  }
+  return end;
+}
+
+void plan_shape(const sm_conv_desc* d, PatchShape* ps) {
+  const int ntn = d->cout_pad / PT_BCO, ng = d->ngroups > 1 ? d->ngroups : 1;
+  const long long segs = (long long)d->batch * ntn * ng;       // segments per level
+  long long full[SM_MAX_LEVELS];                               // whole 256-tiles a segment of the level can hold
+  long long all_big = 0;
+  for (int l = 0; l < d->nlev; ++l) {
+    full[l] = seg_len(d, l) / PT_BPOS;
+    all_big += segs * sm_cdiv(seg_len(d, l), PT_BPOS);
+  }
+  // baseline: the uniform launch (every tile 256 positions)
+  double best = shape_cost(all_big, 0, 128);
+  for (int l = 0; l < SM_MAX_LEVELS; ++l) ps->k256[l] = l < d->nlev ? (int)sm_cdiv(seg_len(d, l), PT_BPOS) : 0;
+  ps->small = 128;
+  ps->nbig = all_big;
+  ps->nsmall = 0;
+  if (d->flags & SM_CONV_DBG_PATCH_UNIFORM) return;
+  const int smalls[2] = {128, 192};
+  const long long max_rounds = all_big / PT_CUS + 1;
+  for (int si = 0; si < 2; ++si) {
+    const int small = smalls[si];
+    if ((d->flags & SM_CONV_DBG_PATCH_SMALL128) && small != 128) continue;
+    if ((d->flags & SM_CONV_DBG_PATCH_SMALL192) && small != 192) continue;
+    for (long long r = 0; r <= max_rounds; ++r) {
+      // spend a budget of r * PT_CUS big tiles on the levels in order (largest first = level 0 first)
+      long long budget = r * PT_CUS, nbig = 0, nsmall = 0;
+      int k[SM_MAX_LEVELS] = {};
+      for (int l = 0; l < d->nlev; ++l) {
+        long long kl = budget / segs;
+        if (kl > full[l]) kl = full[l];
+        k[l] = (int)kl;
+        budget -= kl * segs;
+        nbig += kl * segs;
+        const long long rest = seg_len(d, l) - kl * PT_BPOS;
+        nsmall += segs * sm_cdiv(rest, small);
+      }
+      const double c = shape_cost(nbig, nsmall, small);
+      if (c < best * 0.97) {                                   // only leave the uniform launch for a real gain
+        best = c;
+        for (int l = 0; l < SM_MAX_LEVELS; ++l) ps->k256[l] = k[l];
+        ps->small = small;
+        ps->nbig = nbig;
+        ps->nsmall = nsmall;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int sm_conv3x3_patch_supported(const sm_conv_desc* d) { return patch_check(d) == SM_OK ? 1 : 0; }
 
 extern "C" int64_t sm_conv3x3_patch_tiles(const sm_conv_desc* d) {
   if (patch_check(d) != SM_OK) return 0;
-  long long t = 0;
-  for (int l = 0; l < d->nlev; ++l)
-    t += (long long)d->batch * sm_cdiv((long long)d->in_h[l] * (d->in_w[l] + 2), PT_BPOS);
-  return t * (d->cout_pad / PT_BCO) * (d->ngroups > 1 ? d->ngroups : 1);
+  PatchShape ps;
+  plan_shape(d, &ps);
+  return ps.nbig + ps.nsmall;
+}
+
+extern "C" int sm_conv3x3_patch_plan(const sm_conv_desc* d, int64_t* out) {
+  if (!out) return SM_ERR_BAD_ARG;
+  const int rc = patch_check(d);
+  if (rc != SM_OK) return rc;
+  PatchShape ps;
+  plan_shape(d, &ps);
+  out[0] = ps.nbig;
+  out[1] = ps.nsmall;
+  out[2] = ps.small;
+  out[3] = (int64_t)(shape_cost(ps.nbig, ps.nsmall, ps.small) * 1000.0 / (256 + 24));   // milli tile-times
+  return SM_OK;
 }
 
 extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void* w_patch, const float* bias, void* y,
@@ -350,6 +522,8 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   const int rc = patch_check(d);
   if (rc != SM_OK) return rc;
   if (gn_stats != nullptr && (d->flags & SM_CONV_OUT_F32)) return SM_ERR_UNSUPPORTED;
+  PatchShape ps;
+  plan_shape(d, &ps);
   PatchArgs a;
   a.x = (const uint16_t*)x;
   a.w = (const uint16_t*)w_patch;
@@ -358,7 +532,8 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   a.gn_stats = gn_stats;
   a.nlev = d->nlev;
   a.batch = d->batch;
-  int t = 0, maxw = 1;
+  a.small_pos = ps.small;
+  int t0 = 0, t1 = 0, maxw = 1;
   for (int l = 0; l < SM_MAX_LEVELS; ++l) {
     const bool on = l < d->nlev;
     a.h[l] = on ? d->in_h[l] : 1;
@@ -366,14 +541,24 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
     a.in_row0[l] = on ? d->in_row0[l] : 0;
     a.out_row0[l] = on ? d->out_row0[l] : 0;
     a.level_scale[l] = on ? d->level_scale[l] : 1.f;
-    a.tile0[l] = t;
-    a.tpi[l] = on ? sm_cdiv((long long)d->in_h[l] * (d->in_w[l] + 2), PT_BPOS) : 1;
+    const long long len = on ? seg_len(d, l) : 0;
+    const int k = on ? ps.k256[l] : 0;
+    const long long rest = len - (long long)k * PT_BPOS;
+    const int ks = on && rest > 0 ? sm_cdiv(rest, ps.small) : 0;
+    a.tile0[0][l] = t0;
+    a.tile0[1][l] = t1;
+    a.tpi[0][l] = k > 0 ? k : 1;              // divisor only; a level without tiles of a part is never decoded
+    a.tpi[1][l] = ks > 0 ? ks : 1;
+    a.qbase[0][l] = 0;
+    a.qbase[1][l] = k * PT_BPOS;
     if (on) {
-      t += d->batch * a.tpi[l];
+      t0 += d->batch * k;
+      t1 += d->batch * ks;
       if (d->in_w[l] > maxw) maxw = d->in_w[l];
     }
   }
-  a.tile0[SM_MAX_LEVELS] = t;
+  a.tile0[0][SM_MAX_LEVELS] = t0;
+  a.tile0[1][SM_MAX_LEVELS] = t1;
   a.cin = d->cin;
   a.cout = d->cout;
   a.nc = d->cin / 32;
@@ -386,12 +571,17 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   a.scale_nch = d->scale_nch;
   a.prow_cap = (PT_BPOS + 2 * (maxw + 2) + 2 + 15) / 16 * 16;
   a.ngroups = d->ngroups > 1 ? d->ngroups : 1;
-  a.tpg = t * a.ntn;
+  a.tpg[0] = t0 * a.ntn > 0 ? t0 * a.ntn : 1;
+  a.tpg[1] = t1 * a.ntn > 0 ? t1 * a.ntn : 1;
   a.x_grows = d->x_group_rows;
   a.y_grows = d->y_group_rows;
   a.w_gstride = d->w_group_stride;
   a.b_gstride = d->bias_group_stride;
   a.gn_gstride = d->gn_group_stride;
+  const long long nb0 = (long long)t0 * a.ntn * a.ngroups, nb1 = (long long)t1 * a.ntn * a.ngroups;
+  if (nb0 != ps.nbig || nb1 != ps.nsmall) return SM_ERR_BAD_SHAPE;       // planner / table mismatch: a bug, not a shape
+  a.nblk[0] = (int)nb0;
+  a.nblk[1] = (int)nb1;
   hipStream_t s = sm_hip_stream(stream);
   if (gn_stats != nullptr) {
     if (hipMemsetAsync(gn_stats, 0, sizeof(float) * 2 * a.ngroups * d->batch * d->nlev * (d->cout / 8), s) != hipSuccess)
@@ -399,11 +589,21 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   }
   const size_t lds = 2 * (size_t)PT_WSTAGE + 2 * (size_t)a.prow_cap * 64;
   if (lds > 160 * 1024) return SM_ERR_UNSUPPORTED;
-  if (hipFuncSetAttribute((const void*)conv3x3_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return SM_ERR_LAUNCH;
-  const long long nblk = (long long)t * a.ntn * a.ngroups;
+  const long long nblk = nb0 + nb1;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(conv3x3_patch_kernel, dim3((unsigned)nblk), dim3(PT_THREADS), lds, s, a);
+  const bool pipe = (d->flags & SM_CONV_DBG_PATCH_PIPE) != 0;
+  auto launch = [&](auto kern) -> int {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SM_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(PT_THREADS), lds, s, a);
+    return SM_OK;
+  };
+  int lrc;
+  if (ps.small == 128)
+    lrc = pipe ? launch(conv3x3_patch_kernel<128, true>) : launch(conv3x3_patch_kernel<128, false>);
+  else
+    lrc = pipe ? launch(conv3x3_patch_kernel<192, true>) : launch(conv3x3_patch_kernel<192, false>);
+  if (lrc != SM_OK) return lrc;
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -26,6 +26,8 @@ _GROUPED_TOWERS = __import__("os").environ.get("SIPMASK_GROUPED_TOWERS", "1") ==
 
 _SPLIT_K = __import__("os").environ.get("SIPMASK_SPLIT_K", "1") != "0"     # A/B: split-K for under-filled launches
 _PATCH_CONV = __import__("os").environ.get("SIPMASK_PATCH_CONV", "1") != "0"   # A/B: patch-resident 3x3 kernel
+_PATCH_MIN_WORK = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_WORK", "100"))   # 256x256 tile equivalents
+_PATCH_MIN_FILL = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_FILL", "0.6"))
 # bottleneck fusion in layer1 / layer2: 0 = separate launches, 1 = conv2+conv3, 2 = conv2+conv3+next conv1.  Measured
 # (profiles/r02f_ab_bottleneck_fusion.json, same box): 963 / 998 / 984 img/s -- the chained conv1 needs 72-80 KB of LDS
 # (2 blocks per CU instead of 3-4) and loses under two concurrent sub-plans what it saves per launch
@@ -85,13 +87,18 @@ class _Conv:
                                   pad, in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
                                   scale_nch, level_scale, deform_groups)
             if H.conv3x3_patch_supported(dp):
-                tiles = H.conv3x3_patch_tiles(dp) * getattr(self, "_patch_groups", 1)
-                rounds = (tiles + 255) // 256
-                # one 256x256 tile per CU: take the kernel when the launch is a reasonable share of a round of 256 CUs
-                # and multi-round launches fill their rounds (measured: profiles/r02*_patch_conv_microbench.txt)
-                # ... and the couts fill most of the 256-wide tile (sip_mask_lat, 128 -> 32: 0.061 ms on the 32 x 256
-                # implicit-GEMM tile, 0.101 ms here with 7/8 of the MFMAs on padding)
-                if tiles >= 100 and (rounds == 1 or tiles >= 0.65 * rounds * 256) and co * 4 >= 3 * ((co + 255) // 256 * 256):
+                if getattr(eng, "patch_uniform", False):
+                    dp.flags |= 0x4000                               # SM_CONV_DBG_PATCH_UNIFORM
+                dp.ngroups = getattr(self, "_patch_groups", 1)       # the launch shape depends on every group's tiles
+                pl = H.conv3x3_patch_plan(dp)
+                dp.ngroups = 1
+                # one tile per CU; the library cuts the launch into 256-position tiles + smaller finishing tiles
+                # (sm_conv3x3_patch_plan).  Take the kernel when the launch is a reasonable share of a round of 256 CUs,
+                # the planned shape keeps the CUs busy (fill = work / (256 x makespan)) and the couts fill most of the
+                # 256-wide tile (sip_mask_lat, 128 -> 32: 0.061 ms on the 32 x 256 implicit-GEMM tile, 0.101 ms here with
+                # 7/8 of the MFMAs on padding).  Measured: profiles/r02*_patch_conv_microbench.txt, r03*.
+                if (pl["work"] >= _PATCH_MIN_WORK and (pl["fill"] >= _PATCH_MIN_FILL or pl["makespan"] <= 1.0)
+                        and co * 4 >= 3 * ((co + 255) // 256 * 256)):
                     self.patch = True
                     self.w, _ = H.prep_conv_weight_patch(w.to(dev))
                     self.desc = dp
@@ -230,6 +237,10 @@ class SipMaskEngine:
         # sub_plan: this engine is one chain of a SubBatchPlan -- the other chain fills the CUs a short launch leaves
         # idle, so split-K (an extra reduce launch to fill them) only costs: 966 vs 962 img/s (profiles/r02e_ab_subplans.json)
         self.split_k = _SPLIT_K and not sub_plan
+        # ... and for the same reason its patch convs keep the uniform 256-position launch: the mixed launch (256-position
+        # tiles + 128/192-position finishing tiles, sm_conv3x3_patch_plan) ends a lone launch 15-20 % sooner but spends
+        # 4-6 % more CU time on it, which the other chain would have used (measured 998 vs 991 img/s, profiles/r03a_*)
+        self.patch_uniform = sub_plan
         if precision not in ("bf16", "f32"):
             raise ValueError("precision must be 'bf16' (throughput plan) or 'f32' (parity plan), got %r" % (precision,))
         # "f32": every activation / weight float32, convs on the exact-f32 MFMA kernel (csrc/conv_f32.hip), GroupNorm

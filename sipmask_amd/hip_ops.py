@@ -52,6 +52,19 @@ def conv3x3_patch_tiles(desc):
     return int(_lib.load().sm_conv3x3_patch_tiles(C.byref(desc)))
 
 
+def conv3x3_patch_plan(desc):
+    """launch shape the library will use (host logic only): 256-position tiles + 128/192-position tiles, the estimated
+    makespan in 256-position tile times, and `fill` = work / (256 CUs x makespan)"""
+    out = (C.c_int64 * 4)()
+    _lib.check(_lib.load().sm_conv3x3_patch_plan(C.byref(desc), out), "sm_conv3x3_patch_plan")
+    big, small, spos, milli = (int(v) for v in out)
+    ntn = desc.cout_pad // 256
+    groups = max(1, desc.ngroups)
+    work = sum(desc.batch * desc.in_h[l] * (desc.in_w[l] + 2) for l in range(desc.nlev)) * ntn * groups / 256.0
+    return dict(big=big, small=small, small_pos=spos, makespan=milli / 1000.0, work=work,
+                fill=work / (256.0 * max(milli, 1) / 1000.0))
+
+
 def conv3x3_patch(desc, x, w_patch, bias, y, gn_stats=None):
     _lib.require_cuda(x, w_patch, y)
     lib = _lib.load()

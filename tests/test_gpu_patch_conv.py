@@ -30,7 +30,8 @@ def _rows(ts):
     (2, 128, 512, [(9, 250)]),                                         # two cout tiles, widest supported rows
     (1, 256, 256, [(100, 168)]),                                       # FPN level-0 geometry (67 tiles)
 ])
-def test_patch_conv_vs_torch(cfg):
+@pytest.mark.parametrize("shape_flag", [0, 0x4000, 0x2000, 0x1000, 0x800, 0x2800, 0x1800])   # planner / uniform 256 / finish with 128 / with 192; 0x800 = pipelined stage
+def test_patch_conv_vs_torch(cfg, shape_flag):
     from sipmask_amd import hip_ops as H, _lib
     dev = _dev()
     B, Ci, Co, sizes = cfg
@@ -43,7 +44,7 @@ def test_patch_conv_vs_torch(cfg):
     wq, co_pad = H.prep_conv_weight_patch(w.to(dev))
     scales = [1.0 + 0.25 * l for l in range(len(sizes))]
     for out_f32, relu in ((True, False), (False, True)):
-        flags = (_lib.SM_CONV_OUT_F32 if out_f32 else 0) | (_lib.SM_CONV_RELU if relu else 0)
+        flags = (_lib.SM_CONV_OUT_F32 if out_f32 else 0) | (_lib.SM_CONV_RELU if relu else 0) | shape_flag
         d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, Ci, Co, co_pad, 3, 1, 1, Ci, Co, flags=flags,
                              scale_nch=4, level_scale=scales)
         assert H.conv3x3_patch_supported(d)
@@ -94,3 +95,51 @@ def test_patch_conv_grouped_with_groupnorm_statistics(shared_x):
             r8 = ref.view(B, C // 8, 8, h * wd)
             torch.testing.assert_close(st[:, l, :, 0], r8.sum((2, 3)), rtol=2e-3, atol=0.5)
             torch.testing.assert_close(st[:, l, :, 1], (r8 * r8).sum((2, 3)), rtol=2e-3, atol=0.5)
+
+
+@pytest.mark.parametrize("batch,groups", [(2, 2), (4, 1), (2, 1)])
+def test_patch_conv_mixed_tile_launch_at_head_shape(batch, groups):
+    """the BASELINE head pyramid (5 levels of 800x1344): launches the planner cuts into 256-position tiles + 128- / 192-
+    position finishing tiles (sm_conv3x3_patch_plan), grouped and not, with fused GN statistics; reference = torch f32
+    conv on the device, and the uniform launch (SM_CONV_DBG_PATCH_UNIFORM) must give bit-identical outputs (same K
+    order per output element)."""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(11 + batch + groups)
+    C = 256
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    lv = H.Levels(batch, sizes)
+    xs = [_bf(torch.randn(batch, C, h, w, generator=g)).to(dev) for h, w in sizes]
+    ws = [_bf(torch.randn(C, C, 3, 3, generator=g) / 48).to(dev) for _ in range(groups)]
+    x = _rows(xs).to(torch.bfloat16)
+    packed = [H.prep_conv_weight_patch(w)[0] for w in ws]
+    wq = torch.stack(packed).contiguous()
+    S = 2 * batch * len(sizes) * (C // 8)
+    outs = {}
+    for flag in (0, 0x4000, 0x800):
+        y = torch.zeros(groups * lv.rows, C, dtype=torch.bfloat16, device=dev)
+        stats = torch.full((groups * S,), 7.0, device=dev)
+        d = H.make_conv_desc(batch, sizes, sizes, lv.row0, lv.row0, C, C, 256, 3, 1, 1, C, C, flags=flag, ngroups=groups,
+                             x_group_rows=0, y_group_rows=lv.rows, w_group_stride=packed[0].numel(), bias_group_stride=0,
+                             gn_group_stride=S)
+        pl = H.conv3x3_patch_plan(d)
+        if flag != 0x4000:
+            assert pl["small"] > 0, pl            # these shapes are the ones the mixed launch exists for
+        else:
+            assert pl["small"] == 0, pl
+        H.conv3x3_patch(d, x, wq, None, y, stats)
+        torch.cuda.synchronize()
+        outs[flag] = (y, stats)
+    assert torch.equal(outs[0][0], outs[0x4000][0])
+    assert torch.equal(outs[0][0], outs[0x800][0])          # the pipelined stage issues the same MFMAs in the same order
+    torch.testing.assert_close(outs[0][1], outs[0x4000][1], rtol=1e-4, atol=0.5)      # atomics: order only
+    y, stats = outs[0]
+    for gi in range(groups):
+        st = stats[gi * S:(gi + 1) * S].view(batch, len(sizes), C // 8, 2)
+        for l, (h, wd) in enumerate(sizes):
+            ref = F.conv2d(xs[l], ws[gi], None, 1, 1)
+            got = y[gi * lv.rows + lv.row0[l]: gi * lv.rows + lv.row0[l] + batch * h * wd].float().view(batch, h, wd, C).permute(0, 3, 1, 2)
+            torch.testing.assert_close(got, ref, rtol=2 ** -7, atol=2e-3)
+            r8 = ref.reshape(batch, C // 8, 8, h * wd)
+            torch.testing.assert_close(st[:, l, :, 0], r8.sum((2, 3)), rtol=2e-3, atol=1.0)
+            torch.testing.assert_close(st[:, l, :, 1], (r8 * r8).sum((2, 3)), rtol=2e-3, atol=1.0)

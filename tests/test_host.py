@@ -279,3 +279,44 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
         assert all(rows[n[:-len(".conv_offset")]]["plan"]["lds_dma"] == 0 for n in rows if n.endswith("conv2.conv_offset"))
     if variant == "vis":
         assert "head.sipmask_track" in rows or any(n.startswith("head.track") for n in rows)
+
+
+def test_patch_conv_launch_shapes():
+    """sm_conv3x3_patch_plan (pure host logic): the launch shapes the planner picks for the BASELINE head launches and
+    its invariants -- every shape covers every segment, never estimates worse than the uniform launch, and the A/B
+    flag restores the uniform launch."""
+    from sipmask_amd import hip_ops as H
+    levels = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    expect = {(2, 2, 5): (256, 208, 128), (2, 1, 5): (0, 242, 192), (2, 1, 1): (0, 178, 192), (4, 1, 1): (256, 20, 128),
+              (4, 2, 5): (736, 0, 128)}
+    for (b, g, nl), (big, small, spos) in expect.items():
+        sizes = levels[:nl]
+        lv = H.Levels(b, sizes)
+        d = H.make_conv_desc(b, sizes, sizes, lv.row0, lv.row0, 256, 256, 256, 3, 1, 1, 256, 256, ngroups=g)
+        pl = H.conv3x3_patch_plan(d)
+        assert (pl["big"], pl["small"]) == (big, small), (b, g, nl, pl)
+        if small:
+            assert pl["small_pos"] == spos
+        assert H.conv3x3_patch_tiles(d) == big + small
+        d.flags = 0x4000
+        un = H.conv3x3_patch_plan(d)
+        assert un["small"] == 0 and un["makespan"] >= pl["makespan"]
+        assert un["big"] == g * b * sum(-(-h * (w + 2) // 256) for h, w in sizes)
+    # ragged shapes: positions covered = segment length, for random geometries and every forced variant
+    import random
+    rnd = random.Random(0)
+    for _ in range(50):
+        nl = rnd.randint(1, 5)
+        sizes = [(rnd.randint(1, 120), rnd.randint(1, 250)) for _ in range(nl)]
+        b, g = rnd.randint(1, 6), rnd.randint(1, 2)
+        co = rnd.choice([8, 208, 256, 512])
+        lv = H.Levels(b, sizes)
+        for flag in (0, 0x2000, 0x1000):
+            d = H.make_conv_desc(b, sizes, sizes, lv.row0, lv.row0, 64, co, (co + 255) // 256 * 256, 3, 1, 1, 64, co,
+                                 flags=flag, ngroups=g)
+            pl = H.conv3x3_patch_plan(d)
+            segs = b * g * ((co + 255) // 256)
+            assert pl["big"] % segs == 0 and pl["small"] % segs == 0
+            cover = pl["big"] * 256 + pl["small"] * pl["small_pos"]
+            need = segs * sum(h * (w + 2) for h, w in sizes)
+            assert cover >= need and cover < need + segs * nl * 256, (sizes, b, g, co, pl)
