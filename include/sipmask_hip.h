@@ -44,6 +44,8 @@ typedef enum {
 #define SM_CONV_RES_NEAREST 8u   /* y += residual at nearest-neighbour source (FPN top-down,
                                     M/mmdet/models/necks/fpn.py:149-152) */
 #define SM_CONV_IN_RELU 16u      /* x = max(x,0) applied on load (fpn.py:174-175 P7) */
+#define SM_CONV_BWD_GX_BF16 64u   /* sm_conv2d_bwd only: grad_x is written as bf16 rows (stride-1 convs: the dX GEMM's own
+                                    output type; the training graph on row tensors hands it straight to the next op) */
 #define SM_CONV_RELU_NCH 32u     /* y = max(y, 0) on channels < scale_nch only (the maskrcnn-benchmark variant's
                                     relu(scale(bbox_pred)), SipMask-benchmark/.../sipmask/sipmask.py:155-157) */
 #define SM_CONV_DBG_LINEAR_TILES 0x40000000u /* A/B switch: disable the XCD-aware tile remap */
@@ -203,6 +205,42 @@ int sm_deform_conv2d_bwd(const sm_conv_desc* d, const void* x, const float* offs
  * Every output is nullable.  Workspace: sm_deform_conv2d_bwd_workspace(d). */
 int sm_conv2d_bwd(const sm_conv_desc* d, const void* x, const void* w_t, const void* w_dgrad, const void* gout,
                   float* grad_x, float* grad_w_t, float* grad_bias, void* workspace, sm_stream_t stream);
+
+/* ---- training graph on NHWC bf16 row tensors (csrc/train_rows.hip; host side sipmask_amd/ops_rows.py).  These replace
+ * the chains of ATen launches (permute / contiguous / to / zeros / mul / threshold_backward / native_group_norm_backward
+ * / upsample_bilinear2d_backward ...) autograd runs between the reference's conv layers in training mode
+ * (M/mmdet/models/backbones/resnet.py:205-239, necks/fpn.py:137-178, anchor_heads/sipmask_head.py:241-287).
+ *
+ * sm_weight_prep: f32 OIHW parameter (x scale[cout] when given: the frozen-BatchNorm fold) -> bf16 [rows_pad][kp]:
+ *   mode 0  sm_conv2d weight            rows = cout, k = (r*kw+s)*cin_pad + c
+ *   mode 1  sm_conv2d_bwd w_dgrad       rows = cin,  k = (r*kw+s)*cout + o, taps flipped
+ *   mode 2  sm_conv2d_bwd w_t           rows = (r*kw+s)*cin + c, k = o
+ * sm_wgrad_finish: grad_w_t f32 [K][cout] (sm_conv2d_bwd) -> OIHW f32, x scale[cout] when given.
+ * sm_relu_bwd_bf16: out = y > 0 ? g : 0 (n elements, n % 8 == 0).
+ * sm_bias_grad_rows: out f32[channels] = column sums of g bf16 [rows][cstride] (channels % 8 == 0, <= 256).
+ * sm_gn_bwd_rows: GroupNorm(+ReLU) backward.  x = the normalised tensor's INPUT (bf16 pyramid rows, geometry as
+ *   sm_groupnorm), stats = the forward's (sum, sum of squares) per (image, level, group); dy bf16; outputs dx bf16,
+ *   dgamma / dbeta f32[channels]; bins f32 [batch][nlev][groups][2] is scratch (zeroed by the call).
+ * sm_upsample_bilinear_bwd_rows: adjoint of sm_upsample_bilinear: gout bf16 rows of the upsampled grid (row stride
+ *   out_cstride, first channel out_coff -> a slice of a concatenated gradient), gin bf16 [batch*h*w][c].
+ * sm_nearest_bwd_rows: adjoint of the SM_CONV_RES_NEAREST residual: g_coarse[src(p)] += g_fine[p].
+ * sm_scatter_stride_rows: out [batch*h*w][c] = in [batch*out_h*out_w][c] placed at (y*stride, x*stride), zero elsewhere
+ *   (dX of a strided 1x1 convolution after the channel GEMM). */
+int sm_weight_prep(const float* w, const float* scale, int cout, int cin, int kh, int kw, int mode, void* out,
+                   int rows_pad, int kp, int cin_pad, sm_stream_t stream);
+int sm_wgrad_finish(const float* grad_w_t, const float* scale, int cout, int cin, int kh, int kw, float* out,
+                    sm_stream_t stream);
+int sm_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t n, sm_stream_t stream);
+int sm_bias_grad_rows(const void* g, int64_t rows, int cstride, int channels, float* out, sm_stream_t stream);
+int sm_gn_bwd_rows(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats, int batch,
+                   int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups, float eps, int relu,
+                   void* dx, float* dgamma, float* dbeta, float* bins, sm_stream_t stream);
+int sm_upsample_bilinear_bwd_rows(const void* gout, int out_cstride, int out_coff, int batch, int h, int w, int c,
+                                  int factor, void* gin, sm_stream_t stream);
+int sm_nearest_bwd_rows(const void* g_fine, int batch, int fine_h, int fine_w, int coarse_h, int coarse_w, int c,
+                        void* g_coarse, sm_stream_t stream);
+int sm_scatter_stride_rows(const void* in, int batch, int h, int w, int out_h, int out_w, int stride, int c, void* out,
+                           sm_stream_t stream);
 
 /* sm_conv2d / sm_deform_conv2d (offset != NULL) with the GroupNorm statistics of the output fused in the
  * epilogue: gn_stats f32 [batch][nlev][cout/8][2] = (sum, sum of squares) per (image, level, group of 8

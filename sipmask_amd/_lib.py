@@ -109,6 +109,14 @@ PROTOTYPES = {
     "sm_track_match": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P]),
     "sm_mask_rescore": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "sm_conv2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sm_weight_prep": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    "sm_wgrad_finish": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "sm_relu_bwd_bf16": (_I, [_P, _P, _P, C.c_int64, _P]),
+    "sm_bias_grad_rows": (_I, [_P, C.c_int64, _I, _I, _P, _P]),
+    "sm_gn_bwd_rows": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
+    "sm_upsample_bilinear_bwd_rows": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "sm_nearest_bwd_rows": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "sm_scatter_stride_rows": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sm_groupnorm_nchw_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "sm_groupnorm_nchw_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sm_upsample_bilinear_nchw_fwd": (_I, [_P, _P, C.c_int64, _I, _I, _I, _P]),

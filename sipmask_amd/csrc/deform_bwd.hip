@@ -370,6 +370,7 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
   // transposed weights (w_dgrad); everything else goes through grad columns + col2im
   const bool fast_dgrad = grad_x && !offset && w_dgrad && d->stride == 1;
   const bool col_path = (grad_x && !fast_dgrad) || grad_offset;
+  if ((d->flags & SM_CONV_BWD_GX_BF16) && grad_x && !fast_dgrad) return SM_ERR_UNSUPPORTED;   // col2im accumulates in f32
   if (col_path && (!w_t || d->cin % 64 != 0 || (d->cin / G) % 64 != 0)) return w_t ? SM_ERR_UNSUPPORTED : SM_ERR_BAD_ARG;
   hipStream_t s = sm_hip_stream(stream);
   Plan pl;
@@ -419,7 +420,7 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
     if (g0.pad < 0 || d->kh != d->kw) return SM_ERR_UNSUPPORTED;
     g0.in_cstride = d->out_cstride;
     g0.out_cstride = d->cin;
-    g0.flags = SM_CONV_OUT_F32;
+    g0.flags = (d->flags & SM_CONV_BWD_GX_BF16) ? 0u : SM_CONV_OUT_F32;      // bf16 rows for the row-tensor training graph
     const int st = sm_conv2d(&g0, gout, w_dgrad, nullptr, nullptr, grad_x, stream);
     if (st != SM_OK) return st;
   }

@@ -96,8 +96,25 @@ class SipMask(nn.Module):
         assert imgs[0].size(0) == 1                      # base.py:118-119
         return self.simple_test(imgs[0], img_metas[0], **kwargs)
 
+    def extract_feat_rows(self, img):
+        """extract_feat (single_stage.py:41-47) on row tensors: (pyramid rows bf16 [sum_l B*h_l*w_l, C], Levels) -- the
+        head's input layout, all levels in one matrix (ops_rows.py)."""
+        from . import hip_ops as H
+        outs = self.backbone.forward_rows(img)
+        if self.with_neck:
+            outs = self.neck.forward_rows(outs)
+        rows = outs[0][0] if len(outs) == 1 else torch.cat([r for r, _ in outs])
+        return rows, H.Levels(img.shape[0], [lv.sizes[0] for _, lv in outs])
+
     def extract_feat_train(self, img):
-        """extract_feat (single_stage.py:41-47) as a differentiable graph of HIP autograd ops."""
+        """extract_feat (single_stage.py:41-47) as a differentiable graph of HIP autograd ops; NCHW tensors (views of the
+        row tensors the graph runs on)."""
+        from .modules import _train_rows_enabled
+        if _train_rows_enabled(img) and self.with_neck:
+            from .ops_rows import rows_to_nchw
+            rows, lv = self.extract_feat_rows(img)
+            return tuple(rows_to_nchw(rows[lv.row0[l]:lv.row0[l] + lv.batch * h * w], lv.batch, h, w)
+                         for l, (h, w) in enumerate(lv.sizes))
         x = self.backbone.forward_train(img)
         return self.neck.forward_train(x) if self.with_neck else x
 
@@ -106,8 +123,12 @@ class SipMask(nn.Module):
         graph), FPN and head run layer by layer on the HIP forward/backward ops; `.backward()` on the summed losses
         fills every trainable parameter's .grad."""
         self.bbox_head.train()
-        x = self.extract_feat_train(img)
-        outs = self.bbox_head(x)
+        from .modules import _train_rows_enabled
+        if _train_rows_enabled(img) and self.with_neck and hasattr(self.bbox_head, "forward_rows") and \
+                self.bbox_head.rows_path_ok():
+            outs = self.bbox_head.forward_rows(*self.extract_feat_rows(img))
+        else:
+            outs = self.bbox_head(self.extract_feat_train(img))
         return self.bbox_head.loss(*outs, gt_bboxes, gt_labels, img_metas, self.train_cfg,
                                    gt_bboxes_ignore=gt_bboxes_ignore, gt_masks_list=gt_masks)
 

@@ -666,3 +666,95 @@ def sgd_step(param, grad, buf, lr, momentum, weight_decay, first_step):
     lib = _lib.load()
     _lib.check(lib.sm_sgd_step(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(buf), param.numel(), float(lr), float(momentum),
                                float(weight_decay), int(first_step), _lib.stream_ptr()), "sm_sgd_step")
+
+
+# ------------------------------------------------------------------------------- training graph on row tensors
+def weight_prep(w, scale, mode, cin_pad=None):
+    """f32 OIHW parameter (x scale[cout]) -> bf16 operand of sm_conv2d (mode 0) / the dX conv (mode 1) / the grad-column
+    GEMM (mode 2), in ONE launch (sm_weight_prep) -- the layouts of prep_conv_weight applied to w, w.flip(2,3).permute(1,0,2,3)
+    and w.permute(2,3,1,0).reshape(K,co,1,1).  Returns (tensor, rows_pad)."""
+    lib = _lib.load()
+    co, ci, kh, kw = w.shape
+    if mode == 0:
+        cin_pad = cin_pad or ((ci + 7) // 8 * 8)
+        rows, k = co, kh * kw * cin_pad
+    elif mode == 1:
+        cin_pad = co
+        rows, k = ci, kh * kw * co
+    else:
+        cin_pad = co
+        rows, k = kh * kw * ci, co
+    tile = cout_tile(rows)
+    rows_pad = (rows + tile - 1) // tile * tile
+    kp = (k + 63) // 64 * 64
+    out = torch.empty(rows_pad, kp, dtype=BF16, device=w.device)
+    wc = w.detach()
+    if wc.dtype != torch.float32 or not wc.is_contiguous():
+        wc = wc.float().contiguous()
+    _lib.check(lib.sm_weight_prep(_lib.ptr(wc), _lib.ptr(scale), co, ci, kh, kw, mode, _lib.ptr(out), rows_pad, kp, cin_pad,
+                                  _lib.stream_ptr()), "sm_weight_prep")
+    return out, rows_pad
+
+
+def wgrad_finish(gw_t, scale, co, ci, kh, kw):
+    lib = _lib.load()
+    out = torch.empty(co, ci, kh, kw, dtype=torch.float32, device=gw_t.device)
+    _lib.check(lib.sm_wgrad_finish(_lib.ptr(gw_t), _lib.ptr(scale), co, ci, kh, kw, _lib.ptr(out), _lib.stream_ptr()),
+               "sm_wgrad_finish")
+    return out
+
+
+def relu_bwd_bf16(g, y):
+    lib = _lib.load()
+    assert g.dtype == BF16 and y.dtype == BF16 and g.numel() == y.numel() and g.is_contiguous() and y.is_contiguous()
+    out = torch.empty_like(g)
+    _lib.check(lib.sm_relu_bwd_bf16(_lib.ptr(g), _lib.ptr(y), _lib.ptr(out), g.numel(), _lib.stream_ptr()), "sm_relu_bwd_bf16")
+    return out
+
+
+def bias_grad_rows(g, channels):
+    lib = _lib.load()
+    assert g.dtype == BF16 and g.dim() == 2 and g.is_contiguous()
+    out = torch.empty(channels, dtype=torch.float32, device=g.device)
+    _lib.check(lib.sm_bias_grad_rows(_lib.ptr(g), g.shape[0], g.shape[1], channels, _lib.ptr(out), _lib.stream_ptr()),
+               "sm_bias_grad_rows")
+    return out
+
+
+def gn_bwd_rows(x, dy, gamma, beta, stats, lv, channels, groups, eps, relu):
+    lib = _lib.load()
+    nlev = len(lv)
+    hw = (C.c_int32 * nlev)(*[h * w for h, w in lv.sizes])
+    row0 = (C.c_int64 * nlev)(*lv.row0)
+    dx = torch.empty_like(x)
+    dg = torch.empty(channels, dtype=torch.float32, device=x.device)
+    db = torch.empty(channels, dtype=torch.float32, device=x.device)
+    bins = torch.empty(lv.batch * nlev * groups * 2, dtype=torch.float32, device=x.device)
+    _lib.check(lib.sm_gn_bwd_rows(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats), lv.batch, nlev,
+                                  hw, row0, channels, groups, eps, int(relu), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db),
+                                  _lib.ptr(bins), _lib.stream_ptr()), "sm_gn_bwd_rows")
+    return dx, dg, db
+
+
+def upsample_bilinear_bwd_rows(gout, out_cstride, out_coff, batch, h, w, c, factor):
+    lib = _lib.load()
+    gin = torch.empty(batch * h * w, c, dtype=BF16, device=gout.device)
+    _lib.check(lib.sm_upsample_bilinear_bwd_rows(_lib.ptr(gout), out_cstride, out_coff, batch, h, w, c, factor, _lib.ptr(gin),
+                                                 _lib.stream_ptr()), "sm_upsample_bilinear_bwd_rows")
+    return gin
+
+
+def nearest_bwd_rows(g_fine, batch, fine_hw, coarse_hw, c):
+    lib = _lib.load()
+    out = torch.empty(batch * coarse_hw[0] * coarse_hw[1], c, dtype=BF16, device=g_fine.device)
+    _lib.check(lib.sm_nearest_bwd_rows(_lib.ptr(g_fine), batch, fine_hw[0], fine_hw[1], coarse_hw[0], coarse_hw[1], c,
+                                       _lib.ptr(out), _lib.stream_ptr()), "sm_nearest_bwd_rows")
+    return out
+
+
+def scatter_stride_rows(t, batch, hw, out_hw, stride, c):
+    lib = _lib.load()
+    out = torch.empty(batch * hw[0] * hw[1], c, dtype=BF16, device=t.device)
+    _lib.check(lib.sm_scatter_stride_rows(_lib.ptr(t), batch, hw[0], hw[1], out_hw[0], out_hw[1], stride, c, _lib.ptr(out),
+                                          _lib.stream_ptr()), "sm_scatter_stride_rows")
+    return out

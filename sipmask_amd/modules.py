@@ -122,6 +122,29 @@ class Bottleneck(nn.Module):
         self.add_module("bn3", _norm_layer(norm_cfg, planes * 4)[1])
         self.downsample = downsample
 
+    def forward_rows(self, x, lv):
+        """resnet.py:205-239 on row tensors: three conv launches (+ the shortcut's), BN / ReLU / residual add fused"""
+        from . import ops_rows as R
+        out, l1 = _conv_bn_rows(x, lv, self.conv1, self.bn1, self.conv1_stride, 0, True)
+        if self.with_dcn:
+            n_off = self.conv2.conv_offset.weight.shape[0]
+            wo, bo = _pad_cout8(self.conv2.conv_offset.weight, self.conv2.conv_offset.bias)
+            off, _ = R.conv_rows(out, l1, wo, bo, 1, 1, out_f32=True)
+            off = off[:, :n_off].contiguous()
+            if self.bn2.weight.requires_grad or self.bn2.bias.requires_grad:
+                w, b = _fold(self.conv2.weight, self.bn2)
+                out = R.deform_conv_rows(out, l1, off, w, b, 1, 1, self.conv2.deformable_groups, relu=True)
+            else:
+                s2, b2 = R.bn_fold_constants(self.bn2)
+                out = R.deform_conv_rows(out, l1, off, self.conv2.weight, b2, 1, 1, self.conv2.deformable_groups, relu=True,
+                                         scale=s2)
+            l2 = l1
+        else:
+            out, l2 = _conv_bn_rows(out, l1, self.conv2, self.bn2, self.conv2_stride, 1, True)
+        idt = x if self.downsample is None else _conv_bn_rows(x, lv, self.downsample[0], self.downsample[1],
+                                                              self.downsample[0].stride[0], 0, False)[0]
+        return _conv_bn_rows(out, l2, self.conv3, self.bn3, 1, 0, True, residual=idt)
+
     def forward_train(self, x):
         """resnet.py:205-239 on the HIP autograd ops; the (eval-mode, frozen) BatchNorms are folded into the conv
         weights inside the graph, so their affine parameters would still receive gradients if they required them."""
@@ -139,6 +162,27 @@ class Bottleneck(nn.Module):
         idt = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1],
                                                          self.downsample[0].stride[0], 0)
         return torch.relu(out + idt)
+
+
+def _train_rows_enabled(x):
+    """the row-tensor training graph (ops_rows.py) is the default on the device; SIPMASK_TRAIN_ROWS=0 keeps the first
+    version (per-op NCHW float interface, ops.py) for A/B runs, and CPU tensors take it too (the CPU emulation in
+    tests/test_gpu_api.py swaps ops.conv2d under it)"""
+    import os
+    return x.is_cuda and os.environ.get("SIPMASK_TRAIN_ROWS", "1") != "0"
+
+
+def _conv_bn_rows(x, lv, conv, bn, stride, pad, relu, residual=None):
+    """conv + eval-mode BatchNorm (+ residual, + ReLU) as ONE conv launch on row tensors: with frozen affine parameters
+    (the sipmask configs: norm_cfg requires_grad=False) the fold is a per-cout scale applied when the bf16 weight operand
+    is written (sm_weight_prep) and undone on the weight gradient (sm_wgrad_finish); otherwise the differentiable
+    tensor fold feeds the same op."""
+    from . import ops_rows as R
+    if bn.weight.requires_grad or bn.bias.requires_grad:
+        w, b = _fold(conv.weight, bn)
+        return R.conv_rows(x, lv, w, b, stride, pad, relu, None, residual)
+    s, b = R.bn_fold_constants(bn)
+    return R.conv_rows(x, lv, conv.weight, b, stride, pad, relu, s, residual)
 
 
 def _fold(weight, bn):
@@ -202,10 +246,39 @@ class ResNet(nn.Module):
             self.res_layers.append(name)
         self._freeze_stages()
 
+    def forward_rows(self, img):
+        """resnet.py:501-512 on row tensors: list of (rows bf16 [B*h*w, C], Levels) per out_index.  Stem and frozen
+        stages run without a graph; BN is always in eval mode (norm_eval, cfg requires_grad=False)."""
+        from . import ops_rows as R
+        from . import hip_ops as H
+        b, _, hh, ww = img.shape
+        outs = []
+        with torch.no_grad():
+            x = R.nchw_to_rows(img, 8)
+            x, lv = _conv_bn_rows(x, H.Levels(b, [(hh, ww)]), self.conv1, self.bn1, 2, 3, True)
+            h, w = lv.sizes[0]
+            ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+            y = torch.empty(b * ho * wo, 64, dtype=torch.bfloat16, device=img.device)
+            H.maxpool3x3s2(x, y, b, h, w, 64)
+            x, lv = y, H.Levels(b, [(ho, wo)])
+        for i, name in enumerate(self.res_layers):
+            frozen = (i + 1) <= self.frozen_stages
+            with torch.set_grad_enabled(torch.is_grad_enabled() and not frozen):
+                for blk in getattr(self, name):
+                    x, lv = blk.forward_rows(x, lv)
+            if frozen:
+                x = x.detach()
+            if i in self.out_indices:
+                outs.append((x, lv))
+        return outs
+
     def forward_train(self, x):
         """resnet.py:501-512 as a differentiable graph (BN always in eval mode: norm_eval, cfg requires_grad=False).
         Frozen stages run without building a graph.  x: [B,3,H,W] float on the device."""
         from . import ops as P
+        if _train_rows_enabled(x):
+            from .ops_rows import rows_to_nchw
+            return tuple(rows_to_nchw(r, lv.batch, *lv.sizes[0]) for r, lv in self.forward_rows(x))
         outs = []
         with torch.no_grad():
             x8 = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 5))                      # 3 -> 8 input channels
@@ -284,6 +357,29 @@ class FPN(nn.Module):
         for i in range(num_outs - self.backbone_end_level + start_level):
             self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, stride=2, padding=1, act_cfg=act_cfg,
                                              inplace=False))
+
+    def forward_rows(self, inputs):
+        """fpn.py:137-178 on row tensors: inputs = [(rows, Levels)] per backbone level -> [(rows, Levels)] per output.
+        The top-down nearest-neighbour add rides in the lateral conv's epilogue (SM_CONV_RES_NEAREST)."""
+        from . import ops_rows as R
+        n = len(self.lateral_convs)
+        lats = [None] * n
+        for i in range(n - 1, -1, -1):
+            x, lv = inputs[i + self.start_level]
+            lc = self.lateral_convs[i].conv
+            if i == n - 1:
+                lats[i] = R.conv_rows(x, lv, lc.weight, lc.bias, 1, 0)
+            else:
+                lats[i] = R.conv_rows(x, lv, lc.weight, lc.bias, 1, 0, residual=lats[i + 1][0], res_mode='nearest',
+                                      res_lv=lats[i + 1][1])
+        outs = [R.conv_rows(lats[i][0], lats[i][1], self.fpn_convs[i].conv.weight, self.fpn_convs[i].conv.bias, 1, 1)
+                for i in range(n)]
+        for i in range(n, len(self.fpn_convs)):
+            src, lv = outs[-1]
+            if i > n:
+                src = torch.relu(src)
+            outs.append(R.conv_rows(src, lv, self.fpn_convs[i].conv.weight, self.fpn_convs[i].conv.bias, 2, 1))
+        return outs
 
     def forward_train(self, inputs):
         """fpn.py:137-178 (start_level, extra convs on the outputs, ReLU before P7) on the HIP conv autograd op."""

@@ -125,6 +125,66 @@ class SipMaskHead(nn.Module):
                 x = torch.relu(P.conv2d(x, m.conv.weight, m.conv.bias, 1, 1))
         return x
 
+    def rows_path_ok(self):
+        """the row-tensor training graph covers the plain SipMaskHead forward (subclasses that add branches to
+        forward_train keep their own graph on top of the NCHW views it returns)"""
+        return type(self).forward_train is SipMaskHead.forward_train or getattr(self, "_rows_forward_ok", False)
+
+    def _tower_rows(self, x, lv, convs):
+        from . import ops_rows as R
+        for m in convs:
+            if m.with_norm:
+                y, _ = R.conv_rows(x, lv, m.conv.weight, None, 1, 1)
+                x = R.gn_rows(y, lv, m.norm.weight, m.norm.bias, m.norm.num_groups, m.norm.eps, True)
+            else:
+                x, _ = R.conv_rows(x, lv, m.conv.weight, m.conv.bias, 1, 1, relu=True)
+        return x
+
+    def forward_rows(self, pyr, lv):
+        """SipMaskHead.forward (sipmask_head.py:241-287) on the pyramid row tensor: every tower / predictor conv is ONE
+        launch over all levels and images (the five levels share the weights), GroupNorm statistics per (image, level),
+        FeatureAlign's deformable conv over the whole pyramid, cls + coefficient predictors as one 208-channel conv.
+        Returns the reference's five lists of NCHW tensors (views of the row tensors)."""
+        from . import ops as P
+        from . import ops_rows as R
+        from . import hip_ops as H
+        b, nl = lv.batch, len(lv)
+        cls_feat = self._tower_rows(pyr, lv, self.cls_convs)
+        reg_feat = self._tower_rows(pyr, lv, self.reg_convs)
+        # fcos_reg (4) + fcos_centerness (1) as ONE 8-channel conv (3 zero channels): the GEMM wants cout % 8 == 0
+        zw = self.fcos_reg.weight.new_zeros(3, *self.fcos_reg.weight.shape[1:])
+        w_rc = torch.cat([self.fcos_reg.weight, self.fcos_centerness.weight, zw], 0)
+        b_rc = torch.cat([self.fcos_reg.bias, self.fcos_centerness.bias, self.fcos_reg.bias.new_zeros(3)], 0)
+        rc, _ = R.conv_rows(reg_feat, lv, w_rc, b_rc, 1, 1, out_f32=True)                    # [rows, 8] f32
+        seg = [(lv.row0[l], lv.row0[l] + b * h * w, h, w) for l, (h, w) in enumerate(lv.sizes)]
+        box_rows = [self.scales[l](rc[r0:r1, :4]) for l, (r0, r1, _, _) in enumerate(seg)]
+        # FeatureAlign (:49-55): offsets = conv_offset (1x1, 4 -> 72, no bias) of the DETACHED box prediction
+        w_off = self.feat_align.conv_offset.weight.flatten(1)
+        offset = torch.cat([t.detach() for t in box_rows]).float() @ w_off.t()
+        ad = self.feat_align.conv_adaption
+        y = R.deform_conv_rows(cls_feat, lv, offset, ad.weight, None, ad.padding[0] if isinstance(ad.padding, tuple) else ad.padding,
+                               1, ad.deformable_groups, relu=not self.feat_align.flag_norm)
+        if self.feat_align.flag_norm:
+            n = self.feat_align.norm
+            y = R.gn_rows(y, lv, n.weight, n.bias, n.num_groups, n.eps, True)
+        nc = self.fcos_cls.weight.shape[0]
+        cc, _ = R.conv_rows(y, lv, torch.cat([self.fcos_cls.weight, self.sip_cof.weight], 0),
+                            torch.cat([self.fcos_cls.bias, self.sip_cof.bias], 0), 1, 1, out_f32=True)
+        view = lambda t, r0, r1, h, w: t[r0:r1].view(b, h, w, t.shape[1]).permute(0, 3, 1, 2)
+        cls_scores = [view(cc[:, :nc], *sg) for sg in seg]
+        cof_preds = [view(cc[:, nc:], *sg) for sg in seg]
+        centernesses = [view(rc[:, 4:5], *sg) for sg in seg]
+        bbox_preds = [box_rows[l].view(b, h, w, 4).permute(0, 3, 1, 2).float() * self.strides[l]
+                      for l, (_, _, h, w) in enumerate(seg)]
+        # mask branch (:266-287): [l0 | up2(l1) | up4(l2)] -> 1x1 (768 -> 512) -> 3x3 (512 -> nc) -> x4
+        h0, w0 = lv.sizes[0]
+        l0 = H.Levels(b, [(h0, w0)])
+        fm = R.mask_feat_rows(reg_feat, lv)
+        lat0, _ = R.conv_rows(fm, l0, self.sip_mask_lat0.weight, self.sip_mask_lat0.bias, 1, 0, relu=True)
+        lat, _ = R.conv_rows(lat0, l0, self.sip_mask_lat.weight, self.sip_mask_lat.bias, 1, 1, relu=True)
+        feat_masks = P.upsample_bilinear(R.rows_to_nchw(lat, b, h0, w0), 4)
+        return cls_scores, bbox_preds, centernesses, cof_preds, feat_masks
+
     def forward_train(self, feats):
         """SipMaskHead.forward (sipmask_head.py:241-287) as a differentiable graph of HIP autograd ops
         (ops.conv2d, ops.deform_conv, ops.group_norm, ops.upsample_bilinear; bf16 operands / f32 accumulation in
@@ -132,6 +192,12 @@ class SipMaskHead(nn.Module):
         kernels.  Layer by layer with NCHW<->NHWC conversions in every conv: correct, not yet fast (the fused static
         plan is inference-only)."""
         from . import ops as P
+        from .modules import _train_rows_enabled
+        if _train_rows_enabled(feats[0]) and len(feats) >= 3:
+            from . import ops_rows as R
+            from . import hip_ops as H
+            lv = H.Levels(feats[0].shape[0], [tuple(f.shape[-2:]) for f in feats])
+            return self.forward_rows(torch.cat([R.RowsFromNCHW.apply(f) for f in feats]), lv)
         cls_scores, bbox_preds, centernesses, cof_preds, fm = [], [], [], [], []
         # fcos_reg (4) + fcos_centerness (1) as ONE 8-channel conv (3 zero channels): the GEMM wants cout % 8 == 0
         zw = self.fcos_reg.weight.new_zeros(3, *self.fcos_reg.weight.shape[1:])
