@@ -328,11 +328,25 @@ bool make_plan(const sm_conv_desc* d, Plan* pl) {
   pl->K = (long long)d->kh * d->kw * d->cin;
   // split-K: one batched GEMM over S slices of the position axis (enough blocks to fill the chip even though the
   // result is only K x cout), partial sums reduced afterwards
-  pl->L = (int)std::min<long long>((pl->P + 63) / 64 * 64, DB_SLICE);
-  pl->S = (int)((pl->P + pl->L - 1) / pl->L);
   pl->Kpad = (int)((pl->K + 255) / 256 * 256);   // every position tile (<= 256 rows) stays inside one slice
   const int t2 = sm_conv_cout_tile(d->cout);
   pl->cout_pad2 = (d->cout + t2 - 1) / t2 * t2;
+  // slice length: the GEMM of one slice has only ceil(Kpad/128) x ceil(cout/128) output tiles (4 for a 512 -> 128 1x1
+  // conv), so small layers take MORE, shorter slices until ~1024 tiles exist -- bounded below by the length at which the
+  // f32 partial slabs (S x Kpad x cout, written and re-read) would outweigh the bf16 operands (P x (Kpad + cout))
+  {
+    const long long tiles = ((pl->Kpad + 127) / 128) * (long long)((pl->cout_pad2 + 127) / 128);
+    const long long s_want = (1024 + tiles - 1) / tiles;
+    long long L = (pl->P + s_want - 1) / s_want;
+    const long long l_min = 4ll * pl->Kpad * pl->cout_pad2 / (pl->Kpad + pl->cout_pad2);
+    if (L < l_min) L = l_min;
+    if (L < 256) L = 256;
+    if (L > DB_SLICE) L = DB_SLICE;
+    L = (L + 63) / 64 * 64;
+    const long long Pr = (pl->P + 63) / 64 * 64;
+    pl->L = (int)(L < Pr ? L : Pr);
+  }
+  pl->S = (int)((pl->P + pl->L - 1) / pl->L);
   const int t1 = sm_conv_cout_tile((int)pl->K);
   pl->kpad1 = (int)((pl->K + t1 - 1) / t1 * t1);
   size_t o = 0;

@@ -25,44 +25,53 @@ inline int grid_for(long long n, int block) {
 }
 
 // ------------------------------------------------------------------------------------------------ weight layouts
-// out is [rows_pad][kp] bf16, zero outside the logical extent.  One thread per 8 consecutive k.
+// out is [rows_pad][kp] bf16, zeroed by the host before the launch (padding rows / K padding / channel padding).
 //  mode 0: rows = cout,  k = (r*kw + s)*cin_pad + c            value w[o][c][r][s]
 //  mode 1: rows = cin,   k = (r*kw + s)*cout + o               value w[o][c][kh-1-r][kw-1-s]     (dX as a forward conv)
 //  mode 2: rows = (r*kw + s)*cin + c,  k = o                   value w[o][c][r][s]               (grad-column GEMM)
-__global__ void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ scale, uint16_t* __restrict__ out,
-                                   int co, int ci, int kh, int kw, int mode, int rows_pad, int kp, int cin_pad) {
-  const int kp8 = kp >> 3;
-  const long long total = (long long)rows_pad * kp8;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int row = (int)(i / kp8);
-    const int k0 = (int)(i - (long long)row * kp8) * 8;
-    float v[8];
+// A block owns a tile of 32 couts x 32 cins (all taps): it reads the 32 rows of w coalesced (the (c, tap) axis is
+// contiguous in OIHW) into LDS and writes 16-byte pieces of 8 consecutive channels (mode 0) / couts (modes 1, 2).
+constexpr int WP_T = 32;
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                          uint16_t* __restrict__ out, int co, int ci, int kh, int kw, int mode,
+                                                          int kp, int cin_pad, int tc) {
+  extern __shared__ float tile[];                    // [32 o][tc c * kk + 1]; tc = channels per tile (32, or 8 for big kernels)
+  const int kk = kh * kw;
+  const int o0 = blockIdx.y * WP_T, c0 = blockIdx.x * tc;
+  const int cw = min(tc, ci - c0);                   // live channels of the tile
+  const int pitch = tc * kk + 1;
+  const int nch = tc >> 3;                           // 8-wide pieces along the channel / cout axis of a tile
+  const int ncol = cw * kk;
+  for (int i = threadIdx.x; i < WP_T * ncol; i += 256) {
+    const int r = i / ncol, col = i - r * ncol;
+    const int o = o0 + r;
+    tile[r * pitch + col] = o < co ? w[((long long)o * ci + c0) * kk + col] * (scale ? scale[o] : 1.f) : 0.f;
+  }
+  __syncthreads();
+  if (mode == 0) {
+    // pieces: (o in tile, tap, 8-channel chunk)
+    for (int i = threadIdx.x; i < WP_T * kk * nch; i += 256) {
+      const int ch = i % nch, t = (i / nch) % kk, r = (i / nch) / kk;
+      const int o = o0 + r, c = c0 + ch * 8;
+      if (o >= co || c >= cin_pad) continue;
+      float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = k0 + e;
-      float val = 0.f;
-      if (mode == 0) {
-        const int tap = k / cin_pad, c = k - tap * cin_pad;
-        if (row < co && tap < kh * kw && c < ci) {
-          const int r = tap / kw, s = tap - r * kw;
-          val = w[(((long long)row * ci + c) * kh + r) * kw + s] * (scale ? scale[row] : 1.f);
-        }
-      } else if (mode == 1) {
-        const int tap = k / co, o = k - tap * co;
-        if (row < ci && tap < kh * kw) {
-          const int r = tap / kw, s = tap - r * kw;
-          val = w[(((long long)o * ci + row) * kh + (kh - 1 - r)) * kw + (kw - 1 - s)] * (scale ? scale[o] : 1.f);
-        }
-      } else {
-        if (row < kh * kw * ci && k < co) {
-          const int tap = row / ci, c = row - tap * ci;
-          const int r = tap / kw, s = tap - r * kw;
-          val = w[(((long long)k * ci + c) * kh + r) * kw + s] * (scale ? scale[k] : 1.f);
-        }
-      }
-      v[e] = val;
+      for (int e = 0; e < 8; ++e) v[e] = (ch * 8 + e < cw) ? tile[r * pitch + (ch * 8 + e) * kk + t] : 0.f;
+      *reinterpret_cast<uint4*>(out + (long long)o * kp + (long long)t * cin_pad + c) = pack_bf16x8(v);
     }
-    *reinterpret_cast<uint4*>(out + (long long)row * kp + k0) = pack_bf16x8(v);
+  } else {
+    // pieces: (c in tile, tap, 8-cout chunk)
+    for (int i = threadIdx.x; i < tc * kk * 4; i += 256) {
+      const int ch = i & 3, t = (i >> 2) % kk, cl = (i >> 2) / kk;
+      const int c = c0 + cl, o = o0 + ch * 8;
+      if (cl >= cw || o >= co) continue;
+      const int ts = mode == 1 ? kk - 1 - t : t;     // source tap (flipped for the dX operand)
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[(ch * 8 + e) * pitch + cl * kk + ts];
+      const long long at = mode == 1 ? (long long)c * kp + (long long)t * co + o : ((long long)t * ci + c) * kp + o;
+      *reinterpret_cast<uint4*>(out + at) = pack_bf16x8(v);
+    }
   }
 }
 
@@ -397,9 +406,15 @@ extern "C" int sm_weight_prep(const float* w, const float* scale, int cout, int 
   const long long klog = mode == 0 ? (long long)kh * kw * cin_pad : (mode == 1 ? (long long)kh * kw * cout : cout);
   const long long rlog = mode == 0 ? cout : (mode == 1 ? cin : (long long)kh * kw * cin);
   if (klog > kp || rlog > rows_pad || (mode == 0 && cin_pad < cin)) return SM_ERR_BAD_SHAPE;
-  const long long n = (long long)rows_pad * (kp / 8);
-  hipLaunchKernelGGL(weight_prep_kernel, dim3(grid_for(n, 256)), dim3(256), 0, sm_hip_stream(stream), w, scale,
-                     (uint16_t*)out, cout, cin, kh, kw, mode, rows_pad, kp, cin_pad);
+  if (cout % 8 != 0 && mode != 0) return SM_ERR_UNSUPPORTED;        // 16-byte pieces along cout
+  if (mode == 0 && cin_pad % 8 != 0) return SM_ERR_BAD_SHAPE;
+  hipStream_t s = sm_hip_stream(stream);
+  if (hipMemsetAsync(out, 0, (size_t)rows_pad * kp * 2, s) != hipSuccess) return SM_ERR_LAUNCH;
+  const int tc = kh * kw <= 9 ? 32 : 8;               // channels per tile: the LDS tile is 32 couts x tc x (kh*kw) floats
+  const size_t lds = sizeof(float) * WP_T * (tc * kh * kw + 1);
+  if (lds > 64 * 1024) return SM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(weight_prep_kernel, dim3((cin + tc - 1) / tc, (cout + WP_T - 1) / WP_T), dim3(256), lds, s, w, scale,
+                     (uint16_t*)out, cout, cin, kh, kw, mode, kp, cin_pad, tc);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

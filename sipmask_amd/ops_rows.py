@@ -77,7 +77,6 @@ class ConvRowsFunction(Function):
         H.conv2d(d, x, wq, b, residual, y)
         ctx.cfg = (lv, olv, stride, pad, relu, res_mode, res_lv, out_f32, k, co, ci, cs, bias is not None)
         ctx.save_for_backward(x, weight, scale, y if relu else None)
-        ctx.mark_non_differentiable()
         return y
 
     @staticmethod
@@ -108,29 +107,39 @@ class ConvRowsFunction(Function):
             if need_x and ci != cs:
                 raise NotImplementedError("conv_rows: input gradient needs cin == the row stride")
             d = H.make_conv_desc(lv.batch, lv.sizes, olv.sizes, lv.row0, olv.row0, cs, co, co, k, stride, pad, cs, co)
-            w_t = w_dg = gx_buf = None
-            strided_1x1 = need_x and stride > 1 and k == 1
+            w_dg = gx_buf = None
             if need_x and stride == 1:
                 w_dg, _ = H.weight_prep(weight, scale, 1)
                 d.flags = SM_CONV_BWD_GX_BF16
                 gx_buf = torch.empty(lv.rows, cs, dtype=BF16, device=g.device)
-            elif need_x and not strided_1x1:                       # strided 3x3 (FPN P6 / P7): grad columns + col2im, f32
-                w_t, _ = H.weight_prep(weight, scale, 2)
-                gx_buf = torch.empty(lv.rows, cs, dtype=torch.float32, device=g.device)
             gw_t = torch.empty(k * k * cs, co, dtype=torch.float32, device=g.device) if need_w else None
             if gx_buf is not None or gw_t is not None:
-                H.conv2d_bwd(d, x, w_t, w_dg, g, gx_buf, gw_t, None)
-            if strided_1x1:
-                # dX of a strided 1x1 conv: channel GEMM on the strided grid, then scatter into the input grid
+                H.conv2d_bwd(d, x, None, w_dg, g, gx_buf, gw_t, None)
+            if need_x and stride == 1:
+                gx = gx_buf
+            elif need_x:
+                # strided conv: dX = (stride-1 conv with the flipped weights) of the gradient placed on the stride-1 output
+                # grid -- for a 1x1 conv that is a channel GEMM on the strided grid followed by the scatter, for k > 1
+                # the scatter (zero-dilation) comes first and the conv pads by k-1-pad.  Both stay on the bf16 MFMA path
+                # for any channel count (the grad-column + col2im route of sm_conv2d_bwd needs cin % 64 == 0 and f32 atomics).
                 w_dg, rp = H.weight_prep(weight, scale, 1)
-                d1 = H.make_conv_desc(olv.batch, olv.sizes, olv.sizes, olv.row0, olv.row0, co, cs, rp, 1, 1, 0, co, cs)
-                t = torch.empty(olv.rows, cs, dtype=BF16, device=g.device)
-                H.conv2d(d1, g, w_dg, None, None, t)
-                parts = [H.scatter_stride_rows(t[olv.row0[l]:olv.row0[l] + olv.batch * oh * ow], lv.batch, lv.sizes[l], (oh, ow),
-                                               stride, cs) for l, (oh, ow) in enumerate(olv.sizes)]
+                parts = []
+                for l, (oh, ow) in enumerate(olv.sizes):
+                    h, w = lv.sizes[l]
+                    gl = g[olv.row0[l]:olv.row0[l] + olv.batch * oh * ow]
+                    if k == 1:
+                        d1 = H.make_conv_desc(olv.batch, [(oh, ow)], [(oh, ow)], [0], [0], co, cs, rp, 1, 1, 0, co, cs)
+                        t = torch.empty(olv.batch * oh * ow, cs, dtype=BF16, device=g.device)
+                        H.conv2d(d1, gl, w_dg, None, None, t)
+                        parts.append(H.scatter_stride_rows(t, lv.batch, (h, w), (oh, ow), stride, cs))
+                    else:
+                        hd, wd = h + 2 * pad - k + 1, w + 2 * pad - k + 1          # stride-1 output grid
+                        dil = H.scatter_stride_rows(gl, lv.batch, (hd, wd), (oh, ow), stride, co)
+                        d1 = H.make_conv_desc(lv.batch, [(hd, wd)], [(h, w)], [0], [0], co, cs, rp, k, 1, k - 1 - pad, co, cs)
+                        t = torch.empty(lv.batch * h * w, cs, dtype=BF16, device=g.device)
+                        H.conv2d(d1, dil, w_dg, None, None, t)
+                        parts.append(t)
                 gx = parts[0] if len(parts) == 1 else torch.cat(parts)
-            elif gx_buf is not None:
-                gx = gx_buf if gx_buf.dtype == BF16 else gx_buf.to(BF16)
             if need_w:
                 gw = H.wgrad_finish(gw_t, scale, co, cs, k, k)
                 if cs != ci:

@@ -54,6 +54,8 @@ class SipMaskHead(nn.Module):
         self.loss_cls = build_loss(loss_cls)
         self.loss_bbox = build_loss(loss_bbox)
         self.loss_centerness = build_loss(loss_centerness)
+        if rescoring_flag:                                             # sipmask_head.py:155-156
+            self.loss_iou = build_loss(dict(type='MSELoss', loss_weight=1.0, reduction='sum'))
         self.conv_cfg, self.norm_cfg = conv_cfg, norm_cfg
         self.fp16_enabled = False
         self.center_sampling, self.center_sample_radius = center_sampling, center_sample_radius
@@ -331,6 +333,7 @@ class SipMaskHead(nn.Module):
         img_box = torch.cat([b.detach().permute(0, 2, 3, 1).reshape(num_imgs, -1, 4) for b in bbox_preds], 1)
         cat_pts = torch.cat(points)
         loss_mask = 0
+        loss_iou, num_iou = 0, 0.1                                                        # :404-405
         for i in range(num_imgs):
             labels = torch.cat([l.flatten() for l in lab_img[i]])
             pi = (labels > 0).nonzero().view(-1)
@@ -352,5 +355,43 @@ class SipMaskHead(nn.Module):
             bce = mask_loss(feat_masks[i], img_cof[i][pk], bdt, gt_new, idx)             # [N] per-detection sums
             pre = bce / (bdt[:, 2] - bdt[:, 0]) / (bdt[:, 3] - bdt[:, 1]) / bdt.shape[0]
             loss_mask = loss_mask + torch.sum(pre * weighting)
+            if self.rescoring_flag:                                                       # :463-483
+                li, wi = self._rescoring_loss(feat_masks[i], img_cof[i][pk], bdt, gt_new, idx, labels[pk] - 1)
+                loss_iou, num_iou = loss_iou + li, num_iou + wi
         loss_mask = loss_mask / num_imgs
-        return dict(loss_cls=loss_cls, loss_bbox=loss_bbox, loss_centerness=loss_centerness, loss_mask=loss_mask)
+        out = dict(loss_cls=loss_cls, loss_bbox=loss_bbox, loss_centerness=loss_centerness, loss_mask=loss_mask)
+        if self.rescoring_flag:
+            out["loss_iou"] = loss_iou * 10 / num_iou                                     # :485-486
+        return out
+
+    def _rescoring_loss(self, feat_mask, cof, bdt, gt_new, idx, pos_labels):
+        """SipMask++ rescoring loss of one image (sipmask_head.py:463-483): the DETACHED cropped probability masks of
+        the positives go through convs_scoring (six 3x3 stride-2 convs) + mask_scoring + global max; target = IoU of
+        the mask thresholded at 0.4 with the (uncropped) ground-truth mask.  The conv chain runs on the row-tensor
+        training ops (one 'image' per positive), so gradients reach exactly the scoring branch's parameters."""
+        from . import ops as P
+        from . import ops_rows as R
+        from . import hip_ops as H
+        n = bdt.shape[0]
+        with torch.no_grad():
+            img = feat_mask.detach().float().permute(1, 2, 0)                            # [Hm,Wm,32]
+            c = cof.detach().float()
+            probs = torch.stack([torch.sigmoid(img @ c[:, 32 * q:32 * (q + 1)].t()) for q in range(4)], 0).contiguous()
+            pred = P.crop_split(probs, bdt.detach().float().contiguous(), 2)              # [Hm,Wm,N] cropped probabilities
+            gsel = gt_new[idx].float()                                                   # [N,Hm,Wm] UNcropped gt masks
+            pm = pred.permute(2, 0, 1)
+            mp = (pm > 0.4).float()
+            inter = (mp * gsel).sum((1, 2))
+            gt_area = gsel.sum((1, 2))
+            iou_t = inter / (mp.sum((1, 2)) + gt_area - inter + 0.1)
+            iou_w = ((iou_t > 0.1) & (iou_t <= 1.0) & (gt_area >= 100)).float()
+            hm, wm = pm.shape[1:]
+            x = torch.zeros(n * hm * wm, 8, dtype=torch.bfloat16, device=pm.device)       # 1 channel padded to 8
+            x[:, 0] = pm.reshape(-1)
+        lv = H.Levels(n, [(hm, wm)])
+        for m in self.convs_scoring:
+            x, lv = R.conv_rows(x, lv, m.conv.weight, m.conv.bias, 2, 0, relu=True)
+        x, lv = R.conv_rows(x, lv, self.mask_scoring.weight, self.mask_scoring.bias, 1, 0, relu=True, out_f32=True)
+        h, w = lv.sizes[0]
+        pred_iou = x.view(n, h * w, -1).max(1).values[torch.arange(n, device=x.device), pos_labels]
+        return self.loss_iou(pred_iou.view(-1, 1), iou_t.view(-1, 1), iou_w.view(-1, 1)), iou_w.sum()
