@@ -65,7 +65,7 @@ def head_forward(sd, feats, strides=FPN_STRIDES, prefix="rpn.head."):
         ctrs.append(F.conv2d(bt, sd[h + "centerness.weight"], sd[h + "centerness.bias"], 1, 1))
         bp = F.relu(sd[h + "scales.%d.scale" % l] * F.conv2d(bt, sd[h + "bbox_pred.weight"], sd[h + "bbox_pred.bias"], 1, 1))
         bbox_reg.append(bp * s)
-        off = F.conv2d(bp, sd[h + "feat_align.conv_offset.weight"])
+        off = F.conv2d(bp.detach(), sd[h + "feat_align.conv_offset.weight"])     # FeatureAlign.forward: shape.detach() (sipmask.py:44)
         y = ops.deform_conv(ct, off, sd[h + "feat_align.conv_adaption.weight"], 1, 1, 1, 4) + \
             sd[h + "feat_align.conv_adaption.bias"].view(1, -1, 1, 1)
         y = F.relu(F.group_norm(y, 32, sd[h + "feat_align.norm.weight"], sd[h + "feat_align.norm.bias"], 1e-5))

@@ -124,7 +124,9 @@ class DeformConv(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
                  deformable_groups=1, bias=False):
         super(DeformConv, self).__init__()
-        assert not bias
+        # M/ asserts `not bias` (deform_conv.py:203); the maskrcnn-benchmark module takes one
+        # (B/fcos_core/layers/dcn/deform_conv_module.py:10-50), which its FeatureAlign uses
+        self.with_bias = bool(bias)
         assert in_channels % groups == 0, \
             'in_channels {} cannot be divisible by groups {}'.format(in_channels, groups)
         assert out_channels % groups == 0, \
@@ -140,6 +142,8 @@ class DeformConv(nn.Module):
         self.transposed = False
         self.output_padding = _single(0)
         self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
+        if self.with_bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -161,6 +165,8 @@ class DeformConv(nn.Module):
                           self.deformable_groups)
         if input_pad:
             out = out[:, :, :out.size(2) - pad_h, :out.size(3) - pad_w].contiguous()
+        if self.with_bias:
+            out = out + self.bias.view(1, -1, 1, 1)
         return out
 
 

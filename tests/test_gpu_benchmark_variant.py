@@ -128,3 +128,107 @@ def test_benchmark_checkpoint_conversion_end_to_end():
         d = (a[:, :4] - res["bbox"][i].cpu()).abs().max(1)[0]
         matched += int(d.min() < 0.5)
     assert matched >= 0.9 * n, (matched, n)
+
+
+def _synthetic_targets(g, num_imgs, img_h, img_w, n_gt):
+    rng = np.random.RandomState(int(torch.randint(0, 10000, (1,), generator=g)))
+    out = []
+    yy, xx = np.mgrid[:img_h, :img_w]
+    for _ in range(num_imgs):
+        xy = rng.rand(n_gt, 2) * np.array([img_w * 0.6, img_h * 0.6])
+        wh = rng.rand(n_gt, 2) * np.array([img_w * 0.5, img_h * 0.5]) + 10
+        b = np.concatenate([xy, np.minimum(xy + wh, [img_w - 1, img_h - 1])], 1).astype(np.float32)
+        m = np.zeros((n_gt, img_h, img_w), np.uint8)
+        for k in range(n_gt):
+            cx, cy, rx, ry = (b[k, 0] + b[k, 2]) / 2, (b[k, 1] + b[k, 3]) / 2, (b[k, 2] - b[k, 0]) / 2, (b[k, 3] - b[k, 1]) / 2
+            m[k] = (((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) <= 1.0
+        out.append(dict(bbox=torch.from_numpy(b), labels=torch.from_numpy(rng.randint(1, 81, n_gt).astype(np.int64)), masks=m))
+    return out
+
+
+def test_benchmark_loss_vs_oracle():
+    """SipMaskLossComputation (product side, B/...sipmask/loss.py:330-487) on caller-provided head outputs: the four
+    losses and their gradients w.r.t. every head output against the CPU oracle's autograd (oracle.fcos_core.loss, itself
+    pinned to the reference's own __call__ by fixture L_b_loss).  f32 both sides: 2e-4."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd.benchmark_train import SipMaskLossComputation, compute_locations
+    g = torch.Generator().manual_seed(41)
+    B, C = 2, 80
+    sizes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    strides = (8, 16, 32, 64, 128)
+    mk = lambda c, sc, sh: [(torch.randn(B, c, h, w, generator=g) * sc + sh) for h, w in sizes]
+    cls, ctr, cof = mk(C, 1.5, -3.0), mk(1, 1.0, 0.0), mk(128, 0.3, 0.0)
+    reg = [torch.rand(B, 4, h, w, generator=g) * 3 + 0.5 for h, w in sizes]                # stride units, > 0 (relu'd)
+    fm = torch.randn(B, 32, 64, 80, generator=g)
+    tg = _synthetic_targets(g, B, 128, 160, 5)
+    leaves_r = [[t.clone().requires_grad_() for t in ts] for ts in (cls, reg, ctr, cof)] + [fm.clone().requires_grad_()]
+    ref, labels = OB.loss(leaves_r[0], leaves_r[1], leaves_r[2], leaves_r[3], leaves_r[4], [t["bbox"] for t in tg],
+                          [t["labels"] for t in tg], [t["masks"] for t in tg])
+    assert int((labels > 0).sum()) > 20
+    sum(ref.values()).backward()
+    leaves_d = [[t.cuda().requires_grad_() for t in ts] for ts in (cls, reg, ctr, cof)] + [fm.cuda().requires_grad_()]
+    ev = SipMaskLossComputation()
+    loc = compute_locations(leaves_d[0], strides)
+    out = dict(zip(("loss_cls", "loss_reg", "loss_centerness", "loss_mask"),
+                   ev(loc, leaves_d[0], leaves_d[1], leaves_d[2], leaves_d[3], leaves_d[4], tg)))
+    for k in out:
+        a, b = float(out[k].detach()), float(ref[k].detach())
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (k, a, b)
+    sum(out.values()).backward()
+    flat = lambda L: [t for ts in L[:4] for t in ts] + [L[4]]
+    for a, b in zip(flat(leaves_d), flat(leaves_r)):
+        assert b.grad is not None and a.grad is not None
+        scale = float(b.grad.abs().max()) + 1e-12
+        assert float((a.grad.cpu() - b.grad).abs().max()) <= 2e-4 * scale + 1e-7, (tuple(a.shape), scale)
+
+
+def test_benchmark_head_training_forward_and_step_vs_oracle():
+    """SipMaskBenchmarkHead in training mode (sipmask.py:142-190 on the row-tensor HIP autograd ops): loads the B/
+    parameter names, outputs against the f32 oracle head (bbox_reg in stride units = oracle's eval output / stride),
+    then loss + backward: every parameter receives a gradient close to the oracle's autograd (wiring bound as in
+    test_head_training_step_vs_oracle: cosine > 0.98, relative error < 0.2)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd.benchmark_train import SipMaskBenchmarkModule
+    sd_b = OB.init_head_state_dict(seed=6)
+    with torch.no_grad():
+        sd_b["rpn.head.cls_logits.bias"].fill_(-3.0)
+    mod = SipMaskBenchmarkModule()
+    missing = mod.head.load_state_dict({k[len("rpn.head."):]: v.clone() for k, v in sd_b.items()}, strict=True)
+    mod = mod.cuda().train()
+    g = torch.Generator().manual_seed(8)
+    B = 2
+    sizes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    strides = (8, 16, 32, 64, 128)
+    feats = [torch.randn(B, 256, h, w, generator=g).to(torch.bfloat16).float() for h, w in sizes]
+    tg = _synthetic_targets(g, B, 128, 160, 4)
+    osd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd_b.items()}
+    oref = OB.head_forward(osd, feats)
+    oreg = [r / s for r, s in zip(oref[1], strides)]
+    oloss, labels = OB.loss(oref[0], oreg, oref[2], oref[3], oref[4], [t["bbox"] for t in tg], [t["labels"] for t in tg],
+                            [t["masks"] for t in tg])
+    assert int((labels > 0).sum()) > 10
+    sum(oloss.values()).backward()
+    out = mod.head([f.cuda() for f in feats])
+    for name, got_l, ref_l in zip(("cls", "bbox", "ctr", "cof"), out[:4], (oref[0], oreg, oref[2], oref[3])):
+        for l, (a, b) in enumerate(zip(got_l, ref_l)):
+            assert _rel(a.detach(), b.detach()) < 0.06, (name, l, _rel(a.detach(), b.detach()))
+    assert _rel(out[4].detach(), oref[4].detach()) < 0.05
+    loss = mod([f.cuda() for f in feats], tg)
+    for k in loss:
+        a, b = float(loss[k].detach()), float(oloss[k].detach())
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (k, a, b)
+    sum(loss.values()).backward()
+    bad = []
+    for name, p in mod.head.named_parameters():
+        ref = osd["rpn.head." + name].grad
+        assert p.grad is not None, name
+        if ref is None or float(ref.norm()) == 0.0:
+            continue
+        got = p.grad.cpu().float().reshape(ref.shape)
+        err = float((got - ref).norm() / ref.norm())
+        cos = float((got * ref).sum() / (got.norm() * ref.norm() + 1e-30))
+        if err > 0.2 or cos < 0.98:
+            bad.append((name, round(err, 3), round(cos, 4)))
+    assert not bad, sorted(bad, key=lambda t: -t[1])[:40]
