@@ -228,6 +228,12 @@ int sm_conv2d_bwd(const sm_conv_desc* d, const void* x, const void* w_t, const v
  *   (dX of a strided 1x1 convolution after the channel GEMM). */
 int sm_weight_prep(const float* w, const float* scale, int cout, int cin, int kh, int kw, int mode, void* out,
                    int rows_pad, int kp, int cin_pad, sm_stream_t stream);
+/* sm_weight_prep for many weights in ONE launch (a training step re-lays out ~130 operands).  items: device array of
+ *   struct { const float* w; const float* scale; uint16_t* out; int32 co, ci, kh, kw, mode, kp, cin_pad, tc, tiles_x, pad; }
+ * (tc = channels per tile: 32 for kh*kw <= 9, else 8; tiles_x = ceil(ci / tc)); blocks: device int32 pairs (item, tile) with
+ * tile < tiles_x * ceil(co / 32); lds_bytes >= 4 * 32 * (tc*kh*kw + 1) of the largest item.  The outputs' padding is NOT
+ * touched: allocate them zeroed once (the host side keeps them across steps). */
+int sm_weight_prep_multi(const void* items, const int32_t* blocks, int nblocks, int lds_bytes, sm_stream_t stream);
 int sm_wgrad_finish(const float* grad_w_t, const float* scale, int cout, int cin, int kh, int kw, float* out,
                     sm_stream_t stream);
 int sm_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t n, sm_stream_t stream);

@@ -110,6 +110,7 @@ PROTOTYPES = {
     "sm_mask_rescore": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "sm_conv2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_weight_prep": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    "sm_weight_prep_multi": (_I, [_P, _P, _I, _I, _P]),
     "sm_wgrad_finish": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "sm_relu_bwd_bf16": (_I, [_P, _P, _P, C.c_int64, _P]),
     "sm_bias_grad_rows": (_I, [_P, C.c_int64, _I, _I, _P, _P]),

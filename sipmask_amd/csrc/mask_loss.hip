@@ -20,6 +20,9 @@ namespace {
 
 constexpr int ML_THREADS = 256;
 constexpr int ML_DETS = 32;   // detections staged per pass in the pixel-major kernel
+constexpr int ML_CHUNKS = 16; // blocks per detection in the detection-major kernels: a training image has 50-500 positives
+                              // with boxes of up to the whole grid, so one block per detection leaves most CUs idle and
+                              // the largest box sets the time (0.67 ms per image before the split)
 
 struct MLArgs {
   const float* basis;
@@ -89,7 +92,9 @@ __global__ __launch_bounds__(ML_THREADS) void mask_loss_fwd_kernel(const MLArgs 
   float acc = 0.f;
   if (bw > 0 && bh > 0) {
     const int npix = bw * bh;
-    for (int t = tid; t < npix; t += ML_THREADS) {
+    const int per = (npix + ML_CHUNKS - 1) / ML_CHUNKS;
+    const int t1 = min(npix, ((int)blockIdx.y + 1) * per);
+    for (int t = (int)blockIdx.y * per + tid; t < t1; t += ML_THREADS) {
       const int py = g.ylo + t / bw, px = g.xlo + t % bw;
       const int c = cell_of(g, px, py);
       if (c == -1) continue;
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(ML_THREADS) void mask_loss_fwd_kernel(const MLArgs 
   if (tid == 0) {
     float t = 0.f;
     for (int w = 0; w < ML_THREADS / 64; ++w) t += s_red[w];
-    out[n] = t;
+    if (t != 0.f) atomicAdd(out + n, t);        // out is zeroed by the host entry point
   }
 }
 
@@ -125,15 +130,19 @@ __global__ __launch_bounds__(ML_THREADS) void mask_loss_bwd_cof_kernel(const MLA
   const int bw = g.xhi - g.xlo + 1, bh = g.yhi - g.ylo + 1;
   const uint8_t* gt = a.gt + a.idx_gt[n] * (long long)a.hm * a.wm;
   const float go = gsum[n];
+  bool block_any = false;
   if (bw > 0 && bh > 0) {
     const int npix = bw * bh;
+    const int per = (npix + ML_CHUNKS - 1) / ML_CHUNKS;
+    const int t0 = (int)blockIdx.y * per, t1 = min(npix, t0 + per);
+    block_any = t0 < t1;
     // quadrant by quadrant, so that a thread accumulates one 32-vector in registers at a time
     for (int q = 0; q < 4; ++q) {
       float acc[32];
 #pragma unroll
       for (int k = 0; k < 32; ++k) acc[k] = 0.f;
       bool any = false;
-      for (int t = tid; t < npix; t += ML_THREADS) {
+      for (int t = t0 + tid; t < t1; t += ML_THREADS) {
         const int py = g.ylo + t / bw, px = g.xlo + t % bw;
         if (cell_of(g, px, py) != q) continue;
         const long long pix = (long long)py * a.wm + px;
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(ML_THREADS) void mask_loss_bwd_cof_kernel(const MLA
     }
   }
   __syncthreads();
-  if (tid < 128) gcof[(long long)n * 128 + tid] = s_acc[tid];
+  if (tid < 128 && block_any && s_acc[tid] != 0.f) atomicAdd(gcof + (long long)n * 128 + tid, s_acc[tid]);   // gcof zeroed by the host
 }
 
 struct DetStage {
@@ -236,7 +245,8 @@ extern "C" int sm_mask_loss_fwd(const float* basis, int basis_hwc, const float* 
   if (st != SM_OK) return st;
   if (!bce_sum) return SM_ERR_BAD_ARG;
   if (n == 0) return SM_OK;
-  hipLaunchKernelGGL(mask_loss_fwd_kernel, dim3(n), dim3(ML_THREADS), 0, sm_hip_stream(stream), a, bce_sum);
+  if (hipMemsetAsync(bce_sum, 0, sizeof(float) * n, sm_hip_stream(stream)) != hipSuccess) return SM_ERR_LAUNCH;
+  hipLaunchKernelGGL(mask_loss_fwd_kernel, dim3(n, ML_CHUNKS), dim3(ML_THREADS), 0, sm_hip_stream(stream), a, bce_sum);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -250,7 +260,8 @@ extern "C" int sm_mask_loss_bwd(const float* basis, int basis_hwc, const float* 
   if (!grad_sum) return SM_ERR_BAD_ARG;
   hipStream_t s = sm_hip_stream(stream);
   if (grad_cof && n > 0) {
-    hipLaunchKernelGGL(mask_loss_bwd_cof_kernel, dim3(n), dim3(ML_THREADS), 0, s, a, grad_sum, grad_cof);
+    if (hipMemsetAsync(grad_cof, 0, sizeof(float) * 128 * n, s) != hipSuccess) return SM_ERR_LAUNCH;
+    hipLaunchKernelGGL(mask_loss_bwd_cof_kernel, dim3(n, ML_CHUNKS), dim3(ML_THREADS), 0, s, a, grad_sum, grad_cof);
   }
   if (grad_basis) {
     hipLaunchKernelGGL(mask_loss_bwd_basis_kernel, dim3(sm_cdiv(wm, 64), sm_cdiv(hm, 4)), dim3(ML_THREADS), 0, s, a,

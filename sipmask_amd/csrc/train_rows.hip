@@ -32,12 +32,12 @@ inline int grid_for(long long n, int block) {
 // A block owns a tile of 32 couts x 32 cins (all taps): it reads the 32 rows of w coalesced (the (c, tap) axis is
 // contiguous in OIHW) into LDS and writes 16-byte pieces of 8 consecutive channels (mode 0) / couts (modes 1, 2).
 constexpr int WP_T = 32;
-__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                                          uint16_t* __restrict__ out, int co, int ci, int kh, int kw, int mode,
-                                                          int kp, int cin_pad, int tc) {
-  extern __shared__ float tile[];                    // [32 o][tc c * kk + 1]; tc = channels per tile (32, or 8 for big kernels)
+__device__ __forceinline__ void weight_prep_tile(const float* __restrict__ w, const float* __restrict__ scale,
+                                                 uint16_t* __restrict__ out, int co, int ci, int kh, int kw, int mode,
+                                                 int kp, int cin_pad, int tc, int bx, int by, float* tile) {
+  // tile: [32 o][tc c * kk + 1]; tc = channels per tile (32, or 8 for big kernels)
   const int kk = kh * kw;
-  const int o0 = blockIdx.y * WP_T, c0 = blockIdx.x * tc;
+  const int o0 = by * WP_T, c0 = bx * tc;
   const int cw = min(tc, ci - c0);                   // live channels of the tile
   const int pitch = tc * kk + 1;
   const int nch = tc >> 3;                           // 8-wide pieces along the channel / cout axis of a tile
@@ -73,6 +73,28 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
       *reinterpret_cast<uint4*>(out + at) = pack_bf16x8(v);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                          uint16_t* __restrict__ out, int co, int ci, int kh, int kw, int mode,
+                                                          int kp, int cin_pad, int tc) {
+  extern __shared__ float wp_tile[];
+  weight_prep_tile(w, scale, out, co, ci, kh, kw, mode, kp, cin_pad, tc, blockIdx.x, blockIdx.y, wp_tile);
+}
+
+// every conv of a training step in ONE launch: item table on the device, (item, tile) list per block
+struct WPItem {
+  const float* w;
+  const float* scale;
+  uint16_t* out;
+  int co, ci, kh, kw, mode, kp, cin_pad, tc, tiles_x, pad_;
+};
+__global__ __launch_bounds__(256) void weight_prep_multi_kernel(const WPItem* __restrict__ items, const int2* __restrict__ blocks) {
+  extern __shared__ float wp_tile[];
+  const int2 bk = blocks[blockIdx.x];
+  const WPItem it = items[bk.x];
+  weight_prep_tile(it.w, it.scale, it.out, it.co, it.ci, it.kh, it.kw, it.mode, it.kp, it.cin_pad, it.tc, bk.y % it.tiles_x,
+                   bk.y / it.tiles_x, wp_tile);
 }
 
 // gw_t [kh*kw*ci][co] f32 -> out [co][ci][kh][kw] f32 (x scale[o]); thread per output element, reads are strided by co
@@ -415,6 +437,15 @@ extern "C" int sm_weight_prep(const float* w, const float* scale, int cout, int 
   if (lds > 64 * 1024) return SM_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(weight_prep_kernel, dim3((cin + tc - 1) / tc, (cout + WP_T - 1) / WP_T), dim3(256), lds, s, w, scale,
                      (uint16_t*)out, cout, cin, kh, kw, mode, kp, cin_pad, tc);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_weight_prep_multi(const void* items, const int32_t* blocks, int nblocks, int lds_bytes, sm_stream_t stream) {
+  if (!items || !blocks || lds_bytes < 0 || lds_bytes > 64 * 1024) return SM_ERR_BAD_ARG;
+  if (nblocks < 1) return SM_OK;
+  hipLaunchKernelGGL(weight_prep_multi_kernel, dim3(nblocks), dim3(256), (size_t)lds_bytes, sm_hip_stream(stream),
+                     (const WPItem*)items, (const int2*)blocks);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -162,6 +162,9 @@ def head_train_step(head, feats, gt_bboxes, gt_labels, gt_masks, img_metas, opti
     -> loss -> backward (bucketed all-reduce overlapped) -> SGD.  Returns the loss dict (detached floats)."""
     head.train()
     optimizer.zero_grad()
+    if feats[0].is_cuda:
+        from .ops_rows import begin_step
+        begin_step()
     out = head(feats)
     losses = head.loss(*out, gt_bboxes, gt_labels, img_metas, train_cfg, gt_masks_list=gt_masks)
     total = sum(losses.values())
@@ -177,6 +180,9 @@ def detector_train_step(det, img, img_metas, gt_bboxes, gt_labels, gt_masks, opt
     autograd ops for backbone stages 2-4, FPN and head; BN and stage 1 frozen as in the config) -> backward with the
     bucketed all-reduce overlapped -> SGD.  Returns the loss dict (floats)."""
     optimizer.zero_grad()
+    if img.is_cuda:
+        from .ops_rows import begin_step
+        begin_step()
     losses = det.forward_train(img, img_metas, gt_bboxes, gt_labels, gt_masks=gt_masks)
     sum(losses.values()).backward()
     if bucketer is not None:

@@ -317,6 +317,12 @@ def rows_to_nchw(y, batch, h, w):
     return y.view(batch, h, w, y.shape[1]).permute(0, 3, 1, 2)
 
 
+def begin_step():
+    """start of a training step: re-lay out every cached conv-parameter operand that changed since the last step in one
+    launch (hip_ops.WEIGHT_PREP_CACHE).  Optional -- without it each operand is refreshed by its own launch on first use."""
+    return H.WEIGHT_PREP_CACHE.refresh()
+
+
 _FOLD_CACHE = {}
 
 

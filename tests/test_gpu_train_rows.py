@@ -250,3 +250,34 @@ def test_mask_feat_rows_forward_backward():
             torch.testing.assert_close(got, xs[l].grad, rtol=2 ** -7, atol=2e-2)
         else:
             assert float(got.abs().max()) == 0.0
+
+
+def test_weight_prep_cache_refreshes_all_stale_operands_in_one_launch():
+    """hip_ops.WEIGHT_PREP_CACHE: parameters get persistent operand buffers; refresh() (ops_rows.begin_step) rewrites
+    exactly the ones whose parameter / scale changed (in-place update under no_grad = what an optimizer step or a
+    checkpoint load does) through sm_weight_prep_multi, with results identical to the single-operand launch"""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    cache = H._WeightPrepCache()
+    shapes = ((64, 3, 7, 8), (256, 64, 1, 64), (72, 128, 3, 128), (8, 256, 3, 256), (128, 512, 1, 512))
+    params = [torch.nn.Parameter(torch.randn(co, ci, k, k, generator=g).to(dev)) for co, ci, k, _ in shapes]
+    scales = [None, (torch.rand(256, generator=g) + 0.5).to(dev), None, None, (torch.rand(128, generator=g) + 0.5).to(dev)]
+    req = [(p, s, m, cp if m == 0 else None) for p, s, (_, _, _, cp) in zip(params, scales, shapes) for m in (0, 1, 2)
+           if not (m != 0 and p.shape[1] == 3)]
+    first = [cache.get(*r)[0] for r in req]
+    assert all(cache.get(*r)[0] is f for r, f in zip(req, first))          # served from the cache, no new buffer
+    assert cache.refresh() == 0
+    with torch.no_grad():
+        for p in params[1:]:
+            p.mul_(1.5).add_(0.01)
+        scales[1].mul_(0.5)
+    n = cache.refresh()
+    assert n == len([r for r in req if r[0] is not params[0]])
+    for (p, s, m, cp), buf in zip(req, first):
+        ref, _ = H.prep_conv_weight(*{0: (p.detach() if s is None else p.detach() * s.view(-1, 1, 1, 1), cp),
+                                      1: ((p.detach() if s is None else p.detach() * s.view(-1, 1, 1, 1)).flip(2, 3).permute(1, 0, 2, 3).contiguous(), p.shape[0]),
+                                      2: ((p.detach() if s is None else p.detach() * s.view(-1, 1, 1, 1)).permute(2, 3, 1, 0).reshape(-1, p.shape[0], 1, 1).contiguous(), p.shape[0])}[m])
+        assert torch.equal(cache.get(p, s, m, cp)[0], ref), (tuple(p.shape), m)
+        assert cache.get(p, s, m, cp)[0] is buf
+    assert cache.refresh() == 0
