@@ -320,7 +320,11 @@ def run_train(args, rank, world, dev):
     gtb, gtl, gtm = synthetic_gt(rank, B, IMG_H, IMG_W, dev)
     metas = [dict(img_shape=(IMG_H, IMG_W, 3), pad_shape=(IMG_H, IMG_W, 3), scale_factor=1.0) for _ in range(B)]
     opt = HipSGD(det.named_parameters(), lr=0.0005, momentum=0.9, weight_decay=1e-4)
-    bucket = GradBucketer([p for p in det.parameters() if p.requires_grad]) if world > 1 else None
+    # SIPMASK_FORCE_DIST=1 (one rank under a launcher): run the collective path anyway -- a 1-GPU box can then execute the
+    # RCCL all-reduce of the gradient buckets (world size 1) that the N-GPU job uses
+    import torch.distributed as dist
+    forced = dist.is_available() and dist.is_initialized()
+    bucket = GradBucketer([p for p in det.parameters() if p.requires_grad], force=forced) if (world > 1 or forced) else None
     losses = {}
 
     def step():
@@ -346,7 +350,7 @@ def run_train(args, rank, world, dev):
                                "f32 master weights, SGD momentum .9 wd 1e-4" % (args.depth, B),
                    "global_batch": B * world,
                    "parallelism": "dp%d (gradient all-reduce over %s, 64 MB buckets overlapped with backward)" %
-                                  (world, "RCCL" if world > 1 else "no collective at 1 GPU"),
+                                  (world, "RCCL" if bucket is not None else "no collective at 1 GPU"),
                    "losses": {k: round(v, 4) for k, v in losses.items()},
                    "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -443,9 +447,10 @@ def main():
         assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("SIPMASK_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group("gloo" if STUB else "nccl", rank=rank, world_size=world)
         assert dist.get_world_size() == world
     if STUB:
@@ -463,7 +468,7 @@ def main():
         line.update(out)
         line.setdefault("cpu_baseline", None)
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or os.environ.get("SIPMASK_FORCE_DIST") == "1":
         import torch.distributed as dist
         dist.destroy_process_group()
 

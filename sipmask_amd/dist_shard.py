@@ -25,6 +25,13 @@ def shard_range(n_items, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _collective(ws):
+    """collectives run for world size > 1 -- and, with SIPMASK_FORCE_DIST=1 under an initialised process group, also for a
+    single rank (a 1-GPU box then executes the same RCCL calls the N-GPU job issues)"""
+    import os
+    return ws > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get("SIPMASK_FORCE_DIST") == "1")
+
+
 def timed_steps(step_fn, steps, sync_fn=None, device=None):
     """Run ``step_fn`` ``steps`` times between two (barrier + device sync) fences and return the MAX
     elapsed seconds over ranks -- the bench.py contract."""
@@ -33,7 +40,7 @@ def timed_steps(step_fn, steps, sync_fn=None, device=None):
     def fence():
         if sync_fn is not None:
             sync_fn()
-        if ws > 1:
+        if _collective(ws):
             dist.barrier()
             if sync_fn is not None:
                 sync_fn()
@@ -44,7 +51,7 @@ def timed_steps(step_fn, steps, sync_fn=None, device=None):
         step_fn()
     fence()
     elapsed = time.perf_counter() - t0
-    if ws > 1:
+    if _collective(ws):
         t = torch.tensor([elapsed], dtype=torch.float64, device=device or "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -56,7 +63,7 @@ def gather_counts(local_counts, device=None):
     concatenated in rank order = global image order of shard_range."""
     rank, ws = world()
     t = torch.as_tensor(local_counts, dtype=torch.int64, device=device or "cpu").reshape(-1)
-    if ws == 1:
+    if not _collective(ws):
         return t
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(ws)]

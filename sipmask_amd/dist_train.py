@@ -24,10 +24,12 @@ class GradBucketer:
     order, so all ranks issue the same sequence of equally sized all-reduces (no RCCL hang, no mispaired buffers).
     Parameters without a gradient contribute zeros, as DDP(find_unused_parameters=True) would."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, force=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force: issue the all-reduces even in a one-rank group (exercises the RCCL path on a 1-GPU box)
+        self.force = bool(force) and dist.is_initialized()
         self.buckets = []                 # dict(flat, params, offsets, pending, work)
         cur, size = [], 0
         for p in reversed(self.params):
@@ -58,7 +60,7 @@ class GradBucketer:
         """launch, in index order, every bucket that is full (all of them when force)"""
         while self._next < len(self.buckets) and (force or self.buckets[self._next]["pending"] == 0):
             b = self.buckets[self._next]
-            if self.world > 1:
+            if self.world > 1 or self.force:
                 b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._next += 1
 
