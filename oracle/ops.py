@@ -247,8 +247,13 @@ def fast_nms(boxes, scores, cofs, iou_threshold=0.5, top_k=200, score_thr=0.1, m
 # ----------------------------------------------------------------------------
 
 
-def deform_conv(x, offset, weight, stride=1, padding=1, dilation=1, deformable_groups=1):
+def deform_conv(x, offset, weight, stride=1, padding=1, dilation=1, deformable_groups=1, col_round=None):
     """Deformable conv v1 forward, groups=1.
+
+    col_round (test aid, not in the reference): applied to the sampled columns before the contraction -- the bf16 plan
+    blends the four corners in f32 and rounds the SAMPLE once to bf16 (the MFMA operand type); with
+    col_round=lambda t: t.bfloat16().float() this restatement follows that arithmetic, so the kernel can be held to
+    it tightly (accumulation order + rare rounding flips) instead of to a bound that has to absorb operand rounding.
 
     Sampling: M/mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:191-243 (offset
     channel layout [g, 2*(i*kw+j)+{0:h,1:w}] :216,222-223; sample taken iff
@@ -303,6 +308,8 @@ def deform_conv(x, offset, weight, stride=1, padding=1, dilation=1, deformable_g
                 w3 = (lh * hw).unsqueeze(1)
                 w4 = (lh * lw).unsqueeze(1)
                 cols[:, g, :, t] = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4
+    if col_round is not None:
+        cols = col_round(cols)
     cols = cols.view(B, C * kh * kw, Ho * Wo)
     out = torch.matmul(weight.reshape(Co, C * kh * kw), cols)
     return out.view(B, Co, Ho, Wo)

@@ -28,8 +28,15 @@ class SipMask(nn.Module):
         return self.neck is not None
 
     def init_weights(self, pretrained=None):
-        self.backbone.init_weights(pretrained=pretrained if isinstance(pretrained, str) and
-                                   not pretrained.startswith("open-mmlab://") else None)
+        if isinstance(pretrained, str) and pretrained.startswith(("open-mmlab://", "http://", "https://", "modelzoo://")):
+            # every reference sipmask config names a model-zoo URL (pretrained='open-mmlab://resnet50_caffe'); there is no
+            # downloader here, so say loudly that the backbone starts from random weights instead of doing it silently
+            import warnings
+            warnings.warn("SipMask.init_weights: pretrained=%r cannot be resolved (no model-zoo access): the backbone is "
+                          "RANDOMLY initialised -- pass a local checkpoint path or load_state_dict() afterwards" % pretrained,
+                          RuntimeWarning, stacklevel=2)
+            pretrained = None
+        self.backbone.init_weights(pretrained=pretrained if isinstance(pretrained, str) else None)
         if self.with_neck:
             self.neck.init_weights()
         self.bbox_head.init_weights()

@@ -251,6 +251,9 @@ class ResNet(nn.Module):
         stages run without a graph; BN is always in eval mode (norm_eval, cfg requires_grad=False)."""
         from . import ops_rows as R
         from . import hip_ops as H
+        if not self.norm_eval or self.frozen_stages < 0:
+            raise NotImplementedError("ResNet.forward_rows implements the sipmask configs: norm_eval=True and "
+                                      "frozen_stages >= 0 (got norm_eval=%r, frozen_stages=%r)" % (self.norm_eval, self.frozen_stages))
         b, _, hh, ww = img.shape
         outs = []
         with torch.no_grad():
@@ -276,6 +279,10 @@ class ResNet(nn.Module):
         """resnet.py:501-512 as a differentiable graph (BN always in eval mode: norm_eval, cfg requires_grad=False).
         Frozen stages run without building a graph.  x: [B,3,H,W] float on the device."""
         from . import ops as P
+        if not self.norm_eval or self.frozen_stages < 0:
+            # the training graph folds eval-mode BatchNorm into the convs and runs the stem without a graph
+            raise NotImplementedError("ResNet.forward_train implements the sipmask configs: norm_eval=True and "
+                                      "frozen_stages >= 0 (got norm_eval=%r, frozen_stages=%r)" % (self.norm_eval, self.frozen_stages))
         if _train_rows_enabled(x):
             from .ops_rows import rows_to_nchw
             return tuple(rows_to_nchw(r, lv.batch, *lv.sizes[0]) for r, lv in self.forward_rows(x))

@@ -458,10 +458,17 @@ def multiclass_nms_idx(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-
     boxes = multi_bboxes.float().contiguous().view(1, k, 4)
     ctr = (torch.ones(1, k, device=dev) if score_factors is None else score_factors.float().contiguous().view(1, k))
     ncand = torch.full((1,), k, dtype=torch.int32, device=dev)
+    # max_num <= 0 means "no cap" in the reference (bbox_nms.py:139-143): every (box, class) pair above score_thr can
+    # survive, so the output is sized for all of them
+    # the kernel's output list holds at most 2048 detections (TK_CAP, csrc/detect.hip)
     cap = max_num if max_num > 0 else min(k * c, 2048)
     out = H.multiclass_nms_alloc(1, k, c, cap, dev)
     H.multiclass_nms(boxes, scores, ctr, ncand, score_thr, iou_thr, cap, out)
     n = int(out["ndet"][0].item())
+    if max_num <= 0 and n == cap and cap < k * c:
+        # never truncate silently: an uncapped call that fills the kernel's list may have lost detections
+        raise RuntimeError("multiclass_nms_idx(max_num=-1): %d detections survive NMS, the device list holds %d; pass max_num"
+                           % (n, cap))
     return out["det"][0, :n], out["labels"][0, :n], out["keep"][0, :n]
 
 
