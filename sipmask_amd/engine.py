@@ -96,7 +96,7 @@ class _Conv:
                 # (sm_conv3x3_patch_plan).  Take the kernel when the launch is a reasonable share of a round of 256 CUs,
                 # the planned shape keeps the CUs busy (fill = work / (256 x makespan)) and the couts fill most of the
                 # 256-wide tile (sip_mask_lat, 128 -> 32: 0.061 ms on the 32 x 256 implicit-GEMM tile, 0.101 ms here with
-                # 7/8 of the MFMAs on padding).  Measured: profiles/r02*_patch_conv_microbench.txt, r03*.
+                # 7/8 of the MFMAs on padding).  Measured: profiles/r02d_patch_conv_microbench.txt, r02g_patch_tile_shapes_microbench.txt.
                 if (pl["work"] >= _PATCH_MIN_WORK and (pl["fill"] >= _PATCH_MIN_FILL or pl["makespan"] <= 1.0)
                         and co * 4 >= 3 * ((co + 255) // 256 * 256)):
                     self.patch = True
@@ -239,7 +239,7 @@ class SipMaskEngine:
         self.split_k = _SPLIT_K and not sub_plan
         # ... and for the same reason its patch convs keep the uniform 256-position launch: the mixed launch (256-position
         # tiles + 128/192-position finishing tiles, sm_conv3x3_patch_plan) ends a lone launch 15-20 % sooner but spends
-        # 4-6 % more CU time on it, which the other chain would have used (measured 998 vs 991 img/s, profiles/r03a_*)
+        # 4-6 % more CU time on it, which the other chain would have used (measured 998 vs 991 img/s, profiles/r02g_ab_patch_launch_shape.json)
         self.patch_uniform = sub_plan
         if precision not in ("bf16", "f32"):
             raise ValueError("precision must be 'bf16' (throughput plan) or 'f32' (parity plan), got %r" % (precision,))

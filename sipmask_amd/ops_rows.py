@@ -3,7 +3,7 @@
 The reference trains through ATen/cuDNN layer by layer on NCHW float tensors (M/mmdet/models/backbones/resnet.py:205-239,
 necks/fpn.py:137-178, anchor_heads/sipmask_head.py:241-287).  The first version here (ops.py: conv2d / group_norm /
 deform_conv on NCHW float tensors) kept that interface per op and paid for it between the ops: 19 ms of a 62 ms step
-were ATen copies, casts, fills and adds, 7 ms NCHW<->NHWC transposes (profiles/r03_train_kernel_stats_before.csv).
+were ATen copies, casts, fills and adds, 7 ms NCHW<->NHWC transposes (profiles/r02h_train_kernel_stats_before.csv).
 These ops exchange what the MFMA kernels read and write -- `[positions, channels]` bf16 matrices, all images of all
 pyramid levels in one tensor (hip_ops.Levels carries the geometry) -- and fuse bias / frozen-BN fold / ReLU / residual
 into the conv launches:
