@@ -66,6 +66,10 @@ typedef enum {
 #define SM_CONV_DBG_PATCH_SMALL128 0x00002000u /* A/B switch (sm_conv3x3_patch): only 128-position tiles finish a launch */
 #define SM_CONV_DBG_PATCH_SMALL192 0x00001000u /* A/B switch (sm_conv3x3_patch): only 192-position tiles finish a launch */
 #define SM_CONV_DBG_PATCH_PIPE 0x00000800u     /* A/B switch (sm_conv3x3_patch): fragment reads of sub-step i+1 pinned under the MFMAs of sub-step i */
+#define SM_CONV_DBG_PATCH_STAGGER 0x00000400u  /* A/B switch (sm_conv3x3_patch): waves 4-7 issue their LDS-DMA between the two taps of a stage */
+#define SM_CONV_DBG_PATCH_NO_DMA 0x00000200u   /* ABLATION (micro-benchmark only, wrong results): no LDS-DMA in the main loop */
+#define SM_CONV_DBG_PATCH_NO_MFMA 0x00000100u  /* ABLATION (micro-benchmark only, wrong results): no MFMA / fragment reads in the main loop */
+#define SM_CONV_DBG_PATCH_PINGPONG 0x00000080u /* A/B switch (sm_conv3x3_patch): ping-pong schedule, waves 0-3 compute while waves 4-7 load and vice versa */
 #define SM_CONV_DBG_NO_SPLITK 0x00010000u   /* A/B switch: sm_conv2d_ws never splits K */
 #define SM_CONV_DBG_WARP_SPEC 0x02000000u    /* A/B switch: 8-wave producer/consumer variant of the 64-wide-K kernel */
 

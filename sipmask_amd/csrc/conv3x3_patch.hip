@@ -69,9 +69,14 @@ constexpr int PT_MAXPP = 6;                       // patch DMA pieces per wave (
 // One tile: 256 couts x (WPOS * TPOS * 32) positions on 8 waves laid out WCO (cout) x WPOS (position), each wave
 // TCO x TPOS MFMA tiles of 32 x 32.  <2,4,4,2> is the 256-position tile; <4,2,2,3> / <4,2,2,2> are the 192- / 128-
 // position tiles that finish a launch whose last round of 256-tiles would leave most CUs idle.
-template <int WCO, int WPOS, int TCO, int TPOS, bool PIPE>
+template <int WCO, int WPOS, int TCO, int TPOS, int VAR>
 __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, const int tlin, unsigned char* const smem) {
   static_assert(WCO * WPOS == 8 && WCO * TCO * 32 == PT_BCO, "8 waves, 256 couts");
+  // VAR bits: 1 = software-pipelined stage, 2 = staggered DMA issue (waves 4-7 issue theirs between the two taps of a stage,
+  // so the two waves of a SIMD are never both stalled in the LDS-DMA issue); 4 / 8 = ABLATIONS for the micro-benchmark
+  // (no DMA / no MFMA in the main loop: wrong results by construction, never used by the library's own launches)
+  constexpr bool PIPE = (VAR & 1) != 0, STAGGER = (VAR & 2) != 0, NO_DMA = (VAR & 4) != 0, NO_MFMA = (VAR & 8) != 0;
+  constexpr bool PINGPONG = (VAR & 16) != 0;
   constexpr int BPOS = WPOS * TPOS * 32;
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -197,21 +202,129 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   sfor<PT_MAXPP>([&](auto I) { dma_patch_piece(I, 0, 0); });
   dma_w(0, 0);
   __syncthreads();
+  if constexpr (PINGPONG) {
+    // ---- ping-pong schedule (MI355X_MICROARCH.md, "Two waves per SIMD"): the block's waves form two groups, A = waves
+    // 0-3 and B = waves 4-7 (one of each per SIMD).  Time runs in slots separated by raw s_barriers; in every slot one
+    // group issues the 2*TCO*TPOS MFMAs of a tap back to back -- it has the SIMD's matrix pipe to itself -- while the other
+    // group reads ITS fragments of the next tap from LDS and issues its share of the LDS-DMA.  Slot 2T: A computes tap T,
+    // B loads tap T; slot 2T+1: A loads tap T+1, B computes tap T.  One fragment register set per wave (load and compute
+    // alternate).  The profile of the stage-synchronous loop above (tools/patch_variants_bench.py): both waves of a SIMD
+    // wait for LDS / the barrier at the same moments, 54 us per tile even with the DMA removed against 31 us of MFMA time.
+    // Hazards (T = 2*stage + hh; reads of tap T happen in slots 2T-1 (A) and 2T (B)):
+    //  * weight buffer (s+1)&1 was last read for tap 2s-1 in slot 4s-2; A issues stage s+1's DMA in slot 4s-1, B in slot
+    //    4s; every wave drains its DMA (vmcnt(0)) at the end of slot 4s+2, the first read of the data is in slot 4s+3;
+    //  * patch pieces ride with the weight DMA of the same stages as before (chunk c0+1 with stages 0-2, c0+2 with 5-7);
+    //  * a loading wave waits for its own ds_reads (lgkmcnt(0)) before the barrier, so a buffer is never overwritten
+    //    while a read of it is in flight.  The barriers are raw s_barrier: they must not drain the DMA queue.
+    const bool grp_a = wave < 4;
+    bf16x8 wf[2][TCO], xf[2][TPOS];
+    auto load_tap = [&](int st, auto SC) {                 // fragments of tap SC (0..17 inside the pair) of stage st
+      constexpr int sidx = decltype(SC)::value;
+      constexpr int hh = sidx & 1;
+      constexpr int cc = sidx / 9, t9 = sidx % 9, kh = t9 / 3, kw = t9 % 3;
+      const unsigned char* Wh = Wb0 + (st & 1) * PT_WSTAGE + hh * (PT_BCO * 64);
+      const unsigned char* P = Pb0 + cc * PB;
+      // the patch-row addresses of the 18 taps are invariant over the channel-chunk loop and hipcc hoists all of them
+      // (36+ VGPRs held across the loop -> spills next to 128 accumulators + 48 fragment registers); an opaque copy of
+      // the row pitch makes them a per-tap recomputation of ~5 VALU in the load slot instead
+      int wp_l = Wp;
+      asm volatile("" : "+s"(wp_l));
+      const int shift = kh * wp_l + kw;
+      // t*32 rows do not change (row >> 2) & 3: one swizzle per tap, the K-half is one XOR with 32 bytes
+      const int pr0 = prow0 + shift;
+      const int xa = pr0 * 64 + ((khalf ^ ((pr0 >> 2) & 3)) * 16);
+      const int wa = wrow_off + ((khalf ^ rsw) * 16);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int t = 0; t < TCO; ++t)
+          wf[kk][t] = *reinterpret_cast<const bf16x8*>(Wh + (wa ^ (kk * 32)) + t * 32 * 64);
+#pragma unroll
+        for (int t = 0; t < TPOS; ++t)
+          xf[kk][t] = *reinterpret_cast<const bf16x8*>(P + (xa ^ (kk * 32)) + t * 32 * 64);
+      }
+    };
+    auto compute_tap = [&]() {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+          for (int tp = 0; tp < TPOS; ++tp)
+            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][tc], xf[kk][tp], acc[tc][tp], 0, 0, 0);
+    };
+    auto issue_stage = [&](int cpv, auto SPC) {            // the DMA the old loop issues at the top of stage (cpv, sp)
+      constexpr int sp = decltype(SPC)::value;
+      const int st = cpv * 9 + sp, c0 = 2 * cpv;
+      if (st + 1 < nstage) dma_w(st + 1, (st + 1) & 1);
+      if constexpr (sp < 3) {
+        dma_patch_piece(std::integral_constant<int, 2 * sp>{}, c0 + 1, 1);
+        dma_patch_piece(std::integral_constant<int, 2 * sp + 1>{}, c0 + 1, 1);
+      } else if constexpr (sp >= 5 && sp < 8) {
+        if (cpv + 1 < npair) {
+          dma_patch_piece(std::integral_constant<int, 2 * (sp - 5)>{}, c0 + 2, 0);
+          dma_patch_piece(std::integral_constant<int, 2 * (sp - 5) + 1>{}, c0 + 2, 0);
+        }
+      }
+    };
+    // sched_barrier(0): nothing may be scheduled across -- an asm statement orders memory operations only, and hipcc moved
+    // MFMAs (register-only) and fragment reads from one slot into the next, which is exactly what the slots forbid
+    auto bar = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto wait_lds = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto wait_dma = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // ONE instruction stream for both groups -- L(0) C(0) L(1) C(1) ... with a barrier after every segment -- in which group
+    // A skips the very first barrier: from then on A runs one segment ahead of B (A computes tap T while B loads it, A loads
+    // tap T+1 while B computes T).  A executes one extra barrier at the end.
+    for (int cp = 0; cp < npair; ++cp) {
+      sfor<18>([&](auto SC) {
+        constexpr int sidx = decltype(SC)::value;           // tap inside the pair
+        constexpr int sp = sidx >> 1, hh = sidx & 1;
+        const int st = cp * 9 + sp;
+        if constexpr (hh == 0 && !NO_DMA) issue_stage(cp, std::integral_constant<int, sp>{});
+        load_tap(st, SC);                                   // segment L(T)
+        wait_lds();
+        if constexpr (hh == 1) {
+          if (!grp_a) wait_dma();
+        }
+        if (!(grp_a && cp == 0 && sidx == 0)) bar();
+        if constexpr (!NO_MFMA) compute_tap();              // segment C(T)
+        if constexpr (hh == 1) {
+          if (grp_a) wait_dma();
+        }
+        bar();
+      });
+    }
+    if (grp_a) bar();
+    __syncthreads();
+  } else
   for (int cp = 0; cp < npair; ++cp) {
     const int c0 = 2 * cp;
     sfor<9>([&](auto SP) {
       constexpr int sp = decltype(SP)::value;
       const int st = cp * 9 + sp;                                  // global stage index (parity = W buffer)
-      if (st + 1 < nstage) dma_w(st + 1, (st + 1) & 1);
-      if constexpr (sp < 3) {                                      // patch of the pair's second chunk
-        dma_patch_piece(std::integral_constant<int, 2 * sp>{}, c0 + 1, 1);
-        dma_patch_piece(std::integral_constant<int, 2 * sp + 1>{}, c0 + 1, 1);
-      } else if constexpr (sp >= 5 && sp < 8) {                    // patch of the NEXT pair's first chunk
-        if (cp + 1 < npair) {
-          dma_patch_piece(std::integral_constant<int, 2 * (sp - 5)>{}, c0 + 2, 0);
-          dma_patch_piece(std::integral_constant<int, 2 * (sp - 5) + 1>{}, c0 + 2, 0);
+      auto issue_dma = [&]() {
+        if constexpr (!NO_DMA) {
+          if (st + 1 < nstage) dma_w(st + 1, (st + 1) & 1);
+          if constexpr (sp < 3) {                                    // patch of the pair's second chunk
+            dma_patch_piece(std::integral_constant<int, 2 * sp>{}, c0 + 1, 1);
+            dma_patch_piece(std::integral_constant<int, 2 * sp + 1>{}, c0 + 1, 1);
+          } else if constexpr (sp >= 5 && sp < 8) {                  // patch of the NEXT pair's first chunk
+            if (cp + 1 < npair) {
+              dma_patch_piece(std::integral_constant<int, 2 * (sp - 5)>{}, c0 + 2, 0);
+              dma_patch_piece(std::integral_constant<int, 2 * (sp - 5) + 1>{}, c0 + 2, 0);
+            }
+          }
         }
-      }
+      };
+      const bool early = !STAGGER || wave < 4;                      // wave-uniform (SGPR)
+      if (early) issue_dma();
       const unsigned char* Wst = Wb0 + (st & 1) * PT_WSTAGE;
       if constexpr (PIPE) {
         // software-pipelined stage: 4 sub-steps (tap hh, K half kk) of TCO*TPOS MFMAs; the fragments of sub-step i+1 are
@@ -241,12 +354,16 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
         __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);
         sfor<4>([&](auto IC) {
           constexpr int i = decltype(IC)::value;
+          if constexpr (i == 2 && STAGGER) {
+            if (!early) issue_dma();
+          }
           if constexpr (i < 3) rd(std::integral_constant<int, i + 1>{}, (i + 1) & 1);
 #pragma unroll
           for (int tc = 0; tc < TCO; ++tc)
 #pragma unroll
             for (int tp = 0; tp < TPOS; ++tp)
-              acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 1][tc], xf[i & 1][tp], acc[tc][tp], 0, 0, 0);
+              if constexpr (!NO_MFMA)
+                acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 1][tc], xf[i & 1][tp], acc[tc][tp], 0, 0, 0);
           if constexpr (i < 3) {
 #pragma unroll
             for (int j = 0; j < NPAIR; ++j) {
@@ -264,7 +381,10 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
         constexpr int hh = decltype(HH)::value;
         constexpr int s = 2 * sp + hh;                             // tap index inside the pair, 0..17
         constexpr int cc = s / 9, t = s % 9, kh = t / 3, kw = t % 3;
-        tap(Wst + hh * (PT_BCO * 64), Pb0 + cc * PB, kh * Wp + kw);
+        if constexpr (hh == 1 && STAGGER) {
+          if (!early) issue_dma();
+        }
+        if constexpr (!NO_MFMA) tap(Wst + hh * (PT_BCO * 64), Pb0 + cc * PB, kh * Wp + kw);
       });
       }
       __syncthreads();                                             // drains the DMA queue (vmcnt(0)) and fences the buffers
@@ -378,7 +498,7 @@ __device__ __forceinline__ int xcd_tile(int b, int nblk) {
 
 // blocks [0, nblk[0]) are 256-position tiles, blocks [nblk[0], nblk[0] + nblk[1]) the SMALL-position tiles: the
 // dispatcher hands out blocks in index order, so a CU that retires a big tile picks up a small one.
-template <int SMALL, bool PIPE>
+template <int SMALL, int PIPE>
 __global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_kernel(const PatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [W stage 0][W stage 1][patch 0][patch 1]
   const int b = blockIdx.x;
@@ -591,18 +711,25 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   if (lds > 160 * 1024) return SM_ERR_UNSUPPORTED;
   const long long nblk = nb0 + nb1;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
-  const bool pipe = (d->flags & SM_CONV_DBG_PATCH_PIPE) != 0;
+  const int var = ((d->flags & SM_CONV_DBG_PATCH_PIPE) ? 1 : 0) | ((d->flags & SM_CONV_DBG_PATCH_STAGGER) ? 2 : 0) |
+                  ((d->flags & SM_CONV_DBG_PATCH_NO_DMA) ? 4 : 0) | ((d->flags & SM_CONV_DBG_PATCH_NO_MFMA) ? 8 : 0) |
+                  ((d->flags & SM_CONV_DBG_PATCH_PINGPONG) ? 16 : 0);
   auto launch = [&](auto kern) -> int {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SM_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(PT_THREADS), lds, s, a);
     return SM_OK;
   };
-  int lrc;
-  if (ps.small == 128)
-    lrc = pipe ? launch(conv3x3_patch_kernel<128, true>) : launch(conv3x3_patch_kernel<128, false>);
-  else
-    lrc = pipe ? launch(conv3x3_patch_kernel<192, true>) : launch(conv3x3_patch_kernel<192, false>);
+  int lrc = SM_ERR_UNSUPPORTED;
+#define PT_CASE(V)                                                                                                  \
+  case V:                                                                                                           \
+    lrc = ps.small == 128 ? launch(conv3x3_patch_kernel<128, V>) : launch(conv3x3_patch_kernel<192, V>);            \
+    break;
+  switch (var) {
+    PT_CASE(0) PT_CASE(1) PT_CASE(2) PT_CASE(3) PT_CASE(4) PT_CASE(8) PT_CASE(16) PT_CASE(20) PT_CASE(24)
+    default: break;
+  }
+#undef PT_CASE
   if (lrc != SM_OK) return lrc;
   SM_LAUNCH_CHECK();
   return SM_OK;

@@ -30,7 +30,7 @@ def _rows(ts):
     (2, 128, 512, [(9, 250)]),                                         # two cout tiles, widest supported rows
     (1, 256, 256, [(100, 168)]),                                       # FPN level-0 geometry (67 tiles)
 ])
-@pytest.mark.parametrize("shape_flag", [0, 0x4000, 0x2000, 0x1000, 0x800, 0x2800, 0x1800])   # planner / uniform 256 / finish with 128 / with 192; 0x800 = pipelined stage
+@pytest.mark.parametrize("shape_flag", [0, 0x4000, 0x2000, 0x1000, 0x800, 0x2800, 0x1800, 0x80, 0x4080, 0x2080, 0x1080, 0x400])   # planner / uniform 256 / finish with 128 / with 192; 0x800 = pipelined stage, 0x80 = ping-pong schedule, 0x400 = staggered DMA
 def test_patch_conv_vs_torch(cfg, shape_flag):
     from sipmask_amd import hip_ops as H, _lib
     dev = _dev()
@@ -116,14 +116,14 @@ def test_patch_conv_mixed_tile_launch_at_head_shape(batch, groups):
     wq = torch.stack(packed).contiguous()
     S = 2 * batch * len(sizes) * (C // 8)
     outs = {}
-    for flag in (0, 0x4000, 0x800):
+    for flag in (0, 0x4000, 0x800, 0x80, 0x4080):
         y = torch.zeros(groups * lv.rows, C, dtype=torch.bfloat16, device=dev)
         stats = torch.full((groups * S,), 7.0, device=dev)
         d = H.make_conv_desc(batch, sizes, sizes, lv.row0, lv.row0, C, C, 256, 3, 1, 1, C, C, flags=flag, ngroups=groups,
                              x_group_rows=0, y_group_rows=lv.rows, w_group_stride=packed[0].numel(), bias_group_stride=0,
                              gn_group_stride=S)
         pl = H.conv3x3_patch_plan(d)
-        if flag != 0x4000:
+        if not (flag & 0x4000):
             assert pl["small"] > 0, pl            # these shapes are the ones the mixed launch exists for
         else:
             assert pl["small"] == 0, pl
@@ -132,6 +132,7 @@ def test_patch_conv_mixed_tile_launch_at_head_shape(batch, groups):
         outs[flag] = (y, stats)
     assert torch.equal(outs[0][0], outs[0x4000][0])
     assert torch.equal(outs[0][0], outs[0x800][0])          # the pipelined stage issues the same MFMAs in the same order
+    assert torch.equal(outs[0][0], outs[0x80][0]) and torch.equal(outs[0][0], outs[0x4080][0])     # ... and so does ping-pong
     torch.testing.assert_close(outs[0][1], outs[0x4000][1], rtol=1e-4, atol=0.5)      # atomics: order only
     y, stats = outs[0]
     for gi in range(groups):
