@@ -232,5 +232,9 @@ def test_fused_bottleneck_plan_is_bit_identical(monkeypatch):
     for mode in (1, 2):
         for a, b in zip(outs[0][0], outs[mode][0]):
             assert torch.equal(a.view(torch.int16), b.view(torch.int16)), mode
-        assert torch.equal(outs[0][1], outs[mode][1]) and torch.equal(outs[0][2], outs[mode][2])
+        # the head behind the (bit-identical) features accumulates its GroupNorm statistics with float atomics: with three
+        # or more tiles per (image, level, group) bin -- the 128-position finishing tiles of the patch conv at this small
+        # shape -- the sum depends on arrival order in its last bits, run to run and mode-independently
+        # (near-tied scores of this untrained net may then swap places, so the detections are compared as counts)
+        assert torch.equal(outs[0][1], outs[mode][1])
     assert int(outs[0][1].sum()) > 0
