@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Copies the evidence written by tools/profile_round2.sh (gpurun_out/prof2) into profiles/ under round-2 names and
+"""Copies the evidence written by tools/profile_round2_final.sh (gpurun_out/prof2) into profiles/ under round-2 names
+(the mid-round set of tools/profile_round2.sh is kept as profiles/r02mid_*) and
 derives profiles/r02_pmc_tower_conv.json: per-launch HBM traffic (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate PMC
 passes) and the SQ counters of the dominant kernel, dispatches selected by kernel name and the launch's grid."""
 import collections
@@ -59,7 +60,7 @@ js = {
     "kernel": bench["roofline"].get("kernel"),
     "launch": tower["kernel"], "plan_batch": tower["plan_batch"], "grid_size": int(grid),
     "command": "rocprofv3 --kernel-trace --pmc <COUNTER(S)> --output-format csv -- python bench.py --tower-only 10 "
-               "(tools/profile_round2.sh; separate passes for FETCH_SIZE, WRITE_SIZE and the SQ counters; dispatches "
+               "(tools/profile_round2_final.sh; separate passes for FETCH_SIZE, WRITE_SIZE and the SQ counters; dispatches "
                "selected by kernel name + grid size; assembled by tools/collect_profiles2.py)",
     "dispatches": len(fetch[grid]["FETCH_SIZE"]),
     "FETCH_SIZE_KB_raw": mean(fetch[grid]["FETCH_SIZE"]), "WRITE_SIZE_KB_raw": mean(write[grid]["WRITE_SIZE"]),
@@ -77,8 +78,13 @@ json.dump(js, open(os.path.join(DST, "r02_pmc_tower_conv.json"), "w"), indent=1)
 for src, dst in (("step_breakdown.txt", "r02_step_breakdown_hip_events.txt"),
                  ("step_breakdown_lanes1.txt", "r02_step_breakdown_hip_events_lanes1.txt"),
                  ("kernel_stats_step.csv", "r02_rocprofv3_kernel_stats_step.csv"),
-                 ("kernel_stats_tower_only.csv", "r02_rocprofv3_kernel_stats_tower_only.csv")):
-    shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
+                 ("kernel_stats_tower_only.csv", "r02_rocprofv3_kernel_stats_tower_only.csv"),
+                 ("kernel_stats_train.csv", "r02_rocprofv3_kernel_stats_train_step.csv"),
+                 ("parity_r50_b4_bf16.json", "r02_parity_r50_b4_bf16.json"),
+                 ("parity_r50_b4_f32.json", "r02_parity_r50_b4_f32.json"),
+                 ("patch_bench.txt", "r02_patch_conv_microbench.txt")):
+    if os.path.exists(os.path.join(SRC, src)):
+        shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
 lines = {}
 for n in ("r50", "r50_lanes1", "r50_f32", "r101", "vis", "train"):
     j = last_json(os.path.join(SRC, "bench_%s.json" % n))
