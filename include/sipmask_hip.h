@@ -46,6 +46,10 @@ typedef enum {
 #define SM_CONV_IN_RELU 16u      /* x = max(x,0) applied on load (fpn.py:174-175 P7) */
 #define SM_CONV_BWD_GX_BF16 64u   /* sm_conv2d_bwd only: grad_x is written as bf16 rows (stride-1 convs: the dX GEMM's own
                                     output type; the training graph on row tensors hands it straight to the next op) */
+#define SM_CONV_BWD_WGRAD_GEMM 128u /* sm_conv2d_bwd only, A/B switch: weight gradient through the materialised im2col^T / gout^T
+                                    GEMM (the round-1 path) instead of sm_wgrad_direct */
+#define SM_CONV_BWD_WGRAD_DIRECT 256u /* sm_conv2d_bwd only, A/B switch: sm_wgrad_direct wherever it is supported (default: where
+                                    sm_wgrad_direct_preferred says it is the faster path) */
 #define SM_CONV_RELU_NCH 32u     /* y = max(y, 0) on channels < scale_nch only (the maskrcnn-benchmark variant's
                                     relu(scale(bbox_pred)), SipMask-benchmark/.../sipmask/sipmask.py:155-157) */
 #define SM_CONV_DBG_LINEAR_TILES 0x40000000u /* A/B switch: disable the XCD-aware tile remap */
@@ -209,6 +213,15 @@ int sm_deform_conv2d_bwd(const sm_conv_desc* d, const void* x, const float* offs
  * Every output is nullable.  Workspace: sm_deform_conv2d_bwd_workspace(d). */
 int sm_conv2d_bwd(const sm_conv_desc* d, const void* x, const void* w_t, const void* w_dgrad, const void* gout,
                   float* grad_x, float* grad_w_t, float* grad_bias, void* workspace, sm_stream_t stream);
+
+/* Weight gradient of a plain convolution straight from the NHWC rows (csrc/wgrad_direct.hip): d is the FORWARD descriptor,
+ * x / gout bf16 rows as in sm_conv2d_bwd, grad_w_t f32 [kh*kw*cin][cout] (zeroed and accumulated by the call: split-K over
+ * position slices with float atomics, so the last bits depend on arrival order).  Needs channels % 8 == 0.  sm_conv2d_bwd
+ * uses it where sm_wgrad_direct_preferred(d) (long position axes; measured crossover) unless SM_CONV_BWD_WGRAD_GEMM /
+ * SM_CONV_BWD_WGRAD_DIRECT force a path. */
+int sm_wgrad_direct_supported(const sm_conv_desc* d);
+int sm_wgrad_direct_preferred(const sm_conv_desc* d);
+int sm_wgrad_direct(const sm_conv_desc* d, const void* x, const void* gout, float* grad_w_t, sm_stream_t stream);
 
 /* ---- training graph on NHWC bf16 row tensors (csrc/train_rows.hip; host side sipmask_amd/ops_rows.py).  These replace
  * the chains of ATen launches (permute / contiguous / to / zeros / mul / threshold_backward / native_group_norm_backward

@@ -109,6 +109,9 @@ PROTOTYPES = {
     "sm_track_match": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P]),
     "sm_mask_rescore": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "sm_conv2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sm_wgrad_direct_supported": (_I, [C.POINTER(ConvDesc)]),
+    "sm_wgrad_direct_preferred": (_I, [C.POINTER(ConvDesc)]),
+    "sm_wgrad_direct": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "sm_weight_prep": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
     "sm_weight_prep_multi": (_I, [_P, _P, _I, _I, _P]),
     "sm_wgrad_finish": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),

@@ -476,7 +476,12 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
     hipLaunchKernelGGL(deform_col2im_kernel, dim3(blocks), dim3(256), 0, s, a, gcol, gx_col, grad_offset, nunits);
     SM_LAUNCH_CHECK();
   }
-  if (grad_w_t) {
+  if (grad_w_t && offset == nullptr && !(d->flags & SM_CONV_BWD_WGRAD_GEMM) &&
+      ((d->flags & SM_CONV_BWD_WGRAD_DIRECT) ? sm_wgrad_direct_supported(d) : sm_wgrad_direct_preferred(d))) {
+    // plain conv: dW straight from the NHWC rows (wgrad_direct.hip: transposing LDS reads, no im2col^T / gout^T, no slabs)
+    const int st = sm_wgrad_direct(d, x, gout, grad_w_t, stream);
+    if (st != SM_OK) return st;
+  } else if (grad_w_t) {
     // ---- dW^T[k][co] = sum_s col^T_s @ gout_s: ONE launch of the implicit-GEMM kernel as a batch of S 1x1
     // "convolutions" (image s: Kpad rows, cin = L, its own weight matrix gout^T_s via w_batch_stride), then a reduce
     uint16_t* colT = (uint16_t*)(ws + pl.off_colT);

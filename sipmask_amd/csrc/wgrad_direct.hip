@@ -1,0 +1,288 @@
+// Weight gradient of a plain convolution straight from the NHWC row tensors (gfx950):
+//
+//   dW^T[(tap, ci)][co] = sum over output positions p of  x[p (+) tap][ci] * gout[p][co]
+//
+// Both operands are [position][channel] row matrices, i.e. the contraction index is the SLOW dimension of both, while an
+// MFMA lane wants 8 consecutive k of one row / column.  The first version (deform_bwd.hip: transpose_tile_kernel + the
+// implicit-GEMM kernel + wgrad_reduce_kernel) therefore materialised im2col^T (9x the activation for a 3x3 conv) and
+// gout^T per conv: 3.6 ms of transposes + 1.0 ms of partial-slab reduction in a 33 ms training step.  Here the tiles are
+// LDS-DMAed as they lie -- [32 positions][16 channels] sub-tiles of 1 KB, one `global_load_lds_dwordx4` each -- and the
+// fragments are read with gfx950's transposing LDS read:
+//
+//   ds_read_b64_tr_b16: inside a 16-lane group, lane 4r+q supplies the address of 4 consecutive bf16 (row r, columns
+//   4q..4q+3 of a 4 x 16 block; the row pitch is free); lane i receives column i = {row 0..3}[i].
+//   (measured with tools/tr_probe.hip; MI355X_MICROARCH.md lists the rate: 2 LDS cycles per wave instruction)
+//
+// so two reads give a lane the 8 consecutive POSITIONS (k) of its channel that v_mfma_f32_32x32x16_bf16 wants, for the
+// x tile (A: M = ci) and the gout tile (B: N = co) alike.  Sub-tiles are laid out at a 1152-byte pitch: the two 16-lane
+// groups an LDS cycle serves then hit disjoint bank halves.  Split-K over position slices, partial tiles are added into
+// the (zeroed) output with hardware float atomics, coalesced along co (lanes = N).
+#include "common.h"
+
+namespace {
+
+struct WGArgs {
+  const uint16_t* x;
+  const uint16_t* g;
+  float* out;                      // [kh*kw*cin][cout] f32, zeroed by the host entry point
+  int nlev, batch;
+  int in_h[SM_MAX_LEVELS], in_w[SM_MAX_LEVELS], out_h[SM_MAX_LEVELS], out_w[SM_MAX_LEVELS];
+  long long in_row0[SM_MAX_LEVELS], out_row0[SM_MAX_LEVELS];
+  long long pos_end[SM_MAX_LEVELS];   // compact position index one past each level (level, image, y, x order)
+  int cin, cout, kh, kw, stride, pad, dil, in_cstride, g_cstride;
+  long long P;
+  int slice;                       // positions per split-K slice (multiple of 32)
+  int ci_tiles;                    // ceil(cin / 128): blockIdx.x = tap * ci_tiles + ci tile
+};
+
+constexpr int WG_T = 128;          // tile: 128 ci x 128 co
+constexpr int WG_PB = 2;           // 32-position blocks per stage (a stage = 16 * WG_PB MFMAs per wave between two barriers)
+constexpr int WG_KC = 32 * WG_PB;  // positions per stage
+constexpr int WG_SUB = 1152;       // sub-tile pitch: 1 KB of data + 128 B so that neighbouring sub-tiles sit in the other bank half
+constexpr int WG_REGION = WG_PB * 8 * WG_SUB;    // per position block 8 sub-tiles of 16 channels
+constexpr int WG_STAGE = 2 * WG_REGION;          // x region + gout region
+constexpr int WG_RING = 2;         // LDS ring: WG_RING - 1 stages of LDS-DMA in flight per block.  Measured (tools/wgrad_bench.py, tower
+                                   // conv): ring 2 with two blocks per CU 293 TF/s; ring 4 (96 KB in flight, ONE block per CU) 164 TF/s
+                                   // -- with a single wave per SIMD the ~100-cycle issue cost of every global_load_lds stalls the only
+                                   // wave that could issue MFMAs, so the second resident block is worth more than the deeper ring
+constexpr int WG_DMA_PER_STAGE = 4 * WG_PB;      // global_load_lds instructions per wave per stage
+
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16w[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ unsigned long long tr_read(unsigned addr) {
+  unsigned long long v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ unsigned long long tr_read_128(unsigned addr) {       // + 4 rows of 32 bytes
+  unsigned long long v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:128" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(const WGArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 stages x (x region + gout region)
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tap = blockIdx.x / a.ci_tiles, ci0 = (blockIdx.x - tap * a.ci_tiles) * WG_T;
+  const int co0 = blockIdx.y * WG_T;
+  const int ti = tap / a.kw, tj = tap - ti * a.kw;
+  const long long p_begin = (long long)blockIdx.z * a.slice;
+  const long long p_end = p_begin + a.slice < a.P ? p_begin + a.slice : a.P;
+  if (p_begin >= p_end) return;
+  const int nst = (int)((p_end - p_begin + WG_KC - 1) / WG_KC);
+  const unsigned long long zero_page = (unsigned long long)g_zero16w;
+
+  // ---- loader: waves 0,1 fetch the x tile (8 sub-tiles of 16 ci), waves 2,3 the gout tile; a wave's lane = (position
+  // lane >> 1, 8-channel half lane & 1) of every one of its 4 sub-tiles, so one position decode per thread per stage
+  const bool is_x = wave < 2;
+  const int sub0 = (wave & 1) * 4;                 // first of this wave's 4 sub-tiles
+  const int lpos = lane >> 1, lhalf = lane & 1;
+  auto issue = [&](int st, int buf) {
+#pragma unroll
+    for (int pb = 0; pb < WG_PB; ++pb) {
+      const long long p = p_begin + (long long)st * WG_KC + pb * 32 + lpos;
+      unsigned long long src_row = 0;              // byte address of channel 0 of the row, 0 = no row (zero page)
+      if (p < p_end) {
+        int l = 0;
+#pragma unroll
+        for (int q = 1; q < SM_MAX_LEVELS; ++q)
+          if (q < a.nlev && p >= a.pos_end[q - 1]) l = q;
+        const int pl = (int)(p - (l ? a.pos_end[l - 1] : 0));     // < 2^31 per level (checked by the host): 32-bit divisions
+        if (is_x) {
+          const int hw = a.out_h[l] * a.out_w[l];
+          const int b = pl / hw;
+          const int rem = pl - b * hw;
+          const int oy = rem / a.out_w[l], ox = rem - oy * a.out_w[l];
+          const int iy = oy * a.stride - a.pad + ti * a.dil, ix = ox * a.stride - a.pad + tj * a.dil;
+          if (iy >= 0 && iy < a.in_h[l] && ix >= 0 && ix < a.in_w[l])
+            src_row = (unsigned long long)(a.x + (a.in_row0[l] + ((long long)b * a.in_h[l] + iy) * a.in_w[l] + ix) * a.in_cstride);
+        } else {
+          src_row = (unsigned long long)(a.g + (a.out_row0[l] + pl) * a.g_cstride);
+        }
+      }
+      const int c_base = (is_x ? ci0 : co0) + lhalf * 8;
+      const int c_lim = is_x ? a.cin : a.cout;
+      unsigned char* dst = smem + buf * WG_STAGE + (is_x ? 0 : WG_REGION) + pb * 8 * WG_SUB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s = sub0 + i;
+        const int c = c_base + s * 16;
+        const bool ok = src_row != 0 && c < c_lim;           // channels are multiples of 8: a 16-byte piece is all in or all out
+        const unsigned long long src = ok ? src_row + (unsigned long long)c * 2 : zero_page;
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + s * WG_SUB), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- fragment addresses.  wave tile 64 (ci) x 64 (co): 2 x 2 MFMA tiles.  Inside a 16-lane group: i = lane & 15 ->
+  // supplied row r = i >> 2, column quad q = i & 3; group g = lane >> 4 -> channel half (g & 1) of the 32-wide MFMA tile
+  // and position half (g >> 1) of the 16-position k step.
+  const int wm = wave >> 1, wn = wave & 1;
+  const int grp = lane >> 4, li = lane & 15;
+  const unsigned frag_off = (unsigned)(((grp >> 1) * 8 + (li >> 2)) * 32 + (li & 3) * 8);       // inside a sub-tile, k step 0
+  const unsigned smem_base = (unsigned)(uintptr_t)smem;
+  unsigned a_addr[2], b_addr[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    a_addr[t] = smem_base + (unsigned)((wm * 4 + t * 2 + (grp & 1)) * WG_SUB) + frag_off;
+    b_addr[t] = smem_base + WG_REGION + (unsigned)((wn * 4 + t * 2 + (grp & 1)) * WG_SUB) + frag_off;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+#pragma unroll
+  for (int i = 0; i < WG_RING - 1; ++i)
+    if (i < nst) issue(i, i);
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st % WG_RING;
+    // stage st has landed when at most the DMA of the (up to WG_RING - 2) later stages is outstanding: counted vmcnt, then
+    // a raw s_barrier (it must not drain the queue; __syncthreads() would).  The barrier also says every wave is done
+    // with stage st - 1, whose buffer the DMA issued below overwrites.
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int later = nst - 1 - st < WG_RING - 2 ? nst - 1 - st : WG_RING - 2;
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WG_DMA_PER_STAGE) : "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WG_DMA_PER_STAGE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (st + WG_RING - 1 < nst) issue(st + WG_RING - 1, (st + WG_RING - 1) % WG_RING);
+    const unsigned boff = (unsigned)(buf * WG_STAGE);
+    // fragment pipeline: the transposing reads of k step ks+1 are in flight while the MFMAs of ks issue.  The reads are
+    // inline asm (no builtin), so the compiler neither knows they are asynchronous nor places a wait: counted waits by
+    // hand, fenced with sched_barrier(0) -- an MFMA is a register-only instruction that the "memory" clobber does not
+    // order, and hipcc did hoist it above the wait.
+    constexpr int NKS = 2 * WG_PB;
+    unsigned long long af[2][2][2], bf[2][2][2];   // [set][mfma tile][k half]
+    auto rd = [&](int ks, int set) {
+      const unsigned koff = boff + (unsigned)((ks >> 1) * 8 * WG_SUB + (ks & 1) * 512);   // + 16 rows per k step, next position block after 2
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        af[set][t][0] = tr_read(a_addr[t] + koff);
+        af[set][t][1] = tr_read_128(a_addr[t] + koff);
+        bf[set][t][0] = tr_read(b_addr[t] + koff);
+        bf[set][t][1] = tr_read_128(b_addr[t] + koff);
+      }
+    };
+    rd(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      if (ks + 1 < NKS) rd(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < NKS)
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // the 8 reads of ks+1 may stay outstanding
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
+          const u64x2 av = {af[ks & 1][mi][0], af[ks & 1][mi][1]};
+          const u64x2 bv = {bf[ks & 1][ni][0], bf[ks & 1][ni][1]};
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                                acc[mi][ni], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue: acc[mi][ni][e] = D[m][n], m = 8*(e/4) + 4*(lane/32) + e%4 (ci), n = lane%32 (co): atomics coalesced along co
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int co = co0 + wn * 64 + ni * 32 + l31;
+      if (co >= a.cout) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = ci0 + wm * 64 + mi * 32 + 8 * (e >> 2) + 4 * lhi + (e & 3);
+        if (ci < a.cin) unsafeAtomicAdd(a.out + ((long long)tap * a.cin + ci) * a.cout + co, acc[mi][ni][e]);
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int sm_wgrad_direct_supported(const sm_conv_desc* d) {
+  if (!d || d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return 0;
+  if (d->cin % 8 != 0 || d->cout % 8 != 0 || d->in_cstride % 8 != 0 || d->out_cstride % 8 != 0) return 0;
+  if (d->kh < 1 || d->kw < 1 || d->stride < 1) return 0;
+  return 1;
+}
+
+// Where the direct kernel beats the im2col^T GEMM path (tools/wgrad_bench.py, B=4 800x1344 shapes): the position axis must
+// be long enough to amortise the float-atomic epilogue of every slice, and a 3x3 conv saves 9x the transposition traffic of
+// a 1x1 -- >= 60 000 positions, or >= 16 000 for k >= 3 (layer3's 3x3 convs: 201 vs 186 TF/s); below that the GEMM path
+// wins (layer4 1x1 512 -> 2048 at 4 200 positions: 146 vs 185 TF/s).
+extern "C" int sm_wgrad_direct_preferred(const sm_conv_desc* d) {
+  if (!sm_wgrad_direct_supported(d)) return 0;
+  long long P = 0;
+  for (int l = 0; l < d->nlev; ++l) P += (long long)d->batch * d->out_h[l] * d->out_w[l];
+  return (P >= 60000 || (d->kh * d->kw >= 9 && P >= 16000)) ? 1 : 0;
+}
+
+extern "C" int sm_wgrad_direct(const sm_conv_desc* d, const void* x, const void* gout, float* grad_w_t, sm_stream_t stream) {
+  if (!d || !x || !gout || !grad_w_t) return SM_ERR_BAD_ARG;
+  if (!sm_wgrad_direct_supported(d)) return SM_ERR_UNSUPPORTED;
+  WGArgs a;
+  a.x = (const uint16_t*)x;
+  a.g = (const uint16_t*)gout;
+  a.out = grad_w_t;
+  a.nlev = d->nlev;
+  a.batch = d->batch;
+  long long P = 0;
+  for (int l = 0; l < SM_MAX_LEVELS; ++l) {
+    const bool on = l < d->nlev;
+    a.in_h[l] = on ? d->in_h[l] : 1, a.in_w[l] = on ? d->in_w[l] : 1;
+    a.out_h[l] = on ? d->out_h[l] : 1, a.out_w[l] = on ? d->out_w[l] : 1;
+    a.in_row0[l] = on ? d->in_row0[l] : 0, a.out_row0[l] = on ? d->out_row0[l] : 0;
+    if (on) {
+      const long long n = (long long)d->batch * d->out_h[l] * d->out_w[l];
+      if (n >= (1ll << 31)) return SM_ERR_UNSUPPORTED;
+      P += n;
+    }
+    a.pos_end[l] = P;
+  }
+  a.cin = d->cin, a.cout = d->cout, a.kh = d->kh, a.kw = d->kw, a.stride = d->stride, a.pad = d->pad;
+  a.dil = d->dil > 0 ? d->dil : 1;
+  a.in_cstride = d->in_cstride, a.g_cstride = d->out_cstride;
+  a.P = P;
+  a.ci_tiles = (d->cin + WG_T - 1) / WG_T;
+  const long long K = (long long)d->kh * d->kw * d->cin;
+  hipStream_t s = sm_hip_stream(stream);
+  if (hipMemsetAsync(grad_w_t, 0, sizeof(float) * K * d->cout, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (P == 0) return SM_OK;
+  const long long tiles = (long long)d->kh * d->kw * a.ci_tiles * ((d->cout + WG_T - 1) / WG_T);
+  // split K: two rounds of the 512 resident blocks (2 per CU); every slice ends in 128 x 128 float atomics per tile, so
+  // slices stay >= 512 positions (the atomics of a 256-position slice cost as much as its MFMAs)
+  long long S = (1024 + tiles - 1) / tiles;
+  const long long s_max = (P + 511) / 512;
+  if (S > s_max) S = s_max;
+  if (S > 512) S = 512;
+  if (S < 1) S = 1;
+  long long slice = ((P + S - 1) / S + WG_KC - 1) / WG_KC * WG_KC;
+  S = (P + slice - 1) / slice;
+  a.slice = (int)slice;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)wgrad_direct_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING * WG_STAGE) != hipSuccess)
+      return SM_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad_direct_kernel, dim3((unsigned)(d->kh * d->kw * a.ci_tiles), (unsigned)((d->cout + WG_T - 1) / WG_T), (unsigned)S),
+                     dim3(256), WG_RING * WG_STAGE, s, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

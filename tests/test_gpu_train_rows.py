@@ -281,3 +281,43 @@ def test_weight_prep_cache_refreshes_all_stale_operands_in_one_launch():
         assert torch.equal(cache.get(p, s, m, cp)[0], ref), (tuple(p.shape), m)
         assert cache.get(p, s, m, cp)[0] is buf
     assert cache.refresh() == 0
+
+
+@pytest.mark.parametrize("cfg", [
+    # cin, cout, k, stride, pad, sizes
+    (256, 256, 3, 1, 1, [(12, 20), (6, 10), (3, 5), (2, 3), (1, 2)]),      # tower-like pyramid
+    (512, 128, 1, 2, 0, [(9, 14)]),                                        # strided 1x1 (layer2.0.conv1)
+    (64, 72, 3, 1, 1, [(7, 9)]),                                           # channel tails inside the 128 tiles
+    (16, 32, 3, 2, 0, [(21, 17)]),                                         # the SipMask++ scoring convs
+    (256, 8, 3, 1, 1, [(6, 10), (3, 5)]),
+    (128, 128, 3, 1, 1, [(40, 56)]),                                       # several split-K slices
+])
+def test_wgrad_direct_vs_gemm_path_and_torch(cfg):
+    """sm_wgrad_direct (transposing LDS reads on the NHWC rows) against the materialised im2col^T GEMM path it replaces
+    (same bf16 operands, f32 accumulation: only the summation order differs) and against torch's conv2d_weight in f64"""
+    from sipmask_amd import hip_ops as H, _lib
+    import ctypes as C
+    dev = _dev()
+    ci, co, k, stride, pad, sizes = cfg
+    g = torch.Generator().manual_seed(ci + co + k)
+    b = 2
+    lv = H.Levels(b, sizes)
+    osz = [((h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1) for h, w in sizes]
+    olv = H.Levels(b, osz)
+    xs = [_bf(torch.randn(b, ci, h, w, generator=g)) for h, w in sizes]
+    gos = [_bf(torch.randn(b, co, h, w, generator=g)) for h, w in osz]
+    x = torch.cat([_rows(t) for t in xs]).to(torch.bfloat16).to(dev)
+    go = torch.cat([_rows(t) for t in gos]).to(torch.bfloat16).to(dev)
+    d = H.make_conv_desc(b, sizes, osz, lv.row0, olv.row0, ci, co, co, k, stride, pad, ci, co)
+    lib = _lib.load()
+    assert lib.sm_wgrad_direct_supported(C.byref(d)) == 1
+    gw_new = torch.full((k * k * ci, co), float("nan"), device=dev)
+    _lib.check(lib.sm_wgrad_direct(C.byref(d), _lib.ptr(x), _lib.ptr(go), _lib.ptr(gw_new), _lib.stream_ptr()), "sm_wgrad_direct")
+    d.flags = 128                                                    # SM_CONV_BWD_WGRAD_GEMM: the round-1 path
+    gw_old = torch.empty(k * k * ci, co, device=dev)
+    H.conv2d_bwd(d, x, None, None, go, None, gw_old, None)
+    ref = sum(torch.nn.grad.conv2d_weight(xi.double(), (co, ci, k, k), gi.double(), stride, pad) for xi, gi in zip(xs, gos))
+    ref_t = ref.permute(2, 3, 1, 0).reshape(k * k * ci, co).float()
+    scale = float(ref_t.abs().max())
+    assert float((gw_new.cpu() - ref_t).abs().max()) <= 2e-5 * scale * max(1.0, (b * sum(h * w for h, w in osz)) ** 0.5 / 8)
+    assert float((gw_new - gw_old).abs().max()) <= 2e-5 * scale * max(1.0, (b * sum(h * w for h, w in osz)) ** 0.5 / 8)
