@@ -224,13 +224,16 @@ extern "C" int sm_wgrad_direct_supported(const sm_conv_desc* d) {
 
 // Where the direct kernel beats the im2col^T GEMM path (tools/wgrad_bench.py, B=4 800x1344 shapes): the position axis must
 // be long enough to amortise the float-atomic epilogue of every slice, and a 3x3 conv saves 9x the transposition traffic of
-// a 1x1 -- >= 60 000 positions, or >= 16 000 for k >= 3 (layer3's 3x3 convs: 201 vs 186 TF/s); below that the GEMM path
-// wins (layer4 1x1 512 -> 2048 at 4 200 positions: 146 vs 185 TF/s).
+// a 1x1 -- >= 16 000 positions for k >= 3 (layer3's 3x3 convs: 197 vs 185 TF/s), >= 60 000 for narrow 1x1 convs; below that
+// the GEMM path wins (layer4 1x1 512 -> 2048 at 4 200 positions: 142 vs 182 TF/s).  profiles/r02k_wgrad_direct_vs_gemm.txt
 extern "C" int sm_wgrad_direct_preferred(const sm_conv_desc* d) {
   if (!sm_wgrad_direct_supported(d)) return 0;
   long long P = 0;
   for (int l = 0; l < d->nlev; ++l) P += (long long)d->batch * d->out_h[l] * d->out_w[l];
-  return (P >= 60000 || (d->kh * d->kw >= 9 && P >= 16000)) ? 1 : 0;
+  if (d->kh * d->kw >= 9) return P >= 16000 ? 1 : 0;
+  // 1x1: the transposition it saves is only 1x the activation; wins for the narrow convs of layer2 (512 -> 128: 113 vs 86
+  // TF/s), loses 5 % on the mask branch's 768 -> 512
+  return (P >= 60000 && (long long)d->cin * d->cout <= 131072) ? 1 : 0;
 }
 
 extern "C" int sm_wgrad_direct(const sm_conv_desc* d, const void* x, const void* gout, float* grad_w_t, sm_stream_t stream) {
