@@ -119,8 +119,10 @@ def test_benchmark_checkpoint_conversion_end_to_end():
     # same weights through both naming schemes: identical plans up to the float-atomic order of the fused GroupNorm
     # statistics, so compare the head outputs numerically and the detections as sets
     eng_b = list(model._engines.values())[0]
-    assert _rel(eng_b.cls_cof, eng.cls_cof) < 1e-3 and _rel(eng_b.reg_out, eng.reg_out) < 1e-3
-    assert _rel(eng_b.basis, eng.basis) < 1e-3
+    # (a last-bit difference of a statistic flips bf16 roundings of the normalised tensor, which the following convs
+    # spread: 0.3e-3 .. 1.1e-3 relative over repeated runs of the SAME plan -- bound 3e-3)
+    assert _rel(eng_b.cls_cof, eng.cls_cof) < 3e-3 and _rel(eng_b.reg_out, eng.reg_out) < 3e-3
+    assert _rel(eng_b.basis, eng.basis) < 3e-3
     assert abs(int(r["ndet"][0]) - n) <= 2
     a = r["det_bboxes"][0, :int(r["ndet"][0])].cpu()
     matched = 0
