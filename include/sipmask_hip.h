@@ -490,9 +490,10 @@ int sm_fcos_target(const float* points, const float* point_stride, const float* 
  * of F.binary_cross_entropy(CropSplit(sigmoid(basis . cof_q))[.., n], CropSplitGt(gt[idx_gt[n]])[.., n]) --
  * without materialising the 4 x [Hm,Wm,N] probability volumes.  basis f32 [32][Hm][Wm] (basis_hwc=0) or
  * [Hm][Wm][32]; cof f32 [N][128]; boxes f32 [N][4] in basis-grid coordinates (the CropSplit rois);
- * gt u8 0/1 [G][Hm][Wm]; idx_gt int64 [N].  fwd: bce_sum f32 [N].
- * bwd: grad_sum f32 [N] (dL/d bce_sum) -> grad_cof f32 [N][128], grad_basis f32 (layout of basis, fully
- * written); either output may be NULL. */
+ * gt u8 0/1 [G][Hm][Wm]; idx_gt int64 [N].  fwd: bce_sum f32 [N] (zeroed by the call: every box is split over 16
+ * blocks that add their share with float atomics).
+ * bwd: grad_sum f32 [N] (dL/d bce_sum) -> grad_cof f32 [N][128] (zeroed by the call, accumulated the same way),
+ * grad_basis f32 (layout of basis, fully written); either output may be NULL. */
 int sm_mask_loss_fwd(const float* basis, int basis_hwc, const float* cof, const float* boxes, const uint8_t* gt,
                      const int64_t* idx_gt, int n, int hm, int wm, float* bce_sum, sm_stream_t stream);
 int sm_mask_loss_bwd(const float* basis, int basis_hwc, const float* cof, const float* boxes, const uint8_t* gt,

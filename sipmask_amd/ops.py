@@ -397,7 +397,7 @@ class MaskLossFunction(Function):
         if basis.dim() != 3 or basis.shape[0] != 32 or cof.shape[1] != 128 or rois.shape != (n, 4) or \
                 gt.shape[1:] != basis.shape[1:] or idx.shape != (n,):
             raise ValueError("mask_loss: inconsistent shapes")
-        out = torch.zeros(n, dtype=torch.float32, device=basis.device)
+        out = torch.empty(n, dtype=torch.float32, device=basis.device)      # zeroed by sm_mask_loss_fwd
         H.mask_loss_fwd(basis, cof, rois, gt, idx, out)
         ctx.save_for_backward(basis, cof, rois, gt, idx)
         ctx.dtypes = (feat_mask.dtype, cof_pred.dtype)
@@ -408,7 +408,7 @@ class MaskLossFunction(Function):
     def backward(ctx, grad_sum):
         basis, cof, rois, gt, idx = ctx.saved_tensors
         gb = torch.empty_like(basis) if ctx.needs_input_grad[0] else None
-        gc = torch.zeros_like(cof) if ctx.needs_input_grad[1] else None
+        gc = torch.empty_like(cof) if ctx.needs_input_grad[1] else None      # zeroed by sm_mask_loss_bwd
         H.mask_loss_bwd(basis, cof, rois, gt, idx, grad_sum.detach().float().contiguous(), gc, gb)
         return (None if gb is None else gb.to(ctx.dtypes[0]), None if gc is None else gc.to(ctx.dtypes[1]),
                 None, None, None)
