@@ -50,6 +50,9 @@ typedef enum {
                                     GEMM (the round-1 path) instead of sm_wgrad_direct */
 #define SM_CONV_BWD_WGRAD_DIRECT 256u /* sm_conv2d_bwd only, A/B switch: sm_wgrad_direct wherever it is supported (default: where
                                     sm_wgrad_direct_preferred says it is the faster path) */
+#define SM_CONV_BWD_WGRAD_TILE128 512u /* sm_conv2d_bwd / sm_wgrad_direct only, A/B switch: always the 128 x 128 4-wave tile.  (The
+                                    SM_CONV_BWD_* bits are read from backward descriptors only; the SM_CONV_DBG_PATCH_* bits that
+                                    share their values are read by sm_conv3x3_patch only.) */
 #define SM_CONV_RELU_NCH 32u     /* y = max(y, 0) on channels < scale_nch only (the maskrcnn-benchmark variant's
                                     relu(scale(bbox_pred)), SipMask-benchmark/.../sipmask/sipmask.py:155-157) */
 #define SM_CONV_DBG_LINEAR_TILES 0x40000000u /* A/B switch: disable the XCD-aware tile remap */

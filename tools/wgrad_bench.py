@@ -18,14 +18,14 @@ SHAPES = [("tower 3x3 256->256 x5lev", 256, 256, 3, 1, 1, LEVELS),
           ("mask lat0 1x1 768->512", 768, 512, 1, 1, 0, [(100, 168)])]
 B = 4
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-tot = {"direct": 0.0, "gemm": 0.0}
+tot = {"direct": 0.0, "direct128": 0.0, "gemm": 0.0}
 for name, ci, co, k, s, p, sizes in SHAPES:
     lv = H.Levels(B, sizes)
     x = (torch.randn(lv.rows, ci, device=dev) * 0.5).to(torch.bfloat16)
     g = (torch.randn(lv.rows, co, device=dev) * 0.1).to(torch.bfloat16)
     gw = torch.empty(k * k * ci, co, device=dev)
     res = {}
-    for label, flag in (("direct", 256), ("gemm", 128)):
+    for label, flag in (("direct", 256), ("direct128", 256 | 512), ("gemm", 128)):
         d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, ci, co, co, k, s, p, ci, co, flags=flag)
         ts = []
         for r in range(5):
@@ -39,6 +39,6 @@ for name, ci, co, k, s, p, sizes in SHAPES:
         res[label] = sorted(ts)[len(ts) // 2]
         tot[label] += res[label]
     fl = 2.0 * lv.rows * co * ci * k * k
-    print("%-28s %7.1f GFLOP  direct %.4f ms (%4.0f TF/s)   gemm path %.4f ms (%4.0f TF/s)" % (
-        name, fl / 1e9, res["direct"], fl / res["direct"] / 1e9, res["gemm"], fl / res["gemm"] / 1e9))
-print("sum: direct %.3f ms, gemm path %.3f ms" % (tot["direct"], tot["gemm"]))
+    print("%-28s %7.1f GFLOP  direct %.4f ms (%4.0f TF/s)   direct, 128x128 tile only %.4f ms (%4.0f TF/s)   gemm path %.4f ms (%4.0f TF/s)" % (
+        name, fl / 1e9, res["direct"], fl / res["direct"] / 1e9, res["direct128"], fl / res["direct128"] / 1e9, res["gemm"], fl / res["gemm"] / 1e9))
+print("sum: direct %.3f ms, direct 128x128 only %.3f ms, gemm path %.3f ms" % (tot["direct"], tot["direct128"], tot["gemm"]))
