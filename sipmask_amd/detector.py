@@ -131,13 +131,37 @@ class SipMask(nn.Module):
         fills every trainable parameter's .grad."""
         self.bbox_head.train()
         from .modules import _train_rows_enabled
+        kw = {}
         if _train_rows_enabled(img) and self.with_neck and hasattr(self.bbox_head, "forward_rows") and \
                 self.bbox_head.rows_path_ok():
+            if gt_masks is not None and hasattr(self.bbox_head, "prepare_targets"):
+                # the ground-truth half of the loss first: its nonzero() syncs then wait on an idle device instead of
+                # draining the forward's launch queue in the middle of the step (the loss checks the geometry it was built for)
+                sizes = self._head_sizes(tuple(img.shape[-2:]))
+                kw["_targets"] = self.bbox_head.prepare_targets(sizes, (4 * sizes[0][0], 4 * sizes[0][1]), gt_bboxes, gt_labels,
+                                                                gt_masks, img.device)
             outs = self.bbox_head.forward_rows(*self.extract_feat_rows(img))
         else:
             outs = self.bbox_head(self.extract_feat_train(img))
         return self.bbox_head.loss(*outs, gt_bboxes, gt_labels, img_metas, self.train_cfg,
-                                   gt_bboxes_ignore=gt_bboxes_ignore, gt_masks_list=gt_masks)
+                                   gt_bboxes_ignore=gt_bboxes_ignore, gt_masks_list=gt_masks, **kw)
+
+    def _head_sizes(self, hw):
+        """(h, w) of the five head levels for an input of size hw: the conv arithmetic of the caffe-style ResNet (7x7 s2 p3,
+        3x3 max-pool s2 p1, one stride-2 1x1 per stage) and of the FPN's two extra 3x3 s2 p1 convs (fpn.py:120-135)"""
+        out = []
+        for n in hw:
+            n = (n + 6 - 7) // 2 + 1
+            n = (n + 2 - 3) // 2 + 1
+            lv = []
+            for _ in range(3):
+                n = (n - 1) // 2 + 1
+                lv.append(n)
+            for _ in range(2):
+                n = (n + 2 - 3) // 2 + 1
+                lv.append(n)
+            out.append(lv)
+        return list(zip(*out))
 
     def forward(self, img, img_meta, return_loss=True, **kwargs):
         if return_loss:

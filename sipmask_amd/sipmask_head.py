@@ -327,8 +327,8 @@ class SipMaskHead(nn.Module):
                 if k.startswith("convs_scoring.") or k.startswith("mask_scoring.")}
 
     def loss(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, gt_bboxes, gt_labels, img_metas, cfg,
-             gt_bboxes_ignore=None, gt_masks_list=None, _per_image=None):
-        """sipmask_head.py:289-498 (rescoring_flag=False): dict(loss_cls, loss_bbox, loss_centerness, loss_mask).
+             gt_bboxes_ignore=None, gt_masks_list=None, _per_image=None, _targets=None):
+        """sipmask_head.py:289-498: dict(loss_cls, loss_bbox, loss_centerness, loss_mask[, loss_iou]).
 
         Same arguments as the reference.  Target assignment is tensor code (targets.py); the classification
         loss runs on the HIP sigmoid-focal-loss kernel and the mask loss on the fused HIP kernels
@@ -341,18 +341,14 @@ class SipMaskHead(nn.Module):
         assert len(cls_scores) == len(bbox_preds) == len(centernesses)
         dev = cls_scores[0].device
         sizes = [tuple(f.shape[-2:]) for f in cls_scores]
-        points = T.level_points(sizes, self.strides, bbox_preds[0].dtype, dev)
-        nums = [p.shape[0] for p in points]
         num_imgs, C = cls_scores[0].size(0), self.cls_out_channels
-        lab_lvl, tgt_lvl, lab_img, tgt_img, gt_inds = T.fcos_target(
-            points, self.strides, self.regress_ranges, gt_bboxes, gt_labels, self.center_sampling,
-            self.center_sample_radius)
+        tg = _targets
+        if tg is None or tg["sizes"] != sizes or tg["mask_hw"] != tuple(feat_masks.shape[-2:]):
+            tg = self.prepare_targets(sizes, tuple(feat_masks.shape[-2:]), gt_bboxes, gt_labels, gt_masks_list, dev,
+                                      bbox_preds[0].dtype)
+        points, f_lab, f_tgt, f_pts, f_str, pos, num_pos = (tg[k] for k in ("points", "f_lab", "f_tgt", "f_pts", "f_str",
+                                                                           "pos", "num_pos"))
         f_cls, f_box, f_ctr = _flat_rows(cls_scores, C), _flat_rows(bbox_preds, 4), _flat_rows(centernesses, 1).reshape(-1)
-        f_lab, f_tgt = torch.cat(lab_lvl), torch.cat(tgt_lvl)
-        f_pts = torch.cat([p.repeat(num_imgs, 1) for p in points])
-        f_str = torch.cat([p.new_full((n * num_imgs, 1), float(s)) for p, n, s in zip(points, nums, self.strides)])
-        pos = f_lab.nonzero().reshape(-1)
-        num_pos = len(pos)
         loss_cls = self.loss_cls(f_cls, f_lab, avg_factor=num_pos + num_imgs)             # :364-366
         p_box, p_ctr = f_box[pos], f_ctr[pos]
         if num_pos > 0:
@@ -375,23 +371,36 @@ class SipMaskHead(nn.Module):
         cat_pts = torch.cat(points)
         loss_mask = 0
         loss_iou, num_iou = 0, 0.1                                                        # :404-405
+        # The reference drops positives whose predicted box has area <= 1 by boolean indexing (:421-424) -- a
+        # data-dependent shape, i.e. a device->host sync per image in the middle of the step.  Without per-image hooks
+        # the same sums are formed over ALL positives with the dropped ones masked to zero: no sync after the targets.
+        masked = _per_image is None and not self.rescoring_flag
         for i in range(num_imgs):
-            labels = torch.cat([l.flatten() for l in lab_img[i]])
-            pi = (labels > 0).nonzero().view(-1)
+            labels, pi, gt_new = tg["labels"][i], tg["pi"][i], tg["gt_new"][i]
+            if pi.numel() == 0:
+                continue
             ri = img_rows[i][pi]                                                          # rows of this image's positives
             bdt = T.distance2bbox(cat_pts[pi], box_flat[ri]) / 2                          # det_bboxes[i] / 2
-            area = (bdt[:, 2] - bdt[:, 0]) * (bdt[:, 3] - bdt[:, 1])
-            keep = area > 1.0
-            bdt, idx, pk, rk = bdt[keep], gt_inds[i][keep], pi[keep], ri[keep]
+            wb, hb = bdt[:, 2] - bdt[:, 0], bdt[:, 3] - bdt[:, 1]
+            keep = wb * hb > 1.0
+            idx = tg["gt_inds"][i]
+            if masked:
+                with torch.no_grad():
+                    cnt = keep.sum()
+                    score = cls_flat[ri, labels[pi] - 1].sigmoid()
+                    wgt = torch.where(keep, score * T.aligned_iou(gt_bboxes[i][idx] / 2, bdt), score.new_zeros(()))
+                    wgt = wgt / (wgt.sum() + 0.0001) * cnt
+                    den = torch.where(keep, wb * hb, wb.new_ones(())) * cnt.clamp(min=1)
+                bce = mask_loss(feat_masks[i], cof_flat[ri], bdt, gt_new, idx)           # [N] per-detection sums
+                loss_mask = loss_mask + torch.sum(torch.where(keep, bce / den, bce.new_zeros(())) * wgt)
+                continue
+            bdt, idx, pk, rk = bdt[keep], idx[keep], pi[keep], ri[keep]
             if bdt.shape[0] == 0:
-                loss_mask = loss_mask + area.sum() * 0
                 continue
             with torch.no_grad():
                 score = cls_flat[rk, labels[pk] - 1].sigmoid()
                 weighting = score * T.aligned_iou(gt_bboxes[i][idx] / 2, bdt)
                 weighting = weighting / (weighting.sum() + 0.0001) * len(weighting)
-                hm, wm = feat_masks[i].shape[1:]
-                gt_new = T.prepare_gt_masks(gt_masks_list[i][:gt_labels[i].shape[0]], hm, wm, dev)
             if _per_image is not None:       # hook for heads that add per-image terms (VIS track loss)
                 _per_image(i, bdt, idx)
             bce = mask_loss(feat_masks[i], cof_flat[rk], bdt, gt_new, idx)               # [N] per-detection sums
@@ -400,11 +409,38 @@ class SipMaskHead(nn.Module):
             if self.rescoring_flag:                                                       # :463-483
                 li, wi = self._rescoring_loss(feat_masks[i], cof_flat[rk], bdt, gt_new, idx, labels[pk] - 1)
                 loss_iou, num_iou = loss_iou + li, num_iou + wi
+        if not torch.is_tensor(loss_mask):
+            loss_mask = f_box.sum() * 0                                                   # no positives anywhere (:425-427)
         loss_mask = loss_mask / num_imgs
         out = dict(loss_cls=loss_cls, loss_bbox=loss_bbox, loss_centerness=loss_centerness, loss_mask=loss_mask)
         if self.rescoring_flag:
             out["loss_iou"] = loss_iou * 10 / num_iou                                     # :485-486
         return out
+
+    def prepare_targets(self, sizes, mask_hw, gt_bboxes, gt_labels, gt_masks_list, device, dtype=torch.float32):
+        """Everything of `loss` that depends on the ground truth only (sipmask_head.py:311-352, 405-436): point grid, FCOS
+        target assignment (one device launch), the positives' indices (the `nonzero()` calls -- host syncs -- of the
+        loss) and the ground-truth masks on the basis grid.  `SipMask.forward_train` calls it BEFORE the forward pass,
+        so those syncs wait on an idle device instead of draining the forward's launch queue mid-step; `loss` computes
+        it itself when it is not handed one."""
+        from . import targets as T
+        sizes = [tuple(s) for s in sizes]
+        points = T.level_points(sizes, self.strides, dtype, device)
+        nums = [p.shape[0] for p in points]
+        num_imgs = len(gt_bboxes)
+        lab_lvl, tgt_lvl, lab_img, _, gt_inds = T.fcos_target(points, self.strides, self.regress_ranges, gt_bboxes, gt_labels,
+                                                              self.center_sampling, self.center_sample_radius)
+        f_lab, f_tgt = torch.cat(lab_lvl), torch.cat(tgt_lvl)
+        pos = f_lab.nonzero().reshape(-1)
+        labels = [torch.cat([l.flatten() for l in lab_img[i]]) for i in range(num_imgs)]
+        pi = [(lab > 0).nonzero().view(-1) for lab in labels]
+        hm, wm = mask_hw
+        gt_new = [T.prepare_gt_masks(gt_masks_list[i][:gt_labels[i].shape[0]], hm, wm, device) if pi[i].numel() else None
+                  for i in range(num_imgs)]
+        return dict(sizes=sizes, mask_hw=(hm, wm), points=points, f_lab=f_lab, f_tgt=f_tgt,
+                    f_pts=torch.cat([p.repeat(num_imgs, 1) for p in points]),
+                    f_str=torch.cat([p.new_full((n * num_imgs, 1), float(s)) for p, n, s in zip(points, nums, self.strides)]),
+                    pos=pos, num_pos=len(pos), labels=labels, pi=pi, gt_inds=gt_inds, gt_new=gt_new)
 
     def _rescoring_loss(self, feat_mask, cof, bdt, gt_new, idx, pos_labels):
         """SipMask++ rescoring loss of one image (sipmask_head.py:463-483): the DETACHED cropped probability masks of
