@@ -147,7 +147,18 @@ class HipSGD:
         for t, it, g in zip(tab, live, grads):
             t.p, t.g, t.buf, t.n = it["p"].data_ptr(), g.data_ptr(), it["buf"].data_ptr(), it["p"].numel()
             t.lr, t.wd = it["lr"], it["wd"]
-        items = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
+        # the table goes up through PINNED host memory with a non-blocking copy: a pageable H2D copy is stream-ordered behind
+        # the whole queued backward AND blocks the host until it ran, i.e. a device sync per step that kept the host from
+        # enqueueing the next step's forward while this step's backward is still running (two alternating buffers: the
+        # copy of step n may not have executed yet when step n+1 fills its table)
+        nbytes = C.sizeof(tab)
+        if getattr(self, "_pin", None) is None or self._pin[0].numel() < nbytes:
+            self._pin = [torch.empty(max(nbytes, 64), dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self._dev_items = [torch.empty(max(nbytes, 64), dtype=torch.uint8, device=dev) for _ in range(2)]
+        k = self._steps & 1
+        C.memmove(self._pin[k].data_ptr(), C.addressof(tab), nbytes)
+        items = self._dev_items[k]
+        items[:nbytes].copy_(self._pin[k][:nbytes], non_blocking=True)
         lib = _lib.load()
         _lib.check(lib.sm_sgd_multi(_lib.ptr(items), _lib.ptr(self._blocks[1]), self._blocks[2], float(self.momentum),
                                     int(first), _lib.stream_ptr()), "sm_sgd_multi")
@@ -177,10 +188,12 @@ def head_train_step(head, feats, gt_bboxes, gt_labels, gt_masks, img_metas, opti
     return {k: float(v.detach()) for k, v in losses.items()}
 
 
-def detector_train_step(det, img, img_metas, gt_bboxes, gt_labels, gt_masks, optimizer, bucketer=None):
+def detector_train_step(det, img, img_metas, gt_bboxes, gt_labels, gt_masks, optimizer, bucketer=None, sync=True):
     """One data-parallel training step of the whole detector (BASELINE config #4): SipMask.forward_train (HIP
     autograd ops for backbone stages 2-4, FPN and head; BN and stage 1 frozen as in the config) -> backward with the
-    bucketed all-reduce overlapped -> SGD.  Returns the loss dict (floats)."""
+    bucketed all-reduce overlapped -> SGD.  Returns the loss dict: floats, or with sync=False detached 0-d device tensors
+    -- reading a loss value is a device sync, and a training loop that logs every N iterations need not pay one per step
+    (the host then enqueues the next step's forward while this step's backward is still running)."""
     optimizer.zero_grad()
     if img.is_cuda:
         from .ops_rows import begin_step
@@ -190,4 +203,4 @@ def detector_train_step(det, img, img_metas, gt_bboxes, gt_labels, gt_masks, opt
     if bucketer is not None:
         bucketer.finish()
     optimizer.step()
-    return {k: float(v.detach()) for k, v in losses.items()}
+    return {k: (float(v.detach()) if sync else v.detach()) for k, v in losses.items()}
