@@ -57,9 +57,9 @@ def parse(argv=None):
                          "statistics fused) N times and exit, so a rocprofv3 --stats / --pmc run sees that kernel alone")
     a = ap.parse_args(argv)
     if a.steps is None:
-        a.steps = {"r50": 20, "r101": 20, "train": 5, "vis": 5}[a.config]
+        a.steps = {"r50": 20, "r101": 20, "train": 5, "vis": 10}[a.config]
     if a.warmup is None:
-        a.warmup = {"r50": 5, "r101": 5, "train": 2, "vis": 1}[a.config]
+        a.warmup = {"r50": 5, "r101": 5, "train": 2, "vis": 2}[a.config]
     if a.depth is None:
         a.depth = 101 if a.config == "r101" else 50
     return a

@@ -70,7 +70,9 @@ js = {
     "hbm_bytes_per_launch": fb + wb, "algorithmic_bytes_per_launch": tower["algorithmic_mb"] * 1e6,
     "rocprofv3_kernel_trace": krow,
     "live_hip_event_ms_per_launch": {"bench.py breakdown (no profiler)": bench["roofline"].get("ms_per_launch"),
-                                     "bench.py --tower-only under rocprofv3": tower["ms_per_launch"]},
+                                     "bench.py --tower-only under rocprofv3 (includes the profiler's per-dispatch "
+                                     "overhead, which varies from box to box; the kernel's own duration is the trace below)":
+                                         tower["ms_per_launch"]},
     "SQ_per_dispatch": {k: mean(v) for k, v in sq[grid].items()},
     "rocprofv3_kernel_trace_this_grid_us": trace_by_grid(),
 }
