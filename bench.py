@@ -47,6 +47,9 @@ def parse(argv=None):
     ap.add_argument("--lanes", type=int, default=0, help="run the batch as this many independent sub-batch plans on "
                     "concurrent HIP streams (engine.SubBatchPlan); 0 = the product default (2 for even batches >= 4)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--free-run", type=int, default=0, choices=[0, 1, 2],
+                    help="with --sub-graphs: the sub-plan chains replay on their own streams without a per-step join "
+                         "(1 = started in phase, 2 = started half a pass apart)")
     ap.add_argument("--sub-graphs", type=int, default=0, choices=[0, 1, 2],
                     help="with 2 sub-plans: one hipGraph per sub-plan on concurrent streams (1 = sub-plans keep their "
                          "internal side lanes, 2 = single-lane sub-plans) instead of one graph around both")
@@ -177,8 +180,14 @@ def run_inference(args, rank, world, dev):
             graph = None
             torch.cuda.synchronize()
 
+    free_run = sub_graphs and args.free_run
+    if free_run == 2:
+        plan.offset_chains()
+
     def step():
-        if sub_graphs:
+        if free_run:
+            plan.replay(join=False)
+        elif sub_graphs:
             plan.replay()
         elif graph is not None:
             graph.replay()
@@ -189,6 +198,8 @@ def run_inference(args, rank, world, dev):
         step()
     # barrier + torch.cuda.synchronize() on both sides, MAX over ranks (tested with gloo in tests/test_dist_shard.py)
     elapsed = timed_steps(step, args.steps, sync_fn=torch.cuda.synchronize, device=dev)
+    if free_run:
+        plan.join()
     ndet = gather_counts(plan.results()["ndet"].to(torch.int64), device=dev).cpu().tolist()
 
     # ---- per-step HIP-event breakdown (eager, on the launch stream) -> roofline of the dominant kernel

@@ -13,9 +13,9 @@
 // outputs: 1.2 % at W = 168), so a tap (kh, kw) is the constant row shift kh*(W+2) + kw inside the patch and the 32
 // positions of an MFMA tile read 32 CONSECUTIVE patch rows: the XOR swizzle of the 64-byte rows stays conflict free
 // for any shift (rows distinct mod 16 per ds_read_b128 lane group).  Patch rows = 256 + 2*(W+2) + 2 (598 for W = 168).
-// LDS: 2 patch buffers (chunk c computes while chunk c+1 lands) + 2 weight stages of 2 taps x 256 couts x 64 B.
-// Weights come in their own layout [cout_pad][cin/32][9][32] (K order = chunk, tap, channel), one DMA piece = 16 cout
-// rows x 64 B.  8 waves (2 cout x 4 pos), wave tile 128 couts x 64 positions, 1 block per CU, one barrier per 2 taps.
+// LDS: 2 patch buffers (chunk c computes while chunk c+1 lands) + 2 weight stages of 256 couts x 128 B (2 taps).
+// Weights come in their own layout [cout_pad][cin/32][9][32] (K order = chunk, tap, channel), one DMA piece = 8 cout
+// rows x 128 B (the two taps of a stage are one cache line of the row).  8 waves (2 cout x 4 pos), wave tile 128 couts x 64 positions, 1 block per CU, one barrier per 2 taps.
 // Epilogue: conv_igemm's register epilogue (v_permlane32_swap -> 8 consecutive couts per lane), bias, per-level Scale,
 // ReLU, bf16 / f32 stores, fused GroupNorm statistics; multi-level launches and the group dimension (cls + reg towers).
 #include <utility>
@@ -63,7 +63,7 @@ __device__ __forceinline__ void sfor(F&& f) {
 __device__ __attribute__((aligned(16))) const unsigned int g_zero16p[4] = {0u, 0u, 0u, 0u};
 
 constexpr int PT_BCO = 256, PT_BPOS = 256, PT_THREADS = 512;
-constexpr int PT_WSTAGE = 2 * PT_BCO * 64;        // one weight stage: 2 taps x 256 couts x 64 B
+constexpr int PT_WSTAGE = PT_BCO * 128;           // one weight stage: 256 cout rows x 128 B (2 taps x 32 channels)
 constexpr int PT_MAXPP = 6;                       // patch DMA pieces per wave (<= 768 patch rows)
 
 // One tile: 256 couts x (WPOS * TPOS * 32) positions on 8 waves laid out WCO (cout) x WPOS (position), each wave
@@ -123,14 +123,19 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
     poff[i] = ok ? (int)((ih * W + iwp - 1) * a.in_cstride + chunk * 8) : -1;
   }
   const uint16_t* const xbase = a.x + img_row0 * a.in_cstride;
-  // weights: a stage = 2 halves (taps) x 16 pieces; this wave owns pieces wave*4 .. wave*4+3 (half = piece >> 4)
+  // weights: the two taps of a stage are 128 CONTIGUOUS bytes of a cout row in the [cout][chunk][tap][32] layout, so a
+  // weight piece is 8 cout rows x one whole 128-byte line (8 lanes per line) instead of 16 rows x half a line: what the
+  // L2 -> LDS path charges for is the number of lines a wave-instruction touches (PMC: one TCP access per row; 64-byte
+  // rows moved 40 GB/s per CU, conv_igemm's 128-byte rows 92), and the weights are 80 % of this kernel's DMA rows.
+  // LDS stage = [256 cout rows][128 B]: 16-byte slot (tap * 4 + K chunk) ^ ((row >> 1) & 7) -- the 16 lanes a
+  // ds_read_b128 services together (MI355X_MICROARCH.md, LDS) then cover all 64 banks once.
+  // A stage = 32 pieces; this wave owns pieces wave*4 .. wave*4+3.
   const uint16_t* wsrc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int piece = wave * 4 + i;
-    const int half = piece >> 4, row = (piece & 15) * 16 + lrow;
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    wsrc[i] = a.w + grp * a.w_gstride + (long long)(nt * PT_BCO + row) * a.Kp + half * 32 + chunk * 8;
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    wsrc[i] = a.w + grp * a.w_gstride + (long long)(nt * PT_BCO + row) * a.Kp + chunk * 8;
   }
   auto dma_w = [&](int stage, int buf) {            // weight stage `stage` (K steps 2*stage, 2*stage+1) -> Wb[buf]
     unsigned char* dst = Wb0 + buf * PT_WSTAGE;
@@ -138,7 +143,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
       constexpr int i = decltype(I)::value;
       const int piece = wave * 4 + i;
       __builtin_amdgcn_global_load_lds((glb_void*)(wsrc[i] + (long long)stage * 64),
-                                       (lds_void*)(dst + (piece >> 4) * (PT_BCO * 64) + (piece & 15) * 1024), 16, 0, 0);
+                                       (lds_void*)(dst + piece * 1024), 16, 0, 0);
     });
   };
   auto dma_patch_piece = [&](auto I, int chunk_c, int buf) {     // piece I of this wave, channel chunk c -> Pb[buf]
@@ -159,15 +164,15 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[tc][tp][e] = 0.f;
 
-  const int rsw = (l31 >> 2) & 3;
-  const int wrow_off = (wco * (TCO * 32) + l31) * 64;
+  const int rsw = (l31 >> 1) & 7;
+  const int wrow_off = (wco * (TCO * 32) + l31) * 128;
   const int prow0 = wpos * (TPOS * 32) + l31;              // patch row of this lane's position at tap (0,0), tp = 0
 
   // one tap: 2 K sub-steps of 16, 8 MFMAs each; both sub-steps' fragments are requested up front and hipcc schedules the
   // stage (2 taps = 24 reads + 32 MFMAs, one basic block).  A/B (round 2): the same stage with the reads of sub-step
   // u+1 pinned under the MFMAs of u and the DMA issues pinned behind every second MFMA (sched_barrier(0) per slot)
   // needed 256 VGPRs + 19 spills and ran 764 vs 835 TFLOP/s on the B=2 tower launch -- not kept.
-  auto tap = [&](const unsigned char* Wh, const unsigned char* P, int shift) {
+  auto tap = [&](const unsigned char* Wst, const int hx, const unsigned char* P, int shift) {   // hx = 64 * (tap of the stage)
     bf16x8 wf[2][TCO], xf[2][TPOS];
     int pr[TPOS], psw[TPOS];
 #pragma unroll
@@ -178,7 +183,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
     auto rd = [&](int kk, int set) {
 #pragma unroll
       for (int t = 0; t < TCO; ++t)
-        wf[set][t] = *reinterpret_cast<const bf16x8*>(Wh + wrow_off + t * 32 * 64 + (((kk * 2 + khalf) ^ rsw) * 16));
+        wf[set][t] = *reinterpret_cast<const bf16x8*>(Wst + wrow_off + t * 32 * 128 + ((((kk * 2 + khalf) ^ rsw) * 16) ^ hx));
 #pragma unroll
       for (int t = 0; t < TPOS; ++t)
         xf[set][t] = *reinterpret_cast<const bf16x8*>(P + pr[t] * 64 + (((kk * 2 + khalf) ^ psw[t]) * 16));
@@ -222,7 +227,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
       constexpr int sidx = decltype(SC)::value;
       constexpr int hh = sidx & 1;
       constexpr int cc = sidx / 9, t9 = sidx % 9, kh = t9 / 3, kw = t9 % 3;
-      const unsigned char* Wh = Wb0 + (st & 1) * PT_WSTAGE + hh * (PT_BCO * 64);
+      const unsigned char* Wh = Wb0 + (st & 1) * PT_WSTAGE;
       const unsigned char* P = Pb0 + cc * PB;
       // the patch-row addresses of the 18 taps are invariant over the channel-chunk loop and hipcc hoists all of them
       // (36+ VGPRs held across the loop -> spills next to 128 accumulators + 48 fragment registers); an opaque copy of
@@ -233,12 +238,12 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
       // t*32 rows do not change (row >> 2) & 3: one swizzle per tap, the K-half is one XOR with 32 bytes
       const int pr0 = prow0 + shift;
       const int xa = pr0 * 64 + ((khalf ^ ((pr0 >> 2) & 3)) * 16);
-      const int wa = wrow_off + ((khalf ^ rsw) * 16);
+      const int wa = wrow_off + (((hh * 4 + khalf) ^ rsw) * 16);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
         for (int t = 0; t < TCO; ++t)
-          wf[kk][t] = *reinterpret_cast<const bf16x8*>(Wh + (wa ^ (kk * 32)) + t * 32 * 64);
+          wf[kk][t] = *reinterpret_cast<const bf16x8*>(Wh + (wa ^ (kk * 32)) + t * 32 * 128);
 #pragma unroll
         for (int t = 0; t < TPOS; ++t)
           xf[kk][t] = *reinterpret_cast<const bf16x8*>(P + (xa ^ (kk * 32)) + t * 32 * 64);
@@ -338,12 +343,11 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
           constexpr int hh = i >> 1, kk = i & 1;
           constexpr int s = 2 * sp + hh;
           constexpr int cc = s / 9, t9 = s % 9, kh = t9 / 3, kw = t9 % 3;
-          const unsigned char* Wh = Wst + hh * (PT_BCO * 64);
           const unsigned char* P = Pb0 + cc * PB;
           const int shift = kh * Wp + kw;
 #pragma unroll
           for (int t = 0; t < TCO; ++t)
-            wf[set][t] = *reinterpret_cast<const bf16x8*>(Wh + wrow_off + t * 32 * 64 + (((kk * 2 + khalf) ^ rsw) * 16));
+            wf[set][t] = *reinterpret_cast<const bf16x8*>(Wst + wrow_off + t * 32 * 128 + (((hh * 4 + kk * 2 + khalf) ^ rsw) * 16));
 #pragma unroll
           for (int t = 0; t < TPOS; ++t) {
             const int pr = prow0 + t * 32 + shift;
@@ -384,7 +388,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
         if constexpr (hh == 1 && STAGGER) {
           if (!early) issue_dma();
         }
-        if constexpr (!NO_MFMA) tap(Wst + hh * (PT_BCO * 64), Pb0 + cc * PB, kh * Wp + kw);
+        if constexpr (!NO_MFMA) tap(Wst, hh * 64, Pb0 + cc * PB, kh * Wp + kw);
       });
       }
       __syncthreads();                                             // drains the DMA queue (vmcnt(0)) and fences the buffers

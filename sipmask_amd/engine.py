@@ -934,8 +934,21 @@ class SubBatchPlan:
             b0 += e.batch
         return self
 
-    def replay(self):
+    def replay(self, join=True):
+        """join=True: fork from / join to the caller's stream around every replay (results valid in stream order).
+        join=False: FREE-RUNNING chains -- sub-plan i replays on its own stream behind its previous replay only, so
+        the chains of consecutive batches drift apart and one chain's low-parallelism tail (top-k select, NMS on a few
+        blocks, mask assembly) overlaps the other chain's convs of the NEXT batch instead of the other chain's tail.
+        The caller calls join() before reading the outputs or overwriting the input."""
         main = torch.cuda.current_stream()
+        if not join:
+            if not hasattr(self, "free_streams"):
+                self.free_streams = [torch.cuda.Stream(device=self.engines[0].device) for _ in self.engines]
+            for g, st in zip(self.graphs, self.free_streams):
+                st.wait_stream(main)                    # the input the caller produced on its stream
+                with torch.cuda.stream(st):
+                    g.replay()
+            return None
         for g, st in zip(self.graphs[1:], self.streams):
             st.wait_stream(main)
             with torch.cuda.stream(st):
@@ -944,6 +957,28 @@ class SubBatchPlan:
         for st in self.streams:
             main.wait_stream(st)
         return self.results()
+
+    def join(self):
+        """the caller's stream waits for every free-running chain (replay(join=False))"""
+        main = torch.cuda.current_stream()
+        for st in getattr(self, "free_streams", ()):
+            main.wait_stream(st)
+        return self.results()
+
+    def offset_chains(self):
+        """One-time phase offset for free-running chains: chain i > 0 first runs i/n of a pass eagerly on its stream (its
+        outputs are overwritten by the next replay), so the chains start out of phase instead of in lock step."""
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "free_streams"):
+            self.free_streams = [torch.cuda.Stream(device=self.engines[0].device) for _ in self.engines]
+        n = len(self.engines)
+        for i, (e, st) in enumerate(zip(self.engines, self.free_streams)):
+            if i == 0:
+                continue
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                k = len(e.steps) * i // n
+                e._run_steps(e.steps[:k], e.lanes[:k])
 
     def results(self):
         r = dict(det_bboxes=self.out["det"], det_labels=self.out["labels"], idxs_keep=self.out["keep"], ndet=self.out["ndet"],
