@@ -55,6 +55,8 @@ typedef enum {
                                     share their values are read by sm_conv3x3_patch only.) */
 #define SM_CONV_RELU_NCH 32u     /* y = max(y, 0) on channels < scale_nch only (the maskrcnn-benchmark variant's
                                     relu(scale(bbox_pred)), SipMask-benchmark/.../sipmask/sipmask.py:155-157) */
+#define SM_CONV_DBG_DEFORM_GATHER 0x80000000u /* A/B switch: deformable conv through conv_igemm's global-gather loader where the
+                                    LDS-patch kernel (deform_patch.hip: 3x3, 64 channels per deformable group) would run */
 #define SM_CONV_DBG_LINEAR_TILES 0x40000000u /* A/B switch: disable the XCD-aware tile remap */
 #define SM_CONV_DBG_REG_STAGING 0x20000000u  /* A/B switch: register-staged loader instead of LDS-DMA */
 #define SM_CONV_DBG_K32 0x10000000u          /* A/B switch: force 32-wide K steps, 4 blocks per CU */

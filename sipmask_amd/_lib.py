@@ -19,6 +19,7 @@ SM_CONV_RES_ADD = 4
 SM_CONV_RES_NEAREST = 8
 SM_CONV_IN_RELU = 16
 SM_CONV_RELU_NCH = 32
+SM_CONV_DBG_DEFORM_GATHER = 0x80000000   # A/B: the global-gather deformable loader instead of deform_patch.hip
 
 _i32x5 = C.c_int32 * SM_MAX_LEVELS
 _i64x5 = C.c_int64 * SM_MAX_LEVELS

@@ -17,6 +17,11 @@
 
 #include "common.h"
 
+// deform_patch.hip
+bool sm_deform_patch_supported(const sm_conv_desc* d);
+int sm_deform_patch_launch(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,
+                           void* y, hipStream_t stream, float* gn_stats, long long k_padded);
+
 namespace {
 
 struct ConvKArgs {
@@ -1768,6 +1773,11 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     if (ng > 1 && d->gn_group_stride != 2ll * d->batch * d->nlev * (d->cout / 8)) return SM_ERR_BAD_ARG;   // contiguous
     if (hipMemsetAsync(gn_stats, 0, sizeof(float) * 2 * d->batch * d->nlev * (d->cout / 8) * ng, stream) != hipSuccess)
       return SM_ERR_LAUNCH;
+  }
+  if constexpr (DEFORM) {
+    // FeatureAlign's shape goes to the LDS-patch kernel (deform_patch.hip); everything else, and the A/B flag, gathers
+    if (!(d->flags & SM_CONV_DBG_DEFORM_GATHER) && sm_deform_patch_supported(d) && bco == 256)
+      return sm_deform_patch_launch(d, x, offset, w, bias, y, stream, gn_stats, plan.k_padded);
   }
   a.nlev = d->nlev;
   a.batch = d->batch;
