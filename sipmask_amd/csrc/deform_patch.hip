@@ -130,15 +130,16 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Pb + (wave + 8 * i) * 1024), 16, 0, 0);
     });
   };
-  const uint16_t* const wsrc0 = a.w + (long long)(nt * DP_BCO + wave * 32 + (lane >> 3)) * a.Kp;
-  auto dma_w = [&](int g, int tap, int buf) {                    // K step (g, tap) -> Wb[buf]; this wave: rows wave*32 ..+31
+  // weights: uniform base (SGPRs) + one per-lane 32-bit offset.  Piece i of this wave = rows wave*32 + 8i .. +7; lane L ->
+  // row r = L >> 3 of the piece, physical slot L & 7 = logical chunk (L & 7) ^ ((row >> 1) & 7) = (L & 7) ^ (r >> 1) ^ 4*(i & 1)
+  const unsigned wvoff0 = (unsigned)((lane >> 3) * (int)a.Kp + (((lane & 7) ^ ((lane >> 4) & 3)) * 8));   // Kp % 64 == 0
+  const unsigned wvoff1 = wvoff0 ^ 32u;
+  auto dma_w = [&](int g, int tap, int buf) {                    // K step (g, tap) -> Wb[buf]
     unsigned char* dst = Wb0 + buf * DP_WSTAGE;
-    const int koff = tap * a.cin + g * 64;
+    const uint16_t* const ubase = a.w + ((long long)(nt * DP_BCO + wave * 32) * a.Kp + tap * a.cin + g * 64);
     dfor<4>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      const int row = (wave * 4 + i) * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      __builtin_amdgcn_global_load_lds((glb_void*)(wsrc0 + (long long)(8 * i) * a.Kp + koff + chunk * 8),
+      __builtin_amdgcn_global_load_lds((glb_void*)(ubase + (long long)(8 * i) * a.Kp + ((i & 1) ? wvoff1 : wvoff0)),
                                        (lds_void*)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
     });
   };
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 w1v, w2v, w3v, w4v;
   int c1, c2, c3, c4;            // LDS byte addresses of the four corners, K chunk khalf (sub-step kk: ^ (kk * 32))
-  int e1, e2, e3, e4;            // element offsets of the same corners in the image (fallback)
+  int hlo, wlo, gofs;            // the sample's top-left pixel in the image and the channel offset (fallback only)
   bool far;                      // wave-uniform: some lane samples outside the LDS window
   // the DEFORM loader of conv_igemm.hip with rhi = oy - 1, rwi = ox - 1 (deform_conv_cuda_kernel.cu:85-115,216-229)
   auto setup = [&](int g_, int tap_, float2 off) {
@@ -194,11 +195,7 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
     c2 = (a1 + 128) ^ ((((p1 + 1) >> 1) & 7) * 16);
     c3 = (a1 + DP_PW * 128) ^ ((((p1 + DP_PW) >> 1) & 7) * 16);
     c4 = (a1 + DP_PW * 128 + 128) ^ ((((p1 + DP_PW + 1) >> 1) & 7) * 16);
-    const int hl = min(max(h_low, 0), H - 1), hh_ = min(max(h_high, 0), H - 1);
-    const int wl = min(max(w_low, 0), W - 1), wh_ = min(max(w_high, 0), W - 1);
-    const int gofs = g_ * 64 + khalf * 8;
-    e1 = (hl * W + wl) * a.in_cstride + gofs, e2 = (hl * W + wh_) * a.in_cstride + gofs;
-    e3 = (hh_ * W + wl) * a.in_cstride + gofs, e4 = (hh_ * W + wh_) * a.in_cstride + gofs;
+    hlo = h_low, wlo = w_low, gofs = g_ * 64 + khalf * 8;
   };
   // corners of K sub-step kk.  Fallback arm: this tap's corners come from global memory for the whole wave (clamped
   // addresses, the weights carry the zero padding); the empty asm makes its results register-defined, so that the code
@@ -212,10 +209,15 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
     q3 = *reinterpret_cast<const lds_u32x4*>(smem3 + (c3 ^ (kk * 32)));
     q4 = *reinterpret_cast<const lds_u32x4*>(smem3 + (c4 ^ (kk * 32)));
     if (far) {
-      q1 = *reinterpret_cast<const u32x4*>(ximg + e1 + kk * 16);
-      q2 = *reinterpret_cast<const u32x4*>(ximg + e2 + kk * 16);
-      q3 = *reinterpret_cast<const u32x4*>(ximg + e3 + kk * 16);
-      q4 = *reinterpret_cast<const u32x4*>(ximg + e4 + kk * 16);
+      int W_l = W;
+      asm volatile("" : "+s"(W_l));                       // opaque: hipcc otherwise speculates this arm's address arithmetic
+      const int hl = min(max(hlo, 0), H - 1), hh_ = min(max(hlo + 1, 0), H - 1);       // (12 v_mul_lo_u32) into every step
+      const int wl = min(max(wlo, 0), W_l - 1), wh_ = min(max(wlo + 1, 0), W_l - 1);
+      const uint16_t* const gp = ximg + gofs + kk * 16;
+      q1 = *reinterpret_cast<const u32x4*>(gp + (hl * W_l + wl) * a.in_cstride);
+      q2 = *reinterpret_cast<const u32x4*>(gp + (hl * W_l + wh_) * a.in_cstride);
+      q3 = *reinterpret_cast<const u32x4*>(gp + (hh_ * W_l + wl) * a.in_cstride);
+      q4 = *reinterpret_cast<const u32x4*>(gp + (hh_ * W_l + wh_) * a.in_cstride);
       asm volatile("" : "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4));
     }
   };

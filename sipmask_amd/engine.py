@@ -26,6 +26,11 @@ _GROUPED_TOWERS = __import__("os").environ.get("SIPMASK_GROUPED_TOWERS", "1") ==
 
 _SPLIT_K = __import__("os").environ.get("SIPMASK_SPLIT_K", "1") != "0"     # A/B: split-K for under-filled launches
 _PATCH_CONV = __import__("os").environ.get("SIPMASK_PATCH_CONV", "1") != "0"   # A/B: patch-resident 3x3 kernel
+# FeatureAlign's deformable conv: the LDS-window kernel (csrc/deform_patch.hip) is 1.3-1.6x the gather loader while the
+# learned offsets stay within ~3 pixels and falls behind it when most waves sample farther out (random offsets of sigma 4:
+# 0.35 vs 0.26 ms at B=4, profiles/r02_deform_conv_microbench.txt); SIPMASK_DEFORM_GATHER=1 keeps a model with such
+# offsets on the gather loader
+_DEFORM_FLAGS = _lib.SM_CONV_DBG_DEFORM_GATHER if __import__("os").environ.get("SIPMASK_DEFORM_GATHER", "0") == "1" else 0
 _PATCH_MIN_WORK = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_WORK", "100"))   # 256x256 tile equivalents
 _PATCH_MIN_FILL = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_FILL", "0.6"))
 # bottleneck fusion in layer1 / layer2: 0 = separate launches, 1 = conv2+conv3, 2 = conv2+conv3+next conv1.  Measured
@@ -662,7 +667,7 @@ class SipMaskEngine:
         c = self._add_conv(_Conv(self, "head.feat_align", sd[h + "feat_align.conv_adaption.weight"],
                                  sd.get(h + "feat_align.conv_adaption.bias"), B, sizes,
                                  row0, self.cls_feat, 256, 1, 1, self.aligned, row0, 256, deform_groups=4,
-                                 offset=self.offsets, flags=0 if self.flag_norm else SM_CONV_RELU))
+                                 offset=self.offsets, flags=(0 if self.flag_norm else SM_CONV_RELU) | _DEFORM_FLAGS))
         if self.flag_norm:                                 # FeatureAlign.forward, sipmask_head.py:49-55
             self._gn("feat_align", self.aligned, sd[h + "feat_align.norm.weight"], sd[h + "feat_align.norm.bias"],
                      conv=c)

@@ -84,7 +84,8 @@ for src, dst in (("step_breakdown.txt", "r02_step_breakdown_hip_events.txt"),
                  ("kernel_stats_train.csv", "r02_rocprofv3_kernel_stats_train_step.csv"),
                  ("parity_r50_b4_bf16.json", "r02_parity_r50_b4_bf16.json"),
                  ("parity_r50_b4_f32.json", "r02_parity_r50_b4_f32.json"),
-                 ("patch_bench.txt", "r02_patch_conv_microbench.txt")):
+                 ("patch_bench.txt", "r02_patch_conv_microbench.txt"),
+                 ("deform_bench.txt", "r02_deform_conv_microbench.txt")):
     if os.path.exists(os.path.join(SRC, src)):
         shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
 lines = {}

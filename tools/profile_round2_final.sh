@@ -31,4 +31,5 @@ cd $R
 timeout 600 python tools/parity_baseline.py --depth 50 --batch 4 --precision bf16 --out $OUT/parity_r50_b4_bf16.json > $OUT/parity_bf16.log 2>&1
 timeout 600 python tools/parity_baseline.py --depth 50 --batch 4 --precision f32 --out $OUT/parity_r50_b4_f32.json > $OUT/parity_f32.log 2>&1
 timeout 300 python tools/patch_bench.py > $OUT/patch_bench.txt 2>&1
+timeout 300 python tools/deform_fwd_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/deform_bench.txt
 find $OUT -name "*counter_collection.csv" | head -3; tail -c 300 $OUT/tower.log; cut -c1-250 $OUT/bench_r50.json; cut -c1-160 $OUT/bench_train.json
