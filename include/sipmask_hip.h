@@ -188,7 +188,12 @@ int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void* w_patch, 
  * (never materialises the column buffer).  Replaces deform_conv_forward_cuda,
  * M/mmdet/ops/dcn/src/deform_conv_cuda.cpp:152-260 + deformable_im2col_gpu_kernel,
  * M/mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:191-243.
- * offset: f32 [rows][G*kh*kw*2] with the reference channel order (kernel.cu:216-223). */
+ * offset: f32 [rows][G*kh*kw*2] with the reference channel order (kernel.cu:216-223).
+ * Two kernels behind this entry point: FeatureAlign's shape (3x3, stride 1, pad 1, 64 channels per deformable group,
+ * cout_pad % 256 == 0, plain epilogue) runs on csrc/deform_patch.hip -- one group's pixel window resident in LDS, offsets
+ * beyond 3 pixels handled by a per-wave global fallback; every other shape, and SM_CONV_DBG_DEFORM_GATHER, on the
+ * gather loader of csrc/conv_igemm.hip.  Same samples either way (f32 blend, one rounding to the bf16 operand); the K
+ * summation order differs. */
 int sm_deform_conv2d(const sm_conv_desc* d, const void* x, const float* offset, const void* w,
                      const float* bias, void* y, sm_stream_t stream);
 
