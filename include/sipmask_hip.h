@@ -196,6 +196,9 @@ int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void* w_patch, 
  * summation order differs. */
 int sm_deform_conv2d(const sm_conv_desc* d, const void* x, const float* offset, const void* w,
                      const float* bias, void* y, sm_stream_t stream);
+/* Which of the two kernels takes d (pure host logic, no GPU needed): SM_OK and out4 = {blocks, tile rows, tile columns,
+ * LDS window pixels per deformable group} for the LDS-window kernel, SM_ERR_UNSUPPORTED for the gather loader. */
+int sm_deform_conv_window_plan(const sm_conv_desc* d, int64_t* out4);
 
 /* Deformable conv v1 backward: replaces deform_conv_backward_input_cuda + deform_conv_backward_parameters_cuda
  * (M/mmdet/ops/dcn/src/deform_conv_cuda.cpp:262-490; kernels deform_conv_cuda_kernel.cu:279-433).

@@ -83,6 +83,7 @@ PROTOTYPES = {
     "sm_conv3x3_patch_plan": (_I, [C.POINTER(ConvDesc), _P]),
     "sm_conv3x3_patch": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "sm_deform_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    "sm_deform_conv_window_plan": (_I, [C.POINTER(ConvDesc), _P]),
     "sm_conv2d_gn_stats": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_conv2d_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "sm_nchw_f32_to_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

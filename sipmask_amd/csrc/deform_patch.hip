@@ -422,6 +422,21 @@ bool sm_deform_patch_supported(const sm_conv_desc* d) {
   return true;
 }
 
+// Host-side query (no GPU): does sm_deform_conv2d / sm_conv2d_gn_stats run this deformable conv on the LDS-window kernel?
+// SM_OK and out4 = {blocks, tile rows, tile columns, LDS window pixels per deformable group}, or SM_ERR_UNSUPPORTED when the
+// gather loader of conv_igemm.hip takes it (other shapes, SM_CONV_DBG_DEFORM_GATHER).
+extern "C" int sm_deform_conv_window_plan(const sm_conv_desc* d, int64_t* out4) {
+  if (!d || !out4) return SM_ERR_BAD_ARG;
+  if ((d->flags & SM_CONV_DBG_DEFORM_GATHER) || !sm_deform_patch_supported(d)) return SM_ERR_UNSUPPORTED;
+  long long t = 0;
+  for (int l = 0; l < d->nlev; ++l) t += (long long)d->batch * sm_cdiv(d->in_w[l], DP_TW) * sm_cdiv(d->in_h[l], DP_TH);
+  out4[0] = t * (d->cout_pad / DP_BCO);
+  out4[1] = DP_TH;
+  out4[2] = DP_TW;
+  out4[3] = DP_PPIX;
+  return SM_OK;
+}
+
 // k_padded: row pitch (elements) of the [cout_pad][k_padded] weight operand (sm_conv_plan.k_padded); gn_stats is zeroed by
 // the caller (launch_conv)
 int sm_deform_patch_launch(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,

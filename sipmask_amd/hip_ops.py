@@ -146,6 +146,17 @@ def conv2d_ws(desc, x, w, bias, residual, y, workspace):
     return y
 
 
+def deform_conv_window_plan(desc):
+    """host logic only: dict(blocks, tile=(rows, cols), window_pixels) when the LDS-window kernel (csrc/deform_patch.hip)
+    takes this deformable conv, None when the gather loader of conv_igemm.hip does"""
+    out = (C.c_int64 * 4)()
+    rc = _lib.load().sm_deform_conv_window_plan(C.byref(desc), out)
+    if rc == -4:                       # SM_ERR_UNSUPPORTED: the gather loader's conv
+        return None
+    _lib.check(rc, "sm_deform_conv_window_plan")
+    return dict(blocks=int(out[0]), tile=(int(out[1]), int(out[2])), window_pixels=int(out[3]))
+
+
 def deform_conv2d(desc, x, offset, w, bias, y):
     _lib.require_cuda(x, offset, w, y)
     lib = _lib.load()

@@ -320,3 +320,26 @@ def test_patch_conv_launch_shapes():
             cover = pl["big"] * 256 + pl["small"] * pl["small_pos"]
             need = segs * sum(h * (w + 2) for h, w in sizes)
             assert cover >= need and cover < need + segs * nl * 256, (sizes, b, g, co, pl)
+
+
+def test_deform_conv_kernel_choice_is_host_logic():
+    """sm_deform_conv_window_plan (no GPU): FeatureAlign's shape -- 3x3, 64 channels per deformable group, 256-cout tiles --
+    runs on the LDS-window kernel with 8 x 32-position tiles; the backbone DCN of SipMask++ (1 deformable group), a 1x1
+    kernel, a residual epilogue and the A/B flag stay on the gather loader."""
+    from sipmask_amd import hip_ops as H, _lib
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    lv = H.Levels(2, sizes)
+    mk = lambda cin, co, k, G, flags=0, szs=sizes, l=lv: H.make_conv_desc(
+        2, szs, szs, l.row0, l.row0, cin, co, (co + 255) // 256 * 256, k, 1, k // 2, cin, co, flags=flags, deform_groups=G)
+    pl = H.deform_conv_window_plan(mk(256, 256, 3, 4))
+    # ceil(h / 8) * ceil(w / 32) tiles per image and level: 13*6 + 7*3 + 4*2 + 2*1 + 1*1 = 110
+    assert pl == dict(blocks=2 * 110, tile=(8, 32), window_pixels=16 * 40)
+    assert H.deform_conv_window_plan(mk(256, 512, 3, 4))["blocks"] == 2 * 110 * 2          # two 256-cout tiles
+    assert H.deform_conv_window_plan(mk(256, 256, 3, 4, flags=_lib.SM_CONV_DBG_DEFORM_GATHER)) is None
+    assert H.deform_conv_window_plan(mk(256, 256, 3, 1)) is None                            # 256 channels per group
+    assert H.deform_conv_window_plan(mk(128, 256, 3, 4)) is None                            # 32 channels per group
+    assert H.deform_conv_window_plan(mk(256, 256, 1, 4)) is None
+    assert H.deform_conv_window_plan(mk(256, 256, 3, 4, flags=_lib.SM_CONV_RES_ADD)) is None
+    d = mk(256, 256, 3, 4)
+    d.cout_pad = 128 * 3                                                                     # not a multiple of 256
+    assert H.deform_conv_window_plan(d) is None

@@ -3,7 +3,12 @@
 width, K-loop variant and grid that `sm_conv_plan_query` (the launcher's own selection code) picks for it, the
 fill of its last round of resident blocks, and the non-conv steps with their lanes.
 
-    python tools/plan_dump.py [--batch 4] [--hw 800 1344] [--depth 50] [--variant r50|ssd|vis|benchmark|dcn] [--flags 0x...]
+    python tools/plan_dump.py [--batch 4] [--hw 800 1344] [--depth 50] [--variant r50|ssd|vis|benchmark|dcn] [--sub-plan]
+
+--sub-plan: the plan of ONE chain of engine.SubBatchPlan (the benchmarked structure: --batch 2 --sub-plan): no split-K,
+uniform patch-conv launches.  Round 2: the LDS-window kernels (conv3x3_patch.hip, deform_patch.hip) and the fused
+bottleneck tails (bottleneck.hip) are listed with their own launch shapes (sm_conv3x3_patch_plan,
+sm_deform_conv_window_plan -- host logic as well).
 """
 import argparse
 import os
@@ -15,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build_on_cpu(variant="r50", batch=4, hw=(800, 1344), depth=50):
+def build_on_cpu(variant="r50", batch=4, hw=(800, 1344), depth=50, sub_plan=False):
     """The plan is host logic: with torch.cuda.is_available patched the engine allocates its buffers on the CPU and
     prepares every descriptor; nothing is launched."""
     real = torch.cuda.is_available
@@ -44,7 +49,7 @@ def build_on_cpu(variant="r50", batch=4, hw=(800, 1344), depth=50):
             kw = dict(benchmark=dict(pre_nms_thresh=0.05, pre_nms_top_n=1000, nms_thresh=0.6, post_top_n=100))
         else:
             sd = OM.init_state_dict(depth, 0)
-        return SipMaskEngine(sd, batch, tuple(hw), depth, device="cpu", **kw)
+        return SipMaskEngine(sd, batch, tuple(hw), depth, device="cpu", sub_plan=sub_plan, **kw)
     finally:
         torch.cuda.is_available = real
 
@@ -53,14 +58,41 @@ def conv_rows(eng):
     from sipmask_amd import hip_ops as H
     rows = []
     for c in eng.convs:
+        if getattr(c, "patch", False):                   # conv3x3_patch.hip: one block per CU, its own launch planner
+            pp = H.conv3x3_patch_plan(c.desc)
+            blocks = pp["big"] + pp["small"]
+            shape = "256x256" + ("" if not pp["small"] else "+%d" % pp["small_pos"])
+            rows.append(dict(name=c.name, kind="patch", shape=shape, blocks=blocks, waves=blocks / 256.0,
+                             note="LDS patch, makespan %.2f tiles, CU fill %.0f %%" % (pp["makespan"], 100 * pp["fill"]),
+                             gflop=c.flops / 1e9, mb=c.bytes / 1e6))
+            continue
+        if c.offset is not None:
+            wp = H.deform_conv_window_plan(c.desc)
+            if wp is not None:                            # deform_patch.hip
+                rows.append(dict(name=c.name, kind="window", shape="256x(%dx%d)" % wp["tile"], blocks=wp["blocks"],
+                                 waves=wp["blocks"] / 256.0, note="LDS window %d px / deformable group" % wp["window_pixels"],
+                                 gflop=c.flops / 1e9, mb=c.bytes / 1e6))
+                continue
         p = H.conv_plan(c.desc, deformable=c.offset is not None, with_gn_stats=c.gn_stats is not None)
+        if p.get("split_k", 1) > 1 and getattr(c, "ws", None) is None:
+            # the engine gave this conv no split-K workspace (sub-plan chains, lanes): the launcher then plans without the split
+            import copy
+            d2 = copy.copy(c.desc)
+            d2.flags |= 0x00010000                       # SM_CONV_DBG_NO_SPLITK
+            p = H.conv_plan(d2, deformable=c.offset is not None, with_gn_stats=c.gn_stats is not None)
         per_cu = 1 if p["threads"] == 512 else (4 if p["k_step"] == 32 else 2)
         slots = 256 * per_cu
-        rounds = -(-p["blocks"] // slots)
-        # fill = how full the rounds of resident blocks are; with several blocks per CU the leftover blocks of a
-        # barely started round run alone and faster, so a low fill costs less than its face value (waves = blocks/slots)
-        rows.append(dict(name=c.name, plan=p, gflop=c.flops / 1e9, mb=c.bytes / 1e6, fill=p["blocks"] / (rounds * slots),
-                         waves=p["blocks"] / slots))
+        # waves = blocks / resident slots: with several blocks per CU the leftover blocks of a barely started round run
+        # alone and faster, so a low fill costs less than its face value
+        loop = {0: "legacy", 1: "flat", 3: "pipelined"}[p["k_loop"]] if p["lds_dma"] else "reg-stage"
+        rows.append(dict(name=c.name, kind="igemm", shape="%dx%d" % (p["tile_cout"], p["tile_pos"]), blocks=p["blocks"],
+                         waves=p["blocks"] / slots, note="K%d %s%s" % (p["k_step"], loop, "" if p.get("split_k", 1) <= 1
+                                                                      else " split-K %d" % p["split_k"]),
+                         gflop=c.flops / 1e9, mb=c.bytes / 1e6))
+    for t in eng.fused:                                   # bottleneck.hip: conv2 + conv3 (+ next conv1) per launch
+        rows.append(dict(name=t.name, kind="fused", shape="tail", blocks=0, waves=0.0,
+                         note="conv2+conv3%s in one launch" % ("+next conv1" if t.w1n is not None else ""),
+                         gflop=t.flops / 1e9, mb=t.bytes / 1e6))
     return rows
 
 
@@ -70,21 +102,21 @@ def main():
     ap.add_argument("--hw", type=int, nargs=2, default=(800, 1344))
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--variant", default="r50", choices=["r50", "ssd", "vis", "benchmark", "dcn"])
+    ap.add_argument("--sub-plan", action="store_true")
     args = ap.parse_args()
-    eng = build_on_cpu(args.variant, args.batch, args.hw, args.depth)
+    eng = build_on_cpu(args.variant, args.batch, args.hw, args.depth, args.sub_plan)
     rows = {r["name"]: r for r in conv_rows(eng)}
-    print("# %s, batch %d, %dx%d: %d steps, %d conv launches, %.1f conv GFLOP per step" % (
-        args.variant, args.batch, args.hw[0], args.hw[1], len(eng.steps), len(eng.convs), sum(r["gflop"] for r in rows.values())))
-    print("# lane | step | tile (cout x pos) | K step | loop | blocks | blocks / resident slots (256 CUs x 1, 2 or 4) | GFLOP | algorithmic MB")
+    print("# %s, batch %d%s, %dx%d: %d steps, %d conv launches (+ %d fused bottleneck tails), %.1f conv GFLOP per step" % (
+        args.variant, args.batch, " (one chain of a SubBatchPlan)" if args.sub_plan else "", args.hw[0], args.hw[1],
+        len(eng.steps), len(eng.convs), len(eng.fused), sum(r["gflop"] for r in rows.values())))
+    print("# lane | step | kernel | tile (cout x pos) | blocks | blocks / resident slots (256 CUs x 1, 2 or 4) | GFLOP | "
+          "algorithmic MB | notes")
     for (label, _), lane in zip(eng.steps, eng.lanes):
         ln = "join " + ",".join(str(x) for x in lane[1:]) if isinstance(lane, tuple) else str(lane)
-        if label.startswith("conv:"):
+        if label.startswith("conv:") and label[5:] in rows:
             r = rows[label[5:]]
-            p = r["plan"]
-            print("%-8s %-34s %3dx%-3d K%-2d %-9s %6d  %5.2f  %8.2f %8.1f" % (
-                ln, label, p["tile_cout"], p["tile_pos"], p["k_step"],
-                {0: "legacy", 1: "flat", 3: "pipelined"}[p["k_loop"]] if p["lds_dma"] else "reg-stage", p["blocks"],
-                r["waves"], r["gflop"], r["mb"]))
+            print("%-8s %-36s %-6s %-12s %6d  %5.2f  %8.2f %8.1f  %s" % (
+                ln, label, r["kind"], r["shape"], r["blocks"], r["waves"], r["gflop"], r["mb"], r["note"]))
         elif label != "join":
             print("%-8s %s" % (ln, label))
         else:
