@@ -227,7 +227,9 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     avail = torch.cuda.is_available
     eng = pd.build_on_cpu(variant, batch=2, hw=(256, 320))
     assert torch.cuda.is_available is avail                       # the patch is undone
-    rows = {r["name"]: r for r in pd.conv_rows(eng)}
+    allrows = pd.conv_rows(eng)
+    rows = {r["name"]: r for r in allrows if r["kind"] != "fused"}          # one row per conv launch ...
+    assert sum(1 for r in allrows if r["kind"] == "fused") == len(eng.fused)   # ... and one per fused bottleneck tail
     # the cls and reg tower convs of one depth run as ONE grouped launch (default; SIPMASK_GROUPED_TOWERS=0 = A/B):
     # every "head.towerN" launch stands for two of the nconv convolutions
     ngrouped = sum(1 for n in rows if n.startswith("head.tower"))
@@ -238,7 +240,7 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     if variant in ("r50", "vis", "benchmark", "ssd") and os.environ.get("SIPMASK_FUSE_BOTTLENECK", "1") == "1":
         assert len(eng.fused) == 7 and nfused == 7 * 2
     assert len(rows) == len(eng.convs) and len(rows) == nconv - ngrouped - nfused
-    assert all(r["plan"]["blocks"] > 0 and 0 < r["fill"] <= 1 for r in rows.values())
+    assert all(r["blocks"] > 0 and r["waves"] > 0 and r["kind"] in ("igemm", "patch", "window") for r in rows.values())
     assert len(eng.steps) == len(eng.lanes)
     joined = set()
     for lane in eng.lanes:                                           # every side lane that is used gets joined
@@ -268,12 +270,14 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
             assert c.offset.numel() >= rows_out * d.deform_groups * d.kh * d.kw * 2, c.name
         if c.bias is not None:
             assert c.bias.numel() >= d.cout, c.name
-    fa = rows["head.feat_align"]["plan"]
-    assert fa["lds_dma"] == 0 and fa["k_step"] == 64                # deformable gather: register-staged loader
+    # FeatureAlign (3x3, 4 deformable groups of 64 channels): the LDS-window kernel, 8 x 32-position tiles per image and level
+    fa = rows["head.feat_align"]
+    assert fa["kind"] == "window" and fa["shape"] == "256x(8x32)"
+    assert fa["blocks"] == 2 * sum(-(-h // 8) * -(-w // 32) for h, w in eng.lv.sizes)
     # P7 = conv(relu(P6)) (fpn.py:166-170): the plan feeds it a ReLU'd copy so it keeps the LDS-DMA path
     assert rows["fpn.p7"]["plan"]["lds_dma"] == 1 and any(lbl == "relu:p6" for lbl, _ in eng.steps)
-    tower = rows["head.tower0" if grouped and "head.tower0" in rows else "head.reg_convs.0"]["plan"]
-    assert (tower["k_step"], tower["k_loop"]) == (64, 3)
+    tower = rows["head.tower0" if grouped and "head.tower0" in rows else "head.reg_convs.0"]
+    assert tower["kind"] == "patch" or (tower["plan"]["k_step"], tower["plan"]["k_loop"]) == (64, 3)
     if variant == "dcn":
         assert sum(1 for n in rows if n.endswith("conv2.conv_offset")) == 5
         assert all(rows[n[:-len(".conv_offset")]]["plan"]["lds_dma"] == 0 for n in rows if n.endswith("conv2.conv_offset"))

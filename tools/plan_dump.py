@@ -85,7 +85,7 @@ def conv_rows(eng):
         # waves = blocks / resident slots: with several blocks per CU the leftover blocks of a barely started round run
         # alone and faster, so a low fill costs less than its face value
         loop = {0: "legacy", 1: "flat", 3: "pipelined"}[p["k_loop"]] if p["lds_dma"] else "reg-stage"
-        rows.append(dict(name=c.name, kind="igemm", shape="%dx%d" % (p["tile_cout"], p["tile_pos"]), blocks=p["blocks"],
+        rows.append(dict(name=c.name, kind="igemm", plan=p, shape="%dx%d" % (p["tile_cout"], p["tile_pos"]), blocks=p["blocks"],
                          waves=p["blocks"] / slots, note="K%d %s%s" % (p["k_step"], loop, "" if p.get("split_k", 1) <= 1
                                                                       else " split-K %d" % p["split_k"]),
                          gflop=c.flops / 1e9, mb=c.bytes / 1e6))
