@@ -182,7 +182,7 @@ int sm_conv3x3_patch_supported(const sm_conv_desc* d);
 int64_t sm_conv3x3_patch_tiles(const sm_conv_desc* d);
 int sm_conv3x3_patch_plan(const sm_conv_desc* d, int64_t* out4);
 int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void* w_patch, const float* bias, void* y,
-                     float* gn_stats, sm_stream_t stream);
+                     int64_t* gn_stats, sm_stream_t stream);
 
 /* Deformable conv v1 forward, bilinear gather fused into the GEMM operand load
  * (never materialises the column buffer).  Replaces deform_conv_forward_cuda,
@@ -268,7 +268,7 @@ int sm_wgrad_finish(const float* grad_w_t, const float* scale, int cout, int cin
                     sm_stream_t stream);
 int sm_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t n, sm_stream_t stream);
 int sm_bias_grad_rows(const void* g, int64_t rows, int cstride, int channels, float* out, sm_stream_t stream);
-int sm_gn_bwd_rows(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats, int batch,
+int sm_gn_bwd_rows(const void* x, const void* dy, const float* gamma, const float* beta, const int64_t* stats, int batch,
                    int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups, float eps, int relu,
                    void* dx, float* dgamma, float* dbeta, float* bins, sm_stream_t stream);
 int sm_upsample_bilinear_bwd_rows(const void* gout, int out_cstride, int out_coff, int batch, int h, int w, int c,
@@ -279,10 +279,14 @@ int sm_scatter_stride_rows(const void* in, int batch, int h, int w, int out_h, i
                            sm_stream_t stream);
 
 /* sm_conv2d / sm_deform_conv2d (offset != NULL) with the GroupNorm statistics of the output fused in the
- * epilogue: gn_stats f32 [batch][nlev][cout/8][2] = (sum, sum of squares) per (image, level, group of 8
- * channels), zeroed by the call.  Feed it to sm_groupnorm_apply.  Needs cout % 8 == 0, bf16 output. */
+ * epilogue: gn_stats int64 [batch][nlev][cout/8][2] = (sum, sum of squares) per (image, level, group of 8
+ * channels), zeroed by the call.  Feed it to sm_groupnorm_apply.  Needs cout % 8 == 0.
+ * GroupNorm statistics format (every gn_stats / stats argument of the bf16 row kernels): 64-bit FIXED POINT in units
+ * of 2^-24.  Tiles contribute partial sums in arrival order; integer addition is associative, so the statistics -- and
+ * every result downstream of them, NMS keep indices included -- are bit-reproducible from run to run, as the
+ * reference's ATen GroupNorm is (M/mmdet/ops/norm.py:12-55).  Range: |sum| < 5.5e11 per (image, level, group). */
 int sm_conv2d_gn_stats(const sm_conv_desc* d, const void* x, const float* offset, const void* w,
-                       const float* bias, const void* residual, void* y, float* gn_stats,
+                       const float* bias, const void* residual, void* y, int64_t* gn_stats,
                        sm_stream_t stream);
 
 /* offset = W_off (72x4) . (level_scale * reg[row][0:4]) -- FeatureAlign.conv_offset (level_scale
@@ -299,13 +303,13 @@ int sm_relu_bf16(const void* x, void* y, int64_t n, sm_stream_t stream);
 
 /* GroupNorm(groups) + optional ReLU over each (image, level), in place allowed.
  * nn.GroupNorm in M/mmdet/ops/conv_module.py:116-120 / sipmask_head.py:42,52.
- * stats: f32 workspace [batch*nlev*groups*2], zeroed by the call. */
-int sm_groupnorm(const void* x, void* y, const float* gamma, const float* beta, float* stats,
+ * stats: int64 fixed-point workspace [batch*nlev*groups*2] (see sm_conv2d_gn_stats), zeroed by the call. */
+int sm_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int64_t* stats,
                  int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels,
                  int groups, float eps, int relu, sm_stream_t stream);
 
 /* the normalisation half of sm_groupnorm, given precomputed statistics (same stats layout) */
-int sm_groupnorm_apply(const void* x, void* y, const float* gamma, const float* beta, const float* stats,
+int sm_groupnorm_apply(const void* x, void* y, const float* gamma, const float* beta, const int64_t* stats,
                        int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels,
                        int groups, float eps, int relu, sm_stream_t stream);
 
@@ -454,7 +458,12 @@ int sm_mask_assemble(const float* basis, int basis_hwc, const float* cofs, const
  * order up to f32 rounding), and only the 128x8-pixel tiles of each detection's box rectangle are written, plus zeros
  * over the tiles the same slot covered in the previous call.  `state` int32 [batch*max_num][4] carries those tile
  * ranges between calls: zero it together with `masks` when the buffer is created, never touch either in between.
- * After the call `masks` holds exactly what sm_mask_assemble would have written (zeros outside the rectangles). */
+ * After the call `masks` holds exactly what sm_mask_assemble would have written (zeros outside the rectangles).
+ * The kernel's LDS tiles are sized by up_scale (dynamic shared memory); sm_mask_assemble_lo_supported (host logic) tells
+ * whether a geometry fits: 2 * batch * max_num <= 4096 work-list entries and up_scale above ~0.45 (scale_factor <= ~4.4
+ * in get_bboxes' 2 / scale_factor).  Unsupported geometries return SM_ERR_UNSUPPORTED: assemble from the upsampled
+ * basis (sm_mask_assemble) instead, as sipmask_amd/engine.py does at plan-build time. */
+int sm_mask_assemble_lo_supported(int batch, int max_num, int factor, double up_scale_h, double up_scale_w);
 int64_t sm_mask_assemble_lo_workspace(int batch, int max_num);
 int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, int factor, const float* cofs, const int64_t* keep,
                         const float* det, const int32_t* ndet, int batch, int kmax, int max_num, int ho, int wo,

@@ -139,6 +139,7 @@ PROTOTYPES = {
     "sm_nms": (_I, [_P, _I, _F, _P, _P, _P, _P]),
     "sm_mask_assemble": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, C.c_double, C.c_double, _F,
                               _P, _P, _P]),
+    "sm_mask_assemble_lo_supported": (_I, [_I, _I, _I, C.c_double, C.c_double]),
     "sm_mask_assemble_lo_workspace": (C.c_int64, [_I, _I]),
     "sm_mask_assemble_lo": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, C.c_double, C.c_double,
                                  _F, _P, _P, _P, _P]),

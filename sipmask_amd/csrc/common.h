@@ -90,5 +90,28 @@ __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + e
 // (oracle/ops.py: sigmoid_ref) and this kernel produce the same f32 bits and the comparisons downstream are exact.
 __device__ __forceinline__ float sigmoid_rank(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
 
+// GroupNorm statistics that several blocks contribute to (the conv epilogues, gn_stats_kernel) are accumulated as
+// 64-bit FIXED POINT in units of 2^-SM_GN_FIX_SHIFT: integer addition is associative, so the sums -- and everything
+// normalised with them, down to the NMS keep indices -- do not depend on the order in which tiles / waves arrive
+// (the reference's GroupNorm is deterministic: M/mmdet/ops/norm.py:12-55 -> ATen).  A contribution is a partial sum
+// that was itself formed in a fixed order (one lane's 8 couts, a fixed shuffle tree) and is rounded ONCE to the grid:
+// 6e-8 absolute per partial of >= 256 elements, i.e. below 1e-9 of a sum of squares of O(1) activations; the range is
+// |sum| < 2^39 = 5.5e11 (rms of a group below ~2000 at 134 400 elements per (image, level, group)).
+#define SM_GN_FIX_SHIFT 24
+__device__ __forceinline__ unsigned long long gn_fix(float v) {
+  // clamp far inside the int64 range so a stray inf/NaN cannot hit the undefined float->int conversion
+  const float s = fminf(fmaxf(v * 16777216.f, -4.0e18f), 4.0e18f);
+  return (unsigned long long)(long long)rintf(s == s ? s : 0.f);
+}
+__device__ __forceinline__ double gn_unfix(unsigned long long q) { return (double)(long long)q * (1.0 / 16777216.0); }
+// mean / reciprocal standard deviation of one group from its fixed-point (sum, sum of squares); double arithmetic (a
+// handful of operations per thread) so that E[x^2] - E[x]^2 does not cancel in f32
+__device__ __forceinline__ void gn_mean_rstd(const unsigned long long* st, double cnt, float eps, float* mean, float* rstd) {
+  const double m = gn_unfix(st[0]) / cnt;
+  const double var = fmax(gn_unfix(st[1]) / cnt - m * m, 0.0);
+  *mean = (float)m;
+  *rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 static inline hipStream_t sm_hip_stream(sm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int sm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

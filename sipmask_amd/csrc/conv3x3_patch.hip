@@ -29,7 +29,7 @@ struct PatchArgs {
   const uint16_t* w;
   const float* bias;
   void* y;
-  float* gn_stats;
+  unsigned long long* gn_stats;   // fixed point (common.h: gn_fix)
   int nlev, batch;
   int h[SM_MAX_LEVELS], w_[SM_MAX_LEVELS];
   long long in_row0[SM_MAX_LEVELS], out_row0[SM_MAX_LEVELS];
@@ -398,13 +398,13 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   // ---- epilogue (register epilogue of conv_igemm.hip): lanes i / i+32 swap 4-cout groups -> 8 consecutive couts
   const float lscale = a.level_scale[lev];
   const float* const biasp = a.bias != nullptr ? a.bias + grp * a.b_gstride : nullptr;
-  float* const gnp = a.gn_stats != nullptr ? a.gn_stats + grp * a.gn_gstride : nullptr;
+  unsigned long long* const gnp = a.gn_stats != nullptr ? a.gn_stats + grp * a.gn_gstride : nullptr;
   const bool out_f32 = a.flags & SM_CONV_OUT_F32;
   const long long out_img_row0 = a.out_row0[lev] + grp * a.y_grows + (long long)n * H * W;
-  float* gn_bins = reinterpret_cast<float*>(smem);                  // [256/8][2]; the K loop's last barrier freed the LDS
+  unsigned long long* gn_bins = reinterpret_cast<unsigned long long*>(smem);                  // [256/8][2]; the K loop's last barrier freed the LDS
   const bool gn = gnp != nullptr;
   if (gn) {
-    if (tid < 64) gn_bins[tid] = 0.f;
+    if (tid < 64) gn_bins[tid] = 0ull;
     __syncthreads();
   }
 #pragma unroll
@@ -458,8 +458,8 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
             gss += __shfl_xor(gss, d, 64);
           }
           if (l31 == 0 && c0 < a.cout) {
-            atomicAdd(&gn_bins[(cl >> 3) * 2 + 0], gs);
-            atomicAdd(&gn_bins[(cl >> 3) * 2 + 1], gss);
+            atomicAdd(&gn_bins[(cl >> 3) * 2 + 0], gn_fix(gs));
+            atomicAdd(&gn_bins[(cl >> 3) * 2 + 1], gn_fix(gss));
           }
         }
         if (!live) continue;
@@ -485,9 +485,9 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   if (gn) {                                          // the whole tile lies in image n of level lev
     __syncthreads();
     if (tid < 64) {
-      const float v = gn_bins[tid];
+      const unsigned long long v = gn_bins[tid];
       const int g = (nt * PT_BCO >> 3) + (tid >> 1);
-      if (v != 0.f && g < (a.cout >> 3))
+      if (v != 0ull && g < (a.cout >> 3))
         atomicAdd(gnp + (((long long)n * a.nlev + lev) * (a.cout >> 3) + g) * 2 + (tid & 1), v);
     }
   }
@@ -641,8 +641,9 @@ extern "C" int sm_conv3x3_patch_plan(const sm_conv_desc* d, int64_t* out) {
 }
 
 extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void* w_patch, const float* bias, void* y,
-                                float* gn_stats, sm_stream_t stream) {
+                                int64_t* gn_stats_fix, sm_stream_t stream) {
   if (!x || !w_patch || !y) return SM_ERR_BAD_ARG;
+  unsigned long long* gn_stats = reinterpret_cast<unsigned long long*>(gn_stats_fix);
   const int rc = patch_check(d);
   if (rc != SM_OK) return rc;
   if (gn_stats != nullptr && (d->flags & SM_CONV_OUT_F32)) return SM_ERR_UNSUPPORTED;
@@ -708,7 +709,7 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   a.nblk[1] = (int)nb1;
   hipStream_t s = sm_hip_stream(stream);
   if (gn_stats != nullptr) {
-    if (hipMemsetAsync(gn_stats, 0, sizeof(float) * 2 * a.ngroups * d->batch * d->nlev * (d->cout / 8), s) != hipSuccess)
+    if (hipMemsetAsync(gn_stats, 0, sizeof(unsigned long long) * 2 * a.ngroups * d->batch * d->nlev * (d->cout / 8), s) != hipSuccess)
       return SM_ERR_LAUNCH;
   }
   const size_t lds = 2 * (size_t)PT_WSTAGE + 2 * (size_t)a.prow_cap * 64;

@@ -20,7 +20,7 @@
 // deform_patch.hip
 bool sm_deform_patch_supported(const sm_conv_desc* d);
 int sm_deform_patch_launch(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,
-                           void* y, hipStream_t stream, float* gn_stats, long long k_padded);
+                           void* y, hipStream_t stream, unsigned long long* gn_stats, long long k_padded);
 
 namespace {
 
@@ -43,7 +43,7 @@ struct ConvKArgs {
   int scale_nch;
   float level_scale[SM_MAX_LEVELS];
   int dg, cpg8;  // deform groups, chunks (of 8 ch) per deform group
-  float* gn_stats;  // optional fused GroupNorm statistics [batch][nlev][cout/8][2] (sum, sum of squares)
+  unsigned long long* gn_stats;  // optional fused GroupNorm statistics [batch][nlev][cout/8][2] (sum, sum of squares), fixed point (common.h: gn_fix)
   long long w_bstride;  // elements between the weight matrices of consecutive images (0 = shared): batched / split-K GEMMs
   // group dimension (64-wide-K LDS-DMA kernel only): ngroups problems of identical shape in one launch, e.g. the cls
   // and reg tower convs of one depth.  Tiles [g*tpg, (g+1)*tpg) belong to group g; its operands sit at fixed offsets.
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   constexpr int EPI_LD = BCO + 4;                  // padded f32 row of the epilogue staging tile
   constexpr int EPI_BYTES = BPOS * EPI_LD * 4;
   constexpr int GN_SEG = 4;                        // images a tile may span before falling back to global atomics
-  constexpr int GN_BYTES = GN_SEG * (BCO / 8) * 2 * 4;
+  constexpr int GN_BYTES = GN_SEG * (BCO / 8) * 2 * 8;   // 64-bit fixed-point bins
   // tiles above 128x128 exist with the register epilogue only (the launcher checks its alignment conditions): their
   // f32 staging tile would not fit beside nothing, and they are picked for the reuse, not for odd shapes
   constexpr bool REG_ONLY = BCO * BPOS > 128 * 128;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   const int nt = tl_g % a.ntn;
   const int mt = tl_g / a.ntn;
   const float* const biasp = a.bias != nullptr ? a.bias + grp * a.b_gstride : nullptr;
-  float* const gnp = a.gn_stats != nullptr ? a.gn_stats + grp * a.gn_gstride : nullptr;
+  unsigned long long* const gnp = a.gn_stats != nullptr ? a.gn_stats + grp * a.gn_gstride : nullptr;
   int lev = 0;
 #pragma unroll
   for (int l = 1; l < SM_MAX_LEVELS; ++l)
@@ -761,8 +761,8 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   const long long out_row0 = a.out_row0[lev] + grp * a.y_grows;
   const bool out_f32 = a.flags & SM_CONV_OUT_F32;
   float* E = reinterpret_cast<float*>(smem);
-  float* gn_bins = reinterpret_cast<float*>(smem + SMEM_MAIN);   // [GN_SEG][BCO/8][2]
-  if (gnp != nullptr && gtid < GN_SEG * (BCO / 8) * 2) gn_bins[gtid] = 0.f;
+  unsigned long long* gn_bins = reinterpret_cast<unsigned long long*>(smem + SMEM_MAIN);   // [GN_SEG][BCO/8][2]
+  if (gnp != nullptr && gtid < GN_SEG * (BCO / 8) * 2) gn_bins[gtid] = 0ull;
   // ---- register epilogue (same scheme as conv_dma32_kernel: v_permlane32_swap -> 8 consecutive couts per lane ->
   // 16-byte loads/stores, no LDS round trip).  GroupNorm statistics: after the swap a lane's 8 couts are exactly
   // one 8-channel group, so (sum, sum of squares) reduce over the 32 positions of the half-wave with shuffles and
@@ -873,31 +873,35 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
               }
             }
             if (uniform_img) {
+              // one POSITION's 8 couts (summed in a fixed order) is the unit that is rounded to the fixed-point grid:
+              // it does not depend on where tiles start, so plans that cut the same tensor differently (a B=4 plan
+              // and two B=2 sub-plans) accumulate identical integers.  Everything after this line is integer addition.
+              unsigned long long qs = gn_fix(gs), qss = gn_fix(gss);
 #pragma unroll
               for (int d = 16; d > 0; d >>= 1) {   // within the half-wave: xor < 32 never crosses halves
-                gs += __shfl_xor(gs, d, 64);
-                gss += __shfl_xor(gss, d, 64);
+                qs += __shfl_xor(qs, d, 64);
+                qss += __shfl_xor(qss, d, 64);
               }
               if (l31 == 0 && c0 < a.cout) {
                 const int seg = n_first - gn_n0;
                 if (seg < GN_SEG) {
-                  atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 0], gs);
-                  atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 1], gss);
+                  atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 0], qs);
+                  atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 1], qss);
                 } else {
-                  float* st = gnp + (((long long)n_first * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
-                  atomicAdd(st, gs);
-                  atomicAdd(st + 1, gss);
+                  unsigned long long* st = gnp + (((long long)n_first * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
+                  atomicAdd(st, qs);
+                  atomicAdd(st + 1, qss);
                 }
               }
             } else if (live) {
               const int seg = n_img - gn_n0;
               if (seg < GN_SEG) {
-                atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 0], gs);
-                atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 1], gss);
+                atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 0], gn_fix(gs));
+                atomicAdd(&gn_bins[(seg * (BCO / 8) + (cl >> 3)) * 2 + 1], gn_fix(gss));
               } else {
-                float* st = gnp + (((long long)n_img * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
-                atomicAdd(st, gs);
-                atomicAdd(st + 1, gss);
+                unsigned long long* st = gnp + (((long long)n_img * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
+                atomicAdd(st, gn_fix(gs));
+                atomicAdd(st + 1, gn_fix(gss));
               }
             }
           }
@@ -924,10 +928,10 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
     if (gn) {                                       // flush the bins (same as the LDS-staged path)
       __syncthreads();
       if (gtid < GN_SEG * (BCO / 8) * 2) {
-        const float v = gn_bins[gtid];
+        const unsigned long long v = gn_bins[gtid];
         const int seg = gtid / ((BCO / 8) * 2), rem = gtid - seg * ((BCO / 8) * 2);
         const int g = (nt * BCO >> 3) + (rem >> 1);
-        if (v != 0.f && g < gn_groups && gn_n0 + seg < a.batch)
+        if (v != 0ull && g < gn_groups && gn_n0 + seg < a.batch)
           atomicAdd(gnp + (((long long)(gn_n0 + seg) * a.nlev + lev) * gn_groups + g) * 2 + (rem & 1), v);
       }
     }
@@ -975,21 +979,21 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   const int gn_groups = a.cout >> 3;
   const int gn_n0 = m0 / HoWo;               // first image touched by this tile
   int gn_n = gn_n0, gn_bound = (gn_n0 + 1) * HoWo;
-  float gn_s = 0.f, gn_ss = 0.f;
+  unsigned long long gn_s = 0ull, gn_ss = 0ull;    // fixed point; one position's 8 couts per rounding (tiling independent)
   auto gn_flush = [&]() {
-    if (gn_s != 0.f || gn_ss != 0.f) {
+    if (gn_s != 0ull || gn_ss != 0ull) {
       const int seg = gn_n - gn_n0;
       if (seg < GN_SEG) {
         atomicAdd(&gn_bins[(seg * (BCO / 8) + ec) * 2 + 0], gn_s);
         atomicAdd(&gn_bins[(seg * (BCO / 8) + ec) * 2 + 1], gn_ss);
       } else {
-        float* st = gnp + (((long long)gn_n * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
+        unsigned long long* st = gnp + (((long long)gn_n * a.nlev + lev) * gn_groups + (c0 >> 3)) * 2;
         atomicAdd(st, gn_s);
         atomicAdd(st + 1, gn_ss);
       }
     }
-    gn_s = 0.f;
-    gn_ss = 0.f;
+    gn_s = 0ull;
+    gn_ss = 0ull;
   };
   if (c0 < a.cout) {
 #pragma unroll 2
@@ -1031,11 +1035,14 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
           ++gn_n;
           gn_bound += HoWo;
         }
+        float ps = 0.f, pss = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          gn_s += v[e];
-          gn_ss += v[e] * v[e];
+          ps += v[e];
+          pss += v[e] * v[e];
         }
+        gn_s += gn_fix(ps);
+        gn_ss += gn_fix(pss);
       }
       if (a.flags & SM_CONV_RELU) {
 #pragma unroll
@@ -1072,10 +1079,10 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
     gn_flush();
     __syncthreads();
     if (gtid < GN_SEG * (BCO / 8) * 2) {
-      const float v = gn_bins[gtid];
+      const unsigned long long v = gn_bins[gtid];
       const int seg = gtid / ((BCO / 8) * 2), rem = gtid - seg * ((BCO / 8) * 2);
       const int g = (nt * BCO >> 3) + (rem >> 1);
-      if (v != 0.f && g < gn_groups && gn_n0 + seg < a.batch)
+      if (v != 0ull && g < gn_groups && gn_n0 + seg < a.batch)
         atomicAdd(gnp + (((long long)(gn_n0 + seg) * a.nlev + lev) * gn_groups + g) * 2 + (rem & 1), v);
     }
   }
@@ -1746,7 +1753,7 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p,
 
 template <bool DEFORM>
 int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,
-                const void* residual, void* y, hipStream_t stream, float* gn_stats = nullptr, void* workspace = nullptr,
+                const void* residual, void* y, hipStream_t stream, unsigned long long* gn_stats = nullptr, void* workspace = nullptr,
                 long long workspace_bytes = 0) {
   if (!d || !x || !w || !y) return SM_ERR_BAD_ARG;
   if (DEFORM && !offset) return SM_ERR_BAD_ARG;
@@ -1771,7 +1778,7 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   if (gn_stats != nullptr) {
     const int ng = d->ngroups > 1 ? d->ngroups : 1;
     if (ng > 1 && d->gn_group_stride != 2ll * d->batch * d->nlev * (d->cout / 8)) return SM_ERR_BAD_ARG;   // contiguous
-    if (hipMemsetAsync(gn_stats, 0, sizeof(float) * 2 * d->batch * d->nlev * (d->cout / 8) * ng, stream) != hipSuccess)
+    if (hipMemsetAsync(gn_stats, 0, sizeof(unsigned long long) * 2 * d->batch * d->nlev * (d->cout / 8) * ng, stream) != hipSuccess)
       return SM_ERR_LAUNCH;
   }
   if constexpr (DEFORM) {
@@ -1929,9 +1936,10 @@ extern "C" int sm_conv2d_ws(const sm_conv_desc* d, const void* x, const void* w,
 }
 
 extern "C" int sm_conv2d_gn_stats(const sm_conv_desc* d, const void* x, const float* offset, const void* w,
-                                  const float* bias, const void* residual, void* y, float* gn_stats,
+                                  const float* bias, const void* residual, void* y, int64_t* gn_stats_fix,
                                   sm_stream_t stream) {
-  if (!gn_stats) return SM_ERR_BAD_ARG;
+  if (!gn_stats_fix) return SM_ERR_BAD_ARG;
+  unsigned long long* gn_stats = reinterpret_cast<unsigned long long*>(gn_stats_fix);
   if (offset != nullptr)
     return launch_conv<true>(d, x, offset, w, bias, nullptr, y, sm_hip_stream(stream), gn_stats);
   return launch_conv<false>(d, x, nullptr, w, bias, residual, y, sm_hip_stream(stream), gn_stats);

@@ -43,7 +43,7 @@ struct DeformPatchArgs {
   const float* bias;
   const float* offset;
   void* y;
-  float* gn_stats;
+  unsigned long long* gn_stats;   // fixed point (common.h: gn_fix)
   int nlev, batch;
   int h[SM_MAX_LEVELS], w_[SM_MAX_LEVELS];
   long long in_row0[SM_MAX_LEVELS], out_row0[SM_MAX_LEVELS];
@@ -319,10 +319,10 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
   // ---- epilogue (the register epilogue of conv3x3_patch.hip): lanes i / i+32 swap 4-cout groups -> 8 consecutive couts
   const float lscale = a.level_scale[lev];
   const bool out_f32 = a.flags & SM_CONV_OUT_F32;
-  float* gn_bins = reinterpret_cast<float*>(smem);                  // [256/8][2]; the K loop's last barrier freed the LDS
+  unsigned long long* gn_bins = reinterpret_cast<unsigned long long*>(smem);                  // [256/8][2]; the K loop's last barrier freed the LDS
   const bool gn = a.gn_stats != nullptr;
   if (gn) {
-    if (tid < 64) gn_bins[tid] = 0.f;
+    if (tid < 64) gn_bins[tid] = 0ull;
     __syncthreads();
   }
 #pragma unroll
@@ -369,8 +369,8 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
           gss += __shfl_xor(gss, d, 64);
         }
         if (l31 == 0 && c0 < a.cout) {
-          atomicAdd(&gn_bins[(cl >> 3) * 2 + 0], gs);
-          atomicAdd(&gn_bins[(cl >> 3) * 2 + 1], gss);
+          atomicAdd(&gn_bins[(cl >> 3) * 2 + 0], gn_fix(gs));
+          atomicAdd(&gn_bins[(cl >> 3) * 2 + 1], gn_fix(gss));
         }
       }
       if (!live) continue;
@@ -395,9 +395,9 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
   if (gn) {                                          // the whole tile lies in image n of level lev
     __syncthreads();
     if (tid < 64) {
-      const float v = gn_bins[tid];
+      const unsigned long long v = gn_bins[tid];
       const int gi = (nt * DP_BCO >> 3) + (tid >> 1);
-      if (v != 0.f && gi < (a.cout >> 3))
+      if (v != 0ull && gi < (a.cout >> 3))
         atomicAdd(a.gn_stats + (((long long)n * a.nlev + lev) * (a.cout >> 3) + gi) * 2 + (tid & 1), v);
     }
   }
@@ -440,7 +440,7 @@ extern "C" int sm_deform_conv_window_plan(const sm_conv_desc* d, int64_t* out4) 
 // k_padded: row pitch (elements) of the [cout_pad][k_padded] weight operand (sm_conv_plan.k_padded); gn_stats is zeroed by
 // the caller (launch_conv)
 int sm_deform_patch_launch(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,
-                           void* y, hipStream_t stream, float* gn_stats, long long k_padded) {
+                           void* y, hipStream_t stream, unsigned long long* gn_stats, long long k_padded) {
   if (!sm_deform_patch_supported(d)) return SM_ERR_UNSUPPORTED;
   if (gn_stats != nullptr && (d->flags & SM_CONV_OUT_F32)) return SM_ERR_UNSUPPORTED;
   DeformPatchArgs a;

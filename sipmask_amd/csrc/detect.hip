@@ -377,7 +377,10 @@ __device__ __forceinline__ bool iou_plus1_gt(const float4 a, const float4 b, flo
   const float sb = __fmul_rn(__fadd_rn(__fsub_rn(b.z, b.x), 1.f), __fadd_rn(__fsub_rn(b.w, b.y), 1.f));
   const float uni = __fsub_rn(__fadd_rn(sa, sb), inter);
   const float t = fmaf(-thr, uni, inter);
-  if (fabsf(t) > 1e-5f * fabsf(uni) && fabsf(uni) < 3e38f) return t > 0.f;     // NaN / inf fall through
+  // the sign of t decides only for a POSITIVE union: a box with x2 < x1 - 1 (or y2 < y1 - 1; bbox_pred is not
+  // exp'd or ReLU'd, so negative distances are reachable) has a negative area, the union may be <= 0, the
+  // reference's quotient (nms_kernel.cu:17-22) is then negative / inf / NaN and compares as such
+  if (uni > 0.f && uni < 3e38f && fabsf(t) > 1e-5f * uni) return t > 0.f;      // NaN / inf / uni <= 0 fall through
   return __fdiv_rn(inter, uni) > thr;
 }
 

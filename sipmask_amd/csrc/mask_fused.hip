@@ -23,8 +23,10 @@ namespace {
 
 constexpr int MF_THREADS = 256;
 constexpr int MF_TW = 128, MF_TH = 8;    // output tile (pixels): stores cover whole 128-byte lines
-constexpr int MF_SRC_CAP = 640;          // mask-resolution source pixels per tile
-constexpr int MF_LO_CAP = 160;           // low-resolution pixels per tile
+// The LDS tiles of one output tile -- its mask-resolution source window and the conv-resolution window under that --
+// are DYNAMIC shared memory sized by the launch's up_scale (a keep_ratio COCO resize gives scale_factor 1.6-2.7, i.e.
+// up_scale = 2 / scale_factor down to 0.74: a 128x8 output tile then reads a 176x13 source window)
+constexpr int MF_DYN_LDS_MAX = 40 * 1024;   // bytes of dynamic LDS a launch may ask for (beside 17 KB static)
 constexpr int MF_MAX_ENTRIES = 4096;     // 2 * batch * max_num work-list entries (prefix copy lives in LDS)
 
 struct MaskFArgs {
@@ -39,6 +41,7 @@ struct MaskFArgs {
   int32_t* prefix;         // workspace [2*B*max_num + 1]
   int batch, kmax, max_num, lo_h, lo_w, factor, hm, wm, ho, wo, pitch;
   float box_mul_x, box_mul_y, box_div, up_x, up_y, inv_up_x, inv_up_y, inv_f, thr;
+  int src_cap, lo_cap;     // floats of the dynamic LDS tiles (mask_lo_caps)
 };
 
 // ---- plan: per slot the tile range of the new rectangle (mask_rects_kernel's conservative rule, rle.hip) and of the
@@ -118,8 +121,9 @@ struct FBox {
 __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs a) {
   __shared__ int s_prefix[MF_MAX_ENTRIES + 1];
   __shared__ __attribute__((aligned(16))) float s_cof[128];
-  __shared__ float s_lo[4][MF_LO_CAP];
-  __shared__ float s_prob[MF_SRC_CAP];
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float* const s_lo_base = s_dyn;                     // [4][lo_cap] quadrant logits at conv resolution
+  float* const s_prob = s_dyn + 4 * a.lo_cap;         // [src_cap] probabilities at mask resolution
   const int tid = threadIdx.x;
   const int n2 = 2 * a.batch * a.max_num;
   for (int i = tid; i <= n2; i += MF_THREADS) s_prefix[i] = a.prefix[i];
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
         acc = fmaf(v.z, cq[k + 2], acc);
         acc = fmaf(v.w, cq[k + 3], acc);
       }
-      s_lo[q][p] = acc;
+      s_lo_base[q * a.lo_cap + p] = acc;
     }
     __syncthreads();
     // (2) mask-resolution probabilities: quadrant select (CropSplit), bilinear xfactor of that quadrant's logits
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
       if (pw >= bx.x1 && ph >= bx.y1 && pw < bx.x2 && ph < bx.y2) {
         const int iw = (int)__fdiv_rn(__fsub_rn(pw, bx.x1), bx.rw);
         const int ih = (int)__fdiv_rn(__fsub_rn(ph, bx.y1), bx.rh);
-        const float* L = s_lo[(ih * 2 + iw) & 3];
+        const float* L = s_lo_base + ((ih * 2 + iw) & 3) * a.lo_cap;
         const float fy = lo_c(gy), fx = lo_c(gx);
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = min(y0 + 1, a.lo_h - 1), x1 = min(x0 + 1, a.lo_w - 1);
@@ -251,6 +255,24 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
 
 }  // namespace
 
+// LDS tile sizes of a launch (floats): upper bounds of the source windows of one MF_TW x MF_TH output tile; false when
+// the geometry does not fit (then the caller assembles from the upsampled basis: sm_mask_assemble)
+static bool mask_lo_caps(int batch, int max_num, int factor, double up_scale_h, double up_scale_w, int* src_cap, int* lo_cap) {
+  if (batch < 1 || max_num < 1 || factor < 1 || !(up_scale_h > 0) || !(up_scale_w > 0)) return false;
+  if (2 * (long long)batch * max_num > MF_MAX_ENTRIES) return false;
+  const double spw_d = (double)MF_TW / up_scale_w + 3.0, sph_d = (double)MF_TH / up_scale_h + 3.0;
+  if (spw_d * sph_d > 1.0e6) return false;
+  const int spw = (int)spw_d, sph = (int)sph_d;
+  *src_cap = spw * sph;
+  *lo_cap = ((spw / factor + 3) * (sph / factor + 3) + 3) & ~3;        // 16-byte aligned quadrant planes
+  return (size_t)(*src_cap + 4 * *lo_cap) * sizeof(float) <= (size_t)MF_DYN_LDS_MAX;
+}
+
+extern "C" int sm_mask_assemble_lo_supported(int batch, int max_num, int factor, double up_scale_h, double up_scale_w) {
+  int s, l;
+  return mask_lo_caps(batch, max_num, factor, up_scale_h, up_scale_w, &s, &l) ? 1 : 0;
+}
+
 extern "C" int64_t sm_mask_assemble_lo_workspace(int batch, int max_num) {
   if (batch < 1 || max_num < 1) return 0;
   const int64_t nslot = (int64_t)batch * max_num;
@@ -266,10 +288,8 @@ extern "C" int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, in
   if (batch < 1 || max_num < 1 || lo_h < 1 || lo_w < 1 || factor < 1 || ho < 1 || wo < 1 || mask_pitch % 4 != 0 ||
       mask_pitch < wo || !(up_scale_h > 0) || !(up_scale_w > 0) || !(box_div != 0.f))
     return SM_ERR_BAD_SHAPE;
-  if (2 * batch * max_num > MF_MAX_ENTRIES) return SM_ERR_UNSUPPORTED;
-  // the tile's source windows must fit the LDS tiles
-  const int spw = (int)((double)MF_TW / up_scale_w) + 3, sph = (int)((double)MF_TH / up_scale_h) + 3;
-  if (spw * sph > MF_SRC_CAP || (spw / factor + 3) * (sph / factor + 3) > MF_LO_CAP) return SM_ERR_UNSUPPORTED;
+  int src_cap, lo_cap;
+  if (!mask_lo_caps(batch, max_num, factor, up_scale_h, up_scale_w, &src_cap, &lo_cap)) return SM_ERR_UNSUPPORTED;
   MaskFArgs a;
   a.basis_lo = basis_lo;
   a.cofs = cofs;
@@ -300,9 +320,11 @@ extern "C" int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, in
   a.inv_up_y = (float)(1.0 / up_scale_h);
   a.inv_f = 1.f / (float)factor;
   a.thr = mask_thr;
+  a.src_cap = src_cap;
+  a.lo_cap = lo_cap;
   hipStream_t s = sm_hip_stream(stream);
   hipLaunchKernelGGL(mask_plan_kernel, dim3(1), dim3(1024), 0, s, a);
-  hipLaunchKernelGGL(mask_fused_kernel, dim3(2048), dim3(MF_THREADS), 0, s, a);
+  hipLaunchKernelGGL(mask_fused_kernel, dim3(2048), dim3(MF_THREADS), (size_t)(src_cap + 4 * lo_cap) * sizeof(float), s, a);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -71,7 +71,7 @@ constexpr int GN_ROWS_PER_BLOCK = 256;
 
 // Each block reduces GN_ROWS_PER_BLOCK rows of one (image, level); a thread owns one
 // 16-byte chunk column (8 channels, inside one group) and strides over rows.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ stats,
+__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ x, unsigned long long* __restrict__ stats,
                                                        const GnArgs a) {
   const int n = blockIdx.y;
   int lev = 0;
@@ -114,16 +114,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
         ts += sh[0][t];
         tss += sh[1][t];
       }
-    float* st = stats + (((long long)n * a.nlev + lev) * a.groups + g) * 2;
-    atomicAdd(st, ts);
-    atomicAdd(st + 1, tss);
+    // ts / tss were formed in a fixed order; the cross-block sum is fixed point (common.h: gn_fix) = order independent
+    unsigned long long* st = stats + (((long long)n * a.nlev + lev) * a.groups + g) * 2;
+    atomicAdd(st, gn_fix(ts));
+    atomicAdd(st + 1, gn_fix(tss));
   }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
-                                                       const float* __restrict__ stats, const GnArgs a) {
+                                                       const unsigned long long* __restrict__ stats, const GnArgs a) {
   const int n = blockIdx.y;
   int lev = 0;
 #pragma unroll
@@ -137,11 +138,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
   const int rr = threadIdx.x / c8;
   if (rr >= rows_per_iter) return;
   const int g = (cc * 8) / a.cpg;
-  const float* st = stats + (((long long)n * a.nlev + lev) * a.groups + g) * 2;
-  const float cnt = (float)HW * (float)a.cpg;
-  const float mean = st[0] / cnt;
-  const float var = fmaxf(st[1] / cnt - mean * mean, 0.f);
-  const float rstd = rsqrtf(var + a.eps);
+  float mean, rstd;
+  gn_mean_rstd(stats + (((long long)n * a.nlev + lev) * a.groups + g) * 2, (double)HW * (double)a.cpg, a.eps, &mean, &rstd);
   float sc[8], sf[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -457,16 +455,17 @@ static int gn_fill_args(GnArgs& a, int& t, int batch, int nlev, const int32_t* h
   return SM_OK;
 }
 
-extern "C" int sm_groupnorm(const void* x, void* y, const float* gamma, const float* beta, float* stats, int batch,
+extern "C" int sm_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int64_t* stats_fix, int batch,
                             int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups, float eps,
                             int relu, sm_stream_t stream) {
-  if (!x || !y || !gamma || !beta || !stats || !hw || !row0) return SM_ERR_BAD_ARG;
+  if (!x || !y || !gamma || !beta || !stats_fix || !hw || !row0) return SM_ERR_BAD_ARG;
+  unsigned long long* stats = reinterpret_cast<unsigned long long*>(stats_fix);
   GnArgs a;
   int t;
   const int st = gn_fill_args(a, t, batch, nlev, hw, row0, channels, groups, eps, relu);
   if (st != SM_OK) return st;
   hipStream_t s = sm_hip_stream(stream);
-  if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (hipMemsetAsync(stats, 0, sizeof(unsigned long long) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(t, batch), dim3(256), 0, s, (const uint16_t*)x, stats, a);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(t, batch), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)y, gamma, beta,
                      stats, a);
@@ -474,10 +473,11 @@ extern "C" int sm_groupnorm(const void* x, void* y, const float* gamma, const fl
   return SM_OK;
 }
 
-extern "C" int sm_groupnorm_apply(const void* x, void* y, const float* gamma, const float* beta, const float* stats,
+extern "C" int sm_groupnorm_apply(const void* x, void* y, const float* gamma, const float* beta, const int64_t* stats_fix,
                                   int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups,
                                   float eps, int relu, sm_stream_t stream) {
-  if (!x || !y || !gamma || !beta || !stats || !hw || !row0) return SM_ERR_BAD_ARG;
+  if (!x || !y || !gamma || !beta || !stats_fix || !hw || !row0) return SM_ERR_BAD_ARG;
+  const unsigned long long* stats = reinterpret_cast<const unsigned long long*>(stats_fix);
   GnArgs a;
   int t;
   const int st = gn_fill_args(a, t, batch, nlev, hw, row0, channels, groups, eps, relu, 8, true);

@@ -183,7 +183,7 @@ struct GnbArgs {
 // dbeta = sum dy (dy already gated by the ReLU).  Thread = one 8-channel chunk column of the block's rows.
 __global__ __launch_bounds__(256) void gn_bwd_rows_reduce_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 const float* __restrict__ stats, float* __restrict__ bins,
+                                                                 const unsigned long long* __restrict__ stats, float* __restrict__ bins,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                  const GnbArgs a) {
   const int n = blockIdx.y;
@@ -197,10 +197,8 @@ __global__ __launch_bounds__(256) void gn_bwd_rows_reduce_kernel(const uint16_t*
   const int lanes = 256 / c8;
   const int cc = threadIdx.x % c8, rr = threadIdx.x / c8;
   const int g = (cc * 8) / a.cpg;
-  const float* st = stats + (((long long)n * a.nlev + lev) * a.groups + g) * 2;
-  const float cnt = (float)HW * (float)a.cpg;
-  const float mean = st[0] / cnt;
-  const float rstd = rsqrtf(fmaxf(st[1] / cnt - mean * mean, 0.f) + a.eps);
+  float mean, rstd;      // the forward's fixed-point statistics (common.h: gn_fix), the forward's own arithmetic
+  gn_mean_rstd(stats + (((long long)n * a.nlev + lev) * a.groups + g) * 2, (double)HW * (double)a.cpg, a.eps, &mean, &rstd);
   float ga[8], be[8], sdy[8], sdyx[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -266,7 +264,7 @@ __global__ __launch_bounds__(256) void gn_bwd_rows_reduce_kernel(const uint16_t*
 // pass 2: dx = rstd * (dy*gamma - a1/N - xhat * a2/N)
 __global__ __launch_bounds__(256) void gn_bwd_rows_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                const float* __restrict__ stats, const float* __restrict__ bins,
+                                                                const unsigned long long* __restrict__ stats, const float* __restrict__ bins,
                                                                 uint16_t* __restrict__ dx, const GnbArgs a) {
   const int n = blockIdx.y;
   int lev = 0;
@@ -282,8 +280,8 @@ __global__ __launch_bounds__(256) void gn_bwd_rows_apply_kernel(const uint16_t* 
   const int g = (cc * 8) / a.cpg;
   const long long sidx = (((long long)n * a.nlev + lev) * a.groups + g) * 2;
   const float cnt = (float)HW * (float)a.cpg;
-  const float mean = stats[sidx] / cnt;
-  const float rstd = rsqrtf(fmaxf(stats[sidx + 1] / cnt - mean * mean, 0.f) + a.eps);
+  float mean, rstd;
+  gn_mean_rstd(stats + sidx, (double)HW * (double)a.cpg, a.eps, &mean, &rstd);
   const float m1 = bins[sidx] / cnt, m2 = bins[sidx + 1] / cnt;
   float ga[8], be[8];
 #pragma unroll
@@ -482,11 +480,12 @@ extern "C" int sm_bias_grad_rows(const void* g, int64_t rows, int cstride, int c
   return SM_OK;
 }
 
-extern "C" int sm_gn_bwd_rows(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats,
+extern "C" int sm_gn_bwd_rows(const void* x, const void* dy, const float* gamma, const float* beta, const int64_t* stats_fix,
                               int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups,
                               float eps, int relu, void* dx, float* dgamma, float* dbeta, float* bins,
                               sm_stream_t stream) {
-  if (!x || !dy || !gamma || !beta || !stats || !hw || !row0 || !dx || !dgamma || !dbeta || !bins) return SM_ERR_BAD_ARG;
+  if (!x || !dy || !gamma || !beta || !stats_fix || !hw || !row0 || !dx || !dgamma || !dbeta || !bins) return SM_ERR_BAD_ARG;
+  const unsigned long long* stats = reinterpret_cast<const unsigned long long*>(stats_fix);
   GnbArgs a;
   int t;
   const int st = gnb_fill(a, t, batch, nlev, hw, row0, channels, groups, eps, relu);

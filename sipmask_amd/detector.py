@@ -20,7 +20,7 @@ class SipMask(nn.Module):
         self.neck = build_neck(neck) if neck is not None else None
         self.bbox_head = build_head(bbox_head)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
-        self._engines = PlanCache()
+        self._engines = PlanCache().attach_invalidation(self)
         self.init_weights(pretrained=pretrained)
 
     @property
@@ -41,6 +41,14 @@ class SipMask(nn.Module):
             self.neck.init_weights()
         self.bbox_head.init_weights()
         self._engines.clear()
+
+    def invalidate_plans(self):
+        """Drop every cached launch plan.  Needed only after writing weights in a way the cache cannot see (through
+        `.data` or a raw-pointer kernel: plan_cache.py); load_state_dict, optimizer steps and in-place tensor ops are seen."""
+        self._engines.invalidate()
+        head = getattr(self.bbox_head, "_engines", None)
+        if head is not None:
+            head.invalidate()
 
     def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False, precision="bf16", lanes="auto"):
         """Build (or fetch) the static launch plan for this input geometry; weights are snapshotted,

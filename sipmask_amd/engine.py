@@ -558,7 +558,7 @@ class SipMaskEngine:
         B, lv, dev, h = self.batch, self.lv, self.device, prefix
         self._sd, self._sd_keys = sd, set(sd.keys())
         sizes, row0 = lv.sizes, lv.row0
-        self.gn_stats = torch.zeros(B * len(lv) * 32 * 2, dtype=torch.float32, device=dev)
+        self.gn_stats = H.gn_stats_alloc(B * len(lv) * 32, dev)
         self.gn_stats64 = torch.zeros(B * len(lv) * 32 * 2, dtype=torch.float64, device=dev)
         self._gn64 = {}
 
@@ -594,7 +594,7 @@ class SipMaskEngine:
             # rounds to 92 %), each followed by the two towers' GroupNorm passes on two lanes
             n_sh = min(depth("cls"), depth("reg"))
             S = self.gn_stats.numel()
-            stats2 = torch.zeros(2 * S, dtype=torch.float32, device=dev)
+            stats2 = H.gn_stats_alloc(S, dev)       # [2 towers][B][nlev][32][2]
             x, xg = self.pyr, 0
             for i in range(n_sh):
                 y = self._buf(2 * lv.rows, 256)
@@ -767,7 +767,10 @@ class SipMaskEngine:
             self.rescorer = MaskRescorer(self._sd, "bbox_head.", B, self.max_num, self.hm, self.wm, self.device)
         # the rescoring branch consumes the cropped probability maps at mask resolution (pos_masks), which only
         # sm_mask_assemble produces; every other plan assembles masks from the conv-resolution basis
-        self.fused_masks = self.rescorer is None and __import__("os").environ.get("SIPMASK_FUSED_MASKS", "1") != "0"
+        # ... as do geometries whose per-tile source window exceeds the fused kernel's LDS tiles (up_scale = 2 /
+        # scale_factor below ~0.45: sm_mask_assemble_lo_supported)
+        self.fused_masks = (self.rescorer is None and __import__("os").environ.get("SIPMASK_FUSED_MASKS", "1") != "0"
+                            and H.mask_assemble_lo_supported(B, self.max_num, 4, self.up))
         self._needs_basis = not self.fused_masks
         if self._needs_basis:
             self._basis = self._buf(B * self.hm * self.wm, 32, torch.float32)     # allocated at build (capture-safe)

@@ -65,8 +65,28 @@ def conv3x3_patch_plan(desc):
                 fill=work / (256.0 * max(milli, 1) / 1000.0))
 
 
+GN_FIX_SCALE = float(1 << 24)      # csrc/common.h: SM_GN_FIX_SHIFT
+
+
+def gn_stats_alloc(n, device):
+    """GroupNorm statistics workspace: n (sum, sum of squares) pairs as 64-bit fixed point (2^-24 units; integer
+    accumulation makes the statistics independent of the order in which tiles arrive -- include/sipmask_hip.h)."""
+    return torch.zeros(2 * n, dtype=torch.int64, device=device)
+
+
+def gn_stats_to_float(stats):
+    """fixed-point statistics -> float64 (tests, diagnostics)"""
+    return stats.double() / GN_FIX_SCALE
+
+
+def _check_gn_stats(stats):
+    if stats is not None and stats.dtype != torch.int64:
+        raise TypeError("GroupNorm statistics are int64 fixed point (hip_ops.gn_stats_alloc), got %s" % stats.dtype)
+
+
 def conv3x3_patch(desc, x, w_patch, bias, y, gn_stats=None):
     _lib.require_cuda(x, w_patch, y)
+    _check_gn_stats(gn_stats)
     lib = _lib.load()
     _lib.check(lib.sm_conv3x3_patch(C.byref(desc), _lib.ptr(x), _lib.ptr(w_patch), _lib.ptr(bias), _lib.ptr(y),
                                     _lib.ptr(gn_stats), _lib.stream_ptr()), "sm_conv3x3_patch")
@@ -167,6 +187,7 @@ def deform_conv2d(desc, x, offset, w, bias, y):
 
 def conv2d_gn_stats(desc, x, offset, w, bias, residual, y, stats):
     """conv (deformable when offset is given) with the output's GroupNorm statistics fused in the epilogue"""
+    _check_gn_stats(stats)
     lib = _lib.load()
     _lib.check(lib.sm_conv2d_gn_stats(C.byref(desc), _lib.ptr(x), _lib.ptr(offset), _lib.ptr(w), _lib.ptr(bias),
                                       _lib.ptr(residual), _lib.ptr(y), _lib.ptr(stats), _lib.stream_ptr()),
@@ -175,6 +196,7 @@ def conv2d_gn_stats(desc, x, offset, w, bias, residual, y, stats):
 
 
 def groupnorm_apply(x, y, gamma, beta, stats, lv, channels, groups=32, eps=1e-5, relu=True):
+    _check_gn_stats(stats)
     lib = _lib.load()
     nlev = len(lv)
     hw = (C.c_int32 * nlev)(*[h * w for h, w in lv.sizes])
@@ -244,6 +266,7 @@ def conv2d_bwd(desc, x, w_t, w_dgrad, gout, grad_x, grad_w_t, grad_bias):
 
 
 def groupnorm(x, y, gamma, beta, stats, lv, channels, groups=32, eps=1e-5, relu=True):
+    _check_gn_stats(stats)
     lib = _lib.load()
     nlev = len(lv)
     hw = (C.c_int32 * nlev)(*[h * w for h, w in lv.sizes])
@@ -485,6 +508,12 @@ def mask_assemble(basis, basis_hwc, cofs, keep, det, ndet, hm, wm, ho, wo, box_m
     return masks
 
 
+def mask_assemble_lo_supported(batch, max_num, factor, up_scale):
+    """does sm_mask_assemble_lo take this geometry (host logic; else the plan assembles from the upsampled basis)"""
+    uh, uw = _pair(up_scale)
+    return bool(_lib.load().sm_mask_assemble_lo_supported(int(batch), int(max_num), int(factor), float(uh), float(uw)))
+
+
 def mask_assemble_lo_alloc(batch, max_num, ho, wo, device):
     """buffers owned by the plan for sm_mask_assemble_lo: the u8 masks (zeroed once), the per-slot tile-range state
     (zeroed with them) and the work-list workspace"""
@@ -677,6 +706,9 @@ def sgd_step(param, grad, buf, lr, momentum, weight_decay, first_step):
     lib = _lib.load()
     _lib.check(lib.sm_sgd_step(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(buf), param.numel(), float(lr), float(momentum),
                                float(weight_decay), int(first_step), _lib.stream_ptr()), "sm_sgd_step")
+    # the kernel wrote through a raw pointer: tell autograd (and the launch-plan cache, which fingerprints
+    # (data_ptr, _version) of every weight -- plan_cache.py) that the tensor changed
+    torch.autograd.graph.increment_version(param)
 
 
 # ------------------------------------------------------------------------------- training graph on row tensors
@@ -793,9 +825,63 @@ def weight_prep(w, scale, mode, cin_pad=None):
     return WEIGHT_PREP_CACHE.get(w, scale, mode, cin_pad)
 
 
-def wgrad_finish(gw_t, scale, co, ci, kh, kw):
+class _GradSink:
+    """Where parameter gradients go when they live in all-reduce buckets (dist_train.GradBucketer): the kernels that
+    produce a parameter gradient (sm_wgrad_finish, sm_bias_grad_rows, sm_gn_bwd_rows) write it STRAIGHT into the
+    parameter's slice of the flat bucket instead of into a fresh tensor that autograd would then add or copy there --
+    what torch DDP's gradient_as_bucket_view buys MMDistributedDataParallel (M/mmdet/apis/train.py:135-139), minus
+    its copy-in.  Keys are the parameters' data_ptr()s (saved tensors come back as other Python objects).
+
+    Direct writes OVERWRITE, so they are only safe for a parameter that one backward op uses once per step.  The first
+    step after attach() is a census: every op reports its use and returns its gradient the ordinary way (autograd adds
+    it into the zeroed view); parameters counted once become direct from the second step on.  A second contribution in
+    a later step still goes through autograd's in-place add; the bucketer raises if its bucket was already launched."""
+
+    def __init__(self):
+        self.detach()
+
+    def detach(self):
+        self.views, self.uses, self.direct, self.written, self.on_write, self.census = {}, {}, set(), set(), None, True
+
+    def attach(self, views, on_write):
+        self.detach()
+        self.views, self.on_write = dict(views), on_write
+
+    def begin_step(self):
+        if self.census and self.uses:
+            self.direct = {k for k, c in self.uses.items() if c == 1}
+            self.census = False
+        self.written.clear()
+
+    def target(self, param):
+        """the view to write `param`'s gradient into, or None (= return the gradient to autograd)"""
+        if not self.views or param is None:
+            return None
+        k = param.data_ptr()
+        v = self.views.get(k)
+        if v is None:
+            return None
+        if self.census:
+            self.uses[k] = self.uses.get(k, 0) + 1
+            return None
+        if k in self.direct and k not in self.written:
+            return v
+        return None
+
+    def commit(self, param):
+        k = param.data_ptr()
+        self.written.add(k)
+        self.on_write(k)
+
+
+GRAD_SINK = _GradSink()
+
+
+def wgrad_finish(gw_t, scale, co, ci, kh, kw, out=None):
     lib = _lib.load()
-    out = torch.empty(co, ci, kh, kw, dtype=torch.float32, device=gw_t.device)
+    if out is None:
+        out = torch.empty(co, ci, kh, kw, dtype=torch.float32, device=gw_t.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == co * ci * kh * kw
     _lib.check(lib.sm_wgrad_finish(_lib.ptr(gw_t), _lib.ptr(scale), co, ci, kh, kw, _lib.ptr(out), _lib.stream_ptr()),
                "sm_wgrad_finish")
     return out
@@ -809,23 +895,26 @@ def relu_bwd_bf16(g, y):
     return out
 
 
-def bias_grad_rows(g, channels):
+def bias_grad_rows(g, channels, out=None):
     lib = _lib.load()
     assert g.dtype == BF16 and g.dim() == 2 and g.is_contiguous()
-    out = torch.empty(channels, dtype=torch.float32, device=g.device)
+    if out is None:
+        out = torch.empty(channels, dtype=torch.float32, device=g.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == channels
     _lib.check(lib.sm_bias_grad_rows(_lib.ptr(g), g.shape[0], g.shape[1], channels, _lib.ptr(out), _lib.stream_ptr()),
                "sm_bias_grad_rows")
     return out
 
 
-def gn_bwd_rows(x, dy, gamma, beta, stats, lv, channels, groups, eps, relu):
+def gn_bwd_rows(x, dy, gamma, beta, stats, lv, channels, groups, eps, relu, dg=None, db=None):
+    _check_gn_stats(stats)
     lib = _lib.load()
     nlev = len(lv)
     hw = (C.c_int32 * nlev)(*[h * w for h, w in lv.sizes])
     row0 = (C.c_int64 * nlev)(*lv.row0)
     dx = torch.empty_like(x)
-    dg = torch.empty(channels, dtype=torch.float32, device=x.device)
-    db = torch.empty(channels, dtype=torch.float32, device=x.device)
+    dg = torch.empty(channels, dtype=torch.float32, device=x.device) if dg is None else dg
+    db = torch.empty(channels, dtype=torch.float32, device=x.device) if db is None else db
     bins = torch.empty(lv.batch * nlev * groups * 2, dtype=torch.float32, device=x.device)
     _lib.check(lib.sm_gn_bwd_rows(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats), lv.batch, nlev,
                                   hw, row0, channels, groups, eps, int(relu), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db),

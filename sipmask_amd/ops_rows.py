@@ -76,6 +76,7 @@ class ConvRowsFunction(Function):
         b = None if bias is None else bias.detach().float().contiguous()
         H.conv2d(d, x, wq, b, residual, y)
         ctx.cfg = (lv, olv, stride, pad, relu, res_mode, res_lv, out_f32, k, co, ci, cs, bias is not None)
+        ctx.bias_ref = bias.detach() if (bias is not None and bias.dtype == torch.float32) else None
         ctx.save_for_backward(x, weight, scale, y if relu else None)
         return y
 
@@ -101,7 +102,12 @@ class ConvRowsFunction(Function):
                 g_res = g
         gb = None
         if need_b:
-            gb = H.bias_grad_rows(g, co) if co <= 256 else g.float().sum(0)
+            bias_p = ctx.bias_ref
+            sink = H.GRAD_SINK.target(bias_p) if co <= 256 else None
+            gb = H.bias_grad_rows(g, co, out=sink) if co <= 256 else g.float().sum(0)
+            if sink is not None:          # written straight into the all-reduce bucket (hip_ops._GradSink)
+                H.GRAD_SINK.commit(bias_p)
+                gb = None
         gx = gw = None
         if need_x or need_w:
             if need_x and ci != cs:
@@ -141,8 +147,12 @@ class ConvRowsFunction(Function):
                         parts.append(t)
                 gx = parts[0] if len(parts) == 1 else torch.cat(parts)
             if need_w:
-                gw = H.wgrad_finish(gw_t, scale, co, cs, k, k)
-                if cs != ci:
+                sink = H.GRAD_SINK.target(weight) if (cs == ci and weight.dtype == torch.float32) else None
+                gw = H.wgrad_finish(gw_t, scale, co, cs, k, k, out=sink)
+                if sink is not None:
+                    H.GRAD_SINK.commit(weight)
+                    gw = None
+                elif cs != ci:
                     gw = gw[:, :ci].contiguous()
         return gx, gw, gb, None, g_res, None
 
@@ -166,7 +176,7 @@ class GroupNormRowsFunction(Function):
         if x.dtype != BF16 or not x.is_contiguous() or x.shape[0] != lv.rows:
             raise NotImplementedError("gn_rows: bf16 contiguous pyramid rows")
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        stats = torch.empty(lv.batch * len(lv) * groups * 2, dtype=torch.float32, device=x.device)
+        stats = H.gn_stats_alloc(lv.batch * len(lv) * groups, x.device)
         y = torch.empty_like(x)
         H.groupnorm(x, y, g32, b32, stats, lv, c, groups, eps, relu)
         ctx.save_for_backward(x, g32, b32, stats)
@@ -181,7 +191,15 @@ class GroupNormRowsFunction(Function):
         dy = dy.contiguous()
         if dy.dtype != BF16:
             dy = dy.to(BF16)
-        dx, dg, db = H.gn_bwd_rows(x, dy, g32, b32, stats, lv, c, groups, eps, relu)
+        # g32 / b32 share the parameters' storage (f32 contiguous parameters), so they address the gradient sink
+        sg, sb = H.GRAD_SINK.target(g32), H.GRAD_SINK.target(b32)
+        if sg is None or sb is None:
+            sg = sb = None
+        dx, dg, db = H.gn_bwd_rows(x, dy, g32, b32, stats, lv, c, groups, eps, relu, dg=sg, db=sb)
+        if sg is not None:
+            H.GRAD_SINK.commit(g32)
+            H.GRAD_SINK.commit(b32)
+            dg = db = None
         return dx, dg, db, None, None, None, None
 
 
@@ -235,7 +253,13 @@ class DeformConvRowsFunction(Function):
         goff = torch.empty_like(off) if need_in else None
         gw_t = torch.empty(k * k * ci, co, dtype=torch.float32, device=x.device) if need_w else None
         H.deform_conv2d_bwd(d, x, off, w_t, gout, gx, goff, gw_t)
-        gw = H.wgrad_finish(gw_t, scale, co, ci, k, k) if need_w else None
+        gw = None
+        if need_w:
+            sink = H.GRAD_SINK.target(weight) if weight.dtype == torch.float32 else None
+            gw = H.wgrad_finish(gw_t, scale, co, ci, k, k, out=sink)
+            if sink is not None:
+                H.GRAD_SINK.commit(weight)
+                gw = None
         return (None if gx is None else gx.to(BF16)), goff, gw, gb, None, None
 
 

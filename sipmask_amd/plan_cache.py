@@ -8,13 +8,29 @@ buffer -- with the one the cached plans were built from; any in-place update bum
 (``param.copy_``, ``optimizer.step``, and HipSGD bumps it explicitly after its raw-pointer update) and drops them.
 A small LRU keeps the plans of the last few geometries (keep_ratio resizing yields many padded sizes in a real
 evaluation run).
+
+What the fingerprint cannot see: writes that bypass the version counter while keeping the storage -- ``p.data.copy_()``,
+``p.data.mul_()`` (EMA hooks, hand-written optimizers), or a raw-pointer kernel on ``p.data``.  ``Module.load_state_dict``
+therefore also drops the plans explicitly (``attach_invalidation``: a load_state_dict post-hook), ``hip_ops.sgd_step`` and
+``HipSGD`` bump the counter themselves, and anything else of that kind must call ``invalidate()`` (``SipMask.invalidate_plans``).
+``SIPMASK_PLAN_CHECKSUM=1`` adds a content check for debugging: a device-side sum of every tensor is compared on each
+lookup (one sync per lookup -- not for production).
 """
+import os
 from collections import OrderedDict
+
+
+_CHECKSUM = os.environ.get("SIPMASK_PLAN_CHECKSUM", "0") == "1"
 
 
 def weights_version(tensors):
     """fingerprint of a set of live tensors: changes whenever one of them is updated in place or replaced"""
-    return tuple((t.data_ptr(), t._version) for t in tensors)
+    ver = tuple((t.data_ptr(), t._version) for t in tensors)
+    if _CHECKSUM:           # debug mode: also catches writes through .data / raw pointers (costs a device sync)
+        import torch
+        with torch.no_grad():
+            ver += (float(sum(t.detach().double().sum() for t in tensors if t.is_floating_point())),)
+    return ver
 
 
 class PlanCache:
@@ -42,6 +58,13 @@ class PlanCache:
     def clear(self):
         self._plans.clear()
         self._version = None
+
+    invalidate = clear      # public name: call after writing weights through .data / raw pointers
+
+    def attach_invalidation(self, module):
+        """drop the plans whenever `module.load_state_dict` has run (belt and braces beside the version fingerprint)"""
+        module.register_load_state_dict_post_hook(lambda mod, incompatible: self.clear())
+        return self
 
     def values(self):
         return self._plans.values()

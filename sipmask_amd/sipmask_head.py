@@ -101,7 +101,7 @@ class SipMaskHead(nn.Module):
         self.center_sampling, self.center_sample_radius = center_sampling, center_sample_radius
         self.ssd_flag, self.rescoring_flag = ssd_flag, rescoring_flag
         self.nc = 32
-        self._engines = PlanCache()
+        self._engines = PlanCache().attach_invalidation(self)
         self._init_layers()
 
     def _init_layers(self):

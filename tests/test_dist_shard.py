@@ -67,15 +67,24 @@ def _bucket_worker(rank, world, port, out):
     torch.manual_seed(0)                       # same parameters on every rank
     net = nn.Sequential(nn.Linear(37, 50), nn.ReLU(), nn.Linear(50, 20), nn.ReLU(), nn.Linear(20, 3))
     net[2].bias.requires_grad_(False)          # a frozen parameter is simply not bucketed
+    import copy
+    twin = copy.deepcopy(net)                  # same weights, no bucketer: this rank's LOCAL gradients
     b = GradBucketer(net.parameters(), bucket_bytes=4096)       # several buckets
+    # the gradients live in the buckets: .grad IS a view of the flat buffer, for good
+    assert all(p.grad.data_ptr() == v.data_ptr() for bk in b.buckets for p, v in zip(bk["params"], bk["views"]))
     g = torch.Generator().manual_seed(100 + rank)               # different data per rank
     res = []
     for step in range(2):
         x = torch.randn(8, 37, generator=g)
-        net.zero_grad()
-        net(x).square().sum().backward()
-        local = [p.grad.clone().numpy().tolist() for p in net.parameters() if p.requires_grad]
+        twin.zero_grad()
+        twin(x).square().sum().backward()
+        local = [p.grad.clone().numpy().tolist() for p in twin.parameters() if p.requires_grad]
+        if step == 1:
+            net.zero_grad()                    # a caller that resets .grad to None: the hook folds the fresh tensor back in
+        b.zero_grad()
+        net(x).square().sum().backward()       # hooks launch each bucket's in-place all-reduce as it fills
         b.finish()
+        assert all(p.grad.data_ptr() == v.data_ptr() for bk in b.buckets for p, v in zip(bk["params"], bk["views"]))
         res.append((local, [p.grad.clone().numpy().tolist() for p in net.parameters() if p.requires_grad]))
     out[rank] = (len(b.buckets), res)
     dist.destroy_process_group()
@@ -112,20 +121,29 @@ def _uneven_worker(rank, world, port, out):
     head_a = nn.Linear(32, 40)            # always used
     head_b = nn.Linear(32, 24)            # the "mask branch": used on rank 0 only
     params = list(trunk.parameters()) + list(head_a.parameters()) + list(head_b.parameters())
+    import copy
+    twins = [copy.deepcopy(m) for m in (trunk, head_a, head_b)]          # this rank's LOCAL gradients, no bucketer
+    tparams = [p for m in twins for p in m.parameters()]
     b = GradBucketer(params, bucket_bytes=1024)                 # 1 KB buckets: several, of different sizes
     sizes = [bk["flat"].numel() for bk in b.buckets]
     g = torch.Generator().manual_seed(7 + rank)
     res = []
     for step in range(2):
-        for p in params:
-            p.grad = None
         x = torch.randn(4, 16, generator=g)
+        for p in tparams:
+            p.grad = None
+        h = torch.relu(twins[0](x))
+        tl = twins[1](h).square().sum()
+        if rank == 0:
+            tl = tl + twins[2](h).square().sum()
+        tl.backward()
+        local = [(None if p.grad is None else p.grad.clone()) for p in tparams]
+        b.zero_grad()
         h = torch.relu(trunk(x))
         loss = head_a(h).square().sum()
         if rank == 0:
             loss = loss + head_b(h).square().sum()
         loss.backward()
-        local = [(None if p.grad is None else p.grad.clone()) for p in params]
         b.finish()
         res.append(([None if t is None else t.numpy().tolist() for t in local],
                     [p.grad.clone().numpy().tolist() for p in params]))

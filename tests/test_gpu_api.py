@@ -524,6 +524,65 @@ def test_head_train_step_sgd_updates():
     assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
 
 
+def test_gradients_living_in_allreduce_buckets_match_plain_training():
+    """with a GradBucketer every `.grad` is a view of a flat bucket, the wgrad / bias / GroupNorm backward
+    kernels write into it directly (hip_ops.GRAD_SINK; step 0 is the use census, steps >= 1 are direct), and HipSGD's
+    pointer table is uploaded once.  Three steps from the same initialisation with and without the bucketer must give
+    the same losses and parameters (float-atomic split-K sums in the weight gradients: tolerance, not bits)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import copy
+    from sipmask_amd.registry import build_head
+    from sipmask_amd import sipmask_head  # noqa: F401
+    from sipmask_amd import hip_ops as H
+    from sipmask_amd.dist_train import GradBucketer, HipSGD, head_train_step
+    head = build_head(dict(type='SipMaskHead', num_classes=81, in_channels=256, stacked_convs=4, feat_channels=256,
+                           strides=[8, 16, 32, 64, 128], center_sampling=True, center_sample_radius=1.5)).cuda()
+    sd = {k[len("bbox_head."):]: v for k, v in OM.init_state_dict(50, seed=17, calibrate=True).items()
+          if k.startswith("bbox_head.")}
+    sd["fcos_cls.bias"].fill_(-3.0)
+    head.load_state_dict(sd, strict=True)
+    twin = copy.deepcopy(head)
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    sizes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    feats = [torch.randn(B, 256, h, w, generator=g).cuda() for h, w in sizes]
+    gtb, gtl, gtm = _synthetic_gt(g, B, 128, 160, 4)
+    gtb, gtl = [b.cuda() for b in gtb], [l.cuda() for l in gtl]
+    metas = [dict(img_shape=(128, 160, 3), pad_shape=(128, 160, 3), scale_factor=1.0) for _ in range(B)]
+    opt_a = HipSGD(twin.named_parameters(), lr=0.002, momentum=0.9, weight_decay=1e-4)
+    plain = [head_train_step(twin, feats, gtb, gtl, gtm, metas, opt_a) for _ in range(3)]
+    opt_b = HipSGD(head.named_parameters(), lr=0.002, momentum=0.9, weight_decay=1e-4)
+    bucket = GradBucketer([p for p in head.parameters() if p.requires_grad], bucket_bytes=4 << 20)
+    assert len(bucket.buckets) >= 2
+    try:
+        got = []
+        for step in range(3):
+            got.append(head_train_step(head, feats, gtb, gtl, gtm, metas, opt_b, bucketer=bucket))
+            if step == 0:
+                assert H.GRAD_SINK.census and len(H.GRAD_SINK.uses) > 20
+            else:
+                assert not H.GRAD_SINK.census and len(H.GRAD_SINK.written) > 20       # direct writes happened
+            for bk in bucket.buckets:
+                for p, v in zip(bk["params"], bk["views"]):
+                    assert p.grad.data_ptr() == v.data_ptr()
+        assert opt_b._tab_raw is not None
+        raw = opt_b._tab_raw
+        head_train_step(head, feats, gtb, gtl, gtm, metas, opt_b, bucketer=bucket)
+        assert opt_b._tab_raw == raw                      # the pointer table did not change: no upload after the first
+    finally:
+        bucket.remove()
+    assert not H.GRAD_SINK.views
+    for a, b in zip(plain, got):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    # compare after 3 steps (the 4th above ran on `head` only): re-run the twin once more to stay in step
+    head_train_step(twin, feats, gtb, gtl, gtm, metas, opt_a)
+    for (n, p), (_, q) in zip(head.named_parameters(), twin.named_parameters()):
+        err = float((p.detach() - q.detach()).norm() / (q.detach().norm() + 1e-12))
+        assert err < 2e-3, (n, err)
+
+
 def test_detector_forward_train_vs_oracle():
     """SipMask.forward_train (single_stage.py:49-73): backbone (BN frozen, stage 1 frozen) + FPN + head + loss on the
     HIP autograd ops, against torch-CPU autograd through the oracle.

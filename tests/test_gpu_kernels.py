@@ -219,14 +219,14 @@ def test_conv_fused_groupnorm_statistics(extra):
     x = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, C) for t in xs]).to(torch.bfloat16).to(dev)
     wq, co_pad = H.prep_conv_weight(w.to(dev))
     y = torch.zeros(lv.rows, Co, dtype=torch.bfloat16, device=dev)
-    stats = torch.full((B, len(sizes), Co // 8, 2), 123.0, device=dev)
+    stats = torch.full((B, len(sizes), Co // 8, 2), 123, dtype=torch.int64, device=dev)    # zeroed by the call
     d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, C, Co, co_pad, 3, 1, 1, C, Co, flags=extra)
     H.conv2d_gn_stats(d, x, None, wq, None, None, y, stats)
     torch.cuda.synchronize()
     for l, (h, wd) in enumerate(sizes):
         ref = F.conv2d(xs[l], w, None, 1, 1).double()                       # [B,Co,h,w]
         rs = ref.view(B, Co // 8, 8 * h * wd)
-        got = stats[:, l].cpu().double()
+        got = H.gn_stats_to_float(stats[:, l].cpu())
         torch.testing.assert_close(got[..., 0], rs.sum(-1), rtol=1e-4, atol=2e-3)
         torch.testing.assert_close(got[..., 1], (rs * rs).sum(-1), rtol=1e-4, atol=2e-3)
         out = y[lv.row0[l]:lv.row0[l] + B * h * wd].float().view(B, h, wd, Co).permute(0, 3, 1, 2).cpu()
@@ -259,7 +259,7 @@ def test_grouped_conv_with_groupnorm_statistics(extra, shared_x):
     wq, co_pad = torch.stack([p[0] for p in packed]).contiguous(), packed[0][1]
     y = torch.zeros(G * lv.rows, Co, dtype=torch.bfloat16, device=dev)
     S = 2 * B * len(sizes) * (Co // 8)
-    stats = torch.full((G * S,), 7.0, device=dev)
+    stats = torch.full((G * S,), 7, dtype=torch.int64, device=dev)
     d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, C, Co, co_pad, 3, 1, 1, C, Co, flags=extra, ngroups=G,
                          x_group_rows=0 if shared_x else lv.rows, y_group_rows=lv.rows, w_group_stride=packed[0][0].numel(),
                          gn_group_stride=S)
@@ -267,7 +267,7 @@ def test_grouped_conv_with_groupnorm_statistics(extra, shared_x):
     torch.cuda.synchronize()
     for gi in range(G):
         src = xs[0] if shared_x else xs[gi]
-        st = stats[gi * S:(gi + 1) * S].view(B, len(sizes), Co // 8, 2).cpu().double()
+        st = H.gn_stats_to_float(stats[gi * S:(gi + 1) * S].view(B, len(sizes), Co // 8, 2).cpu())
         for l, (h, wd) in enumerate(sizes):
             ref = F.conv2d(src[l], ws[gi], None, 1, 1).double()
             r0 = gi * lv.rows + lv.row0[l]
@@ -328,7 +328,7 @@ def test_groupnorm_relu_multilevel():
     xs = [_bf(torch.randn(B, C, h, w, generator=g) * 3 + 0.5) for h, w in sizes]
     gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
     x = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, C) for t in xs]).to(torch.bfloat16).to(dev)
-    stats = torch.zeros(B * 5 * 32 * 2, device=dev)
+    stats = H.gn_stats_alloc(B * 5 * 32, dev)
     H.groupnorm(x, x, gamma.to(dev), beta.to(dev), stats, lv, C, 32, 1e-5, True)
     torch.cuda.synchronize()
     for l, (h, w) in enumerate(sizes):
@@ -405,6 +405,29 @@ def test_nms_random_vs_oracle(n):
     sc[: n // 3] = np.round(sc[: n // 3], 1)          # many exact score ties
     dets = np.concatenate([xy, xy + wh, sc[:, None]], 1).astype(np.float32)
     ref = O.nms(dets, 0.5, "gpu")
+    got = P.nms(torch.from_numpy(dets).to(dev), 0.5)[1].cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("n", [64, 700])
+def test_nms_inverted_boxes_vs_oracle(n):
+    """SipMask's bbox_pred is neither exp'd nor ReLU'd, so decoded boxes with x2 < x1 - 1 (negative "+1" area)
+    are reachable.  devIoU (nms_kernel.cu:14-22) then divides by a union that may be negative or zero and the quotient
+    compares as it falls (negative / inf / NaN never exceed thr ... or do): the division-free fast path must not decide
+    those pairs.  A third of the boxes are inverted along x, y or both, some with a union of exactly 0."""
+    from sipmask_amd import ops as P
+    dev = _dev()
+    rng = np.random.RandomState(1000 + n)
+    xy = rng.rand(n, 2).astype(np.float32) * 200
+    wh = rng.rand(n, 2).astype(np.float32) * 80 + 2
+    inv = rng.rand(n, 2) < 0.2
+    wh = np.where(inv, -wh * 3 - 2, wh).astype(np.float32)
+    dets = np.concatenate([xy, xy + wh, rng.rand(n, 1).astype(np.float32)], 1).astype(np.float32)
+    dets[3, :4] = [10, 10, 9, 30]            # width + 1 == 0: area 0
+    dets[4, :4] = [50, 50, 20, 60]           # strongly negative area: union with most boxes < 0
+    dets[3:5, 4] = [0.999, 0.998]            # ... and kept early, so every later box is tested against them
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ref = O.nms(dets, 0.5, "gpu")
     got = P.nms(torch.from_numpy(dets).to(dev), 0.5)[1].cpu().numpy()
     np.testing.assert_array_equal(got, ref)
 
@@ -804,6 +827,45 @@ def test_mask_assemble_lo_vs_oracle_and_rectangle_tracking():
             r = O.mask_assemble(feat[b], cofs[b][keep[b, :n]], det[b, :n], 1.0, False)
             diff = got[b, :n] != r["masks"]
             assert bool(((r["up"] - 0.4).abs()[diff] < 1e-5).all()), (it, b)
+            assert int(diff.sum()) <= 5
+
+
+@pytest.mark.parametrize("sf", [1.667, 2.0, 2.7, 0.8])
+def test_mask_assemble_lo_keep_ratio_scale_factors(sf):
+    """get_bboxes upsamples by 2 / scale_factor (sipmask_head.py:632), and a keep_ratio COCO resize gives
+    scale factors of 1.6-2.7, i.e. up_scale down to 0.74 -- a 128x8 output tile then reads a source window several times
+    the one of up_scale 2.  The kernel sizes its LDS tiles per launch; every such geometry must be supported and match the
+    oracle (crop boxes scaled by scale_factor / 2, :623), and the plan-build query must say so."""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(int(sf * 1000))
+    B, h0, w0, kmax, max_num = 2, 13, 21, 40, 6
+    Hm, Wm = 4 * h0, 4 * w0
+    mul, up, (Ho, Wo) = H.post_geometry(Hm, Wm, sf, True)
+    assert H.mask_assemble_lo_supported(B, max_num, 4, up)
+    assert not H.mask_assemble_lo_supported(B, max_num, 4, 2.0 / 8.0)          # (far outside any pipeline: falls back)
+    basis_lo = torch.relu(torch.randn(B, 32, h0, w0, generator=g))
+    feat = F.interpolate(basis_lo, scale_factor=4, mode="bilinear", align_corners=False)
+    cofs = torch.randn(B, kmax, 128, generator=g) * 0.5
+    lo_rows = basis_lo.permute(0, 2, 3, 1).contiguous().to(dev)
+    buf = H.mask_assemble_lo_alloc(B, max_num, Ho, Wo, dev)
+    for nd in ([6, 2], [1, 5]):
+        # boxes in ORIGINAL-image coordinates (rescale=True: det / scale_factor), so that box * sf / 2 lands on the grid
+        xy = torch.rand(B, max_num, 2, generator=g) * torch.tensor([Wo * 0.7, Ho * 0.7])
+        wh = torch.rand(B, max_num, 2, generator=g) * torch.tensor([Wo * 0.5, Ho * 0.5]) + 3
+        det = torch.cat([xy, xy + wh, torch.rand(B, max_num, 1, generator=g)], 2)
+        keep = torch.randint(0, kmax, (B, max_num), generator=g)
+        H.mask_assemble_lo(lo_rows, h0, w0, 4, cofs.to(dev), keep.to(dev), det.to(dev),
+                           torch.tensor(nd, dtype=torch.int32, device=dev), Ho, Wo, mul, 2.0, up, 0.4, buf)
+        torch.cuda.synchronize()
+        got = buf["masks"][..., :Wo].cpu()
+        for b in range(B):
+            n = nd[b]
+            assert int(got[b, n:].sum()) == 0
+            r = O.mask_assemble(feat[b], cofs[b][keep[b, :n]], det[b, :n], sf, True)
+            assert tuple(r["masks"].shape[-2:]) == (Ho, Wo)
+            diff = got[b, :n] != r["masks"]
+            assert bool(((r["up"] - 0.4).abs()[diff] < 1e-5).all()), (sf, b)
             assert int(diff.sum()) <= 5
 
 

@@ -79,7 +79,7 @@ def test_patch_conv_grouped_with_groupnorm_statistics(shared_x):
     wq = torch.stack(packed).contiguous()
     y = torch.zeros(G * lv.rows, C, dtype=torch.bfloat16, device=dev)
     S = 2 * B * len(sizes) * (C // 8)
-    stats = torch.full((G * S,), 7.0, device=dev)
+    stats = torch.full((G * S,), 7, dtype=torch.int64, device=dev)      # zeroed by the call
     d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, C, C, 256, 3, 1, 1, C, C, ngroups=G,
                          x_group_rows=0 if shared_x else lv.rows, y_group_rows=lv.rows, w_group_stride=packed[0].numel(),
                          bias_group_stride=0, gn_group_stride=S)
@@ -87,7 +87,7 @@ def test_patch_conv_grouped_with_groupnorm_statistics(shared_x):
     torch.cuda.synchronize()
     for gi in range(G):
         src = xs[0] if shared_x else xs[gi]
-        st = stats[gi * S:(gi + 1) * S].view(B, len(sizes), C // 8, 2).cpu()
+        st = H.gn_stats_to_float(stats[gi * S:(gi + 1) * S].view(B, len(sizes), C // 8, 2).cpu()).float()
         for l, (h, wd) in enumerate(sizes):
             ref = F.conv2d(src[l], ws[gi], None, 1, 1)
             got = y[gi * lv.rows + lv.row0[l]: gi * lv.rows + lv.row0[l] + B * h * wd].float().view(B, h, wd, C).permute(0, 3, 1, 2).cpu()
@@ -118,7 +118,7 @@ def test_patch_conv_mixed_tile_launch_at_head_shape(batch, groups):
     outs = {}
     for flag in (0, 0x4000, 0x800, 0x80, 0x4080):
         y = torch.zeros(groups * lv.rows, C, dtype=torch.bfloat16, device=dev)
-        stats = torch.full((groups * S,), 7.0, device=dev)
+        stats = torch.full((groups * S,), 7, dtype=torch.int64, device=dev)
         d = H.make_conv_desc(batch, sizes, sizes, lv.row0, lv.row0, C, C, 256, 3, 1, 1, C, C, flags=flag, ngroups=groups,
                              x_group_rows=0, y_group_rows=lv.rows, w_group_stride=packed[0].numel(), bias_group_stride=0,
                              gn_group_stride=S)
@@ -129,14 +129,19 @@ def test_patch_conv_mixed_tile_launch_at_head_shape(batch, groups):
             assert pl["small"] == 0, pl
         H.conv3x3_patch(d, x, wq, None, y, stats)
         torch.cuda.synchronize()
+        # run to run: the statistics are fixed-point sums (integer atomics), so a second launch reproduces them bit for bit
+        again = torch.full_like(stats, 3)
+        H.conv3x3_patch(d, x, wq, None, y, again)
+        torch.cuda.synchronize()
+        assert torch.equal(stats, again)
         outs[flag] = (y, stats)
     assert torch.equal(outs[0][0], outs[0x4000][0])
     assert torch.equal(outs[0][0], outs[0x800][0])          # the pipelined stage issues the same MFMAs in the same order
     assert torch.equal(outs[0][0], outs[0x80][0]) and torch.equal(outs[0][0], outs[0x4080][0])     # ... and so does ping-pong
-    torch.testing.assert_close(outs[0][1], outs[0x4000][1], rtol=1e-4, atol=0.5)      # atomics: order only
+    torch.testing.assert_close(H.gn_stats_to_float(outs[0][1]), H.gn_stats_to_float(outs[0x4000][1]), rtol=1e-4, atol=0.5)   # other tile cut: other partial sums
     y, stats = outs[0]
     for gi in range(groups):
-        st = stats[gi * S:(gi + 1) * S].view(batch, len(sizes), C // 8, 2)
+        st = H.gn_stats_to_float(stats[gi * S:(gi + 1) * S].view(batch, len(sizes), C // 8, 2)).float()
         for l, (h, wd) in enumerate(sizes):
             ref = F.conv2d(xs[l], ws[gi], None, 1, 1)
             got = y[gi * lv.rows + lv.row0[l]: gi * lv.rows + lv.row0[l] + batch * h * wd].float().view(batch, h, wd, C).permute(0, 3, 1, 2)

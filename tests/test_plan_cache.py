@@ -77,3 +77,29 @@ def test_detector_and_head_use_the_cache():
     from sipmask_amd.synthetic import build_synthetic_detector
     det = build_synthetic_detector(50, seed=0)
     assert isinstance(det._engines, PlanCache) and isinstance(det.bbox_head._engines, PlanCache)
+
+
+def test_writes_through_dot_data_need_an_explicit_invalidate_and_load_state_dict_drops_plans():
+    """`p.data.copy_` keeps data_ptr AND _version, so the fingerprint cannot see it -- documented; the two
+    answers are the load_state_dict post-hook (attach_invalidation) and the public invalidate()."""
+    net, builds = _Net(), []
+    cache = PlanCache().attach_invalidation(net)
+
+    def get():
+        return cache.get("k", module_tensors(net), lambda: builds.append(1) or float(net.conv.weight.flatten()[0]))
+    w0 = get()
+    net.conv.weight.data.mul_(2.0)                       # invisible to the fingerprint ...
+    assert get() == w0 and len(builds) == 1              # ... (the documented caveat)
+    cache.invalidate()                                   # the caller's obligation after such a write
+    assert get() == 2 * w0 and len(builds) == 2
+    # load_state_dict drops the plans even when the loaded tensors are written through .data-like paths
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd["conv.weight"] = sd["conv.weight"] * 0 + 5.0
+    net.load_state_dict(sd)
+    assert get() == 5.0 and len(builds) == 3
+    # the detector exposes the same thing
+    from sipmask_amd.synthetic import build_synthetic_detector
+    det = build_synthetic_detector(50, seed=0)
+    det._engines._plans["x"] = object()
+    det.invalidate_plans()
+    assert len(det._engines) == 0

@@ -16,7 +16,7 @@ for B in BS:
     w = torch.randn(256, 256, 3, 3, device=dev) / 48
     wq, cp = H.prep_conv_weight(w, 256)
     y = torch.empty(lv.rows, 256, dtype=torch.bfloat16, device=dev)
-    st = torch.empty(B * 5 * 32 * 2, dtype=torch.float32, device=dev)
+    st = H.gn_stats_alloc(B * 5 * 32, dev)
     for scale in SCALES:
         off = torch.randn(lv.rows, 72, device=dev) * scale
         res = {}

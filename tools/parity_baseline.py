@@ -82,6 +82,28 @@ def oracle_outputs(sd, img, depth, cache_tag):
     return res
 
 
+def oracle_forward(sd, img, depth):
+    """the oracle record of `oracle_outputs` for a state_dict that is used AS IS (no calibration, no cache): what
+    bench.py compares its timed plan with"""
+    from oracle import model as OM
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    t0 = time.time()
+    with torch.no_grad():
+        feats = OM.backbone_forward(sd, img, depth)
+        pyr = OM.fpn_forward(sd, feats)
+        out = tuple(OM.head_forward(sd, pyr)[:5])
+        H, W = img.shape[-2:]
+        post = []
+        for b in range(img.shape[0]):
+            r = OM.get_masks_single([c[b] for c in out[0]], [c[b] for c in out[1]], [c[b] for c in out[2]],
+                                    [c[b] for c in out[3]], out[4][b], (H, W - 11 if W == IMG_W else W, 3),
+                                    OM.DEFAULT_TEST_CFG)
+            post.append({k: (torch.as_tensor(v) if not torch.is_tensor(v) else v) for k, v in r.items()
+                         if k in ("det_bboxes", "det_labels", "idxs_keep", "cand_level", "cand_pos", "det_cofs")})
+    return dict(feats=feats, pyr=pyr, out=out, post=post, cls_bias=float(sd["bbox_head.fcos_cls.bias"][0]),
+                seconds=time.time() - t0)
+
+
 def mask_logit_errors(eng, ora, b):
     """|engine logit - oracle logit| over the 4 quadrant logit maps of the ORACLE's detections of image b.
     engine logits = engine basis . engine coefficient rows at the oracle's kept (level, position)."""
@@ -177,19 +199,79 @@ def compare_detections(eng, res, ora, B, with_masks=True):
     return out
 
 
-def run(depth=50, batch=4, precision="bf16", features_too=True, verbose=True):
+def sub_view(ora, b0, b1):
+    """the oracle record restricted to images [b0, b1) (one chain of a SubBatchPlan)"""
+    return dict(feats=[f[b0:b1] for f in ora["feats"]], pyr=[p[b0:b1] for p in ora["pyr"]],
+                out=tuple([t[b0:b1] for t in o] if isinstance(o, (list, tuple)) else o[b0:b1] for o in ora["out"][:5]),
+                post=ora["post"][b0:b1], cls_bias=ora["cls_bias"], seconds=ora["seconds"])
+
+
+def _merge(reports):
+    """stage reports of the chains of a SubBatchPlan -> one report: worst case per stage (rel_fro: the chains' maximum)"""
+    out = {}
+    for k in reports[0]:
+        vs = [r[k] for r in reports]
+        m = {}
+        for f in vs[0]:
+            if f == "ndet":
+                m[f] = sum((v[f] for v in vs), [])
+            elif f in ("mean_abs", "ref_rms"):
+                m[f] = float(np.mean([v[f] for v in vs]))
+            else:
+                m[f] = max(v[f] for v in vs)
+        out[k] = m
+    return out
+
+
+def compare_plan(plan, res, ora, B, from_image=True, with_masks=True):
+    """stage report + detection report of a launch plan -- a SipMaskEngine or a SubBatchPlan (every chain against its
+    slice of the oracle record; `res` = the plan's result dict over the whole batch)"""
+    chains = getattr(plan, "engines", None)
+    if not chains:
+        return compare_engine(plan, ora, B, from_image), compare_detections(plan, res, ora, B, with_masks)
+    reps, dets, b0 = [], [], 0
+    for e in chains:
+        o = sub_view(ora, b0, b0 + e.batch)
+        reps.append(compare_engine(e, o, e.batch, from_image))
+        dets += compare_detections(e, {k: v[b0:b0 + e.batch] for k, v in res.items()}, o, e.batch, with_masks)
+        b0 += e.batch
+    return _merge(reps), dets
+
+
+def parity_summary(stage_report, det_report):
+    """the two numbers north_star names, for the bench line: mask-logit max-abs error and detections in common"""
+    return dict(mask_logit_max_abs=round(stage_report["mask_logits"]["max_abs"], 6),
+                mask_logit_ref_max_abs=round(stage_report["mask_logits"]["ref_max_abs"], 3),
+                common_dets=[d["common"] for d in det_report], oracle_dets=[d["ndet_oracle"] for d in det_report],
+                engine_dets=[d["ndet_engine"] for d in det_report], same_order=[d["same_order"] for d in det_report])
+
+
+def run(depth=50, batch=4, precision="bf16", features_too=True, verbose=True, plan="single"):
+    """plan: "single" = one SipMaskEngine over the batch; "subbatch" = the object bench.py times, i.e.
+    det.prepare(batch, ..., lanes="auto") (engine.SubBatchPlan: two half-batch chains, no split-K, uniform patch tiles)."""
     from sipmask_amd.engine import SipMaskEngine
     dev = torch.device("cuda")
     det, sd, img = build_case(depth, batch)
     ora = oracle_outputs(sd, img, depth, "r%d_b%d" % (depth, batch))
     sd["bbox_head.fcos_cls.bias"].fill_(ora["cls_bias"])
     kw = {} if precision == "bf16" else dict(precision=precision)
-    report = dict(depth=depth, batch=batch, hw=[IMG_H, IMG_W], precision=precision, oracle_seconds=ora["seconds"])
-    eng = SipMaskEngine(sd, batch, (IMG_H, IMG_W), depth, img_shape=(IMG_H, 1333, 3), **kw)
+    report = dict(depth=depth, batch=batch, hw=[IMG_H, IMG_W], precision=precision, plan=plan, oracle_seconds=ora["seconds"])
+    if plan == "subbatch":
+        with torch.no_grad():
+            det.bbox_head.fcos_cls.bias.fill_(ora["cls_bias"])
+        eng = det.prepare(batch, (IMG_H, IMG_W), (IMG_H, 1333, 3), precision=precision, lanes="auto")
+        report["chains"] = [e.batch for e in getattr(eng, "engines", [eng])]
+    else:
+        eng = SipMaskEngine(sd, batch, (IMG_H, IMG_W), depth, img_shape=(IMG_H, 1333, 3), **kw)
     res = eng.run(img.to(dev))
     torch.cuda.synchronize()
-    report["image"] = compare_engine(eng, ora, batch, True)
-    report["detections"] = compare_detections(eng, res, ora, batch, with_masks=(precision != "bf16"))
+    first = {k: v.clone() for k, v in res.items() if k != "masks"}
+    report["image"], report["detections"] = compare_plan(eng, res, ora, batch, True, with_masks=(precision != "bf16"))
+    report["parity"] = parity_summary(report["image"], report["detections"])
+    # run to run: a second pass of the same plan over the same images must reproduce every integer output bit for bit
+    res2 = eng.run(img.to(dev))
+    torch.cuda.synchronize()
+    report["rerun_bit_identical"] = bool(all(torch.equal(first[k], res2[k]) for k in first))
     del eng
     torch.cuda.empty_cache()
     if features_too:
@@ -201,6 +283,7 @@ def run(depth=50, batch=4, precision="bf16", features_too=True, verbose=True):
         torch.cuda.synchronize()
         report["features"] = compare_engine(heng, ora, batch, False)
         report["features_detections"] = compare_detections(heng, heng.results(), ora, batch, with_masks=False)
+        report["features_parity"] = parity_summary(report["features"], report["features_detections"])
     if verbose:
         for sec in ("image", "features"):
             if sec in report:
@@ -208,6 +291,9 @@ def run(depth=50, batch=4, precision="bf16", features_too=True, verbose=True):
                     print("%-9s %-12s rel %.3e  max_abs %.3e  (ref max %.3g rms %.3g)" %
                           (sec, k, v["rel_fro"], v["max_abs"], v["ref_max_abs"], v["ref_rms"]))
         print("detections:", json.dumps(report["detections"]))
+        print("parity:", json.dumps(report["parity"]), "rerun_bit_identical:", report["rerun_bit_identical"])
+        if "features_parity" in report:
+            print("features parity:", json.dumps(report["features_parity"]))
     return report
 
 
@@ -216,9 +302,10 @@ if __name__ == "__main__":
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--plan", default="single", choices=("single", "subbatch"))
     ap.add_argument("--out", default="")
     a = ap.parse_args()
-    rep = run(a.depth, a.batch, a.precision)
+    rep = run(a.depth, a.batch, a.precision, plan=a.plan)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         with open(a.out, "w") as f:
