@@ -10,6 +10,7 @@ inference; RCCL gradient all-reduce in training).  BASELINE.json configs:
   --config vis    (configs[4]) SipMask-VIS R50 on YouTube-VIS-shaped clips (8 frames of 3x384x640 = 640x360 padded),
                   sharded BY VIDEO (the tracker is sequential inside a clip); step = one clip per GPU
   --precision f32 the parity plan (exact-f32 MFMA convs) instead of the bf16 throughput plan (r50 / r101)
+  --precision head_x3  bf16 backbone + FPN, split-precision head (the reference head's fp32 arithmetic to ~1e-4)
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config ...]
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under torch.distributed.run with N
@@ -41,7 +42,10 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=("r50", "r101", "train", "vis"), default="r50")
-    ap.add_argument("--precision", choices=("bf16", "f32"), default="bf16")
+    ap.add_argument("--precision", choices=("bf16", "f32", "head_x3"), default="bf16",
+                    help="bf16 = the throughput plan (BASELINE configs[1] names bf16); head_x3 = bf16 backbone + FPN with the "
+                         "split-precision head (binary16 halves, three MFMA terms, f32 activations: mask logits within 1e-3 "
+                         "of the fp32 reference head on identical features); f32 = the all-f32 parity plan")
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE configs[1]: 4)")
     ap.add_argument("--depth", type=int, default=None, help="backbone depth (overrides the config's)")
     ap.add_argument("--lanes", type=int, default=0, help="run the batch as this many independent sub-batch plans on "
@@ -126,8 +130,9 @@ def parity_of_timed_plan(det, plan, img, depth):
     stages, dets = PB.compare_plan(plan, plan.results(), ora, img.shape[0], True, with_masks=False)
     p = PB.parity_summary(stages, dets)
     p["mask_logit_rel_fro"] = round(stages["mask_logits"]["rel_fro"], 5)
-    p["note"] = ("timed plan vs fp32 CPU oracle from the same images; bf16 storage end to end is NOT within north_star's "
-                 "1e-3 (the f32 / head_x3 plans are: --precision)")
+    p["note"] = ("timed plan vs fp32 CPU oracle from the same IMAGES: the bf16 backbone's rounding is part of this number for "
+                 "--precision bf16 and head_x3 (north_star's 1e-3 is stated for identical head inputs: tools/parity_baseline.py "
+                 "'features' section, tests/test_gpu_baseline_shape.py; from the image only --precision f32 meets it)")
     p["oracle_seconds"] = round(ora["seconds"], 1)
     return p
 
@@ -252,7 +257,10 @@ def run_inference(args, rank, world, dev):
     if grouped:
         towers = grouped
     tower_ms = sum(conv_ms[c.name] for c in towers) / len(towers)
-    tower_flops = towers[0].flops
+    x3 = args.precision == "head_x3"
+    # x3: three binary16 half products per element product -- the MFMA pipe does 3x the algorithmic FLOPs, and THAT is what
+    # the roofline fraction prices (the algorithmic figure is reported beside it)
+    tower_flops = getattr(towers[0], "mfma_flops", towers[0].flops)
     all_conv_ms = sum(v for v in conv_ms.values())
     all_conv_flops = eng.total_conv_flops()
     fpn = [c for c in eng.convs if c.name.startswith("fpn.")]
@@ -284,6 +292,11 @@ def run_inference(args, rank, world, dev):
     if f32:
         kernel = ("conv_f32_kernel<2,2,2,2> (v_mfma_f32_32x32x2_f32, 128x128 tile, 16-wide K steps, register-staged "
                   "loader) = tower 3x3 256->256 over 5 FPN levels (M=%d,N=256,K=2304)" % (eng.batch * 22400))
+    elif x3:
+        kernel = ("conv3x3_patch_kernel, binary16 operands (v_mfma_f32_32x32x16_f16): cls+reg tower 3x3 256->256 of one depth "
+                  "over 5 FPN levels as ONE grouped launch on split operands [hi|lo|hi] x [hi|hi|lo] (2 x (M=%d,N=256,"
+                  "K=3*2304)), f32 output, fixed-point GroupNorm statistics fused; achieved = MFMA FLOPs issued "
+                  "(3 x %.1f algorithmic GFLOP)" % (eng.batch * 22400, towers[0].flops / 1e9))
     elif getattr(towers[0], "patch", False):
         kernel = ("conv3x3_patch_kernel (input patch + 2 taps of weights resident in LDS via LDS-DMA, 256x256 tile on 8 "
                   "waves, GroupNorm statistics fused)%s = tower 3x3 256->256 over 5 FPN levels (%sM=%d,N=256,K=2304)"
@@ -302,12 +315,13 @@ def run_inference(args, rank, world, dev):
         "value": round(B * args.steps * world / elapsed, 3),
         "unit": "img/s",
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "dtype": "f32" if f32 else "bf16",
+        "dtype": "f32" if f32 else ("bf16 (backbone, FPN) + 3 x f16 split products / f32 activations (head)" if x3 else "bf16"),
         "data": "synthetic (randn images, %d batches resident in HBM rotated through the plan's input every step; "
                 "reference-init random weights + SURVEY 8d calibration overrides)" % NSETS,
         "config": {"workload": "SipMask-R%d FPN inference, batch=%d/GPU, 3x800x1344 (800x1333 padded), %s, score_thr .05, "
-                               "nms .5, max_per_img 100" % (args.depth, B, "f32 storage + exact-f32 MFMA (parity plan)" if f32
-                                                            else "bf16 storage + f32 accumulate"),
+                               "nms .5, max_per_img 100" % (args.depth, B, "f32 storage + exact-f32 MFMA (parity plan)" if f32 else
+                                                            ("bf16 backbone + FPN, split-precision (x3) head" if x3 else
+                                                             "bf16 storage + f32 accumulate")),
                    "global_batch": B * world, "parallelism": "dp%d (batch shard, no collective)" % world,
                    "launch": ("hipGraph replay" if graph is not None else "eager") +
                              ("" if not subplans else ", %d sub-batch plans of %d images on concurrent streams"

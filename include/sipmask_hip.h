@@ -55,32 +55,30 @@ typedef enum {
                                     share their values are read by sm_conv3x3_patch only.) */
 #define SM_CONV_RELU_NCH 32u     /* y = max(y, 0) on channels < scale_nch only (the maskrcnn-benchmark variant's
                                     relu(scale(bbox_pred)), SipMask-benchmark/.../sipmask/sipmask.py:155-157) */
-#define SM_CONV_DBG_DEFORM_GATHER 0x80000000u /* A/B switch: deformable conv through conv_igemm's global-gather loader where the
-                                    LDS-patch kernel (deform_patch.hip: 3x3, 64 channels per deformable group) would run */
-#define SM_CONV_DBG_LINEAR_TILES 0x40000000u /* A/B switch: disable the XCD-aware tile remap */
-#define SM_CONV_DBG_REG_STAGING 0x20000000u  /* A/B switch: register-staged loader instead of LDS-DMA */
-#define SM_CONV_DBG_K32 0x10000000u          /* A/B switch: force 32-wide K steps, 4 blocks per CU */
-#define SM_CONV_DBG_K64 0x08000000u          /* A/B switch: force 64-wide K steps, 2 blocks per CU */
-#define SM_CONV_DBG_BIG_TILES 0x04000000u    /* A/B switch: never shrink tiles for occupancy */
-#define SM_CONV_DBG_LDS_EPILOGUE 0x01000000u /* A/B switch: LDS-staged epilogue in the 32-wide-K kernel (default: registers) */
-#define SM_CONV_DBG_WIDE_POS 0x00800000u     /* A/B switch: 128-cout x 256-position tiles (64x128 per wave) where the register epilogue applies */
-#define SM_CONV_DBG_TILE256 0x00400000u      /* A/B switch: 256x256 tiles on 8 waves, 1 block per CU (64-wide K steps, cout_pad % 256 == 0) */
-#define SM_CONV_DBG_FLAT_LOOP 0x00200000u    /* A/B switch: flat LDS-DMA loader + peeled K loop WITHOUT the pipelined fragment reads of the default loop */
-#define SM_CONV_DBG_LEGACY_LOOP 0x00100000u  /* A/B switch: the original K loop (branchy loader, one fragment register set) on the 128/64-cout tiles */
-#define SM_CONV_DBG_K32_OPT 0x00080000u      /* A/B switch: flat loader + peeled loop + pipelined fragment reads in the 32-wide-K kernel (cin >= 32) */
-#define SM_CONV_DBG_HAND_PLACED 0x00040000u  /* A/B switch (with TILE256): hand-placed K step, LDS-DMA pieces between the MFMAs */
-#define SM_CONV_DBG_RES_PREFETCH 0x00020000u /* A/B switch: 32-wide-K kernel loads the residual rows BEFORE the K loop (HBM-bound 1x1 + residual convs) */
-#define SM_CONV_DBG_DEFORM_128 0x00008000u  /* A/B switch: deformable conv on the 128-cout x 128-position 4-wave tile (default: 256 x 128 on 8 waves) */
-#define SM_CONV_DBG_PATCH_UNIFORM 0x00004000u  /* A/B switch (sm_conv3x3_patch): every tile 256 positions (the round-2 launch shape) */
-#define SM_CONV_DBG_PATCH_SMALL128 0x00002000u /* A/B switch (sm_conv3x3_patch): only 128-position tiles finish a launch */
-#define SM_CONV_DBG_PATCH_SMALL192 0x00001000u /* A/B switch (sm_conv3x3_patch): only 192-position tiles finish a launch */
-#define SM_CONV_DBG_PATCH_PIPE 0x00000800u     /* A/B switch (sm_conv3x3_patch): fragment reads of sub-step i+1 pinned under the MFMAs of sub-step i */
-#define SM_CONV_DBG_PATCH_STAGGER 0x00000400u  /* A/B switch (sm_conv3x3_patch): waves 4-7 issue their LDS-DMA between the two taps of a stage */
-#define SM_CONV_DBG_PATCH_NO_DMA 0x00000200u   /* ABLATION (micro-benchmark only, wrong results): no LDS-DMA in the main loop */
-#define SM_CONV_DBG_PATCH_NO_MFMA 0x00000100u  /* ABLATION (micro-benchmark only, wrong results): no MFMA / fragment reads in the main loop */
-#define SM_CONV_DBG_PATCH_PINGPONG 0x00000080u /* A/B switch (sm_conv3x3_patch): ping-pong schedule, waves 0-3 compute while waves 4-7 load and vice versa */
-#define SM_CONV_DBG_NO_SPLITK 0x00010000u   /* A/B switch: sm_conv2d_ws never splits K */
-#define SM_CONV_DBG_WARP_SPEC 0x02000000u    /* A/B switch: 8-wave producer/consumer variant of the 64-wide-K kernel */
+/* Launch-plan selectors.  Every one of them picks a different kernel / tile / loop for the SAME arithmetic: results are
+ * equal up to f32 accumulation order (TILE256 / HAND_PLACED / PATCH_UNIFORM / BIG_TILES / LDS_EPILOGUE: bit-identical).
+ * The rejected variants and ablations of rounds 1-2 (ping-pong, pipelined, staggered, legacy / flat loops, warp
+ * specialisation, wide tiles, no-DMA / no-MFMA ablations ...) are NOT part of this interface: they are compiled only
+ * with `make EXPERIMENTS=1` (sipmask_amd/csrc/experiments.h) for the A/B tools under tools/. */
+#define SM_CONV_DBG_DEFORM_GATHER 0x80000000u /* deformable conv through conv_igemm's global-gather loader where the LDS-window
+                                    kernel (deform_patch.hip: 3x3, 64 channels per deformable group) would run: the faster
+                                    path when most learned offsets exceed ~3 pixels (sipmask_amd/engine.py measures it) */
+#define SM_CONV_DBG_K32 0x10000000u          /* force 32-wide K steps, 4 blocks per CU */
+#define SM_CONV_DBG_K64 0x08000000u          /* force 64-wide K steps, 2 blocks per CU */
+#define SM_CONV_DBG_BIG_TILES 0x04000000u    /* never shrink tiles for occupancy (tests force large tiles at small shapes) */
+#define SM_CONV_DBG_LDS_EPILOGUE 0x01000000u /* LDS-staged epilogue where the register epilogue would run (the path unaligned
+                                    shapes take) */
+#define SM_CONV_DBG_TILE256 0x00400000u      /* 256x256 tiles on 8 waves, 1 block per CU (64-wide K steps, cout_pad % 256 == 0) */
+#define SM_CONV_DBG_HAND_PLACED 0x00040000u  /* with TILE256: hand-placed K step, LDS-DMA pieces between the MFMAs */
+#define SM_CONV_DBG_PATCH_UNIFORM 0x00004000u  /* sm_conv3x3_patch: every tile 256 positions (no 128/192-position finishing tiles) */
+#define SM_CONV_DBG_NO_SPLITK 0x00010000u   /* sm_conv2d_ws never splits K */
+/* Operand type.  Default: bf16 operands (x, w), v_mfma_f32_32x32x16_bf16.  SM_CONV_F16: x and w hold IEEE binary16
+ * values and the contraction runs on v_mfma_f32_32x32x16_f16 -- the operand type of the split-precision ("x3") head
+ * plan, where every f32 value v travels as two halves hi = f16(v), lo = f16(v - hi) (22 mantissa bits together) laid
+ * out as 3*C channels [hi | lo | hi] against weights [hi | hi | lo]: one ordinary convolution over 3*C channels then IS
+ * the three-term product hi*hi + lo*hi + hi*lo with f32 accumulation (sm_split3_f16 writes that layout).  Needs
+ * SM_CONV_OUT_F32, no residual / input ReLU / deformable gather; sm_conv2d, sm_conv2d_gn_stats, sm_conv3x3_patch. */
+#define SM_CONV_F16 0x00020000u
 
 /* One (multi-level) 2-D convolution as an implicit GEMM.  Replaces the ATen/cuDNN
  * conv calls under M/mmdet/models/backbones/resnet.py:206-229,
@@ -116,6 +114,10 @@ typedef struct {
    * bias at g*bias_group_stride floats and GroupNorm statistics at g*gn_group_stride floats.  0 or 1 = no groups. */
   int32_t ngroups;
   int64_t x_group_rows, y_group_rows, w_group_stride, bias_group_stride, gn_group_stride;
+  float acc_scale;                /* 0 or 1: none.  Otherwise y = epilogue(acc * acc_scale ...): the accumulator is
+                                   * multiplied BEFORE bias / Scale / ReLU.  The x3 plan stores weights multiplied by a
+                                   * power of two (so that the low half of a ~1e-2 weight stays out of binary16's
+                                   * subnormals) and passes the inverse here -- exact. */
 } sm_conv_desc;
 
 int sm_version(void);
@@ -312,6 +314,25 @@ int sm_groupnorm(const void* x, void* y, const float* gamma, const float* beta, 
 int sm_groupnorm_apply(const void* x, void* y, const float* gamma, const float* beta, const int64_t* stats,
                        int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels,
                        int groups, float eps, int relu, sm_stream_t stream);
+
+/* ---- split-precision ("x3") head plan: the layout kernels behind SM_CONV_F16 (csrc/split_x3.hip).
+ * The reference head computes in fp32 (sipmask_head.py:241-287,609-633).  The x3 plan keeps head activations f32 and
+ * hands every convolution its operands as two binary16 halves per value, hi = f16(v), lo = f16(v - hi), along the
+ * channel axis as [hi | lo | hi] (3*C channels; weights [hi | hi | lo], prepared by the host).
+ * sm_split3_f16: x = f32 (x_is_f32) or bf16 rows [rows][in_cstride], first `channels` channels -> y binary16 rows of
+ *   3*ctot channels: hi at [coff, coff+channels), lo at ctot + the same, hi again at 2*ctot + the same (ctot > channels
+ *   lets several sources fill one destination: the mask branch's concatenation, sipmask_head.py:266-275).
+ * sm_gn_stats_f32_fix: GroupNorm statistics of f32 pyramid rows (geometry as sm_groupnorm) in the fixed-point format of
+ *   sm_conv2d_gn_stats; zeroed by the call.
+ * sm_groupnorm_apply_x3: y = [relu](GroupNorm(x)) from such statistics; x f32 rows [rows][channels]; writes y_f32 (f32
+ *   rows, may alias x) and / or y_split (binary16 [rows][3*channels], [hi | lo | hi]); either may be NULL, not both. */
+int sm_split3_f16(const void* x, int x_is_f32, int64_t rows, int channels, int in_cstride, void* y, int ctot, int coff,
+                  sm_stream_t stream);
+int sm_gn_stats_f32_fix(const float* x, int64_t* stats, int batch, int nlev, const int32_t* hw, const int64_t* row0,
+                        int channels, int groups, sm_stream_t stream);
+int sm_groupnorm_apply_x3(const float* x, const float* gamma, const float* beta, const int64_t* stats, int batch, int nlev,
+                          const int32_t* hw, const int64_t* row0, int channels, int groups, float eps, int relu,
+                          float* y_f32, void* y_split, sm_stream_t stream);
 
 /* 3x3 stride-2 pad-1 max pool (resnet.py:460), NHWC bf16. */
 int sm_maxpool3x3s2(const void* x, void* y, int batch, int h, int w, int c, sm_stream_t stream);

@@ -19,7 +19,13 @@ SM_CONV_RES_ADD = 4
 SM_CONV_RES_NEAREST = 8
 SM_CONV_IN_RELU = 16
 SM_CONV_RELU_NCH = 32
-SM_CONV_DBG_DEFORM_GATHER = 0x80000000   # A/B: the global-gather deformable loader instead of deform_patch.hip
+SM_CONV_DBG_DEFORM_GATHER = 0x80000000   # the global-gather deformable loader instead of deform_patch.hip
+SM_CONV_DBG_BIG_TILES = 0x04000000
+SM_CONV_DBG_TILE256 = 0x00400000
+SM_CONV_DBG_HAND_PLACED = 0x00040000
+SM_CONV_DBG_PATCH_UNIFORM = 0x00004000
+SM_CONV_DBG_LDS_EPILOGUE = 0x01000000
+SM_CONV_F16 = 0x00020000                 # IEEE binary16 operands (the x3 head plan), f32 output
 
 _i32x5 = C.c_int32 * SM_MAX_LEVELS
 _i64x5 = C.c_int64 * SM_MAX_LEVELS
@@ -41,6 +47,7 @@ class ConvDesc(C.Structure):
         ("deform_groups", C.c_int32), ("w_batch_stride", C.c_int64),
         ("ngroups", C.c_int32), ("x_group_rows", C.c_int64), ("y_group_rows", C.c_int64), ("w_group_stride", C.c_int64),
         ("bias_group_stride", C.c_int64), ("gn_group_stride", C.c_int64),
+        ("acc_scale", C.c_float),
     ]
 
 
@@ -94,6 +101,9 @@ PROTOTYPES = {
     "sm_relu_bf16": (_I, [_P, _P, C.c_int64, _P]),
     "sm_bottleneck_tail_supported": (_I, [_I]),
     "sm_bottleneck_tail": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sm_split3_f16": (_I, [_P, _I, C.c_int64, _I, _I, _P, _I, _I, _P]),
+    "sm_gn_stats_f32_fix": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _P]),
+    "sm_groupnorm_apply_x3": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P]),
     "sm_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P]),
     "sm_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sm_nchw_f32_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

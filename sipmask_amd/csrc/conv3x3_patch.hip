@@ -21,6 +21,21 @@
 #include <utility>
 
 #include "common.h"
+#include "experiments.h"
+
+// Operand type of this translation unit: compiled twice like conv_igemm.hip (csrc/Makefile) -- bf16 operands on
+// v_mfma_f32_32x32x16_bf16, and with -DSM_OPERAND_F16 binary16 operands on v_mfma_f32_32x32x16_f16 (SM_CONV_F16: the
+// split-precision head plan, f32 output only).  The LDS-DMA loader never interprets the 16-bit payloads.
+#ifdef SM_OPERAND_F16
+typedef _Float16 frag8 __attribute__((ext_vector_type(8)));
+#define SM_MFMA_32x32x16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16((A), (B), (C), 0, 0, 0)
+#else
+typedef bf16x8 frag8;
+#define SM_MFMA_32x32x16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
+// conv3x3_patch_f16.o
+int sm_conv3x3_patch_f16(const sm_conv_desc* d, const void* x, const void* w_patch, const float* bias, void* y,
+                         unsigned long long* gn_stats, hipStream_t stream);
+#endif
 
 namespace {
 
@@ -46,6 +61,7 @@ struct PatchArgs {
   unsigned flags;
   int scale_nch;
   float level_scale[SM_MAX_LEVELS];
+  float acc_scale;                // accumulators x this before bias / Scale (1 = none; sm_conv_desc.acc_scale)
   int prow_cap;                   // rows of one patch buffer (multiple of 16)
   int ngroups, tpg[2];
   long long x_grows, y_grows, w_gstride, b_gstride, gn_gstride;
@@ -173,7 +189,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   // u+1 pinned under the MFMAs of u and the DMA issues pinned behind every second MFMA (sched_barrier(0) per slot)
   // needed 256 VGPRs + 19 spills and ran 764 vs 835 TFLOP/s on the B=2 tower launch -- not kept.
   auto tap = [&](const unsigned char* Wst, const int hx, const unsigned char* P, int shift) {   // hx = 64 * (tap of the stage)
-    bf16x8 wf[2][TCO], xf[2][TPOS];
+    frag8 wf[2][TCO], xf[2][TPOS];
     int pr[TPOS], psw[TPOS];
 #pragma unroll
     for (int t = 0; t < TPOS; ++t) {
@@ -183,10 +199,10 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
     auto rd = [&](int kk, int set) {
 #pragma unroll
       for (int t = 0; t < TCO; ++t)
-        wf[set][t] = *reinterpret_cast<const bf16x8*>(Wst + wrow_off + t * 32 * 128 + ((((kk * 2 + khalf) ^ rsw) * 16) ^ hx));
+        wf[set][t] = *reinterpret_cast<const frag8*>(Wst + wrow_off + t * 32 * 128 + ((((kk * 2 + khalf) ^ rsw) * 16) ^ hx));
 #pragma unroll
       for (int t = 0; t < TPOS; ++t)
-        xf[set][t] = *reinterpret_cast<const bf16x8*>(P + pr[t] * 64 + (((kk * 2 + khalf) ^ psw[t]) * 16));
+        xf[set][t] = *reinterpret_cast<const frag8*>(P + pr[t] * 64 + (((kk * 2 + khalf) ^ psw[t]) * 16));
     };
     rd(0, 0);
     rd(1, 1);
@@ -196,7 +212,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
       for (int tc = 0; tc < TCO; ++tc)
 #pragma unroll
         for (int tp = 0; tp < TPOS; ++tp)
-          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][tc], xf[kk][tp], acc[tc][tp], 0, 0, 0);
+          acc[tc][tp] = SM_MFMA_32x32x16(wf[kk][tc], xf[kk][tp], acc[tc][tp]);
   };
 
   // ---- main loop over channel-chunk PAIRS: 18 taps = 9 weight stages per iteration.
@@ -222,7 +238,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
     //  * a loading wave waits for its own ds_reads (lgkmcnt(0)) before the barrier, so a buffer is never overwritten
     //    while a read of it is in flight.  The barriers are raw s_barrier: they must not drain the DMA queue.
     const bool grp_a = wave < 4;
-    bf16x8 wf[2][TCO], xf[2][TPOS];
+    frag8 wf[2][TCO], xf[2][TPOS];
     auto load_tap = [&](int st, auto SC) {                 // fragments of tap SC (0..17 inside the pair) of stage st
       constexpr int sidx = decltype(SC)::value;
       constexpr int hh = sidx & 1;
@@ -243,10 +259,10 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
       for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
         for (int t = 0; t < TCO; ++t)
-          wf[kk][t] = *reinterpret_cast<const bf16x8*>(Wh + (wa ^ (kk * 32)) + t * 32 * 128);
+          wf[kk][t] = *reinterpret_cast<const frag8*>(Wh + (wa ^ (kk * 32)) + t * 32 * 128);
 #pragma unroll
         for (int t = 0; t < TPOS; ++t)
-          xf[kk][t] = *reinterpret_cast<const bf16x8*>(P + (xa ^ (kk * 32)) + t * 32 * 64);
+          xf[kk][t] = *reinterpret_cast<const frag8*>(P + (xa ^ (kk * 32)) + t * 32 * 64);
       }
     };
     auto compute_tap = [&]() {
@@ -256,7 +272,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
         for (int tc = 0; tc < TCO; ++tc)
 #pragma unroll
           for (int tp = 0; tp < TPOS; ++tp)
-            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][tc], xf[kk][tp], acc[tc][tp], 0, 0, 0);
+            acc[tc][tp] = SM_MFMA_32x32x16(wf[kk][tc], xf[kk][tp], acc[tc][tp]);
     };
     auto issue_stage = [&](int cpv, auto SPC) {            // the DMA the old loop issues at the top of stage (cpv, sp)
       constexpr int sp = decltype(SPC)::value;
@@ -337,7 +353,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
         // first sub-step after the barrier waits for the LDS.  hipcc's own schedule (the else branch) re-uses one set per
         // tap: read -> lgkmcnt(0) -> 2-4 MFMAs, eight exposed LDS round trips per stage.
         constexpr int NFR = TCO + TPOS, NMF = TCO * TPOS, NPAIR = NFR < NMF ? NFR : NMF;
-        bf16x8 wf[2][TCO], xf[2][TPOS];
+        frag8 wf[2][TCO], xf[2][TPOS];
         auto rd = [&](auto IC, int set) {
           constexpr int i = decltype(IC)::value;
           constexpr int hh = i >> 1, kk = i & 1;
@@ -347,11 +363,11 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
           const int shift = kh * Wp + kw;
 #pragma unroll
           for (int t = 0; t < TCO; ++t)
-            wf[set][t] = *reinterpret_cast<const bf16x8*>(Wst + wrow_off + t * 32 * 128 + (((hh * 4 + kk * 2 + khalf) ^ rsw) * 16));
+            wf[set][t] = *reinterpret_cast<const frag8*>(Wst + wrow_off + t * 32 * 128 + (((hh * 4 + kk * 2 + khalf) ^ rsw) * 16));
 #pragma unroll
           for (int t = 0; t < TPOS; ++t) {
             const int pr = prow0 + t * 32 + shift;
-            xf[set][t] = *reinterpret_cast<const bf16x8*>(P + pr * 64 + (((kk * 2 + khalf) ^ ((pr >> 2) & 3)) * 16));
+            xf[set][t] = *reinterpret_cast<const frag8*>(P + pr * 64 + (((kk * 2 + khalf) ^ ((pr >> 2) & 3)) * 16));
           }
         };
         rd(std::integral_constant<int, 0>{}, 0);
@@ -367,7 +383,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
 #pragma unroll
             for (int tp = 0; tp < TPOS; ++tp)
               if constexpr (!NO_MFMA)
-                acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 1][tc], xf[i & 1][tp], acc[tc][tp], 0, 0, 0);
+                acc[tc][tp] = SM_MFMA_32x32x16(wf[i & 1][tc], xf[i & 1][tp], acc[tc][tp]);
           if constexpr (i < 3) {
 #pragma unroll
             for (int j = 0; j < NPAIR; ++j) {
@@ -426,6 +442,10 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
           const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
           v[e] = __uint_as_float(r[0]);
           v[4 + e] = __uint_as_float(r[1]);
+        }
+        if (a.acc_scale != 1.f) {                   // block-uniform: the x3 plan's power-of-two weight scale, undone exactly
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= a.acc_scale;
         }
         const int cl = wco * (TCO * 32) + tc * 32 + 8 * (2 * qp + khalf);
         const int c0 = nt * PT_BCO + cl;
@@ -618,6 +638,7 @@ void plan_shape(const sm_conv_desc* d, PatchShape* ps) {
 
 }  // namespace
 
+#ifndef SM_OPERAND_F16
 extern "C" int sm_conv3x3_patch_supported(const sm_conv_desc* d) { return patch_check(d) == SM_OK ? 1 : 0; }
 
 extern "C" int64_t sm_conv3x3_patch_tiles(const sm_conv_desc* d) {
@@ -640,13 +661,25 @@ extern "C" int sm_conv3x3_patch_plan(const sm_conv_desc* d, int64_t* out) {
   return SM_OK;
 }
 
+#endif
+
+#ifdef SM_OPERAND_F16
+int sm_conv3x3_patch_f16(const sm_conv_desc* d, const void* x, const void* w_patch, const float* bias, void* y,
+                         unsigned long long* gn_stats, hipStream_t s) {
+  if (!x || !w_patch || !y) return SM_ERR_BAD_ARG;
+  const int rc = patch_check(d);
+  if (rc != SM_OK) return rc;
+  if (!(d->flags & SM_CONV_OUT_F32)) return SM_ERR_UNSUPPORTED;       // binary16 operands: f32 output only
+#else
 extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void* w_patch, const float* bias, void* y,
                                 int64_t* gn_stats_fix, sm_stream_t stream) {
   if (!x || !w_patch || !y) return SM_ERR_BAD_ARG;
   unsigned long long* gn_stats = reinterpret_cast<unsigned long long*>(gn_stats_fix);
   const int rc = patch_check(d);
   if (rc != SM_OK) return rc;
-  if (gn_stats != nullptr && (d->flags & SM_CONV_OUT_F32)) return SM_ERR_UNSUPPORTED;
+  hipStream_t s = sm_hip_stream(stream);
+  if (d->flags & SM_CONV_F16) return sm_conv3x3_patch_f16(d, x, w_patch, bias, y, gn_stats, s);
+#endif
   PatchShape ps;
   plan_shape(d, &ps);
   PatchArgs a;
@@ -694,6 +727,7 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   a.Kp = 9ll * d->cin;
   a.flags = d->flags;
   a.scale_nch = d->scale_nch;
+  a.acc_scale = (d->acc_scale == 0.f) ? 1.f : d->acc_scale;
   a.prow_cap = (PT_BPOS + 2 * (maxw + 2) + 2 + 15) / 16 * 16;
   a.ngroups = d->ngroups > 1 ? d->ngroups : 1;
   a.tpg[0] = t0 * a.ntn > 0 ? t0 * a.ntn : 1;
@@ -707,7 +741,6 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   if (nb0 != ps.nbig || nb1 != ps.nsmall) return SM_ERR_BAD_SHAPE;       // planner / table mismatch: a bug, not a shape
   a.nblk[0] = (int)nb0;
   a.nblk[1] = (int)nb1;
-  hipStream_t s = sm_hip_stream(stream);
   if (gn_stats != nullptr) {
     if (hipMemsetAsync(gn_stats, 0, sizeof(unsigned long long) * 2 * a.ngroups * d->batch * d->nlev * (d->cout / 8), s) != hipSuccess)
       return SM_ERR_LAUNCH;
@@ -746,7 +779,10 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
     lrc = ps.small == 128 ? launch(conv3x3_patch_kernel<128, V>) : launch(conv3x3_patch_kernel<192, V>);            \
     break;
   switch (var) {
-    PT_CASE(0) PT_CASE(1) PT_CASE(2) PT_CASE(3) PT_CASE(4) PT_CASE(8) PT_CASE(16) PT_CASE(20) PT_CASE(24)
+    PT_CASE(0)
+#ifdef SM_EXPERIMENTS
+    PT_CASE(1) PT_CASE(2) PT_CASE(3) PT_CASE(4) PT_CASE(8) PT_CASE(16) PT_CASE(20) PT_CASE(24)
+#endif
     default: break;
   }
 #undef PT_CASE

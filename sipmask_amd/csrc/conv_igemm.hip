@@ -16,11 +16,31 @@
 #include <utility>
 
 #include "common.h"
+#include "experiments.h"
 
+// conv_igemm_f16.o (this file compiled with -DSM_OPERAND_F16)
+int sm_conv_igemm_f16(const sm_conv_desc* d, const void* x, const void* w, const float* bias, void* y, hipStream_t stream,
+                      unsigned long long* gn_stats, void* workspace, long long workspace_bytes);
 // deform_patch.hip
 bool sm_deform_patch_supported(const sm_conv_desc* d);
 int sm_deform_patch_launch(const sm_conv_desc* d, const void* x, const float* offset, const void* w, const float* bias,
                            void* y, hipStream_t stream, unsigned long long* gn_stats, long long k_padded);
+
+// Operand type of this translation unit.  conv_igemm.hip is compiled TWICE (csrc/Makefile): as is -- bf16 operands,
+// v_mfma_f32_32x32x16_bf16 -- and with -DSM_OPERAND_F16 into conv_igemm_f16.o -- IEEE binary16 operands on
+// v_mfma_f32_32x32x16_f16, the kernels behind SM_CONV_F16 (the split-precision head plan, include/sipmask_hip.h).  The
+// operands are 16-bit payloads that the LDS-DMA loader never interprets, so the two builds differ in the MFMA
+// instruction only; the f16 build carries the LDS-DMA kernels with f32 output and nothing else (no deformable gather,
+// no input ReLU, no bf16 residual / output) and exports one C++ entry point instead of the C ABI.
+#ifdef SM_OPERAND_F16
+typedef _Float16 frag8 __attribute__((ext_vector_type(8)));
+#define SM_MFMA_32x32x16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16((A), (B), (C), 0, 0, 0)
+#else
+typedef bf16x8 frag8;
+#define SM_MFMA_32x32x16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
+#endif
+
+extern "C" int sm_conv_cout_tile(int cout);
 
 namespace {
 
@@ -42,6 +62,7 @@ struct ConvKArgs {
   unsigned flags;
   int scale_nch;
   float level_scale[SM_MAX_LEVELS];
+  float acc_scale;   // accumulators are multiplied by this before bias / Scale (1 = none; sm_conv_desc.acc_scale)
   int dg, cpg8;  // deform groups, chunks (of 8 ch) per deform group
   unsigned long long* gn_stats;  // optional fused GroupNorm statistics [batch][nlev][cout/8][2] (sum, sum of squares), fixed point (common.h: gn_fix)
   long long w_bstride;  // elements between the weight matrices of consecutive images (0 = shared): batched / split-K GEMMs
@@ -470,13 +491,13 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   auto compute = [&](int buf) {
     const unsigned char* S = smem + buf * STAGE;
     if constexpr (FRAG_PIPE) {
-      bf16x8 wf[2][TCO], xf[2][TPOS];
+      frag8 wf[2][TCO], xf[2][TPOS];
       auto rd = [&](int kk, int set) {
         const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
 #pragma unroll
-        for (int t = 0; t < TCO; ++t) wf[set][t] = *reinterpret_cast<const bf16x8*>(S + wrow_off + t * 32 * 128 + slot);
+        for (int t = 0; t < TCO; ++t) wf[set][t] = *reinterpret_cast<const frag8*>(S + wrow_off + t * 32 * 128 + slot);
 #pragma unroll
-        for (int t = 0; t < TPOS; ++t) xf[set][t] = *reinterpret_cast<const bf16x8*>(S + xrow_off + t * 32 * 128 + slot);
+        for (int t = 0; t < TPOS; ++t) xf[set][t] = *reinterpret_cast<const frag8*>(S + xrow_off + t * 32 * 128 + slot);
       };
       rd(0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, TCO + TPOS, 0);
@@ -487,7 +508,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
         for (int tc = 0; tc < TCO; ++tc)
 #pragma unroll
           for (int tp = 0; tp < TPOS; ++tp)
-            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][tc], xf[kk & 1][tp], acc[tc][tp], 0, 0, 0);
+            acc[tc][tp] = SM_MFMA_32x32x16(wf[kk & 1][tc], xf[kk & 1][tp], acc[tc][tp]);
         // ladder: one fragment read of kk+1 behind each MFMA of kk
         constexpr int NFR = TCO + TPOS, NMF = TCO * TPOS, NPAIR = NFR < NMF ? NFR : NMF;
         if (kk < 3) {
@@ -506,16 +527,16 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
-      bf16x8 wf[TCO], xf[TPOS];
+      frag8 wf[TCO], xf[TPOS];
 #pragma unroll
-      for (int t = 0; t < TCO; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(S + wrow_off + t * 32 * 128 + slot);
+      for (int t = 0; t < TCO; ++t) wf[t] = *reinterpret_cast<const frag8*>(S + wrow_off + t * 32 * 128 + slot);
 #pragma unroll
-      for (int t = 0; t < TPOS; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(S + xrow_off + t * 32 * 128 + slot);
+      for (int t = 0; t < TPOS; ++t) xf[t] = *reinterpret_cast<const frag8*>(S + xrow_off + t * 32 * 128 + slot);
 #pragma unroll
       for (int tc = 0; tc < TCO; ++tc)
 #pragma unroll
         for (int tp = 0; tp < TPOS; ++tp)
-          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+          acc[tc][tp] = SM_MFMA_32x32x16(wf[tc], xf[tp], acc[tc][tp]);
     }
     }
   };
@@ -599,14 +620,14 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
       constexpr int NFR = TCO + TPOS, NMF = TCO * TPOS, NP = NW + NX;
       constexpr int DMA_EVERY = (2 * NMF) / NP > 0 ? (2 * NMF) / NP : 1;
       static_assert(!HAND_PLACED || NFR <= NMF, "one fragment read per MFMA slot");
-      bf16x8 wf[2][TCO], xf[2][TPOS];
+      frag8 wf[2][TCO], xf[2][TPOS];
       const bool kvalid = ld_kc < a.nchunk;
       const int dh = ld_kh * a.dil, dw = ld_kw * a.dil;
       const long long toff = (long long)((dh * W + dw) * a.in_cstride + ld_cc * 8);
       auto rd1 = [&](int kk, int set, int f) {                       // fragment f of sub-step kk -> register set
         const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
-        if (f < TCO) wf[set][f] = *reinterpret_cast<const bf16x8*>(S + wrow_off + f * 32 * 128 + slot);
-        else xf[set][f - TCO] = *reinterpret_cast<const bf16x8*>(S + xrow_off + (f - TCO) * 32 * 128 + slot);
+        if (f < TCO) wf[set][f] = *reinterpret_cast<const frag8*>(S + wrow_off + f * 32 * 128 + slot);
+        else xf[set][f - TCO] = *reinterpret_cast<const frag8*>(S + xrow_off + (f - TCO) * 32 * 128 + slot);
       };
       static_for<NFR>([&](auto F) { rd1(0, 0, decltype(F)::value); });
       __builtin_amdgcn_sched_barrier(0);
@@ -615,7 +636,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
         static_for<NMF>([&](auto MM) {
           constexpr int m = decltype(MM)::value;
           constexpr int tc = m / TPOS, tp = m % TPOS;
-          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][tc], xf[kk & 1][tp], acc[tc][tp], 0, 0, 0);
+          acc[tc][tp] = SM_MFMA_32x32x16(wf[kk & 1][tc], xf[kk & 1][tp], acc[tc][tp]);
           if constexpr (kk < 3 && m < NFR) rd1(kk + 1, (kk + 1) & 1, m);
           constexpr int slot_idx = kk * NMF + m;
           if constexpr (kk < 2 && (slot_idx % DMA_EVERY) == DMA_EVERY - 1 && slot_idx / DMA_EVERY < NP) {
@@ -841,6 +862,10 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
             v[e] = __uint_as_float(r[0]);
             v[4 + e] = __uint_as_float(r[1]);
           }
+          if (a.acc_scale != 1.f) {                 // block-uniform; the x3 plan's power-of-two weight scale, undone exactly
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= a.acc_scale;
+          }
           const int cl = wco * TCO * 32 + tc * 32 + 8 * (2 * qp + khalf);   // cout inside the tile
           const int c0 = nt * BCO + cl;
           const bool live = mvalid && c0 < a.cout;
@@ -952,10 +977,10 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
       for (int tp = 0; tp < TPOS; ++tp) {
         const int pl = wpos * TPOS * 32 + tp * 32 + l31;
         float4 v;
-        v.x = acc[tc][tp][4 * q + 0] + bv[0];
-        v.y = acc[tc][tp][4 * q + 1] + bv[1];
-        v.z = acc[tc][tp][4 * q + 2] + bv[2];
-        v.w = acc[tc][tp][4 * q + 3] + bv[3];
+        v.x = acc[tc][tp][4 * q + 0] * a.acc_scale + bv[0];
+        v.y = acc[tc][tp][4 * q + 1] * a.acc_scale + bv[1];
+        v.z = acc[tc][tp][4 * q + 2] * a.acc_scale + bv[2];
+        v.w = acc[tc][tp][4 * q + 3] * a.acc_scale + bv[3];
         if (c + 0 < a.scale_nch) v.x *= lscale;
         if (c + 1 < a.scale_nch) v.y *= lscale;
         if (c + 2 < a.scale_nch) v.z *= lscale;
@@ -1238,16 +1263,16 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
-      bf16x8 wf[TCO], xf[TPOS];
+      frag8 wf[TCO], xf[TPOS];
 #pragma unroll
-      for (int t = 0; t < TCO; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(S + wrow_off + t * 32 * 64 + slot);
+      for (int t = 0; t < TCO; ++t) wf[t] = *reinterpret_cast<const frag8*>(S + wrow_off + t * 32 * 64 + slot);
 #pragma unroll
-      for (int t = 0; t < TPOS; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(S + xrow_off + t * 32 * 64 + slot);
+      for (int t = 0; t < TPOS; ++t) xf[t] = *reinterpret_cast<const frag8*>(S + xrow_off + t * 32 * 64 + slot);
 #pragma unroll
       for (int tc = 0; tc < TCO; ++tc)
 #pragma unroll
         for (int tp = 0; tp < TPOS; ++tp)
-          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+          acc[tc][tp] = SM_MFMA_32x32x16(wf[tc], xf[tp], acc[tc][tp]);
     }
   };
 
@@ -1301,13 +1326,13 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
     };
     auto compute_p = [&](int buf) {
       const unsigned char* S = smem + buf * STAGE;
-      bf16x8 wf[2][TCO], xf[2][TPOS];
+      frag8 wf[2][TCO], xf[2][TPOS];
       auto rd = [&](int kk, int set) {
         const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
 #pragma unroll
-        for (int t = 0; t < TCO; ++t) wf[set][t] = *reinterpret_cast<const bf16x8*>(S + wrow_off + t * 32 * 64 + slot);
+        for (int t = 0; t < TCO; ++t) wf[set][t] = *reinterpret_cast<const frag8*>(S + wrow_off + t * 32 * 64 + slot);
 #pragma unroll
-        for (int t = 0; t < TPOS; ++t) xf[set][t] = *reinterpret_cast<const bf16x8*>(S + xrow_off + t * 32 * 64 + slot);
+        for (int t = 0; t < TPOS; ++t) xf[set][t] = *reinterpret_cast<const frag8*>(S + xrow_off + t * 32 * 64 + slot);
       };
       constexpr int NFR = TCO + TPOS, NMF = TCO * TPOS, NPAIR = NFR < NMF ? NFR : NMF;
       rd(0, 0);
@@ -1319,7 +1344,7 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
         for (int tc = 0; tc < TCO; ++tc)
 #pragma unroll
           for (int tp = 0; tp < TPOS; ++tp)
-            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][tc], xf[kk][tp], acc[tc][tp], 0, 0, 0);
+            acc[tc][tp] = SM_MFMA_32x32x16(wf[kk][tc], xf[kk][tp], acc[tc][tp]);
         if (kk == 0) {
 #pragma unroll
           for (int i = 0; i < NPAIR; ++i) {
@@ -1396,6 +1421,10 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
             v[e] = __uint_as_float(r[0]);       // lanes 0-31: own group 2qp      | lanes 32-63: lower half's group 2qp+1
             v[4 + e] = __uint_as_float(r[1]);   // lanes 0-31: upper's group 2qp  | lanes 32-63: own group 2qp+1
           }
+          if (a.acc_scale != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= a.acc_scale;
+          }
           const int c0 = nt * BCO + wco * TCO * 32 + tc * 32 + 8 * (2 * qp + khalf);
           if (m >= M || c0 >= a.cout) continue;
           if (a.bias != nullptr) {
@@ -1466,10 +1495,10 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
           for (int tp = 0; tp < TPOS; ++tp) {
             const int pl = wave_p0 % HROWS + tp * 32 + l31;
             float4 v;
-            v.x = acc[tc][tp][4 * q + 0] + bv[0];
-            v.y = acc[tc][tp][4 * q + 1] + bv[1];
-            v.z = acc[tc][tp][4 * q + 2] + bv[2];
-            v.w = acc[tc][tp][4 * q + 3] + bv[3];
+            v.x = acc[tc][tp][4 * q + 0] * a.acc_scale + bv[0];
+            v.y = acc[tc][tp][4 * q + 1] * a.acc_scale + bv[1];
+            v.z = acc[tc][tp][4 * q + 2] * a.acc_scale + bv[2];
+            v.w = acc[tc][tp][4 * q + 3] * a.acc_scale + bv[3];
             if (c + 0 < a.scale_nch) v.x *= lscale;
             if (c + 1 < a.scale_nch) v.y *= lscale;
             if (c + 2 < a.scale_nch) v.z *= lscale;
@@ -1557,6 +1586,7 @@ struct SplitKEpi {
   long long rows, part_rows, out_row0;
   int S, cout, cpad, out_cstride, out_coff, res_cstride;
   unsigned flags;
+  float acc_scale;
 };
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitKEpi e) {
@@ -1571,6 +1601,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitKEpi e) {
       const float4 a0 = *reinterpret_cast<const float4*>(q), a1 = *reinterpret_cast<const float4*>(q + 4);
       v[0] += a0.x, v[1] += a0.y, v[2] += a0.z, v[3] += a0.w;
       v[4] += a1.x, v[5] += a1.y, v[6] += a1.z, v[7] += a1.w;
+    }
+    if (e.acc_scale != 1.f) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] *= e.acc_scale;
     }
     if (e.bias != nullptr) {
       const float4 b0 = *reinterpret_cast<const float4*>(e.bias + c0), b1 = *reinterpret_cast<const float4*>(e.bias + c0 + 4);
@@ -1611,7 +1645,7 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p,
     if (d->deform_groups < 1 || d->cin % (8 * d->deform_groups) != 0) return SM_ERR_BAD_ARG;
     if (d->stride != 1) return SM_ERR_UNSUPPORTED;
   }
-  if (with_gn && (d->cout % 8 != 0 || (d->flags & SM_CONV_OUT_F32))) return SM_ERR_UNSUPPORTED;
+  if (with_gn && d->cout % 8 != 0) return SM_ERR_UNSUPPORTED;
   for (int l = 0; l < d->nlev; ++l) {
     if (d->out_h[l] < 1 || d->out_w[l] < 1 || d->in_h[l] < 1 || d->in_w[l] < 1) return SM_ERR_BAD_SHAPE;
     const int eh = (d->in_h[l] + 2 * d->pad - (d->dil * (d->kh - 1) + 1)) / d->stride + 1;
@@ -1762,6 +1796,15 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   if (prc == SM_OK && plan.split_k > 1 && workspace_bytes < plan.workspace_bytes)      // workspace too small: no split
     prc = plan_conv(d, DEFORM, gn_stats != nullptr, &plan, false);
   if (prc != SM_OK) return prc;
+#ifdef SM_OPERAND_F16
+  // the binary16 build: LDS-DMA kernels with f32 output only (what the x3 head plan launches)
+  if (DEFORM || !plan.lds_dma || !(d->flags & SM_CONV_OUT_F32) || (d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)))
+    return SM_ERR_UNSUPPORTED;
+#else
+  if (!DEFORM && (d->flags & SM_CONV_F16))          // same plan, same launch code, the other MFMA (conv_igemm_f16.o)
+    return sm_conv_igemm_f16(d, x, w, bias, y, stream, gn_stats, workspace, workspace_bytes);
+  if (d->flags & SM_CONV_F16) return SM_ERR_UNSUPPORTED;
+#endif
   if ((d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)) && !residual) return SM_ERR_BAD_ARG;
   const int tile = sm_conv_cout_tile(d->cout);
   const bool dma = plan.lds_dma != 0, k32 = plan.k_step == 32, ws = plan.warp_spec != 0;
@@ -1824,6 +1867,7 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   a.nk = a.Kp / 64;
   a.flags = d->flags;
   a.scale_nch = d->scale_nch;
+  a.acc_scale = (d->acc_scale == 0.f) ? 1.f : d->acc_scale;
   a.dg = DEFORM ? d->deform_groups : 1;
   a.cpg8 = DEFORM ? d->cin / (8 * d->deform_groups) : 1;
   const int S = plan.split_k > 1 ? plan.split_k : 1;
@@ -1842,15 +1886,15 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   dim3 grid((unsigned)nblk), block(256);
 #define SM_LAUNCH(KERNEL) hipLaunchKernelGGL((KERNEL), grid, block, 0, stream, a)
   if (!dma) {
+#ifndef SM_OPERAND_F16
     if (DEFORM && bco == 256) { block = dim3(512); SM_LAUNCH((conv_igemm_kernel<4, 2, 2, 2, DEFORM, false>)); }
     else if (tile == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, DEFORM, false>));
     else if (tile == 64) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 2, DEFORM, false>));
     else SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 2, DEFORM, false>));
+#endif
   } else if (k32) {
+#ifdef SM_EXPERIMENTS
     const bool o3 = opt == 3;
-    // residual prefetch: same-row residual + the register epilogue's alignment conditions (the kernel's reg_epi test)
-    const bool respf = (d->flags & SM_CONV_DBG_RES_PREFETCH) && (d->flags & SM_CONV_RES_ADD) && !(d->flags & SM_CONV_DBG_LDS_EPILOGUE) &&
-                       (d->cout & 7) == 0 && (d->out_cstride & 7) == 0 && (d->out_coff & 7) == 0 && (d->res_cstride & 7) == 0;
     if (o3 && bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2, 4, 3>));
     else if (o3 && bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1, 4, 3>));
     else if (o3 && bco == 64 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 2, 4, 3>));
@@ -1859,38 +1903,43 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else if (o3 && bco == 32 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 2, 4, 3>));
     else if (o3 && bco == 32) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 1, 4, 3>));
     else if (bco == 128 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 4, 2>));
-    else if (respf && bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2, 4, 0, true>));
-    else if (respf && bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1, 4, 0, true>));
-    else if (bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2>));
+    else
+#endif
+    if (bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2>));
     else if (bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1>));
     else if (bco == 64 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 2>));
     else if (bco == 64 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 1>));
     else if (bco == 64 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 1, 1>));
     else if (bco == 32 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 2>));
-    else SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 1>));
+    else if (bco == 32) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 1>));
+    else return SM_ERR_UNSUPPORTED;
   } else if constexpr (!DEFORM) {
+#ifdef SM_EXPERIMENTS
     if (ws) block = dim3(512);
     if (ws && bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 1>));
     else if (ws && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 1>));
     else if (ws && bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true, 1>));
     else if (ws) return SM_ERR_UNSUPPORTED;
-    else if (bco == 256 && (d->flags & SM_CONV_DBG_HAND_PLACED)) { block = dim3(512); SM_LAUNCH((conv_igemm_kernel<2, 4, 4, 2, false, true, 0, 7>)); }
+    else if (opt == 1 && bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 0, 1>));
+    else if (opt == 1 && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 0, 1>));
+    else if (opt == 1 && bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true, 0, 1>));
+    else if (bco == 128 && bpos == 256) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 4, false, true>));
+    else
+#endif
+    if (bco == 256 && (d->flags & SM_CONV_DBG_HAND_PLACED)) { block = dim3(512); SM_LAUNCH((conv_igemm_kernel<2, 4, 4, 2, false, true, 0, 7>)); }
     else if (bco == 256) { block = dim3(512); SM_LAUNCH((conv_igemm_kernel<2, 4, 4, 2, false, true, 0, 3>)); }
     else if (opt == 3 && bco == 128 && bpos == 128 && (d->flags & SM_CONV_DBG_HAND_PLACED)) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 0, 7>));
     else if (opt == 3 && bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 0, 3>));
     else if (opt == 3 && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 0, 3>));
     else if (opt == 3 && bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true, 0, 3>));
-    else if (opt == 1 && bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true, 0, 1>));
-    else if (opt == 1 && bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true, 0, 1>));
-    else if (opt == 1 && bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true, 0, 1>));
-    else if (bco == 128 && bpos == 256) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 4, false, true>));
-    else if (bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true>));
-    else if (bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true>));
+    else if (bco == 128 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, false, true>));          // (cin < 64: the loop with the
+    else if (bco == 128 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 1, false, true>));           //  division path in its loader)
     else if (bco == 64 && bpos == 256) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 2, false, true>));
     else if (bco == 64 && bpos == 128) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 1, false, true>));
     else if (bco == 64 && bpos == 64) SM_LAUNCH((conv_igemm_kernel<2, 2, 1, 1, false, true>));
     else if (bco == 32 && bpos == 256) SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 2, false, true>));
-    else SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 1, false, true>));
+    else if (bco == 32) SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 1, false, true>));
+    else return SM_ERR_UNSUPPORTED;
   }
 #undef SM_LAUNCH
   if (S > 1) {
@@ -1909,6 +1958,7 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     e.out_coff = d->out_coff;
     e.res_cstride = d->res_cstride;
     e.flags = d->flags;
+    e.acc_scale = a.acc_scale;
     const long long items = e.rows * (d->cout >> 3);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256)), dim3(256), 0,
                        stream, e);
@@ -1919,6 +1969,13 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
 
 }  // namespace
 
+#ifdef SM_OPERAND_F16
+// the binary16 build's only external symbol (C++ linkage, called from the bf16 build's launch_conv)
+int sm_conv_igemm_f16(const sm_conv_desc* d, const void* x, const void* w, const float* bias, void* y, hipStream_t stream,
+                      unsigned long long* gn_stats, void* workspace, long long workspace_bytes) {
+  return launch_conv<false>(d, x, nullptr, w, bias, nullptr, y, stream, gn_stats, workspace, workspace_bytes);
+}
+#else
 extern "C" int sm_conv_cout_tile(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
 
 extern "C" int sm_conv_plan_query(const sm_conv_desc* d, int deformable, int with_gn_stats, sm_conv_plan* out) {
@@ -1949,3 +2006,4 @@ extern "C" int sm_deform_conv2d(const sm_conv_desc* d, const void* x, const floa
                                 const float* bias, void* y, sm_stream_t stream) {
   return launch_conv<true>(d, x, offset, w, bias, nullptr, y, sm_hip_stream(stream));
 }
+#endif  // !SM_OPERAND_F16

@@ -75,8 +75,9 @@ __device__ __forceinline__ int dp_xcd_tile(int b, int nblk) {
   return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
 }
 
-// ABL: ablations for the micro-benchmark (wrong results by construction; SIPMASK_DEFORM_ABLATE=n, never set by the
-// library's callers): 2 no blend (the raw corners are the operand), 4 no DMA in the K loop
+// ABL: ablations for the micro-benchmark (wrong results by construction): 2 no blend (the raw corners are the operand),
+// 4 no DMA in the K loop.  Instantiated only by `make EXPERIMENTS=1` (then selected by SIPMASK_DEFORM_ABLATE=n);
+// the default library contains deform_patch_kernel<0> alone.
 template <int ABL>
 __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const DeformPatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [W stage 0][W stage 1][patch]
@@ -485,10 +486,12 @@ int sm_deform_patch_launch(const sm_conv_desc* d, const void* x, const float* of
   (void)hipGetDevice(&dev);
   bool done = false;
   for (int i = 0; i < nattr; ++i) done = done || attr_dev[i] == dev;
-  static const int ablate = getenv("SIPMASK_DEFORM_ABLATE") ? atoi(getenv("SIPMASK_DEFORM_ABLATE")) : 0;
   const void* kern = (const void*)deform_patch_kernel<0>;
+#ifdef SM_EXPERIMENTS
+  static const int ablate = getenv("SIPMASK_DEFORM_ABLATE") ? atoi(getenv("SIPMASK_DEFORM_ABLATE")) : 0;
   if (ablate == 2) kern = (const void*)deform_patch_kernel<2>;
   if (ablate == 4) kern = (const void*)deform_patch_kernel<4>;
+#endif
   if (!done) {
     if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS) != hipSuccess) return SM_ERR_LAUNCH;
     if (nattr < 16) attr_dev[nattr++] = dev;

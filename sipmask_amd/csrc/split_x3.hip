@@ -1,0 +1,242 @@
+// Elementwise kernels of the split-precision ("x3") head plan (include/sipmask_hip.h: SM_CONV_F16).
+//
+// The reference head is fp32 end to end (M/mmdet/models/anchor_heads/sipmask_head.py:241-287,609-633); the bf16 plan's
+// operand rounding (2^-9 per element) is what separates its mask logits from the reference's by ~1.5.  The x3 plan keeps
+// every head activation in f32 between layers and feeds the MFMA convolutions with TWO binary16 halves per value,
+//     v  =  hi + lo,   hi = f16(v),   lo = f16(v - hi)          (11 + 11 mantissa bits; v - hi is exact in f32)
+// laid out along the channel axis as [hi | lo | hi] (3*C channels) against weights [hi | hi | lo]: one ordinary convolution
+// over 3*C channels is then  x_hi*w_hi + x_lo*w_hi + x_hi*w_lo  accumulated in f32 by the MFMA -- the product to ~2^-21,
+// the dropped lo*lo term is 2^-22.  (bf16 halves give 8 + 8 bits: tools/x3_emulate.py measures 1.0e-3 on the mask logits
+// with them, 7.8e-5 with binary16.)  These kernels produce that layout:
+//   sm_split3_f16          f32 or bf16 rows -> [hi | lo | hi] rows (a channel slice of a wider destination: the mask branch's
+//                          concatenation writes three sources into one)
+//   sm_gn_stats_f32_fix    GroupNorm statistics of f32 rows as fixed-point sums (common.h: gn_fix; one POSITION's 8
+//                          channels per rounding, integer accumulation: order- and tiling-independent)
+//   sm_groupnorm_apply_x3  normalise (+ReLU) f32 rows with such statistics -> f32 rows and / or [hi | lo | hi] rows
+// Values beyond binary16's range (|v| > 65504) saturate; activations of a working detector are orders of magnitude below.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float c = fminf(fmaxf(v[e], -65504.f), 65504.f);
+    const _Float16 h = (_Float16)c;                 // v_cvt_f16_f32, round to nearest even
+    hi[e] = h;
+    lo[e] = (_Float16)(c - (float)h);               // exact difference (<= 13 significant bits), then one rounding
+  }
+}
+
+struct SplitArgs {
+  const void* x;
+  uint16_t* y;
+  long long rows;
+  int c8;          // 8-channel chunks per source row
+  int in_cs;       // source row stride (elements)
+  int out_cs;      // destination row stride (elements) = 3 * ctot
+  int ctot, coff;  // channels of one third of the destination row, first channel of this source inside it
+};
+
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void split3_kernel(const SplitArgs a) {
+  const long long total = a.rows * a.c8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / a.c8;
+    const int c = (int)(i - r * a.c8) * 8;
+    float v[8];
+    if constexpr (IN_F32) {
+      const float* p = (const float*)a.x + r * a.in_cs + c;
+      const float4 q0 = *reinterpret_cast<const float4*>(p), q1 = *reinterpret_cast<const float4*>(p + 4);
+      v[0] = q0.x, v[1] = q0.y, v[2] = q0.z, v[3] = q0.w, v[4] = q1.x, v[5] = q1.y, v[6] = q1.z, v[7] = q1.w;
+    } else {
+      unpack_bf16x8(*reinterpret_cast<const uint4*>((const uint16_t*)a.x + r * a.in_cs + c), v);
+    }
+    half8 hi, lo;
+    split8(v, hi, lo);
+    uint16_t* o = a.y + r * a.out_cs + a.coff + c;
+    *reinterpret_cast<half8*>(o) = hi;
+    *reinterpret_cast<half8*>(o + a.ctot) = lo;
+    *reinterpret_cast<half8*>(o + 2 * a.ctot) = hi;
+  }
+}
+
+struct GnxArgs {
+  int nlev, batch, C, groups, cpg;
+  int hw[SM_MAX_LEVELS];
+  long long row0[SM_MAX_LEVELS];
+  int blk0[SM_MAX_LEVELS + 1];
+  float eps;
+  int relu, rpb;
+};
+
+__device__ __forceinline__ int gnx_level(const GnxArgs& a) {
+  int lev = 0;
+#pragma unroll
+  for (int l = 1; l < SM_MAX_LEVELS; ++l)
+    if (l < a.nlev && (int)blockIdx.x >= a.blk0[l]) lev = l;
+  return lev;
+}
+
+// thread = one 8-channel chunk column (inside one group) of the block's rows
+__global__ __launch_bounds__(256) void gnx_stats_kernel(const float* __restrict__ x, unsigned long long* __restrict__ stats,
+                                                        const GnxArgs a) {
+  const int n = blockIdx.y, lev = gnx_level(a);
+  const int rb = (blockIdx.x - a.blk0[lev]) * a.rpb, HW = a.hw[lev];
+  const int c8 = a.C / 8, lanes = 256 / c8;
+  const int cc = threadIdx.x % c8, rr = threadIdx.x / c8;
+  const float* base = x + (a.row0[lev] + (long long)n * HW) * a.C;
+  unsigned long long s = 0ull, ss = 0ull;
+  if (rr < lanes) {
+    const int rend = min(rb + a.rpb, HW);
+    for (int r = rb + rr; r < rend; r += lanes) {
+      const float* p = base + (long long)r * a.C + cc * 8;
+      const float4 q0 = *reinterpret_cast<const float4*>(p), q1 = *reinterpret_cast<const float4*>(p + 4);
+      const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+      float ps = 0.f, pss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ps += v[e];
+        pss += v[e] * v[e];
+      }
+      s += gn_fix(ps);               // one position's 8 channels per rounding: the conv epilogues' unit (conv_igemm.hip)
+      ss += gn_fix(pss);
+    }
+  }
+  __shared__ unsigned long long sh[2][256];
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = ss;
+  __syncthreads();
+  const int cpg8 = a.cpg / 8;
+  if ((int)threadIdx.x < a.groups) {
+    const int g = threadIdx.x;
+    unsigned long long ts = 0ull, tss = 0ull;
+    for (int r = 0; r < lanes; ++r)
+      for (int k = 0; k < cpg8; ++k) {
+        ts += sh[0][r * c8 + g * cpg8 + k];
+        tss += sh[1][r * c8 + g * cpg8 + k];
+      }
+    unsigned long long* st = stats + (((long long)n * a.nlev + lev) * a.groups + g) * 2;
+    atomicAdd(st, ts);
+    atomicAdd(st + 1, tss);
+  }
+}
+
+__global__ __launch_bounds__(256) void gnx_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        const unsigned long long* __restrict__ stats, float* __restrict__ y32,
+                                                        uint16_t* __restrict__ y3, const GnxArgs a) {
+  const int n = blockIdx.y, lev = gnx_level(a);
+  const int rb = (blockIdx.x - a.blk0[lev]) * a.rpb, HW = a.hw[lev];
+  const int c8 = a.C / 8, lanes = 256 / c8;
+  const int cc = threadIdx.x % c8, rr = threadIdx.x / c8;
+  if (rr >= lanes) return;
+  const int g = (cc * 8) / a.cpg;
+  float mean, rstd;
+  gn_mean_rstd(stats + (((long long)n * a.nlev + lev) * a.groups + g) * 2, (double)HW * (double)a.cpg, a.eps, &mean, &rstd);
+  float sc[8], sf[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float ga = gamma[cc * 8 + e] * rstd;
+    sc[e] = ga;
+    sf[e] = beta[cc * 8 + e] - mean * ga;
+  }
+  const long long row00 = a.row0[lev] + (long long)n * HW;
+  const int rend = min(rb + a.rpb, HW);
+  for (int r = rb + rr; r < rend; r += lanes) {
+    const long long row = row00 + r;
+    const float* p = x + row * a.C + cc * 8;
+    const float4 q0 = *reinterpret_cast<const float4*>(p), q1 = *reinterpret_cast<const float4*>(p + 4);
+    float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = v[e] * sc[e] + sf[e];
+      v[e] = a.relu ? fmaxf(t, 0.f) : t;
+    }
+    if (y32 != nullptr) {
+      float* o = y32 + row * a.C + cc * 8;
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    if (y3 != nullptr) {
+      half8 hi, lo;
+      split8(v, hi, lo);
+      uint16_t* o = y3 + row * (3ll * a.C) + cc * 8;
+      *reinterpret_cast<half8*>(o) = hi;
+      *reinterpret_cast<half8*>(o + a.C) = lo;
+      *reinterpret_cast<half8*>(o + 2 * a.C) = hi;
+    }
+  }
+}
+
+int gnx_fill(GnxArgs& a, int& t, int batch, int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups,
+             float eps, int relu) {
+  if (nlev < 1 || nlev > SM_MAX_LEVELS || batch < 1 || groups < 1 || groups > 256) return SM_ERR_BAD_SHAPE;
+  if (channels % (8 * groups) != 0 || channels > 2048 || 256 % (channels / 8) != 0) return SM_ERR_BAD_SHAPE;
+  a.nlev = nlev, a.batch = batch, a.C = channels, a.groups = groups, a.cpg = channels / groups;
+  a.eps = eps, a.relu = relu;
+  long long blocks = 0;
+  for (int l = 0; l < nlev; ++l) blocks += (long long)batch * sm_cdiv(hw[l], 256);
+  a.rpb = blocks < 512 ? 32 : (blocks < 1024 ? 64 : 256);          // short blocks for small tensors (>= ~4 blocks per CU)
+  t = 0;
+  for (int l = 0; l < SM_MAX_LEVELS; ++l) {
+    a.hw[l] = l < nlev ? hw[l] : 0;
+    a.row0[l] = l < nlev ? row0[l] : 0;
+    a.blk0[l] = t;
+    if (l < nlev) t += sm_cdiv(hw[l], a.rpb);
+  }
+  a.blk0[SM_MAX_LEVELS] = t;
+  return SM_OK;
+}
+
+}  // namespace
+
+extern "C" int sm_split3_f16(const void* x, int x_is_f32, int64_t rows, int channels, int in_cstride, void* y,
+                             int ctot, int coff, sm_stream_t stream) {
+  if (!x || !y) return SM_ERR_BAD_ARG;
+  if (rows < 1 || channels < 8 || channels % 8 || in_cstride % 8 || in_cstride < channels || ctot % 8 || coff % 8 ||
+      coff + channels > ctot)
+    return SM_ERR_BAD_SHAPE;
+  SplitArgs a;
+  a.x = x, a.y = (uint16_t*)y, a.rows = rows, a.c8 = channels / 8, a.in_cs = in_cstride, a.out_cs = 3 * ctot;
+  a.ctot = ctot, a.coff = coff;
+  const long long n = rows * a.c8;
+  long long g = (n + 255) / 256;
+  if (g > 256 * 32) g = 256 * 32;
+  if (x_is_f32)
+    hipLaunchKernelGGL(split3_kernel<true>, dim3((unsigned)g), dim3(256), 0, sm_hip_stream(stream), a);
+  else
+    hipLaunchKernelGGL(split3_kernel<false>, dim3((unsigned)g), dim3(256), 0, sm_hip_stream(stream), a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_gn_stats_f32_fix(const float* x, int64_t* stats, int batch, int nlev, const int32_t* hw,
+                                   const int64_t* row0, int channels, int groups, sm_stream_t stream) {
+  if (!x || !stats || !hw || !row0) return SM_ERR_BAD_ARG;
+  GnxArgs a;
+  int t;
+  const int rc = gnx_fill(a, t, batch, nlev, hw, row0, channels, groups, 0.f, 0);
+  if (rc != SM_OK) return rc;
+  hipStream_t s = sm_hip_stream(stream);
+  if (hipMemsetAsync(stats, 0, sizeof(unsigned long long) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
+  hipLaunchKernelGGL(gnx_stats_kernel, dim3(t, batch), dim3(256), 0, s, x, reinterpret_cast<unsigned long long*>(stats), a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_groupnorm_apply_x3(const float* x, const float* gamma, const float* beta, const int64_t* stats, int batch,
+                                     int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups, float eps,
+                                     int relu, float* y_f32, void* y_split, sm_stream_t stream) {
+  if (!x || !gamma || !beta || !stats || !hw || !row0 || (!y_f32 && !y_split)) return SM_ERR_BAD_ARG;
+  GnxArgs a;
+  int t;
+  const int rc = gnx_fill(a, t, batch, nlev, hw, row0, channels, groups, eps, relu);
+  if (rc != SM_OK) return rc;
+  hipLaunchKernelGGL(gnx_apply_kernel, dim3(t, batch), dim3(256), 0, sm_hip_stream(stream), x, gamma, beta,
+                     reinterpret_cast<const unsigned long long*>(stats), y_f32, (uint16_t*)y_split, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

@@ -47,18 +47,16 @@ class GradBucketer:
         if cur:
             self._close(cur)
         self._where = {}                  # id(param) -> (bucket index, slot): tensors must not be compared with ==
-        self._by_ptr = {}                 # parameter data_ptr -> parameter (the gradient sink reports pointers)
         for bi, b in enumerate(self.buckets):
             for i, p in enumerate(b["params"]):
                 self._where[id(p)] = (bi, i)
-                self._by_ptr[p.data_ptr()] = p
         self._next = 0                    # first bucket whose all-reduce has not been launched this step
         self._seen = set()                # parameters whose gradient has been counted this step
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         if self.params and self.params[0].is_cuda:
             from . import hip_ops as H
             H.GRAD_SINK.attach({p.data_ptr(): p._sm_grad_view for p in self.params
-                                if p.dtype == torch.float32 and p.is_contiguous()}, self._on_direct)
+                                if p.dtype == torch.float32 and p.is_contiguous()})
 
     def _close(self, ps):
         n = sum(p.numel() for p in ps)
@@ -89,33 +87,26 @@ class GradBucketer:
                 b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._next += 1
 
-    def _count(self, p):
+    def _on_grad(self, p):
+        """post-accumulate hook = "this parameter's gradient is final for this step".  The engine runs a leaf's
+        AccumulateGrad node once per backward, after EVERY op that uses the leaf has run -- also when those ops wrote the
+        gradient straight into the view and handed autograd `None` (the hook fires for an undefined gradient as well; torch
+        2.10) -- so readiness is counted here and nowhere else.  If something reset `.grad` to None meanwhile, autograd
+        installed a fresh tensor: it is folded back into the view."""
         bi, i = self._where[id(p)]
         b = self.buckets[bi]
+        v = b["views"][i]
+        if p.grad is None:
+            p.grad = v
+        elif p.grad is not v and p.grad.data_ptr() != v.data_ptr():
+            v.add_(p.grad.reshape(v.shape))
+            p.grad = v
         if id(p) in self._seen:
-            if bi < self._next:
-                raise RuntimeError("GradBucketer: a second gradient contribution arrived for a parameter whose bucket is "
-                                   "already being all-reduced (a parameter used by more than one backward op must not be "
-                                   "written directly: re-create the bucketer so that the use census runs again)")
             return
         self._seen.add(id(p))
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch_ready()
-
-    def _on_grad(self, p):
-        """post-accumulate hook: autograd has added (in place) into the bucket view -- or, if something reset `.grad` to
-        None meanwhile, installed a fresh tensor, which is folded back into the view here"""
-        bi, i = self._where[id(p)]
-        v = self.buckets[bi]["views"][i]
-        if p.grad is not v and p.grad.data_ptr() != v.data_ptr():
-            v.add_(p.grad.reshape(v.shape))
-            p.grad = v
-        self._count(p)
-
-    def _on_direct(self, ptr):
-        """a HIP kernel wrote this parameter's gradient straight into its view (hip_ops.GRAD_SINK.commit)"""
-        self._count(self._by_ptr[ptr])
 
     def finish(self):
         """Wait for every bucket and turn sums into means, in place.  Parameters that received no gradient this step

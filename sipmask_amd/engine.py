@@ -41,7 +41,7 @@ _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"
 
 
 def _lib_flag(name):
-    return {"SM_CONV_DBG_TILE256": 0x00400000, "SM_CONV_DBG_HAND_PLACED": 0x00040000}[name]
+    return getattr(_lib, name)
 BF16 = torch.bfloat16
 
 
@@ -58,42 +58,57 @@ def fold_bn(w, sd, p, eps=1e-5):
 
 
 class _Conv:
-    """One prepared conv launch."""
+    """One prepared conv launch.  mode: "bf16" (bf16 operands, the throughput kernels), "f32" (exact-f32 MFMA kernel,
+    csrc/conv_f32.hip) or "x3" (split-precision: binary16 halves [hi | lo | hi] of f32 activations against weights
+    [hi | hi | lo] on the bf16 plan's own kernels with the f16 MFMA, SM_CONV_F16 -- `x` is then the 3*ci-channel split
+    tensor, `y` f32).  Default: the plan's precision ("f32" plan -> "f32", else "bf16")."""
 
     def __init__(self, eng, name, w, bias, batch, in_sizes, in_row0, x, in_cstride, stride, pad, y, out_row0,
                  out_cstride, out_coff=0, flags=0, cin_pad=None, residual=None, res_cstride=0, res_sizes=None,
-                 res_row0=None, scale_nch=0, level_scale=None, deform_groups=0, offset=None):
+                 res_row0=None, scale_nch=0, level_scale=None, deform_groups=0, offset=None, mode=None):
         dev = eng.device
         co, ci, k, _ = w.shape
         cin = cin_pad or ci
         self.name = name
+        self.mode = mode or ("f32" if getattr(eng, "precision", "bf16") == "f32" else "bf16")
         # exact-f32 plan (parity mode): f32 operands on v_mfma_f32_32x32x2_f32, every conv output f32
-        self.f32 = getattr(eng, "precision", "bf16") == "f32"
+        self.f32 = self.mode == "f32"
+        self.x3 = self.mode == "x3"
+        acc_scale = 0.0
         if self.f32:
             cin = cin_pad = ci if ci % 4 == 0 else (ci + 3) // 4 * 4
             self.w, co_pad = H.prep_conv_weight_f32(w.to(dev), cin)
+        elif self.x3:
+            if offset is not None or residual is not None or cin_pad is not None or ci % 8 != 0:
+                raise NotImplementedError("x3 convs: plain convolutions over 8-aligned channel counts")
+            cin = 3 * ci
+            assert in_cstride == cin, "x3 convs read the [hi | lo | hi] split tensor (3 * cin channels)"
+            self.x3_scale = getattr(self, "_x3_scale", None) or H.x3_weight_scale([w])
+            self.w, co_pad = H.prep_conv_weight_x3(w.to(dev), self.x3_scale)
+            flags |= _lib.SM_CONV_F16 | SM_CONV_OUT_F32
+            acc_scale = 1.0 / self.x3_scale
         else:
             self.w, co_pad = H.prep_conv_weight(w.to(dev), cin)
         self.bias = None if bias is None else bias.float().to(dev).contiguous()
         out_sizes = [(_conv_out(h, k, stride, pad), _conv_out(ww, k, stride, pad)) for h, ww in in_sizes]
         self.out_sizes = out_sizes
-        flags |= _DEBUG_CONV_FLAGS          # A/B switches of include/sipmask_hip.h for whole-plan experiments
+        flags |= _DEBUG_CONV_FLAGS          # plan selectors of include/sipmask_hip.h for whole-plan experiments
         self.desc = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, co_pad, k, stride, pad,
                                      in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
-                                     scale_nch, level_scale, deform_groups)
+                                     scale_nch, level_scale, deform_groups, acc_scale=acc_scale)
         self.x, self.y, self.residual, self.offset = x, y, residual, offset
         self.gn_stats = None      # set -> GroupNorm statistics of y are accumulated in the conv epilogue
         # large 3x3 / stride-1 convs run on the patch-resident kernel (csrc/conv3x3_patch.hip): own weight layout, cout
         # padded to 256.  `groups` launches of this shape share one grid (tower pairs): the tile rule sees all of them.
         self.patch = False
         if (not self.f32 and offset is None and residual is None and _PATCH_CONV and k == 3 and stride == 1 and pad == 1
-                and ci % 64 == 0 and cin == ci):
+                and ci % 64 == 0 and (cin == ci or self.x3)):
             dp = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, (co + 255) // 256 * 256, k, stride,
                                   pad, in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
-                                  scale_nch, level_scale, deform_groups)
+                                  scale_nch, level_scale, deform_groups, acc_scale=acc_scale)
             if H.conv3x3_patch_supported(dp):
                 if getattr(eng, "patch_uniform", False):
-                    dp.flags |= 0x4000                               # SM_CONV_DBG_PATCH_UNIFORM
+                    dp.flags |= _lib.SM_CONV_DBG_PATCH_UNIFORM
                 dp.ngroups = getattr(self, "_patch_groups", 1)       # the launch shape depends on every group's tiles
                 pl = H.conv3x3_patch_plan(dp)
                 dp.ngroups = 1
@@ -105,7 +120,8 @@ class _Conv:
                 if (pl["work"] >= _PATCH_MIN_WORK and (pl["fill"] >= _PATCH_MIN_FILL or pl["makespan"] <= 1.0)
                         and co * 4 >= 3 * ((co + 255) // 256 * 256)):
                     self.patch = True
-                    self.w, _ = H.prep_conv_weight_patch(w.to(dev))
+                    self.w, _ = (H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale) if self.x3
+                                 else H.prep_conv_weight_patch(w.to(dev)))
                     self.desc = dp
         # split-K workspace (own buffer per conv: launches on different lanes may run concurrently); sized by the
         # library's plan, allocated once at build -- 288 GB of HBM
@@ -114,7 +130,9 @@ class _Conv:
             pl = H.conv_plan(self.desc)
             if pl["split_k"] > 1:
                 self.ws = torch.empty(pl["workspace_bytes"], dtype=torch.uint8, device=dev)
+        kin = 3 if self.x3 else 1                                   # MFMA work: three half products per element product
         self.flops = 2.0 * sum(batch * h * ww for h, ww in out_sizes) * co * ci * k * k
+        self.mfma_flops = self.flops * kin
         # algorithmic HBM bytes: x read once + y written once (+ residual read) + weights
         in_rows = sum(batch * h * ww for h, ww in in_sizes)
         out_rows = sum(batch * h * ww for h, ww in out_sizes)
@@ -171,14 +189,20 @@ class _GroupedConv(_Conv):
     [G][batch][nlev][cout/8][2].  Used for the cls / reg tower convs of one depth (sipmask_head.py:252-257)."""
 
     def __init__(self, eng, name, ws, biases, batch, in_sizes, in_row0, x, x_group_rows, in_cstride, y, y_group_rows,
-                 out_row0, out_cstride, flags=0):
+                 out_row0, out_cstride, flags=0, mode=None):
         G = len(ws)
         self._patch_groups = G
+        if mode == "x3":
+            self._x3_scale = H.x3_weight_scale(ws)              # one accumulator scale per launch: shared by the groups
         _Conv.__init__(self, eng, name, ws[0], biases[0], batch, in_sizes, in_row0, x, in_cstride, 1, 1, y, out_row0,
-                       out_cstride, flags=flags)
+                       out_cstride, flags=flags, mode=mode)
         dev = eng.device
-        prep = (lambda w: H.prep_conv_weight_patch(w.to(dev))[0]) if self.patch else \
-            (lambda w: H.prep_conv_weight(w.to(dev), in_cstride)[0])
+        if self.x3:
+            prep = (lambda w: H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale)[0]) if self.patch else \
+                (lambda w: H.prep_conv_weight_x3(w.to(dev), self.x3_scale)[0])
+        else:
+            prep = (lambda w: H.prep_conv_weight_patch(w.to(dev))[0]) if self.patch else \
+                (lambda w: H.prep_conv_weight(w.to(dev), in_cstride)[0])
         packed = [self.w] + [prep(w) for w in ws[1:]]
         assert all(p.shape == packed[0].shape for p in packed)
         self.w = torch.stack(packed).contiguous()
@@ -191,6 +215,7 @@ class _GroupedConv(_Conv):
         d.bias_group_stride = 0 if biases[0] is None else biases[0].numel()
         d.gn_group_stride = 2 * batch * len(in_sizes) * (ws[0].shape[0] // 8)
         self.flops *= G
+        self.mfma_flops *= G
         self.bytes = self.bytes * G - (0 if x_group_rows else (G - 1) * sum(batch * h * ww for h, ww in in_sizes) * in_cstride * 2)
 
 
@@ -246,8 +271,10 @@ class SipMaskEngine:
         # tiles + 128/192-position finishing tiles, sm_conv3x3_patch_plan) ends a lone launch 15-20 % sooner but spends
         # 4-6 % more CU time on it, which the other chain would have used (measured 998 vs 991 img/s, profiles/r02g_ab_patch_launch_shape.json)
         self.patch_uniform = sub_plan
-        if precision not in ("bf16", "f32"):
-            raise ValueError("precision must be 'bf16' (throughput plan) or 'f32' (parity plan), got %r" % (precision,))
+        if precision not in ("bf16", "f32", "head_x3"):
+            raise ValueError("precision must be 'bf16' (throughput plan), 'head_x3' (bf16 backbone + FPN, split-precision "
+                             "head: the reference head's fp32 arithmetic to ~1e-4 on its logits) or 'f32' (parity plan), "
+                             "got %r" % (precision,))
         # "f32": every activation / weight float32, convs on the exact-f32 MFMA kernel (csrc/conv_f32.hip), GroupNorm
         # statistics in double -- the plan that is held to the fp32 reference within accumulation-order rounding
         self.precision = precision
@@ -288,7 +315,8 @@ class SipMaskEngine:
         else:                  # head-only plan on caller-provided FPN features
             sd = {k: v.detach() for k, v in state_dict.items()}
             self.lv = H.Levels(batch, head_sizes)
-            self.pyr = self._buf(self.lv.rows, 256)
+            # (the x3 head splits f32 features itself: a head-only plan takes the caller's f32 features as they are)
+            self.pyr = self._buf(self.lv.rows, 256, torch.float32 if precision == "head_x3" else None)
             self._build_head(sd)
             self._build_post()
 
@@ -308,7 +336,7 @@ class SipMaskEngine:
         for l, f in enumerate(feats):
             h, w = lv.sizes[l]
             assert tuple(f.shape) == (self.batch, 256, h, w), (tuple(f.shape), (self.batch, 256, h, w))
-            to_rows = H.nchw_to_nhwc_f32 if self.precision == "f32" else H.nchw_to_nhwc_bf16
+            to_rows = H.nchw_to_nhwc_f32 if self.pyr.dtype == torch.float32 else H.nchw_to_nhwc_bf16
             to_rows(f.detach().float().contiguous(), self.pyr[lv.row0[l]:lv.row0[l] + self.batch * h * w], 256)
 
     def run_head(self, with_post=False):
@@ -553,8 +581,145 @@ class SipMaskEngine:
             self._gn64[k] = torch.zeros(stats.numel(), dtype=torch.float64, device=self.device)
         return self._gn64[k]
 
+    def _build_head_x3(self, sd, prefix="bbox_head."):
+        """SipMaskHead.forward (sipmask_head.py:241-287) in split precision (`precision="head_x3"`): the reference head is
+        fp32, and bf16 operand rounding is what moves the bf16 plan's mask logits by ~1.5.  Here every head activation
+        stays f32 between layers; a conv reads its input as two binary16 halves per value, [hi | lo | hi] along the
+        channel axis (csrc/split_x3.hip), against weights [hi | hi | lo] on the bf16 plan's own MFMA kernels with the
+        f16 instruction (SM_CONV_F16): three half products per element product, f32 accumulation, ~2^-21 per product.
+        GroupNorm statistics come out of the conv epilogues as before (fixed point); the normalise pass writes the next
+        layer's split operand (and f32 rows where a consumer wants them).  FeatureAlign's deformable conv -- the one
+        operand VALU has to touch -- runs on the exact-f32 MFMA kernel (csrc/conv_f32.hip) on f32 rows."""
+        B, lv, dev, h = self.batch, self.lv, self.device, prefix
+        self._sd, self._sd_keys = sd, set(sd.keys())
+        sizes, row0, rows = lv.sizes, lv.row0, lv.rows
+        f32, F16 = torch.float32, torch.float16
+        depth = lambda kind: sum(1 for k in sd if k.startswith(h + kind + "_convs.") and k.endswith(".conv.weight"))
+        self.flag_norm = (h + "reg_convs.0.gn.weight") in sd
+        if any(k.startswith(h + "track_convs.") for k in sd):
+            raise NotImplementedError("precision='head_x3' covers the SipMask head (no VIS track branch)")
+        ncls, nreg = depth("cls"), depth("reg")
+        if not (1 <= ncls <= nreg):
+            raise NotImplementedError("head_x3: cls tower not deeper than the reg tower (every reference config)")
+        S = 2 * B * len(lv) * 32
+        self.gn_stats = H.gn_stats_alloc(B * len(lv) * 32, dev)
+        stats2 = H.gn_stats_alloc(2 * B * len(lv) * 32, dev)
+        par = lambda n: sd[n].float().to(dev).contiguous()
+        TF = _lib_flag("SM_CONV_DBG_TILE256") | _lib_flag("SM_CONV_DBG_HAND_PLACED")
+        # head input: the FPN pyramid as [hi | lo | hi] (bf16 rows of the bf16 backbone, or the caller's f32 features)
+        self.pyr_x3 = torch.empty(rows, 768, dtype=F16, device=dev)
+        self._add("split:pyr", lambda: H.split3_f16(self.pyr, self.pyr_x3, 256))
+
+        relu = 0 if self.flag_norm else SM_CONV_RELU
+        x, xg = self.pyr_x3, 0
+        cls_f32 = reg_x3 = None
+        for i in range(ncls):                         # cls + reg tower convs of one depth = ONE grouped launch
+            y = torch.empty(2 * rows, 256, dtype=f32, device=dev)
+            names = ["cls_convs.%d" % i, "reg_convs.%d" % i]
+            c = self._add_conv(_GroupedConv(self, "head.tower%d" % i, [sd[h + n + ".conv.weight"] for n in names],
+                                            [sd.get(h + n + ".conv.bias") for n in names], B, sizes, row0, x, xg, 768, y,
+                                            rows, row0, 256, flags=TF | relu, mode="x3"))
+            if self.flag_norm:
+                c.gn_stats = stats2
+            nxt = torch.empty(2 * rows, 768, dtype=F16, device=dev)
+            for g, n in enumerate(names):
+                yv, st = y[g * rows:(g + 1) * rows], stats2[g * S:(g + 1) * S]
+                last_cls = g == 0 and i == ncls - 1               # feeds FeatureAlign's f32 deformable conv only
+                last_reg = g == 1 and i == nreg - 1               # feeds reg_ctr (split) and the mask branch (f32)
+                o3 = nxt[g * rows:(g + 1) * rows]
+                if self.flag_norm:
+                    gam, bet = par(h + n + ".gn.weight"), par(h + n + ".gn.bias")
+                    self._add("gn:" + n, (lambda yv=yv, gam=gam, bet=bet, st=st, o3=o3, lc=last_cls, lr=last_reg:
+                                          H.groupnorm_apply_x3(yv, gam, bet, st, lv, 256, 32, 1e-5, True,
+                                                               y_f32=yv if (lc or lr) else None, y_split=None if lc else o3)))
+                elif not last_cls:
+                    self._add("split:" + n, (lambda yv=yv, o3=o3: H.split3_f16(yv, o3, 256)))
+                if last_cls:
+                    cls_f32 = yv
+                if last_reg:
+                    self.reg_feat, reg_x3 = yv, o3
+            x, xg = nxt, rows
+        xr = x[rows:]                                 # the reg tower's split operand
+        for i in range(ncls, nreg):                   # the reg tower is deeper (stacked_convs vs stacked_convs - 1)
+            y = torch.empty(rows, 256, dtype=f32, device=dev)
+            name = "reg_convs.%d" % i
+            c = self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"], sd.get(h + name + ".conv.bias"), B,
+                                     sizes, row0, xr, 768, 1, 1, y, row0, 256, flags=relu, mode="x3"))
+            if self.flag_norm:
+                c.gn_stats = self.gn_stats
+            last = i == nreg - 1
+            o3 = torch.empty(rows, 768, dtype=F16, device=dev)
+            if self.flag_norm:
+                gam, bet = par(h + name + ".gn.weight"), par(h + name + ".gn.bias")
+                self._add("gn:" + name, (lambda y=y, gam=gam, bet=bet, o3=o3, last=last: H.groupnorm_apply_x3(
+                    y, gam, bet, self.gn_stats, lv, 256, 32, 1e-5, True, y_f32=y if last else None, y_split=o3)))
+            else:
+                self._add("split:" + name, (lambda y=y, o3=o3: H.split3_f16(y, o3, 256)))
+            xr = o3
+            if last:
+                self.reg_feat, reg_x3 = y, o3
+        self.cls_feat = cls_f32
+        # mask basis branch (sipmask_head.py:275-285) on lane 2: f32 [l0 | up2(l1) | up4(l2)] -> split -> 1x1 -> split -> 3x3
+        (h0, w0) = sizes[0]
+        n0 = B * h0 * w0
+        self.cat = torch.empty(n0, 768, dtype=f32, device=dev)
+        for l in range(3):
+            fh, fw = sizes[l]
+            src = self.reg_feat[row0[l]:row0[l] + B * fh * fw]
+            self._add("up:cat%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear(
+                s, self.cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, True)), 2)
+        cat_x3 = torch.empty(n0, 3 * 768, dtype=F16, device=dev)
+        self._add("split:cat", lambda: H.split3_f16(self.cat, cat_x3, 768), 2)
+        self.lat0 = torch.empty(n0, 512, dtype=f32, device=dev)
+        self._add_conv(_Conv(self, "head.sip_mask_lat0", sd[h + "sip_mask_lat0.weight"], sd[h + "sip_mask_lat0.bias"],
+                             B, [(h0, w0)], [0], cat_x3, 3 * 768, 1, 0, self.lat0, [0], 512, flags=SM_CONV_RELU, mode="x3"), 2)
+        lat0_x3 = torch.empty(n0, 3 * 512, dtype=F16, device=dev)
+        self._add("split:lat0", lambda: H.split3_f16(self.lat0, lat0_x3, 512), 2)
+        self.basis_lo = torch.empty(n0, 32, dtype=f32, device=dev)
+        self._add_conv(_Conv(self, "head.sip_mask_lat", sd[h + "sip_mask_lat.weight"], sd[h + "sip_mask_lat.bias"], B,
+                             [(h0, w0)], [0], lat0_x3, 3 * 512, 1, 1, self.basis_lo, [0], 32, flags=SM_CONV_RELU, mode="x3"), 2)
+        self.hm, self.wm = 4 * h0, 4 * w0
+        self._basis = None
+        self._basis_h0w0 = (h0, w0)
+        self._add("up:basis", lambda: self._basis_step(), 2)
+        # fcos_reg (4, x Scale) + fcos_centerness (1): one 5-channel conv on the reg tower's split output
+        w_rc = torch.cat([sd[h + "fcos_reg.weight"], sd[h + "fcos_centerness.weight"]], 0)
+        b_rc = torch.cat([sd[h + "fcos_reg.bias"], sd[h + "fcos_centerness.bias"]], 0)
+        scales = [float(sd[h + "scales.%d.scale" % i]) for i in range(len(lv))]
+        self.reg_out = torch.zeros(rows, 8, dtype=f32, device=dev)
+        self._add_conv(_Conv(self, "head.reg_ctr", w_rc, b_rc, B, sizes, row0, reg_x3, 768, 1, 1, self.reg_out, row0, 8,
+                             flags=(_lib.SM_CONV_RELU_NCH if self.benchmark else 0), scale_nch=4, level_scale=scales,
+                             mode="x3"))
+        # FeatureAlign: offsets (f32 1x1 of the box prediction) -> deformable conv in exact f32 -> GN + ReLU -> split
+        self.w_off = sd[h + "feat_align.conv_offset.weight"].float().view(72, 4).to(dev).contiguous()
+        self.offsets = torch.empty(rows, 72, dtype=f32, device=dev)
+        self._add("offset", lambda: H.offset_linear(self.reg_out, 8, self.w_off, lv, self.offsets))
+        self.aligned = torch.empty(rows, 256, dtype=f32, device=dev)
+        self._add_conv(_Conv(self, "head.feat_align", sd[h + "feat_align.conv_adaption.weight"],
+                             sd.get(h + "feat_align.conv_adaption.bias"), B, sizes, row0, self.cls_feat, 256, 1, 1,
+                             self.aligned, row0, 256, deform_groups=4, offset=self.offsets,
+                             flags=(0 if self.flag_norm else SM_CONV_RELU), mode="f32"))
+        aligned_x3 = torch.empty(rows, 768, dtype=F16, device=dev)
+        if self.flag_norm:
+            gam, bet = par(h + "feat_align.norm.weight"), par(h + "feat_align.norm.bias")
+            self._add("gn_stats:feat_align", lambda: H.gn_stats_f32_fix(self.aligned, self.gn_stats, lv, 256, 32))
+            self._add("gn:feat_align", lambda: H.groupnorm_apply_x3(self.aligned, gam, bet, self.gn_stats, lv, 256, 32, 1e-5,
+                                                                    True, y_split=aligned_x3))
+        else:
+            self._add("split:feat_align", lambda: H.split3_f16(self.aligned, aligned_x3, 256))
+        # fcos_cls (80) + sip_cof (128): one 208-channel conv
+        w_cc = torch.cat([sd[h + "fcos_cls.weight"], sd[h + "sip_cof.weight"]], 0)
+        b_cc = torch.cat([sd[h + "fcos_cls.bias"], sd[h + "sip_cof.bias"]], 0)
+        self.ncc = self.ncls + 128
+        self.cls_cof = torch.empty(rows, self.ncc, dtype=f32, device=dev)
+        self._add_conv(_Conv(self, "head.cls_cof", w_cc, b_cc, B, sizes, row0, aligned_x3, 768, 1, 1, self.cls_cof, row0,
+                             self.ncc, mode="x3"))
+        self.track_feats = None
+
     def _build_head(self, sd, prefix="bbox_head."):
         """SipMaskHead.forward, sipmask_head.py:241-287, on the pyramid tensor self.pyr."""
+        if self.precision == "head_x3":
+            return self._build_head_x3(sd, prefix)
         B, lv, dev, h = self.batch, self.lv, self.device, prefix
         self._sd, self._sd_keys = sd, set(sd.keys())
         sizes, row0 = lv.sizes, lv.row0

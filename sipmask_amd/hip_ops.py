@@ -44,6 +44,93 @@ def prep_conv_weight_patch(w):
     return out.reshape(co_pad, 9 * ci).to(BF16).contiguous(), co_pad
 
 
+# ------------------------------------------------------------------------------- split-precision ("x3") operands
+F16 = torch.float16
+
+
+def x3_weight_scale(ws):
+    """power of two s such that the largest |w| * s lies in [2^11, 2^12): the low half of a ~1e-2 weight (~5e-6) would sit
+    in binary16's subnormals (quantum 6e-8) and lose the bits it exists for; scaled it is a normal number.  The conv
+    undoes it exactly on the accumulator (sm_conv_desc.acc_scale = 1 / s).  One scale per LAUNCH (grouped convs share it)."""
+    import math
+    m = max(float(w.detach().abs().max()) for w in ws)
+    return 2.0 ** math.floor(math.log2(4096.0 / m)) if m > 0 and math.isfinite(m) else 1.0
+
+
+def _x3_halves(w, scale):
+    """w * scale as two binary16 halves along the input-channel axis in the order that pairs with activations laid out
+    [hi | lo | hi]: [w_hi | w_hi | w_lo]  =>  x_hi*w_hi + x_lo*w_hi + x_hi*w_lo."""
+    ws = w.float() * scale
+    hi = ws.to(F16)
+    lo = (ws - hi.float()).to(F16)
+    return torch.cat([hi, hi, lo], 1)                     # [co, 3*ci, kh, kw] binary16 values
+
+
+def prep_conv_weight_x3(w, scale):
+    """[co,ci,kh,kw] float -> binary16 [cout_pad][Kp], K order (kh,kw,3*ci) for sm_conv2d with SM_CONV_F16"""
+    w3 = _x3_halves(w, scale)
+    co, ci3, kh, kw = w3.shape
+    assert ci3 % 8 == 0
+    tile = cout_tile(co)
+    co_pad = (co + tile - 1) // tile * tile
+    k = kh * kw * ci3
+    kp = (k + 63) // 64 * 64
+    out = torch.zeros(co_pad, kp, dtype=F16, device=w.device)
+    out[:co, :k] = w3.permute(0, 2, 3, 1).reshape(co, k)
+    return out.contiguous(), co_pad
+
+
+def prep_conv_weight_patch_x3(w, scale):
+    """[co,ci,3,3] float -> binary16 [cout_pad][3*ci/32][9][32] for sm_conv3x3_patch with SM_CONV_F16"""
+    w3 = _x3_halves(w, scale)
+    co, ci3, kh, kw = w3.shape
+    assert (kh, kw) == (3, 3) and ci3 % 64 == 0
+    co_pad = (co + 255) // 256 * 256
+    out = torch.zeros(co_pad, ci3 // 32, 9, 32, dtype=F16, device=w.device)
+    out[:co] = w3.permute(0, 2, 3, 1).reshape(co, 9, ci3 // 32, 32).permute(0, 2, 1, 3)
+    return out.reshape(co_pad, 9 * ci3).contiguous(), co_pad
+
+
+def split3_f16(x, y, channels=None, ctot=None, coff=0):
+    """x: f32 or bf16 rows [rows, >= channels] -> y binary16 [rows, 3*ctot]: [hi | lo | hi] of x's first `channels` channels at
+    channel offset coff of each third (sm_split3_f16)"""
+    _lib.require_cuda(x, y)
+    channels = channels or x.shape[1]
+    ctot = ctot or channels
+    if x.dtype not in (torch.float32, BF16) or y.dtype != F16 or y.shape[1] != 3 * ctot or y.shape[0] != x.shape[0]:
+        raise ValueError("split3_f16: f32 / bf16 rows in, binary16 [rows, 3*ctot] out")
+    lib = _lib.load()
+    _lib.check(lib.sm_split3_f16(_lib.ptr(x), int(x.dtype == torch.float32), x.shape[0], channels, x.stride(0), _lib.ptr(y),
+                                 ctot, coff, _lib.stream_ptr()), "sm_split3_f16")
+    return y
+
+
+def _lv_geometry(lv):
+    nlev = len(lv)
+    return nlev, (C.c_int32 * nlev)(*[h * w for h, w in lv.sizes]), (C.c_int64 * nlev)(*lv.row0)
+
+
+def gn_stats_f32_fix(x, stats, lv, channels, groups=32):
+    """fixed-point GroupNorm statistics of f32 pyramid rows (sm_gn_stats_f32_fix)"""
+    _check_gn_stats(stats)
+    nlev, hw, row0 = _lv_geometry(lv)
+    _lib.check(_lib.load().sm_gn_stats_f32_fix(_lib.ptr(x), _lib.ptr(stats), lv.batch, nlev, hw, row0, channels, groups,
+                                               _lib.stream_ptr()), "sm_gn_stats_f32_fix")
+    return stats
+
+
+def groupnorm_apply_x3(x, gamma, beta, stats, lv, channels, groups=32, eps=1e-5, relu=True, y_f32=None, y_split=None):
+    """normalise (+ReLU) f32 rows with fixed-point statistics -> f32 rows and / or [hi | lo | hi] binary16 rows"""
+    _check_gn_stats(stats)
+    if x.dtype != torch.float32 or (y_f32 is not None and y_f32.dtype != torch.float32) or \
+            (y_split is not None and (y_split.dtype != F16 or y_split.shape[1] != 3 * channels)):
+        raise ValueError("groupnorm_apply_x3: f32 rows in; f32 and / or binary16 [rows, 3*C] rows out")
+    nlev, hw, row0 = _lv_geometry(lv)
+    _lib.check(_lib.load().sm_groupnorm_apply_x3(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats), lv.batch, nlev,
+                                                 hw, row0, channels, groups, eps, int(relu), _lib.ptr(y_f32),
+                                                 _lib.ptr(y_split), _lib.stream_ptr()), "sm_groupnorm_apply_x3")
+
+
 def conv3x3_patch_supported(desc):
     return bool(_lib.load().sm_conv3x3_patch_supported(C.byref(desc)))
 
@@ -113,7 +200,7 @@ class Levels:
 def make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, cout, cout_pad, k, stride, pad,
                    in_cstride, out_cstride, out_coff=0, flags=0, dil=1, res_cstride=0, res_sizes=None,
                    res_row0=None, scale_nch=0, level_scale=None, deform_groups=0, ngroups=1, x_group_rows=0, y_group_rows=0,
-                   w_group_stride=0, bias_group_stride=0, gn_group_stride=0):
+                   w_group_stride=0, bias_group_stride=0, gn_group_stride=0, acc_scale=0.0):
     d = ConvDesc()
     nlev = len(in_sizes)
     assert 1 <= nlev <= SM_MAX_LEVELS
@@ -137,6 +224,7 @@ def make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, cout, cou
     d.ngroups = ngroups
     d.x_group_rows, d.y_group_rows, d.w_group_stride = x_group_rows, y_group_rows, w_group_stride
     d.bias_group_stride, d.gn_group_stride = bias_group_stride, gn_group_stride
+    d.acc_scale = float(acc_scale)
     return d
 
 
@@ -835,17 +923,19 @@ class _GradSink:
     Direct writes OVERWRITE, so they are only safe for a parameter that one backward op uses once per step.  The first
     step after attach() is a census: every op reports its use and returns its gradient the ordinary way (autograd adds
     it into the zeroed view); parameters counted once become direct from the second step on.  A second contribution in
-    a later step still goes through autograd's in-place add; the bucketer raises if its bucket was already launched."""
+    a later step still goes through autograd's in-place add.  Readiness of a gradient is NOT signalled from here: the
+    bucketer counts a parameter when autograd's AccumulateGrad node for it has run (its post-accumulate hook), which
+    is after every op that uses the parameter -- direct writers included."""
 
     def __init__(self):
         self.detach()
 
     def detach(self):
-        self.views, self.uses, self.direct, self.written, self.on_write, self.census = {}, {}, set(), set(), None, True
+        self.views, self.uses, self.direct, self.written, self.census = {}, {}, set(), set(), True
 
-    def attach(self, views, on_write):
+    def attach(self, views):
         self.detach()
-        self.views, self.on_write = dict(views), on_write
+        self.views = dict(views)
 
     def begin_step(self):
         if self.census and self.uses:
@@ -869,9 +959,7 @@ class _GradSink:
         return None
 
     def commit(self, param):
-        k = param.data_ptr()
-        self.written.add(k)
-        self.on_write(k)
+        self.written.add(param.data_ptr())
 
 
 GRAD_SINK = _GradSink()

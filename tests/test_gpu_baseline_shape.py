@@ -62,3 +62,23 @@ def test_bf16_plan_at_baseline_shape():
     assert img["mask_logits"]["rel_fro"] < 0.05 and feat["mask_logits"]["rel_fro"] < 0.025
     for d in rep["detections"]:
         assert d["ndet_engine"] > 0 and d["ndet_oracle"] > 0
+
+
+def test_head_x3_plan_at_baseline_shape():
+    """the split-precision head plan (bf16 backbone + FPN, x3 head) at BASELINE's shape, as the SubBatchPlan
+    bench.py --precision head_x3 times.  On IDENTICAL f32 FPN features (north_star's setting: "match the reference head
+    on identical inputs") the mask logits are within 1e-3 absolute of the fp32 oracle and the detections are the oracle's;
+    from the image the bf16 backbone's rounding dominates and the bf16 plan's stage bounds apply."""
+    _need_gpu()
+    import parity_baseline as PB
+    rep = PB.run(50, 4, "head_x3", features_too=True, verbose=False, plan="subbatch")
+    assert rep["chains"] == [2, 2] and rep["rerun_bit_identical"]
+    feat = rep["features"]
+    assert feat["mask_logits"]["max_abs"] <= 1e-3, feat["mask_logits"]
+    for k in ("cls_logits", "bbox_pred", "centerness", "cof", "basis"):
+        assert feat[k]["max_abs"] <= 1e-4 * feat[k]["ref_max_abs"], (k, feat[k])
+    for d in rep["features_detections"]:
+        assert d["ndet_engine"] == d["ndet_oracle"] and d["common"] >= d["ndet_oracle"] - 1, d
+    img = rep["image"]
+    for k in ("C2", "C3", "C4", "C5", "P3", "P4", "P5", "P6", "P7"):
+        assert img[k]["rel_fro"] < 0.02, (k, img[k])

@@ -100,7 +100,7 @@ def test_deform_patch_mixed_offsets_one_launch():
 
 def test_deform_patch_gn_stats_bias_relu_bf16():
     """FeatureAlign's launch: bf16 rows out, GroupNorm statistics of the (pre-activation) output fused, 512 couts = 2 tiles"""
-    from sipmask_amd import _lib
+    from sipmask_amd import _lib, hip_ops as H
     B, C, Co, G = 2, 256, 512, 4
     sizes = [(13, 37), (7, 11)]
     xs, offs, wt, x_rows, off_rows, lv = _inputs(B, sizes, C, Co, G, 1.0, 21)

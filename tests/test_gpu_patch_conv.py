@@ -30,7 +30,7 @@ def _rows(ts):
     (2, 128, 512, [(9, 250)]),                                         # two cout tiles, widest supported rows
     (1, 256, 256, [(100, 168)]),                                       # FPN level-0 geometry (67 tiles)
 ])
-@pytest.mark.parametrize("shape_flag", [0, 0x4000, 0x2000, 0x1000, 0x800, 0x2800, 0x1800, 0x80, 0x4080, 0x2080, 0x1080, 0x400])   # planner / uniform 256 / finish with 128 / with 192; 0x800 = pipelined stage, 0x80 = ping-pong schedule, 0x400 = staggered DMA
+@pytest.mark.parametrize("shape_flag", [0, 0x4000])   # the planner's launch shape / uniform 256-position tiles (SM_CONV_DBG_PATCH_UNIFORM)
 def test_patch_conv_vs_torch(cfg, shape_flag):
     from sipmask_amd import hip_ops as H, _lib
     dev = _dev()
@@ -116,7 +116,7 @@ def test_patch_conv_mixed_tile_launch_at_head_shape(batch, groups):
     wq = torch.stack(packed).contiguous()
     S = 2 * batch * len(sizes) * (C // 8)
     outs = {}
-    for flag in (0, 0x4000, 0x800, 0x80, 0x4080):
+    for flag in (0, 0x4000):
         y = torch.zeros(groups * lv.rows, C, dtype=torch.bfloat16, device=dev)
         stats = torch.full((groups * S,), 7, dtype=torch.int64, device=dev)
         d = H.make_conv_desc(batch, sizes, sizes, lv.row0, lv.row0, C, C, 256, 3, 1, 1, C, C, flags=flag, ngroups=groups,
@@ -136,9 +136,9 @@ def test_patch_conv_mixed_tile_launch_at_head_shape(batch, groups):
         assert torch.equal(stats, again)
         outs[flag] = (y, stats)
     assert torch.equal(outs[0][0], outs[0x4000][0])
-    assert torch.equal(outs[0][0], outs[0x800][0])          # the pipelined stage issues the same MFMAs in the same order
-    assert torch.equal(outs[0][0], outs[0x80][0]) and torch.equal(outs[0][0], outs[0x4080][0])     # ... and so does ping-pong
-    torch.testing.assert_close(H.gn_stats_to_float(outs[0][1]), H.gn_stats_to_float(outs[0x4000][1]), rtol=1e-4, atol=0.5)   # other tile cut: other partial sums
+    # another tile cut, the SAME statistics: a contribution is the sum over 32 consecutive padded-flat positions x 8 couts
+    # whatever tile they fall into, and the sums of contributions are integer
+    assert torch.equal(outs[0][1], outs[0x4000][1])
     y, stats = outs[0]
     for gi in range(groups):
         st = H.gn_stats_to_float(stats[gi * S:(gi + 1) * S].view(batch, len(sizes), C // 8, 2)).float()

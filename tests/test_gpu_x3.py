@@ -1,0 +1,261 @@
+"""The split-precision ("x3") head plan: binary16 halves [hi | lo | hi] of f32 activations against weights
+[hi | hi | lo] on the bf16 plan's MFMA kernels with v_mfma_f32_32x32x16_f16 (SM_CONV_F16), f32 activations between the
+layers.  Kernel tests against torch float64 convolutions of the SAME f32 inputs (no operand pre-rounding: the point of
+the plan is that f32 operands survive), plan tests against the fp32 oracle.  Reference arithmetic: the reference head
+is fp32 end to end, M/mmdet/models/anchor_heads/sipmask_head.py:241-287,609-633."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model as OM  # noqa: E402
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+def _rows(ts):
+    return torch.cat([t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in ts]).contiguous()
+
+
+def test_split3_layout_and_precision():
+    """sm_split3_f16: hi = f16(v) exactly, hi + lo reproduces v to 2^-21 relative (|v| in binary16's normal range), from
+    f32 and from bf16 rows, into a channel slice of a wider destination; out-of-range values saturate"""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(1000, 64, generator=g) * torch.logspace(-3, 2, 64)).contiguous()
+    x[0, :4] = torch.tensor([0.0, -0.0, 7e4, -1e9])
+    y = torch.full((1000, 3 * 96), 7.0, dtype=torch.float16, device=dev)
+    H.split3_f16(x.to(dev), y, 64, 96, 16)
+    yc = y.cpu().float()
+    hi, lo, hi2 = yc[:, 16:80], yc[:, 96 + 16:96 + 80], yc[:, 192 + 16:192 + 80]
+    xc = x.clamp(-65504, 65504)
+    assert torch.equal(hi, xc.half().float()) and torch.equal(hi, hi2)
+    big = xc.abs() > 1e-2
+    assert float(((hi + lo - xc).abs() / xc.abs().clamp_min(1e-30))[big].max()) < 2.0 ** -21
+    assert float((hi + lo - xc).abs()[~big].max()) < 1e-7                     # subnormal lows: absolute 2^-25
+    assert bool((yc[:, :16] == 7).all()) and bool((yc[:, 80:96] == 7).all())   # other sources' slices untouched
+    xb = x.to(torch.bfloat16)
+    y2 = torch.empty(1000, 192, dtype=torch.float16, device=dev)
+    H.split3_f16(xb.to(dev), y2)
+    y2 = y2.cpu().float()
+    xbc = xb.float().clamp(-65504, 65504)
+    assert torch.equal(y2[:, :64], xbc.half().float()) and torch.equal(y2[:, 128:], y2[:, :64])
+    assert float((y2[:, :64] + y2[:, 64:128] - xbc).abs().max()) <= float(xbc.abs().max()) * 2.0 ** -21
+
+
+@pytest.mark.parametrize("kernel", ["igemm", "igemm256", "patch"])
+def test_x3_conv_matches_f64_conv_of_f32_operands(kernel):
+    """3x3 256->256 over a 3-level pyramid, grouped (2 weight sets, shared input), fused fixed-point GN statistics, f32
+    output: within 2e-6 of the float64 convolution of the SAME f32 operands, relative to the output's largest value
+    (bf16 operands: 4e-3).  The weight scale is a power of two and is undone exactly."""
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    B, C, G = 2, 256, 2
+    sizes = [(40, 66), (20, 33), (5, 9)] if kernel != "patch" else [(100, 168), (50, 84), (25, 42)]
+    lv = H.Levels(B, sizes)
+    xs = [torch.randn(B, C, h, w, generator=g) * 1.7 for h, w in sizes]
+    ws = [torch.randn(C, C, 3, 3, generator=g) * 0.03 for _ in range(G)]
+    bias = [torch.randn(C, generator=g) for _ in range(G)]
+    x3 = torch.empty(lv.rows, 3 * C, dtype=torch.float16, device=dev)
+    H.split3_f16(_rows(xs).to(dev), x3)
+    scale = H.x3_weight_scale(ws)
+    assert scale == 2.0 ** round(np.log2(scale)) and 2048 <= max(float(w.abs().max()) for w in ws) * scale < 4096
+    flags = _lib.SM_CONV_F16 | _lib.SM_CONV_OUT_F32
+    if kernel == "patch":
+        packed = [H.prep_conv_weight_patch_x3(w.to(dev), scale)[0] for w in ws]
+        co_pad = 256
+    else:
+        packed = [H.prep_conv_weight_x3(w.to(dev), scale) for w in ws]
+        co_pad = packed[0][1]
+        packed = [p[0] for p in packed]
+        if kernel == "igemm256":
+            flags |= _lib.SM_CONV_DBG_TILE256 | _lib.SM_CONV_DBG_HAND_PLACED | _lib.SM_CONV_DBG_BIG_TILES
+    assert packed[0].dtype == torch.float16
+    wq = torch.stack(packed).contiguous()
+    S = 2 * B * len(sizes) * (C // 8)
+    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, 3 * C, C, co_pad, 3, 1, 1, 3 * C, C, flags=flags, ngroups=G,
+                         x_group_rows=0, y_group_rows=lv.rows, w_group_stride=packed[0].numel(), bias_group_stride=C,
+                         gn_group_stride=S, acc_scale=1.0 / scale)
+    y = torch.zeros(G * lv.rows, C, dtype=torch.float32, device=dev)
+    stats = torch.full((G * S,), 5, dtype=torch.int64, device=dev)
+    bq = torch.stack(bias).to(dev).contiguous()
+    if kernel == "patch":
+        assert H.conv3x3_patch_supported(d)
+        H.conv3x3_patch(d, x3, wq, bq, y, stats)
+    else:
+        H.conv2d_gn_stats(d, x3, None, wq, bq, None, y, stats)
+    torch.cuda.synchronize()
+    for gi in range(G):
+        st = H.gn_stats_to_float(stats[gi * S:(gi + 1) * S].view(B, len(sizes), C // 8, 2).cpu())
+        for l, (h, w) in enumerate(sizes):
+            ref = F.conv2d(xs[l].double(), ws[gi].double(), bias[gi].double(), 1, 1)
+            r0 = gi * lv.rows + lv.row0[l]
+            got = y[r0:r0 + B * h * w].view(B, h, w, C).permute(0, 3, 1, 2).cpu().double()
+            err = float((got - ref).abs().max()) / float(ref.abs().max())
+            assert err < 2e-6, (kernel, gi, l, err)
+            r8 = ref.reshape(B, C // 8, 8 * h * w)
+            torch.testing.assert_close(st[:, l, :, 0], r8.sum(-1), rtol=1e-5, atol=1e-3 * (h * w) ** 0.5)
+            torch.testing.assert_close(st[:, l, :, 1], (r8 * r8).sum(-1), rtol=1e-5, atol=1e-3)
+
+
+def test_x3_small_cout_and_1x1_convs():
+    """the head's other x3 launches: 1x1 over 3*768 channels (sip_mask_lat0), 3x3 to 32 couts (sip_mask_lat) and to 8
+    couts with per-level Scale on 4 of them (fcos_reg + centerness), ReLU, bias -- f32 out, within 2e-6 of float64"""
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    B = 2
+    for (ci, co, k, sizes, relu, nch) in [(768, 512, 1, [(25, 40)], True, 0), (512, 32, 3, [(25, 40)], True, 0),
+                                          (256, 5, 3, [(20, 33), (10, 17), (5, 9)], False, 4)]:
+        lv = H.Levels(B, sizes)
+        xs = [torch.randn(B, ci, h, w, generator=g).abs() for h, w in sizes]
+        wt = torch.randn(co, ci, k, k, generator=g) * (0.5 / (ci * k * k) ** 0.5)
+        bias = torch.randn(co, generator=g)
+        lscale = [1.0 + 0.25 * l for l in range(len(sizes))]
+        x3 = torch.empty(lv.rows, 3 * ci, dtype=torch.float16, device=dev)
+        H.split3_f16(_rows(xs).to(dev), x3)
+        scale = H.x3_weight_scale([wt])
+        wq, co_pad = H.prep_conv_weight_x3(wt.to(dev), scale)
+        cs = (co + 7) // 8 * 8
+        d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, 3 * ci, co, co_pad, k, 1, k // 2, 3 * ci, cs,
+                             flags=_lib.SM_CONV_F16 | _lib.SM_CONV_OUT_F32 | (_lib.SM_CONV_RELU if relu else 0), scale_nch=nch,
+                             level_scale=lscale, acc_scale=1.0 / scale)
+        y = torch.zeros(lv.rows, cs, dtype=torch.float32, device=dev)
+        H.conv2d(d, x3, wq, bias.to(dev), None, y)
+        torch.cuda.synchronize()
+        for l, (h, w) in enumerate(sizes):
+            ref = F.conv2d(xs[l].double(), wt.double(), bias.double(), 1, k // 2)
+            if nch:
+                ref[:, :nch] *= lscale[l]
+            if relu:
+                ref = ref.clamp_min(0)
+            got = y[lv.row0[l]:lv.row0[l] + B * h * w, :co].view(B, h, w, co).permute(0, 3, 1, 2).cpu().double()
+            err = float((got - ref).abs().max()) / float(ref.abs().max())
+            assert err < 2e-6, (ci, co, k, l, err)
+    # binary16 operands need f32 output, no residual
+    d.flags &= ~_lib.SM_CONV_OUT_F32
+    with pytest.raises(RuntimeError):
+        H.conv2d(d, x3, wq, None, None, y)
+
+
+def test_groupnorm_apply_x3_and_f32_statistics():
+    """sm_gn_stats_f32_fix + sm_groupnorm_apply_x3 == F.group_norm + ReLU of the f32 rows (1e-5), written as f32 rows
+    (in place) and as the next layer's split operand; the statistics are bit-reproducible"""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    B, C = 2, 256
+    sizes = [(20, 33), (10, 17), (5, 9), (3, 5), (2, 3)]
+    lv = H.Levels(B, sizes)
+    xs = [torch.randn(B, C, h, w, generator=g) * 3 + 0.5 for h, w in sizes]
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    x = _rows(xs).to(dev)
+    st = H.gn_stats_alloc(B * 5 * 32, dev)
+    H.gn_stats_f32_fix(x, st, lv, C, 32)
+    st2 = torch.full_like(st, 9)
+    H.gn_stats_f32_fix(x, st2, lv, C, 32)
+    torch.cuda.synchronize()
+    assert torch.equal(st, st2)
+    y3 = torch.empty(lv.rows, 3 * C, dtype=torch.float16, device=dev)
+    H.groupnorm_apply_x3(x, gamma.to(dev), beta.to(dev), st, lv, C, 32, 1e-5, True, y_f32=x, y_split=y3)
+    torch.cuda.synchronize()
+    for l, (h, w) in enumerate(sizes):
+        ref = F.relu(F.group_norm(xs[l].double(), 32, gamma.double(), beta.double(), 1e-5)).float()
+        got = x[lv.row0[l]:lv.row0[l] + B * h * w].view(B, h, w, C).permute(0, 3, 1, 2).cpu()
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+        s3 = y3[lv.row0[l]:lv.row0[l] + B * h * w].float().cpu()
+        rec = (s3[:, :C] + s3[:, C:2 * C]).view(B, h, w, C).permute(0, 3, 1, 2)
+        torch.testing.assert_close(rec, got, rtol=2.0 ** -20, atol=1e-7)
+        assert torch.equal(s3[:, :C], s3[:, 2 * C:])
+
+
+@pytest.fixture(scope="module")
+def head_case():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    torch.manual_seed(0)
+    B = 2
+    sd = OM.init_state_dict(50, 0, calibrate=True)
+    g = torch.Generator().manual_seed(1)
+    sizes = [(24, 32), (12, 16), (6, 8), (3, 4), (2, 2)]
+    feats = [torch.randn(B, 256, h, w, generator=g) * 2.0 for h, w in sizes]
+    out = OM.head_forward(sd, feats)
+    allc = torch.cat([c[0].reshape(-1) for c in out[0]]) - sd["bbox_head.fcos_cls.bias"][0]
+    OM.calibrate_cls_bias(sd, allc, target=300)
+    out = OM.head_forward(sd, feats)
+    return dict(sd=sd, feats=feats, out=out, B=B, sizes=sizes)
+
+
+def test_x3_head_matches_the_fp32_oracle_on_identical_features(head_case):
+    """north_star: "outputs match the reference head on identical inputs ... mask logits within 1e-3".  The head-only
+    x3 plan on the oracle's own f32 features: every head output within 1e-4 of its largest value, mask logits (basis .
+    coefficients at the oracle's detections) within 1e-3 ABSOLUTE, the detections the SAME SET with identical labels."""
+    from sipmask_amd.engine import SipMaskEngine
+    c = head_case
+    hsd = {k: v for k, v in c["sd"].items() if k.startswith("bbox_head.")}
+    eng = SipMaskEngine.for_head(hsd, c["B"], c["sizes"], img_shape=(192, 256, 3), precision="head_x3")
+    assert all(cv.mode in ("x3", "f32") for cv in eng.convs) and sum(cv.mode == "f32" for cv in eng.convs) == 1
+    eng.load_pyramid([f.cuda() for f in c["feats"]])
+    eng.run_head(with_post=True)
+    torch.cuda.synchronize()
+    cls, bb, ctr, cof, fm = eng.head_outputs()
+    ocls, obb, octr, ocof, ofm = c["out"][:5]
+    worst = {}
+    for name, got, ref in (("cls", cls, ocls), ("bbox", bb, obb), ("ctr", ctr, octr), ("cof", cof, ocof)):
+        e = max(float((a.cpu() - b).abs().max()) for a, b in zip(got, ref))
+        m = max(float(b.abs().max()) for b in ref)
+        worst[name] = e / m
+        assert e <= 1e-4 * m, (name, e, m)
+    assert float((fm.cpu() - ofm).abs().max()) <= 1e-4 * float(ofm.abs().max())
+    res = eng.results()
+    for b in range(c["B"]):
+        r = OM.get_masks_single([x[b] for x in ocls], [x[b] for x in obb], [x[b] for x in octr], [x[b] for x in ocof], ofm[b],
+                                (192, 256, 3), OM.DEFAULT_TEST_CFG)
+        n = int(res["ndet"][b])
+        assert n == r["det_bboxes"].shape[0] and n > 0
+        # same detections in the same order unless two ranking keys are within rounding of each other: compare as sets
+        got = sorted(zip(res["idxs_keep"][b, :n].cpu().tolist(), res["det_labels"][b, :n].cpu().tolist()))
+        ref = sorted(zip(r["idxs_keep"].tolist(), r["det_labels"].tolist()))
+        assert got == ref
+        # mask logits at the oracle's detections
+        keep = torch.as_tensor(r["idxs_keep"]).long()
+        basis = fm[b].reshape(32, -1).t().cpu()
+        obasis = ofm[b].reshape(32, -1).t()
+        gcof = eng.sel["cofs"][b].cpu()[keep]
+        ocf = torch.as_tensor(r["det_cofs"]).float()
+        for q in range(4):
+            lg = basis @ gcof[:, 32 * q:32 * q + 32].t()
+            lr = obasis @ ocf[:, 32 * q:32 * q + 32].t()
+            assert float((lg - lr).abs().max()) <= 1e-3, (b, q, float((lg - lr).abs().max()), float(lr.abs().max()))
+
+
+def test_x3_plan_from_the_image_and_subbatch(head_case):
+    """the whole plan (bf16 backbone + FPN, x3 head) runs, is bit-reproducible, and its HEAD reproduces the oracle head
+    evaluated on the plan's own FPN features (what "identical inputs" means for a plan that starts at the image)."""
+    from sipmask_amd.engine import SipMaskEngine
+    sd = head_case["sd"]
+    img = torch.randn(2, 3, 192, 256, generator=torch.Generator().manual_seed(3)).cuda()
+    eng = SipMaskEngine(sd, 2, (192, 256), 50, precision="head_x3")
+    r1 = {k: v.clone() for k, v in eng.run(img).items()}
+    cc = eng.cls_cof.clone()
+    r2 = eng.run(img)
+    torch.cuda.synchronize()
+    assert torch.equal(cc, eng.cls_cof) and all(torch.equal(r1[k], r2[k]) for k in r1)
+    lv = eng.lv
+    pyr = [eng.pyr[lv.row0[l]:lv.row0[l] + 2 * h * w].float().view(2, h, w, 256).permute(0, 3, 1, 2).cpu()
+           for l, (h, w) in enumerate(lv.sizes)]
+    out = OM.head_forward(sd, pyr)
+    cls, bb, ctr, cof, fm = eng.head_outputs()
+    for name, got, ref in (("cls", cls, out[0]), ("bbox", bb, out[1]), ("ctr", ctr, out[2]), ("cof", cof, out[3])):
+        e = max(float((a.cpu() - b).abs().max()) for a, b in zip(got, ref))
+        m = max(float(b.abs().max()) for b in ref)
+        assert e <= 1e-4 * m, (name, e, m)
+    assert float((fm.cpu() - out[4]).abs().max()) <= 1e-4 * float(out[4].abs().max())

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 3): the A/B flags this tool toggles are experiments -- build the library with `make -C sipmask_amd/csrc EXPERIMENTS=1` first (csrc/experiments.h); the default build ignores them.
 # One-call A/B of the conv K-loop variants on the GPU box: kernel parity, conv micro-benchmark, end-to-end bench per
 # variant, then the engine/API parity tests under the fastest variant.  Everything lands in gpurun_out/ab_conv/.
 #   FLAT_LOOP 0x00200000 | LEGACY_LOOP 0x00100000 | TILE256 0x00400000 (see include/sipmask_hip.h)

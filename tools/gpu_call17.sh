@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 3): the A/B flags this tool toggles are experiments -- build the library with `make -C sipmask_amd/csrc EXPERIMENTS=1` first (csrc/experiments.h); the default build ignores them.
 # pipelined patch stage (SM_CONV_DBG_PATCH_PIPE): parity, micro-benchmark, whole-step A/B
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}

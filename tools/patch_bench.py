@@ -1,4 +1,5 @@
 #!/usr/bin/env python
+# NOTE (round 3): the A/B flags this tool toggles are experiments -- build the library with `make -C sipmask_amd/csrc EXPERIMENTS=1` first (csrc/experiments.h); the default build ignores them.
 """patch-resident 3x3 kernel vs the implicit-GEMM kernel on the R50 head shapes (B=2 and B=4), interleaved rounds"""
 import os, sys
 import torch

@@ -1,4 +1,5 @@
 #!/usr/bin/env python
+# NOTE (round 3): the A/B flags this tool toggles are experiments -- build the library with `make -C sipmask_amd/csrc EXPERIMENTS=1` first (csrc/experiments.h); the default build ignores them.
 """patch-conv main-loop variants and ablations on the tower shape (uniform 256-position tiles): B=2 is 184 tiles = one
 partly filled round (pure per-tile time), B=4 368 tiles = two rounds"""
 import os, sys

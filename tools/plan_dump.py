@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build_on_cpu(variant="r50", batch=4, hw=(800, 1344), depth=50, sub_plan=False):
+def build_on_cpu(variant="r50", batch=4, hw=(800, 1344), depth=50, sub_plan=False, precision="bf16"):
     """The plan is host logic: with torch.cuda.is_available patched the engine allocates its buffers on the CPU and
     prepares every descriptor; nothing is launched."""
     real = torch.cuda.is_available
@@ -49,7 +49,7 @@ def build_on_cpu(variant="r50", batch=4, hw=(800, 1344), depth=50, sub_plan=Fals
             kw = dict(benchmark=dict(pre_nms_thresh=0.05, pre_nms_top_n=1000, nms_thresh=0.6, post_top_n=100))
         else:
             sd = OM.init_state_dict(depth, 0)
-        return SipMaskEngine(sd, batch, tuple(hw), depth, device="cpu", sub_plan=sub_plan, **kw)
+        return SipMaskEngine(sd, batch, tuple(hw), depth, device="cpu", sub_plan=sub_plan, precision=precision, **kw)
     finally:
         torch.cuda.is_available = real
 
@@ -58,6 +58,12 @@ def conv_rows(eng):
     from sipmask_amd import hip_ops as H
     rows = []
     for c in eng.convs:
+        if getattr(c, "f32", False):                     # conv_f32.hip (the exact-f32 MFMA kernel): 128x128 tiles
+            blocks = sum(-(-c.desc.batch * c.desc.out_h[l] * c.desc.out_w[l] // 128) for l in range(c.desc.nlev)) * (c.desc.cout_pad // 128 or 1)
+            rows.append(dict(name=c.name, kind="f32", shape="128x128", blocks=blocks, waves=blocks / 512.0,
+                             note="exact-f32 MFMA%s" % (" (deformable)" if c.offset is not None else ""),
+                             gflop=c.flops / 1e9, mb=c.bytes / 1e6))
+            continue
         if getattr(c, "patch", False):                   # conv3x3_patch.hip: one block per CU, its own launch planner
             pp = H.conv3x3_patch_plan(c.desc)
             blocks = pp["big"] + pp["small"]
@@ -103,8 +109,9 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--variant", default="r50", choices=["r50", "ssd", "vis", "benchmark", "dcn"])
     ap.add_argument("--sub-plan", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "head_x3"])
     args = ap.parse_args()
-    eng = build_on_cpu(args.variant, args.batch, args.hw, args.depth, args.sub_plan)
+    eng = build_on_cpu(args.variant, args.batch, args.hw, args.depth, args.sub_plan, args.precision)
     rows = {r["name"]: r for r in conv_rows(eng)}
     print("# %s, batch %d%s, %dx%d: %d steps, %d conv launches (+ %d fused bottleneck tails), %.1f conv GFLOP per step" % (
         args.variant, args.batch, " (one chain of a SubBatchPlan)" if args.sub_plan else "", args.hw[0], args.hw[1],
