@@ -355,7 +355,12 @@ int sm_upsample_bilinear(const void* x, void* y, int batch, int h, int w, int c,
  * Layout as above with f32 elements: activations f32 rows (cin, in_cstride multiples of 4), weights f32
  * [cout_pad][Kp], K = (kh,kw,cin) cin fastest, Kp = K rounded up to 16, rows padded to sm_conv_cout_tile(cout).
  * sm_conv2d_f32: offset != NULL selects the deformable variant (bilinear samples formed in f32 exactly as
- * deform_conv_cuda_kernel.cu:85-115); residual f32 rows; y f32 (SM_CONV_OUT_F32 is implied). */
+ * deform_conv_cuda_kernel.cu:85-115); residual f32 rows; y f32 (SM_CONV_OUT_F32 is implied).
+ * With SM_CONV_F16 in d->flags the SAME tensors are contracted in split precision: the loader turns every f32 operand
+ * element (the blended deformable sample included) into binary16 halves hi + lo and a product is three
+ * v_mfma_f32_32x32x16_f16 terms (w_hi*x_hi + w_hi*x_lo + w_lo*x_hi, ~2^-21) -- FeatureAlign's deformable conv in the x3
+ * head plan (5x less matrix-pipe time than the exact kernel; cout tile 128 only; weights pre-multiplied by a power
+ * of two with d->acc_scale its inverse). */
 int sm_conv2d_f32(const sm_conv_desc* d, const float* x, const float* offset, const float* w, const float* bias,
                   const float* residual, float* y, sm_stream_t stream);
 /* NCHW f32 image -> NHWC f32 with channels zero padded to cpad (multiple of 4). */
@@ -386,6 +391,10 @@ typedef struct {
   int32_t rescale;
   int32_t reg_prescaled;         /* 1: reg ch0-3 already carry x stride (API path: bbox_preds as
                                     returned by SipMaskHead.forward) */
+  const float* per_image;        /* NULL: img_h / img_w / scale_factor above hold for every image of the batch.  Otherwise a
+                                  * DEVICE table f32 [batch][6] = (img_h, img_w, scale_factor[0..3]) read per image -- the
+                                  * reference takes them from img_metas[img_id] (sipmask_head.py:517-541): a keep_ratio
+                                  * resize gives every image of a batch its own. */
 } sm_det_desc;
 
 /* workspace bytes for sm_det_select */
@@ -430,7 +439,7 @@ int64_t sm_rle_workspace(int batch, int max_num, int canvas_w, int max_runs);
 /* rect hint for sm_rle_encode from the detections sm_mask_assemble used (same box_mul/box_div/up_scale):
  * a conservative output-pixel rectangle per detection outside which the assembled mask is zero. */
 int sm_mask_rects(const float* det, int batch, int max_num, float box_mul_x, float box_mul_y, float box_div,
-                  double up_scale_h, double up_scale_w, int32_t* rect, sm_stream_t stream);
+                  double up_scale_h, double up_scale_w, int32_t* rect, const float* per_image, sm_stream_t stream);
 int sm_rle_encode(const uint8_t* masks, const int32_t* ndet, const int32_t* rect, int batch, int max_num, int ho,
                   int wo, int canvas_h, int canvas_w, int max_runs, uint32_t* counts, int32_t* nruns,
                   int32_t* nchars, uint8_t* packed, int64_t packed_cap, int64_t* offsets, void* workspace,
@@ -466,12 +475,17 @@ int sm_nms(const float* dets, int n, float iou_thr, int64_t* keep, int32_t* nkee
  * crop box = (det[:4] * box_mul_{x,y}) / box_div  (sipmask_head.py:623: * scale_factor / 2, per coordinate for
  * the [w,h,w,h] scale factors of keep_ratio=False pipelines);
  * up_scale_{h,w} = the F.interpolate scale_factor (:629-632; ssd_flag: 2 / scale_factor[3:1:-1]), Ho/Wo the
- * resulting size. */
+ * resulting size.
+ * per_image (sm_mask_assemble, sm_mask_assemble_lo, sm_mask_rects): NULL = one geometry for the batch (the scalar
+ * arguments).  Otherwise a DEVICE table f32 [batch][8] = (box_mul_x, box_mul_y, up_scale_h, up_scale_w, Ho, Wo, 0, 0) read
+ * per image (get_bboxes_single runs with img_metas[img_id]['scale_factor'], sipmask_head.py:517-541,621-633); the
+ * scalar Ho / Wo then give the CANVAS every mask plane is allocated with (>= every image's Ho / Wo), pixels of a plane
+ * outside its image's Ho x Wo are not part of the result. */
 int sm_mask_assemble(const float* basis, int basis_hwc, const float* cofs, const int64_t* keep,
                      const float* det, const int32_t* ndet, int batch, int kmax, int max_num,
                      int hm, int wm, int ho, int wo, int mask_pitch, float box_mul_x, float box_mul_y, float box_div,
                      double up_scale_h, double up_scale_w, float mask_thr, uint8_t* masks, float* pos_masks,
-                     sm_stream_t stream);
+                     const float* per_image, sm_stream_t stream);
 
 /* sm_mask_assemble for a launch plan that owns its buffers: the basis is given at its CONV resolution (basis_lo f32
  * [B][lo_h][lo_w][32], the relu(sip_mask_lat) output BEFORE the bilinear x`factor` of sipmask_head.py:285; Hm = lo_h *
@@ -490,7 +504,7 @@ int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, int factor, c
                         const float* det, const int32_t* ndet, int batch, int kmax, int max_num, int ho, int wo,
                         int mask_pitch, float box_mul_x, float box_mul_y, float box_div, double up_scale_h,
                         double up_scale_w, float mask_thr, uint8_t* masks, int32_t* state, void* workspace,
-                        sm_stream_t stream);
+                        const float* per_image, sm_stream_t stream);
 
 /* SipMask++ rescoring tail (sipmask_head.py:638-641): mask_scores[b][i] = max over the hw positions of
  * feat[(b*max_num+i)*hw + p][labels[b][i]] (feat = relu(mask_scoring(convs_scoring(pos_masks))), f32 NHWC rows)

@@ -70,6 +70,7 @@ class DetDesc(C.Structure):
         ("reg_cstride", C.c_int32), ("nms_pre", C.c_int32),
         ("img_h", C.c_int32), ("img_w", C.c_int32), ("kmax", C.c_int32),
         ("scale_factor", C.c_float * 4), ("rescale", C.c_int32), ("reg_prescaled", C.c_int32),
+        ("per_image", C.c_void_p),
     ]
 
 
@@ -143,16 +144,16 @@ PROTOTYPES = {
     "sm_pairs_select": (_I, [_P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_preprocess_u8": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "sm_rle_workspace": (C.c_int64, [_I, _I, _I, _I]),
-    "sm_mask_rects": (_I, [_P, _I, _I, _F, _F, _F, C.c_double, C.c_double, _P, _P]),
+    "sm_mask_rects": (_I, [_P, _I, _I, _F, _F, _F, C.c_double, C.c_double, _P, _P, _P]),
     "sm_rle_encode": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "sm_nms_workspace": (C.c_int64, [_I]),
     "sm_nms": (_I, [_P, _I, _F, _P, _P, _P, _P]),
     "sm_mask_assemble": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, C.c_double, C.c_double, _F,
-                              _P, _P, _P]),
+                              _P, _P, _P, _P]),
     "sm_mask_assemble_lo_supported": (_I, [_I, _I, _I, C.c_double, C.c_double]),
     "sm_mask_assemble_lo_workspace": (C.c_int64, [_I, _I]),
     "sm_mask_assemble_lo": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, C.c_double, C.c_double,
-                                 _F, _P, _P, _P, _P]),
+                                 _F, _P, _P, _P, _P, _P]),
     "sm_fcos_target": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
     "sm_crop_split_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sm_crop_split_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

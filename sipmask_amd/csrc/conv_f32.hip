@@ -15,6 +15,15 @@
 // inside a K step is a free permutation as long as A and B use the same one.
 // Loader: global -> VGPR -> LDS (VALU may touch the operand: zero padding, input ReLU, and for the DEFORM variant
 // the bilinear gather of deform_conv_cuda_kernel.cu:85-115,216-229 in f32, exactly as the reference samples).
+//
+// X3 variant (SM_CONV_F16 on sm_conv2d_f32; round 3): the same kernel -- f32 tensors in HBM, the same loader -- with the
+// contraction on the f16 matrix pipe in split precision: the loader turns every f32 operand element (the blended
+// deformable sample included) into two binary16 halves, hi = f16(v), lo = f16(v - hi), an LDS row holds
+// [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] (the same 64 bytes as 16 floats), and a K step is three
+// v_mfma_f32_32x32x16_f16 per tile pair: w_hi*x_hi + w_hi*x_lo + w_lo*x_hi (~2^-21 per product, f32 accumulation) instead
+// of eight v_mfma_f32_32x32x2_f32 -- 5.3x less matrix-pipe time.  This is FeatureAlign's deformable conv in the x3 head
+// plan: the one operand VALU has to produce cannot come through LDS-DMA, so it cannot use the K-concatenated layout of the
+// other convs (split_x3.hip).  Weights arrive multiplied by a power of two (binary16's subnormals), undone by acc_scale.
 #include "common.h"
 
 namespace {
@@ -38,9 +47,24 @@ struct ConvFArgs {
   int scale_nch;
   float level_scale[SM_MAX_LEVELS];
   int dg, cpg;  // deform groups, channels per deform group
+  float acc_scale;  // X3 only: accumulators x this before bias (1 = none)
 };
 
-template <int WCO, int WPOS, int TCO, int TPOS, bool DEFORM>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+// 4 f32 -> (hi, lo) binary16 quadruples; |v| beyond binary16's range saturates
+__device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float c = fminf(fmaxf(v[e], -65504.f), 65504.f);
+    const _Float16 h = (_Float16)c;
+    hi[e] = h;
+    lo[e] = (_Float16)(c - (float)h);
+  }
+}
+
+template <int WCO, int WPOS, int TCO, int TPOS, bool DEFORM, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvFArgs a) {
   constexpr int BCO = WCO * TCO * 32;
   constexpr int BPOS = WPOS * TPOS * 32;
@@ -158,6 +182,31 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvFArgs a) {
   auto store_tile = [&](int buf) {
     unsigned char* Wb = smem + buf * STAGE;
     unsigned char* Xb = Wb + BCO * 64;
+    if constexpr (X3) {
+      // row = [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15]; this thread's 4 floats are k = 4cj .. 4cj+3
+      const int hslot = cj >> 1, sub = (cj & 1) * 8;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const int r = r0 + 64 * i;
+        if (BCO >= 64 || r0 < BCO) {
+          half4 hi, lo;
+          split4(wreg[i], hi, lo);
+          const int sw = (r >> 2) & 3;
+          *reinterpret_cast<half4*>(Wb + r * 64 + ((hslot ^ sw) * 16) + sub) = hi;
+          *reinterpret_cast<half4*>(Wb + r * 64 + (((2 + hslot) ^ sw) * 16) + sub) = lo;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int r = r0 + 64 * i;
+        half4 hi, lo;
+        split4(xreg[i], hi, lo);
+        const int sw = (r >> 2) & 3;
+        *reinterpret_cast<half4*>(Xb + r * 64 + ((hslot ^ sw) * 16) + sub) = hi;
+        *reinterpret_cast<half4*>(Xb + r * 64 + (((2 + hslot) ^ sw) * 16) + sub) = lo;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       const int r = r0 + 64 * i;
@@ -185,6 +234,30 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvFArgs a) {
   const int xrow_off = BCO * 64 + (wpos * TPOS * 32 + l31) * 64;
   auto compute = [&](int buf) {
     const unsigned char* S = smem + buf * STAGE;
+    if constexpr (X3) {
+      // MFMA 32x32x16: a lane of half h supplies k = 8h .. 8h+7 of its row: slot h (hi) / 2 + h (lo)
+      const int sh = (khalf ^ rsw) * 16, sl = ((2 + khalf) ^ rsw) * 16;
+      half8 wh[TCO], wl[TCO], xh[TPOS], xl[TPOS];
+#pragma unroll
+      for (int t = 0; t < TCO; ++t) {
+        wh[t] = *reinterpret_cast<const half8*>(S + wrow_off + t * 32 * 64 + sh);
+        wl[t] = *reinterpret_cast<const half8*>(S + wrow_off + t * 32 * 64 + sl);
+      }
+#pragma unroll
+      for (int t = 0; t < TPOS; ++t) {
+        xh[t] = *reinterpret_cast<const half8*>(S + xrow_off + t * 32 * 64 + sh);
+        xl[t] = *reinterpret_cast<const half8*>(S + xrow_off + t * 32 * 64 + sl);
+      }
+#pragma unroll
+      for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TPOS; ++tp) {
+          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tc], xh[tp], acc[tc][tp], 0, 0, 0);
+          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[tc], xl[tp], acc[tc][tp], 0, 0, 0);
+          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[tc], xh[tp], acc[tc][tp], 0, 0, 0);
+        }
+      return;
+    }
     const int s0 = ((2 * khalf) ^ rsw) * 16, s1 = ((2 * khalf + 1) ^ rsw) * 16;
     f32x4 wf[TCO][2], xf[TPOS][2];
 #pragma unroll
@@ -254,6 +327,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvFArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = acc[tc][tp][4 * q + e];
+          if constexpr (X3) v[e] *= a.acc_scale;
           if (c0 + e < a.cout) {
             if (a.bias != nullptr) v[e] += a.bias[c0 + e];
             if (c0 + e < a.scale_nch) v[e] *= lscale;
@@ -358,9 +432,16 @@ int launch_conv_f32(const sm_conv_desc* d, const float* x, const float* offset, 
   a.scale_nch = d->scale_nch;
   a.dg = DEFORM ? d->deform_groups : 1;
   a.cpg = DEFORM ? d->cin / d->deform_groups : d->cin;
+  a.acc_scale = (d->acc_scale == 0.f) ? 1.f : d->acc_scale;
   const long long nblk = (long long)t * a.ntn;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
   dim3 grid((unsigned)nblk), block(256);
+  if (d->flags & SM_CONV_F16) {            // split-precision contraction of the f32 operands (X3 above): 128-cout tiles
+    if (tile != 128) return SM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((conv_f32_kernel<2, 2, 2, 2, DEFORM, true>), grid, block, 0, stream, a);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+  }
   if (tile == 128) hipLaunchKernelGGL((conv_f32_kernel<2, 2, 2, 2, DEFORM>), grid, block, 0, stream, a);
   else if (tile == 64) hipLaunchKernelGGL((conv_f32_kernel<1, 4, 2, 1, DEFORM>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL((conv_f32_kernel<1, 4, 1, 1, DEFORM>), grid, block, 0, stream, a);

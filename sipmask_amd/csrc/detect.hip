@@ -151,6 +151,7 @@ struct DetArgs {
   int nms_pre, img_h, img_w, kmax;
   float scale_factor[4];
   int rescale, reg_prescaled;
+  const float* per_image;  // [batch][6] = (img_h, img_w, scale_factor[4]) or nullptr (sm_det_desc.per_image)
   int topk_cache_floats;   // dynamic LDS floats available to det_topk_kernel (0 = scan global memory)
 };
 
@@ -221,17 +222,19 @@ __global__ __launch_bounds__(256) void det_gather_kernel(const float* __restrict
       const int s = a.stride[lev];
       const int py = pos / a.w[lev], px = pos - py * a.w[lev];
       const float x = (float)(px * s) + (float)(s / 2), y = (float)(py * s) + (float)(s / 2);
-      const float xmax = (float)(a.img_w - 1), ymax = (float)(a.img_h - 1);
+      // img_shape / scale_factor of THIS image (img_metas[img_id], sipmask_head.py:517-541) when a table is given
+      const float* pi = a.per_image != nullptr ? a.per_image + (long long)b * 6 : nullptr;
+      const float xmax = (pi ? pi[1] : (float)a.img_w) - 1.f, ymax = (pi ? pi[0] : (float)a.img_h) - 1.f;
       const float fs = a.reg_prescaled ? 1.f : (float)s;  // bbox_pred.float() * stride (sipmask_head.py:268)
       float x1 = fminf(fmaxf(__fsub_rn(x, __fmul_rn(rp[0], fs)), 0.f), xmax);
       float y1 = fminf(fmaxf(__fsub_rn(y, __fmul_rn(rp[1], fs)), 0.f), ymax);
       float x2 = fminf(fmaxf(__fadd_rn(x, __fmul_rn(rp[2], fs)), 0.f), xmax);
       float y2 = fminf(fmaxf(__fadd_rn(y, __fmul_rn(rp[3], fs)), 0.f), ymax);
       if (a.rescale) {
-        x1 /= a.scale_factor[0];
-        y1 /= a.scale_factor[1];
-        x2 /= a.scale_factor[2];
-        y2 /= a.scale_factor[3];
+        x1 /= pi ? pi[2] : a.scale_factor[0];
+        y1 /= pi ? pi[3] : a.scale_factor[1];
+        x2 /= pi ? pi[4] : a.scale_factor[2];
+        y2 /= pi ? pi[5] : a.scale_factor[3];
       }
       *reinterpret_cast<float4*>(boxes + o * 4) = make_float4(x1, y1, x2, y2);
       s_row[lc] = row;
@@ -337,7 +340,8 @@ __global__ __launch_bounds__(128) void pair_gather_kernel(const float* __restric
     const int s = a.stride[lev];
     const int py = pos / a.w[lev], px = pos - py * a.w[lev];
     const float x = (float)(px * s) + (float)(s / 2), y = (float)(py * s) + (float)(s / 2);
-    const float xmax = (float)(a.img_w - 1), ymax = (float)(a.img_h - 1);   // clip_to_image, TO_REMOVE = 1
+    const float* pi = a.per_image != nullptr ? a.per_image + (long long)b * 6 : nullptr;
+    const float xmax = (pi ? pi[1] : (float)a.img_w) - 1.f, ymax = (pi ? pi[0] : (float)a.img_h) - 1.f;   // clip_to_image, TO_REMOVE = 1
     const float fs = a.reg_prescaled ? 1.f : (float)s;                       // bbox_pred * fpn_strides[l] (sipmask.py:161)
     const float x1 = fminf(fmaxf(__fsub_rn(x, __fmul_rn(rp[0], fs)), 0.f), xmax);
     const float y1 = fminf(fmaxf(__fsub_rn(y, __fmul_rn(rp[1], fs)), 0.f), ymax);
@@ -754,6 +758,7 @@ int fill_det_args(const sm_det_desc* d, DetArgs& a) {
   for (int i = 0; i < 4; ++i) a.scale_factor[i] = d->scale_factor[i];
   a.rescale = d->rescale;
   a.reg_prescaled = d->reg_prescaled;
+  a.per_image = d->per_image;
   a.topk_cache_floats = 0;
   return SM_OK;
 }

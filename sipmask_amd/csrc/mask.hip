@@ -31,6 +31,7 @@ struct MaskArgs {
   int kmax, max_num, hm, wm, ho, wo, pitch;   // wo = logical width, pitch = row pitch of masks (multiple of 4)
   long long pix_stride, ch_stride;  // basis strides (elements)
   float box_mul_x, box_mul_y, box_div, inv_up_x, inv_up_y, thr;
+  const float* per_image;   // [batch][8] = (box_mul_x, box_mul_y, up_h, up_w, Ho, Wo, 1/up_h, 1/up_w) or nullptr
 };
 
 struct DetBox {
@@ -47,11 +48,21 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
   const int tid = threadIdx.x;
   const int nd = min(a.ndet[b], a.max_num);
   if (nd <= 0) return;
+  // this image's crop / upsample geometry (img_metas[img_id]['scale_factor'], sipmask_head.py:517-541,621-633); a.ho /
+  // a.pitch stay the canvas every mask plane is allocated with
+  float g_mul_x = a.box_mul_x, g_mul_y = a.box_mul_y, g_inv_up_x = a.inv_up_x, g_inv_up_y = a.inv_up_y;
+  int g_ho = a.ho, g_wo = a.wo;
+  if (a.per_image != nullptr) {
+    const float* g = a.per_image + (long long)b * 8;
+    g_mul_x = g[0], g_mul_y = g[1], g_inv_up_y = g[6], g_inv_up_x = g[7];
+    g_ho = min((int)g[4], a.ho), g_wo = min((int)g[5], a.wo);
+  }
+  if (ox0 >= g_wo || oy0 >= g_ho) return;          // (block-uniform) tile outside this image's mask
 
   // source window of this output tile
-  auto src_x = [&](int o) { return fmaxf(a.inv_up_x * ((float)o + 0.5f) - 0.5f, 0.f); };
-  auto src_y = [&](int o) { return fmaxf(a.inv_up_y * ((float)o + 0.5f) - 0.5f, 0.f); };
-  const int oxe = min(ox0 + TOW, a.wo) - 1, oye = min(oy0 + TOH, a.ho) - 1;
+  auto src_x = [&](int o) { return fmaxf(g_inv_up_x * ((float)o + 0.5f) - 0.5f, 0.f); };
+  auto src_y = [&](int o) { return fmaxf(g_inv_up_y * ((float)o + 0.5f) - 0.5f, 0.f); };
+  const int oxe = min(ox0 + TOW, g_wo) - 1, oye = min(oy0 + TOH, g_ho) - 1;
   const int sx0 = (int)src_x(ox0), sy0 = (int)src_y(oy0);
   const int sx1 = min((int)src_x(oxe) + 1, a.wm - 1), sy1 = min((int)src_y(oye) + 1, a.hm - 1);
   const int spw = sx1 - sx0 + 1, sph = sy1 - sy0 + 1;
@@ -99,10 +110,10 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
     if (tid < nn) {
       const float* d = a.det + ((long long)b * a.max_num + n0 + tid) * 5;
       DetBox bx;
-      bx.x1 = __fdiv_rn(__fmul_rn(d[0], a.box_mul_x), a.box_div);
-      bx.y1 = __fdiv_rn(__fmul_rn(d[1], a.box_mul_y), a.box_div);
-      bx.x2 = __fdiv_rn(__fmul_rn(d[2], a.box_mul_x), a.box_div);
-      bx.y2 = __fdiv_rn(__fmul_rn(d[3], a.box_mul_y), a.box_div);
+      bx.x1 = __fdiv_rn(__fmul_rn(d[0], g_mul_x), a.box_div);
+      bx.y1 = __fdiv_rn(__fmul_rn(d[1], g_mul_y), a.box_div);
+      bx.x2 = __fdiv_rn(__fmul_rn(d[2], g_mul_x), a.box_div);
+      bx.y2 = __fdiv_rn(__fmul_rn(d[3], g_mul_y), a.box_div);
       // roi_w = (x2 - x1 + 0.1) / num_cell in double, rounded to float (kernel.cu:47-48)
       bx.rw = (float)(((double)__fsub_rn(bx.x2, bx.x1) + 0.1) / 2.0);
       bx.rh = (float)(((double)__fsub_rn(bx.y2, bx.y1) + 0.1) / 2.0);
@@ -128,7 +139,7 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
           const int gi = tid + g * MA_THREADS;
           if (gi < GROUPS) {
             const int oy = oy0 + gi / (TOW / 4), ox = ox0 + (gi % (TOW / 4)) * 4;
-            if (oy < a.ho && ox < a.wo) *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.pitch + ox) = 0u;
+            if (oy < g_ho && ox < g_wo) *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.pitch + ox) = 0u;
           }
         }
         if (a.pos_masks) {
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
         const int gi = tid + g * MA_THREADS;
         if (gi >= GROUPS) continue;
         const int oy = oy0 + gi / (TOW / 4), oxb = ox0 + (gi % (TOW / 4)) * 4;
-        if (oy >= a.ho || oxb >= a.wo) continue;
+        if (oy >= g_ho || oxb >= g_wo) continue;
         const float sy = src_y(oy);
         const int y0 = (int)sy, y1 = min(y0 + 1, a.hm - 1);
         const float ly = sy - (float)y0, hy = 1.f - ly;
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(MA_THREADS) void mask_assemble_kernel(const MaskArg
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int ox = oxb + e;
-          if (ox < a.wo) {
+          if (ox < g_wo) {
             const float sx = src_x(ox);
             const int x0 = (int)sx, x1 = min(x0 + 1, a.wm - 1);
             const float lx = sx - (float)x0, hx = 1.f - lx;
@@ -223,7 +234,7 @@ extern "C" int sm_mask_assemble(const float* basis, int basis_hwc, const float* 
                                 const float* det, const int32_t* ndet, int batch, int kmax, int max_num, int hm,
                                 int wm, int ho, int wo, int mask_pitch, float box_mul_x, float box_mul_y, float box_div, double up_scale_h,
                                 double up_scale_w, float mask_thr,
-                                uint8_t* masks, float* pos_masks, sm_stream_t stream) {
+                                uint8_t* masks, float* pos_masks, const float* per_image, sm_stream_t stream) {
   if (!basis || !cofs || !keep || !det || !ndet || !masks) return SM_ERR_BAD_ARG;
   if (batch < 1 || hm < 1 || wm < 1 || ho < 1 || wo < 1 || mask_pitch % 4 != 0 || mask_pitch < wo || !(up_scale_h > 0) || !(up_scale_w > 0))
     return SM_ERR_BAD_SHAPE;
@@ -250,6 +261,7 @@ extern "C" int sm_mask_assemble(const float* basis, int basis_hwc, const float* 
   a.inv_up_x = (float)(1.0 / up_scale_w);  // area_pixel_compute_scale with an explicit scale_factor
   a.inv_up_y = (float)(1.0 / up_scale_h);
   a.thr = mask_thr;
+  a.per_image = per_image;   // (the scalar up_scale then bounds the tile's source window: pass the batch's SMALLEST)
   hipStream_t s = sm_hip_stream(stream);
   // pick the widest output tile whose source window (TOW/up + 3) x (TOH/up + 3) fits the
   // per-thread ownership (512 source pixels); wide tiles = full-line mask stores

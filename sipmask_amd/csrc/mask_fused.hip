@@ -42,7 +42,27 @@ struct MaskFArgs {
   int batch, kmax, max_num, lo_h, lo_w, factor, hm, wm, ho, wo, pitch;
   float box_mul_x, box_mul_y, box_div, up_x, up_y, inv_up_x, inv_up_y, inv_f, thr;
   int src_cap, lo_cap;     // floats of the dynamic LDS tiles (mask_lo_caps)
+  const float* per_image;  // [batch][8] = (box_mul_x, box_mul_y, up_h, up_w, Ho, Wo, 1/up_h, 1/up_w) or nullptr
 };
+
+// geometry of image b: the shared scalars, or this image's row of the per-image table (img_metas[img_id]['scale_factor'],
+// sipmask_head.py:517-541,621-633); a.ho / a.wo / a.pitch remain the canvas the mask planes are allocated with
+struct MfGeom {
+  float mul_x, mul_y, up_x, up_y, inv_up_x, inv_up_y;
+  int ho, wo;
+};
+__device__ __forceinline__ MfGeom mf_geom(const MaskFArgs& a, int b) {
+  MfGeom g;
+  g.mul_x = a.box_mul_x, g.mul_y = a.box_mul_y, g.up_x = a.up_x, g.up_y = a.up_y;
+  g.inv_up_x = a.inv_up_x, g.inv_up_y = a.inv_up_y, g.ho = a.ho, g.wo = a.wo;
+  if (a.per_image != nullptr) {
+    const float* t = a.per_image + (long long)b * 8;
+    g.mul_x = t[0], g.mul_y = t[1], g.up_y = t[2], g.up_x = t[3];
+    g.ho = min((int)t[4], a.ho), g.wo = min((int)t[5], a.wo);
+    g.inv_up_y = t[6], g.inv_up_x = t[7];
+  }
+  return g;
+}
 
 // ---- plan: per slot the tile range of the new rectangle (mask_rects_kernel's conservative rule, rle.hip) and of the
 // previous call's; entry 2d = new tiles, 2d+1 = previous tiles; exclusive prefix sum of the tile counts.
@@ -71,13 +91,14 @@ __global__ __launch_bounds__(1024) void mask_plan_kernel(const MaskFArgs a) {
         const int b = d / a.max_num, i = d - b * a.max_num;
         r[0] = r[1] = r[2] = r[3] = 0;
         if (i < min(a.ndet[b], a.max_num)) {
+          const MfGeom G = mf_geom(a, b);
           const float* bx = a.det + (long long)d * 5;
-          const float x1 = bx[0] * a.box_mul_x / a.box_div, y1 = bx[1] * a.box_mul_y / a.box_div;
-          const float x2 = bx[2] * a.box_mul_x / a.box_div, y2 = bx[3] * a.box_mul_y / a.box_div;
+          const float x1 = bx[0] * G.mul_x / a.box_div, y1 = bx[1] * G.mul_y / a.box_div;
+          const float x2 = bx[2] * G.mul_x / a.box_div, y2 = bx[3] * G.mul_y / a.box_div;
           auto lo = [&](float v, float up) { return (int)fmaxf(fminf(floorf((v - 1.f) * up) - 2.f, 1e9f), -1e9f); };
           auto hi = [&](float v, float up) { return (int)fmaxf(fminf(ceilf((v + 1.f) * up) + 2.f, 1e9f), -1e9f); };
-          const int px0 = max(lo(x1, a.up_x), 0), py0 = max(lo(y1, a.up_y), 0);
-          const int px1 = min(hi(x2, a.up_x), a.wo), py1 = min(hi(y2, a.up_y), a.ho);
+          const int px0 = max(lo(x1, G.up_x), 0), py0 = max(lo(y1, G.up_y), 0);
+          const int px1 = min(hi(x2, G.up_x), G.wo), py1 = min(hi(y2, G.up_y), G.ho);
           if (px1 > px0 && py1 > py0) {
             r[0] = px0 / MF_TW;
             r[1] = py0 / MF_TH;
@@ -129,8 +150,6 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
   for (int i = tid; i <= n2; i += MF_THREADS) s_prefix[i] = a.prefix[i];
   __syncthreads();
   const int total = s_prefix[n2];
-  auto src_x = [&](int o) { return fmaxf(a.inv_up_x * ((float)o + 0.5f) - 0.5f, 0.f); };
-  auto src_y = [&](int o) { return fmaxf(a.inv_up_y * ((float)o + 0.5f) - 0.5f, 0.f); };
   auto lo_c = [&](int g) { return fmaxf(a.inv_f * ((float)g + 0.5f) - 0.5f, 0.f); };   // mask-res -> conv-res coordinate
 
   for (int w = blockIdx.x; w < total; w += gridDim.x) {
@@ -159,6 +178,9 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
       continue;
     }
     const int b = d / a.max_num;
+    const MfGeom G = mf_geom(a, b);                    // block-uniform: this image's crop / upsample geometry
+    auto src_x = [&](int o) { return fmaxf(G.inv_up_x * ((float)o + 0.5f) - 0.5f, 0.f); };
+    auto src_y = [&](int o) { return fmaxf(G.inv_up_y * ((float)o + 0.5f) - 0.5f, 0.f); };
     __syncthreads();   // previous tile of this block is done with the LDS tiles
     if (tid < 32) {
       const long long src = ((long long)b * a.kmax + a.keep[d]) * 128;
@@ -167,15 +189,15 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
     FBox bx;
     {
       const float* dd = a.det + (long long)d * 5;
-      bx.x1 = __fdiv_rn(__fmul_rn(dd[0], a.box_mul_x), a.box_div);
-      bx.y1 = __fdiv_rn(__fmul_rn(dd[1], a.box_mul_y), a.box_div);
-      bx.x2 = __fdiv_rn(__fmul_rn(dd[2], a.box_mul_x), a.box_div);
-      bx.y2 = __fdiv_rn(__fmul_rn(dd[3], a.box_mul_y), a.box_div);
+      bx.x1 = __fdiv_rn(__fmul_rn(dd[0], G.mul_x), a.box_div);
+      bx.y1 = __fdiv_rn(__fmul_rn(dd[1], G.mul_y), a.box_div);
+      bx.x2 = __fdiv_rn(__fmul_rn(dd[2], G.mul_x), a.box_div);
+      bx.y2 = __fdiv_rn(__fmul_rn(dd[3], G.mul_y), a.box_div);
       bx.rw = (float)(((double)__fsub_rn(bx.x2, bx.x1) + 0.1) / 2.0);   // crop_split_cuda_kernel.cu:47-48
       bx.rh = (float)(((double)__fsub_rn(bx.y2, bx.y1) + 0.1) / 2.0);
     }
     // mask-resolution source window of the tile (as sm_mask_assemble) and the conv-resolution window under it
-    const int oxe = min(ox0 + MF_TW, a.wo) - 1, oye = min(oy0 + MF_TH, a.ho) - 1;
+    const int oxe = min(ox0 + MF_TW, G.wo) - 1, oye = min(oy0 + MF_TH, G.ho) - 1;
     const int sx0 = (int)src_x(ox0), sy0 = (int)src_y(oy0);
     const int sx1 = min((int)src_x(oxe) + 1, a.wm - 1), sy1 = min((int)src_y(oye) + 1, a.hm - 1);
     const int spw = sx1 - sx0 + 1, sph = sy1 - sy0 + 1;
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
     // (3) image-resolution bilinear + threshold, 4 pixels per 32-bit store
     for (int gi = tid; gi < GROUPS; gi += MF_THREADS) {
       const int oy = oy0 + gi / (MF_TW / 4), oxb = ox0 + (gi % (MF_TW / 4)) * 4;
-      if (oy >= a.ho || oxb >= a.wo) continue;
+      if (oy >= G.ho || oxb >= G.wo) continue;
       const float sy = src_y(oy);
       const int y0 = (int)sy, y1 = min(y0 + 1, a.hm - 1);
       const float ly = sy - (float)y0, hy = 1.f - ly;
@@ -240,7 +262,7 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int ox = oxb + k;
-        if (ox < a.wo) {
+        if (ox < G.wo) {
           const float sx = src_x(ox);
           const int x0 = (int)sx, x1 = min(x0 + 1, a.wm - 1);
           const float lx = sx - (float)x0, hx = 1.f - lx;
@@ -283,7 +305,7 @@ extern "C" int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, in
                                    const int64_t* keep, const float* det, const int32_t* ndet, int batch, int kmax,
                                    int max_num, int ho, int wo, int mask_pitch, float box_mul_x, float box_mul_y,
                                    float box_div, double up_scale_h, double up_scale_w, float mask_thr, uint8_t* masks,
-                                   int32_t* state, void* workspace, sm_stream_t stream) {
+                                   int32_t* state, void* workspace, const float* per_image, sm_stream_t stream) {
   if (!basis_lo || !cofs || !keep || !det || !ndet || !masks || !state || !workspace) return SM_ERR_BAD_ARG;
   if (batch < 1 || max_num < 1 || lo_h < 1 || lo_w < 1 || factor < 1 || ho < 1 || wo < 1 || mask_pitch % 4 != 0 ||
       mask_pitch < wo || !(up_scale_h > 0) || !(up_scale_w > 0) || !(box_div != 0.f))
@@ -320,8 +342,9 @@ extern "C" int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, in
   a.inv_up_y = (float)(1.0 / up_scale_h);
   a.inv_f = 1.f / (float)factor;
   a.thr = mask_thr;
-  a.src_cap = src_cap;
+  a.src_cap = src_cap;       // (with a per-image table the scalar up_scale must be the batch's SMALLEST: it sizes the LDS tiles)
   a.lo_cap = lo_cap;
+  a.per_image = per_image;
   hipStream_t s = sm_hip_stream(stream);
   hipLaunchKernelGGL(mask_plan_kernel, dim3(1), dim3(1024), 0, s, a);
   hipLaunchKernelGGL(mask_fused_kernel, dim3(2048), dim3(MF_THREADS), (size_t)(src_cap + 4 * lo_cap) * sizeof(float), s, a);

@@ -308,10 +308,14 @@ __global__ __launch_bounds__(RLE_THREADS) void rle_pack_kernel(const uint32_t* _
 
 // Conservative output-pixel rectangle outside which sm_mask_assemble wrote zeros: the crop keeps half-resolution
 // pixels inside box*mul/div (crop_split_cuda_kernel.cu:45), bilinear x`up` reads two neighbours per axis.
-__global__ void mask_rects_kernel(const float* __restrict__ det, int n, float mul_x, float mul_y, float div, float up_y,
-                                  float up_x, int32_t* __restrict__ rect) {
+__global__ void mask_rects_kernel(const float* __restrict__ det, int n, int max_num, float mul_x, float mul_y, float div,
+                                  float up_y, float up_x, int32_t* __restrict__ rect, const float* __restrict__ per_image) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= n) return;
+  if (per_image != nullptr) {                     // this image's geometry (see sm_mask_assemble)
+    const float* g = per_image + (long long)(d / max_num) * 8;
+    mul_x = g[0], mul_y = g[1], up_y = g[2], up_x = g[3];
+  }
   const float* b = det + (long long)d * 5;
   const float x1 = b[0] * mul_x / div, y1 = b[1] * mul_y / div, x2 = b[2] * mul_x / div, y2 = b[3] * mul_y / div;
   auto lo = [&](float v, float up) { return (int)fmaxf(fminf(floorf((v - 1.f) * up) - 2.f, 1e9f), -1e9f); };
@@ -336,12 +340,13 @@ extern "C" int64_t sm_rle_workspace(int batch, int max_num, int canvas_w, int ma
 }
 
 extern "C" int sm_mask_rects(const float* det, int batch, int max_num, float box_mul_x, float box_mul_y, float box_div,
-                             double up_scale_h, double up_scale_w, int32_t* rect, sm_stream_t stream) {
+                             double up_scale_h, double up_scale_w, int32_t* rect, const float* per_image,
+                             sm_stream_t stream) {
   if (!det || !rect) return SM_ERR_BAD_ARG;
   if (batch < 1 || max_num < 1 || !(up_scale_h > 0) || !(up_scale_w > 0) || !(box_div != 0.f)) return SM_ERR_BAD_SHAPE;
   const int n = batch * max_num;
-  hipLaunchKernelGGL(mask_rects_kernel, dim3((n + 255) / 256), dim3(256), 0, sm_hip_stream(stream), det, n, box_mul_x,
-                     box_mul_y, box_div, (float)up_scale_h, (float)up_scale_w, rect);
+  hipLaunchKernelGGL(mask_rects_kernel, dim3((n + 255) / 256), dim3(256), 0, sm_hip_stream(stream), det, n, max_num, box_mul_x,
+                     box_mul_y, box_div, (float)up_scale_h, (float)up_scale_w, rect, per_image);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

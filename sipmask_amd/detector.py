@@ -50,9 +50,12 @@ class SipMask(nn.Module):
         if head is not None:
             head.invalidate()
 
-    def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False, precision="bf16", lanes="auto"):
+    def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False, precision="bf16", lanes="auto",
+                scale_factor_max=None):
         """Build (or fetch) the static launch plan for this input geometry; weights are snapshotted,
         BN folded, re-laid out as bf16 GEMM operands.  Call again after load_state_dict.
+        img_shape / scale_factor are the DEFAULT metas of every image; plan.set_image_metas(img_metas) gives each image
+        its own before a run (scale_factor then sizes the mask canvas: the batch's smallest; scale_factor_max: its largest).
         scale_factor / rescale: img_meta['scale_factor'] and the rescale flag of simple_test (boxes and masks
         in original-image coordinates, sipmask_head.py:587-588,621-632).  precision: "bf16" = the throughput plan,
         "f32" = the parity plan (exact-f32 MFMA convs, every tensor f32: held to the fp32 reference within
@@ -61,7 +64,8 @@ class SipMask(nn.Module):
         import numpy as np
         from .engine import SipMaskEngine
         key = (batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
-               rescale, precision, lanes)
+               rescale, precision, lanes,
+               None if scale_factor_max is None else tuple(np.asarray(scale_factor_max, np.float64).reshape(-1)))
         # plans are valid for the weights they were built from: PlanCache drops them when any parameter / buffer has
         # been updated in place since (optimizer.step, load_state_dict, mmcv load_checkpoint)
         if lanes == "auto":        # SubBatchPlan: two concurrent half-batch chains pay off from 2 images per chain on
@@ -73,19 +77,45 @@ class SipMask(nn.Module):
             mk = lambda b: SipMaskEngine(sd, b, img_hw, self.backbone.depth, self.test_cfg, self.bbox_head.num_classes,
                                          strides=self.bbox_head.strides, img_shape=img_shape,
                                          ssd_flag=self.bbox_head.ssd_flag, scale_factor=scale_factor, rescale=rescale,
-                                         precision=precision, sub_plan=lanes > 1)
+                                         precision=precision, sub_plan=lanes > 1, scale_factor_max=scale_factor_max)
             if lanes == 1:
                 return mk(batch)
             from .engine import SubBatchPlan
             return SubBatchPlan([mk(batch // lanes) for _ in range(lanes)])
         return self._engines.get(key, module_tensors(self), build)
 
-    def get_masks(self, img, img_metas=None):
+    def plan_for_metas(self, batch, img_hw, img_metas, rescale=False, precision="bf16", lanes="auto"):
+        """The launch plan for a batch whose images carry their OWN img_shape / scale_factor (a keep_ratio pipeline:
+        every image of a batch is resized by a different factor; the reference reads img_metas[img_id],
+        sipmask_head.py:517-541).  The plan depends on the batch only through the mask canvas (the smallest scale_factor)
+        and the kernels' source-window bound (the largest), both rounded outward to 1/16 so that consecutive batches of
+        an evaluation run share plans; the per-image values go to the device tables (set_image_metas)."""
+        import numpy as np
+        sfl = [np.asarray(m.get('scale_factor', 1.0), np.float64).reshape(-1) for m in img_metas]
+        if any(a.size not in (1, 4) for a in sfl):
+            raise ValueError("scale_factor is a scalar (keep_ratio) or [w, h, w, h]")
+        scalar = all(a.size == 1 for a in sfl)
+        sfs = np.stack([np.broadcast_to(a, (4,)) for a in sfl])
+        lo = np.maximum(np.floor(sfs.min(0) * 16.0) / 16.0, 1.0 / 16.0)
+        hi = np.ceil(sfs.max(0) * 16.0) / 16.0
+        if scalar:
+            lo, hi = float(lo[0]), float(hi[0])
+        else:
+            lo, hi = lo.astype(np.float32), hi.astype(np.float32)
+        plan = self.prepare(batch, img_hw, None, lo, rescale, precision, lanes, scale_factor_max=hi)
+        return plan.set_image_metas(img_metas)
+
+    def get_masks(self, img, img_metas=None, rescale=False):
         """Batch-capable tensor-only inference (compare before RLE): dict of device tensors
-        det_bboxes [B,max,5], det_labels [B,max], idxs_keep [B,max], ndet [B], masks u8 [B,max,H,W]."""
-        shape = None if not img_metas else tuple(img_metas[0]['img_shape'])
-        eng = self.prepare(img.shape[0], tuple(img.shape[-2:]), shape)
-        return eng.run(img)
+        det_bboxes [B,max,5], det_labels [B,max], idxs_keep [B,max], ndet [B], masks u8 [B,max,Hc,Wc] on the batch's
+        canvas, and "out_hw": every image's own (Ho, Wo) -- its masks are masks[b, :ndet[b], :Ho, :Wo]."""
+        if not img_metas:
+            eng = self.prepare(img.shape[0], tuple(img.shape[-2:]))
+        else:
+            eng = self.plan_for_metas(img.shape[0], tuple(img.shape[-2:]), img_metas, rescale)
+        r = dict(eng.run(img))
+        r["out_hw"] = list(eng.out_hw)
+        return r
 
     def simple_test(self, img, img_meta, rescale=False):
         """single_stage.py:75-96: returns (bbox_results, segm_results) of image 0; segm_results[label] is the

@@ -40,6 +40,11 @@ _FUSE_BOTTLENECK = int(__import__("os").environ.get("SIPMASK_FUSE_BOTTLENECK", "
 _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"   # A/B: relu(P6) copy vs input-ReLU flag
 
 
+# FeatureAlign's deformable conv in the x3 head plan: "f32x3" = f32 rows, operands split in the loader, f16 MFMAs (default);
+# "f32" = the exact-f32 MFMA kernel (A/B)
+_X3_FEAT_ALIGN = __import__("os").environ.get("SIPMASK_X3_FEAT_ALIGN", "f32x3")
+
+
 def _lib_flag(name):
     return getattr(_lib, name)
 BF16 = torch.bfloat16
@@ -72,12 +77,20 @@ class _Conv:
         self.name = name
         self.mode = mode or ("f32" if getattr(eng, "precision", "bf16") == "f32" else "bf16")
         # exact-f32 plan (parity mode): f32 operands on v_mfma_f32_32x32x2_f32, every conv output f32
-        self.f32 = self.mode == "f32"
+        self.f32 = self.mode in ("f32", "f32x3")            # f32 tensors in HBM: csrc/conv_f32.hip
         self.x3 = self.mode == "x3"
         acc_scale = 0.0
         if self.f32:
             cin = cin_pad = ci if ci % 4 == 0 else (ci + 3) // 4 * 4
-            self.w, co_pad = H.prep_conv_weight_f32(w.to(dev), cin)
+            if self.mode == "f32x3":
+                # the same kernel with the contraction in split precision (operands split into binary16 halves in the
+                # loader, three f16 MFMAs per product): FeatureAlign's deformable conv in the x3 head plan
+                self.x3_scale = H.x3_weight_scale([w])
+                self.w, co_pad = H.prep_conv_weight_f32(w.to(dev).float() * self.x3_scale, cin)
+                flags |= _lib.SM_CONV_F16
+                acc_scale = 1.0 / self.x3_scale
+            else:
+                self.w, co_pad = H.prep_conv_weight_f32(w.to(dev), cin)
         elif self.x3:
             if offset is not None or residual is not None or cin_pad is not None or ci % 8 != 0:
                 raise NotImplementedError("x3 convs: plain convolutions over 8-aligned channel counts")
@@ -130,7 +143,7 @@ class _Conv:
             pl = H.conv_plan(self.desc)
             if pl["split_k"] > 1:
                 self.ws = torch.empty(pl["workspace_bytes"], dtype=torch.uint8, device=dev)
-        kin = 3 if self.x3 else 1                                   # MFMA work: three half products per element product
+        kin = 3 if (self.x3 or self.mode == "f32x3") else 1         # MFMA work: three half products per element product
         self.flops = 2.0 * sum(batch * h * ww for h, ww in out_sizes) * co * ci * k * k
         self.mfma_flops = self.flops * kin
         # algorithmic HBM bytes: x read once + y written once (+ residual read) + weights
@@ -262,7 +275,7 @@ class SipMaskEngine:
 
     def __init__(self, state_dict, batch, img_hw, depth=50, test_cfg=None, num_classes=81, device="cuda",
                  strides=(8, 16, 32, 64, 128), img_shape=None, head_sizes=None, ssd_flag=False, scale_factor=1.0,
-                 rescale=False, vis=False, benchmark=None, precision="bf16", sub_plan=False):
+                 rescale=False, vis=False, benchmark=None, precision="bf16", sub_plan=False, scale_factor_max=None):
         _lib.load()   # fail loudly before anything else if the HIP library is missing
         # sub_plan: this engine is one chain of a SubBatchPlan -- the other chain fills the CUs a short launch leaves
         # idle, so split-K (an extra reduce launch to fill them) only costs: 966 vs 962 img/s (profiles/r02e_ab_subplans.json)
@@ -294,6 +307,10 @@ class SipMaskEngine:
         self.img_shape = img_shape or (self.H, self.W, 3)
         # ssd_flag configs: fast_nms + per-axis mask upsampling (sipmask_head.py:594-605,629-630)
         self.ssd_flag, self.scale_factor, self.rescale = bool(ssd_flag), scale_factor, rescale
+        # img_shape / scale_factor are the DEFAULT of every image; set_image_metas() gives each image its own before a
+        # run (sipmask_head.py:517-541).  The mask canvas is sized for `scale_factor` (pass the SMALLEST the plan will
+        # see: masks are upsampled by 2 / scale_factor), the kernels' source windows for `scale_factor_max`.
+        self.scale_factor_max = scale_factor if scale_factor_max is None else scale_factor_max
         # SipMask-VIS head (V/mmdet/models/anchor_heads/sipmask_head.py): track branch, always fast_nms with
         # cfg.max_per_img, mask threshold 0.5, crop/upsample scaled only when rescale (:734-764)
         self.vis = bool(vis)
@@ -589,7 +606,7 @@ class SipMaskEngine:
         f16 instruction (SM_CONV_F16): three half products per element product, f32 accumulation, ~2^-21 per product.
         GroupNorm statistics come out of the conv epilogues as before (fixed point); the normalise pass writes the next
         layer's split operand (and f32 rows where a consumer wants them).  FeatureAlign's deformable conv -- the one
-        operand VALU has to touch -- runs on the exact-f32 MFMA kernel (csrc/conv_f32.hip) on f32 rows."""
+        operand VALU has to produce -- reads f32 rows and splits the blended samples in its loader (csrc/conv_f32.hip, X3)."""
         B, lv, dev, h = self.batch, self.lv, self.device, prefix
         self._sd, self._sd_keys = sd, set(sd.keys())
         sizes, row0, rows = lv.sizes, lv.row0, lv.rows
@@ -698,7 +715,7 @@ class SipMaskEngine:
         self._add_conv(_Conv(self, "head.feat_align", sd[h + "feat_align.conv_adaption.weight"],
                              sd.get(h + "feat_align.conv_adaption.bias"), B, sizes, row0, self.cls_feat, 256, 1, 1,
                              self.aligned, row0, 256, deform_groups=4, offset=self.offsets,
-                             flags=(0 if self.flag_norm else SM_CONV_RELU), mode="f32"))
+                             flags=(0 if self.flag_norm else SM_CONV_RELU), mode=_X3_FEAT_ALIGN))
         aligned_x3 = torch.empty(rows, 768, dtype=F16, device=dev)
         if self.flag_norm:
             gam, bet = par(h + "feat_align.norm.weight"), par(h + "feat_align.norm.bias")
@@ -924,9 +941,19 @@ class SipMaskEngine:
         self.max_num = 100 if (self.ssd_flag and not self.vis) else cfg["max_per_img"]
         self.nms_out = H.multiclass_nms_alloc(B, self.det_desc.kmax, self.ncls, self.max_num, self.device)
         geo_rescale = (True if self.rescale else None) if self.vis else self.rescale
-        self.box_mul, self.up, (self.ho, self.wo) = H.post_geometry(self.hm, self.wm, self.scale_factor, geo_rescale,
-                                                                    self.ssd_flag)
+        self._geo_rescale = geo_rescale
+        self.box_mul, up_canvas, (self.ho, self.wo) = H.post_geometry(self.hm, self.wm, self.scale_factor, geo_rescale,
+                                                                      self.ssd_flag)
+        # scalar up_scale of the launches = the smallest any image may bring: it sizes the kernels' source windows
+        _, self.up, _ = H.post_geometry(self.hm, self.wm, self.scale_factor_max, geo_rescale, self.ssd_flag)
+        self.up = (min(self.up[0], up_canvas[0]), min(self.up[1], up_canvas[1]))
         self.pitch = (self.wo + 3) // 4 * 4
+        # per-image tables (img_shape, scale_factor | crop / upsample geometry), read by det_select / mask assembly /
+        # mask_rects; filled with the plan's defaults, rewritten by set_image_metas()
+        self.det_tab = torch.zeros(B, 6, dtype=torch.float32, device=self.device)
+        self.geom_tab = torch.zeros(B, 8, dtype=torch.float32, device=self.device)
+        self.det_desc.per_image = self.det_tab.data_ptr()
+        self.set_image_metas([dict(img_shape=self.img_shape, scale_factor=self.scale_factor)] * B)
         self.rescorer = None
         if ("bbox_head.convs_scoring.0.conv.weight") in self._sd_keys:
             self.rescorer = MaskRescorer(self._sd, "bbox_head.", B, self.max_num, self.hm, self.wm, self.device)
@@ -959,11 +986,13 @@ class SipMaskEngine:
             h0, w0 = self._basis_h0w0
             self._add("mask_assemble", lambda: H.mask_assemble_lo(
                 self.basis_lo, h0, w0, 4, self.sel["cofs"], self.nms_out["keep"], self.nms_out["det"],
-                self.nms_out["ndet"], self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, self.mask_buf))
+                self.nms_out["ndet"], self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, self.mask_buf,
+                per_image=self.geom_tab))
         else:
             self._add("mask_assemble", lambda: H.mask_assemble(
                 self._basis, True, self.sel["cofs"], self.nms_out["keep"], self.nms_out["det"], self.nms_out["ndet"],
-                self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, self.masks, pos))
+                self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, self.masks, pos,
+                per_image=self.geom_tab))
         if self.rescorer is not None:
             self._add("rescore", lambda: self.rescorer.run(self.nms_out["labels"], self.nms_out["det"],
                                                            self.nms_out["ndet"]))
@@ -975,6 +1004,27 @@ class SipMaskEngine:
             self._add("track_gather", lambda: H.track_gather(
                 self.track_feats, self.nms_out["det"], self.nms_out["ndet"], lv.sizes[0][0], lv.sizes[0][1],
                 sfv if self.rescale else 1.0, self.det_feats))
+
+    def set_image_metas(self, img_metas):
+        """img_metas[i]['img_shape'] / ['scale_factor'] of the images of the NEXT run() (the reference reads them per image:
+        sipmask_head.py:517-541,579,587-588,621-633).  Two small host->device copies into the tables the kernels read;
+        call it outside a captured graph.  Every image's mask (floor(Hm * 2 / scale_factor)) must fit the plan's canvas
+        and its scale_factor must not exceed scale_factor_max (prepare() / SipMask.get_masks choose both from the batch)."""
+        if self.benchmark:
+            raise NotImplementedError("the maskrcnn-benchmark post-processor takes one geometry per plan")
+        if len(img_metas) != self.batch:
+            raise ValueError("%d img_metas for a plan of %d images" % (len(img_metas), self.batch))
+        det, geom, canvas, up_min = H.image_geometry_tables(img_metas, self.hm, self.wm, self._geo_rescale, self.ssd_flag)
+        if canvas[0] > self.ho or canvas[1] > self.wo:
+            raise ValueError("a mask of %dx%d does not fit the plan's %dx%d canvas: prepare() with the batch's smallest "
+                             "scale_factor" % (canvas[0], canvas[1], self.ho, self.wo))
+        if up_min[0] < self.up[0] * (1 - 1e-6) or up_min[1] < self.up[1] * (1 - 1e-6):
+            raise ValueError("scale_factor above the plan's scale_factor_max (%r): prepare() with the batch's largest" %
+                             (self.scale_factor_max,))
+        self.det_tab.copy_(det)
+        self.geom_tab.copy_(geom)
+        self.out_hw = [(int(g[4]), int(g[5])) for g in geom]
+        return self
 
     # -------------------------------------------------------------------------------- execution
     def run(self, img):
@@ -998,11 +1048,26 @@ class SipMaskEngine:
         """Result packing on device (sipmask_head.py:645-657 without the per-mask D2H): run-length encodes the
         masks of the last run() on the current stream, restricted to each detection's box (sm_mask_rects).
         Returns per image the list of RLE dicts (fetch=True: two small D2H copies) or the device buffers."""
+        per_img = canvas_hw is not None and isinstance(canvas_hw[0], (tuple, list))
+        if per_img or any(hw != (self.ho, self.wo) for hw in getattr(self, "out_hw", [])):
+            # images with their own mask size / canvas (set_image_metas): one launch per image over its sub-view (result
+            # packing is outside the timed path)
+            from . import ops as P
+            rect = torch.zeros(self.batch * self.max_num, 4, dtype=torch.int32, device=self.device)
+            H.mask_rects(self.nms_out["det"], self.box_mul, 2.0, self.up, rect, per_image=self.geom_tab)
+            out = []
+            for b in range(self.batch):
+                ho, wo = self.out_hw[b]
+                cv = tuple(canvas_hw[b]) if per_img else tuple(canvas_hw or self.img_shape[:2])
+                out += P.encode_masks(self.masks[b:b + 1, :, :ho, :wo].contiguous(), self.nms_out["ndet"][b:b + 1], cv,
+                                      rect.view(self.batch, self.max_num, 4)[b].contiguous(), max_runs=max_runs)
+            return out
         canvas_hw = tuple(canvas_hw or self.img_shape[:2])
         if getattr(self, "_rle", None) is None or self._rle["canvas_w"] != canvas_hw[1] or \
                 self._rle["max_runs"] < max_runs:
             self._rle = H.rle_alloc(self.batch, self.max_num, canvas_hw[1], self.device, max_runs=max_runs)
-        H.mask_rects(self.nms_out["det"], self.box_mul, 2.0, self.up, self._rle["rect"])
+        H.mask_rects(self.nms_out["det"], self.box_mul, 2.0, self.up, self._rle["rect"],
+                     per_image=None if self.benchmark else self.geom_tab)
         H.rle_encode(self.masks, self.nms_out["ndet"], canvas_hw, self._rle, self._rle["rect"])
         if not fetch:
             return self._rle
@@ -1074,6 +1139,16 @@ class SubBatchPlan:
                 e.det_feats = self.det_feats[sl]
             b0 += e.batch
         self.streams = [torch.cuda.Stream(device=dev) for _ in engines[1:]]
+        self.out_hw = [hw for e in engines for hw in getattr(e, "out_hw", [])]
+
+    def set_image_metas(self, img_metas):
+        """per-image img_shape / scale_factor (SipMaskEngine.set_image_metas) for every chain's slice of the batch"""
+        b0 = 0
+        for e in self.engines:
+            e.set_image_metas(img_metas[b0:b0 + e.batch])
+            b0 += e.batch
+        self.out_hw = [hw for e in self.engines for hw in e.out_hw]
+        return self
 
     def run(self, img):
         assert img.shape[0] == self.batch
@@ -1162,9 +1237,11 @@ class SubBatchPlan:
 
     def encode_rle(self, canvas_hw=None, fetch=True, max_runs=8192):
         assert fetch, "device-side RLE buffers are per sub-plan"
-        out = []
+        per_img = canvas_hw is not None and isinstance(canvas_hw[0], (tuple, list))
+        out, b0 = [], 0
         for e in self.engines:
-            out.extend(e.encode_rle(canvas_hw, True, max_runs))
+            out.extend(e.encode_rle(canvas_hw[b0:b0 + e.batch] if per_img else canvas_hw, True, max_runs))
+            b0 += e.batch
         return out
 
     @property
@@ -1197,20 +1274,21 @@ class PostProcessor:
                               torch.zeros(lv.rows, 3, device=dev)], 1).contiguous()
         self.basis = feat_masks.detach().float().contiguous()           # [B,32,Hm,Wm]
         self.hm, self.wm = self.basis.shape[-2:]
-        import numpy as np
-        meta = img_metas[0]
-        for m in img_metas[1:]:
-            if tuple(m['img_shape']) != tuple(meta['img_shape']) or \
-                    not np.array_equal(np.asarray(m['scale_factor']), np.asarray(meta['scale_factor'])):
-                raise NotImplementedError("a batch must share img_shape / scale_factor (one launch plan)")
-        sf = meta['scale_factor']
+        # every image brings its own img_shape / scale_factor (sipmask_head.py:517-541: get_bboxes_single is called with
+        # img_metas[img_id]): the kernels read them from two small per-image device tables
         self.cfg, self.ssd_flag, self.vis = cfg, bool(ssd_flag), bool(vis)
         self.mask_thr = 0.5 if self.vis else 0.4                      # V/...:764 vs sipmask_head.py:633
         geo_rescale = (True if rescale else None) if self.vis else rescale
-        self.box_mul, self.up, (self.ho, self.wo) = H.post_geometry(self.hm, self.wm, sf, geo_rescale, self.ssd_flag)
+        det_tab, geom_tab, (self.ho, self.wo), self.up = H.image_geometry_tables(img_metas, self.hm, self.wm, geo_rescale,
+                                                                                self.ssd_flag)
+        self.det_tab, self.geom_tab = det_tab.to(dev), geom_tab.to(dev)
+        self.out_hw = [(int(g[4]), int(g[5])) for g in geom_tab]       # (Ho, Wo) of every image
+        self.box_mul = (float(geom_tab[0, 0]), float(geom_tab[0, 1]))  # scalars: unused while the tables are given
         self.pitch = (self.wo + 3) // 4 * 4
+        meta = img_metas[0]
         self.desc = H.make_det_desc(B, sizes, strides, lv.row0, C, C, 0, 128, 0, 8, cfg.get('nms_pre', -1),
-                                    meta['img_shape'][0], meta['img_shape'][1], sf, bool(rescale), True)
+                                    meta['img_shape'][0], meta['img_shape'][1], meta.get('scale_factor', 1.0), bool(rescale), True)
+        self.desc.per_image = self.det_tab.data_ptr()
         self.sel = H.det_select_alloc(self.desc, dev)
         self.max_num = 100 if (self.ssd_flag and not self.vis) else cfg['max_per_img']
         self.out = H.multiclass_nms_alloc(B, self.desc.kmax, C, self.max_num, dev)
@@ -1235,7 +1313,7 @@ class PostProcessor:
                               if want_pos_masks else None)
         H.mask_assemble(self.basis, False, self.sel["cofs"], self.out["keep"], self.out["det"], self.out["ndet"],
                         self.hm, self.wm, self.ho, self.wo, self.box_mul, 2.0, self.up, self.mask_thr, masks,
-                        self.pos_masks)
+                        self.pos_masks, per_image=self.geom_tab)
         self.masks = masks
         self.mask_scores = None
         if self.rescorer is not None:
@@ -1244,13 +1322,25 @@ class PostProcessor:
         res = []
         for b in range(self.B):
             n = nd[b]
+            ho, wo = self.out_hw[b]                    # this image's mask size (planes share the batch's canvas)
             res.append((self.out["det"][b, :n], self.out["labels"][b, :n], self.out["keep"][b, :n],
-                        masks[b, :n, :, :self.wo]))
+                        masks[b, :n, :ho, :wo]))
         return res
 
     def encode_rle(self, canvas_hw):
-        """RLE dicts of the masks of the last run(), per image (sipmask_head.py:645-657), encoded on device."""
+        """RLE dicts of the masks of the last run(), per image (sipmask_head.py:645-657), encoded on device.
+        canvas_hw: one (H, W) for the batch or a list with one per image (img_metas[i]['ori_shape' / 'img_shape'])."""
         from . import ops as P
         rect = torch.zeros(self.B * self.max_num, 4, dtype=torch.int32, device=self.dev)
-        H.mask_rects(self.out["det"], self.box_mul, 2.0, self.up, rect)
-        return P.encode_masks(self.masks, self.out["ndet"], canvas_hw, rect)
+        H.mask_rects(self.out["det"], self.box_mul, 2.0, self.up, rect, per_image=self.geom_tab)
+        per_img = isinstance(canvas_hw[0], (tuple, list))
+        same = not per_img and all(hw == (self.ho, self.wo) for hw in self.out_hw)
+        if same:                                       # one geometry: the whole batch in one launch
+            return P.encode_masks(self.masks[..., :self.wo], self.out["ndet"], canvas_hw, rect)
+        out = []
+        for b in range(self.B):                        # result packing is outside the timed path: one launch per image
+            ho, wo = self.out_hw[b]
+            cv = canvas_hw[b] if per_img else canvas_hw
+            out += P.encode_masks(self.masks[b:b + 1, :, :ho, :wo].contiguous(), self.out["ndet"][b:b + 1], cv,
+                                  rect.view(self.B, self.max_num, 4)[b].contiguous())
+        return out

@@ -488,6 +488,28 @@ def post_geometry(hm, wm, scale_factor, rescale, ssd_flag=False):
     return mul, up, (int(math.floor(hm * up[0])), int(math.floor(wm * up[1])))
 
 
+def image_geometry_tables(img_metas, hm, wm, rescale, ssd_flag=False):
+    """Per-image post-processing geometry from the batch's img_metas (sipmask_head.py:517-541: get_bboxes_single runs with
+    img_metas[img_id]['img_shape'] / ['scale_factor']): host tensors
+      det  f32 [B, 6] = (img_h, img_w, scale_factor x 4)                       -> sm_det_desc.per_image
+      geom f32 [B, 8] = (box_mul_x, box_mul_y, up_h, up_w, Ho, Wo, 1/up_h, 1/up_w) -> sm_mask_assemble*.per_image
+    and the bounds a launch needs as scalars: canvas (max Ho, max Wo), the smallest up_scale (h, w)."""
+    import numpy as np
+    B = len(img_metas)
+    det = torch.zeros(B, 6, dtype=torch.float32)
+    geom = torch.zeros(B, 8, dtype=torch.float32)
+    for b, m in enumerate(img_metas):
+        sf = np.asarray(m.get('scale_factor', 1.0), np.float32).reshape(-1)
+        sf4 = np.repeat(sf, 4) if sf.size == 1 else sf.reshape(4)
+        det[b, 0], det[b, 1] = float(m['img_shape'][0]), float(m['img_shape'][1])
+        det[b, 2:] = torch.from_numpy(sf4.astype(np.float32))
+        mul, up, (ho, wo) = post_geometry(hm, wm, m.get('scale_factor', 1.0), rescale, ssd_flag)
+        geom[b] = torch.tensor([mul[0], mul[1], up[0], up[1], ho, wo, float(np.float32(1.0 / up[0])), float(np.float32(1.0 / up[1]))])
+    canvas = (int(geom[:, 4].max()), int(geom[:, 5].max()))
+    up_min = (float(geom[:, 2].min()), float(geom[:, 3].min()))
+    return det, geom, canvas, up_min
+
+
 def make_det_desc(batch, sizes, strides, row0, num_classes, cls_cstride, cls_coff, cof_cstride, cof_coff,
                   reg_cstride, nms_pre, img_h, img_w, scale_factor=1.0, rescale=False, reg_prescaled=False, kmax=None):
     d = DetDesc()
@@ -581,9 +603,10 @@ def fast_nms(boxes, scores, ctr, ncand, score_thr, iou_thr, top_k, max_num, out)
 
 
 def mask_assemble(basis, basis_hwc, cofs, keep, det, ndet, hm, wm, ho, wo, box_mul, box_div, up_scale, thr,
-                  masks, pos_masks=None):
+                  masks, pos_masks=None, per_image=None):
     """box_mul: scalar or (x, y); up_scale: scalar or (h, w) -- per axis for keep_ratio=False pipelines.
-    masks u8 [B, max_num, ho, pitch] with pitch % 4 == 0 and pitch >= wo (the logical width)."""
+    masks u8 [B, max_num, ho, pitch] with pitch % 4 == 0 and pitch >= wo (the logical width).
+    per_image: device table f32 [B, 8] (image_geometry_tables) -- then ho / wo are the canvas, up_scale the batch's smallest."""
     lib = _lib.load()
     (mx, my), (uh, uw) = _pair(box_mul), _pair(up_scale)
     b, kmax = cofs.shape[0], cofs.shape[1]
@@ -591,7 +614,7 @@ def mask_assemble(basis, basis_hwc, cofs, keep, det, ndet, hm, wm, ho, wo, box_m
     _lib.check(lib.sm_mask_assemble(_lib.ptr(basis), int(basis_hwc), _lib.ptr(cofs), _lib.ptr(keep), _lib.ptr(det),
                                     _lib.ptr(ndet), b, kmax, max_num, hm, wm, ho, wo, int(masks.shape[-1]), mx, my,
                                     float(box_div),
-                                    uh, uw, float(thr), _lib.ptr(masks), _lib.ptr(pos_masks),
+                                    uh, uw, float(thr), _lib.ptr(masks), _lib.ptr(pos_masks), _lib.ptr(per_image),
                                     _lib.stream_ptr()), "sm_mask_assemble")
     return masks
 
@@ -612,7 +635,8 @@ def mask_assemble_lo_alloc(batch, max_num, ho, wo, device):
                 ws=torch.empty(int(lib.sm_mask_assemble_lo_workspace(batch, max_num)), dtype=torch.uint8, device=device))
 
 
-def mask_assemble_lo(basis_lo, lo_h, lo_w, factor, cofs, keep, det, ndet, ho, wo, box_mul, box_div, up_scale, thr, buf):
+def mask_assemble_lo(basis_lo, lo_h, lo_w, factor, cofs, keep, det, ndet, ho, wo, box_mul, box_div, up_scale, thr, buf,
+                     per_image=None):
     """fused-upsample, rectangle-tracked mask assembly (see sm_mask_assemble_lo); buf from mask_assemble_lo_alloc"""
     lib = _lib.load()
     (mx, my), (uh, uw) = _pair(box_mul), _pair(up_scale)
@@ -622,7 +646,7 @@ def mask_assemble_lo(basis_lo, lo_h, lo_w, factor, cofs, keep, det, ndet, ho, wo
     _lib.check(lib.sm_mask_assemble_lo(_lib.ptr(basis_lo), lo_h, lo_w, factor, _lib.ptr(cofs), _lib.ptr(keep), _lib.ptr(det),
                                        _lib.ptr(ndet), b, kmax, max_num, ho, wo, int(masks.shape[-1]), mx, my, float(box_div),
                                        uh, uw, float(thr), _lib.ptr(masks), _lib.ptr(buf["state"]), _lib.ptr(buf["ws"]),
-                                       _lib.stream_ptr()), "sm_mask_assemble_lo")
+                                       _lib.ptr(per_image), _lib.stream_ptr()), "sm_mask_assemble_lo")
     return masks
 
 
@@ -642,12 +666,12 @@ def rle_alloc(batch, max_num, canvas_w, device, max_runs=8192, packed_cap=None):
                 ws=torch.empty(int(ws), dtype=torch.uint8, device=device), max_runs=max_runs, canvas_w=canvas_w)
 
 
-def mask_rects(det, box_mul, box_div, up_scale, rect):
+def mask_rects(det, box_mul, box_div, up_scale, rect, per_image=None):
     lib = _lib.load()
     b, n = det.shape[0], det.shape[1]
     (mx, my), (uh, uw) = _pair(box_mul), _pair(up_scale)
     _lib.check(lib.sm_mask_rects(_lib.ptr(det), b, n, mx, my, float(box_div), uh, uw,
-                                 _lib.ptr(rect), _lib.stream_ptr()), "sm_mask_rects")
+                                 _lib.ptr(rect), _lib.ptr(per_image), _lib.stream_ptr()), "sm_mask_rects")
     return rect
 
 

@@ -303,9 +303,8 @@ class SipMaskHead(nn.Module):
         post = PostProcessor(cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg,
                              self.strides, rescale, self.ssd_flag, rescore_sd=self._rescore_sd())
         res = post.run()
-        meta = img_metas[0]
-        shp = meta['ori_shape'] if rescale else meta['img_shape']
-        rles = post.encode_rle(shp[:2])
+        # every image is pasted on ITS canvas (sipmask_head.py:645-657: ori_shape when rescaling, else img_shape)
+        rles = post.encode_rle([tuple((m['ori_shape'] if rescale else m['img_shape'])[:2]) for m in img_metas])
         out = []
         for b, ((det, labels, _, _), rle) in enumerate(zip(res, rles)):
             cls_segms = [[] for _ in range(self.num_classes - 1)]

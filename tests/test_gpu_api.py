@@ -527,11 +527,15 @@ def test_head_train_step_sgd_updates():
 def test_gradients_living_in_allreduce_buckets_match_plain_training():
     """with a GradBucketer every `.grad` is a view of a flat bucket, the wgrad / bias / GroupNorm backward
     kernels write into it directly (hip_ops.GRAD_SINK; step 0 is the use census, steps >= 1 are direct), and HipSGD's
-    pointer table is uploaded once.  Three steps from the same initialisation with and without the bucketer must give
-    the same losses and parameters (float-atomic split-K sums in the weight gradients: tolerance, not bits)."""
+    pointer table is uploaded once.  With lr = 0 the weights never move, so every step computes the SAME gradients: the
+    bucket-resident ones (census step through autograd's in-place add, later steps through direct kernel writes) must
+    equal those of a plain step parameter by parameter, unused parameters stay zero, and the losses agree.  Tolerance 5e-3
+    relative, not bits: the backward is not run-to-run reproducible -- FeatureAlign's col2im and the split-K weight
+    gradients accumulate with float atomics, and a last-bit difference flips bf16 roundings of the gradient rows upstream
+    (measured: 9e-4 on cls_convs.0.conv.weight between two identical plain steps' worth of arithmetic); a lost or
+    doubled contribution would be an O(1) error."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    import copy
     from sipmask_amd.registry import build_head
     from sipmask_amd import sipmask_head  # noqa: F401
     from sipmask_amd import hip_ops as H
@@ -542,7 +546,6 @@ def test_gradients_living_in_allreduce_buckets_match_plain_training():
           if k.startswith("bbox_head.")}
     sd["fcos_cls.bias"].fill_(-3.0)
     head.load_state_dict(sd, strict=True)
-    twin = copy.deepcopy(head)
     g = torch.Generator().manual_seed(5)
     B = 2
     sizes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
@@ -550,37 +553,44 @@ def test_gradients_living_in_allreduce_buckets_match_plain_training():
     gtb, gtl, gtm = _synthetic_gt(g, B, 128, 160, 4)
     gtb, gtl = [b.cuda() for b in gtb], [l.cuda() for l in gtl]
     metas = [dict(img_shape=(128, 160, 3), pad_shape=(128, 160, 3), scale_factor=1.0) for _ in range(B)]
-    opt_a = HipSGD(twin.named_parameters(), lr=0.002, momentum=0.9, weight_decay=1e-4)
-    plain = [head_train_step(twin, feats, gtb, gtl, gtm, metas, opt_a) for _ in range(3)]
-    opt_b = HipSGD(head.named_parameters(), lr=0.002, momentum=0.9, weight_decay=1e-4)
+    opt = HipSGD(head.named_parameters(), lr=0.0, momentum=0.0, weight_decay=0.0)
+    plain_loss = head_train_step(head, feats, gtb, gtl, gtm, metas, opt)
+    plain = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in head.named_parameters()}
+    assert sum(v is not None for v in plain.values()) > 30
+    opt.zero_grad()
     bucket = GradBucketer([p for p in head.parameters() if p.requires_grad], bucket_bytes=4 << 20)
     assert len(bucket.buckets) >= 2
     try:
-        got = []
         for step in range(3):
-            got.append(head_train_step(head, feats, gtb, gtl, gtm, metas, opt_b, bucketer=bucket))
+            loss = head_train_step(head, feats, gtb, gtl, gtm, metas, opt, bucketer=bucket)
             if step == 0:
                 assert H.GRAD_SINK.census and len(H.GRAD_SINK.uses) > 20
             else:
                 assert not H.GRAD_SINK.census and len(H.GRAD_SINK.written) > 20       # direct writes happened
+            for k in plain_loss:
+                assert abs(loss[k] - plain_loss[k]) <= 1e-4 * max(1.0, abs(plain_loss[k])), (step, k, loss[k], plain_loss[k])
+            bad = []
             for bk in bucket.buckets:
                 for p, v in zip(bk["params"], bk["views"]):
                     assert p.grad.data_ptr() == v.data_ptr()
-        assert opt_b._tab_raw is not None
-        raw = opt_b._tab_raw
-        head_train_step(head, feats, gtb, gtl, gtm, metas, opt_b, bucketer=bucket)
-        assert opt_b._tab_raw == raw                      # the pointer table did not change: no upload after the first
+            for n, p in head.named_parameters():
+                if not p.requires_grad:
+                    continue
+                ref = plain[n]
+                if ref is None:
+                    assert float(p.grad.abs().max()) == 0.0, n                         # unused: stays zero
+                    continue
+                err = float((p.grad - ref).norm() / (ref.norm() + 1e-20))
+                if err > 5e-3:
+                    bad.append((n, err))
+            assert not bad, (step, sorted(bad, key=lambda t: -t[1])[:10])
+        raw = opt._tab_raw
+        assert raw is not None
+        head_train_step(head, feats, gtb, gtl, gtm, metas, opt, bucketer=bucket)
+        assert opt._tab_raw == raw                        # the pointer table did not change: no upload after the first
     finally:
         bucket.remove()
     assert not H.GRAD_SINK.views
-    for a, b in zip(plain, got):
-        for k in a:
-            assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
-    # compare after 3 steps (the 4th above ran on `head` only): re-run the twin once more to stay in step
-    head_train_step(twin, feats, gtb, gtl, gtm, metas, opt_a)
-    for (n, p), (_, q) in zip(head.named_parameters(), twin.named_parameters()):
-        err = float((p.detach() - q.detach()).norm() / (q.detach().norm() + 1e-12))
-        assert err < 2e-3, (n, err)
 
 
 def test_detector_forward_train_vs_oracle():

@@ -37,9 +37,11 @@ def test_split3_layout_and_precision():
     hi, lo, hi2 = yc[:, 16:80], yc[:, 96 + 16:96 + 80], yc[:, 192 + 16:192 + 80]
     xc = x.clamp(-65504, 65504)
     assert torch.equal(hi, xc.half().float()) and torch.equal(hi, hi2)
-    big = xc.abs() > 1e-2
-    assert float(((hi + lo - xc).abs() / xc.abs().clamp_min(1e-30))[big].max()) < 2.0 ** -21
-    assert float((hi + lo - xc).abs()[~big].max()) < 1e-7                     # subnormal lows: absolute 2^-25
+    # |lo| <= 2^-11 |v|; it is a normal binary16 (11 more bits: 2^-22 |v| in all) while |lo| >= 2^-14, i.e. |v| >= 0.125,
+    # and is quantised to binary16's subnormal step 2^-24 below that (absolute error <= 2^-25)
+    big = xc.abs() >= 0.25
+    assert float(((hi + lo - xc).abs() / xc.abs().clamp_min(1e-30))[big].max()) <= 2.0 ** -21
+    assert float((hi + lo - xc).abs()[~big].max()) <= 2.0 ** -25
     assert bool((yc[:, :16] == 7).all()) and bool((yc[:, 80:96] == 7).all())   # other sources' slices untouched
     xb = x.to(torch.bfloat16)
     y2 = torch.empty(1000, 192, dtype=torch.float16, device=dev)
@@ -53,8 +55,8 @@ def test_split3_layout_and_precision():
 @pytest.mark.parametrize("kernel", ["igemm", "igemm256", "patch"])
 def test_x3_conv_matches_f64_conv_of_f32_operands(kernel):
     """3x3 256->256 over a 3-level pyramid, grouped (2 weight sets, shared input), fused fixed-point GN statistics, f32
-    output: within 2e-6 of the float64 convolution of the SAME f32 operands, relative to the output's largest value
-    (bf16 operands: 4e-3).  The weight scale is a power of two and is undone exactly."""
+    output: within 4e-6 of the float64 convolution of the SAME f32 operands, relative to the output's largest value
+    (bf16 operands: 4e-3; K = 2304 products of ~2^-21 each plus the f32 accumulation).  The weight scale is a power of two and is undone exactly."""
     from sipmask_amd import hip_ops as H, _lib
     dev = _dev()
     g = torch.Generator().manual_seed(5)
@@ -100,7 +102,7 @@ def test_x3_conv_matches_f64_conv_of_f32_operands(kernel):
             r0 = gi * lv.rows + lv.row0[l]
             got = y[r0:r0 + B * h * w].view(B, h, w, C).permute(0, 3, 1, 2).cpu().double()
             err = float((got - ref).abs().max()) / float(ref.abs().max())
-            assert err < 2e-6, (kernel, gi, l, err)
+            assert err < 4e-6, (kernel, gi, l, err)
             r8 = ref.reshape(B, C // 8, 8 * h * w)
             torch.testing.assert_close(st[:, l, :, 0], r8.sum(-1), rtol=1e-5, atol=1e-3 * (h * w) ** 0.5)
             torch.testing.assert_close(st[:, l, :, 1], (r8 * r8).sum(-1), rtol=1e-5, atol=1e-3)
@@ -108,7 +110,7 @@ def test_x3_conv_matches_f64_conv_of_f32_operands(kernel):
 
 def test_x3_small_cout_and_1x1_convs():
     """the head's other x3 launches: 1x1 over 3*768 channels (sip_mask_lat0), 3x3 to 32 couts (sip_mask_lat) and to 8
-    couts with per-level Scale on 4 of them (fcos_reg + centerness), ReLU, bias -- f32 out, within 2e-6 of float64"""
+    couts with per-level Scale on 4 of them (fcos_reg + centerness), ReLU, bias -- f32 out, within 4e-6 of float64"""
     from sipmask_amd import hip_ops as H, _lib
     dev = _dev()
     g = torch.Generator().manual_seed(9)
@@ -139,7 +141,7 @@ def test_x3_small_cout_and_1x1_convs():
                 ref = ref.clamp_min(0)
             got = y[lv.row0[l]:lv.row0[l] + B * h * w, :co].view(B, h, w, co).permute(0, 3, 1, 2).cpu().double()
             err = float((got - ref).abs().max()) / float(ref.abs().max())
-            assert err < 2e-6, (ci, co, k, l, err)
+            assert err < 4e-6, (ci, co, k, l, err)
     # binary16 operands need f32 output, no residual
     d.flags &= ~_lib.SM_CONV_OUT_F32
     with pytest.raises(RuntimeError):
@@ -177,6 +179,40 @@ def test_groupnorm_apply_x3_and_f32_statistics():
         assert torch.equal(s3[:, :C], s3[:, 2 * C:])
 
 
+@pytest.mark.parametrize("deform", [True, False])
+def test_f32_conv_with_split_precision_contraction(deform):
+    """sm_conv2d_f32 + SM_CONV_F16 (conv_f32.hip, X3): f32 rows in, operands split into binary16 halves in the loader,
+    three f16 MFMAs per product.  FeatureAlign's shape (3x3, 256 -> 256, 4 deformable groups) against the oracle's
+    deformable conv in float64 / torch's conv: 4e-6 of the output's largest value (the exact-f32 kernel: 1e-6)."""
+    from oracle import ops as O
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    B, C, Co = 2, 256, 256
+    sizes = [(21, 34), (9, 13)]
+    lv = H.Levels(B, sizes)
+    xs = [torch.randn(B, C, h, w, generator=g).abs() * 1.3 for h, w in sizes]
+    offs = [torch.randn(B, 72, h, w, generator=g) * 1.5 for h, w in sizes]
+    wt = torch.randn(Co, C, 3, 3, generator=g) * 0.03
+    bias = torch.randn(Co, generator=g)
+    scale = H.x3_weight_scale([wt])
+    wq, co_pad = H.prep_conv_weight_f32(wt.to(dev) * scale, C)
+    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, C, Co, co_pad, 3, 1, 1, C, Co, flags=_lib.SM_CONV_F16,
+                         deform_groups=4 if deform else 0, acc_scale=1.0 / scale)
+    y = torch.zeros(lv.rows, Co, dtype=torch.float32, device=dev)
+    off_rows = _rows(offs).to(dev) if deform else None
+    H.conv2d_f32(d, _rows(xs).to(dev), off_rows, wq, bias.to(dev), None, y)
+    torch.cuda.synchronize()
+    for l, (h, w) in enumerate(sizes):
+        if deform:
+            ref = O.deform_conv(xs[l].double(), offs[l].double(), wt.double(), 1, 1, 1, 4) + bias.double().view(1, -1, 1, 1)
+        else:
+            ref = F.conv2d(xs[l].double(), wt.double(), bias.double(), 1, 1)
+        got = y[lv.row0[l]:lv.row0[l] + B * h * w].view(B, h, w, Co).permute(0, 3, 1, 2).cpu().double()
+        err = float((got - ref).abs().max()) / float(ref.abs().max())
+        assert err < 4e-6, (deform, l, err)
+
+
 @pytest.fixture(scope="module")
 def head_case():
     if not torch.cuda.is_available():
@@ -202,7 +238,7 @@ def test_x3_head_matches_the_fp32_oracle_on_identical_features(head_case):
     c = head_case
     hsd = {k: v for k, v in c["sd"].items() if k.startswith("bbox_head.")}
     eng = SipMaskEngine.for_head(hsd, c["B"], c["sizes"], img_shape=(192, 256, 3), precision="head_x3")
-    assert all(cv.mode in ("x3", "f32") for cv in eng.convs) and sum(cv.mode == "f32" for cv in eng.convs) == 1
+    assert all(cv.mode in ("x3", "f32x3") for cv in eng.convs) and sum(cv.mode == "f32x3" for cv in eng.convs) == 1
     eng.load_pyramid([f.cuda() for f in c["feats"]])
     eng.run_head(with_post=True)
     torch.cuda.synchronize()
