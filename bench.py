@@ -117,6 +117,72 @@ def cpu_baseline_inference(det, depth, seed=0):
                        "mask ops), 1 warm-up + %d timed forward(s) in a 30 s budget, median %.2f s" % (len(timed), t))
 
 
+def cpu_baseline_train(det, depth, seed=0):
+    """The CPU oracle's TRAINING step on ONE 800x1344 image (kind "port"): backbone -> FPN -> head -> loss (oracle/model.py,
+    oracle/loss.py; torch-CPU autograd through the restated ops) -> backward, 1 warm-up + up to 3 timed steps in a ~40 s
+    budget, median.  No optimizer step (negligible next to the convolutions)."""
+    import numpy as np
+    import torch
+    from oracle import loss as OL
+    from oracle import model as OM
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    pn = set(n for n, p in det.named_parameters() if p.requires_grad)
+    sd = {k: (v.detach().float().cpu().clone().requires_grad_(k in pn)) for k, v in det.state_dict().items()}
+    img = torch.randn(1, 3, IMG_H, IMG_W, generator=torch.Generator().manual_seed(seed))
+    gtb, gtl, gtm = synthetic_gt(seed, 1, IMG_H, IMG_W, torch.device("cpu"))
+    times = []
+    budget = time.perf_counter() + 40.0
+    for it in range(4):
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        out = OM.head_forward(sd, OM.fpn_forward(sd, OM.backbone_forward(sd, img, depth)))
+        losses, _ = OL.head_loss(out[0], out[1], out[2], out[3], out[4], gtb, gtl, gtm)
+        sum(losses.values()).backward()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() > budget and len(times) >= 2:
+            break
+    timed = sorted(times[1:]) if len(times) > 1 else times
+    t = timed[len(timed) // 2]
+    return dict(value=round(1.0 / t, 4), unit="img/s", cores=cores, kind="port",
+                sample="1 image 3x800x1344 fp32 per step (forward + loss + backward, no optimizer), torch-CPU oracle, 1 warm-up + "
+                       "%d timed step(s) in a 40 s budget, median %.2f s" % (len(timed), t))
+
+
+def cpu_baseline_vis(det, seed=0):
+    """The CPU oracle on ONE 384x640 frame (kind "port"): backbone -> FPN -> head + track branch -> VIS post-processing
+    (fast_nms, mask assembly, embedding gather); 1 warm-up + up to 5 timed frames in a ~20 s budget, median."""
+    import torch
+    from oracle import model as OM
+    from oracle import vis as OV
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in det.state_dict().items()}
+    img = torch.randn(1, 3, VIS_H, VIS_W, generator=torch.Generator().manual_seed(seed))
+    from sipmask_amd.synthetic import VIS_TEST_CFG
+    times = []
+    budget = time.perf_counter() + 20.0
+    for it in range(6):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            pyr = OM.fpn_forward(sd, OM.backbone_forward(sd, img, 50))
+            cls, bb, ctr, cof, fm = OM.head_forward(sd, pyr)
+            tf = OV.track_forward(sd, pyr)
+            r = OV.get_masks_single_vis([c[0] for c in cls], [c[0] for c in bb], [c[0] for c in ctr], [c[0] for c in cof], fm[0],
+                                        (VIS_H - 24, VIS_W, 3), dict(VIS_TEST_CFG))
+            if r["det_bboxes"].shape[0]:
+                OV.extract_box_feature_center(tf[0], torch.as_tensor(r["det_bboxes"])[:, :4])
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() > budget and len(times) >= 2:
+            break
+    timed = sorted(times[1:]) if len(times) > 1 else times
+    t = timed[len(timed) // 2]
+    return dict(value=round(1.0 / t, 4), unit="frames/s", cores=cores, kind="port",
+                sample="1 frame 3x384x640 fp32 per forward (backbone, FPN, head, track branch, fast_nms, masks), torch-CPU "
+                       "oracle, 1 warm-up + %d timed frame(s) in a 20 s budget, median %.2f s" % (len(timed), t))
+
+
 def parity_of_timed_plan(det, plan, img, depth):
     """The TIMED plan's last step against the CPU oracle on the same images and weights (checker leg, like the CPU
     baseline): mask-logit max-abs error at the oracle's detections (sipmask_head.py:609-620, north_star's quantity) and
@@ -371,8 +437,11 @@ def run_train(args, rank, world, dev):
     det = build_synthetic_detector(args.depth, seed=0).to(dev)
     det.train()
     B = args.batch
-    img = torch.randn(B, 3, IMG_H, IMG_W, generator=torch.Generator().manual_seed(100 + rank)).to(dev)
-    gtb, gtl, gtm = synthetic_gt(rank, B, IMG_H, IMG_W, dev)
+    # two synthetic batches (images + ground truth) resident on the device, alternated step by step
+    NSETS = 2
+    gi = torch.Generator().manual_seed(100 + rank)
+    sets = [(torch.randn(B, 3, IMG_H, IMG_W, generator=gi).to(dev),) + synthetic_gt(rank * NSETS + k, B, IMG_H, IMG_W, dev)
+            for k in range(NSETS)]
     metas = [dict(img_shape=(IMG_H, IMG_W, 3), pad_shape=(IMG_H, IMG_W, 3), scale_factor=1.0) for _ in range(B)]
     opt = HipSGD(det.named_parameters(), lr=0.0005, momentum=0.9, weight_decay=1e-4)
     # SIPMASK_FORCE_DIST=1 (one rank under a launcher): run the collective path anyway -- a 1-GPU box can then execute the
@@ -381,9 +450,12 @@ def run_train(args, rank, world, dev):
     forced = dist.is_available() and dist.is_initialized()
     bucket = GradBucketer([p for p in det.parameters() if p.requires_grad], force=forced) if (world > 1 or forced) else None
     losses = {}
+    nstep = [0]
 
     def step():
         # loss values stay on the device during the timed steps (read once after them): no per-step host sync
+        img, gtb, gtl, gtm = sets[nstep[0] % NSETS]
+        nstep[0] += 1
         losses.update(detector_train_step(det, img, metas, gtb, gtl, gtm, opt, bucket, sync=False))
 
     for _ in range(args.warmup):
@@ -394,14 +466,39 @@ def run_train(args, rank, world, dev):
     fwd_gflop = 450.9 * B                           # conv FLOPs per image
     train_gflop = fwd_gflop * 3.0 - 2.0 * (2.5 + 14.3) * 2 * B
     ms = elapsed / args.steps * 1e3
-    achieved = train_gflop / ms                     # GFLOP per ms = TFLOP/s
+    step_tflops = train_gflop / ms                  # GFLOP per ms = TFLOP/s (analytic FLOPs over wall time: context only)
+    # ---- dominant kernel of the step, timed live with HIP events on the launch stream: the direct weight-gradient kernel
+    # (csrc/wgrad_direct.hip) on its largest launch -- dW of a tower conv (3x3, 256 -> 256) over the whole pyramid of the
+    # batch: [256 x 2304] += gout^T [256 x rows] . im2col(x) [rows x 2304], rows = B * 22 400
+    from sipmask_amd import hip_ops as H
+    LEV = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    lvw = H.Levels(B, LEV)
+    xw = (torch.randn(lvw.rows, 256, device=dev) * 0.5).to(torch.bfloat16)
+    gw_in = (torch.randn(lvw.rows, 256, device=dev) * 0.1).to(torch.bfloat16)
+    gw_out = torch.empty(9 * 256, 256, device=dev)
+    dw = H.make_conv_desc(B, LEV, LEV, lvw.row0, lvw.row0, 256, 256, 256, 3, 1, 1, 256, 256)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for r in range(6):
+        e0.record()
+        for _ in range(4):
+            H.conv2d_bwd(dw, xw, None, None, gw_in, None, gw_out, None)
+        e1.record()
+        torch.cuda.synchronize()
+        if r:
+            ts.append(e0.elapsed_time(e1) / 4)
+    wg_ms = sorted(ts)[len(ts) // 2]
+    wg_gflop = 2.0 * lvw.rows * 256 * 2304 / 1e9
+    wg_mb = (lvw.rows * 256 * 2 * 2 + 2304 * 256 * 4) / 1e6          # x + gout read once (bf16), dW written (f32)
+    achieved = wg_gflop / wg_ms
     out = {
         "metric": "img/s SipMask-R%d training step (forward_train + loss + backward + gradient all-reduce + SGD)" % args.depth,
         "value": round(B * args.steps * world / elapsed, 3),
         "unit": "img/s",
         "ms_per_step": round(ms, 3),
         "dtype": "bf16",
-        "data": "synthetic (randn images, 6 boxes + elliptical masks per image, reference-init random weights)",
+        "data": "synthetic (randn images, 6 boxes + elliptical masks per image; %d batches resident on the device, alternated "
+                "step by step; reference-init random weights)" % NSETS,
         "config": {"workload": "SipMask-R%d training step, %d img/GPU, 3x800x1344, bf16 MFMA operands + f32 accumulate / "
                                "f32 master weights, SGD momentum .9 wd 1e-4" % (args.depth, B),
                    "global_batch": B * world,
@@ -411,10 +508,18 @@ def run_train(args, rank, world, dev):
                    "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                     "kernel": "whole step: forward + dgrad + wgrad GEMMs of all trained convs on conv_igemm_kernel "
-                               "(%.0f GFLOP per step)" % train_gflop},
+                     "kernel": "wgrad_direct_kernel (dW straight from NHWC rows: LDS-DMA sub-tiles + ds_read_b64_tr_b16 "
+                               "fragments, split-K with float atomics) on its largest launch: dW of a tower conv 3x3 256->256 "
+                               "over the batch's pyramid (M=256, N=2304, K=%d positions)" % lvw.rows,
+                     "gflop_per_launch": round(wg_gflop, 2), "ms_per_launch": round(wg_ms, 4),
+                     "algorithmic_mb_per_launch": round(wg_mb, 1),
+                     "whole_step_tflops": round(step_tflops, 2),
+                     "whole_step_note": "analytic %.0f GFLOP (forward + dgrad + wgrad of every trained conv) over the step's "
+                                        "wall time" % train_gflop},
         "cpu_baseline": None,
     }
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_train(det, args.depth)
     return out
 
 
@@ -428,21 +533,26 @@ def run_vis(args, rank, world, dev):
     # every step: `world` clips in flight (one per GPU); a clip's frames run as ONE batch through the plan
     # (SipMaskVIS.clip_test), its identity matching in frame order afterwards
     clips_per_step = world
+    NSETS = 2                                        # two sets of clips resident on the device, alternated step by step
     g = torch.Generator().manual_seed(4321)
-    clips = [torch.randn(VIS_T, 3, VIS_H, VIS_W, generator=g) for _ in range(clips_per_step)]
+    clips = [torch.randn(VIS_T, 3, VIS_H, VIS_W, generator=g) for _ in range(clips_per_step * NSETS)]
     eng = det.prepare(1, (VIS_H, VIS_W), shape)
     calibrate_cls_bias(det, eng, clips[0][:1].to(dev), target_per_img=300, score_thr=0.03)
     del eng
     mine = shard_videos([VIS_T] * clips_per_step, world)[rank]
-    clips_dev = {vi: clips[vi].to(dev) for vi in mine}
+    clips_dev = {(k, vi): clips[k * clips_per_step + vi].to(dev) for k in range(NSETS) for vi in mine}
+    use_graph = not args.no_graph
     metas = [dict(img_shape=shape, ori_shape=shape, pad_shape=(VIS_H, VIS_W, 3), scale_factor=1.0, is_first=(t == 0))
              for t in range(VIS_T)]
     counts = []
+    nstep = [0]
 
     def step():
         counts.clear()
+        k = nstep[0] % NSETS
+        nstep[0] += 1
         for vi in mine:                              # whole videos, in order; tracker reset by is_first of frame 0
-            res = det.clip_test(clips_dev[vi], metas, encode=False)
+            res = det.clip_test(clips_dev[(k, vi)], metas, encode=False, graph=use_graph)
             counts.append(sum(len(b) for b, _ in res))
 
     for _ in range(args.warmup):
@@ -452,6 +562,25 @@ def run_vis(args, rank, world, dev):
     plan = det.prepare(VIS_T, (VIS_H, VIS_W), shape, 1.0, False, lanes=2)
     flops = plan.total_conv_flops() / VIS_T
     ms_frame = elapsed / (VIS_T * args.steps) * 1e3
+    # ---- dominant kernel, timed live with HIP events (eager launches of ONE 4-frame chain of the plan): the grouped
+    # tower launch (cls + reg 3x3 256 -> 256 of one depth over the 5 levels of 4 frames)
+    eng = plan.engines[0]
+    eng.img = clips_dev[(0, mine[0])][:eng.batch].contiguous()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in eng.steps]
+    acc = [0.0] * len(eng.steps)
+    for r in range(3):
+        for (label, fn), (e0, e1) in zip(eng.steps, ev):
+            e0.record()
+            fn()
+            e1.record()
+        torch.cuda.synchronize()
+        for i, (e0, e1) in enumerate(ev):
+            acc[i] += e0.elapsed_time(e1) / 3
+    tms = {label[5:]: ms for (label, _), ms in zip(eng.steps, acc) if label.startswith("conv:")}
+    towers = [c for c in eng.convs if c.name.startswith("head.tower")] or \
+        [c for c in eng.convs if c.name.startswith("head.reg_convs") or c.name.startswith("head.cls_convs")]
+    tower_ms = sum(tms[c.name] for c in towers) / len(towers)
+    tower_tf = towers[0].flops / tower_ms / 1e9
     out = {
         "metric": "frames/s SipMask-VIS R50 on 640x360 clips (backbone+FPN+head+track head, fast_nms, mask assembly, "
                   "identity matching)",
@@ -459,19 +588,29 @@ def run_vis(args, rank, world, dev):
         "unit": "frames/s",
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "dtype": "bf16",
-        "data": "synthetic (randn frames, reference-init random weights + calibration overrides)",
+        "data": "synthetic (randn frames, %d clip sets resident on the device alternated step by step; reference-init random "
+                "weights + calibration overrides)" % NSETS,
         "config": {"workload": "SipMask-VIS R50, clips of %d frames 3x%dx%d (640x360 padded), 1 clip per GPU per step; the "
                                "frames of a clip run as one batch (two 4-frame launch chains), identity matching in frame "
                                "order on the host (tracker state)" % (VIS_T, VIS_H, VIS_W),
                    "global_batch": clips_per_step, "parallelism": "dp%d (sharded by video, no collective)" % world,
-                   "launch": "eager (one plan run + one device->host sync per clip)",
+                   "launch": ("hipGraph replay of the whole clip" if use_graph else "eager") +
+                             " + one device->host sync per clip (detection counts for the host-side matching)",
                    "tracked_objects_last_step_this_rank": list(counts)},
-        "roofline": {"bound": "mfma", "achieved": round(flops / ms_frame / 1e9, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(flops / ms_frame / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                     "kernel": "whole frame: all conv launches of one 384x640 frame (%.1f GFLOP) over the frame time incl. "
-                               "the host-side matching" % (flops / 1e9)},
+        "roofline": {"bound": "mfma", "achieved": round(tower_tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(tower_tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel": "%s = %s, cls+reg tower 3x3 256->256 of one depth over 5 levels of %d frames (one chain)" %
+                               (towers[0].name, "conv3x3_patch_kernel" if getattr(towers[0], "patch", False) else "conv_igemm_kernel",
+                                eng.batch),
+                     "gflop_per_launch": round(towers[0].flops / 1e9, 2), "ms_per_launch": round(tower_ms, 4),
+                     "algorithmic_mb_per_launch": round(towers[0].bytes / 1e6, 1),
+                     "whole_frame_tflops": round(flops / ms_frame / 1e9, 2),
+                     "whole_frame_note": "all conv launches of one 384x640 frame (%.1f GFLOP) over the frame time incl. the "
+                                         "host-side matching" % (flops / 1e9)},
         "cpu_baseline": None,
     }
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_vis(det)
     return out
 
 

@@ -118,6 +118,14 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvFArgs a) {
   const int ntap = a.kh * a.kw;
 
   f32x4 wreg[NW], xreg[NX];
+  // deformable variant: sampling geometry of the current (tap, deformable group) per tile row (see load_tile)
+  float geo_w[DEFORM ? NX : 1][4];
+  int geo_o[DEFORM ? NX : 1][4];
+  int geo_tg[DEFORM ? NX : 1];
+#pragma unroll
+  for (int i = 0; i < (DEFORM ? NX : 1); ++i) geo_tg[i] = -1;
+  // a K step's 16 channels lie inside one tap and one deformable group for every thread of the block
+  const bool geo_hoist = DEFORM && (a.cin % 16 == 0) && (a.cpg % 16 == 0);
   auto load_tile = [&](int kt) {
     const int k0 = kt * 16 + cj * 4;                 // first K element of this thread's chunk
     const bool kvalid = k0 < a.K;
@@ -143,32 +151,46 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvFArgs a) {
         if (ok) v = q;
       } else {
         // deformable_im2col_gpu_kernel (deform_conv_cuda_kernel.cu:191-243) for one (position, tap, 4 channels):
-        // offset channel layout [g][2*tap + {0: h, 1: w}] (:216,222-223), stride-1 "same" conv => offset row = out row
+        // offset channel layout [g][2*tap + {0: h, 1: w}] (:216,222-223), stride-1 "same" conv => offset row = out row.
+        // The sampling geometry -- offset, bilinear weights, corner addresses -- belongs to a (position, tap, deformable
+        // group): it is the same for every K step inside the group's channels (4 steps of 16 at 64 channels per group), so
+        // it is computed when (tap, group) changes and kept in registers; a K step then is four independent corner loads
+        // and the blend instead of offset load -> address -> corner loads (two dependent memory latencies).
         const int g = ci / a.cpg;
-        const long long orow = a.out_row0[lev] + m0 + r0 + 64 * i;
-        const long long oo = rvalid ? orow * (long long)(a.dg * ntap * 2) + (g * ntap + tap) * 2 : 0ll;
-        const float2 off = *reinterpret_cast<const float2*>(a.offset + oo);
-        const float h_im = (float)(rhi[i] + dh) + off.x;
-        const float w_im = (float)(rwi[i] + dw) + off.y;
-        const bool inr = rvalid && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;   // :229
-        const float hf = floorf(h_im), wf = floorf(w_im);
-        const int h_low = inr ? (int)hf : 0, w_low = inr ? (int)wf : 0;
-        const int h_high = h_low + 1, w_high = w_low + 1;
-        const float lh = h_im - hf, lw = w_im - wf;
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        const bool t_ok = h_low >= 0, b_ok = h_high <= H - 1, l_ok = w_low >= 0, r_ok = w_high <= W - 1;   // :98-109
-        const int hl = min(max(h_low, 0), H - 1), hh_ = min(max(h_high, 0), H - 1);
-        const int wl = min(max(w_low, 0), W - 1), wh_ = min(max(w_high, 0), W - 1);
-        const float* base = a.x + (in_row0 + (long long)(rvalid ? rn[i] : 0) * H * W) * a.in_cstride + (rvalid ? ci : 0);
-        const f32x4 q1 = *reinterpret_cast<const f32x4*>(base + (long long)(hl * W + wl) * a.in_cstride);
-        const f32x4 q2 = *reinterpret_cast<const f32x4*>(base + (long long)(hl * W + wh_) * a.in_cstride);
-        const f32x4 q3 = *reinterpret_cast<const f32x4*>(base + (long long)(hh_ * W + wl) * a.in_cstride);
-        const f32x4 q4 = *reinterpret_cast<const f32x4*>(base + (long long)(hh_ * W + wh_) * a.in_cstride);
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;                             // :111-112
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 v1 = (t_ok && l_ok) ? q1 : z, v2 = (t_ok && r_ok) ? q2 : z;
-        const f32x4 v3 = (b_ok && l_ok) ? q3 : z, v4 = (b_ok && r_ok) ? q4 : z;
-        if (inr) v = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;                                            // :113
+        const int tg = kvalid ? tap * a.dg + g : -2;
+        if (!geo_hoist || tg != geo_tg[i]) {
+          geo_tg[i] = tg;
+          const long long orow = a.out_row0[lev] + m0 + r0 + 64 * i;
+          const long long oo = rvalid ? orow * (long long)(a.dg * ntap * 2) + (g * ntap + tap) * 2 : 0ll;
+          const float2 off = *reinterpret_cast<const float2*>(a.offset + oo);
+          const float h_im = (float)(rhi[i] + dh) + off.x;
+          const float w_im = (float)(rwi[i] + dw) + off.y;
+          const bool inr = rvalid && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;   // :229
+          const float hf = floorf(h_im), wf = floorf(w_im);
+          const int h_low = inr ? (int)hf : 0, w_low = inr ? (int)wf : 0;
+          const int h_high = h_low + 1, w_high = w_low + 1;
+          const float lh = h_im - hf, lw = w_im - wf;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          const bool t_ok = h_low >= 0, b_ok = h_high <= H - 1, l_ok = w_low >= 0, r_ok = w_high <= W - 1;   // :98-109
+          const int hl = min(max(h_low, 0), H - 1), hh_ = min(max(h_high, 0), H - 1);
+          const int wl = min(max(w_low, 0), W - 1), wh_ = min(max(w_high, 0), W - 1);
+          // a corner outside the image contributes 0 (:98-109), a sample outside (-1, H) x (-1, W) is 0 (:229): zero weights
+          geo_w[i][0] = (inr && t_ok && l_ok) ? hh * hw : 0.f;                                           // :111-112
+          geo_w[i][1] = (inr && t_ok && r_ok) ? hh * lw : 0.f;
+          geo_w[i][2] = (inr && b_ok && l_ok) ? lh * hw : 0.f;
+          geo_w[i][3] = (inr && b_ok && r_ok) ? lh * lw : 0.f;
+          const int nrow = rvalid ? rn[i] * H * W : 0;
+          geo_o[i][0] = nrow + hl * W + wl;
+          geo_o[i][1] = nrow + hl * W + wh_;
+          geo_o[i][2] = nrow + hh_ * W + wl;
+          geo_o[i][3] = nrow + hh_ * W + wh_;
+        }
+        const float* base = a.x + in_row0 * a.in_cstride + (rvalid ? ci : 0);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(base + (long long)geo_o[i][0] * a.in_cstride);
+        const f32x4 q2 = *reinterpret_cast<const f32x4*>(base + (long long)geo_o[i][1] * a.in_cstride);
+        const f32x4 q3 = *reinterpret_cast<const f32x4*>(base + (long long)geo_o[i][2] * a.in_cstride);
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(base + (long long)geo_o[i][3] * a.in_cstride);
+        v = geo_w[i][0] * q1 + geo_w[i][1] * q2 + geo_w[i][2] * q3 + geo_w[i][3] * q4;                   // :113
       }
       if (in_relu) {
         v.x = fmaxf(v.x, 0.f);

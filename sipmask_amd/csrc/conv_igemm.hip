@@ -1807,7 +1807,10 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
 #endif
   if ((d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)) && !residual) return SM_ERR_BAD_ARG;
   const int tile = sm_conv_cout_tile(d->cout);
-  const bool dma = plan.lds_dma != 0, k32 = plan.k_step == 32, ws = plan.warp_spec != 0;
+  const bool dma = plan.lds_dma != 0, k32 = plan.k_step == 32;
+#ifdef SM_EXPERIMENTS
+  const bool ws = plan.warp_spec != 0;
+#endif
   const int bco = plan.tile_cout, bpos = plan.tile_pos, opt = plan.k_loop;
   ConvKArgs a;
   a.x = (const uint16_t*)x;

@@ -196,19 +196,62 @@ class SipMaskVIS(SipMask):
             return mk(batch) if lanes == 1 else SubBatchPlan([mk(batch // lanes) for _ in range(lanes)])
         return self._engines.get(key, module_tensors(self), build)
 
-    def clip_test(self, imgs, img_metas, rescale=False, encode=True):
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, ref_img, ref_bboxes, gt_pids, gt_bboxes_ignore=None,
+                      gt_masks=None, jitter=None):
+        """V/mmdet/models/detectors/single_stage.py:50-67: losses of one batch of (key frame, reference frame) pairs --
+        extract_feat on both frames, bbox_head(x, x_f) with the track branch on both, SipMask losses + loss_match.
+        The two frames go through backbone and FPN as ONE batch of 2B images (the same launches at twice the rows: the
+        reference runs extract_feat twice), then split per level.  ref_bboxes: gt boxes of the reference frame,
+        gt_pids: for every key-frame gt box the 1-based index of its reference box (0 = new object).  jitter: optional
+        per-image [n_ref, 4] offsets replacing the reference's uniform_(-0.05, 0.05) draw (tests)."""
+        if ref_img.shape != img.shape:
+            raise ValueError("key and reference frames must share one shape")
+        self.bbox_head.train()
+        B = img.shape[0]
+        both = self.extract_feat_train(torch.cat([img, ref_img], 0))
+        x, x_f = tuple(f[:B] for f in both), tuple(f[B:] for f in both)
+        outs = self.bbox_head(x, x_f, True)
+        return self.bbox_head.loss(*outs, gt_bboxes, gt_labels, img_metas, self.train_cfg, gt_bboxes_ignore=gt_bboxes_ignore,
+                                   gt_masks_list=gt_masks, ref_bboxes_list=ref_bboxes, gt_pids_list=gt_pids, jitter=jitter)
+
+    def _run_plan(self, eng, imgs, graph):
+        """eng.run(imgs), or -- graph=True -- the replay of a hipGraph of the whole plan captured once per plan on a static
+        input buffer: a clip is ~2 x 115 launches of a few microseconds each, and the eager launch path is what bounds a
+        clip at this frame size."""
+        if not graph:
+            return eng.run(imgs)
+        st = getattr(eng, "_clip_graph", None)
+        if st is None:
+            static = imgs.clone()
+            eng.run(static)                                   # eager once: side streams and lazy buffers get created
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream(device=imgs.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                eng.run(static)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eng.run(static)
+            st = eng._clip_graph = (static, g)
+        st[0].copy_(imgs)
+        st[1].replay()
+        return eng.results()
+
+    def clip_test(self, imgs, img_metas, rescale=False, encode=True, graph=False):
         """A whole clip at once.  Everything up to the identity matching is independent per frame (backbone, FPN, head,
         track embeddings, fast_nms, mask assembly: V/...:565-616), so the T frames run as ONE batch through the launch
         plan (two half-clip chains for even T >= 4); only `match` (V/...:616-667) is sequential, and it runs here in
         frame order on the batched results -- the same ids as T calls of simple_test, without T latency-bound
         batch-1 passes.  imgs [T,3,H,W]; img_metas: T dicts (is_first resets the tracker).  Returns the T
-        (bbox_results, segm_results) pairs of simple_test (segm_results empty dicts when encode=False)."""
+        (bbox_results, segm_results) pairs of simple_test (segm_results empty dicts when encode=False).
+        graph=True replays one hipGraph per clip instead of launching the plan's kernels one by one (same results)."""
         T = imgs.shape[0]
         m0 = img_metas[0]
         lanes = 2 if (T >= 4 and T % 2 == 0) else 1
         eng = self.prepare(T, tuple(imgs.shape[-2:]), tuple(m0['img_shape']), m0.get('scale_factor', 1.0), bool(rescale),
                            lanes=lanes)
-        r = eng.run(imgs)
+        r = self._run_plan(eng, imgs, graph)
         nd = r["ndet"].cpu().tolist()                              # ONE device->host sync per clip
         rles = eng.encode_rle(tuple(m0['ori_shape'])[:2]) if encode else None
         out = []

@@ -249,3 +249,67 @@ def test_vis_training_losses_vs_oracle():
     for name in ("track_convs.0.conv.weight", "track_convs.1.gn.weight", "sipmask_track.weight", "sipmask_track.bias"):
         gr = dict(head.named_parameters())[name].grad
         assert gr is not None and float(gr.abs().sum()) > 0, name
+
+
+def test_vis_detector_forward_train_vs_oracle():
+    """VERDICT r2 missing #4: SipMaskVIS.forward_train(img, img_metas, gt_bboxes, gt_labels, ref_img, ref_bboxes, gt_pids,
+    gt_masks) -- V/mmdet/models/detectors/single_stage.py:50-67: extract_feat on the key AND the reference frame,
+    bbox_head(x, x_f) with the track branch on both, the SipMask losses + loss_match -- driven from IMAGES on the HIP
+    training graph, against the oracle chain (backbone -> FPN -> head -> track branch -> losses) on the same weights.
+    Loss values within 5 % (bf16 pipeline vs f32 oracle on an untrained, gain-calibrated net, as
+    test_detector_forward_train_vs_oracle); gradients reach backbone, FPN, head and track branch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import loss as OL
+    from sipmask_amd.synthetic import build_synthetic_vis_detector
+    det = build_synthetic_vis_detector(seed=4).cuda()
+    with torch.no_grad():
+        det.bbox_head.fcos_cls.bias.fill_(-3.0)
+    det.train()
+    g = torch.Generator().manual_seed(21)
+    B, Hh, Ww = 2, 128, 160
+    img = torch.randn(B, 3, Hh, Ww, generator=g)
+    ref = img + 0.1 * torch.randn(B, 3, Hh, Ww, generator=g)
+    rng = np.random.RandomState(9)
+    gtb, gtl, gtm, refb, pids, jit = [], [], [], [], [], []
+    for _ in range(B):
+        n = 4
+        xy = rng.rand(n, 2) * np.array([90.0, 70.0])
+        wh = rng.rand(n, 2) * np.array([60.0, 50.0]) + 12
+        b = np.concatenate([xy, np.minimum(xy + wh, [Ww - 1, Hh - 1])], 1).astype(np.float32)
+        m = np.zeros((n, Hh, Ww), np.uint8)
+        for k in range(n):
+            m[k, int(b[k, 1]):int(b[k, 3]) + 1, int(b[k, 0]):int(b[k, 2]) + 1] = 1
+        gtb.append(torch.from_numpy(b))
+        gtl.append(torch.from_numpy(rng.randint(1, 41, n).astype(np.int64)))
+        gtm.append(m)
+        refb.append(torch.from_numpy((b[:3] + rng.randn(3, 4).astype(np.float32) * 2).clip(0, 120)))
+        pids.append(torch.from_numpy(np.array([1, 2, 3, 0], np.int64)))
+        jit.append(torch.from_numpy((rng.rand(3, 4).astype(np.float32) - 0.5) * 0.1))
+    # ---- oracle, from the images
+    osd = {k: v.detach().float().cpu().clone() for k, v in det.state_dict().items()}
+    with torch.no_grad():
+        pyr = OM.fpn_forward(osd, OM.backbone_forward(osd, img, 50))
+        pyr_ref = OM.fpn_forward(osd, OM.backbone_forward(osd, ref, 50))
+        oout = OM.head_forward(osd, pyr)
+        otf, otr = OV.track_forward(osd, pyr), OV.track_forward(osd, pyr_ref)
+        oloss, aux = OL.head_loss(oout[0], oout[1], oout[2], oout[3], oout[4], gtb, gtl, gtm, stride_norm=False)
+        omatch = OV.track_loss(otf, otr, aux["mask_aux"], refb, pids, jit)
+    # ---- HIP training graph, from the images
+    metas = [dict(img_shape=(Hh, Ww, 3), pad_shape=(Hh, Ww, 3), scale_factor=1.0) for _ in range(B)]
+    loss = det.forward_train(img.cuda(), metas, [b.cuda() for b in gtb], [l.cuda() for l in gtl], ref.cuda(),
+                             [r.cuda() for r in refb], [p.cuda() for p in pids], gt_masks=gtm, jitter=jit)
+    assert set(loss) == {"loss_cls", "loss_bbox", "loss_centerness", "loss_mask", "loss_match", "match_acc"}
+    for k in oloss:
+        a, b = float(loss[k].detach()), float(oloss[k].detach())
+        assert abs(a - b) <= 5e-2 * max(1.0, abs(b)), (k, a, b)
+    a, b = float(loss["loss_match"].detach()), float(omatch)
+    assert abs(a - b) <= 5e-2 * max(1.0, abs(b)), ("loss_match", a, b)
+    sum(v for k, v in loss.items() if k != "match_acc").backward()
+    params = dict(det.named_parameters())
+    for name in ("backbone.layer2.0.conv1.weight", "backbone.layer4.2.conv3.weight", "neck.lateral_convs.0.conv.weight",
+                 "neck.fpn_convs.2.conv.weight", "bbox_head.reg_convs.0.conv.weight", "bbox_head.track_convs.0.conv.weight",
+                 "bbox_head.sipmask_track.weight"):
+        gr = params[name].grad
+        assert gr is not None and torch.isfinite(gr).all() and float(gr.abs().sum()) > 0, name
+    assert params["backbone.layer1.0.conv1.weight"].grad is None          # frozen_stages=1 (config)
