@@ -392,7 +392,9 @@ def run_inference(args, rank, world, dev):
                    "launch": ("hipGraph replay" if graph is not None else "eager") +
                              ("" if not subplans else ", %d sub-batch plans of %d images on concurrent streams"
                               % (len(subplans), eng.batch)),
-                   "detections_per_image": ndet},
+                   "detections_per_image": ndet,
+                   # FeatureAlign's kernel, chosen by a one-off measurement on the first eager run (engine._tune_deform)
+                   "deform_kernel": getattr(eng, "deform_choice", None)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_mb_per_launch": round(towers[0].bytes / 1e6, 1), "kernel": kernel,

@@ -611,6 +611,18 @@ int sm_track_match(const float* det_feats, const float* prev_feats, const float*
                    const float* prev_boxes, const int64_t* prev_labels, int n, int t, int channels,
                    float coeff_score, float coeff_iou, float coeff_label, float* comp, int32_t* match_id,
                    float* match_score, sm_stream_t stream);
+/* The tracker of a whole clip on the device (V/mmdet/models/anchor_heads/sipmask_head.py:616-667, frames in order): per
+ * frame the comprehensive scores of sm_track_match against the object memory, the reference's sequential identity
+ * assignment (best claim per object wins, a detection whose best column is the dummy opens a new object, losers get
+ * -1) and the memory update -- one launch per clip instead of a kernel + two device->host syncs per frame.
+ * det_feats f32 [T][max_num][C], det f32 [T][max_num][5], det_labels i64 [T][max_num], ndet / is_first i32 [T] (device);
+ * the memory mem_feats [cap][C] / mem_boxes [cap][5] / mem_labels [cap] / mem_count i32[1] persists between calls
+ * (mem_count = 0: empty, as after reset); comp_ws f32 [max_num][cap + 1] scratch; ids i32 [T][max_num] out (-1 beyond
+ * ndet).  max_num <= 64, cap <= 4096; objects beyond cap are not opened (ids -1). */
+int sm_track_clip(const float* det_feats, const float* det, const int64_t* det_labels, const int32_t* ndet,
+                  const int32_t* is_first, int nframes, int max_num, int channels, float coeff_score, float coeff_iou,
+                  float coeff_label, float* mem_feats, float* mem_boxes, int64_t* mem_labels, int32_t* mem_count,
+                  int capacity, float* comp_ws, int32_t* ids, sm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -119,6 +119,7 @@ PROTOTYPES = {
     "sm_mask_loss_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "sm_mask_loss_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "sm_track_gather": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
+    "sm_track_clip": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _I, _P, _P, _P]),
     "sm_track_match": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P]),
     "sm_mask_rescore": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "sm_conv2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

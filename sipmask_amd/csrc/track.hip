@@ -40,23 +40,17 @@ __device__ __forceinline__ float iou_plus1_f(const float* a, const float* b) {
 }
 
 // comp[n][0..T]: log_softmax([0, f_n . g_t]) + c0 log(score_n) + c1 IoU(+1) + c2 [label equal], dummy column 0
-// has IoU 0 and label_delta 1.  One block per detection; also the row argmax (first maximum) and its value.
-__global__ __launch_bounds__(TR_THREADS) void track_match_kernel(const float* __restrict__ det_feats,
-                                                                 const float* __restrict__ prev_feats,
-                                                                 const float* __restrict__ det,
-                                                                 const int64_t* __restrict__ det_labels,
-                                                                 const float* __restrict__ prev_boxes,
-                                                                 const int64_t* __restrict__ prev_labels, int T, int C,
-                                                                 float c0, float c1, float c2, float* __restrict__ comp,
-                                                                 int32_t* __restrict__ match_id,
-                                                                 float* __restrict__ match_score) {
-  extern __shared__ float s_f[];             // C floats: this detection's embedding
-  __shared__ float s_red[TR_THREADS / 64];
-  __shared__ int s_idx[TR_THREADS / 64];
-  const int n = blockIdx.x, tid = threadIdx.x;
-  for (int c = tid; c < C; c += TR_THREADS) s_f[c] = det_feats[(long long)n * C + c];
+// has IoU 0 and label_delta 1; also the row argmax (first maximum) and its value.  The whole block works on ONE
+// detection (feat / db / lab = its embedding, box, label); s_f: C floats of LDS.  Shared by the per-frame kernel and
+// the clip tracker so that both assign identical ids.
+__device__ __forceinline__ void comp_row(const float* __restrict__ feat, const float* __restrict__ prev_feats,
+                                         const float* __restrict__ db, const int64_t lab,
+                                         const float* __restrict__ prev_boxes, const int64_t* __restrict__ prev_labels,
+                                         int T, int C, float c0, float c1, float c2, float* __restrict__ row, float* s_f,
+                                         float* s_red, int* s_idx, int* out_id, float* out_score) {
+  const int tid = threadIdx.x;
+  for (int c = tid; c < C; c += TR_THREADS) s_f[c] = feat[c];
   __syncthreads();
-  float* row = comp + (long long)n * (T + 1);
   // pass 1: raw products into the row (column 0 = the dummy logit 0)
   if (tid == 0) row[0] = 0.f;
   for (int t = tid; t < T; t += TR_THREADS) {
@@ -87,9 +81,7 @@ __global__ __launch_bounds__(TR_THREADS) void track_match_kernel(const float* __
   const float lse = mx + logf(se);
   __syncthreads();
   // pass 2: comprehensive score, running arg max (first maximum wins)
-  const float* db = det + (long long)n * 5;
   const float ls = c0 * logf(db[4]);
-  const int64_t lab = det_labels[n];
   float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int t = tid; t <= T; t += TR_THREADS) {
@@ -125,9 +117,127 @@ __global__ __launch_bounds__(TR_THREADS) void track_match_kernel(const float* __
         best = s_red[wv];
         bi = s_idx[wv];
       }
-    match_id[n] = bi;
-    match_score[n] = best;
+    *out_id = bi;
+    *out_score = best;
   }
+  __syncthreads();
+}
+
+// one block per detection
+__global__ __launch_bounds__(TR_THREADS) void track_match_kernel(const float* __restrict__ det_feats,
+                                                                 const float* __restrict__ prev_feats,
+                                                                 const float* __restrict__ det,
+                                                                 const int64_t* __restrict__ det_labels,
+                                                                 const float* __restrict__ prev_boxes,
+                                                                 const int64_t* __restrict__ prev_labels, int T, int C,
+                                                                 float c0, float c1, float c2, float* __restrict__ comp,
+                                                                 int32_t* __restrict__ match_id,
+                                                                 float* __restrict__ match_score) {
+  extern __shared__ float s_f[];             // C floats: this detection's embedding
+  __shared__ float s_red[TR_THREADS / 64];
+  __shared__ int s_idx[TR_THREADS / 64];
+  const int n = blockIdx.x;
+  comp_row(det_feats + (long long)n * C, prev_feats, det + (long long)n * 5, det_labels[n], prev_boxes, prev_labels, T, C, c0,
+           c1, c2, comp + (long long)n * (T + 1), s_f, s_red, s_idx, match_id + n, match_score + n);
+}
+
+// The tracker of a whole clip on the device (V/mmdet/models/anchor_heads/sipmask_head.py:616-667 for frames 0..T-1 in
+// order): ONE block walks the frames; per frame the comprehensive scores of every detection against the object memory
+// (comp_row above: identical arithmetic to the per-frame kernel), then the reference's sequential identity assignment
+// -- a detection whose best column is 0 opens a new object, otherwise it claims object o if its score beats the best
+// claim so far (the memory slot takes the LAST winner's embedding and box), losers get -1 -- and the memory append.
+// The memory (feats [cap][C], boxes [cap][5], labels [cap], count) lives in HBM between calls: no host round trip per
+// frame, one D2H of the ids per clip.  Frames without detections are skipped (as the host loop did).
+constexpr int TC_MAXDET = 64;
+__global__ __launch_bounds__(TR_THREADS) void track_clip_kernel(const float* __restrict__ det_feats, const float* __restrict__ det,
+                                                                const int64_t* __restrict__ det_labels,
+                                                                const int32_t* __restrict__ ndet,
+                                                                const int32_t* __restrict__ is_first, int nframes, int max_num,
+                                                                int C, float c0, float c1, float c2, float* __restrict__ mem_feats,
+                                                                float* __restrict__ mem_boxes, int64_t* __restrict__ mem_labels,
+                                                                int32_t* __restrict__ mem_count, int cap,
+                                                                float* __restrict__ comp_ws, int32_t* __restrict__ ids) {
+  extern __shared__ float s_dyn[];           // [C] embedding | [cap] best claim per object | [cap] its detection (int)
+  float* s_f = s_dyn;
+  float* s_best = s_dyn + C;
+  int* s_win = reinterpret_cast<int*>(s_best + cap);
+  __shared__ float s_red[TR_THREADS / 64];
+  __shared__ int s_idx[TR_THREADS / 64];
+  __shared__ int s_mid[TC_MAXDET], s_id[TC_MAXDET], s_new[TC_MAXDET], s_cnt, s_nnew;
+  __shared__ float s_msc[TC_MAXDET];
+  const int tid = threadIdx.x;
+  if (tid == 0) s_cnt = *mem_count;
+  __syncthreads();
+  for (int t = 0; t < nframes; ++t) {
+    const int n = min(min(ndet[t], max_num), TC_MAXDET);
+    int32_t* idt = ids + (long long)t * max_num;
+    for (int i = tid; i < max_num; i += TR_THREADS) idt[i] = -1;
+    if (n <= 0) continue;                                                   // block-uniform
+    const float* ft = det_feats + (long long)t * max_num * C;
+    const float* bt = det + (long long)t * max_num * 5;
+    const int64_t* lt = det_labels + (long long)t * max_num;
+    const int cnt = s_cnt;
+    if (is_first[t] != 0 || cnt == 0) {                                     // the frame's detections ARE the memory
+      const int m = min(n, cap);
+      for (int j = tid; j < m * C; j += TR_THREADS) mem_feats[j] = ft[j];
+      for (int j = tid; j < m * 5; j += TR_THREADS) mem_boxes[j] = bt[j];
+      for (int j = tid; j < m; j += TR_THREADS) {
+        mem_labels[j] = lt[j];
+        idt[j] = j;
+      }
+      __syncthreads();
+      if (tid == 0) s_cnt = m;
+      __syncthreads();
+      continue;
+    }
+    for (int i = 0; i < n; ++i)
+      comp_row(ft + (long long)i * C, mem_feats, bt + i * 5, lt[i], mem_boxes, mem_labels, cnt, C, c0, c1, c2,
+               comp_ws + (long long)i * (cap + 1), s_f, s_red, s_idx, &s_mid[i], &s_msc[i]);
+    for (int o = tid; o < cnt; o += TR_THREADS) {
+      s_best[o] = -100.f;
+      s_win[o] = -1;
+    }
+    __syncthreads();
+    if (tid == 0) {                                                         // the reference's sequential loop (:641-660)
+      int nnew = 0;
+      for (int i = 0; i < n; ++i) {
+        const int m = s_mid[i];
+        int id = -1;
+        if (m == 0) {
+          if (cnt + nnew < cap) {
+            id = cnt + nnew;
+            s_new[nnew++] = i;
+          }
+        } else if (s_msc[i] > s_best[m - 1]) {
+          id = m - 1;
+          s_best[m - 1] = s_msc[i];
+          s_win[m - 1] = i;
+        }
+        s_id[i] = id;
+      }
+      s_nnew = nnew;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += TR_THREADS) idt[i] = s_id[i];
+    // memory update: slot o takes its last winner; new objects are appended in detection order
+    for (int o = 0; o < cnt; ++o) {
+      const int w = s_win[o];
+      if (w < 0) continue;                                                  // block-uniform (LDS value)
+      for (int c = tid; c < C; c += TR_THREADS) mem_feats[(long long)o * C + c] = ft[(long long)w * C + c];
+      if (tid < 5) mem_boxes[o * 5 + tid] = bt[w * 5 + tid];
+    }
+    const int nnew = s_nnew;
+    for (int k = 0; k < nnew; ++k) {
+      const int w = s_new[k], o = cnt + k;
+      for (int c = tid; c < C; c += TR_THREADS) mem_feats[(long long)o * C + c] = ft[(long long)w * C + c];
+      if (tid < 5) mem_boxes[o * 5 + tid] = bt[w * 5 + tid];
+      if (tid == 0) mem_labels[o] = lt[w];
+    }
+    __syncthreads();
+    if (tid == 0) s_cnt = cnt + nnew;
+    __syncthreads();
+  }
+  if (tid == 0) *mem_count = s_cnt;
 }
 
 }  // namespace
@@ -154,6 +264,24 @@ extern "C" int sm_track_match(const float* det_feats, const float* prev_feats, c
   hipLaunchKernelGGL(track_match_kernel, dim3(n), dim3(TR_THREADS), channels * sizeof(float), sm_hip_stream(stream),
                      det_feats, prev_feats, det, det_labels, prev_boxes, prev_labels, t, channels, coeff_score, coeff_iou,
                      coeff_label, comp, match_id, match_score);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_track_clip(const float* det_feats, const float* det, const int64_t* det_labels, const int32_t* ndet,
+                             const int32_t* is_first, int nframes, int max_num, int channels, float coeff_score,
+                             float coeff_iou, float coeff_label, float* mem_feats, float* mem_boxes, int64_t* mem_labels,
+                             int32_t* mem_count, int capacity, float* comp_ws, int32_t* ids, sm_stream_t stream) {
+  if (!det_feats || !det || !det_labels || !ndet || !is_first || !mem_feats || !mem_boxes || !mem_labels || !mem_count ||
+      !comp_ws || !ids)
+    return SM_ERR_BAD_ARG;
+  if (nframes < 1 || max_num < 1 || max_num > TC_MAXDET || channels < 1 || channels > 8192 || capacity < max_num ||
+      capacity > 4096)
+    return SM_ERR_BAD_SHAPE;
+  const size_t lds = (size_t)(channels + 2 * capacity) * sizeof(float);
+  hipLaunchKernelGGL(track_clip_kernel, dim3(1), dim3(TR_THREADS), lds, sm_hip_stream(stream), det_feats, det, det_labels,
+                     ndet, is_first, nframes, max_num, channels, coeff_score, coeff_iou, coeff_label, mem_feats, mem_boxes,
+                     mem_labels, mem_count, capacity, comp_ws, ids);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -30,7 +30,11 @@ _PATCH_CONV = __import__("os").environ.get("SIPMASK_PATCH_CONV", "1") != "0"   #
 # learned offsets stay within ~3 pixels and falls behind it when most waves sample farther out (random offsets of sigma 4:
 # 0.35 vs 0.26 ms at B=4, profiles/r02_deform_conv_microbench.txt); SIPMASK_DEFORM_GATHER=1 keeps a model with such
 # offsets on the gather loader
-_DEFORM_FLAGS = _lib.SM_CONV_DBG_DEFORM_GATHER if __import__("os").environ.get("SIPMASK_DEFORM_GATHER", "0") == "1" else 0
+# ... so the plan MEASURES it: SIPMASK_DEFORM_GATHER = "auto" (default) times both kernels once, on the offsets of the first
+# eager run of the plan (the checkpoint's own offsets on a real input), and keeps the gather loader only where it is
+# more than 10 % faster; "0" / "1" pin the window kernel / the gather loader.
+_DEFORM_MODE = __import__("os").environ.get("SIPMASK_DEFORM_GATHER", "auto")
+_DEFORM_FLAGS = _lib.SM_CONV_DBG_DEFORM_GATHER if _DEFORM_MODE == "1" else 0
 _PATCH_MIN_WORK = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_WORK", "100"))   # 256x256 tile equivalents
 _PATCH_MIN_FILL = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_FILL", "0.6"))
 # bottleneck fusion in layer1 / layer2: 0 = separate launches, 1 = conv2+conv3, 2 = conv2+conv3+next conv1.  Measured
@@ -850,6 +854,12 @@ class SipMaskEngine:
                                  sd.get(h + "feat_align.conv_adaption.bias"), B, sizes,
                                  row0, self.cls_feat, 256, 1, 1, self.aligned, row0, 256, deform_groups=4,
                                  offset=self.offsets, flags=(0 if self.flag_norm else SM_CONV_RELU) | _DEFORM_FLAGS))
+        # two kernels can run this conv (LDS window / global gather): which one is faster depends on how far the
+        # checkpoint's learned offsets reach -- measured once on the first eager run (_tune_deform)
+        self._fa_conv = c
+        self._deform_tune = (_DEFORM_MODE == "auto" and self.precision == "bf16" and
+                             H.deform_conv_window_plan(c.desc) is not None)
+        self.deform_choice = None
         if self.flag_norm:                                 # FeatureAlign.forward, sipmask_head.py:49-55
             self._gn("feat_align", self.aligned, sd[h + "feat_align.norm.weight"], sd[h + "feat_align.norm.bias"],
                      conv=c)
@@ -1026,11 +1036,39 @@ class SipMaskEngine:
         self.out_hw = [(int(g[4]), int(g[5])) for g in geom]
         return self
 
+    def _tune_deform(self):
+        """One-off choice of FeatureAlign's kernel on THIS plan's offsets (just produced by the first eager run): the
+        LDS-window kernel serves offsets within ~3 pixels from LDS and sends a wave whose samples reach further through a
+        slower global gather, the gather loader costs the same everywhere (profiles/r02_deform_conv_microbench.txt:
+        0.107 vs 0.18 ms with small offsets, 0.353 vs 0.258 ms with ~N(0, 4 px) offsets at B=4).  Both produce the same
+        result up to accumulation order; the choice is made once per plan, so a plan stays bit-reproducible."""
+        self._deform_tune = False
+        c = self._fa_conv
+        base = c.desc.flags & ~_lib.SM_CONV_DBG_DEFORM_GATHER
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t = {}
+        for name, fl in (("window", base), ("gather", base | _lib.SM_CONV_DBG_DEFORM_GATHER)):
+            c.desc.flags = fl
+            c()
+            e0.record()
+            for _ in range(3):
+                c()
+            e1.record()
+            torch.cuda.synchronize()
+            t[name] = e0.elapsed_time(e1) / 3
+        pick = "gather" if t["gather"] < 0.9 * t["window"] else "window"
+        c.desc.flags = base | (_lib.SM_CONV_DBG_DEFORM_GATHER if pick == "gather" else 0)
+        c()                                                   # leave the buffers as the chosen kernel writes them
+        self.deform_choice = dict(kernel=pick, window_ms=round(t["window"], 4), gather_ms=round(t["gather"], 4))
+
     # -------------------------------------------------------------------------------- execution
     def run(self, img):
         """img: float32 NCHW [B,3,H,W] on the device.  Returns the result dict (device tensors)."""
         assert img.shape == (self.batch, 3, self.H, self.W) and img.dtype == torch.float32 and img.is_cuda
         self.img = img.contiguous()
+        if getattr(self, "_deform_tune", False) and not torch.cuda.is_current_stream_capturing():
+            self._run_steps(self.steps, self.lanes)           # first eager run: produces the offsets to measure on
+            self._tune_deform()
         self._run_steps(self.steps, self.lanes)
         return self.results()
 

@@ -762,6 +762,32 @@ def track_match(det_feats, prev_feats, det, det_labels, prev_boxes, prev_labels,
     return comp, mid, msc
 
 
+def track_state_alloc(channels, max_num, device, capacity=1024):
+    """object memory of the device tracker (sm_track_clip): embeddings, boxes (x1,y1,x2,y2,score), labels, count"""
+    return dict(feats=torch.zeros(capacity, channels, dtype=torch.float32, device=device),
+                boxes=torch.zeros(capacity, 5, dtype=torch.float32, device=device),
+                labels=torch.zeros(capacity, dtype=torch.int64, device=device),
+                count=torch.zeros(1, dtype=torch.int32, device=device),
+                comp=torch.empty(max_num, capacity + 1, dtype=torch.float32, device=device), capacity=capacity, max_num=max_num)
+
+
+def track_clip(det_feats, det, det_labels, ndet, is_first, coeff, state, ids=None):
+    """identity assignment of T frames in order on the device; det_feats [T,max,C], det [T,max,5], det_labels [T,max] i64,
+    ndet / is_first i32 [T] device tensors -> ids i32 [T,max] (device; -1 beyond ndet / lost claims)"""
+    _lib.require_cuda(det_feats, det, det_labels, ndet, is_first)
+    T, mx, c = det_feats.shape
+    if mx > state["max_num"]:
+        raise ValueError("tracker state was allocated for %d detections per frame, got %d" % (state["max_num"], mx))
+    if ids is None:
+        ids = torch.empty(T, mx, dtype=torch.int32, device=det_feats.device)
+    _lib.check(_lib.load().sm_track_clip(_lib.ptr(det_feats), _lib.ptr(det), _lib.ptr(det_labels), _lib.ptr(ndet),
+                                         _lib.ptr(is_first), T, mx, c, float(coeff[0]), float(coeff[1]), float(coeff[2]),
+                                         _lib.ptr(state["feats"]), _lib.ptr(state["boxes"]), _lib.ptr(state["labels"]),
+                                         _lib.ptr(state["count"]), state["capacity"], _lib.ptr(state["comp"]), _lib.ptr(ids),
+                                         _lib.stream_ptr()), "sm_track_clip")
+    return ids
+
+
 def mask_rescore(feat, labels, det, ndet, hw, out):
     """feat f32 [B*max_num*hw, C]; labels [B, max_num]; det [B, max_num, 5]; out f32 [B, max_num]."""
     lib = _lib.load()

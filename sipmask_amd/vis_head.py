@@ -40,8 +40,29 @@ class SipMaskVISHead(SipMaskHead):
         self.reset_tracker()
 
     # ------------------------------------------------------------------ tracker state (:169-171)
+    # The object memory (prev_roi_feats / prev_bboxes / prev_det_labels of the reference) lives on the device and is
+    # walked by ONE kernel per clip (sm_track_clip); the attributes below are views of it for code that reads them.
     def reset_tracker(self):
-        self.prev_roi_feats = self.prev_bboxes = self.prev_det_labels = None
+        st = getattr(self, "_trk", None)
+        if st is not None:
+            st["count"].zero_()
+
+    def _tracker(self, device, max_num):
+        st = getattr(self, "_trk", None)
+        if st is None or st["feats"].device != device or st["max_num"] < max_num:
+            st = self._trk = H.track_state_alloc(512, max(max_num, 16), device)
+        return st
+
+    def _mem(self, key):
+        st = getattr(self, "_trk", None)
+        if st is None:
+            return None
+        n = int(st["count"].item())
+        return st[key][:n] if n else None
+
+    prev_roi_feats = property(lambda self: self._mem("feats"))
+    prev_bboxes = property(lambda self: self._mem("boxes"))
+    prev_det_labels = property(lambda self: self._mem("labels"))
 
     def _engine(self, batch, sizes, img_shape=None, cfg=None):
         from .engine import SipMaskEngine
@@ -121,36 +142,26 @@ class SipMaskVISHead(SipMaskHead):
     def match(self, det_bboxes, det_labels, det_roi_feats, is_first):
         """Identity assignment of one frame.  det_bboxes [N,5], det_labels [N], det_roi_feats [N,512] on the
         device.  Returns det_obj_ids (numpy int32 [N]; -1 = duplicate claim that lost, as in the reference).
-        The scores come from sm_track_match; the sequential memory update is the reference's host loop."""
+        One frame of the device tracker (sm_track_clip: scores, the reference's sequential assignment and the memory
+        update in one launch), one D2H of the ids."""
         n = det_bboxes.shape[0]
-        if is_first or self.prev_bboxes is None:
-            self.prev_bboxes, self.prev_roi_feats = det_bboxes.clone(), det_roi_feats.clone()
-            self.prev_det_labels = det_labels.clone()
-            return np.arange(n)
-        comp, mid, _ = H.track_match(det_roi_feats.contiguous(), self.prev_roi_feats.contiguous(),
-                                     det_bboxes.contiguous(), det_labels.contiguous(), self.prev_bboxes.contiguous(),
-                                     self.prev_det_labels.contiguous(), self.match_coeff)
-        match_ids = mid.cpu().numpy()
-        comp_h = comp.cpu().numpy()
-        ids = -np.ones(n, dtype=np.int32)
-        best = -100.0 * np.ones(self.prev_bboxes.size(0))
-        new = []
-        for i, m in enumerate(match_ids):
-            if m == 0:
-                ids[i] = self.prev_roi_feats.size(0) + len(new)
-                new.append(i)
-            else:
-                o = int(m) - 1
-                if comp_h[i, m] > best[o]:
-                    ids[i], best[o] = o, comp_h[i, m]
-                    self.prev_roi_feats[o] = det_roi_feats[i]
-                    self.prev_bboxes[o] = det_bboxes[i]
-        if new:
-            idx = torch.as_tensor(new, device=det_bboxes.device)
-            self.prev_roi_feats = torch.cat((self.prev_roi_feats, det_roi_feats[idx]), 0)
-            self.prev_bboxes = torch.cat((self.prev_bboxes, det_bboxes[idx]), 0)
-            self.prev_det_labels = torch.cat((self.prev_det_labels, det_labels[idx]), 0)
-        return ids
+        dev = det_bboxes.device
+        st = self._tracker(dev, n)
+        ids = H.track_clip(det_roi_feats.contiguous().view(1, n, -1), det_bboxes.contiguous().view(1, n, 5),
+                           det_labels.contiguous().view(1, n), torch.tensor([n], dtype=torch.int32, device=dev),
+                           torch.tensor([1 if is_first else 0], dtype=torch.int32, device=dev), self.match_coeff, st)
+        return ids[0].cpu().numpy()
+
+    def match_clip(self, det_feats, det_bboxes, det_labels, ndet, is_first):
+        """The frames of a clip in order (det_feats [T,max,512], det_bboxes [T,max,5], det_labels [T,max], ndet i32 [T] on the
+        device; is_first: T bools) -> ids i32 [T,max] on the device: no host round trip per frame."""
+        dev = det_feats.device
+        st = self._tracker(dev, det_feats.shape[1])
+        key = tuple(bool(f) for f in is_first)
+        flags = getattr(self, "_first_flags", None)
+        if flags is None or flags[0] != key or flags[1].device != dev:
+            flags = self._first_flags = (key, torch.tensor([int(f) for f in key], dtype=torch.int32, device=dev))
+        return H.track_clip(det_feats, det_bboxes, det_labels, ndet, flags[1], self.match_coeff, st)
 
     def get_bboxes(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, track_feats, track_feats_ref,
                    img_metas, cfg, rescale=None):
@@ -252,7 +263,11 @@ class SipMaskVIS(SipMask):
         eng = self.prepare(T, tuple(imgs.shape[-2:]), tuple(m0['img_shape']), m0.get('scale_factor', 1.0), bool(rescale),
                            lanes=lanes)
         r = self._run_plan(eng, imgs, graph)
-        nd = r["ndet"].cpu().tolist()                              # ONE device->host sync per clip
+        ids_dev = self.bbox_head.match_clip(r["det_feats"], r["det_bboxes"], r["det_labels"], r["ndet"],
+                                            [m['is_first'] for m in img_metas])
+        # ONE synchronising device->host fetch per clip (counts), three more small copies behind it
+        nd = r["ndet"].cpu().tolist()
+        ids_h, det_h, lab_h = ids_dev.cpu().numpy(), r["det_bboxes"].cpu().numpy(), r["det_labels"].cpu().numpy()
         rles = eng.encode_rle(tuple(m0['ori_shape'])[:2]) if encode else None
         out = []
         for t in range(T):
@@ -260,9 +275,7 @@ class SipMaskVIS(SipMask):
             if n == 0:
                 out.append((dict(), [[] for _ in range(self.bbox_head.num_classes - 1)]))
                 continue
-            det, labels = r["det_bboxes"][t, :n], r["det_labels"][t, :n]
-            ids = self.bbox_head.match(det, labels, r["det_feats"][t, :n], img_metas[t]['is_first'])
-            d, l = det.cpu().numpy(), labels.cpu().numpy()
+            ids, d, l = ids_h[t, :n], det_h[t, :n], lab_h[t, :n]
             bbox_results, segm_results = {}, {}
             for i in range(n):
                 if ids[i] >= 0:
