@@ -79,6 +79,11 @@ typedef enum {
  * the three-term product hi*hi + lo*hi + hi*lo with f32 accumulation (sm_split3_f16 writes that layout).  Needs
  * SM_CONV_OUT_F32, no residual / input ReLU / deformable gather; sm_conv2d, sm_conv2d_gn_stats, sm_conv3x3_patch. */
 #define SM_CONV_F16 0x00020000u
+/* With SM_CONV_F16 on sm_conv2d / sm_conv2d_ws (forward descriptors only; the bit is SM_CONV_BWD_GX_BF16 on backward ones):
+ * y is written as the NEXT layer's split operand instead of f32 -- binary16 [rows][out_cstride] with out_cstride = 3 * ctot:
+ * hi at out_coff + c, lo at ctot + out_coff + c, hi at 2 * ctot + out_coff + c (after bias / Scale / ReLU).  For convs
+ * without a GroupNorm behind them (sip_mask_lat0, the SSD-style towers).  Needs the register epilogue's alignment. */
+#define SM_CONV_OUT_X3 64u
 
 /* One (multi-level) 2-D convolution as an implicit GEMM.  Replaces the ATen/cuDNN
  * conv calls under M/mmdet/models/backbones/resnet.py:206-229,
@@ -328,6 +333,10 @@ int sm_groupnorm_apply(const void* x, void* y, const float* gamma, const float* 
  *   rows, may alias x) and / or y_split (binary16 [rows][3*channels], [hi | lo | hi]); either may be NULL, not both. */
 int sm_split3_f16(const void* x, int x_is_f32, int64_t rows, int channels, int in_cstride, void* y, int ctot, int coff,
                   sm_stream_t stream);
+/* sm_upsample_bilinear (f32 rows [batch*h*w][in_cstride], first c channels, integer factor, align_corners=False) with
+ * the result written as the split layout of sm_split3_f16 (y binary16 [batch*h*factor*w*factor][3*ctot], slice coff). */
+int sm_upsample_bilinear_x3(const float* x, void* y, int batch, int h, int w, int c, int factor, int in_cstride, int ctot,
+                            int coff, sm_stream_t stream);
 int sm_gn_stats_f32_fix(const float* x, int64_t* stats, int batch, int nlev, const int32_t* hw, const int64_t* row0,
                         int channels, int groups, sm_stream_t stream);
 int sm_groupnorm_apply_x3(const float* x, const float* gamma, const float* beta, const int64_t* stats, int batch, int nlev,
@@ -617,8 +626,9 @@ int sm_track_match(const float* det_feats, const float* prev_feats, const float*
  * -1) and the memory update -- one launch per clip instead of a kernel + two device->host syncs per frame.
  * det_feats f32 [T][max_num][C], det f32 [T][max_num][5], det_labels i64 [T][max_num], ndet / is_first i32 [T] (device);
  * the memory mem_feats [cap][C] / mem_boxes [cap][5] / mem_labels [cap] / mem_count i32[1] persists between calls
- * (mem_count = 0: empty, as after reset); comp_ws f32 [max_num][cap + 1] scratch; ids i32 [T][max_num] out (-1 beyond
- * ndet).  max_num <= 64, cap <= 4096; objects beyond cap are not opened (ids -1). */
+ * (mem_count = 0: empty, as after reset); comp_ws: reserved, may be NULL (the score rows live in LDS); ids i32 [T][max_num]
+ * out (-1 beyond ndet).  max_num <= 64, channels a multiple of 64 up to 1024, cap <= 2000 (LDS); objects beyond cap are
+ * not opened (ids -1). */
 int sm_track_clip(const float* det_feats, const float* det, const int64_t* det_labels, const int32_t* ndet,
                   const int32_t* is_first, int nframes, int max_num, int channels, float coeff_score, float coeff_iou,
                   float coeff_label, float* mem_feats, float* mem_boxes, int64_t* mem_labels, int32_t* mem_count,

@@ -26,6 +26,7 @@ SM_CONV_DBG_HAND_PLACED = 0x00040000
 SM_CONV_DBG_PATCH_UNIFORM = 0x00004000
 SM_CONV_DBG_LDS_EPILOGUE = 0x01000000
 SM_CONV_F16 = 0x00020000                 # IEEE binary16 operands (the x3 head plan), f32 output
+SM_CONV_OUT_X3 = 64                      # ... or the next layer's split operand [hi | lo | hi] (forward descriptors)
 
 _i32x5 = C.c_int32 * SM_MAX_LEVELS
 _i64x5 = C.c_int64 * SM_MAX_LEVELS
@@ -103,6 +104,7 @@ PROTOTYPES = {
     "sm_bottleneck_tail_supported": (_I, [_I]),
     "sm_bottleneck_tail": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_split3_f16": (_I, [_P, _I, C.c_int64, _I, _I, _P, _I, _I, _P]),
+    "sm_upsample_bilinear_x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sm_gn_stats_f32_fix": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _P]),
     "sm_groupnorm_apply_x3": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P]),
     "sm_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P]),

@@ -940,6 +940,23 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
               if (c0 + e < a.scale_nch) v[e] = fmaxf(v[e], 0.f);
           }
           const long long o = (out_row0 + m) * a.out_cstride + a.out_coff + c0;
+#ifdef SM_OPERAND_F16
+          if (a.flags & SM_CONV_OUT_X3) {          // the next layer's split operand: [hi | lo | hi], ctot = out_cstride / 3
+            const int ctot = a.out_cstride / 3;
+            frag8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float cv = fminf(fmaxf(v[e], -65504.f), 65504.f);
+              const _Float16 hv = (_Float16)cv;
+              hi[e] = hv;
+              lo[e] = (_Float16)(cv - (float)hv);
+            }
+            uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + o;
+            *reinterpret_cast<frag8*>(yp) = hi;
+            *reinterpret_cast<frag8*>(yp + ctot) = lo;
+            *reinterpret_cast<frag8*>(yp + 2 * ctot) = hi;
+          } else
+#endif
           if (out_f32) {
             float* yp = reinterpret_cast<float*>(a.y) + o;
             *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1454,6 +1471,23 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
               if (c0 + e < a.scale_nch) v[e] = fmaxf(v[e], 0.f);
           }
           const long long o = (out_row0 + m) * a.out_cstride + a.out_coff + c0;
+#ifdef SM_OPERAND_F16
+          if (a.flags & SM_CONV_OUT_X3) {          // the next layer's split operand: [hi | lo | hi], ctot = out_cstride / 3
+            const int ctot = a.out_cstride / 3;
+            frag8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float cv = fminf(fmaxf(v[e], -65504.f), 65504.f);
+              const _Float16 hv = (_Float16)cv;
+              hi[e] = hv;
+              lo[e] = (_Float16)(cv - (float)hv);
+            }
+            uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + o;
+            *reinterpret_cast<frag8*>(yp) = hi;
+            *reinterpret_cast<frag8*>(yp + ctot) = lo;
+            *reinterpret_cast<frag8*>(yp + 2 * ctot) = hi;
+          } else
+#endif
           if (out_f32) {
             float* yp = reinterpret_cast<float*>(a.y) + o;
             *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1798,11 +1832,18 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   if (prc != SM_OK) return prc;
 #ifdef SM_OPERAND_F16
   // the binary16 build: LDS-DMA kernels with f32 output only (what the x3 head plan launches)
-  if (DEFORM || !plan.lds_dma || !(d->flags & SM_CONV_OUT_F32) || (d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)))
+  if (DEFORM || !plan.lds_dma || !(d->flags & (SM_CONV_OUT_F32 | SM_CONV_OUT_X3)) ||
+      (d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)))
     return SM_ERR_UNSUPPORTED;
+  if (d->flags & SM_CONV_OUT_X3) {                  // written by the register epilogue only (8 couts per lane, 16-byte stores)
+    if ((d->flags & SM_CONV_DBG_LDS_EPILOGUE) || (d->cout & 7) || (d->out_cstride % 24) || (d->out_coff & 7) || gn_stats ||
+        d->out_cstride < 3 * d->cout || plan.split_k > 1)
+      return SM_ERR_UNSUPPORTED;
+  }
 #else
   if (!DEFORM && (d->flags & SM_CONV_F16))          // same plan, same launch code, the other MFMA (conv_igemm_f16.o)
-    return sm_conv_igemm_f16(d, x, w, bias, y, stream, gn_stats, workspace, workspace_bytes);
+    return sm_conv_igemm_f16(d, x, w, bias, y, stream, gn_stats, (d->flags & SM_CONV_OUT_X3) ? nullptr : workspace,
+                             workspace_bytes);
   if (d->flags & SM_CONV_F16) return SM_ERR_UNSUPPORTED;
 #endif
   if ((d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)) && !residual) return SM_ERR_BAD_ARG;

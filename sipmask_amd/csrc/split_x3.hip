@@ -63,6 +63,49 @@ __global__ __launch_bounds__(256) void split3_kernel(const SplitArgs a) {
   }
 }
 
+// bilinear x`factor` upsampling (align_corners=False; the formula of upsample_bilinear_kernel, misc.hip) of f32 rows
+// written straight as [hi | lo | hi]: the mask branch's concatenation [l0 | up2(l1) | up4(l2)] (sipmask_head.py:266-275)
+// becomes three launches into one split tensor instead of three upsamples into an f32 tensor + a split pass over it
+__global__ __launch_bounds__(256) void upsample_split3_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int B, int H,
+                                                              int W, int C, int factor, int in_cs, int ctot, int coff) {
+  const int Ho = H * factor, Wo = W * factor, cv = C / 8;
+  const long long total = (long long)B * Ho * Wo * cv;
+  const float inv = 1.f / (float)factor;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cv);
+    long long p = i / cv;
+    const int wo = (int)(p % Wo);
+    p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const float sy = fmaxf(((float)ho + 0.5f) * inv - 0.5f, 0.f), sx = fmaxf(((float)wo + 0.5f) * inv - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* pa = x + (((long long)n * H + y0) * W + x0) * in_cs + cc * 8;
+    const float* pb = x + (((long long)n * H + y0) * W + x1) * in_cs + cc * 8;
+    const float* pc = x + (((long long)n * H + y1) * W + x0) * in_cs + cc * 8;
+    const float* pd = x + (((long long)n * H + y1) * W + x1) * in_cs + cc * 8;
+    float a[8], b[8], c[8], d[8], r[8];
+    *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(pa);
+    *reinterpret_cast<float4*>(a + 4) = *reinterpret_cast<const float4*>(pa + 4);
+    *reinterpret_cast<float4*>(b) = *reinterpret_cast<const float4*>(pb);
+    *reinterpret_cast<float4*>(b + 4) = *reinterpret_cast<const float4*>(pb + 4);
+    *reinterpret_cast<float4*>(c) = *reinterpret_cast<const float4*>(pc);
+    *reinterpret_cast<float4*>(c + 4) = *reinterpret_cast<const float4*>(pc + 4);
+    *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(pd);
+    *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(pd + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = hy * (hx * a[e] + lx * b[e]) + ly * (hx * c[e] + lx * d[e]);
+    half8 hi, lo;
+    split8(r, hi, lo);
+    uint16_t* o = y + (((long long)n * Ho + ho) * Wo + wo) * (3ll * ctot) + coff + cc * 8;
+    *reinterpret_cast<half8*>(o) = hi;
+    *reinterpret_cast<half8*>(o + ctot) = lo;
+    *reinterpret_cast<half8*>(o + 2 * ctot) = hi;
+  }
+}
+
 struct GnxArgs {
   int nlev, batch, C, groups, cpg;
   int hw[SM_MAX_LEVELS];
@@ -237,6 +280,20 @@ extern "C" int sm_groupnorm_apply_x3(const float* x, const float* gamma, const f
   if (rc != SM_OK) return rc;
   hipLaunchKernelGGL(gnx_apply_kernel, dim3(t, batch), dim3(256), 0, sm_hip_stream(stream), x, gamma, beta,
                      reinterpret_cast<const unsigned long long*>(stats), y_f32, (uint16_t*)y_split, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_upsample_bilinear_x3(const float* x, void* y, int batch, int h, int w, int c, int factor, int in_cstride,
+                                       int ctot, int coff, sm_stream_t stream) {
+  if (!x || !y || factor < 1) return SM_ERR_BAD_ARG;
+  if (batch < 1 || h < 1 || w < 1 || c < 8 || c % 8 || in_cstride % 4 || in_cstride < c || ctot % 8 || coff % 8 || coff + c > ctot)
+    return SM_ERR_BAD_SHAPE;
+  const long long n = (long long)batch * h * factor * w * factor * (c / 8);
+  long long g = (n + 255) / 256;
+  if (g > 256 * 32) g = 256 * 32;
+  hipLaunchKernelGGL(upsample_split3_kernel, dim3((unsigned)g), dim3(256), 0, sm_hip_stream(stream), x, (uint16_t*)y, batch, h, w,
+                     c, factor, in_cstride, ctot, coff);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -142,14 +142,15 @@ __global__ __launch_bounds__(TR_THREADS) void track_match_kernel(const float* __
 }
 
 // The tracker of a whole clip on the device (V/mmdet/models/anchor_heads/sipmask_head.py:616-667 for frames 0..T-1 in
-// order): ONE block walks the frames; per frame the comprehensive scores of every detection against the object memory
-// (comp_row above: identical arithmetic to the per-frame kernel), then the reference's sequential identity assignment
-// -- a detection whose best column is 0 opens a new object, otherwise it claims object o if its score beats the best
-// claim so far (the memory slot takes the LAST winner's embedding and box), losers get -1 -- and the memory append.
-// The memory (feats [cap][C], boxes [cap][5], labels [cap], count) lives in HBM between calls: no host round trip per
-// frame, one D2H of the ids per clip.  Frames without detections are skipped (as the host loop did).
-constexpr int TC_MAXDET = 64;
-__global__ __launch_bounds__(TR_THREADS) void track_clip_kernel(const float* __restrict__ det_feats, const float* __restrict__ det,
+// order): ONE block walks the frames.  Per frame every detection's comprehensive scores against the object memory are
+// formed by one WAVE (16 waves = 16 detections at a time; a lane holds channels lane, lane+64, ... of the embedding, a
+// dot product is 8 coalesced loads + a shuffle tree), then the reference's sequential identity assignment -- a detection
+// whose best column is the dummy opens a new object, otherwise it claims object o if its score beats the best claim so
+// far (the memory slot takes the LAST winner's embedding and box), losers get -1 -- and the memory append.  The memory
+// (feats [cap][C], boxes [cap][5], labels [cap], count) lives in HBM between calls: no host round trip per frame, one
+// D2H of the ids per clip.  Frames without detections are skipped (as the host loop did).
+constexpr int TC_MAXDET = 64, TC_THREADS = 1024, TC_MAXCJ = 16;   // C <= 64 * TC_MAXCJ channels
+__global__ __launch_bounds__(TC_THREADS) void track_clip_kernel(const float* __restrict__ det_feats, const float* __restrict__ det,
                                                                 const int64_t* __restrict__ det_labels,
                                                                 const int32_t* __restrict__ ndet,
                                                                 const int32_t* __restrict__ is_first, int nframes, int max_num,
@@ -157,21 +158,20 @@ __global__ __launch_bounds__(TR_THREADS) void track_clip_kernel(const float* __r
                                                                 float* __restrict__ mem_boxes, int64_t* __restrict__ mem_labels,
                                                                 int32_t* __restrict__ mem_count, int cap,
                                                                 float* __restrict__ comp_ws, int32_t* __restrict__ ids) {
-  extern __shared__ float s_dyn[];           // [C] embedding | [cap] best claim per object | [cap] its detection (int)
-  float* s_f = s_dyn;
-  float* s_best = s_dyn + C;
+  extern __shared__ float s_dyn[];           // [cap] best claim per object | [cap] its detection (int) | 16 x [cap + 1] score rows
+  float* s_best = s_dyn;
   int* s_win = reinterpret_cast<int*>(s_best + cap);
-  __shared__ float s_red[TR_THREADS / 64];
-  __shared__ int s_idx[TR_THREADS / 64];
+  float* s_rows = s_dyn + 2 * cap;
   __shared__ int s_mid[TC_MAXDET], s_id[TC_MAXDET], s_new[TC_MAXDET], s_cnt, s_nnew;
   __shared__ float s_msc[TC_MAXDET];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cj = C >> 6;                     // channels per lane (C % 64 == 0)
   if (tid == 0) s_cnt = *mem_count;
   __syncthreads();
   for (int t = 0; t < nframes; ++t) {
     const int n = min(min(ndet[t], max_num), TC_MAXDET);
     int32_t* idt = ids + (long long)t * max_num;
-    for (int i = tid; i < max_num; i += TR_THREADS) idt[i] = -1;
+    for (int i = tid; i < max_num; i += TC_THREADS) idt[i] = -1;
     if (n <= 0) continue;                                                   // block-uniform
     const float* ft = det_feats + (long long)t * max_num * C;
     const float* bt = det + (long long)t * max_num * 5;
@@ -179,9 +179,9 @@ __global__ __launch_bounds__(TR_THREADS) void track_clip_kernel(const float* __r
     const int cnt = s_cnt;
     if (is_first[t] != 0 || cnt == 0) {                                     // the frame's detections ARE the memory
       const int m = min(n, cap);
-      for (int j = tid; j < m * C; j += TR_THREADS) mem_feats[j] = ft[j];
-      for (int j = tid; j < m * 5; j += TR_THREADS) mem_boxes[j] = bt[j];
-      for (int j = tid; j < m; j += TR_THREADS) {
+      for (int j = tid; j < m * C; j += TC_THREADS) mem_feats[j] = ft[j];
+      for (int j = tid; j < m * 5; j += TC_THREADS) mem_boxes[j] = bt[j];
+      for (int j = tid; j < m; j += TC_THREADS) {
         mem_labels[j] = lt[j];
         idt[j] = j;
       }
@@ -190,10 +190,63 @@ __global__ __launch_bounds__(TR_THREADS) void track_clip_kernel(const float* __r
       __syncthreads();
       continue;
     }
-    for (int i = 0; i < n; ++i)
-      comp_row(ft + (long long)i * C, mem_feats, bt + i * 5, lt[i], mem_boxes, mem_labels, cnt, C, c0, c1, c2,
-               comp_ws + (long long)i * (cap + 1), s_f, s_red, s_idx, &s_mid[i], &s_msc[i]);
-    for (int o = tid; o < cnt; o += TR_THREADS) {
+    // ---- comprehensive scores: one wave per detection.  comp[i][0..cnt]: log_softmax([0, f_i . g_o]) + c0 log(score_i)
+    // + c1 IoU(+1) + c2 [label equal], dummy column 0 with IoU 0 and label term c2 (compute_comp_scores, :544-562)
+    for (int i = wave; i < n; i += TC_THREADS / 64) {
+      float f[TC_MAXCJ];
+#pragma unroll
+      for (int j = 0; j < TC_MAXCJ; ++j) f[j] = j < cj ? ft[(long long)i * C + lane + 64 * j] : 0.f;
+      float* row = s_rows + (long long)wave * (cap + 1);           // LDS: in order inside a wave, no cache in between
+      if (lane == 0) row[0] = 0.f;
+      for (int o = 0; o < cnt; ++o) {
+        const float* g = mem_feats + (long long)o * C + lane;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < TC_MAXCJ; ++j)
+          if (j < cj) acc = fmaf(f[j], g[64 * j], acc);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (lane == 0) row[o + 1] = acc;
+      }
+      __builtin_amdgcn_wave_barrier();                                    // row[] written by lane 0, read by all lanes
+      float mx = -INFINITY;
+      for (int o = lane; o <= cnt; o += 64) mx = fmaxf(mx, row[o]);
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+      float se = 0.f;
+      for (int o = lane; o <= cnt; o += 64) se += expf(row[o] - mx);
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) se += __shfl_xor(se, d, 64);
+      const float lse = mx + logf(se);
+      const float* db = bt + i * 5;
+      const float ls = c0 * logf(db[4]);
+      const int64_t lab = lt[i];
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int o = lane; o <= cnt; o += 64) {
+        float v = row[o] - lse + ls;
+        if (o == 0) v += c2;
+        else v += c1 * iou_plus1_f(db, mem_boxes + (long long)(o - 1) * 5) + (mem_labels[o - 1] == lab ? c2 : 0.f);
+        if (v > best) {                                                     // ascending o per lane: first maximum wins
+          best = v;
+          bi = o;
+        }
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        const float ob = __shfl_xor(best, d, 64);
+        const int oi = __shfl_xor(bi, d, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+          best = ob;
+          bi = oi;
+        }
+      }
+      if (lane == 0) {
+        s_mid[i] = bi;
+        s_msc[i] = best;
+      }
+    }
+    for (int o = tid; o < cnt; o += TC_THREADS) {
       s_best[o] = -100.f;
       s_win[o] = -1;
     }
@@ -218,21 +271,22 @@ __global__ __launch_bounds__(TR_THREADS) void track_clip_kernel(const float* __r
       s_nnew = nnew;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += TR_THREADS) idt[i] = s_id[i];
-    // memory update: slot o takes its last winner; new objects are appended in detection order
-    for (int o = 0; o < cnt; ++o) {
+    for (int i = tid; i < n; i += TC_THREADS) idt[i] = s_id[i];
+    // memory update: slot o takes its last winner (wave per slot); new objects are appended in detection order
+    for (int o = wave; o < cnt; o += TC_THREADS / 64) {
       const int w = s_win[o];
-      if (w < 0) continue;                                                  // block-uniform (LDS value)
-      for (int c = tid; c < C; c += TR_THREADS) mem_feats[(long long)o * C + c] = ft[(long long)w * C + c];
-      if (tid < 5) mem_boxes[o * 5 + tid] = bt[w * 5 + tid];
+      if (w < 0) continue;                                                  // wave-uniform (LDS value)
+      for (int c = lane; c < C; c += 64) mem_feats[(long long)o * C + c] = ft[(long long)w * C + c];
+      if (lane < 5) mem_boxes[o * 5 + lane] = bt[w * 5 + lane];
     }
     const int nnew = s_nnew;
-    for (int k = 0; k < nnew; ++k) {
+    for (int k = wave; k < nnew; k += TC_THREADS / 64) {
       const int w = s_new[k], o = cnt + k;
-      for (int c = tid; c < C; c += TR_THREADS) mem_feats[(long long)o * C + c] = ft[(long long)w * C + c];
-      if (tid < 5) mem_boxes[o * 5 + tid] = bt[w * 5 + tid];
-      if (tid == 0) mem_labels[o] = lt[w];
+      for (int c = lane; c < C; c += 64) mem_feats[(long long)o * C + c] = ft[(long long)w * C + c];
+      if (lane < 5) mem_boxes[o * 5 + lane] = bt[w * 5 + lane];
+      if (lane == 0) mem_labels[o] = lt[w];
     }
+    __threadfence_block();
     __syncthreads();
     if (tid == 0) s_cnt = cnt + nnew;
     __syncthreads();
@@ -273,13 +327,20 @@ extern "C" int sm_track_clip(const float* det_feats, const float* det, const int
                              float coeff_iou, float coeff_label, float* mem_feats, float* mem_boxes, int64_t* mem_labels,
                              int32_t* mem_count, int capacity, float* comp_ws, int32_t* ids, sm_stream_t stream) {
   if (!det_feats || !det || !det_labels || !ndet || !is_first || !mem_feats || !mem_boxes || !mem_labels || !mem_count ||
-      !comp_ws || !ids)
+      !ids)
     return SM_ERR_BAD_ARG;
-  if (nframes < 1 || max_num < 1 || max_num > TC_MAXDET || channels < 1 || channels > 8192 || capacity < max_num ||
-      capacity > 4096)
+  if (nframes < 1 || max_num < 1 || max_num > TC_MAXDET || channels < 64 || channels % 64 != 0 || channels > 64 * TC_MAXCJ ||
+      capacity < max_num || capacity > 4096)
     return SM_ERR_BAD_SHAPE;
-  const size_t lds = (size_t)(channels + 2 * capacity) * sizeof(float);
-  hipLaunchKernelGGL(track_clip_kernel, dim3(1), dim3(TR_THREADS), lds, sm_hip_stream(stream), det_feats, det, det_labels,
+  const size_t lds = (size_t)(2 * capacity + (TC_THREADS / 64) * (capacity + 1)) * sizeof(float);
+  if (lds > 150 * 1024) return SM_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)track_clip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+      return SM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(track_clip_kernel, dim3(1), dim3(TC_THREADS), lds, sm_hip_stream(stream), det_feats, det, det_labels,
                      ndet, is_first, nframes, max_num, channels, coeff_score, coeff_iou, coeff_label, mem_feats, mem_boxes,
                      mem_labels, mem_count, capacity, comp_ws, ids);
   SM_LAUNCH_CHECK();

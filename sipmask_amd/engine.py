@@ -102,7 +102,7 @@ class _Conv:
             assert in_cstride == cin, "x3 convs read the [hi | lo | hi] split tensor (3 * cin channels)"
             self.x3_scale = getattr(self, "_x3_scale", None) or H.x3_weight_scale([w])
             self.w, co_pad = H.prep_conv_weight_x3(w.to(dev), self.x3_scale)
-            flags |= _lib.SM_CONV_F16 | SM_CONV_OUT_F32
+            flags |= _lib.SM_CONV_F16 | (0 if flags & _lib.SM_CONV_OUT_X3 else SM_CONV_OUT_F32)
             acc_scale = 1.0 / self.x3_scale
         else:
             self.w, co_pad = H.prep_conv_weight(w.to(dev), cin)
@@ -683,19 +683,18 @@ class SipMaskEngine:
         # mask basis branch (sipmask_head.py:275-285) on lane 2: f32 [l0 | up2(l1) | up4(l2)] -> split -> 1x1 -> split -> 3x3
         (h0, w0) = sizes[0]
         n0 = B * h0 * w0
-        self.cat = torch.empty(n0, 768, dtype=f32, device=dev)
+        # [l0 | up2(l1) | up4(l2)] written straight as the split operand of sip_mask_lat0 (768 channels -> 3 x 768 halves),
+        # and that 1x1 conv writes ITS output as the split operand of sip_mask_lat (SM_CONV_OUT_X3): no f32 round trips
+        cat_x3 = torch.empty(n0, 3 * 768, dtype=F16, device=dev)
         for l in range(3):
             fh, fw = sizes[l]
             src = self.reg_feat[row0[l]:row0[l] + B * fh * fw]
-            self._add("up:cat%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear(
-                s, self.cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, True)), 2)
-        cat_x3 = torch.empty(n0, 3 * 768, dtype=F16, device=dev)
-        self._add("split:cat", lambda: H.split3_f16(self.cat, cat_x3, 768), 2)
-        self.lat0 = torch.empty(n0, 512, dtype=f32, device=dev)
-        self._add_conv(_Conv(self, "head.sip_mask_lat0", sd[h + "sip_mask_lat0.weight"], sd[h + "sip_mask_lat0.bias"],
-                             B, [(h0, w0)], [0], cat_x3, 3 * 768, 1, 0, self.lat0, [0], 512, flags=SM_CONV_RELU, mode="x3"), 2)
+            self._add("up:cat%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear_x3(
+                s, cat_x3, B, fh, fw, 256, 2 ** l, 768, 256 * l)), 2)
         lat0_x3 = torch.empty(n0, 3 * 512, dtype=F16, device=dev)
-        self._add("split:lat0", lambda: H.split3_f16(self.lat0, lat0_x3, 512), 2)
+        self._add_conv(_Conv(self, "head.sip_mask_lat0", sd[h + "sip_mask_lat0.weight"], sd[h + "sip_mask_lat0.bias"],
+                             B, [(h0, w0)], [0], cat_x3, 3 * 768, 1, 0, lat0_x3, [0], 3 * 512,
+                             flags=SM_CONV_RELU | _lib.SM_CONV_OUT_X3, mode="x3"), 2)
         self.basis_lo = torch.empty(n0, 32, dtype=f32, device=dev)
         self._add_conv(_Conv(self, "head.sip_mask_lat", sd[h + "sip_mask_lat.weight"], sd[h + "sip_mask_lat.bias"], B,
                              [(h0, w0)], [0], lat0_x3, 3 * 512, 1, 1, self.basis_lo, [0], 32, flags=SM_CONV_RELU, mode="x3"), 2)

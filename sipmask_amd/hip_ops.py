@@ -105,6 +105,16 @@ def split3_f16(x, y, channels=None, ctot=None, coff=0):
     return y
 
 
+def upsample_bilinear_x3(x, y, batch, h, w, c, factor, ctot, coff):
+    """bilinear x factor of f32 rows -> the [hi | lo | hi] slice (coff) of a binary16 [rows, 3*ctot] tensor"""
+    _lib.require_cuda(x, y)
+    if x.dtype != torch.float32 or y.dtype != F16 or y.shape[1] != 3 * ctot:
+        raise ValueError("upsample_bilinear_x3: f32 rows in, binary16 [rows, 3*ctot] out")
+    _lib.check(_lib.load().sm_upsample_bilinear_x3(_lib.ptr(x), _lib.ptr(y), batch, h, w, c, factor, x.stride(0), ctot, coff,
+                                                   _lib.stream_ptr()), "sm_upsample_bilinear_x3")
+    return y
+
+
 def _lv_geometry(lv):
     nlev = len(lv)
     return nlev, (C.c_int32 * nlev)(*[h * w for h, w in lv.sizes]), (C.c_int64 * nlev)(*lv.row0)

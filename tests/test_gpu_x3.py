@@ -148,6 +148,57 @@ def test_x3_small_cout_and_1x1_convs():
         H.conv2d(d, x3, wq, None, None, y)
 
 
+def test_fused_split_producers():
+    """the two producers that write a split operand directly: sm_upsample_bilinear_x3 (the mask branch's [l0 | up2(l1) |
+    up4(l2)] concatenation) and the SM_CONV_OUT_X3 epilogue (sip_mask_lat0 -> sip_mask_lat without an f32 round trip);
+    both must equal "f32 result, then sm_split3_f16" bit for bit"""
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(13)
+    B, C = 2, 256
+    sizes = [(24, 40), (12, 20), (6, 10)]
+    lv = H.Levels(B, sizes)
+    xs = [torch.randn(B, C, h, w, generator=g) for h, w in sizes]
+    rows = _rows(xs).to(dev)
+    n0 = B * 24 * 40
+    cat3 = torch.zeros(n0, 3 * 768, dtype=torch.float16, device=dev)
+    cat32 = torch.zeros(n0, 768, dtype=torch.float32, device=dev)
+    for l, (h, w) in enumerate(sizes):
+        src = rows[lv.row0[l]:lv.row0[l] + B * h * w]
+        H.upsample_bilinear_x3(src, cat3, B, h, w, C, 2 ** l, 768, 256 * l)
+        H.upsample_bilinear(src, cat32, B, h, w, C, 2 ** l, C, 768, 256 * l, True)
+    ref3 = torch.empty_like(cat3)
+    H.split3_f16(cat32, ref3, 768)
+    torch.cuda.synchronize()
+    assert torch.equal(cat3, ref3)
+    up = torch.cat([xs[0]] + [F.interpolate(xs[l], scale_factor=2 ** l, mode="bilinear", align_corners=False) for l in (1, 2)], 1)
+    rec = (cat3[:, :768].float() + cat3[:, 768:1536].float()).view(B, 24, 40, 768).permute(0, 3, 1, 2).cpu()
+    torch.testing.assert_close(rec, up, rtol=1e-5, atol=1e-5)
+    # 1x1 conv 768 -> 512 + bias + ReLU with the split output
+    wt = torch.randn(512, 768, 1, 1, generator=g) * 0.05
+    bias = torch.randn(512, generator=g)
+    scale = H.x3_weight_scale([wt])
+    wq, co_pad = H.prep_conv_weight_x3(wt.to(dev), scale)
+    one = [(24, 40)]
+    l1 = H.Levels(B, one)
+    base = _lib.SM_CONV_F16 | _lib.SM_CONV_RELU
+    d32 = H.make_conv_desc(B, one, one, l1.row0, l1.row0, 3 * 768, 512, co_pad, 1, 1, 0, 3 * 768, 512,
+                           flags=base | _lib.SM_CONV_OUT_F32, acc_scale=1.0 / scale)
+    d3 = H.make_conv_desc(B, one, one, l1.row0, l1.row0, 3 * 768, 512, co_pad, 1, 1, 0, 3 * 768, 3 * 512,
+                          flags=base | _lib.SM_CONV_OUT_X3, acc_scale=1.0 / scale)
+    y32 = torch.zeros(n0, 512, dtype=torch.float32, device=dev)
+    y3 = torch.zeros(n0, 3 * 512, dtype=torch.float16, device=dev)
+    H.conv2d(d32, cat3, wq, bias.to(dev), None, y32)
+    H.conv2d(d3, cat3, wq, bias.to(dev), None, y3)
+    r3 = torch.empty_like(y3)
+    H.split3_f16(y32, r3, 512)
+    torch.cuda.synchronize()
+    assert torch.equal(y3, r3)
+    ref = F.relu(F.conv2d(up.double(), wt.double(), bias.double()))
+    got = y32.view(B, 24, 40, 512).permute(0, 3, 1, 2).cpu().double()
+    assert float((got - ref).abs().max()) / float(ref.abs().max()) < 4e-6
+
+
 def test_groupnorm_apply_x3_and_f32_statistics():
     """sm_gn_stats_f32_fix + sm_groupnorm_apply_x3 == F.group_norm + ReLU of the f32 rows (1e-5), written as f32 rows
     (in place) and as the next layer's split operand; the statistics are bit-reproducible"""
