@@ -337,7 +337,9 @@ def run_inference(args, rank, world, dev):
     # HBM traffic of the dominant kernel: PMC passes cannot run inside this process; the number comes from the
     # committed rocprofv3 summary of the same kernel/shape (profiles/), per launch
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_tower_conv.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_tower_conv.json")
+    if not os.path.exists(pmc_file):
+        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_tower_conv.json")
     pmc = json.load(open(pmc_file)) if os.path.exists(pmc_file) else None
     if pmc and pmc.get("plan_batch") == eng.batch and pmc.get("launch") == towers[0].name and not f32:
         traffic = round(pmc["hbm_bytes_per_launch"] / 1e6, 1)

@@ -47,11 +47,10 @@ int main(int argc, char** argv) {
     hipMemcpy(h, clk, 32, hipMemcpyDeviceToHost);
     // one wave issues iters * nacc MFMAs; the SIMD it sits on also serves (waves * bpc / 4 - 1) other waves of this launch
     const double mhz0 = 100.0 * (double)h[0] / (double)h[1], mhz1 = 100.0 * (double)h[2] / (double)h[3];
-    const double cyc_per_mfma = (double)h[0] / ((double)iters * nacc * waves * bpc / 4.0);
     printf("waves/block %d blocks/CU %d iters %d %s operands: %.3f ms  %.0f TFLOP/s  (%.2f ns per MFMA per SIMD); shader clock "
-           "%.0f MHz (block 0) / %.0f MHz (last block), %.1f shader cycles per MFMA per SIMD -> %.0f TFLOP/s at that clock x 256 CUs x "
-           "4 SIMDs if every MFMA took 32 cycles\n", waves, bpc, iters, zero ? "zero" : "non-zero", ms, flop / ms / 1e9,
-           ms * 1e6 / per_simd, mhz0, mhz1, cyc_per_mfma, 2.0 * 32 * 32 * 16 / 32.0 * mhz0 * 1e6 * 256 * 4 / 1e12);
+           "%.0f MHz (block 0) / %.0f MHz (last block); one MFMA per 32 cycles per SIMD at that clock = %.0f TFLOP/s\n", waves,
+           bpc, iters, zero ? "zero" : "non-zero", ms, flop / ms / 1e9, ms * 1e6 / per_simd, mhz0, mhz1,
+           2.0 * 32 * 32 * 16 / 32.0 * mhz0 * 1e6 * 256 * 4 / 1e12);
   }
   return 0;
 }
