@@ -30,9 +30,9 @@ _PATCH_CONV = __import__("os").environ.get("SIPMASK_PATCH_CONV", "1") != "0"   #
 # learned offsets stay within ~3 pixels and falls behind it when most waves sample farther out (random offsets of sigma 4:
 # 0.35 vs 0.26 ms at B=4, profiles/r02_deform_conv_microbench.txt); SIPMASK_DEFORM_GATHER=1 keeps a model with such
 # offsets on the gather loader
-# ... so the plan MEASURES it: SIPMASK_DEFORM_GATHER = "auto" (default) times both kernels once, on the offsets of the first
-# eager run of the plan (the checkpoint's own offsets on a real input), and keeps the gather loader only where it is
-# more than 10 % faster; "0" / "1" pin the window kernel / the gather loader.
+# ... so the plan LOOKS: SIPMASK_DEFORM_GATHER = "auto" (default) inspects the offsets of the first eager run of the plan
+# (the checkpoint's own offsets on a real input) and keeps the gather loader where more than 20 % of the offset components
+# reach beyond the window radius (SipMaskEngine._tune_deform); "0" / "1" pin the window kernel / the gather loader.
 _DEFORM_MODE = __import__("os").environ.get("SIPMASK_DEFORM_GATHER", "auto")
 _DEFORM_FLAGS = _lib.SM_CONV_DBG_DEFORM_GATHER if _DEFORM_MODE == "1" else 0
 _PATCH_MIN_WORK = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_WORK", "100"))   # 256x256 tile equivalents
@@ -1036,13 +1036,18 @@ class SipMaskEngine:
         return self
 
     def _tune_deform(self):
-        """One-off choice of FeatureAlign's kernel on THIS plan's offsets (just produced by the first eager run): the
-        LDS-window kernel serves offsets within ~3 pixels from LDS and sends a wave whose samples reach further through a
-        slower global gather, the gather loader costs the same everywhere (profiles/r02_deform_conv_microbench.txt:
-        0.107 vs 0.18 ms with small offsets, 0.353 vs 0.258 ms with ~N(0, 4 px) offsets at B=4).  Both produce the same
-        result up to accumulation order; the choice is made once per plan, so a plan stays bit-reproducible."""
+        """One-off choice of FeatureAlign's kernel from THIS plan's offsets (just produced by the first eager run): the
+        LDS-window kernel serves samples within 3 pixels of their tap from LDS and sends a wave with a farther sample
+        through a slower global gather; the gather loader costs the same everywhere.  The rule is a function of the DATA --
+        the share of offset components beyond the window radius -- not of a timing, so that two plans fed the same input
+        choose the same kernel (a timing-based pick differed between otherwise identical plans at small shapes, which
+        breaks plan-to-plan bit equality: the two kernels agree only up to accumulation order).  Calibration
+        (profiles/r02_deform_conv_microbench.txt, B=2 / B=4 head): offsets ~N(0, 2 px) = 13 % beyond 3 px: window 0.132 /
+        0.254 ms vs gather 0.18 / 0.257; ~N(0, 4 px) = 45 %: 0.182 / 0.353 vs 0.18 / 0.258 -> gather above 20 %.
+        Both kernels are also timed once on these offsets; the times are reported (bench.py: config.deform_kernel), not used."""
         self._deform_tune = False
         c = self._fa_conv
+        far = float((self.offsets.abs() > 3.0).float().mean())          # one device->host read, at the first run only
         base = c.desc.flags & ~_lib.SM_CONV_DBG_DEFORM_GATHER
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t = {}
@@ -1055,10 +1060,11 @@ class SipMaskEngine:
             e1.record()
             torch.cuda.synchronize()
             t[name] = e0.elapsed_time(e1) / 3
-        pick = "gather" if t["gather"] < 0.9 * t["window"] else "window"
+        pick = "gather" if far > 0.20 else "window"
         c.desc.flags = base | (_lib.SM_CONV_DBG_DEFORM_GATHER if pick == "gather" else 0)
         c()                                                   # leave the buffers as the chosen kernel writes them
-        self.deform_choice = dict(kernel=pick, window_ms=round(t["window"], 4), gather_ms=round(t["gather"], 4))
+        self.deform_choice = dict(kernel=pick, offsets_beyond_3px=round(far, 4), window_ms=round(t["window"], 4),
+                                  gather_ms=round(t["gather"], 4))
 
     # -------------------------------------------------------------------------------- execution
     def run(self, img):
