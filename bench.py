@@ -33,6 +33,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICRO
 MFMA_F32_PEAK_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (= the f32 vector rate), same guide
 IMG_H, IMG_W = 800, 1344           # 800x1333 padded to a multiple of 32 (cfg Pad size_divisor=32)
 VIS_H, VIS_W, VIS_T = 384, 640, 8  # 640x360 frames padded to 32 (V/ config size_divisor=32), frames per clip
+VIS_CLIPS = 4                        # clips per GPU per step of --config vis (pipelined: SipMaskVIS.clip_test_many)
 STUB = os.environ.get("SIPMASK_BENCH_STUB", "0") == "1"   # CPU test hook: gloo + a sleeping step, no GPU work
 
 
@@ -534,9 +535,10 @@ def run_vis(args, rank, world, dev):
     from sipmask_amd.synthetic import build_synthetic_vis_detector, calibrate_cls_bias
     det = build_synthetic_vis_detector(seed=0)
     shape = (VIS_H - 24, VIS_W, 3)                  # 360x640 frames padded to 384x640
-    # every step: `world` clips in flight (one per GPU); a clip's frames run as ONE batch through the plan
-    # (SipMaskVIS.clip_test), its identity matching in frame order afterwards
-    clips_per_step = world
+    # every step: VIS_CLIPS clips per GPU (videos shard over the GPUs); a clip's frames run as ONE batch through the plan, its
+    # identity matching in frame order behind it; the clips of a step are pipelined (SipMaskVIS.clip_test_many: clip i+1 is
+    # enqueued before the results of clip i are fetched)
+    clips_per_step = world * VIS_CLIPS
     NSETS = 2                                        # two sets of clips resident on the device, alternated step by step
     g = torch.Generator().manual_seed(4321)
     clips = [torch.randn(VIS_T, 3, VIS_H, VIS_W, generator=g) for _ in range(clips_per_step * NSETS)]
@@ -555,8 +557,8 @@ def run_vis(args, rank, world, dev):
         counts.clear()
         k = nstep[0] % NSETS
         nstep[0] += 1
-        for vi in mine:                              # whole videos, in order; tracker reset by is_first of frame 0
-            res = det.clip_test(clips_dev[(k, vi)], metas, encode=False, graph=use_graph)
+        # whole videos, in order; tracker reset by is_first of frame 0
+        for res in det.clip_test_many([clips_dev[(k, vi)] for vi in mine], [metas] * len(mine), encode=False, graph=use_graph):
             counts.append(sum(len(b) for b, _ in res))
 
     for _ in range(args.warmup):
@@ -565,7 +567,7 @@ def run_vis(args, rank, world, dev):
     frames = clips_per_step * VIS_T * args.steps
     plan = det.prepare(VIS_T, (VIS_H, VIS_W), shape, 1.0, False, lanes=2)
     flops = plan.total_conv_flops() / VIS_T
-    ms_frame = elapsed / (VIS_T * args.steps) * 1e3
+    ms_frame = elapsed / (VIS_CLIPS * VIS_T * args.steps) * 1e3
     # ---- dominant kernel, timed live with HIP events (eager launches of ONE 4-frame chain of the plan): the grouped
     # tower launch (cls + reg 3x3 256 -> 256 of one depth over the 5 levels of 4 frames)
     eng = plan.engines[0]
@@ -594,12 +596,13 @@ def run_vis(args, rank, world, dev):
         "dtype": "bf16",
         "data": "synthetic (randn frames, %d clip sets resident on the device alternated step by step; reference-init random "
                 "weights + calibration overrides)" % NSETS,
-        "config": {"workload": "SipMask-VIS R50, clips of %d frames 3x%dx%d (640x360 padded), 1 clip per GPU per step; the "
+        "config": {"workload": "SipMask-VIS R50, clips of %d frames 3x%dx%d (640x360 padded), %d clips per GPU per step; the "
                                "frames of a clip run as one batch (two 4-frame launch chains), identity matching in frame "
-                               "order on the host (tracker state)" % (VIS_T, VIS_H, VIS_W),
+                               "order by one kernel per clip (device tracker state); the clips of a step are pipelined (clip "
+                               "i+1 is enqueued before the results of clip i are fetched)" % (VIS_T, VIS_H, VIS_W, VIS_CLIPS),
                    "global_batch": clips_per_step, "parallelism": "dp%d (sharded by video, no collective)" % world,
                    "launch": ("hipGraph replay of the whole clip" if use_graph else "eager") +
-                             " + one device->host sync per clip (detection counts for the host-side matching)",
+                             " + one host wait per clip (ids, boxes, labels and counts land in pinned buffers)",
                    "tracked_objects_last_step_this_rank": list(counts)},
         "roofline": {"bound": "mfma", "achieved": round(tower_tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(tower_tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,

@@ -247,6 +247,34 @@ def fast_nms(boxes, scores, cofs, iou_threshold=0.5, top_k=200, score_thr=0.1, m
 # ----------------------------------------------------------------------------
 
 
+def _pair2(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def deform_conv_grouped(x, offset, weight, stride=1, padding=1, dilation=1, groups=1, deformable_groups=1):
+    """The op with conv groups (deform_conv_cuda.cpp:176-236): the columns are sampled for ALL channels with the
+    deformable-group offsets (channel c -> deformable group c // (C / deformable_groups), kernel.cu:206), then conv
+    group g contracts its C/groups channels with its Co/groups filters.  Restated as: full-channel columns via the
+    groups=1 path with an identity-like trick is wasteful, so sample per conv group with per-channel offsets instead."""
+    B, C, H, W = x.shape
+    Co, Ci, kh, kw = weight.shape
+    assert Ci * groups == C and Co % groups == 0
+    cg, cog, cpd = C // groups, Co // groups, C // deformable_groups
+    kk2 = 2 * kh * kw
+    outs = []
+    for g in range(groups):
+        # per-channel deformable group of the slice -> run the groups=1 restatement once per distinct deformable group
+        # present in the slice and with only that group's channels, then add (the contraction is linear in the channels)
+        acc = None
+        for d in sorted(set(c // cpd for c in range(g * cg, (g + 1) * cg))):
+            ch = [c for c in range(g * cg, (g + 1) * cg) if c // cpd == d]
+            part = deform_conv(x[:, ch], offset[:, d * kk2:(d + 1) * kk2], weight[g * cog:(g + 1) * cog][:, [c - g * cg for c in ch]],
+                               stride, padding, dilation, 1)
+            acc = part if acc is None else acc + part
+        outs.append(acc)
+    return torch.cat(outs, 1)
+
+
 def deform_conv(x, offset, weight, stride=1, padding=1, dilation=1, deformable_groups=1, col_round=None):
     """Deformable conv v1 forward, groups=1.
 
@@ -267,12 +295,13 @@ def deform_conv(x, offset, weight, stride=1, padding=1, dilation=1, deformable_g
     assert Ci == C
     G = deformable_groups
     cpg = C // G
-    Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
-    Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+    (sh, sw), (ph, pw), (dh_, dw_) = _pair2(stride), _pair2(padding), _pair2(dilation)   # deform_conv.py:32-34 (_pair)
+    Ho = (H + 2 * ph - (dh_ * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw_ * (kw - 1) + 1)) // sw + 1
     assert offset.shape == (B, G * 2 * kh * kw, Ho, Wo), (offset.shape, (B, G * 2 * kh * kw, Ho, Wo))
     dt = x.dtype
-    ho = torch.arange(Ho, dtype=dt).view(1, Ho, 1) * stride - padding
-    wo = torch.arange(Wo, dtype=dt).view(1, 1, Wo) * stride - padding
+    ho = torch.arange(Ho, dtype=dt).view(1, Ho, 1) * sh - ph
+    wo = torch.arange(Wo, dtype=dt).view(1, 1, Wo) * sw - pw
     xf = x.reshape(B, G, cpg, H * W)
     cols = x.new_zeros(B, G, cpg, kh * kw, Ho, Wo)
     off = offset.view(B, G, kh * kw, 2, Ho, Wo)
@@ -280,8 +309,8 @@ def deform_conv(x, offset, weight, stride=1, padding=1, dilation=1, deformable_g
         for i in range(kh):
             for j in range(kw):
                 t = i * kw + j
-                h_im = ho + i * dilation + off[:, g, t, 0]      # [B,Ho,Wo]
-                w_im = wo + j * dilation + off[:, g, t, 1]
+                h_im = ho + i * dh_ + off[:, g, t, 0]      # [B,Ho,Wo]
+                w_im = wo + j * dw_ + off[:, g, t, 1]
                 valid = (h_im > -1) & (w_im > -1) & (h_im < H) & (w_im < W)
                 h_low = torch.floor(h_im)
                 w_low = torch.floor(w_im)
@@ -329,12 +358,13 @@ def deform_conv_backward(x, offset, weight, grad_out, stride=1, padding=1, dilat
     Co, Ci, kh, kw = weight.shape
     G = deformable_groups
     cpg = C // G
-    Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
-    Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+    (sh, sw), (ph, pw), (dh_, dw_) = _pair2(stride), _pair2(padding), _pair2(dilation)
+    Ho = (H + 2 * ph - (dh_ * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw_ * (kw - 1) + 1)) // sw + 1
     dt = x.dtype
     gcol = torch.einsum("ocij,bohw->bcijhw", weight, grad_out).reshape(B, G, cpg, kh * kw, Ho, Wo)
-    ho = torch.arange(Ho, dtype=dt).view(1, Ho, 1) * stride - padding
-    wo = torch.arange(Wo, dtype=dt).view(1, 1, Wo) * stride - padding
+    ho = torch.arange(Ho, dtype=dt).view(1, Ho, 1) * sh - ph
+    wo = torch.arange(Wo, dtype=dt).view(1, 1, Wo) * sw - pw
     xf = x.reshape(B, G, cpg, H * W)
     off = offset.view(B, G, kh * kw, 2, Ho, Wo)
     gx = x.new_zeros(B, G, cpg, H * W)
@@ -343,8 +373,8 @@ def deform_conv_backward(x, offset, weight, grad_out, stride=1, padding=1, dilat
     for g in range(G):
         for t in range(kh * kw):
             i, j = t // kw, t % kw
-            h_im = ho + i * dilation + off[:, g, t, 0]
-            w_im = wo + j * dilation + off[:, g, t, 1]
+            h_im = ho + i * dh_ + off[:, g, t, 0]
+            w_im = wo + j * dw_ + off[:, g, t, 1]
             valid = (h_im > -1) & (w_im > -1) & (h_im < H) & (w_im < W)
             hl, wl = torch.floor(h_im), torch.floor(w_im)
             lh, lw = h_im - hl, w_im - wl

@@ -103,6 +103,29 @@ __device__ __forceinline__ unsigned long long gn_fix(float v) {
   const float s = fminf(fmaxf(v * 16777216.f, -4.0e18f), 4.0e18f);
   return (unsigned long long)(long long)rintf(s == s ? s : 0.f);
 }
+// Sum NV per-lane floats over the 32 lanes of a half-wave and leave total k on the lanes with (lane & 31) >> (5 - log2 NV)
+// == k ("transposing" butterfly: at each of the first log2 NV levels a lane keeps one half of its values and hands the
+// other half to its partner, so NV values cost NV - 1 + (5 - log2 NV) shuffles instead of 5 NV).  Every total is formed by
+// the SAME tree as the plain xor butterfly (pairs at distance 16, then 8, 4, 2, 1; a + b == b + a bitwise), so the bits
+// do not depend on NV or on which lane ends up holding the value.
+template <int NV>
+__device__ __forceinline__ float gn_half_wave_totals(float (&v)[NV], int l31) {
+  static_assert(NV == 2 || NV == 4 || NV == 8 || NV == 16 || NV == 32, "NV");
+  int d = 16;
+#pragma unroll
+  for (int n = NV; n > 1; n >>= 1, d >>= 1) {
+    const bool up = (l31 & d) != 0;
+#pragma unroll
+    for (int j = 0; j < n / 2; ++j) {
+      float lo = v[j], hi = v[j + n / 2];
+      asm("" : "+v"(lo), "+v"(hi));                 // keep the two values in registers: a select of ADDRESSES would put v[] in scratch
+      v[j] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, d, 64);
+    }
+  }
+#pragma unroll
+  for (; d > 0; d >>= 1) v[0] += __shfl_xor(v[0], d, 64);
+  return v[0];
+}
 __device__ __forceinline__ double gn_unfix(unsigned long long q) { return (double)(long long)q * (1.0 / 16777216.0); }
 // mean / reciprocal standard deviation of one group from its fixed-point (sum, sum of squares); double arithmetic (a
 // handful of operations per thread) so that E[x^2] - E[x]^2 does not cancel in f32

@@ -407,6 +407,9 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
         if constexpr (!NO_MFMA) tap(Wst, hh * 64, Pb0 + cc * PB, kh * Wp + kw);
       });
       }
+      // (A/B round 3: a 3-stage weight ring -- stage st+2 issued at the top of stage st, vmcnt(4) + raw s_barrier at its end,
+      // so a stage of weights has two stage times to land -- is 3-8 % SLOWER where it fits (image width <= 125):
+      // profiles/r03_patch_weight_ring_ab.txt.  The landing latency of the DMA is not what the stage waits for.)
       __syncthreads();                                             // drains the DMA queue (vmcnt(0)) and fences the buffers
     });
   }
@@ -430,6 +433,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
     const int owp = q - oh * Wp;
     const bool pvalid = oh < H && owp >= 1 && owp <= W;
     const long long orow = out_img_row0 + (long long)oh * W + owp - 1;
+    float gpart[TCO * 4];                           // (sum, sum of squares) of this position's 8 couts, per (tc, qp)
 #pragma unroll
     for (int tc = 0; tc < TCO; ++tc) {
 #pragma unroll
@@ -463,24 +467,17 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
               if (c0 + e < a.scale_nch) v[e] *= lscale;
           }
         }
-        if (gn) {                                   // wave-uniform: the shuffles need every lane
+        if (gn) {
           float gs = 0.f, gss = 0.f;
           if (live) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               gs += v[e];
-              gss += v[e] * v[e];
+              gss = __builtin_fmaf(v[e], v[e], gss);   // explicit: left to -ffp-contract, instantiations differed in the last bit
             }
           }
-#pragma unroll
-          for (int d = 16; d > 0; d >>= 1) {        // within the half-wave (xor < 32 never crosses halves)
-            gs += __shfl_xor(gs, d, 64);
-            gss += __shfl_xor(gss, d, 64);
-          }
-          if (l31 == 0 && c0 < a.cout) {
-            atomicAdd(&gn_bins[(cl >> 3) * 2 + 0], gn_fix(gs));
-            atomicAdd(&gn_bins[(cl >> 3) * 2 + 1], gn_fix(gss));
-          }
+          gpart[(tc * 2 + qp) * 2 + 0] = gs;
+          gpart[(tc * 2 + qp) * 2 + 1] = gss;
         }
         if (!live) continue;
         if (a.flags & SM_CONV_RELU) {
@@ -500,6 +497,16 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
           *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(a.y) + o) = pack_bf16x8_v(v);
         }
       }
+    }
+    if (gn) {                                       // wave-uniform: the shuffles need every lane
+      // 32 positions x 8 couts per total, summed over the half-wave in the fixed butterfly order; lane group k = l31 >> sh
+      // ends up with total k = ((tc * 2 + qp) * 2 + stat) and rounds it ONCE to the fixed-point grid
+      constexpr int sh = TCO == 2 ? 2 : (TCO == 1 ? 3 : (TCO == 4 ? 1 : 0));
+      static_assert((TCO * 4) << sh == 32, "TCO");
+      const float tot = gn_half_wave_totals<TCO * 4>(gpart, l31);
+      const int k = l31 >> sh;
+      const int cl = wco * (TCO * 32) + (k >> 2) * 32 + 8 * (2 * ((k >> 1) & 1) + khalf);
+      if ((l31 & ((1 << sh) - 1)) == 0 && nt * PT_BCO + cl < a.cout) atomicAdd(&gn_bins[(cl >> 3) * 2 + (k & 1)], gn_fix(tot));
     }
   }
   if (gn) {                                          // the whole tile lies in image n of level lev

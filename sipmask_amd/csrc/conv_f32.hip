@@ -400,7 +400,6 @@ int launch_conv_f32(const sm_conv_desc* d, const float* x, const float* offset, 
   if ((d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)) && !residual) return SM_ERR_BAD_ARG;
   if (DEFORM) {
     if (d->deform_groups < 1 || d->cin % (4 * d->deform_groups) != 0) return SM_ERR_BAD_ARG;
-    if (d->stride != 1) return SM_ERR_UNSUPPORTED;
   }
   for (int l = 0; l < d->nlev; ++l) {
     if (d->out_h[l] < 1 || d->out_w[l] < 1 || d->in_h[l] < 1 || d->in_w[l] < 1) return SM_ERR_BAD_SHAPE;

@@ -894,7 +894,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 gs += v[e];
-                gss += v[e] * v[e];
+                gss = __builtin_fmaf(v[e], v[e], gss);
               }
             }
             if (uniform_img) {
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           ps += v[e];
-          pss += v[e] * v[e];
+          pss = __builtin_fmaf(v[e], v[e], pss);
         }
         gn_s += gn_fix(ps);
         gn_ss += gn_fix(pss);
@@ -1677,7 +1677,8 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p,
   if (d->cout_pad % tile != 0 || d->cout_pad < d->cout) return SM_ERR_BAD_SHAPE;
   if (deform) {
     if (d->deform_groups < 1 || d->cin % (8 * d->deform_groups) != 0) return SM_ERR_BAD_ARG;
-    if (d->stride != 1) return SM_ERR_UNSUPPORTED;
+    // any stride: the offset rows are OUTPUT rows (deform_conv_cuda_kernel.cu:216-223), the sampling centre is
+    // ho * stride - pad + kh * dil in the loaders
   }
   if (with_gn && d->cout % 8 != 0) return SM_ERR_UNSUPPORTED;
   for (int l = 0; l < d->nlev; ++l) {

@@ -379,7 +379,7 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
   if (d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return SM_ERR_BAD_SHAPE;
   const int G = offset ? d->deform_groups : 1;
   if (d->cin % 8 != 0 || d->cout % 8 != 0 || d->out_cstride % 8 != 0 || d->in_cstride % 8 != 0) return SM_ERR_UNSUPPORTED;
-  if (offset && (G < 1 || d->stride != 1)) return SM_ERR_UNSUPPORTED;
+  if (offset && G < 1) return SM_ERR_UNSUPPORTED;
   // fast input gradient of a plain stride-1 conv: one forward implicit GEMM over gout with the flipped,
   // transposed weights (w_dgrad); everything else goes through grad columns + col2im
   const bool fast_dgrad = grad_x && !offset && w_dgrad && d->stride == 1;

@@ -326,6 +326,7 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
     if (tid < 64) gn_bins[tid] = 0ull;
     __syncthreads();
   }
+  float gpart[32];                                  // (sum, sum of squares) of this position's 8 couts, per (tc, qp)
 #pragma unroll
   for (int tc = 0; tc < 8; ++tc) {
 #pragma unroll
@@ -355,24 +356,17 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
             if (c0 + e < a.scale_nch) v[e] *= lscale;
         }
       }
-      if (gn) {                                     // wave-uniform: the shuffles need every lane
+      if (gn) {
         float gs = 0.f, gss = 0.f;
         if (live) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             gs += v[e];
-            gss += v[e] * v[e];
+            gss = __builtin_fmaf(v[e], v[e], gss);
           }
         }
-#pragma unroll
-        for (int d = 16; d > 0; d >>= 1) {          // within the half-wave (xor < 32 never crosses halves)
-          gs += __shfl_xor(gs, d, 64);
-          gss += __shfl_xor(gss, d, 64);
-        }
-        if (l31 == 0 && c0 < a.cout) {
-          atomicAdd(&gn_bins[(cl >> 3) * 2 + 0], gn_fix(gs));
-          atomicAdd(&gn_bins[(cl >> 3) * 2 + 1], gn_fix(gss));
-        }
+        gpart[(tc * 2 + qp) * 2 + 0] = gs;
+        gpart[(tc * 2 + qp) * 2 + 1] = gss;
       }
       if (!live) continue;
       if (a.flags & SM_CONV_RELU) {
@@ -392,6 +386,13 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
         *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(a.y) + o) = pack_bf16x8_v(v);
       }
     }
+  }
+  if (gn) {                                          // wave-uniform: the shuffles need every lane
+    // the 32 totals of the wave's 32 positions (fixed butterfly order, common.h): lane l31 ends up with total
+    // k = l31 = (tc * 2 + qp) * 2 + stat and rounds it ONCE to the fixed-point grid
+    const float tot = gn_half_wave_totals<32>(gpart, l31);
+    const int cl = (l31 >> 2) * 32 + 8 * (2 * ((l31 >> 1) & 1) + khalf);
+    if (nt * DP_BCO + cl < a.cout) atomicAdd(&gn_bins[(cl >> 3) * 2 + (l31 & 1)], gn_fix(tot));
   }
   if (gn) {                                          // the whole tile lies in image n of level lev
     __syncthreads();

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         s += f[e];
-        ss += f[e] * f[e];
+        ss = __builtin_fmaf(f[e], f[e], ss);
       }
     }
   }

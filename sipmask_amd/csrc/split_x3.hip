@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void gnx_stats_kernel(const float* __restrict_
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         ps += v[e];
-        pss += v[e] * v[e];
+        pss = __builtin_fmaf(v[e], v[e], pss);
       }
       s += gn_fix(ps);               // one position's 8 channels per rounding: the conv epilogues' unit (conv_igemm.hip)
       ss += gn_fix(pss);

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from . import modules, sipmask_head  # noqa: F401  (register ResNet / FPN / SipMaskHead)
+from .fp16 import auto_fp16
 from .plan_cache import PlanCache, module_tensors
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
@@ -16,6 +17,7 @@ class SipMask(nn.Module):
 
     def __init__(self, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None):
         super().__init__()
+        self.fp16_enabled = False              # base.py:26; fp16.wrap_fp16_model switches it on
         self.backbone = build_backbone(backbone)
         self.neck = build_neck(neck) if neck is not None else None
         self.bbox_head = build_head(bbox_head)
@@ -201,6 +203,7 @@ class SipMask(nn.Module):
             out.append(lv)
         return list(zip(*out))
 
+    @auto_fp16(apply_to=('img', ))             # M/mmdet/models/detectors/base.py:136
     def forward(self, img, img_meta, return_loss=True, **kwargs):
         if return_loss:
             return self.forward_train(img, img_meta, **kwargs)

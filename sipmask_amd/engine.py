@@ -10,6 +10,7 @@ Layout: activations are NHWC bf16 "pyramid tensors" (all FPN levels of all image
 matrix) so the 5 levels that share tower weights run as ONE implicit-GEMM launch.
 """
 import math
+import os
 
 import torch
 
@@ -18,7 +19,7 @@ from . import hip_ops as H
 from ._lib import SM_CONV_RELU, SM_CONV_OUT_F32, SM_CONV_RES_ADD, SM_CONV_RES_NEAREST, SM_CONV_IN_RELU
 
 ARCH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
-_DEBUG_CONV_FLAGS = int(__import__("os").environ.get("SIPMASK_CONV_DEBUG_FLAGS", "0"), 0)
+_DEBUG_CONV_FLAGS = int(os.environ.get("SIPMASK_CONV_DEBUG_FLAGS", "0"), 0)
 # cls + reg tower convs of one depth as ONE grouped 256x256-tile launch (measured round 2: 0.2225 ms per pair =
 # 950 TFLOP/s vs 2 x 0.1346 ms = 785 TFLOP/s as two launches; profiles/r02_*); SIPMASK_GROUPED_TOWERS=0 = A/B
 _GROUPED_TOWERS = __import__("os").environ.get("SIPMASK_GROUPED_TOWERS", "1") == "1"
@@ -40,7 +41,7 @@ _PATCH_MIN_FILL = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_FILL", "
 # bottleneck fusion in layer1 / layer2: 0 = separate launches, 1 = conv2+conv3, 2 = conv2+conv3+next conv1.  Measured
 # (profiles/r02f_ab_bottleneck_fusion.json, same box): 963 / 998 / 984 img/s -- the chained conv1 needs 72-80 KB of LDS
 # (2 blocks per CU instead of 3-4) and loses under two concurrent sub-plans what it saves per launch
-_FUSE_BOTTLENECK = int(__import__("os").environ.get("SIPMASK_FUSE_BOTTLENECK", "1"))
+_FUSE_BOTTLENECK = int(os.environ.get("SIPMASK_FUSE_BOTTLENECK", "1"))
 _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"   # A/B: relu(P6) copy vs input-ReLU flag
 
 
@@ -287,7 +288,7 @@ class SipMaskEngine:
         # ... and for the same reason its patch convs keep the uniform 256-position launch: the mixed launch (256-position
         # tiles + 128/192-position finishing tiles, sm_conv3x3_patch_plan) ends a lone launch 15-20 % sooner but spends
         # 4-6 % more CU time on it, which the other chain would have used (measured 998 vs 991 img/s, profiles/r02g_ab_patch_launch_shape.json)
-        self.patch_uniform = sub_plan
+        self.patch_uniform = sub_plan and os.environ.get("SIPMASK_PATCH_MIXED", "0") != "1"   # =1: A/B switch (tools/)
         if precision not in ("bf16", "f32", "head_x3"):
             raise ValueError("precision must be 'bf16' (throughput plan), 'head_x3' (bf16 backbone + FPN, split-precision "
                              "head: the reference head's fp32 arithmetic to ~1e-4 on its logits) or 'f32' (parity plan), "

@@ -224,7 +224,7 @@ def make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, cout, cou
             d.res_row0[l] = res_row0[l]
         d.level_scale[l] = 1.0 if level_scale is None else float(level_scale[l])
     d.cin, d.cout, d.cout_pad = cin, cout, cout_pad
-    d.kh = d.kw = k
+    d.kh, d.kw = (k, k) if isinstance(k, int) else (int(k[0]), int(k[1]))      # k: int or (kh, kw)
     d.stride, d.pad, d.dil = stride, pad, dil
     d.in_cstride, d.out_cstride, d.out_coff = in_cstride, out_cstride, out_coff
     d.res_cstride = res_cstride

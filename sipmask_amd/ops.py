@@ -40,6 +40,8 @@ def _rows_bf16(t, c):
 
 # ------------------------------------------------------------------------------- deform conv
 class DeformConvFunction(Function):
+    """One conv group (groups == 1) of M/mmdet/ops/dcn/deform_conv.py:16-96 on the C ABI: kh x kw kernels, one stride /
+    dilation for both axes (the descriptor's), symmetric padding (deform_conv() pads explicitly when the axes differ)."""
 
     @staticmethod
     def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
@@ -50,13 +52,14 @@ class DeformConvFunction(Function):
             raise NotImplementedError
         stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
         if groups != 1:
-            raise NotImplementedError("sipmask_amd DeformConv: groups != 1 is not on the SipMask path")
-        if stride != (1, 1) or stride[0] != stride[1] or padding[0] != padding[1] or dilation[0] != dilation[1]:
-            raise NotImplementedError("sipmask_amd DeformConv: only stride 1 and square pad/dilation")
+            raise NotImplementedError("DeformConvFunction is one conv group; deform_conv() splits groups > 1")
+        if stride[0] != stride[1] or dilation[0] != dilation[1]:
+            raise NotImplementedError("sipmask_amd DeformConv: one stride and one dilation for both axes (the C ABI's "
+                                      "sm_conv_desc carries one of each)")
+        if padding[0] != padding[1]:
+            raise NotImplementedError("DeformConvFunction takes symmetric padding; deform_conv() pads per axis")
         b, c, h, w = input.shape
         co, ci, kh, kw = weight.shape
-        if kh != kw:
-            raise NotImplementedError("square kernels only")
         g = deformable_groups
         ho = (h + 2 * padding[0] - (dilation[0] * (kh - 1) + 1)) // stride[0] + 1
         wo = (w + 2 * padding[1] - (dilation[1] * (kw - 1) + 1)) // stride[1] + 1
@@ -73,12 +76,12 @@ class DeformConvFunction(Function):
         off = offset.detach().float().permute(0, 2, 3, 1).contiguous().view(b * ho * wo, -1)
         wq, co_pad = H.prep_conv_weight(weight.detach())
         y = torch.empty(b * ho * wo, co, dtype=torch.float32, device=input.device)
-        d = H.make_conv_desc(b, [(h, w)], [(ho, wo)], [0], [0], c, co, co_pad, kh, 1, padding[0], c, co,
+        d = H.make_conv_desc(b, [(h, w)], [(ho, wo)], [0], [0], c, co, co_pad, (kh, kw), stride[0], padding[0], c, co,
                              flags=_lib.SM_CONV_OUT_F32, dil=dilation[0], deform_groups=g)
         H.deform_conv2d(d, x, off, wq, None, y)
         if input.requires_grad or offset.requires_grad or weight.requires_grad:
             ctx.save_for_backward(x, off, weight)
-            ctx.geom = (b, c, h, w, co, kh, ho, wo, padding[0], dilation[0], g, input.dtype)
+            ctx.geom = (b, c, h, w, co, kh, kw, ho, wo, stride[0], padding[0], dilation[0], g, input.dtype)
         return y.view(b, ho, wo, co).permute(0, 3, 1, 2).to(input.dtype)
 
     @staticmethod
@@ -89,16 +92,16 @@ class DeformConvFunction(Function):
         if not grad_output.is_cuda:
             raise NotImplementedError
         x, off, weight = ctx.saved_tensors
-        b, c, h, w, co, k, ho, wo, pad, dil, g, dt = ctx.geom
+        b, c, h, w, co, kh, kw, ho, wo, stride, pad, dil, g, dt = ctx.geom
         dev = grad_output.device
         if c % 64 != 0 or (c // g) % 64 != 0 or co % 8 != 0:
             raise NotImplementedError("deform conv backward needs 64 | channels per deformable group and 8 | out_channels")
         go = _rows_bf16(grad_output, co)
-        d = H.make_conv_desc(b, [(h, w)], [(ho, wo)], [0], [0], c, co, co, k, 1, pad, c, co,
+        d = H.make_conv_desc(b, [(h, w)], [(ho, wo)], [0], [0], c, co, co, (kh, kw), stride, pad, c, co,
                              dil=dil, deform_groups=g)
         need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         need_w = ctx.needs_input_grad[2]
-        K = k * k * c
+        K = kh * kw * c
         w_t = None
         if need_in:      # W^T as the operand of the grad-column GEMM: a 1x1 conv weight [K][co]
             w_t, _ = H.prep_conv_weight(weight.detach().permute(2, 3, 1, 0).reshape(K, co, 1, 1).contiguous(), co)
@@ -111,11 +114,49 @@ class DeformConvFunction(Function):
             grad_input = gx.view(b, h, w, c).permute(0, 3, 1, 2).to(dt)
             grad_offset = goff.view(b, ho, wo, -1).permute(0, 3, 1, 2).contiguous()
         if need_w:
-            grad_weight = gw_t.view(k, k, c, co).permute(3, 2, 0, 1).contiguous().to(weight.dtype)
+            grad_weight = gw_t.view(kh, kw, c, co).permute(3, 2, 0, 1).contiguous().to(weight.dtype)
         return (grad_input, grad_offset, grad_weight, None, None, None, None, None, None)
 
 
-deform_conv = DeformConvFunction.apply
+def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
+    """M/mmdet/ops/dcn/deform_conv.py:99 (`deform_conv = DeformConvFunction.apply`) with the op's full argument range:
+      * groups > 1: one launch per conv group over its channel slice (the reference's grouped GEMM,
+        deform_conv_cuda.cpp:231-236); the deformable groups follow the CHANNELS (channel c samples with the offsets of
+        deformable group c // (C / deformable_groups), deform_conv_cuda_kernel.cu:206), so a conv group takes the
+        deformable groups its slice covers -- whole ones when deformable_groups is a multiple of groups, the one it lies in
+        when groups is a multiple of deformable_groups; autograd sums the offset gradients of groups that share one;
+      * padding that differs between the axes: the input is zero-padded explicitly and the op runs unpadded -- the same
+        values, because a bilinear corner outside the image contributes zero either way (kernel.cu:98-109);
+      * stride / dilation must be the same for both axes (NotImplementedError otherwise)."""
+    stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    if input is not None and input.dim() != 4:
+        raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(input.dim()))
+    if padding[0] != padding[1]:
+        input = torch.nn.functional.pad(input, (padding[1], padding[1], padding[0], padding[0]))
+        padding = (0, 0)
+    if groups == 1:
+        return DeformConvFunction.apply(input, offset, weight, stride, padding, dilation, 1, deformable_groups, im2col_step)
+    c, co = input.shape[1], weight.shape[0]
+    if c % groups or co % groups or weight.shape[1] * groups != c:
+        raise ValueError("channels {} / out_channels {} / weight {} do not fit groups={}".format(
+            c, co, tuple(weight.shape), groups))
+    dg, kk2 = deformable_groups, 2 * weight.shape[2] * weight.shape[3]
+    if dg % groups != 0 and groups % dg != 0:
+        raise NotImplementedError("groups={} and deformable_groups={}: one must divide the other".format(groups, dg))
+    cg, cog, outs = c // groups, co // groups, []
+    for gi in range(groups):
+        if dg % groups == 0:
+            sub = dg // groups
+            off = offset[:, gi * sub * kk2:(gi + 1) * sub * kk2]
+        else:
+            sub = 1
+            di = gi // (groups // dg)
+            off = offset[:, di * kk2:(di + 1) * kk2]
+        outs.append(DeformConvFunction.apply(input[:, gi * cg:(gi + 1) * cg], off, weight[gi * cog:(gi + 1) * cog], stride,
+                                             padding, dilation, 1, sub, im2col_step))
+    return torch.cat(outs, 1)
+
+
 
 
 class DeformConv(nn.Module):

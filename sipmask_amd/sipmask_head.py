@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import hip_ops as H
+from .fp16 import force_fp32
 from .modules import ConvModule, bias_init_with_prob, normal_init
 from .ops import CropSplit, CropSplitGt, DeformConv, Scale
 from .plan_cache import PlanCache, module_tensors
@@ -87,6 +88,7 @@ class SipMaskHead(nn.Module):
                  conv_cfg=None, norm_cfg=dict(type='GN', num_groups=32, requires_grad=True)):
         super().__init__()
         self.num_classes = num_classes
+        self.fp16_enabled = False            # fp16.wrap_fp16_model switches it on (sipmask_head.py: force_fp32 on loss / get_bboxes)
         self.cls_out_channels = num_classes - 1
         self.in_channels, self.feat_channels, self.stacked_convs = in_channels, feat_channels, stacked_convs
         self.strides, self.regress_ranges = strides, regress_ranges
@@ -294,6 +296,7 @@ class SipMaskHead(nn.Module):
             res = [r + (post.mask_scores[b, :r[0].shape[0]],) for b, r in enumerate(res)]
         return res
 
+    @force_fp32(apply_to=('cls_scores', 'bbox_preds', 'centernesses'))
     def get_bboxes(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, img_metas, cfg, rescale=None):
         """Reference packaging (sipmask_head.py:645-662): list of (det_bboxes, det_labels, cls_segms) with
         cls_segms[label] = list of COCO RLE dicts {'size': [H, W], 'counts': bytes}.  The masks are pasted on the
@@ -325,6 +328,7 @@ class SipMaskHead(nn.Module):
         return {k: v.detach() for k, v in self.state_dict().items()
                 if k.startswith("convs_scoring.") or k.startswith("mask_scoring.")}
 
+    @force_fp32(apply_to=('cls_scores', 'bbox_preds', 'centernesses'))
     def loss(self, cls_scores, bbox_preds, centernesses, cof_preds, feat_masks, gt_bboxes, gt_labels, img_metas, cfg,
              gt_bboxes_ignore=None, gt_masks_list=None, _per_image=None, _targets=None):
         """sipmask_head.py:289-498: dict(loss_cls, loss_bbox, loss_centerness, loss_mask[, loss_iou]).

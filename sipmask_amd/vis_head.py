@@ -194,10 +194,11 @@ class SipMaskVIS(SipMask):
     """V/mmdet/models/detectors/single_stage.py:69-82: simple_test on one frame -> (bbox_results, segm_results) keyed
     by object id; the whole frame (backbone ... mask assembly, embedding gather) is one static launch plan."""
 
-    def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False, lanes=1):
+    def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False, lanes=1, slot=0):
+        """slot: clip_test_many keeps two plans of one shape (clip i+1 runs while the results of clip i are fetched)"""
         from .engine import SipMaskEngine, SubBatchPlan
         key = (batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
-               rescale, lanes)
+               rescale, lanes) + ((slot,) if slot else ())
 
         def build():
             sd = self.state_dict()
@@ -269,8 +270,12 @@ class SipMaskVIS(SipMask):
         nd = r["ndet"].cpu().tolist()
         ids_h, det_h, lab_h = ids_dev.cpu().numpy(), r["det_bboxes"].cpu().numpy(), r["det_labels"].cpu().numpy()
         rles = eng.encode_rle(tuple(m0['ori_shape'])[:2]) if encode else None
+        return self._clip_results(nd, ids_h, det_h, lab_h, rles)
+
+    def _clip_results(self, nd, ids_h, det_h, lab_h, rles):
+        """the (bbox_results, segm_results) pairs of simple_test (V/...:640-667) for the frames of one clip"""
         out = []
-        for t in range(T):
+        for t in range(len(nd)):
             n = int(nd[t])
             if n == 0:
                 out.append((dict(), [[] for _ in range(self.bbox_head.num_classes - 1)]))
@@ -280,9 +285,92 @@ class SipMaskVIS(SipMask):
             for i in range(n):
                 if ids[i] >= 0:
                     bbox_results[int(ids[i])] = {'bbox': d[i], 'label': l[i]}
-                    if encode:
+                    if rles is not None:
                         segm_results[int(ids[i])] = rles[t][i]
             out.append((bbox_results, segm_results))
+        return out
+
+    def clip_test_many(self, clips, clip_metas, rescale=False, encode=True, graph=True):
+        """Several clips, pipelined: clip_test spends a fifth of a clip's time on the host (one synchronising fetch, the
+        result dictionaries) while the device idles, and the device part of a clip ends in a latency-bound tail.  Here clip
+        i+1 is enqueued BEFORE the results of clip i are fetched: two plans of the clip shape (slots, each with its own
+        graph, input and output buffers) alternate on two streams; the identity matching -- the only part that depends on
+        the previous clip, through the tracker's memory -- is enqueued in clip order on a third stream behind each clip's
+        detections, followed by the device->host copies into pinned buffers; the host waits for ONE event per clip.
+        clips: list of [T,3,H,W] device tensors of one shape; clip_metas: per clip the T meta dicts (is_first resets the
+        tracker: consecutive clips of one video and independent videos both work -- the memory is walked in clip order).
+        Returns per clip what clip_test returns; same ids, boxes and masks (tests/test_gpu_vis.py)."""
+        n = len(clips)
+        if n == 0:
+            return []
+        T, hw, dev = clips[0].shape[0], tuple(clips[0].shape[-2:]), clips[0].device
+        m0 = clip_metas[0][0]
+        for c, ms in zip(clips, clip_metas):
+            if tuple(c.shape) != tuple(clips[0].shape) or len(ms) != T:
+                raise ValueError("clip_test_many: the clips of one call share one shape")
+        lanes = 2 if (T >= 4 and T % 2 == 0) else 1
+        nslot = min(2, n)
+        engs = [self.prepare(T, hw, tuple(m0['img_shape']), m0.get('scale_factor', 1.0), bool(rescale), lanes=lanes, slot=k)
+                for k in range(nslot)]
+        pipe = getattr(self, "_clip_pipe", None)
+        if pipe is None or pipe["dev"] != dev:
+            pipe = self._clip_pipe = dict(dev=dev, streams=[torch.cuda.Stream(device=dev) for _ in range(2)],
+                                          track=torch.cuda.Stream(device=dev), host={})
+        main = torch.cuda.current_stream()
+        if graph:
+            for e in engs:                                         # capture on the caller's stream, before the pipeline starts
+                if getattr(e, "_clip_graph", None) is None:
+                    self._run_plan(e, clips[0], True)
+        mx = engs[0].max_num
+        hkey = (T, mx)
+        host = pipe["host"].get(hkey)
+        if host is None:                                           # pinned landing buffers, one set per slot
+            host = pipe["host"][hkey] = [dict(nd=torch.empty(T, dtype=torch.int32).pin_memory(),
+                                              ids=torch.empty(T, mx, dtype=torch.int32).pin_memory(),
+                                              det=torch.empty(T, mx, 5, dtype=torch.float32).pin_memory(),
+                                              lab=torch.empty(T, mx, dtype=torch.int64).pin_memory()) for _ in range(2)]
+        done, freed, out = [None] * n, [None] * 2, [None] * n
+
+        def launch(i):
+            k = i % nslot
+            st = pipe["streams"][k]
+            st.wait_stream(main)                                   # the clip was produced on the caller's stream
+            if freed[k] is not None:
+                st.wait_event(freed[k])                            # the matching of clip i-2 has read this slot's outputs
+            with torch.cuda.stream(st):
+                r = self._run_plan(engs[k], clips[i], graph)
+                ready = torch.cuda.Event()
+                ready.record(st)
+            tr = pipe["track"]
+            tr.wait_event(ready)
+            with torch.cuda.stream(tr):
+                ids = self.bbox_head.match_clip(r["det_feats"], r["det_bboxes"], r["det_labels"], r["ndet"],
+                                                [m['is_first'] for m in clip_metas[i]])
+                h = host[k]
+                h["nd"].copy_(r["ndet"].view(-1), non_blocking=True)
+                h["ids"].copy_(ids, non_blocking=True)
+                h["det"].copy_(r["det_bboxes"], non_blocking=True)
+                h["lab"].copy_(r["det_labels"], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(tr)
+            done[i], freed[k] = ev, ev
+
+        def finish(i):
+            k = i % nslot
+            done[i].synchronize()                                  # the one host wait of the clip
+            h = host[k]
+            rles = engs[k].encode_rle(tuple(clip_metas[i][0]['ori_shape'])[:2]) if encode else None
+            out[i] = self._clip_results(h["nd"].tolist(), h["ids"].numpy().copy(), h["det"].numpy().copy(),
+                                        h["lab"].numpy().copy(), rles)
+
+        for i in range(n):
+            if i >= nslot:
+                finish(i - nslot)                                  # frees the slot clip i is about to use (host buffers too)
+            launch(i)
+        for i in range(max(0, n - nslot), n):
+            finish(i)
+        for st in pipe["streams"] + [pipe["track"]]:
+            main.wait_stream(st)
         return out
 
     def simple_test(self, img, img_meta, rescale=False):

@@ -775,3 +775,48 @@ def test_hip_sgd_multi_tensor_matches_torch_sgd():
         for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
             torch.testing.assert_close(p, q, rtol=1e-5, atol=1e-7, msg=lambda m_: "%s step %d: %s" % (n, step, m_))
     assert net[0].weight._version >= 3
+
+
+@pytest.mark.parametrize("case", [
+    dict(k=3, stride=2, pad=1, dil=1, groups=1, dg=1),           # strided
+    dict(k=3, stride=1, pad=2, dil=2, groups=1, dg=2),           # dilated
+    dict(k=(1, 3), stride=1, pad=(0, 1), dil=1, groups=1, dg=1),   # rectangular kernel, per-axis padding
+    dict(k=(3, 5), stride=2, pad=(1, 2), dil=1, groups=1, dg=1),
+    dict(k=3, stride=1, pad=1, dil=1, groups=2, dg=2),           # conv groups == deformable groups
+    dict(k=3, stride=1, pad=1, dil=1, groups=2, dg=4),           # two deformable groups inside every conv group
+    dict(k=3, stride=1, pad=1, dil=1, groups=2, dg=1),           # both conv groups share one deformable group
+])
+def test_deform_conv_module_argument_range(case):
+    """DeformConv over the op's argument range (M/mmdet/ops/dcn/deform_conv.py:192-255: stride, dilation, conv groups,
+    rectangular kernels, per-axis padding) against the oracle, forward and backward (autograd through the per-group launches;
+    offset gradients of conv groups that share a deformable group add up)."""
+    from sipmask_amd.ops import DeformConv
+    torch.manual_seed(3)
+    kh, kw = (case["k"], case["k"]) if isinstance(case["k"], int) else case["k"]
+    ph, pw = (case["pad"], case["pad"]) if isinstance(case["pad"], int) else case["pad"]
+    s, dl, G, dg = case["stride"], case["dil"], case["groups"], case["dg"]
+    C, Co, H, W = 128 * max(1, dg // G) if G > 1 else 128, 64, 11, 13
+    if G > 1:
+        C = 64 * G * max(1, dg // G)                      # 64 | channels per deformable group inside a conv group (backward)
+    m = DeformConv(C, Co, (kh, kw), stride=s, padding=(ph, pw), dilation=dl, groups=G, deformable_groups=dg).cuda()
+    with torch.no_grad():
+        m.weight.copy_((m.weight * 3).to(torch.bfloat16).float())
+    ho = (H + 2 * ph - (dl * (kh - 1) + 1)) // s + 1
+    wo = (W + 2 * pw - (dl * (kw - 1) + 1)) // s + 1
+    x = torch.randn(2, C, H, W).to(torch.bfloat16).float()
+    off = torch.randn(2, dg * 2 * kh * kw, ho, wo) * 0.8
+    xg, og = x.cuda().requires_grad_(True), off.cuda().requires_grad_(True)
+    y = m(xg, og)
+    wref = m.weight.detach().cpu()
+    ref = O.deform_conv_grouped(x, off, wref, s, (ph, pw), dl, G, dg)
+    assert y.shape == ref.shape == (2, Co, ho, wo)
+    torch.testing.assert_close(y.detach().cpu(), ref, rtol=2e-2, atol=3e-2)
+    go = torch.randn(ref.shape).to(torch.bfloat16).float()
+    y.backward(go.cuda())
+    # reference gradients: autograd through the (differentiable) oracle in float64
+    x64, o64, w64 = x.double().requires_grad_(True), off.double().requires_grad_(True), wref.double().requires_grad_(True)
+    O.deform_conv_grouped(x64, o64, w64, s, (ph, pw), dl, G, dg).backward(go.double())
+    for name, got, want in (("input", xg.grad, x64.grad), ("offset", og.grad, o64.grad), ("weight", m.weight.grad, w64.grad)):
+        want = want.float()
+        err = (got.cpu() - want).abs().max().item()
+        assert err <= 3e-2 * max(1.0, want.abs().max().item()), (name, err, want.abs().max().item())

@@ -188,6 +188,36 @@ def test_vis_clip_test_equals_frame_by_frame(vdet):
                 assert s2[oid]["size"] == s1[oid]["size"]
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_vis_clip_test_many_equals_clip_by_clip(vdet, graph):
+    """SipMaskVIS.clip_test_many (clip i+1 enqueued before the results of clip i are fetched; two plan slots, the matching
+    in clip order on its own stream) returns exactly what clip_test returns clip by clip -- same plan, same kernels, so
+    ids, boxes and RLEs are equal bit for bit.  Five clips: a video of two clips (the second continues the tracker's
+    memory), then three independent videos (is_first resets it); odd count, so both slots and the drain are exercised."""
+    g = torch.Generator().manual_seed(21)
+    base = [torch.randn(1, 3, 192, 320, generator=g) for _ in range(4)]
+    src = [base[0], base[0], base[1], base[2], base[3]]
+    clips = [torch.cat([b + torch.randn(b.shape, generator=g) * 0.02 for _ in range(4)]).cuda() for b in src]
+    first = [True, False, True, True, True]
+    metas = [[dict(img_shape=(192, 320, 3), ori_shape=(192, 320, 3), pad_shape=(192, 320, 3), scale_factor=1.0,
+                   is_first=(t == 0 and f)) for t in range(4)] for f in first]
+    vdet.bbox_head.reset_tracker()
+    one = [vdet.clip_test(c, m, rescale=True, graph=graph) for c, m in zip(clips, metas)]
+    vdet.bbox_head.reset_tracker()
+    many = vdet.clip_test_many(clips, metas, rescale=True, graph=graph)
+    assert len(many) == 5 and sum(len(b) for clip in one for b, _ in clip) > 0
+    continued = set(one[0][-1][0]) & set(one[1][0][0])
+    assert continued, "the second clip continues the identities of the first"
+    for ci in range(5):
+        for t in range(4):
+            (b1, s1), (b2, s2) = one[ci][t], many[ci][t]
+            assert sorted(b1) == sorted(b2), (ci, t)
+            for oid in b1:
+                assert b1[oid]['label'] == b2[oid]['label']
+                np.testing.assert_array_equal(b1[oid]['bbox'], b2[oid]['bbox'])
+                assert s1[oid] == s2[oid]
+
+
 def test_vis_training_losses_vs_oracle():
     """SipMaskVISHead.forward(feats, feats_x, flag_train=True) + loss: the SipMask losses plus loss_match against the
     oracle (same jitter offsets injected on both sides); gradients reach the track branch."""

@@ -247,3 +247,27 @@ def test_oracle_cpu_nms_equals_the_compiled_reference_extension(kat):
     d = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 19, 0.8]], np.float32)
     assert ref.nms(torch.from_numpy(d), 0.5).numpy().tolist() == [0]
     assert sorted(ops.nms(d, 0.5, mode="cpu")) == [0] and sorted(ops.nms(d, 0.5, mode="gpu")) == [0, 1]
+
+
+def test_deform_conv_per_axis_arguments_and_groups_reduce_to_conv2d():
+    """oracle.ops.deform_conv with per-axis stride / padding / dilation (deform_conv.py:32-34 `_pair`) and
+    deform_conv_grouped: zero offsets give F.conv2d for every argument combination the module accepts"""
+    O = ops
+    torch.manual_seed(1)
+    x = torch.randn(2, 8, 9, 10, dtype=torch.float64)
+    for (kh, kw), st, pd, dl, G, dg in (((3, 3), 2, 1, 1, 1, 1), ((1, 3), (2, 1), (0, 1), 1, 1, 2), ((3, 5), 1, (1, 2), (1, 2), 1, 1),
+                                        ((3, 3), 1, 1, 1, 2, 2), ((3, 3), 1, 1, 1, 2, 4), ((3, 3), 2, 2, 2, 4, 2)):
+        w = torch.randn(8, 8 // G, kh, kw, dtype=torch.float64)
+        ref = F.conv2d(x, w, None, st, pd, dl, G)
+        off = torch.zeros(2, dg * 2 * kh * kw, ref.shape[2], ref.shape[3], dtype=torch.float64)
+        got = O.deform_conv_grouped(x, off, w, st, pd, dl, G, dg)
+        torch.testing.assert_close(got, ref, rtol=1e-12, atol=1e-12)
+    # integer offsets shift the sampling grid: every tap moved one pixel down == conv of the image shifted up
+    w = torch.randn(4, 8, 3, 3, dtype=torch.float64)
+    off = torch.zeros(2, 18, 9, 10, dtype=torch.float64)
+    off[:, 0::2] = 1.0
+    shifted = torch.zeros_like(x)
+    shifted[:, :, :-1] = x[:, :, 1:]
+    # (output row 0 excepted: its top taps sample image row 0, which the shifted image keeps only as zero padding)
+    torch.testing.assert_close(O.deform_conv(x, off, w, 1, 1, 1, 1)[:, :, 1:], F.conv2d(shifted, w, None, 1, 1)[:, :, 1:],
+                               rtol=1e-12, atol=1e-12)
