@@ -88,7 +88,7 @@ __device__ __forceinline__ Sample sample_of(const DBArgs& a, const Pos& ps, int 
 }
 
 // ---------------------------------------------------------------- grad_input + grad_offset
-__global__ __launch_bounds__(256) void deform_col2im_kernel(const DBArgs a, const float* __restrict__ gcol,
+__global__ __launch_bounds__(256) void deform_col2im_kernel(const DBArgs a, const uint16_t* __restrict__ gcol,
                                                             float* __restrict__ gx, float* __restrict__ goff,
                                                             long long nunits) {
   const int lane = threadIdx.x & 63;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const DBArgs a, cons
     const int g = (q * 64) / cpg;
     const Sample s = sample_of(a, ps, tap, g);
     if (!s.valid) continue;   // wave-uniform: contributes nothing (kernel.cu:423-426; no in-bounds neighbour :324-327)
-    const float top = gcol[p * K + (long long)tap * a.cin + c];
+    const float top = bf16_bits_to_f32((uint32_t)gcol[p * K + (long long)tap * a.cin + c]);
     const int H = a.in_h[ps.l], W = a.in_w[ps.l];
     const long long base = a.in_row0[ps.l] + (long long)ps.b * H * W;
     float dh = 0.f, dw = 0.f;
@@ -143,6 +143,120 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const DBArgs a, cons
     }
   }
 }
+
+// 3x3 kernels (every deformable conv of the SipMask configs): ONE wave per (position, 64-channel chunk) with the nine
+// taps unrolled.  The generic kernel above gives a wave one (position, tap, chunk) unit: one locate(), one offset load,
+// one grad-column load and four x loads per unit, each waiting for the one before -- 3.2 M such dependent chains for the
+// B=4 head, 3.07 ms (profiles/r02_rocprofv3_kernel_stats_train_step.csv).  Here a wave decodes its position once, fetches
+// the group's 18 offsets with one 72-byte load (lanes 0-17; the taps read them with v_readlane), and issues its 9
+// grad-column loads and all 36 corner loads UNCONDITIONALLY (clamped addresses, validity folded into the weights) before the
+// first use, so a wave has 45 loads in flight instead of one.  The offset gradients -- 18 sums over the 64 channels -- are
+// folded with v_permlane32_swap (two values per swap: the low half keeps d/dh, the high half d/dw) and finished by the
+// transposing half-wave reduce of common.h: 9 swaps + 16 shuffles instead of 108.
+// body: one (position, 64-channel chunk); `scatter(row, hc, wc, value)` takes the d(x) contribution of this lane's channel
+// at input pixel (hc, wc) = row `row` of the level's image (wave-uniform arguments except the value)
+template <typename Scatter>
+__device__ __forceinline__ void col2im9_position(const DBArgs& a, const Pos& ps, const long long p, const int q, const int lane,
+                                                 const uint16_t* __restrict__ gcol, const bool want_gx,
+                                                 float* __restrict__ goff, Scatter&& scatter) {
+  const int l31 = lane & 31;
+  const int cpg = a.cin / a.G;
+  const long long K = 9ll * a.cin;
+  const int c = q * 64 + lane;
+  const int g = (q * 64) / cpg;
+  const int H = a.in_h[ps.l], W = a.in_w[ps.l];
+  const long long base = a.in_row0[ps.l] + (long long)ps.b * H * W;
+  const long long orow18 = ps.orow * (long long)(a.G * 18) + g * 18;
+  float ofs = 0.f;
+  if (a.offset != nullptr && lane < 18) ofs = a.offset[orow18 + lane];
+  uint16_t topb[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) topb[t] = gcol[p * K + (long long)t * a.cin + c];
+  // phase 1: sampling geometry of the nine taps, all corner loads
+  float lhs[9], lws[9];
+  int inm[9];                                    // bit 0 / 1: corner row hl / hl+1 inside the image, bit 2 / 3: column wl / wl+1
+  int hls[9], wls[9];
+  uint16_t xv[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int i = t / 3, j = t - 3 * (t / 3);
+    const float o0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ofs), 2 * t));
+    const float o1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ofs), 2 * t + 1));
+    const float h_im = (float)(ps.oy * a.stride - a.pad + i * a.dil) + o0;
+    const float w_im = (float)(ps.ox * a.stride - a.pad + j * a.dil) + o1;
+    const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;   // kernel.cu:229
+    const float fh = floorf(h_im), fw = floorf(w_im);
+    const int hl = valid ? (int)fh : 0, wl = valid ? (int)fw : 0;
+    hls[t] = hl;
+    wls[t] = wl;
+    lhs[t] = h_im - fh;
+    lws[t] = w_im - fw;
+    inm[t] = valid ? ((hl >= 0 ? 1 : 0) | (hl + 1 <= H - 1 ? 2 : 0) | (wl >= 0 ? 4 : 0) | (wl + 1 <= W - 1 ? 8 : 0)) : 0;
+    const int h0 = min(max(hl, 0), H - 1), h1 = min(max(hl + 1, 0), H - 1);
+    const int w0 = min(max(wl, 0), W - 1), w1 = min(max(wl + 1, 0), W - 1);
+    xv[t][0] = a.x[(base + (long long)h0 * W + w0) * a.in_cstride + c];
+    xv[t][1] = a.x[(base + (long long)h0 * W + w1) * a.in_cstride + c];
+    xv[t][2] = a.x[(base + (long long)h1 * W + w0) * a.in_cstride + c];
+    xv[t][3] = a.x[(base + (long long)h1 * W + w1) * a.in_cstride + c];
+  }
+  // phase 2: scatter d(x), accumulate d(offset).  Corner (row bit, column bit) carries weight wy * wx
+  // (get_gradient_weight, kernel.cu:117-142); d/dh = +-wx * x, d/dw = +-wy * x (get_coordinate_weight :144-188); a
+  // corner outside the image contributes to neither (its flags, not its weights, decide: lh == 0 is a legal weight).
+  float fold[16];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float top = bf16_bits_to_f32((uint32_t)topb[t]);
+    float dh = 0.f, dw = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool in = ((inm[t] >> (k >> 1)) & 1) && ((inm[t] >> (2 + (k & 1))) & 1);      // wave-uniform
+      if (!in) continue;
+      const float wy = (k >> 1) ? lhs[t] : 1.f - lhs[t], wx = (k & 1) ? lws[t] : 1.f - lws[t];
+      const float v = bf16_bits_to_f32((uint32_t)xv[t][k]);
+      const int hc = hls[t] + (k >> 1), wc = wls[t] + (k & 1);
+      if (want_gx) scatter(base + (long long)hc * W + wc, hc, wc, top * (wy * wx));
+      dh += ((k >> 1) ? wx : -wx) * v;
+      dw += ((k & 1) ? wy : -wy) * v;
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(top * dh), __float_as_uint(top * dw), false, false);
+    fold[t] = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // low half: d/dh over lanes {l, l+32}; high half: d/dw
+  }
+  if (goff != nullptr) {
+#pragma unroll
+    for (int t = 9; t < 16; ++t) fold[t] = 0.f;
+    const float tot = gn_half_wave_totals<16>(fold, l31);            // lane pair k = l31 >> 1 holds tap k
+    const int k = l31 >> 1;
+    if ((l31 & 1) == 0 && k < 9) {
+      float* o = goff + orow18 + k * 2 + (lane >> 5);
+      if (cpg == 64)
+        *o = tot;                                                     // this wave owns the (position, group)
+      else
+        unsafeAtomicAdd(o, tot);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void deform_col2im9_kernel(const DBArgs a, const uint16_t* __restrict__ gcol,
+                                                             float* __restrict__ gx, float* __restrict__ goff,
+                                                             long long nunits) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nq = a.cin >> 6;
+  for (long long u = (long long)blockIdx.x * 4 + wv; u < nunits; u += (long long)gridDim.x * 4) {
+    const int q = (int)(u % nq);
+    const long long p = u / nq;
+    const Pos ps = locate(a, p);
+    const int c = q * 64 + lane;
+    col2im9_position(a, ps, p, q, lane, gcol, gx != nullptr, goff,
+                     [&](long long row, int, int, float v) { unsafeAtomicAdd(gx + row * a.cin + c, v); });
+  }
+}
+
+// (Round 3 A/B, removed: accumulating d(x) per 8 x 16-position tile in an f32 LDS window -- ds_add_f32, lane = channel --
+// and flushing the window with one global atomic per touched pixel, 425 instead of 4608 per tile.  Bit-compatible with the
+// direct scatter up to summation order and 2x SLOWER: 5.1 ms against 2.74 for d(x) + d(offset) of the B=4 head with 16 waves
+// per window, 6.0 with 4 (profiles/r03_deform_bwd_scatter_ab.txt).  A 64-lane ds_add_f32 costs ~170 cycles here; the L2's
+// float atomics retire 826 M lane-adds in 1.85 ms.  What the kernel above spends without any scatter: 0.88 ms.)
 
 // ---------------------------------------------------------------- operands of the weight-gradient GEMM
 // col^T[k][pl] (bf16, k = tap*cin + c) for positions p0 .. p0+n of the compact order; columns n..Lp are zero
@@ -189,6 +303,68 @@ __global__ __launch_bounds__(256) void deform_im2col_t_kernel(const DBArgs a, in
     uint16_t* o = colT + ((long long)sl * Kpad + (long long)tap * a.cin + c8 * 8) * L + pl;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[(long long)e * L] = (uint16_t)f32_to_bf16_bits(v[e]);
+  }
+}
+
+// The same operand, one thread per (position, tap, deformable group) instead of per (position, tap, 8 channels): with 64
+// channels per group the sampling point -- locate(), the offset load, the bilinear set-up, ~150 VALU -- was recomputed
+// for each of the group's 8 chunks (1.29 ms for the B=4 head, profiles/r03_rocprofv3_kernel_stats_train_step.csv).  Here
+// it is computed once and the thread walks its group's channels 8 at a time: per chunk 4 corner loads of 16 bytes, the
+// blend, 8 two-byte stores (coalesced across the lanes = consecutive positions of a K-major col^T row).
+__global__ __launch_bounds__(256) void deform_im2col_t_group_kernel(const DBArgs a, int S, int L, int Kpad,
+                                                                    uint16_t* __restrict__ colT) {
+  const int kk = a.kh * a.kw;
+  const int cpg = a.cin / a.G;                   // multiple of 8
+  const long long SL = (long long)S * L;
+  const long long total = (long long)kk * a.G * SL;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long gp = t % SL;
+    const int sl = (int)(gp / L), pl = (int)(gp - (long long)sl * L);
+    const int g = (int)((t / SL) % a.G);
+    const int tap = (int)(t / (SL * a.G));
+    uint16_t* o = colT + ((long long)sl * Kpad + (long long)tap * a.cin + g * cpg) * L + pl;
+    bool live = gp < a.P;
+    Pos ps;
+    Sample s;
+    if (live) {
+      ps = locate(a, gp);
+      s = sample_of(a, ps, tap, g);
+      live = s.valid;
+    }
+    if (!live) {                                  // positions beyond P and samples outside the image: zero columns
+      for (int c = 0; c < cpg; ++c) o[(long long)c * L] = 0;
+      continue;
+    }
+    const int H = a.in_h[ps.l], W = a.in_w[ps.l];
+    const long long base = a.in_row0[ps.l] + (long long)ps.b * H * W;
+    const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+    float wgt[4];
+    const uint16_t* src[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int hc = s.hl + (k >> 1), wc = s.wl + (k & 1);
+      const bool in = hc >= 0 && hc <= H - 1 && wc >= 0 && wc <= W - 1;
+      wgt[k] = in ? ((k >> 1) ? s.lh : hh) * ((k & 1) ? s.lw : hw) : 0.f;
+      const int hcc = min(max(hc, 0), H - 1), wcc = min(max(wc, 0), W - 1);
+      src[k] = a.x + (base + (long long)hcc * W + wcc) * a.in_cstride + g * cpg;       // clamped: the load is unconditional
+    }
+    for (int c8 = 0; c8 < cpg; c8 += 8) {
+      u32x4 raw[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) raw[k] = *reinterpret_cast<const u32x4*>(src[k] + c8);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] += wgt[k] * __uint_as_float(raw[k][e] << 16);
+          v[2 * e + 1] += wgt[k] * __uint_as_float(raw[k][e] & 0xffff0000u);
+        }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[(long long)(c8 + e) * L] = (uint16_t)f32_to_bf16_bits(v[e]);
+    }
   }
 }
 
@@ -458,8 +634,8 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
     g1.kh = g1.kw = 1, g1.stride = 1, g1.pad = 0, g1.dil = 1;
     g1.in_cstride = d->out_cstride;
     g1.out_cstride = (int)pl.K;
-    g1.flags = SM_CONV_OUT_F32;
-    float* gcol = (float*)(ws + pl.off_gcol);
+    g1.flags = 0;                                 // bf16 grad columns: half the bytes the scatter kernel has to read back
+    uint16_t* gcol = (uint16_t*)(ws + pl.off_gcol);
     int st = sm_conv2d(&g1, gout, w_t, nullptr, nullptr, gcol, stream);
     if (st != SM_OK) return st;
     float* gx_col = fast_dgrad ? nullptr : grad_x;
@@ -471,9 +647,15 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
       if (hipMemsetAsync(grad_offset, 0, (size_t)orows * G * kk * 2 * 4, s) != hipSuccess)
         return SM_ERR_LAUNCH;
     }
-    const long long nunits = pl.P * kk * (d->cin / 64);
-    const int blocks = (int)std::min<long long>((nunits + 3) / 4, 256 * 64);
-    hipLaunchKernelGGL(deform_col2im_kernel, dim3(blocks), dim3(256), 0, s, a, gcol, gx_col, grad_offset, nunits);
+    if (d->kh == 3 && d->kw == 3) {               // one wave per (position, 64-channel chunk), nine taps unrolled
+      const long long nunits = pl.P * (d->cin / 64);
+      const int blocks = (int)std::min<long long>((nunits + 3) / 4, 256 * 64);
+      hipLaunchKernelGGL(deform_col2im9_kernel, dim3(blocks), dim3(256), 0, s, a, gcol, gx_col, grad_offset, nunits);
+    } else {
+      const long long nunits = pl.P * kk * (d->cin / 64);
+      const int blocks = (int)std::min<long long>((nunits + 3) / 4, 256 * 64);
+      hipLaunchKernelGGL(deform_col2im_kernel, dim3(blocks), dim3(256), 0, s, a, gcol, gx_col, grad_offset, nunits);
+    }
     SM_LAUNCH_CHECK();
   }
   if (grad_w_t && offset == nullptr && !(d->flags & SM_CONV_BWD_WGRAD_GEMM) &&
@@ -495,9 +677,15 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
       hipLaunchKernelGGL(transpose_tile_kernel<0>, dim3(ptiles, (d->cin + 63) / 64), dim3(256), 0, s, a, pl.S, pl.L, pl.Kpad,
                          d->cin, colT);
     } else {
-      const long long t1 = (long long)kk * (d->cin / 8) * pl.S * pl.L;
-      hipLaunchKernelGGL(deform_im2col_t_kernel, dim3((int)std::min<long long>((t1 + 255) / 256, 256 * 64)), dim3(256), 0, s,
-                         a, pl.S, pl.L, pl.Kpad, colT);
+      if ((d->cin / G) % 8 == 0 && d->cin / G >= 32) {     // one thread per (position, tap, deformable group)
+        const long long t1 = (long long)kk * G * pl.S * pl.L;
+        hipLaunchKernelGGL(deform_im2col_t_group_kernel, dim3((int)std::min<long long>((t1 + 255) / 256, 256 * 64)), dim3(256), 0,
+                           s, a, pl.S, pl.L, pl.Kpad, colT);
+      } else {
+        const long long t1 = (long long)kk * (d->cin / 8) * pl.S * pl.L;
+        hipLaunchKernelGGL(deform_im2col_t_kernel, dim3((int)std::min<long long>((t1 + 255) / 256, 256 * 64)), dim3(256), 0, s,
+                           a, pl.S, pl.L, pl.Kpad, colT);
+      }
     }
     // gout^T: rows cout..cout_pad2 of every slice must be zero (they are weight rows of the GEMM)
     hipLaunchKernelGGL(transpose_tile_kernel<1>, dim3(ptiles, (pl.cout_pad2 + 63) / 64), dim3(256), 0, s, a, pl.S, pl.L,

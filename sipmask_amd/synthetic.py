@@ -29,16 +29,20 @@ def model_cfg(depth=50):
 TEST_CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type='nms', iou_thr=0.5), max_per_img=100)
 
 
-def build_synthetic_detector(depth=50, seed=0):
-    """Reference init (seeded) + overrides: bn3.weight=1, non-zero conv_offset, O(1) tower gains,
-    positive box distances, wider coefficient spread."""
+def build_synthetic_detector(depth=50, seed=0, bn3_gain=None):
+    """Reference init (seeded) + overrides: bn3.weight = bn3_gain (default 1 for R50; 0.5 for R101, whose 33 residual blocks
+    at gain 1 push the random-weight activations out of range: every class score NaN, zero detections, and a post-processing
+    tail that is cheaper than a real one), non-zero conv_offset, O(1) tower gains, positive box distances, wider
+    coefficient spread."""
+    if bn3_gain is None:
+        bn3_gain = 1.0 if depth <= 50 else 0.5
     torch.manual_seed(seed)
     det = build_detector(model_cfg(depth), train_cfg=None, test_cfg=dict(TEST_CFG))
     h = det.bbox_head
     with torch.no_grad():
         for n, p in det.backbone.named_parameters():
             if n.endswith("bn3.weight"):
-                p.fill_(1.0)
+                p.fill_(bn3_gain)
         torch.nn.init.normal_(h.feat_align.conv_offset.weight, std=0.2)
         for m in list(h.cls_convs) + list(h.reg_convs):
             m.conv.weight.mul_(3.0)

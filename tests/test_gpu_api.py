@@ -690,12 +690,15 @@ def test_detector_forward_train_vs_oracle():
     # HIP vs the same-operand-rounding torch pipeline: same scale as emu vs f32.  The row-tensor graph additionally STORES
     # activations and back-propagated gradients as bf16 (the emulation keeps them f32 between the convs and sums the two
     # gradient branches of every residual block in f32), which the deepest checked weight feels most: layer2.0.conv1
-    # measured cosine 0.925 / 0.40 against the emulation (0.93 / 0.39 with f32 storage)
-    compare(trunk, emu, 0.9, 0.45)
+    # measured cosine 0.925 / 0.40 against the emulation (0.93 / 0.39 with f32 storage) -- and, one run in six, 0.8996 / 0.462:
+    # the backward's split-K sums are float atomics, their order varies, and one flipped bf16 rounding upstream of a ReLU
+    # gate of this chaotic trunk moves this one tensor between two outcomes (round 3, six back-to-back runs).  The bound is a
+    # wiring check (a mis-wired layer gives cosine ~ 0), so it leaves that room.
+    compare(trunk, emu, 0.85, 0.55)
     # shallow part: tight (0.05: the stride-2 P6 conv's weight gradient sums only 2 x 13 x 21 positions of a gradient that
     # the row graph stores as bf16 after adding the P7 branch -- measured 0.034; every other neck tensor < 0.02)
     compare([n for n in trunk if n.startswith("neck.")], emu, 0.999, 0.05)
-    compare(trunk, osd, 0.9, 0.45)            # vs the f32 oracle: wiring only
+    compare(trunk, osd, 0.85, 0.55)           # vs the f32 oracle: wiring only
     det.zero_grad()
     # ---- (2) the full training graph
     osd = fresh_osd()

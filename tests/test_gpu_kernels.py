@@ -575,8 +575,10 @@ def test_mask_rects_cover_assembled_masks():
 def test_deform_conv_backward_vs_oracle(cfg):
     """DeformConvFunction.backward (sm_deform_conv2d_bwd) against the oracle restatement of the reference's
     col2im / col2im_coord / parameter-gradient kernels on bf16-representable x, weight, grad_output.
-    Tolerances (relative to the tensor's max): grad_input / grad_offset 2e-3 (f32 accumulation order + atomics),
-    grad_weight 1e-2 (the sampled columns are rounded to bf16 before the MFMA, as in the forward)."""
+    Tolerances (relative to the tensor's max): grad_input / grad_offset 6e-3 (the grad columns W^T gout are stored as bf16
+    rows, like every other gradient of the row-tensor training graph -- 2^-9 per column element -- then f32 accumulation:
+    LDS-window / HBM float atomics in any order; measured 2.1e-3), grad_weight 1e-2 (the sampled columns are rounded to
+    bf16 before the MFMA, as in the forward)."""
     from sipmask_amd import ops as P
     dev = _dev()
     B, C, Hh, Ww, Co, G, dil = cfg
@@ -595,8 +597,8 @@ def test_deform_conv_backward_vs_oracle(cfg):
 
     def rel(a, b):
         return float((a.cpu() - b).abs().max() / b.abs().max())
-    assert rel(xd.grad, rx) < 2e-3, rel(xd.grad, rx)
-    assert rel(od.grad, roff) < 2e-3, rel(od.grad, roff)
+    assert rel(xd.grad, rx) < 6e-3, rel(xd.grad, rx)
+    assert rel(od.grad, roff) < 6e-3, rel(od.grad, roff)
     assert rel(wd.grad, rw) < 1e-2, rel(wd.grad, rw)
     assert float(od.grad[:, :, -1, -1].abs().max()) == 0.0
     # only the weight gradient requested (backward_parameters alone, deform_conv.py:86-94)
@@ -635,7 +637,8 @@ def test_conv2d_backward_vs_torch(cfg):
 
     def rel(a, b):
         return float((a.cpu() - b).abs().max() / b.abs().max())
-    assert rel(xd.grad, x.grad) < 2e-3, rel(xd.grad, x.grad)
+    # strided convs take the grad-column path, whose columns are bf16 rows (2^-9 per element; measured 2.1e-3)
+    assert rel(xd.grad, x.grad) < (6e-3 if s_ != 1 else 2e-3), rel(xd.grad, x.grad)
     assert rel(bd.grad, bias.grad) < 2e-3, rel(bd.grad, bias.grad)
     assert rel(wd.grad, w.grad) < 1e-2, rel(wd.grad, w.grad)
 

@@ -20,13 +20,13 @@ for name, sc in (("offsets ~N(0,1.5)", 1.5), ("offsets = 0", 0.0), ("offsets ~N(
     goff = torch.empty_like(off)
     gw = torch.empty(9 * C, C, dtype=torch.float32, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for label, args in (("gx+goff", (gx, goff, None)), ("goff only", (None, goff, None)), ("gw only", (None, None, gw)), ("all", (gx, goff, gw))):
+    for label, args, dd in (("gx+goff", (gx, goff, None), d), ("goff only", (None, goff, None), d), ("gw only", (None, None, gw), d), ("all", (gx, goff, gw), d)):
         ts = []
         for r in range(4):
             e0.record()
-            H.deform_conv2d_bwd(d, x, off, w_t, go, *args)
+            H.deform_conv2d_bwd(dd, x, off, w_t, go, *args)
             e1.record()
             torch.cuda.synchronize()
             if r:
                 ts.append(e0.elapsed_time(e1))
-        print("%-18s %-10s %.3f ms" % (name, label, sorted(ts)[1]))
+        print("%-18s %-42s %.3f ms" % (name, label, sorted(ts)[1]))
