@@ -142,8 +142,11 @@ def test_conv_launch_plan_rejects_bad_descriptors():
             H.conv_plan(H.make_conv_desc(**dict(ok, **bad)))
     # fused GN statistics go with f32 output as well (the x3 plan normalises f32 rows)
     assert H.conv_plan(H.make_conv_desc(**dict(ok, flags=_lib.SM_CONV_OUT_F32)), with_gn_stats=True)["blocks"] > 0
-    with pytest.raises(RuntimeError):                                              # deformable conv is stride 1
-        H.conv_plan(H.make_conv_desc(**dict(ok, stride=2, out_sizes=[(5, 6)], deform_groups=1)), deformable=True)
+    # round 3: deformable convs take any stride (the offset rows are output rows); what stays rejected is a group count
+    # that does not divide the channels into multiples of 8
+    assert H.conv_plan(H.make_conv_desc(**dict(ok, stride=2, out_sizes=[(5, 6)], deform_groups=1)), deformable=True)["blocks"] > 0
+    with pytest.raises(RuntimeError):
+        H.conv_plan(H.make_conv_desc(**dict(ok, deform_groups=3)), deformable=True)
 
 
 def test_registry_contract():
