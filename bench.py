@@ -342,7 +342,9 @@ def run_inference(args, rank, world, dev):
     if not os.path.exists(pmc_file):
         pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_tower_conv.json")
     pmc = json.load(open(pmc_file)) if os.path.exists(pmc_file) else None
-    if pmc and pmc.get("plan_batch") == eng.batch and pmc.get("launch") == towers[0].name and not f32:
+    if pmc and pmc.get("plan_batch") == eng.batch and pmc.get("launch") == towers[0].name and args.precision == "bf16":
+        # (the PMC passes were taken on the bf16 plan's launch; the split-precision launch reads three 16-bit planes of
+        # every input channel and writes f32 -- its traffic was not collected: null)
         traffic = round(pmc["hbm_bytes_per_launch"] / 1e6, 1)
         traffic_src = "profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), MB per launch" % os.path.basename(pmc_file)
     if args.breakdown and rank == 0:

@@ -81,6 +81,7 @@ for src, dst in (("step_breakdown.txt", "r03_step_breakdown_hip_events.txt"),
                  ("kernel_stats_step.csv", "r03_rocprofv3_kernel_stats_step.csv"),
                  ("kernel_stats_step_x3.csv", "r03_rocprofv3_kernel_stats_step_head_x3.csv"),
                  ("kernel_stats_tower_only.csv", "r03_rocprofv3_kernel_stats_tower_only.csv"),
+                 ("kernel_stats_train_step.csv", "r03_rocprofv3_kernel_stats_train_step.csv"),
                  ("kernel_stats_tower_only_x3.csv", "r03_rocprofv3_kernel_stats_tower_only_head_x3.csv"),
                  ("parity_r50_b4_bf16.json", "r03_parity_r50_b4_bf16_subbatch.json"),
                  ("parity_r50_b4_x3.json", "r03_parity_r50_b4_head_x3_subbatch.json"),
