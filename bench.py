@@ -560,7 +560,8 @@ def run_vis(args, rank, world, dev):
         k = nstep[0] % NSETS
         nstep[0] += 1
         # whole videos, in order; tracker reset by is_first of frame 0
-        for res in det.clip_test_many([clips_dev[(k, vi)] for vi in mine], [metas] * len(mine), encode=False, graph=use_graph):
+        for res in det.clip_test_many([clips_dev[(k, vi)] for vi in mine], [metas] * len(mine), encode=False, graph=use_graph,
+                                      slots=int(os.environ.get("SIPMASK_VIS_SLOTS", "2"))):
             counts.append(sum(len(b) for b, _ in res))
 
     for _ in range(args.warmup):

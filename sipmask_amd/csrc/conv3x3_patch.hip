@@ -80,19 +80,23 @@ __device__ __attribute__((aligned(16))) const unsigned int g_zero16p[4] = {0u, 0
 
 constexpr int PT_BCO = 256, PT_BPOS = 256, PT_THREADS = 512;
 constexpr int PT_WSTAGE = PT_BCO * 128;           // one weight stage: 256 cout rows x 128 B (2 taps x 32 channels)
-constexpr int PT_MAXPP = 6;                       // patch DMA pieces per wave (<= 768 patch rows)
 
 // One tile: 256 couts x (WPOS * TPOS * 32) positions on 8 waves laid out WCO (cout) x WPOS (position), each wave
 // TCO x TPOS MFMA tiles of 32 x 32.  <2,4,4,2> is the 256-position tile; <4,2,2,3> / <4,2,2,2> are the 192- / 128-
 // position tiles that finish a launch whose last round of 256-tiles would leave most CUs idle.
 template <int WCO, int WPOS, int TCO, int TPOS, int VAR>
 __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, const int tlin, unsigned char* const smem) {
-  static_assert(WCO * WPOS == 8 && WCO * TCO * 32 == PT_BCO, "8 waves, 256 couts");
+  constexpr int NWV = WCO * WPOS;               // waves of the block: 8 (shipped), 4 in the one-wave-per-SIMD experiment
+  constexpr int MAXPP = 48 / NWV;               // patch DMA pieces per wave (<= 768 patch rows = 48 pieces)
+  constexpr int WPW = 32 / NWV;                 // weight DMA pieces per wave per stage
+  constexpr int PPS = MAXPP / 3;                // patch pieces per wave per stage (a chunk lands over three stages)
+  static_assert((NWV == 8 || NWV == 4) && WCO * TCO * 32 == PT_BCO, "8 or 4 waves, 256 couts");
   // VAR bits: 1 = software-pipelined stage, 2 = staggered DMA issue (waves 4-7 issue theirs between the two taps of a stage,
   // so the two waves of a SIMD are never both stalled in the LDS-DMA issue); 4 / 8 = ABLATIONS for the micro-benchmark
   // (no DMA / no MFMA in the main loop: wrong results by construction, never used by the library's own launches)
   constexpr bool PIPE = (VAR & 1) != 0, STAGGER = (VAR & 2) != 0, NO_DMA = (VAR & 4) != 0, NO_MFMA = (VAR & 8) != 0;
   constexpr bool PINGPONG = (VAR & 16) != 0;
+  static_assert(!PINGPONG || WCO * WPOS == 8, "the ping-pong schedule pairs waves w and w + 4");
   constexpr int BPOS = WPOS * TPOS * 32;
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -126,10 +130,10 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   const int npieces = (BPOS + 2 * Wp + 2 + 15) >> 4;
   const unsigned long long zero_page = (unsigned long long)g_zero16p;
   // patch: this wave owns pieces wave, wave + 8, ...; per piece the lane's source offset (elements) or -1 (zero page)
-  int poff[PT_MAXPP];
+  int poff[MAXPP];
 #pragma unroll
-  for (int i = 0; i < PT_MAXPP; ++i) {
-    const int piece = wave + 8 * i;
+  for (int i = 0; i < MAXPP; ++i) {
+    const int piece = wave + NWV * i;
     const int r = piece * 16 + lrow;                           // patch row
     const int qi = q0 - Wp - 1 + r;                            // padded-flat input index
     const int ih = qi >= 0 ? qi / Wp : -1;
@@ -146,25 +150,25 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   // LDS stage = [256 cout rows][128 B]: 16-byte slot (tap * 4 + K chunk) ^ ((row >> 1) & 7) -- the 16 lanes a
   // ds_read_b128 services together (MI355X_MICROARCH.md, LDS) then cover all 64 banks once.
   // A stage = 32 pieces; this wave owns pieces wave*4 .. wave*4+3.
-  const uint16_t* wsrc[4];
+  const uint16_t* wsrc[WPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+  for (int i = 0; i < WPW; ++i) {
+    const int row = (wave * WPW + i) * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     wsrc[i] = a.w + grp * a.w_gstride + (long long)(nt * PT_BCO + row) * a.Kp + chunk * 8;
   }
   auto dma_w = [&](int stage, int buf) {            // weight stage `stage` (K steps 2*stage, 2*stage+1) -> Wb[buf]
     unsigned char* dst = Wb0 + buf * PT_WSTAGE;
-    sfor<4>([&](auto I) {
+    sfor<WPW>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      const int piece = wave * 4 + i;
+      const int piece = wave * WPW + i;
       __builtin_amdgcn_global_load_lds((glb_void*)(wsrc[i] + (long long)stage * 64),
                                        (lds_void*)(dst + piece * 1024), 16, 0, 0);
     });
   };
   auto dma_patch_piece = [&](auto I, int chunk_c, int buf) {     // piece I of this wave, channel chunk c -> Pb[buf]
     constexpr int i = decltype(I)::value;
-    const int piece = wave + 8 * i;
+    const int piece = wave + NWV * i;
     if (piece < npieces) {                                       // wave-uniform
       const unsigned long long pm = poff[i] >= 0 ? ~0ull : 0ull;
       const unsigned long long src = ((unsigned long long)(xbase + poff[i] + chunk_c * 32) & pm) | (zero_page & ~pm);
@@ -220,7 +224,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   // during stages 5-7 (after tap 8, the last reader of Pb[0], finished in stage 4); weight stage s+1 during stage s.
   const int npair = a.nc >> 1;
   const int nstage = npair * 9;
-  sfor<PT_MAXPP>([&](auto I) { dma_patch_piece(I, 0, 0); });
+  sfor<MAXPP>([&](auto I) { dma_patch_piece(I, 0, 0); });
   dma_w(0, 0);
   __syncthreads();
   if constexpr (PINGPONG) {
@@ -334,12 +338,10 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
         if constexpr (!NO_DMA) {
           if (st + 1 < nstage) dma_w(st + 1, (st + 1) & 1);
           if constexpr (sp < 3) {                                    // patch of the pair's second chunk
-            dma_patch_piece(std::integral_constant<int, 2 * sp>{}, c0 + 1, 1);
-            dma_patch_piece(std::integral_constant<int, 2 * sp + 1>{}, c0 + 1, 1);
+            sfor<PPS>([&](auto J) { dma_patch_piece(std::integral_constant<int, PPS * sp + decltype(J)::value>{}, c0 + 1, 1); });
           } else if constexpr (sp >= 5 && sp < 8) {                  // patch of the NEXT pair's first chunk
             if (cp + 1 < npair) {
-              dma_patch_piece(std::integral_constant<int, 2 * (sp - 5)>{}, c0 + 2, 0);
-              dma_patch_piece(std::integral_constant<int, 2 * (sp - 5) + 1>{}, c0 + 2, 0);
+              sfor<PPS>([&](auto J) { dma_patch_piece(std::integral_constant<int, PPS * (sp - 5) + decltype(J)::value>{}, c0 + 2, 0); });
             }
           }
         }
@@ -543,6 +545,17 @@ __global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_kernel(const Patc
   }
 }
 
+#ifdef SM_EXPERIMENTS
+// EXPERIMENT (round 3): the same 256 x 256 tile on FOUR waves, 128 couts x 128 positions each (16 accumulator tiles = 256
+// registers, beyond the 256 architectural VGPRs: one wave per SIMD, accumulators in AGPRs), 8 fragment reads per 16 MFMAs
+// instead of 6 per 8.  Uniform launches only.
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void conv3x3_patch_kernel_w4(const PatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  patch_tile<2, 2, 4, 4, VAR>(a, 0, xcd_tile(blockIdx.x, a.nblk[0]), smem);
+}
+#endif
+
 int patch_check(const sm_conv_desc* d) {
   if (!d) return SM_ERR_BAD_ARG;
   if (d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return SM_ERR_BAD_SHAPE;
@@ -554,7 +567,7 @@ int patch_check(const sm_conv_desc* d) {
   if (d->w_batch_stride != 0) return SM_ERR_UNSUPPORTED;
   for (int l = 0; l < d->nlev; ++l) {
     if (d->in_h[l] != d->out_h[l] || d->in_w[l] != d->out_w[l] || d->in_h[l] < 1 || d->in_w[l] < 1) return SM_ERR_BAD_SHAPE;
-    if (PT_BPOS + 2 * (d->in_w[l] + 2) + 2 > 16 * 8 * PT_MAXPP) return SM_ERR_UNSUPPORTED;   // patch rows the loader covers
+    if (PT_BPOS + 2 * (d->in_w[l] + 2) + 2 > 16 * 48) return SM_ERR_UNSUPPORTED;   // patch rows the loader covers (48 pieces)
     if ((long long)d->in_h[l] * d->in_w[l] * d->in_cstride >= (1ll << 31)) return SM_ERR_UNSUPPORTED;   // 32-bit patch offsets
   }
   return SM_OK;
@@ -759,7 +772,7 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   const int var = ((d->flags & SM_CONV_DBG_PATCH_PIPE) ? 1 : 0) | ((d->flags & SM_CONV_DBG_PATCH_STAGGER) ? 2 : 0) |
                   ((d->flags & SM_CONV_DBG_PATCH_NO_DMA) ? 4 : 0) | ((d->flags & SM_CONV_DBG_PATCH_NO_MFMA) ? 8 : 0) |
                   ((d->flags & SM_CONV_DBG_PATCH_PINGPONG) ? 16 : 0);
-  auto launch = [&](auto kern) -> int {
+  auto launch = [&](auto kern, int threads = PT_THREADS) -> int {
     // the attribute is per kernel, not per launch: set it once to the most any launch can ask for (the call is a driver
     // round trip -- and two orders of magnitude slower under rocprofv3's API interception)
     static const void* seen[64];                         // every instantiation has the same pointer type: key by address
@@ -777,7 +790,7 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
         seen_dev[nseen++] = dev;
       }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(PT_THREADS), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(threads), lds, s, a);
     return SM_OK;
   };
   int lrc = SM_ERR_UNSUPPORTED;
@@ -785,6 +798,11 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   case V:                                                                                                           \
     lrc = ps.small == 128 ? launch(conv3x3_patch_kernel<128, V>) : launch(conv3x3_patch_kernel<192, V>);            \
     break;
+#ifdef SM_EXPERIMENTS
+  if ((d->flags & SM_CONV_DBG_PATCH_W4) && nb1 == 0 && (var == 0 || var == 1)) {
+    lrc = var == 0 ? launch(conv3x3_patch_kernel_w4<0>, 256) : launch(conv3x3_patch_kernel_w4<1>, 256);
+  } else
+#endif
   switch (var) {
     PT_CASE(0)
 #ifdef SM_EXPERIMENTS

@@ -19,6 +19,7 @@
 #define SM_CONV_DBG_PATCH_NO_MFMA 0x00000100u  // ABLATION (wrong results): no MFMA / fragment reads in the main loop
 #define SM_CONV_DBG_PATCH_PINGPONG 0x00000080u // sm_conv3x3_patch: ping-pong schedule of two wave groups
 #define SM_CONV_DBG_WARP_SPEC 0x02000000u      // 8-wave producer/consumer variant of the 64-wide-K kernel
+#define SM_CONV_DBG_PATCH_W4 0x10000000u       // sm_conv3x3_patch (uniform launches): 4 waves x (128 couts x 128 positions), accumulators in AGPRs
 #else
 #define SM_CONV_DBG_LINEAR_TILES 0u
 #define SM_CONV_DBG_REG_STAGING 0u
@@ -35,4 +36,5 @@
 #define SM_CONV_DBG_PATCH_NO_MFMA 0u
 #define SM_CONV_DBG_PATCH_PINGPONG 0u
 #define SM_CONV_DBG_WARP_SPEC 0u
+#define SM_CONV_DBG_PATCH_W4 0u
 #endif

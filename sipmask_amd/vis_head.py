@@ -290,7 +290,7 @@ class SipMaskVIS(SipMask):
             out.append((bbox_results, segm_results))
         return out
 
-    def clip_test_many(self, clips, clip_metas, rescale=False, encode=True, graph=True):
+    def clip_test_many(self, clips, clip_metas, rescale=False, encode=True, graph=True, slots=2):
         """Several clips, pipelined: clip_test spends a fifth of a clip's time on the host (one synchronising fetch, the
         result dictionaries) while the device idles, and the device part of a clip ends in a latency-bound tail.  Here clip
         i+1 is enqueued BEFORE the results of clip i are fetched: two plans of the clip shape (slots, each with its own
@@ -309,27 +309,29 @@ class SipMaskVIS(SipMask):
             if tuple(c.shape) != tuple(clips[0].shape) or len(ms) != T:
                 raise ValueError("clip_test_many: the clips of one call share one shape")
         lanes = 2 if (T >= 4 and T % 2 == 0) else 1
-        nslot = min(2, n)
+        nslot = max(1, min(int(slots), n))
         engs = [self.prepare(T, hw, tuple(m0['img_shape']), m0.get('scale_factor', 1.0), bool(rescale), lanes=lanes, slot=k)
                 for k in range(nslot)]
         pipe = getattr(self, "_clip_pipe", None)
         if pipe is None or pipe["dev"] != dev:
-            pipe = self._clip_pipe = dict(dev=dev, streams=[torch.cuda.Stream(device=dev) for _ in range(2)],
+            pipe = self._clip_pipe = dict(dev=dev, streams=[],
                                           track=torch.cuda.Stream(device=dev), host={})
+        while len(pipe["streams"]) < nslot:
+            pipe["streams"].append(torch.cuda.Stream(device=dev))
         main = torch.cuda.current_stream()
         if graph:
             for e in engs:                                         # capture on the caller's stream, before the pipeline starts
                 if getattr(e, "_clip_graph", None) is None:
                     self._run_plan(e, clips[0], True)
         mx = engs[0].max_num
-        hkey = (T, mx)
+        hkey = (T, mx, nslot)
         host = pipe["host"].get(hkey)
         if host is None:                                           # pinned landing buffers, one set per slot
             host = pipe["host"][hkey] = [dict(nd=torch.empty(T, dtype=torch.int32).pin_memory(),
                                               ids=torch.empty(T, mx, dtype=torch.int32).pin_memory(),
                                               det=torch.empty(T, mx, 5, dtype=torch.float32).pin_memory(),
-                                              lab=torch.empty(T, mx, dtype=torch.int64).pin_memory()) for _ in range(2)]
-        done, freed, out = [None] * n, [None] * 2, [None] * n
+                                              lab=torch.empty(T, mx, dtype=torch.int64).pin_memory()) for _ in range(nslot)]
+        done, freed, out = [None] * n, [None] * nslot, [None] * n
 
         def launch(i):
             k = i % nslot
@@ -369,7 +371,7 @@ class SipMaskVIS(SipMask):
             launch(i)
         for i in range(max(0, n - nslot), n):
             finish(i)
-        for st in pipe["streams"] + [pipe["track"]]:
+        for st in pipe["streams"][:nslot] + [pipe["track"]]:
             main.wait_stream(st)
         return out
 

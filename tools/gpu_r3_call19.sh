@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out; cd $GRAFT_REPO_ROOT
+timeout 300 python tools/patch_w4_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3c19_w4.txt
+
+
