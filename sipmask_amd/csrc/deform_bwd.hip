@@ -316,12 +316,20 @@ __global__ __launch_bounds__(256) void deform_im2col_t_group_kernel(const DBArgs
   const int kk = a.kh * a.kw;
   const int cpg = a.cin / a.G;                   // multiple of 8
   const long long SL = (long long)S * L;
-  const long long total = (long long)kk * a.G * SL;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-    const long long gp = t % SL;
+  // one block = 256 consecutive positions x one (tap, group); XCD-aware order (workgroups go round-robin to the 8 XCDs): the
+  // kk * G blocks of a position chunk read the same x rows (shifted by the taps) and run consecutively on XCD chunk % 8
+  const int per_chunk = kk * a.G;
+  const long long nchunk = (SL + 255) / 256;
+  {
+    const int xcd = blockIdx.x & 7;
+    const long long kq = blockIdx.x >> 3;
+    const long long chunk = (kq / per_chunk) * 8 + xcd;
+    const int rq = (int)(kq % per_chunk);
+    const long long gp = chunk * 256 + threadIdx.x;
+    if (chunk >= nchunk || gp >= SL) return;
     const int sl = (int)(gp / L), pl = (int)(gp - (long long)sl * L);
-    const int g = (int)((t / SL) % a.G);
-    const int tap = (int)(t / (SL * a.G));
+    const int g = rq % a.G;
+    const int tap = rq / a.G;
     uint16_t* o = colT + ((long long)sl * Kpad + (long long)tap * a.cin + g * cpg) * L + pl;
     bool live = gp < a.P;
     Pos ps;
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(256) void deform_im2col_t_group_kernel(const DBArgs
     }
     if (!live) {                                  // positions beyond P and samples outside the image: zero columns
       for (int c = 0; c < cpg; ++c) o[(long long)c * L] = 0;
-      continue;
+      return;
     }
     const int H = a.in_h[ps.l], W = a.in_w[ps.l];
     const long long base = a.in_row0[ps.l] + (long long)ps.b * H * W;
@@ -678,9 +686,10 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
                          d->cin, colT);
     } else {
       if ((d->cin / G) % 8 == 0 && d->cin / G >= 32) {     // one thread per (position, tap, deformable group)
-        const long long t1 = (long long)kk * G * pl.S * pl.L;
-        hipLaunchKernelGGL(deform_im2col_t_group_kernel, dim3((int)std::min<long long>((t1 + 255) / 256, 256 * 64)), dim3(256), 0,
-                           s, a, pl.S, pl.L, pl.Kpad, colT);
+        const long long nchunk = ((long long)pl.S * pl.L + 255) / 256;
+        const long long nblk = 8 * ((nchunk + 7) / 8) * kk * G;
+        if (nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
+        hipLaunchKernelGGL(deform_im2col_t_group_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a, pl.S, pl.L, pl.Kpad, colT);
       } else {
         const long long t1 = (long long)kk * (d->cin / 8) * pl.S * pl.L;
         hipLaunchKernelGGL(deform_im2col_t_kernel, dim3((int)std::min<long long>((t1 + 255) / 256, 256 * 64)), dim3(256), 0, s,
