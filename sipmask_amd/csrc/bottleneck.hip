@@ -64,7 +64,11 @@ __global__ __launch_bounds__(256, 3) void bottleneck_tail_kernel(const BtArgs a)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, khalf = lane >> 5;
-  const int m0 = blockIdx.x * BT_BPOS;
+  // XCD-contiguous tile ranges (workgroups go round-robin to the 8 XCDs): the tiles of three neighbouring image rows read the
+  // same conv2 input rows, and as neighbours in one XCD's range they find them in that L2
+  const int nblk_ = (int)gridDim.x, xcd_ = blockIdx.x & 7, xq_ = nblk_ >> 3, xr_ = nblk_ & 7;
+  const int tile_ = (xcd_ < xr_ ? xcd_ * (xq_ + 1) : xr_ * (xq_ + 1) + (xcd_ - xr_) * xq_) + (int)(blockIdx.x >> 3);
+  const int m0 = tile_ * BT_BPOS;
   const int H = a.H, W = a.W, HW = H * W, M = a.M;
 
   // ---- weight slices of the 1x1 convs: 16 KB = 128 flat rows of 128 B, lane L of a wave instruction -> row L>>3,
