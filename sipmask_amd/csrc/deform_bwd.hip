@@ -619,6 +619,7 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
     g0.in_cstride = d->out_cstride;
     g0.out_cstride = d->cin;
     g0.flags = (d->flags & SM_CONV_BWD_GX_BF16) ? 0u : SM_CONV_OUT_F32;      // bf16 rows for the row-tensor training graph
+    g0.flags |= d->flags & (SM_CONV_DBG_TILE256 | SM_CONV_DBG_HAND_PLACED);  // the caller's tile choice for the dX conv (same results)
     const int st = sm_conv2d(&g0, gout, w_dgrad, nullptr, nullptr, grad_x, stream);
     if (st != SM_OK) return st;
   }
