@@ -33,7 +33,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICRO
 MFMA_F32_PEAK_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (= the f32 vector rate), same guide
 IMG_H, IMG_W = 800, 1344           # 800x1333 padded to a multiple of 32 (cfg Pad size_divisor=32)
 VIS_H, VIS_W, VIS_T = 384, 640, 8  # 640x360 frames padded to 32 (V/ config size_divisor=32), frames per clip
-VIS_CLIPS = 4                        # clips per GPU per step of --config vis (pipelined: SipMaskVIS.clip_test_many)
+VIS_CLIPS = int(os.environ.get("SIPMASK_VIS_CLIPS", "8"))   # clips per GPU per step of --config vis (pipelined: SipMaskVIS.clip_test_many)
 STUB = os.environ.get("SIPMASK_BENCH_STUB", "0") == "1"   # CPU test hook: gloo + a sleeping step, no GPU work
 
 
