@@ -568,12 +568,12 @@ def run_vis(args, rank, world, dev):
         step()
     elapsed = timed_steps(step, args.steps, sync_fn=torch.cuda.synchronize, device=dev)
     frames = clips_per_step * VIS_T * args.steps
-    plan = det.prepare(VIS_T, (VIS_H, VIS_W), shape, 1.0, False, lanes=2)
+    plan = det.prepare(VIS_T, (VIS_H, VIS_W), shape, 1.0, False, lanes=int(os.environ.get("SIPMASK_VIS_LANES", "1")))   # slot 0 of the timed path
     flops = plan.total_conv_flops() / VIS_T
     ms_frame = elapsed / (VIS_CLIPS * VIS_T * args.steps) * 1e3
-    # ---- dominant kernel, timed live with HIP events (eager launches of ONE 4-frame chain of the plan): the grouped
-    # tower launch (cls + reg 3x3 256 -> 256 of one depth over the 5 levels of 4 frames)
-    eng = plan.engines[0]
+    # ---- dominant kernel, timed live with HIP events (eager launches of one chain of the timed plan): the grouped
+    # tower launch (cls + reg 3x3 256 -> 256 of one depth over the 5 levels of the chain's frames)
+    eng = plan.engines[0] if hasattr(plan, "engines") else plan
     eng.img = clips_dev[(0, mine[0])][:eng.batch].contiguous()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in eng.steps]
     acc = [0.0] * len(eng.steps)
@@ -600,7 +600,7 @@ def run_vis(args, rank, world, dev):
         "data": "synthetic (randn frames, %d clip sets resident on the device alternated step by step; reference-init random "
                 "weights + calibration overrides)" % NSETS,
         "config": {"workload": "SipMask-VIS R50, clips of %d frames 3x%dx%d (640x360 padded), %d clips per GPU per step; the "
-                               "frames of a clip run as one batch (two 4-frame launch chains), identity matching in frame "
+                               "frames of a clip run as one batch (one 8-frame launch chain, two clips in flight), identity matching in frame "
                                "order by one kernel per clip (device tracker state); the clips of a step are pipelined (clip "
                                "i+1 is enqueued before the results of clip i are fetched)" % (VIS_T, VIS_H, VIS_W, VIS_CLIPS),
                    "global_batch": clips_per_step, "parallelism": "dp%d (sharded by video, no collective)" % world,
