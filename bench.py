@@ -40,6 +40,9 @@ STUB = os.environ.get("SIPMASK_BENCH_STUB", "0") == "1"   # CPU test hook: gloo 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--in-flight", type=int, default=2, dest="in_flight",
+                    help="inference configs: steps in flight (engine.PipelinedPlan); 1 = one step at a time, its batch cut into "
+                         "two concurrent half-batch chains (engine.SubBatchPlan)")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=("r50", "r101", "train", "vis"), default="r50")
@@ -228,9 +231,17 @@ def run_inference(args, rank, world, dev):
     # (engine.SubBatchPlan); --lanes 1 forces the single plan
     del eng
     torch.cuda.empty_cache()
-    plan = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=args.lanes or "auto")
+    pipelined = args.in_flight > 1 and not args.no_graph and not args.sub_graphs and not args.tower_only
+    plan = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=args.lanes or "auto",
+                       in_flight=args.in_flight if pipelined else 1)
+    if args.tower_only and args.in_flight > 1:       # the profiling aid times the kernel of the plan the pipelined default runs
+        plan = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=args.lanes or 1, slot=1)
+        plan.multi_stream = False
     subplans = getattr(plan, "engines", None)
-    eng = subplans[0] if subplans else plan          # the plan whose launches the breakdown / roofline below time
+    eng = plan.plans[0] if pipelined else (subplans[0] if subplans else plan)   # the plan whose launches the breakdown / roofline time
+    if pipelined:
+        subplans = getattr(eng, "engines", None)
+        eng = subplans[0] if subplans else eng
     eng_img = img[:eng.batch].contiguous()
     run_all = lambda: plan.run(img)
     if args.tower_only:      # the dominant kernel of the SAME plan the breakdown below times, alone and back to back
@@ -252,12 +263,17 @@ def run_inference(args, rank, world, dev):
         return None
 
     # ---- warm-up (eager), then optional graph capture
-    for _ in range(max(1, min(args.warmup, 2))):
-        run_all()
+    if pipelined:
+        plan.capture(img)
+    else:
+        for _ in range(max(1, min(args.warmup, 2))):
+            run_all()
     torch.cuda.synchronize()
     graph = None
     sub_graphs = False
-    if args.sub_graphs and not args.no_graph and hasattr(plan, "capture"):
+    if pipelined:
+        pass
+    elif args.sub_graphs and not args.no_graph and hasattr(plan, "capture"):
         plan.capture(img, multi_stream=(args.sub_graphs == 1))
         sub_graphs = True
     elif not args.no_graph:
@@ -282,6 +298,10 @@ def run_inference(args, rank, world, dev):
     nstep = [0]
 
     def step():
+        if pipelined:           # enqueue and return: the slot copies the batch into its own input on its own stream
+            plan.submit(imgs[nstep[0] % NSETS])
+            nstep[0] += 1
+            return
         if not free_run:        # (free-running chains still read the previous batch when the next step is enqueued)
             img.copy_(imgs[nstep[0] % NSETS])
         nstep[0] += 1
@@ -298,7 +318,7 @@ def run_inference(args, rank, world, dev):
         step()
     # barrier + torch.cuda.synchronize() on both sides, MAX over ranks (tested with gloo in tests/test_dist_shard.py)
     elapsed = timed_steps(step, args.steps, sync_fn=torch.cuda.synchronize, device=dev)
-    if free_run:
+    if free_run or pipelined:
         plan.join()
     ndet = gather_counts(plan.results()["ndet"].to(torch.int64), device=dev).cpu().tolist()
 
@@ -394,9 +414,13 @@ def run_inference(args, rank, world, dev):
                                                             ("bf16 backbone + FPN, split-precision (x3) head" if x3 else
                                                              "bf16 storage + f32 accumulate")),
                    "global_batch": B * world, "parallelism": "dp%d (batch shard, no collective)" % world,
-                   "launch": ("hipGraph replay" if graph is not None else "eager") +
+                   "launch": (("hipGraph replay, %d steps in flight: %d complete plans (own buffers, graph and stream) used round-robin, "
+                               "step k+1 is enqueued while step k runs (engine.PipelinedPlan); every step is one batch of %d images"
+                               % (plan.depth, plan.depth, B)) if pipelined else
+                              ("hipGraph replay" if graph is not None else "eager")) +
                              ("" if not subplans else ", %d sub-batch plans of %d images on concurrent streams"
                               % (len(subplans), eng.batch)),
+                   "steps_in_flight": plan.depth if pipelined else 1,
                    "detections_per_image": ndet,
                    # FeatureAlign's kernel, chosen by a one-off measurement on the first eager run (engine._tune_deform)
                    "deform_kernel": getattr(eng, "deform_choice", None)},
@@ -410,7 +434,8 @@ def run_inference(args, rank, world, dev):
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_inference(det, args.depth)
-        out["parity"] = parity_of_timed_plan(det, plan, imgs[(args.warmup + args.steps - 1) % len(imgs)], args.depth)
+        out["parity"] = parity_of_timed_plan(det, plan.plans[plan.last_slot] if pipelined else plan,
+                                             imgs[(args.warmup + args.steps - 1) % len(imgs)], args.depth)
     return out
 
 

@@ -136,5 +136,30 @@ __device__ __forceinline__ void gn_mean_rstd(const unsigned long long* st, doubl
   *rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// Zero-fill as a KERNEL.  hipMemsetAsync inside a captured hipGraph becomes a memset node, and on ROCm 7.2 the GroupNorm
+// statistics cleared that way came back from graph replays with a 16-byte garbage pattern (two pointer-like 64-bit values
+// alternating over the whole buffer, i.e. the fill kernel behind the node ran with a stale value argument) -- one replay in
+// three at small shapes, never in eager mode (round 3, tools/debug: replay of [conv + GN apply] on changing inputs).
+// Everything a launch plan clears per step goes through this instead.  `bytes` and `p` multiples of 4.
+static __global__ void sm_zero_u32_kernel(unsigned int* __restrict__ p, long long n, int vec) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {                                       // 16-byte aligned base: uint4 stores + a scalar tail
+    const long long n4 = n >> 2;
+    if (i < n4) reinterpret_cast<uint4*>(p)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < (n & 3)) p[(n4 << 2) + i] = 0u;
+  } else if (i < n) {
+    p[i] = 0u;
+  }
+}
+static inline hipError_t sm_zero_async(void* p, size_t bytes, hipStream_t s) {
+  if ((bytes & 3) != 0 || ((uintptr_t)p & 3) != 0) return hipErrorInvalidValue;
+  const long long n = (long long)(bytes >> 2);
+  if (n == 0) return hipSuccess;
+  const int vec = ((uintptr_t)p & 15) == 0 ? 1 : 0;
+  const long long nthr = vec ? ((n >> 2) > 4 ? (n >> 2) : 4) : n;
+  hipLaunchKernelGGL(sm_zero_u32_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (unsigned int*)p, n, vec);
+  return hipGetLastError();
+}
+
 static inline hipStream_t sm_hip_stream(sm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int sm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -762,7 +762,7 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   a.nblk[0] = (int)nb0;
   a.nblk[1] = (int)nb1;
   if (gn_stats != nullptr) {
-    if (hipMemsetAsync(gn_stats, 0, sizeof(unsigned long long) * 2 * a.ngroups * d->batch * d->nlev * (d->cout / 8), s) != hipSuccess)
+    if (sm_zero_async(gn_stats, sizeof(unsigned long long) * 2 * a.ngroups * d->batch * d->nlev * (d->cout / 8), s) != hipSuccess)
       return SM_ERR_LAUNCH;
   }
   const size_t lds = 2 * (size_t)PT_WSTAGE + 2 * (size_t)a.prow_cap * 64;

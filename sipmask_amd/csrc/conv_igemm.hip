@@ -1866,7 +1866,7 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   if (gn_stats != nullptr) {
     const int ng = d->ngroups > 1 ? d->ngroups : 1;
     if (ng > 1 && d->gn_group_stride != 2ll * d->batch * d->nlev * (d->cout / 8)) return SM_ERR_BAD_ARG;   // contiguous
-    if (hipMemsetAsync(gn_stats, 0, sizeof(unsigned long long) * 2 * d->batch * d->nlev * (d->cout / 8) * ng, stream) != hipSuccess)
+    if (sm_zero_async(gn_stats, sizeof(unsigned long long) * 2 * d->batch * d->nlev * (d->cout / 8) * ng, stream) != hipSuccess)
       return SM_ERR_LAUNCH;
   }
   if constexpr (DEFORM) {

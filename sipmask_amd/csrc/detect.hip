@@ -860,7 +860,7 @@ extern "C" int sm_pairs_select(const sm_det_desc* d, float pre_nms_thresh, const
   const long long total = (long long)a.batch * a.pos0[a.nlev] * a.C;
   int g = (int)((total + 255) / 256);
   if (g > 16384) g = 16384;
-  if (hipMemsetAsync(scores, 0, (size_t)a.batch * a.C * a.kmax * sizeof(float), s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (sm_zero_async(scores, (size_t)a.batch * a.C * a.kmax * sizeof(float), s) != hipSuccess) return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(pair_score_kernel, dim3(g), dim3(256), 0, s, cls, reg, keys, a, pre_nms_thresh);
   hipLaunchKernelGGL(pair_topk_kernel, dim3(a.nlev, a.batch), dim3(TK_THREADS), 0, s, keys, cand_pair, lvl_cnt, a);
   hipLaunchKernelGGL(pair_gather_kernel, dim3(a.kmax, a.batch), dim3(128), 0, s, cls, reg, cof, keys, cand_pair, lvl_cnt,
@@ -955,7 +955,7 @@ extern "C" int sm_nms(const float* dets, int n, float iou_thr, int64_t* keep, in
   if (!dets || !keep || !nkeep || n < 0) return SM_ERR_BAD_ARG;
   hipStream_t s = sm_hip_stream(stream);
   if (n == 0) {
-    if (hipMemsetAsync(nkeep, 0, sizeof(int32_t), s) != hipSuccess) return SM_ERR_LAUNCH;
+    if (sm_zero_async(nkeep, sizeof(int32_t), s) != hipSuccess) return SM_ERR_LAUNCH;
     return SM_OK;
   }
   const int P = next_pow2(n);

@@ -465,7 +465,7 @@ extern "C" int sm_groupnorm(const void* x, void* y, const float* gamma, const fl
   const int st = gn_fill_args(a, t, batch, nlev, hw, row0, channels, groups, eps, relu);
   if (st != SM_OK) return st;
   hipStream_t s = sm_hip_stream(stream);
-  if (hipMemsetAsync(stats, 0, sizeof(unsigned long long) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (sm_zero_async(stats, sizeof(unsigned long long) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(t, batch), dim3(256), 0, s, (const uint16_t*)x, stats, a);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(t, batch), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)y, gamma, beta,
                      stats, a);
@@ -583,7 +583,7 @@ extern "C" int sm_groupnorm_f32(const float* x, float* y, const float* gamma, co
   const int st = gn_fill_args(a, t, batch, nlev, hw, row0, channels, groups, eps, relu, 4);
   if (st != SM_OK) return st;
   hipStream_t s = sm_hip_stream(stream);
-  if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (sm_zero_async(stats, sizeof(double) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(gn_stats_f32_kernel, dim3(t, batch), dim3(256), 0, s, x, stats, a);
   hipLaunchKernelGGL(gn_apply_f32_kernel, dim3(t, batch), dim3(256), 0, s, x, y, gamma, beta, stats, a);
   SM_LAUNCH_CHECK();

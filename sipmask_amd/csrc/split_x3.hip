@@ -264,7 +264,7 @@ extern "C" int sm_gn_stats_f32_fix(const float* x, int64_t* stats, int batch, in
   const int rc = gnx_fill(a, t, batch, nlev, hw, row0, channels, groups, 0.f, 0);
   if (rc != SM_OK) return rc;
   hipStream_t s = sm_hip_stream(stream);
-  if (hipMemsetAsync(stats, 0, sizeof(unsigned long long) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (sm_zero_async(stats, sizeof(unsigned long long) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(gnx_stats_kernel, dim3(t, batch), dim3(256), 0, s, x, reinterpret_cast<unsigned long long*>(stats), a);
   SM_LAUNCH_CHECK();
   return SM_OK;

@@ -219,6 +219,56 @@ def test_sub_batch_plan_matches_single_plan(monkeypatch):
         e.multi_stream = False
 
 
+@pytest.mark.parametrize("depth", [2, 3])
+def test_pipelined_plan_equals_one_step_at_a_time(depth):
+    """engine.PipelinedPlan (SipMask.prepare(in_flight=N): N complete plans, each with its own buffers / hipGraph / stream,
+    steps submitted back to back) against the single plan run one step at a time: 24 steps over 5 different batches, every
+    step's detections, keep indices and masks equal bit for bit -- the steps in flight share weights and nothing else."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sipmask_amd.engine import PipelinedPlan
+    from sipmask_amd.synthetic import build_synthetic_detector
+    det = build_synthetic_detector(50, seed=0)
+    with torch.no_grad():
+        det.bbox_head.fcos_cls.bias.fill_(-2.0)
+    g = torch.Generator().manual_seed(17)
+    batches = [torch.randn(4, 3, 192, 256, generator=g).cuda() for _ in range(5)]
+    one = det.prepare(4, (192, 256), (192, 256, 3), lanes=1)
+    keys = ("ndet", "idxs_keep", "det_labels", "det_bboxes", "masks")
+    want = []
+    for b in batches:
+        r = one.run(b)
+        torch.cuda.synchronize()
+        want.append({k: r[k].clone() for k in keys})
+    assert sum(int(w["ndet"].sum()) for w in want) > 0
+    assert any(not torch.equal(want[0]["masks"], w["masks"]) for w in want[1:])     # the batches do differ
+    pipe = det.prepare(4, (192, 256), (192, 256, 3), in_flight=depth)
+    assert isinstance(pipe, PipelinedPlan) and pipe.depth == depth and len({id(p) for p in pipe.plans}) == depth
+    assert det.prepare(4, (192, 256), (192, 256, 3), in_flight=depth) is pipe        # cached like every plan
+    order = [(3 * i + i // 5) % 5 for i in range(24)]
+    got, pending = [], []
+    for step, bi in enumerate(order):
+        slot = pipe.submit(batches[bi])
+        pending.append((slot, bi))
+        if len(pending) == depth:               # read a slot's results before it is submitted again
+            s0, b0 = pending.pop(0)
+            r = pipe.results(s0)
+            got.append((b0, {k: r[k].clone() for k in keys}))
+    for s0, b0 in pending:
+        r = pipe.results(s0)
+        got.append((b0, {k: r[k].clone() for k in keys}))
+    torch.cuda.synchronize()
+    assert len(got) == 24
+    for i, (bi, r) in enumerate(got):
+        for k in keys:
+            assert torch.equal(r[k], want[bi][k]), (i, bi, k)
+    # the plain interface: one step, start to finish
+    r = pipe.run(batches[2])
+    torch.cuda.synchronize()
+    for k in keys:
+        assert torch.equal(r[k], want[2][k]), k
+
+
 def test_fused_bottleneck_plan_is_bit_identical(monkeypatch):
     """The launch plan with fused bottleneck tails in layer1 / layer2 (conv2+conv3, and conv2+conv3+next conv1) gives the
     same bits as the plan of separate conv launches: C2..C5 features, head outputs and the detections."""

@@ -16,6 +16,8 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def last_json(path):
+    if not os.path.exists(path):
+        return None
     ls = [l for l in open(path) if l.startswith("{")]
     return json.loads(ls[-1]) if ls else None
 
@@ -89,7 +91,7 @@ for src, dst in (("step_breakdown.txt", "r03_step_breakdown_hip_events.txt"),
     if os.path.exists(os.path.join(SRC, src)):
         shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
 lines = {}
-for n in ("r50", "r50_x3", "r50_lanes1", "r50_f32", "r101", "vis", "train", "train_rccl1"):
+for n in ("r50", "r50_inflight1", "r50_inflight3", "r50_x3", "r50_lanes1", "r50_f32", "r101", "vis", "train", "train_rccl1"):
     j = last_json(os.path.join(SRC, "bench_%s.json" % n))
     if j:
         lines[n] = j

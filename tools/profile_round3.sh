@@ -14,7 +14,9 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 python $R/bench.py --breakdown $OUT/step_breakdown.txt > $OUT/bench_r50.json 2> $OUT/bench_r50.err
 timeout 600 python $R/bench.py --precision head_x3 --breakdown $OUT/step_breakdown_x3.txt > $OUT/bench_r50_x3.json 2> $OUT/bench_r50_x3.err
 timeout 300 python $R/bench.py --no-cpu-baseline --precision f32 > $OUT/bench_r50_f32.json 2>/dev/null
-timeout 300 python $R/bench.py --no-cpu-baseline --lanes 1 > $OUT/bench_r50_lanes1.json 2>/dev/null
+timeout 300 python $R/bench.py --no-cpu-baseline --lanes 1 --in-flight 1 > $OUT/bench_r50_lanes1.json 2>/dev/null
+timeout 300 python $R/bench.py --in-flight 1 > $OUT/bench_r50_inflight1.json 2>/dev/null
+timeout 300 python $R/bench.py --no-cpu-baseline --in-flight 3 > $OUT/bench_r50_inflight3.json 2>/dev/null
 timeout 600 python $R/bench.py --config r101 > $OUT/bench_r101.json 2> $OUT/bench_r101.err
 timeout 600 python $R/bench.py --config vis > $OUT/bench_vis.json 2> $OUT/bench_vis.err
 timeout 900 python $R/bench.py --config train --steps 20 --warmup 5 > $OUT/bench_train.json 2> $OUT/bench_train.err
