@@ -40,7 +40,7 @@ STUB = os.environ.get("SIPMASK_BENCH_STUB", "0") == "1"   # CPU test hook: gloo 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--in-flight", type=int, default=2, dest="in_flight",
+    ap.add_argument("--in-flight", type=int, default=3, dest="in_flight",
                     help="inference configs: steps in flight (engine.PipelinedPlan); 1 = one step at a time, its batch cut into "
                          "two concurrent half-batch chains (engine.SubBatchPlan)")
     ap.add_argument("--steps", type=int, default=None)

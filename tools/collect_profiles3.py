@@ -91,7 +91,7 @@ for src, dst in (("step_breakdown.txt", "r03_step_breakdown_hip_events.txt"),
     if os.path.exists(os.path.join(SRC, src)):
         shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
 lines = {}
-for n in ("r50", "r50_inflight1", "r50_inflight3", "r50_x3", "r50_lanes1", "r50_f32", "r101", "vis", "train", "train_rccl1"):
+for n in ("r50", "r50_inflight1", "r50_inflight2", "r50_inflight3", "r50_x3", "r50_x3b", "r50_lanes1", "r50_f32", "r101", "r101b", "vis", "train", "train_rccl1"):
     j = last_json(os.path.join(SRC, "bench_%s.json" % n))
     if j:
         lines[n] = j
