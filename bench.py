@@ -235,7 +235,7 @@ def run_inference(args, rank, world, dev):
     plan = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=args.lanes or "auto",
                        in_flight=args.in_flight if pipelined else 1)
     if args.tower_only and args.in_flight > 1:       # the profiling aid times the kernel of the plan the pipelined default runs
-        plan = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=args.lanes or 1, slot=1)
+        plan = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=args.lanes or 1, slot=1, pipelined=True)
         plan.multi_stream = False
     subplans = getattr(plan, "engines", None)
     eng = plan.plans[0] if pipelined else (subplans[0] if subplans else plan)   # the plan whose launches the breakdown / roofline time

@@ -12,9 +12,6 @@ from .plan_cache import PlanCache, module_tensors
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
 
-_PIPE_SUBPLAN = __import__("os").environ.get("SIPMASK_PIPE_SUBPLAN", "0") == "1"   # A/B: slots of a PipelinedPlan built like sub-plans
-
-
 @DETECTORS.register_module
 class SipMask(nn.Module):
 
@@ -56,7 +53,7 @@ class SipMask(nn.Module):
             head.invalidate()
 
     def prepare(self, batch, img_hw, img_shape=None, scale_factor=1.0, rescale=False, precision="bf16", lanes="auto",
-                scale_factor_max=None, in_flight=1, slot=0):
+                scale_factor_max=None, in_flight=1, slot=0, pipelined=False):
         """Build (or fetch) the static launch plan for this input geometry; weights are snapshotted,
         BN folded, re-laid out as bf16 GEMM operands.  Call again after load_state_dict.
         img_shape / scale_factor are the DEFAULT metas of every image; plan.set_image_metas(img_metas) gives each image
@@ -67,7 +64,8 @@ class SipMask(nn.Module):
         accumulation-order rounding).  lanes: the batch as this many concurrent sub-batch plans (engine.SubBatchPlan);
         "auto" = 2 for even batches >= 4, else 1.  in_flight > 1: an engine.PipelinedPlan of that many complete plans
         (steps submitted back to back overlap: the throughput structure; `lanes` then describes each of them, "auto" = 1).
-        slot: distinguishes otherwise identical plans in the cache."""
+        slot: distinguishes otherwise identical plans in the cache; pipelined: the plan is a slot of a PipelinedPlan
+        (SipMaskEngine(pipelined=True): no split-K, big tiles, no side lanes)."""
         import numpy as np
         from .engine import SipMaskEngine
         if in_flight > 1:
@@ -76,12 +74,12 @@ class SipMask(nn.Module):
             key = ("pipelined", batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
                    rescale, precision, ln, in_flight)
             return self._engines.get(key, module_tensors(self), lambda: PipelinedPlan(
-                [self.prepare(batch, img_hw, img_shape, scale_factor, rescale, precision, ln, scale_factor_max, 1, slot=k + 1)
-                 for k in range(in_flight)]))
+                [self.prepare(batch, img_hw, img_shape, scale_factor, rescale, precision, ln, scale_factor_max, 1, slot=k + 1,
+                              pipelined=True) for k in range(in_flight)]))
         key = (batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
                rescale, precision, lanes,
                None if scale_factor_max is None else tuple(np.asarray(scale_factor_max, np.float64).reshape(-1))) + \
-            ((slot,) if slot else ())
+            ((slot, bool(pipelined)) if slot else ())
         # plans are valid for the weights they were built from: PlanCache drops them when any parameter / buffer has
         # been updated in place since (optimizer.step, load_state_dict, mmcv load_checkpoint)
         if lanes == "auto":        # SubBatchPlan: two concurrent half-batch chains pay off from 2 images per chain on
@@ -93,8 +91,8 @@ class SipMask(nn.Module):
             mk = lambda b: SipMaskEngine(sd, b, img_hw, self.backbone.depth, self.test_cfg, self.bbox_head.num_classes,
                                          strides=self.bbox_head.strides, img_shape=img_shape,
                                          ssd_flag=self.bbox_head.ssd_flag, scale_factor=scale_factor, rescale=rescale,
-                                         precision=precision, sub_plan=lanes > 1 or (bool(slot) and _PIPE_SUBPLAN),
-                                         scale_factor_max=scale_factor_max)
+                                         precision=precision, sub_plan=lanes > 1, scale_factor_max=scale_factor_max,
+                                         pipelined=bool(pipelined) and lanes == 1)
             if lanes == 1:
                 return mk(batch)
             from .engine import SubBatchPlan

@@ -111,6 +111,7 @@ class _Conv:
         out_sizes = [(_conv_out(h, k, stride, pad), _conv_out(ww, k, stride, pad)) for h, ww in in_sizes]
         self.out_sizes = out_sizes
         flags |= _DEBUG_CONV_FLAGS          # plan selectors of include/sipmask_hip.h for whole-plan experiments
+        flags |= getattr(eng, "extra_conv_flags", 0)   # ... and the engine's own (PipelinedPlan slots: big tiles)
         self.desc = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, co_pad, k, stride, pad,
                                      in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
                                      scale_nch, level_scale, deform_groups, acc_scale=acc_scale)
@@ -280,11 +281,18 @@ class SipMaskEngine:
 
     def __init__(self, state_dict, batch, img_hw, depth=50, test_cfg=None, num_classes=81, device="cuda",
                  strides=(8, 16, 32, 64, 128), img_shape=None, head_sizes=None, ssd_flag=False, scale_factor=1.0,
-                 rescale=False, vis=False, benchmark=None, precision="bf16", sub_plan=False, scale_factor_max=None):
+                 rescale=False, vis=False, benchmark=None, precision="bf16", sub_plan=False, scale_factor_max=None,
+                 pipelined=False):
         _lib.load()   # fail loudly before anything else if the HIP library is missing
         # sub_plan: this engine is one chain of a SubBatchPlan -- the other chain fills the CUs a short launch leaves
         # idle, so split-K (an extra reduce launch to fill them) only costs: 966 vs 962 img/s (profiles/r02e_ab_subplans.json)
-        self.split_k = _SPLIT_K and not sub_plan
+        self.split_k = _SPLIT_K and not sub_plan and not pipelined
+        # pipelined: this engine is one slot of a PipelinedPlan -- the steps in flight next to it fill the CUs a launch leaves
+        # idle, so what counts is CU time, not the latency of a launch: no split-K, no shrinking of the implicit-GEMM tiles for
+        # occupancy (SM_CONV_DBG_BIG_TILES: fewer operand bytes per FLOP; identical results), no side lanes.  Measured at three
+        # steps in flight: 1 263 vs 1 211 img/s (big tiles +2.7 %, no split-K +0.9 %); inside the lock-stepped chains of ONE step
+        # the same flag LOSES 5 % (round 2).
+        self.extra_conv_flags = _lib.SM_CONV_DBG_BIG_TILES if pipelined else 0
         # ... and for the same reason its patch convs keep the uniform 256-position launch: the mixed launch (256-position
         # tiles + 128/192-position finishing tiles, sm_conv3x3_patch_plan) ends a lone launch 15-20 % sooner but spends
         # 4-6 % more CU time on it, which the other chain would have used (measured 998 vs 991 img/s, profiles/r02g_ab_patch_launch_shape.json)

@@ -220,14 +220,17 @@ def test_sub_batch_plan_matches_single_plan(monkeypatch):
 
 
 @pytest.mark.parametrize("depth", [2, 3])
-def test_pipelined_plan_equals_one_step_at_a_time(depth):
+def test_pipelined_plan_equals_one_step_at_a_time(depth, monkeypatch):
     """engine.PipelinedPlan (SipMask.prepare(in_flight=N): N complete plans, each with its own buffers / hipGraph / stream,
     steps submitted back to back) against the single plan run one step at a time: 24 steps over 5 different batches, every
     step's detections, keep indices and masks equal bit for bit -- the steps in flight share weights and nothing else."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    import sipmask_amd.engine as E
     from sipmask_amd.engine import PipelinedPlan
     from sipmask_amd.synthetic import build_synthetic_detector
+    # slots run without split-K (engine.py: pipelined); the single plan of this comparison must sum in the same order
+    monkeypatch.setattr(E, "_SPLIT_K", False)
     det = build_synthetic_detector(50, seed=0)
     with torch.no_grad():
         det.bbox_head.fcos_cls.bias.fill_(-2.0)
@@ -244,6 +247,7 @@ def test_pipelined_plan_equals_one_step_at_a_time(depth):
     assert any(not torch.equal(want[0]["masks"], w["masks"]) for w in want[1:])     # the batches do differ
     pipe = det.prepare(4, (192, 256), (192, 256, 3), in_flight=depth)
     assert isinstance(pipe, PipelinedPlan) and pipe.depth == depth and len({id(p) for p in pipe.plans}) == depth
+    assert all(p.extra_conv_flags and not p.split_k and not p.multi_stream for p in pipe.plans)
     assert det.prepare(4, (192, 256), (192, 256, 3), in_flight=depth) is pipe        # cached like every plan
     order = [(3 * i + i // 5) % 5 for i in range(24)]
     got, pending = [], []
