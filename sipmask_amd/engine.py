@@ -296,7 +296,8 @@ class SipMaskEngine:
         # ... and for the same reason its patch convs keep the uniform 256-position launch: the mixed launch (256-position
         # tiles + 128/192-position finishing tiles, sm_conv3x3_patch_plan) ends a lone launch 15-20 % sooner but spends
         # 4-6 % more CU time on it, which the other chain would have used (measured 998 vs 991 img/s, profiles/r02g_ab_patch_launch_shape.json)
-        self.patch_uniform = sub_plan and os.environ.get("SIPMASK_PATCH_MIXED", "0") != "1"   # =1: A/B switch (tools/)
+        self.patch_uniform = (sub_plan and os.environ.get("SIPMASK_PATCH_MIXED", "0") != "1") or \
+            (pipelined and os.environ.get("SIPMASK_PIPE_UNIFORM", "0") == "1")          # A/B switches (tools/)
         if precision not in ("bf16", "f32", "head_x3"):
             raise ValueError("precision must be 'bf16' (throughput plan), 'head_x3' (bf16 backbone + FPN, split-precision "
                              "head: the reference head's fp32 arithmetic to ~1e-4 on its logits) or 'f32' (parity plan), "
