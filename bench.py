@@ -3,12 +3,15 @@
 inference; RCCL gradient all-reduce in training).  BASELINE.json configs:
 
   --config r50    (default, configs[1]) SipMask-R50 800x1333 (padded 800x1344) inference, batch 4 per GPU, images sharded
-                  by batch; step = NCHW image -> ResNet-50 -> FPN -> SipMaskHead -> top-k / NMS -> fused mask assembly
+                  by batch; step = one batch: NCHW image -> ResNet-50 -> FPN -> SipMaskHead -> top-k / NMS -> fused mask assembly.
+                  --in-flight N (default 3): N steps in flight (engine.PipelinedPlan: N complete plans used round-robin, step
+                  k+1 enqueued while step k runs; every timed step still is one full batch and all K steps finish inside the
+                  timed region); --in-flight 1: one step at a time, its batch cut into two concurrent half-batch chains
   --config r101   (configs[2]) the same with the R101 backbone (sipmask_r101_caffe_fpn_gn_ms_4x.py)
   --config train  (configs[3]) SipMask-R50 training step: forward_train + loss + backward + bucketed gradient
                   all-reduce (RCCL) + SGD, 4 images per GPU
   --config vis    (configs[4]) SipMask-VIS R50 on YouTube-VIS-shaped clips (8 frames of 3x384x640 = 640x360 padded),
-                  sharded BY VIDEO (the tracker is sequential inside a clip); step = one clip per GPU
+                  sharded BY VIDEO (the tracker is sequential inside a clip); step = 8 clips per GPU, pipelined
   --precision f32 the parity plan (exact-f32 MFMA convs) instead of the bf16 throughput plan (r50 / r101)
   --precision head_x3  bf16 backbone + FPN, split-precision head (the reference head's fp32 arithmetic to ~1e-4)
 
