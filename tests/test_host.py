@@ -352,3 +352,32 @@ def test_deform_conv_kernel_choice_is_host_logic():
     d = mk(256, 256, 3, 4)
     d.cout_pad = 128 * 3                                                                     # not a multiple of 256
     assert H.deform_conv_window_plan(d) is None
+
+
+def test_deform_conv_argument_checks_run_before_any_launch():
+    """ops.deform_conv (M/mmdet/ops/dcn/deform_conv.py:16-58,99): the argument checks of the grouped wrapper are host logic --
+    a group count that does not divide the channels is a ValueError, conv groups / deformable groups where neither divides the
+    other a NotImplementedError, and a CPU tensor reaches the reference's NotImplementedError (no CPU implementation)."""
+    import torch
+    from sipmask_amd import ops as P
+    x = torch.zeros(1, 12, 5, 5)
+    w = torch.zeros(8, 4, 3, 3)
+    with pytest.raises(ValueError):
+        P.deform_conv(x, torch.zeros(1, 18, 5, 5), torch.zeros(8, 5, 3, 3), 1, 1, 1, 3, 1)       # weight does not fit groups
+    with pytest.raises(NotImplementedError):
+        P.deform_conv(torch.zeros(1, 24, 5, 5), torch.zeros(1, 72, 5, 5), torch.zeros(12, 4, 3, 3), 1, 1, 1, 6, 4)
+    with pytest.raises(NotImplementedError):
+        P.deform_conv(x, torch.zeros(1, 18, 5, 5), torch.zeros(8, 12, 3, 3), 1, 1, 1, 1, 1)      # CPU tensors
+    with pytest.raises(ValueError):
+        P.deform_conv(torch.zeros(12, 5, 5), torch.zeros(1, 18, 5, 5), w)                         # not 4-D
+    m = P.DeformConv(16, 8, (1, 3), stride=2, padding=(0, 1), groups=2, deformable_groups=2)
+    assert m.weight.shape == (8, 8, 1, 3) and m.kernel_size == (1, 3) and m.padding == (0, 1) and m.groups == 2
+
+
+def test_training_rows_pick_the_big_tile_for_wide_pyramid_convs():
+    from sipmask_amd import ops_rows as R, _lib
+    big = _lib.SM_CONV_DBG_TILE256 | _lib.SM_CONV_DBG_HAND_PLACED
+    assert R._big_tile_flags(3, 1, 256, 89600) == big
+    assert R._big_tile_flags(3, 1, 256, 20000) == 0          # short position axis: the library's own rule
+    assert R._big_tile_flags(1, 1, 256, 89600) == 0 and R._big_tile_flags(3, 2, 256, 89600) == 0
+    assert R._big_tile_flags(3, 1, 208, 89600) == 0          # couts that do not fill the 256-wide tile
