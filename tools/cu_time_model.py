@@ -7,15 +7,20 @@ free-running chains +1 %), so this -- not the chain's laten
 import collections
 import os
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# usage: cu_time_model.py [breakdown.txt launch_plan.txt chains_in_flight]   (defaults: the round-2 sub-plan chain, 2)
+BREAKDOWN = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_step_breakdown_hip_events.txt")
+PLAN = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r02_launch_plan_r50_subplan.txt")
+CHAINS = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 ms = {}
-for l in open(os.path.join(ROOT, "profiles", "r02_step_breakdown_hip_events.txt")):
+for l in open(BREAKDOWN):
     m = re.match(r"(\S+)\s+([\d.]+) ms", l)
     if m:
         ms.setdefault(m.group(1), []).append(float(m.group(2)))
 occ = {}
-for l in open(os.path.join(ROOT, "profiles", "r02_launch_plan_r50_subplan.txt")):
+for l in open(PLAN):
     p = l.split()
     if len(p) > 6 and p[1].startswith("conv:") and p[2] in ("igemm", "patch", "window"):
         occ[p[1]] = min(1.0, float(p[5]))
@@ -50,4 +55,4 @@ T, Cs = sum(tot.values()), sum(cut.values())
 print("stage          ms (chain alone)  share    CU-time (ms x occupied fraction)  share")
 for s in tot:
     print("%-14s %8.3f %8.1f %% %14.3f %18.1f %%" % (s, tot[s], 100 * tot[s] / T, cut[s], 100 * cut[s] / Cs))
-print("sum %.3f ms; CU-time %.3f ms per chain, two chains -> %.2f ms of chip time per step" % (T, Cs, 2 * Cs))
+print("sum %.3f ms; CU-time %.3f ms per chain; %d chain(s) per step -> %.2f ms of chip time per step" % (T, Cs, CHAINS if CHAINS == 2 and "r02" in BREAKDOWN else 1, (CHAINS if CHAINS == 2 and "r02" in BREAKDOWN else 1) * Cs))

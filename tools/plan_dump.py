@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build_on_cpu(variant="r50", batch=4, hw=(800, 1344), depth=50, sub_plan=False, precision="bf16"):
+def build_on_cpu(variant="r50", batch=4, hw=(800, 1344), depth=50, sub_plan=False, precision="bf16", pipelined=False):
     """The plan is host logic: with torch.cuda.is_available patched the engine allocates its buffers on the CPU and
     prepares every descriptor; nothing is launched."""
     real = torch.cuda.is_available
@@ -49,7 +49,8 @@ def build_on_cpu(variant="r50", batch=4, hw=(800, 1344), depth=50, sub_plan=Fals
             kw = dict(benchmark=dict(pre_nms_thresh=0.05, pre_nms_top_n=1000, nms_thresh=0.6, post_top_n=100))
         else:
             sd = OM.init_state_dict(depth, 0)
-        return SipMaskEngine(sd, batch, tuple(hw), depth, device="cpu", sub_plan=sub_plan, precision=precision, **kw)
+        return SipMaskEngine(sd, batch, tuple(hw), depth, device="cpu", sub_plan=sub_plan, precision=precision,
+                             pipelined=pipelined, **kw)
     finally:
         torch.cuda.is_available = real
 
@@ -109,12 +110,13 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--variant", default="r50", choices=["r50", "ssd", "vis", "benchmark", "dcn"])
     ap.add_argument("--sub-plan", action="store_true")
+    ap.add_argument("--pipelined", action="store_true", help="one slot of a PipelinedPlan (big tiles, no split-K, no side lanes)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "head_x3"])
     args = ap.parse_args()
-    eng = build_on_cpu(args.variant, args.batch, args.hw, args.depth, args.sub_plan, args.precision)
+    eng = build_on_cpu(args.variant, args.batch, args.hw, args.depth, args.sub_plan, args.precision, args.pipelined)
     rows = {r["name"]: r for r in conv_rows(eng)}
     print("# %s, batch %d%s, %dx%d: %d steps, %d conv launches (+ %d fused bottleneck tails), %.1f conv GFLOP per step" % (
-        args.variant, args.batch, " (one chain of a SubBatchPlan)" if args.sub_plan else "", args.hw[0], args.hw[1],
+        args.variant, args.batch, " (one chain of a SubBatchPlan)" if args.sub_plan else (" (one slot of a PipelinedPlan)" if args.pipelined else ""), args.hw[0], args.hw[1],
         len(eng.steps), len(eng.convs), len(eng.fused), sum(r["gflop"] for r in rows.values())))
     print("# lane | step | kernel | tile (cout x pos) | blocks | blocks / resident slots (256 CUs x 1, 2 or 4) | GFLOP | "
           "algorithmic MB | notes")
