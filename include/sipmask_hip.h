@@ -199,8 +199,8 @@ int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void* w_patch, 
  * Two kernels behind this entry point: FeatureAlign's shape (3x3, stride 1, pad 1, 64 channels per deformable group,
  * cout_pad % 256 == 0, plain epilogue) runs on csrc/deform_patch.hip -- one group's pixel window resident in LDS, offsets
  * beyond 3 pixels handled by a per-wave global fallback; every other shape, and SM_CONV_DBG_DEFORM_GATHER, on the
- * gather loader of csrc/conv_igemm.hip.  Same samples either way (f32 blend, one rounding to the bf16 operand); the K
- * summation order differs. */
+ * gather loader of csrc/conv_igemm.hip (any stride / dilation / kh x kw).  Same samples either way (f32 blend, one rounding
+ * to the bf16 operand); the K summation order differs. */
 int sm_deform_conv2d(const sm_conv_desc* d, const void* x, const float* offset, const void* w,
                      const float* bias, void* y, sm_stream_t stream);
 /* Which of the two kernels takes d (pure host logic, no GPU needed): SM_OK and out4 = {blocks, tile rows, tile columns,
@@ -216,7 +216,9 @@ int sm_deform_conv_window_plan(const sm_conv_desc* d, int64_t* out4);
  *      grad_x / grad_offset only);
  * outputs (each nullable = skipped): grad_x f32 [in rows][cin] (zeroed by the call), grad_offset f32 like offset,
  * grad_w_t f32 [K][cout] = dW^T (overwritten; dW[co][c][i][j] = grad_w_t[(i*kw+j)*cin + c][co]).
- * Needs cin % 64 == 0, (cin/G) % 64 == 0, cout % 8 == 0, stride 1. */
+ * Needs cin % 64 == 0, (cin/G) % 64 == 0, cout % 8 == 0; any stride / dilation / kh x kw of the descriptor (round 3; the
+ * offset rows are OUTPUT rows).  The grad columns W^T gout are kept as bf16 rows in the workspace (like every other
+ * gradient row of the training graph); 3x3 kernels take the wave-per-(position, 64 channels) scatter, others the generic one. */
 int64_t sm_deform_conv2d_bwd_workspace(const sm_conv_desc* d);
 int sm_deform_conv2d_bwd(const sm_conv_desc* d, const void* x, const float* offset, const void* w_t,
                          const void* gout, float* grad_x, float* grad_offset, float* grad_w_t, void* workspace,
