@@ -71,9 +71,9 @@ def parse(argv=None):
                          "statistics fused) N times and exit, so a rocprofv3 --stats / --pmc run sees that kernel alone")
     a = ap.parse_args(argv)
     if a.steps is None:
-        a.steps = {"r50": 20, "r101": 20, "train": 5, "vis": 10}[a.config]
+        a.steps = {"r50": 50, "r101": 50, "train": 10, "vis": 10}[a.config]      # >= 50 iterations after 10 warm-ups
     if a.warmup is None:
-        a.warmup = {"r50": 5, "r101": 5, "train": 2, "vis": 2}[a.config]
+        a.warmup = {"r50": 10, "r101": 10, "train": 3, "vis": 2}[a.config]
     if a.depth is None:
         a.depth = 101 if a.config == "r101" else 50
     return a
