@@ -5,8 +5,9 @@ also the script that writes profiles/r02_parity_*.json).
 
   * f32 plan (the parity mode): mask logits within 1e-3 ABSOLUTE of the oracle (north_star's tolerance), from the
     same image AND from identical fp32 FPN features; every stage within 2e-4 of its largest value.
-  * bf16 plan (the throughput mode) -- THE OBJECT bench.py TIMES: det.prepare(4, ..., lanes="auto") = a SubBatchPlan of
-    two B=2 chains without split-K.  Stated bound = relative Frobenius error per stage (bf16 storage of ~60 stacked
+  * bf16 plan (the throughput mode) -- THE OBJECTS bench.py TIMES: a slot of det.prepare(4, ..., in_flight=3) (the default:
+    engine.PipelinedPlan, complete single-chain plans with big tiles and no split-K) and det.prepare(4, ..., lanes="auto")
+    (--in-flight 1: a SubBatchPlan of two B=2 chains without split-K).  Stated bound = relative Frobenius error per stage (bf16 storage of ~60 stacked
     convs): backbone/FPN < 2 %, head outputs < 4 %, mask logits < 5 %; a second pass over the same images reproduces
     every output bit for bit (fixed-point GroupNorm statistics); its exactness claims live in the kernel tests
     (identical inputs) and in test_gpu_engine.py (post-processing on the engine's own head outputs)."""
@@ -62,6 +63,23 @@ def test_bf16_plan_at_baseline_shape():
     assert img["mask_logits"]["rel_fro"] < 0.05 and feat["mask_logits"]["rel_fro"] < 0.025
     for d in rep["detections"]:
         assert d["ndet_engine"] > 0 and d["ndet_oracle"] > 0
+
+
+def test_bf16_pipelined_plan_at_baseline_shape():
+    """the default object of bench.py: a slot of the PipelinedPlan (SipMask.prepare(in_flight=3)) at BASELINE's shape, held to
+    the bounds of the bf16 plan above"""
+    _need_gpu()
+    import parity_baseline as PB
+    rep = PB.run(50, 4, "bf16", features_too=False, verbose=False, plan="pipelined")
+    assert rep["steps_in_flight"] == 3 and rep["rerun_bit_identical"]
+    img = rep["image"]
+    for k in ("C2", "C3", "C4", "C5", "P3", "P4", "P5", "P6", "P7"):
+        assert img[k]["rel_fro"] < 0.02, (k, img[k])
+    for k in ("cls_logits", "bbox_pred", "centerness", "cof", "basis"):
+        assert img[k]["rel_fro"] < 0.04, (k, img[k])
+    assert img["mask_logits"]["rel_fro"] < 0.05
+    for d in rep["detections"]:
+        assert d["ndet_engine"] > 0 and d["ndet_oracle"] > 0 and d["common"] >= 80, d
 
 
 def test_head_x3_plan_at_baseline_shape():

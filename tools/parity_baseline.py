@@ -247,8 +247,9 @@ def parity_summary(stage_report, det_report):
 
 
 def run(depth=50, batch=4, precision="bf16", features_too=True, verbose=True, plan="single"):
-    """plan: "single" = one SipMaskEngine over the batch; "subbatch" = the object bench.py times, i.e.
-    det.prepare(batch, ..., lanes="auto") (engine.SubBatchPlan: two half-batch chains, no split-K, uniform patch tiles)."""
+    """plan: "single" = one SipMaskEngine over the batch; "subbatch" = what bench.py --in-flight 1 times, i.e.
+    det.prepare(batch, ..., lanes="auto") (engine.SubBatchPlan: two half-batch chains, no split-K, uniform patch tiles);
+    "pipelined" = what bench.py times by default (a slot of engine.PipelinedPlan)."""
     from sipmask_amd.engine import SipMaskEngine
     dev = torch.device("cuda")
     det, sd, img = build_case(depth, batch)
@@ -261,6 +262,16 @@ def run(depth=50, batch=4, precision="bf16", features_too=True, verbose=True, pl
             det.bbox_head.fcos_cls.bias.fill_(ora["cls_bias"])
         eng = det.prepare(batch, (IMG_H, IMG_W), (IMG_H, 1333, 3), precision=precision, lanes="auto")
         report["chains"] = [e.batch for e in getattr(eng, "engines", [eng])]
+    elif plan == "pipelined":
+        # what bench.py times by default: one slot of det.prepare(batch, ..., in_flight=3) (engine.PipelinedPlan: complete
+        # single-chain plans built for CU time -- big tiles, no split-K, no side lanes); the slots are identical plans and
+        # a step is one of them run on one batch, so the comparison runs slot 0 through the pipeline's own submit / results
+        with torch.no_grad():
+            det.bbox_head.fcos_cls.bias.fill_(ora["cls_bias"])
+        pipe = det.prepare(batch, (IMG_H, IMG_W), (IMG_H, 1333, 3), precision=precision, in_flight=3)
+        report["steps_in_flight"] = pipe.depth
+        pipe.run(img.to(dev))                                  # slot 0 (captures its graph)
+        eng = pipe.plans[0]
     else:
         eng = SipMaskEngine(sd, batch, (IMG_H, IMG_W), depth, img_shape=(IMG_H, 1333, 3), **kw)
     res = eng.run(img.to(dev))
@@ -302,7 +313,7 @@ if __name__ == "__main__":
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--plan", default="single", choices=("single", "subbatch"))
+    ap.add_argument("--plan", default="single", choices=("single", "subbatch", "pipelined"))
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     rep = run(a.depth, a.batch, a.precision, plan=a.plan)
