@@ -24,6 +24,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 """
 import argparse
 import json
+import math
 import os
 import socket
 import sys
@@ -65,6 +66,12 @@ def parse(argv=None):
                     help="with 2 sub-plans: one hipGraph per sub-plan on concurrent streams (1 = sub-plans keep their "
                          "internal side lanes, 2 = single-lane sub-plans) instead of one graph around both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the contract line (value / roofline [/ cpu_baseline, parity]): skip steady_state, with_results, "
+                         "parity_plan, mask_assemble_worst_case and other_configs")
+    ap.add_argument("--extras-budget", type=float, default=240.0, dest="extras_budget",
+                    help="wall-clock seconds the extra blocks of the default line may take together (an extra that does not "
+                         "fit is reported as skipped)")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-step HIP-event breakdown to this file")
     ap.add_argument("--tower-only", type=int, default=0, metavar="N",
                     help="profiling aid: launch only the dominant kernel (first tower launch of the plan, GN "
@@ -190,23 +197,51 @@ def cpu_baseline_vis(det, seed=0):
                        "oracle, 1 warm-up + %d timed frame(s) in a 20 s budget, median %.2f s" % (len(timed), t))
 
 
-def parity_of_timed_plan(det, plan, img, depth):
-    """The TIMED plan's last step against the CPU oracle on the same images and weights (checker leg, like the CPU
-    baseline): mask-logit max-abs error at the oracle's detections (sipmask_head.py:609-620, north_star's quantity) and
-    the detections in common, per image.  The plan's buffers still hold the last timed step's tensors."""
-    import torch
+def oracle_record(det, img, depth):
+    """the CPU oracle's forward of `img` with the detector's weights as they are (checker leg, like the CPU baseline)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import parity_baseline as PB
     sd = {k: v.detach().float().cpu() for k, v in det.state_dict().items()}
-    ora = PB.oracle_forward(sd, img.detach().float().cpu(), depth)
+    return PB.oracle_forward(sd, img.detach().float().cpu(), depth)
+
+
+def parity_of_timed_plan(plan, ora, batch):
+    """A step of the TIMED plan against the CPU oracle on the same images and weights: mask-logit max-abs error at the
+    oracle's detections (sipmask_head.py:609-620, north_star's quantity) and the detections in common, per image.  The
+    plan's buffers hold that step's tensors (the caller ran it on the oracle's images and synchronised)."""
+    import torch
+    import parity_baseline as PB
     torch.cuda.synchronize()
-    stages, dets = PB.compare_plan(plan, plan.results(), ora, img.shape[0], True, with_masks=False)
+    stages, dets = PB.compare_plan(plan, plan.results(), ora, batch, True, with_masks=False)
     p = PB.parity_summary(stages, dets)
     p["mask_logit_rel_fro"] = round(stages["mask_logits"]["rel_fro"], 5)
-    p["note"] = ("timed plan vs fp32 CPU oracle from the same IMAGES: the bf16 backbone's rounding is part of this number for "
-                 "--precision bf16 and head_x3 (north_star's 1e-3 is stated for identical head inputs: tools/parity_baseline.py "
-                 "'features' section, tests/test_gpu_baseline_shape.py; from the image only --precision f32 meets it)")
+    p["setting"] = "from the same IMAGES (the bf16 backbone's rounding is part of this number for bf16 and head_x3)"
     p["oracle_seconds"] = round(ora["seconds"], 1)
+    return p
+
+
+def parity_on_identical_features(det, ora, batch, shape, precision):
+    """north_star's setting -- "outputs match the reference head on identical inputs": the oracle's fp32 FPN outputs are
+    fed to a head-only plan of the same precision built like a slot of the timed pipeline (SipMaskEngine.for_head(...,
+    pipelined=True): same kernels, tiles and launch shapes as the timed head), its head outputs, detections and mask
+    logits compared with the oracle's (tools/parity_baseline.py, tests/test_gpu_baseline_shape.py)."""
+    import torch
+    import parity_baseline as PB
+    from sipmask_amd.engine import SipMaskEngine
+    sizes = [tuple(p.shape[-2:]) for p in ora["pyr"]]
+    hsd = {k: v.detach() for k, v in det.state_dict().items() if k.startswith("bbox_head.")}
+    heng = SipMaskEngine.for_head(hsd, batch, sizes, img_shape=shape, precision=precision, pipelined=True)
+    heng.load_pyramid([p.cuda() for p in ora["pyr"]])
+    heng.run_head(with_post=True)
+    torch.cuda.synchronize()
+    stages = PB.compare_engine(heng, ora, batch, False)
+    dets = PB.compare_detections(heng, heng.results(), ora, batch, with_masks=False)
+    p = PB.parity_summary(stages, dets)
+    p["mask_logit_rel_fro"] = round(stages["mask_logits"]["rel_fro"], 8)
+    p["head_outputs_rel_fro"] = {k: float("%.3g" % stages[k]["rel_fro"]) for k in ("cls_logits", "bbox_pred", "centerness", "cof", "basis")}
+    p["setting"] = "identical head inputs: the oracle's fp32 FPN features fed to a head-only plan (north_star's tolerance 1e-3)"
+    del heng
+    torch.cuda.empty_cache()
     return p
 
 
@@ -325,6 +360,76 @@ def run_inference(args, rank, world, dev):
         plan.join()
     ndet = gather_counts(plan.results()["ndet"].to(torch.int64), device=dev).cpu().tolist()
 
+    # ---- extra timed windows (every rank runs them: their fences are collective)
+    extras = {}
+    t_extras = time.perf_counter()
+    left = lambda: args.extras_budget - (time.perf_counter() - t_extras)
+    do_extras = not args.no_extras and not args.no_graph and not free_run
+    if do_extras:
+        # (a) the same step over a window of >= 2 s: the K steps of the contract are a 65-160 ms burst, during which the
+        # shader clock is still settling (profiles/r03_mfma_peak_clock.txt); this is the steady-state figure
+        n_ss = max(args.steps, int(math.ceil(2.2 / (elapsed / args.steps))))
+        e_ss = timed_steps(step, n_ss, sync_fn=torch.cuda.synchronize, device=dev)
+        if pipelined:
+            plan.join()
+        extras["steady_state"] = dict(value=round(B * n_ss * world / e_ss, 3), unit="img/s", steps=n_ss,
+                                      timed_region_s=round(e_ss, 3), ms_per_step=round(e_ss / n_ss * 1e3, 3),
+                                      note="the timed step repeated for >= 2 s after the contract's K steps (same plan, same "
+                                           "fences); `value` above is the contract's K-step figure")
+    if do_extras and pipelined:
+        # (b) the step WITH its results returned to the host, as the reference's evaluation loop does per batch
+        # (M/mmdet/apis/test.py:12-72, sipmask_head.py:645-662): behind every step, on the slot's stream, sm_mask_rects +
+        # sm_rle_encode and asynchronous copies of boxes / labels / counts / RLE strings into pinned buffers; the host
+        # consumes them (RLE dicts per detection) before the slot is reused, i.e. `in_flight` steps later
+        pending = [False] * plan.depth
+        stat = dict(dets=0, rle_bytes=0, batches=0)
+
+        def consume(k):
+            for boxes, labels, rles in plan.fetch(k):
+                stat["dets"] += len(rles)
+                stat["rle_bytes"] += sum(len(r["counts"]) for r in rles)
+            stat["batches"] += 1
+            pending[k] = False
+
+        n_wr = max(args.steps, int(math.ceil(1.5 / (elapsed / args.steps))))
+        calls = [0]
+
+        def step_results():
+            k = plan.next_slot
+            if pending[k]:
+                consume(k)
+            plan.submit(imgs[nstep[0] % NSETS], pack=True, canvas_hw=shape[:2])
+            nstep[0] += 1
+            pending[k] = True
+            calls[0] += 1
+            if calls[0] == n_wr:                       # the last step of the window: drain, every result is consumed inside it
+                for j in range(plan.depth):
+                    kk = (k + 1 + j) % plan.depth
+                    if pending[kk]:
+                        consume(kk)
+
+        for _ in range(plan.depth + 2):                # warm-up: pinned buffers, RLE workspaces
+            k = plan.next_slot
+            if pending[k]:
+                consume(k)
+            plan.submit(imgs[nstep[0] % NSETS], pack=True, canvas_hw=shape[:2])
+            nstep[0] += 1
+            pending[k] = True
+        for k in range(plan.depth):
+            if pending[k]:
+                consume(k)
+        stat.update(dets=0, rle_bytes=0, batches=0)
+        e_wr = timed_steps(step_results, n_wr, sync_fn=torch.cuda.synchronize, device=dev)
+        extras["with_results"] = dict(
+            value=round(B * n_wr * world / e_wr, 3), unit="img/s", steps=n_wr, timed_region_s=round(e_wr, 3),
+            ms_per_step=round(e_wr / n_wr * 1e3, 3), batches_consumed_this_rank=stat["batches"],
+            detections_per_step=round(stat["dets"] / max(1, stat["batches"]), 1),
+            rle_bytes_per_step=int(stat["rle_bytes"] / max(1, stat["batches"])),
+            per_step="device-side RLE of the step's masks (sm_mask_rects + sm_rle_encode) on the slot's stream + async D2H of "
+                     "det_bboxes / det_labels / ndet / run counts / offsets / RLE strings into pinned buffers; the host builds "
+                     "the per-detection RLE dicts before the slot is reused (PipelinedPlan.submit(pack=True) / fetch)")
+        plan.join()
+
     # ---- per-step HIP-event breakdown (eager, on the launch stream) -> roofline of the dominant kernel
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in eng.steps]
     reps = 3
@@ -409,6 +514,7 @@ def run_inference(args, rank, world, dev):
         "value": round(B * args.steps * world / elapsed, 3),
         "unit": "img/s",
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "timed_region_s": round(elapsed, 4),
         "dtype": "f32" if f32 else ("bf16 (backbone, FPN) + 3 x f16 split products / f32 activations (head)" if x3 else "bf16"),
         "data": "synthetic (randn images, %d batches resident in HBM rotated through the plan's input every step; "
                 "reference-init random weights + SURVEY 8d calibration overrides)" % NSETS,
@@ -435,11 +541,135 @@ def run_inference(args, rank, world, dev):
                      "fpn_convs_tflops": round(fpn_tf, 2),
                      "conv_gflop_per_step": round(plan.total_conv_flops() / 1e9, 1)},
     }
+    out.update(extras)
+    if world == 1 and rank == 0 and do_extras and getattr(eng, "fused_masks", False):
+        out["mask_assemble_worst_case"] = mask_assemble_worst_case(eng)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_inference(det, args.depth)
-        out["parity"] = parity_of_timed_plan(det, plan.plans[plan.last_slot] if pipelined else plan,
-                                             imgs[(args.warmup + args.steps - 1) % len(imgs)], args.depth)
+        # parity of the TIMED plan object: one more step of it on the images the oracle gets
+        ora = oracle_record(det, imgs[0], args.depth)
+        if pipelined:
+            plan.run(imgs[0])
+            target = plan.plans[plan.last_slot]
+        else:
+            img.copy_(imgs[0])
+            (plan.replay() if sub_graphs else (graph.replay() if graph is not None else run_all()))
+            target = plan
+        out["parity"] = parity_of_timed_plan(target, ora, B)
+        if args.precision != "bf16":
+            out["parity"]["identical_features"] = parity_on_identical_features(det, ora, B, shape, args.precision)
+        if do_extras and pipelined and args.precision == "bf16" and left() > 45:
+            out["parity_plan"] = parity_plan_block(det, args, imgs, ora, shape, dev)
+        elif do_extras and args.precision == "bf16":
+            out["parity_plan"] = dict(skipped="extras budget" if pipelined else "needs the pipelined plan")
+    if world == 1 and rank == 0 and do_extras and args.config == "r50" and args.precision == "bf16":
+        out["other_configs"] = other_configs(min(left(), 150.0))
     return out
+
+
+def parity_plan_block(det, args, imgs, ora, shape, dev):
+    """The plan that MEETS north_star's tolerance, timed in the same run as the bf16 line: `precision="head_x3"` (bf16
+    backbone + FPN, the head in split precision: f32 activations, every product as three binary16 half products, f32
+    accumulation).  Same structure as the default line (steps in flight, one B-image chain per step, inputs rotated);
+    its parity block is measured here too -- on identical head inputs (north_star's setting) and from the image."""
+    import torch
+    from sipmask_amd.dist_shard import timed_steps
+    B = args.batch
+    plan3 = det.prepare(B, (IMG_H, IMG_W), shape, precision="head_x3", lanes=args.lanes or "auto", in_flight=args.in_flight)
+    plan3.capture(imgs[0])
+    n = [0]
+
+    def step3():
+        plan3.submit(imgs[n[0] % len(imgs)])
+        n[0] += 1
+
+    for _ in range(6):
+        step3()
+    e = timed_steps(step3, 20, sync_fn=torch.cuda.synchronize, device=dev)
+    steps = max(20, int(math.ceil(2.0 / (e / 20))))
+    e = timed_steps(step3, steps, sync_fn=torch.cuda.synchronize, device=dev)
+    plan3.join()
+    plan3.run(imgs[0])
+    from_image = parity_of_timed_plan(plan3.plans[plan3.last_slot], ora, B)
+    del plan3
+    torch.cuda.empty_cache()
+    feat = parity_on_identical_features(det, ora, B, shape, "head_x3")
+    ok = feat["mask_logit_max_abs"] <= 1e-3 and all(feat["same_order"])
+    return dict(precision="head_x3", value=round(B * steps / e, 3), unit="img/s", ms_per_step=round(e / steps * 1e3, 3),
+                steps=steps, timed_region_s=round(e, 3), steps_in_flight=args.in_flight,
+                mask_logit_max_abs=feat["mask_logit_max_abs"], mask_logit_ref_max_abs=feat["mask_logit_ref_max_abs"],
+                same_order=feat["same_order"], common_dets=feat["common_dets"], meets_north_star_tolerance=bool(ok),
+                identical_features=feat, from_image=from_image,
+                dtype="bf16 (backbone, FPN) + 3 x f16 split products / f32 activations (head)")
+
+
+def mask_assemble_worst_case(eng):
+    """sm_mask_assemble_lo with the worst geometry a batch can bring: max_per_img detections per image, every box the
+    whole image (each step rewrites every mask plane completely: B x 100 x 800 x 1344 u8) -- the timed steps' cost follows
+    the synthetic detections' (small) rectangles.  HIP events over 10 launches on the launch stream."""
+    import torch
+    from sipmask_amd import hip_ops as H
+    B, n = eng.batch, eng.max_num
+    buf = H.mask_assemble_lo_alloc(B, n, eng.ho, eng.wo, eng.device)
+    det = torch.zeros(B, n, 5, device=eng.device)
+    det[..., 2], det[..., 3], det[..., 4] = float(eng.W), float(eng.H), 0.9
+    keep = torch.arange(n, dtype=eng.nms_out["keep"].dtype, device=eng.device).repeat(B, 1).contiguous()
+    ndet = torch.full((B,), n, dtype=eng.nms_out["ndet"].dtype, device=eng.device)
+    h0, w0 = eng._basis_h0w0
+    run = lambda: H.mask_assemble_lo(eng.basis_lo, h0, w0, 4, eng.sel["cofs"], keep, det, ndet, eng.ho, eng.wo, eng.box_mul,
+                                     2.0, eng.up, eng.mask_thr, buf, per_image=eng.geom_tab)
+    for _ in range(2):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    out_mb = B * n * eng.ho * eng.wo / 1e6
+    covered = float((buf["masks"][..., :eng.wo] != 0).float().mean())
+    del buf
+    return dict(ms_per_step=round(ms, 4), detections=B * n, box="whole image", mask_mb_written=round(out_mb, 1),
+                achieved_gb_s=round(out_mb / ms, 1), hbm_peak_gb_s=8000.0, frac=round(out_mb / ms / 8000.0, 4),
+                mask_pixels_set=round(covered, 4),
+                note="timed plan's launch (sm_mask_assemble_lo) on 100 image-sized boxes per image; the u8 mask canvas written "
+                     "once per step is the algorithmic traffic (SURVEY 8d: 107.5 MB per image)")
+
+
+def other_configs(budget_s):
+    """BASELINE configs[2]-[4] in the SAME driver run: each as `bench.py --config ... --no-extras --no-cpu-baseline` in a
+    child process on the same GPU (one at a time, a time limit each), reduced to value / ms_per_step / roofline.frac."""
+    import subprocess
+    res = {}
+    t0 = time.perf_counter()
+    for name, extra in (("r101", ["--config", "r101", "--steps", "100", "--warmup", "10"]),
+                        ("train", ["--config", "train", "--steps", "10", "--warmup", "3"]),
+                        ("vis", ["--config", "vis", "--steps", "8", "--warmup", "2"])):
+        remaining = budget_s - (time.perf_counter() - t0)
+        if remaining < 25:
+            res[name] = dict(skipped="extras budget (%.0f s left)" % max(0.0, remaining))
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extras", "--no-cpu-baseline"] + extra
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SIPMASK_FORCE_DIST"):
+            env.pop(k, None)
+        try:
+            t1 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(remaining, 90.0), env=env, cwd=ROOT)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                res[name] = dict(error="rc %d: %s" % (r.returncode, (r.stderr or "")[-300:]))
+                continue
+            d = json.loads(line[-1])
+            rf = d.get("roofline") or {}
+            res[name] = dict(metric=d["metric"], value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"], steps=d["steps"],
+                             timed_region_s=round(d["ms_per_step"] * d["steps"] / 1e3, 3), dtype=d["dtype"],
+                             roofline_frac=rf.get("frac"), roofline_achieved=rf.get("achieved"), roofline_unit=rf.get("unit"),
+                             roofline_kernel=(rf.get("kernel") or "")[:120], wall_s=round(time.perf_counter() - t1, 1))
+        except subprocess.TimeoutExpired:
+            res[name] = dict(skipped="time limit")
+    return res
 
 
 # ------------------------------------------------------------------------------------------------ training step
@@ -680,6 +910,9 @@ def main():
         assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
+        if world > 1:            # one process per GPU: keep each rank's launch thread on the CPUs next to its GPU
+            from sipmask_amd.dist_shard import pin_rank
+            pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if world > 1 or os.environ.get("SIPMASK_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -305,6 +305,14 @@ int sm_offset_linear(const float* reg, int reg_cstride, const float* w_off, int 
                      const int64_t* row0, const int32_t* rows_per_level, const float* level_scale,
                      int nlev, float* out, sm_stream_t stream);
 
+/* Weight gradient of FeatureAlign.conv_offset (the 1x1 conv 4 -> nout, no bias, of the DETACHED box prediction:
+ * sipmask_head.py:30-33,50 -- autograd reaches only its weight): grad_w[o][c] = sum_rows grad_out[row][o] * reg[row][c]
+ * (reg already carries Scale).  Replaces the ATen matmul backward (a vendor GEMM, K = all positions).  Deterministic
+ * (fixed-order two-pass reduction); workspace of sm_offset_linear_bwd_workspace(rows, nout) bytes. */
+int64_t sm_offset_linear_bwd_workspace(int64_t rows, int nout);
+int sm_offset_linear_bwd(const float* reg, int reg_cstride, const float* grad_out, int nout, int64_t rows,
+                         float* workspace, float* grad_w, sm_stream_t stream);
+
 /* y = relu(x) over n bf16 elements (n % 8 == 0): halves with the sign bit set become +0 (so a negative NaN becomes 0
    where torch.relu would keep it; activations on this path are finite).  Replaces the `F.relu(outs[-1])` in front of
    the P7 conv (M/mmdet/models/necks/fpn.py:166-170) so that conv takes the LDS-DMA operand path. */

@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from . import targets as T
 from .ops import DeformConv, Scale, mask_loss, nms, sigmoid_focal_loss
+from .registry import HEADS
 
 INF = 100000000
 REGRESS_RANGES = ((-1, 64), (64, 128), (128, 256), (256, 512), (512, INF))
@@ -104,7 +105,8 @@ class SipMaskBenchmarkHead(nn.Module):
         rc, _ = R.conv_rows(box_t, lv, w_rc, b_rc, 1, 1, out_f32=True)
         seg = [(lv.row0[l], lv.row0[l] + b * h * w, h, w) for l, (h, w) in enumerate(lv.sizes)]
         box_rows = [torch.relu(self.scales[l](rc[r0:r1, :4])) for l, (r0, r1, _, _) in enumerate(seg)]
-        offset = torch.cat([t.detach() for t in box_rows]).float() @ self.feat_align.conv_offset.weight.flatten(1).t()
+        offset = R.offset_linear_rows(torch.cat([t.detach() for t in box_rows]).float().contiguous(),
+                                      self.feat_align.conv_offset.weight.flatten(1), lv)
         ad = self.feat_align.conv_adaption
         y = R.deform_conv_rows(cls_t, lv, offset, ad.weight, ad.bias, 1, 1, ad.deformable_groups)
         n = self.feat_align.norm
@@ -171,6 +173,32 @@ def _reduce_sum(t):
 def _num_gpus():
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+@HEADS.register_module
+class FCOSSipMaskHead(SipMaskBenchmarkHead):
+    """The second registry name north_star gives ("SipMaskHead / FCOSSipMaskHead").  The reference has no class of that
+    name; it denotes the FCOS-style head of the maskrcnn-benchmark variant
+    (B/fcos_core/modeling/rpn/sipmask/sipmask.py:48-190), so `dict(type='FCOSSipMaskHead', ...)` in an mmdet-style config
+    builds that head: the reference's B/ parameter names (cls_tower.0.weight, bbox_pred.bias, ...), conv bias + GN towers,
+    relu(scale(bbox_pred)), biased DeformConv in FeatureAlign.  Constructor keywords: B/'s (num_convs, fpn_strides,
+    prior_prob -- cfg.MODEL.SIPMASK.NUM_CONVS / FPN_STRIDES / PRIOR_PROB, sipmask.py:56-61) or the mmdet spelling of
+    the same quantities (stacked_convs, strides); feat_channels must equal in_channels (B/ has one width)."""
+
+    def __init__(self, num_classes=81, in_channels=256, num_convs=None, fpn_strides=None, prior_prob=0.01,
+                 stacked_convs=None, strides=None, feat_channels=None, **kwargs):
+        if kwargs:
+            raise TypeError("FCOSSipMaskHead: unexpected keyword(s) %s" % sorted(kwargs))
+        if num_convs is not None and stacked_convs is not None and num_convs != stacked_convs:
+            raise ValueError("num_convs and stacked_convs name the same quantity")
+        if fpn_strides is not None and strides is not None and tuple(fpn_strides) != tuple(strides):
+            raise ValueError("fpn_strides and strides name the same quantity")
+        if feat_channels not in (None, in_channels):
+            raise ValueError("the B/ head has one width: feat_channels must equal in_channels")
+        nconv = num_convs if num_convs is not None else (stacked_convs if stacked_convs is not None else 4)
+        st = fpn_strides if fpn_strides is not None else (strides if strides is not None else (8, 16, 32, 64, 128))
+        super().__init__(num_classes, in_channels, nconv, tuple(st), prior_prob)
+        self.num_classes, self.strides = num_classes, tuple(st)
 
 
 class SipMaskLossComputation(object):

@@ -648,12 +648,12 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
     int st = sm_conv2d(&g1, gout, w_t, nullptr, nullptr, gcol, stream);
     if (st != SM_OK) return st;
     float* gx_col = fast_dgrad ? nullptr : grad_x;
-    if (gx_col && hipMemsetAsync(gx_col, 0, (size_t)in_rows * d->cin * 4, s) != hipSuccess) return SM_ERR_LAUNCH;
+    if (gx_col && sm_zero_async(gx_col, (size_t)in_rows * d->cin * 4, s) != hipSuccess) return SM_ERR_LAUNCH;
     if (grad_offset) {   // positions sampling outside the image are skipped by the kernel: their gradient is 0
       long long orows = 0;
       for (int l = 0; l < d->nlev; ++l)
         orows = std::max<long long>(orows, d->out_row0[l] + (long long)d->batch * d->out_h[l] * d->out_w[l]);
-      if (hipMemsetAsync(grad_offset, 0, (size_t)orows * G * kk * 2 * 4, s) != hipSuccess)
+      if (sm_zero_async(grad_offset, (size_t)orows * G * kk * 2 * 4, s) != hipSuccess)
         return SM_ERR_LAUNCH;
     }
     if (d->kh == 3 && d->kw == 3) {               // one wave per (position, 64-channel chunk), nine taps unrolled

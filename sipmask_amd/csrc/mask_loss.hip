@@ -245,7 +245,7 @@ extern "C" int sm_mask_loss_fwd(const float* basis, int basis_hwc, const float* 
   if (st != SM_OK) return st;
   if (!bce_sum) return SM_ERR_BAD_ARG;
   if (n == 0) return SM_OK;
-  if (hipMemsetAsync(bce_sum, 0, sizeof(float) * n, sm_hip_stream(stream)) != hipSuccess) return SM_ERR_LAUNCH;
+  if (sm_zero_async(bce_sum, sizeof(float) * n, sm_hip_stream(stream)) != hipSuccess) return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(mask_loss_fwd_kernel, dim3(n, ML_CHUNKS), dim3(ML_THREADS), 0, sm_hip_stream(stream), a, bce_sum);
   SM_LAUNCH_CHECK();
   return SM_OK;
@@ -260,7 +260,7 @@ extern "C" int sm_mask_loss_bwd(const float* basis, int basis_hwc, const float* 
   if (!grad_sum) return SM_ERR_BAD_ARG;
   hipStream_t s = sm_hip_stream(stream);
   if (grad_cof && n > 0) {
-    if (hipMemsetAsync(grad_cof, 0, sizeof(float) * 128 * n, s) != hipSuccess) return SM_ERR_LAUNCH;
+    if (sm_zero_async(grad_cof, sizeof(float) * 128 * n, s) != hipSuccess) return SM_ERR_LAUNCH;
     hipLaunchKernelGGL(mask_loss_bwd_cof_kernel, dim3(n, ML_CHUNKS), dim3(ML_THREADS), 0, s, a, grad_sum, grad_cof);
   }
   if (grad_basis) {

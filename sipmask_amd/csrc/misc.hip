@@ -255,6 +255,47 @@ __global__ void offset_linear_kernel(const float* __restrict__ reg, const float*
   }
 }
 
+// Adjoint of conv_offset w.r.t. ITS WEIGHT (the box prediction it reads is detached, sipmask_head.py:50):
+// grad_w[o][c] = sum_rows gout[row][o] * reg[row][c].  Deterministic: a block reduces OFFB_ROWS rows in a fixed order into
+// partial[block][nout*4], a second launch sums the partials in block order (no float atomics).
+#define OFFB_ROWS 256
+__global__ void offset_linear_bwd_partial_kernel(const float* __restrict__ reg, int reg_cs, const float* __restrict__ gout,
+                                                 int nout, long long rows, float* __restrict__ partial) {
+  extern __shared__ float sm_off_red[];                 // [4][nout][4]
+  const int o = threadIdx.x % nout, sub = threadIdx.x / nout;       // blockDim.x = 4 * nout
+  const long long r0 = (long long)blockIdx.x * OFFB_ROWS;
+  const long long r1 = r0 + OFFB_ROWS < rows ? r0 + OFFB_ROWS : rows;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (long long r = r0 + sub; r < r1; r += 4) {
+    const float g = gout[r * nout + o];
+    const float4 v = *reinterpret_cast<const float4*>(reg + r * reg_cs);
+    a0 = fmaf(g, v.x, a0);
+    a1 = fmaf(g, v.y, a1);
+    a2 = fmaf(g, v.z, a2);
+    a3 = fmaf(g, v.w, a3);
+  }
+  float* mine = sm_off_red + ((size_t)sub * nout + o) * 4;
+  mine[0] = a0; mine[1] = a1; mine[2] = a2; mine[3] = a3;
+  __syncthreads();
+  if (sub == 0) {
+    float* dst = partial + (size_t)blockIdx.x * nout * 4 + o * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float t = sm_off_red[((size_t)0 * nout + o) * 4 + c];
+      for (int q = 1; q < 4; ++q) t += sm_off_red[((size_t)q * nout + o) * 4 + c];
+      dst[c] = t;
+    }
+  }
+}
+
+__global__ void offset_linear_bwd_final_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ gw) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float t = 0.f;
+  for (int b = 0; b < nblk; ++b) t += partial[(size_t)b * n + j];
+  gw[j] = t;
+}
+
 // ================================================================ exact-f32 plan (parity mode, conv_f32.hip)
 // NCHW f32 -> NHWC f32 (channels zero padded to cpad, multiple of 4)
 __global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW,
@@ -522,6 +563,24 @@ extern "C" int sm_offset_linear(const float* reg, int reg_cstride, const float* 
   }
   hipLaunchKernelGGL(offset_linear_kernel, dim3(grid_for(a.total * nout, 256)), dim3(256), 0, sm_hip_stream(stream),
                      reg, w_off, out, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int64_t sm_offset_linear_bwd_workspace(int64_t rows, int nout) {
+  return (int64_t)((rows + OFFB_ROWS - 1) / OFFB_ROWS) * nout * 4 * (int64_t)sizeof(float);
+}
+
+extern "C" int sm_offset_linear_bwd(const float* reg, int reg_cstride, const float* grad_out, int nout, int64_t rows,
+                                    float* workspace, float* grad_w, sm_stream_t stream) {
+  if (!reg || !grad_out || !workspace || !grad_w || rows < 1) return SM_ERR_BAD_ARG;
+  if (reg_cstride % 4 != 0 || nout < 1 || nout > 256) return SM_ERR_BAD_SHAPE;
+  const int nblk = (int)((rows + OFFB_ROWS - 1) / OFFB_ROWS);
+  hipLaunchKernelGGL(offset_linear_bwd_partial_kernel, dim3(nblk), dim3(4 * nout), sizeof(float) * 16 * nout,
+                     sm_hip_stream(stream), reg, reg_cstride, grad_out, nout, (long long)rows, workspace);
+  SM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(offset_linear_bwd_final_kernel, dim3(sm_cdiv(nout * 4, 256)), dim3(256), 0, sm_hip_stream(stream),
+                     workspace, nblk, nout * 4, grad_w);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

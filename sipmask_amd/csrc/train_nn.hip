@@ -254,7 +254,7 @@ extern "C" int sm_groupnorm_nchw_fwd(const float* x, const float* gamma, const f
   const long long m = (long long)(channels / groups) * hw;
   const int ns = gn_nsplit(batch, groups, m);
   // the (mean, rstd) buffer doubles as the partial-sum buffer of phase 1
-  if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * ng, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (sm_zero_async(stats, sizeof(float) * 2 * ng, s) != hipSuccess) return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(gn_reduce_kernel, dim3(groups, batch, ns), dim3(TN_THREADS), 0, s, x, stats, channels, hw, groups, ns);
   hipLaunchKernelGGL(gn_finish_kernel, dim3((ng + 63) / 64), dim3(64), 0, s, x, stats, stats, ng, channels, hw, groups, eps);
   const long long total = (long long)batch * channels * hw;
@@ -270,11 +270,11 @@ extern "C" int sm_groupnorm_nchw_bwd(const float* x, const float* y, const float
   if (!x || !dy || !gamma || !stats || !scratch || (relu && !y)) return SM_ERR_BAD_ARG;
   if (batch < 1 || channels < 1 || hw < 1 || groups < 1 || channels % groups != 0) return SM_ERR_BAD_SHAPE;
   hipStream_t s = sm_hip_stream(stream);
-  if (dgamma && hipMemsetAsync(dgamma, 0, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
-  if (dbeta && hipMemsetAsync(dbeta, 0, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (dgamma && sm_zero_async(dgamma, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (dbeta && sm_zero_async(dbeta, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
   // scratch f32 [batch][groups][2]: the group sums (sum gamma*dy, sum gamma*dy*xhat) between the two phases
   const int ng = batch * groups;
-  if (hipMemsetAsync(scratch, 0, sizeof(float) * 2 * ng, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (sm_zero_async(scratch, sizeof(float) * 2 * ng, s) != hipSuccess) return SM_ERR_LAUNCH;
   const int ns = gn_nsplit(batch, groups, hw);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(groups, batch, ns), dim3(TN_THREADS), 0, s, x, y, dy, gamma, stats, scratch,
                      dgamma, dbeta, channels, hw, groups, relu, ns);

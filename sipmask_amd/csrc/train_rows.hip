@@ -429,7 +429,7 @@ extern "C" int sm_weight_prep(const float* w, const float* scale, int cout, int 
   if (cout % 8 != 0 && mode != 0) return SM_ERR_UNSUPPORTED;        // 16-byte pieces along cout
   if (mode == 0 && cin_pad % 8 != 0) return SM_ERR_BAD_SHAPE;
   hipStream_t s = sm_hip_stream(stream);
-  if (hipMemsetAsync(out, 0, (size_t)rows_pad * kp * 2, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (sm_zero_async(out, (size_t)rows_pad * kp * 2, s) != hipSuccess) return SM_ERR_LAUNCH;
   const int tc = kh * kw <= 9 ? 32 : 8;               // channels per tile: the LDS tile is 32 couts x tc x (kh*kw) floats
   const size_t lds = sizeof(float) * WP_T * (tc * kh * kw + 1);
   if (lds > 64 * 1024) return SM_ERR_UNSUPPORTED;
@@ -472,7 +472,7 @@ extern "C" int sm_bias_grad_rows(const void* g, int64_t rows, int cstride, int c
   if (!g || !out || rows < 0) return SM_ERR_BAD_ARG;
   if (channels < 8 || channels % 8 != 0 || channels > 256 || cstride % 8 != 0 || cstride < channels) return SM_ERR_UNSUPPORTED;
   hipStream_t s = sm_hip_stream(stream);
-  if (hipMemsetAsync(out, 0, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (sm_zero_async(out, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
   if (rows == 0) return SM_OK;
   hipLaunchKernelGGL(bias_grad_rows_kernel, dim3((unsigned)((rows + BG_ROWS - 1) / BG_ROWS)), dim3(256), 0, s,
                      (const uint16_t*)g, out, (long long)rows, cstride, channels);
@@ -491,9 +491,9 @@ extern "C" int sm_gn_bwd_rows(const void* x, const void* dy, const float* gamma,
   const int st = gnb_fill(a, t, batch, nlev, hw, row0, channels, groups, eps, relu);
   if (st != SM_OK) return st;
   hipStream_t s = sm_hip_stream(stream);
-  if (hipMemsetAsync(bins, 0, sizeof(float) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
-  if (hipMemsetAsync(dgamma, 0, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
-  if (hipMemsetAsync(dbeta, 0, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (sm_zero_async(bins, sizeof(float) * 2 * batch * nlev * groups, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (sm_zero_async(dgamma, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
+  if (sm_zero_async(dbeta, sizeof(float) * channels, s) != hipSuccess) return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(gn_bwd_rows_reduce_kernel, dim3(t, batch), dim3(256), 0, s, (const uint16_t*)x, (const uint16_t*)dy,
                      gamma, beta, stats, bins, dgamma, dbeta, a);
   hipLaunchKernelGGL(gn_bwd_rows_apply_kernel, dim3(t, batch), dim3(256), 0, s, (const uint16_t*)x, (const uint16_t*)dy,

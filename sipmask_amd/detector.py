@@ -6,7 +6,7 @@ extract_feat + bbox_head + get_bboxes run as ONE static HIP launch plan (sipmask
 import torch
 import torch.nn as nn
 
-from . import modules, sipmask_head  # noqa: F401  (register ResNet / FPN / SipMaskHead)
+from . import benchmark_train, modules, sipmask_head  # noqa: F401  (register ResNet / FPN / SipMaskHead / FCOSSipMaskHead)
 from .fp16 import auto_fp16
 from .plan_cache import PlanCache, module_tensors
 from .registry import DETECTORS, build_backbone, build_head, build_neck
@@ -68,25 +68,14 @@ class SipMask(nn.Module):
         (SipMaskEngine(pipelined=True): no split-K, big tiles, no side lanes)."""
         import numpy as np
         from .engine import SipMaskEngine
-        if in_flight > 1:
-            from .engine import PipelinedPlan
-            ln = 1 if lanes == "auto" else lanes
-            key = ("pipelined", batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
-                   rescale, precision, ln, in_flight)
-            return self._engines.get(key, module_tensors(self), lambda: PipelinedPlan(
-                [self.prepare(batch, img_hw, img_shape, scale_factor, rescale, precision, ln, scale_factor_max, 1, slot=k + 1,
-                              pipelined=True) for k in range(in_flight)]))
-        key = (batch, tuple(img_hw), tuple(img_shape or ()), tuple(np.asarray(scale_factor, np.float64).reshape(-1)),
-               rescale, precision, lanes,
-               None if scale_factor_max is None else tuple(np.asarray(scale_factor_max, np.float64).reshape(-1))) + \
-            ((slot, bool(pipelined)) if slot else ())
-        # plans are valid for the weights they were built from: PlanCache drops them when any parameter / buffer has
-        # been updated in place since (optimizer.step, load_state_dict, mmcv load_checkpoint)
-        if lanes == "auto":        # SubBatchPlan: two concurrent half-batch chains pay off from 2 images per chain on
-            lanes = 2 if (batch >= 4 and batch % 2 == 0 and not getattr(self.bbox_head, "rescoring_flag", False)) else 1
-        assert batch % lanes == 0
+        sf_key = tuple(np.asarray(scale_factor, np.float64).reshape(-1))
+        sfm_key = None if scale_factor_max is None else tuple(np.asarray(scale_factor_max, np.float64).reshape(-1))
 
-        def build():
+        def build_plan(lanes, pipelined):
+            """one complete launch plan (uncached): a SipMaskEngine, or a SubBatchPlan of `lanes` half-batch chains"""
+            if lanes == "auto":    # SubBatchPlan: two concurrent half-batch chains pay off from 2 images per chain on
+                lanes = 2 if (batch >= 4 and batch % 2 == 0 and not getattr(self.bbox_head, "rescoring_flag", False)) else 1
+            assert batch % lanes == 0
             sd = self.state_dict()
             mk = lambda b: SipMaskEngine(sd, b, img_hw, self.backbone.depth, self.test_cfg, self.bbox_head.num_classes,
                                          strides=self.bbox_head.strides, img_shape=img_shape,
@@ -97,7 +86,20 @@ class SipMask(nn.Module):
                 return mk(batch)
             from .engine import SubBatchPlan
             return SubBatchPlan([mk(batch // lanes) for _ in range(lanes)])
-        return self._engines.get(key, module_tensors(self), build)
+
+        if in_flight > 1:
+            # ONE cache entry for the whole pipeline: its slots live inside the PipelinedPlan only (as separate entries they
+            # took in_flight + 1 places of the LRU and evicted each other -- ADVICE r3); scale_factor_max is part of the key
+            from .engine import PipelinedPlan
+            ln = 1 if lanes == "auto" else lanes
+            key = ("pipelined", batch, tuple(img_hw), tuple(img_shape or ()), sf_key, rescale, precision, ln, in_flight, sfm_key)
+            return self._engines.get(key, module_tensors(self), lambda: PipelinedPlan(
+                [build_plan(ln, True) for _ in range(in_flight)]))
+        key = (batch, tuple(img_hw), tuple(img_shape or ()), sf_key, rescale, precision, lanes, sfm_key) + \
+            ((slot, bool(pipelined)) if slot else ())
+        # plans are valid for the weights they were built from: PlanCache drops them when any parameter / buffer has
+        # been updated in place since (optimizer.step, load_state_dict, mmcv load_checkpoint)
+        return self._engines.get(key, module_tensors(self), lambda: build_plan(lanes, pipelined))
 
     def plan_for_metas(self, batch, img_hw, img_metas, rescale=False, precision="bf16", lanes="auto"):
         """The launch plan for a batch whose images carry their OWN img_shape / scale_factor (a keep_ratio pipeline:
@@ -150,6 +152,13 @@ class SipMask(nn.Module):
             ms = r["mask_scores"][0, :n].cpu().numpy()
             segm_results = (segm_results, [ms[l == i] for i in range(ncls)])
         return bbox_results, segm_results
+
+    def forward_dummy(self, img):
+        """single_stage.py:52-59 (`tools/get_flops.py`): extract_feat + bbox_head, no post-processing.  Returns the head's
+        outputs as SipMaskHead.forward does (cls_scores, bbox_preds, centernesses, cof_preds, feat_masks: NCHW views of
+        the launch plan's buffers) -- the conv-only entry SURVEY 5 recommends for a roofline run."""
+        eng = self.prepare(img.shape[0], tuple(img.shape[-2:]), lanes=1)
+        return eng.run_convs(img)
 
     def forward_test(self, imgs, img_metas, **kwargs):
         assert len(imgs) == 1, "aug test is not on the SipMask path"

@@ -107,3 +107,107 @@ def run_videos(videos, frame_fn, reset_fn, rank=None, world_size=None):
         reset_fn()
         out[vi] = [frame_fn(vi, fi, fr) for fi, fr in enumerate(videos[vi])]
     return out
+
+
+# ---- cross-rank result merge (evaluation) ------------------------------------------------------------------------
+def collect_results(local_results, size=None, order="contiguous", device=None, dst=0):
+    """Merge per-rank result lists into ONE list in dataset order on rank `dst` (None on the other ranks; dst=None: on
+    every rank) -- the reference's multi_gpu_test / collect_results (M/mmdet/apis/test.py:75-147: every rank pickles its
+    part to a shared tmpdir, rank 0 loads, zips and truncates to len(dataset)).  Here the pickles travel through ONE
+    all_gather of byte tensors (RCCL on GPUs: `device` = this rank's GPU; gloo: CPU), no filesystem.
+    order: "contiguous" = rank r owns shard_range(size, r, world) (this package's batch shard);
+           "interleaved" = rank r owns items r, r + world, ... (DistributedSampler(shuffle=False), M/tools/test.py:120-149:
+           the sampler pads the last round by repeating items, which `size` truncates, test.py:108-110).
+    `local_results` are arbitrary picklable per-image results, e.g. (bbox_results, segm_results) with RLE dicts."""
+    import pickle
+    rank, ws = world()
+    local_results = list(local_results)
+    if not _collective(ws):
+        return local_results if size is None else local_results[:size]
+    blob = torch.frombuffer(bytearray(pickle.dumps(local_results, protocol=pickle.HIGHEST_PROTOCOL)), dtype=torch.uint8)
+    dev = device or "cpu"
+    n = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    pad = torch.zeros(max(sizes), dtype=torch.uint8, device=dev)
+    pad[:blob.numel()] = blob.to(dev)
+    bufs = [torch.zeros_like(pad) for _ in range(ws)]
+    dist.all_gather(bufs, pad)
+    if dst is not None and rank != dst:
+        return None
+    parts = [pickle.loads(b[:s].cpu().numpy().tobytes()) for b, s in zip(bufs, sizes)]
+    if order == "contiguous":
+        merged = [x for p in parts for x in p]
+    elif order == "interleaved":
+        merged = []
+        for i in range(max(len(p) for p in parts)):
+            merged.extend(p[i] for p in parts if i < len(p))
+    else:
+        raise ValueError("order must be 'contiguous' or 'interleaved', got %r" % (order,))
+    return merged if size is None else merged[:size]
+
+
+# ---- CPU affinity of a rank (one process per GPU) -----------------------------------------------------------------
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def local_cpus_of_gpu(pci_bus_id, sysfs="/sys/bus/pci/devices"):
+    """CPUs of the NUMA node the GPU hangs off (`local_cpulist` of its PCI function), or None if sysfs does not say"""
+    import os
+    path = os.path.join(sysfs, pci_bus_id.lower(), "local_cpulist")
+    try:
+        with open(path) as f:
+            cpus = _parse_cpulist(f.read())
+        return cpus or None
+    except (OSError, ValueError):
+        return None
+
+
+def rank_cpu_slice(local_rank, local_world, gpu_cpus_by_rank, all_cpus):
+    """The CPUs rank `local_rank` should run on: its GPU's NUMA-local CPUs, divided evenly among the ranks whose GPUs share
+    that CPU set (so two ranks never pin themselves onto the same cores); without topology information an even
+    contiguous split of `all_cpus`.  Pure function (tested on the CPU)."""
+    mine = gpu_cpus_by_rank[local_rank] if gpu_cpus_by_rank else None
+    if not mine:
+        cpus, peers = sorted(all_cpus), list(range(local_world))
+    else:
+        allowed = set(all_cpus)
+        cpus = sorted(c for c in mine if c in allowed) or sorted(all_cpus)
+        peers = [r for r in range(local_world) if gpu_cpus_by_rank[r] and set(gpu_cpus_by_rank[r]) == set(mine)]
+    i, n = peers.index(local_rank), len(peers)
+    per = max(1, len(cpus) // n)
+    sl = cpus[i * per:(i + 1) * per] if i < n - 1 else cpus[i * per:]
+    return sl or cpus
+
+
+def pin_rank(local_rank, local_world):
+    """Pin this process (and the threads it spawns later) to CPUs next to its GPU.  The host side of a step is launch
+    enqueue + small pinned copies: on a two-socket box a rank scheduled on the far socket pays a cross-socket hop per
+    launch.  The reference leaves this to the launcher's environment (M/tools/dist_test.sh); here bench.py /
+    relaunch_with_ranks call it per rank.  Returns the CPU list (None if affinity is unsupported / SIPMASK_PIN_CPUS=0)."""
+    import os
+    if os.environ.get("SIPMASK_PIN_CPUS", "1") == "0" or not hasattr(os, "sched_setaffinity") or local_world <= 1:
+        return None
+    try:
+        all_cpus = sorted(os.sched_getaffinity(0))
+        by_rank = None
+        if torch.cuda.is_available():
+            by_rank = []
+            for r in range(local_world):
+                p = torch.cuda.get_device_properties(r) if r < torch.cuda.device_count() else None
+                bdf = None if p is None else "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0),
+                                                                   getattr(p, "pci_device_id", 0))
+                by_rank.append(local_cpus_of_gpu(bdf) if bdf else None)
+        cpus = rank_cpu_slice(local_rank, local_world, by_rank, all_cpus)
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except (OSError, RuntimeError, AttributeError):
+        return None

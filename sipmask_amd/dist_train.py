@@ -56,7 +56,16 @@ class GradBucketer:
         if self.params and self.params[0].is_cuda:
             from . import hip_ops as H
             H.GRAD_SINK.attach({p.data_ptr(): p._sm_grad_view for p in self.params
-                                if p.dtype == torch.float32 and p.is_contiguous()})
+                                if p.dtype == torch.float32 and p.is_contiguous()}, owner=self)
+            # the overlap of a bucket of directly written gradients with backward relies on the post-accumulate hook firing
+            # for a leaf whose backward op returned None (torch >= 2.1 registers the hook; verified on 2.10) -- on an older
+            # torch such buckets would silently be reduced in finish() only
+            ver = tuple(int(x) for x in torch.__version__.split("+")[0].split(".")[:2])
+            if ver < (2, 4):
+                import warnings
+                warnings.warn("GradBucketer: torch %s may not fire post-accumulate hooks for undefined gradients; buckets of "
+                              "directly written gradients are then reduced in finish() (correct, no overlap)" % torch.__version__)
+        self._zeroed = False              # zero_grad() seen since the last finish(): gradients ACCUMULATE in the views
 
     def _close(self, ps):
         n = sum(p.numel() for p in ps)
@@ -75,6 +84,7 @@ class GradBucketer:
         for b in self.buckets:
             b["flat"].zero_()
         self._seen.clear()
+        self._zeroed = True
         if self.params and self.params[0].is_cuda:
             from . import hip_ops as H
             H.GRAD_SINK.begin_step()
@@ -93,6 +103,9 @@ class GradBucketer:
         gradient straight into the view and handed autograd `None` (the hook fires for an undefined gradient as well; torch
         2.10) -- so readiness is counted here and nowhere else.  If something reset `.grad` to None meanwhile, autograd
         installed a fresh tensor: it is folded back into the view."""
+        if not self._zeroed:
+            raise RuntimeError("GradBucketer: backward without bucketer.zero_grad() at the start of the step -- the gradients "
+                               "live in the buckets and would accumulate across steps (optimizer.zero_grad() leaves them alone)")
         bi, i = self._where[id(p)]
         b = self.buckets[bi]
         v = b["views"][i]
@@ -119,13 +132,14 @@ class GradBucketer:
                 if self.world > 1:
                     b["flat"].div_(self.world)
             b["pending"], b["work"] = len(b["params"]), None
+        self._zeroed = False
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         if self.params and self.params[0].is_cuda:
             from . import hip_ops as H
-            H.GRAD_SINK.detach()
+            H.GRAD_SINK.detach(self)
         for p in self.params:
             if getattr(p, "_sm_grad_view", None) is not None:
                 p._sm_grad_view = None

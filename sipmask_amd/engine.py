@@ -353,13 +353,17 @@ class SipMaskEngine:
 
     @classmethod
     def for_head(cls, state_dict, batch, sizes, num_classes=81, strides=(8, 16, 32, 64, 128), test_cfg=None,
-                 img_shape=None, ssd_flag=False, vis=False, benchmark=None, precision="bf16"):
-        """Plan for SipMaskHead.forward / get_bboxes alone (features come from the caller)."""
+                 img_shape=None, ssd_flag=False, vis=False, benchmark=None, precision="bf16", pipelined=False):
+        """Plan for SipMaskHead.forward / get_bboxes alone (features come from the caller).  pipelined: built like a slot
+        of a PipelinedPlan (big tiles, no split-K, no side lanes) -- the head of the plan bench.py times."""
         h0, w0 = sizes[0]
         img_hw = (h0 * strides[0], w0 * strides[0])
-        return cls(state_dict, batch, img_hw, 50, test_cfg, num_classes, "cuda", strides,
-                   img_shape or (img_hw[0], img_hw[1], 3), head_sizes=list(sizes), ssd_flag=ssd_flag, vis=vis, benchmark=benchmark,
-                   precision=precision)
+        eng = cls(state_dict, batch, img_hw, 50, test_cfg, num_classes, "cuda", strides,
+                  img_shape or (img_hw[0], img_hw[1], 3), head_sizes=list(sizes), ssd_flag=ssd_flag, vis=vis, benchmark=benchmark,
+                  precision=precision, pipelined=pipelined)
+        if pipelined:
+            eng.multi_stream = False
+        return eng
 
     def load_pyramid(self, feats):
         """copy caller features (tuple of NCHW float tensors) into the bf16 pyramid tensor"""
@@ -369,6 +373,17 @@ class SipMaskEngine:
             assert tuple(f.shape) == (self.batch, 256, h, w), (tuple(f.shape), (self.batch, 256, h, w))
             to_rows = H.nchw_to_nhwc_f32 if self.pyr.dtype == torch.float32 else H.nchw_to_nhwc_bf16
             to_rows(f.detach().float().contiguous(), self.pyr[lv.row0[l]:lv.row0[l] + self.batch * h * w], 256)
+
+    POST_STEPS = ("det_select", "nms", "mask_assemble", "track_gather", "rescore")
+
+    def run_convs(self, img):
+        """extract_feat + bbox_head only (SingleStageDetector.forward_dummy, single_stage.py:52-59: the conv-only entry
+        `tools/get_flops.py` uses): every launch of the plan except post-processing.  Returns head_outputs()."""
+        assert img.shape == (self.batch, 3, self.H, self.W) and img.dtype == torch.float32 and img.is_cuda
+        self.img = img.contiguous()
+        sel = [i for i in range(len(self.steps)) if self.steps[i][0] not in self.POST_STEPS]
+        self._run_steps([self.steps[i] for i in sel], [self.lanes[i] for i in sel])
+        return self.head_outputs()
 
     def run_head(self, with_post=False):
         post = ("det_select", "nms", "mask_assemble", "track_gather", "rescore")
@@ -1076,6 +1091,18 @@ class SipMaskEngine:
         self.deform_choice = dict(kernel=pick, offsets_beyond_3px=round(far, 4), window_ms=round(t["window"], 4),
                                   gather_ms=round(t["gather"], 4))
 
+    def adopt_deform_choice(self, other):
+        """take FeatureAlign's kernel choice of another engine of the same configuration (the slots of a PipelinedPlan, the
+        chains of a SubBatchPlan): lazily prepared members see different first batches, and two kernels that agree only up
+        to accumulation order would break the slot-to-slot / cut-independent bit equality"""
+        if not getattr(self, "_deform_tune", False) or getattr(other, "deform_choice", None) is None:
+            return
+        self._deform_tune = False
+        c = self._fa_conv
+        base = c.desc.flags & ~_lib.SM_CONV_DBG_DEFORM_GATHER
+        c.desc.flags = base | (_lib.SM_CONV_DBG_DEFORM_GATHER if other.deform_choice["kernel"] == "gather" else 0)
+        self.deform_choice = dict(other.deform_choice, adopted=True)
+
     # -------------------------------------------------------------------------------- execution
     def run(self, img):
         """img: float32 NCHW [B,3,H,W] on the device.  Returns the result dict (device tensors)."""
@@ -1206,6 +1233,11 @@ class SubBatchPlan:
     def run(self, img):
         assert img.shape[0] == self.batch
         main = torch.cuda.current_stream()
+        e0 = self.engines[0]
+        if getattr(e0, "_deform_tune", False) and not torch.cuda.is_current_stream_capturing():
+            e0.run(img[:e0.batch])                      # chain 0 chooses FeatureAlign's kernel, the other chains adopt it
+            for e in self.engines[1:]:
+                e.adopt_deform_choice(e0)
         b0 = self.engines[0].batch
         for e, st in zip(self.engines[1:], self.streams):
             st.wait_stream(main)
@@ -1226,6 +1258,8 @@ class SubBatchPlan:
         for e in self.engines:
             e.multi_stream = bool(multi_stream)
             sub = img[b0:b0 + e.batch]
+            if e is not self.engines[0]:
+                e.adopt_deform_choice(self.engines[0])
             e.run(sub)                                   # eager once with this lane setting (side streams get created)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -1427,10 +1461,16 @@ class PipelinedPlan:
         self.done = [None] * self.depth
         self.next_slot = 0
         self.last_slot = None
+        self._host = {}                                    # per slot: pinned host buffers of submit(pack=True)
 
     def _prepare_slot(self, k, img):
         plan = self.plans[k]
         static = img.clone()
+        if k > 0 and self.static[0] is None:               # slot 0 chooses FeatureAlign's kernel for every slot
+            self._prepare_slot(0, img)
+        if k > 0:
+            for a, b in zip(getattr(plan, "engines", [plan]), getattr(self.plans[0], "engines", [self.plans[0]])):
+                a.adopt_deform_choice(b)
         plan.run(static)                                   # eager once: lazy buffers, the deformable-kernel choice
         torch.cuda.synchronize(self.device)
         if self.use_graph:
@@ -1452,8 +1492,14 @@ class PipelinedPlan:
                 self._prepare_slot(k, img)
         return self
 
-    def submit(self, img):
-        """enqueue one step on the next slot (after whatever produced `img` on the caller's stream); returns the slot"""
+    def submit(self, img, img_metas=None, pack=False, canvas_hw=None):
+        """enqueue one step on the next slot (after whatever produced `img` on the caller's stream); returns the slot.
+        img_metas: this BATCH's per-image img_shape / scale_factor -- written into the slot's own device tables on the
+        slot's stream, i.e. behind the slot's previous step and in front of this one (the other slots, whose steps may
+        still be in flight, keep the metas they were submitted with; the reference reads img_metas per batch,
+        sipmask_head.py:517-541).  pack=True: result packing rides on the slot's stream behind the step (sm_mask_rects +
+        sm_rle_encode, then the boxes / labels / counts / RLE strings go to pinned host buffers asynchronously): fetch(slot)
+        returns them (sipmask_head.py:645-662, M/mmdet/apis/test.py:12-72 return results per batch)."""
         assert img.shape[0] == self.batch
         k = self.next_slot
         if self.static[k] is None:
@@ -1461,17 +1507,74 @@ class PipelinedPlan:
         st = self.streams[k]
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
+            if img_metas is not None:
+                self.plans[k].set_image_metas(img_metas)
             self.static[k].copy_(img, non_blocking=True)
             if self.graphs[k] is not None:
                 self.graphs[k].replay()
             else:
                 self.plans[k].run(self.static[k])
+            if pack:
+                self._pack(k, canvas_hw)
             ev = torch.cuda.Event()
             ev.record(st)
         self.done[k] = ev
         self.last_slot = k
         self.next_slot = (k + 1) % self.depth
         return k
+
+    # RLE strings of one batch that travel with the first (asynchronous) copy; a batch with longer strings pays a second,
+    # synchronous copy in fetch()
+    PACK_PREFIX_BYTES = 4 << 20
+
+    def _pack(self, k, canvas_hw):
+        """on the slot's stream, behind its step: device-side RLE of the step's masks + asynchronous D2H of everything the
+        caller's evaluation loop consumes (boxes, labels, counts, run counts, string offsets, a prefix of the strings)"""
+        plan = self.plans[k]
+        if hasattr(plan, "engines"):
+            raise NotImplementedError("submit(pack=True): single-chain slots (det.prepare(..., in_flight=N) builds them)")
+        rle = plan.encode_rle(canvas_hw, fetch=False)
+        if not isinstance(rle, dict):
+            raise NotImplementedError("submit(pack=True): one mask geometry per batch (per-image canvases: encode_rle(slot=k))")
+        hb = self._host.get(k)
+        if hb is None:
+            pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            o = plan.nms_out
+            hb = self._host[k] = dict(det=pin(o["det"]), labels=pin(o["labels"]), ndet=pin(o["ndet"]), nruns=pin(rle["nruns"]),
+                                      offsets=pin(rle["offsets"]),
+                                      packed=torch.empty(min(self.PACK_PREFIX_BYTES, rle["packed"].numel()), dtype=torch.uint8,
+                                                         pin_memory=True))
+        o = plan.nms_out
+        for name, src in (("det", o["det"]), ("labels", o["labels"]), ("ndet", o["ndet"]), ("nruns", rle["nruns"]),
+                          ("offsets", rle["offsets"])):
+            hb[name].copy_(src, non_blocking=True)
+        hb["packed"].copy_(rle["packed"][:hb["packed"].numel()], non_blocking=True)
+        hb["canvas"] = tuple(canvas_hw or plan.img_shape[:2])
+        hb["rle"] = rle
+
+    def fetch(self, slot=None):
+        """the packed results of a step submitted with pack=True: blocks the HOST until that step (and its copies) are done,
+        returns per image (det_bboxes [n,5] ndarray, det_labels [n] ndarray, [RLE dict] * n).  Call it before `depth`
+        further submits reuse the slot."""
+        k = self.last_slot if slot is None else slot
+        self.done[k].synchronize()
+        hb = self._host[k]
+        nruns, offs = hb["nruns"].numpy(), hb["offsets"].numpy()
+        if (nruns < 0).any():
+            raise RuntimeError("sm_rle_encode: max_runs too small, a mask needs %d runs" % (-nruns.min()))
+        total = int(offs[-1])
+        blob = hb["packed"][:min(total, hb["packed"].numel())].numpy().tobytes()
+        if total > hb["packed"].numel():        # rare: longer strings than the prefix that travelled with the step
+            blob += hb["rle"]["packed"][hb["packed"].numel():total].cpu().numpy().tobytes()
+        plan = self.plans[k]
+        size = [int(hb["canvas"][0]), int(hb["canvas"][1])]
+        out, mx = [], plan.max_num
+        nd = hb["ndet"].numpy()
+        for b in range(self.batch):
+            n = int(nd[b])
+            out.append((hb["det"][b, :n].numpy().copy(), hb["labels"][b, :n].numpy().copy(),
+                        [dict(size=list(size), counts=blob[offs[b * mx + i]:offs[b * mx + i + 1]]) for i in range(n)]))
+        return out
 
     def results(self, slot=None):
         """the step's outputs, valid in the caller's stream order (the caller's stream waits for the slot)"""
@@ -1480,17 +1583,28 @@ class PipelinedPlan:
             torch.cuda.current_stream().wait_event(self.done[k])
         return self.plans[k].results()
 
+    @property
+    def out_hw(self):
+        """(Ho, Wo) of every image of the LAST submitted step (each slot keeps the metas it was submitted with)"""
+        return self.plans[self.last_slot if self.last_slot is not None else 0].out_hw
+
     def join(self):
         for ev in self.done:
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
         return self
 
-    def run(self, img):
+    def run(self, img, img_metas=None):
         """one step, start to finish (the plain plan interface)"""
-        return self.results(self.submit(img))
+        return self.results(self.submit(img, img_metas))
 
     def set_image_metas(self, img_metas):
+        """default metas of EVERY slot (e.g. right after prepare()).  Steps still in flight read their slot's tables, so all
+        slots are joined first; per-batch metas belong in submit(img, img_metas) (the tables of a slot must
+        never change under a step in flight)."""
+        for ev in self.done:
+            if ev is not None:
+                ev.synchronize()
         for p in self.plans:
             p.set_image_metas(img_metas)
         return self

@@ -316,6 +316,21 @@ def offset_linear(reg, reg_cstride, w_off, lv, out, level_scale=None):
     return out
 
 
+def offset_linear_bwd(reg, reg_cstride, grad_out, out=None):
+    """grad of FeatureAlign.conv_offset's weight: [nout, 4] = grad_out^T [nout, rows] . reg[:, :4] (sm_offset_linear_bwd;
+    deterministic two-pass reduction on the device -- replaces the ATen matmul backward = a vendor GEMM)"""
+    lib = _lib.load()
+    _lib.require_cuda(reg, grad_out)
+    rows, nout = grad_out.shape
+    assert grad_out.dtype == torch.float32 and reg.dtype == torch.float32 and grad_out.is_contiguous()
+    ws = torch.empty(int(lib.sm_offset_linear_bwd_workspace(rows, nout)) // 4, dtype=torch.float32, device=reg.device)
+    if out is None:
+        out = torch.empty(nout, 4, dtype=torch.float32, device=reg.device)
+    _lib.check(lib.sm_offset_linear_bwd(_lib.ptr(reg), reg_cstride, _lib.ptr(grad_out), nout, rows, _lib.ptr(ws),
+                                        _lib.ptr(out), _lib.stream_ptr()), "sm_offset_linear_bwd")
+    return out
+
+
 def bottleneck_tail(batch, h, w, channels, x, w2, b2, w3, b3, identity, y, w1_next=None, b1_next=None, t1_next=None):
     """conv2 + conv3 (+ the next block's conv1) of a ResNet bottleneck as one launch (resnet.py:167-200); weights in
     the prep_conv_weight layout ([cout][K], K = (kh, kw, cin)), bf16 rows, f32 biases"""
@@ -990,12 +1005,28 @@ class _GradSink:
     def __init__(self):
         self.detach()
 
-    def detach(self):
-        self.views, self.uses, self.direct, self.written, self.census = {}, {}, set(), set(), True
+    def detach(self, owner=None):
+        """owner None: forget everything; else only the views that `owner` (a GradBucketer) attached -- a second bucketer's
+        attach() or remove() must not take the first one's views away"""
+        if owner is None or not getattr(self, "owners", None):
+            self.views, self.uses, self.direct, self.written, self.census, self.owners = {}, {}, set(), set(), True, {}
+            return
+        for k in self.owners.pop(id(owner), ()):
+            self.views.pop(k, None)
+            self.uses.pop(k, None)
+            self.direct.discard(k)
+            self.written.discard(k)
 
-    def attach(self, views):
-        self.detach()
-        self.views = dict(views)
+    def attach(self, views, owner=None):
+        """register `views` {param.data_ptr(): gradient view}; views of other owners stay (a fresh census covers all)"""
+        views = dict(views)
+        if owner is None:
+            self.detach()
+        else:
+            self.detach(owner)
+            self.owners[id(owner)] = list(views.keys())
+        self.views.update(views)
+        self.uses, self.direct, self.census = {}, set(), True
 
     def begin_step(self):
         if self.census and self.uses:

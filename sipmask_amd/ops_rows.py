@@ -277,6 +277,37 @@ def deform_conv_rows(x, lv, offset, weight, bias=None, pad=1, dil=1, deformable_
     return DeformConvRowsFunction.apply(x, offset, weight, bias, scale, (lv, pad, dil, deformable_groups, relu))
 
 
+class OffsetLinearRowsFunction(Function):
+    """FeatureAlign.conv_offset on rows (sipmask_head.py:30-33,50): offset [rows, nout] = box [rows, 4] . W^T, a 1x1 conv
+    without bias of the DETACHED box prediction -- only the weight receives a gradient.  Forward = the inference plan's
+    sm_offset_linear, backward = sm_offset_linear_bwd (deterministic two-pass reduction); the torch matmul this replaces
+    put a vendor GEMM (K = every position of the pyramid) on the training path."""
+
+    @staticmethod
+    def forward(ctx, box, w_off, lv):
+        _need_cuda(box)
+        box = box.detach()
+        if box.dtype != torch.float32 or not box.is_contiguous() or box.shape[1] % 4 != 0 or box.shape[0] != lv.rows:
+            raise NotImplementedError("offset_linear_rows: contiguous f32 rows [lv.rows, 4k]")
+        w = w_off.detach().float().contiguous()
+        out = torch.empty(lv.rows, w.shape[0], dtype=torch.float32, device=box.device)
+        H.offset_linear(box, box.shape[1], w, lv, out)
+        ctx.save_for_backward(box)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (box,) = ctx.saved_tensors
+        gw = H.offset_linear_bwd(box, box.shape[1], gout.float().contiguous()) if ctx.needs_input_grad[1] else None
+        return None, gw, None
+
+
+def offset_linear_rows(box, w_off, lv):
+    """box f32 [rows, 4] (no gradient flows into it), w_off f32 [nout, 4] -> offsets f32 [rows, nout]"""
+    return OffsetLinearRowsFunction.apply(box, w_off, lv)
+
+
 class MaskFeatRowsFunction(Function):
     """[level 0 | bilinear x2 of level 1 | bilinear x4 of level 2] of a pyramid row tensor as one [B*H0*W0, 3c] matrix
     (sipmask_head.py:266-275: the feat_masks list the mask branch concatenates); the upsampling kernel writes straight

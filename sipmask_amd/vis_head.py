@@ -50,9 +50,19 @@ class SipMaskVISHead(SipMaskHead):
             st["count"].zero_()
 
     def _tracker(self, device, max_num):
+        """the device object memory, sized ONCE for the most detections a frame can bring (64 = the clip kernel's limit: one
+        wave per detection, sm_track_clip).  A later frame with more detections than an earlier one must not empty the
+        memory mid-video: if the state ever has to grow or move, the tracked objects are carried over."""
+        if max_num > 64:
+            raise ValueError("the device tracker handles at most 64 detections per frame (test_cfg.max_per_img = %d; the "
+                             "reference VIS configs use 10)" % max_num)
         st = getattr(self, "_trk", None)
         if st is None or st["feats"].device != device or st["max_num"] < max_num:
-            st = self._trk = H.track_state_alloc(512, max(max_num, 16), device)
+            new = H.track_state_alloc(512, 64, device)
+            if st is not None:                           # carry the memory over (same video, larger frame / other device)
+                for k in ("feats", "boxes", "labels", "count"):
+                    new[k].copy_(st[k])
+            st = self._trk = new
         return st
 
     def _mem(self, key):

@@ -242,3 +242,61 @@ def test_bench_self_launches_its_ranks_cpu_stub():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env1, capture_output=True,
                        text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+# ---- cross-rank result merge (M/mmdet/apis/test.py:75-147) -------------------------------------------------------------
+def _collect_worker(rank, ws, port, out):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from sipmask_amd.dist_shard import collect_results
+    n = 7                                                # odd: the ranks own 4 and 3 images
+    mk = lambda i: (np.full((i % 3, 5), float(i), np.float32), [dict(size=[8, 9], counts=bytes([65 + i] * (i + 1)))] * (i % 3))
+    lo, hi = shard_range(n, rank, ws)
+    a = collect_results([mk(i) for i in range(lo, hi)], size=n)                     # contiguous shard, rank 0 only
+    b = collect_results([mk(i) for i in range(lo, hi)], size=n, dst=None)           # ... on every rank
+    # DistributedSampler(shuffle=False) order: rank r owns r, r + ws, ...; the sampler pads the last round by repeating
+    idx = list(range(n)) + list(range((-n) % ws))
+    c = collect_results([mk(i) for i in idx[rank::ws]], size=n, order="interleaved", dst=None)
+    ok = lambda res: res is not None and len(res) == n and all(
+        float(r[0].sum()) == float(mk(i)[0].sum()) and r[0].shape == mk(i)[0].shape and r[1] == mk(i)[1] for i, r in enumerate(res))
+    out[rank] = (a is None, a is not None and ok(a), ok(b), ok(c))
+    dist.destroy_process_group()
+
+
+def test_collect_results_merges_in_dataset_order_world2():
+    ws = 2
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_collect_worker, args=(ws, port, out), nprocs=ws, join=True)
+        r0, r1 = out[0], out[1]
+    assert r0 == (False, True, True, True)            # rank 0 holds the merged list (boxes + RLE dicts, dataset order)
+    assert r1 == (True, False, True, True)            # dst=0: the other rank gets None; dst=None: every rank gets it
+
+
+def test_collect_results_single_process_passthrough():
+    from sipmask_amd.dist_shard import collect_results
+    assert collect_results([1, 2, 3], size=2) == [1, 2]
+
+
+def test_rank_cpu_slices_are_disjoint_and_numa_local(tmp_path):
+    from sipmask_amd.dist_shard import local_cpus_of_gpu, rank_cpu_slice, _parse_cpulist
+    assert _parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    d = tmp_path / "0000:05:00.0"
+    d.mkdir()
+    (d / "local_cpulist").write_text("0-15,64-79\n")
+    assert local_cpus_of_gpu("0000:05:00.0", str(tmp_path)) == list(range(16)) + list(range(64, 80))
+    assert local_cpus_of_gpu("0000:06:00.0", str(tmp_path)) is None
+    # 8 ranks, GPUs 0-3 on socket 0 (CPUs 0-31), 4-7 on socket 1 (32-63): every rank gets 8 CPUs of ITS socket, all disjoint
+    s0, s1 = list(range(32)), list(range(32, 64))
+    by_rank = [s0] * 4 + [s1] * 4
+    sl = [rank_cpu_slice(r, 8, by_rank, range(64)) for r in range(8)]
+    assert all(len(s) == 8 for s in sl) and len(set(c for s in sl for c in s)) == 64
+    assert all(set(sl[r]) <= set(by_rank[r]) for r in range(8))
+    # no topology information: an even contiguous split
+    sl = [rank_cpu_slice(r, 4, None, range(10)) for r in range(4)]
+    assert [len(s) for s in sl] == [2, 2, 2, 4] and sorted(c for s in sl for c in s) == list(range(10))
+    # a cgroup that hides a GPU's local CPUs: fall back to what the process may use
+    assert rank_cpu_slice(0, 2, [[100, 101], [100, 101]], range(4)) == [0, 1]

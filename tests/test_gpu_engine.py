@@ -359,3 +359,80 @@ def test_mixed_size_batch_reads_img_shape_and_scale_factor_per_image(rescale):
     small = det.prepare(3, tuple(batch.shape[-2:]), None, max(sfs) * 1.5, rescale)
     with pytest.raises(ValueError):
         small.set_image_metas(metas)
+
+
+def test_pipelined_submit_packs_results_and_keeps_metas_per_slot():
+    """PipelinedPlan.submit(img, img_metas, pack=True) / fetch (round 4):
+    (1) result packing behind every step on the slot's stream (sm_mask_rects + sm_rle_encode + asynchronous copies into
+        pinned buffers) returns per image exactly what the single plan's results() + encode_rle() give
+        (sipmask_head.py:645-662: boxes, labels, one RLE dict per detection);
+    (2) img_metas travel with the SUBMIT: consecutive batches with different img_shape / scale_factor are in flight at the
+        same time and every step is post-processed with its own metas (set_image_metas used to rewrite the
+        tables of every slot at once, under steps still running)."""
+    from sipmask_amd.synthetic import build_synthetic_detector
+    det = build_synthetic_detector(50, seed=0)
+    with torch.no_grad():
+        det.bbox_head.fcos_cls.bias.fill_(-2.0)
+    g = torch.Generator().manual_seed(23)
+    H_, W_ = 192, 256
+    batches = [torch.randn(2, 3, H_, W_, generator=g).cuda() for _ in range(4)]
+    # two meta sets: full-size images, and images whose valid area is smaller (boxes clamp to img_shape)
+    metas = [[dict(img_shape=(H_, W_, 3), scale_factor=1.0)] * 2,
+             [dict(img_shape=(150, 200, 3), scale_factor=1.0), dict(img_shape=(176, 230, 3), scale_factor=1.0)]]
+    one = det.prepare(2, (H_, W_), (H_, W_, 3), lanes=1)
+    want = []
+    for i, b in enumerate(batches):
+        one.set_image_metas(metas[i % 2])
+        r = one.run(b)
+        torch.cuda.synchronize()
+        rle = one.encode_rle((H_, W_))
+        nd = r["ndet"].cpu().tolist()
+        want.append([(r["det_bboxes"][k, :nd[k]].cpu().numpy().copy(), r["det_labels"][k, :nd[k]].cpu().numpy().copy(), rle[k])
+                     for k in range(2)])
+    assert sum(len(w[2]) for ws in want for w in ws) > 0
+    # the two meta sets do change the outcome (otherwise the test would not see a mix-up)
+    one.set_image_metas(metas[0])
+    r = one.run(batches[1])
+    torch.cuda.synchronize()
+    assert not np.array_equal(r["det_bboxes"][0, :int(r["ndet"][0])].cpu().numpy(), want[1][0][0])
+    pipe = det.prepare(2, (H_, W_), (H_, W_, 3), in_flight=3)
+    got, pending = [], []
+    order = [0, 1, 2, 3, 1, 0, 3, 2, 0, 1]
+    for bi in order:
+        k = pipe.next_slot
+        if any(s == k for s, _ in pending):
+            s0, b0 = pending.pop(0)
+            assert s0 == k
+            got.append((b0, pipe.fetch(s0)))
+        pending.append((pipe.submit(batches[bi], img_metas=metas[bi % 2], pack=True, canvas_hw=(H_, W_)), bi))
+    for s0, b0 in pending:
+        got.append((b0, pipe.fetch(s0)))
+    assert len(got) == len(order)
+    for bi, res in got:
+        for k in range(2):
+            np.testing.assert_array_equal(res[k][0], want[bi][k][0])
+            np.testing.assert_array_equal(res[k][1], want[bi][k][1])
+            assert res[k][2] == want[bi][k][2], (bi, k)
+    assert pipe.out_hw == pipe.plans[pipe.last_slot].out_hw
+
+
+def test_forward_dummy_returns_the_head_outputs(setup):
+    """SingleStageDetector.forward_dummy (single_stage.py:52-59): extract_feat + bbox_head without post-processing, the five
+    output lists of SipMaskHead.forward -- the same tensors the full plan computes on the same image."""
+    from sipmask_amd.synthetic import build_synthetic_detector
+    det = build_synthetic_detector(50, seed=0)
+    img = torch.randn(2, 3, 128, 160, generator=torch.Generator().manual_seed(5)).cuda()
+    outs = det.forward_dummy(img)
+    torch.cuda.synchronize()
+    assert len(outs) == 5 and [len(o) for o in outs[:4]] == [5] * 4
+    assert tuple(outs[0][0].shape) == (2, 80, 16, 20) and tuple(outs[3][0].shape) == (2, 128, 16, 20)
+    assert tuple(outs[4].shape) == (2, 32, 64, 80)
+    got = [[t.clone() for t in o] for o in outs[:4]] + [outs[4].clone()]
+    eng = det.prepare(2, (128, 160), lanes=1)
+    eng.run(img)
+    torch.cuda.synchronize()
+    ref = eng.head_outputs()
+    for a, b in zip(got[:4], ref[:4]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert torch.equal(got[4], ref[4])

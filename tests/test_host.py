@@ -381,3 +381,30 @@ def test_training_rows_pick_the_big_tile_for_wide_pyramid_convs():
     assert R._big_tile_flags(3, 1, 256, 20000) == 0          # short position axis: the library's own rule
     assert R._big_tile_flags(1, 1, 256, 89600) == 0 and R._big_tile_flags(3, 2, 256, 89600) == 0
     assert R._big_tile_flags(3, 1, 208, 89600) == 0          # couts that do not fill the 256-wide tile
+
+
+def test_fcos_sipmask_head_alias_builds_from_cfg():
+    """north_star names two registry entries, "SipMaskHead / FCOSSipMaskHead"; the second denotes the FCOS-style head of the
+    maskrcnn-benchmark variant (B/fcos_core/modeling/rpn/sipmask/sipmask.py:48-190): an mmdet-style cfg dict
+    builds it with B/'s parameter names, and the detector exposes forward_dummy (single_stage.py:52-59)."""
+    import sipmask_amd.detector as D
+    from sipmask_amd.benchmark_train import SipMaskBenchmarkHead
+    from sipmask_amd.registry import HEADS, build_head
+    assert {"SipMaskHead", "FCOSSipMaskHead"} <= set(HEADS.module_dict)
+    h = build_head(dict(type="FCOSSipMaskHead", num_classes=81, in_channels=256, stacked_convs=4, feat_channels=256,
+                        strides=[8, 16, 32, 64, 128]))
+    assert isinstance(h, SipMaskBenchmarkHead) and h.fpn_strides == (8, 16, 32, 64, 128)
+    keys = set(h.state_dict())
+    # B/ names: towers as Sequential(conv, GN, ReLU) x N with conv bias, cls_logits / bbox_pred / centerness, 5 Scales
+    assert {"cls_tower.0.weight", "cls_tower.0.bias", "cls_tower.7.weight", "bbox_tower.10.bias", "cls_logits.bias",
+            "bbox_pred.weight", "centerness.weight", "scales.4.scale", "feat_align.conv_adaption.bias",
+            "sip_cof.weight", "sip_mask_lat0.weight"} <= keys
+    assert "cls_tower.9.weight" not in keys and "bbox_tower.9.weight" in keys          # cls tower: one conv fewer
+    b = build_head(dict(type="FCOSSipMaskHead", num_convs=2, fpn_strides=(8, 16, 32, 64, 128)))
+    assert "bbox_tower.3.weight" in b.state_dict() and "bbox_tower.6.weight" not in b.state_dict()
+    import pytest
+    with pytest.raises(ValueError):
+        build_head(dict(type="FCOSSipMaskHead", num_convs=2, stacked_convs=4))
+    with pytest.raises(TypeError):
+        build_head(dict(type="FCOSSipMaskHead", loss_cls=dict(type="FocalLoss")))
+    assert callable(getattr(D.SipMask, "forward_dummy"))
