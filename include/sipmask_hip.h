@@ -123,6 +123,10 @@ typedef struct {
                                    * multiplied BEFORE bias / Scale / ReLU.  The x3 plan stores weights multiplied by a
                                    * power of two (so that the low half of a ~1e-2 weight stays out of binary16's
                                    * subnormals) and passes the inverse here -- exact. */
+  /* per-LEVEL weights (sm_conv3x3_patch only): != 0 -> level l uses the weight matrix at w + l*w_level_stride elements
+   * and the bias at bias + l*bias_level_stride floats -- levels of one launch that do NOT share weights: the FPN's three
+   * output 3x3 convs (fpn.py:154-157: fpn_convs[i] on the i-th merged lateral) as ONE launch.  0 = shared (towers). */
+  int64_t w_level_stride, bias_level_stride;
 } sm_conv_desc;
 
 int sm_version(void);

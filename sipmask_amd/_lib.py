@@ -49,6 +49,7 @@ class ConvDesc(C.Structure):
         ("ngroups", C.c_int32), ("x_group_rows", C.c_int64), ("y_group_rows", C.c_int64), ("w_group_stride", C.c_int64),
         ("bias_group_stride", C.c_int64), ("gn_group_stride", C.c_int64),
         ("acc_scale", C.c_float),
+        ("w_level_stride", C.c_int64), ("bias_level_stride", C.c_int64),
     ]
 
 

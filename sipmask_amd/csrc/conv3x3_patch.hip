@@ -65,6 +65,7 @@ struct PatchArgs {
   int prow_cap;                   // rows of one patch buffer (multiple of 16)
   int ngroups, tpg[2];
   long long x_grows, y_grows, w_gstride, b_gstride, gn_gstride;
+  long long w_lstride, b_lstride;  // per-level weights / bias (0 = the levels share them)
 };
 
 template <int N, typename F, int... Is>
@@ -155,7 +156,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   for (int i = 0; i < WPW; ++i) {
     const int row = (wave * WPW + i) * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    wsrc[i] = a.w + grp * a.w_gstride + (long long)(nt * PT_BCO + row) * a.Kp + chunk * 8;
+    wsrc[i] = a.w + grp * a.w_gstride + lev * a.w_lstride + (long long)(nt * PT_BCO + row) * a.Kp + chunk * 8;
   }
   auto dma_w = [&](int stage, int buf) {            // weight stage `stage` (K steps 2*stage, 2*stage+1) -> Wb[buf]
     unsigned char* dst = Wb0 + buf * PT_WSTAGE;
@@ -418,7 +419,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
 
   // ---- epilogue (register epilogue of conv_igemm.hip): lanes i / i+32 swap 4-cout groups -> 8 consecutive couts
   const float lscale = a.level_scale[lev];
-  const float* const biasp = a.bias != nullptr ? a.bias + grp * a.b_gstride : nullptr;
+  const float* const biasp = a.bias != nullptr ? a.bias + grp * a.b_gstride + lev * a.b_lstride : nullptr;
   unsigned long long* const gnp = a.gn_stats != nullptr ? a.gn_stats + grp * a.gn_gstride : nullptr;
   const bool out_f32 = a.flags & SM_CONV_OUT_F32;
   const long long out_img_row0 = a.out_row0[lev] + grp * a.y_grows + (long long)n * H * W;
@@ -757,6 +758,8 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   a.w_gstride = d->w_group_stride;
   a.b_gstride = d->bias_group_stride;
   a.gn_gstride = d->gn_group_stride;
+  a.w_lstride = d->w_level_stride;
+  a.b_lstride = d->bias_level_stride;
   const long long nb0 = (long long)t0 * a.ntn * a.ngroups, nb1 = (long long)t1 * a.ntn * a.ngroups;
   if (nb0 != ps.nbig || nb1 != ps.nsmall) return SM_ERR_BAD_SHAPE;       // planner / table mismatch: a bug, not a shape
   a.nblk[0] = (int)nb0;

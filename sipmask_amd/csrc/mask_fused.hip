@@ -22,11 +22,16 @@
 namespace {
 
 constexpr int MF_THREADS = 256;
-constexpr int MF_TW = 128, MF_TH = 8;    // output tile (pixels): stores cover whole 128-byte lines
+// Output tile: 128 pixels wide (stores cover whole 128-byte lines) x `th` rows, th in {64, 32, 16, 8} = the tallest whose
+// LDS tiles fit (mask_lo_caps).  Round 4: the first version used 8-row tiles, and with 100 image-sized boxes per image (the
+// worst case a batch can bring) it spent 3.1 ms per 4-image step = 1.7 % of the HBM roof: an 8-row tile reads a 7-row
+// probability window and a 4-5-row conv-resolution window for ONE useful conv-resolution row, pays 5 barriers, a binary
+// search and a coefficient load per 1 024 pixels.  A 64-row tile amortises all of that over 8 192 pixels.
+constexpr int MF_TW = 128, MF_TH_MAX = 64;
 // The LDS tiles of one output tile -- its mask-resolution source window and the conv-resolution window under that --
 // are DYNAMIC shared memory sized by the launch's up_scale (a keep_ratio COCO resize gives scale_factor 1.6-2.7, i.e.
 // up_scale = 2 / scale_factor down to 0.74: a 128x8 output tile then reads a 176x13 source window)
-constexpr int MF_DYN_LDS_MAX = 40 * 1024;   // bytes of dynamic LDS a launch may ask for (beside 17 KB static)
+constexpr int MF_DYN_LDS_MAX = 44 * 1024;   // bytes of dynamic LDS a launch may ask for (beside 17 KB static)
 constexpr int MF_MAX_ENTRIES = 4096;     // 2 * batch * max_num work-list entries (prefix copy lives in LDS)
 
 struct MaskFArgs {
@@ -36,7 +41,8 @@ struct MaskFArgs {
   const float* det;
   const int32_t* ndet;
   uint8_t* masks;
-  int32_t* state;          // [B*max_num][4] tile range written by the previous call (tx0, ty0, tx1, ty1), exclusive end
+  int32_t* state;          // [B*max_num][4] PIXEL rectangle written by the previous call (x0, y0, x1, y1), exclusive end
+  int th;                  // tile height of this launch (rows)
   int32_t* ranges;         // workspace [B*max_num][8]: new range, previous range
   int32_t* prefix;         // workspace [2*B*max_num + 1]
   int batch, kmax, max_num, lo_h, lo_w, factor, hm, wm, ho, wo, pitch;
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(1024) void mask_plan_kernel(const MaskFArgs a) {
   const int nslot = a.batch * a.max_num;
   const int n2 = 2 * nslot;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int ntx = (a.wo + MF_TW - 1) / MF_TW, nty = (a.ho + MF_TH - 1) / MF_TH;
+  const int ntx = (a.wo + MF_TW - 1) / MF_TW, nty = (a.ho + a.th - 1) / a.th;
   if (tid == 0) {
     s_carry = 0;
     a.prefix[0] = 0;
@@ -84,9 +90,17 @@ __global__ __launch_bounds__(1024) void mask_plan_kernel(const MaskFArgs a) {
     if (e < n2) {
       const int d = e >> 1;
       int r[4];
+      int pxr[4] = {0, 0, 0, 0};                 // the pixel rectangle behind r (new rectangle: next call's state)
       if (e & 1) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = a.state[d * 4 + k];
+        for (int k = 0; k < 4; ++k) pxr[k] = a.state[d * 4 + k];
+        r[0] = r[1] = r[2] = r[3] = 0;
+        if (pxr[2] > pxr[0] && pxr[3] > pxr[1]) {
+          r[0] = pxr[0] / MF_TW;
+          r[1] = pxr[1] / a.th;
+          r[2] = min((pxr[2] + MF_TW - 1) / MF_TW, ntx);
+          r[3] = min((pxr[3] + a.th - 1) / a.th, nty);
+        }
       } else {
         const int b = d / a.max_num, i = d - b * a.max_num;
         r[0] = r[1] = r[2] = r[3] = 0;
@@ -101,11 +115,16 @@ __global__ __launch_bounds__(1024) void mask_plan_kernel(const MaskFArgs a) {
           const int px1 = min(hi(x2, G.up_x), G.wo), py1 = min(hi(y2, G.up_y), G.ho);
           if (px1 > px0 && py1 > py0) {
             r[0] = px0 / MF_TW;
-            r[1] = py0 / MF_TH;
+            r[1] = py0 / a.th;
             r[2] = min((px1 + MF_TW - 1) / MF_TW, ntx);
-            r[3] = min((py1 + MF_TH - 1) / MF_TH, nty);
+            r[3] = min((py1 + a.th - 1) / a.th, nty);
+            // what the tiles of this rectangle cover, in pixels: the state of the next call (any tile height)
+            pxr[0] = r[0] * MF_TW, pxr[1] = r[1] * a.th, pxr[2] = min(r[2] * MF_TW, a.wo), pxr[3] = min(r[3] * a.th, a.ho);
           }
         }
+        // (stashed behind the prefix array; copied into the state after every entry has read the old one)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.prefix[n2 + 1 + d * 4 + k] = pxr[k];
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) a.ranges[d * 8 + (e & 1) * 4 + k] = r[k];
@@ -128,10 +147,10 @@ __global__ __launch_bounds__(1024) void mask_plan_kernel(const MaskFArgs a) {
     if (tid == 1023) s_carry = carry + woff + v;
     __syncthreads();
   }
-  // the new ranges become the state of the next call (read above, so no race inside this single block)
+  // the new rectangles become the state of the next call (the old ones were read above: single block, barriers in between)
   for (int d = tid; d < nslot; d += 1024) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a.state[d * 4 + k] = a.ranges[d * 8 + k];
+    for (int k = 0; k < 4; ++k) a.state[d * 4 + k] = a.prefix[n2 + 1 + d * 4 + k];
   }
 }
 
@@ -139,14 +158,24 @@ struct FBox {
   float x1, y1, x2, y2, rw, rh;
 };
 
+// fast sigmoid of the mask path: v_exp_f32 / v_rcp_f32 (absolute error < 1e-6 on the probability for |x| < 40; the masks
+// are held to the oracle away from |up - thr| < 1e-5, tests/test_gpu_kernels.py).  Rankings use sigmoid_rank (common.h).
+__device__ __forceinline__ float mf_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+
 __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs a) {
   __shared__ int s_prefix[MF_MAX_ENTRIES + 1];
   __shared__ __attribute__((aligned(16))) float s_cof[128];
+  // per-tile coordinate tables: output column / row -> (first source index relative to the window, fraction)
+  __shared__ int s_cx0[MF_TW];
+  __shared__ float s_clx[MF_TW];
+  __shared__ int s_ry0[MF_TH_MAX];
+  __shared__ float s_rly[MF_TH_MAX];
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float* const s_lo_base = s_dyn;                     // [4][lo_cap] quadrant logits at conv resolution
   float* const s_prob = s_dyn + 4 * a.lo_cap;         // [src_cap] probabilities at mask resolution
   const int tid = threadIdx.x;
   const int n2 = 2 * a.batch * a.max_num;
+  const int TH = a.th;
   for (int i = tid; i <= n2; i += MF_THREADS) s_prefix[i] = a.prefix[i];
   __syncthreads();
   const int total = s_prefix[n2];
@@ -164,13 +193,13 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
     const int r0 = rg[kind * 4 + 0], r1 = rg[kind * 4 + 1], r2 = rg[kind * 4 + 2];
     const int t = w - s_prefix[e];
     const int tx = r0 + t % (r2 - r0), ty = r1 + t / (r2 - r0);
-    const int ox0 = tx * MF_TW, oy0 = ty * MF_TH;
+    const int ox0 = tx * MF_TW, oy0 = ty * TH;
     uint8_t* mrow = a.masks + (long long)d * a.ho * a.pitch;
-    constexpr int GROUPS = MF_TW * MF_TH / 4;
+    const int ngroups = (MF_TW / 4) * TH;
     if (kind == 1) {
       // a tile the slot covered last time: zero it unless this call's rectangle rewrites it anyway
       if (!(tx >= rg[0] && tx < rg[2] && ty >= rg[1] && ty < rg[3])) {
-        for (int gi = tid; gi < GROUPS; gi += MF_THREADS) {
+        for (int gi = tid; gi < ngroups; gi += MF_THREADS) {
           const int oy = oy0 + gi / (MF_TW / 4), ox = ox0 + (gi % (MF_TW / 4)) * 4;
           if (oy < a.ho && ox < a.wo) *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.pitch + ox) = 0u;
         }
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
       bx.rh = (float)(((double)__fsub_rn(bx.y2, bx.y1) + 0.1) / 2.0);
     }
     // mask-resolution source window of the tile (as sm_mask_assemble) and the conv-resolution window under it
-    const int oxe = min(ox0 + MF_TW, G.wo) - 1, oye = min(oy0 + MF_TH, G.ho) - 1;
+    const int oxe = min(ox0 + MF_TW, G.wo) - 1, oye = min(oy0 + TH, G.ho) - 1;
     const int sx0 = (int)src_x(ox0), sy0 = (int)src_y(oy0);
     const int sx1 = min((int)src_x(oxe) + 1, a.wm - 1), sy1 = min((int)src_y(oye) + 1, a.hm - 1);
     const int spw = sx1 - sx0 + 1, sph = sy1 - sy0 + 1;
@@ -206,7 +235,20 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
     const int lx1 = min((int)lo_c(sx1) + 1, a.lo_w - 1), ly1 = min((int)lo_c(sy1) + 1, a.lo_h - 1);
     const int lpw = lx1 - lx0 + 1, lph = ly1 - ly0 + 1;
     const int nlo = lpw * lph;
-    __syncthreads();   // s_cof
+    // coordinate tables of stage (3): the expressions of the per-pixel version, evaluated once per tile column / row
+    if (tid < MF_TW) {
+      const float sx = src_x(ox0 + tid);
+      const int x0 = (int)sx;
+      s_cx0[tid] = x0 - sx0;
+      s_clx[tid] = sx - (float)x0;
+    } else if (tid < MF_TW + MF_TH_MAX) {
+      const int r = tid - MF_TW;
+      const float sy = src_y(oy0 + r);
+      const int y0 = (int)sy;
+      s_ry0[r] = y0 - sy0;
+      s_rly[r] = sy - (float)y0;
+    }
+    __syncthreads();   // s_cof, tables
     // (1) the 4 quadrant logits at conv resolution: one 32-long dot product per (quadrant, pixel)
     for (int i = tid; i < 4 * nlo; i += MF_THREADS) {
       const int q = i / nlo, p = i - q * nlo;
@@ -226,16 +268,18 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
     }
     __syncthreads();
     // (2) mask-resolution probabilities: quadrant select (CropSplit), bilinear xfactor of that quadrant's logits
-    //     (upsample_bilinear_kernel's formula, misc.hip), sigmoid
+    //     (upsample_bilinear_kernel's formula, misc.hip), sigmoid.  The quadrant index of the reference,
+    //     (int)((p - x1) / rw), is 0 or 1 inside the box (p < x2 and 2 rw = x2 - x1 + 0.1) and a correctly rounded quotient
+    //     of positive floats is >= 1 exactly when numerator >= denominator: a comparison replaces each division.
     for (int li = tid; li < nsrc; li += MF_THREADS) {
       const int yy = li / spw, xx = li - yy * spw;
       const int gx = sx0 + xx, gy = sy0 + yy;
       const float pw = (float)gx, ph = (float)gy;
       float prob = 0.f;
       if (pw >= bx.x1 && ph >= bx.y1 && pw < bx.x2 && ph < bx.y2) {
-        const int iw = (int)__fdiv_rn(__fsub_rn(pw, bx.x1), bx.rw);
-        const int ih = (int)__fdiv_rn(__fsub_rn(ph, bx.y1), bx.rh);
-        const float* L = s_lo_base + ((ih * 2 + iw) & 3) * a.lo_cap;
+        const int iw = __fsub_rn(pw, bx.x1) >= bx.rw ? 1 : 0;
+        const int ih = __fsub_rn(ph, bx.y1) >= bx.rh ? 1 : 0;
+        const float* L = s_lo_base + (ih * 2 + iw) * a.lo_cap;
         const float fy = lo_c(gy), fx = lo_c(gx);
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = min(y0 + 1, a.lo_h - 1), x1 = min(x0 + 1, a.lo_w - 1);
@@ -244,28 +288,27 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
         const float* q0 = L + (y0 - ly0) * lpw - lx0;
         const float* q1 = L + (y1 - ly0) * lpw - lx0;
         const float logit = hy * (hx * q0[x0] + lx * q0[x1]) + ly * (hx * q1[x0] + lx * q1[x1]);
-        prob = sigmoidf_acc(logit);
+        prob = mf_sigmoid(logit);
       }
       s_prob[li] = prob;
     }
     __syncthreads();
     // (3) image-resolution bilinear + threshold, 4 pixels per 32-bit store
-    for (int gi = tid; gi < GROUPS; gi += MF_THREADS) {
-      const int oy = oy0 + gi / (MF_TW / 4), oxb = ox0 + (gi % (MF_TW / 4)) * 4;
+    const int xlast = a.wm - 1 - sx0, ylast = a.hm - 1 - sy0;      // clamp of the +1 neighbour, window-relative
+    for (int gi = tid; gi < ngroups; gi += MF_THREADS) {
+      const int ry = gi / (MF_TW / 4), cx = (gi % (MF_TW / 4)) * 4;
+      const int oy = oy0 + ry, oxb = ox0 + cx;
       if (oy >= G.ho || oxb >= G.wo) continue;
-      const float sy = src_y(oy);
-      const int y0 = (int)sy, y1 = min(y0 + 1, a.hm - 1);
-      const float ly = sy - (float)y0, hy = 1.f - ly;
-      const float* p0 = s_prob + (y0 - sy0) * spw - sx0;
-      const float* p1 = s_prob + (y1 - sy0) * spw - sx0;
+      const int y0 = s_ry0[ry], y1 = min(y0 + 1, ylast);
+      const float ly = s_rly[ry], hy = 1.f - ly;
+      const float* p0 = s_prob + y0 * spw;
+      const float* p1 = s_prob + y1 * spw;
       uint32_t packed = 0u;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int ox = oxb + k;
-        if (ox < G.wo) {
-          const float sx = src_x(ox);
-          const int x0 = (int)sx, x1 = min(x0 + 1, a.wm - 1);
-          const float lx = sx - (float)x0, hx = 1.f - lx;
+        if (oxb + k < G.wo) {
+          const int x0 = s_cx0[cx + k], x1 = min(x0 + 1, xlast);
+          const float lx = s_clx[cx + k], hx = 1.f - lx;
           const float v = hy * (hx * p0[x0] + lx * p0[x1]) + ly * (hx * p1[x0] + lx * p1[x1]);
           packed |= (v > a.thr ? 1u : 0u) << (8 * k);
         }
@@ -279,15 +322,26 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
 
 // LDS tile sizes of a launch (floats): upper bounds of the source windows of one MF_TW x MF_TH output tile; false when
 // the geometry does not fit (then the caller assembles from the upsampled basis: sm_mask_assemble)
-static bool mask_lo_caps(int batch, int max_num, int factor, double up_scale_h, double up_scale_w, int* src_cap, int* lo_cap) {
-  if (batch < 1 || max_num < 1 || factor < 1 || !(up_scale_h > 0) || !(up_scale_w > 0)) return false;
-  if (2 * (long long)batch * max_num > MF_MAX_ENTRIES) return false;
-  const double spw_d = (double)MF_TW / up_scale_w + 3.0, sph_d = (double)MF_TH / up_scale_h + 3.0;
+static bool mask_lo_caps_th(int th, int factor, double up_scale_h, double up_scale_w, int* src_cap, int* lo_cap) {
+  const double spw_d = (double)MF_TW / up_scale_w + 3.0, sph_d = (double)th / up_scale_h + 3.0;
   if (spw_d * sph_d > 1.0e6) return false;
   const int spw = (int)spw_d, sph = (int)sph_d;
   *src_cap = spw * sph;
   *lo_cap = ((spw / factor + 3) * (sph / factor + 3) + 3) & ~3;        // 16-byte aligned quadrant planes
   return (size_t)(*src_cap + 4 * *lo_cap) * sizeof(float) <= (size_t)MF_DYN_LDS_MAX;
+}
+
+static bool mask_lo_caps(int batch, int max_num, int factor, double up_scale_h, double up_scale_w, int* src_cap, int* lo_cap,
+                         int* th_out = nullptr) {
+  if (batch < 1 || max_num < 1 || factor < 1 || !(up_scale_h > 0) || !(up_scale_w > 0)) return false;
+  if (2 * (long long)batch * max_num > MF_MAX_ENTRIES) return false;
+  for (int th = MF_TH_MAX; th >= 8; th >>= 1) {              // the tallest tile whose windows fit the LDS budget
+    if (mask_lo_caps_th(th, factor, up_scale_h, up_scale_w, src_cap, lo_cap)) {
+      if (th_out) *th_out = th;
+      return true;
+    }
+  }
+  return false;
 }
 
 extern "C" int sm_mask_assemble_lo_supported(int batch, int max_num, int factor, double up_scale_h, double up_scale_w) {
@@ -298,7 +352,7 @@ extern "C" int sm_mask_assemble_lo_supported(int batch, int max_num, int factor,
 extern "C" int64_t sm_mask_assemble_lo_workspace(int batch, int max_num) {
   if (batch < 1 || max_num < 1) return 0;
   const int64_t nslot = (int64_t)batch * max_num;
-  return nslot * 8 * 4 + (2 * nslot + 1) * 4 + 64;
+  return nslot * 8 * 4 + (2 * nslot + 1) * 4 + nslot * 4 * 4 + 64;     // ranges, prefix, next-state stash
 }
 
 extern "C" int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, int factor, const float* cofs,
@@ -310,9 +364,10 @@ extern "C" int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, in
   if (batch < 1 || max_num < 1 || lo_h < 1 || lo_w < 1 || factor < 1 || ho < 1 || wo < 1 || mask_pitch % 4 != 0 ||
       mask_pitch < wo || !(up_scale_h > 0) || !(up_scale_w > 0) || !(box_div != 0.f))
     return SM_ERR_BAD_SHAPE;
-  int src_cap, lo_cap;
-  if (!mask_lo_caps(batch, max_num, factor, up_scale_h, up_scale_w, &src_cap, &lo_cap)) return SM_ERR_UNSUPPORTED;
+  int src_cap, lo_cap, th;
+  if (!mask_lo_caps(batch, max_num, factor, up_scale_h, up_scale_w, &src_cap, &lo_cap, &th)) return SM_ERR_UNSUPPORTED;
   MaskFArgs a;
+  a.th = th;
   a.basis_lo = basis_lo;
   a.cofs = cofs;
   a.keep = keep;

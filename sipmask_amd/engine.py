@@ -43,6 +43,11 @@ _PATCH_MIN_FILL = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_FILL", "
 # (2 blocks per CU instead of 3-4) and loses under two concurrent sub-plans what it saves per launch
 _FUSE_BOTTLENECK = int(os.environ.get("SIPMASK_FUSE_BOTTLENECK", "1"))
 _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"   # A/B: relu(P6) copy vs input-ReLU flag
+# FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes
+# the shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
+# shapes), "0" = three launches (A/B)
+_FPN_GROUPED = os.environ.get("SIPMASK_FPN_GROUPED", "auto")
+_LEVEL_CONV_MIN_WORK = float(os.environ.get("SIPMASK_LEVEL_CONV_MIN_WORK", "50"))
 
 
 # FeatureAlign's deformable conv in the x3 head plan: "f32x3" = f32 rows, operands split in the loader, f16 MFMAs (default);
@@ -136,7 +141,9 @@ class _Conv:
                 # the planned shape keeps the CUs busy (fill = work / (256 x makespan)) and the couts fill most of the
                 # 256-wide tile (sip_mask_lat, 128 -> 32: 0.061 ms on the 32 x 256 implicit-GEMM tile, 0.101 ms here with
                 # 7/8 of the MFMAs on padding).  Measured: profiles/r02d_patch_conv_microbench.txt, r02g_patch_tile_shapes_microbench.txt.
-                if (pl["work"] >= _PATCH_MIN_WORK and (pl["fill"] >= _PATCH_MIN_FILL or pl["makespan"] <= 1.0)
+                force = getattr(self, "_patch_force", False)
+                if ((force or (pl["work"] >= getattr(self, "_patch_min_work", _PATCH_MIN_WORK) and
+                               (pl["fill"] >= _PATCH_MIN_FILL or pl["makespan"] <= 1.0)))
                         and co * 4 >= 3 * ((co + 255) // 256 * 256)):
                     self.patch = True
                     self.w, _ = (H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale) if self.x3
@@ -236,6 +243,32 @@ class _GroupedConv(_Conv):
         self.flops *= G
         self.mfma_flops *= G
         self.bytes = self.bytes * G - (0 if x_group_rows else (G - 1) * sum(batch * h * ww for h, ww in in_sizes) * in_cstride * 2)
+
+
+class _LevelConv(_Conv):
+    """L 3x3 convs of identical channel shape on L pyramid LEVELS, each level with its OWN weights and bias, as ONE launch
+    of the patch-resident kernel (sm_conv_desc.w_level_stride): the FPN's output convs fpn_convs[0..2] on the merged
+    laterals (fpn.py:154-157) -- 268 + 68 + 20 tiles at B=4, 800 x 1344, which as three launches are one full round and two
+    launch-latency-shaped ones.  `patch` stays False when the patch kernel does not take the shape (the caller then builds
+    the separate launches)."""
+
+    def __init__(self, eng, name, ws, biases, batch, sizes, in_row0, x, in_cstride, y, out_row0, out_cstride, flags=0,
+                 force=False):
+        self._patch_min_work = _LEVEL_CONV_MIN_WORK
+        self._patch_force = bool(force)
+        _Conv.__init__(self, eng, name, ws[0], biases[0], batch, sizes, in_row0, x, in_cstride, 1, 1, y, out_row0, out_cstride,
+                       flags=flags)
+        if not self.patch:
+            return
+        dev = eng.device
+        packed = [self.w] + [H.prep_conv_weight_patch(w.to(dev))[0] for w in ws[1:]]
+        assert all(p.shape == packed[0].shape for p in packed)
+        self.w = torch.stack(packed).contiguous()
+        self.desc.w_level_stride = packed[0].numel()
+        if biases[0] is not None:
+            self.bias = torch.stack([b.float().to(dev) for b in biases]).contiguous()
+            self.desc.bias_level_stride = biases[0].numel()
+        self.bytes += sum(p.numel() for p in packed[1:]) * 2
 
 
 class MaskRescorer:
@@ -539,44 +572,69 @@ class SipMaskEngine:
         lv = self.lv
         lats = [None] * 3
         self.pyr = self._buf(lv.rows, 256)
+        # the three merged laterals live in ONE row tensor (levels 0-2 of a pyramid layout), so that the three output convs
+        # can read them as the levels of one launch
+        lv3 = H.Levels(B, sizes)
+        lat_rows = self._buf(lv3.rows, 256)
+        for i in range(3):
+            lats[i] = lat_rows[lv3.row0[i]:lv3.row0[i] + B * sizes[i][0] * sizes[i][1]]
 
         def out_conv(i, lane):
             self._add_conv(_Conv(self, "fpn.out%d" % i, sd["neck.fpn_convs.%d.conv.weight" % i],
                                  sd["neck.fpn_convs.%d.conv.bias" % i], B, [sizes[i]], [0], lats[i], 256, 1, 1,
                                  self.pyr, [lv.row0[i]], 256), lane)
-        # plan order = dependency order on lane 0 (lat2 -> lat1 -> lat0 -> out0); the coarse outputs only need
-        # their own lateral, so they leave for side lanes as soon as it is queued: lane 1 = out2 -> P6 -> P7 (66, 20
-        # and 8 blocks), lane 2 = out1 (264 blocks), both overlapped with lat1 / lat0 / out0 on lane 0
+
+        # fpn_convs[0..2] as ONE launch with per-level weights (round 4; _LevelConv): at B=4, 800 x 1344 the three launches
+        # were 268 / 68 / 20 tiles -- one full round and two launch-latency-shaped ones (0.106 + 0.045 + 0.043 ms)
+        grouped = None
+        if self.precision != "f32" and _FPN_GROUPED != "0":
+            g = _LevelConv(self, "fpn.outs", [sd["neck.fpn_convs.%d.conv.weight" % i] for i in range(3)],
+                           [sd["neck.fpn_convs.%d.conv.bias" % i] for i in range(3)], B, sizes, list(lv3.row0), lat_rows, 256,
+                           self.pyr, list(lv.row0[:3]), 256, force=(_FPN_GROUPED == "1"))
+            grouped = g if g.patch else None
+        self.fpn_grouped = grouped is not None
+
+        def p6_p7(lane):
+            self._add_conv(_Conv(self, "fpn.p6", sd["neck.fpn_convs.3.conv.weight"], sd["neck.fpn_convs.3.conv.bias"],
+                                 B, [sizes[2]], [lv.row0[2]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[3]], 256), lane)
+            if self.precision == "f32" or not _RELU_COPY_P7:
+                self._add_conv(_Conv(self, "fpn.p7", sd["neck.fpn_convs.4.conv.weight"], sd["neck.fpn_convs.4.conv.bias"],
+                                     B, [p6], [lv.row0[3]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[4]], 256,
+                                     flags=SM_CONV_IN_RELU), lane)
+            else:
+                # relu(P6) as its own 100-KB tensor: the P7 launch is a handful of tiles with 36 K steps, and the
+                # input-ReLU flag would put it on the register-staged loader (one exposed load latency per K step)
+                n6 = B * p6[0] * p6[1]
+                self.p6_relu = self._buf(n6, 256)
+                p6_rows = self.pyr[lv.row0[3]:lv.row0[3] + n6]
+                self._add("relu:p6", lambda: H.relu_bf16(p6_rows, self.p6_relu), lane)
+                self._add_conv(_Conv(self, "fpn.p7", sd["neck.fpn_convs.4.conv.weight"], sd["neck.fpn_convs.4.conv.bias"],
+                                     B, [p6], [0], self.p6_relu, 256, 2, 1, self.pyr, [lv.row0[4]], 256), lane)
+
+        # plan order = dependency order on lane 0 (lat2 -> lat1 -> lat0 -> outputs).  Separate output convs: the coarse ones
+        # only need their own lateral, so they leave for side lanes as soon as it is queued: lane 1 = out2 -> P6 -> P7 (66,
+        # 20 and 8 blocks), lane 2 = out1 (264 blocks), both overlapped with lat1 / lat0 / out0 on lane 0.  Grouped: the
+        # three laterals, the grouped launch, then P6 -> P7 on lane 1 (the head's first convs need all five levels).
         for i in (2, 1, 0):
             f, fh, fw, fc = feats[i + 1]
-            lats[i] = self._buf(B * fh * fw, 256)
             wl = sd["neck.lateral_convs.%d.conv.weight" % i]
             bl = sd["neck.lateral_convs.%d.conv.bias" % i]
             if i == 2:
                 self._add_conv(_Conv(self, "fpn.lat%d" % i, wl, bl, B, [(fh, fw)], [0], f, fc, 1, 0, lats[i], [0], 256))
-                out_conv(2, 1)
-                self._add_conv(_Conv(self, "fpn.p6", sd["neck.fpn_convs.3.conv.weight"], sd["neck.fpn_convs.3.conv.bias"],
-                                     B, [sizes[2]], [lv.row0[2]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[3]], 256), 1)
-                if self.precision == "f32" or not _RELU_COPY_P7:
-                    self._add_conv(_Conv(self, "fpn.p7", sd["neck.fpn_convs.4.conv.weight"], sd["neck.fpn_convs.4.conv.bias"],
-                                         B, [p6], [lv.row0[3]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[4]], 256,
-                                         flags=SM_CONV_IN_RELU), 1)
-                else:
-                    # relu(P6) as its own 100-KB tensor: the P7 launch is a handful of tiles with 36 K steps, and the
-                    # input-ReLU flag would put it on the register-staged loader (one exposed load latency per K step)
-                    n6 = B * p6[0] * p6[1]
-                    self.p6_relu = self._buf(n6, 256)
-                    p6_rows = self.pyr[lv.row0[3]:lv.row0[3] + n6]
-                    self._add("relu:p6", lambda: H.relu_bf16(p6_rows, self.p6_relu), 1)
-                    self._add_conv(_Conv(self, "fpn.p7", sd["neck.fpn_convs.4.conv.weight"], sd["neck.fpn_convs.4.conv.bias"],
-                                         B, [p6], [0], self.p6_relu, 256, 2, 1, self.pyr, [lv.row0[4]], 256), 1)
+                if grouped is None:
+                    out_conv(2, 1)
+                    p6_p7(1)
             else:
                 self._add_conv(_Conv(self, "fpn.lat%d" % i, wl, bl, B, [(fh, fw)], [0], f, fc, 1, 0, lats[i], [0], 256,
                                      flags=SM_CONV_RES_NEAREST, residual=lats[i + 1], res_cstride=256,
                                      res_sizes=[sizes[i + 1]], res_row0=[0]))
-                if i == 1:
+                if i == 1 and grouped is None:
                     out_conv(1, 2)
-        out_conv(0, 0)
+        if grouped is None:
+            out_conv(0, 0)
+        else:
+            self._add_conv(grouped)
+            p6_p7(1)
         self._join(1, 2)
         self.head_start = len(self.steps)
         self._build_head(sd)

@@ -361,7 +361,7 @@ def test_mixed_size_batch_reads_img_shape_and_scale_factor_per_image(rescale):
         small.set_image_metas(metas)
 
 
-def test_pipelined_submit_packs_results_and_keeps_metas_per_slot():
+def test_pipelined_submit_packs_results_and_keeps_metas_per_slot(monkeypatch):
     """PipelinedPlan.submit(img, img_metas, pack=True) / fetch (round 4):
     (1) result packing behind every step on the slot's stream (sm_mask_rects + sm_rle_encode + asynchronous copies into
         pinned buffers) returns per image exactly what the single plan's results() + encode_rle() give
@@ -369,7 +369,10 @@ def test_pipelined_submit_packs_results_and_keeps_metas_per_slot():
     (2) img_metas travel with the SUBMIT: consecutive batches with different img_shape / scale_factor are in flight at the
         same time and every step is post-processed with its own metas (set_image_metas used to rewrite the
         tables of every slot at once, under steps still running)."""
+    import sipmask_amd.engine as E
     from sipmask_amd.synthetic import build_synthetic_detector
+    # slots run without split-K (engine.py: pipelined); the single plan of this comparison must sum in the same order
+    monkeypatch.setattr(E, "_SPLIT_K", False)
     det = build_synthetic_detector(50, seed=0)
     with torch.no_grad():
         det.bbox_head.fcos_cls.bias.fill_(-2.0)
@@ -436,3 +439,32 @@ def test_forward_dummy_returns_the_head_outputs(setup):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     assert torch.equal(got[4], ref[4])
+
+
+def test_fpn_output_convs_as_one_launch_with_per_level_weights(setup, monkeypatch):
+    """fpn_convs[0..2] on the merged laterals (fpn.py:154-157) as ONE launch of the patch-resident kernel with per-level
+    weights and biases (sm_conv_desc.w_level_stride, engine._LevelConv; round 4): P3-P7 against the oracle at the bound of the
+    separate launches, and against the plan of separate launches within bf16 accumulation-order rounding; P6 / P7 hang off
+    the grouped launch's P5."""
+    import sipmask_amd.engine as E
+    from sipmask_amd.engine import SipMaskEngine
+    B, (Hh, Ww) = setup["B"], setup["hw"]
+    base = setup["eng"]
+    assert not base.fpn_grouped                      # 24 tiles at this size: the planner keeps three launches
+    monkeypatch.setattr(E, "_FPN_GROUPED", "1")
+    eng = SipMaskEngine(setup["sd"], B, (Hh, Ww), 50)
+    assert eng.fpn_grouped and [c.name for c in eng.convs if c.name.startswith("fpn.out")] == ["fpn.outs"]
+    g = [c for c in eng.convs if c.name == "fpn.outs"][0]
+    assert g.desc.w_level_stride == g.w[0].numel() and g.desc.bias_level_stride == 256 and g.desc.nlev == 3
+    eng.run(setup["img"].cuda())
+    torch.cuda.synchronize()
+    lv = eng.lv
+    for l, (h, w) in enumerate(lv.sizes):
+        got = eng.pyr[lv.row0[l]:lv.row0[l] + B * h * w].float().view(B, h, w, 256).permute(0, 3, 1, 2)
+        assert _rel(got, setup["pyr"][l]) < 0.03, ("P%d" % (l + 3))
+        ref = base.pyr[lv.row0[l]:lv.row0[l] + B * h * w].float().view(B, h, w, 256).permute(0, 3, 1, 2)
+        assert _rel(got, ref) < 6e-3, ("P%d vs separate launches" % (l + 3))
+    # the weights of the levels really differ: level 1 through level 0's matrix would be far off
+    w0 = setup["sd"]["neck.fpn_convs.0.conv.weight"]
+    w1 = setup["sd"]["neck.fpn_convs.1.conv.weight"]
+    assert float((w0 - w1).abs().max()) > 1e-3
