@@ -28,10 +28,15 @@ constexpr int MF_THREADS = 256;
 // probability window and a 4-5-row conv-resolution window for ONE useful conv-resolution row, pays 5 barriers, a binary
 // search and a coefficient load per 1 024 pixels.  A 64-row tile amortises all of that over 8 192 pixels.
 constexpr int MF_TW = 128, MF_TH_MAX = 64;
+constexpr int MF_SRC_MAXW = 320, MF_SRC_MAXH = 96;   // probability window of a tile (mask_lo_caps enforces both)
+// floor(n / d) for n < 2^16, d < 2^16 as one multiply-high with m = ceil(2^32 / d) (n * (m * d - 2^32) < 2^32): the
+// window sizes are run-time values, and a hardware-less integer division is ~40 VALU instructions per work item
+__device__ __forceinline__ unsigned mf_magic(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }
+__device__ __forceinline__ int mf_div(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
 // The LDS tiles of one output tile -- its mask-resolution source window and the conv-resolution window under that --
 // are DYNAMIC shared memory sized by the launch's up_scale (a keep_ratio COCO resize gives scale_factor 1.6-2.7, i.e.
 // up_scale = 2 / scale_factor down to 0.74: a 128x8 output tile then reads a 176x13 source window)
-constexpr int MF_DYN_LDS_MAX = 44 * 1024;   // bytes of dynamic LDS a launch may ask for (beside 17 KB static)
+constexpr int MF_DYN_LDS_MAX = 40 * 1024;   // bytes of dynamic LDS a launch may ask for (beside 22 KB static: 64 KB per block)
 constexpr int MF_MAX_ENTRIES = 4096;     // 2 * batch * max_num work-list entries (prefix copy lives in LDS)
 
 struct MaskFArgs {
@@ -170,6 +175,9 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
   __shared__ float s_clx[MF_TW];
   __shared__ int s_ry0[MF_TH_MAX];
   __shared__ float s_rly[MF_TH_MAX];
+  // ... and of stage (2): probability-window column / row -> (conv-resolution index relative to the window, fraction)
+  __shared__ int s_mx0[MF_SRC_MAXW], s_my0[MF_SRC_MAXH];
+  __shared__ float s_mlx[MF_SRC_MAXW], s_mly[MF_SRC_MAXH];
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float* const s_lo_base = s_dyn;                     // [4][lo_cap] quadrant logits at conv resolution
   float* const s_prob = s_dyn + 4 * a.lo_cap;         // [src_cap] probabilities at mask resolution
@@ -248,45 +256,66 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
       s_ry0[r] = y0 - sy0;
       s_rly[r] = sy - (float)y0;
     }
-    __syncthreads();   // s_cof, tables
-    // (1) the 4 quadrant logits at conv resolution: one 32-long dot product per (quadrant, pixel)
-    for (int i = tid; i < 4 * nlo; i += MF_THREADS) {
-      const int q = i / nlo, p = i - q * nlo;
-      const int py = p / lpw, px = p - py * lpw;
-      const float* bp = a.basis_lo + (((long long)b * a.lo_h + (ly0 + py)) * a.lo_w + (lx0 + px)) * 32;
-      const float* cq = s_cof + q * 32;
-      float acc = 0.f;
-#pragma unroll
-      for (int k = 0; k < 32; k += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(bp + k);
-        acc = fmaf(v.x, cq[k], acc);
-        acc = fmaf(v.y, cq[k + 1], acc);
-        acc = fmaf(v.z, cq[k + 2], acc);
-        acc = fmaf(v.w, cq[k + 3], acc);
+    // ... and of stage (2): conv-resolution neighbours of every probability column / row (lo_c: the x4 bilinear's source rule)
+    for (int i = tid; i < spw + sph; i += MF_THREADS) {
+      if (i < spw) {
+        const float fx = lo_c(sx0 + i);
+        const int x0 = (int)fx;
+        s_mx0[i] = x0 - lx0;
+        s_mlx[i] = fx - (float)x0;
+      } else {
+        const int r = i - spw;
+        const float fy = lo_c(sy0 + r);
+        const int y0 = (int)fy;
+        s_my0[r] = y0 - ly0;
+        s_mly[r] = fy - (float)y0;
       }
-      s_lo_base[q * a.lo_cap + p] = acc;
+    }
+    __syncthreads();   // s_cof, tables
+    // (1) the 4 quadrant logits at conv resolution: per pixel ONE read of its 32 basis values (8 loads in flight) and four
+    //     32-long dot products against the coefficient quadrants (each in the reference's channel order)
+    const unsigned m_lpw = mf_magic((unsigned)lpw), m_spw = mf_magic((unsigned)spw);
+    for (int p = tid; p < nlo; p += MF_THREADS) {
+      const int py = mf_div(p, m_lpw), px = p - py * lpw;
+      const float* bp = a.basis_lo + (((long long)b * a.lo_h + (ly0 + py)) * a.lo_w + (lx0 + px)) * 32;
+      float4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(bp + 4 * k);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4* cq = reinterpret_cast<const float4*>(s_cof + q * 32);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float4 c = cq[k];
+          acc = fmaf(v[k].x, c.x, acc);
+          acc = fmaf(v[k].y, c.y, acc);
+          acc = fmaf(v[k].z, c.z, acc);
+          acc = fmaf(v[k].w, c.w, acc);
+        }
+        s_lo_base[q * a.lo_cap + p] = acc;
+      }
     }
     __syncthreads();
     // (2) mask-resolution probabilities: quadrant select (CropSplit), bilinear xfactor of that quadrant's logits
     //     (upsample_bilinear_kernel's formula, misc.hip), sigmoid.  The quadrant index of the reference,
     //     (int)((p - x1) / rw), is 0 or 1 inside the box (p < x2 and 2 rw = x2 - x1 + 0.1) and a correctly rounded quotient
     //     of positive floats is >= 1 exactly when numerator >= denominator: a comparison replaces each division.
+    const int lxlast = a.lo_w - 1 - lx0, lylast = a.lo_h - 1 - ly0;
     for (int li = tid; li < nsrc; li += MF_THREADS) {
-      const int yy = li / spw, xx = li - yy * spw;
-      const int gx = sx0 + xx, gy = sy0 + yy;
-      const float pw = (float)gx, ph = (float)gy;
+      const int yy = mf_div(li, m_spw), xx = li - yy * spw;
+      const float pw = (float)(sx0 + xx), ph = (float)(sy0 + yy);
       float prob = 0.f;
       if (pw >= bx.x1 && ph >= bx.y1 && pw < bx.x2 && ph < bx.y2) {
         const int iw = __fsub_rn(pw, bx.x1) >= bx.rw ? 1 : 0;
         const int ih = __fsub_rn(ph, bx.y1) >= bx.rh ? 1 : 0;
         const float* L = s_lo_base + (ih * 2 + iw) * a.lo_cap;
-        const float fy = lo_c(gy), fx = lo_c(gx);
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = min(y0 + 1, a.lo_h - 1), x1 = min(x0 + 1, a.lo_w - 1);
-        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const int y0 = s_my0[yy], x0 = s_mx0[xx];
+        const int y1 = min(y0 + 1, lylast), x1 = min(x0 + 1, lxlast);
+        const float ly = s_mly[yy], lx = s_mlx[xx];
         const float hy = 1.f - ly, hx = 1.f - lx;
-        const float* q0 = L + (y0 - ly0) * lpw - lx0;
-        const float* q1 = L + (y1 - ly0) * lpw - lx0;
+        const float* q0 = L + y0 * lpw;
+        const float* q1 = L + y1 * lpw;
         const float logit = hy * (hx * q0[x0] + lx * q0[x1]) + ly * (hx * q1[x0] + lx * q1[x1]);
         prob = mf_sigmoid(logit);
       }
@@ -326,6 +355,7 @@ static bool mask_lo_caps_th(int th, int factor, double up_scale_h, double up_sca
   const double spw_d = (double)MF_TW / up_scale_w + 3.0, sph_d = (double)th / up_scale_h + 3.0;
   if (spw_d * sph_d > 1.0e6) return false;
   const int spw = (int)spw_d, sph = (int)sph_d;
+  if (spw > MF_SRC_MAXW || sph > MF_SRC_MAXH) return false;       // the kernel's coordinate tables
   *src_cap = spw * sph;
   *lo_cap = ((spw / factor + 3) * (sph / factor + 3) + 3) & ~3;        // 16-byte aligned quadrant planes
   return (size_t)(*src_cap + 4 * *lo_cap) * sizeof(float) <= (size_t)MF_DYN_LDS_MAX;

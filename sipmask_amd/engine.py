@@ -46,6 +46,7 @@ _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"
 # FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes
 # the shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
 # shapes), "0" = three launches (A/B)
+_DIAG_SKIP = __import__("re").compile(os.environ["SIPMASK_DIAG_SKIP"]) if os.environ.get("SIPMASK_DIAG_SKIP") else None
 _FPN_GROUPED = os.environ.get("SIPMASK_FPN_GROUPED", "auto")
 _LEVEL_CONV_MIN_WORK = float(os.environ.get("SIPMASK_LEVEL_CONV_MIN_WORK", "50"))
 
@@ -448,6 +449,14 @@ class SipMaskEngine:
         """Launch the plan.  Side lanes are torch streams: a lane forks (waits for everything lane 0 has queued so
         far) at its first step after a join, so a step on a side lane may read anything produced before it in plan
         order on lane 0; capture-safe (the side streams join the capture through wait_stream)."""
+        # diagnostic (tools/marginal_cost.sh): launches whose label matches SIPMASK_DIAG_SKIP are left out of CAPTURED graphs
+        # only -- the eager run before the capture has filled every buffer, so what follows a skipped launch reads plausible
+        # (stale) data and the replay's time is the step's time WITHOUT those launches: the marginal cost of a stage inside
+        # the pipelined step, which per-launch timings cannot give (the steps in flight overlap)
+        skip = _DIAG_SKIP if (_DIAG_SKIP is not None and torch.cuda.is_current_stream_capturing()) else None
+        if skip is not None:
+            kept = [i for i, (label, _) in enumerate(steps) if not skip.search(label)]
+            steps, lanes = [steps[i] for i in kept], [lanes[i] for i in kept]
         if not self.multi_stream:
             for _, fn in steps:
                 fn()
