@@ -36,7 +36,7 @@ __device__ __forceinline__ int mf_div(int n, unsigned m) { return (int)__umulhi(
 // The LDS tiles of one output tile -- its mask-resolution source window and the conv-resolution window under that --
 // are DYNAMIC shared memory sized by the launch's up_scale (a keep_ratio COCO resize gives scale_factor 1.6-2.7, i.e.
 // up_scale = 2 / scale_factor down to 0.74: a 128x8 output tile then reads a 176x13 source window)
-constexpr int MF_DYN_LDS_MAX = 40 * 1024;   // bytes of dynamic LDS a launch may ask for (beside 22 KB static: 64 KB per block)
+constexpr int MF_DYN_LDS_MAX = 56 * 1024;   // bytes of dynamic LDS a launch may ask for (beside 6 KB static: 64 KB per block)
 constexpr int MF_MAX_ENTRIES = 4096;     // 2 * batch * max_num work-list entries (prefix copy lives in LDS)
 
 struct MaskFArgs {
@@ -168,7 +168,6 @@ struct FBox {
 __device__ __forceinline__ float mf_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 
 __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs a) {
-  __shared__ int s_prefix[MF_MAX_ENTRIES + 1];
   __shared__ __attribute__((aligned(16))) float s_cof[128];
   // per-tile coordinate tables: output column / row -> (first source index relative to the window, fraction)
   __shared__ int s_cx0[MF_TW];
@@ -181,6 +180,9 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float* const s_lo_base = s_dyn;                     // [4][lo_cap] quadrant logits at conv resolution
   float* const s_prob = s_dyn + 4 * a.lo_cap;         // [src_cap] probabilities at mask resolution
+  // the work list's prefix sums, sized by the launch (2 * batch * max_num + 1 entries; a static 16 KB array cost a block of
+  // occupancy per CU, and this kernel lives on occupancy: its tiles are chains of short dependent phases)
+  int* const s_prefix = reinterpret_cast<int*>(s_dyn + 4 * a.lo_cap + a.src_cap);
   const int tid = threadIdx.x;
   const int n2 = 2 * a.batch * a.max_num;
   const int TH = a.th;
@@ -351,24 +353,28 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
 
 // LDS tile sizes of a launch (floats): upper bounds of the source windows of one MF_TW x MF_TH output tile; false when
 // the geometry does not fit (then the caller assembles from the upsampled basis: sm_mask_assemble)
-static bool mask_lo_caps_th(int th, int factor, double up_scale_h, double up_scale_w, int* src_cap, int* lo_cap) {
+static bool mask_lo_caps_th(int th, int factor, double up_scale_h, double up_scale_w, int* src_cap, int* lo_cap, int nentries) {
   const double spw_d = (double)MF_TW / up_scale_w + 3.0, sph_d = (double)th / up_scale_h + 3.0;
   if (spw_d * sph_d > 1.0e6) return false;
   const int spw = (int)spw_d, sph = (int)sph_d;
   if (spw > MF_SRC_MAXW || sph > MF_SRC_MAXH) return false;       // the kernel's coordinate tables
   *src_cap = spw * sph;
   *lo_cap = ((spw / factor + 3) * (sph / factor + 3) + 3) & ~3;        // 16-byte aligned quadrant planes
-  return (size_t)(*src_cap + 4 * *lo_cap) * sizeof(float) <= (size_t)MF_DYN_LDS_MAX;
+  return (size_t)(*src_cap + 4 * *lo_cap + nentries + 1) * sizeof(float) <= (size_t)MF_DYN_LDS_MAX;
 }
 
 static bool mask_lo_caps(int batch, int max_num, int factor, double up_scale_h, double up_scale_w, int* src_cap, int* lo_cap,
                          int* th_out = nullptr) {
   if (batch < 1 || max_num < 1 || factor < 1 || !(up_scale_h > 0) || !(up_scale_w > 0)) return false;
   if (2 * (long long)batch * max_num > MF_MAX_ENTRIES) return false;
-  for (int th = MF_TH_MAX; th >= 8; th >>= 1) {              // the tallest tile whose windows fit the LDS budget
-    if (mask_lo_caps_th(th, factor, up_scale_h, up_scale_w, src_cap, lo_cap)) {
-      if (th_out) *th_out = th;
-      return true;
+  // the tallest tile whose windows fit 28 KB (5 blocks per CU), else the tallest that fits at all
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int th = MF_TH_MAX; th >= 8; th >>= 1) {
+      if (mask_lo_caps_th(th, factor, up_scale_h, up_scale_w, src_cap, lo_cap, 2 * batch * max_num) &&
+          (pass == 1 || (size_t)(*src_cap + 4 * *lo_cap + 2 * batch * max_num + 1) * sizeof(float) <= 28u * 1024u)) {
+        if (th_out) *th_out = th;
+        return true;
+      }
     }
   }
   return false;
@@ -432,7 +438,8 @@ extern "C" int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, in
   a.per_image = per_image;
   hipStream_t s = sm_hip_stream(stream);
   hipLaunchKernelGGL(mask_plan_kernel, dim3(1), dim3(1024), 0, s, a);
-  hipLaunchKernelGGL(mask_fused_kernel, dim3(2048), dim3(MF_THREADS), (size_t)(src_cap + 4 * lo_cap) * sizeof(float), s, a);
+  hipLaunchKernelGGL(mask_fused_kernel, dim3(2048), dim3(MF_THREADS),
+                     (size_t)(src_cap + 4 * lo_cap + 2 * batch * max_num + 1) * sizeof(float), s, a);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

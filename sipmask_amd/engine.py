@@ -26,6 +26,7 @@ _GROUPED_TOWERS = __import__("os").environ.get("SIPMASK_GROUPED_TOWERS", "1") ==
 
 
 _SPLIT_K = __import__("os").environ.get("SIPMASK_SPLIT_K", "1") != "0"     # A/B: split-K for under-filled launches
+_SPLIT_K_SMALL_FPN = __import__("os").environ.get("SIPMASK_SPLIT_K_FPN", "1") != "0"   # A/B: ... of lat2 / P6 / P7 in pipelined slots
 _PATCH_CONV = __import__("os").environ.get("SIPMASK_PATCH_CONV", "1") != "0"   # A/B: patch-resident 3x3 kernel
 # FeatureAlign's deformable conv: the LDS-window kernel (csrc/deform_patch.hip) is 1.3-1.6x the gather loader while the
 # learned offsets stay within ~3 pixels and falls behind it when most waves sample farther out (random offsets of sigma 4:
@@ -81,7 +82,7 @@ class _Conv:
 
     def __init__(self, eng, name, w, bias, batch, in_sizes, in_row0, x, in_cstride, stride, pad, y, out_row0,
                  out_cstride, out_coff=0, flags=0, cin_pad=None, residual=None, res_cstride=0, res_sizes=None,
-                 res_row0=None, scale_nch=0, level_scale=None, deform_groups=0, offset=None, mode=None):
+                 res_row0=None, scale_nch=0, level_scale=None, deform_groups=0, offset=None, mode=None, split_k=None):
         dev = eng.device
         co, ci, k, _ = w.shape
         cin = cin_pad or ci
@@ -117,7 +118,8 @@ class _Conv:
         out_sizes = [(_conv_out(h, k, stride, pad), _conv_out(ww, k, stride, pad)) for h, ww in in_sizes]
         self.out_sizes = out_sizes
         flags |= _DEBUG_CONV_FLAGS          # plan selectors of include/sipmask_hip.h for whole-plan experiments
-        flags |= getattr(eng, "extra_conv_flags", 0)   # ... and the engine's own (PipelinedPlan slots: big tiles)
+        if not (split_k is True and _SPLIT_K_SMALL_FPN):   # ... and the engine's own (PipelinedPlan slots: big tiles), except
+            flags |= getattr(eng, "extra_conv_flags", 0)   # for the launches that keep the latency-shaped plan (below)
         self.desc = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, co_pad, k, stride, pad,
                                      in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
                                      scale_nch, level_scale, deform_groups, acc_scale=acc_scale)
@@ -153,7 +155,10 @@ class _Conv:
         # split-K workspace (own buffer per conv: launches on different lanes may run concurrently); sized by the
         # library's plan, allocated once at build -- 288 GB of HBM
         self.ws = None
-        if not self.f32 and offset is None and getattr(eng, "split_k", _SPLIT_K) and not self.patch:
+        # (split_k: None = the engine's rule; True = also inside a pipelined slot -- the FPN's three launch-latency-shaped
+        # convs, lat2 / P6 / P7: 6-66 tiles with 32-36 serial K steps, where the reduce launch costs no CU time worth counting)
+        want_split = getattr(eng, "split_k", _SPLIT_K) if split_k is None else (bool(split_k) and _SPLIT_K_SMALL_FPN)
+        if not self.f32 and offset is None and want_split and not self.patch:
             pl = H.conv_plan(self.desc)
             if pl["split_k"] > 1:
                 self.ws = torch.empty(pl["workspace_bytes"], dtype=torch.uint8, device=dev)
@@ -595,6 +600,7 @@ class SipMaskEngine:
 
         # fpn_convs[0..2] as ONE launch with per-level weights (round 4; _LevelConv): at B=4, 800 x 1344 the three launches
         # were 268 / 68 / 20 tiles -- one full round and two launch-latency-shaped ones (0.106 + 0.045 + 0.043 ms)
+        small_split = True if getattr(self, "extra_conv_flags", 0) else None    # pipelined slot: see _Conv(split_k=...)
         grouped = None
         if self.precision != "f32" and _FPN_GROUPED != "0":
             g = _LevelConv(self, "fpn.outs", [sd["neck.fpn_convs.%d.conv.weight" % i] for i in range(3)],
@@ -605,7 +611,8 @@ class SipMaskEngine:
 
         def p6_p7(lane):
             self._add_conv(_Conv(self, "fpn.p6", sd["neck.fpn_convs.3.conv.weight"], sd["neck.fpn_convs.3.conv.bias"],
-                                 B, [sizes[2]], [lv.row0[2]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[3]], 256), lane)
+                                 B, [sizes[2]], [lv.row0[2]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[3]], 256,
+                                 split_k=small_split), lane)
             if self.precision == "f32" or not _RELU_COPY_P7:
                 self._add_conv(_Conv(self, "fpn.p7", sd["neck.fpn_convs.4.conv.weight"], sd["neck.fpn_convs.4.conv.bias"],
                                      B, [p6], [lv.row0[3]], self.pyr, 256, 2, 1, self.pyr, [lv.row0[4]], 256,
@@ -618,7 +625,8 @@ class SipMaskEngine:
                 p6_rows = self.pyr[lv.row0[3]:lv.row0[3] + n6]
                 self._add("relu:p6", lambda: H.relu_bf16(p6_rows, self.p6_relu), lane)
                 self._add_conv(_Conv(self, "fpn.p7", sd["neck.fpn_convs.4.conv.weight"], sd["neck.fpn_convs.4.conv.bias"],
-                                     B, [p6], [0], self.p6_relu, 256, 2, 1, self.pyr, [lv.row0[4]], 256), lane)
+                                     B, [p6], [0], self.p6_relu, 256, 2, 1, self.pyr, [lv.row0[4]], 256,
+                                     split_k=small_split), lane)
 
         # plan order = dependency order on lane 0 (lat2 -> lat1 -> lat0 -> outputs).  Separate output convs: the coarse ones
         # only need their own lateral, so they leave for side lanes as soon as it is queued: lane 1 = out2 -> P6 -> P7 (66,
@@ -629,7 +637,8 @@ class SipMaskEngine:
             wl = sd["neck.lateral_convs.%d.conv.weight" % i]
             bl = sd["neck.lateral_convs.%d.conv.bias" % i]
             if i == 2:
-                self._add_conv(_Conv(self, "fpn.lat%d" % i, wl, bl, B, [(fh, fw)], [0], f, fc, 1, 0, lats[i], [0], 256))
+                self._add_conv(_Conv(self, "fpn.lat%d" % i, wl, bl, B, [(fh, fw)], [0], f, fc, 1, 0, lats[i], [0], 256,
+                                     split_k=small_split))
                 if grouped is None:
                     out_conv(2, 1)
                     p6_p7(1)

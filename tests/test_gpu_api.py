@@ -1,5 +1,6 @@
 """GPU tests of the reference-facing API (registry-built modules): SipMaskHead.forward / get_masks /
 get_bboxes on caller tensors, SipMask.simple_test, DeformConv module -- against the CPU oracle."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -823,3 +824,57 @@ def test_deform_conv_module_argument_range(case):
         want = want.float()
         err = (got.cpu() - want).abs().max().item()
         assert err <= 3e-2 * max(1.0, want.abs().max().item()), (name, err, want.abs().max().item())
+
+
+def test_backbone_fpn_backward_vs_same_rounding_emulation():
+    """The COMPOSED backward of the row-tensor training graph, held tightly (the comparison with the
+    fp32 oracle above can only be a wiring check -- the deep trunk of this untrained net is chaotic in its ReLU gates).
+    Here the same Python graph (ResNet.forward_rows + FPN.forward_rows: 49 conv ops, residual and top-down branches,
+    strided and 3x3 / 1x1 data gradients, frozen-BN folds) runs twice: on the HIP kernels, and on the CPU with every op
+    replaced by a torch emulation that rounds where the kernels round (tests/rows_emulation.py: bf16 operands and storage,
+    f32 accumulation).  What is left between the two is accumulation order (and the float atomics of the split-K weight
+    gradients), so EVERY trainable tensor of backbone and neck must agree: cosine >= 0.999, relative error <= 2e-2; the
+    five FPN outputs agree to a bf16 ulp on a handful of elements."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import rows_emulation as EMU
+    from sipmask_amd.synthetic import build_synthetic_detector
+    det = build_synthetic_detector(50, seed=3).cuda()
+    det.train()
+    ref = build_synthetic_detector(50, seed=3)
+    ref.load_state_dict({k: v.cpu() for k, v in det.state_dict().items()})
+    ref.train()
+    g = torch.Generator().manual_seed(7)
+    B = 2
+    img = torch.randn(B, 3, 128, 160, generator=g)
+    with EMU.emulated_rows():
+        rows_e, lv = ref.extract_feat_rows(img)
+    probe = torch.randn(rows_e.shape, generator=g) / 16.0
+    (rows_e.float() * probe).sum().backward()
+    rows_g, lv_g = det.extract_feat_rows(img.cuda())
+    assert lv_g.sizes == lv.sizes and rows_g.shape == rows_e.shape and rows_g.dtype == torch.bfloat16
+    (rows_g.float() * probe.cuda()).sum().backward()
+    # forward: equal up to single bf16 roundings that fell the other way
+    a, b = rows_g.detach().float().cpu(), rows_e.detach().float()
+    assert float((a - b).norm() / b.norm()) < 2e-3
+    assert float((a != b).float().mean()) < 0.05
+    worst = []
+    pe = dict(ref.named_parameters())
+    n_checked = 0
+    for name, p in det.named_parameters():
+        if not (name.startswith("backbone.") or name.startswith("neck.")):
+            continue
+        if p.grad is None:
+            assert pe[name].grad is None, name                      # frozen on both sides (stem, stage 1, BatchNorms)
+            continue
+        got, want = p.grad.float().cpu(), pe[name].grad.float()
+        err = float((got - want).norm() / (want.norm() + 1e-30))
+        cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-30))
+        worst.append((round(err, 5), round(cos, 6), name))
+        n_checked += 1
+    worst.sort(reverse=True)
+    assert n_checked >= 60, n_checked
+    bad = [w for w in worst if w[0] > 2e-2 or w[1] < 0.999]
+    assert not bad, (bad[:8], worst[:3])
