@@ -17,6 +17,8 @@
 //      box areas.
 // Work decomposition: a plan kernel turns (detections, previous ranges) into a prefix sum of 128x8-pixel output tiles;
 // a fixed grid of blocks walks that list (binary search in an LDS copy of the prefix).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -167,6 +169,10 @@ struct FBox {
 // are held to the oracle away from |up - thr| < 1e-5, tests/test_gpu_kernels.py).  Rankings use sigmoid_rank (common.h).
 __device__ __forceinline__ float mf_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 
+// VAR (A/B, SIPMASK_MASK_VARIANT): bit 0 = stage (1) per pixel (one read of the 32 basis values, four dot products) instead
+// of per (quadrant, pixel); bit 1 = stage (2) reads its conv-resolution neighbours from per-tile tables instead of
+// recomputing them per probability
+template <int VAR>
 __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs a) {
   __shared__ __attribute__((aligned(16))) float s_cof[128];
   // per-tile coordinate tables: output column / row -> (first source index relative to the window, fraction)
@@ -277,6 +283,25 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
     // (1) the 4 quadrant logits at conv resolution: per pixel ONE read of its 32 basis values (8 loads in flight) and four
     //     32-long dot products against the coefficient quadrants (each in the reference's channel order)
     const unsigned m_lpw = mf_magic((unsigned)lpw), m_spw = mf_magic((unsigned)spw);
+    if constexpr ((VAR & 1) == 0) {
+      const unsigned m_nlo = mf_magic((unsigned)nlo);
+      for (int i = tid; i < 4 * nlo; i += MF_THREADS) {
+        const int q = mf_div(i, m_nlo), p = i - q * nlo;
+        const int py = mf_div(p, m_lpw), px = p - py * lpw;
+        const float* bp = a.basis_lo + (((long long)b * a.lo_h + (ly0 + py)) * a.lo_w + (lx0 + px)) * 32;
+        const float* cq = s_cof + q * 32;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(bp + k);
+          acc = fmaf(v.x, cq[k], acc);
+          acc = fmaf(v.y, cq[k + 1], acc);
+          acc = fmaf(v.z, cq[k + 2], acc);
+          acc = fmaf(v.w, cq[k + 3], acc);
+        }
+        s_lo_base[q * a.lo_cap + p] = acc;
+      }
+    } else
     for (int p = tid; p < nlo; p += MF_THREADS) {
       const int py = mf_div(p, m_lpw), px = p - py * lpw;
       const float* bp = a.basis_lo + (((long long)b * a.lo_h + (ly0 + py)) * a.lo_w + (lx0 + px)) * 32;
@@ -312,9 +337,18 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
         const int iw = __fsub_rn(pw, bx.x1) >= bx.rw ? 1 : 0;
         const int ih = __fsub_rn(ph, bx.y1) >= bx.rh ? 1 : 0;
         const float* L = s_lo_base + (ih * 2 + iw) * a.lo_cap;
-        const int y0 = s_my0[yy], x0 = s_mx0[xx];
+        int y0, x0;
+        float ly, lx;
+        if constexpr ((VAR & 2) != 0) {
+          y0 = s_my0[yy], x0 = s_mx0[xx];
+          ly = s_mly[yy], lx = s_mlx[xx];
+        } else {
+          const float fy = lo_c(sy0 + yy), fx = lo_c(sx0 + xx);
+          const int ay = (int)fy, ax = (int)fx;
+          y0 = ay - ly0, x0 = ax - lx0;
+          ly = fy - (float)ay, lx = fx - (float)ax;
+        }
         const int y1 = min(y0 + 1, lylast), x1 = min(x0 + 1, lxlast);
-        const float ly = s_mly[yy], lx = s_mlx[xx];
         const float hy = 1.f - ly, hx = 1.f - lx;
         const float* q0 = L + y0 * lpw;
         const float* q1 = L + y1 * lpw;
@@ -438,8 +472,17 @@ extern "C" int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, in
   a.per_image = per_image;
   hipStream_t s = sm_hip_stream(stream);
   hipLaunchKernelGGL(mask_plan_kernel, dim3(1), dim3(1024), 0, s, a);
-  hipLaunchKernelGGL(mask_fused_kernel, dim3(2048), dim3(MF_THREADS),
-                     (size_t)(src_cap + 4 * lo_cap + 2 * batch * max_num + 1) * sizeof(float), s, a);
+  static const int variant = [] {
+    const char* e = getenv("SIPMASK_MASK_VARIANT");
+    return e ? atoi(e) & 3 : 0;
+  }();
+  const size_t dyn = (size_t)(src_cap + 4 * lo_cap + 2 * batch * max_num + 1) * sizeof(float);
+  switch (variant) {
+    case 1: hipLaunchKernelGGL(mask_fused_kernel<1>, dim3(2048), dim3(MF_THREADS), dyn, s, a); break;
+    case 2: hipLaunchKernelGGL(mask_fused_kernel<2>, dim3(2048), dim3(MF_THREADS), dyn, s, a); break;
+    case 3: hipLaunchKernelGGL(mask_fused_kernel<3>, dim3(2048), dim3(MF_THREADS), dyn, s, a); break;
+    default: hipLaunchKernelGGL(mask_fused_kernel<0>, dim3(2048), dim3(MF_THREADS), dyn, s, a); break;
+  }
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -118,7 +118,7 @@ class _Conv:
         out_sizes = [(_conv_out(h, k, stride, pad), _conv_out(ww, k, stride, pad)) for h, ww in in_sizes]
         self.out_sizes = out_sizes
         flags |= _DEBUG_CONV_FLAGS          # plan selectors of include/sipmask_hip.h for whole-plan experiments
-        if not (split_k is True and _SPLIT_K_SMALL_FPN):   # ... and the engine's own (PipelinedPlan slots: big tiles), except
+        if not (split_k is True and _SPLIT_K_SMALL_FPN and _SPLIT_K):   # ... and the engine's own (PipelinedPlan slots: big tiles), except
             flags |= getattr(eng, "extra_conv_flags", 0)   # for the launches that keep the latency-shaped plan (below)
         self.desc = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, co_pad, k, stride, pad,
                                      in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
@@ -157,7 +157,7 @@ class _Conv:
         self.ws = None
         # (split_k: None = the engine's rule; True = also inside a pipelined slot -- the FPN's three launch-latency-shaped
         # convs, lat2 / P6 / P7: 6-66 tiles with 32-36 serial K steps, where the reduce launch costs no CU time worth counting)
-        want_split = getattr(eng, "split_k", _SPLIT_K) if split_k is None else (bool(split_k) and _SPLIT_K_SMALL_FPN)
+        want_split = getattr(eng, "split_k", _SPLIT_K) if split_k is None else (bool(split_k) and _SPLIT_K_SMALL_FPN and _SPLIT_K)
         if not self.f32 and offset is None and want_split and not self.patch:
             pl = H.conv_plan(self.desc)
             if pl["split_k"] > 1:
