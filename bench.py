@@ -381,53 +381,51 @@ def run_inference(args, rank, world, dev):
         # (M/mmdet/apis/test.py:12-72, sipmask_head.py:645-662): behind every step, on the slot's stream, sm_mask_rects +
         # sm_rle_encode and asynchronous copies of boxes / labels / counts / RLE strings into pinned buffers; the host
         # consumes them (RLE dicts per detection) before the slot is reused, i.e. `in_flight` steps later
-        pending = [False] * plan.depth
-        stat = dict(dets=0, rle_bytes=0, batches=0)
+        queue = []                                      # slots with unread results, oldest first
+        stat = dict(dets=0, rle_bytes=0, batches=0, host_s=0.0)
 
         def consume(k):
+            t0 = time.perf_counter()
             for boxes, labels, rles in plan.fetch(k):
                 stat["dets"] += len(rles)
                 stat["rle_bytes"] += sum(len(r["counts"]) for r in rles)
             stat["batches"] += 1
-            pending[k] = False
+            stat["host_s"] += time.perf_counter() - t0
 
         n_wr = max(args.steps, int(math.ceil(1.5 / (elapsed / args.steps))))
         calls = [0]
 
         def step_results():
-            k = plan.next_slot
-            if pending[k]:
-                consume(k)
-            plan.submit(imgs[nstep[0] % NSETS], pack=True, canvas_hw=shape[:2])
+            # submit FIRST, then read the results of the step submitted `depth` steps ago (its slot is the one just resubmitted:
+            # every slot double-buffers its pinned result sets), so `depth` steps stay in flight while the host builds the dicts
+            queue.append(plan.submit(imgs[nstep[0] % NSETS], pack=True, canvas_hw=shape[:2]))
             nstep[0] += 1
-            pending[k] = True
+            if len(queue) > plan.depth:
+                consume(queue.pop(0))
             calls[0] += 1
             if calls[0] == n_wr:                       # the last step of the window: drain, every result is consumed inside it
-                for j in range(plan.depth):
-                    kk = (k + 1 + j) % plan.depth
-                    if pending[kk]:
-                        consume(kk)
+                while queue:
+                    consume(queue.pop(0))
 
-        for _ in range(plan.depth + 2):                # warm-up: pinned buffers, RLE workspaces
-            k = plan.next_slot
-            if pending[k]:
-                consume(k)
-            plan.submit(imgs[nstep[0] % NSETS], pack=True, canvas_hw=shape[:2])
+        for _ in range(plan.depth + 3):                # warm-up: pinned buffers, RLE workspaces
+            queue.append(plan.submit(imgs[nstep[0] % NSETS], pack=True, canvas_hw=shape[:2]))
             nstep[0] += 1
-            pending[k] = True
-        for k in range(plan.depth):
-            if pending[k]:
-                consume(k)
-        stat.update(dets=0, rle_bytes=0, batches=0)
+            if len(queue) > plan.depth:
+                consume(queue.pop(0))
+        while queue:
+            consume(queue.pop(0))
+        stat.update(dets=0, rle_bytes=0, batches=0, host_s=0.0)
         e_wr = timed_steps(step_results, n_wr, sync_fn=torch.cuda.synchronize, device=dev)
         extras["with_results"] = dict(
             value=round(B * n_wr * world / e_wr, 3), unit="img/s", steps=n_wr, timed_region_s=round(e_wr, 3),
             ms_per_step=round(e_wr / n_wr * 1e3, 3), batches_consumed_this_rank=stat["batches"],
             detections_per_step=round(stat["dets"] / max(1, stat["batches"]), 1),
             rle_bytes_per_step=int(stat["rle_bytes"] / max(1, stat["batches"])),
+            host_ms_per_step_reading_results=round(stat["host_s"] / max(1, stat["batches"]) * 1e3, 3),
             per_step="device-side RLE of the step's masks (sm_mask_rects + sm_rle_encode) on the slot's stream + async D2H of "
                      "det_bboxes / det_labels / ndet / run counts / offsets / RLE strings into pinned buffers; the host builds "
-                     "the per-detection RLE dicts before the slot is reused (PipelinedPlan.submit(pack=True) / fetch)")
+                     "the per-detection RLE dicts of step k after submitting step k + in_flight (double-buffered pinned result "
+                     "sets per slot: PipelinedPlan.submit(pack=True) / fetch)")
         plan.join()
 
     # ---- per-step HIP-event breakdown (eager, on the launch stream) -> roofline of the dominant kernel

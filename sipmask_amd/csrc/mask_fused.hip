@@ -474,7 +474,7 @@ extern "C" int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, in
   hipLaunchKernelGGL(mask_plan_kernel, dim3(1), dim3(1024), 0, s, a);
   static const int variant = [] {
     const char* e = getenv("SIPMASK_MASK_VARIANT");
-    return e ? atoi(e) & 3 : 0;
+    return e ? atoi(e) & 3 : 2;     // measured (r4c5, 100 image-sized boxes x 4 images): 1.09 / 1.29 / 1.07 / 1.30 ms for 0..3
   }();
   const size_t dyn = (size_t)(src_cap + 4 * lo_cap + 2 * batch * max_num + 1) * sizeof(float);
   switch (variant) {

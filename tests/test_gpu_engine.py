@@ -402,14 +402,21 @@ def test_pipelined_submit_packs_results_and_keeps_metas_per_slot(monkeypatch):
     got, pending = [], []
     order = [0, 1, 2, 3, 1, 0, 3, 2, 0, 1]
     for bi in order:
-        k = pipe.next_slot
-        if any(s == k for s, _ in pending):
-            s0, b0 = pending.pop(0)
-            assert s0 == k
-            got.append((b0, pipe.fetch(s0)))
+        # submit first, read the step submitted `depth` steps ago afterwards: its slot is the one just resubmitted, so that
+        # slot momentarily holds TWO unread result sets (double-buffered pinned buffers) and three steps stay in flight
         pending.append((pipe.submit(batches[bi], img_metas=metas[bi % 2], pack=True, canvas_hw=(H_, W_)), bi))
+        if len(pending) > pipe.depth:
+            s0, b0 = pending.pop(0)
+            assert s0 == pending[-1][0]
+            got.append((b0, pipe.fetch(s0)))
     for s0, b0 in pending:
         got.append((b0, pipe.fetch(s0)))
+    with pytest.raises(RuntimeError):
+        pipe.fetch(0)                                    # nothing unread left
+    for _ in range(2 * pipe.depth):
+        pipe.submit(batches[0], pack=True, canvas_hw=(H_, W_))
+    with pytest.raises(RuntimeError):                    # a third unread set on a slot would overwrite the first
+        pipe.submit(batches[0], pack=True, canvas_hw=(H_, W_))
     assert len(got) == len(order)
     for bi, res in got:
         for k in range(2):
