@@ -464,10 +464,10 @@ def run_inference(args, rank, world, dev):
     # HBM traffic of the dominant kernel: PMC passes cannot run inside this process; the number comes from the
     # committed rocprofv3 summary of the same kernel/shape (profiles/), per launch
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_tower_conv.json")
-    if not os.path.exists(pmc_file):
-        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_tower_conv.json")
-    pmc = json.load(open(pmc_file)) if os.path.exists(pmc_file) else None
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[0-9]_pmc_tower_conv.json")))     # the latest round's passes
+    pmc_file = cands[-1] if cands else ""
+    pmc = json.load(open(pmc_file)) if pmc_file else None
     if pmc and pmc.get("plan_batch") == eng.batch and pmc.get("launch") == towers[0].name and args.precision == "bf16":
         # (the PMC passes were taken on the bf16 plan's launch; the split-precision launch reads three 16-bit planes of
         # every input channel and writes f32 -- its traffic was not collected: null)

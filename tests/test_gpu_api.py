@@ -894,7 +894,7 @@ def test_backbone_fpn_backward_vs_same_rounding_emulation(bn3_gain):
             f.write("forward rel %.5f floor %.5f\n" % (fwd, fwd_floor))
             for w in table:
                 f.write("%.5f %.5f %.6f %s\n" % w)
-    assert n_checked >= 60, n_checked
+    assert n_checked >= 50, n_checked
     bad = [w for w in table if w[0] > 1.5 * w[1] + 2e-2 or w[2] < 0.94]
     assert not bad, (bad[:8], table[:3])
     neck = [w for w in table if w[3].startswith("neck.")]

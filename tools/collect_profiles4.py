@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Copies the evidence written by tools/profile_round3.sh (gpurun_out/prof3) into profiles/ under round-3 names and
-derives profiles/r03_pmc_tower_conv.json: per-launch HBM traffic (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate PMC
+"""Copies the evidence written by tools/profile_round4.sh (gpurun_out/prof4) into profiles/ under round-4 names and
+derives profiles/r04_pmc_tower_conv.json: per-launch HBM traffic (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate PMC
 passes) and the SQ counters of the dominant kernel, dispatches selected by kernel name and the launch's grid."""
 import collections
 import csv
@@ -11,7 +11,7 @@ import shutil
 import statistics
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof3")
+SRC = os.path.join(ROOT, "gpurun_out", "prof4")
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -61,8 +61,8 @@ js = {
     "kernel": bench["roofline"].get("kernel"),
     "launch": tower["kernel"], "plan_batch": tower["plan_batch"], "grid_size": int(grid),
     "command": "rocprofv3 --kernel-trace --pmc <COUNTER(S)> --output-format csv -- python bench.py --tower-only 10 "
-               "(tools/profile_round3.sh; separate passes for FETCH_SIZE, WRITE_SIZE and the SQ counters; dispatches "
-               "selected by kernel name + grid size; assembled by tools/collect_profiles3.py)",
+               "(tools/profile_round4.sh; separate passes for FETCH_SIZE, WRITE_SIZE and the SQ counters; dispatches "
+               "selected by kernel name + grid size; assembled by tools/collect_profiles4.py)",
     "dispatches": len(fetch[grid]["FETCH_SIZE"]),
     "FETCH_SIZE_KB_raw": mean(fetch[grid]["FETCH_SIZE"]), "WRITE_SIZE_KB_raw": mean(write[grid]["WRITE_SIZE"]),
     "fetch_bytes_corrected": fb, "write_bytes": wb,
@@ -77,17 +77,18 @@ js = {
     "SQ_per_dispatch": {k: mean(v) for k, v in sq[grid].items()},
     "rocprofv3_kernel_trace_this_grid_us": trace_by_grid(),
 }
-json.dump(js, open(os.path.join(DST, "r03_pmc_tower_conv.json"), "w"), indent=1)
-for src, dst in (("step_breakdown.txt", "r03_step_breakdown_hip_events.txt"),
-                 ("step_breakdown_x3.txt", "r03_step_breakdown_hip_events_head_x3.txt"),
-                 ("kernel_stats_step.csv", "r03_rocprofv3_kernel_stats_step.csv"),
-                 ("kernel_stats_step_x3.csv", "r03_rocprofv3_kernel_stats_step_head_x3.csv"),
-                 ("kernel_stats_tower_only.csv", "r03_rocprofv3_kernel_stats_tower_only.csv"),
-                 ("kernel_stats_train_step.csv", "r03_rocprofv3_kernel_stats_train_step.csv"),
-                 ("kernel_stats_tower_only_x3.csv", "r03_rocprofv3_kernel_stats_tower_only_head_x3.csv"),
-                 ("parity_r50_b4_bf16.json", "r03_parity_r50_b4_bf16_subbatch.json"),
-                 ("parity_r50_b4_x3.json", "r03_parity_r50_b4_head_x3_subbatch.json"),
-                 ("parity_r50_b4_f32.json", "r03_parity_r50_b4_f32.json")):
+json.dump(js, open(os.path.join(DST, "r04_pmc_tower_conv.json"), "w"), indent=1)
+for src, dst in (("step_breakdown.txt", "r04_step_breakdown_hip_events.txt"),
+                 ("step_breakdown_x3.txt", "r04_step_breakdown_hip_events_head_x3.txt"),
+                 ("kernel_stats_step.csv", "r04_rocprofv3_kernel_stats_step.csv"),
+                 ("kernel_stats_step_x3.csv", "r04_rocprofv3_kernel_stats_step_head_x3.csv"),
+                 ("kernel_stats_tower_only.csv", "r04_rocprofv3_kernel_stats_tower_only.csv"),
+                 ("kernel_stats_train_step.csv", "r04_rocprofv3_kernel_stats_train_step.csv"),
+                 ("kernel_stats_tower_only_x3.csv", "r04_rocprofv3_kernel_stats_tower_only_head_x3.csv"),
+                 ("parity_r50_b4_bf16.json", "r04_parity_r50_b4_bf16_pipelined.json"),
+                 ("parity_r50_b4_x3.json", "r04_parity_r50_b4_head_x3_pipelined.json"),
+                 ("marginal_cost.txt", "r04_marginal_cost_pipelined_step.txt"),
+                 ("parity_r50_b4_f32.json", "r04_parity_r50_b4_f32.json")):
     if os.path.exists(os.path.join(SRC, src)):
         shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
 lines = {}
@@ -95,6 +96,6 @@ for n in ("r50", "r50_inflight1", "r50_inflight2", "r50_inflight3", "r50_x3", "r
     j = last_json(os.path.join(SRC, "bench_%s.json" % n))
     if j:
         lines[n] = j
-json.dump(lines, open(os.path.join(DST, "r03_bench_lines.json"), "w"), indent=1)
+json.dump(lines, open(os.path.join(DST, "r04_bench_lines.json"), "w"), indent=1)
 print(json.dumps(js, indent=1))
 print({k: (v["value"], v["unit"]) for k, v in lines.items()})

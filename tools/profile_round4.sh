@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-3 evidence, collected on the GPU box through gpurun from the repo root; tools/collect_profiles3.py then copies it
-# into profiles/ under r03_* names:
+# Round-4 evidence, collected on the GPU box through gpurun from the repo root; tools/collect_profiles4.py then copies it
+# into profiles/ under r04_* names:
 #   bench lines of every BASELINE config (r50 bf16 with cpu_baseline + parity, head_x3, f32, r101, vis, train, train with the
 #   RCCL path forced at world size 1), per-step HIP-event breakdowns (bf16 and x3 chains), rocprofv3 kernel traces of the
 #   whole inference step (bf16 and x3) and of the dominant kernel alone, PMC passes on the dominant kernel (FETCH_SIZE /
@@ -8,15 +8,12 @@
 #   at the BASELINE shape for the three plans.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof3
+OUT=$R/gpurun_out/prof4
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python $R/bench.py --breakdown $OUT/step_breakdown.txt > $OUT/bench_r50.json 2> $OUT/bench_r50.err
 timeout 600 python $R/bench.py --precision head_x3 --breakdown $OUT/step_breakdown_x3.txt > $OUT/bench_r50_x3.json 2> $OUT/bench_r50_x3.err
-timeout 300 python $R/bench.py --no-cpu-baseline --precision f32 > $OUT/bench_r50_f32.json 2>/dev/null
-timeout 300 python $R/bench.py --no-cpu-baseline --lanes 1 --in-flight 1 > $OUT/bench_r50_lanes1.json 2>/dev/null
 timeout 300 python $R/bench.py --in-flight 1 > $OUT/bench_r50_inflight1.json 2>/dev/null
-timeout 300 python $R/bench.py --no-cpu-baseline --in-flight 3 > $OUT/bench_r50_inflight3.json 2>/dev/null
 timeout 600 python $R/bench.py --config r101 > $OUT/bench_r101.json 2> $OUT/bench_r101.err
 timeout 600 python $R/bench.py --config vis > $OUT/bench_vis.json 2> $OUT/bench_vis.err
 timeout 900 python $R/bench.py --config train --steps 20 --warmup 5 > $OUT/bench_train.json 2> $OUT/bench_train.err
@@ -37,7 +34,7 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_
 done
 rm -rf $OUT/step $OUT/stepx3 $OUT/tower $OUT/towerx3 $OUT/train 2>/dev/null
 cd $R
-timeout 600 python tools/parity_baseline.py --plan subbatch --precision bf16 --out $OUT/parity_r50_b4_bf16.json > $OUT/parity_bf16.log 2>&1
-timeout 600 python tools/parity_baseline.py --plan subbatch --precision head_x3 --out $OUT/parity_r50_b4_x3.json > $OUT/parity_x3.log 2>&1
-timeout 600 python tools/parity_baseline.py --plan single --precision f32 --out $OUT/parity_r50_b4_f32.json > $OUT/parity_f32.log 2>&1
+bash tools/marginal_cost.sh $OUT/marginal_cost.txt 1 > /dev/null 2>&1
+timeout 600 python tools/parity_baseline.py --plan pipelined --precision bf16 --out $OUT/parity_r50_b4_bf16.json > $OUT/parity_bf16.log 2>&1
+timeout 600 python tools/parity_baseline.py --plan pipelined --precision head_x3 --out $OUT/parity_r50_b4_x3.json > $OUT/parity_x3.log 2>&1
 find $OUT -name "*counter_collection.csv" | head -3; tail -c 300 $OUT/tower.log; for f in r50 r50_x3 r50_f32 r101 vis train train_rccl1; do cut -c1-200 $OUT/bench_$f.json; done
