@@ -10,6 +10,8 @@
 // `rect` hint (the detection box plus a margin: CropSplit zeroes everything outside the box) only the box is
 // read.  Threads own 4 adjacent columns (one dword per row) of a row slice, so a wave reads 256 contiguous
 // bytes per row; transitions are found with one XOR per dword against the previous row.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -372,10 +374,14 @@ extern "C" int sm_rle_encode(const uint8_t* masks, const int32_t* ndet, const in
   int32_t* unit_ws = (int32_t*)((char*)workspace + nd * max_runs * 4);
   hipStream_t s = sm_hip_stream(stream);
   const bool aligned = (wo % 4 == 0) && (((uintptr_t)masks & 3) == 0);
-  // Block size: one block per detection.  With a batch's worth of detections (>= 256) the 4-wave blocks already cover every
-  // SIMD, and a 16-wave block spends most of its time in block-wide scans over threads that own nothing (the timed plan's
-  // 400 detections of ~65 x 65 pixels: 0.122 ms with 1 024 threads); a handful of detections keeps the 16 waves (latency).
-  const int nthreads = (long long)batch * max_num >= 256 ? 256 : RLE_THREADS;
+  // Block size: one block per detection, 16 waves.  Measured on the timed plan's 400 detections of ~65 x 65 pixels (r4c7 / r4c8):
+  // 1 024 threads 0.122 ms, 256 threads 0.212 ms -- the kernel is a chain of block-wide scans whose length follows the units
+  // per thread, not the pixels.  SIPMASK_RLE_THREADS (256 / 512 / 1024) keeps the A/B.
+  static const int nthreads = [] {
+    const char* e = getenv("SIPMASK_RLE_THREADS");
+    const int v = e ? atoi(e) : RLE_THREADS;
+    return (v == 256 || v == 512) ? v : RLE_THREADS;
+  }();
   if (aligned)
     hipLaunchKernelGGL(rle_encode_kernel<true>, dim3(max_num, batch), dim3(nthreads), 0, s, masks, ndet, rect, pos_ws,
                        unit_ws, counts, nruns, nchars, a);
