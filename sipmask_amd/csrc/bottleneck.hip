@@ -12,6 +12,8 @@
 // path (same K order, same rounding points).  The same holds between conv3's output and the next conv1.
 // Every wave owns 32 positions for the whole chain; the 1x1 weights stream through LDS in 16 KB slices (LDS-DMA,
 // ping-pong between a dedicated buffer and the finished K loop's stages), 128-byte rows with the conv_igemm swizzle.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -35,8 +37,11 @@ __device__ __attribute__((aligned(16))) const unsigned int g_zero16b[4] = {0u, 0
 constexpr int BT_BPOS = 128;
 constexpr int BT_SLICE_BYTES = 16384;
 
-template <int C2, bool CHAIN1>
-__global__ __launch_bounds__(256, 3) void bottleneck_tail_kernel(const BtArgs a) {
+// OCC: blocks per CU the register allocation aims for.  The unchained <64> kernel needs 135 VGPRs at OCC 3; capped at 128
+// (OCC 4: four spills outside the loops) a fourth block fits, and these launches are bandwidth-shaped (layer1: 310 MB per
+// 4-image launch): more loads in flight per CU.  A/B: SIPMASK_BT_OCC (3 | 4).
+template <int C2, bool CHAIN1, int OCC>
+__global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs a) {
   constexpr int TCO = C2 / 32;                  // MFMA tiles along the conv2 couts (all of them in one wave)
   constexpr int NW = C2 / 64;                   // weight DMA instructions per thread per K step
   constexpr int NX = BT_BPOS / 64;
@@ -313,17 +318,17 @@ __global__ __launch_bounds__(256, 3) void bottleneck_tail_kernel(const BtArgs a)
 
 constexpr int bt_lds_bytes(int c2, bool chain) { return 2 * (c2 + BT_BPOS) * 64 + BT_SLICE_BYTES + (chain ? 2 * BT_SLICE_BYTES : 0); }
 
-template <int C2, bool CHAIN1>
+template <int C2, bool CHAIN1, int OCC>
 int bt_launch(const BtArgs& a, dim3 grid, hipStream_t s) {
   constexpr int lds = bt_lds_bytes(C2, CHAIN1);
   static bool attr_set = false;                 // > 64 KB of dynamic LDS needs the opt-in once per kernel
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail_kernel<C2, CHAIN1>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail_kernel<C2, CHAIN1, OCC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return SM_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bottleneck_tail_kernel<C2, CHAIN1>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((bottleneck_tail_kernel<C2, CHAIN1, OCC>), grid, dim3(256), lds, s, a);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -358,6 +363,14 @@ extern "C" int sm_bottleneck_tail(int batch, int h, int w, int channels, const v
   a.M = (int)M;
   const dim3 grid(sm_cdiv(M, BT_BPOS));
   hipStream_t s = sm_hip_stream(stream);
-  if (channels == 64) return chain ? bt_launch<64, true>(a, grid, s) : bt_launch<64, false>(a, grid, s);
-  return chain ? bt_launch<128, true>(a, grid, s) : bt_launch<128, false>(a, grid, s);
+  static const int occ = [] {
+    const char* e = getenv("SIPMASK_BT_OCC");
+    return (e && atoi(e) == 4) ? 4 : 3;
+  }();
+  if (channels == 64) {
+    if (chain) return bt_launch<64, true, 3>(a, grid, s);
+    return occ == 4 ? bt_launch<64, false, 4>(a, grid, s) : bt_launch<64, false, 3>(a, grid, s);
+  }
+  if (chain) return bt_launch<128, true, 3>(a, grid, s);
+  return occ == 4 ? bt_launch<128, false, 4>(a, grid, s) : bt_launch<128, false, 3>(a, grid, s);
 }
