@@ -109,15 +109,11 @@ __device__ __forceinline__ uint32_t rle_prev(const uint8_t* __restrict__ m, cons
 }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(RLE_THREADS) void rle_encode_kernel(const uint8_t* __restrict__ masks,
-                                                                 const int32_t* __restrict__ ndet,
-                                                                 const int32_t* __restrict__ rect,
-                                                                 uint32_t* __restrict__ pos_ws, int32_t* __restrict__ unit_ws,
-                                                                 uint32_t* __restrict__ counts, int32_t* __restrict__ nruns,
-                                                                 int32_t* __restrict__ nchars, const RleArgs a) {
-  __shared__ int s_wave[RLE_THREADS / 64];
-  __shared__ long long s_red[RLE_THREADS / 64];
-  const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+__device__ void rle_encode_one(const int i, const int b, int* s_wave, long long* s_red, const uint8_t* __restrict__ masks,
+                               const int32_t* __restrict__ ndet, const int32_t* __restrict__ rect,
+                               uint32_t* __restrict__ pos_ws, int32_t* __restrict__ unit_ws, uint32_t* __restrict__ counts,
+                               int32_t* __restrict__ nruns, int32_t* __restrict__ nchars, const RleArgs& a) {
+  const int tid = threadIdx.x;
   const int det = b * a.max_num + i;
   if (i >= ndet[b]) {
     if (tid == 0) {
@@ -259,15 +255,33 @@ __global__ __launch_bounds__(RLE_THREADS) void rle_encode_kernel(const uint8_t* 
   }
 }
 
-// rleToString of every detection into one packed buffer; offsets[d] .. offsets[d+1] is detection d's string
-__global__ __launch_bounds__(RLE_THREADS) void rle_pack_kernel(const uint32_t* __restrict__ counts,
-                                                               const int32_t* __restrict__ nruns,
-                                                               const int32_t* __restrict__ nchars,
-                                                               uint8_t* __restrict__ packed, int64_t* __restrict__ offsets,
-                                                               const RleArgs a) {
+// At most RLE_MAX_BLOCKS blocks, each walking detections blockIdx.x, blockIdx.x + gridDim.x, ...: a 16-wave block per
+// detection (400 of them for a 4-image batch) takes 25 of a CU's 32 wave slots wherever two land on one CU, and for the ~0.1 ms
+// the scans take no 8-wave / 140 KB tile of another step in flight can start there; one block per CU leaves room for it.
+constexpr int RLE_MAX_BLOCKS = 256;
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(RLE_THREADS) void rle_encode_kernel(const uint8_t* __restrict__ masks,
+                                                                 const int32_t* __restrict__ ndet,
+                                                                 const int32_t* __restrict__ rect,
+                                                                 uint32_t* __restrict__ pos_ws, int32_t* __restrict__ unit_ws,
+                                                                 uint32_t* __restrict__ counts, int32_t* __restrict__ nruns,
+                                                                 int32_t* __restrict__ nchars, const RleArgs a) {
   __shared__ int s_wave[RLE_THREADS / 64];
   __shared__ long long s_red[RLE_THREADS / 64];
-  const int det = blockIdx.y * a.max_num + blockIdx.x, tid = threadIdx.x;
+  const int total = a.batch * a.max_num;
+  for (int d = blockIdx.x; d < total; d += gridDim.x) {
+    rle_encode_one<ALIGNED>(d % a.max_num, d / a.max_num, s_wave, s_red, masks, ndet, rect, pos_ws, unit_ws, counts, nruns,
+                            nchars, a);
+    __syncthreads();                       // the shared scratch is reused by the next detection
+  }
+}
+
+// rleToString of every detection into one packed buffer; offsets[d] .. offsets[d+1] is detection d's string
+__device__ void rle_pack_one(const int det, int* s_wave, long long* s_red, const uint32_t* __restrict__ counts,
+                             const int32_t* __restrict__ nruns, const int32_t* __restrict__ nchars,
+                             uint8_t* __restrict__ packed, int64_t* __restrict__ offsets, const RleArgs& a) {
+  const int tid = threadIdx.x;
   const int ndets = a.batch * a.max_num;
   long long off = 0;
   for (int d = tid; d < det; d += (int)blockDim.x) off += nchars[d];
@@ -305,6 +319,20 @@ __global__ __launch_bounds__(RLE_THREADS) void rle_pack_kernel(const uint32_t* _
       out[o++] = (uint8_t)(ch + 48);
     }
     carry += tot;
+  }
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void rle_pack_kernel(const uint32_t* __restrict__ counts,
+                                                               const int32_t* __restrict__ nruns,
+                                                               const int32_t* __restrict__ nchars,
+                                                               uint8_t* __restrict__ packed, int64_t* __restrict__ offsets,
+                                                               const RleArgs a) {
+  __shared__ int s_wave[RLE_THREADS / 64];
+  __shared__ long long s_red[RLE_THREADS / 64];
+  const int total = a.batch * a.max_num;
+  for (int d = blockIdx.x; d < total; d += gridDim.x) {
+    rle_pack_one(d, s_wave, s_red, counts, nruns, nchars, packed, offsets, a);
+    __syncthreads();
   }
 }
 
@@ -382,13 +410,14 @@ extern "C" int sm_rle_encode(const uint8_t* masks, const int32_t* ndet, const in
     const int v = e ? atoi(e) : RLE_THREADS;
     return (v == 256 || v == 512) ? v : RLE_THREADS;
   }();
+  const int nblocks = (int)(nd < RLE_MAX_BLOCKS ? nd : RLE_MAX_BLOCKS);
   if (aligned)
-    hipLaunchKernelGGL(rle_encode_kernel<true>, dim3(max_num, batch), dim3(nthreads), 0, s, masks, ndet, rect, pos_ws,
+    hipLaunchKernelGGL(rle_encode_kernel<true>, dim3(nblocks), dim3(nthreads), 0, s, masks, ndet, rect, pos_ws,
                        unit_ws, counts, nruns, nchars, a);
   else
-    hipLaunchKernelGGL(rle_encode_kernel<false>, dim3(max_num, batch), dim3(nthreads), 0, s, masks, ndet, rect, pos_ws,
+    hipLaunchKernelGGL(rle_encode_kernel<false>, dim3(nblocks), dim3(nthreads), 0, s, masks, ndet, rect, pos_ws,
                        unit_ws, counts, nruns, nchars, a);
-  hipLaunchKernelGGL(rle_pack_kernel, dim3(max_num, batch), dim3(nthreads), 0, s, counts, nruns, nchars, packed, offsets,
+  hipLaunchKernelGGL(rle_pack_kernel, dim3(nblocks), dim3(nthreads), 0, s, counts, nruns, nchars, packed, offsets,
                      a);
   SM_LAUNCH_CHECK();
   return SM_OK;
