@@ -47,8 +47,6 @@ _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"
 # FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes
 # the shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
 # shapes), "0" = three launches (A/B)
-# sip_mask_lat0 (1x1, 768 -> 512 over the stride-8 grid: M = 67 200 at B=4) on the 256 x 256 8-wave tile: A/B SIPMASK_LAT0_TILE256
-_LAT0_FLAGS = (_lib.SM_CONV_DBG_TILE256 | _lib.SM_CONV_DBG_HAND_PLACED) if os.environ.get("SIPMASK_LAT0_TILE256", "0") == "1" else 0
 _DIAG_SKIP = __import__("re").compile(os.environ["SIPMASK_DIAG_SKIP"]) if os.environ.get("SIPMASK_DIAG_SKIP") else None
 _FPN_GROUPED = os.environ.get("SIPMASK_FPN_GROUPED", "auto")
 _LEVEL_CONV_MIN_WORK = float(os.environ.get("SIPMASK_LEVEL_CONV_MIN_WORK", "50"))
@@ -797,7 +795,7 @@ class SipMaskEngine:
         lat0_x3 = torch.empty(n0, 3 * 512, dtype=F16, device=dev)
         self._add_conv(_Conv(self, "head.sip_mask_lat0", sd[h + "sip_mask_lat0.weight"], sd[h + "sip_mask_lat0.bias"],
                              B, [(h0, w0)], [0], cat_x3, 3 * 768, 1, 0, lat0_x3, [0], 3 * 512,
-                             flags=SM_CONV_RELU | _lib.SM_CONV_OUT_X3 | _LAT0_FLAGS, mode="x3"), 2)
+                             flags=SM_CONV_RELU | _lib.SM_CONV_OUT_X3, mode="x3"), 2)
         self.basis_lo = torch.empty(n0, 32, dtype=f32, device=dev)
         self._add_conv(_Conv(self, "head.sip_mask_lat", sd[h + "sip_mask_lat.weight"], sd[h + "sip_mask_lat.bias"], B,
                              [(h0, w0)], [0], lat0_x3, 3 * 512, 1, 1, self.basis_lo, [0], 32, flags=SM_CONV_RELU, mode="x3"), 2)
@@ -925,7 +923,7 @@ class SipMaskEngine:
                 s, self.cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, self.precision == "f32")), 2)
         self.lat0 = self._buf(B * h0 * w0, 512)
         self._add_conv(_Conv(self, "head.sip_mask_lat0", sd[h + "sip_mask_lat0.weight"], sd[h + "sip_mask_lat0.bias"],
-                             B, [(h0, w0)], [0], self.cat, 768, 1, 0, self.lat0, [0], 512, flags=SM_CONV_RELU | _LAT0_FLAGS), 2)
+                             B, [(h0, w0)], [0], self.cat, 768, 1, 0, self.lat0, [0], 512, flags=SM_CONV_RELU), 2)
         self.basis_lo = self._buf(B * h0 * w0, 32, torch.float32)
         self._add_conv(_Conv(self, "head.sip_mask_lat", sd[h + "sip_mask_lat.weight"], sd[h + "sip_mask_lat.bias"], B,
                              [(h0, w0)], [0], self.lat0, 512, 1, 1, self.basis_lo, [0], 32,
