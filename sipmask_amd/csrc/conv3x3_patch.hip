@@ -80,7 +80,6 @@ __device__ __forceinline__ void sfor(F&& f) {
 __device__ __attribute__((aligned(16))) const unsigned int g_zero16p[4] = {0u, 0u, 0u, 0u};
 
 constexpr int PT_BCO = 256, PT_BPOS = 256, PT_THREADS = 512;
-constexpr int PT_WSTAGE = PT_BCO * 128;           // one weight stage: 256 cout rows x 128 B (2 taps x 32 channels)
 
 // One tile: 256 couts x (WPOS * TPOS * 32) positions on 8 waves laid out WCO (cout) x WPOS (position), each wave
 // TCO x TPOS MFMA tiles of 32 x 32.  <2,4,4,2> is the 256-position tile; <4,2,2,3> / <4,2,2,2> are the 192- / 128-
@@ -89,9 +88,15 @@ template <int WCO, int WPOS, int TCO, int TPOS, int VAR>
 __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, const int tlin, unsigned char* const smem) {
   constexpr int NWV = WCO * WPOS;               // waves of the block: 8 (shipped), 4 in the one-wave-per-SIMD experiment
   constexpr int MAXPP = 48 / NWV;               // patch DMA pieces per wave (<= 768 patch rows = 48 pieces)
-  constexpr int WPW = 32 / NWV;                 // weight DMA pieces per wave per stage
+  // couts of the tile: 256 (towers, FPN, predictors) or 32 (round 4: the convs with a handful of output channels --
+  // sip_mask_lat 512 -> 32, fcos_reg + centerness 256 -> 5 -- whose cost on the implicit-GEMM kernel is the 9x re-read of
+  // their INPUT, 0.10 / 0.065 ms per B=4 launch for 20 / 2 GFLOP; here the input crosses L2 -> LDS once)
+  constexpr int BCO = WCO * TCO * 32;
+  constexpr int WST = BCO * 128;                // one weight stage: BCO cout rows x 128 B (2 taps x 32 channels)
+  constexpr int NPIECE = BCO / 8;               // weight DMA pieces (8 rows x 128 B) of a stage
+  constexpr int WPW = (NPIECE + NWV - 1) / NWV; // ... per wave
   constexpr int PPS = MAXPP / 3;                // patch pieces per wave per stage (a chunk lands over three stages)
-  static_assert((NWV == 8 || NWV == 4) && WCO * TCO * 32 == PT_BCO, "8 or 4 waves, 256 couts");
+  static_assert((NWV == 8 || NWV == 4) && (BCO == 256 || BCO == 32), "8 or 4 waves, 256 or 32 couts");
   // VAR bits: 1 = software-pipelined stage, 2 = staggered DMA issue (waves 4-7 issue theirs between the two taps of a stage,
   // so the two waves of a SIMD are never both stalled in the LDS-DMA issue); 4 / 8 = ABLATIONS for the micro-benchmark
   // (no DMA / no MFMA in the main loop: wrong results by construction, never used by the library's own launches)
@@ -123,7 +128,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
 
   const int PB = a.prow_cap * 64;                 // bytes of one patch buffer
   unsigned char* const Wb0 = smem;
-  unsigned char* const Pb0 = smem + 2 * PT_WSTAGE;
+  unsigned char* const Pb0 = smem + 2 * WST;
 
   // ---- loader state.  A DMA piece is 16 rows x 64 B: lane L -> row (L >> 2), physical slot (L & 3), so it fetches
   // the logical 16-byte chunk (L & 3) ^ ((row >> 2) & 3) of that row (swizzle on the source side, guide rule 21).
@@ -154,17 +159,19 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   const uint16_t* wsrc[WPW];
 #pragma unroll
   for (int i = 0; i < WPW; ++i) {
-    const int row = (wave * WPW + i) * 8 + (lane >> 3);
+    const int piece = wave * WPW + i;
+    const int row = (piece < NPIECE ? piece : 0) * 8 + (lane >> 3);      // (pieces beyond the stage are never issued)
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    wsrc[i] = a.w + grp * a.w_gstride + lev * a.w_lstride + (long long)(nt * PT_BCO + row) * a.Kp + chunk * 8;
+    wsrc[i] = a.w + grp * a.w_gstride + lev * a.w_lstride + (long long)(nt * BCO + row) * a.Kp + chunk * 8;
   }
   auto dma_w = [&](int stage, int buf) {            // weight stage `stage` (K steps 2*stage, 2*stage+1) -> Wb[buf]
-    unsigned char* dst = Wb0 + buf * PT_WSTAGE;
+    unsigned char* dst = Wb0 + buf * WST;
     sfor<WPW>([&](auto I) {
       constexpr int i = decltype(I)::value;
       const int piece = wave * WPW + i;
-      __builtin_amdgcn_global_load_lds((glb_void*)(wsrc[i] + (long long)stage * 64),
-                                       (lds_void*)(dst + piece * 1024), 16, 0, 0);
+      if (NPIECE % NWV == 0 || piece < NPIECE)             // wave-uniform; compile-time true for the 256-cout tile
+        __builtin_amdgcn_global_load_lds((glb_void*)(wsrc[i] + (long long)stage * 64),
+                                         (lds_void*)(dst + piece * 1024), 16, 0, 0);
     });
   };
   auto dma_patch_piece = [&](auto I, int chunk_c, int buf) {     // piece I of this wave, channel chunk c -> Pb[buf]
@@ -248,7 +255,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
       constexpr int sidx = decltype(SC)::value;
       constexpr int hh = sidx & 1;
       constexpr int cc = sidx / 9, t9 = sidx % 9, kh = t9 / 3, kw = t9 % 3;
-      const unsigned char* Wh = Wb0 + (st & 1) * PT_WSTAGE;
+      const unsigned char* Wh = Wb0 + (st & 1) * WST;
       const unsigned char* P = Pb0 + cc * PB;
       // the patch-row addresses of the 18 taps are invariant over the channel-chunk loop and hipcc hoists all of them
       // (36+ VGPRs held across the loop -> spills next to 128 accumulators + 48 fragment registers); an opaque copy of
@@ -349,7 +356,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
       };
       const bool early = !STAGGER || wave < 4;                      // wave-uniform (SGPR)
       if (early) issue_dma();
-      const unsigned char* Wst = Wb0 + (st & 1) * PT_WSTAGE;
+      const unsigned char* Wst = Wb0 + (st & 1) * WST;
       if constexpr (PIPE) {
         // software-pipelined stage: 4 sub-steps (tap hh, K half kk) of TCO*TPOS MFMAs; the fragments of sub-step i+1 are
         // read into the other register set behind the MFMAs of sub-step i ("1 MFMA, 1 ds_read" ladder), so only the
@@ -455,7 +462,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
           for (int e = 0; e < 8; ++e) v[e] *= a.acc_scale;
         }
         const int cl = wco * (TCO * 32) + tc * 32 + 8 * (2 * qp + khalf);
-        const int c0 = nt * PT_BCO + cl;
+        const int c0 = nt * BCO + cl;
         const bool live = pvalid && c0 < a.cout;
         if (live) {
           if (biasp != nullptr) {
@@ -509,14 +516,14 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
       const float tot = gn_half_wave_totals<TCO * 4>(gpart, l31);
       const int k = l31 >> sh;
       const int cl = wco * (TCO * 32) + (k >> 2) * 32 + 8 * (2 * ((k >> 1) & 1) + khalf);
-      if ((l31 & ((1 << sh) - 1)) == 0 && nt * PT_BCO + cl < a.cout) atomicAdd(&gn_bins[(cl >> 3) * 2 + (k & 1)], gn_fix(tot));
+      if ((l31 & ((1 << sh) - 1)) == 0 && nt * BCO + cl < a.cout) atomicAdd(&gn_bins[(cl >> 3) * 2 + (k & 1)], gn_fix(tot));
     }
   }
   if (gn) {                                          // the whole tile lies in image n of level lev
     __syncthreads();
     if (tid < 64) {
       const unsigned long long v = gn_bins[tid];
-      const int g = (nt * PT_BCO >> 3) + (tid >> 1);
+      const int g = (nt * BCO >> 3) + (tid >> 1);
       if (v != 0ull && g < (a.cout >> 3))
         atomicAdd(gnp + (((long long)n * a.nlev + lev) * (a.cout >> 3) + g) * 2 + (tid & 1), v);
     }
@@ -546,6 +553,13 @@ __global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_kernel(const Patc
   }
 }
 
+// 32 couts x 256 positions on 8 waves (one 32 x 32 MFMA tile per wave per K sub-step), uniform launches only
+template <int PIPE>
+__global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_n32_kernel(const PatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [W stage 0][W stage 1][patch 0][patch 1]
+  patch_tile<1, 8, 1, 1, PIPE>(a, 0, xcd_tile(blockIdx.x, a.nblk[0]), smem);
+}
+
 #ifdef SM_EXPERIMENTS
 // EXPERIMENT (round 3): the same 256 x 256 tile on FOUR waves, 128 couts x 128 positions each (16 accumulator tiles = 256
 // registers, beyond the 256 architectural VGPRs: one wave per SIMD, accumulators in AGPRs), 8 fragment reads per 16 MFMAs
@@ -557,12 +571,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_kernel_w4(const PatchArg
 }
 #endif
 
+// cout tile of a descriptor: weights padded to 32 rows select the 32-cout kernel, else 256-row tiles
+int patch_bco(const sm_conv_desc* d) { return d->cout_pad == 32 ? 32 : PT_BCO; }
+
 int patch_check(const sm_conv_desc* d) {
   if (!d) return SM_ERR_BAD_ARG;
   if (d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return SM_ERR_BAD_SHAPE;
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dil != 1) return SM_ERR_UNSUPPORTED;
   if (d->cin % 64 != 0 || d->cin < 64 || d->in_cstride % 8 != 0) return SM_ERR_UNSUPPORTED;
-  if (d->cout < 1 || d->cout_pad % PT_BCO != 0 || d->cout_pad < d->cout) return SM_ERR_UNSUPPORTED;
+  if (d->cout < 1 || (d->cout_pad % PT_BCO != 0 && d->cout_pad != 32) || d->cout_pad < d->cout) return SM_ERR_UNSUPPORTED;
+  if (d->cout_pad == 32 && (d->ngroups > 1 || d->w_level_stride != 0)) return SM_ERR_UNSUPPORTED;   // plain launches only
   if ((d->cout & 7) || (d->out_cstride & 7) || (d->out_coff & 7)) return SM_ERR_UNSUPPORTED;
   if (d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST | SM_CONV_IN_RELU)) return SM_ERR_UNSUPPORTED;
   if (d->w_batch_stride != 0) return SM_ERR_UNSUPPORTED;
@@ -611,7 +629,7 @@ double shape_cost(long long nbig, long long nsmall, int small) {
 }
 
 void plan_shape(const sm_conv_desc* d, PatchShape* ps) {
-  const int ntn = d->cout_pad / PT_BCO, ng = d->ngroups > 1 ? d->ngroups : 1;
+  const int ntn = d->cout_pad / patch_bco(d), ng = d->ngroups > 1 ? d->ngroups : 1;
   const long long segs = (long long)d->batch * ntn * ng;       // segments per level
   long long full[SM_MAX_LEVELS];                               // whole 256-tiles a segment of the level can hold
   long long all_big = 0;
@@ -625,7 +643,7 @@ void plan_shape(const sm_conv_desc* d, PatchShape* ps) {
   ps->small = 128;
   ps->nbig = all_big;
   ps->nsmall = 0;
-  if (d->flags & SM_CONV_DBG_PATCH_UNIFORM) return;
+  if ((d->flags & SM_CONV_DBG_PATCH_UNIFORM) || d->cout_pad == 32) return;      // (the 32-cout kernel has the 256-position tile only)
   const int smalls[2] = {128, 192};
   const long long max_rounds = all_big / PT_CUS + 1;
   for (int si = 0; si < 2; ++si) {
@@ -741,7 +759,8 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   a.cin = d->cin;
   a.cout = d->cout;
   a.nc = d->cin / 32;
-  a.ntn = d->cout_pad / PT_BCO;
+  const int bco = patch_bco(d);
+  a.ntn = d->cout_pad / bco;
   a.in_cstride = d->in_cstride;
   a.out_cstride = d->out_cstride;
   a.out_coff = d->out_coff;
@@ -768,7 +787,7 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
     if (sm_zero_async(gn_stats, sizeof(unsigned long long) * 2 * a.ngroups * d->batch * d->nlev * (d->cout / 8), s) != hipSuccess)
       return SM_ERR_LAUNCH;
   }
-  const size_t lds = 2 * (size_t)PT_WSTAGE + 2 * (size_t)a.prow_cap * 64;
+  const size_t lds = 2 * (size_t)bco * 128 + 2 * (size_t)a.prow_cap * 64;
   if (lds > 160 * 1024) return SM_ERR_UNSUPPORTED;
   const long long nblk = nb0 + nb1;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
@@ -797,6 +816,13 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
     return SM_OK;
   };
   int lrc = SM_ERR_UNSUPPORTED;
+  if (bco == 32) {
+    if (nb1 != 0) return SM_ERR_BAD_SHAPE;
+    lrc = launch(conv3x3_patch_n32_kernel<0>);
+    if (lrc != SM_OK) return lrc;
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+  }
 #define PT_CASE(V)                                                                                                  \
   case V:                                                                                                           \
     lrc = ps.small == 128 ? launch(conv3x3_patch_kernel<128, V>) : launch(conv3x3_patch_kernel<192, V>);            \

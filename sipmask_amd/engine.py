@@ -37,6 +37,7 @@ _PATCH_CONV = __import__("os").environ.get("SIPMASK_PATCH_CONV", "1") != "0"   #
 # reach beyond the window radius (SipMaskEngine._tune_deform); "0" / "1" pin the window kernel / the gather loader.
 _DEFORM_MODE = __import__("os").environ.get("SIPMASK_DEFORM_GATHER", "auto")
 _DEFORM_FLAGS = _lib.SM_CONV_DBG_DEFORM_GATHER if _DEFORM_MODE == "1" else 0
+_PATCH_SMALL_COUT = __import__("os").environ.get("SIPMASK_PATCH_SMALL_COUT", "1") != "0"   # A/B: the 32-cout patch tile
 _PATCH_MIN_WORK = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_WORK", "100"))   # 256x256 tile equivalents
 _PATCH_MIN_FILL = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_FILL", "0.6"))
 # bottleneck fusion in layer1 / layer2: 0 = separate launches, 1 = conv2+conv3, 2 = conv2+conv3+next conv1.  Measured
@@ -130,7 +131,12 @@ class _Conv:
         self.patch = False
         if (not self.f32 and offset is None and residual is None and _PATCH_CONV and k == 3 and stride == 1 and pad == 1
                 and ci % 64 == 0 and (cin == ci or self.x3)):
-            dp = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, (co + 255) // 256 * 256, k, stride,
+            # cout tile of the patch kernel: 256, or 32 for the convs with a handful of output channels (round 4: sip_mask_lat
+            # 512 -> 32 and fcos_reg + centerness 256 -> 8 spent 0.10 / 0.065 ms per B=4 launch on the implicit-GEMM kernel
+            # re-reading their INPUT nine times; the grouped / per-level launches keep the 256 tile)
+            small_co = co <= 32 and co % 8 == 0 and getattr(self, "_patch_groups", 1) == 1 and _PATCH_SMALL_COUT
+            pad_co = H.patch_cout_pad(co) if small_co else (co + 255) // 256 * 256
+            dp = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, pad_co, k, stride,
                                   pad, in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
                                   scale_nch, level_scale, deform_groups, acc_scale=acc_scale)
             if H.conv3x3_patch_supported(dp):
@@ -147,10 +153,10 @@ class _Conv:
                 force = getattr(self, "_patch_force", False)
                 if ((force or (pl["work"] >= getattr(self, "_patch_min_work", _PATCH_MIN_WORK) and
                                (pl["fill"] >= _PATCH_MIN_FILL or pl["makespan"] <= 1.0)))
-                        and co * 4 >= 3 * ((co + 255) // 256 * 256)):
+                        and (small_co or co * 4 >= 3 * ((co + 255) // 256 * 256))):
                     self.patch = True
-                    self.w, _ = (H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale) if self.x3
-                                 else H.prep_conv_weight_patch(w.to(dev)))
+                    self.w, _ = (H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale, pad_co) if self.x3
+                                 else H.prep_conv_weight_patch(w.to(dev), pad_co))
                     self.desc = dp
         # split-K workspace (own buffer per conv: launches on different lanes may run concurrently); sized by the
         # library's plan, allocated once at build -- 288 GB of HBM
@@ -804,8 +810,10 @@ class SipMaskEngine:
         self._basis_h0w0 = (h0, w0)
         self._add("up:basis", lambda: self._basis_step(), 2)
         # fcos_reg (4, x Scale) + fcos_centerness (1): one 5-channel conv on the reg tower's split output
-        w_rc = torch.cat([sd[h + "fcos_reg.weight"], sd[h + "fcos_centerness.weight"]], 0)
-        b_rc = torch.cat([sd[h + "fcos_reg.bias"], sd[h + "fcos_centerness.bias"]], 0)
+        # (+ 3 zero channels: 8 couts = one 16-byte store per position and the patch kernel's 32-cout tile)
+        w_rc = torch.cat([sd[h + "fcos_reg.weight"], sd[h + "fcos_centerness.weight"],
+                          torch.zeros_like(sd[h + "fcos_reg.weight"][:3])], 0)
+        b_rc = torch.cat([sd[h + "fcos_reg.bias"], sd[h + "fcos_centerness.bias"], torch.zeros_like(sd[h + "fcos_reg.bias"][:3])], 0)
         scales = [float(sd[h + "scales.%d.scale" % i]) for i in range(len(lv))]
         self.reg_out = torch.zeros(rows, 8, dtype=f32, device=dev)
         self._add_conv(_Conv(self, "head.reg_ctr", w_rc, b_rc, B, sizes, row0, reg_x3, 768, 1, 1, self.reg_out, row0, 8,
@@ -936,8 +944,10 @@ class SipMaskEngine:
         self._basis_h0w0 = (h0, w0)
         self._add("up:basis", lambda: self._basis_step(), 2)
         # fcos_reg (4, x Scale) + fcos_centerness (1) share reg_feat -> one 5-channel f32 conv
-        w_rc = torch.cat([sd[h + "fcos_reg.weight"], sd[h + "fcos_centerness.weight"]], 0)
-        b_rc = torch.cat([sd[h + "fcos_reg.bias"], sd[h + "fcos_centerness.bias"]], 0)
+        # (+ 3 zero channels: 8 couts = one 16-byte store per position and the patch kernel's 32-cout tile)
+        w_rc = torch.cat([sd[h + "fcos_reg.weight"], sd[h + "fcos_centerness.weight"],
+                          torch.zeros_like(sd[h + "fcos_reg.weight"][:3])], 0)
+        b_rc = torch.cat([sd[h + "fcos_reg.bias"], sd[h + "fcos_centerness.bias"], torch.zeros_like(sd[h + "fcos_reg.bias"][:3])], 0)
         scales = [float(sd[h + "scales.%d.scale" % i]) for i in range(len(lv))]
         self.reg_out = self._buf(lv.rows, 8, torch.float32)
         self.reg_out.zero_()

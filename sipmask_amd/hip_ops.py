@@ -33,12 +33,19 @@ def prep_conv_weight(w, cin_pad=None):
     return out.to(BF16).contiguous(), co_pad
 
 
-def prep_conv_weight_patch(w):
+def patch_cout_pad(co):
+    """weight rows of the patch-resident kernel: 32 for the convs with a handful of output channels (its 32-cout tile),
+    else a multiple of 256"""
+    return 32 if co <= 32 else (co + 255) // 256 * 256
+
+
+def prep_conv_weight_patch(w, co_pad=None):
     """[co,ci,3,3] float -> bf16 [cout_pad][ci/32][9][32] for sm_conv3x3_patch (K order: 32-channel chunk, tap, channel);
-    cout_pad a multiple of 256, ci a multiple of 64."""
+    cout_pad a multiple of 256 (default) or 32 (co <= 32: the 32-cout tile), ci a multiple of 64."""
     co, ci, kh, kw = w.shape
     assert (kh, kw) == (3, 3) and ci % 64 == 0
-    co_pad = (co + 255) // 256 * 256
+    co_pad = co_pad or (co + 255) // 256 * 256
+    assert co_pad >= co and (co_pad % 256 == 0 or co_pad == 32)
     out = torch.zeros(co_pad, ci // 32, 9, 32, dtype=torch.float32, device=w.device)
     out[:co] = w.float().permute(0, 2, 3, 1).reshape(co, 9, ci // 32, 32).permute(0, 2, 1, 3)
     return out.reshape(co_pad, 9 * ci).to(BF16).contiguous(), co_pad
@@ -80,12 +87,13 @@ def prep_conv_weight_x3(w, scale):
     return out.contiguous(), co_pad
 
 
-def prep_conv_weight_patch_x3(w, scale):
+def prep_conv_weight_patch_x3(w, scale, co_pad=None):
     """[co,ci,3,3] float -> binary16 [cout_pad][3*ci/32][9][32] for sm_conv3x3_patch with SM_CONV_F16"""
     w3 = _x3_halves(w, scale)
     co, ci3, kh, kw = w3.shape
     assert (kh, kw) == (3, 3) and ci3 % 64 == 0
-    co_pad = (co + 255) // 256 * 256
+    co_pad = co_pad or (co + 255) // 256 * 256
+    assert co_pad >= co and (co_pad % 256 == 0 or co_pad == 32)
     out = torch.zeros(co_pad, ci3 // 32, 9, 32, dtype=F16, device=w.device)
     out[:co] = w3.permute(0, 2, 3, 1).reshape(co, 9, ci3 // 32, 32).permute(0, 2, 1, 3)
     return out.reshape(co_pad, 9 * ci3).contiguous(), co_pad
@@ -155,7 +163,7 @@ def conv3x3_patch_plan(desc):
     out = (C.c_int64 * 4)()
     _lib.check(_lib.load().sm_conv3x3_patch_plan(C.byref(desc), out), "sm_conv3x3_patch_plan")
     big, small, spos, milli = (int(v) for v in out)
-    ntn = desc.cout_pad // 256
+    ntn = max(1, desc.cout_pad // 256)          # (cout_pad 32: one tile along the couts)
     groups = max(1, desc.ngroups)
     work = sum(desc.batch * desc.in_h[l] * (desc.in_w[l] + 2) for l in range(desc.nlev)) * ntn * groups / 256.0
     return dict(big=big, small=small, small_pos=spos, makespan=milli / 1000.0, work=work,

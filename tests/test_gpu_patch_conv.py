@@ -149,3 +149,51 @@ def test_patch_conv_mixed_tile_launch_at_head_shape(batch, groups):
             r8 = ref.reshape(batch, C // 8, 8, h * wd)
             torch.testing.assert_close(st[:, l, :, 0], r8.sum((2, 3)), rtol=2e-3, atol=1.0)
             torch.testing.assert_close(st[:, l, :, 1], (r8 * r8).sum((2, 3)), rtol=2e-3, atol=1.0)
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, Cin, Cout, sizes: the two convs the 32-cout tile exists for, at reduced sizes, and odd geometries
+    (2, 512, 32, [(25, 42)]),                                          # sip_mask_lat: 512 -> 32 on the stride-8 grid
+    (2, 256, 8, [(25, 42), (13, 21), (7, 11), (4, 6), (2, 3)]),         # fcos_reg + centerness (+3 zero channels) over the pyramid
+    (1, 64, 24, [(19, 37), (9, 250)]),                                  # cout tail inside the 32 tile, odd / widest rows
+])
+def test_patch_conv_small_cout_tile_vs_torch(cfg):
+    """round 4: sm_conv3x3_patch with weights padded to 32 cout rows runs its 32-cout x 256-position tile (one MFMA tile per
+    wave): same contract as the 256-cout tile -- f32 outputs within accumulation order, bf16 plus one rounding, per-level
+    Scale on the first channels, ReLU, multi-level launches -- and the same bits as the implicit-GEMM kernel's K order is
+    not required (patch order = chunk, tap, channel)."""
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    B, Ci, Co, sizes = cfg
+    g = torch.Generator().manual_seed(Ci + Co + len(sizes))
+    lv = H.Levels(B, sizes)
+    xs = [_bf(torch.randn(B, Ci, h, w, generator=g)) for h, w in sizes]
+    w = _bf(torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5)
+    bias = torch.randn(Co, generator=g)
+    x = _rows(xs).to(torch.bfloat16).to(dev)
+    assert H.patch_cout_pad(Co) == 32
+    wq, co_pad = H.prep_conv_weight_patch(w.to(dev), 32)
+    assert co_pad == 32 and wq.shape == (32, 9 * Ci)
+    scales = [1.0 + 0.25 * l for l in range(len(sizes))]
+    for out_f32, relu in ((True, False), (False, True)):
+        flags = (_lib.SM_CONV_OUT_F32 if out_f32 else 0) | (_lib.SM_CONV_RELU if relu else 0)
+        d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, Ci, Co, co_pad, 3, 1, 1, Ci, Co, flags=flags,
+                             scale_nch=4, level_scale=scales)
+        assert H.conv3x3_patch_supported(d)
+        y = torch.full((lv.rows, Co), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
+        H.conv3x3_patch(d, x, wq, bias.to(dev), y)
+        torch.cuda.synchronize()
+        for l, (h, wd) in enumerate(sizes):
+            ref = F.conv2d(xs[l], w, bias, 1, 1)
+            ref[:, :4] *= scales[l]
+            if relu:
+                ref = F.relu(ref)
+            got = y[lv.row0[l]:lv.row0[l] + B * h * wd].float().view(B, h, wd, Co).permute(0, 3, 1, 2).cpu()
+            if out_f32:
+                torch.testing.assert_close(got, ref, rtol=1e-4, atol=2e-4)
+            else:
+                torch.testing.assert_close(got, ref, rtol=2 ** -7, atol=2e-3)
+    # grouped / per-level launches keep the 256-cout tile: the library refuses them on 32-row weights
+    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, Ci, Co, 32, 3, 1, 1, Ci, Co, ngroups=2, y_group_rows=lv.rows,
+                         w_group_stride=wq.numel())
+    assert not H.conv3x3_patch_supported(d)
