@@ -127,6 +127,10 @@ typedef struct {
    * and the bias at bias + l*bias_level_stride floats -- levels of one launch that do NOT share weights: the FPN's three
    * output 3x3 convs (fpn.py:154-157: fpn_convs[i] on the i-th merged lateral) as ONE launch.  0 = shared (towers). */
   int64_t w_level_stride, bias_level_stride;
+  /* sm_conv3x3_patch: cout tile of the launch.  0 = by the weight padding (cout_pad == 32: the 32-cout tile, else 256-cout
+   * tiles); 128 = 128-cout x 256-position tiles (cout_pad % 128 == 0) for convs whose position count cannot fill the chip
+   * with 256-cout tiles -- the 3x3 convs of ResNet layer3 / layer4 (resnet.py:84-239: 4 200 / 1 050 positions per image). */
+  int32_t patch_cout_tile;
 } sm_conv_desc;
 
 int sm_version(void);

@@ -50,6 +50,7 @@ class ConvDesc(C.Structure):
         ("bias_group_stride", C.c_int64), ("gn_group_stride", C.c_int64),
         ("acc_scale", C.c_float),
         ("w_level_stride", C.c_int64), ("bias_level_stride", C.c_int64),
+        ("patch_cout_tile", C.c_int32),
     ]
 
 

@@ -96,7 +96,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   constexpr int NPIECE = BCO / 8;               // weight DMA pieces (8 rows x 128 B) of a stage
   constexpr int WPW = (NPIECE + NWV - 1) / NWV; // ... per wave
   constexpr int PPS = MAXPP / 3;                // patch pieces per wave per stage (a chunk lands over three stages)
-  static_assert((NWV == 8 || NWV == 4) && (BCO == 256 || BCO == 32), "8 or 4 waves, 256 or 32 couts");
+  static_assert((NWV == 8 || NWV == 4) && (BCO == 256 || BCO == 128 || BCO == 32), "8 or 4 waves; 256, 128 or 32 couts");
   // VAR bits: 1 = software-pipelined stage, 2 = staggered DMA issue (waves 4-7 issue theirs between the two taps of a stage,
   // so the two waves of a SIMD are never both stalled in the LDS-DMA issue); 4 / 8 = ABLATIONS for the micro-benchmark
   // (no DMA / no MFMA in the main loop: wrong results by construction, never used by the library's own launches)
@@ -560,6 +560,14 @@ __global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_n32_kernel(const 
   patch_tile<1, 8, 1, 1, PIPE>(a, 0, xcd_tile(blockIdx.x, a.nblk[0]), smem);
 }
 
+// 128 couts x 256 positions on 8 waves (2 cout x 4 position waves, 64 x 64 per wave), uniform launches only: the 3x3 convs
+// whose position count gives too few 256-cout tiles (ResNet layer3 / layer4: 66 / 17 position tiles at B=4)
+template <int PIPE>
+__global__ __launch_bounds__(PT_THREADS, 1) void conv3x3_patch_n128_kernel(const PatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  patch_tile<2, 4, 2, 2, PIPE>(a, 0, xcd_tile(blockIdx.x, a.nblk[0]), smem);
+}
+
 #ifdef SM_EXPERIMENTS
 // EXPERIMENT (round 3): the same 256 x 256 tile on FOUR waves, 128 couts x 128 positions each (16 accumulator tiles = 256
 // registers, beyond the 256 architectural VGPRs: one wave per SIMD, accumulators in AGPRs), 8 fragment reads per 16 MFMAs
@@ -572,15 +580,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_kernel_w4(const PatchArg
 #endif
 
 // cout tile of a descriptor: weights padded to 32 rows select the 32-cout kernel, else 256-row tiles
-int patch_bco(const sm_conv_desc* d) { return d->cout_pad == 32 ? 32 : PT_BCO; }
+int patch_bco(const sm_conv_desc* d) { return d->patch_cout_tile == 128 ? 128 : (d->cout_pad == 32 ? 32 : PT_BCO); }
 
 int patch_check(const sm_conv_desc* d) {
   if (!d) return SM_ERR_BAD_ARG;
   if (d->nlev < 1 || d->nlev > SM_MAX_LEVELS || d->batch < 1) return SM_ERR_BAD_SHAPE;
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dil != 1) return SM_ERR_UNSUPPORTED;
   if (d->cin % 64 != 0 || d->cin < 64 || d->in_cstride % 8 != 0) return SM_ERR_UNSUPPORTED;
-  if (d->cout < 1 || (d->cout_pad % PT_BCO != 0 && d->cout_pad != 32) || d->cout_pad < d->cout) return SM_ERR_UNSUPPORTED;
-  if (d->cout_pad == 32 && (d->ngroups > 1 || d->w_level_stride != 0)) return SM_ERR_UNSUPPORTED;   // plain launches only
+  if (d->patch_cout_tile != 0 && d->patch_cout_tile != 128) return SM_ERR_UNSUPPORTED;
+  if (d->cout < 1 || d->cout_pad < d->cout || d->cout_pad % patch_bco(d) != 0) return SM_ERR_UNSUPPORTED;
+  if (patch_bco(d) != PT_BCO && (d->ngroups > 1 || d->w_level_stride != 0)) return SM_ERR_UNSUPPORTED;   // plain launches only
   if ((d->cout & 7) || (d->out_cstride & 7) || (d->out_coff & 7)) return SM_ERR_UNSUPPORTED;
   if (d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST | SM_CONV_IN_RELU)) return SM_ERR_UNSUPPORTED;
   if (d->w_batch_stride != 0) return SM_ERR_UNSUPPORTED;
@@ -643,7 +652,7 @@ void plan_shape(const sm_conv_desc* d, PatchShape* ps) {
   ps->small = 128;
   ps->nbig = all_big;
   ps->nsmall = 0;
-  if ((d->flags & SM_CONV_DBG_PATCH_UNIFORM) || d->cout_pad == 32) return;      // (the 32-cout kernel has the 256-position tile only)
+  if ((d->flags & SM_CONV_DBG_PATCH_UNIFORM) || patch_bco(d) != PT_BCO) return;   // (the 32- / 128-cout kernels have the 256-position tile only)
   const int smalls[2] = {128, 192};
   const long long max_rounds = all_big / PT_CUS + 1;
   for (int si = 0; si < 2; ++si) {
@@ -816,9 +825,9 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
     return SM_OK;
   };
   int lrc = SM_ERR_UNSUPPORTED;
-  if (bco == 32) {
+  if (bco != PT_BCO) {
     if (nb1 != 0) return SM_ERR_BAD_SHAPE;
-    lrc = launch(conv3x3_patch_n32_kernel<0>);
+    lrc = bco == 32 ? launch(conv3x3_patch_n32_kernel<0>) : launch(conv3x3_patch_n128_kernel<0>);
     if (lrc != SM_OK) return lrc;
     SM_LAUNCH_CHECK();
     return SM_OK;

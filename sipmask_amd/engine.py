@@ -37,6 +37,7 @@ _PATCH_CONV = __import__("os").environ.get("SIPMASK_PATCH_CONV", "1") != "0"   #
 # reach beyond the window radius (SipMaskEngine._tune_deform); "0" / "1" pin the window kernel / the gather loader.
 _DEFORM_MODE = __import__("os").environ.get("SIPMASK_DEFORM_GATHER", "auto")
 _DEFORM_FLAGS = _lib.SM_CONV_DBG_DEFORM_GATHER if _DEFORM_MODE == "1" else 0
+_PATCH_COUT128 = __import__("os").environ.get("SIPMASK_PATCH_COUT128", "1") != "0"         # A/B: the 128-cout patch tile
 _PATCH_SMALL_COUT = __import__("os").environ.get("SIPMASK_PATCH_SMALL_COUT", "1") != "0"   # A/B: the 32-cout patch tile
 _PATCH_MIN_WORK = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_WORK", "100"))   # 256x256 tile equivalents
 _PATCH_MIN_FILL = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_FILL", "0.6"))
@@ -151,13 +152,29 @@ class _Conv:
                 # 256-wide tile (sip_mask_lat, 128 -> 32: 0.061 ms on the 32 x 256 implicit-GEMM tile, 0.101 ms here with
                 # 7/8 of the MFMAs on padding).  Measured: profiles/r02d_patch_conv_microbench.txt, r02g_patch_tile_shapes_microbench.txt.
                 force = getattr(self, "_patch_force", False)
+                # (small_co: the alternative is the implicit-GEMM kernel's nine-fold re-read of the input, whatever the fill)
                 if ((force or (pl["work"] >= getattr(self, "_patch_min_work", _PATCH_MIN_WORK) and
-                               (pl["fill"] >= _PATCH_MIN_FILL or pl["makespan"] <= 1.0)))
+                               (small_co or pl["fill"] >= _PATCH_MIN_FILL or pl["makespan"] <= 1.0)))
                         and (small_co or co * 4 >= 3 * ((co + 255) // 256 * 256))):
                     self.patch = True
                     self.w, _ = (H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale, pad_co) if self.x3
                                  else H.prep_conv_weight_patch(w.to(dev), pad_co))
                     self.desc = dp
+        # 128-cout x 256-position patch tiles (round 4) for single-level 3x3 convs whose position count gives too few 256-cout
+        # tiles to be worth a launch of them: ResNet layer3 / layer4 conv2 (4 200 / 1 050 positions per image: 66 / 17 position
+        # tiles at B=4, x 2 / 4 cout tiles).  The implicit-GEMM kernel re-reads their input nine times through L2 -> LDS and is
+        # bound by it (HISTORY "stream-K ... analysed"): 0.045 / 0.075 ms per launch.  The rule is per IMAGE (h * w >= 900), so
+        # that plans of different batch cuts choose alike (plan-to-plan bit equality).
+        if (not self.patch and not self.f32 and not self.x3 and offset is None and residual is None and _PATCH_CONV
+                and _PATCH_COUT128 and k == 3 and stride == 1 and pad == 1 and ci % 64 == 0 and cin == ci and co % 128 == 0
+                and len(in_sizes) == 1 and getattr(self, "_patch_groups", 1) == 1 and in_sizes[0][0] * in_sizes[0][1] >= 900):
+            dp = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, co, k, stride, pad, in_cstride,
+                                  out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0, scale_nch, level_scale,
+                                  deform_groups, acc_scale=acc_scale, patch_cout_tile=128)
+            if H.conv3x3_patch_supported(dp):
+                self.patch = True
+                self.w, _ = H.prep_conv_weight_patch(w.to(dev), co)
+                self.desc = dp
         # split-K workspace (own buffer per conv: launches on different lanes may run concurrently); sized by the
         # library's plan, allocated once at build -- 288 GB of HBM
         self.ws = None

@@ -45,7 +45,7 @@ def prep_conv_weight_patch(w, co_pad=None):
     co, ci, kh, kw = w.shape
     assert (kh, kw) == (3, 3) and ci % 64 == 0
     co_pad = co_pad or (co + 255) // 256 * 256
-    assert co_pad >= co and (co_pad % 256 == 0 or co_pad == 32)
+    assert co_pad >= co and (co_pad % 128 == 0 or co_pad == 32)
     out = torch.zeros(co_pad, ci // 32, 9, 32, dtype=torch.float32, device=w.device)
     out[:co] = w.float().permute(0, 2, 3, 1).reshape(co, 9, ci // 32, 32).permute(0, 2, 1, 3)
     return out.reshape(co_pad, 9 * ci).to(BF16).contiguous(), co_pad
@@ -93,7 +93,7 @@ def prep_conv_weight_patch_x3(w, scale, co_pad=None):
     co, ci3, kh, kw = w3.shape
     assert (kh, kw) == (3, 3) and ci3 % 64 == 0
     co_pad = co_pad or (co + 255) // 256 * 256
-    assert co_pad >= co and (co_pad % 256 == 0 or co_pad == 32)
+    assert co_pad >= co and (co_pad % 128 == 0 or co_pad == 32)
     out = torch.zeros(co_pad, ci3 // 32, 9, 32, dtype=F16, device=w.device)
     out[:co] = w3.permute(0, 2, 3, 1).reshape(co, 9, ci3 // 32, 32).permute(0, 2, 1, 3)
     return out.reshape(co_pad, 9 * ci3).contiguous(), co_pad
@@ -163,7 +163,7 @@ def conv3x3_patch_plan(desc):
     out = (C.c_int64 * 4)()
     _lib.check(_lib.load().sm_conv3x3_patch_plan(C.byref(desc), out), "sm_conv3x3_patch_plan")
     big, small, spos, milli = (int(v) for v in out)
-    ntn = max(1, desc.cout_pad // 256)          # (cout_pad 32: one tile along the couts)
+    ntn = desc.cout_pad // 128 if desc.patch_cout_tile == 128 else max(1, desc.cout_pad // 256)   # (cout_pad 32: one tile)
     groups = max(1, desc.ngroups)
     work = sum(desc.batch * desc.in_h[l] * (desc.in_w[l] + 2) for l in range(desc.nlev)) * ntn * groups / 256.0
     return dict(big=big, small=small, small_pos=spos, makespan=milli / 1000.0, work=work,
@@ -218,7 +218,7 @@ class Levels:
 def make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, cout, cout_pad, k, stride, pad,
                    in_cstride, out_cstride, out_coff=0, flags=0, dil=1, res_cstride=0, res_sizes=None,
                    res_row0=None, scale_nch=0, level_scale=None, deform_groups=0, ngroups=1, x_group_rows=0, y_group_rows=0,
-                   w_group_stride=0, bias_group_stride=0, gn_group_stride=0, acc_scale=0.0):
+                   w_group_stride=0, bias_group_stride=0, gn_group_stride=0, acc_scale=0.0, patch_cout_tile=0):
     d = ConvDesc()
     nlev = len(in_sizes)
     assert 1 <= nlev <= SM_MAX_LEVELS
@@ -243,6 +243,7 @@ def make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, cout, cou
     d.x_group_rows, d.y_group_rows, d.w_group_stride = x_group_rows, y_group_rows, w_group_stride
     d.bias_group_stride, d.gn_group_stride = bias_group_stride, gn_group_stride
     d.acc_scale = float(acc_scale)
+    d.patch_cout_tile = int(patch_cout_tile)
     return d
 
 

@@ -197,3 +197,45 @@ def test_patch_conv_small_cout_tile_vs_torch(cfg):
     d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, Ci, Co, 32, 3, 1, 1, Ci, Co, ngroups=2, y_group_rows=lv.rows,
                          w_group_stride=wq.numel())
     assert not H.conv3x3_patch_supported(d)
+
+
+@pytest.mark.parametrize("cfg", [(2, 256, 256, (50, 84)), (1, 512, 512, (25, 42)), (2, 64, 128, (19, 37))])
+def test_patch_conv_cout128_tile_vs_torch(cfg):
+    """round 4: sm_conv_desc.patch_cout_tile = 128 -- 128-cout x 256-position tiles for the 3x3 convs of ResNet layer3 / layer4
+    (too few positions for 256-cout tiles): f32 outputs within accumulation order of torch, bf16 + ReLU plus one rounding, and
+    BIT-IDENTICAL to the 256-cout tile of the same kernel (same K order per output element)."""
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    B, Ci, Co, (h, wd) = cfg
+    g = torch.Generator().manual_seed(Ci + Co + h)
+    xs = _bf(torch.randn(B, Ci, h, wd, generator=g))
+    w = _bf(torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5)
+    bias = torch.randn(Co, generator=g)
+    x = _rows([xs]).to(torch.bfloat16).to(dev)
+    wq, co_pad = H.prep_conv_weight_patch(w.to(dev), Co)
+    assert co_pad == Co
+    rows = B * h * wd
+    for out_f32, relu in ((True, False), (False, True)):
+        flags = (_lib.SM_CONV_OUT_F32 if out_f32 else 0) | (_lib.SM_CONV_RELU if relu else 0)
+        d = H.make_conv_desc(B, [(h, wd)], [(h, wd)], [0], [0], Ci, Co, co_pad, 3, 1, 1, Ci, Co, flags=flags, patch_cout_tile=128)
+        assert H.conv3x3_patch_supported(d) and H.conv3x3_patch_plan(d)["small"] == 0
+        y = torch.full((rows, Co), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
+        H.conv3x3_patch(d, x, wq, bias.to(dev), y)
+        torch.cuda.synchronize()
+        ref = F.conv2d(xs, w, bias, 1, 1)
+        if relu:
+            ref = F.relu(ref)
+        got = y.float().view(B, h, wd, Co).permute(0, 3, 1, 2).cpu()
+        if out_f32:
+            torch.testing.assert_close(got, ref, rtol=1e-4, atol=2e-4)
+        else:
+            torch.testing.assert_close(got, ref, rtol=2 ** -7, atol=2e-3)
+        if Co % 256 == 0:
+            wq256, cp = H.prep_conv_weight_patch(w.to(dev))
+            d256 = H.make_conv_desc(B, [(h, wd)], [(h, wd)], [0], [0], Ci, Co, cp, 3, 1, 1, Ci, Co, flags=flags | 0x4000)
+            y256 = torch.empty_like(y)
+            H.conv3x3_patch(d256, x, wq256, bias.to(dev), y256)
+            torch.cuda.synchronize()
+            assert torch.equal(y, y256)
+    bad = H.make_conv_desc(B, [(h, wd)], [(h, wd)], [0], [0], Ci, Co, co_pad, 3, 1, 1, Ci, Co, patch_cout_tile=64)
+    assert not H.conv3x3_patch_supported(bad)
