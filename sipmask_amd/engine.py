@@ -833,9 +833,10 @@ class SipMaskEngine:
         b_rc = torch.cat([sd[h + "fcos_reg.bias"], sd[h + "fcos_centerness.bias"], torch.zeros_like(sd[h + "fcos_reg.bias"][:3])], 0)
         scales = [float(sd[h + "scales.%d.scale" % i]) for i in range(len(lv))]
         self.reg_out = torch.zeros(rows, 8, dtype=f32, device=dev)
-        self._add_conv(_Conv(self, "head.reg_ctr", w_rc, b_rc, B, sizes, row0, reg_x3, 768, 1, 1, self.reg_out, row0, 8,
-                             flags=(_lib.SM_CONV_RELU_NCH if self.benchmark else 0), scale_nch=4, level_scale=scales,
-                             mode="x3"))
+        c = self._add_conv(_Conv(self, "head.reg_ctr", w_rc, b_rc, B, sizes, row0, reg_x3, 768, 1, 1, self.reg_out, row0, 8,
+                                 flags=(_lib.SM_CONV_RELU_NCH if self.benchmark else 0), scale_nch=4, level_scale=scales,
+                                 mode="x3"))
+        c.flops, c.mfma_flops = c.flops * 5 / 8, c.mfma_flops * 5 / 8      # the 3 zero channels are not work (FLOP accounting)
         # FeatureAlign: offsets (f32 1x1 of the box prediction) -> deformable conv in exact f32 -> GN + ReLU -> split
         self.w_off = sd[h + "feat_align.conv_offset.weight"].float().view(72, 4).to(dev).contiguous()
         self.offsets = torch.empty(rows, 72, dtype=f32, device=dev)
@@ -968,9 +969,10 @@ class SipMaskEngine:
         scales = [float(sd[h + "scales.%d.scale" % i]) for i in range(len(lv))]
         self.reg_out = self._buf(lv.rows, 8, torch.float32)
         self.reg_out.zero_()
-        self._add_conv(_Conv(self, "head.reg_ctr", w_rc, b_rc, B, sizes, row0, self.reg_feat, 256, 1, 1, self.reg_out,
-                             row0, 8, flags=SM_CONV_OUT_F32 | (_lib.SM_CONV_RELU_NCH if self.benchmark else 0),
-                             scale_nch=4, level_scale=scales))
+        c = self._add_conv(_Conv(self, "head.reg_ctr", w_rc, b_rc, B, sizes, row0, self.reg_feat, 256, 1, 1, self.reg_out,
+                                 row0, 8, flags=SM_CONV_OUT_F32 | (_lib.SM_CONV_RELU_NCH if self.benchmark else 0),
+                                 scale_nch=4, level_scale=scales))
+        c.flops, c.mfma_flops = c.flops * 5 / 8, c.mfma_flops * 5 / 8      # the 3 zero channels are not work (FLOP accounting)
         # FeatureAlign: offset = conv1x1(bbox_pred), y = relu(GN(deform_conv(cls_feat, offset)))
         self.w_off = sd[h + "feat_align.conv_offset.weight"].float().view(72, 4).to(dev).contiguous()
         self.offsets = self._buf(lv.rows, 72, torch.float32)

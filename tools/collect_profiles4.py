@@ -91,6 +91,15 @@ for src, dst in (("step_breakdown.txt", "r04_step_breakdown_hip_events.txt"),
                  ("parity_r50_b4_f32.json", "r04_parity_r50_b4_f32.json")):
     if os.path.exists(os.path.join(SRC, src)):
         shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
+# headers for the two derived text files
+mc = os.path.join(DST, "r04_marginal_cost_pipelined_step.txt")
+if os.path.exists(mc):
+    body = [l for l in open(mc).read().splitlines() if l and not l.startswith("#")]
+    hdr = ["# tools/marginal_cost.sh (via tools/profile_round4.sh): bench.py --no-extras --steps 300 with one stage's launches left out of the",
+           "# captured graphs (SIPMASK_DIAG_SKIP); img/s and ms per 4-image step, one box, one pass ('none' first and last).  Stages whose",
+           "# removal corrupts the data the post-processing sees (towers, GroupNorm applies, FeatureAlign) are not listed: see the tool's header.",
+           "# stage   img/s   ms_per_step"]
+    open(mc, "w").write("\n".join(hdr + body) + "\n")
 lines = {}
 for n in ("r50", "r50_inflight1", "r50_inflight2", "r50_inflight3", "r50_x3", "r50_x3b", "r50_lanes1", "r50_f32", "r101", "r101b", "vis", "train", "train_rccl1"):
     j = last_json(os.path.join(SRC, "bench_%s.json" % n))

@@ -68,7 +68,8 @@ def conv_rows(eng):
         if getattr(c, "patch", False):                   # conv3x3_patch.hip: one block per CU, its own launch planner
             pp = H.conv3x3_patch_plan(c.desc)
             blocks = pp["big"] + pp["small"]
-            shape = "256x256" + ("" if not pp["small"] else "+%d" % pp["small_pos"])
+            bco = 128 if c.desc.patch_cout_tile == 128 else (32 if c.desc.cout_pad == 32 else 256)    # cout tile of the launch
+            shape = "%dx256" % bco + ("" if not pp["small"] else "+%d" % pp["small_pos"])
             rows.append(dict(name=c.name, kind="patch", shape=shape, blocks=blocks, waves=blocks / 256.0,
                              note="LDS patch, makespan %.2f tiles, CU fill %.0f %%" % (pp["makespan"], 100 * pp["fill"]),
                              gflop=c.flops / 1e9, mb=c.bytes / 1e6))
