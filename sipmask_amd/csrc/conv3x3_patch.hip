@@ -84,6 +84,11 @@ constexpr int PT_BCO = 256, PT_BPOS = 256, PT_THREADS = 512;
 // One tile: 256 couts x (WPOS * TPOS * 32) positions on 8 waves laid out WCO (cout) x WPOS (position), each wave
 // TCO x TPOS MFMA tiles of 32 x 32.  <2,4,4,2> is the 256-position tile; <4,2,2,3> / <4,2,2,2> are the 192- / 128-
 // position tiles that finish a launch whose last round of 256-tiles would leave most CUs idle.
+template <int VAR>
+struct PINGPONG_T {
+  static constexpr bool value = (VAR & 16) != 0;
+};
+
 template <int WCO, int WPOS, int TCO, int TPOS, int VAR>
 __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, const int tlin, unsigned char* const smem) {
   constexpr int NWV = WCO * WPOS;               // waves of the block: 8 (shipped), 4 in the one-wave-per-SIMD experiment
@@ -96,6 +101,12 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   constexpr int NPIECE = BCO / 8;               // weight DMA pieces (8 rows x 128 B) of a stage
   constexpr int WPW = (NPIECE + NWV - 1) / NWV; // ... per wave
   constexpr int PPS = MAXPP / 3;                // patch pieces per wave per stage (a chunk lands over three stages)
+  // Weight ring.  The 256-cout tile double-buffers its weight stages: it is matrix-pipe / power bound and a third buffer
+  // measured 3-8 % SLOWER (HISTORY 6).  The 128- and 32-cout tiles (round 4) are the opposite case: 16 / 2 MFMAs per wave and
+  // tap against one weight-DMA landing (~0.9 us) per stage at one block per CU -- stage s+2 is issued at the top of stage s,
+  // and the stage ends in a COUNTED wait (everything but the weights just issued) + a raw barrier instead of a full drain.
+  constexpr bool RING = (BCO != PT_BCO) && !PINGPONG_T<VAR>::value && ((VAR & 0xf) == 0);
+  constexpr int NWB = RING ? 3 : 2;
   static_assert((NWV == 8 || NWV == 4) && (BCO == 256 || BCO == 128 || BCO == 32), "8 or 4 waves; 256, 128 or 32 couts");
   // VAR bits: 1 = software-pipelined stage, 2 = staggered DMA issue (waves 4-7 issue theirs between the two taps of a stage,
   // so the two waves of a SIMD are never both stalled in the LDS-DMA issue); 4 / 8 = ABLATIONS for the micro-benchmark
@@ -128,7 +139,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
 
   const int PB = a.prow_cap * 64;                 // bytes of one patch buffer
   unsigned char* const Wb0 = smem;
-  unsigned char* const Pb0 = smem + 2 * WST;
+  unsigned char* const Pb0 = smem + NWB * WST;
 
   // ---- loader state.  A DMA piece is 16 rows x 64 B: lane L -> row (L >> 2), physical slot (L & 3), so it fetches
   // the logical 16-byte chunk (L & 3) ^ ((row >> 2) & 3) of that row (swizzle on the source side, guide rule 21).
@@ -234,6 +245,9 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   const int nstage = npair * 9;
   sfor<MAXPP>([&](auto I) { dma_patch_piece(I, 0, 0); });
   dma_w(0, 0);
+  if constexpr (RING) {
+    if (1 < nstage) dma_w(1, 1);
+  }
   __syncthreads();
   if constexpr (PINGPONG) {
     // ---- ping-pong schedule (MI355X_MICROARCH.md, "Two waves per SIMD"): the block's waves form two groups, A = waves
@@ -344,7 +358,9 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
       const int st = cp * 9 + sp;                                  // global stage index (parity = W buffer)
       auto issue_dma = [&]() {
         if constexpr (!NO_DMA) {
-          if (st + 1 < nstage) dma_w(st + 1, (st + 1) & 1);
+          if constexpr (!RING) {
+            if (st + 1 < nstage) dma_w(st + 1, (st + 1) & 1);
+          }
           if constexpr (sp < 3) {                                    // patch of the pair's second chunk
             sfor<PPS>([&](auto J) { dma_patch_piece(std::integral_constant<int, PPS * sp + decltype(J)::value>{}, c0 + 1, 1); });
           } else if constexpr (sp >= 5 && sp < 8) {                  // patch of the NEXT pair's first chunk
@@ -352,11 +368,14 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
               sfor<PPS>([&](auto J) { dma_patch_piece(std::integral_constant<int, PPS * (sp - 5) + decltype(J)::value>{}, c0 + 2, 0); });
             }
           }
+          if constexpr (RING) {                                      // LAST in issue order: the counted wait below skips exactly these
+            if (st + 2 < nstage) dma_w(st + 2, (st + 2) % 3);
+          }
         }
       };
       const bool early = !STAGGER || wave < 4;                      // wave-uniform (SGPR)
       if (early) issue_dma();
-      const unsigned char* Wst = Wb0 + (st & 1) * WST;
+      const unsigned char* Wst = Wb0 + (RING ? st % 3 : (st & 1)) * WST;
       if constexpr (PIPE) {
         // software-pipelined stage: 4 sub-steps (tap hh, K half kk) of TCO*TPOS MFMAs; the fragments of sub-step i+1 are
         // read into the other register set behind the MFMAs of sub-step i ("1 MFMA, 1 ds_read" ladder), so only the
@@ -420,9 +439,26 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
       // (A/B round 3: a 3-stage weight ring -- stage st+2 issued at the top of stage st, vmcnt(4) + raw s_barrier at its end,
       // so a stage of weights has two stage times to land -- is 3-8 % SLOWER where it fits (image width <= 125):
       // profiles/r03_patch_weight_ring_ab.txt.  The landing latency of the DMA is not what the stage waits for.)
-      __syncthreads();                                             // drains the DMA queue (vmcnt(0)) and fences the buffers
+      if constexpr (RING) {
+        // weights of stage st+1 (issued a stage ago) and this stage's patch pieces must have landed; the weights of stage
+        // st+2, issued last, may stay in flight.  vmcnt retires in order, so "all but my last WPW" is exact for the waves
+        // that own weight pieces; the others drain.  Raw barrier: a __syncthreads would drain the queue again.
+        __builtin_amdgcn_sched_barrier(0);
+        const bool mine = wave * WPW < NPIECE && st + 2 < nstage;     // wave-uniform
+        if (mine) {
+          if constexpr (WPW == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        __syncthreads();                                           // drains the DMA queue (vmcnt(0)) and fences the buffers
+      }
     });
   }
+  if constexpr (RING) __syncthreads();                             // the epilogue reuses the LDS: everything landed, everyone done
 
   // ---- epilogue (register epilogue of conv_igemm.hip): lanes i / i+32 swap 4-cout groups -> 8 consecutive couts
   const float lscale = a.level_scale[lev];
@@ -796,7 +832,7 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
     if (sm_zero_async(gn_stats, sizeof(unsigned long long) * 2 * a.ngroups * d->batch * d->nlev * (d->cout / 8), s) != hipSuccess)
       return SM_ERR_LAUNCH;
   }
-  const size_t lds = 2 * (size_t)bco * 128 + 2 * (size_t)a.prow_cap * 64;
+  const size_t lds = (bco == PT_BCO ? 2 : 3) * (size_t)bco * 128 + 2 * (size_t)a.prow_cap * 64;   // (weight ring of the small tiles)
   if (lds > 160 * 1024) return SM_ERR_UNSUPPORTED;
   const long long nblk = nb0 + nb1;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
