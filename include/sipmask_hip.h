@@ -355,6 +355,13 @@ int sm_split3_f16(const void* x, int x_is_f32, int64_t rows, int channels, int i
  * the result written as the split layout of sm_split3_f16 (y binary16 [batch*h*factor*w*factor][3*ctot], slice coff). */
 int sm_upsample_bilinear_x3(const float* x, void* y, int batch, int h, int w, int c, int factor, int in_cstride, int ctot,
                             int coff, sm_stream_t stream);
+/* out = [relu](a0 + up2(a1) + up4(a2)) on the fine grid [batch][h0][w0][c] (bilinear, align_corners=False; h0, w0 multiples of
+ * 4; a1 on h0/2 x w0/2, a2 on h0/4 x w0/4, all rows of c channels).  sip_mask_lat0 by linearity: the 1x1 conv over
+ * [l0 | up2(l1) | up4(l2)] (sipmask_head.py:275-283) = W0.l0 + up2(W1.l1) + up4(W2.l2), so the three products run at their own
+ * resolutions and this adds the coarse ones.  is_f32 = 0: a1, a2, out bf16, a0 NULL (out is the RES_ADD residual of the l0
+ * conv); is_f32 = 1: a0 (or NULL), a1, a2 f32, out f32 rows or -- out_x3 -- the split layout of sm_split3_f16 (3*c channels). */
+int sm_upsample_sum2(const float* a0, const void* a1, const void* a2, int is_f32, int batch, int h0, int w0, int c, int relu,
+                     int out_x3, void* out, sm_stream_t stream);
 int sm_gn_stats_f32_fix(const float* x, int64_t* stats, int batch, int nlev, const int32_t* hw, const int64_t* row0,
                         int channels, int groups, sm_stream_t stream);
 int sm_groupnorm_apply_x3(const float* x, const float* gamma, const float* beta, const int64_t* stats, int batch, int nlev,

@@ -109,6 +109,7 @@ PROTOTYPES = {
     "sm_bottleneck_tail": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_split3_f16": (_I, [_P, _I, C.c_int64, _I, _I, _P, _I, _I, _P]),
     "sm_upsample_bilinear_x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sm_upsample_sum2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sm_gn_stats_f32_fix": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _P]),
     "sm_groupnorm_apply_x3": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P]),
     "sm_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P]),

@@ -49,6 +49,7 @@ _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"
 # FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes
 # the shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
 # shapes), "0" = three launches (A/B)
+_LAT0_LINEAR = os.environ.get("SIPMASK_LAT0_LINEAR", "1") != "0"      # A/B: sip_mask_lat0 by linearity (three convs + upsample_sum2)
 _DIAG_SKIP = __import__("re").compile(os.environ["SIPMASK_DIAG_SKIP"]) if os.environ.get("SIPMASK_DIAG_SKIP") else None
 _FPN_GROUPED = os.environ.get("SIPMASK_FPN_GROUPED", "auto")
 _LEVEL_CONV_MIN_WORK = float(os.environ.get("SIPMASK_LEVEL_CONV_MIN_WORK", "50"))
@@ -809,16 +810,30 @@ class SipMaskEngine:
         n0 = B * h0 * w0
         # [l0 | up2(l1) | up4(l2)] written straight as the split operand of sip_mask_lat0 (768 channels -> 3 x 768 halves),
         # and that 1x1 conv writes ITS output as the split operand of sip_mask_lat (SM_CONV_OUT_X3): no f32 round trips
-        cat_x3 = torch.empty(n0, 3 * 768, dtype=F16, device=dev)
-        for l in range(3):
-            fh, fw = sizes[l]
-            src = self.reg_feat[row0[l]:row0[l] + B * fh * fw]
-            self._add("up:cat%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear_x3(
-                s, cat_x3, B, fh, fw, 256, 2 ** l, 768, 256 * l)), 2)
         lat0_x3 = torch.empty(n0, 3 * 512, dtype=F16, device=dev)
-        self._add_conv(_Conv(self, "head.sip_mask_lat0", sd[h + "sip_mask_lat0.weight"], sd[h + "sip_mask_lat0.bias"],
-                             B, [(h0, w0)], [0], cat_x3, 3 * 768, 1, 0, lat0_x3, [0], 3 * 512,
-                             flags=SM_CONV_RELU | _lib.SM_CONV_OUT_X3, mode="x3"), 2)
+        w_l0 = sd[h + "sip_mask_lat0.weight"]
+        exact_grids = all(sizes[l][0] * 2 ** l == h0 and sizes[l][1] * 2 ** l == w0 for l in range(3)) and h0 % 4 == 0 and w0 % 4 == 0
+        self.lat0_by_linearity = _LAT0_LINEAR and tuple(w_l0.shape) == (512, 768, 1, 1) and exact_grids
+        if self.lat0_by_linearity:
+            # sip_mask_lat0 by linearity (see _build_head): three x3 convs on the levels' split operands (reg_x3 holds all
+            # levels), f32 outputs; sm_upsample_sum2 adds them on the fine grid in f32, applies the ReLU and writes the split
+            # operand of sip_mask_lat -- the same arithmetic as upsample-then-conv up to f32 rounding.
+            outs = [torch.empty(B * sizes[l][0] * sizes[l][1], 512, dtype=f32, device=dev) for l in range(3)]
+            for l in (1, 2, 0):
+                self._add_conv(_Conv(self, "head.sip_mask_lat0" + ("" if l == 0 else ".l%d" % l),
+                                     w_l0[:, 256 * l:256 * (l + 1)].contiguous(), sd[h + "sip_mask_lat0.bias"] if l == 0 else None,
+                                     B, [sizes[l]], [row0[l]], reg_x3, 768, 1, 0, outs[l], [0], 512, mode="x3"), 2)
+            self._add("up:sum2", lambda: H.upsample_sum2(outs[0], outs[1], outs[2], lat0_x3, B, h0, w0, 512, relu=True), 2)
+        else:
+            cat_x3 = torch.empty(n0, 3 * 768, dtype=F16, device=dev)
+            for l in range(3):
+                fh, fw = sizes[l]
+                src = self.reg_feat[row0[l]:row0[l] + B * fh * fw]
+                self._add("up:cat%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear_x3(
+                    s, cat_x3, B, fh, fw, 256, 2 ** l, 768, 256 * l)), 2)
+            self._add_conv(_Conv(self, "head.sip_mask_lat0", w_l0, sd[h + "sip_mask_lat0.bias"],
+                                 B, [(h0, w0)], [0], cat_x3, 3 * 768, 1, 0, lat0_x3, [0], 3 * 512,
+                                 flags=SM_CONV_RELU | _lib.SM_CONV_OUT_X3, mode="x3"), 2)
         self.basis_lo = torch.empty(n0, 32, dtype=f32, device=dev)
         self._add_conv(_Conv(self, "head.sip_mask_lat", sd[h + "sip_mask_lat.weight"], sd[h + "sip_mask_lat.bias"], B,
                              [(h0, w0)], [0], lat0_x3, 3 * 512, 1, 1, self.basis_lo, [0], 32, flags=SM_CONV_RELU, mode="x3"), 2)
@@ -941,15 +956,35 @@ class SipMaskEngine:
         # runs on lane 2 next to reg_ctr / FeatureAlign / cls_cof and the low-occupancy det_select + NMS (joined in
         # _build_post right before mask assembly)
         (h0, w0) = sizes[0]
-        self.cat = self._buf(B * h0 * w0, 768)
-        for l in range(3):
-            fh, fw = sizes[l]
-            src = self.reg_feat[row0[l]:row0[l] + B * fh * fw]
-            self._add("up:cat%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear(
-                s, self.cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, self.precision == "f32")), 2)
         self.lat0 = self._buf(B * h0 * w0, 512)
-        self._add_conv(_Conv(self, "head.sip_mask_lat0", sd[h + "sip_mask_lat0.weight"], sd[h + "sip_mask_lat0.bias"],
-                             B, [(h0, w0)], [0], self.cat, 768, 1, 0, self.lat0, [0], 512, flags=SM_CONV_RELU), 2)
+        w_l0 = sd[h + "sip_mask_lat0.weight"]
+        exact_grids = all(sizes[l][0] * 2 ** l == h0 and sizes[l][1] * 2 ** l == w0 for l in range(3)) and h0 % 4 == 0 and w0 % 4 == 0
+        self.lat0_by_linearity = (_LAT0_LINEAR and self.precision == "bf16" and tuple(w_l0.shape) == (512, 768, 1, 1) and exact_grids)
+        if self.lat0_by_linearity:
+            # sip_mask_lat0 by linearity (round 4): a 1x1 conv commutes with bilinear upsampling, so
+            #   W . [l0 | up2(l1) | up4(l2)] = W0 . l0 + up2(W1 . l1) + up4(W2 . l2)
+            # -- the three products at their own resolutions (23.1 instead of 52.9 GFLOP per 4 images), no 768-channel
+            # concatenation (103 MB written and read back); the coarse sum is the RES_ADD residual of the l0 conv, whose
+            # epilogue adds the bias and the ReLU as before.
+            n1, n2 = B * sizes[1][0] * sizes[1][1], B * sizes[2][0] * sizes[2][1]
+            a1, a2 = self._buf(n1, 512), self._buf(n2, 512)
+            res = self._buf(B * h0 * w0, 512)
+            for l, dst in ((1, a1), (2, a2)):
+                self._add_conv(_Conv(self, "head.sip_mask_lat0.l%d" % l, w_l0[:, 256 * l:256 * (l + 1)].contiguous(), None, B,
+                                     [sizes[l]], [row0[l]], self.reg_feat, 256, 1, 0, dst, [0], 512), 2)
+            self._add("up:sum2", lambda: H.upsample_sum2(None, a1, a2, res, B, h0, w0, 512), 2)
+            self._add_conv(_Conv(self, "head.sip_mask_lat0", w_l0[:, :256].contiguous(), sd[h + "sip_mask_lat0.bias"], B,
+                                 [(h0, w0)], [row0[0]], self.reg_feat, 256, 1, 0, self.lat0, [0], 512,
+                                 flags=SM_CONV_RELU | SM_CONV_RES_ADD, residual=res, res_cstride=512), 2)
+        else:
+            self.cat = self._buf(B * h0 * w0, 768)
+            for l in range(3):
+                fh, fw = sizes[l]
+                src = self.reg_feat[row0[l]:row0[l] + B * fh * fw]
+                self._add("up:cat%d" % l, (lambda s=src, fh=fh, fw=fw, l=l: H.upsample_bilinear(
+                    s, self.cat, B, fh, fw, 256, 2 ** l, 256, 768, 256 * l, self.precision == "f32")), 2)
+            self._add_conv(_Conv(self, "head.sip_mask_lat0", w_l0, sd[h + "sip_mask_lat0.bias"],
+                                 B, [(h0, w0)], [0], self.cat, 768, 1, 0, self.lat0, [0], 512, flags=SM_CONV_RELU), 2)
         self.basis_lo = self._buf(B * h0 * w0, 32, torch.float32)
         self._add_conv(_Conv(self, "head.sip_mask_lat", sd[h + "sip_mask_lat.weight"], sd[h + "sip_mask_lat.bias"], B,
                              [(h0, w0)], [0], self.lat0, 512, 1, 1, self.basis_lo, [0], 32,

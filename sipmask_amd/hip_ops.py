@@ -123,6 +123,21 @@ def upsample_bilinear_x3(x, y, batch, h, w, c, factor, ctot, coff):
     return y
 
 
+def upsample_sum2(a0, a1, a2, out, batch, h0, w0, c, relu=False):
+    """out = [relu](a0 + up2(a1) + up4(a2)) on the [batch, h0, w0] grid (sm_upsample_sum2): bf16 a1 / a2 -> bf16 out (a0 None),
+    or f32 a0 / a1 / a2 -> f32 rows or, when `out` is binary16 with 3*c channels, the [hi | lo | hi] split layout"""
+    lib = _lib.load()
+    _lib.require_cuda(a1, a2, out)
+    is_f32 = a1.dtype == torch.float32
+    out_x3 = out.dtype == torch.float16
+    assert a1.dtype == a2.dtype and (a0 is None or a0.dtype == torch.float32)
+    assert a1.shape == (batch * (h0 // 2) * (w0 // 2), c) and a2.shape == (batch * (h0 // 4) * (w0 // 4), c)
+    assert out.shape == (batch * h0 * w0, 3 * c if out_x3 else c) and out.is_contiguous()
+    _lib.check(lib.sm_upsample_sum2(_lib.ptr(a0), _lib.ptr(a1), _lib.ptr(a2), int(is_f32), batch, h0, w0, c, int(relu),
+                                    int(out_x3), _lib.ptr(out), _lib.stream_ptr()), "sm_upsample_sum2")
+    return out
+
+
 def _lv_geometry(lv):
     nlev = len(lv)
     return nlev, (C.c_int32 * nlev)(*[h * w for h, w in lv.sizes]), (C.c_int64 * nlev)(*lv.row0)

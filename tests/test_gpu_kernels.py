@@ -982,3 +982,43 @@ def test_bottleneck_tail_bit_identical_to_separate_convs(C, chain):
     r2 = bf(torch.relu(torch.nn.functional.conv2d(xi, w2, b2.cpu(), 1, 1))).float()
     r3 = torch.relu(torch.nn.functional.conv2d(r2, w3, b3.cpu()) + idt.float().cpu().view(B, h, w, 4 * C).permute(0, 3, 1, 2))
     torch.testing.assert_close(y[:M].float().cpu(), r3.permute(0, 2, 3, 1).reshape(M, 4 * C), rtol=1e-2, atol=2e-2)
+
+
+def test_upsample_sum2_vs_torch_and_lat0_by_linearity():
+    """sm_upsample_sum2 (round 4): out = [relu](a0 + up2(a1) + up4(a2)), bilinear align_corners=False, against
+    F.interpolate -- bf16 rows (one rounding), f32 rows (1e-6), the split layout [hi | lo | hi] (hi + lo == f32 value to 2^-21) --
+    and the identity the launch plan uses it for: the 1x1 conv sip_mask_lat0 over [l0 | up2(l1) | up4(l2)]
+    (sipmask_head.py:275-283) equals W0.l0 + up2(W1.l1) + up4(W2.l2) up to f32 rounding."""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    B, h0, w0, C = 2, 12, 20, 32
+    a0 = torch.randn(B, C, h0, w0, generator=g)
+    a1 = torch.randn(B, C, h0 // 2, w0 // 2, generator=g)
+    a2 = torch.randn(B, C, h0 // 4, w0 // 4, generator=g)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+    up = lambda t, f: F.interpolate(t, scale_factor=f, mode="bilinear", align_corners=False)
+    # f32 rows, with and without a0 / relu
+    want = a0 + up(a1, 2) + up(a2, 4)
+    out = torch.empty(B * h0 * w0, C, device=dev)
+    H.upsample_sum2(rows(a0).to(dev), rows(a1).to(dev), rows(a2).to(dev), out, B, h0, w0, C)
+    torch.testing.assert_close(out.cpu(), rows(want), rtol=1e-6, atol=1e-6)
+    H.upsample_sum2(None, rows(a1).to(dev), rows(a2).to(dev), out, B, h0, w0, C, relu=True)
+    torch.testing.assert_close(out.cpu(), rows(torch.relu(up(a1, 2) + up(a2, 4))), rtol=1e-6, atol=1e-6)
+    # split output
+    o3 = torch.empty(B * h0 * w0, 3 * C, dtype=torch.float16, device=dev)
+    H.upsample_sum2(rows(a0).to(dev), rows(a1).to(dev), rows(a2).to(dev), o3, B, h0, w0, C, relu=True)
+    o3 = o3.cpu().float()
+    assert torch.equal(o3[:, :C], o3[:, 2 * C:])
+    torch.testing.assert_close(o3[:, :C] + o3[:, C:2 * C], rows(torch.relu(want)), rtol=2e-6, atol=2e-6)
+    # bf16 rows
+    b1, b2 = a1.to(torch.bfloat16), a2.to(torch.bfloat16)
+    ob = torch.empty(B * h0 * w0, C, dtype=torch.bfloat16, device=dev)
+    H.upsample_sum2(None, rows(b1).to(dev), rows(b2).to(dev), ob, B, h0, w0, C)
+    torch.testing.assert_close(ob.cpu().float(), rows(up(b1.float(), 2) + up(b2.float(), 4)), rtol=2 ** -7, atol=1e-3)
+    # the identity
+    w = torch.randn(16, 3 * C, 1, 1, generator=g) / (3 * C) ** 0.5
+    l0, l1, l2 = a0, a1, a2
+    direct = F.conv2d(torch.cat([l0, up(l1, 2), up(l2, 4)], 1), w)
+    by_lin = F.conv2d(l0, w[:, :C]) + up(F.conv2d(l1, w[:, C:2 * C]), 2) + up(F.conv2d(l2, w[:, 2 * C:]), 4)
+    torch.testing.assert_close(by_lin, direct, rtol=1e-5, atol=1e-5)
