@@ -244,7 +244,12 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     nfused = sum(2 + (t.w1n is not None) for t in eng.fused)
     if variant in ("r50", "vis", "benchmark", "ssd") and os.environ.get("SIPMASK_FUSE_BOTTLENECK", "1") == "1":
         assert len(eng.fused) == 7 and nfused == 7 * 2
-    assert len(rows) == len(eng.convs) and len(rows) == nconv - ngrouped - nfused
+    # sip_mask_lat0 by linearity (round 4): the 768 -> 512 conv runs as three 1x1 convs (l0, l1, l2) + sm_upsample_sum2
+    nlin = 2 if getattr(eng, "lat0_by_linearity", False) else 0
+    if nlin:
+        assert {"head.sip_mask_lat0", "head.sip_mask_lat0.l1", "head.sip_mask_lat0.l2"} <= set(rows)
+        assert any(lbl == "up:sum2" for lbl, _ in eng.steps) and not any(lbl.startswith("up:cat") for lbl, _ in eng.steps)
+    assert len(rows) == len(eng.convs) and len(rows) == nconv - ngrouped - nfused + nlin
     assert all(r["blocks"] > 0 and r["waves"] > 0 and r["kind"] in ("igemm", "patch", "window") for r in rows.values())
     assert len(eng.steps) == len(eng.lanes)
     joined = set()
@@ -408,3 +413,37 @@ def test_fcos_sipmask_head_alias_builds_from_cfg():
     with pytest.raises(TypeError):
         build_head(dict(type="FCOSSipMaskHead", loss_cls=dict(type="FocalLoss")))
     assert callable(getattr(D.SipMask, "forward_dummy"))
+
+
+def test_launch_plan_decisions_at_the_baseline_shape():
+    """Round 4's launch-plan rules, pinned on the CPU at BASELINE configs[1] (R50, batch 4, 800 x 1344, a PipelinedPlan slot):
+    the FPN's three output convs are ONE patch launch with per-level weights; layer3 / layer4 conv2 take the 128-cout patch
+    tile; sip_mask_lat and fcos_reg + centerness the 32-cout tile; sip_mask_lat0 runs by linearity; lat2 / P6 / P7 keep the
+    latency-shaped plan (no big-tile flag); the conv FLOPs of a step are the reference's 1 803.7 GFLOP minus what the
+    linearity saves."""
+    import importlib.util
+    from sipmask_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libsipmask_hip.so not built (run __graft_entry__.build())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("plan_dump", os.path.join(root, "tools", "plan_dump.py"))
+    pd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pd)
+    eng = pd.build_on_cpu("r50", batch=4, hw=(800, 1344), pipelined=True)
+    convs = {c.name: c for c in eng.convs}
+    outs = convs["fpn.outs"]
+    assert eng.fpn_grouped and outs.patch and outs.desc.nlev == 3 and outs.desc.w_level_stride == 256 * 9 * 256
+    assert [tuple(s) for s in zip(outs.desc.in_h[:3], outs.desc.in_w[:3])] == [(100, 168), (50, 84), (25, 42)]
+    assert not any(n.startswith("fpn.out") and n != "fpn.outs" for n in convs)
+    for n in ("backbone.layer3.2.conv2", "backbone.layer4.1.conv2"):
+        assert convs[n].patch and convs[n].desc.patch_cout_tile == 128, n
+    assert convs["head.tower0"].patch and convs["head.tower0"].desc.patch_cout_tile == 0 and convs["head.tower0"].desc.cout_pad == 256
+    for n, co in (("head.sip_mask_lat", 32), ("head.reg_ctr", 8)):
+        assert convs[n].patch and convs[n].desc.cout_pad == 32 and convs[n].desc.cout == co, n
+    assert eng.lat0_by_linearity and convs["head.sip_mask_lat0"].desc.cin == 256 and convs["head.sip_mask_lat0"].residual is not None
+    big = _lib.SM_CONV_DBG_BIG_TILES
+    assert convs["backbone.layer3.2.conv1"].desc.flags & big                 # a slot builds for CU time ...
+    for n in ("fpn.lat2", "fpn.p6", "fpn.p7"):
+        assert not (convs[n].desc.flags & big), n                              # ... except the three launch-latency-shaped convs
+    gf = eng.total_conv_flops() / 1e9
+    assert abs(gf - (1803.7 - 29.7)) < 0.5, gf
