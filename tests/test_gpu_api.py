@@ -837,8 +837,8 @@ def test_backbone_fpn_backward_vs_same_rounding_emulation(bn3_gain):
     other way perturbs everything downstream, so the comparison has a NOISE FLOOR, which the test measures instead of
     guessing: the emulation against ITSELF with one input pixel moved by 0.02 (measured on this untrained, gain-calibrated
     net: the five FPN outputs move by 0.6 %, 40 % of their bf16 values change, the layer2 weight gradients move by ~25 %).
-    Bounds: shallow tensors (neck) cosine >= 0.999 / error <= 5e-2; every trunk tensor within 1.5x its own noise floor
-    (+ 2e-2), cosine >= 0.94; a mis-wired or dropped branch gives an O(1) error far above any floor.  bn3_gain = 0.25 is a
+    Bounds: shallow tensors (neck) cosine >= 0.998 / error <= 6e-2 (measured 0.9995 / 3.2e-2); every trunk tensor within 1.5x
+    its own noise floor (+ 3e-2; measured 1.0-1.1x), cosine >= 0.93 (measured 0.963); a mis-wired or dropped branch gives an O(1) error far above any floor.  bn3_gain = 0.25 is a
     tamer trunk (smaller residual branches): there the floor and the HIP error both drop."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -895,10 +895,10 @@ def test_backbone_fpn_backward_vs_same_rounding_emulation(bn3_gain):
             for w in table:
                 f.write("%.5f %.5f %.6f %s\n" % w)
     assert n_checked >= 50, n_checked
-    bad = [w for w in table if w[0] > 1.5 * w[1] + 2e-2 or w[2] < 0.94]
+    bad = [w for w in table if w[0] > 1.5 * w[1] + 3e-2 or w[2] < 0.93]
     assert not bad, (bad[:8], table[:3])
     neck = [w for w in table if w[3].startswith("neck.")]
-    assert neck and all(w[0] <= 5e-2 and w[2] >= 0.999 for w in neck), sorted(neck, reverse=True)[:5]
+    assert neck and all(w[0] <= 6e-2 and w[2] >= 0.998 for w in neck), sorted(neck, reverse=True)[:5]
 
 
 def test_collective_path_runs_through_rccl_on_one_rank():
