@@ -20,7 +20,17 @@ inference; RCCL gradient all-reduce in training).  BASELINE.json configs:
 ranks (one per GPU); the driver's own `python -m torch.distributed.run ... bench.py --gpus N` works unchanged.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel) and `cpu_baseline`
-(the CPU oracle on the host cores on a bounded sample; rank 0, N=1 only).
+(the CPU oracle on the host cores on a bounded sample; rank 0, N=1 only).  The default r50 line also carries (round 4;
+`--no-extras` / `--extras-budget` bound them):
+  timed_region_s          seconds of the contract's K timed steps (`value` is computed from them)
+  steady_state            the same step over a window of >= 2 s (every rank; same fences)
+  with_results            ... with the results returned to the host per batch: device RLE + async D2H behind every step, the
+                          RLE dicts built on the host inside the timed window (PipelinedPlan.submit(pack=True) / fetch)
+  parity                  the TIMED plan against the fp32 CPU oracle from the same images
+  parity_plan             the plan that meets north_star's tolerance (`--precision head_x3`), timed with the same structure over
+                          >= 2 s in this run, its parity measured on identical head inputs (and from the image)
+  mask_assemble_worst_case  the timed plan's mask assembly on 100 image-sized boxes per image
+  other_configs           BASELINE configs[2]-[4] (r101 / train / vis) as child runs under a time budget
 """
 import argparse
 import json
