@@ -27,6 +27,7 @@ struct RleArgs {
   int hc, wc;          // copied window = min(mask, canvas) (:649,652)
   int max_runs, cap;
   long long packed_cap;
+  int lds_scratch;     // 1: the encode kernel keeps a detection's scratch arrays in dynamic LDS
 };
 
 __device__ __forceinline__ int block_excl_scan(int v, int* s_wave, int* total) {
@@ -109,7 +110,8 @@ __device__ __forceinline__ uint32_t rle_prev(const uint8_t* __restrict__ m, cons
 }
 
 template <bool ALIGNED>
-__device__ void rle_encode_one(const int i, const int b, int* s_wave, long long* s_red, const uint8_t* __restrict__ masks,
+__device__ void rle_encode_one(const int i, const int b, int* s_wave, long long* s_red, unsigned char* lds_scratch,
+                               const uint8_t* __restrict__ masks,
                                const int32_t* __restrict__ ndet, const int32_t* __restrict__ rect,
                                uint32_t* __restrict__ pos_ws, int32_t* __restrict__ unit_ws, uint32_t* __restrict__ counts,
                                int32_t* __restrict__ nruns, int32_t* __restrict__ nchars, const RleArgs& a) {
@@ -123,8 +125,11 @@ __device__ void rle_encode_one(const int i, const int b, int* s_wave, long long*
     return;
   }
   const uint8_t* m = masks + (long long)det * a.ho * a.wo;
-  uint32_t* pos = pos_ws + (long long)det * a.max_runs;
-  int32_t* unit = unit_ws + (long long)det * a.cap;
+  // scratch of one detection: transition positions and per-unit counts.  In LDS when the launch gave the block room for them
+  // (round 4: every phase of this kernel is a block-wide pass over these arrays between barriers, and out of HBM / L2 each
+  // pass was a memory round trip), else in the global workspace (wide canvases, large max_runs).
+  uint32_t* pos = lds_scratch ? reinterpret_cast<uint32_t*>(lds_scratch) + a.cap : pos_ws + (long long)det * a.max_runs;
+  int32_t* unit = lds_scratch ? reinterpret_cast<int32_t*>(lds_scratch) : unit_ws + (long long)det * a.cap;
   uint32_t* cnt_out = counts + (long long)det * a.max_runs;
   const uint32_t N = (uint32_t)a.H * (uint32_t)a.W;
 
@@ -269,10 +274,12 @@ __global__ __launch_bounds__(RLE_THREADS) void rle_encode_kernel(const uint8_t* 
                                                                  int32_t* __restrict__ nchars, const RleArgs a) {
   __shared__ int s_wave[RLE_THREADS / 64];
   __shared__ long long s_red[RLE_THREADS / 64];
+  extern __shared__ __attribute__((aligned(16))) unsigned char rle_dyn[];    // (cap + max_runs) * 4 bytes, or nothing
+  unsigned char* const lds_scratch = a.lds_scratch ? rle_dyn : nullptr;
   const int total = a.batch * a.max_num;
   for (int d = blockIdx.x; d < total; d += gridDim.x) {
-    rle_encode_one<ALIGNED>(d % a.max_num, d / a.max_num, s_wave, s_red, masks, ndet, rect, pos_ws, unit_ws, counts, nruns,
-                            nchars, a);
+    rle_encode_one<ALIGNED>(d % a.max_num, d / a.max_num, s_wave, s_red, lds_scratch, masks, ndet, rect, pos_ws, unit_ws, counts,
+                            nruns, nchars, a);
     __syncthreads();                       // the shared scratch is reused by the next detection
   }
 }
@@ -411,11 +418,26 @@ extern "C" int sm_rle_encode(const uint8_t* masks, const int32_t* ndet, const in
     return (v == 256 || v == 512) ? v : RLE_THREADS;
   }();
   const int nblocks = (int)(nd < RLE_MAX_BLOCKS ? nd : RLE_MAX_BLOCKS);
+  static const bool lds_ok = [] {
+    const char* e = getenv("SIPMASK_RLE_LDS");
+    return !(e && atoi(e) == 0);
+  }();
+  size_t dyn = ((size_t)a.cap + (size_t)max_runs) * 4;
+  a.lds_scratch = (lds_ok && dyn <= 144u * 1024u) ? 1 : 0;
+  if (!a.lds_scratch) dyn = 0;
+  if (dyn > 48u * 1024u) {                       // > 64 KB of LDS per block needs the opt-in, once per kernel
+    static bool attr_set[2] = {false, false};
+    const void* fn = aligned ? (const void*)&rle_encode_kernel<true> : (const void*)&rle_encode_kernel<false>;
+    if (!attr_set[aligned ? 1 : 0]) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) return SM_ERR_LAUNCH;
+      attr_set[aligned ? 1 : 0] = true;
+    }
+  }
   if (aligned)
-    hipLaunchKernelGGL(rle_encode_kernel<true>, dim3(nblocks), dim3(nthreads), 0, s, masks, ndet, rect, pos_ws,
+    hipLaunchKernelGGL(rle_encode_kernel<true>, dim3(nblocks), dim3(nthreads), dyn, s, masks, ndet, rect, pos_ws,
                        unit_ws, counts, nruns, nchars, a);
   else
-    hipLaunchKernelGGL(rle_encode_kernel<false>, dim3(nblocks), dim3(nthreads), 0, s, masks, ndet, rect, pos_ws,
+    hipLaunchKernelGGL(rle_encode_kernel<false>, dim3(nblocks), dim3(nthreads), dyn, s, masks, ndet, rect, pos_ws,
                        unit_ws, counts, nruns, nchars, a);
   hipLaunchKernelGGL(rle_pack_kernel, dim3(nblocks), dim3(nthreads), 0, s, counts, nruns, nchars, packed, offsets,
                      a);
