@@ -480,6 +480,15 @@ struct NmsArgs {
   int top_k;         // fast_nms: boxes kept per class before the IoU test (:871)
   int P_lds;         // per-class capacity of the LDS working set (keys + kept boxes + indices, 28 bytes per entry)
   unsigned char* ext;   // [B][C][P] x 28 bytes in HBM/L2: working set of a class with more than P_lds candidates
+  // heavy classes (more than heavy_min candidates above score_thr): the class block only sorts; the IoU tests run
+  // chip-wide as a bit matrix (nms_heavy_matrix_kernel) and ONE wave scans it (nms_heavy_scan_kernel)
+  int heavy_min, heavy_slots;   // heavy_slots == 0: path off
+  int rows, W;                  // per slot: rows = kmax rounded up to 64, W = rows / 64 mask words per row
+  int32_t* heavy_cnt;           // [1] slots requested by this launch (may exceed heavy_slots: the rest stay in-block)
+  int32_t* heavy_meta;          // [slots][4] = (image, class, n, -)
+  float4* hbox;                 // [slots][rows] boxes in score order
+  uint32_t* hidx;               // [slots][rows] candidate indices in score order
+  unsigned long long* hmat;     // [slots][rows][W] bit j of word w of row i: box w*64+j > i is suppressed by box i
 };
 
 // One block per (image, class).  A class typically passes score_thr with a few dozen candidates, rarely with
@@ -517,10 +526,18 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __r
     if (tid == 0) cls_cnt[b * a.C + c] = 0;
     return;
   }
-  if (tid == 0) sm.n = 0;
   int P = 1;
   while (P < n) P <<= 1;
-  const bool in_lds = P <= a.P_lds;
+  // a heavy class asks for a slot of the chip-wide path; with a slot only the keys are needed here (8 bytes per entry)
+  int slot = -1;
+  if (a.heavy_slots > 0 && n > a.heavy_min) {
+    if (tid == 0) sm.nkept = atomicAdd(a.heavy_cnt, 1);
+    __syncthreads();
+    slot = sm.nkept < a.heavy_slots ? sm.nkept : -1;
+    __syncthreads();
+  }
+  if (tid == 0) sm.n = 0;
+  const bool in_lds = slot >= 0 ? (size_t)P * 8 <= (size_t)a.P_lds * 28 : P <= a.P_lds;
   unsigned char* ws = in_lds ? dsm : a.ext + ((size_t)b * a.C + c) * (size_t)a.P * 28;
   const size_t cap = in_lds ? (size_t)a.P_lds : (size_t)a.P;
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws);
@@ -546,6 +563,21 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __r
   __syncthreads();
   // 2. sort (score desc, index asc)
   block_bitonic_desc(keys, P, in_lds);
+  if (slot >= 0) {   // hand the sorted class over: boxes + indices in score order
+    float4* hb = a.hbox + (size_t)slot * a.rows;
+    uint32_t* hi = a.hidx + (size_t)slot * a.rows;
+    for (int i = tid; i < n; i += NMS_THREADS) {
+      const uint32_t idx = 0xffffffffu - (uint32_t)(keys[i] & 0xffffffffull);
+      hi[i] = idx;
+      hb[i] = bx[idx];
+    }
+    if (tid == 0) {
+      a.heavy_meta[slot * 4 + 0] = b;
+      a.heavy_meta[slot * 4 + 1] = c;
+      a.heavy_meta[slot * 4 + 2] = n;
+    }
+    return;
+  }
   // 3. greedy NMS
   const int nk = block_greedy_nms(keys, n, a.iou_thr, kept_box, kept_idx, sm, [&](uint32_t idx) { return bx[idx]; });
   // 4. reference returns kept ORIGINAL indices ascending (nms_kernel.cu:135-138)
@@ -553,6 +585,153 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __r
   for (int i = tid; i < nk; i += NMS_THREADS) outk[i] = (int32_t)(0xffffffffu - (uint32_t)keys[i]);
   if (tid == 0) cls_cnt[b * a.C + c] = nk;
 }
+
+// ---- heavy classes: bit matrix over the whole chip + one-wave scan.  In the class block the IoU tests of a class with n
+// candidates and k kept boxes (n * k / 2 of them, 22 VALU instructions each) run on ONE CU: 1 000 candidates cost 60 us,
+// 3 350 (every candidate of an image in one class) over a millisecond.  Here tile (r, w) of the reference's own n x n/64
+// mask (nms_kernel.cu:24-68: bit j of word w of row i = IoU(i, w*64+j) > thr, j > i) is one wave: 64 ballots.
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+__global__ __launch_bounds__(256) void nms_heavy_matrix_kernel(const NmsArgs a) {
+  const int slot = blockIdx.y;
+  const int nh = min(*a.heavy_cnt, a.heavy_slots);
+  if (slot >= nh) return;
+  const int n = a.heavy_meta[slot * 4 + 2];
+  const int Wn = (n + 63) >> 6;
+  const float4* hb = a.hbox + (size_t)slot * a.rows;
+  unsigned long long* M = a.hmat + (size_t)slot * a.rows * a.W;
+  const int lane = threadIdx.x & 63;
+  const int nw = gridDim.x * 4;
+  for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < Wn * Wn; q += nw) {
+    const int r = q / Wn, w = q - r * Wn;
+    if (w < r) continue;
+    const int col = w * 64 + lane, rowi = r * 64 + lane;
+    const bool cv = col < n;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 cb = cv ? hb[col] : z;
+    const float4 rb = rowi < n ? hb[rowi] : z;
+    unsigned long long mine = 0ull;
+#pragma unroll 16
+    for (int t = 0; t < 64; ++t) {
+      float4 bt;
+      bt.x = readlane_f(rb.x, t);
+      bt.y = readlane_f(rb.y, t);
+      bt.z = readlane_f(rb.z, t);
+      bt.w = readlane_f(rb.w, t);
+      const int ri = r * 64 + t;
+      const bool hit = cv && ri < n && col > ri && iou_plus1_gt(bt, cb, a.iou_thr);
+      const unsigned long long bal = __ballot(hit);
+      if (lane == t) mine = bal;
+    }
+    if (rowi < n) M[(size_t)rowi * a.W + w] = mine;
+  }
+}
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, l);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// The host scan of the reference (nms_kernel.cu:113-138: `if (!(remv[nblock] & (1 << inblock))) { keep; remv |= row }`)
+// by one wave: lane w holds word w (+64, +128 ...) of `remv`, the word of the running chunk is mirrored in a scalar so
+// the dependent chain of a step is three scalar instructions; the rows are prefetched G at a time (they do not depend on
+// any decision).  The other 3 waves of the block only take part in the final ascending index sort.
+constexpr int SCAN_THREADS = 256;   // one wave per SIMD: the scanning wave may use the whole VGPR file for its row buffers
+template <int WPL, int G>
+__global__ __launch_bounds__(SCAN_THREADS) void nms_heavy_scan_kernel(int32_t* __restrict__ cls_keep,
+                                                                     int32_t* __restrict__ cls_cnt, const NmsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  __shared__ int s_nk;
+  const int slot = blockIdx.x;
+  const int nh = min(*a.heavy_cnt, a.heavy_slots);
+  if (slot >= nh) return;
+  const int b = a.heavy_meta[slot * 4 + 0], c = a.heavy_meta[slot * 4 + 1], n = a.heavy_meta[slot * 4 + 2];
+  int P = 1;
+  while (P < n) P <<= 1;
+  unsigned long long* sortbuf = reinterpret_cast<unsigned long long*>(dsm);
+  uint32_t* kept_idx = reinterpret_cast<uint32_t*>(dsm + (size_t)a.P * 8);
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < 64) {
+    const int Wn = (n + 63) >> 6;
+    const unsigned long long* M = a.hmat + (size_t)slot * a.rows * a.W;
+    const uint32_t* hi = a.hidx + (size_t)slot * a.rows;
+    unsigned long long removed[WPL];
+#pragma unroll
+    for (int k = 0; k < WPL; ++k) removed[k] = 0ull;
+    unsigned long long buf[2][G][WPL];
+    auto load = [&](unsigned long long (&dst)[G][WPL], int row0) {
+      // branch-free: rows past n are clamped (process() ignores them), words below the diagonal or past the class's
+      // last word were never written and are masked out
+      const int cr = row0 >> 6;
+#pragma unroll
+      for (int k = 0; k < WPL; ++k) {
+        const int wd = k * 64 + lane;
+        const bool live = wd >= cr && wd < Wn;
+        const unsigned long long* mp = M + min(wd, a.W - 1);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const unsigned long long v = mp[(size_t)min(row0 + g, n - 1) * a.W];
+          dst[g][k] = live ? v : 0ull;
+        }
+      }
+    };
+    int nk = 0;
+    unsigned long long cw = 0ull, km = 0ull;
+    auto process = [&](unsigned long long (&cur)[G][WPL], int row0) {
+      const int cc = row0 >> 6, cl = cc & 63, ck = cc >> 6;
+      if ((row0 & 63) == 0) {
+        unsigned long long v = removed[0];
+#pragma unroll
+        for (int k = 1; k < WPL; ++k)
+          if (ck == k) v = removed[k];
+        cw = readlane_u64(v, cl);
+        if (cc * 64 + 64 > n) cw |= ~0ull << (n - cc * 64);   // rows past n: "removed", so a step is one bit test
+        km = 0ull;
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int t = (row0 & 63) + g;
+        unsigned long long dv = cur[g][0];
+#pragma unroll
+        for (int k = 1; k < WPL; ++k)
+          if (ck == k) dv = cur[g][k];
+        const unsigned long long dg = readlane_u64(dv, cl);
+        if (!((cw >> t) & 1ull)) {
+          cw |= dg;
+          km |= 1ull << t;
+#pragma unroll
+          for (int k = 0; k < WPL; ++k) removed[k] |= cur[g][k];
+        }
+      }
+      if (((row0 + G) & 63) == 0 || row0 + G >= n) {   // chunk complete: append its kept boxes in score order
+        if ((km >> lane) & 1ull) kept_idx[nk + __popcll(km & ((1ull << lane) - 1ull))] = hi[cc * 64 + lane];
+        nk += __popcll(km);
+      }
+    };
+    const int ng = (n + G - 1) / G;
+    load(buf[0], 0);
+    for (int gi = 0; gi < ng; gi += 2) {
+      if (gi + 1 < ng) load(buf[1], (gi + 1) * G);
+      process(buf[0], gi * G);
+      if (gi + 1 < ng) {
+        if (gi + 2 < ng) load(buf[0], (gi + 2) * G);
+        process(buf[1], (gi + 1) * G);
+      }
+    }
+    if (lane == 0) s_nk = nk;
+  }
+  __syncthreads();
+  const int nk = s_nk;
+  // reference returns kept ORIGINAL indices ascending (nms_kernel.cu:135-138)
+  block_sort_idx_asc(sortbuf, kept_idx, nk);
+  int32_t* outk = cls_keep + ((long long)b * a.C + c) * a.kmax;
+  for (int i = tid; i < nk; i += SCAN_THREADS) outk[i] = (int32_t)(0xffffffffu - (uint32_t)sortbuf[i]);
+  if (tid == 0) cls_cnt[b * a.C + c] = nk;
+}
+
 
 __global__ __launch_bounds__(TK_THREADS) void nms_final_kernel(const float* __restrict__ boxes,
                                                                const float* __restrict__ scores,
@@ -621,7 +800,15 @@ __global__ __launch_bounds__(TK_THREADS) void nms_final_kernel(const float* __re
     fk[p] = __fmul_rn(scores[((long long)b * a.C + lo) * a.kmax + idx], ctr[(long long)b * a.kmax + idx]);
   }
   __syncthreads();
-  block_topk(fk, total, nout, sm);
+  if (total <= TK_CAP) {   // the usual case (a few hundred survivors): sort them all, no radix select (46 -> 15 us)
+    int P = 1;
+    while (P < total) P <<= 1;
+    for (int p = tid; p < P; p += TK_THREADS)
+      sm.sel[p] = p < total ? compose_key(float_to_ordered(fk[p]), (uint32_t)p) : 0ull;
+    block_bitonic_desc(sm.sel, P);
+  } else {
+    block_topk(fk, total, nout, sm);
+  }
   for (int i = tid; i < nout; i += TK_THREADS)
     emit(i, (int)(0xffffffffu - (uint32_t)(sm.sel[i] & 0xffffffffull)));
   if (tid == 0) ndet[b] = nout;
@@ -870,12 +1057,61 @@ extern "C" int sm_pairs_select(const sm_det_desc* d, float pre_nms_thresh, const
   return SM_OK;
 }
 
-extern "C" int64_t sm_multiclass_nms_workspace(int batch, int kmax, int num_classes) {
+namespace {
+// heavy-class path: classes with more than heavy_min candidates above the score threshold; SIPMASK_NMS_HEAVY_MIN=0
+// turns it off (A/B), slots beyond NMS_HEAVY_SLOTS in one launch stay on the in-block path
+constexpr int NMS_HEAVY_SLOTS = 32;
+int nms_heavy_min() {
+  static const int v = [] {
+    const char* e = getenv("SIPMASK_NMS_HEAVY_MIN");
+    return e ? atoi(e) : 512;
+  }();
+  return v;
+}
+struct HeavyLayout {
+  int slots, rows, W;
+  size_t off_cnt, off_meta, off_box, off_idx, off_mat, end;
+};
+HeavyLayout heavy_layout(int batch, int kmax, int num_classes, size_t base) {
+  HeavyLayout h;
+  const long long cls = (long long)batch * num_classes;
+  h.slots = cls < NMS_HEAVY_SLOTS ? (int)cls : NMS_HEAVY_SLOTS;
+  h.rows = (kmax + 63) / 64 * 64;
+  h.W = h.rows / 64;
+  if (nms_heavy_min() <= 0 || kmax <= nms_heavy_min() || h.W > 128) h.slots = 0;   // scan kernel: <= 2 words per lane
+  h.off_cnt = (base + 255) / 256 * 256;
+  h.off_meta = h.off_cnt + 256;
+  h.off_box = h.off_meta + (size_t)h.slots * 16;
+  h.off_idx = h.off_box + (size_t)h.slots * h.rows * 16;
+  h.off_mat = (h.off_idx + (size_t)h.slots * h.rows * 4 + 255) / 256 * 256;
+  h.end = h.off_mat + (size_t)h.slots * h.rows * h.W * 8;
+  return h;
+}
+size_t nms_base_bytes(int batch, int kmax, int num_classes) {
   // cls_keep i32 [B][C][kmax] + flat_key f32 [B][C][kmax] + cls_cnt i32 [B][C]
-  int64_t n = (int64_t)batch * num_classes * kmax * 8 + (int64_t)batch * num_classes * 4;
-  const int64_t P = next_pow2(kmax);
-  if (P > NMS_P_LDS) n = (n + 255) / 256 * 256 + (int64_t)batch * num_classes * P * 28;   // scratch of heavy classes
+  size_t n = (size_t)batch * num_classes * kmax * 8 + (size_t)batch * num_classes * 4;
+  const size_t P = next_pow2(kmax);
+  if (P > NMS_P_LDS) n = (n + 255) / 256 * 256 + (size_t)batch * num_classes * P * 28;   // in-block scratch of big classes
   return n;
+}
+
+template <int WPL, int G>
+int launch_heavy_scan(int slots, size_t lds, hipStream_t s, int32_t* cls_keep, int32_t* cls_cnt, const NmsArgs& a) {
+  static bool attr_done = false;
+  if (lds > 48 * 1024 && !attr_done) {
+    if (hipFuncSetAttribute((const void*)nms_heavy_scan_kernel<WPL, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            144 * 1024) != hipSuccess)
+      return SM_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((nms_heavy_scan_kernel<WPL, G>), dim3(slots), dim3(SCAN_THREADS), lds, s, cls_keep, cls_cnt, a);
+  return SM_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t sm_multiclass_nms_workspace(int batch, int kmax, int num_classes) {
+  return (int64_t)heavy_layout(batch, kmax, num_classes, nms_base_bytes(batch, kmax, num_classes)).end;
 }
 
 extern "C" int sm_multiclass_nms(const float* boxes, const float* scores, const float* ctr, const int32_t* ncand,
@@ -885,7 +1121,7 @@ extern "C" int sm_multiclass_nms(const float* boxes, const float* scores, const 
   if (!boxes || !scores || !ctr || !ncand || !det || !labels || !keep || !ndet || !workspace) return SM_ERR_BAD_ARG;
   if (batch < 1 || kmax < 1 || num_classes < 1 || num_classes > 256) return SM_ERR_BAD_SHAPE;
   if (max_num < 1 || max_num > TK_CAP) return SM_ERR_UNSUPPORTED;
-  NmsArgs a;
+  NmsArgs a = {};
   a.batch = batch;
   a.kmax = kmax;
   a.C = num_classes;
@@ -904,11 +1140,31 @@ extern "C" int sm_multiclass_nms(const float* boxes, const float* scores, const 
   int32_t* cls_cnt = (int32_t*)((char*)workspace + (size_t)batch * num_classes * kmax * 8);
   if (a.P > NMS_P_LDS)           // classes with more than NMS_P_LDS candidates work out of their global scratch slice
     a.ext = (unsigned char*)workspace + (((size_t)batch * num_classes * kmax * 8 + (size_t)batch * num_classes * 4 + 255) / 256) * 256;
+  const HeavyLayout h = heavy_layout(batch, kmax, num_classes, nms_base_bytes(batch, kmax, num_classes));
+  unsigned char* wsb = (unsigned char*)workspace;
+  a.heavy_min = nms_heavy_min();
+  a.heavy_slots = h.slots;
+  a.rows = h.rows;
+  a.W = h.W;
+  a.heavy_cnt = (int32_t*)(wsb + h.off_cnt);
+  a.heavy_meta = (int32_t*)(wsb + h.off_meta);
+  a.hbox = (float4*)(wsb + h.off_box);
+  a.hidx = (uint32_t*)(wsb + h.off_idx);
+  a.hmat = (unsigned long long*)(wsb + h.off_mat);
   if (hipFuncSetAttribute((const void*)nms_class_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return SM_ERR_LAUNCH;
+  if (h.slots > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s, a.heavy_cnt, 1, 0);
   hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(NMS_THREADS), lds, s, boxes, scores, ctr, ncand, cls_keep,
                      cls_cnt, a);
+  if (h.slots > 0) {
+    hipLaunchKernelGGL(nms_heavy_matrix_kernel, dim3(128, h.slots), dim3(256), 0, s, a);
+    const size_t slds = (size_t)a.P * 8 + (size_t)h.rows * 4;
+    int st;
+    if (h.W <= 64) st = launch_heavy_scan<1, 32>(h.slots, slds, s, cls_keep, cls_cnt, a);
+    else st = launch_heavy_scan<2, 16>(h.slots, slds, s, cls_keep, cls_cnt, a);
+    if (st != SM_OK) return st;
+  }
   hipLaunchKernelGGL(nms_final_kernel, dim3(batch), dim3(TK_THREADS), 0, s, boxes, scores, ctr, cls_keep, cls_cnt,
                      flat_key, det, labels, keep, ndet, a);
   SM_LAUNCH_CHECK();
@@ -922,7 +1178,7 @@ extern "C" int sm_fast_nms(const float* boxes, const float* scores, const float*
   if (!boxes || !scores || !ctr || !ncand || !det || !labels || !keep || !ndet || !workspace) return SM_ERR_BAD_ARG;
   if (batch < 1 || kmax < 1 || num_classes < 1 || num_classes > 256) return SM_ERR_BAD_SHAPE;
   if (max_num < 1 || max_num > TK_CAP || top_k < 1 || top_k > TK_CAP) return SM_ERR_UNSUPPORTED;
-  NmsArgs a;
+  NmsArgs a = {};
   a.batch = batch;
   a.kmax = kmax;
   a.C = num_classes;

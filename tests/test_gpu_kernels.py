@@ -450,6 +450,37 @@ def test_multiclass_nms_idx_vs_oracle(case):
     np.testing.assert_array_equal(b.cpu().numpy(), rb)       # boxes copied, score = f32 product: exact
 
 
+@pytest.mark.parametrize("case", [(3350, 3, 600.0, (513, 576, 3350)), (1500, 4, 150.0, (577, 640, 1, 1500)),
+                                  (5000, 2, 400.0, (5000, 4097)), (6000, 40, 900.0, (700,) * 40)])
+def test_multiclass_nms_heavy_classes_vs_oracle(case):
+    """Classes with more than 512 candidates above score_thr leave the class block: sort there, IoU bit matrix over the
+    whole chip (nms_heavy_matrix_kernel), one-wave scan (nms_heavy_scan_kernel) -- nms_kernel.cu:24-68,113-138.  Class
+    sizes on and around the 64-row chunk edges, every candidate in one class, crowded boxes (long suppression chains),
+    duplicates and score ties, kmax > 4096 (two mask words per lane), and more heavy classes than slots (40 > 32: the
+    rest stay in the block)."""
+    from sipmask_amd import ops as P
+    dev = _dev()
+    K, C, extent, sizes = case
+    rng = np.random.RandomState(K + C)
+    xy = rng.rand(K, 2).astype(np.float32) * extent
+    wh = rng.rand(K, 2).astype(np.float32) * 120 + 4
+    boxes = np.concatenate([xy, xy + wh], 1)
+    boxes[K // 2: K // 2 + 40] = boxes[:40]                    # duplicates
+    scores = np.zeros((K, C + 1), np.float32)
+    for c, n in enumerate(sizes):
+        sel = rng.permutation(K)[:n]
+        scores[sel, c + 1] = 0.06 + 0.9 * rng.rand(n).astype(np.float32)
+    scores[: K // 4] = np.round(scores[: K // 4], 2)           # ties
+    ctr = 0.5 + 0.5 * rng.rand(K).astype(np.float32)
+    for max_num in (100, 2000):
+        rb, rl, rk = O.multiclass_nms_idx(boxes, scores, 0.05, 0.5, max_num, ctr)
+        b, l, k = P.multiclass_nms_idx(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), 0.05,
+                                       dict(type="nms", iou_thr=0.5), max_num, torch.from_numpy(ctr).to(dev))
+        np.testing.assert_array_equal(k.cpu().numpy(), rk)
+        np.testing.assert_array_equal(l.cpu().numpy(), rl)
+        np.testing.assert_array_equal(b.cpu().numpy(), rb)
+
+
 @pytest.mark.parametrize("case", [(700, 80, 0.1), (150, 5, 0.0), (1, 3, 0.1), (3000, 20, 0.3)])
 def test_fast_nms_vs_oracle(case):
     """SipMaskHead.fast_nms (ssd_flag configs, sipmask_head.py:868-910): same boxes, classes, coefficient rows."""
