@@ -465,6 +465,7 @@ def run_inference(args, rank, world, dev):
     # the roofline fraction prices (the algorithmic figure is reported beside it)
     tower_flops = getattr(towers[0], "mfma_flops", towers[0].flops)
     all_conv_ms = sum(v for v in conv_ms.values())
+    all_conv_ms += sum(ms for (label, _), ms in zip(eng.steps, acc) if label == "stem_fused")   # conv1 + pool in one launch
     all_conv_flops = eng.total_conv_flops()
     fpn = [c for c in eng.convs if c.name.startswith("fpn.")]
     fpn_tf = sum(c.flops for c in fpn) / (sum(conv_ms[c.name] for c in fpn) * 1e-3) / 1e12
@@ -492,6 +493,11 @@ def run_inference(args, rank, world, dev):
                 if c is not None:
                     f.write("%-44s %9.4f ms %8.2f GFLOP %8.1f MB %7.1f TFLOP/s %7.0f GB/s\n" %
                             (label, ms, c.flops / 1e9, c.bytes / 1e6, c.flops / ms / 1e9, c.bytes / ms / 1e6))
+                elif label == "stem_fused":     # algorithmic bytes: the f32 image in, the pooled bf16 rows out
+                    h2, w2 = ((IMG_H - 1) // 2) // 2 + 1, ((IMG_W - 1) // 2) // 2 + 1      # conv 7x7/2 pad 3, pool 3x3/2 pad 1
+                    sb = eng.img.numel() * 4 + eng.batch * h2 * w2 * 128
+                    f.write("%-44s %9.4f ms %8.2f GFLOP %8.1f MB %7.1f TFLOP/s %7.0f GB/s\n" %
+                            (label, ms, eng.stem_flops / 1e9, sb / 1e6, eng.stem_flops / ms / 1e9, sb / ms / 1e6))
                 else:
                     f.write("%-44s %9.4f ms\n" % (label, ms))
             f.write("# sum %.3f ms; convs %.3f ms = %.1f TFLOP/s over %.1f GFLOP\n" %

@@ -368,6 +368,14 @@ int sm_groupnorm_apply_x3(const float* x, const float* gamma, const float* beta,
                           const int32_t* hw, const int64_t* row0, int channels, int groups, float eps, int relu,
                           float* y_f32, void* y_split, sm_stream_t stream);
 
+/* The ResNet stem as one launch (resnet.py:497-505: conv1 7x7 / stride 2 / pad 3 -> norm1 (frozen, folded into w / bias by the
+ * caller) -> ReLU -> maxpool 3x3 / stride 2 / pad 1): img NCHW f32 [batch][3][h][w] -> y NHWC bf16 rows
+ * [batch * h2 * w2][64] with h1 = (h - 1) / 2 + 1, h2 = (h1 - 1) / 2 + 1 (same for w).  w_stem: bf16 [64][7][8][4] =
+ * (cout, kh, kw, cin) with zeros in the kw = 7 and cin = 3 slots; bias f32 [64].  Same rounding points as
+ * sm_nchw_f32_to_nhwc_bf16 + sm_conv2d(SM_CONV_RELU) + sm_maxpool3x3s2; the f32 sum runs in a different K order. */
+int sm_stem_fused(const float* img, const void* w_stem, const float* bias, void* y, int batch, int h, int w,
+                  sm_stream_t stream);
+
 /* 3x3 stride-2 pad-1 max pool (resnet.py:460), NHWC bf16. */
 int sm_maxpool3x3s2(const void* x, void* y, int batch, int h, int w, int c, sm_stream_t stream);
 

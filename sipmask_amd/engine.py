@@ -49,6 +49,7 @@ _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"
 # FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes
 # the shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
 # shapes), "0" = three launches (A/B)
+_STEM_FUSED = os.environ.get("SIPMASK_STEM_FUSED", "1") != "0"        # A/B: conv1 + bn1 + relu + maxpool as one launch (stem_fused.hip)
 _LAT0_LINEAR = os.environ.get("SIPMASK_LAT0_LINEAR", "1") != "0"      # A/B: sip_mask_lat0 by linearity (three convs + upsample_sum2)
 _DIAG_SKIP = __import__("re").compile(os.environ["SIPMASK_DIAG_SKIP"]) if os.environ.get("SIPMASK_DIAG_SKIP") else None
 _FPN_GROUPED = os.environ.get("SIPMASK_FPN_GROUPED", "auto")
@@ -524,18 +525,26 @@ class SipMaskEngine:
         # ---- stem
         f32 = self.precision == "f32"
         cpad = 4 if f32 else 8
-        self.img_nhwc = self._buf(B * Himg * Wimg, cpad)
         h1, w1 = _conv_out(Himg, 7, 2, 3), _conv_out(Wimg, 7, 2, 3)
         w, b = fold_bn(sd["backbone.conv1.weight"], sd, "backbone.bn1")
-        stem = self._buf(B * h1 * w1, 64)
-        to_rows = H.nchw_to_nhwc_f32 if f32 else H.nchw_to_nhwc_bf16
-        self._add("nhwc", lambda: to_rows(self.img, self.img_nhwc, cpad))
-        self._add_conv(_Conv(self, "stem", w, b, B, [(Himg, Wimg)], [0], self.img_nhwc, cpad, 2, 3, stem, [0], 64,
-                             flags=SM_CONV_RELU, cin_pad=cpad))
         h2, w2 = _conv_out(h1, 3, 2, 1), _conv_out(w1, 3, 2, 1)
         x = self._buf(B * h2 * w2, 64)
-        pool = H.maxpool3x3s2_f32 if f32 else H.maxpool3x3s2
-        self._add("maxpool", (lambda s=stem, y=x: pool(s, y, B, h1, w1, 64)))
+        if _STEM_FUSED and not f32:
+            # conv1 + bn1 + relu + maxpool (resnet.py:497-505) as ONE launch from the NCHW f32 image (csrc/stem_fused.hip):
+            # the 400 x 672 x 64 conv output never goes to HBM
+            self.stem_w = H.prep_stem_weight(w.to(dev))
+            self.stem_b = b.float().to(dev).contiguous()
+            self.stem_flops = 2.0 * B * h1 * w1 * 64 * 147
+            self._add("stem_fused", lambda y=x: H.stem_fused(self.img, self.stem_w, self.stem_b, y))
+        else:
+            self.img_nhwc = self._buf(B * Himg * Wimg, cpad)
+            stem = self._buf(B * h1 * w1, 64)
+            to_rows = H.nchw_to_nhwc_f32 if f32 else H.nchw_to_nhwc_bf16
+            self._add("nhwc", lambda: to_rows(self.img, self.img_nhwc, cpad))
+            self._add_conv(_Conv(self, "stem", w, b, B, [(Himg, Wimg)], [0], self.img_nhwc, cpad, 2, 3, stem, [0], 64,
+                                 flags=SM_CONV_RELU, cin_pad=cpad))
+            pool = H.maxpool3x3s2_f32 if f32 else H.maxpool3x3s2
+            self._add("maxpool", (lambda s=stem, y=x: pool(s, y, B, h1, w1, 64)))
         # ---- residual stages (caffe style: stride on conv1, resnet.py:125-130)
         cur, ch, cw, cc = x, h2, w2, 64
         feats = []
@@ -1318,7 +1327,7 @@ class SipMaskEngine:
         return cls, bb, ctr, cof, fm
 
     def total_conv_flops(self):
-        return sum(c.flops for c in self.convs) + sum(c.flops for c in self.fused)
+        return sum(c.flops for c in self.convs) + sum(c.flops for c in self.fused) + getattr(self, "stem_flops", 0.0)
 
 
 class SubBatchPlan:

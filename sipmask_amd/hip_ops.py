@@ -420,6 +420,29 @@ def maxpool3x3s2(x, y, batch, h, w, c):
     return y
 
 
+def prep_stem_weight(w):
+    """[64, 3, 7, 7] f32 (BN folded) -> the operand of sm_stem_fused: bf16 [64][7][8][4] = (cout, kh, kw, cin), zeros in
+    the kw = 7 and cin = 3 slots (two kw-adjacent pixels x 4 channels = one 16-byte MFMA fragment)."""
+    co, ci, kh, kw = w.shape
+    if (co, ci, kh, kw) != (64, 3, 7, 7):
+        raise ValueError("sm_stem_fused is the 3 -> 64, 7x7 ResNet stem")
+    wp = torch.zeros(64, 7, 8, 4, dtype=torch.float32, device=w.device)
+    wp[:, :, :7, :3] = w.float().permute(0, 2, 3, 1)
+    return wp.to(torch.bfloat16).contiguous()
+
+
+def stem_fused(img, w_stem, bias, y):
+    """conv1 + folded bn1 + ReLU + maxpool of resnet.py:497-505 in one launch: img NCHW f32 -> y NHWC bf16 rows."""
+    lib = _lib.load()
+    _lib.require_cuda(img, w_stem, bias, y)
+    if img.dtype != torch.float32 or not img.is_contiguous() or img.shape[1] != 3:
+        raise ValueError("expected a contiguous float32 [B, 3, H, W] image")
+    b, _, h, w = img.shape
+    _lib.check(lib.sm_stem_fused(_lib.ptr(img), _lib.ptr(w_stem), _lib.ptr(bias), _lib.ptr(y), b, h, w,
+                                 _lib.stream_ptr()), "sm_stem_fused")
+    return y
+
+
 def nchw_to_nhwc_bf16(x, y, cpad):
     lib = _lib.load()
     _lib.require_cuda(x, y)

@@ -361,6 +361,33 @@ def test_maxpool_upsample_layout():
                                rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 224, 320), (3, 33, 57), (1, 7, 7)])
+def test_stem_fused_vs_torch(shape):
+    """sm_stem_fused: conv1 7x7/2 + folded bn1 + ReLU + maxpool 3x3/2 (resnet.py:497-505) in one launch, against torch
+    f32 on the same bf16-rounded operands.  Sizes that leave partial 8 x 14 pooled tiles on both axes, an image smaller
+    than one tile, several images (tile -> image decoding).  Bound: one bf16 ulp (the f32 sums differ in order only)."""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    B, Hi, Wi = shape
+    g = torch.Generator().manual_seed(Hi * 1000 + Wi)
+    img = torch.randn(B, 3, Hi, Wi, generator=g) * 1.5
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.08
+    b = torch.randn(64, generator=g) * 0.3
+    h1, w1 = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
+    h2, w2 = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
+    y = torch.full((B * h2 * w2, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    wp = H.prep_stem_weight(w.to(dev))
+    assert tuple(wp.shape) == (64, 7, 8, 4) and float(wp[:, :, 7].abs().max()) == 0 and float(wp[..., 3].abs().max()) == 0
+    H.stem_fused(img.to(dev), wp, b.to(dev), y)
+    ref = F.max_pool2d(_bf(F.relu(F.conv2d(_bf(img).double(), _bf(w).double(), b.double(), 2, 3)).float()), 3, 2, 1)
+    got = y.float().view(B, h2, w2, 64).permute(0, 3, 1, 2).cpu()
+    assert tuple(ref.shape) == tuple(got.shape)
+    assert bool(torch.isfinite(got).all())
+    diff = (got - ref).abs()
+    assert bool((diff <= 2.0 ** -7 * ref.abs() + 1e-30).all()), float(diff.max())
+    assert float((diff > 0).float().mean()) < 0.02          # rounding-boundary cases only
+
+
 # ------------------------------------------------------------------------------------- NMS
 def _kat(golden_dir):
     return json.load(open(os.path.join(golden_dir, "nms_kat.json")))

@@ -10,7 +10,7 @@ OUT=${1:-marginal_cost.txt}
 REP=${2:-2}
 declare -A PAT=(
   [none]=''
-  [stem]='^nhwc$|conv:stem|^maxpool$'
+  [stem]='^nhwc$|conv:stem|^maxpool$|^stem_fused$'
   [layer1]='conv:backbone\.layer1\.'
   [layer2]='conv:backbone\.layer2\.'
   [layer3]='conv:backbone\.layer3\.'
