@@ -368,6 +368,16 @@ int sm_groupnorm_apply_x3(const float* x, const float* gamma, const float* beta,
                           const int32_t* hw, const int64_t* row0, int channels, int groups, float eps, int relu,
                           float* y_f32, void* y_split, sm_stream_t stream);
 
+/* 3x3 / stride 1 / pad 1 convolution with 8..32 output channels (cout % 8 == 0) over cin % 32 == 0 input channels, bf16
+ * operands: SipMaskHead's sip_mask_lat (512 -> 32, sipmask_head.py:284) and fcos_reg + fcos_centerness (256 -> 4 + 1,
+ * :261-268).  Same descriptor and epilogue as sm_conv2d (bias, Scale() on the first scale_nch channels, SM_CONV_RELU /
+ * SM_CONV_RELU_NCH / SM_CONV_OUT_F32, acc_scale; no residual, no groups), own kernel: one wave per 2 x 32-position tile, the
+ * weights in MFMA-fragment order w_frag = bf16 [cin / 32][9 taps][2][64 lanes][8] (lane = 32 * khalf + cout row, rows >= cout
+ * zero; channel = 32 * slice + 16 * half + 8 * khalf + e) read straight from L2 (csrc/conv3x3_smallco.hip). */
+int sm_conv3x3_smallco_supported(const sm_conv_desc* d);
+int sm_conv3x3_smallco(const sm_conv_desc* d, const void* x, const void* w_frag, const float* bias, void* y,
+                       sm_stream_t stream);
+
 /* The ResNet stem as one launch (resnet.py:497-505: conv1 7x7 / stride 2 / pad 3 -> norm1 (frozen, folded into w / bias by the
  * caller) -> ReLU -> maxpool 3x3 / stride 2 / pad 1): img NCHW f32 [batch][3][h][w] -> y NHWC bf16 rows
  * [batch * h2 * w2][64] with h1 = (h - 1) / 2 + 1, h2 = (h1 - 1) / 2 + 1 (same for w).  w_stem: bf16 [64][7][8][4] =

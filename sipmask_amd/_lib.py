@@ -115,6 +115,8 @@ PROTOTYPES = {
     "sm_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P]),
     "sm_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sm_stem_fused": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "sm_conv3x3_smallco_supported": (_I, [_P]),
+    "sm_conv3x3_smallco": (_I, [_P, _P, _P, _P, _P, _P]),
     "sm_nchw_f32_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "sm_upsample_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sm_det_select_workspace": (C.c_int64, [C.POINTER(DetDesc)]),

@@ -49,6 +49,7 @@ _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"
 # FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes
 # the shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
 # shapes), "0" = three launches (A/B)
+_SMALLCO_CONV = os.environ.get("SIPMASK_SMALLCO_CONV", "1") != "0"    # A/B: the small-cout 3x3 kernel (conv3x3_smallco.hip)
 _STEM_FUSED = os.environ.get("SIPMASK_STEM_FUSED", "1") != "0"        # A/B: conv1 + bn1 + relu + maxpool as one launch (stem_fused.hip)
 _LAT0_LINEAR = os.environ.get("SIPMASK_LAT0_LINEAR", "1") != "0"      # A/B: sip_mask_lat0 by linearity (three convs + upsample_sum2)
 _DIAG_SKIP = __import__("re").compile(os.environ["SIPMASK_DIAG_SKIP"]) if os.environ.get("SIPMASK_DIAG_SKIP") else None
@@ -132,8 +133,21 @@ class _Conv:
         # large 3x3 / stride-1 convs run on the patch-resident kernel (csrc/conv3x3_patch.hip): own weight layout, cout
         # padded to 256.  `groups` launches of this shape share one grid (tower pairs): the tile rule sees all of them.
         self.patch = False
-        if (not self.f32 and offset is None and residual is None and _PATCH_CONV and k == 3 and stride == 1 and pad == 1
-                and ci % 64 == 0 and (cin == ci or self.x3)):
+        # 3x3 convs with a handful of output channels on the bf16 plan (sip_mask_lat 512 -> 32, fcos_reg + centerness 256 -> 8):
+        # their own kernel (round 4, csrc/conv3x3_smallco.hip: one wave per 2 x 32-position tile, weights straight from L2)
+        self.smallco = False
+        if (not self.f32 and not self.x3 and offset is None and residual is None and _SMALLCO_CONV and k == 3 and stride == 1
+                and pad == 1 and co <= 32 and co % 8 == 0 and ci % 32 == 0 and cin == ci
+                and getattr(self, "_patch_groups", 1) == 1):
+            ds = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, 32, k, stride, pad, in_cstride,
+                                  out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0, scale_nch, level_scale,
+                                  deform_groups, acc_scale=acc_scale)
+            if H.conv3x3_smallco_supported(ds):
+                self.smallco = True
+                self.w = H.prep_conv_weight_smallco(w.to(dev))
+                self.desc = ds
+        if (not self.smallco and not self.f32 and offset is None and residual is None and _PATCH_CONV and k == 3 and stride == 1
+                and pad == 1 and ci % 64 == 0 and (cin == ci or self.x3)):
             # cout tile of the patch kernel: 256, or 32 for the convs with a handful of output channels (round 4: sip_mask_lat
             # 512 -> 32 and fcos_reg + centerness 256 -> 8 spent 0.10 / 0.065 ms per B=4 launch on the implicit-GEMM kernel
             # re-reading their INPUT nine times; the grouped / per-level launches keep the 256 tile)
@@ -200,6 +214,8 @@ class _Conv:
     def __call__(self):
         if self.f32:
             H.conv2d_f32(self.desc, self.x, self.offset, self.w, self.bias, self.residual, self.y)
+        elif self.smallco:
+            H.conv3x3_smallco(self.desc, self.x, self.w, self.bias, self.y)
         elif self.patch:
             H.conv3x3_patch(self.desc, self.x, self.w, self.bias, self.y, self.gn_stats)
         elif self.gn_stats is not None:

@@ -213,6 +213,36 @@ def conv3x3_patch(desc, x, w_patch, bias, y, gn_stats=None):
     return y
 
 
+def conv3x3_smallco_supported(desc):
+    return bool(_lib.load().sm_conv3x3_smallco_supported(C.byref(desc)))
+
+
+def conv3x3_smallco_tiles(desc):
+    """blocks of the launch (host arithmetic of csrc/conv3x3_smallco.hip: one wave per 2 x 32-position tile)"""
+    return sum(desc.batch * -(-desc.in_h[l] // 2) * -(-desc.in_w[l] // 32) for l in range(desc.nlev))
+
+
+def prep_conv_weight_smallco(w):
+    """[co <= 32, ci % 32 == 0, 3, 3] -> the A fragments of sm_conv3x3_smallco: bf16 [ci / 32][9][2][64][8] with
+    lane = 32 * khalf + cout row (rows >= co zero) and channel = 32 * slice + 16 * half + 8 * khalf + e."""
+    co, ci, kh, kw = w.shape
+    if kh != 3 or kw != 3 or co > 32 or ci % 32 != 0:
+        raise ValueError("sm_conv3x3_smallco: 3x3, cout <= 32, cin % 32 == 0")
+    w32 = torch.zeros(32, ci, 9, dtype=torch.float32, device=w.device)
+    w32[:co] = w.float().reshape(co, ci, 9)
+    # ci = slice*32 + half*16 + khalf*8 + e  ->  [m, slice, half, khalf, e, tap] -> [slice, tap, half, khalf, m, e]
+    f = w32.view(32, ci // 32, 2, 2, 8, 9).permute(1, 5, 2, 3, 0, 4).contiguous()
+    return f.view(ci // 32, 9, 2, 64, 8).to(torch.bfloat16).contiguous()
+
+
+def conv3x3_smallco(desc, x, w_frag, bias, y):
+    _lib.require_cuda(x, w_frag, y)
+    lib = _lib.load()
+    _lib.check(lib.sm_conv3x3_smallco(C.byref(desc), _lib.ptr(x), _lib.ptr(w_frag), _lib.ptr(bias), _lib.ptr(y),
+                                      _lib.stream_ptr()), "sm_conv3x3_smallco")
+    return y
+
+
 class Levels:
     """Row bookkeeping of a pyramid tensor: levels [(h,w)], batch -> row0 per level."""
 

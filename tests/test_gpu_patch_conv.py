@@ -199,6 +199,64 @@ def test_patch_conv_small_cout_tile_vs_torch(cfg):
     assert not H.conv3x3_patch_supported(d)
 
 
+@pytest.mark.parametrize("cfg", [
+    (2, 512, 32, [(25, 42)], 512, 32, 0),                                      # sip_mask_lat
+    (2, 256, 8, [(25, 42), (13, 21), (7, 11), (4, 6), (2, 3)], 256, 8, 0),     # fcos_reg + centerness over the pyramid
+    (1, 64, 24, [(19, 37), (9, 250), (1, 1)], 96, 40, 8),                      # input / output channel slices, 1-pixel level
+    (3, 32, 16, [(5, 33)], 32, 16, 0),                                         # a single channel slice, 33 columns (2 tiles)
+    (1, 96, 32, [(3, 64)], 96, 32, 0),                                         # odd slice count (3), odd row count
+])
+def test_conv3x3_smallco_vs_torch(cfg):
+    """round 4: sm_conv3x3_smallco -- the 3x3 convs with 8..32 output channels (sip_mask_lat, fcos_reg + centerness) on their
+    own kernel (one wave per 2 x 32-position tile, three channel slices in flight, weights as MFMA fragments from L2): the
+    contract of sm_conv2d's epilogue (bias, per-level Scale on the first channels, ReLU / ReLU on those channels only, f32 or
+    bf16 rows, channel slices of wider row tensors) against torch f32 on the same bf16 operands."""
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    B, Ci, Co, sizes, in_cs, out_cs, out_coff = cfg
+    g = torch.Generator().manual_seed(Ci + Co + len(sizes))
+    lv = H.Levels(B, sizes)
+    xs = [_bf(torch.randn(B, Ci, h, w, generator=g)) for h, w in sizes]
+    w = _bf(torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5)
+    bias = torch.randn(Co, generator=g)
+    x = torch.full((lv.rows, in_cs), float("nan"), dtype=torch.bfloat16)       # channels beyond cin must never be read
+    x[:, :Ci] = _rows(xs).to(torch.bfloat16)
+    x = x.to(dev)
+    wq = H.prep_conv_weight_smallco(w.to(dev))
+    assert tuple(wq.shape) == (Ci // 32, 9, 2, 64, 8)
+    scales = [1.0 + 0.25 * l for l in range(len(sizes))]
+    for out_f32, relu in ((True, 0), (False, _lib.SM_CONV_RELU), (True, _lib.SM_CONV_RELU_NCH)):
+        flags = (_lib.SM_CONV_OUT_F32 if out_f32 else 0) | relu
+        d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, Ci, Co, 32, 3, 1, 1, in_cs, out_cs, out_coff, flags=flags,
+                             scale_nch=4, level_scale=scales)
+        assert H.conv3x3_smallco_supported(d)
+        assert H.conv3x3_smallco_tiles(d) == sum(B * -(-h // 2) * -(-wd // 32) for h, wd in sizes)
+        y = torch.full((lv.rows, out_cs), -7.0, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
+        H.conv3x3_smallco(d, x, wq, bias.to(dev), y)
+        torch.cuda.synchronize()
+        for l, (h, wd) in enumerate(sizes):
+            ref = F.conv2d(xs[l], w, bias, 1, 1)
+            ref[:, :4] *= scales[l]
+            if relu == _lib.SM_CONV_RELU:
+                ref = F.relu(ref)
+            elif relu:
+                ref[:, :4] = F.relu(ref[:, :4])
+            blk = y[lv.row0[l]:lv.row0[l] + B * h * wd].float().cpu()
+            got = blk[:, out_coff:out_coff + Co].view(B, h, wd, Co).permute(0, 3, 1, 2)
+            if out_f32:
+                torch.testing.assert_close(got, ref, rtol=1e-4, atol=2e-4)
+            else:
+                torch.testing.assert_close(got, ref, rtol=2 ** -7, atol=2e-3)
+            rest = torch.cat([blk[:, :out_coff], blk[:, out_coff + Co:]], 1)     # neighbouring channel slices untouched
+            assert rest.numel() == 0 or bool((rest == -7.0).all())
+    # what the kernel does not do is refused, not approximated
+    for kw in (dict(flags=_lib.SM_CONV_RES_ADD), dict(ngroups=2, y_group_rows=lv.rows, w_group_stride=wq.numel())):
+        d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, Ci, Co, 32, 3, 1, 1, in_cs, out_cs, out_coff, **kw)
+        assert not H.conv3x3_smallco_supported(d)
+    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, Ci, 64, 64, 3, 1, 1, in_cs, 64)
+    assert not H.conv3x3_smallco_supported(d)
+
+
 @pytest.mark.parametrize("cfg", [(2, 256, 256, (50, 84)), (1, 512, 512, (25, 42)), (2, 64, 128, (19, 37))])
 def test_patch_conv_cout128_tile_vs_torch(cfg):
     """round 4: sm_conv_desc.patch_cout_tile = 128 -- 128-cout x 256-position tiles for the 3x3 convs of ResNet layer3 / layer4

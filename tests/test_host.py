@@ -254,7 +254,7 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     assert nstem == (0 if os.environ.get("SIPMASK_STEM_FUSED", "1") == "0" else 1)
     assert not (nstem and any(lbl in ("nhwc", "maxpool", "conv:stem") for lbl, _ in eng.steps))
     assert len(rows) == len(eng.convs) and len(rows) == nconv - ngrouped - nfused + nlin - nstem
-    assert all(r["blocks"] > 0 and r["waves"] > 0 and r["kind"] in ("igemm", "patch", "window") for r in rows.values())
+    assert all(r["blocks"] > 0 and r["waves"] > 0 and r["kind"] in ("igemm", "patch", "window", "smallco") for r in rows.values())
     assert len(eng.steps) == len(eng.lanes)
     joined = set()
     for lane in eng.lanes:                                           # every side lane that is used gets joined
@@ -266,7 +266,10 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
         d = c.desc
         K = d.kh * d.kw * d.cin
         G = max(int(d.ngroups), 1)
-        assert tuple(c.w.shape)[-2:] == (d.cout_pad, (K + 63) // 64 * 64) and c.w.numel() == G * d.cout_pad * ((K + 63) // 64 * 64), c.name
+        if getattr(c, "smallco", False):                              # MFMA-fragment order: [cin / 32][9][2][64 lanes][8]
+            assert tuple(c.w.shape) == (d.cin // 32, 9, 2, 64, 8) and d.cout_pad == 32 and d.cout <= 32, c.name
+        else:
+            assert tuple(c.w.shape)[-2:] == (d.cout_pad, (K + 63) // 64 * 64) and c.w.numel() == G * d.cout_pad * ((K + 63) // 64 * 64), c.name
         if G > 1:
             assert d.w_group_stride == d.cout_pad * ((K + 63) // 64 * 64) and c.gn_stats.numel() == G * d.gn_group_stride, c.name
         assert c.x.dim() == 2 and c.y.dim() == 2 and d.in_cstride <= c.x.shape[1] and d.cin <= d.in_cstride, c.name
@@ -422,7 +425,7 @@ def test_fcos_sipmask_head_alias_builds_from_cfg():
 def test_launch_plan_decisions_at_the_baseline_shape():
     """Round 4's launch-plan rules, pinned on the CPU at BASELINE configs[1] (R50, batch 4, 800 x 1344, a PipelinedPlan slot):
     the FPN's three output convs are ONE patch launch with per-level weights; layer3 / layer4 conv2 take the 128-cout patch
-    tile; sip_mask_lat and fcos_reg + centerness the 32-cout tile; sip_mask_lat0 runs by linearity; lat2 / P6 / P7 keep the
+    tile; sip_mask_lat and fcos_reg + centerness their own small-cout kernel; the stem is one launch; sip_mask_lat0 runs by linearity; lat2 / P6 / P7 keep the
     latency-shaped plan (no big-tile flag); the conv FLOPs of a step are the reference's 1 803.7 GFLOP minus what the
     linearity saves."""
     import importlib.util
@@ -442,8 +445,10 @@ def test_launch_plan_decisions_at_the_baseline_shape():
     for n in ("backbone.layer3.2.conv2", "backbone.layer4.1.conv2"):
         assert convs[n].patch and convs[n].desc.patch_cout_tile == 128, n
     assert convs["head.tower0"].patch and convs["head.tower0"].desc.patch_cout_tile == 0 and convs["head.tower0"].desc.cout_pad == 256
-    for n, co in (("head.sip_mask_lat", 32), ("head.reg_ctr", 8)):
-        assert convs[n].patch and convs[n].desc.cout_pad == 32 and convs[n].desc.cout == co, n
+    for n, co in (("head.sip_mask_lat", 32), ("head.reg_ctr", 8)):     # the small-cout kernel (one wave per 2 x 32 tile)
+        assert convs[n].smallco and not convs[n].patch and convs[n].desc.cout_pad == 32 and convs[n].desc.cout == co, n
+    assert not any(c.smallco for n, c in convs.items() if n not in ("head.sip_mask_lat", "head.reg_ctr"))
+    assert any(lbl == "stem_fused" for lbl, _ in eng.steps) and "stem" not in convs
     assert eng.lat0_by_linearity and convs["head.sip_mask_lat0"].desc.cin == 256 and convs["head.sip_mask_lat0"].residual is not None
     big = _lib.SM_CONV_DBG_BIG_TILES
     assert convs["backbone.layer3.2.conv1"].desc.flags & big                 # a slot builds for CU time ...

@@ -65,6 +65,11 @@ def conv_rows(eng):
                              note="exact-f32 MFMA%s" % (" (deformable)" if c.offset is not None else ""),
                              gflop=c.flops / 1e9, mb=c.bytes / 1e6))
             continue
+        if getattr(c, "smallco", False):                 # conv3x3_smallco.hip: one wave per 2 x 32-position tile
+            blocks = H.conv3x3_smallco_tiles(c.desc)
+            rows.append(dict(name=c.name, kind="smallco", shape="32x(2x32)", blocks=blocks, waves=blocks / (256 * 5.0),
+                             note="one-wave tiles, weights as MFMA fragments from L2", gflop=c.flops / 1e9, mb=c.bytes / 1e6))
+            continue
         if getattr(c, "patch", False):                   # conv3x3_patch.hip: one block per CU, its own launch planner
             pp = H.conv3x3_patch_plan(c.desc)
             blocks = pp["big"] + pp["small"]
