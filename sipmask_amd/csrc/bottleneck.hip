@@ -12,6 +12,13 @@
 // path (same K order, same rounding points).  The same holds between conv3's output and the next conv1.
 // Every wave owns 32 positions for the whole chain; the 1x1 weights stream through LDS in 16 KB slices (LDS-DMA,
 // ping-pong between a dedicated buffer and the finished K loop's stages), 128-byte rows with the conv_igemm swizzle.
+//
+// CDS > 0 (round 4): the FIRST block of layer1, whose shortcut is a 1x1 conv of the block input (resnet.py:453-469
+// make_res_layer's downsample, stride 1 in layer1): that conv is one more stretch of K for conv3 -- the weight rows are
+// [w3 | w_downsample] (K3 = C2 + CDS), the B fragments of the extra K steps are the block input's rows of this wave's 32
+// positions, read straight from HBM into the fragment layout -- so the 4C-channel shortcut tensor is neither written
+// (138 MB at four 800 x 1344 images) nor read back, and its launch disappears.  The shortcut stays f32 until the one
+// rounding of the block output (the two-launch path rounds it to bf16 in between).
 #include <cstdlib>
 
 #include "common.h"
@@ -24,7 +31,8 @@ struct BtArgs {
   const float* b2;
   const uint16_t* w3;    // [4C][C]
   const float* b3;
-  const uint16_t* res;   // identity     [M][4C]
+  const uint16_t* res;   // identity     [M][4C]   (CDS == 0)
+  const uint16_t* xds;   // CDS > 0: the block input [M][CDS] the shortcut conv reads; w3 = [4C][C + CDS], b3 = b3 + b_downsample
   uint16_t* y;           // block output [M][4C]
   const uint16_t* w1n;   // next conv1   [C][4C] or null
   const float* b1n;
@@ -40,8 +48,11 @@ constexpr int BT_SLICE_BYTES = 16384;
 // OCC: blocks per CU the register allocation aims for.  The unchained <64> kernel needs 135 VGPRs at OCC 3; capped at 128
 // (OCC 4: four spills outside the loops) a fourth block fits, and these launches are bandwidth-shaped (layer1: 310 MB per
 // 4-image launch): more loads in flight per CU.  A/B: SIPMASK_BT_OCC (3 | 4).
-template <int C2, bool CHAIN1, int OCC>
+template <int C2, bool CHAIN1, int OCC, int CDS = 0>
 __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs a) {
+  static_assert(!(CHAIN1 && CDS > 0) && CDS % 64 == 0, "the chained conv1 is not combined with the fused shortcut conv");
+  constexpr int K3 = C2 + CDS;                  // conv3's K: the conv2 tile (+ the shortcut conv's input channels)
+  constexpr int KKD = CDS / 16;
   constexpr int TCO = C2 / 32;                  // MFMA tiles along the conv2 couts (all of them in one wave)
   constexpr int NW = C2 / 64;                   // weight DMA instructions per thread per K step
   constexpr int NX = BT_BPOS / 64;
@@ -50,14 +61,11 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
   constexpr int CPT = C2 / 8;                   // 16-byte chunks per tap
   constexpr int NK = 9 * C2 / 32;
   constexpr int C4 = 4 * C2;
-  constexpr int SL = BT_SLICE_BYTES / (C2 * 2); // conv3 couts per slice (128 | 64)
+  constexpr int SL = BT_SLICE_BYTES / (K3 * 2); // conv3 couts per slice (128 | 64)
   constexpr int NPASS = C4 / SL;
-  constexpr int NSUB = C2 / 64;                 // 128-byte-row sub-tiles (64 k each) of a conv3 weight slice
   constexpr int CT = SL / 32;                   // MFMA tiles along the slice's couts
   constexpr int KK3 = C2 / 16;                  // K steps of 16 in conv3
   // chained conv1 of the next block: per pass a K slice of SL input channels, weights [C2 rows][SL k]
-  constexpr int NSUB1 = SL / 64;
-  constexpr int W1_BYTES = CHAIN1 ? BT_SLICE_BYTES : 0;
   static_assert(2 * STAGE >= BT_SLICE_BYTES, "the finished stages hold one weight slice");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // bt_lds_bytes(C2, CHAIN1)
   typedef __attribute__((address_space(3))) void lds_void;
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
       const int fr = (r * 4 + wave) * 8 + (lane >> 3);
       const int sub = fr / SL, row = fr - sub * SL;
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      const uint16_t* src = a.w3 + (long long)(p * SL + row) * C2 + sub * 64 + chunk * 8;
+      const uint16_t* src = a.w3 + (long long)(p * SL + row) * K3 + sub * 64 + chunk * 8;
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(buf + (r * 4 + wave) * 1024), 16, 0, 0);
     }
   };
@@ -183,6 +191,15 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
   }
   compute((NK - 1) & 1);
 
+  // ---- CDS: the B fragments of the shortcut conv -- lane (position, khalf) holds channels 16*kk + 8*khalf .. + 8 of its row
+  bf16x8 dfr[KKD > 0 ? KKD : 1];
+  if constexpr (CDS > 0) {
+    const int md = m0 + wave * 32 + l31;
+    const uint16_t* xr = a.xds + (long long)(md < M ? md : 0) * CDS + 8 * khalf;
+#pragma unroll
+    for (int kk = 0; kk < KKD; ++kk) dfr[kk] = *reinterpret_cast<const bf16x8*>(xr + 16 * kk);
+  }
+
   // ---- conv2 epilogue in registers: bias, ReLU, bf16 -> the B fragments of conv3 (K step kk = 2*tc + qp)
   bf16x8 tfr[KK3];
 #pragma unroll
@@ -229,24 +246,27 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
       if constexpr (CHAIN1) dma_w1_slice(p + 1, w1buf + ((p + 1) & 1) * BT_SLICE_BYTES);
     }
     u32x4 rv[CT][2];
+    if constexpr (CDS == 0) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int qp = 0; qp < 2; ++qp)
-        rv[ct][qp] = *reinterpret_cast<const u32x4*>(a.res + orow + p * SL + ct * 32 + 16 * qp + 8 * khalf);
+        for (int qp = 0; qp < 2; ++qp)
+          rv[ct][qp] = *reinterpret_cast<const u32x4*>(a.res + orow + p * SL + ct * 32 + 16 * qp + 8 * khalf);
+    }
     f32x16 acc3[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc3[ct][e] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < KK3; ++kk) {
+    for (int kk = 0; kk < KK3 + KKD; ++kk) {     // K = [conv2 tile | shortcut input]
       const int sub = kk >> 2;
       const int slot = ((((kk & 3) * 2 + khalf) ^ asw)) * 16;
+      const bf16x8 bfr = kk < KK3 ? tfr[kk < KK3 ? kk : 0] : dfr[kk >= KK3 ? kk - KK3 : 0];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(buf + (sub * SL + ct * 32 + l31) * 128 + slot);
-        acc3[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, tfr[kk], acc3[ct], 0, 0, 0);
+        acc3[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, bfr, acc3[ct], 0, 0, 0);
       }
     }
     bf16x8 yfr[CT * 2];                          // this pass's outputs as B fragments of the chained conv1
@@ -268,10 +288,15 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
         const float4 b1 = *reinterpret_cast<const float4*>(a.b3 + c0 + 4);
         v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w;
         v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
-        float f[8];
-        unpack_bf16x8(rv[ct][qp], f);
+        if constexpr (CDS == 0) {
+          float f[8];
+          unpack_bf16x8(rv[ct][qp], f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + f[e], 0.f);
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + f[e], 0.f);
+        } else {                                   // the shortcut is already in the accumulator (bias folded into b3)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
         const u32x4 packed = pack_bf16x8_v(v);
         if (mok) *reinterpret_cast<u32x4*>(a.y + orow + c0) = packed;
         yfr[ct * 2 + qp] = __builtin_bit_cast(bf16x8, packed);
@@ -318,17 +343,17 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
 
 constexpr int bt_lds_bytes(int c2, bool chain) { return 2 * (c2 + BT_BPOS) * 64 + BT_SLICE_BYTES + (chain ? 2 * BT_SLICE_BYTES : 0); }
 
-template <int C2, bool CHAIN1, int OCC>
+template <int C2, bool CHAIN1, int OCC, int CDS = 0>
 int bt_launch(const BtArgs& a, dim3 grid, hipStream_t s) {
   constexpr int lds = bt_lds_bytes(C2, CHAIN1);
   static bool attr_set = false;                 // > 64 KB of dynamic LDS needs the opt-in once per kernel
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail_kernel<C2, CHAIN1, OCC>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return SM_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bottleneck_tail_kernel<C2, CHAIN1, OCC>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS>), grid, dim3(256), lds, s, a);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -353,6 +378,7 @@ extern "C" int sm_bottleneck_tail(int batch, int h, int w, int channels, const v
   a.w3 = (const uint16_t*)w3;
   a.b3 = b3;
   a.res = (const uint16_t*)identity;
+  a.xds = nullptr;
   a.y = (uint16_t*)y;
   a.w1n = (const uint16_t*)w1_next;
   a.b1n = b1_next;
@@ -373,4 +399,31 @@ extern "C" int sm_bottleneck_tail(int batch, int h, int w, int channels, const v
   }
   if (chain) return bt_launch<128, true, 3>(a, grid, s);
   return occ == 4 ? bt_launch<128, false, 4>(a, grid, s) : bt_launch<128, false, 3>(a, grid, s);
+}
+
+/* conv2 + conv3 + the block's 1x1 SHORTCUT conv (stride 1) as one launch: layer1's first bottleneck. */
+extern "C" int sm_bottleneck_tail_ds(int batch, int h, int w, int channels, const void* x, const void* w2, const float* b2,
+                                     const void* w3_ds, const float* b3_ds, const void* x_block, int ds_channels, void* y,
+                                     sm_stream_t stream) {
+  if (!x || !w2 || !b2 || !w3_ds || !b3_ds || !x_block || !y || batch < 1 || h < 1 || w < 1) return SM_ERR_BAD_ARG;
+  if (channels != 64 || ds_channels != 64) return SM_ERR_UNSUPPORTED;
+  const long long M = (long long)batch * h * w;
+  if (M * 4 * channels >= (1ll << 31) * 8) return SM_ERR_BAD_SHAPE;
+  BtArgs a;
+  a.x = (const uint16_t*)x;
+  a.w2 = (const uint16_t*)w2;
+  a.b2 = b2;
+  a.w3 = (const uint16_t*)w3_ds;
+  a.b3 = b3_ds;
+  a.res = nullptr;
+  a.xds = (const uint16_t*)x_block;
+  a.y = (uint16_t*)y;
+  a.w1n = nullptr;
+  a.b1n = nullptr;
+  a.t1n = nullptr;
+  a.batch = batch;
+  a.H = h;
+  a.W = w;
+  a.M = (int)M;
+  return bt_launch<64, false, 4, 64>(a, dim3(sm_cdiv(M, BT_BPOS)), sm_hip_stream(stream));   // 95 VGPRs, 40 KB of LDS: four blocks per CU
 }

@@ -49,6 +49,7 @@ _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"
 # FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes
 # the shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
 # shapes), "0" = three launches (A/B)
+_FUSE_SHORTCUT = os.environ.get("SIPMASK_FUSE_SHORTCUT", "1") != "0"  # A/B: layer1.0's shortcut conv inside the fused tail
 _SMALLCO_CONV = os.environ.get("SIPMASK_SMALLCO_CONV", "1") != "0"    # A/B: the small-cout 3x3 kernel (conv3x3_smallco.hip)
 _STEM_FUSED = os.environ.get("SIPMASK_STEM_FUSED", "1") != "0"        # A/B: conv1 + bn1 + relu + maxpool as one launch (stem_fused.hip)
 _LAT0_LINEAR = os.environ.get("SIPMASK_LAT0_LINEAR", "1") != "0"      # A/B: sip_mask_lat0 by linearity (three convs + upsample_sum2)
@@ -233,7 +234,7 @@ class _BottleneckTail:
     resnet.py:167-200): the C-channel tensor between conv2 and conv3, and the read of the block output by the next
     conv1, never touch HBM.  Same arithmetic as the separate launches (bit-identical outputs)."""
 
-    def __init__(self, name, batch, hw, planes, x, w2, b2, w3, b3, identity, y, next1=None):
+    def __init__(self, name, batch, hw, planes, x, w2, b2, w3, b3, identity, y, next1=None, shortcut=None):
         dev = x.device
         self.name, self.batch, self.hw, self.planes = name, batch, hw, planes
         prep = lambda w: H.prep_conv_weight(w.to(dev), w.shape[1])[0][:w.shape[0]].contiguous()
@@ -245,6 +246,16 @@ class _BottleneckTail:
         self.flops = 2.0 * rows * planes * planes * 9 + 2.0 * rows * planes * 4 * planes
         # algorithmic bytes of the fused launch: x in, identity in, y out (+ next t1 out) + weights
         self.bytes = rows * planes * 2 + 2 * rows * 4 * planes * 2 + (self.w2.numel() + self.w3.numel()) * 2
+        # shortcut = (w_downsample, b_downsample, block input rows): the block's 1x1 shortcut conv rides conv3's K loop
+        # (layer1's first block: resnet.py:453-469; csrc/bottleneck.hip CDS) -- `identity` is not used
+        self.x_block = None
+        if shortcut is not None:
+            wd, bd, self.x_block = shortcut
+            self.w3 = torch.cat([self.w3, prep(wd)], 1).contiguous()
+            self.b3 = (self.b3 + fb(bd)).contiguous()
+            cds = self.x_block.shape[1]
+            self.flops += 2.0 * rows * cds * 4 * planes
+            self.bytes = rows * planes * 2 + rows * cds * 2 + rows * 4 * planes * 2 + (self.w2.numel() + self.w3.numel()) * 2
         if next1 is not None:
             w1, b1, t1n = next1
             self.w1n, self.b1n, self.t1n = prep(w1), fb(b1), t1n
@@ -252,6 +263,10 @@ class _BottleneckTail:
             self.bytes += rows * planes * 2 + self.w1n.numel() * 2
 
     def __call__(self):
+        if self.x_block is not None:
+            H.bottleneck_tail_ds(self.batch, self.hw[0], self.hw[1], self.planes, self.x, self.w2, self.b2, self.w3, self.b3,
+                                 self.x_block, self.y)
+            return
         H.bottleneck_tail(self.batch, self.hw[0], self.hw[1], self.planes, self.x, self.w2, self.b2, self.w3, self.b3,
                           self.identity, self.y, self.w1n, self.b1n, self.t1n)
 
@@ -571,7 +586,15 @@ class SipMaskEngine:
                 p = "backbone.layer%d.%d" % (li + 1, bi)
                 s = 2 if (bi == 0 and li > 0) else 1
                 oh, ow = _conv_out(ch, 1, s, 0), _conv_out(cw, 1, s, 0)
-                if bi == 0:       # the shortcut conv reads the block input only: it forks onto a side lane BEFORE
+                has_dcn = (p + ".conv2.conv_offset.weight") in sd
+                fuse = _FUSE_BOTTLENECK if (not f32 and planes in (64, 128) and not has_dcn) else 0
+                # layer1's first block: the 1x1 shortcut conv (64 -> 256, stride 1) rides the fused tail's conv3 (round 4)
+                fuse_ds = bool(fuse) and _FUSE_SHORTCUT and bi == 0 and s == 1 and planes == 64 and cc == 64
+                shortcut = None
+                if bi == 0 and fuse_ds:
+                    wd, bd = fold_bn(sd[p + ".downsample.0.weight"], sd, p + ".downsample.1")
+                    shortcut, idt = (wd, bd, cur), None
+                elif bi == 0:     # the shortcut conv reads the block input only: it forks onto a side lane BEFORE
                     # conv1/conv2 are queued and is joined right before conv3 adds it
                     wd, bd = fold_bn(sd[p + ".downsample.0.weight"], sd, p + ".downsample.1")
                     idt = self._buf(B * oh * ow, planes * 4)
@@ -579,8 +602,6 @@ class SipMaskEngine:
                                          planes * 4), lane=1)
                 else:
                     idt = cur
-                has_dcn = (p + ".conv2.conv_offset.weight") in sd
-                fuse = _FUSE_BOTTLENECK if (not f32 and planes in (64, 128) and not has_dcn) else 0
                 wa, ba = fold_bn(sd[p + ".conv1.weight"], sd, p + ".bn1")
                 if chained_t1 is not None:       # the previous block's fused launch already produced this conv1
                     t1, chained_t1 = chained_t1, None
@@ -592,15 +613,17 @@ class SipMaskEngine:
                 wc, bc = fold_bn(sd[p + ".conv3.weight"], sd, p + ".bn3")
                 out = self._buf(B * oh * ow, planes * 4)
                 if fuse:
-                    if bi == 0:
+                    if bi == 0 and shortcut is None:
                         self._join(1)
                     next1 = None
                     pn = "backbone.layer%d.%d" % (li + 1, bi + 1)
-                    if fuse >= 2 and bi + 1 < nblocks and (pn + ".conv2.conv_offset.weight") not in sd:
+                    if (fuse >= 2 and shortcut is None and bi + 1 < nblocks
+                            and (pn + ".conv2.conv_offset.weight") not in sd):
                         wn, bn = fold_bn(sd[pn + ".conv1.weight"], sd, pn + ".bn1")
                         chained_t1 = self._buf(B * oh * ow, planes)
                         next1 = (wn, bn, chained_t1)
-                    tail = _BottleneckTail(p + ".tail", B, (oh, ow), planes, t1, wb, bb, wc, bc, idt, out, next1)
+                    tail = _BottleneckTail(p + ".tail", B, (oh, ow), planes, t1, wb, bb, wc, bc, idt, out, next1,
+                                           shortcut=shortcut)
                     self.fused.append(tail)
                     self._add("conv:" + tail.name, tail)
                     cur, ch, cw, cc = out, oh, ow, planes * 4

@@ -405,6 +405,20 @@ def bottleneck_tail(batch, h, w, channels, x, w2, b2, w3, b3, identity, y, w1_ne
     return y
 
 
+def bottleneck_tail_ds(batch, h, w, channels, x, w2, b2, w3_ds, b3_ds, x_block, y):
+    """conv2 + conv3 + the block's 1x1 shortcut conv (resnet.py:453-469, stride 1) as one launch: w3_ds = [w3 | w_downsample]
+    ([4C][C + Cds] bf16), b3_ds = b3 + b_downsample; x_block = the block input rows the shortcut conv reads."""
+    lib = _lib.load()
+    _lib.require_cuda(x, w2, b2, w3_ds, b3_ds, x_block, y)
+    C4, cds = 4 * channels, x_block.shape[1]
+    assert tuple(w2.shape) == (channels, 9 * channels) and tuple(w3_ds.shape) == (C4, channels + cds), (w2.shape, w3_ds.shape)
+    assert x.shape[1] == channels and y.shape[1] == C4 and min(x.shape[0], x_block.shape[0], y.shape[0]) >= batch * h * w
+    _lib.check(lib.sm_bottleneck_tail_ds(batch, h, w, channels, _lib.ptr(x), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(w3_ds),
+                                         _lib.ptr(b3_ds), _lib.ptr(x_block), cds, _lib.ptr(y), _lib.stream_ptr()),
+               "sm_bottleneck_tail_ds")
+    return y
+
+
 def relu_bf16(x, y):
     """y = relu(x), bf16, same shape (fpn.py:166-170: the ReLU in front of the P7 conv)"""
     lib = _lib.load()

@@ -283,6 +283,9 @@ def test_fused_bottleneck_plan_is_bit_identical(monkeypatch):
     sd["bbox_head.fcos_cls.bias"].fill_(-2.5)
     img = torch.randn(2, 3, 160, 224, generator=torch.Generator().manual_seed(9)).cuda()
     outs = {}
+    # (layer1.0's fused SHORTCUT conv -- round 4 -- keeps the shortcut in f32 where the separate launch rounds it to bf16:
+    # not bit-identical by design, switched off here and covered by the next test)
+    monkeypatch.setattr(E, "_FUSE_SHORTCUT", False)
     for mode in (0, 1, 2):
         monkeypatch.setattr(E, "_FUSE_BOTTLENECK", mode)
         eng = E.SipMaskEngine(sd, 2, (160, 224), 50)
@@ -299,6 +302,29 @@ def test_fused_bottleneck_plan_is_bit_identical(monkeypatch):
         for a, b in zip(outs[0][1] + outs[0][2], outs[mode][1] + outs[mode][2]):
             assert torch.equal(a, b), mode
     assert int(outs[0][2][0].sum()) > 0
+
+
+def test_fused_shortcut_conv_plan_matches_separate_launch(monkeypatch):
+    """round 4: layer1's first block with its 1x1 shortcut conv inside the fused tail (csrc/bottleneck.hip CDS; the 256-channel
+    shortcut tensor is never written) against the plan that runs the shortcut as its own launch: C2..C5 features within the
+    one bf16 rounding the separate launch adds (the fused path keeps the shortcut in f32 until the block output)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import sipmask_amd.engine as E
+    sd = OM.init_state_dict(50, 0)
+    img = torch.randn(2, 3, 160, 224, generator=torch.Generator().manual_seed(9)).cuda()
+    feats = {}
+    for on in (False, True):
+        monkeypatch.setattr(E, "_FUSE_SHORTCUT", on)
+        eng = E.SipMaskEngine(sd, 2, (160, 224), 50)
+        assert sum(t.x_block is not None for t in eng.fused) == (1 if on else 0)
+        assert any(c.name == "backbone.layer1.0.downsample" for c in eng.convs) == (not on)
+        eng.run(img)
+        torch.cuda.synchronize()
+        feats[on] = [f[0].float().clone() for f in eng.backbone_feats]
+    for a, b in zip(feats[False], feats[True]):
+        rel = float((a - b).norm() / a.norm())
+        assert rel < 6e-3, rel                       # bf16 ulp = 2^-8 relative per element, a fraction of them differ
 
 
 @pytest.mark.parametrize("rescale", [False, True])

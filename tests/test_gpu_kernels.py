@@ -1042,6 +1042,49 @@ def test_bottleneck_tail_bit_identical_to_separate_convs(C, chain):
     torch.testing.assert_close(y[:M].float().cpu(), r3.permute(0, 2, 3, 1).reshape(M, 4 * C), rtol=1e-2, atol=2e-2)
 
 
+def test_bottleneck_tail_with_fused_shortcut_conv():
+    """sm_bottleneck_tail_ds (round 4): conv2 3x3 + conv3 1x1 + the block's 1x1 SHORTCUT conv (resnet.py:453-469; layer1's
+    first block) in one launch -- the shortcut's K rides conv3's accumulator, [w3 | w_downsample] rows.  Against torch fp32 on
+    the same bf16 rounding points (conv2 output rounded; shortcut NOT rounded: it stays f32 until the block output's
+    rounding), and against the two-launch path (separate shortcut conv, rounded to bf16, + sm_bottleneck_tail): equal up to
+    that one extra rounding.  M = 2*13*19 rows (not a multiple of the 128-position tile), borders everywhere."""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    B, h, w, C = 2, 13, 19, 64
+    M = B * h * w
+    g = torch.Generator().manual_seed(11)
+    bf = lambda t: t.to(torch.bfloat16)
+    x = bf(torch.randn(M, C, generator=g)).to(dev)                    # conv1 output (the tail's input)
+    xb = bf(torch.relu(torch.randn(M, 64, generator=g))).to(dev)      # block input (max-pool output: non-negative)
+    w2 = bf(torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)).float()
+    w3 = bf(torch.randn(4 * C, C, 1, 1, generator=g) / C ** 0.5).float()
+    wd = bf(torch.randn(4 * C, 64, 1, 1, generator=g) / 8.0).float()
+    b2, b3, bd = (torch.randn(n, generator=g).to(dev) * 0.1 for n in (C, 4 * C, 4 * C))
+    prep = lambda wt: H.prep_conv_weight(wt.to(dev), wt.shape[1])[0][:wt.shape[0]].contiguous()
+    w3ds = torch.cat([prep(w3), prep(wd)], 1).contiguous()
+    assert tuple(w3ds.shape) == (4 * C, 128)
+    y = torch.zeros(M + 7, 4 * C, dtype=torch.bfloat16, device=dev)
+    H.bottleneck_tail_ds(B, h, w, C, x, prep(w2), b2, w3ds, (b3 + bd).contiguous(), xb, y)
+    torch.cuda.synchronize()
+    assert not bool(y[M:].any())                                       # nothing written past M
+    nchw = lambda t, c: t.float().cpu().view(B, h, w, c).permute(0, 3, 1, 2)
+    r2 = bf(torch.relu(F.conv2d(nchw(x, C), w2, b2.cpu(), 1, 1))).float()
+    sc = F.conv2d(nchw(xb, 64), wd, bd.cpu())
+    r3 = torch.relu(F.conv2d(r2, w3, b3.cpu()) + sc)
+    ref = bf(r3).float().permute(0, 2, 3, 1).reshape(M, 4 * C)
+    got = y[:M].float().cpu()
+    diff = (got - ref).abs()
+    assert bool((diff <= 2.0 ** -7 * ref.abs() + 1e-6).all()), float(diff.max())     # one bf16 ulp (f32 summation order)
+    assert float((diff > 0).float().mean()) < 0.02
+    # two-launch path: shortcut conv as its own launch (rounded to bf16), then the tail with it as identity
+    dsc = H.make_conv_desc(B, [(h, w)], [(h, w)], [0], [0], 64, 4 * C, 4 * C, 1, 1, 0, 64, 4 * C)
+    idt = torch.zeros(M, 4 * C, dtype=torch.bfloat16, device=dev)
+    H.conv2d(dsc, xb, H.prep_conv_weight(wd.to(dev), 64)[0], bd, None, idt)
+    y2 = torch.zeros(M, 4 * C, dtype=torch.bfloat16, device=dev)
+    H.bottleneck_tail(B, h, w, C, x, prep(w2), b2, prep(w3), b3, idt, y2)
+    torch.testing.assert_close(got, y2.float().cpu(), rtol=2 ** -6, atol=2e-2)
+
+
 def test_upsample_sum2_vs_torch_and_lat0_by_linearity():
     """sm_upsample_sum2 (round 4): out = [relu](a0 + up2(a1) + up4(a2)), bilinear align_corners=False, against
     F.interpolate -- bf16 rows (one rounding), f32 rows (1e-6), the split layout [hi | lo | hi] (hi + lo == f32 value to 2^-21) --

@@ -241,9 +241,13 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     grouped = ngrouped > 0
     assert grouped == (os.environ.get("SIPMASK_GROUPED_TOWERS", "1") == "1" and eng.flag_norm)   # GN heads only
     # fused bottleneck tails (layer1 / layer2, plain conv2): conv2 + conv3 (+ the next block's conv1) per launch
-    nfused = sum(2 + (t.w1n is not None) for t in eng.fused)
+    # (round 4: layer1's first tail also carries the block's 1x1 shortcut conv -- three convs in that launch)
+    nfused = sum(2 + (t.w1n is not None) + (t.x_block is not None) for t in eng.fused)
+    nshort = sum(1 for t in eng.fused if t.x_block is not None)
     if variant in ("r50", "vis", "benchmark", "ssd") and os.environ.get("SIPMASK_FUSE_BOTTLENECK", "1") == "1":
-        assert len(eng.fused) == 7 and nfused == 7 * 2
+        assert len(eng.fused) == 7 and nfused == 7 * 2 + nshort
+        assert nshort == (0 if os.environ.get("SIPMASK_FUSE_SHORTCUT", "1") == "0" else 1)
+        assert ("backbone.layer1.0.downsample" in rows) == (nshort == 0) and "backbone.layer2.0.downsample" in rows
     # sip_mask_lat0 by linearity (round 4): the 768 -> 512 conv runs as three 1x1 convs (l0, l1, l2) + sm_upsample_sum2
     nlin = 2 if getattr(eng, "lat0_by_linearity", False) else 0
     if nlin:
