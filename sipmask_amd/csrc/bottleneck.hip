@@ -48,9 +48,12 @@ constexpr int BT_SLICE_BYTES = 16384;
 // OCC: blocks per CU the register allocation aims for.  The unchained <64> kernel needs 135 VGPRs at OCC 3; capped at 128
 // (OCC 4: four spills outside the loops) a fourth block fits, and these launches are bandwidth-shaped (layer1: 310 MB per
 // 4-image launch): more loads in flight per CU.  A/B: SIPMASK_BT_OCC (3 | 4).
-template <int C2, bool CHAIN1, int OCC, int CDS = 0>
+// SLB: bytes of a conv3 weight slice.  16 KB by default; the CHAINED variants take 8 KB -- half the couts per pass, so half
+// the conv3 accumulators, residual chunks and chained-conv1 B fragments live at a time: 168 VGPRs + spills -> no spills at
+// three blocks per CU (round 4; the chain was "neutral" in round 2 because of exactly that).
+template <int C2, bool CHAIN1, int OCC, int CDS = 0, int SLB = BT_SLICE_BYTES>
 __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs a) {
-  static_assert(!(CHAIN1 && CDS > 0) && CDS % 64 == 0, "the chained conv1 is not combined with the fused shortcut conv");
+  static_assert(CDS % 64 == 0, "shortcut input channels");
   constexpr int K3 = C2 + CDS;                  // conv3's K: the conv2 tile (+ the shortcut conv's input channels)
   constexpr int KKD = CDS / 16;
   constexpr int TCO = C2 / 32;                  // MFMA tiles along the conv2 couts (all of them in one wave)
@@ -61,18 +64,22 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
   constexpr int CPT = C2 / 8;                   // 16-byte chunks per tap
   constexpr int NK = 9 * C2 / 32;
   constexpr int C4 = 4 * C2;
-  constexpr int SL = BT_SLICE_BYTES / (K3 * 2); // conv3 couts per slice (128 | 64)
+  constexpr int SL = SLB / (K3 * 2);            // conv3 couts per slice (128 | 64 | 32)
+  constexpr int W1B = C2 * SL * 2;              // chained conv1: a K slice of SL input channels, [C2 rows][SL k]
+  constexpr int NR3 = SLB / 128, NR1 = W1B / 128; // 128-byte rows of a w3 / w1 slice
+  static_assert(SL % 32 == 0 && (C2 + CDS) * SL * 2 == SLB && NR3 % 32 == 0 && NR1 % 32 == 0, "slice shape");
+  static_assert(!CHAIN1 || SL % 64 == 0, "the chained conv1's K slice is laid out in 128-byte (64-channel) rows");
   constexpr int NPASS = C4 / SL;
   constexpr int CT = SL / 32;                   // MFMA tiles along the slice's couts
   constexpr int KK3 = C2 / 16;                  // K steps of 16 in conv3
   // chained conv1 of the next block: per pass a K slice of SL input channels, weights [C2 rows][SL k]
-  static_assert(2 * STAGE >= BT_SLICE_BYTES, "the finished stages hold one weight slice");
+  static_assert(2 * STAGE >= SLB, "the finished stages hold one weight slice");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // bt_lds_bytes(C2, CHAIN1)
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
   unsigned char* const bufA = smem + 2 * STAGE;
   unsigned char* const bufB = smem;
-  unsigned char* const w1buf = smem + 2 * STAGE + BT_SLICE_BYTES;     // [2][16 KB] (CHAIN1)
+  unsigned char* const w1buf = smem + 2 * STAGE + SLB;                // [2][W1B] (CHAIN1)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
   // physical slot L&7, i.e. it fetches logical chunk (L&7) ^ ((row>>1)&7)
   auto dma_w3_slice = [&](int p, unsigned char* buf) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NR3 / 32; ++r) {
       const int fr = (r * 4 + wave) * 8 + (lane >> 3);
       const int sub = fr / SL, row = fr - sub * SL;
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
   };
   auto dma_w1_slice = [&](int p, unsigned char* buf) {       // rows = next conv1 couts (C2), k = [p*SL, (p+1)*SL)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NR1 / 32; ++r) {
       const int fr = (r * 4 + wave) * 8 + (lane >> 3);
       const int sub = fr / C2, row = fr - sub * C2;
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
     __syncthreads();                             // slice p has landed; the other buffer's readers (pass p-1) are done
     if (p + 1 < NPASS) {
       dma_w3_slice(p + 1, (p & 1) ? bufA : bufB);
-      if constexpr (CHAIN1) dma_w1_slice(p + 1, w1buf + ((p + 1) & 1) * BT_SLICE_BYTES);
+      if constexpr (CHAIN1) dma_w1_slice(p + 1, w1buf + ((p + 1) & 1) * W1B);
     }
     u32x4 rv[CT][2];
     if constexpr (CDS == 0) {
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
         yfr[ct * 2 + qp] = __builtin_bit_cast(bf16x8, packed);
       }
     if constexpr (CHAIN1) {
-      const unsigned char* wb = w1buf + (p & 1) * BT_SLICE_BYTES;
+      const unsigned char* wb = w1buf + (p & 1) * W1B;
 #pragma unroll
       for (int kk = 0; kk < SL / 16; ++kk) {       // k = p*SL + 16*kk (+ 8*khalf) <-> yfr[kk]
         const int sub = kk >> 2;
@@ -341,19 +348,21 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
   }
 }
 
-constexpr int bt_lds_bytes(int c2, bool chain) { return 2 * (c2 + BT_BPOS) * 64 + BT_SLICE_BYTES + (chain ? 2 * BT_SLICE_BYTES : 0); }
+constexpr int bt_lds_bytes(int c2, bool chain, int cds, int slb) {
+  return 2 * (c2 + BT_BPOS) * 64 + slb + (chain ? 2 * (c2 * (slb / ((c2 + cds) * 2)) * 2) : 0);
+}
 
-template <int C2, bool CHAIN1, int OCC, int CDS = 0>
+template <int C2, bool CHAIN1, int OCC, int CDS = 0, int SLB = BT_SLICE_BYTES>
 int bt_launch(const BtArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int lds = bt_lds_bytes(C2, CHAIN1);
+  constexpr int lds = bt_lds_bytes(C2, CHAIN1, CDS, SLB);
   static bool attr_set = false;                 // > 64 KB of dynamic LDS needs the opt-in once per kernel
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS, SLB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return SM_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS, SLB>), grid, dim3(256), lds, s, a);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -394,19 +403,22 @@ extern "C" int sm_bottleneck_tail(int batch, int h, int w, int channels, const v
     return (e && atoi(e) == 4) ? 4 : 3;
   }();
   if (channels == 64) {
-    if (chain) return bt_launch<64, true, 3>(a, grid, s);
+    if (chain) return bt_launch<64, true, 3, 0, 8192>(a, grid, s);     // 8 KB slices: see SLB
     return occ == 4 ? bt_launch<64, false, 4>(a, grid, s) : bt_launch<64, false, 3>(a, grid, s);
   }
   if (chain) return bt_launch<128, true, 3>(a, grid, s);
   return occ == 4 ? bt_launch<128, false, 4>(a, grid, s) : bt_launch<128, false, 3>(a, grid, s);
 }
 
-/* conv2 + conv3 + the block's 1x1 SHORTCUT conv (stride 1) as one launch: layer1's first bottleneck. */
+/* conv2 + conv3 + the block's 1x1 SHORTCUT conv (stride 1) as one launch: layer1's first bottleneck; optionally the next
+ * block's conv1 chained behind it like sm_bottleneck_tail. */
 extern "C" int sm_bottleneck_tail_ds(int batch, int h, int w, int channels, const void* x, const void* w2, const float* b2,
                                      const void* w3_ds, const float* b3_ds, const void* x_block, int ds_channels, void* y,
-                                     sm_stream_t stream) {
+                                     const void* w1_next, const float* b1_next, void* t1_next, sm_stream_t stream) {
   if (!x || !w2 || !b2 || !w3_ds || !b3_ds || !x_block || !y || batch < 1 || h < 1 || w < 1) return SM_ERR_BAD_ARG;
   if (channels != 64 || ds_channels != 64) return SM_ERR_UNSUPPORTED;
+  const bool chain = w1_next != nullptr;
+  if (chain && (!b1_next || !t1_next)) return SM_ERR_BAD_ARG;
   const long long M = (long long)batch * h * w;
   if (M * 4 * channels >= (1ll << 31) * 8) return SM_ERR_BAD_SHAPE;
   BtArgs a;
@@ -418,12 +430,14 @@ extern "C" int sm_bottleneck_tail_ds(int batch, int h, int w, int channels, cons
   a.res = nullptr;
   a.xds = (const uint16_t*)x_block;
   a.y = (uint16_t*)y;
-  a.w1n = nullptr;
-  a.b1n = nullptr;
-  a.t1n = nullptr;
+  a.w1n = (const uint16_t*)w1_next;
+  a.b1n = b1_next;
+  a.t1n = (uint16_t*)t1_next;
   a.batch = batch;
   a.H = h;
   a.W = w;
   a.M = (int)M;
-  return bt_launch<64, false, 4, 64>(a, dim3(sm_cdiv(M, BT_BPOS)), sm_hip_stream(stream));   // 95 VGPRs, 40 KB of LDS: four blocks per CU
+  const dim3 grid(sm_cdiv(M, BT_BPOS));
+  if (chain) return bt_launch<64, true, 3, 64>(a, grid, sm_hip_stream(stream));
+  return bt_launch<64, false, 4, 64>(a, grid, sm_hip_stream(stream));   // 95 VGPRs, 40 KB of LDS: four blocks per CU
 }

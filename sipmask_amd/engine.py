@@ -49,6 +49,7 @@ _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"
 # FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes
 # the shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
 # shapes), "0" = three launches (A/B)
+_CHAIN_CONV1 = int(os.environ.get("SIPMASK_CHAIN_CONV1", "1"))        # A/B: layer1 tails also compute the next block's conv1 (2: not the one with the fused shortcut)
 _FUSE_SHORTCUT = os.environ.get("SIPMASK_FUSE_SHORTCUT", "1") != "0"  # A/B: layer1.0's shortcut conv inside the fused tail
 _SMALLCO_CONV = os.environ.get("SIPMASK_SMALLCO_CONV", "1") != "0"    # A/B: the small-cout 3x3 kernel (conv3x3_smallco.hip)
 _STEM_FUSED = os.environ.get("SIPMASK_STEM_FUSED", "1") != "0"        # A/B: conv1 + bn1 + relu + maxpool as one launch (stem_fused.hip)
@@ -265,7 +266,7 @@ class _BottleneckTail:
     def __call__(self):
         if self.x_block is not None:
             H.bottleneck_tail_ds(self.batch, self.hw[0], self.hw[1], self.planes, self.x, self.w2, self.b2, self.w3, self.b3,
-                                 self.x_block, self.y)
+                                 self.x_block, self.y, self.w1n, self.b1n, self.t1n)
             return
         H.bottleneck_tail(self.batch, self.hw[0], self.hw[1], self.planes, self.x, self.w2, self.b2, self.w3, self.b3,
                           self.identity, self.y, self.w1n, self.b1n, self.t1n)
@@ -617,7 +618,11 @@ class SipMaskEngine:
                         self._join(1)
                     next1 = None
                     pn = "backbone.layer%d.%d" % (li + 1, bi + 1)
-                    if (fuse >= 2 and shortcut is None and bi + 1 < nblocks
+                    # the next block's conv1 chained behind this launch: everywhere with SIPMASK_FUSE_BOTTLENECK=2 (the round-2
+                    # A/B), in layer1 by default (round 4: 8 KB weight slices took the chained kernel from 168 VGPRs + spills
+                    # to three clean blocks per CU; the 256-channel block output is then read once instead of twice)
+                    if ((fuse >= 2 or (_CHAIN_CONV1 and planes == 64 and not (_CHAIN_CONV1 == 2 and shortcut is not None)))
+                            and bi + 1 < nblocks
                             and (pn + ".conv2.conv_offset.weight") not in sd):
                         wn, bn = fold_bn(sd[pn + ".conv1.weight"], sd, pn + ".bn1")
                         chained_t1 = self._buf(B * oh * ow, planes)

@@ -286,16 +286,17 @@ def test_fused_bottleneck_plan_is_bit_identical(monkeypatch):
     # (layer1.0's fused SHORTCUT conv -- round 4 -- keeps the shortcut in f32 where the separate launch rounds it to bf16:
     # not bit-identical by design, switched off here and covered by the next test)
     monkeypatch.setattr(E, "_FUSE_SHORTCUT", False)
-    for mode in (0, 1, 2):
-        monkeypatch.setattr(E, "_FUSE_BOTTLENECK", mode)
+    for mode in (0, 1, 2, 3):                    # 3 = the default plan: tails everywhere, chained conv1 in layer1 only
+        monkeypatch.setattr(E, "_FUSE_BOTTLENECK", min(mode, 2) if mode < 3 else 1)
+        monkeypatch.setattr(E, "_CHAIN_CONV1", 1 if mode == 3 else 0)
         eng = E.SipMaskEngine(sd, 2, (160, 224), 50)
         assert len(eng.fused) == (0 if mode == 0 else 7)
-        assert sum(t.w1n is not None for t in eng.fused) == (5 if mode == 2 else 0)
+        assert sum(t.w1n is not None for t in eng.fused) == {0: 0, 1: 0, 2: 5, 3: 2}[mode]
         r = eng.run(img)
         torch.cuda.synchronize()
         outs[mode] = ([f[0].clone() for f in eng.backbone_feats], _head_bits(eng),
                       [r[k].clone() for k in ("ndet", "idxs_keep", "det_labels", "det_bboxes", "masks")])
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         for a, b in zip(outs[0][0], outs[mode][0]):
             assert torch.equal(a.view(torch.int16), b.view(torch.int16)), mode
         # the head behind the (bit-identical) features is reproducible too: its GroupNorm statistics are integer sums
@@ -322,9 +323,10 @@ def test_fused_shortcut_conv_plan_matches_separate_launch(monkeypatch):
         eng.run(img)
         torch.cuda.synchronize()
         feats[on] = [f[0].float().clone() for f in eng.backbone_feats]
-    for a, b in zip(feats[False], feats[True]):
-        rel = float((a - b).norm() / a.norm())
-        assert rel < 6e-3, rel                       # bf16 ulp = 2^-8 relative per element, a fraction of them differ
+    # a bf16 ulp is 2^-8 relative and a fraction of layer1.0's outputs move by one; the 13 blocks behind C2 carry that on
+    # (two bf16 pipelines of this random-weight trunk agree to ~1 %: test_backbone_fpn_features holds each to 2 % of the oracle)
+    rels = [float((a - b).norm() / a.norm()) for a, b in zip(feats[False], feats[True])]
+    assert rels[0] < 5e-3 and max(rels) < 2e-2, rels
 
 
 @pytest.mark.parametrize("rescale", [False, True])

@@ -1083,6 +1083,19 @@ def test_bottleneck_tail_with_fused_shortcut_conv():
     y2 = torch.zeros(M, 4 * C, dtype=torch.bfloat16, device=dev)
     H.bottleneck_tail(B, h, w, C, x, prep(w2), b2, prep(w3), b3, idt, y2)
     torch.testing.assert_close(got, y2.float().cpu(), rtol=2 ** -6, atol=2e-2)
+    # ... and with the next block's conv1 chained behind it: same block output bits, t1 = the separate conv1 launch on it
+    from sipmask_amd._lib import SM_CONV_RELU
+    w1 = bf(torch.randn(C, 4 * C, 1, 1, generator=g) / (2 * C ** 0.5)).float()
+    b1 = (torch.randn(C, generator=g) * 0.1).to(dev)
+    y3 = torch.zeros(M + 7, 4 * C, dtype=torch.bfloat16, device=dev)
+    t1n = torch.zeros(M + 7, C, dtype=torch.bfloat16, device=dev)
+    H.bottleneck_tail_ds(B, h, w, C, x, prep(w2), b2, w3ds, (b3 + bd).contiguous(), xb, y3, prep(w1), b1, t1n)
+    torch.cuda.synchronize()
+    assert torch.equal(y3.view(torch.int16), y.view(torch.int16)) and not bool(t1n[M:].any())
+    d1 = H.make_conv_desc(B, [(h, w)], [(h, w)], [0], [0], 4 * C, C, C, 1, 1, 0, 4 * C, C, 0, SM_CONV_RELU)
+    t1_ref = torch.zeros(M, C, dtype=torch.bfloat16, device=dev)
+    H.conv2d(d1, y[:M].contiguous(), H.prep_conv_weight(w1.to(dev), 4 * C)[0], b1, None, t1_ref)
+    assert torch.equal(t1n[:M].view(torch.int16), t1_ref.view(torch.int16))
 
 
 def test_upsample_sum2_vs_torch_and_lat0_by_linearity():

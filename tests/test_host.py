@@ -245,7 +245,9 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     nfused = sum(2 + (t.w1n is not None) + (t.x_block is not None) for t in eng.fused)
     nshort = sum(1 for t in eng.fused if t.x_block is not None)
     if variant in ("r50", "vis", "benchmark", "ssd") and os.environ.get("SIPMASK_FUSE_BOTTLENECK", "1") == "1":
-        assert len(eng.fused) == 7 and nfused == 7 * 2 + nshort
+        nchain = sum(1 for t in eng.fused if t.w1n is not None)          # layer1: the next block's conv1 rides along
+        assert nchain == (0 if os.environ.get("SIPMASK_CHAIN_CONV1", "1") == "0" else 2)
+        assert len(eng.fused) == 7 and nfused == 7 * 2 + nshort + nchain
         assert nshort == (0 if os.environ.get("SIPMASK_FUSE_SHORTCUT", "1") == "0" else 1)
         assert ("backbone.layer1.0.downsample" in rows) == (nshort == 0) and "backbone.layer2.0.downsample" in rows
     # sip_mask_lat0 by linearity (round 4): the 768 -> 512 conv runs as three 1x1 convs (l0, l1, l2) + sm_upsample_sum2
