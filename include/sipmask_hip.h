@@ -180,14 +180,15 @@ int sm_bottleneck_tail_supported(int channels);
 int sm_bottleneck_tail(int batch, int h, int w, int channels, const void* x, const void* w2, const float* b2,
                        const void* w3, const float* b3, const void* identity, void* y, const void* w1_next,
                        const float* b1_next, void* t1_next, sm_stream_t stream);
-/* The same with the block's 1x1 SHORTCUT conv fused in (resnet.py:453-469, stride 1: layer1's first block; channels == 64,
- * ds_channels == 64): w3_ds = bf16 [4 * channels][channels + ds_channels] = [w3 | w_downsample] row by row, b3_ds = b3 +
- * b_downsample (both BN-folded), x_block = the block input rows [M][ds_channels].  The shortcut is never materialised: it
- * stays in the f32 accumulator until the one rounding of the block output.  w1_next / b1_next / t1_next: as in
- * sm_bottleneck_tail (NULL = no chained conv1). */
+/* The same with the block's 1x1 SHORTCUT conv fused in (resnet.py:453-469: the first block of a stage): layer1 (channels 64,
+ * ds_channels 64, ds_stride 1) and layer2 (channels 128, ds_channels 256, ds_stride 2).  w3_ds = bf16 [4 * channels][channels +
+ * ds_channels] = [w3 | w_downsample] row by row, b3_ds = b3 + b_downsample (both BN-folded), x_block = the block input rows
+ * [batch * ds_h * ds_w][ds_channels]; output position (n, ho, wo) reads input (n, ds_stride * ho, ds_stride * wo).  The
+ * shortcut is never materialised: it stays in the f32 accumulator until the one rounding of the block output.  w1_next /
+ * b1_next / t1_next: as in sm_bottleneck_tail (NULL = no chained conv1; layer1 only). */
 int sm_bottleneck_tail_ds(int batch, int h, int w, int channels, const void* x, const void* w2, const float* b2,
-                          const void* w3_ds, const float* b3_ds, const void* x_block, int ds_channels, void* y,
-                          const void* w1_next, const float* b1_next, void* t1_next, sm_stream_t stream);
+                          const void* w3_ds, const float* b3_ds, const void* x_block, int ds_channels, int ds_stride, int ds_h,
+                          int ds_w, void* y, const void* w1_next, const float* b1_next, void* t1_next, sm_stream_t stream);
 
 /* 3x3 / stride 1 / pad 1 convolution with the input patch resident in LDS (csrc/conv3x3_patch.hip): the throughput
  * kernel for the large 3x3 layers (tower convs -- also as the grouped cls+reg launch --, fcos_cls + sip_cof, FPN

@@ -32,7 +32,9 @@ struct BtArgs {
   const uint16_t* w3;    // [4C][C]
   const float* b3;
   const uint16_t* res;   // identity     [M][4C]   (CDS == 0)
-  const uint16_t* xds;   // CDS > 0: the block input [M][CDS] the shortcut conv reads; w3 = [4C][C + CDS], b3 = b3 + b_downsample
+  const uint16_t* xds;   // CDS > 0: the block input rows [batch * dsH * dsW][CDS] the shortcut conv reads (at stride ds_stride);
+                         // w3 = [4C][C + CDS], b3 = b3 + b_downsample
+  int ds_stride, dsH, dsW;
   uint16_t* y;           // block output [M][4C]
   const uint16_t* w1n;   // next conv1   [C][4C] or null
   const float* b1n;
@@ -201,8 +203,14 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
   // ---- CDS: the B fragments of the shortcut conv -- lane (position, khalf) holds channels 16*kk + 8*khalf .. + 8 of its row
   bf16x8 dfr[KKD > 0 ? KKD : 1];
   if constexpr (CDS > 0) {
-    const int md = m0 + wave * 32 + l31;
-    const uint16_t* xr = a.xds + (long long)(md < M ? md : 0) * CDS + 8 * khalf;
+    const int md = min(m0 + wave * 32 + l31, M - 1);
+    long long drow = md;
+    if (a.ds_stride != 1) {                          // 1x1 / stride-s shortcut: output (n, ho, wo) reads input (n, s*ho, s*wo)
+      const int n = md / HW, rem = md - n * HW;
+      const int ho = rem / W, wo = rem - ho * W;
+      drow = ((long long)n * a.dsH + ho * a.ds_stride) * a.dsW + wo * a.ds_stride;
+    }
+    const uint16_t* xr = a.xds + drow * CDS + 8 * khalf;
 #pragma unroll
     for (int kk = 0; kk < KKD; ++kk) dfr[kk] = *reinterpret_cast<const bf16x8*>(xr + 16 * kk);
   }
@@ -388,6 +396,7 @@ extern "C" int sm_bottleneck_tail(int batch, int h, int w, int channels, const v
   a.b3 = b3;
   a.res = (const uint16_t*)identity;
   a.xds = nullptr;
+  a.ds_stride = 1, a.dsH = h, a.dsW = w;
   a.y = (uint16_t*)y;
   a.w1n = (const uint16_t*)w1_next;
   a.b1n = b1_next;
@@ -406,19 +415,23 @@ extern "C" int sm_bottleneck_tail(int batch, int h, int w, int channels, const v
     if (chain) return bt_launch<64, true, 3, 0, 8192>(a, grid, s);     // 8 KB slices: see SLB
     return occ == 4 ? bt_launch<64, false, 4>(a, grid, s) : bt_launch<64, false, 3>(a, grid, s);
   }
-  if (chain) return bt_launch<128, true, 3>(a, grid, s);
+  if (chain) return bt_launch<128, true, 2>(a, grid, s);     // 80 KB of LDS: two blocks per CU whatever the registers -- no cap, no spills
   return occ == 4 ? bt_launch<128, false, 4>(a, grid, s) : bt_launch<128, false, 3>(a, grid, s);
 }
 
-/* conv2 + conv3 + the block's 1x1 SHORTCUT conv (stride 1) as one launch: layer1's first bottleneck; optionally the next
- * block's conv1 chained behind it like sm_bottleneck_tail. */
+/* conv2 + conv3 + the block's 1x1 SHORTCUT conv as one launch: the first bottleneck of layer1 (64 -> 256, stride 1) and of
+ * layer2 (256 -> 512, stride 2); optionally the next block's conv1 chained behind it like sm_bottleneck_tail (layer1). */
 extern "C" int sm_bottleneck_tail_ds(int batch, int h, int w, int channels, const void* x, const void* w2, const float* b2,
-                                     const void* w3_ds, const float* b3_ds, const void* x_block, int ds_channels, void* y,
-                                     const void* w1_next, const float* b1_next, void* t1_next, sm_stream_t stream) {
+                                     const void* w3_ds, const float* b3_ds, const void* x_block, int ds_channels,
+                                     int ds_stride, int ds_h, int ds_w, void* y, const void* w1_next, const float* b1_next,
+                                     void* t1_next, sm_stream_t stream) {
   if (!x || !w2 || !b2 || !w3_ds || !b3_ds || !x_block || !y || batch < 1 || h < 1 || w < 1) return SM_ERR_BAD_ARG;
-  if (channels != 64 || ds_channels != 64) return SM_ERR_UNSUPPORTED;
+  const bool l1 = channels == 64 && ds_channels == 64 && ds_stride == 1;
+  const bool l2 = channels == 128 && ds_channels == 256 && ds_stride == 2;
+  if (!l1 && !l2) return SM_ERR_UNSUPPORTED;
+  if ((ds_h - 1) / ds_stride + 1 != h || (ds_w - 1) / ds_stride + 1 != w) return SM_ERR_BAD_SHAPE;
   const bool chain = w1_next != nullptr;
-  if (chain && (!b1_next || !t1_next)) return SM_ERR_BAD_ARG;
+  if (chain && (!b1_next || !t1_next || !l1)) return SM_ERR_BAD_ARG;
   const long long M = (long long)batch * h * w;
   if (M * 4 * channels >= (1ll << 31) * 8) return SM_ERR_BAD_SHAPE;
   BtArgs a;
@@ -429,6 +442,7 @@ extern "C" int sm_bottleneck_tail_ds(int batch, int h, int w, int channels, cons
   a.b3 = b3_ds;
   a.res = nullptr;
   a.xds = (const uint16_t*)x_block;
+  a.ds_stride = ds_stride, a.dsH = ds_h, a.dsW = ds_w;
   a.y = (uint16_t*)y;
   a.w1n = (const uint16_t*)w1_next;
   a.b1n = b1_next;
@@ -438,6 +452,8 @@ extern "C" int sm_bottleneck_tail_ds(int batch, int h, int w, int channels, cons
   a.W = w;
   a.M = (int)M;
   const dim3 grid(sm_cdiv(M, BT_BPOS));
-  if (chain) return bt_launch<64, true, 3, 64>(a, grid, sm_hip_stream(stream));
-  return bt_launch<64, false, 4, 64>(a, grid, sm_hip_stream(stream));   // 95 VGPRs, 40 KB of LDS: four blocks per CU
+  hipStream_t s = sm_hip_stream(stream);
+  if (l2) return bt_launch<128, false, 3, 256, 24576>(a, grid, s);   // K3 = 384: 32-cout slices of 24 KB
+  if (chain) return bt_launch<64, true, 3, 64>(a, grid, s);
+  return bt_launch<64, false, 4, 64>(a, grid, s);   // 95 VGPRs, 40 KB of LDS: four blocks per CU
 }

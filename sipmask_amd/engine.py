@@ -49,8 +49,8 @@ _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"
 # FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes
 # the shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
 # shapes), "0" = three launches (A/B)
-_CHAIN_CONV1 = int(os.environ.get("SIPMASK_CHAIN_CONV1", "1"))        # A/B: layer1 tails also compute the next block's conv1 (2: not the one with the fused shortcut)
-_FUSE_SHORTCUT = os.environ.get("SIPMASK_FUSE_SHORTCUT", "1") != "0"  # A/B: layer1.0's shortcut conv inside the fused tail
+_CHAIN_CONV1 = int(os.environ.get("SIPMASK_CHAIN_CONV1", "1"))        # A/B: layer1 tails also compute the next block's conv1 (2: not the one with the fused shortcut; 3: layer2 as well)
+_FUSE_SHORTCUT = int(os.environ.get("SIPMASK_FUSE_SHORTCUT", "2"))    # A/B: the shortcut conv inside the fused tail: 1 = layer1.0, 2 = + layer2.0
 _SMALLCO_CONV = os.environ.get("SIPMASK_SMALLCO_CONV", "1") != "0"    # A/B: the small-cout 3x3 kernel (conv3x3_smallco.hip)
 _STEM_FUSED = os.environ.get("SIPMASK_STEM_FUSED", "1") != "0"        # A/B: conv1 + bn1 + relu + maxpool as one launch (stem_fused.hip)
 _LAT0_LINEAR = os.environ.get("SIPMASK_LAT0_LINEAR", "1") != "0"      # A/B: sip_mask_lat0 by linearity (three convs + upsample_sum2)
@@ -250,8 +250,11 @@ class _BottleneckTail:
         # shortcut = (w_downsample, b_downsample, block input rows): the block's 1x1 shortcut conv rides conv3's K loop
         # (layer1's first block: resnet.py:453-469; csrc/bottleneck.hip CDS) -- `identity` is not used
         self.x_block = None
+        self.ds_stride, self.ds_hw = 1, hw
         if shortcut is not None:
-            wd, bd, self.x_block = shortcut
+            wd, bd, self.x_block = shortcut[:3]
+            if len(shortcut) > 3:
+                self.ds_stride, self.ds_hw = shortcut[3], shortcut[4]
             self.w3 = torch.cat([self.w3, prep(wd)], 1).contiguous()
             self.b3 = (self.b3 + fb(bd)).contiguous()
             cds = self.x_block.shape[1]
@@ -266,7 +269,7 @@ class _BottleneckTail:
     def __call__(self):
         if self.x_block is not None:
             H.bottleneck_tail_ds(self.batch, self.hw[0], self.hw[1], self.planes, self.x, self.w2, self.b2, self.w3, self.b3,
-                                 self.x_block, self.y, self.w1n, self.b1n, self.t1n)
+                                 self.x_block, self.y, self.w1n, self.b1n, self.t1n, self.ds_stride, self.ds_hw)
             return
         H.bottleneck_tail(self.batch, self.hw[0], self.hw[1], self.planes, self.x, self.w2, self.b2, self.w3, self.b3,
                           self.identity, self.y, self.w1n, self.b1n, self.t1n)
@@ -590,11 +593,13 @@ class SipMaskEngine:
                 has_dcn = (p + ".conv2.conv_offset.weight") in sd
                 fuse = _FUSE_BOTTLENECK if (not f32 and planes in (64, 128) and not has_dcn) else 0
                 # layer1's first block: the 1x1 shortcut conv (64 -> 256, stride 1) rides the fused tail's conv3 (round 4)
-                fuse_ds = bool(fuse) and _FUSE_SHORTCUT and bi == 0 and s == 1 and planes == 64 and cc == 64
+                # (... and layer2's: 256 -> 512 at stride 2, SIPMASK_FUSE_SHORTCUT=2)
+                fuse_ds = bool(fuse) and bi == 0 and ((_FUSE_SHORTCUT >= 1 and s == 1 and planes == 64 and cc == 64) or
+                                                      (_FUSE_SHORTCUT >= 2 and s == 2 and planes == 128 and cc == 256))
                 shortcut = None
                 if bi == 0 and fuse_ds:
                     wd, bd = fold_bn(sd[p + ".downsample.0.weight"], sd, p + ".downsample.1")
-                    shortcut, idt = (wd, bd, cur), None
+                    shortcut, idt = (wd, bd, cur, s, (ch, cw)), None
                 elif bi == 0:     # the shortcut conv reads the block input only: it forks onto a side lane BEFORE
                     # conv1/conv2 are queued and is joined right before conv3 adds it
                     wd, bd = fold_bn(sd[p + ".downsample.0.weight"], sd, p + ".downsample.1")
@@ -621,7 +626,9 @@ class SipMaskEngine:
                     # the next block's conv1 chained behind this launch: everywhere with SIPMASK_FUSE_BOTTLENECK=2 (the round-2
                     # A/B), in layer1 by default (round 4: 8 KB weight slices took the chained kernel from 168 VGPRs + spills
                     # to three clean blocks per CU; the 256-channel block output is then read once instead of twice)
-                    if ((fuse >= 2 or (_CHAIN_CONV1 and planes == 64 and not (_CHAIN_CONV1 == 2 and shortcut is not None)))
+                    if ((fuse >= 2 or (_CHAIN_CONV1 and (planes == 64 or _CHAIN_CONV1 == 3)
+                                       and not (_CHAIN_CONV1 == 2 and shortcut is not None)))
+                            and not (shortcut is not None and planes != 64)       # (the stride-2 shortcut kernel has no chain)
                             and bi + 1 < nblocks
                             and (pn + ".conv2.conv_offset.weight") not in sd):
                         wn, bn = fold_bn(sd[pn + ".conv1.weight"], sd, pn + ".bn1")

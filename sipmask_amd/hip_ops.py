@@ -405,18 +405,21 @@ def bottleneck_tail(batch, h, w, channels, x, w2, b2, w3, b3, identity, y, w1_ne
     return y
 
 
-def bottleneck_tail_ds(batch, h, w, channels, x, w2, b2, w3_ds, b3_ds, x_block, y, w1_next=None, b1_next=None, t1_next=None):
+def bottleneck_tail_ds(batch, h, w, channels, x, w2, b2, w3_ds, b3_ds, x_block, y, w1_next=None, b1_next=None, t1_next=None,
+                       ds_stride=1, ds_hw=None):
     """conv2 + conv3 + the block's 1x1 shortcut conv (resnet.py:453-469, stride 1) as one launch: w3_ds = [w3 | w_downsample]
     ([4C][C + Cds] bf16), b3_ds = b3 + b_downsample; x_block = the block input rows the shortcut conv reads."""
     lib = _lib.load()
     _lib.require_cuda(x, w2, b2, w3_ds, b3_ds, x_block, y)
     C4, cds = 4 * channels, x_block.shape[1]
     assert tuple(w2.shape) == (channels, 9 * channels) and tuple(w3_ds.shape) == (C4, channels + cds), (w2.shape, w3_ds.shape)
-    assert x.shape[1] == channels and y.shape[1] == C4 and min(x.shape[0], x_block.shape[0], y.shape[0]) >= batch * h * w
+    dh, dw = ds_hw if ds_hw is not None else (h, w)
+    assert x.shape[1] == channels and y.shape[1] == C4 and min(x.shape[0], y.shape[0]) >= batch * h * w
+    assert x_block.shape[0] >= batch * dh * dw and x_block.is_contiguous()
     if w1_next is not None:
         assert tuple(w1_next.shape) == (channels, C4) and t1_next.shape[1] == channels and t1_next.shape[0] >= batch * h * w
     _lib.check(lib.sm_bottleneck_tail_ds(batch, h, w, channels, _lib.ptr(x), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(w3_ds),
-                                         _lib.ptr(b3_ds), _lib.ptr(x_block), cds, _lib.ptr(y),
+                                         _lib.ptr(b3_ds), _lib.ptr(x_block), cds, ds_stride, dh, dw, _lib.ptr(y),
                                          None if w1_next is None else _lib.ptr(w1_next),
                                          None if w1_next is None else _lib.ptr(b1_next),
                                          None if w1_next is None else _lib.ptr(t1_next), _lib.stream_ptr()),

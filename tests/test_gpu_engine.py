@@ -285,7 +285,7 @@ def test_fused_bottleneck_plan_is_bit_identical(monkeypatch):
     outs = {}
     # (layer1.0's fused SHORTCUT conv -- round 4 -- keeps the shortcut in f32 where the separate launch rounds it to bf16:
     # not bit-identical by design, switched off here and covered by the next test)
-    monkeypatch.setattr(E, "_FUSE_SHORTCUT", False)
+    monkeypatch.setattr(E, "_FUSE_SHORTCUT", 0)
     for mode in (0, 1, 2, 3):                    # 3 = the default plan: tails everywhere, chained conv1 in layer1 only
         monkeypatch.setattr(E, "_FUSE_BOTTLENECK", min(mode, 2) if mode < 3 else 1)
         monkeypatch.setattr(E, "_CHAIN_CONV1", 1 if mode == 3 else 0)
@@ -316,10 +316,12 @@ def test_fused_shortcut_conv_plan_matches_separate_launch(monkeypatch):
     img = torch.randn(2, 3, 160, 224, generator=torch.Generator().manual_seed(9)).cuda()
     feats = {}
     for on in (False, True):
-        monkeypatch.setattr(E, "_FUSE_SHORTCUT", on)
+        monkeypatch.setattr(E, "_FUSE_SHORTCUT", 2 if on else 0)
         eng = E.SipMaskEngine(sd, 2, (160, 224), 50)
-        assert sum(t.x_block is not None for t in eng.fused) == (1 if on else 0)
+        assert sum(t.x_block is not None for t in eng.fused) == (2 if on else 0)        # layer1's and layer2's first blocks
         assert any(c.name == "backbone.layer1.0.downsample" for c in eng.convs) == (not on)
+        assert any(c.name == "backbone.layer2.0.downsample" for c in eng.convs) == (not on)
+        assert any(c.name == "backbone.layer3.0.downsample" for c in eng.convs)
         eng.run(img)
         torch.cuda.synchronize()
         feats[on] = [f[0].float().clone() for f in eng.backbone_feats]

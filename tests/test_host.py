@@ -248,8 +248,8 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
         nchain = sum(1 for t in eng.fused if t.w1n is not None)          # layer1: the next block's conv1 rides along
         assert nchain == (0 if os.environ.get("SIPMASK_CHAIN_CONV1", "1") == "0" else 2)
         assert len(eng.fused) == 7 and nfused == 7 * 2 + nshort + nchain
-        assert nshort == (0 if os.environ.get("SIPMASK_FUSE_SHORTCUT", "1") == "0" else 1)
-        assert ("backbone.layer1.0.downsample" in rows) == (nshort == 0) and "backbone.layer2.0.downsample" in rows
+        assert nshort == int(os.environ.get("SIPMASK_FUSE_SHORTCUT", "2"))
+        assert ("backbone.layer1.0.downsample" in rows) == (nshort == 0) and ("backbone.layer2.0.downsample" in rows) == (nshort < 2)
     # sip_mask_lat0 by linearity (round 4): the 768 -> 512 conv runs as three 1x1 convs (l0, l1, l2) + sm_upsample_sum2
     nlin = 2 if getattr(eng, "lat0_by_linearity", False) else 0
     if nlin:
