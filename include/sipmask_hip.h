@@ -190,6 +190,13 @@ int sm_bottleneck_tail_ds(int batch, int h, int w, int channels, const void* x, 
                           const void* w3_ds, const float* b3_ds, const void* x_block, int ds_channels, int ds_stride, int ds_h,
                           int ds_w, void* y, const void* w1_next, const float* b1_next, void* t1_next, sm_stream_t stream);
 
+/* conv3 (1x1, channels -> 4 * channels, folded BN, + identity, ReLU) of one bottleneck chained with conv1 (1x1, 4 * channels ->
+ * channels, folded BN, ReLU) of the NEXT one as one launch (resnet.py:188-200 then :175-178; channels == 256: ResNet layer3).
+ * x = conv2's output rows [rows][channels], identity / y [rows][4 * channels], t1_next [rows][channels]; weights in the
+ * sm_conv2d layout ([cout][cin]).  Bit-identical to the two sm_conv2d launches (same K order, same rounding points). */
+int sm_conv1x1_pair(long long rows, int channels, const void* x, const void* w3, const float* b3, const void* identity, void* y,
+                    const void* w1_next, const float* b1_next, void* t1_next, sm_stream_t stream);
+
 /* 3x3 / stride 1 / pad 1 convolution with the input patch resident in LDS (csrc/conv3x3_patch.hip): the throughput
  * kernel for the large 3x3 layers (tower convs -- also as the grouped cls+reg launch --, fcos_cls + sip_cof, FPN
  * output convs).  Same descriptor, activations and epilogue semantics as sm_conv2d / sm_conv2d_gn_stats (bias,

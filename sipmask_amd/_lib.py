@@ -107,6 +107,7 @@ PROTOTYPES = {
     "sm_relu_bf16": (_I, [_P, _P, C.c_int64, _P]),
     "sm_bottleneck_tail_supported": (_I, [_I]),
     "sm_bottleneck_tail": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sm_conv1x1_pair": (_I, [C.c_int64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_bottleneck_tail_ds": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "sm_split3_f16": (_I, [_P, _I, C.c_int64, _I, _I, _P, _I, _I, _P]),
     "sm_upsample_bilinear_x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -53,7 +53,10 @@ constexpr int BT_SLICE_BYTES = 16384;
 // SLB: bytes of a conv3 weight slice.  16 KB by default; the CHAINED variants take 8 KB -- half the couts per pass, so half
 // the conv3 accumulators, residual chunks and chained-conv1 B fragments live at a time: 168 VGPRs + spills -> no spills at
 // three blocks per CU (round 4; the chain was "neutral" in round 2 because of exactly that).
-template <int C2, bool CHAIN1, int OCC, int CDS = 0, int SLB = BT_SLICE_BYTES>
+// CONV2 = false (round 4): no 3x3 conv in the launch -- conv3 (+ identity, ReLU) of one block chained with conv1 of the next,
+// both 1x1: layer3's pairs (C2 = 256: 16 800 positions at four 800 x 1344 images, where each of the two launches is a
+// 32-step K loop on 132-264 tiles that nothing hides, 0.042 + 0.033 ms, and the 1024-channel block output is read back).
+template <int C2, bool CHAIN1, int OCC, int CDS = 0, int SLB = BT_SLICE_BYTES, bool CONV2 = true>
 __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs a) {
   static_assert(CDS % 64 == 0, "shortcut input channels");
   constexpr int K3 = C2 + CDS;                  // conv3's K: the conv2 tile (+ the shortcut conv's input channels)
@@ -75,13 +78,14 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
   constexpr int CT = SL / 32;                   // MFMA tiles along the slice's couts
   constexpr int KK3 = C2 / 16;                  // K steps of 16 in conv3
   // chained conv1 of the next block: per pass a K slice of SL input channels, weights [C2 rows][SL k]
-  static_assert(2 * STAGE >= SLB, "the finished stages hold one weight slice");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // bt_lds_bytes(C2, CHAIN1)
+  constexpr int PRE = CONV2 ? 2 * STAGE : SLB;  // the conv2 K loop's two stages; afterwards (or without conv2) slice buffer B
+  static_assert(PRE >= SLB, "the finished stages hold one weight slice");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // bt_lds_bytes(C2, CHAIN1, CDS, SLB, CONV2)
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
-  unsigned char* const bufA = smem + 2 * STAGE;
+  unsigned char* const bufA = smem + PRE;
   unsigned char* const bufB = smem;
-  unsigned char* const w1buf = smem + 2 * STAGE + SLB;                // [2][W1B] (CHAIN1)
+  unsigned char* const w1buf = smem + PRE + SLB;                      // [2][W1B] (CHAIN1)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,87 +122,121 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
   dma_w3_slice(0, bufA);                         // independent of everything: lands under the K loop
   if constexpr (CHAIN1) dma_w1_slice(0, w1buf);
 
-  // ---- conv2: implicit GEMM, 32-wide K steps, LDS-DMA double buffer (the conv_dma32_kernel scheme, one level)
-  const int j = (lane & 3) ^ ((lane >> 4) & 3);
-  const int r0 = tid >> 2;
-  int rhi[NX], rwi[NX];
-  long long xoff[NX];
-#pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    const int m = m0 + r0 + 64 * i;
-    if (m < M) {
-      const int n = m / HW;
-      const int rem = m - n * HW;
-      const int ho = rem / W;
-      const int wo = rem - ho * W;
-      rhi[i] = ho - 1;
-      rwi[i] = wo - 1;
-      xoff[i] = ((long long)n * HW + (long long)rhi[i] * W + rwi[i]) * C2;
-    } else {
-      rhi[i] = -0x40000000;
-      rwi[i] = 0;
-      xoff[i] = 0;
-    }
-  }
-  const uint16_t* ld_wp = a.w2 + (long long)r0 * KP2 + j * 8;
-  int ld_cc = j, ld_kh = 0, ld_kw = 0;           // CPT >= 8 > j
-  const unsigned long long zero_page = (unsigned long long)g_zero16b;
-  const int wave_row = wave * 16;
-  auto dma_tile = [&](int buf) {
-    unsigned char* Wb = smem + buf * STAGE + wave_row * 64;
-    unsigned char* Xb = Wb + C2 * 64;
-    const long long toff = (long long)((ld_kh * W + ld_kw) * C2 + ld_cc * 8);
-#pragma unroll
-    for (int i = 0; i < NW; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(ld_wp + (long long)i * 64 * KP2), (lds_void*)(Wb + 64 * i * 64), 16, 0, 0);
-#pragma unroll
+  bf16x8 tfr[KK3];                             // B fragments of conv3: the conv2 tile of this wave's 32 positions
+  if constexpr (CONV2) {
+    // ---- conv2: implicit GEMM, 32-wide K steps, LDS-DMA double buffer (the conv_dma32_kernel scheme, one level)
+    const int j = (lane & 3) ^ ((lane >> 4) & 3);
+    const int r0 = tid >> 2;
+    int rhi[NX], rwi[NX];
+    long long xoff[NX];
+  #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int hi = rhi[i] + ld_kh, wi = rwi[i] + ld_kw;
-      const bool ok = ((unsigned)hi < (unsigned)H) & ((unsigned)wi < (unsigned)W);
-      const unsigned long long pm = ok ? ~0ull : 0ull;
-      const unsigned long long src = ((unsigned long long)(a.x + xoff[i] + toff) & pm) | (zero_page & ~pm);
-      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Xb + 64 * i * 64), 16, 0, 0);
+      const int m = m0 + r0 + 64 * i;
+      if (m < M) {
+        const int n = m / HW;
+        const int rem = m - n * HW;
+        const int ho = rem / W;
+        const int wo = rem - ho * W;
+        rhi[i] = ho - 1;
+        rwi[i] = wo - 1;
+        xoff[i] = ((long long)n * HW + (long long)rhi[i] * W + rwi[i]) * C2;
+      } else {
+        rhi[i] = -0x40000000;
+        rwi[i] = 0;
+        xoff[i] = 0;
+      }
     }
-    ld_wp += 32;
-    ld_cc += 4;
-    const int wrap = ld_cc >= CPT ? 1 : 0;
-    ld_cc -= wrap * CPT;
-    ld_kw += wrap;
-    const int wrap2 = ld_kw == 3 ? 1 : 0;
-    ld_kw -= wrap2 * 3;
-    ld_kh += wrap2;
-  };
+    const uint16_t* ld_wp = a.w2 + (long long)r0 * KP2 + j * 8;
+    int ld_cc = j, ld_kh = 0, ld_kw = 0;           // CPT >= 8 > j
+    const unsigned long long zero_page = (unsigned long long)g_zero16b;
+    const int wave_row = wave * 16;
+    auto dma_tile = [&](int buf) {
+      unsigned char* Wb = smem + buf * STAGE + wave_row * 64;
+      unsigned char* Xb = Wb + C2 * 64;
+      const long long toff = (long long)((ld_kh * W + ld_kw) * C2 + ld_cc * 8);
+  #pragma unroll
+      for (int i = 0; i < NW; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void*)(ld_wp + (long long)i * 64 * KP2), (lds_void*)(Wb + 64 * i * 64), 16, 0, 0);
+  #pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int hi = rhi[i] + ld_kh, wi = rwi[i] + ld_kw;
+        const bool ok = ((unsigned)hi < (unsigned)H) & ((unsigned)wi < (unsigned)W);
+        const unsigned long long pm = ok ? ~0ull : 0ull;
+        const unsigned long long src = ((unsigned long long)(a.x + xoff[i] + toff) & pm) | (zero_page & ~pm);
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Xb + 64 * i * 64), 16, 0, 0);
+      }
+      ld_wp += 32;
+      ld_cc += 4;
+      const int wrap = ld_cc >= CPT ? 1 : 0;
+      ld_cc -= wrap * CPT;
+      ld_kw += wrap;
+      const int wrap2 = ld_kw == 3 ? 1 : 0;
+      ld_kw -= wrap2 * 3;
+      ld_kh += wrap2;
+    };
 
-  f32x16 acc[TCO];
-#pragma unroll
-  for (int tc = 0; tc < TCO; ++tc)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[tc][e] = 0.f;
-  const int rsw = (l31 >> 2) & 3;
-  const int wrow_off = l31 * 64;
-  const int xrow_off = C2 * 64 + (wave * 32 + l31) * 64;
-  auto compute = [&](int buf) {
-    const unsigned char* S = smem + buf * STAGE;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
-      bf16x8 wf[TCO];
-#pragma unroll
-      for (int t = 0; t < TCO; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(S + wrow_off + t * 32 * 64 + slot);
-      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(S + xrow_off + slot);
-#pragma unroll
-      for (int tc = 0; tc < TCO; ++tc) acc[tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tc], xf, acc[tc], 0, 0, 0);
-    }
-  };
-  dma_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt + 1 < NK; ++kt) {
-    const int buf = kt & 1;
-    dma_tile(buf ^ 1);
-    compute(buf);
+    f32x16 acc[TCO];
+  #pragma unroll
+    for (int tc = 0; tc < TCO; ++tc)
+  #pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tc][e] = 0.f;
+    const int rsw = (l31 >> 2) & 3;
+    const int wrow_off = l31 * 64;
+    const int xrow_off = C2 * 64 + (wave * 32 + l31) * 64;
+    auto compute = [&](int buf) {
+      const unsigned char* S = smem + buf * STAGE;
+  #pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
+        bf16x8 wf[TCO];
+  #pragma unroll
+        for (int t = 0; t < TCO; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(S + wrow_off + t * 32 * 64 + slot);
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(S + xrow_off + slot);
+  #pragma unroll
+        for (int tc = 0; tc < TCO; ++tc) acc[tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tc], xf, acc[tc], 0, 0, 0);
+      }
+    };
+    dma_tile(0);
     __syncthreads();
+    for (int kt = 0; kt + 1 < NK; ++kt) {
+      const int buf = kt & 1;
+      dma_tile(buf ^ 1);
+      compute(buf);
+      __syncthreads();
+    }
+    compute((NK - 1) & 1);
+
+    // ---- conv2 epilogue in registers: bias, ReLU, bf16 -> the B fragments of conv3 (K step kk = 2*tc + qp)
+  #pragma unroll
+    for (int tc = 0; tc < TCO; ++tc)
+  #pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        float v[8];
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t lo = __float_as_uint(acc[tc][4 * (2 * qp) + e]);
+          const uint32_t hi = __float_as_uint(acc[tc][4 * (2 * qp + 1) + e]);
+          const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+          v[e] = __uint_as_float(r[0]);
+          v[4 + e] = __uint_as_float(r[1]);
+        }
+        const int c0 = tc * 32 + 16 * qp + 8 * khalf;
+        const float4 b0 = *reinterpret_cast<const float4*>(a.b2 + c0);
+        const float4 b1 = *reinterpret_cast<const float4*>(a.b2 + c0 + 4);
+        v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w;
+        v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        tfr[2 * tc + qp] = __builtin_bit_cast(bf16x8, pack_bf16x8_v(v));
+      }
+
+  } else {
+    // no conv2 in this launch (layer3's conv3 + next conv1 pairs): the conv3 operand is the wave's rows of `x` as they lie
+    const int mx = min(m0 + wave * 32 + l31, M - 1);
+    const uint16_t* xr = a.x + (long long)mx * C2 + 8 * khalf;
+#pragma unroll
+    for (int kk = 0; kk < KK3; ++kk) tfr[kk] = *reinterpret_cast<const bf16x8*>(xr + 16 * kk);
   }
-  compute((NK - 1) & 1);
 
   // ---- CDS: the B fragments of the shortcut conv -- lane (position, khalf) holds channels 16*kk + 8*khalf .. + 8 of its row
   bf16x8 dfr[KKD > 0 ? KKD : 1];
@@ -215,31 +253,6 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
     for (int kk = 0; kk < KKD; ++kk) dfr[kk] = *reinterpret_cast<const bf16x8*>(xr + 16 * kk);
   }
 
-  // ---- conv2 epilogue in registers: bias, ReLU, bf16 -> the B fragments of conv3 (K step kk = 2*tc + qp)
-  bf16x8 tfr[KK3];
-#pragma unroll
-  for (int tc = 0; tc < TCO; ++tc)
-#pragma unroll
-    for (int qp = 0; qp < 2; ++qp) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t lo = __float_as_uint(acc[tc][4 * (2 * qp) + e]);
-        const uint32_t hi = __float_as_uint(acc[tc][4 * (2 * qp + 1) + e]);
-        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
-        v[e] = __uint_as_float(r[0]);
-        v[4 + e] = __uint_as_float(r[1]);
-      }
-      const int c0 = tc * 32 + 16 * qp + 8 * khalf;
-      const float4 b0 = *reinterpret_cast<const float4*>(a.b2 + c0);
-      const float4 b1 = *reinterpret_cast<const float4*>(a.b2 + c0 + 4);
-      v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w;
-      v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      tfr[2 * tc + qp] = __builtin_bit_cast(bf16x8, pack_bf16x8_v(v));
-    }
-
   // ---- conv3 (+ chained conv1) in passes of SL couts
   const int m = m0 + wave * 32 + l31;
   const bool mok = m < M;
@@ -252,6 +265,15 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
       for (int e = 0; e < 16; ++e) acc1[tc][e] = 0.f;
   }
   const int asw = (l31 >> 1) & 7;                // A-fragment swizzle: rows ct*32 + l31, 32 | row base
+  constexpr bool RVPF = !CONV2 && CDS == 0;
+  u32x4 rvn[RVPF ? CT : 1][2];
+  if constexpr (RVPF) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp)
+        rvn[ct][qp] = *reinterpret_cast<const u32x4*>(a.res + orow + ct * 32 + 16 * qp + 8 * khalf);
+  }
 #pragma unroll 1
   for (int p = 0; p < NPASS; ++p) {
     unsigned char* const buf = (p & 1) ? bufB : bufA;
@@ -260,13 +282,25 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
       dma_w3_slice(p + 1, (p & 1) ? bufA : bufB);
       if constexpr (CHAIN1) dma_w1_slice(p + 1, w1buf + ((p + 1) & 1) * W1B);
     }
+    // identity chunks of this pass.  RVPF (the 1x1 pair: 32 conv3 MFMAs per pass cannot hide an HBM round trip, and it
+    // has the registers): they were requested one pass ahead
     u32x4 rv[CT][2];
-    if constexpr (CDS == 0) {
+    if constexpr (CDS == 0 && !RVPF) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp)
           rv[ct][qp] = *reinterpret_cast<const u32x4*>(a.res + orow + p * SL + ct * 32 + 16 * qp + 8 * khalf);
+    }
+    if constexpr (RVPF) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          rv[ct][qp] = rvn[ct][qp];
+          if (p + 1 < NPASS)
+            rvn[ct][qp] = *reinterpret_cast<const u32x4*>(a.res + orow + (p + 1) * SL + ct * 32 + 16 * qp + 8 * khalf);
+        }
     }
     f32x16 acc3[CT];
 #pragma unroll
@@ -356,21 +390,21 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
   }
 }
 
-constexpr int bt_lds_bytes(int c2, bool chain, int cds, int slb) {
-  return 2 * (c2 + BT_BPOS) * 64 + slb + (chain ? 2 * (c2 * (slb / ((c2 + cds) * 2)) * 2) : 0);
+constexpr int bt_lds_bytes(int c2, bool chain, int cds, int slb, bool conv2) {
+  return (conv2 ? 2 * (c2 + BT_BPOS) * 64 : slb) + slb + (chain ? 2 * (c2 * (slb / ((c2 + cds) * 2)) * 2) : 0);
 }
 
-template <int C2, bool CHAIN1, int OCC, int CDS = 0, int SLB = BT_SLICE_BYTES>
+template <int C2, bool CHAIN1, int OCC, int CDS = 0, int SLB = BT_SLICE_BYTES, bool CONV2 = true>
 int bt_launch(const BtArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int lds = bt_lds_bytes(C2, CHAIN1, CDS, SLB);
+  constexpr int lds = bt_lds_bytes(C2, CHAIN1, CDS, SLB, CONV2);
   static bool attr_set = false;                 // > 64 KB of dynamic LDS needs the opt-in once per kernel
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS, SLB>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS, SLB, CONV2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return SM_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS, SLB>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS, SLB, CONV2>), grid, dim3(256), lds, s, a);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -456,4 +490,32 @@ extern "C" int sm_bottleneck_tail_ds(int batch, int h, int w, int channels, cons
   if (l2) return bt_launch<128, false, 3, 256, 24576>(a, grid, s);   // K3 = 384: 32-cout slices of 24 KB
   if (chain) return bt_launch<64, true, 3, 64>(a, grid, s);
   return bt_launch<64, false, 4, 64>(a, grid, s);   // 95 VGPRs, 40 KB of LDS: four blocks per CU
+}
+
+/* conv3 (1x1, C -> 4C, + identity, ReLU) of one bottleneck chained with conv1 (1x1, 4C -> C, ReLU) of the next as ONE launch
+ * (resnet.py:188-200 -> :175-178): layer3's pairs, channels == 256.  x = conv2's output rows [M][C]. */
+extern "C" int sm_conv1x1_pair(long long rows, int channels, const void* x, const void* w3, const float* b3,
+                               const void* identity, void* y, const void* w1_next, const float* b1_next, void* t1_next,
+                               sm_stream_t stream) {
+  if (!x || !w3 || !b3 || !identity || !y || !w1_next || !b1_next || !t1_next || rows < 1) return SM_ERR_BAD_ARG;
+  if (channels != 256) return SM_ERR_UNSUPPORTED;
+  if (rows * 4 * channels >= (1ll << 31) * 8) return SM_ERR_BAD_SHAPE;
+  BtArgs a;
+  a.x = (const uint16_t*)x;
+  a.w2 = nullptr;
+  a.b2 = nullptr;
+  a.w3 = (const uint16_t*)w3;
+  a.b3 = b3;
+  a.res = (const uint16_t*)identity;
+  a.xds = nullptr;
+  a.ds_stride = 1, a.dsH = 1, a.dsW = 1;
+  a.y = (uint16_t*)y;
+  a.w1n = (const uint16_t*)w1_next;
+  a.b1n = b1_next;
+  a.t1n = (uint16_t*)t1_next;
+  a.batch = 1;
+  a.H = 1;
+  a.W = (int)rows;
+  a.M = (int)rows;
+  return bt_launch<256, true, 1, 0, 32768, false>(a, dim3(sm_cdiv(rows, BT_BPOS)), sm_hip_stream(stream));
 }

@@ -49,6 +49,9 @@ _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"
 # FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes
 # the shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
 # shapes), "0" = three launches (A/B)
+# A/B: layer3's conv3 + next conv1 as one launch (sm_conv1x1_pair).  Off: bit-identical, but the launch takes as long as the two
+# it replaces (0.079 vs 0.041 + 0.033 ms) and the pipelined step does not move (1 472-1 496 both ways); DESIGN section 6
+_PAIR_1X1 = os.environ.get("SIPMASK_PAIR_1X1", "0") != "0"
 _CHAIN_CONV1 = int(os.environ.get("SIPMASK_CHAIN_CONV1", "1"))        # A/B: layer1 tails also compute the next block's conv1 (2: not the one with the fused shortcut; 3: layer2 as well)
 _FUSE_SHORTCUT = int(os.environ.get("SIPMASK_FUSE_SHORTCUT", "2"))    # A/B: the shortcut conv inside the fused tail: 1 = layer1.0, 2 = + layer2.0
 _SMALLCO_CONV = os.environ.get("SIPMASK_SMALLCO_CONV", "1") != "0"    # A/B: the small-cout 3x3 kernel (conv3x3_smallco.hip)
@@ -273,6 +276,27 @@ class _BottleneckTail:
             return
         H.bottleneck_tail(self.batch, self.hw[0], self.hw[1], self.planes, self.x, self.w2, self.b2, self.w3, self.b3,
                           self.identity, self.y, self.w1n, self.b1n, self.t1n)
+
+
+class _Conv1x1Pair:
+    """conv3 (+ identity, ReLU) of one bottleneck and conv1 (ReLU) of the next as ONE launch (csrc/bottleneck.hip, CONV2 = false;
+    resnet.py:188-200 then :175-178): ResNet layer3, where each of the two 1x1 launches is a K loop on 132-264 tiles that
+    nothing hides and the 1024-channel block output would be read back by the next conv1.  Bit-identical to the two launches."""
+
+    def __init__(self, name, rows, planes, x, w3, b3, identity, y, w1n, b1n, t1n):
+        dev = x.device
+        self.name, self.rows, self.planes = name, rows, planes
+        prep = lambda w: H.prep_conv_weight(w.to(dev), w.shape[1])[0][:w.shape[0]].contiguous()
+        fb = lambda b: b.float().to(dev).contiguous()
+        self.x, self.identity, self.y, self.t1n = x, identity, y, t1n
+        self.w3, self.b3, self.w1n, self.b1n = prep(w3), fb(b3), prep(w1n), fb(b1n)
+        self.x_block = None
+        self.flops = 2.0 * rows * planes * 4 * planes * 2
+        self.bytes = rows * planes * 2 * 2 + 2 * rows * 4 * planes * 2 + (self.w3.numel() + self.w1n.numel()) * 2
+        self.convs_in_launch = 2
+
+    def __call__(self):
+        H.conv1x1_pair(self.rows, self.planes, self.x, self.w3, self.b3, self.identity, self.y, self.w1n, self.b1n, self.t1n)
 
 
 class _GroupedConv(_Conv):
@@ -656,9 +680,19 @@ class SipMaskEngine:
                                          planes, flags=SM_CONV_RELU))
                 if bi == 0:
                     self._join(1)
-                self._add_conv(_Conv(self, p + ".conv3", wc, bc, B, [(oh, ow)], [0], t2, planes, 1, 0, out, [0],
-                                     planes * 4, flags=SM_CONV_RELU | SM_CONV_RES_ADD, residual=idt,
-                                     res_cstride=planes * 4))
+                pn = "backbone.layer%d.%d" % (li + 1, bi + 1)
+                if (_PAIR_1X1 and not f32 and planes == 256 and bi + 1 < nblocks
+                        and (pn + ".conv2.conv_offset.weight") not in sd):
+                    # layer3: conv3 of this block + conv1 of the next as one launch (round 4)
+                    wn, bn = fold_bn(sd[pn + ".conv1.weight"], sd, pn + ".bn1")
+                    chained_t1 = self._buf(B * oh * ow, planes)
+                    pair = _Conv1x1Pair(p + ".conv3+", B * oh * ow, planes, t2, wc, bc, idt, out, wn, bn, chained_t1)
+                    self.fused.append(pair)
+                    self._add("conv:" + pair.name, pair)
+                else:
+                    self._add_conv(_Conv(self, p + ".conv3", wc, bc, B, [(oh, ow)], [0], t2, planes, 1, 0, out, [0],
+                                         planes * 4, flags=SM_CONV_RELU | SM_CONV_RES_ADD, residual=idt,
+                                         res_cstride=planes * 4))
                 cur, ch, cw, cc = out, oh, ow, planes * 4
             feats.append((cur, ch, cw, cc))
         self.backbone_feats = feats

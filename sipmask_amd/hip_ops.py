@@ -427,6 +427,20 @@ def bottleneck_tail_ds(batch, h, w, channels, x, w2, b2, w3_ds, b3_ds, x_block, 
     return y
 
 
+def conv1x1_pair(rows, channels, x, w3, b3, identity, y, w1_next, b1_next, t1_next):
+    """conv3 (+ identity, ReLU) of one bottleneck + conv1 (ReLU) of the next as one launch (resnet.py:188-200, :175-178)"""
+    lib = _lib.load()
+    _lib.require_cuda(x, w3, b3, identity, y, w1_next, b1_next, t1_next)
+    C4 = 4 * channels
+    assert tuple(w3.shape) == (C4, channels) and tuple(w1_next.shape) == (channels, C4), (w3.shape, w1_next.shape)
+    assert x.shape[1] == channels and identity.shape[1] == C4 and y.shape[1] == C4 and t1_next.shape[1] == channels
+    assert min(x.shape[0], identity.shape[0], y.shape[0], t1_next.shape[0]) >= rows
+    _lib.check(lib.sm_conv1x1_pair(rows, channels, _lib.ptr(x), _lib.ptr(w3), _lib.ptr(b3), _lib.ptr(identity), _lib.ptr(y),
+                                   _lib.ptr(w1_next), _lib.ptr(b1_next), _lib.ptr(t1_next), _lib.stream_ptr()),
+               "sm_conv1x1_pair")
+    return y
+
+
 def relu_bf16(x, y):
     """y = relu(x), bf16, same shape (fpn.py:166-170: the ReLU in front of the P7 conv)"""
     lib = _lib.load()

@@ -107,7 +107,9 @@ def test_r101_backbone_features():
     torch.cuda.synchronize()
     feats = OM.backbone_forward(sd, img, 101)
     pyr = OM.fpn_forward(sd, feats)
-    assert len([c for c in eng.convs if c.name.startswith("backbone.layer3.")]) == 23 * 3 + 1
+    # 23 blocks: 3 convs each + the shortcut conv (SIPMASK_PAIR_1X1=1, an A/B: conv3 of block i + conv1 of block i + 1 per launch)
+    npair = len([t for t in eng.fused if t.name.startswith("backbone.layer3.") and t.name.endswith(".conv3+")])
+    assert len([c for c in eng.convs if c.name.startswith("backbone.layer3.")]) == 23 * 3 + 1 - 2 * npair
     for i, (buf, h, w, c) in enumerate(eng.backbone_feats):
         got = buf.float().view(1, h, w, c).permute(0, 3, 1, 2)
         assert _rel(got, feats[i]) < 0.03, (i, _rel(got, feats[i]))
@@ -286,17 +288,19 @@ def test_fused_bottleneck_plan_is_bit_identical(monkeypatch):
     # (layer1.0's fused SHORTCUT conv -- round 4 -- keeps the shortcut in f32 where the separate launch rounds it to bf16:
     # not bit-identical by design, switched off here and covered by the next test)
     monkeypatch.setattr(E, "_FUSE_SHORTCUT", 0)
-    for mode in (0, 1, 2, 3):                    # 3 = the default plan: tails everywhere, chained conv1 in layer1 only
+    for mode in (0, 1, 2, 3, 4):                 # 3 = tails everywhere, chained conv1 in layer1 only; 4 = + layer3's 1x1 pairs
         monkeypatch.setattr(E, "_FUSE_BOTTLENECK", min(mode, 2) if mode < 3 else 1)
-        monkeypatch.setattr(E, "_CHAIN_CONV1", 1 if mode == 3 else 0)
+        monkeypatch.setattr(E, "_CHAIN_CONV1", 1 if mode >= 3 else 0)
+        monkeypatch.setattr(E, "_PAIR_1X1", mode == 4)
         eng = E.SipMaskEngine(sd, 2, (160, 224), 50)
-        assert len(eng.fused) == (0 if mode == 0 else 7)
-        assert sum(t.w1n is not None for t in eng.fused) == {0: 0, 1: 0, 2: 5, 3: 2}[mode]
+        tails = [t for t in eng.fused if hasattr(t, "w2")]
+        assert len(tails) == (0 if mode == 0 else 7) and len(eng.fused) - len(tails) == (5 if mode == 4 else 0)
+        assert sum(t.w1n is not None for t in tails) == {0: 0, 1: 0, 2: 5, 3: 2, 4: 2}[mode]
         r = eng.run(img)
         torch.cuda.synchronize()
         outs[mode] = ([f[0].clone() for f in eng.backbone_feats], _head_bits(eng),
                       [r[k].clone() for k in ("ndet", "idxs_keep", "det_labels", "det_bboxes", "masks")])
-    for mode in (1, 2, 3):
+    for mode in (1, 2, 3, 4):
         for a, b in zip(outs[0][0], outs[mode][0]):
             assert torch.equal(a.view(torch.int16), b.view(torch.int16)), mode
         # the head behind the (bit-identical) features is reproducible too: its GroupNorm statistics are integer sums

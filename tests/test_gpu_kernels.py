@@ -1133,6 +1133,45 @@ def test_bottleneck_tail_with_fused_stride2_shortcut(ds_hw):
         H.bottleneck_tail_ds(B, h, w, C, x, prep(w2), b2, w3ds, b3, xb, y, ds_stride=2, ds_hw=(ds_hw[0] + 2, ds_hw[1]))
 
 
+def test_conv1x1_pair_bit_identical_to_two_launches():
+    """sm_conv1x1_pair (round 4; csrc/bottleneck.hip with CONV2 = false): conv3 (256 -> 1024, + identity, ReLU) of one layer3
+    bottleneck and conv1 (1024 -> 256, ReLU) of the next in one launch (resnet.py:188-200, :175-178), against the same two
+    convs as separate sm_conv2d launches: identical bf16 bits (same K order, same rounding points).  M = 2 * 13 * 19 rows (not a
+    multiple of the 128-position tile)."""
+    from sipmask_amd import hip_ops as H
+    from sipmask_amd._lib import SM_CONV_RELU, SM_CONV_RES_ADD
+    dev = _dev()
+    B, h, w, C = 2, 13, 19, 256
+    M = B * h * w
+    g = torch.Generator().manual_seed(5)
+    bf = lambda t: t.to(torch.bfloat16)
+    x = bf(torch.relu(torch.randn(M, C, generator=g))).to(dev)
+    idt = bf(torch.randn(M, 4 * C, generator=g)).to(dev)
+    w3 = bf(torch.randn(4 * C, C, 1, 1, generator=g) / C ** 0.5).float()
+    w1 = bf(torch.randn(C, 4 * C, 1, 1, generator=g) / (2 * C ** 0.5)).float()
+    b3, b1 = (torch.randn(n, generator=g).to(dev) * 0.1 for n in (4 * C, C))
+
+    def conv(src, wt, bias, cin, cout, flags, res=None):
+        wp, cop = H.prep_conv_weight(wt.to(dev), cin)
+        d = H.make_conv_desc(B, [(h, w)], [(h, w)], [0], [0], cin, cout, cop, 1, 1, 0, cin, cout, 0, flags, 1,
+                             cout if res is not None else 0)
+        o = torch.zeros(M, cout, dtype=torch.bfloat16, device=dev)
+        H.conv2d(d, src, wp, bias, res, o)
+        return o
+    y_ref = conv(x, w3, b3, C, 4 * C, SM_CONV_RELU | SM_CONV_RES_ADD, idt)
+    t1_ref = conv(y_ref, w1, b1, 4 * C, C, SM_CONV_RELU)
+    prep = lambda wt: H.prep_conv_weight(wt.to(dev), wt.shape[1])[0][:wt.shape[0]].contiguous()
+    y = torch.zeros(M + 7, 4 * C, dtype=torch.bfloat16, device=dev)
+    t1n = torch.zeros(M + 7, C, dtype=torch.bfloat16, device=dev)
+    H.conv1x1_pair(M, C, x, prep(w3), b3, idt, y, prep(w1), b1, t1n)
+    torch.cuda.synchronize()
+    assert not bool(y[M:].any()) and not bool(t1n[M:].any())
+    assert torch.equal(y[:M].view(torch.int16), y_ref.view(torch.int16))
+    assert torch.equal(t1n[:M].view(torch.int16), t1_ref.view(torch.int16))
+    r3 = torch.relu(x.float().cpu() @ w3.view(4 * C, C).t() + b3.cpu() + idt.float().cpu())
+    torch.testing.assert_close(y[:M].float().cpu(), r3, rtol=1e-2, atol=2e-2)
+
+
 def test_upsample_sum2_vs_torch_and_lat0_by_linearity():
     """sm_upsample_sum2 (round 4): out = [relu](a0 + up2(a1) + up4(a2)), bilinear align_corners=False, against
     F.interpolate -- bf16 rows (one rounding), f32 rows (1e-6), the split layout [hi | lo | hi] (hi + lo == f32 value to 2^-21) --

@@ -104,7 +104,9 @@ def conv_rows(eng):
                          gflop=c.flops / 1e9, mb=c.bytes / 1e6))
     for t in eng.fused:                                   # bottleneck.hip: conv2 + conv3 (+ next conv1) per launch
         rows.append(dict(name=t.name, kind="fused", shape="tail", blocks=0, waves=0.0,
-                         note="conv2+conv3%s in one launch" % ("+next conv1" if t.w1n is not None else ""),
+                         note=("conv3+next conv1 in one launch" if getattr(t, "convs_in_launch", 0) == 2 and not hasattr(t, "w2") else
+                               "conv2+conv3%s%s in one launch" % ("+shortcut conv" if t.x_block is not None else "",
+                                                                  "+next conv1" if t.w1n is not None else "")),
                          gflop=t.flops / 1e9, mb=t.bytes / 1e6))
     return rows
 
