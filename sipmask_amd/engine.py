@@ -49,6 +49,7 @@ _RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"
 # FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes
 # the shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
 # shapes), "0" = three launches (A/B)
+_LATENCY_1X1 = os.environ.get("SIPMASK_LATENCY_1X1", "")
 # A/B: layer3's conv3 + next conv1 as one launch (sm_conv1x1_pair).  Off: bit-identical, but the launch takes as long as the two
 # it replaces (0.079 vs 0.041 + 0.033 ms) and the pipelined step does not move (1 472-1 496 both ways); DESIGN section 6
 _PAIR_1X1 = os.environ.get("SIPMASK_PAIR_1X1", "0") != "0"
@@ -606,6 +607,10 @@ class SipMaskEngine:
             self._add("maxpool", (lambda s=stem, y=x: pool(s, y, B, h1, w1, 64)))
         # ---- residual stages (caffe style: stride on conv1, resnet.py:125-130)
         cur, ch, cw, cc = x, h2, w2, 64
+        # A/B (SIPMASK_LATENCY_1X1 = "256", "256,512" ...): the 1x1 convs of those stages keep the latency-shaped plan inside
+        # pipelined slots (no big-tile flag: 64 x 64 tiles, four blocks per CU) like lat2 / P6 / P7
+        lat_planes = [int(v) for v in _LATENCY_1X1.split(",") if v]
+        lat_1x1 = lambda pl: (True if (getattr(self, "extra_conv_flags", 0) and pl in lat_planes) else None)
         feats = []
         chained_t1 = None
         for li, nblocks in enumerate(ARCH[self.depth]):
@@ -638,7 +643,7 @@ class SipMaskEngine:
                 else:
                     t1 = self._buf(B * oh * ow, planes)
                     self._add_conv(_Conv(self, p + ".conv1", wa, ba, B, [(ch, cw)], [0], cur, cc, s, 0, t1, [0], planes,
-                                         flags=SM_CONV_RELU))
+                                         flags=SM_CONV_RELU, split_k=lat_1x1(planes)))
                 wb, bb = fold_bn(sd[p + ".conv2.weight"], sd, p + ".bn2")
                 wc, bc = fold_bn(sd[p + ".conv3.weight"], sd, p + ".bn3")
                 out = self._buf(B * oh * ow, planes * 4)
@@ -692,7 +697,7 @@ class SipMaskEngine:
                 else:
                     self._add_conv(_Conv(self, p + ".conv3", wc, bc, B, [(oh, ow)], [0], t2, planes, 1, 0, out, [0],
                                          planes * 4, flags=SM_CONV_RELU | SM_CONV_RES_ADD, residual=idt,
-                                         res_cstride=planes * 4))
+                                         res_cstride=planes * 4, split_k=lat_1x1(planes)))
                 cur, ch, cw, cc = out, oh, ow, planes * 4
             feats.append((cur, ch, cw, cc))
         self.backbone_feats = feats

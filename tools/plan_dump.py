@@ -125,7 +125,7 @@ def main():
     rows = {r["name"]: r for r in conv_rows(eng)}
     print("# %s, batch %d%s, %dx%d: %d steps, %d conv launches (+ %d fused bottleneck tails), %.1f conv GFLOP per step" % (
         args.variant, args.batch, " (one chain of a SubBatchPlan)" if args.sub_plan else (" (one slot of a PipelinedPlan)" if args.pipelined else ""), args.hw[0], args.hw[1],
-        len(eng.steps), len(eng.convs), len(eng.fused), sum(r["gflop"] for r in rows.values())))
+        len(eng.steps), len(eng.convs), len(eng.fused), eng.total_conv_flops() / 1e9))
     print("# lane | step | kernel | tile (cout x pos) | blocks | blocks / resident slots (256 CUs x 1, 2 or 4) | GFLOP | "
           "algorithmic MB | notes")
     for (label, _), lane in zip(eng.steps, eng.lanes):
