@@ -23,6 +23,13 @@
 
 #include "common.h"
 
+// ablation switches of the 1x1 pair's microbenchmark: compiled in with `make EXPERIMENTS=1` only
+#ifdef SM_EXPERIMENTS
+#define BT_DBG(a) ((a).dbg)
+#else
+#define BT_DBG(a) 0
+#endif
+
 namespace {
 
 struct BtArgs {
@@ -35,6 +42,7 @@ struct BtArgs {
   const uint16_t* xds;   // CDS > 0: the block input rows [batch * dsH * dsW][CDS] the shortcut conv reads (at stride ds_stride);
                          // w3 = [4C][C + CDS], b3 = b3 + b_downsample
   int ds_stride, dsH, dsW;
+  int dbg;               // SM_EXPERIMENTS: ablation mask of the 1x1 pair (tools/r4 microbench); 0 in the library's own launches
   uint16_t* y;           // block output [M][4C]
   const uint16_t* w1n;   // next conv1   [C][4C] or null
   const float* b1n;
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
   for (int p = 0; p < NPASS; ++p) {
     unsigned char* const buf = (p & 1) ? bufB : bufA;
     __syncthreads();                             // slice p has landed; the other buffer's readers (pass p-1) are done
-    if (p + 1 < NPASS) {
+    if (p + 1 < NPASS && !(BT_DBG(a) & 2)) {
       dma_w3_slice(p + 1, (p & 1) ? bufA : bufB);
       if constexpr (CHAIN1) dma_w1_slice(p + 1, w1buf + ((p + 1) & 1) * W1B);
     }
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
           rv[ct][qp] = rvn[ct][qp];
-          if (p + 1 < NPASS)
+          if (p + 1 < NPASS && !(BT_DBG(a) & 4))
             rvn[ct][qp] = *reinterpret_cast<const u32x4*>(a.res + orow + (p + 1) * SL + ct * 32 + 16 * qp + 8 * khalf);
         }
     }
@@ -347,10 +355,10 @@ __global__ __launch_bounds__(256, OCC) void bottleneck_tail_kernel(const BtArgs 
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         const u32x4 packed = pack_bf16x8_v(v);
-        if (mok) *reinterpret_cast<u32x4*>(a.y + orow + c0) = packed;
+        if (mok && !(BT_DBG(a) & 1)) *reinterpret_cast<u32x4*>(a.y + orow + c0) = packed;
         yfr[ct * 2 + qp] = __builtin_bit_cast(bf16x8, packed);
       }
-    if constexpr (CHAIN1) {
+    if (CHAIN1 && !(BT_DBG(a) & 8)) {
       const unsigned char* wb = w1buf + (p & 1) * W1B;
 #pragma unroll
       for (int kk = 0; kk < SL / 16; ++kk) {       // k = p*SL + 16*kk (+ 8*khalf) <-> yfr[kk]
@@ -431,6 +439,7 @@ extern "C" int sm_bottleneck_tail(int batch, int h, int w, int channels, const v
   a.res = (const uint16_t*)identity;
   a.xds = nullptr;
   a.ds_stride = 1, a.dsH = h, a.dsW = w;
+  a.dbg = 0;
   a.y = (uint16_t*)y;
   a.w1n = (const uint16_t*)w1_next;
   a.b1n = b1_next;
@@ -477,6 +486,7 @@ extern "C" int sm_bottleneck_tail_ds(int batch, int h, int w, int channels, cons
   a.res = nullptr;
   a.xds = (const uint16_t*)x_block;
   a.ds_stride = ds_stride, a.dsH = ds_h, a.dsW = ds_w;
+  a.dbg = 0;
   a.y = (uint16_t*)y;
   a.w1n = (const uint16_t*)w1_next;
   a.b1n = b1_next;
@@ -509,6 +519,13 @@ extern "C" int sm_conv1x1_pair(long long rows, int channels, const void* x, cons
   a.res = (const uint16_t*)identity;
   a.xds = nullptr;
   a.ds_stride = 1, a.dsH = 1, a.dsW = 1;
+  {
+    static const int dbg = [] {
+      const char* e = getenv("SIPMASK_PAIR_DEBUG");
+      return e ? atoi(e) : 0;
+    }();
+    a.dbg = dbg;
+  }
   a.y = (uint16_t*)y;
   a.w1n = (const uint16_t*)w1_next;
   a.b1n = b1_next;
