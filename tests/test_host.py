@@ -465,3 +465,33 @@ def test_launch_plan_decisions_at_the_baseline_shape():
         assert not (convs[n].desc.flags & big), n                              # ... except the three launch-latency-shaped convs
     gf = eng.total_conv_flops() / 1e9
     assert abs(gf - (1803.7 - 29.7)) < 0.5, gf
+
+
+def test_round4_weight_layouts_of_the_new_kernels():
+    """Host-side operand layouts of the round-4 kernels, checked element by element against their definitions (no GPU):
+    sm_stem_fused's [64][7][8][4] weights (kw = 7 and cin = 3 slots zero), sm_conv3x3_smallco's MFMA A fragments
+    [cin / 32][9][2][64][8] (lane = 32 * khalf + cout row, channel = 32 * slice + 16 * half + 8 * khalf + e), and the
+    [w3 | w_downsample] rows + summed bias of the fused-shortcut bottleneck tail."""
+    import torch
+    from sipmask_amd import hip_ops as H
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(64, 3, 7, 7, generator=g)
+    ws = H.prep_stem_weight(w).float()
+    assert tuple(ws.shape) == (64, 7, 8, 4)
+    assert float(ws[:, :, 7].abs().max()) == 0 and float(ws[..., 3].abs().max()) == 0
+    for co, kh, kw, c in ((0, 0, 0, 0), (63, 6, 6, 2), (17, 3, 5, 1)):
+        assert float(ws[co, kh, kw, c]) == float(w[co, c, kh, kw].to(torch.bfloat16))
+    with pytest.raises(ValueError):
+        H.prep_stem_weight(torch.zeros(64, 3, 3, 3))
+    co_, ci = 24, 96
+    w2 = torch.randn(co_, ci, 3, 3, generator=g)
+    wf = H.prep_conv_weight_smallco(w2).float()
+    assert tuple(wf.shape) == (ci // 32, 9, 2, 64, 8)
+    for (m, ch, kh, kw) in ((0, 0, 0, 0), (23, 95, 2, 2), (5, 40, 1, 2), (11, 63, 0, 1)):
+        sl, r = divmod(ch, 32)
+        half, r = divmod(r, 16)
+        khalf, e = divmod(r, 8)
+        assert float(wf[sl, kh * 3 + kw, half, 32 * khalf + m, e]) == float(w2[m, ch, kh, kw].to(torch.bfloat16))
+    assert float(wf[:, :, :, 24:32].abs().max()) == 0 and float(wf[:, :, :, 56:64].abs().max()) == 0      # cout rows 24..31: padding
+    with pytest.raises(ValueError):
+        H.prep_conv_weight_smallco(torch.zeros(40, 64, 3, 3))
