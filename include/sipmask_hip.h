@@ -71,6 +71,7 @@ typedef enum {
 #define SM_CONV_DBG_TILE256 0x00400000u      /* 256x256 tiles on 8 waves, 1 block per CU (64-wide K steps, cout_pad % 256 == 0) */
 #define SM_CONV_DBG_HAND_PLACED 0x00040000u  /* with TILE256: hand-placed K step, LDS-DMA pieces between the MFMAs */
 #define SM_CONV_DBG_PATCH_UNIFORM 0x00004000u  /* sm_conv3x3_patch: every tile 256 positions (no 128/192-position finishing tiles) */
+#define SM_CONV_DBG_NO_PIPE 0x00002000u     /* sm_deform_conv2d_x3, A/B switch: every K step blends its own first operand */
 #define SM_CONV_DBG_NO_SPLITK 0x00010000u   /* sm_conv2d_ws never splits K */
 /* Operand type.  Default: bf16 operands (x, w), v_mfma_f32_32x32x16_bf16.  SM_CONV_F16: x and w hold IEEE binary16
  * values and the contraction runs on v_mfma_f32_32x32x16_f16 -- the operand type of the split-precision ("x3") head
@@ -431,6 +432,23 @@ int sm_upsample_bilinear(const void* x, void* y, int batch, int h, int w, int c,
  * of two with d->acc_scale its inverse). */
 int sm_conv2d_f32(const sm_conv_desc* d, const float* x, const float* offset, const float* w, const float* bias,
                   const float* residual, float* y, sm_stream_t stream);
+/* FeatureAlign's deformable conv of the x3 head plan on the LDS-window kernel (csrc/deform_patch_x3.hip, round 5): the
+ * computation of sm_conv2d_f32 + SM_CONV_F16 with offset != NULL (deform_conv_forward_cuda on fp32 tensors,
+ * M/mmdet/ops/dcn/src/deform_conv_cuda.cpp:152-260, deform_conv_cuda_kernel.cu:85-115,191-243, called by
+ * M/mmdet/models/anchor_heads/sipmask_head.py:21-55) for its shape -- 3x3 / stride 1 / pad 1, 64 channels per deformable
+ * group, cout_pad % 256 == 0 -- with the f32 window of half a deformable group resident in LDS instead of four L2 corner
+ * loads per sample.  x: f32 rows; offset: f32 [rows][G*18] in the reference channel order; y: f32 rows;
+ * w_split: binary16 [cout_pad][G*2*9][hi 32 | lo 32] -- per cout row and K step (group g, channel half c, tap t) the 32
+ * channels g*64 + c*32 .. +31 of w[cout][.][t] * s as hi = f16(v), lo = f16(v - hi), s a power of two with
+ * d->acc_scale = 1 / s; epilogue acc * acc_scale + bias, SM_CONV_RELU.  gn_stats != NULL: the output's GroupNorm
+ * statistics [batch][nlev][cout/8][2] in the fixed-point format of sm_conv2d_gn_stats, zeroed by the call.
+ * Samples farther than 3 pixels from their tap leave the window: that wave gathers the tap from global memory (any offset
+ * is handled; a model whose offsets are mostly that large is faster on sm_conv2d_f32).
+ * sm_deform_conv2d_x3_plan (host logic only): out4 = {blocks, 8x32 row tiles, 32x8 column tiles, window pixels}. */
+int sm_deform_conv2d_x3_supported(const sm_conv_desc* d);
+int sm_deform_conv2d_x3_plan(const sm_conv_desc* d, int64_t* out4);
+int sm_deform_conv2d_x3(const sm_conv_desc* d, const float* x, const float* offset, const void* w_split, const float* bias,
+                        float* y, int64_t* gn_stats, sm_stream_t stream);
 /* NCHW f32 image -> NHWC f32 with channels zero padded to cpad (multiple of 4). */
 int sm_nchw_f32_to_nhwc_f32(const float* x, float* y, int batch, int c, int h, int w, int cpad, sm_stream_t stream);
 /* 3x3 stride-2 pad-1 max pool on NHWC f32 (resnet.py:460). */

@@ -24,6 +24,7 @@ SM_CONV_DBG_BIG_TILES = 0x04000000
 SM_CONV_DBG_TILE256 = 0x00400000
 SM_CONV_DBG_HAND_PLACED = 0x00040000
 SM_CONV_DBG_PATCH_UNIFORM = 0x00004000
+SM_CONV_DBG_NO_PIPE = 0x00002000         # sm_deform_conv2d_x3 A/B: every K step blends its own first operand
 SM_CONV_DBG_LDS_EPILOGUE = 0x01000000
 SM_CONV_F16 = 0x00020000                 # IEEE binary16 operands (the x3 head plan), f32 output
 SM_CONV_OUT_X3 = 64                      # ... or the next layer's split operand [hi | lo | hi] (forward descriptors)
@@ -97,6 +98,9 @@ PROTOTYPES = {
     "sm_deform_conv_window_plan": (_I, [C.POINTER(ConvDesc), _P]),
     "sm_conv2d_gn_stats": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_conv2d_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "sm_deform_conv2d_x3_supported": (_I, [C.POINTER(ConvDesc)]),
+    "sm_deform_conv2d_x3_plan": (_I, [C.POINTER(ConvDesc), _P]),
+    "sm_deform_conv2d_x3": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "sm_nchw_f32_to_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "sm_maxpool3x3s2_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sm_groupnorm_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P]),

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/sipmask_hip.h"
 
 #define SM_LAUNCH_CHECK()                         \
@@ -159,6 +161,23 @@ static inline hipError_t sm_zero_async(void* p, size_t bytes, hipStream_t s) {
   const long long nthr = vec ? ((n >> 2) > 4 ? (n >> 2) : 4) : n;
   hipLaunchKernelGGL(sm_zero_u32_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (unsigned int*)p, n, vec);
   return hipGetLastError();
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, DEVICE): the opt-in for launches with more than 64 KB
+// of dynamic LDS is a property of the function on one device, so a process that drives a second GPU (or a second host
+// thread) must not inherit "done" from the first.  One sm_lds_once per kernel (function-local static of the launcher); bit
+// d of `done` = device d has the attribute.  Two threads racing both make the (idempotent) call.
+struct sm_lds_once {
+  std::atomic<unsigned long long> done[4];          // 256 devices
+};
+static inline hipError_t sm_set_max_dynamic_lds(sm_lds_once& o, const void* kern, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) return hipErrorInvalidDevice;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (o.done[dev >> 6].load(std::memory_order_acquire) & bit) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) o.done[dev >> 6].fetch_or(bit, std::memory_order_release);
+  return e;
 }
 
 static inline hipStream_t sm_hip_stream(sm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

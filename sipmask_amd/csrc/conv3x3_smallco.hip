@@ -53,6 +53,10 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// F16: the operands are IEEE binary16 (SM_CONV_F16: the x3 head plan's split tensors [hi | lo | hi] x [hi | hi | lo] -- the
+// kernel never interprets the 16-bit payloads it moves, only the MFMA differs)
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+template <bool F16>
 __global__ __launch_bounds__(64, 2) void conv3x3_smallco_kernel(const SmallCoArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // SC_RING x SC_BUF
   typedef __attribute__((address_space(3))) void lds_void;
@@ -138,7 +142,11 @@ __global__ __launch_bounds__(64, 2) void conv3x3_smallco_kernel(const SmallCoArg
           xf[tp] = *reinterpret_cast<const bf16x8*>(smem + bb + (baddr[tp][tap] ^ (unsigned)(s << 5)));
 #pragma unroll
         for (int tp = 0; tp < SC_TR; ++tp)
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wcur[tap * 2 + s], xf[tp], acc[tp], 0, 0, 0);
+          if constexpr (F16)
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wcur[tap * 2 + s]),
+                                                             __builtin_bit_cast(half8, xf[tp]), acc[tp], 0, 0, 0);
+          else
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wcur[tap * 2 + s], xf[tp], acc[tp], 0, 0, 0);
       }
     }
   };
@@ -214,8 +222,10 @@ bool smallco_ok(const sm_conv_desc* d) {
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dil > 1) return false;
   if (d->cout < 8 || d->cout > 32 || d->cout % 8 != 0 || d->cin < 32 || d->cin % 32 != 0) return false;
   if (d->in_cstride < d->cin || d->in_cstride % 8 != 0) return false;
-  // residual / input ReLU / split-precision operands and outputs: not here (launch-plan selector bits are ignored)
-  if (d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST | SM_CONV_IN_RELU | SM_CONV_OUT_X3 | SM_CONV_F16)) return false;
+  // residual / input ReLU / split-precision outputs: not here (launch-plan selector bits are ignored); binary16 operands
+  // (SM_CONV_F16) with f32 output only
+  if (d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST | SM_CONV_IN_RELU | SM_CONV_OUT_X3)) return false;
+  if ((d->flags & SM_CONV_F16) && !(d->flags & SM_CONV_OUT_F32)) return false;
   if (d->ngroups > 1 || d->w_batch_stride != 0 || d->w_level_stride != 0 || d->deform_groups > 0) return false;
   const int calign = (d->flags & SM_CONV_OUT_F32) ? 4 : 8;        // 16-byte stores
   if (d->out_cstride % calign != 0 || d->out_coff % calign != 0 || d->out_coff + d->cout > d->out_cstride) return false;
@@ -263,7 +273,10 @@ extern "C" int sm_conv3x3_smallco(const sm_conv_desc* d, const void* x, const vo
   a.flags = d->flags;
   a.scale_nch = d->scale_nch;
   a.acc_scale = (d->acc_scale == 0.f) ? 1.f : d->acc_scale;
-  hipLaunchKernelGGL(conv3x3_smallco_kernel, dim3((unsigned)nt), dim3(64), SC_RING * SC_BUF, sm_hip_stream(stream), a);
+  if (d->flags & SM_CONV_F16)
+    hipLaunchKernelGGL(conv3x3_smallco_kernel<true>, dim3((unsigned)nt), dim3(64), SC_RING * SC_BUF, sm_hip_stream(stream), a);
+  else
+    hipLaunchKernelGGL(conv3x3_smallco_kernel<false>, dim3((unsigned)nt), dim3(64), SC_RING * SC_BUF, sm_hip_stream(stream), a);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -63,9 +63,10 @@ _FPN_GROUPED = os.environ.get("SIPMASK_FPN_GROUPED", "auto")
 _LEVEL_CONV_MIN_WORK = float(os.environ.get("SIPMASK_LEVEL_CONV_MIN_WORK", "50"))
 
 
-# FeatureAlign's deformable conv in the x3 head plan: "f32x3" = f32 rows, operands split in the loader, f16 MFMAs (default);
-# "f32" = the exact-f32 MFMA kernel (A/B)
-_X3_FEAT_ALIGN = __import__("os").environ.get("SIPMASK_X3_FEAT_ALIGN", "f32x3")
+# FeatureAlign's deformable conv in the x3 head plan: "window" (default) = the LDS-window kernel csrc/deform_patch_x3.hip where
+# the shape is its own and the offsets stay near (SipMaskEngine._tune_deform); "f32x3" = f32 rows, operands split in the gather
+# loader, f16 MFMAs (the round-3 kernel); "f32" = the exact-f32 MFMA kernel (A/B)
+_X3_FEAT_ALIGN = __import__("os").environ.get("SIPMASK_X3_FEAT_ALIGN", "window")
 
 
 def _lib_flag(name):
@@ -102,8 +103,18 @@ class _Conv:
         # exact-f32 plan (parity mode): f32 operands on v_mfma_f32_32x32x2_f32, every conv output f32
         self.f32 = self.mode in ("f32", "f32x3")            # f32 tensors in HBM: csrc/conv_f32.hip
         self.x3 = self.mode == "x3"
+        self.x3w = self.mode == "x3w"                        # FeatureAlign in the x3 plan on the LDS-window kernel
         acc_scale = 0.0
-        if self.f32:
+        if self.x3w:
+            # f32 rows in / out, [hi | lo] binary16 weights per K step (csrc/deform_patch_x3.hip, round 5)
+            if (offset is None or residual is not None or cin_pad is not None or k != 3 or stride != 1 or pad != 1
+                    or ci != 64 * deform_groups):
+                raise NotImplementedError("x3w: FeatureAlign's deformable 3x3 conv (64 channels per deformable group)")
+            self.x3_scale = H.x3_weight_scale([w])
+            self.w, co_pad = H.prep_deform_weight_x3(w.to(dev), self.x3_scale, deform_groups)
+            flags |= _lib.SM_CONV_F16 | SM_CONV_OUT_F32
+            acc_scale = 1.0 / self.x3_scale
+        elif self.f32:
             cin = cin_pad = ci if ci % 4 == 0 else (ci + 3) // 4 * 4
             if self.mode == "f32x3":
                 # the same kernel with the contraction in split precision (operands split into binary16 halves in the
@@ -142,15 +153,15 @@ class _Conv:
         # 3x3 convs with a handful of output channels on the bf16 plan (sip_mask_lat 512 -> 32, fcos_reg + centerness 256 -> 8):
         # their own kernel (round 4, csrc/conv3x3_smallco.hip: one wave per 2 x 32-position tile, weights straight from L2)
         self.smallco = False
-        if (not self.f32 and not self.x3 and offset is None and residual is None and _SMALLCO_CONV and k == 3 and stride == 1
-                and pad == 1 and co <= 32 and co % 8 == 0 and ci % 32 == 0 and cin == ci
-                and getattr(self, "_patch_groups", 1) == 1):
+        if (not self.f32 and offset is None and residual is None and _SMALLCO_CONV and k == 3 and stride == 1
+                and pad == 1 and co <= 32 and co % 8 == 0 and ci % 32 == 0 and cin == (3 * ci if self.x3 else ci)
+                and getattr(self, "_patch_groups", 1) == 1 and not (self.x3 and (flags & _lib.SM_CONV_OUT_X3))):
             ds = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, 32, k, stride, pad, in_cstride,
                                   out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0, scale_nch, level_scale,
                                   deform_groups, acc_scale=acc_scale)
             if H.conv3x3_smallco_supported(ds):
                 self.smallco = True
-                self.w = H.prep_conv_weight_smallco(w.to(dev))
+                self.w = H.prep_conv_weight_smallco(w.to(dev), x3_scale=self.x3_scale if self.x3 else None)
                 self.desc = ds
         if (not self.smallco and not self.f32 and offset is None and residual is None and _PATCH_CONV and k == 3 and stride == 1
                 and pad == 1 and ci % 64 == 0 and (cin == ci or self.x3)):
@@ -203,22 +214,24 @@ class _Conv:
         # (split_k: None = the engine's rule; True = also inside a pipelined slot -- the FPN's three launch-latency-shaped
         # convs, lat2 / P6 / P7: 6-66 tiles with 32-36 serial K steps, where the reduce launch costs no CU time worth counting)
         want_split = getattr(eng, "split_k", _SPLIT_K) if split_k is None else (bool(split_k) and _SPLIT_K_SMALL_FPN and _SPLIT_K)
-        if not self.f32 and offset is None and want_split and not self.patch:
+        if not self.f32 and offset is None and want_split and not self.patch and not self.smallco:
             pl = H.conv_plan(self.desc)
             if pl["split_k"] > 1:
                 self.ws = torch.empty(pl["workspace_bytes"], dtype=torch.uint8, device=dev)
-        kin = 3 if (self.x3 or self.mode == "f32x3") else 1         # MFMA work: three half products per element product
+        kin = 3 if (self.x3 or self.mode in ("f32x3", "x3w")) else 1   # MFMA work: three half products per element product
         self.flops = 2.0 * sum(batch * h * ww for h, ww in out_sizes) * co * ci * k * k
         self.mfma_flops = self.flops * kin
         # algorithmic HBM bytes: x read once + y written once (+ residual read) + weights
         in_rows = sum(batch * h * ww for h, ww in in_sizes)
         out_rows = sum(batch * h * ww for h, ww in out_sizes)
-        es = 4 if self.f32 else 2
+        es = 4 if (self.f32 or self.x3w) else 2
         self.bytes = (in_rows * cin * es + out_rows * co * (4 if (flags & SM_CONV_OUT_F32 or self.f32) else 2) +
-                      (out_rows * co * es if residual is not None else 0) + self.w.numel() * es)
+                      (out_rows * co * es if residual is not None else 0) + self.w.numel() * (2 if self.x3w else es))
 
     def __call__(self):
-        if self.f32:
+        if self.x3w:
+            H.deform_conv2d_x3(self.desc, self.x, self.offset, self.w, self.bias, self.y, self.gn_stats)
+        elif self.f32:
             H.conv2d_f32(self.desc, self.x, self.offset, self.w, self.bias, self.residual, self.y)
         elif self.smallco:
             H.conv3x3_smallco(self.desc, self.x, self.w, self.bias, self.y)
@@ -360,6 +373,34 @@ class _LevelConv(_Conv):
             self.bias = torch.stack([b.float().to(dev) for b in biases]).contiguous()
             self.desc.bias_level_stride = biases[0].numel()
         self.bytes += sum(p.numel() for p in packed[1:]) * 2
+
+
+class _DeformChoice:
+    """FeatureAlign's deformable conv of the x3 head plan as one plan entry with two kernels behind it: `window`
+    (csrc/deform_patch_x3.hip: the f32 window in LDS, GroupNorm statistics fused; None when the shape is not its own) and
+    `gather` (conv_f32.hip's gather loader).  The active one is chosen once per plan from the data (SipMaskEngine._tune_deform)
+    or adopted from another engine of the same configuration."""
+
+    def __init__(self, window, gather):
+        self.window, self.gather = window, gather
+        self.active = window if window is not None else gather
+
+    def pick(self, kernel):
+        self.active = self.window if (kernel == "window" and self.window is not None) else self.gather
+
+    @property
+    def kernel(self):
+        return "window" if self.active is self.window else "gather"
+
+    @property
+    def fused_stats(self):
+        return self.active is self.window and self.window.gn_stats is not None
+
+    def __getattr__(self, name):          # name, mode, flops, mfma_flops, bytes, desc, ... of the active kernel
+        return getattr(self.__dict__["active"], name)
+
+    def __call__(self):
+        self.active()
 
 
 class MaskRescorer:
@@ -956,14 +997,33 @@ class SipMaskEngine:
         self.offsets = torch.empty(rows, 72, dtype=f32, device=dev)
         self._add("offset", lambda: H.offset_linear(self.reg_out, 8, self.w_off, lv, self.offsets))
         self.aligned = torch.empty(rows, 256, dtype=f32, device=dev)
-        self._add_conv(_Conv(self, "head.feat_align", sd[h + "feat_align.conv_adaption.weight"],
-                             sd.get(h + "feat_align.conv_adaption.bias"), B, sizes, row0, self.cls_feat, 256, 1, 1,
-                             self.aligned, row0, 256, deform_groups=4, offset=self.offsets,
-                             flags=(0 if self.flag_norm else SM_CONV_RELU), mode=_X3_FEAT_ALIGN))
+        fa_args = (self, "head.feat_align", sd[h + "feat_align.conv_adaption.weight"],
+                   sd.get(h + "feat_align.conv_adaption.bias"), B, sizes, row0, self.cls_feat, 256, 1, 1, self.aligned, row0, 256)
+        fa_kw = dict(deform_groups=4, offset=self.offsets, flags=(0 if self.flag_norm else SM_CONV_RELU))
+        # two kernels can run this conv: the LDS-window kernel (csrc/deform_patch_x3.hip, round 5: 0.80 -> 0.3 ms per four
+        # images; its epilogue also produces the GroupNorm statistics) and conv_f32.hip's gather loader, which costs the same
+        # whatever the offsets are.  SIPMASK_X3_FEAT_ALIGN = "window" (default: the window kernel unless the checkpoint's
+        # offsets mostly leave its window -- the bf16 plan's rule, _tune_deform), "f32x3" / "f32" pin the gather kernels.
+        gather = _Conv(*fa_args, mode=("f32" if _X3_FEAT_ALIGN == "f32" else "f32x3"), **fa_kw)
+        window = None
+        if _X3_FEAT_ALIGN not in ("f32", "f32x3"):
+            dq = H.make_conv_desc(B, sizes, sizes, row0, row0, 256, 256, 256, 3, 1, 1, 256, 256, deform_groups=4,
+                                  flags=SM_CONV_OUT_F32 | _lib.SM_CONV_F16)
+            if H.deform_conv2d_x3_supported(dq):
+                window = _Conv(*fa_args, mode="x3w", **fa_kw)
+                if self.flag_norm:
+                    window.gn_stats = self.gn_stats
+        fa = self._fa_conv = _DeformChoice(window, gather)
+        self._add_conv(fa)
+        self._deform_tune = window is not None and _DEFORM_MODE == "auto"
+        if window is not None and _DEFORM_MODE == "1":
+            fa.pick("gather")
+        self.deform_choice = None
         aligned_x3 = torch.empty(rows, 768, dtype=F16, device=dev)
         if self.flag_norm:
             gam, bet = par(h + "feat_align.norm.weight"), par(h + "feat_align.norm.bias")
-            self._add("gn_stats:feat_align", lambda: H.gn_stats_f32_fix(self.aligned, self.gn_stats, lv, 256, 32))
+            # (the window kernel's epilogue has written the statistics already)
+            self._add("gn_stats:feat_align", lambda: None if fa.fused_stats else H.gn_stats_f32_fix(self.aligned, self.gn_stats, lv, 256, 32))
             self._add("gn:feat_align", lambda: H.groupnorm_apply_x3(self.aligned, gam, bet, self.gn_stats, lv, 256, 32, 1e-5,
                                                                     True, y_split=aligned_x3))
         else:
@@ -1312,6 +1372,23 @@ class SipMaskEngine:
         self._deform_tune = False
         c = self._fa_conv
         far = float((self.offsets.abs() > 3.0).float().mean())          # one device->host read, at the first run only
+        if isinstance(c, _DeformChoice):                                # x3 plan: two conv objects instead of a flag
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t = {}
+            for name in ("window", "gather"):
+                c.pick(name)
+                c()
+                e0.record()
+                for _ in range(3):
+                    c()
+                e1.record()
+                torch.cuda.synchronize()
+                t[name] = e0.elapsed_time(e1) / 3
+            pick = "gather" if far > 0.20 else "window"
+            c.pick(pick)
+            self.deform_choice = dict(kernel=pick, offsets_beyond_3px=round(far, 4), window_ms=round(t["window"], 4),
+                                      gather_ms=round(t["gather"], 4))
+            return
         base = c.desc.flags & ~_lib.SM_CONV_DBG_DEFORM_GATHER
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t = {}
@@ -1338,8 +1415,11 @@ class SipMaskEngine:
             return
         self._deform_tune = False
         c = self._fa_conv
-        base = c.desc.flags & ~_lib.SM_CONV_DBG_DEFORM_GATHER
-        c.desc.flags = base | (_lib.SM_CONV_DBG_DEFORM_GATHER if other.deform_choice["kernel"] == "gather" else 0)
+        if isinstance(c, _DeformChoice):
+            c.pick(other.deform_choice["kernel"])
+        else:
+            base = c.desc.flags & ~_lib.SM_CONV_DBG_DEFORM_GATHER
+            c.desc.flags = base | (_lib.SM_CONV_DBG_DEFORM_GATHER if other.deform_choice["kernel"] == "gather" else 0)
         self.deform_choice = dict(other.deform_choice, adopted=True)
 
     # -------------------------------------------------------------------------------- execution

@@ -99,6 +99,50 @@ def prep_conv_weight_patch_x3(w, scale, co_pad=None):
     return out.reshape(co_pad, 9 * ci3).contiguous(), co_pad
 
 
+def prep_deform_weight_x3(w, scale, deform_groups):
+    """[co, 64*G, 3, 3] float -> binary16 [cout_pad][G*2*9][hi 32 | lo 32] for sm_deform_conv2d_x3: per cout row and K step
+    (group g, channel half c, tap t) the 32 channels g*64 + c*32 .. +31 of w * scale as hi = f16(v), lo = f16(v - hi);
+    cout_pad a multiple of 256"""
+    co, ci, kh, kw = w.shape
+    if (kh, kw) != (3, 3) or ci != 64 * deform_groups:
+        raise ValueError("sm_deform_conv2d_x3: 3x3 weights over 64 channels per deformable group")
+    ws = w.float() * scale
+    hi = ws.to(F16)
+    lo = (ws - hi.float()).to(F16)
+    co_pad = (co + 255) // 256 * 256
+    lay = lambda t: t.reshape(co, deform_groups, 2, 32, 9).permute(0, 1, 2, 4, 3)      # [co, g, c, tap, 32]
+    out = torch.zeros(co_pad, deform_groups, 2, 9, 64, dtype=F16, device=w.device)
+    out[:co, ..., :32] = lay(hi)
+    out[:co, ..., 32:] = lay(lo)
+    return out.reshape(co_pad, deform_groups * 18 * 64).contiguous(), co_pad
+
+
+def deform_conv2d_x3_supported(desc):
+    return bool(_lib.load().sm_deform_conv2d_x3_supported(C.byref(desc)))
+
+
+def deform_conv2d_x3_plan(desc):
+    """host logic only: dict(blocks, row_tiles, col_tiles, window_pixels) of sm_deform_conv2d_x3, None when unsupported"""
+    out = (C.c_int64 * 4)()
+    rc = _lib.load().sm_deform_conv2d_x3_plan(C.byref(desc), out)
+    if rc == -4:
+        return None
+    _lib.check(rc, "sm_deform_conv2d_x3_plan")
+    return dict(blocks=int(out[0]), row_tiles=int(out[1]), col_tiles=int(out[2]), window_pixels=int(out[3]))
+
+
+def deform_conv2d_x3(desc, x, offset, w_split, bias, y, gn_stats=None):
+    """FeatureAlign's deformable conv in split precision on the LDS-window kernel: f32 rows in / out, binary16 [hi | lo]
+    weights of prep_deform_weight_x3, optional fused GroupNorm statistics (sm_deform_conv2d_x3)"""
+    _lib.require_cuda(x, offset, w_split, y)
+    _check_gn_stats(gn_stats)
+    if x.dtype != torch.float32 or y.dtype != torch.float32 or offset.dtype != torch.float32 or w_split.dtype != F16:
+        raise ValueError("deform_conv2d_x3: f32 rows / offsets, binary16 split weights")
+    _lib.check(_lib.load().sm_deform_conv2d_x3(C.byref(desc), _lib.ptr(x), _lib.ptr(offset), _lib.ptr(w_split), _lib.ptr(bias),
+                                               _lib.ptr(y), _lib.ptr(gn_stats), _lib.stream_ptr()), "sm_deform_conv2d_x3")
+    return y
+
+
 def split3_f16(x, y, channels=None, ctot=None, coff=0):
     """x: f32 or bf16 rows [rows, >= channels] -> y binary16 [rows, 3*ctot]: [hi | lo | hi] of x's first `channels` channels at
     channel offset coff of each third (sm_split3_f16)"""
@@ -222,9 +266,13 @@ def conv3x3_smallco_tiles(desc):
     return sum(desc.batch * -(-desc.in_h[l] // 2) * -(-desc.in_w[l] // 32) for l in range(desc.nlev))
 
 
-def prep_conv_weight_smallco(w):
+def prep_conv_weight_smallco(w, x3_scale=None):
     """[co <= 32, ci % 32 == 0, 3, 3] -> the A fragments of sm_conv3x3_smallco: bf16 [ci / 32][9][2][64][8] with
-    lane = 32 * khalf + cout row (rows >= co zero) and channel = 32 * slice + 16 * half + 8 * khalf + e."""
+    lane = 32 * khalf + cout row (rows >= co zero) and channel = 32 * slice + 16 * half + 8 * khalf + e.
+    x3_scale: the split-precision operand instead -- binary16 fragments of [w_hi | w_hi | w_lo] * scale over 3 * ci channels
+    (SM_CONV_F16; pairs with activations laid out [hi | lo | hi])."""
+    if x3_scale is not None:
+        w = _x3_halves(w, x3_scale).float()
     co, ci, kh, kw = w.shape
     if kh != 3 or kw != 3 or co > 32 or ci % 32 != 0:
         raise ValueError("sm_conv3x3_smallco: 3x3, cout <= 32, cin % 32 == 0")
@@ -232,7 +280,7 @@ def prep_conv_weight_smallco(w):
     w32[:co] = w.float().reshape(co, ci, 9)
     # ci = slice*32 + half*16 + khalf*8 + e  ->  [m, slice, half, khalf, e, tap] -> [slice, tap, half, khalf, m, e]
     f = w32.view(32, ci // 32, 2, 2, 8, 9).permute(1, 5, 2, 3, 0, 4).contiguous()
-    return f.view(ci // 32, 9, 2, 64, 8).to(torch.bfloat16).contiguous()
+    return f.view(ci // 32, 9, 2, 64, 8).to(F16 if x3_scale is not None else torch.bfloat16).contiguous()
 
 
 def conv3x3_smallco(desc, x, w_frag, bias, y):

@@ -293,7 +293,7 @@ def test_x3_head_matches_the_fp32_oracle_on_identical_features(head_case):
     c = head_case
     hsd = {k: v for k, v in c["sd"].items() if k.startswith("bbox_head.")}
     eng = SipMaskEngine.for_head(hsd, c["B"], c["sizes"], img_shape=(192, 256, 3), precision="head_x3")
-    assert all(cv.mode in ("x3", "f32x3") for cv in eng.convs) and sum(cv.mode == "f32x3" for cv in eng.convs) == 1
+    assert all(cv.mode in ("x3", "x3w") for cv in eng.convs) and sum(cv.mode == "x3w" for cv in eng.convs) == 1
     eng.load_pyramid([f.cuda() for f in c["feats"]])
     eng.run_head(with_post=True)
     torch.cuda.synchronize()

@@ -495,3 +495,23 @@ def test_round4_weight_layouts_of_the_new_kernels():
     assert float(wf[:, :, :, 24:32].abs().max()) == 0 and float(wf[:, :, :, 56:64].abs().max()) == 0      # cout rows 24..31: padding
     with pytest.raises(ValueError):
         H.prep_conv_weight_smallco(torch.zeros(40, 64, 3, 3))
+
+
+def test_deform_x3_tile_plan_host_logic():
+    """pure host arithmetic (sm_deform_conv2d_x3_plan): column tiles replace the row tiles of a level's right-hand strip
+    when they are fewer -- BASELINE's pyramid (100x168 ... 7x11) is 98 tiles per image instead of 110"""
+    from sipmask_amd import hip_ops as H, _lib
+    S = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    lv = H.Levels(4, S)
+    d = H.make_conv_desc(4, S, S, lv.row0, lv.row0, 256, 256, 256, 3, 1, 1, 256, 256, deform_groups=4,
+                         flags=_lib.SM_CONV_F16 | _lib.SM_CONV_OUT_F32)
+    p = H.deform_conv2d_x3_plan(d)
+    assert p == dict(blocks=392, row_tiles=4 * (65 + 14 + 4 + 2 + 1), col_tiles=4 * (4 + 6 + 2), window_pixels=640)
+    SIZES = [(40, 72), (19, 45), (10, 23), (33, 8), (2, 3)]
+    lv = H.Levels(2, SIZES)
+    d = H.make_conv_desc(2, SIZES, SIZES, lv.row0, lv.row0, 256, 256, 256, 3, 1, 1, 256, 256, deform_groups=4,
+                         flags=_lib.SM_CONV_F16 | _lib.SM_CONV_OUT_F32)
+    p = H.deform_conv2d_x3_plan(d)
+    assert (p["row_tiles"], p["col_tiles"]) == (2 * (10 + 3 + 2 + 0 + 1), 2 * (2 + 2 + 0 + 2 + 0))
+    d.cin = 128                                   # 32 channels per deformable group: not this kernel's shape
+    assert H.deform_conv2d_x3_plan(d) is None and not H.deform_conv2d_x3_supported(d)

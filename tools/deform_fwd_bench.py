@@ -34,3 +34,39 @@ for B in BS:
             res[name] = sorted(ts)[len(ts) // 2]
         flops = 2.0 * lv.rows * 256 * 2304
         print("B=%d offsets ~N(0,%.1f): " % (B, scale) + "   ".join("%s %.4f ms %.0f TF/s" % (k, v, flops / v / 1e9) for k, v in res.items()))
+
+# ---- the x3 head plan's FeatureAlign (round 5): f32 rows, split-precision contraction.  window = csrc/deform_patch_x3.hip
+# (K loop pipelined across steps / every step self-contained), gather = conv_f32.hip's loader (the round-3 kernel)
+for B in BS:
+    lv = H.Levels(B, LEVELS)
+    x = (torch.randn(lv.rows, 256, device=dev) * 0.5).abs()
+    w = torch.randn(256, 256, 3, 3, device=dev) / 48
+    scale = H.x3_weight_scale([w])
+    w_win, cp = H.prep_deform_weight_x3(w, scale, 4)
+    w_gat, cpg = H.prep_conv_weight_f32(w * scale, 256)
+    y = torch.empty(lv.rows, 256, dtype=torch.float32, device=dev)
+    st = H.gn_stats_alloc(B * 5 * 32, dev)
+    mk = lambda fl, cpad: H.make_conv_desc(B, LEVELS, LEVELS, lv.row0, lv.row0, 256, 256, cpad, 3, 1, 1, 256, 256, flags=fl,
+                                           deform_groups=4, acc_scale=1.0 / scale)
+    F16, F32O = _lib.SM_CONV_F16, _lib.SM_CONV_OUT_F32
+    print("x3 plan:", H.deform_conv2d_x3_plan(mk(F16 | F32O, cp)))
+    for scale_o in SCALES:
+        off = torch.randn(lv.rows, 72, device=dev) * scale_o
+        runs = (("window", lambda d=mk(F16 | F32O, cp): H.deform_conv2d_x3(d, x, off, w_win, None, y, st)),
+                ("window_nopipe", lambda d=mk(F16 | F32O | _lib.SM_CONV_DBG_NO_PIPE, cp): H.deform_conv2d_x3(d, x, off, w_win, None, y, st)),
+                ("gather", lambda d=mk(F16, cpg): H.conv2d_f32(d, x, off, w_gat, None, None, y)))
+        res = {}
+        for name, fn in runs:
+            ts = []
+            for rnd in range(4):
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd:
+                    ts.append(e0.elapsed_time(e1) / 10)
+            res[name] = sorted(ts)[len(ts) // 2]
+        flops = 2.0 * lv.rows * 256 * 2304
+        print("x3 B=%d offsets ~N(0,%.1f): " % (B, scale_o) +
+              "   ".join("%s %.4f ms %.0f TF/s (x3 MFMA work %.0f)" % (k, v, flops / v / 1e9, 3 * flops / v / 1e9) for k, v in res.items()))
