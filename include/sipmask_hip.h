@@ -71,7 +71,6 @@ typedef enum {
 #define SM_CONV_DBG_TILE256 0x00400000u      /* 256x256 tiles on 8 waves, 1 block per CU (64-wide K steps, cout_pad % 256 == 0) */
 #define SM_CONV_DBG_HAND_PLACED 0x00040000u  /* with TILE256: hand-placed K step, LDS-DMA pieces between the MFMAs */
 #define SM_CONV_DBG_PATCH_UNIFORM 0x00004000u  /* sm_conv3x3_patch: every tile 256 positions (no 128/192-position finishing tiles) */
-#define SM_CONV_DBG_NO_PIPE 0x00002000u     /* sm_deform_conv2d_x3, A/B switch: every K step blends its own first operand */
 #define SM_CONV_DBG_NO_SPLITK 0x00010000u   /* sm_conv2d_ws never splits K */
 /* Operand type.  Default: bf16 operands (x, w), v_mfma_f32_32x32x16_bf16.  SM_CONV_F16: x and w hold IEEE binary16
  * values and the contraction runs on v_mfma_f32_32x32x16_f16 -- the operand type of the split-precision ("x3") head

@@ -24,7 +24,6 @@ SM_CONV_DBG_BIG_TILES = 0x04000000
 SM_CONV_DBG_TILE256 = 0x00400000
 SM_CONV_DBG_HAND_PLACED = 0x00040000
 SM_CONV_DBG_PATCH_UNIFORM = 0x00004000
-SM_CONV_DBG_NO_PIPE = 0x00002000         # sm_deform_conv2d_x3 A/B: every K step blends its own first operand
 SM_CONV_DBG_LDS_EPILOGUE = 0x01000000
 SM_CONV_F16 = 0x00020000                 # IEEE binary16 operands (the x3 head plan), f32 output
 SM_CONV_OUT_X3 = 64                      # ... or the next layer's split operand [hi | lo | hi] (forward descriptors)

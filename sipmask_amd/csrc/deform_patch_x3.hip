@@ -23,6 +23,7 @@
 #include <utility>
 
 #include "common.h"
+#include "experiments.h"
 
 namespace {
 
@@ -77,10 +78,9 @@ __device__ __forceinline__ int dx_xcd_tile(int b, int nblk) {
   return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
 }
 
-// PIPE: the operand of the NEXT K step's first sub-step is blended under the MFMAs of this step's last sub-step whenever
-// the next step reads the same window (8 of 9 steps), so that a step does not open with set-up + LDS round trip + blend
-// in front of its first MFMA.  PIPE = false keeps every step self-contained (A/B; tools/deform_fwd_bench.py).
-template <bool PIPE>
+// ABL: ablations for the micro-benchmark (wrong results by construction; `make EXPERIMENTS=1` only): 1 no corner reads /
+// blend / set-up in the steps (a constant operand), 2 no weight DMA in the K loop, 4 no MFMAs and no fragment reads.
+template <int ABL>
 __global__ __launch_bounds__(DX_THREADS, 1) void deform_patch_x3_kernel(const DeformX3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [W stage 0][W stage 1][window]
   typedef __attribute__((address_space(3))) void lds_void;
@@ -182,7 +182,6 @@ __global__ __launch_bounds__(DX_THREADS, 1) void deform_patch_x3_kernel(const De
   struct Tap {
     float w1, w2, w3, w4;
     int c1, c2, c3, c4;           // LDS byte addresses of the four corners, channels khalf*8 .. +3 of sub-step 0
-    int hlo, wlo, gofs;           // the sample's top-left pixel in the image and the channel offset (fallback only)
     bool far;                     // wave-uniform: some lane samples outside the LDS window
   };
   auto setup = [&](Tap& t, int g_, int ch_, int tap_, float2 off) {
@@ -212,55 +211,63 @@ __global__ __launch_bounds__(DX_THREADS, 1) void deform_patch_x3_kernel(const De
     t.c2 = (a1 + 128) ^ ((((p1 + 1) >> 1) & 7) * 16);
     t.c3 = (a1 + PW * 128) ^ ((((p1 + PW) >> 1) & 7) * 16);
     t.c4 = (a1 + PW * 128 + 128) ^ ((((p1 + PW + 1) >> 1) & 7) * 16);
-    t.hlo = h_low, t.wlo = w_low, t.gofs = g_ * 64 + ch_ * 32 + khalf * 8;
   };
-  // corners of half hf (4 channels) of sub-step kk (16 channels: this lane's 8 are kk*16 + khalf*8 .. +7).
-  // Fallback arm: this tap's corners come from global memory for the whole wave (clamped addresses, the weights carry the
-  // zero padding); the empty asm makes its results register-defined, so that the code after the join never waits on
-  // vmcnt -- that counter is in order, and the next K step's weight DMA is in flight on it.
-  auto corners = [&](const Tap& t, int kk, int hf, f32x4 (&q)[4]) {
+  // the 4 channels kk*16 + khalf*8 + hf*4 .. +3 of the four corners, from the LDS window ...
+  auto corners_lds = [&](const Tap& t, int kk, int hf, f32x4 (&q)[4]) {
     const int x = kk * 64 + hf * 16;
     q[0] = *reinterpret_cast<lds_f32x4*>(smem3 + (t.c1 ^ x));
     q[1] = *reinterpret_cast<lds_f32x4*>(smem3 + (t.c2 ^ x));
     q[2] = *reinterpret_cast<lds_f32x4*>(smem3 + (t.c3 ^ x));
     q[3] = *reinterpret_cast<lds_f32x4*>(smem3 + (t.c4 ^ x));
-    if (t.far) {
-      int W_l = W;
-      asm volatile("" : "+s"(W_l));                       // opaque: keeps this arm's address arithmetic inside the arm
-      const int hl = min(max(t.hlo, 0), H - 1), hh_ = min(max(t.hlo + 1, 0), H - 1);
-      const int wl = min(max(t.wlo, 0), W_l - 1), wh_ = min(max(t.wlo + 1, 0), W_l - 1);
-      const float* const gp = ximg + t.gofs + kk * 16 + hf * 4;
-      q[0] = *reinterpret_cast<const f32x4*>(gp + (long long)(hl * W_l + wl) * a.in_cstride);
-      q[1] = *reinterpret_cast<const f32x4*>(gp + (long long)(hl * W_l + wh_) * a.in_cstride);
-      q[2] = *reinterpret_cast<const f32x4*>(gp + (long long)(hh_ * W_l + wl) * a.in_cstride);
-      q[3] = *reinterpret_cast<const f32x4*>(gp + (long long)(hh_ * W_l + wh_) * a.in_cstride);
-      asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
-    }
   };
-  // blend of 4 channels in f32: ((w1*f1 + w2*f2) + w3*f3) + w4*f4 with the products contracted into FMAs, the expression of
-  // conv_f32.hip's deformable loader; then the split of split_x3.hip (hi = f16(v) saturated, lo = f16(v - hi))
-  auto blend_split = [&](const Tap& t, const f32x4 (&q)[4], int hf, half8& xhi, half8& xlo) {
-    const f32x4 r = t.w1 * q[0] + t.w2 * q[1] + t.w3 * q[2] + t.w4 * q[3];
+  // ... or, for a wave with a sample outside the window, from global memory (clamped addresses: the weights carry the zero
+  // padding; the top-left pixel is recomputed from the offset -- this path keeps nothing in the fast path's registers).
+  // Only the far K step of that wave takes this path.
+  auto corners_global = [&](int g_, int ch_, int tap_, float2 off, int kk, int hf, f32x4 (&q)[4]) {
+    const int kh = tap_ / 3, kw = tap_ - kh * 3;
+    const float h_im = (float)(oy - 1 + kh) + off.x, w_im = (float)(ox - 1 + kw) + off.y;
+    const bool inr = pvalid && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+    const int hlo = inr ? (int)floorf(h_im) : 0, wlo = inr ? (int)floorf(w_im) : 0;
+    const int hl = min(max(hlo, 0), H - 1), hh_ = min(max(hlo + 1, 0), H - 1);
+    const int wl = min(max(wlo, 0), W - 1), wh_ = min(max(wlo + 1, 0), W - 1);
+    const float* const gp = ximg + g_ * 64 + ch_ * 32 + khalf * 8 + kk * 16 + hf * 4;
+    q[0] = *reinterpret_cast<const f32x4*>(gp + (long long)(hl * W + wl) * a.in_cstride);
+    q[1] = *reinterpret_cast<const f32x4*>(gp + (long long)(hl * W + wh_) * a.in_cstride);
+    q[2] = *reinterpret_cast<const f32x4*>(gp + (long long)(hh_ * W + wl) * a.in_cstride);
+    q[3] = *reinterpret_cast<const f32x4*>(gp + (long long)(hh_ * W + wh_) * a.in_cstride);
+  };
+  // blend of 8 channels in f32, two at a time (v_pk_mul_f32 / v_pk_fma_f32 with the weight broadcast by op_sel):
+  // ((w1*f1 + w2*f2) + w3*f3) + w4*f4, the expression of conv_f32.hip's deformable loader; then the split of split_x3.hip:
+  // hi = f16(v) saturated (one v_cvt_pk_f16_f32 per pair), lo = f16(v - hi) (v_fma_mixlo/hi_f16: the binary16 hi read as
+  // a source of an f32 fma whose result is rounded once to binary16 -- v - hi is exact in f32)
+  auto blend_split = [&](const Tap& t, const f32x4 (&q)[4], int hf, u32x4& xhi, u32x4& xlo) {
+    const f32x2 w1v = {t.w1, t.w1}, w2v = {t.w2, t.w2}, w3v = {t.w3, t.w3}, w4v = {t.w4, t.w4};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float cl = fminf(fmaxf(r[e], -65504.f), 65504.f);
-      const _Float16 h = (_Float16)cl;
-      xhi[hf * 4 + e] = h;
-      xlo[hf * 4 + e] = (_Float16)(cl - (float)h);
+    for (int d = 0; d < 2; ++d) {
+      const f32x2 v1 = {q[0][2 * d], q[0][2 * d + 1]}, v2 = {q[1][2 * d], q[1][2 * d + 1]};
+      const f32x2 v3 = {q[2][2 * d], q[2][2 * d + 1]}, v4 = {q[3][2 * d], q[3][2 * d + 1]};
+      const f32x2 r = w1v * v1 + w2v * v2 + w3v * v3 + w4v * v4;
+      const float c0 = fminf(fmaxf(r[0], -65504.f), 65504.f), c1 = fminf(fmaxf(r[1], -65504.f), 65504.f);
+      uint32_t hh, ll;
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hh) : "v"(c0), "v"(c1));
+      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ll) : "v"(hh), "v"(c0));
+      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(ll) : "v"(hh), "v"(c1));
+      xhi[hf * 2 + d] = hh, xlo[hf * 2 + d] = ll;
     }
   };
 
-  // K step index s = (g * 2 + ch) * 9 + tap
+  // K step index s = (g * 2 + ch) * 9 + tap.  Control flow exists only at the start of a step, right behind the barrier,
+  // where no LDS / memory counter is pending: a wave whose tap samples outside the window somewhere (tp.far) gathers both
+  // sub-steps' operands from global memory there; the first step of a window blends its first operand there.
   const int nstep = a.dg * 18;
   dma_patch(0, 0);
   dma_w(0, 0);
-  float2 off_nx = *reinterpret_cast<const float2*>(offp);
+  Tap tp;
+  setup(tp, 0, 0, 0, *reinterpret_cast<const float2*>(offp));
   __syncthreads();
 
-  Tap tp;
-  f32x4 qa[4];
-  half8 xhi, xlo;                                   // operand of the coming sub-step
-  bool have_x = false;                              // PIPE: (xhi, xlo) of this step's sub-step 0 were blended by the step before
+  u32x4 xa_hi, xa_lo, xb_hi, xb_lo;                 // operands of sub-step 0 / 1 as 4 x 2 binary16 (ping-pong: no copies)
+  bool have_x = false;                              // (xa_hi, xa_lo) of this step were blended by the step before
   int g = 0, ch = 0, tap = 0;
   for (int s = 0; s < nstep; ++s) {
     int g1 = g, ch1 = ch, tap1 = tap + 1;
@@ -270,35 +277,26 @@ __global__ __launch_bounds__(DX_THREADS, 1) void deform_patch_x3_kernel(const De
       if (ch1 == 0) ++g1;
     }
     const bool more = s + 1 < nstep;
-    const float2 off = off_nx;                   // requested one step ago: the barrier that closed that step covered it
-    // (in front of the weight DMA: vmcnt is in order, and PIPE reads these offsets in the middle of the step)
-    off_nx = *reinterpret_cast<const float2*>(offp + (more ? (g1 * 9 + tap1) * 2 : 0));   // unconditional: no exec-masked load
-    if (more) dma_w(s + 1, (s + 1) & 1);
+    // the next tap's offsets, requested in front of the weight DMA (vmcnt is in order) and read in the middle of the step
+    const float2 off_nx = *reinterpret_cast<const float2*>(offp + (more ? (g1 * 9 + tap1) * 2 : 0));   // unconditional
+    if (more && !(ABL & 2)) dma_w(s + 1, (s + 1) & 1);
     if (row_live) {
       const int wb = (s & 1) * DX_WSTAGE + wrow_off + ((khalf ^ rs8) * 16);   // hi chunk kk * 2 + khalf: ^ (kk * 32); lo: ^ 64
-      half8 wh[4], wl[4];
       auto frag_addr = [&](int kk, int tc) { return (wb ^ (kk * 32)) + tc * 32 * 128; };
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        wh[t] = *reinterpret_cast<lds_half8*>(smem3 + frag_addr(0, t));
-        wl[t] = *reinterpret_cast<lds_half8*>(smem3 + (frag_addr(0, t) ^ 64));
-      }
-      if (!(PIPE && have_x)) {                    // the blend nothing hides: the first step of a window
-        setup(tp, g, ch, tap, off);
-        corners(tp, 0, 0, qa);
-        blend_split(tp, qa, 0, xhi, xlo);
-        corners(tp, 0, 1, qa);
-        blend_split(tp, qa, 1, xhi, xlo);
-      }
-      corners(tp, 1, 0, qa);
-      half8 xhi_n, xlo_n;
+      half8 wh[4], wl[4];
       // a quad = four cout tiles: 12 MFMAs -- w_hi * x_hi, w_hi * x_lo (w_hi[t] is dead behind it: the next quad's fragment
       // lands in the same registers while the other MFMAs run), w_lo * x_hi (likewise).  Accumulators of one cout tile are
-      // 4 MFMAs apart.  The VALU work handed in as `under` is scheduled between them.
-      auto quad = [&](auto KK, auto Q, auto&& under) {
+      // 4 MFMAs apart.
+      auto quad = [&](auto KK, auto Q, const u32x4& xhi_, const u32x4& xlo_) {
+        const half8 xhi = __builtin_bit_cast(half8, xhi_), xlo = __builtin_bit_cast(half8, xlo_);
         constexpr int kk = decltype(KK)::value, q = decltype(Q)::value;
         constexpr bool reload = !(kk == 1 && q == 1);            // (1, 1): the next fragments belong to the other stage
         constexpr int nkk = q == 1 ? kk + 1 : kk, nq = q ^ 1;
+        if constexpr ((ABL & 4) != 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[q * 4][e] += __uint_as_float(xhi_[e] ^ xlo_[e]);   // keep the operands alive
+          return;
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
           acc[q * 4 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t], xhi, acc[q * 4 + t], 0, 0, 0);
@@ -312,29 +310,67 @@ __global__ __launch_bounds__(DX_THREADS, 1) void deform_patch_x3_kernel(const De
           acc[q * 4 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t], xhi, acc[q * 4 + t], 0, 0, 0);
           if constexpr (reload) wl[t] = *reinterpret_cast<lds_half8*>(smem3 + (frag_addr(nkk, nq * 4 + t) ^ 64));
         }
-        under();
       };
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
-      quad(I0{}, I0{}, [&]() { blend_split(tp, qa, 0, xhi_n, xlo_n); });
-      corners(tp, 1, 1, qa);
-      quad(I0{}, I1{}, [&]() { blend_split(tp, qa, 1, xhi_n, xlo_n); });
-      xhi = xhi_n, xlo = xlo_n;
-      if constexpr (PIPE) {
-        // under the last sub-step: set up the NEXT tap and blend its first operand.  Unconditional (straight-line code that
-        // the scheduler can spread between the MFMAs): when the next step reads another window (tap1 == 0) or does not
-        // exist, the reads stay inside the LDS window (clamped addresses) and the result is dropped (have_x).
-        quad(I1{}, I0{}, [&]() { setup(tp, g1, ch1, tap1, off_nx); });
-        corners(tp, 0, 0, qa);
-        quad(I1{}, I1{}, [&]() { blend_split(tp, qa, 0, xhi_n, xlo_n); });
-        corners(tp, 0, 1, qa);
-        blend_split(tp, qa, 1, xhi_n, xlo_n);
-        xhi = xhi_n, xlo = xlo_n;
-        have_x = more && tap1 != 0;
-      } else {
-        quad(I1{}, I0{}, [&]() {});
-        quad(I1{}, I1{}, [&]() {});
+      if constexpr ((ABL & 4) == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          wh[t] = *reinterpret_cast<lds_half8*>(smem3 + frag_addr(0, t));
+          wl[t] = *reinterpret_cast<lds_half8*>(smem3 + (frag_addr(0, t) ^ 64));
+        }
       }
+      f32x4 cq[4];
+      // (the fragment reads above are in flight while this prologue runs)
+      const bool pre = tp.far;                      // wave-uniform: this tap's operands come from global memory, both sub-steps
+      if (pre) {                                    // rare, and nothing hides it: four dependent L2 round trips
+        const float2 off = *reinterpret_cast<const float2*>(offp + (g * 9 + tap) * 2);
+        corners_global(g, ch, tap, off, 0, 0, cq);
+        blend_split(tp, cq, 0, xa_hi, xa_lo);
+        corners_global(g, ch, tap, off, 0, 1, cq);
+        blend_split(tp, cq, 1, xa_hi, xa_lo);
+        corners_global(g, ch, tap, off, 1, 0, cq);
+        blend_split(tp, cq, 0, xb_hi, xb_lo);
+        corners_global(g, ch, tap, off, 1, 1, cq);
+        blend_split(tp, cq, 1, xb_hi, xb_lo);
+      } else if (!have_x) {                         // first step of a window: nothing hid this blend
+        corners_lds(tp, 0, 0, cq);
+        blend_split(tp, cq, 0, xa_hi, xa_lo);
+        corners_lds(tp, 0, 1, cq);
+        blend_split(tp, cq, 1, xa_hi, xa_lo);
+      }
+      // ---- the step proper: ONE straight-line body (no branch: the scheduler interleaves VALU / LDS / MFMA freely and every
+      // s_waitcnt is exact).  Under sub-step 0's MFMAs the operand of sub-step 1 is blended (kept only when !pre: a select
+      // per register, the window reads of a far tap are clamped and harmless); under sub-step 1's the NEXT tap is set up and
+      // its first operand blended (in-bounds garbage when the next step reads another window or does not exist: have_x).
+      if constexpr ((ABL & 1) != 0) {                // ablation: the MFMA / fragment side alone
+        xb_hi = xa_hi, xb_lo = xa_lo;
+        quad(I0{}, I0{}, xa_hi, xa_lo);
+        quad(I0{}, I1{}, xa_hi, xa_lo);
+        quad(I1{}, I0{}, xb_hi, xb_lo);
+        quad(I1{}, I1{}, xb_hi, xb_lo);
+      } else {
+        u32x4 nb_hi, nb_lo;
+        corners_lds(tp, 1, 0, cq);
+        quad(I0{}, I0{}, xa_hi, xa_lo);
+        blend_split(tp, cq, 0, nb_hi, nb_lo);
+        corners_lds(tp, 1, 1, cq);
+        quad(I0{}, I1{}, xa_hi, xa_lo);
+        blend_split(tp, cq, 1, nb_hi, nb_lo);
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xb_hi[e] = pre ? xb_hi[e] : nb_hi[e];
+          xb_lo[e] = pre ? xb_lo[e] : nb_lo[e];
+        }
+        setup(tp, g1, ch1, tap1, off_nx);             // tp is dead: the next tap
+        corners_lds(tp, 0, 0, cq);
+        quad(I1{}, I0{}, xb_hi, xb_lo);
+        blend_split(tp, cq, 0, xa_hi, xa_lo);
+        corners_lds(tp, 0, 1, cq);
+        quad(I1{}, I1{}, xb_hi, xb_lo);
+        blend_split(tp, cq, 1, xa_hi, xa_lo);
+      }
+      have_x = more && tap1 != 0;                   // (a far next tap recomputes its operands anyway)
     }
     if (tap1 == 0 && more) {                     // the next K step reads another window: every wave is done with this one
       __syncthreads();
@@ -518,10 +554,19 @@ extern "C" int sm_deform_conv2d_x3(const sm_conv_desc* d, const float* x, const 
   if (gn_stats != nullptr &&
       sm_zero_async(gn_stats, sizeof(unsigned long long) * 2 * d->batch * d->nlev * (d->cout / 8), s) != hipSuccess)
     return SM_ERR_LAUNCH;
-  const void* kern = (d->flags & SM_CONV_DBG_NO_PIPE) ? (const void*)deform_patch_x3_kernel<false>
-                                                       : (const void*)deform_patch_x3_kernel<true>;
-  static sm_lds_once once[2];
-  if (sm_set_max_dynamic_lds(once[(d->flags & SM_CONV_DBG_NO_PIPE) ? 0 : 1], kern, DX_LDS) != hipSuccess) return SM_ERR_LAUNCH;
+  const void* kern = (const void*)deform_patch_x3_kernel<0>;
+#ifdef SM_EXPERIMENTS
+  switch (((d->flags & SM_CONV_DBG_DX3_NO_BLEND) ? 1 : 0) | ((d->flags & SM_CONV_DBG_PATCH_NO_DMA) ? 2 : 0) |
+          ((d->flags & SM_CONV_DBG_PATCH_NO_MFMA) ? 4 : 0)) {
+    case 1: kern = (const void*)deform_patch_x3_kernel<1>; break;
+    case 2: kern = (const void*)deform_patch_x3_kernel<2>; break;
+    case 3: kern = (const void*)deform_patch_x3_kernel<3>; break;
+    case 4: kern = (const void*)deform_patch_x3_kernel<4>; break;
+    case 6: kern = (const void*)deform_patch_x3_kernel<6>; break;
+    default: break;
+  }
+#endif
+  if (sm_lds_optin(kern, DX_LDS) != hipSuccess) return SM_ERR_LAUNCH;
   void* kargs[] = {(void*)&a};
   if (hipLaunchKernel(kern, dim3((unsigned)nblk), dim3(DX_THREADS), kargs, DX_LDS, s) != hipSuccess) return SM_ERR_LAUNCH;
   SM_LAUNCH_CHECK();

@@ -36,7 +36,7 @@ for B in BS:
         print("B=%d offsets ~N(0,%.1f): " % (B, scale) + "   ".join("%s %.4f ms %.0f TF/s" % (k, v, flops / v / 1e9) for k, v in res.items()))
 
 # ---- the x3 head plan's FeatureAlign (round 5): f32 rows, split-precision contraction.  window = csrc/deform_patch_x3.hip
-# (K loop pipelined across steps / every step self-contained), gather = conv_f32.hip's loader (the round-3 kernel)
+# gather = conv_f32.hip's loader (the round-3 kernel)
 for B in BS:
     lv = H.Levels(B, LEVELS)
     x = (torch.randn(lv.rows, 256, device=dev) * 0.5).abs()
@@ -53,7 +53,6 @@ for B in BS:
     for scale_o in SCALES:
         off = torch.randn(lv.rows, 72, device=dev) * scale_o
         runs = (("window", lambda d=mk(F16 | F32O, cp): H.deform_conv2d_x3(d, x, off, w_win, None, y, st)),
-                ("window_nopipe", lambda d=mk(F16 | F32O | _lib.SM_CONV_DBG_NO_PIPE, cp): H.deform_conv2d_x3(d, x, off, w_win, None, y, st)),
                 ("gather", lambda d=mk(F16, cpg): H.conv2d_f32(d, x, off, w_gat, None, None, y)))
         res = {}
         for name, fn in runs:
