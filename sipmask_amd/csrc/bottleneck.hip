@@ -19,9 +19,8 @@
 // positions, read straight from HBM into the fragment layout -- so the 4C-channel shortcut tensor is neither written
 // (138 MB at four 800 x 1344 images) nor read back, and its launch disappears.  The shortcut stays f32 until the one
 // rounding of the block output (the two-launch path rounds it to bf16 in between).
-#include <cstdlib>
-
 #include "common.h"
+#include "experiments.h"
 
 // ablation switches of the 1x1 pair's microbenchmark: compiled in with `make EXPERIMENTS=1` only
 #ifdef SM_EXPERIMENTS
@@ -57,7 +56,7 @@ constexpr int BT_SLICE_BYTES = 16384;
 
 // OCC: blocks per CU the register allocation aims for.  The unchained <64> kernel needs 135 VGPRs at OCC 3; capped at 128
 // (OCC 4: four spills outside the loops) a fourth block fits, and these launches are bandwidth-shaped (layer1: 310 MB per
-// 4-image launch): more loads in flight per CU.  A/B: SIPMASK_BT_OCC (3 | 4).
+// 4-image launch): more loads in flight per CU.  (Round 4 A/B of a fourth block: neutral, removed.)
 // SLB: bytes of a conv3 weight slice.  16 KB by default; the CHAINED variants take 8 KB -- half the couts per pass, so half
 // the conv3 accumulators, residual chunks and chained-conv1 B fragments live at a time: 168 VGPRs + spills -> no spills at
 // three blocks per CU (round 4; the chain was "neutral" in round 2 because of exactly that).
@@ -405,13 +404,9 @@ constexpr int bt_lds_bytes(int c2, bool chain, int cds, int slb, bool conv2) {
 template <int C2, bool CHAIN1, int OCC, int CDS = 0, int SLB = BT_SLICE_BYTES, bool CONV2 = true>
 int bt_launch(const BtArgs& a, dim3 grid, hipStream_t s) {
   constexpr int lds = bt_lds_bytes(C2, CHAIN1, CDS, SLB, CONV2);
-  static bool attr_set = false;                 // > 64 KB of dynamic LDS needs the opt-in once per kernel
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS, SLB, CONV2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return SM_ERR_LAUNCH;
-    attr_set = true;
-  }
+  // > 64 KB of dynamic LDS needs the opt-in, once per (kernel, device)
+  if (sm_lds_optin(reinterpret_cast<const void*>(&bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS, SLB, CONV2>), lds) != hipSuccess)
+    return SM_ERR_LAUNCH;
   hipLaunchKernelGGL((bottleneck_tail_kernel<C2, CHAIN1, OCC, CDS, SLB, CONV2>), grid, dim3(256), lds, s, a);
   SM_LAUNCH_CHECK();
   return SM_OK;
@@ -450,16 +445,13 @@ extern "C" int sm_bottleneck_tail(int batch, int h, int w, int channels, const v
   a.M = (int)M;
   const dim3 grid(sm_cdiv(M, BT_BPOS));
   hipStream_t s = sm_hip_stream(stream);
-  static const int occ = [] {
-    const char* e = getenv("SIPMASK_BT_OCC");
-    return (e && atoi(e) == 4) ? 4 : 3;
-  }();
+  // (three blocks per CU: a fourth -- 128 VGPRs, four spills -- measured neutral in round 4 and is gone)
   if (channels == 64) {
     if (chain) return bt_launch<64, true, 3, 0, 8192>(a, grid, s);     // 8 KB slices: see SLB
-    return occ == 4 ? bt_launch<64, false, 4>(a, grid, s) : bt_launch<64, false, 3>(a, grid, s);
+    return bt_launch<64, false, 3>(a, grid, s);
   }
   if (chain) return bt_launch<128, true, 2>(a, grid, s);     // 80 KB of LDS: two blocks per CU whatever the registers -- no cap, no spills
-  return occ == 4 ? bt_launch<128, false, 4>(a, grid, s) : bt_launch<128, false, 3>(a, grid, s);
+  return bt_launch<128, false, 3>(a, grid, s);
 }
 
 /* conv2 + conv3 + the block's 1x1 SHORTCUT conv as one launch: the first bottleneck of layer1 (64 -> 256, stride 1) and of
@@ -519,13 +511,12 @@ extern "C" int sm_conv1x1_pair(long long rows, int channels, const void* x, cons
   a.res = (const uint16_t*)identity;
   a.xds = nullptr;
   a.ds_stride = 1, a.dsH = 1, a.dsW = 1;
-  {
-    static const int dbg = [] {
-      const char* e = getenv("SIPMASK_PAIR_DEBUG");
-      return e ? atoi(e) : 0;
-    }();
-    a.dbg = dbg;
-  }
+#ifdef SM_EXPERIMENTS
+  static const int dbg = sm_experiment_env("SIPMASK_PAIR_DEBUG", 0);
+  a.dbg = dbg;
+#else
+  a.dbg = 0;
+#endif
   a.y = (uint16_t*)y;
   a.w1n = (const uint16_t*)w1_next;
   a.b1n = b1_next;

@@ -840,23 +840,8 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
                   ((d->flags & SM_CONV_DBG_PATCH_NO_DMA) ? 4 : 0) | ((d->flags & SM_CONV_DBG_PATCH_NO_MFMA) ? 8 : 0) |
                   ((d->flags & SM_CONV_DBG_PATCH_PINGPONG) ? 16 : 0);
   auto launch = [&](auto kern, int threads = PT_THREADS) -> int {
-    // the attribute is per kernel, not per launch: set it once to the most any launch can ask for (the call is a driver
-    // round trip -- and two orders of magnitude slower under rocprofv3's API interception)
-    static const void* seen[64];                         // every instantiation has the same pointer type: key by address
-    static int seen_dev[64];                             // ... and by device (one process per GPU is the rule, not a law)
-    static int nseen = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    bool done = false;
-    for (int i = 0; i < nseen; ++i) done = done || (seen[i] == (const void*)kern && seen_dev[i] == dev);
-    if (!done) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return SM_ERR_LAUNCH;
-      if (nseen < 64) {
-        seen[nseen] = (const void*)kern;
-        seen_dev[nseen++] = dev;
-      }
-    }
+    // the attribute is per (kernel, device), not per launch: set once to the most any launch can ask for (common.h)
+    if (sm_lds_optin((const void*)kern, 160 * 1024) != hipSuccess) return SM_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(threads), lds, s, a);
     return SM_OK;
   };

@@ -19,11 +19,10 @@
 // LDS: 2 x 32 KB weights + 80 KB patch (640 pixels x 128 B); the patch is reloaded per group (4 x per tile, exposed).
 // Arithmetic of the bilinear sample is the DEFORM loader's, expression for expression (f32 blend, one rounding to the bf16
 // MFMA operand).
-#include <stdlib.h>
-
 #include <utility>
 
 #include "common.h"
+#include "experiments.h"
 
 namespace {
 
@@ -481,22 +480,13 @@ int sm_deform_patch_launch(const sm_conv_desc* d, const void* x, const float* of
   const long long nblk = (long long)t * a.ntn;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
   a.nblk = (int)nblk;
-  static int attr_dev[16];
-  static int nattr = 0;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  bool done = false;
-  for (int i = 0; i < nattr; ++i) done = done || attr_dev[i] == dev;
   const void* kern = (const void*)deform_patch_kernel<0>;
 #ifdef SM_EXPERIMENTS
-  static const int ablate = getenv("SIPMASK_DEFORM_ABLATE") ? atoi(getenv("SIPMASK_DEFORM_ABLATE")) : 0;
+  static const int ablate = sm_experiment_env("SIPMASK_DEFORM_ABLATE", 0);
   if (ablate == 2) kern = (const void*)deform_patch_kernel<2>;
   if (ablate == 4) kern = (const void*)deform_patch_kernel<4>;
 #endif
-  if (!done) {
-    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS) != hipSuccess) return SM_ERR_LAUNCH;
-    if (nattr < 16) attr_dev[nattr++] = dev;
-  }
+  if (sm_lds_optin(kern, DP_LDS) != hipSuccess) return SM_ERR_LAUNCH;
   void* kargs[] = {(void*)&a};
   if (hipLaunchKernel(kern, dim3((unsigned)nblk), dim3(DP_THREADS), kargs, DP_LDS, stream) != hipSuccess) return SM_ERR_LAUNCH;
   SM_LAUNCH_CHECK();

@@ -983,9 +983,7 @@ extern "C" int sm_det_select(const sm_det_desc* d, const float* cls, const float
   size_t cache_bytes = (size_t)maxn * sizeof(float);
   if (cache_bytes > 128 * 1024) cache_bytes = 0;   // TopkSmem (17 KiB) + cache must fit 160 KiB
   a.topk_cache_floats = (int)(cache_bytes / sizeof(float));
-  if (cache_bytes > 48 * 1024 &&
-      hipFuncSetAttribute((const void*)det_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cache_bytes) !=
-          hipSuccess)
+  if (cache_bytes > 48 * 1024 && sm_lds_optin((const void*)det_topk_kernel, (int)cache_bytes) != hipSuccess)
     return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(det_topk_kernel, dim3(a.nlev, a.batch), dim3(TK_THREADS), cache_bytes, s, keys, cand_pos, a);
   hipLaunchKernelGGL(det_gather_kernel, dim3((a.kmax + 63) / 64, a.batch), dim3(256), 0, s, cls, reg, cof, cand_pos, boxes, scores,
@@ -1058,16 +1056,11 @@ extern "C" int sm_pairs_select(const sm_det_desc* d, float pre_nms_thresh, const
 }
 
 namespace {
-// heavy-class path: classes with more than heavy_min candidates above the score threshold; SIPMASK_NMS_HEAVY_MIN=0
-// turns it off (A/B), slots beyond NMS_HEAVY_SLOTS in one launch stay on the in-block path
+// heavy-class path: classes with more than NMS_HEAVY_MIN candidates above the score threshold; slots beyond
+// NMS_HEAVY_SLOTS in one launch stay on the in-block path
 constexpr int NMS_HEAVY_SLOTS = 32;
-int nms_heavy_min() {
-  static const int v = [] {
-    const char* e = getenv("SIPMASK_NMS_HEAVY_MIN");
-    return e ? atoi(e) : 512;
-  }();
-  return v;
-}
+constexpr int NMS_HEAVY_MIN = 512;
+int nms_heavy_min() { return NMS_HEAVY_MIN; }
 struct HeavyLayout {
   int slots, rows, W;
   size_t off_cnt, off_meta, off_box, off_idx, off_mat, end;
@@ -1097,13 +1090,8 @@ size_t nms_base_bytes(int batch, int kmax, int num_classes) {
 
 template <int WPL, int G>
 int launch_heavy_scan(int slots, size_t lds, hipStream_t s, int32_t* cls_keep, int32_t* cls_cnt, const NmsArgs& a) {
-  static bool attr_done = false;
-  if (lds > 48 * 1024 && !attr_done) {
-    if (hipFuncSetAttribute((const void*)nms_heavy_scan_kernel<WPL, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            144 * 1024) != hipSuccess)
-      return SM_ERR_LAUNCH;
-    attr_done = true;
-  }
+  if (lds > 48 * 1024 && sm_lds_optin((const void*)nms_heavy_scan_kernel<WPL, G>, 144 * 1024) != hipSuccess)
+    return SM_ERR_LAUNCH;
   hipLaunchKernelGGL((nms_heavy_scan_kernel<WPL, G>), dim3(slots), dim3(SCAN_THREADS), lds, s, cls_keep, cls_cnt, a);
   return SM_OK;
 }
@@ -1151,9 +1139,7 @@ extern "C" int sm_multiclass_nms(const float* boxes, const float* scores, const 
   a.hbox = (float4*)(wsb + h.off_box);
   a.hidx = (uint32_t*)(wsb + h.off_idx);
   a.hmat = (unsigned long long*)(wsb + h.off_mat);
-  if (hipFuncSetAttribute((const void*)nms_class_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-      hipSuccess)
-    return SM_ERR_LAUNCH;
+  if (sm_lds_optin((const void*)nms_class_kernel, (int)lds) != hipSuccess) return SM_ERR_LAUNCH;
   if (h.slots > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s, a.heavy_cnt, 1, 0);
   hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(NMS_THREADS), lds, s, boxes, scores, ctr, ncand, cls_keep,
                      cls_cnt, a);
@@ -1217,9 +1203,7 @@ extern "C" int sm_nms(const float* dets, int n, float iou_thr, int64_t* keep, in
   const int P = next_pow2(n);
   const size_t lds = (size_t)P * 28;
   if (lds > 160 * 1024) return SM_ERR_UNSUPPORTED;
-  if (hipFuncSetAttribute((const void*)nms_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-      hipSuccess)
-    return SM_ERR_LAUNCH;
+  if (sm_lds_optin((const void*)nms_single_kernel, (int)lds) != hipSuccess) return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(nms_single_kernel, dim3(1), dim3(NMS_THREADS), lds, s, dets, n, iou_thr, P, keep, nkeep);
   SM_LAUNCH_CHECK();
   return SM_OK;

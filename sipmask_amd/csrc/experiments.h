@@ -3,6 +3,15 @@
 // instantiations out of libsipmask_hip.so; `make EXPERIMENTS=1` brings them back for tools/ab_conv_variants.sh,
 // tools/patch_variants_bench.py and friends.  None of this is declared in include/sipmask_hip.h.
 #pragma once
+// The product library reads NO environment variable: what a caller may choose travels in descriptors and
+// arguments.  The experiment build's ablation masks are the exception, and they go through this one helper.
+#ifdef SM_EXPERIMENTS
+#include <cstdlib>
+static inline int sm_experiment_env(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e ? std::atoi(e) : dflt;
+}
+#endif
 #ifdef SM_EXPERIMENTS
 #define SM_CONV_DBG_LINEAR_TILES 0x40000000u   // disable the XCD-aware tile remap (measured neutral)
 #define SM_CONV_DBG_REG_STAGING 0x20000000u    // register-staged loader instead of LDS-DMA

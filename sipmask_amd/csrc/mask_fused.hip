@@ -17,9 +17,9 @@
 //      box areas.
 // Work decomposition: a plan kernel turns (detections, previous ranges) into a prefix sum of 128x8-pixel output tiles;
 // a fixed grid of blocks walks that list (binary search in an LDS copy of the prefix).
-#include <cstdlib>
 
 #include "common.h"
+#include "experiments.h"
 
 namespace {
 
@@ -472,17 +472,20 @@ extern "C" int sm_mask_assemble_lo(const float* basis_lo, int lo_h, int lo_w, in
   a.per_image = per_image;
   hipStream_t s = sm_hip_stream(stream);
   hipLaunchKernelGGL(mask_plan_kernel, dim3(1), dim3(1024), 0, s, a);
-  static const int variant = [] {
-    const char* e = getenv("SIPMASK_MASK_VARIANT");
-    return e ? atoi(e) & 3 : 2;     // measured (r4c5, 100 image-sized boxes x 4 images): 1.09 / 1.29 / 1.07 / 1.30 ms for 0..3
-  }();
+  // variant 2 of the four stage layouts (measured in round 4 on 100 image-sized boxes x 4 images: 1.09 / 1.29 / 1.07 / 1.30
+  // ms for 0..3, profiles/r04_mask_assemble_variants_ab.txt); the others exist in the experiment build only
   const size_t dyn = (size_t)(src_cap + 4 * lo_cap + 2 * batch * max_num + 1) * sizeof(float);
+#ifdef SM_EXPERIMENTS
+  static const int variant = sm_experiment_env("SIPMASK_MASK_VARIANT", 2) & 3;
   switch (variant) {
     case 1: hipLaunchKernelGGL(mask_fused_kernel<1>, dim3(2048), dim3(MF_THREADS), dyn, s, a); break;
     case 2: hipLaunchKernelGGL(mask_fused_kernel<2>, dim3(2048), dim3(MF_THREADS), dyn, s, a); break;
     case 3: hipLaunchKernelGGL(mask_fused_kernel<3>, dim3(2048), dim3(MF_THREADS), dyn, s, a); break;
     default: hipLaunchKernelGGL(mask_fused_kernel<0>, dim3(2048), dim3(MF_THREADS), dyn, s, a); break;
   }
+#else
+  hipLaunchKernelGGL(mask_fused_kernel<2>, dim3(2048), dim3(MF_THREADS), dyn, s, a);
+#endif
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

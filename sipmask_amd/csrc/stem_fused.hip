@@ -13,7 +13,6 @@
 // Numerics: same rounding points as the three-launch path (image and weights rounded to bf16, f32 accumulation,
 // bias + ReLU in f32, ONE rounding to bf16, max over the rounded values); the K order of the f32 sum differs, so a
 // result can differ from that path by one bf16 ulp where the f32 sums straddle a rounding boundary.
-#include <cstdlib>
 
 #include "common.h"
 
@@ -227,13 +226,7 @@ int launch_stem(StemArgs a, sm_stream_t stream) {
   const long long nt = (long long)a.batch * a.tiles_y * a.tiles_x;
   if (nt > 0x7fffffffll) return SM_ERR_BAD_SHAPE;
   a.ntiles = (int)nt;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)stem_fused_kernel<PR, PC>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) !=
-        hipSuccess)
-      return SM_ERR_LAUNCH;
-    attr_done = true;
-  }
+  if (sm_lds_optin((const void*)stem_fused_kernel<PR, PC>, C::LDS) != hipSuccess) return SM_ERR_LAUNCH;
   const int resident = 256 * (C::THREADS <= 256 ? 2 : 1);          // blocks the chip holds; a multiple of the 8 XCDs
   const int blocks = a.ntiles < resident ? ((a.ntiles + 7) / 8) * 8 : resident;
   hipLaunchKernelGGL((stem_fused_kernel<PR, PC>), dim3(blocks), dim3(C::THREADS), C::LDS, sm_hip_stream(stream), a);
@@ -258,12 +251,7 @@ extern "C" int sm_stem_fused(const float* img, const void* w_stem, const float* 
   a.w1 = (W + 6 - 7) / 2 + 1;
   a.H2 = (a.h1 + 2 - 3) / 2 + 1;
   a.W2 = (a.w1 + 2 - 3) / 2 + 1;
-  static const int small_tile = [] {
-    // A/B: 1 = 4 x 12 pooled positions per tile, two blocks per CU.  Measured SLOWER (0.080 against 0.072 ms for four
-    // 800 x 1344 images, 1 377-1 398 against 1 404-1 413 img/s): the wider halo and twice the per-tile overheads cost
-    // more than the second resident block hides
-    const char* e = getenv("SIPMASK_STEM_TILE");
-    return e ? atoi(e) : 0;
-  }();
-  return small_tile ? launch_stem<4, 12>(a, stream) : launch_stem<8, 14>(a, stream);
+  // (round 4 A/B: 4 x 12 pooled positions per tile at two blocks per CU measured SLOWER -- 0.080 against 0.072 ms for four
+  // 800 x 1344 images: the wider halo and twice the per-tile overheads cost more than the second resident block hides)
+  return launch_stem<8, 14>(a, stream);
 }

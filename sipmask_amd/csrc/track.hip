@@ -334,12 +334,7 @@ extern "C" int sm_track_clip(const float* det_feats, const float* det, const int
     return SM_ERR_BAD_SHAPE;
   const size_t lds = (size_t)(2 * capacity + (TC_THREADS / 64) * (capacity + 1)) * sizeof(float);
   if (lds > 150 * 1024) return SM_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)track_clip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-      return SM_ERR_LAUNCH;
-    attr_set = true;
-  }
+  if (sm_lds_optin((const void*)track_clip_kernel, 150 * 1024) != hipSuccess) return SM_ERR_LAUNCH;
   hipLaunchKernelGGL(track_clip_kernel, dim3(1), dim3(TC_THREADS), lds, sm_hip_stream(stream), det_feats, det, det_labels,
                      ndet, is_first, nframes, max_num, channels, coeff_score, coeff_iou, coeff_label, mem_feats, mem_boxes,
                      mem_labels, mem_count, capacity, comp_ws, ids);

@@ -253,13 +253,7 @@ int wg_launch(WGArgs& a, const sm_conv_desc* d, long long P, hipStream_t s) {
   const long long slice = ((P + S - 1) / S + WG_KC - 1) / WG_KC * WG_KC;
   S = (P + slice - 1) / slice;
   a.slice = (int)slice;
-  static bool attr_done = false;                     // one instance per template instantiation
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)wgrad_direct_kernel<WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) !=
-        hipSuccess)
-      return SM_ERR_LAUNCH;
-    attr_done = true;
-  }
+  if (sm_lds_optin((const void*)wgrad_direct_kernel<WM, WN, TM, TN>, C::LDS) != hipSuccess) return SM_ERR_LAUNCH;
   a.per_slice = (int)tiles;
   const long long nblk = 8 * ((S + 7) / 8) * tiles;          // slices beyond S exit at once
   if (nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;

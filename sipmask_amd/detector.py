@@ -95,18 +95,22 @@ class SipMask(nn.Module):
             key = ("pipelined", batch, tuple(img_hw), tuple(img_shape or ()), sf_key, rescale, precision, ln, in_flight, sfm_key)
             return self._engines.get(key, module_tensors(self), lambda: PipelinedPlan(
                 [build_plan(ln, True) for _ in range(in_flight)]))
-        key = (batch, tuple(img_hw), tuple(img_shape or ()), sf_key, rescale, precision, lanes, sfm_key) + \
-            ((slot, bool(pipelined)) if slot else ())
+        # (slot and pipelined are ALWAYS part of the key: a pipelined plan -- big tiles, no split-K, no side lanes -- must not
+        # share an entry with the latency-shaped plan of the same shape)
+        key = (batch, tuple(img_hw), tuple(img_shape or ()), sf_key, rescale, precision, lanes, sfm_key, int(slot), bool(pipelined))
         # plans are valid for the weights they were built from: PlanCache drops them when any parameter / buffer has
         # been updated in place since (optimizer.step, load_state_dict, mmcv load_checkpoint)
         return self._engines.get(key, module_tensors(self), lambda: build_plan(lanes, pipelined))
 
-    def plan_for_metas(self, batch, img_hw, img_metas, rescale=False, precision="bf16", lanes="auto"):
+    def plan_for_metas(self, batch, img_hw, img_metas, rescale=False, precision="bf16", lanes="auto", in_flight=1):
         """The launch plan for a batch whose images carry their OWN img_shape / scale_factor (a keep_ratio pipeline:
         every image of a batch is resized by a different factor; the reference reads img_metas[img_id],
         sipmask_head.py:517-541).  The plan depends on the batch only through the mask canvas (the smallest scale_factor)
         and the kernels' source-window bound (the largest), both rounded outward to 1/16 so that consecutive batches of
-        an evaluation run share plans; the per-image values go to the device tables (set_image_metas)."""
+        an evaluation run share plans; the per-image values go to the device tables (set_image_metas).
+        in_flight > 1: the engine.PipelinedPlan of that geometry is returned as it is -- its metas travel with every
+        submit(img, img_metas), each slot keeps the tables of the batch it was submitted with (the evaluation loop of
+        M/mmdet/apis/test.py:12-72 over keep_ratio batches: bench.py --config eval_shapes)."""
         import numpy as np
         sfl = [np.asarray(m.get('scale_factor', 1.0), np.float64).reshape(-1) for m in img_metas]
         if any(a.size not in (1, 4) for a in sfl):
@@ -119,8 +123,8 @@ class SipMask(nn.Module):
             lo, hi = float(lo[0]), float(hi[0])
         else:
             lo, hi = lo.astype(np.float32), hi.astype(np.float32)
-        plan = self.prepare(batch, img_hw, None, lo, rescale, precision, lanes, scale_factor_max=hi)
-        return plan.set_image_metas(img_metas)
+        plan = self.prepare(batch, img_hw, None, lo, rescale, precision, lanes, scale_factor_max=hi, in_flight=in_flight)
+        return plan if in_flight > 1 else plan.set_image_metas(img_metas)
 
     def get_masks(self, img, img_metas=None, rescale=False):
         """Batch-capable tensor-only inference (compare before RLE): dict of device tensors

@@ -19,54 +19,57 @@ from . import hip_ops as H
 from ._lib import SM_CONV_RELU, SM_CONV_OUT_F32, SM_CONV_RES_ADD, SM_CONV_RES_NEAREST, SM_CONV_IN_RELU
 
 ARCH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+
+# ---- environment switches of the engine (INTEGRATION.md section 4 lists every SIPMASK_* variable of the package) -----------
+# launch-plan selector bits of include/sipmask_hip.h OR-ed into every conv descriptor (whole-plan experiments, tools/)
 _DEBUG_CONV_FLAGS = int(os.environ.get("SIPMASK_CONV_DEBUG_FLAGS", "0"), 0)
-# cls + reg tower convs of one depth as ONE grouped 256x256-tile launch (measured round 2: 0.2225 ms per pair =
-# 950 TFLOP/s vs 2 x 0.1346 ms = 785 TFLOP/s as two launches; profiles/r02_*); SIPMASK_GROUPED_TOWERS=0 = A/B
-_GROUPED_TOWERS = __import__("os").environ.get("SIPMASK_GROUPED_TOWERS", "1") == "1"
-
-
-_SPLIT_K = __import__("os").environ.get("SIPMASK_SPLIT_K", "1") != "0"     # A/B: split-K for under-filled launches
-_SPLIT_K_SMALL_FPN = __import__("os").environ.get("SIPMASK_SPLIT_K_FPN", "1") != "0"   # A/B: ... of lat2 / P6 / P7 in pipelined slots
-_PATCH_CONV = __import__("os").environ.get("SIPMASK_PATCH_CONV", "1") != "0"   # A/B: patch-resident 3x3 kernel
 # FeatureAlign's deformable conv: the LDS-window kernel (csrc/deform_patch.hip) is 1.3-1.6x the gather loader while the
 # learned offsets stay within ~3 pixels and falls behind it when most waves sample farther out (random offsets of sigma 4:
-# 0.35 vs 0.26 ms at B=4, profiles/r02_deform_conv_microbench.txt); SIPMASK_DEFORM_GATHER=1 keeps a model with such
-# offsets on the gather loader
-# ... so the plan LOOKS: SIPMASK_DEFORM_GATHER = "auto" (default) inspects the offsets of the first eager run of the plan
-# (the checkpoint's own offsets on a real input) and keeps the gather loader where more than 20 % of the offset components
-# reach beyond the window radius (SipMaskEngine._tune_deform); "0" / "1" pin the window kernel / the gather loader.
-_DEFORM_MODE = __import__("os").environ.get("SIPMASK_DEFORM_GATHER", "auto")
+# 0.35 vs 0.26 ms at B=4, profiles/r02_deform_conv_microbench.txt).  "auto" (default) inspects the offsets of the first
+# eager run of the plan (the checkpoint's own offsets on a real input) and keeps the gather loader where more than 20 % of
+# the offset components reach beyond the window radius (SipMaskEngine._tune_deform); "0" / "1" pin the window kernel / the
+# gather loader.
+_DEFORM_MODE = os.environ.get("SIPMASK_DEFORM_GATHER", "auto")
 _DEFORM_FLAGS = _lib.SM_CONV_DBG_DEFORM_GATHER if _DEFORM_MODE == "1" else 0
-_PATCH_COUT128 = __import__("os").environ.get("SIPMASK_PATCH_COUT128", "1") != "0"         # A/B: the 128-cout patch tile
-_PATCH_SMALL_COUT = __import__("os").environ.get("SIPMASK_PATCH_SMALL_COUT", "1") != "0"   # A/B: the 32-cout patch tile
-_PATCH_MIN_WORK = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_WORK", "100"))   # 256x256 tile equivalents
-_PATCH_MIN_FILL = float(__import__("os").environ.get("SIPMASK_PATCH_MIN_FILL", "0.6"))
-# bottleneck fusion in layer1 / layer2: 0 = separate launches, 1 = conv2+conv3, 2 = conv2+conv3+next conv1.  Measured
-# (profiles/r02f_ab_bottleneck_fusion.json, same box): 963 / 998 / 984 img/s -- the chained conv1 needs 72-80 KB of LDS
-# (2 blocks per CU instead of 3-4) and loses under two concurrent sub-plans what it saves per launch
-_FUSE_BOTTLENECK = int(os.environ.get("SIPMASK_FUSE_BOTTLENECK", "1"))
-_RELU_COPY_P7 = __import__("os").environ.get("SIPMASK_RELU_COPY_P7", "1") != "0"   # A/B: relu(P6) copy vs input-ReLU flag
-# FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes
-# the shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
-# shapes), "0" = three launches (A/B)
-_LATENCY_1X1 = os.environ.get("SIPMASK_LATENCY_1X1", "")
-# A/B: layer3's conv3 + next conv1 as one launch (sm_conv1x1_pair).  Off: bit-identical, but the launch takes as long as the two
-# it replaces (0.079 vs 0.041 + 0.033 ms) and the pipelined step does not move (1 472-1 496 both ways); DESIGN section 6
-_PAIR_1X1 = os.environ.get("SIPMASK_PAIR_1X1", "0") != "0"
-_CHAIN_CONV1 = int(os.environ.get("SIPMASK_CHAIN_CONV1", "1"))        # A/B: layer1 tails also compute the next block's conv1 (2: not the one with the fused shortcut; 3: layer2 as well)
-_FUSE_SHORTCUT = int(os.environ.get("SIPMASK_FUSE_SHORTCUT", "2"))    # A/B: the shortcut conv inside the fused tail: 1 = layer1.0, 2 = + layer2.0
-_SMALLCO_CONV = os.environ.get("SIPMASK_SMALLCO_CONV", "1") != "0"    # A/B: the small-cout 3x3 kernel (conv3x3_smallco.hip)
-_STEM_FUSED = os.environ.get("SIPMASK_STEM_FUSED", "1") != "0"        # A/B: conv1 + bn1 + relu + maxpool as one launch (stem_fused.hip)
-_LAT0_LINEAR = os.environ.get("SIPMASK_LAT0_LINEAR", "1") != "0"      # A/B: sip_mask_lat0 by linearity (three convs + upsample_sum2)
-_DIAG_SKIP = __import__("re").compile(os.environ["SIPMASK_DIAG_SKIP"]) if os.environ.get("SIPMASK_DIAG_SKIP") else None
-_FPN_GROUPED = os.environ.get("SIPMASK_FPN_GROUPED", "auto")
-_LEVEL_CONV_MIN_WORK = float(os.environ.get("SIPMASK_LEVEL_CONV_MIN_WORK", "50"))
-
-
 # FeatureAlign's deformable conv in the x3 head plan: "window" (default) = the LDS-window kernel csrc/deform_patch_x3.hip where
-# the shape is its own and the offsets stay near (SipMaskEngine._tune_deform); "f32x3" = f32 rows, operands split in the gather
-# loader, f16 MFMAs (the round-3 kernel); "f32" = the exact-f32 MFMA kernel (A/B)
-_X3_FEAT_ALIGN = __import__("os").environ.get("SIPMASK_X3_FEAT_ALIGN", "window")
+# the shape is its own and the offsets stay near (the rule above); "f32x3" = f32 rows, operands split in the gather loader,
+# f16 MFMAs (the round-3 kernel); "f32" = the exact-f32 MFMA kernel
+_X3_FEAT_ALIGN = os.environ.get("SIPMASK_X3_FEAT_ALIGN", "window")
+# diagnostic (tools/marginal_cost.sh): launches whose label matches are left out of CAPTURED graphs; bench.py marks its line
+_DIAG_SKIP = __import__("re").compile(os.environ["SIPMASK_DIAG_SKIP"]) if os.environ.get("SIPMASK_DIAG_SKIP") else None
+
+# ---- plan-structure constants --------------------------------------------------------------------------------------------
+# Each of these was an environment A/B switch while it was being measured (rounds 2-4; HISTORY.md / DESIGN.md section 6 hold
+# the numbers); the measured best is fixed here and the variables are gone (41 switches were 41 untested
+# configurations of the shipped path).  tests/test_gpu_engine.py monkeypatches them to hold the alternative launch structures
+# to bit-identical results, which is what they remain good for.
+_GROUPED_TOWERS = True         # cls + reg tower convs of one depth as ONE grouped 256x256-tile launch (950 vs 785 TFLOP/s)
+_SPLIT_K = True                # split-K for under-filled launches of lone plans
+_SPLIT_K_SMALL_FPN = True      # ... and of lat2 / P6 / P7 inside pipelined slots
+_PATCH_CONV = True             # the patch-resident 3x3 kernel (csrc/conv3x3_patch.hip)
+_PATCH_COUT128 = True          # its 128-cout tile (layer3 / layer4 conv2)
+_PATCH_SMALL_COUT = True       # its 32-cout tile (where the small-cout kernel below does not take the conv)
+_PATCH_MIN_WORK = 100.0        # 256x256 tile equivalents a launch must have to take the patch kernel ...
+_PATCH_MIN_FILL = 0.6          # ... and the share of the CUs its planned shape keeps busy
+# bottleneck fusion in layer1 / layer2: 0 = separate launches, 1 = conv2+conv3, 2 = conv2+conv3+next conv1 everywhere
+# (profiles/r02f_ab_bottleneck_fusion.json: 963 / 998 / 984 img/s)
+_FUSE_BOTTLENECK = 1
+_CHAIN_CONV1 = 1               # layer1 tails also compute the next block's conv1 (2: not behind the fused shortcut; 3: layer2 too)
+_FUSE_SHORTCUT = 2             # the shortcut conv inside the fused tail: 1 = layer1.0, 2 = + layer2.0
+_PAIR_1X1 = False              # layer3's conv3 + next conv1 as one launch (sm_conv1x1_pair): bit-identical, no faster
+_LATENCY_1X1 = ()              # stage widths whose 1x1 convs keep the latency-shaped plan inside pipelined slots: neutral
+_RELU_COPY_P7 = True           # relu(P6) as its own tensor instead of the input-ReLU loader for P7
+_SMALLCO_CONV = True           # 3x3 convs with <= 32 couts on csrc/conv3x3_smallco.hip
+_STEM_FUSED = True             # conv1 + bn1 + relu + maxpool as one launch (csrc/stem_fused.hip)
+_LAT0_LINEAR = True            # sip_mask_lat0 by linearity (three convs + sm_upsample_sum2)
+_FUSED_MASKS = True            # coefficient x basis, x4 upsample, sigmoid, threshold, crop in one kernel
+# FPN output convs of levels 0-2 as ONE launch with per-level weights (_LevelConv): "auto" = where the patch kernel takes the
+# shape and the launch is at least _LEVEL_CONV_MIN_WORK tile equivalents, "1" = wherever it is supported (tests at small
+# shapes), "0" = three launches
+_FPN_GROUPED = "auto"
+_LEVEL_CONV_MIN_WORK = 50.0
+_PATCH_MIXED_IN_CHAINS = False     # mixed 256 / 128 / 192-position tiles inside SubBatchPlan chains (998 vs 991 img/s uniform)
+_PATCH_UNIFORM_IN_SLOTS = False    # uniform 256-position tiles inside PipelinedPlan slots (slower)
 
 
 def _lib_flag(name):
@@ -461,8 +464,7 @@ class SipMaskEngine:
         # ... and for the same reason its patch convs keep the uniform 256-position launch: the mixed launch (256-position
         # tiles + 128/192-position finishing tiles, sm_conv3x3_patch_plan) ends a lone launch 15-20 % sooner but spends
         # 4-6 % more CU time on it, which the other chain would have used (measured 998 vs 991 img/s, profiles/r02g_ab_patch_launch_shape.json)
-        self.patch_uniform = (sub_plan and os.environ.get("SIPMASK_PATCH_MIXED", "0") != "1") or \
-            (pipelined and os.environ.get("SIPMASK_PIPE_UNIFORM", "0") == "1")          # A/B switches (tools/)
+        self.patch_uniform = (sub_plan and not _PATCH_MIXED_IN_CHAINS) or (pipelined and _PATCH_UNIFORM_IN_SLOTS)
         if precision not in ("bf16", "f32", "head_x3"):
             raise ValueError("precision must be 'bf16' (throughput plan), 'head_x3' (bf16 backbone + FPN, split-precision "
                              "head: the reference head's fp32 arithmetic to ~1e-4 on its logits) or 'f32' (parity plan), "
@@ -502,7 +504,7 @@ class SipMaskEngine:
         self._side_streams = {}
         # independent branches (bottleneck downsample, FPN output convs of the coarse levels) on side streams: their
         # launches are 20-130 blocks, far below the 512 resident blocks of the chip
-        self.multi_stream = __import__("os").environ.get("SIPMASK_MULTI_STREAM", "1") != "0"
+        self.multi_stream = os.environ.get("SIPMASK_MULTI_STREAM", "1") != "0"
         self.convs = []        # _Conv objects (for FLOP accounting / per-kernel timing)
         self.fused = []        # _BottleneckTail launches (several convs each; counted in total_conv_flops)
         self.head_start = 0
@@ -586,7 +588,7 @@ class SipMaskEngine:
         # the pipelined step, which per-launch timings cannot give (the steps in flight overlap)
         skip = _DIAG_SKIP if (_DIAG_SKIP is not None and torch.cuda.is_current_stream_capturing()) else None
         if skip is not None:
-            kept = [i for i, (label, _) in enumerate(steps) if not skip.search(label)]
+            kept = [i for i, (label, _) in enumerate(steps) if label == "join" or not skip.search(label)]
             steps, lanes = [steps[i] for i in kept], [lanes[i] for i in kept]
         if not self.multi_stream:
             for _, fn in steps:
@@ -650,7 +652,7 @@ class SipMaskEngine:
         cur, ch, cw, cc = x, h2, w2, 64
         # A/B (SIPMASK_LATENCY_1X1 = "256", "256,512" ...): the 1x1 convs of those stages keep the latency-shaped plan inside
         # pipelined slots (no big-tile flag: 64 x 64 tiles, four blocks per CU) like lat2 / P6 / P7
-        lat_planes = [int(v) for v in _LATENCY_1X1.split(",") if v]
+        lat_planes = [int(v) for v in _LATENCY_1X1]
         lat_1x1 = lambda pl: (True if (getattr(self, "extra_conv_flags", 0) and pl in lat_planes) else None)
         feats = []
         chained_t1 = None
@@ -1294,7 +1296,7 @@ class SipMaskEngine:
         # sm_mask_assemble produces; every other plan assembles masks from the conv-resolution basis
         # ... as do geometries whose per-tile source window exceeds the fused kernel's LDS tiles (up_scale = 2 /
         # scale_factor below ~0.45: sm_mask_assemble_lo_supported)
-        self.fused_masks = (self.rescorer is None and __import__("os").environ.get("SIPMASK_FUSED_MASKS", "1") != "0"
+        self.fused_masks = (self.rescorer is None and _FUSED_MASKS
                             and H.mask_assemble_lo_supported(B, self.max_num, 4, self.up))
         self._needs_basis = not self.fused_masks
         if self._needs_basis:
@@ -1338,11 +1340,13 @@ class SipMaskEngine:
                 self.track_feats, self.nms_out["det"], self.nms_out["ndet"], lv.sizes[0][0], lv.sizes[0][1],
                 sfv if self.rescale else 1.0, self.det_feats))
 
-    def set_image_metas(self, img_metas):
+    def set_image_metas(self, img_metas, staging=None):
         """img_metas[i]['img_shape'] / ['scale_factor'] of the images of the NEXT run() (the reference reads them per image:
         sipmask_head.py:517-541,579,587-588,621-633).  Two small host->device copies into the tables the kernels read;
         call it outside a captured graph.  Every image's mask (floor(Hm * 2 / scale_factor)) must fit the plan's canvas
-        and its scale_factor must not exceed scale_factor_max (prepare() / SipMask.get_masks choose both from the batch)."""
+        and its scale_factor must not exceed scale_factor_max (prepare() / SipMask.get_masks choose both from the batch).
+        staging: (pinned det table, pinned geom table) -- the copies are then asynchronous on the current stream (the
+        caller keeps the pinned pair untouched until they have run: PipelinedPlan.submit)."""
         if self.benchmark:
             raise NotImplementedError("the maskrcnn-benchmark post-processor takes one geometry per plan")
         if len(img_metas) != self.batch:
@@ -1354,8 +1358,14 @@ class SipMaskEngine:
         if up_min[0] < self.up[0] * (1 - 1e-6) or up_min[1] < self.up[1] * (1 - 1e-6):
             raise ValueError("scale_factor above the plan's scale_factor_max (%r): prepare() with the batch's largest" %
                              (self.scale_factor_max,))
-        self.det_tab.copy_(det)
-        self.geom_tab.copy_(geom)
+        if staging is not None:
+            staging[0].copy_(det)
+            staging[1].copy_(geom)
+            self.det_tab.copy_(staging[0], non_blocking=True)
+            self.geom_tab.copy_(staging[1], non_blocking=True)
+        else:
+            self.det_tab.copy_(det)
+            self.geom_tab.copy_(geom)
         self.out_hw = [(int(g[4]), int(g[5])) for g in geom]
         return self
 
@@ -1782,6 +1792,9 @@ class PipelinedPlan:
         self.last_slot = None
         self._host = {}                                    # per slot: two sets of pinned host buffers of submit(pack=True)
         self._packs, self._pack_gen = {}, {}               # per slot: unread result sets (oldest first), packs issued
+        self._rle_sets = {}                                # per slot: two device-side RLE buffer sets used alternately
+        self._meta_pins, self._meta_gen = {}, {}           # per slot: two pinned (det, geom) table pairs + their copy events
+        self.last_fetch = dict(wait_s=0.0, pack_s=0.0)     # host seconds of the last fetch(): waiting for the GPU / building dicts
 
     def _prepare_slot(self, k, img):
         plan = self.plans[k]
@@ -1812,7 +1825,7 @@ class PipelinedPlan:
                 self._prepare_slot(k, img)
         return self
 
-    def submit(self, img, img_metas=None, pack=False, canvas_hw=None):
+    def submit(self, img, img_metas=None, pack=False, canvas_hw=None, max_runs=8192):
         """enqueue one step on the next slot (after whatever produced `img` on the caller's stream); returns the slot.
         img_metas: this BATCH's per-image img_shape / scale_factor -- written into the slot's own device tables on the
         slot's stream, i.e. behind the slot's previous step and in front of this one (the other slots, whose steps may
@@ -1830,14 +1843,14 @@ class PipelinedPlan:
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
             if img_metas is not None:
-                self.plans[k].set_image_metas(img_metas)
+                self._submit_metas(k, img_metas)
             self.static[k].copy_(img, non_blocking=True)
             if self.graphs[k] is not None:
                 self.graphs[k].replay()
             else:
                 self.plans[k].run(self.static[k])
             if pack:
-                self._pack(k, canvas_hw)
+                self._pack(k, canvas_hw, max_runs)
             ev = torch.cuda.Event()
             ev.record(st)
         self.done[k] = ev
@@ -1845,11 +1858,36 @@ class PipelinedPlan:
         self.next_slot = (k + 1) % self.depth
         return k
 
+    def _submit_metas(self, k, img_metas):
+        """this batch's img_metas into slot k's device tables, on the slot's stream and WITHOUT blocking the host: the tables
+        are staged in pinned memory (two pairs per slot, used alternately; a pair is refilled only after the copy that read it
+        has run -- by then `depth` further submits have passed) and copied with non_blocking=True.  (A pageable source made
+        every submit wait for the slot's previous step: ADVICE r4.)"""
+        plan = self.plans[k]
+        engs = getattr(plan, "engines", None)
+        if engs is not None:                                # SubBatchPlan slots keep the blocking path (not the timed structure)
+            plan.set_image_metas(img_metas)
+            return
+        pins = self._meta_pins.setdefault(k, [])
+        g = self._meta_gen.get(k, 0)
+        self._meta_gen[k] = g + 1
+        if len(pins) < 2:
+            pins.append(dict(det=torch.empty(plan.det_tab.shape, dtype=plan.det_tab.dtype, pin_memory=True),
+                             geom=torch.empty(plan.geom_tab.shape, dtype=plan.geom_tab.dtype, pin_memory=True), ev=None))
+            pin = pins[-1]
+        else:
+            pin = pins[g % 2]
+            if pin["ev"] is not None:
+                pin["ev"].synchronize()                     # two submits of this slot ago: long done
+        plan.set_image_metas(img_metas, staging=(pin["det"], pin["geom"]))
+        pin["ev"] = torch.cuda.Event()
+        pin["ev"].record(self.streams[k])
+
     # RLE strings of one batch that travel with the first (asynchronous) copy; a batch with longer strings pays a second,
-    # synchronous copy in fetch()
+    # synchronous copy in fetch() (from the slot's device buffers, which are double-buffered like the pinned sets)
     PACK_PREFIX_BYTES = 4 << 20
 
-    def _pack(self, k, canvas_hw):
+    def _pack(self, k, canvas_hw, max_runs=8192):
         """on the slot's stream, behind its step: device-side RLE of the step's masks + asynchronous D2H of everything the
         caller's evaluation loop consumes (boxes, labels, counts, run counts, string offsets, a prefix of the strings).
         Every slot owns TWO sets of pinned host buffers used alternately, so the host may submit the slot's next step
@@ -1860,7 +1898,13 @@ class PipelinedPlan:
         if hasattr(plan, "engines"):
             raise NotImplementedError("submit(pack=True): single-chain slots (det.prepare(..., in_flight=N) builds them)")
         q = self._packs.setdefault(k, [])
-        rle = plan.encode_rle(canvas_hw, fetch=False)
+        # two device-side RLE buffer sets per slot, alternated like the pinned sets: the strings of step k stay on the device
+        # until the slot's second next pack, so fetch()'s fallback copy of an over-long batch never reads rewritten bytes
+        sets_d = self._rle_sets.setdefault(k, [None, None])
+        gd = self._pack_gen.get(k, 0) % 2
+        plan._rle = sets_d[gd]
+        rle = plan.encode_rle(canvas_hw, fetch=False, max_runs=max_runs)
+        sets_d[gd] = plan._rle
         if not isinstance(rle, dict):
             raise NotImplementedError("submit(pack=True): one mask geometry per batch (per-image canvases: encode_rle(slot=k))")
         sets = self._host.setdefault(k, [])
@@ -1887,23 +1931,26 @@ class PipelinedPlan:
         """the packed results of the OLDEST unread step submitted to `slot` with pack=True: blocks the HOST until that step
         (and its copies) are done, returns per image (det_bboxes [n,5] ndarray, det_labels [n] ndarray, [RLE dict] * n).
         A slot holds at most two unread result sets."""
+        import time as _time
         k = self.last_slot if slot is None else slot
         q = self._packs.get(k)
         if not q:
             raise RuntimeError("PipelinedPlan.fetch: no unread results on slot %r (submit(..., pack=True) first)" % (k,))
-        rec = q.pop(0)
+        rec = q[0]                              # popped only once nothing can fail any more (ADVICE r4)
+        t0 = _time.perf_counter()
         rec["ev"].synchronize()
+        t1 = _time.perf_counter()
         hb = rec["hb"]
         nruns, offs = hb["nruns"].numpy(), hb["offsets"].numpy()
         if (nruns < 0).any():
+            q.pop(0)                            # this result set is unusable whatever the caller does next
             raise RuntimeError("sm_rle_encode: max_runs too small, a mask needs %d runs" % (-nruns.min()))
         total = int(offs[-1])
         blob = hb["packed"][:min(total, hb["packed"].numel())].numpy().tobytes()
-        if total > hb["packed"].numel():        # rare: longer strings than the prefix that travelled with the step
-            if q:                               # the slot's NEXT pack has been issued: its rle_encode rewrites the device strings
-                raise RuntimeError("RLE strings of %d bytes exceed PipelinedPlan.PACK_PREFIX_BYTES = %d: raise it, or fetch a "
-                                   "slot before resubmitting it" % (total, hb["packed"].numel()))
+        if total > hb["packed"].numel():        # rare: longer strings than the prefix that travelled with the step -- the
+            # slot's device buffers are double-buffered (_pack), and a slot holds at most two unread sets: still intact
             blob += rec["rle"]["packed"][hb["packed"].numel():total].cpu().numpy().tobytes()
+        q.pop(0)
         plan = self.plans[k]
         size = [int(rec["canvas"][0]), int(rec["canvas"][1])]
         out, mx = [], plan.max_num
@@ -1912,6 +1959,7 @@ class PipelinedPlan:
             n = int(nd[b])
             out.append((hb["det"][b, :n].numpy().copy(), hb["labels"][b, :n].numpy().copy(),
                         [dict(size=list(size), counts=blob[offs[b * mx + i]:offs[b * mx + i + 1]]) for i in range(n)]))
+        self.last_fetch = dict(wait_s=t1 - t0, pack_s=_time.perf_counter() - t1)
         return out
 
     def results(self, slot=None):

@@ -17,7 +17,7 @@ from .registry import HEADS, build_loss
 INF = 1e8
 
 
-_USE_FLAT = __import__("os").environ.get("SIPMASK_LOSS_FLAT", "1") != "0"      # A/B: re-flatten the per-level views instead
+_USE_FLAT = True      # the loss reads the head's flat row matrices (False: re-flatten the per-level views; -0.4 ms per step)
 
 
 class LevelList(list):

@@ -323,7 +323,7 @@ class SipMaskVIS(SipMask):
         # ONE chain per clip here (clip_test splits a lone clip into two half-clip chains to fill the chip): with two clips in
         # flight the second clip is the other chain, and 8-frame launches beat twice as many 4-frame ones -- 3 160 vs 2 870
         # frames/s (same bits: the plans are cut-independent)
-        lanes = int(os.environ.get("SIPMASK_VIS_LANES", "1"))          # A/B switch (tools/)
+        lanes = 1
         nslot = max(1, min(int(slots), n))
         engs = [self.prepare(T, hw, tuple(m0['img_shape']), m0.get('scale_factor', 1.0), bool(rescale), lanes=lanes, slot=k)
                 for k in range(nslot)]

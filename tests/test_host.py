@@ -235,23 +235,24 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     allrows = pd.conv_rows(eng)
     rows = {r["name"]: r for r in allrows if r["kind"] != "fused"}          # one row per conv launch ...
     assert sum(1 for r in allrows if r["kind"] == "fused") == len(eng.fused)   # ... and one per fused bottleneck launch
-    # the cls and reg tower convs of one depth run as ONE grouped launch (default; SIPMASK_GROUPED_TOWERS=0 = A/B):
+    from sipmask_amd import engine as E
+    # the cls and reg tower convs of one depth run as ONE grouped launch:
     # every "head.towerN" launch stands for two of the nconv convolutions
     ngrouped = sum(1 for n in rows if n.startswith("head.tower"))
     grouped = ngrouped > 0
-    assert grouped == (os.environ.get("SIPMASK_GROUPED_TOWERS", "1") == "1" and eng.flag_norm)   # GN heads only
+    assert grouped == (E._GROUPED_TOWERS and eng.flag_norm)   # GN heads only
     # fused bottleneck tails (layer1 / layer2, plain conv2): conv2 + conv3 (+ the next block's conv1) per launch
     # (round 4: layer1's first tail also carries the block's 1x1 shortcut conv -- three convs in that launch)
     pairs = [t for t in eng.fused if not hasattr(t, "w2")]               # layer3: conv3 + next conv1 (two 1x1 convs per launch)
     tails = [t for t in eng.fused if hasattr(t, "w2")]
     nfused = sum(2 + (t.w1n is not None) + (t.x_block is not None) for t in tails) + 2 * len(pairs)
     nshort = sum(1 for t in tails if t.x_block is not None)
-    if variant in ("r50", "vis", "benchmark", "ssd") and os.environ.get("SIPMASK_FUSE_BOTTLENECK", "1") == "1":
+    if variant in ("r50", "vis", "benchmark", "ssd") and E._FUSE_BOTTLENECK == 1:
         nchain = sum(1 for t in tails if t.w1n is not None)              # layer1: the next block's conv1 rides along
-        assert nchain == (0 if os.environ.get("SIPMASK_CHAIN_CONV1", "1") == "0" else 2)
+        assert nchain == (2 if E._CHAIN_CONV1 else 0)
         assert len(tails) == 7 and nfused == 7 * 2 + nshort + nchain + 2 * len(pairs)
-        assert len(pairs) == (0 if os.environ.get("SIPMASK_PAIR_1X1", "0") == "0" else 5)       # R50 layer3: 6 blocks (A/B, off)
-        assert nshort == int(os.environ.get("SIPMASK_FUSE_SHORTCUT", "2"))
+        assert len(pairs) == (5 if E._PAIR_1X1 else 0)       # R50 layer3: 6 blocks (off)
+        assert nshort == E._FUSE_SHORTCUT
         assert ("backbone.layer1.0.downsample" in rows) == (nshort == 0) and ("backbone.layer2.0.downsample" in rows) == (nshort < 2)
     # sip_mask_lat0 by linearity (round 4): the 768 -> 512 conv runs as three 1x1 convs (l0, l1, l2) + sm_upsample_sum2
     nlin = 2 if getattr(eng, "lat0_by_linearity", False) else 0
@@ -260,7 +261,7 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
         assert any(lbl == "up:sum2" for lbl, _ in eng.steps) and not any(lbl.startswith("up:cat") for lbl, _ in eng.steps)
     # the stem (conv1 + bn1 + relu + maxpool) is one launch of its own kernel (round 4, csrc/stem_fused.hip), not a conv row
     nstem = 1 if any(lbl == "stem_fused" for lbl, _ in eng.steps) else 0
-    assert nstem == (0 if os.environ.get("SIPMASK_STEM_FUSED", "1") == "0" else 1)
+    assert nstem == (1 if E._STEM_FUSED else 0)
     assert not (nstem and any(lbl in ("nhwc", "maxpool", "conv:stem") for lbl, _ in eng.steps))
     assert len(rows) == len(eng.convs) and len(rows) == nconv - ngrouped - nfused + nlin - nstem
     assert all(r["blocks"] > 0 and r["waves"] > 0 and r["kind"] in ("igemm", "patch", "window", "smallco") for r in rows.values())

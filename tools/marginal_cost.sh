@@ -23,12 +23,12 @@ declare -A PAT=(
   
   [mask_branch]='^up:|conv:head\.sip_mask'
   [predictors]='conv:head\.(reg_ctr|cls_cof)'
-  [post]='det_select|^nms$|mask_assemble'
+  [post]='det_select|^nms$|mask_assemble|det_boxes'
 )
 ORDER=(none stem layer1 layer2 layer3 layer3_1x1 layer4 fpn fpn_small mask_branch predictors post none)
 for r in $(seq 1 $REP); do
   for k in "${ORDER[@]}"; do
-    v=$(SIPMASK_DIAG_SKIP="${PAT[$k]}" timeout 300 python bench.py --no-extras --no-cpu-baseline --steps 300 --warmup 30 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])")
+    v=$(SIPMASK_DIAG_SKIP="${PAT[$k]}" timeout 300 python bench.py --no-extras --no-cpu-baseline --steps 300 --warmup 30 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d.get('value_with_launches_skipped') or d['value'], d['ms_per_step'])")
     echo "$k $v" | tee -a "$OUT"
   done
 done
