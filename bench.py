@@ -965,8 +965,7 @@ def run_eval_shapes(args, rank, world, dev):
         t0 = time.perf_counter()
         plan = det.plan_for_metas(B, hw, metas, in_flight=args.in_flight)      # the cache lookup an evaluation loop pays per batch
         stat["lookup_s"] += time.perf_counter() - t0
-        canvas = tuple(max(m["img_shape"][i] for m in metas) for i in (0, 1))
-        fifo.append((plan, plan.submit(img, metas, pack=True, canvas_hw=canvas)))
+        fifo.append((plan, plan.submit(img, metas, pack=True)))      # canvases: every image's own img_shape
         while len(fifo) > args.in_flight:
             p, k = fifo.pop(0)
             stat["dets"] += sum(len(r) for _, _, r in p.fetch(k))

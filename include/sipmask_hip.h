@@ -529,6 +529,15 @@ int sm_rle_encode(const uint8_t* masks, const int32_t* ndet, const int32_t* rect
                   int wo, int canvas_h, int canvas_w, int max_runs, uint32_t* counts, int32_t* nruns,
                   int32_t* nchars, uint8_t* packed, int64_t packed_cap, int64_t* offsets, void* workspace,
                   sm_stream_t stream);
+/* ... with every IMAGE's own mask size and canvas (round 5): per_image int32 [batch][4] = (mask_h, mask_w, canvas_h,
+ * canvas_w) on the device, or NULL (= sm_rle_encode).  A keep_ratio batch gives every image its own mask
+ * (floor(Hm * 2 / scale_factor), sipmask_head.py:621-633) inside the batch's [ho][wo] planes and its own canvas (img_shape, or
+ * ori_shape with rescale: sipmask_head.py:645-653); canvas_h / canvas_w are then the LARGEST canvas of the batch (they size
+ * the workspace), the rect hint stays per detection.  One launch per batch instead of one per image. */
+int sm_rle_encode_images(const uint8_t* masks, const int32_t* ndet, const int32_t* rect, const int32_t* per_image, int batch,
+                         int max_num, int ho, int wo, int canvas_h, int canvas_w, int max_runs, uint32_t* counts,
+                         int32_t* nruns, int32_t* nchars, uint8_t* packed, int64_t packed_cap, int64_t* offsets,
+                         void* workspace, sm_stream_t stream);
 
 /* Candidate selection of the maskrcnn-benchmark variant (B/ = SipMask-benchmark/,
  * B/fcos_core/modeling/rpn/sipmask/inference.py:66-138): per level, every (location, class) pair with

@@ -162,6 +162,7 @@ PROTOTYPES = {
     "sm_rle_workspace": (C.c_int64, [_I, _I, _I, _I]),
     "sm_mask_rects": (_I, [_P, _I, _I, _F, _F, _F, C.c_double, C.c_double, _P, _P, _P]),
     "sm_rle_encode": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
+    "sm_rle_encode_images": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "sm_nms_workspace": (C.c_int64, [_I]),
     "sm_nms": (_I, [_P, _I, _F, _P, _P, _P, _P]),
     "sm_mask_assemble": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, C.c_double, C.c_double, _F,

@@ -329,6 +329,60 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
     //     (int)((p - x1) / rw), is 0 or 1 inside the box (p < x2 and 2 rw = x2 - x1 + 0.1) and a correctly rounded quotient
     //     of positive floats is >= 1 exactly when numerator >= denominator: a comparison replaces each division.
     const int lxlast = a.lo_w - 1 - lx0, lylast = a.lo_h - 1 - ly0;
+    // x4 (the plan's factor): mask columns 4m..4m+3 read the conv columns m-1, m, m+1 with the FIXED fractions 5/8, 7/8,
+    // 1/8, 3/8 (lo_c(4m + r) = m + r/4 - 3/8), rows likewise -- a work item is four mask pixels of one row: 6 LDS reads
+    // and one vertical blend per conv column instead of 4 reads + 4 table reads + a full bilinear per pixel (round 5).
+    // Groups that are not uniformly inside one quadrant of the box, or touch the clamped first / last conv column / row, go
+    // pixel by pixel through the general expression below; same operand values, same expression tree.
+    if (a.factor == 4) {
+      const int gx0 = sx0 >> 2, ngx = (sx1 >> 2) - gx0 + 1;
+      const unsigned m_ngx = mf_magic((unsigned)ngx);
+      for (int gi = tid; gi < ngx * sph; gi += MF_THREADS) {
+        const int yy = mf_div(gi, m_ngx), gxi = gi - yy * ngx;
+        const int m = gx0 + gxi, n4 = (sy0 + yy) >> 2, sr = (sy0 + yy) & 3;
+        const int g0 = 4 * m;                                 // first mask column of the group (absolute)
+        const float ph = (float)(sy0 + yy);
+        const float pw0 = (float)g0, pw3 = (float)(g0 + 3);
+        const int cy0 = (sr < 2 ? n4 - 1 : n4) - ly0, cxm = m - 1 - lx0;
+        const bool inside = ph >= bx.y1 && ph < bx.y2 && pw0 >= bx.x1 && pw3 < bx.x2;
+        const int iw0 = __fsub_rn(pw0, bx.x1) >= bx.rw ? 1 : 0, iw3 = __fsub_rn(pw3, bx.x1) >= bx.rw ? 1 : 0;
+        const bool fast = inside && iw0 == iw3 && g0 >= sx0 && g0 + 3 <= sx1 && m >= 1 && n4 >= 1 && cxm >= 0 && cy0 >= 0 &&
+                          cxm + 2 <= lxlast && cy0 + 1 <= lylast && cxm + 2 < lpw && cy0 + 1 < lph;
+        if (fast) {
+          const int ih = __fsub_rn(ph, bx.y1) >= bx.rh ? 1 : 0;
+          const float* q0 = s_lo_base + (ih * 2 + iw0) * a.lo_cap + cy0 * lpw + cxm;
+          const float* q1 = q0 + lpw;
+          const float ly = sr == 0 ? 0.625f : (sr == 1 ? 0.875f : (sr == 2 ? 0.125f : 0.375f)), hy = 1.f - ly;
+          const float a0 = q0[0], a1 = q0[1], a2 = q0[2], b0 = q1[0], b1 = q1[1], b2 = q1[2];
+          const float l0 = hy * (0.375f * a0 + 0.625f * a1) + ly * (0.375f * b0 + 0.625f * b1);
+          const float l1 = hy * (0.125f * a0 + 0.875f * a1) + ly * (0.125f * b0 + 0.875f * b1);
+          const float l2 = hy * (0.875f * a1 + 0.125f * a2) + ly * (0.875f * b1 + 0.125f * b2);
+          const float l3 = hy * (0.625f * a1 + 0.375f * a2) + ly * (0.625f * b1 + 0.375f * b2);
+          float* dst = s_prob + yy * spw + (g0 - sx0);
+          dst[0] = mf_sigmoid(l0), dst[1] = mf_sigmoid(l1), dst[2] = mf_sigmoid(l2), dst[3] = mf_sigmoid(l3);
+          continue;
+        }
+        for (int r = 0; r < 4; ++r) {
+          const int xx = g0 + r - sx0;
+          if (xx < 0 || xx >= spw) continue;
+          const float pw = (float)(g0 + r);
+          float prob = 0.f;
+          if (pw >= bx.x1 && ph >= bx.y1 && pw < bx.x2 && ph < bx.y2) {
+            const int iw = __fsub_rn(pw, bx.x1) >= bx.rw ? 1 : 0;
+            const int ih = __fsub_rn(ph, bx.y1) >= bx.rh ? 1 : 0;
+            const float* L = s_lo_base + (ih * 2 + iw) * a.lo_cap;
+            const int y0 = s_my0[yy], x0 = s_mx0[xx];
+            const float ly = s_mly[yy], lx = s_mlx[xx];
+            const int y1 = min(y0 + 1, lylast), x1 = min(x0 + 1, lxlast);
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            const float* q0 = L + y0 * lpw;
+            const float* q1 = L + y1 * lpw;
+            prob = mf_sigmoid(hy * (hx * q0[x0] + lx * q0[x1]) + ly * (hx * q1[x0] + lx * q1[x1]));
+          }
+          s_prob[yy * spw + xx] = prob;
+        }
+      }
+    } else
     for (int li = tid; li < nsrc; li += MF_THREADS) {
       const int yy = mf_div(li, m_spw), xx = li - yy * spw;
       const float pw = (float)(sx0 + xx), ph = (float)(sy0 + yy);
@@ -358,24 +412,47 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
       s_prob[li] = prob;
     }
     __syncthreads();
-    // (3) image-resolution bilinear + threshold, 4 pixels per 32-bit store
+    // (3) image-resolution bilinear + threshold, 4 pixels per 32-bit store.
+    // Exact x2 (scale_factor 1, or any keep_ratio batch without `rescale`: up_scale = 2): the source of output pixel o is
+    // o/2 - 1/4, so the four pixels of a group 4j..4j+3 read the source columns 2j-1..2j+2 with the FIXED fractions
+    // 3/4, 1/4, 3/4, 1/4 and a row reads two source rows with fraction 1/4 (odd rows) or 3/4 (even rows): 8 LDS reads, four
+    // vertical blends and four horizontal ones per group, no coordinate tables (round 5: ~10 instead of ~40 VALU per
+    // output pixel on the worst case).  The expression tree is the general path's, hy * (hx * a + lx * b) + ly * (hx * c +
+    // lx * d), with the same operand values -- bit-identical results; groups on the window's clamped edges (first row /
+    // column of the image, last source row / column) take the general path.
     const int xlast = a.wm - 1 - sx0, ylast = a.hm - 1 - sy0;      // clamp of the +1 neighbour, window-relative
+    const bool x2 = G.inv_up_x == 0.5f && G.inv_up_y == 0.5f;
     for (int gi = tid; gi < ngroups; gi += MF_THREADS) {
       const int ry = gi / (MF_TW / 4), cx = (gi % (MF_TW / 4)) * 4;
       const int oy = oy0 + ry, oxb = ox0 + cx;
       if (oy >= G.ho || oxb >= G.wo) continue;
-      const int y0 = s_ry0[ry], y1 = min(y0 + 1, ylast);
-      const float ly = s_rly[ry], hy = 1.f - ly;
-      const float* p0 = s_prob + y0 * spw;
-      const float* p1 = s_prob + y1 * spw;
       uint32_t packed = 0u;
+      const int fy0 = ((oy + 1) >> 1) - 1 - sy0, fx0 = (oxb >> 1) - 1 - sx0;      // exact x2: first source row / column
+      if (x2 && oy >= 1 && oxb >= 4 && oxb + 3 < G.wo && fy0 + 1 <= ylast && fx0 + 3 <= xlast) {
+        const float ly = (oy & 1) ? 0.25f : 0.75f, hy = 1.f - ly;
+        const float* p0 = s_prob + fy0 * spw + fx0;
+        const float* p1 = p0 + spw;
+        const float a0 = p0[0], a1 = p0[1], a2 = p0[2], a3 = p0[3];
+        const float b0 = p1[0], b1 = p1[1], b2 = p1[2], b3 = p1[3];
+        // pixel k: x0 = fx0 + {0, 1, 1, 2}[k], lx = {3/4, 1/4, 3/4, 1/4}[k]
+        const float v0 = hy * (0.25f * a0 + 0.75f * a1) + ly * (0.25f * b0 + 0.75f * b1);
+        const float v1 = hy * (0.75f * a1 + 0.25f * a2) + ly * (0.75f * b1 + 0.25f * b2);
+        const float v2 = hy * (0.25f * a1 + 0.75f * a2) + ly * (0.25f * b1 + 0.75f * b2);
+        const float v3 = hy * (0.75f * a2 + 0.25f * a3) + ly * (0.75f * b2 + 0.25f * b3);
+        packed = (v0 > a.thr ? 1u : 0u) | (v1 > a.thr ? 0x100u : 0u) | (v2 > a.thr ? 0x10000u : 0u) | (v3 > a.thr ? 0x1000000u : 0u);
+      } else {
+        const int y0 = s_ry0[ry], y1 = min(y0 + 1, ylast);
+        const float ly = s_rly[ry], hy = 1.f - ly;
+        const float* p0 = s_prob + y0 * spw;
+        const float* p1 = s_prob + y1 * spw;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (oxb + k < G.wo) {
-          const int x0 = s_cx0[cx + k], x1 = min(x0 + 1, xlast);
-          const float lx = s_clx[cx + k], hx = 1.f - lx;
-          const float v = hy * (hx * p0[x0] + lx * p0[x1]) + ly * (hx * p1[x0] + lx * p1[x1]);
-          packed |= (v > a.thr ? 1u : 0u) << (8 * k);
+        for (int k = 0; k < 4; ++k) {
+          if (oxb + k < G.wo) {
+            const int x0 = s_cx0[cx + k], x1 = min(x0 + 1, xlast);
+            const float lx = s_clx[cx + k], hx = 1.f - lx;
+            const float v = hy * (hx * p0[x0] + lx * p0[x1]) + ly * (hx * p1[x0] + lx * p1[x1]);
+            packed |= (v > a.thr ? 1u : 0u) << (8 * k);
+          }
         }
       }
       *reinterpret_cast<uint32_t*>(mrow + (long long)oy * a.pitch + oxb) = packed;

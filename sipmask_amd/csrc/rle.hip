@@ -27,6 +27,10 @@ struct RleArgs {
   int max_runs, cap;
   long long packed_cap;
   int lds_scratch;     // 1: the encode kernel keeps a detection's scratch arrays in dynamic LDS
+  // per image (mask_h, mask_w, canvas_h, canvas_w) or null: a keep_ratio batch gives every image its own mask size
+  // (floor(Hm * 2 / scale_factor)) and canvas (img_shape / ori_shape), sipmask_head.py:621-633,645-653; H / W / hc / wc above
+  // are then the bounds over the batch
+  const int32_t* per_image;
 };
 
 __device__ __forceinline__ int block_excl_scan(int v, int* s_wave, int* total) {
@@ -277,8 +281,14 @@ __global__ __launch_bounds__(RLE_THREADS) void rle_encode_kernel(const uint8_t* 
   unsigned char* const lds_scratch = a.lds_scratch ? rle_dyn : nullptr;
   const int total = a.batch * a.max_num;
   for (int d = blockIdx.x; d < total; d += gridDim.x) {
+    RleArgs al = a;                        // this image's canvas and mask window (block-uniform)
+    if (a.per_image != nullptr) {
+      const int32_t* t = a.per_image + (d / a.max_num) * 4;
+      al.H = min(max(t[2], 1), a.H), al.W = min(max(t[3], 1), a.W);
+      al.hc = min(min(t[0], a.ho), al.H), al.wc = min(min(t[1], a.wo), al.W);
+    }
     rle_encode_one<ALIGNED>(d % a.max_num, d / a.max_num, s_wave, s_red, lds_scratch, masks, ndet, rect, pos_ws, unit_ws, counts,
-                            nruns, nchars, a);
+                            nruns, nchars, al);
     __syncthreads();                       // the shared scratch is reused by the next detection
   }
 }
@@ -391,6 +401,14 @@ extern "C" int sm_rle_encode(const uint8_t* masks, const int32_t* ndet, const in
                              int ho, int wo, int canvas_h, int canvas_w, int max_runs, uint32_t* counts, int32_t* nruns,
                              int32_t* nchars, uint8_t* packed, int64_t packed_cap, int64_t* offsets, void* workspace,
                              sm_stream_t stream) {
+  return sm_rle_encode_images(masks, ndet, rect, nullptr, batch, max_num, ho, wo, canvas_h, canvas_w, max_runs, counts, nruns,
+                              nchars, packed, packed_cap, offsets, workspace, stream);
+}
+
+extern "C" int sm_rle_encode_images(const uint8_t* masks, const int32_t* ndet, const int32_t* rect, const int32_t* per_image,
+                                    int batch, int max_num, int ho, int wo, int canvas_h, int canvas_w, int max_runs,
+                                    uint32_t* counts, int32_t* nruns, int32_t* nchars, uint8_t* packed, int64_t packed_cap,
+                                    int64_t* offsets, void* workspace, sm_stream_t stream) {
   if (!masks || !ndet || !counts || !nruns || !nchars || !packed || !offsets || !workspace) return SM_ERR_BAD_ARG;
   if (batch < 1 || max_num < 1 || ho < 1 || wo < 1 || canvas_h < 1 || canvas_w < 1 || max_runs < 2 || packed_cap < 1)
     return SM_ERR_BAD_SHAPE;
@@ -400,6 +418,7 @@ extern "C" int sm_rle_encode(const uint8_t* masks, const int32_t* ndet, const in
   a.ho = ho, a.wo = wo;
   a.H = canvas_h, a.W = canvas_w;
   a.hc = min(ho, canvas_h), a.wc = min(wo, canvas_w);
+  a.per_image = per_image;
   a.max_runs = max_runs;
   a.cap = rle_cap(canvas_w);
   a.packed_cap = packed_cap;

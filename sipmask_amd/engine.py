@@ -1287,6 +1287,8 @@ class SipMaskEngine:
         # mask_rects; filled with the plan's defaults, rewritten by set_image_metas()
         self.det_tab = torch.zeros(B, 6, dtype=torch.float32, device=self.device)
         self.geom_tab = torch.zeros(B, 8, dtype=torch.float32, device=self.device)
+        # ... and result packing: (mask_h, mask_w, canvas_h, canvas_w) of every image (sm_rle_encode_images)
+        self.rle_tab = torch.zeros(B, 4, dtype=torch.int32, device=self.device)
         self.det_desc.per_image = self.det_tab.data_ptr()
         self.set_image_metas([dict(img_shape=self.img_shape, scale_factor=self.scale_factor)] * B)
         self.rescorer = None
@@ -1345,7 +1347,7 @@ class SipMaskEngine:
         sipmask_head.py:517-541,579,587-588,621-633).  Two small host->device copies into the tables the kernels read;
         call it outside a captured graph.  Every image's mask (floor(Hm * 2 / scale_factor)) must fit the plan's canvas
         and its scale_factor must not exceed scale_factor_max (prepare() / SipMask.get_masks choose both from the batch).
-        staging: (pinned det table, pinned geom table) -- the copies are then asynchronous on the current stream (the
+        staging: (pinned det table, pinned geom table, pinned rle table) -- the copies are then asynchronous on the current stream (the
         caller keeps the pinned pair untouched until they have run: PipelinedPlan.submit)."""
         if self.benchmark:
             raise NotImplementedError("the maskrcnn-benchmark post-processor takes one geometry per plan")
@@ -1358,15 +1360,22 @@ class SipMaskEngine:
         if up_min[0] < self.up[0] * (1 - 1e-6) or up_min[1] < self.up[1] * (1 - 1e-6):
             raise ValueError("scale_factor above the plan's scale_factor_max (%r): prepare() with the batch's largest" %
                              (self.scale_factor_max,))
+        # RLE canvases of the batch: ori_shape with rescale, else img_shape (sipmask_head.py:645-653)
+        self.out_hw = [(int(g[4]), int(g[5])) for g in geom]
+        self.rle_canvases = [tuple(int(v) for v in (m.get('ori_shape', m['img_shape']) if self.rescale else m['img_shape'])[:2])
+                             for m in img_metas]
+        rt = torch.tensor([[hw[0], hw[1], cv[0], cv[1]] for hw, cv in zip(self.out_hw, self.rle_canvases)], dtype=torch.int32)
         if staging is not None:
             staging[0].copy_(det)
             staging[1].copy_(geom)
+            staging[2].copy_(rt)
             self.det_tab.copy_(staging[0], non_blocking=True)
             self.geom_tab.copy_(staging[1], non_blocking=True)
+            self.rle_tab.copy_(staging[2], non_blocking=True)
         else:
             self.det_tab.copy_(det)
             self.geom_tab.copy_(geom)
-        self.out_hw = [(int(g[4]), int(g[5])) for g in geom]
+            self.rle_tab.copy_(rt)
         return self
 
     def _tune_deform(self):
@@ -1456,38 +1465,44 @@ class SipMaskEngine:
     def encode_rle(self, canvas_hw=None, fetch=True, max_runs=8192):
         """Result packing on device (sipmask_head.py:645-657 without the per-mask D2H): run-length encodes the
         masks of the last run() on the current stream, restricted to each detection's box (sm_mask_rects).
-        Returns per image the list of RLE dicts (fetch=True: two small D2H copies) or the device buffers."""
+        canvas_hw: None = every image's own canvas from its img_metas (img_shape, or ori_shape with rescale); one (H, W) for
+        the batch; or a list with one per image.  Images with their own mask size / canvas (a keep_ratio batch) go through
+        ONE launch with a per-image table (sm_rle_encode_images).
+        Returns per image the list of RLE dicts (fetch=True: two small D2H copies) or the device buffers (then
+        `["canvases"]` holds the per-image sizes the dicts need)."""
         per_img = canvas_hw is not None and isinstance(canvas_hw[0], (tuple, list))
-        if per_img or any(hw != (self.ho, self.wo) for hw in getattr(self, "out_hw", [])):
-            # images with their own mask size / canvas (set_image_metas): one launch per image over its sub-view (result
-            # packing is outside the timed path)
-            from . import ops as P
-            rect = torch.zeros(self.batch * self.max_num, 4, dtype=torch.int32, device=self.device)
-            H.mask_rects(self.nms_out["det"], self.box_mul, 2.0, self.up, rect, per_image=self.geom_tab)
-            out = []
-            for b in range(self.batch):
-                ho, wo = self.out_hw[b]
-                cv = tuple(canvas_hw[b]) if per_img else tuple(canvas_hw or self.img_shape[:2])
-                out += P.encode_masks(self.masks[b:b + 1, :, :ho, :wo].contiguous(), self.nms_out["ndet"][b:b + 1], cv,
-                                      rect.view(self.batch, self.max_num, 4)[b].contiguous(), max_runs=max_runs)
-            return out
-        canvas_hw = tuple(canvas_hw or self.img_shape[:2])
-        if getattr(self, "_rle", None) is None or self._rle["canvas_w"] != canvas_hw[1] or \
-                self._rle["max_runs"] < max_runs:
-            self._rle = H.rle_alloc(self.batch, self.max_num, canvas_hw[1], self.device, max_runs=max_runs)
+        if canvas_hw is None:
+            canvases = list(getattr(self, "rle_canvases", None) or [tuple(self.img_shape[:2])] * self.batch)
+        elif per_img:
+            canvases = [tuple(int(v) for v in c[:2]) for c in canvas_hw]
+        else:
+            canvases = [tuple(int(v) for v in canvas_hw[:2])] * self.batch
+        out_hw = list(getattr(self, "out_hw", None) or [(self.ho, self.wo)] * self.batch)
+        uniform = all(c == canvases[0] for c in canvases) and all(hw == (self.ho, self.wo) for hw in out_hw)
+        cmax = (max(c[0] for c in canvases), max(c[1] for c in canvases))
+        if getattr(self, "_rle", None) is None or self._rle["canvas_w"] < cmax[1] or self._rle["max_runs"] < max_runs:
+            self._rle = H.rle_alloc(self.batch, self.max_num, cmax[1], self.device, max_runs=max_runs)
         H.mask_rects(self.nms_out["det"], self.box_mul, 2.0, self.up, self._rle["rect"],
                      per_image=None if self.benchmark else self.geom_tab)
-        H.rle_encode(self.masks, self.nms_out["ndet"], canvas_hw, self._rle, self._rle["rect"])
+        tab = None
+        if not uniform:
+            if canvas_hw is None and not self.benchmark:
+                tab = self.rle_tab                  # written by set_image_metas (stream-ordered, non-blocking in a pipeline)
+            else:
+                tab = torch.tensor([[hw[0], hw[1], c[0], c[1]] for hw, c in zip(out_hw, canvases)], dtype=torch.int32).to(self.device)
+        H.rle_encode(self.masks, self.nms_out["ndet"], cmax, self._rle, self._rle["rect"], per_image=tab)
+        self._rle["canvases"] = canvases
         if not fetch:
             return self._rle
         nd = self.nms_out["ndet"].cpu().tolist()
         try:
-            return H.rle_fetch(self._rle, self.batch, self.max_num, nd, canvas_hw)
+            res = H.rle_fetch(self._rle, self.batch, self.max_num, nd, canvases)
         except RuntimeError:
             need = int(-self._rle["nruns"].min().item()) + 1
             if need <= max_runs:
                 raise
             return self.encode_rle(canvas_hw, True, need)
+        return res
 
     # -------------------------------------------------------------------------------- API views
     def head_outputs(self):
@@ -1873,13 +1888,14 @@ class PipelinedPlan:
         self._meta_gen[k] = g + 1
         if len(pins) < 2:
             pins.append(dict(det=torch.empty(plan.det_tab.shape, dtype=plan.det_tab.dtype, pin_memory=True),
-                             geom=torch.empty(plan.geom_tab.shape, dtype=plan.geom_tab.dtype, pin_memory=True), ev=None))
+                             geom=torch.empty(plan.geom_tab.shape, dtype=plan.geom_tab.dtype, pin_memory=True),
+                             rle=torch.empty(plan.rle_tab.shape, dtype=plan.rle_tab.dtype, pin_memory=True), ev=None))
             pin = pins[-1]
         else:
             pin = pins[g % 2]
             if pin["ev"] is not None:
                 pin["ev"].synchronize()                     # two submits of this slot ago: long done
-        plan.set_image_metas(img_metas, staging=(pin["det"], pin["geom"]))
+        plan.set_image_metas(img_metas, staging=(pin["det"], pin["geom"], pin["rle"]))
         pin["ev"] = torch.cuda.Event()
         pin["ev"].record(self.streams[k])
 
@@ -1905,8 +1921,6 @@ class PipelinedPlan:
         plan._rle = sets_d[gd]
         rle = plan.encode_rle(canvas_hw, fetch=False, max_runs=max_runs)
         sets_d[gd] = plan._rle
-        if not isinstance(rle, dict):
-            raise NotImplementedError("submit(pack=True): one mask geometry per batch (per-image canvases: encode_rle(slot=k))")
         sets = self._host.setdefault(k, [])
         o = plan.nms_out
         if len(sets) < 2:
@@ -1925,7 +1939,7 @@ class PipelinedPlan:
         hb["packed"].copy_(rle["packed"][:hb["packed"].numel()], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(self.streams[k])
-        q.append(dict(ev=ev, hb=hb, canvas=tuple(canvas_hw or plan.img_shape[:2]), rle=rle))
+        q.append(dict(ev=ev, hb=hb, canvases=list(rle["canvases"]), rle=rle))
 
     def fetch(self, slot=None):
         """the packed results of the OLDEST unread step submitted to `slot` with pack=True: blocks the HOST until that step
@@ -1952,11 +1966,11 @@ class PipelinedPlan:
             blob += rec["rle"]["packed"][hb["packed"].numel():total].cpu().numpy().tobytes()
         q.pop(0)
         plan = self.plans[k]
-        size = [int(rec["canvas"][0]), int(rec["canvas"][1])]
         out, mx = [], plan.max_num
         nd = hb["ndet"].numpy()
         for b in range(self.batch):
             n = int(nd[b])
+            size = [int(rec["canvases"][b][0]), int(rec["canvases"][b][1])]
             out.append((hb["det"][b, :n].numpy().copy(), hb["labels"][b, :n].numpy().copy(),
                         [dict(size=list(size), counts=blob[offs[b * mx + i]:offs[b * mx + i + 1]]) for i in range(n)]))
         self.last_fetch = dict(wait_s=t1 - t0, pack_s=_time.perf_counter() - t1)

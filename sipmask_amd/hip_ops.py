@@ -861,16 +861,20 @@ def mask_rects(det, box_mul, box_div, up_scale, rect, per_image=None):
     return rect
 
 
-def rle_encode(masks, ndet, canvas_hw, out, rect=None):
-    """masks u8 [B][max_num][ho][wo] -> run lengths + packed rleToString bytes, all on device (no sync)."""
+def rle_encode(masks, ndet, canvas_hw, out, rect=None, per_image=None):
+    """masks u8 [B][max_num][ho][wo] -> run lengths + packed rleToString bytes, all on device (no sync).
+    per_image: int32 device tensor [B, 4] = (mask_h, mask_w, canvas_h, canvas_w) of every image (sm_rle_encode_images);
+    canvas_hw is then the largest canvas of the batch."""
     lib = _lib.load()
     b, n, ho, wo = masks.shape
-    assert out["canvas_w"] == int(canvas_hw[1])
-    _lib.check(lib.sm_rle_encode(_lib.ptr(masks), _lib.ptr(ndet), _lib.ptr(rect), b, n, ho, wo, int(canvas_hw[0]),
-                                 int(canvas_hw[1]), int(out["max_runs"]), _lib.ptr(out["counts"]),
-                                 _lib.ptr(out["nruns"]), _lib.ptr(out["nchars"]), _lib.ptr(out["packed"]),
-                                 int(out["packed"].numel()), _lib.ptr(out["offsets"]), _lib.ptr(out["ws"]),
-                                 _lib.stream_ptr()), "sm_rle_encode")
+    assert out["canvas_w"] >= int(canvas_hw[1])
+    if per_image is not None and (per_image.dtype != torch.int32 or tuple(per_image.shape) != (b, 4) or not per_image.is_cuda):
+        raise ValueError("rle_encode: per_image is an int32 device tensor [batch, 4]")
+    _lib.check(lib.sm_rle_encode_images(_lib.ptr(masks), _lib.ptr(ndet), _lib.ptr(rect), _lib.ptr(per_image), b, n, ho, wo,
+                                        int(canvas_hw[0]), int(canvas_hw[1]), int(out["max_runs"]), _lib.ptr(out["counts"]),
+                                        _lib.ptr(out["nruns"]), _lib.ptr(out["nchars"]), _lib.ptr(out["packed"]),
+                                        int(out["packed"].numel()), _lib.ptr(out["offsets"]), _lib.ptr(out["ws"]),
+                                        _lib.stream_ptr()), "sm_rle_encode_images")
 
 
 def rle_fetch(out, batch, max_num, ndet, canvas_hw):
@@ -884,9 +888,10 @@ def rle_fetch(out, batch, max_num, ndet, canvas_hw):
     if total > out["packed"].numel():
         raise RuntimeError("sm_rle_encode: packed capacity %d < %d" % (out["packed"].numel(), total))
     blob = out["packed"][:total].cpu().numpy().tobytes()
-    size = [int(canvas_hw[0]), int(canvas_hw[1])]
+    per_img = isinstance(canvas_hw[0], (tuple, list))             # one canvas per image
     res = []
     for b in range(batch):
+        size = [int(v) for v in (canvas_hw[b] if per_img else canvas_hw)[:2]]
         res.append([dict(size=list(size), counts=blob[offs[b * max_num + i]:offs[b * max_num + i + 1]])
                     for i in range(int(ndet[b]))])
     return res

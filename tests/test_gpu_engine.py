@@ -460,6 +460,62 @@ def test_pipelined_submit_packs_results_and_keeps_metas_per_slot(monkeypatch):
     assert pipe.out_hw == pipe.plans[pipe.last_slot].out_hw
 
 
+def test_pipelined_pack_with_own_scale_factor_and_canvas_per_image(monkeypatch):
+    """A keep_ratio batch in the pipeline (round 5): every image its own scale_factor -- hence its own mask size
+    floor(Hm * 2 / scale_factor) inside the batch's planes (sipmask_head.py:621-633) -- and its own RLE canvas
+    (img_shape, :645-653).  submit(img, img_metas, pack=True) packs them in ONE launch with a per-image table
+    (sm_rle_encode_images) and returns exactly what the single plan + per-image oracle-checked encode_rle give."""
+    import sipmask_amd.engine as E
+    from sipmask_amd.synthetic import build_synthetic_detector
+    monkeypatch.setattr(E, "_SPLIT_K", False)
+    det = build_synthetic_detector(50, seed=0)
+    with torch.no_grad():
+        det.bbox_head.fcos_cls.bias.fill_(-2.0)
+    g = torch.Generator().manual_seed(31)
+    H_, W_ = 192, 256
+    batches = [torch.randn(2, 3, H_, W_, generator=g).cuda() for _ in range(3)]
+    metas = [[dict(img_shape=(180, 250, 3), ori_shape=(108, 150, 3), scale_factor=1.6667),
+              dict(img_shape=(192, 240, 3), ori_shape=(96, 120, 3), scale_factor=2.0)],
+             [dict(img_shape=(190, 256, 3), ori_shape=(101, 136, 3), scale_factor=1.875),
+              dict(img_shape=(176, 230, 3), ori_shape=(110, 144, 3), scale_factor=1.6)]]
+    # (a plan whose canvas / window bounds cover all four images: smallest and largest scale_factor of the run)
+    one = det.prepare(2, (H_, W_), None, 1.5625, False, "bf16", 1, scale_factor_max=2.0)
+    want = []
+    for i, b in enumerate(batches):
+        one.set_image_metas(metas[i % 2])
+        r = one.run(b)
+        torch.cuda.synchronize()
+        assert len(set(one.out_hw)) == 2                            # two different mask sizes inside one batch
+        rle = one.encode_rle()                                      # canvases from the metas: img_shape of every image
+        nd = r["ndet"].cpu().tolist()
+        for k in range(2):
+            assert all(d["size"] == list(metas[i % 2][k]["img_shape"][:2]) for d in rle[k])
+            # the strings decode to the masks the plan holds (cropped / padded to the canvas as the reference does)
+            from oracle import ops as O
+            ho, wo = one.out_hw[k]
+            ch, cw = metas[i % 2][k]["img_shape"][:2]
+            for j in range(min(nd[k], 5)):
+                m = r["masks"][k, j, :ho, :wo].cpu().numpy()
+                assert rle[k][j] == O.paste_and_encode(m, (ch, cw)), (i, k, j)
+        want.append([(r["det_bboxes"][k, :nd[k]].cpu().numpy().copy(), r["det_labels"][k, :nd[k]].cpu().numpy().copy(), rle[k])
+                     for k in range(2)])
+    assert sum(len(w[2]) for ws in want for w in ws) > 0
+    pipe = det.prepare(2, (H_, W_), None, 1.5625, False, "bf16", 1, scale_factor_max=2.0, in_flight=3)
+    pending, got = [], []
+    for bi in [0, 1, 2, 1, 0, 2, 2]:
+        pending.append((pipe.submit(batches[bi], img_metas=metas[bi % 2], pack=True), bi))
+        if len(pending) > pipe.depth:
+            s0, b0 = pending.pop(0)
+            got.append((b0, pipe.fetch(s0)))
+    for s0, b0 in pending:
+        got.append((b0, pipe.fetch(s0)))
+    for bi, res in got:
+        for k in range(2):
+            np.testing.assert_array_equal(res[k][0], want[bi][k][0])
+            np.testing.assert_array_equal(res[k][1], want[bi][k][1])
+            assert res[k][2] == want[bi][k][2], (bi, k)
+
+
 def test_forward_dummy_returns_the_head_outputs(setup):
     """SingleStageDetector.forward_dummy (single_stage.py:52-59): extract_feat + bbox_head without post-processing, the five
     output lists of SipMaskHead.forward -- the same tensors the full plan computes on the same image."""
