@@ -284,22 +284,34 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
     //     32-long dot products against the coefficient quadrants (each in the reference's channel order)
     const unsigned m_lpw = mf_magic((unsigned)lpw), m_spw = mf_magic((unsigned)spw);
     if constexpr ((VAR & 1) == 0) {
-      const unsigned m_nlo = mf_magic((unsigned)nlo);
-      for (int i = tid; i < 4 * nlo; i += MF_THREADS) {
-        const int q = mf_div(i, m_nlo), p = i - q * nlo;
-        const int py = mf_div(p, m_lpw), px = p - py * lpw;
-        const float* bp = a.basis_lo + (((long long)b * a.lo_h + (ly0 + py)) * a.lo_w + (lx0 + px)) * 32;
-        const float* cq = s_cof + q * 32;
-        float acc = 0.f;
+      // Round 5.  A work item is (conv pixel, 4-channel chunk): the 8 lanes of a pixel read its 128-byte basis row as one
+      // coalesced line (one 16-byte load each) and reduce their four partial dot products with four shuffles.  (Round 4
+      // gave a lane one (quadrant, pixel): 8 loads of 16 bytes at a 128-byte lane stride -- 64 cache lines per wave
+      // instruction, every pixel fetched four times -- and the launch ran at the L1's line rate, not at the VALU's: that,
+      // not stage (3), was what the worst case cost.)
+      const int ck = tid & 7;                              // this lane's chunk: channels 4 ck .. 4 ck + 3 (fixed over the loop)
+      float4 cq[4];
 #pragma unroll
-        for (int k = 0; k < 32; k += 4) {
-          const float4 v = *reinterpret_cast<const float4*>(bp + k);
-          acc = fmaf(v.x, cq[k], acc);
-          acc = fmaf(v.y, cq[k + 1], acc);
-          acc = fmaf(v.z, cq[k + 2], acc);
-          acc = fmaf(v.w, cq[k + 3], acc);
-        }
-        s_lo_base[q * a.lo_cap + p] = acc;
+      for (int q = 0; q < 4; ++q) cq[q] = *reinterpret_cast<const float4*>(s_cof + q * 32 + ck * 4);
+      const int nitem = ((nlo * 8 + 63) >> 6) << 6;        // whole waves stay in the loop: the shuffles need every lane
+      for (int i = tid; i < nitem; i += MF_THREADS) {
+        const int p = i >> 3;
+        const bool ok = p < nlo;
+        const int pp = ok ? p : 0;
+        const int py = mf_div(pp, m_lpw), px = pp - py * lpw;
+        const float4 v = *reinterpret_cast<const float4*>(
+            a.basis_lo + (((long long)b * a.lo_h + (ly0 + py)) * a.lo_w + (lx0 + px)) * 32 + ck * 4);
+        float sq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sq[q] = fmaf(v.w, cq[q].w, fmaf(v.z, cq[q].z, fmaf(v.y, cq[q].y, v.x * cq[q].x)));
+        // transposing butterfly over the pixel's 8 lanes: xor 4 leaves quadrants (0, 1) on chunks 0-3 and (2, 3) on 4-7, xor 2
+        // one quadrant per lane pair, xor 1 completes it
+        const bool u4 = (ck & 4) != 0, u2 = (ck & 2) != 0;
+        const float t0 = __shfl_xor(u4 ? sq[0] : sq[2], 4, 64), t1 = __shfl_xor(u4 ? sq[1] : sq[3], 4, 64);
+        const float a0 = (u4 ? sq[2] : sq[0]) + t0, a1 = (u4 ? sq[3] : sq[1]) + t1;
+        float c = (u2 ? a1 : a0) + __shfl_xor(u2 ? a0 : a1, 2, 64);
+        c += __shfl_xor(c, 1, 64);
+        if (ok && (ck & 1) == 0) s_lo_base[((u4 ? 2 : 0) + (u2 ? 1 : 0)) * a.lo_cap + p] = c;
       }
     } else
     for (int p = tid; p < nlo; p += MF_THREADS) {
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(MF_THREADS) void mask_fused_kernel(const MaskFArgs 
       const int gx0 = sx0 >> 2, ngx = (sx1 >> 2) - gx0 + 1;
       const unsigned m_ngx = mf_magic((unsigned)ngx);
       for (int gi = tid; gi < ngx * sph; gi += MF_THREADS) {
-        const int yy = mf_div(gi, m_ngx), gxi = gi - yy * ngx;
+        const int yy = ngx == 1 ? gi : mf_div(gi, m_ngx), gxi = gi - yy * ngx;      // (mf_magic(1) does not fit 32 bits)
         const int m = gx0 + gxi, n4 = (sy0 + yy) >> 2, sr = (sy0 + yy) & 3;
         const int g0 = 4 * m;                                 // first mask column of the group (absolute)
         const float ph = (float)(sy0 + yy);
