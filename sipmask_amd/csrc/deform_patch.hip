@@ -26,10 +26,11 @@
 
 namespace {
 
-constexpr int DP_TH = 8, DP_TW = 32, DP_R = 3;
-constexpr int DP_PH = DP_TH + 2 + 2 * DP_R;       // 16 patch rows
-constexpr int DP_PW = DP_TW + 2 + 2 * DP_R;       // 40 patch columns (even: the swizzle pairs pixels 2k, 2k+1)
-constexpr int DP_PPIX = DP_PH * DP_PW;            // 640 pixels = 80 DMA pieces of 8
+// Two tile shapes in one launch (round 5, as csrc/deform_patch_x3.hip): 8 rows x 32 columns, and 32 rows x 8 columns for the
+// strip a level's width leaves beyond a multiple of 32 (168 = 5 x 32 + 8: thirteen row tiles with 24 of 32 columns empty
+// become four column tiles) -- 392 instead of 440 tiles per four 800 x 1344 images.  Both windows are 640 pixels.
+constexpr int DP_R = 3;
+constexpr int DP_PPIX = 640;                      // window pixels: 16 x 40 (row tile) or 40 x 16 (column tile) = 80 DMA pieces of 8
 constexpr int DP_PPW = DP_PPIX / 8 / 8;           // patch pieces per wave (10)
 constexpr int DP_BCO = 256;
 constexpr int DP_WSTAGE = DP_BCO * 128;           // one K step of weights: 256 cout rows x 64 channels
@@ -47,8 +48,11 @@ struct DeformPatchArgs {
   int h[SM_MAX_LEVELS], w_[SM_MAX_LEVELS];
   long long in_row0[SM_MAX_LEVELS], out_row0[SM_MAX_LEVELS];
   int tile0[SM_MAX_LEVELS + 1];   // first position tile of each level
-  int ntx[SM_MAX_LEVELS];         // tiles along x
+  int ntx[SM_MAX_LEVELS];         // row tiles (8 x 32) along x
   int tpi[SM_MAX_LEVELS];         // tiles per image
+  int nrow_t[SM_MAX_LEVELS];      // row tiles per image: the first nrow_t of an image's tiles
+  int xb[SM_MAX_LEVELS];          // first column of the column-tile strip
+  int nbx[SM_MAX_LEVELS];         // column tiles (32 x 8) along x inside the strip
   int cin, cout, ntn, dg;
   int in_cstride, out_cstride, out_coff;
   long long Kp;
@@ -102,8 +106,19 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
   const int ti = mt - a.tile0[lev];
   const int n = ti / a.tpi[lev];
   const int tt = ti - n * a.tpi[lev];
-  const int ty = tt / a.ntx[lev];
-  const int y0 = ty * DP_TH, x0 = (tt - ty * a.ntx[lev]) * DP_TW;
+  const bool col_tile = tt >= a.nrow_t[lev];                      // 32 rows x 8 columns on the right-hand strip
+  int y0, x0;
+  if (!col_tile) {
+    const int ty = tt / a.ntx[lev];
+    y0 = ty * 8, x0 = (tt - ty * a.ntx[lev]) * 32;
+  } else {
+    const int e = tt - a.nrow_t[lev];
+    const int by = e / a.nbx[lev];
+    y0 = by * 32, x0 = a.xb[lev] + (e - by * a.nbx[lev]) * 8;
+  }
+  const int lgw = col_tile ? 3 : 5;                               // log2 of the tile width
+  const int DP_PW = (col_tile ? 8 : 32) + 2 + 2 * DP_R;           // window pitch in pixels: 16 / 40 (even: swizzle parity)
+  const int DP_PH = DP_PPIX / DP_PW;                              // 40 / 16
   const int py0 = y0 - 1 - DP_R, px0 = x0 - 1 - DP_R;           // image coordinates of patch pixel (0, 0)
   const long long img_row0 = a.in_row0[lev] + (long long)n * H * W;
   const uint16_t* const ximg = a.x + img_row0 * a.in_cstride;
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
     dfor<DP_PPW>([&](auto I) {                                    // 4 x per tile, cheaper than 10 live registers)
       constexpr int i = decltype(I)::value;
       const int pix = (wave + 8 * i) * 8 + (lane >> 3);
-      const int pr = pix / DP_PW, pc = pix - pr * DP_PW;
+      const int pr = col_tile ? (pix >> 4) : (pix / 40), pc = pix - pr * DP_PW;
       int py0_l = py0;
       asm volatile("" : "+s"(py0_l));                             // opaque: keeps the 10 addresses out of the K loop's registers
       const int ih = py0_l + pr, iw = px0 + pc;
@@ -145,9 +160,10 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
   };
 
   // ---- this lane's output position
-  const int oy = y0 + wave, ox = x0 + l31;
-  const bool row_live = oy < H;                                  // wave-uniform
-  const bool pvalid = row_live && ox < W;
+  const int wy = wave << (5 - lgw);                              // first tile row of this wave
+  const int oy = y0 + wy + (l31 >> lgw), ox = x0 + (l31 & ((1 << lgw) - 1));
+  const bool row_live = y0 + wy < H;                             // wave-uniform
+  const bool pvalid = oy < H && ox < W;
   const long long orow = a.out_row0[lev] + (long long)n * H * W + (long long)oy * W + ox;
   const float* const offp = a.offset + (pvalid ? orow : 0ll) * (a.dg * 18);
 
@@ -200,6 +216,8 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
   // corners of K sub-step kk.  Fallback arm: this tap's corners come from global memory for the whole wave (clamped
   // addresses, the weights carry the zero padding); the empty asm makes its results register-defined, so that the code
   // after the join never waits on vmcnt -- that counter is in order, and the next K step's weight DMA is in flight on it.
+  // (Round 5 tried the far tap as a step of its own, as csrc/deform_patch_x3.hip handles it: a second body that touches the
+  // 128 accumulators -- even a rolled four-iteration loop -- makes hipcc spill 255 registers; the arm stays.)
   u32x4 q1, q2, q3, q4;
   auto corners = [&](int kk) {
     // the window reads are unconditional (clamped addresses): outside any branch the LDS counter stays exact, and the wait
@@ -265,7 +283,6 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
     off_nx = *reinterpret_cast<const float2*>(offp + (more ? (s + 1) * 2 : 0));   // unconditional: no exec-masked load
     if (row_live) {
       setup(g, tap, off);
-      corners(0);
       const int wbase = (s & 1) * DP_WSTAGE + wrow_off + ((khalf ^ rs8) * 16);   // K chunk kk * 2 + khalf: ^ (kk * 32)
       bf16x8 wfr[8];
       auto fragments = [&](int kk) {
@@ -273,6 +290,7 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
         for (int tc = 0; tc < 8; ++tc)
           wfr[tc] = *reinterpret_cast<const lds_bf16x8*>(smem3 + ((wbase ^ (kk * 32)) + tc * 32 * 128));
       };
+      corners(0);
       fragments(0);
       bf16x8 xf = blend();                                      // sub-step 0's blend is the one nothing hides
       __builtin_amdgcn_sched_barrier(0);
@@ -406,6 +424,27 @@ __global__ __launch_bounds__(DP_THREADS, 1) void deform_patch_kernel(const Defor
 
 }  // namespace
 
+// tile list of one level (host; the rule of csrc/deform_patch_x3.hip): row tiles (8 x 32) over the columns [0, xb), then either
+// row tiles or column tiles (32 x 8) over the strip [xb, W) -- whichever needs fewer blocks
+namespace {
+struct DpLevelTiles {
+  int ntx, nrow_t, xb, nbx, tpi;
+};
+DpLevelTiles dp_level_tiles(int H, int W) {
+  DpLevelTiles t;
+  const int nty = sm_cdiv(H, 8);
+  const int nfull = W / 32, rem = W - nfull * 32;
+  const int nbx = sm_cdiv(rem, 8), nby = sm_cdiv(H, 32);
+  const bool strip = rem > 0 && nbx * nby < nty;                 // the strip as column tiles
+  t.ntx = strip ? nfull : nfull + (rem > 0 ? 1 : 0);
+  t.nrow_t = t.ntx * nty;
+  t.xb = nfull * 32;
+  t.nbx = strip ? nbx : 1;
+  t.tpi = t.nrow_t + (strip ? nbx * nby : 0);
+  return t;
+}
+}  // namespace
+
 // Which deformable convs the LDS-patch kernel takes (conv_igemm.hip's launch_conv<true> asks): 3x3 / stride 1 / pad 1,
 // 64 channels per deformable group, 256-cout weight tiles, plain epilogue.  Everything else stays on the gather loader.
 bool sm_deform_patch_supported(const sm_conv_desc* d) {
@@ -430,10 +469,10 @@ extern "C" int sm_deform_conv_window_plan(const sm_conv_desc* d, int64_t* out4) 
   if (!d || !out4) return SM_ERR_BAD_ARG;
   if ((d->flags & SM_CONV_DBG_DEFORM_GATHER) || !sm_deform_patch_supported(d)) return SM_ERR_UNSUPPORTED;
   long long t = 0;
-  for (int l = 0; l < d->nlev; ++l) t += (long long)d->batch * sm_cdiv(d->in_w[l], DP_TW) * sm_cdiv(d->in_h[l], DP_TH);
+  for (int l = 0; l < d->nlev; ++l) t += (long long)d->batch * dp_level_tiles(d->in_h[l], d->in_w[l]).tpi;
   out4[0] = t * (d->cout_pad / DP_BCO);
-  out4[1] = DP_TH;
-  out4[2] = DP_TW;
+  out4[1] = 8;                         // (row tiles; the right-hand strip of a level may run as 32 x 8 column tiles)
+  out4[2] = 32;
   out4[3] = DP_PPIX;
   return SM_OK;
 }
@@ -461,8 +500,12 @@ int sm_deform_patch_launch(const sm_conv_desc* d, const void* x, const float* of
     a.in_row0[l] = on ? d->in_row0[l] : 0;
     a.out_row0[l] = on ? d->out_row0[l] : 0;
     a.level_scale[l] = on ? d->level_scale[l] : 1.f;
-    a.ntx[l] = on ? sm_cdiv(d->in_w[l], DP_TW) : 1;
-    a.tpi[l] = on ? a.ntx[l] * sm_cdiv(d->in_h[l], DP_TH) : 1;
+    const DpLevelTiles lt = dp_level_tiles(a.h[l], a.w_[l]);
+    a.ntx[l] = lt.ntx > 0 ? lt.ntx : 1;
+    a.nrow_t[l] = lt.nrow_t;
+    a.xb[l] = lt.xb;
+    a.nbx[l] = lt.nbx;
+    a.tpi[l] = lt.tpi;
     a.tile0[l] = t;
     if (on) t += d->batch * a.tpi[l];
   }

@@ -300,7 +300,11 @@ def test_engine_plan_builds_without_gpu_and_every_launch_has_a_plan(variant, nco
     # FeatureAlign (3x3, 4 deformable groups of 64 channels): the LDS-window kernel, 8 x 32-position tiles per image and level
     fa = rows["head.feat_align"]
     assert fa["kind"] == "window" and fa["shape"] == "256x(8x32)"
-    assert fa["blocks"] == 2 * sum(-(-h // 8) * -(-w // 32) for h, w in eng.lv.sizes)
+    def fa_tiles(h, w):            # row tiles 8 x 32; a level's right-hand strip as 32 x 8 column tiles where they are fewer
+        nty, nfull, rem = -(-h // 8), w // 32, w % 32
+        strip = -(-rem // 8) * -(-h // 32)
+        return nty * nfull + (min(strip, nty) if rem else 0)
+    assert fa["blocks"] == 2 * sum(fa_tiles(h, w) for h, w in eng.lv.sizes)
     # P7 = conv(relu(P6)) (fpn.py:166-170): the plan feeds it a ReLU'd copy so it keeps the LDS-DMA path
     assert rows["fpn.p7"]["plan"]["lds_dma"] == 1 and any(lbl == "relu:p6" for lbl, _ in eng.steps)
     tower = rows["head.tower0" if grouped and "head.tower0" in rows else "head.reg_convs.0"]
@@ -355,7 +359,8 @@ def test_patch_conv_launch_shapes():
 
 def test_deform_conv_kernel_choice_is_host_logic():
     """sm_deform_conv_window_plan (no GPU): FeatureAlign's shape -- 3x3, 64 channels per deformable group, 256-cout tiles --
-    runs on the LDS-window kernel with 8 x 32-position tiles; the backbone DCN of SipMask++ (1 deformable group), a 1x1
+    runs on the LDS-window kernel with 8 x 32-position row tiles (+ 32 x 8 column tiles on a level's right-hand strip where
+    they are fewer, round 5); the backbone DCN of SipMask++ (1 deformable group), a 1x1
     kernel, a residual epilogue and the A/B flag stay on the gather loader."""
     from sipmask_amd import hip_ops as H, _lib
     sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
@@ -363,9 +368,10 @@ def test_deform_conv_kernel_choice_is_host_logic():
     mk = lambda cin, co, k, G, flags=0, szs=sizes, l=lv: H.make_conv_desc(
         2, szs, szs, l.row0, l.row0, cin, co, (co + 255) // 256 * 256, k, 1, k // 2, cin, co, flags=flags, deform_groups=G)
     pl = H.deform_conv_window_plan(mk(256, 256, 3, 4))
-    # ceil(h / 8) * ceil(w / 32) tiles per image and level: 13*6 + 7*3 + 4*2 + 2*1 + 1*1 = 110
-    assert pl == dict(blocks=2 * 110, tile=(8, 32), window_pixels=16 * 40)
-    assert H.deform_conv_window_plan(mk(256, 512, 3, 4))["blocks"] == 2 * 110 * 2          # two 256-cout tiles
+    # row tiles ceil(h / 8) * floor(w / 32) + the strip: (13*5 + 4) + (7*2 + 6) + (4*1 + 2) + 2*1 + 1*1 = 98 per image
+    # (all row tiles: 13*6 + 7*3 + 4*2 + 2 + 1 = 110)
+    assert pl == dict(blocks=2 * 98, tile=(8, 32), window_pixels=16 * 40)
+    assert H.deform_conv_window_plan(mk(256, 512, 3, 4))["blocks"] == 2 * 98 * 2           # two 256-cout tiles
     assert H.deform_conv_window_plan(mk(256, 256, 3, 4, flags=_lib.SM_CONV_DBG_DEFORM_GATHER)) is None
     assert H.deform_conv_window_plan(mk(256, 256, 3, 1)) is None                            # 256 channels per group
     assert H.deform_conv_window_plan(mk(128, 256, 3, 4)) is None                            # 32 channels per group
