@@ -46,6 +46,9 @@ typedef enum {
 #define SM_CONV_IN_RELU 16u      /* x = max(x,0) applied on load (fpn.py:174-175 P7) */
 #define SM_CONV_BWD_GX_BF16 64u   /* sm_conv2d_bwd only: grad_x is written as bf16 rows (stride-1 convs: the dX GEMM's own
                                     output type; the training graph on row tensors hands it straight to the next op) */
+#define SM_CONV_BWD_DX_SCATTER 1024u /* sm_deform_conv2d_bwd only, A/B switch: d(x) of FeatureAlign's shape by the atomic scatter alone
+                                      (default, round 5: samples within 3 pixels of their tap by the gather kernel, plain stores in a
+                                      fixed order; the scatter adds the far ones) */
 #define SM_CONV_BWD_WGRAD_GEMM 128u /* sm_conv2d_bwd only, A/B switch: weight gradient through the materialised im2col^T / gout^T
                                     GEMM (the round-1 path) instead of sm_wgrad_direct */
 #define SM_CONV_BWD_WGRAD_DIRECT 256u /* sm_conv2d_bwd only, A/B switch: sm_wgrad_direct wherever it is supported (default: where

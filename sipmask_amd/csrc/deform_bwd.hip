@@ -155,10 +155,13 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const DBArgs a, cons
 // transposing half-wave reduce of common.h: 9 swaps + 16 shuffles instead of 108.
 // body: one (position, 64-channel chunk); `scatter(row, hc, wc, value)` takes the d(x) contribution of this lane's channel
 // at input pixel (hc, wc) = row `row` of the level's image (wave-uniform arguments except the value)
+// far_only: d(x) of the taps whose offsets stay within DX_OMAX is produced by deform_dx_gather_kernel (below); this kernel then
+// scatters the remaining, far taps only (and still computes every offset gradient)
+constexpr float DX_OMAX = 3.0f;
 template <typename Scatter>
 __device__ __forceinline__ void col2im9_position(const DBArgs& a, const Pos& ps, const long long p, const int q, const int lane,
                                                  const uint16_t* __restrict__ gcol, const bool want_gx,
-                                                 float* __restrict__ goff, Scatter&& scatter) {
+                                                 float* __restrict__ goff, Scatter&& scatter, const bool far_only = false) {
   const int l31 = lane & 31;
   const int cpg = a.cin / a.G;
   const long long K = 9ll * a.cin;
@@ -177,11 +180,13 @@ __device__ __forceinline__ void col2im9_position(const DBArgs& a, const Pos& ps,
   int inm[9];                                    // bit 0 / 1: corner row hl / hl+1 inside the image, bit 2 / 3: column wl / wl+1
   int hls[9], wls[9];
   uint16_t xv[9][4];
+  unsigned farm = 0u;                            // bit t: tap t samples farther than DX_OMAX from its tap (wave-uniform)
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     const int i = t / 3, j = t - 3 * (t / 3);
     const float o0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ofs), 2 * t));
     const float o1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ofs), 2 * t + 1));
+    if (!(fabsf(o0) <= DX_OMAX && fabsf(o1) <= DX_OMAX)) farm |= 1u << t;
     const float h_im = (float)(ps.oy * a.stride - a.pad + i * a.dil) + o0;
     const float w_im = (float)(ps.ox * a.stride - a.pad + j * a.dil) + o1;
     const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;   // kernel.cu:229
@@ -214,7 +219,7 @@ __device__ __forceinline__ void col2im9_position(const DBArgs& a, const Pos& ps,
       const float wy = (k >> 1) ? lhs[t] : 1.f - lhs[t], wx = (k & 1) ? lws[t] : 1.f - lws[t];
       const float v = bf16_bits_to_f32((uint32_t)xv[t][k]);
       const int hc = hls[t] + (k >> 1), wc = wls[t] + (k & 1);
-      if (want_gx) scatter(base + (long long)hc * W + wc, hc, wc, top * (wy * wx));
+      if (want_gx && (!far_only || ((farm >> t) & 1u))) scatter(base + (long long)hc * W + wc, hc, wc, top * (wy * wx));
       dh += ((k >> 1) ? wx : -wx) * v;
       dw += ((k & 1) ? wy : -wy) * v;
     }
@@ -238,7 +243,7 @@ __device__ __forceinline__ void col2im9_position(const DBArgs& a, const Pos& ps,
 
 __global__ __launch_bounds__(256) void deform_col2im9_kernel(const DBArgs a, const uint16_t* __restrict__ gcol,
                                                              float* __restrict__ gx, float* __restrict__ goff,
-                                                             long long nunits) {
+                                                             long long nunits, int far_only) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nq = a.cin >> 6;
@@ -248,7 +253,110 @@ __global__ __launch_bounds__(256) void deform_col2im9_kernel(const DBArgs a, con
     const Pos ps = locate(a, p);
     const int c = q * 64 + lane;
     col2im9_position(a, ps, p, q, lane, gcol, gx != nullptr, goff,
-                     [&](long long row, int, int, float v) { unsafeAtomicAdd(gx + row * a.cin + c, v); });
+                     [&](long long row, int, int, float v) { unsafeAtomicAdd(gx + row * a.cin + c, v); }, far_only != 0);
+  }
+}
+
+// ---------------------------------------------------------------- d(x) as a GATHER (round 5)
+// The scatter above retires 36 x 64 float atomics per (position, deformable group) in the L2: 826 M lane-adds = 1.85 ms of
+// the B=4 head's 2.4 ms (profiles/r04_rocprofv3_kernel_stats_train_step.csv); privatising them in LDS was slower still
+// (above).  Turned around: d(x)[pixel, c] = sum over the (position, tap) whose bilinear footprint contains the pixel of
+// weight * gcol[position, tap, c] -- no atomics, one plain store per element, a deterministic order.  Which (position, tap)
+// hit a pixel is data (the offsets), but a sample whose offsets stay within DX_OMAX of its tap can only come from an 8 x 8
+// neighbourhood of positions per tap: 64 candidates = one wave-wide test per tap, ~36 hits per pixel on average.
+// A block owns an 8 x 8 tile of pixels of one image, level and deformable group: it stages the group's 18 offsets of the
+// 17 x 17 positions around the tile in LDS (coalesced), and each of its 4 waves takes 16 pixels in turn -- per tap one
+// candidate per lane (offset from LDS, the forward's sampling arithmetic, hit = the sample's corner pair contains the
+// pixel), hits compacted into a per-wave list (ballot + mbcnt), then the list is walked four entries at a time: lane c adds
+// weight * gcol[entry][c] (one coalesced 128-byte read per entry, four in flight).  Samples farther than DX_OMAX are left to
+// the scatter kernel (far_only), which runs BEHIND this kernel and adds them atomically.  3 x 3, stride 1, pad 1, 64
+// channels per deformable group (FeatureAlign); everything else keeps the scatter.
+constexpr int DXG_T = 8;                          // tile side (pixels)
+constexpr int DXG_R = 17;                         // side of the staged position region: 8 + 2 + DX_OMAX below, 1 + DX_OMAX + ... above
+constexpr int DXG_LIST = 9 * 64;                  // hit list capacity per wave
+
+struct DxgArgs {
+  int tile0[SM_MAX_LEVELS + 1];                   // first block of each level
+  int ntx[SM_MAX_LEVELS], nty[SM_MAX_LEVELS];
+  long long prow0[SM_MAX_LEVELS];                 // first compact position (row of gcol) of each level
+};
+
+__global__ __launch_bounds__(256) void deform_dx_gather_kernel(const DBArgs a, const DxgArgs t, const uint16_t* __restrict__ gcol,
+                                                               float* __restrict__ gx) {
+  __shared__ float s_off[DXG_R * DXG_R][18];      // the group's offsets of the region's positions (garbage outside the image)
+  __shared__ unsigned s_list[4][DXG_LIST];        // per wave: gcol element offset of a hit's (position, tap); < 2^32 (checked by the host)
+  __shared__ float s_lw[4][DXG_LIST];             // ... and its bilinear weight
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int lev = 0;
+#pragma unroll
+  for (int l = 1; l < SM_MAX_LEVELS; ++l)
+    if (l < a.nlev && (int)blockIdx.x >= t.tile0[l]) lev = l;
+  const int H = a.in_h[lev], W = a.in_w[lev];
+  int bi = blockIdx.x - t.tile0[lev];
+  const int g = bi % a.G;
+  bi /= a.G;
+  const int tx = bi % t.ntx[lev];
+  bi /= t.ntx[lev];
+  const int ty = bi % t.nty[lev], b = bi / t.nty[lev];
+  const int y0 = ty * DXG_T, x0 = tx * DXG_T;
+  const int ry0 = y0 - 2 - (int)DX_OMAX, rx0 = x0 - 2 - (int)DX_OMAX;     // image coordinates of region position (0, 0)
+  const long long orow_img = a.out_row0[lev] + (long long)b * H * W;       // row of position (0, 0) of this image in offset / gout
+  const long long prow_img = t.prow0[lev] + (long long)b * H * W;         // ... in gcol (compact order)
+  // ---- stage the offsets: 289 positions x 18 floats, consecutive threads read consecutive floats of a position
+  for (int i = tid; i < DXG_R * DXG_R * 18; i += 256) {
+    const int pos = i / 18, k = i - pos * 18;
+    const int ry = pos / DXG_R, rx = pos - ry * DXG_R;
+    const int oy = ry0 + ry, ox = rx0 + rx;
+    float v = 0.f;
+    if (oy >= 0 && oy < H && ox >= 0 && ox < W) v = a.offset[(orow_img + (long long)oy * W + ox) * (a.G * 18) + g * 18 + k];
+    s_off[pos][k] = v;
+  }
+  __syncthreads();
+  const long long K = 9ll * a.cin;
+  const int c = g * 64 + lane;
+  const int dy = lane >> 3, dx = lane & 7;
+  for (int pi = wv; pi < DXG_T * DXG_T; pi += 4) {
+    const int hc = y0 + (pi >> 3), wc = x0 + (pi & 7);
+    if (hc >= H || wc >= W) continue;             // wave-uniform
+    int n = 0;                                    // entries in this wave's list (wave-uniform)
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int i = tp / 3, j = tp - 3 * (tp / 3);
+      // candidates of this tap: a sample with |offset| <= DX_OMAX that touches row hc comes from oy in [hc - i - OMAX, hc + 1 - i + OMAX]
+      const int oy = hc - i - (int)DX_OMAX + dy, ox = wc - j - (int)DX_OMAX + dx;
+      const bool inimg = oy >= 0 && oy < H && ox >= 0 && ox < W;
+      const int pos = (oy - ry0) * DXG_R + (ox - rx0);                     // inside the region by construction
+      const float o0 = s_off[pos][2 * tp], o1 = s_off[pos][2 * tp + 1];
+      const float h_im = (float)(oy - 1 + i) + o0, w_im = (float)(ox - 1 + j) + o1;
+      const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;      // kernel.cu:229
+      const float fh = floorf(h_im), fw = floorf(w_im);
+      const int dyc = hc - (int)fh, dxc = wc - (int)fw;                    // which corner of the sample this pixel is
+      const bool hit = inimg && valid && fabsf(o0) <= DX_OMAX && fabsf(o1) <= DX_OMAX && (unsigned)dyc <= 1u && (unsigned)dxc <= 1u;
+      const float lh = h_im - fh, lw = w_im - fw;
+      const float wgt = (dyc ? lh : 1.f - lh) * (dxc ? lw : 1.f - lw);     // get_gradient_weight, kernel.cu:117-142
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+      if (hit) {
+        const int rank = n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        s_list[wv][rank] = (unsigned)((prow_img + (long long)oy * W + ox) * K + (long long)tp * a.cin);
+        s_lw[wv][rank] = wgt;
+      }
+      n += __popcll(m);
+    }
+    // (the list is written and read by this wave only: LDS operations of one wave complete in order)
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int e = 0;
+    for (; e + 4 <= n; e += 4) {
+      const float v0 = bf16_bits_to_f32((uint32_t)gcol[s_list[wv][e] + c]);
+      const float v1 = bf16_bits_to_f32((uint32_t)gcol[s_list[wv][e + 1] + c]);
+      const float v2 = bf16_bits_to_f32((uint32_t)gcol[s_list[wv][e + 2] + c]);
+      const float v3 = bf16_bits_to_f32((uint32_t)gcol[s_list[wv][e + 3] + c]);
+      acc0 = fmaf(s_lw[wv][e], v0, acc0);
+      acc1 = fmaf(s_lw[wv][e + 1], v1, acc1);
+      acc2 = fmaf(s_lw[wv][e + 2], v2, acc2);
+      acc3 = fmaf(s_lw[wv][e + 3], v3, acc3);
+    }
+    for (; e < n; ++e) acc0 = fmaf(s_lw[wv][e], bf16_bits_to_f32((uint32_t)gcol[s_list[wv][e] + c]), acc0);
+    gx[(a.in_row0[lev] + (long long)b * H * W + (long long)hc * W + wc) * a.cin + c] = (acc0 + acc1) + (acc2 + acc3);
   }
 }
 
@@ -648,7 +756,17 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
     int st = sm_conv2d(&g1, gout, w_t, nullptr, nullptr, gcol, stream);
     if (st != SM_OK) return st;
     float* gx_col = fast_dgrad ? nullptr : grad_x;
-    if (gx_col && sm_zero_async(gx_col, (size_t)in_rows * d->cin * 4, s) != hipSuccess) return SM_ERR_LAUNCH;
+    // d(x) of the near samples as a gather (deform_dx_gather_kernel): FeatureAlign's shape
+    bool gather = gx_col && offset && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 &&
+                  d->cin / G == 64 && !(d->flags & SM_CONV_BWD_DX_SCATTER) && pl.P * pl.K < (1ll << 32);
+    long long covered = 0;
+    for (int l = 0; l < d->nlev; ++l) {
+      gather = gather && d->in_h[l] == d->out_h[l] && d->in_w[l] == d->out_w[l];
+      covered += (long long)d->batch * d->in_h[l] * d->in_w[l];
+    }
+    // (the gather writes every element of every level's rows: nothing to clear when the levels tile the row range)
+    if (gx_col && !(gather && covered == in_rows) && sm_zero_async(gx_col, (size_t)in_rows * d->cin * 4, s) != hipSuccess)
+      return SM_ERR_LAUNCH;
     if (grad_offset) {   // positions sampling outside the image are skipped by the kernel: their gradient is 0
       long long orows = 0;
       for (int l = 0; l < d->nlev; ++l)
@@ -656,10 +774,31 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
       if (sm_zero_async(grad_offset, (size_t)orows * G * kk * 2 * 4, s) != hipSuccess)
         return SM_ERR_LAUNCH;
     }
+    if (gather) {
+      DxgArgs t;
+      long long nb = 0, prow2 = 0;
+      for (int l = 0; l < SM_MAX_LEVELS; ++l) {
+        const bool on = l < d->nlev;
+        t.ntx[l] = on ? sm_cdiv(d->in_w[l], DXG_T) : 1;
+        t.nty[l] = on ? sm_cdiv(d->in_h[l], DXG_T) : 1;
+        t.tile0[l] = (int)nb;
+        t.prow0[l] = prow2;
+        if (on) {
+          nb += (long long)d->batch * t.ntx[l] * t.nty[l] * G;
+          prow2 += (long long)d->batch * d->out_h[l] * d->out_w[l];
+        }
+      }
+      t.tile0[SM_MAX_LEVELS] = (int)nb;
+      if (nb > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
+      hipLaunchKernelGGL(deform_dx_gather_kernel, dim3((unsigned)nb), dim3(256), 0, s, a, t, gcol, gx_col);
+    }
     if (d->kh == 3 && d->kw == 3) {               // one wave per (position, 64-channel chunk), nine taps unrolled
       const long long nunits = pl.P * (d->cin / 64);
       const int blocks = (int)std::min<long long>((nunits + 3) / 4, 256 * 64);
-      hipLaunchKernelGGL(deform_col2im9_kernel, dim3(blocks), dim3(256), 0, s, a, gcol, gx_col, grad_offset, nunits);
+      // (with the gather in front: every offset gradient, and the d(x) atomics of the far taps only)
+      if (!gather || grad_offset)
+        hipLaunchKernelGGL(deform_col2im9_kernel, dim3(blocks), dim3(256), 0, s, a, gcol, gx_col, grad_offset, nunits,
+                           gather ? 1 : 0);
     } else {
       const long long nunits = pl.P * kk * (d->cin / 64);
       const int blocks = (int)std::min<long long>((nunits + 3) / 4, 256 * 64);

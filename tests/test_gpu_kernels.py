@@ -665,6 +665,45 @@ def test_deform_conv_backward_vs_oracle(cfg):
     assert rel(wd2.grad, rw) < 1e-2
 
 
+@pytest.mark.parametrize("off_scale", [0.6, 2.5, 8.0])
+def test_deform_dx_gather_equals_atomic_scatter(off_scale):
+    """d(x) of FeatureAlign's deformable conv (round 5): samples within 3 pixels of their tap by the gather kernel (plain stores,
+    fixed order), the farther ones by the atomic scatter behind it -- against the scatter alone (SM_CONV_BWD_DX_SCATTER, the
+    kernel the oracle test above held until round 4) on a 3-level pyramid with tiles that hang over the image: equal up to
+    f32 summation order, the offset gradients untouched, and two runs of the gather path bit-identical when no sample is far
+    (0.6) -- the scatter's order is not reproducible.  8.0: nearly every sample takes the far path."""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(41)
+    B, C, Co, G = 2, 256, 256, 4
+    sizes = [(21, 37), (11, 19), (5, 8)]
+    lv = H.Levels(B, sizes)
+    x = torch.randn(lv.rows, C, generator=g).to(torch.bfloat16).to(dev)
+    off = (torch.randn(lv.rows, G * 18, generator=g) * off_scale).to(dev)
+    go = torch.randn(lv.rows, Co, generator=g).to(torch.bfloat16).to(dev)
+    w = torch.randn(Co, C, 3, 3, generator=g) / 48
+    w_t, _ = H.prep_conv_weight(w.permute(2, 3, 1, 0).reshape(9 * C, Co, 1, 1).contiguous().to(dev), Co)
+
+    def run(flags):
+        d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, C, Co, Co, 3, 1, 1, C, Co, flags=flags, deform_groups=G)
+        gx = torch.full((lv.rows, C), float("nan"), dtype=torch.float32, device=dev)
+        goff = torch.full_like(off, float("nan"))
+        H.deform_conv2d_bwd(d, x, off, w_t, go, gx, goff, None)
+        torch.cuda.synchronize()
+        return gx, goff
+
+    a, ao = run(0)
+    b, bo = run(1024)                                    # SM_CONV_BWD_DX_SCATTER
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert torch.equal(ao, bo)
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
+    if off_scale < 1.0:
+        assert float((off.abs() > 3.0).float().sum()) == 0
+        a2, _ = run(0)
+        assert torch.equal(a, a2)
+
+
 @pytest.mark.parametrize("cfg", [
     # (B, Cin, H, W, Cout, k, stride, pad, dil)
     (2, 64, 13, 17, 128, 3, 1, 1, 1),      # tower-like: fast dgrad (flipped-weight forward conv)
