@@ -59,7 +59,7 @@ class ConvPlan(C.Structure):
     _fields_ = [
         ("lds_dma", C.c_int32), ("k_step", C.c_int32), ("k_padded", C.c_int32), ("tile_cout", C.c_int32),
         ("tile_pos", C.c_int32), ("threads", C.c_int32), ("k_loop", C.c_int32), ("warp_spec", C.c_int32),
-        ("blocks", C.c_int64), ("split_k", C.c_int32), ("workspace_bytes", C.c_int64),
+        ("blocks", C.c_int64), ("split_k", C.c_int32), ("ring_stages", C.c_int32), ("workspace_bytes", C.c_int64),
     ]
 
 

@@ -1151,7 +1151,10 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
 // RESPF (A/B flag SM_CONV_DBG_RES_PREFETCH): the same-row residual of the register epilogue is loaded BEFORE the K
 // loop, so its HBM latency overlaps the operand DMA and the MFMAs instead of following them (the 1x1 + residual convs
 // of layer1/2 run 2 K steps per tile: load -> MFMA -> residual load -> store was four serial latencies per block).
-template <int WCO, int WPOS, int TCO, int TPOS, int MINB = 4, int OPT = 0, bool RESPF = false>
+// NST > 2 (round 5): a ring of NST stages with NST - 1 of them in flight -- counted vmcnt wait + raw s_barrier per K step
+// instead of __syncthreads (which drains the DMA queue).  For the launches whose blocks are all resident at once and live
+// for (K steps) x (one L2 / HBM round trip): the 1x1 convs of layer3 (16 800 positions, 8 / 32 steps).
+template <int WCO, int WPOS, int TCO, int TPOS, int MINB = 4, int OPT = 0, bool RESPF = false, int NST = 2>
 __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a) {
   constexpr int BCO = WCO * TCO * 32;
   constexpr int BPOS = WPOS * TPOS * 32;
@@ -1162,8 +1165,9 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
   constexpr int HROWS = BPOS / 2;                  // positions per epilogue pass
   constexpr int EPI_BYTES = HROWS * EPI_LD * 4;
   constexpr bool REG_ONLY = BCO * BPOS > 128 * 128;   // register epilogue only (see conv_igemm_kernel)
-  constexpr int SMEM_BYTES = (REG_ONLY || 2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+  constexpr int SMEM_BYTES = (REG_ONLY || NST * STAGE > EPI_BYTES) ? NST * STAGE : EPI_BYTES;
   static_assert(WCO * WPOS == 4, "4 waves");
+  static_assert(NST == 2 || (OPT != 0 && BCO >= 64 && SMEM_BYTES <= 65536), "ring: flat loader, every wave owns weight rows");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -1375,6 +1379,27 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
         }
       }
     };
+    if constexpr (NST > 2) {
+      // stage kt + NST - 1 is issued at the top of step kt, behind the barrier that says every wave is done with stage
+      // kt - 1 (the buffer it lands in).  vmcnt retires in order and every thread issues PER pieces per stage, so
+      // "all but my last (NST - 2) * PER" = stage kt has landed.  The plan guarantees nk >= NST - 1.
+      constexpr int PER = NW + NX;
+#pragma unroll
+      for (int s = 0; s < NST - 1; ++s) dma_tile_flat(s);
+      int buf = 0, nbuf = NST - 1;
+      for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + NST - 1 < nk) dma_tile_flat(nbuf);
+        compute_p(buf);
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+      }
+      if constexpr (!REG_ONLY) __syncthreads();
+    } else {
     dma_tile_flat(0);
     __syncthreads();
     for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -1385,6 +1410,7 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
     }
     compute_p((nk - 1) & 1);
     if constexpr (!REG_ONLY) __syncthreads();   // the LDS-staged epilogue re-uses the stages
+    }
   } else {
   dma_tile(0);
   __syncthreads();
@@ -1722,6 +1748,7 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p,
     // 128 couts x 256 positions (64x128 per wave: 0.75 fragment reads and 0.75 DMA bytes per MFMA of the 128x128
     // tile), behind an A/B flag
     if ((d->flags & SM_CONV_DBG_WIDE_POS) && reg_ok) cands[ncand++] = {128, 256};
+    if (!(k32 && (d->flags & SM_CONV_DBG_K32_POS64)))
     cands[ncand++] = {128, 128};
     cands[ncand++] = {128, 64};
     if (ncand < 4) cands[ncand++] = {64, 64};
@@ -1804,6 +1831,15 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p,
     else if (has_opt && d->cin >= 64 && !(d->flags & SM_CONV_DBG_LEGACY_LOOP)) opt = (d->flags & SM_CONV_DBG_FLAT_LOOP) ? 1 : 3;
   }
   if (ws && !((bco == 128 && (bpos == 128 || bpos == 64)) || (bco == 64 && bpos == 64))) return SM_ERR_UNSUPPORTED;
+  // 32-wide K: a ring of 3 / 4 stages (conv_dma32_kernel, NST) for launches whose blocks are all resident at once and
+  // whose K loop is a chain of DMA round trips
+  int ring = 0;
+  if (dma && k32 && d->cin >= 32 && ((bco == 128 && (bpos == 128 || bpos == 64)) || (bco == 64 && bpos == 64)) && Kp / 32 >= 8) {
+    if (d->flags & SM_CONV_DBG_K32_RING4) ring = 4;
+    else if (d->flags & SM_CONV_DBG_K32_RING3) ring = 3;
+  }
+  if (ring) opt = 3;
+  p->ring_stages = ring;
   p->lds_dma = dma ? 1 : 0;
   p->k_step = k32 ? 32 : 64;
   p->k_padded = Kp;
@@ -1937,6 +1973,31 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else if (tile == 128) SM_LAUNCH((conv_igemm_kernel<2, 2, 2, 2, DEFORM, false>));
     else if (tile == 64) SM_LAUNCH((conv_igemm_kernel<1, 4, 2, 2, DEFORM, false>));
     else SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 2, DEFORM, false>));
+#endif
+  } else if (k32 && plan.ring_stages > 2) {
+#ifndef SM_OPERAND_F16
+    // residual prefetch in front of the K loop where the register epilogue will run with a same-row residual
+    const bool rp = (d->flags & SM_CONV_RES_ADD) && !(d->flags & SM_CONV_DBG_LDS_EPILOGUE) && (d->cout & 7) == 0 &&
+                    (d->out_cstride & 7) == 0 && (d->out_coff & 7) == 0 && (d->res_cstride & 7) == 0 && d->cout % bco == 0;
+    const int r4 = plan.ring_stages == 4;
+    if (bco == 128 && bpos == 128) {
+      if (r4 && rp) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2, 2, 3, true, 4>));
+      else if (r4) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2, 2, 3, false, 4>));
+      else if (rp) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2, 2, 3, true, 3>));
+      else SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2, 2, 3, false, 3>));
+    } else if (bco == 128 && bpos == 64) {
+      if (r4 && rp) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1, 3, 3, true, 4>));
+      else if (r4) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1, 3, 3, false, 4>));
+      else if (rp) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1, 3, 3, true, 3>));
+      else SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1, 3, 3, false, 3>));
+    } else if (bco == 64 && bpos == 64) {
+      if (r4 && rp) SM_LAUNCH((conv_dma32_kernel<2, 2, 1, 1, 4, 3, true, 4>));
+      else if (r4) SM_LAUNCH((conv_dma32_kernel<2, 2, 1, 1, 4, 3, false, 4>));
+      else if (rp) SM_LAUNCH((conv_dma32_kernel<2, 2, 1, 1, 4, 3, true, 3>));
+      else SM_LAUNCH((conv_dma32_kernel<2, 2, 1, 1, 4, 3, false, 3>));
+    } else return SM_ERR_UNSUPPORTED;
+#else
+    return SM_ERR_UNSUPPORTED;
 #endif
   } else if (k32) {
 #ifdef SM_EXPERIMENTS

@@ -26,6 +26,9 @@ SHAPES = [
     ("l2.conv3 1x1 128->512 +res 100x168", [(100, 168)], 128, 512, 1, 1, 0, _lib.SM_CONV_RELU, True),
     ("l3.conv2 3x3 256->256 50x84", [(50, 84)], 256, 256, 3, 1, 1, _lib.SM_CONV_RELU, False),
     ("l3.conv3 1x1 256->1024 +res 50x84", [(50, 84)], 256, 1024, 1, 1, 0, _lib.SM_CONV_RELU, True),
+    ("l3.conv1 1x1 1024->256 50x84", [(50, 84)], 1024, 256, 1, 1, 0, _lib.SM_CONV_RELU, False),
+    ("l2.conv1 1x1 512->128 100x168", [(100, 168)], 512, 128, 1, 1, 0, _lib.SM_CONV_RELU, False),
+    ("l4.conv3 1x1 512->2048 +res 25x42", [(25, 42)], 512, 2048, 1, 1, 0, _lib.SM_CONV_RELU, True),
     ("l4.conv2 3x3 512->512 25x42", [(25, 42)], 512, 512, 3, 1, 1, _lib.SM_CONV_RELU, False),
     ("mask_lat0 1x1 768->512 100x168", [(100, 168)], 768, 512, 1, 1, 0, _lib.SM_CONV_RELU, False),
     ("stem 7x7 s2 8->64 800x1344", [(800, 1344)], 8, 64, 7, 2, 3, _lib.SM_CONV_RELU, False),
@@ -62,6 +65,20 @@ def main():
                                           flags=fl, res_cstride=cout))
         flops = 2.0 * lo.rows * cout * cin * k * k
         byts = lv.rows * cin * 2 + lo.rows * cout * (4 if f32 else 2) * (2 if res else 1) + wq.numel() * 2
+        # every variant must reproduce variant 0 bit for bit (same K order per output)
+        plans, y0 = [], None
+        for v, d in zip(variants, descs):
+            pl = H.conv_plan(d)
+            plans.append("%dx%d k%d%s b%d" % (pl["tile_cout"], pl["tile_pos"], pl["k_step"],
+                                            (" ring%d" % pl["ring_stages"]) if pl["ring_stages"] else "", pl["blocks"]))
+            y.zero_()
+            H.conv2d(d, x, wq, bias, r, y)
+            torch.cuda.synchronize()
+            if y0 is None:
+                y0 = y.clone()
+            elif not torch.equal(y0, y):
+                print("MISMATCH %s flags=%#x: max abs %.4g" % (name, v, (y0.float() - y.float()).abs().max().item()))
+        print("%-40s plans: %s" % (name, " | ".join(plans)))
         cases.append((name, descs, x, wq, bias, r, y, flops, byts))
     res_ms = {(c[0], v): [] for c in cases for v in variants}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
