@@ -156,7 +156,8 @@ typedef struct sm_conv_plan {
   int32_t warp_spec;  /* producer/consumer A/B variant */
   int64_t blocks;     /* grid size (without split-K) */
   int32_t split_k;    /* K slices per tile sm_conv2d_ws would use given a workspace (1 = no split) */
-  int32_t ring_stages; /* 32-wide K steps: 0 = two LDS stages and a draining barrier per step; 3 / 4 = a ring with 2 / 3 stages in flight */
+  int32_t ring_stages; /* 32-wide K steps: 0 = two LDS stages and a draining barrier per step (always, in the default build);
+                        * 3 / 4 = the experiments build's operand ring (csrc/experiments.h; measured neutral) */
   int64_t workspace_bytes; /* f32 partial slabs [split_k][rows][cout_pad] needed for that; 0 when split_k == 1 */
 } sm_conv_plan;
 int sm_conv_plan_query(const sm_conv_desc* d, int deformable, int with_gn_stats, sm_conv_plan* out);

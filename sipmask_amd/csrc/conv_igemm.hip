@@ -1151,9 +1151,10 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
 // RESPF (A/B flag SM_CONV_DBG_RES_PREFETCH): the same-row residual of the register epilogue is loaded BEFORE the K
 // loop, so its HBM latency overlaps the operand DMA and the MFMAs instead of following them (the 1x1 + residual convs
 // of layer1/2 run 2 K steps per tile: load -> MFMA -> residual load -> store was four serial latencies per block).
-// NST > 2 (round 5): a ring of NST stages with NST - 1 of them in flight -- counted vmcnt wait + raw s_barrier per K step
-// instead of __syncthreads (which drains the DMA queue).  For the launches whose blocks are all resident at once and live
-// for (K steps) x (one L2 / HBM round trip): the 1x1 convs of layer3 (16 800 positions, 8 / 32 steps).
+// NST > 2 (round 5, experiments build): a ring of NST stages with NST - 1 of them in flight -- counted vmcnt wait + raw
+// s_barrier per K step instead of __syncthreads (which drains the DMA queue).  Meant for the launches whose blocks are all
+// resident at once (the 1x1 convs of layer3: 16 800 positions, 8 / 32 K steps); bit-identical, -14..-18 % on those two launches
+// alone, -0.5 % (3 stages) / -3 % (4) on the pipelined step: profiles/r05_conv_ring_ab.txt, DESIGN section 6.
 template <int WCO, int WPOS, int TCO, int TPOS, int MINB = 4, int OPT = 0, bool RESPF = false, int NST = 2>
 __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a) {
   constexpr int BCO = WCO * TCO * 32;
@@ -1831,13 +1832,15 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p,
     else if (has_opt && d->cin >= 64 && !(d->flags & SM_CONV_DBG_LEGACY_LOOP)) opt = (d->flags & SM_CONV_DBG_FLAT_LOOP) ? 1 : 3;
   }
   if (ws && !((bco == 128 && (bpos == 128 || bpos == 64)) || (bco == 64 && bpos == 64))) return SM_ERR_UNSUPPORTED;
-  // 32-wide K: a ring of 3 / 4 stages (conv_dma32_kernel, NST) for launches whose blocks are all resident at once and
-  // whose K loop is a chain of DMA round trips
+  // 32-wide K, experiments build only: a ring of 3 / 4 LDS stages (conv_dma32_kernel, NST; SIPMASK_EXP_K32_RING = 3 | 4)
   int ring = 0;
-  if (dma && k32 && d->cin >= 32 && ((bco == 128 && (bpos == 128 || bpos == 64)) || (bco == 64 && bpos == 64)) && Kp / 32 >= 8) {
-    if (d->flags & SM_CONV_DBG_K32_RING4) ring = 4;
-    else if (d->flags & SM_CONV_DBG_K32_RING3) ring = 3;
+#ifdef SM_EXPERIMENTS
+  if (dma && k32 && !(d->flags & SM_CONV_F16) && d->cin >= 32 && Kp / 32 >= 8 &&
+      ((bco == 128 && (bpos == 128 || bpos == 64)) || (bco == 64 && bpos == 64))) {
+    const int e = sm_experiment_env("SIPMASK_EXP_K32_RING", 0);
+    if (e == 3 || e == 4) ring = e;
   }
+#endif
   if (ring) opt = 3;
   p->ring_stages = ring;
   p->lds_dma = dma ? 1 : 0;
@@ -1975,7 +1978,7 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else SM_LAUNCH((conv_igemm_kernel<1, 4, 1, 2, DEFORM, false>));
 #endif
   } else if (k32 && plan.ring_stages > 2) {
-#ifndef SM_OPERAND_F16
+#if defined(SM_EXPERIMENTS) && !defined(SM_OPERAND_F16)
     // residual prefetch in front of the K loop where the register epilogue will run with a same-row residual
     const bool rp = (d->flags & SM_CONV_RES_ADD) && !(d->flags & SM_CONV_DBG_LDS_EPILOGUE) && (d->cout & 7) == 0 &&
                     (d->out_cstride & 7) == 0 && (d->out_coff & 7) == 0 && (d->res_cstride & 7) == 0 && d->cout % bco == 0;

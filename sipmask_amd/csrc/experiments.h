@@ -29,9 +29,7 @@ static inline int sm_experiment_env(const char* name, int dflt) {
 #define SM_CONV_DBG_PATCH_PINGPONG 0x00000080u // sm_conv3x3_patch: ping-pong schedule of two wave groups
 #define SM_CONV_DBG_WARP_SPEC 0x02000000u      // 8-wave producer/consumer variant of the 64-wide-K kernel
 #define SM_CONV_DBG_PATCH_W4 0x10000000u       // sm_conv3x3_patch (uniform launches): 4 waves x (128 couts x 128 positions), accumulators in AGPRs
-#define SM_CONV_DBG_K32_RING3 0x00002000u       // sm_conv2d, 32-wide K steps: three-stage ring (bits shared with the patch kernel's own flags)
-#define SM_CONV_DBG_K32_RING4 0x00001000u       // ... four-stage ring
-#define SM_CONV_DBG_K32_POS64 0x00000800u       // ... 128-cout tiles start at 64 positions
+#define SM_CONV_DBG_K32_POS64 0x00000800u       // sm_conv2d, 32-wide K steps: 128-cout tiles start at 64 positions (bit shared with a patch-kernel flag)
 #define SM_CONV_DBG_DX3_NO_BLEND 0x00000400u   // ABLATION (wrong results), sm_deform_conv2d_x3: constant operand (with PATCH_NO_DMA / PATCH_NO_MFMA: the other two)
 #else
 #define SM_CONV_DBG_LINEAR_TILES 0u
@@ -50,8 +48,6 @@ static inline int sm_experiment_env(const char* name, int dflt) {
 #define SM_CONV_DBG_PATCH_PINGPONG 0u
 #define SM_CONV_DBG_WARP_SPEC 0u
 #define SM_CONV_DBG_PATCH_W4 0u
-#define SM_CONV_DBG_K32_RING3 0u
-#define SM_CONV_DBG_K32_RING4 0u
 #define SM_CONV_DBG_K32_POS64 0u
 #define SM_CONV_DBG_DX3_NO_BLEND 0u
 #endif

@@ -28,7 +28,7 @@ def _bf(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def _run_conv(x, w, bias, stride, pad, relu=False, out_f32=False, residual=None, in_relu=False, extra_flags=0):
+def _run_conv(x, w, bias, stride, pad, relu=False, out_f32=False, residual=None, in_relu=False, extra_flags=0, want_plan=None):
     """x [B,C,H,W] f32 (bf16-representable), w [Co,Ci,k,k]; returns NCHW f32 on cpu."""
     from sipmask_amd import hip_ops as H, _lib
     dev = _dev()
@@ -49,6 +49,8 @@ def _run_conv(x, w, bias, stride, pad, relu=False, out_f32=False, residual=None,
     y = torch.empty(B * Ho * Wo, Co, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
     d = H.make_conv_desc(B, [(Hh, Ww)], [(Ho, Wo)], [0], [0], cpad, Co, co_pad, k, stride, pad, cpad, Co,
                          flags=flags, res_cstride=Co)
+    if want_plan is not None:
+        want_plan.update(H.conv_plan(d))
     H.conv2d(d, xh, wq, None if bias is None else bias.to(dev), res, y)
     torch.cuda.synchronize()
     return y.float().view(B, Ho, Wo, Co).permute(0, 3, 1, 2).cpu()
@@ -101,6 +103,43 @@ def test_conv_loader_variants(variant):
         torch.testing.assert_close(y, F.relu(ref + r), rtol=1e-4, atol=2e-4)
         yb = _run_conv(x, w, b, s, p, extra_flags=variant)
         torch.testing.assert_close(yb, ref, rtol=2 ** -7, atol=2e-3)
+
+
+@pytest.mark.parametrize("ring", [3, 4])
+def test_conv_k32_operand_ring_is_bit_identical(ring, monkeypatch):
+    """EXPERIMENTS build only (`make -C sipmask_amd/csrc EXPERIMENTS=1`; skipped on the default library): the 32-wide-K kernel
+    with a 3- / 4-stage LDS ring (counted vmcnt waits + raw barrier per K step, round 5; SIPMASK_EXP_K32_RING) accumulates every
+    output in the same K order as the two-stage loop: identical bits on all three tiles it takes (128x128 via BIG_TILES,
+    128x64 / 64x64 by the occupancy rule), with the prefetched same-row residual, ragged position tiles, a 3x3 (the flat
+    loader's tap walk) and bf16 / f32 outputs; a launch it does not take (fewer than 8 K steps) keeps the two-stage loop."""
+    g = torch.Generator().manual_seed(50 + ring)
+    BIG = 0x04000000
+    seen = set()
+    for (B, Ci, Hh, Ww, Co, k, s, p, fl) in [(2, 1024, 21, 33, 256, 1, 1, 0, 0), (2, 1024, 21, 33, 256, 1, 1, 0, BIG),
+                                              (2, 256, 50, 84, 1024, 1, 1, 0, 0), (2, 256, 19, 23, 128, 1, 1, 0, BIG),
+                                              (2, 512, 25, 42, 64, 1, 1, 0, 0), (1, 64, 30, 41, 128, 3, 1, 1, BIG),
+                                              (1, 64, 12, 10, 256, 1, 1, 0, 0)]:
+        x = _bf(torch.randn(B, Ci, Hh, Ww, generator=g))
+        w = _bf(torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5)
+        b = torch.randn(Co, generator=g)
+        r = _bf(torch.randn(B, Co, Hh, Ww, generator=g))
+        for out_f32, res in ((True, r), (False, None), (False, r)):
+            pl = {}
+            monkeypatch.setenv("SIPMASK_EXP_K32_RING", "0")
+            y0 = _run_conv(x, w, b, s, p, relu=True, out_f32=out_f32, residual=res, extra_flags=fl)
+            monkeypatch.setenv("SIPMASK_EXP_K32_RING", str(ring))
+            y1 = _run_conv(x, w, b, s, p, relu=True, out_f32=out_f32, residual=res, extra_flags=fl, want_plan=pl)
+            if pl["ring_stages"] == 0 and Ci * k * k >= 256:
+                pytest.skip("default build: the operand ring exists in the experiments build only")
+            assert pl["k_step"] == 32
+            assert pl["ring_stages"] == (ring if Ci * k * k >= 256 else 0), pl
+            if pl["ring_stages"]:
+                seen.add((pl["tile_cout"], pl["tile_pos"]))
+            assert torch.equal(y0, y1), (Ci, Co, k, fl, out_f32, float((y0 - y1).abs().max()))
+        ref = F.relu(F.conv2d(x, w, b, s, p) + r)
+        torch.testing.assert_close(_run_conv(x, w, b, s, p, relu=True, out_f32=True, residual=r, extra_flags=fl), ref,
+                                   rtol=1e-4, atol=2e-4)
+    assert seen == {(128, 128), (128, 64), (64, 64)}, seen
 
 
 @pytest.mark.parametrize("cfg", [

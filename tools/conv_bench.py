@@ -29,6 +29,10 @@ SHAPES = [
     ("l3.conv1 1x1 1024->256 50x84", [(50, 84)], 1024, 256, 1, 1, 0, _lib.SM_CONV_RELU, False),
     ("l2.conv1 1x1 512->128 100x168", [(100, 168)], 512, 128, 1, 1, 0, _lib.SM_CONV_RELU, False),
     ("l4.conv3 1x1 512->2048 +res 25x42", [(25, 42)], 512, 2048, 1, 1, 0, _lib.SM_CONV_RELU, True),
+    ("l4.conv1 1x1 2048->512 25x42", [(25, 42)], 2048, 512, 1, 1, 0, _lib.SM_CONV_RELU, False),
+    ("fpn.lat2 1x1 2048->256 25x42", [(25, 42)], 2048, 256, 1, 1, 0, 0, False),
+    ("l3.ds 1x1 s2 512->1024 100x168", [(100, 168)], 512, 1024, 1, 2, 0, 0, False),
+    ("l4.ds 1x1 s2 1024->2048 50x84", [(50, 84)], 1024, 2048, 1, 2, 0, 0, False),
     ("l4.conv2 3x3 512->512 25x42", [(25, 42)], 512, 512, 3, 1, 1, _lib.SM_CONV_RELU, False),
     ("mask_lat0 1x1 768->512 100x168", [(100, 168)], 768, 512, 1, 1, 0, _lib.SM_CONV_RELU, False),
     ("stem 7x7 s2 8->64 800x1344", [(800, 1344)], 8, 64, 7, 2, 3, _lib.SM_CONV_RELU, False),
@@ -40,10 +44,19 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=str, default="", help="comma separated substring filters on the shape name")
-    ap.add_argument("--variants", type=str, default="0,%d" % 0x40000000, help="comma separated extra flag words")
+    ap.add_argument("--variants", type=str, default="0,%d" % 0x40000000,
+                    help="comma separated extra flag words; 'FLAGS:rN' also sets SIPMASK_EXP_K32_RING=N for that variant's "
+                         "launches (experiments build)")
     args = ap.parse_args()
     dev = torch.device("cuda")
-    variants = [int(v, 0) for v in args.variants.split(",")]
+    variants = args.variants.split(",")
+
+    def vflags(v):
+        return int(v.split(":")[0], 0)
+
+    def vring(v):
+        return int(v.split(":r")[1]) if ":r" in v else 0
+
     cases = []
     for name, sizes, cin, cout, k, s, p, flags, res in SHAPES:
         if args.only and not any(o in name for o in args.only.split(",")):
@@ -60,7 +73,7 @@ def main():
         bias = torch.randn(cout, device=dev)
         descs = []
         for v in variants:
-            fl = flags | v | (_lib.SM_CONV_RES_ADD if res else 0)
+            fl = flags | vflags(v) | (_lib.SM_CONV_RES_ADD if res else 0)
             descs.append(H.make_conv_desc(B, sizes, osz, lv.row0, lo.row0, cin, cout, co_pad, k, s, p, cin, cout,
                                           flags=fl, res_cstride=cout))
         flops = 2.0 * lo.rows * cout * cin * k * k
@@ -68,6 +81,7 @@ def main():
         # every variant must reproduce variant 0 bit for bit (same K order per output)
         plans, y0 = [], None
         for v, d in zip(variants, descs):
+            os.environ["SIPMASK_EXP_K32_RING"] = str(vring(v))
             pl = H.conv_plan(d)
             plans.append("%dx%d k%d%s b%d" % (pl["tile_cout"], pl["tile_pos"], pl["k_step"],
                                             (" ring%d" % pl["ring_stages"]) if pl["ring_stages"] else "", pl["blocks"]))
@@ -77,7 +91,7 @@ def main():
             if y0 is None:
                 y0 = y.clone()
             elif not torch.equal(y0, y):
-                print("MISMATCH %s flags=%#x: max abs %.4g" % (name, v, (y0.float() - y.float()).abs().max().item()))
+                print("MISMATCH %s variant %s: max abs %.4g" % (name, v, (y0.float() - y.float()).abs().max().item()))
         print("%-40s plans: %s" % (name, " | ".join(plans)))
         cases.append((name, descs, x, wq, bias, r, y, flops, byts))
     res_ms = {(c[0], v): [] for c in cases for v in variants}
@@ -85,6 +99,7 @@ def main():
     for rnd in range(args.rounds + 1):
         for name, descs, x, wq, bias, r, y, flops, byts in cases:
             for v, d in zip(variants, descs):
+                os.environ["SIPMASK_EXP_K32_RING"] = str(vring(v))
                 e0.record()
                 for _ in range(args.iters):
                     H.conv2d(d, x, wq, bias, r, y)
@@ -92,7 +107,7 @@ def main():
                 torch.cuda.synchronize()
                 if rnd > 0:
                     res_ms[(name, v)].append(e0.elapsed_time(e1) / args.iters)
-    print("%-40s %10s %s" % ("shape", "GFLOP", "  ".join("flags=%#x: ms(med) TF/s GB/s" % v for v in variants)))
+    print("%-40s %10s %s" % ("shape", "GFLOP", "  ".join("%s: ms(med) TF/s GB/s" % v for v in variants)))
     for name, descs, x, wq, bias, r, y, flops, byts in cases:
         cols = []
         for v in variants:
