@@ -1,3 +1,4 @@
+# experiments build (make -C sipmask_amd/csrc EXPERIMENTS=1): the operand ring of conv_dma32_kernel, kernel level and step level
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -8,11 +9,11 @@ timeout 400 python tools/conv_bench.py --only "l3.conv1,l3.conv3,l4.conv3,l2.con
 cat gpurun_out/r5c12_conv_ring.txt
 for pass in 1 2; do
   for r in 2 4 3; do
-    timeout 300 python tools/bench_with.py _K32_RING=$r -- --steps 300 --warmup 20 --no-cpu-baseline --no-extras > gpurun_out/r5c12_ring${r}_$pass.json 2> gpurun_out/r5c12_ring${r}_$pass.err
+    SIPMASK_EXP_K32_RING=$r timeout 300 python bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-extras > gpurun_out/r5c12_ring${r}_$pass.json 2> gpurun_out/r5c12_ring${r}_$pass.err
     echo "ring $r pass $pass: $(python -c "import json,sys; d=json.loads(open('gpurun_out/r5c12_ring${r}_$pass.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])")"
   done
 done
 for r in 2 4; do
-  timeout 300 python tools/bench_with.py _K32_RING=$r -- --config r101 --steps 200 --warmup 20 --no-cpu-baseline --no-extras > gpurun_out/r5c12_r101_ring$r.json 2> gpurun_out/r5c12_r101_ring$r.err
+  SIPMASK_EXP_K32_RING=$r timeout 300 python bench.py --config r101 --steps 200 --warmup 20 --no-cpu-baseline --no-extras > gpurun_out/r5c12_r101_ring$r.json 2> gpurun_out/r5c12_r101_ring$r.err
   echo "r101 ring $r: $(python -c "import json,sys; d=json.loads(open('gpurun_out/r5c12_r101_ring$r.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])")"
 done
