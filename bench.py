@@ -52,6 +52,7 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (= the f32 vector rate), same guide
 IMG_H, IMG_W = 800, 1344           # 800x1333 padded to a multiple of 32 (cfg Pad size_divisor=32)
+SSD_HW = (544, 544)                # M/configs/sipmask/sipmask_r50_caffe_fpn_ssd_6x.py:98-109 (img_scale, keep_ratio=False)
 VIS_H, VIS_W, VIS_T = 384, 640, 8  # 640x360 frames padded to 32 (V/ config size_divisor=32), frames per clip
 VIS_CLIPS = int(os.environ.get("SIPMASK_VIS_CLIPS", "8"))   # clips per GPU per step of --config vis (pipelined: SipMaskVIS.clip_test_many)
 STUB = os.environ.get("SIPMASK_BENCH_STUB", "0") == "1"   # CPU test hook: gloo + a sleeping step, no GPU work
@@ -65,12 +66,15 @@ def parse(argv=None):
                          "two concurrent half-batch chains (engine.SubBatchPlan)")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=("r50", "r101", "train", "vis", "eval_shapes"), default="r50")
+    ap.add_argument("--config", choices=("r50", "r101", "train", "vis", "eval_shapes", "ssd"), default="r50",
+                    help="r50 / r101 / train / vis: BASELINE configs[1]-[4]; eval_shapes: an evaluation loop over keep_ratio canvases; "
+                         "ssd: the 544 x 544 SSD-style config (sipmask_r50_caffe_fpn_ssd_6x.py: two-conv towers without GroupNorm, "
+                         "fast_nms, 8 images per GPU)")
     ap.add_argument("--precision", choices=("bf16", "f32", "head_x3"), default="bf16",
                     help="bf16 = the throughput plan (BASELINE configs[1] names bf16); head_x3 = bf16 backbone + FPN with the "
                          "split-precision head (binary16 halves, three MFMA terms, f32 activations: mask logits within 1e-3 "
                          "of the fp32 reference head on identical features); f32 = the all-f32 parity plan")
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE configs[1]: 4)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (BASELINE configs[1]: 4; --config ssd: 8)")
     ap.add_argument("--depth", type=int, default=None, help="backbone depth (overrides the config's)")
     ap.add_argument("--lanes", type=int, default=0, help="run the batch as this many independent sub-batch plans on "
                     "concurrent HIP streams (engine.SubBatchPlan); 0 = the product default (2 for even batches >= 4)")
@@ -101,9 +105,11 @@ def parse(argv=None):
                          "statistics fused) N times and exit, so a rocprofv3 --stats / --pmc run sees that kernel alone")
     a = ap.parse_args(argv)
     if a.steps is None:
-        a.steps = {"r50": 50, "r101": 50, "train": 10, "vis": 10, "eval_shapes": 64}[a.config]      # >= 50 iterations after 10 warm-ups
+        a.steps = {"r50": 50, "r101": 50, "train": 10, "vis": 10, "eval_shapes": 64, "ssd": 50}[a.config]      # >= 50 iterations after 10 warm-ups
     if a.warmup is None:
-        a.warmup = {"r50": 10, "r101": 10, "train": 3, "vis": 2, "eval_shapes": 12}[a.config]
+        a.warmup = {"r50": 10, "r101": 10, "train": 3, "vis": 2, "eval_shapes": 12, "ssd": 10}[a.config]
+    if a.batch is None:
+        a.batch = 8 if a.config == "ssd" else 4
     if a.depth is None:
         a.depth = 101 if a.config == "r101" else 50
     if a.config == "eval_shapes" and a.in_flight < 2:
@@ -127,7 +133,7 @@ def relaunch_with_ranks(args):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines
-def cpu_baseline_inference(det, depth, seed=0, budget_s=0.0):
+def cpu_baseline_inference(det, depth, seed=0, budget_s=0.0, hw=None, img_shape=None, ssd=False):
     """The CPU oracle (kind "port": the reference has no CPU path) on ONE 800x1344 image: 1 warm-up +
     up to 5 timed forwards of extract_feat -> head -> get_masks (no RLE) inside a ~30 s budget, MEDIAN reported."""
     import torch
@@ -137,7 +143,10 @@ def cpu_baseline_inference(det, depth, seed=0, budget_s=0.0):
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in det.state_dict().items()}
-    img = torch.randn(1, 3, IMG_H, IMG_W, generator=torch.Generator().manual_seed(seed))
+    hw = hw or (IMG_H, IMG_W)
+    img_shape = img_shape or (IMG_H, 1333, 3)
+    cfg = dict(OM.DEFAULT_TEST_CFG, score_thr=float(det.test_cfg["score_thr"]))
+    img = torch.randn(1, 3, hw[0], hw[1], generator=torch.Generator().manual_seed(seed))
     times = []
     budget_s = budget_s or 30.0
     budget = time.perf_counter() + budget_s
@@ -146,15 +155,15 @@ def cpu_baseline_inference(det, depth, seed=0, budget_s=0.0):
         with torch.no_grad():
             cls, bb, ctr, cof, fm = OM.detector_forward(sd, img, depth)
             OM.get_masks_single([c[0] for c in cls], [c[0] for c in bb], [c[0] for c in ctr], [c[0] for c in cof],
-                                fm[0], (IMG_H, 1333, 3), OM.DEFAULT_TEST_CFG)
+                                fm[0], img_shape, cfg, scale_factor=[1.0, 1.0, 1.0, 1.0] if ssd else 1.0, ssd_flag=ssd)
         times.append(time.perf_counter() - t0)
         if time.perf_counter() > budget and len(times) >= 2:
             break
     timed = sorted(times[1:]) if len(times) > 1 else times
     t = timed[len(timed) // 2]
     return dict(value=round(1.0 / t, 4), unit="img/s", cores=cores, kind="port",
-                sample="1 image 3x800x1344 fp32 per forward, torch-CPU oracle (oneDNN convs + restated deform/NMS/"
-                       "mask ops), 1 warm-up + %d timed forward(s) in a %.0f s budget, median %.2f s" % (len(timed), budget_s, t))
+                sample="1 image 3x%dx%d fp32 per forward, torch-CPU oracle (oneDNN convs + restated deform/NMS/"
+                       "mask ops), 1 warm-up + %d timed forward(s) in a %.0f s budget, median %.2f s" % (hw[0], hw[1], len(timed), budget_s, t))
 
 
 def cpu_baseline_train(det, depth, seed=0, budget_s=0.0):
@@ -277,7 +286,7 @@ def parity_on_identical_features(det, ora, batch, shape, precision):
 COCO_AREA_MIX = (("small", 0.41, 8.0, 32.0), ("medium", 0.34, 32.0, 96.0), ("large", 0.24, 96.0, 420.0))
 
 
-def coco_boxes(nsets, batch, max_num, img_h, img_w, seed=7):
+def coco_boxes(nsets, batch, max_num, img_h, img_w, seed=7, scale_xy=None):
     """`nsets` x [batch, max_num, 4] boxes (x1, y1, x2, y2, network-input pixels) drawn with a fixed seed from COCO's published
     object-size mix (cocodataset.org detection evaluation: ~41 % of the objects small (area < 32^2 px), 34 % medium, 24 % large
     (> 96^2) in the ORIGINAL image, typically 640 x 480): sqrt(area) log-uniform inside its class, aspect ratio log-uniform in
@@ -297,7 +306,8 @@ def coco_boxes(nsets, batch, max_num, img_h, img_w, seed=7):
         n = int(m.sum())
         side = np.exp(rng.uniform(np.log(lo), np.log(hi), n)) * scale          # sqrt(area) at the network input scale
         ar = np.exp(rng.uniform(np.log(0.5), np.log(2.0), n))
-        w, h = np.minimum(side * np.sqrt(ar), img_w - 2.0), np.minimum(side / np.sqrt(ar), img_h - 2.0)
+        sxy = scale_xy or (scale, scale)           # (keep_ratio=False configs stretch the two axes differently)
+        w, h = np.minimum(side / scale * sxy[0] * np.sqrt(ar), img_w - 2.0), np.minimum(side / scale * sxy[1] / np.sqrt(ar), img_h - 2.0)
         cx, cy = rng.uniform(w / 2, img_w - 1 - w / 2), rng.uniform(h / 2, img_h - 1 - h / 2)
         out[m] = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
     frac = {name: float((cls == k).mean()) for k, (name, _, _, _) in enumerate(COCO_AREA_MIX)}
@@ -387,19 +397,30 @@ def run_inference(args, rank, world, dev):
     from sipmask_amd.dist_shard import gather_counts, timed_steps
     from sipmask_amd.synthetic import build_synthetic_detector, calibrate_cls_bias
     B = args.batch
-    det = build_synthetic_detector(args.depth, seed=0)
+    ssd = args.config == "ssd"
+    det = build_synthetic_detector(args.depth, seed=0, ssd=ssd)
+    # the 544 x 544 SSD-style config resizes without keep_ratio (sipmask_r50_caffe_fpn_ssd_6x.py:98-109): no padding
+    IMG_H, IMG_W = (SSD_HW if ssd else (globals()["IMG_H"], globals()["IMG_W"]))
+    thr = float(det.test_cfg["score_thr"])
+    sfkw = dict(scale_factor=[1.0, 1.0, 1.0, 1.0]) if ssd else {}     # keep_ratio=False pipelines carry [w, h, w, h] (sipmask_head.py:629-630)
     g = torch.Generator().manual_seed(1234 + rank)
     # NSETS synthetic batches resident in HBM; every step copies the next one into the plan's static input (device to
     # device, inside the timed region) so no step sees the images -- and the mask rectangles -- of the step before
     NSETS = 3
     imgs = [torch.randn(B, 3, IMG_H, IMG_W, generator=g).to(dev) for _ in range(NSETS)]
     img = imgs[0].clone()
-    shape = (IMG_H, 1333, 3)
-    eng = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=1)
-    calibrate_cls_bias(det, eng, img, target_per_img=1000)           # updates fcos_cls.bias in place -> plan rebuilt
+    shape = (IMG_H, IMG_W if ssd else 1333, 3)
+    eng = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=1, **sfkw)
+    if ssd:      # no norm layer in these towers: bring the sampling offsets back to ~1 px (conv_offset rescaled -> plan rebuilt)
+        from sipmask_amd.synthetic import calibrate_offset_scale
+        calibrate_offset_scale(det, eng, img, target_std=1.0)
+        del eng
+        torch.cuda.empty_cache()
+        eng = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=1, **sfkw)
+    calibrate_cls_bias(det, eng, img, target_per_img=1000, score_thr=thr)   # updates fcos_cls.bias in place -> plan rebuilt
     del eng
     torch.cuda.empty_cache()
-    eng = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=1)
+    eng = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=1, **sfkw)
 
     # ---- the timed plan: det.prepare's default runs an even batch >= 4 as two concurrent half-batch chains
     # (engine.SubBatchPlan); --lanes 1 forces the single plan
@@ -407,15 +428,16 @@ def run_inference(args, rank, world, dev):
     torch.cuda.empty_cache()
     pipelined = args.in_flight > 1 and not args.no_graph and not args.sub_graphs and not args.tower_only
     plan = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=args.lanes or "auto",
-                       in_flight=args.in_flight if pipelined else 1)
+                       in_flight=args.in_flight if pipelined else 1, **sfkw)
     if args.tower_only and args.in_flight > 1:       # the profiling aid times the kernel of the plan the pipelined default runs
-        plan = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=args.lanes or 1, slot=1, pipelined=True)
+        plan = det.prepare(B, (IMG_H, IMG_W), shape, precision=args.precision, lanes=args.lanes or 1, slot=1, pipelined=True, **sfkw)
         plan.multi_stream = False
     # ---- the post-processing workload of the timed steps (--det-boxes): see coco_boxes / install_det_boxes
     first = plan.plans[0] if hasattr(plan, "plans") else plan
     first = first.engines[0] if hasattr(first, "engines") else first
     det_flag = torch.zeros((), dtype=torch.bool, device=dev)
-    box_sets, box_info = coco_boxes(NSETS, B, first.max_num, shape[0], shape[1])
+    box_sets, box_info = coco_boxes(NSETS, B, first.max_num, shape[0], shape[1],
+                                    scale_xy=(IMG_W / 640.0, IMG_H / 480.0) if ssd else None)
     box_sets = box_sets.to(dev)
     hooked = not args.tower_only and not first.benchmark
     if hooked:
@@ -627,6 +649,7 @@ def run_inference(args, rank, world, dev):
     if grouped:
         towers = grouped
     tower_ms = sum(conv_ms[c.name] for c in towers) / len(towers)
+    rows_m = int(round(towers[0].flops / (2.0 * 256 * 2304) / (2 if grouped else 1)))     # positions of one tower conv (22 400 per 800 x 1344 image)
     x3 = args.precision == "head_x3"
     # x3: three binary16 half products per element product -- the MFMA pipe does 3x the algorithmic FLOPs, and THAT is what
     # the roofline fraction prices (the algorithmic figure is reported beside it)
@@ -671,27 +694,29 @@ def run_inference(args, rank, world, dev):
                     (sum(acc), all_conv_ms, all_conv_flops / all_conv_ms / 1e9, all_conv_flops / 1e9))
     if f32:
         kernel = ("conv_f32_kernel<2,2,2,2> (v_mfma_f32_32x32x2_f32, 128x128 tile, 16-wide K steps, register-staged "
-                  "loader) = tower 3x3 256->256 over 5 FPN levels (M=%d,N=256,K=2304)" % (eng.batch * 22400))
+                  "loader) = tower 3x3 256->256 over 5 FPN levels (M=%d,N=256,K=2304)" % (rows_m))
     elif x3:
         kernel = ("conv3x3_patch_kernel, binary16 operands (v_mfma_f32_32x32x16_f16): cls+reg tower 3x3 256->256 of one depth "
                   "over 5 FPN levels as ONE grouped launch on split operands [hi|lo|hi] x [hi|hi|lo] (2 x (M=%d,N=256,"
                   "K=3*2304)), f32 output, fixed-point GroupNorm statistics fused; achieved = MFMA FLOPs issued "
-                  "(3 x %.1f algorithmic GFLOP)" % (eng.batch * 22400, towers[0].flops / 1e9))
+                  "(3 x %.1f algorithmic GFLOP)" % (rows_m, towers[0].flops / 1e9))
     elif getattr(towers[0], "patch", False):
         kernel = ("conv3x3_patch_kernel (input patch + 2 taps of weights resident in LDS via LDS-DMA, 256x256 tile on 8 "
                   "waves, GroupNorm statistics fused)%s = tower 3x3 256->256 over 5 FPN levels (%sM=%d,N=256,K=2304)"
                   % (", cls+reg towers of one depth as ONE grouped launch" if grouped else "", "2 x " if grouped else "",
-                     eng.batch * 22400))
+                     rows_m))
     elif grouped:
         kernel = ("conv_igemm_kernel<2,4,4,2,false,true,0,7> (LDS-DMA, 256x256 tile on 8 waves, 64-wide K steps, "
                   "hand-placed DMA issue, GroupNorm statistics fused), cls+reg tower 3x3 256->256 of one depth as ONE "
-                  "grouped launch over 5 FPN levels (2 x (M=%d,N=256,K=2304))" % (eng.batch * 22400))
+                  "grouped launch over 5 FPN levels (2 x (M=%d,N=256,K=2304))" % (rows_m))
     else:
         kernel = ("conv_igemm_kernel<2,2,2,2,false,true,0,3> (LDS-DMA, 128x128 tile, 64-wide K steps, flat loader + "
                   "pipelined fragment reads, GroupNorm statistics fused) = tower 3x3 256->256 over 5 FPN levels "
-                  "(M=%d,N=256,K=2304)" % (eng.batch * 22400))
+                  "(M=%d,N=256,K=2304)" % (rows_m))
     out = {
-        "metric": "img/s SipMask-R%d 800x1333 inference (ResNet%d+FPN+SipMaskHead+NMS+mask assembly)" % (args.depth, args.depth),
+        "metric": ("img/s SipMask-R%d 544x544 SSD-style inference (ResNet%d+FPN+SipMaskHead(ssd_flag, 2-conv towers, no GN)+fast_nms+"
+                   "mask assembly)" % (args.depth, args.depth)) if ssd else
+                  "img/s SipMask-R%d 800x1333 inference (ResNet%d+FPN+SipMaskHead+NMS+mask assembly)" % (args.depth, args.depth),
         "value": round(B * args.steps * world / elapsed, 3),
         "unit": "img/s",
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -699,10 +724,13 @@ def run_inference(args, rank, world, dev):
         "dtype": "f32" if f32 else ("bf16 (backbone, FPN) + 3 x f16 split products / f32 activations (head)" if x3 else "bf16"),
         "data": "synthetic (randn images, %d batches resident in HBM rotated through the plan's input every step; "
                 "reference-init random weights + SURVEY 8d calibration overrides)" % NSETS,
-        "config": {"workload": "SipMask-R%d FPN inference, batch=%d/GPU, 3x800x1344 (800x1333 padded), %s, score_thr .05, "
-                               "nms .5, max_per_img 100" % (args.depth, B, "f32 storage + exact-f32 MFMA (parity plan)" if f32 else
+        "config": {"workload": "SipMask-R%d FPN inference, batch=%d/GPU, %s, %s, score_thr %s, "
+                               "%s, max_per_img 100" % (args.depth, B, "3x544x544 (sipmask_r50_caffe_fpn_ssd_6x.py: keep_ratio=False)" if ssd
+                                                            else "3x800x1344 (800x1333 padded)",
+                                                            "f32 storage + exact-f32 MFMA (parity plan)" if f32 else
                                                             ("bf16 backbone + FPN, split-precision (x3) head" if x3 else
-                                                             "bf16 storage + f32 accumulate")),
+                                                             "bf16 storage + f32 accumulate"), ("%.2f" % thr).lstrip("0"),
+                                                            "fast_nms .5 (top 200 per class)" if ssd else "nms .5"),
                    "global_batch": B * world, "parallelism": "dp%d (batch shard, no collective)" % world,
                    "launch": (("hipGraph replay, %d steps in flight: %d complete plans (own buffers, graph and stream) used round-robin, "
                                "step k+1 is enqueued while step k runs (engine.PipelinedPlan); every step is one batch of %d images"
@@ -736,7 +764,8 @@ def run_inference(args, rank, world, dev):
     if world == 1 and rank == 0 and do_extras and getattr(eng, "fused_masks", False):
         out["mask_assemble_worst_case"] = mask_assemble_worst_case(eng)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_inference(det, args.depth, budget_s=args.cpu_budget)
+        out["cpu_baseline"] = cpu_baseline_inference(det, args.depth, budget_s=args.cpu_budget, hw=(IMG_H, IMG_W), img_shape=shape, ssd=ssd)
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and not ssd:    # (ssd: parity lives in tests/test_gpu_api.py, 160 x 160)
         # parity of the TIMED plan object: one more step of it on the images the oracle gets (its own boxes: the workload
         # hook is off while anything is compared)
         det_flag.fill_(False)
@@ -771,7 +800,7 @@ def run_inference(args, rank, world, dev):
                                     "parity = the oracle's fp32 FPN features fed to a head-only plan of that precision built "
                                     "like a slot of the timed pipeline")
     if world == 1 and rank == 0 and do_extras and args.config == "r50" and args.precision == "bf16":
-        out["other_configs"] = other_configs(min(left(), 170.0))
+        out["other_configs"] = other_configs(min(left(), 200.0))
     return out
 
 
@@ -862,7 +891,8 @@ def other_configs(budget_s):
     # plan's parity -- VERDICT r4 weak #12: config #3 had neither in the driver line
     for name, extra in (("r101", ["--config", "r101", "--steps", "100", "--warmup", "10", "--cpu-budget", "10"]),
                         ("train", ["--config", "train", "--steps", "10", "--warmup", "3", "--cpu-budget", "20"]),
-                        ("vis", ["--config", "vis", "--steps", "8", "--warmup", "2", "--cpu-budget", "8"])):
+                        ("vis", ["--config", "vis", "--steps", "8", "--warmup", "2", "--cpu-budget", "8"]),
+                        ("ssd", ["--config", "ssd", "--steps", "100", "--warmup", "10", "--cpu-budget", "6"])):
         remaining = budget_s - (time.perf_counter() - t0)
         if remaining < 25:
             res[name] = dict(skipped="extras budget (%.0f s left)" % max(0.0, remaining))
@@ -1252,7 +1282,7 @@ def main():
         assert dist.get_world_size() == world
     if STUB:
         out = run_stub(args, rank, world)
-    elif args.config in ("r50", "r101"):
+    elif args.config in ("r50", "r101", "ssd"):
         out = run_inference(args, rank, world, dev)
     elif args.config == "eval_shapes":
         out = run_eval_shapes(args, rank, world, dev)

@@ -10,8 +10,8 @@ from . import detector  # noqa: F401  (registers SipMask / ResNet / FPN / SipMas
 from .registry import build_detector
 
 # M/configs/sipmask/sipmask_r50_caffe_fpn_gn_1x.py:2-55 (R101: sipmask_r101_caffe_fpn_gn_ms_4x.py)
-def model_cfg(depth=50):
-    return dict(
+def model_cfg(depth=50, ssd=False):
+    cfg = dict(
         type='SipMask',
         pretrained=None,
         backbone=dict(type='ResNet', depth=depth, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
@@ -24,12 +24,18 @@ def model_cfg(depth=50):
                        loss_bbox=dict(type='IoULoss', loss_weight=1.0),
                        loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
                        center_sampling=True, center_sample_radius=1.5))
+    if ssd:      # M/configs/sipmask/sipmask_r50_caffe_fpn_ssd_6x.py:23-31: two tower convs without GroupNorm, fast_nms
+        cfg['bbox_head'].update(stacked_convs=2, ssd_flag=True, norm_cfg=None)
+    return cfg
 
 
 TEST_CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type='nms', iou_thr=0.5), max_per_img=100)
 
 
-def build_synthetic_detector(depth=50, seed=0, bn3_gain=None):
+SSD_TEST_CFG = dict(TEST_CFG, score_thr=0.1)       # sipmask_r50_caffe_fpn_ssd_6x.py:54-59
+
+
+def build_synthetic_detector(depth=50, seed=0, bn3_gain=None, ssd=False):
     """Reference init (seeded) + overrides: bn3.weight = bn3_gain (default 1 for R50; 0.5 for R101, whose 33 residual blocks
     at gain 1 push the random-weight activations out of range: every class score NaN, zero detections, and a post-processing
     tail that is cheaper than a real one), non-zero conv_offset, O(1) tower gains, positive box distances, wider
@@ -37,7 +43,7 @@ def build_synthetic_detector(depth=50, seed=0, bn3_gain=None):
     if bn3_gain is None:
         bn3_gain = 1.0 if depth <= 50 else 0.5
     torch.manual_seed(seed)
-    det = build_detector(model_cfg(depth), train_cfg=None, test_cfg=dict(TEST_CFG))
+    det = build_detector(model_cfg(depth, ssd), train_cfg=None, test_cfg=dict(SSD_TEST_CFG if ssd else TEST_CFG))
     h = det.bbox_head
     with torch.no_grad():
         for n, p in det.backbone.named_parameters():
@@ -45,7 +51,8 @@ def build_synthetic_detector(depth=50, seed=0, bn3_gain=None):
                 p.fill_(bn3_gain)
         torch.nn.init.normal_(h.feat_align.conv_offset.weight, std=0.2)
         for m in list(h.cls_convs) + list(h.reg_convs):
-            m.conv.weight.mul_(3.0)
+            # (no GroupNorm behind the SSD-style towers: a gain that keeps the std-0.01 init's activations O(1) over two convs)
+            m.conv.weight.mul_(6.0 if ssd else 3.0)
         h.feat_align.conv_adaption.weight.mul_(3.0)
         h.fcos_reg.weight.mul_(3.0)
         h.fcos_reg.bias.fill_(2.0)
@@ -66,7 +73,7 @@ def calibrate_cls_bias(det, engine, img, target_per_img=1000, score_thr=0.05):
     engine.run(img)
     torch.cuda.synchronize()
     ncls = engine.ncls
-    logits = engine.cls_cof[:, :ncls].float() - float(det.bbox_head.fcos_cls.bias[0])
+    logits = engine.cls_cof[:, :ncls].float() - float(det.bbox_head.fcos_cls.bias.detach()[0])
     lt = math.log(score_thr / (1 - score_thr))
     lo, hi = -30.0, 30.0
     target = target_per_img * engine.batch
@@ -80,6 +87,20 @@ def calibrate_cls_bias(det, engine, img, target_per_img=1000, score_thr=0.05):
     with torch.no_grad():
         det.bbox_head.fcos_cls.bias.fill_(b)
     return b
+
+
+def calibrate_offset_scale(det, engine, img, target_std=1.0):
+    """Rescale FeatureAlign.conv_offset so that the sampling offsets of the synthetic net have `target_std` pixels (the GN
+    configs get ~1 px from the overrides above: 0.3 % of the components beyond 3 px; the SSD-style towers have no norm layer,
+    so the same weights give tens of pixels -- every tap far from its position, which no trained FeatureAlign produces).
+    Runs the engine once; the caller re-prepares the plan afterwards."""
+    engine.run(img)
+    torch.cuda.synchronize()
+    std = float(engine.offsets.float().std())
+    if std > 0:
+        with torch.no_grad():
+            det.bbox_head.feat_align.conv_offset.weight.mul_(target_std / std)
+    return std
 
 
 # V/configs/sipmask/sipmask_r50_caffe_fpn_gn_1x.py (V/ = SipMask-VIS/): 41 classes, stacked_convs=3, test_cfg :51-56

@@ -578,7 +578,10 @@ def test_fast_nms_vs_oracle(case):
     (200, 336, 200, 333, "boxes"), (800, 1344, 800, 1333, "boxes"), (16, 16, 16, 16, "edge")])
 def test_rle_encode_vs_oracle(case):
     """Device COCO RLE (sm_rle_encode) == the oracle's restatement of maskApi.c on pasted masks: run lengths and
-    compressed strings, with and without the box hint, aligned and unaligned rows, canvas smaller/larger."""
+    compressed strings, with and without the box hint, aligned and unaligned rows, canvas smaller/larger.
+    PARITY UNPINNED: neither pycocotools nor any RLE string exists in this image or under the reference
+    tree, so the oracle side is held by brute-force run lengths and encode -> string -> parse -> decode round trips only
+    (tests/test_oracle_ops.py: test_rle_restatement_round_trip); this test proves HIP == restatement, not == pycocotools."""
     from sipmask_amd import hip_ops as H, ops as P
     dev = _dev()
     ho, wo, ch, cw, kind = case
@@ -824,7 +827,9 @@ def test_training_layers_vs_torch():
 
 def test_input_pipeline_vs_oracle():
     """sm_preprocess_u8 (resize keep-ratio + normalise + pad + CHW) == the numpy restatement: identical except
-    where the float interpolation lands within rounding distance of .5 (<= 1 grey level on < 0.1 % of the pixels)."""
+    where the float interpolation lands within rounding distance of .5 (<= 1 grey level on < 0.1 % of the pixels).
+    PARITY UNPINNED: cv2 / mmcv are absent, the oracle restates INTER_LINEAR's geometry in float; OpenCV's
+    8-bit fixed-point path may differ from both by one grey level.  This test proves HIP == restatement only."""
     from sipmask_amd.input_pipeline import prepare_batch
     from oracle import pipeline as OP
     dev = _dev()

@@ -522,3 +522,27 @@ def test_deform_x3_tile_plan_host_logic():
     assert (p["row_tiles"], p["col_tiles"]) == (2 * (10 + 3 + 2 + 0 + 1), 2 * (2 + 2 + 0 + 2 + 0))
     d.cin = 128                                   # 32 channels per deformable group: not this kernel's shape
     assert H.deform_conv2d_x3_plan(d) is None and not H.deform_conv2d_x3_supported(d)
+
+
+def test_bench_configs_and_synthetic_ssd_detector():
+    """bench.py's configurations parse to the batch / steps the contract's defaults promise, and the synthetic detector of
+    `--config ssd` is the 544 x 544 SSD-style head (sipmask_r50_caffe_fpn_ssd_6x.py:23-31,54-59: two tower convs, no norm,
+    ssd_flag, score_thr 0.1)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = bench.parse([])
+    assert (a.config, a.gpus, a.batch, a.depth) == ("r50", 1, 4, 50) and a.steps >= 50 and a.warmup >= 10
+    a = bench.parse(["--config", "ssd"])
+    assert (a.batch, a.depth, a.steps) == (8, 50, 50) and bench.SSD_HW == (544, 544)
+    assert bench.parse(["--config", "r101"]).depth == 101
+    from sipmask_amd.synthetic import build_synthetic_detector
+    det = build_synthetic_detector(50, ssd=True)
+    h = det.bbox_head
+    assert h.ssd_flag and h.stacked_convs == 2 and h.norm_cfg is None and det.test_cfg["score_thr"] == 0.1
+    assert len(h.reg_convs) == 2 and not any(".gn." in k for k in h.state_dict())
+    boxes, info = bench.coco_boxes(2, 2, 100, 544, 544, scale_xy=(544 / 640.0, 544 / 480.0))
+    assert boxes.shape == (2, 2, 100, 4) and float(boxes[..., 2].max()) <= 544 and float(boxes[..., 3].max()) <= 544
+    assert 0.02 < info["mean_box_share_of_image"] < 0.08
