@@ -1278,7 +1278,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        dist.init_process_group("gloo" if STUB else "nccl", rank=rank, world_size=world)
+        if STUB:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:     # bind the communicator to this rank's GPU up front (no "guessing device ID" in the first barrier)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == world
     if STUB:
         out = run_stub(args, rank, world)

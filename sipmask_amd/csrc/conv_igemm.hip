@@ -300,7 +300,6 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
   auto load_x = [&](int, Stage8& xreg, uint32_t (&xmask)[NX], auto CS) {
     constexpr int cs = decltype(CS)::value;
     const int kc = ld_kc;
-    const int tap = ld_kh * a.kw + ld_kw;
     const int c0 = ld_cc * 8;
     const bool kvalid = kc < a.nchunk;
     const int dh = ld_kh * a.dil, dw = ld_kw * a.dil;
@@ -321,8 +320,6 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
       // deformable bilinear gather (deform_conv_cuda_kernel.cu:85-115,216-229); the offset row is
       // the output row (stride-1 "same" conv).  Phase 1: offsets of all rows, phase 2: all corner
       // loads, phase 3 (finish_x, after the MFMAs when DSPLIT): blend to bf16.
-      const int ntap = a.kh * a.kw;
-      const long long orow0 = a.out_row0[lev] + m0 + r0;
       // the offsets of THIS K step were requested one step ago (off_pf); request the next step's now, so that the
       // dependent chain of a step is corner loads -> blend only (offset load -> address -> corner load -> blend was two
       // exposed memory latencies per K step at one block per CU)
@@ -1889,6 +1886,7 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
 #endif
   if ((d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)) && !residual) return SM_ERR_BAD_ARG;
   const int tile = sm_conv_cout_tile(d->cout);
+  (void)tile;      // (the binary16 build has no register-staged kernels: unused there)
   const bool dma = plan.lds_dma != 0, k32 = plan.k_step == 32;
 #ifdef SM_EXPERIMENTS
   const bool ws = plan.warp_spec != 0;
