@@ -653,7 +653,8 @@ def run_inference(args, rank, world, dev):
     x3 = args.precision == "head_x3"
     # x3: three binary16 half products per element product -- the MFMA pipe does 3x the algorithmic FLOPs, and THAT is what
     # the roofline fraction prices (the algorithmic figure is reported beside it)
-    tower_flops = getattr(towers[0], "mfma_flops", towers[0].flops)
+    # (mean over the tower launches, like tower_ms: the x3 plan's first launch reads the bf16 pyramid on two terms, the others on three)
+    tower_flops = sum(getattr(c, "mfma_flops", c.flops) for c in towers) / len(towers)
     all_conv_ms = sum(v for v in conv_ms.values())
     all_conv_ms += sum(ms for (label, _), ms in zip(eng.steps, acc) if label == "stem_fused")   # conv1 + pool in one launch
     all_conv_flops = eng.total_conv_flops()
@@ -698,8 +699,9 @@ def run_inference(args, rank, world, dev):
     elif x3:
         kernel = ("conv3x3_patch_kernel, binary16 operands (v_mfma_f32_32x32x16_f16): cls+reg tower 3x3 256->256 of one depth "
                   "over 5 FPN levels as ONE grouped launch on split operands [hi|lo|hi] x [hi|hi|lo] (2 x (M=%d,N=256,"
-                  "K=3*2304)), f32 output, fixed-point GroupNorm statistics fused; achieved = MFMA FLOPs issued "
-                  "(3 x %.1f algorithmic GFLOP)" % (rows_m, towers[0].flops / 1e9))
+                  "K=3*2304)), f32 output, fixed-point GroupNorm statistics fused; achieved = MFMA FLOPs issued, mean over the "
+                  "plan's %d tower launches (3 x %.1f algorithmic GFLOP each; the first reads the bf16 FPN outputs as [hi|hi] x "
+                  "[hi|lo]: 2 x)" % (rows_m, len(towers), towers[0].flops / 1e9))
     elif getattr(towers[0], "patch", False):
         kernel = ("conv3x3_patch_kernel (input patch + 2 taps of weights resident in LDS via LDS-DMA, 256x256 tile on 8 "
                   "waves, GroupNorm statistics fused)%s = tower 3x3 256->256 over 5 FPN levels (%sM=%d,N=256,K=2304)"

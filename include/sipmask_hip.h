@@ -372,6 +372,12 @@ int sm_groupnorm_apply(const void* x, void* y, const float* gamma, const float* 
  *   rows, may alias x) and / or y_split (binary16 [rows][3*channels], [hi | lo | hi]); either may be NULL, not both. */
 int sm_split3_f16(const void* x, int x_is_f32, int64_t rows, int channels, int in_cstride, void* y, int ctot, int coff,
                   sm_stream_t stream);
+/* The two-term layout for bf16 sources (round 5): y binary16 [rows][2*ctot] = [hi | hi] of x's first `channels` channels.  A
+ * bf16 value is a binary16 value (down to 2^-17: below that the low half is at most 2^-24), so against weights [w_hi | w_lo] an
+ * ordinary SM_CONV_F16 convolution over 2*C channels is x_hi*w_hi + x_hi*w_lo -- the three-term product of sm_split3_f16
+ * without the term that is zero.  The x3 plan's first tower convs read the bf16 FPN outputs this way (2/3 of the MFMA work). */
+int sm_split2_f16(const void* x_bf16, int64_t rows, int channels, int in_cstride, void* y, int ctot, int coff,
+                  sm_stream_t stream);
 /* sm_upsample_bilinear (f32 rows [batch*h*w][in_cstride], first c channels, integer factor, align_corners=False) with
  * the result written as the split layout of sm_split3_f16 (y binary16 [batch*h*factor*w*factor][3*ctot], slice coff). */
 int sm_upsample_bilinear_x3(const float* x, void* y, int batch, int h, int w, int c, int factor, int in_cstride, int ctot,

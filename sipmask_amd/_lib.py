@@ -113,6 +113,7 @@ PROTOTYPES = {
     "sm_conv1x1_pair": (_I, [C.c_int64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_bottleneck_tail_ds": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "sm_split3_f16": (_I, [_P, _I, C.c_int64, _I, _I, _P, _I, _I, _P]),
+    "sm_split2_f16": (_I, [_P, C.c_int64, _I, _I, _P, _I, _I, _P]),
     "sm_upsample_bilinear_x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sm_upsample_sum2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sm_gn_stats_f32_fix": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _P]),

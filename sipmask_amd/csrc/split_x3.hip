@@ -40,7 +40,10 @@ struct SplitArgs {
   int ctot, coff;  // channels of one third of the destination row, first channel of this source inside it
 };
 
-template <bool IN_F32>
+// TWO: the two-term layout [hi | hi] for sources whose low half is zero (bf16 rows: every bf16 value above 2^-17 is a
+// binary16 value) -- against weights [hi | lo] the conv is x_hi*w_hi + x_hi*w_lo, the three-term product without its zero
+// term (sm_split2_f16, round 5: the first tower convs of the x3 plan read the bf16 FPN outputs)
+template <bool IN_F32, bool TWO = false>
 __global__ __launch_bounds__(256) void split3_kernel(const SplitArgs a) {
   const long long total = a.rows * a.c8;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -58,8 +61,12 @@ __global__ __launch_bounds__(256) void split3_kernel(const SplitArgs a) {
     split8(v, hi, lo);
     uint16_t* o = a.y + r * a.out_cs + a.coff + c;
     *reinterpret_cast<half8*>(o) = hi;
-    *reinterpret_cast<half8*>(o + a.ctot) = lo;
-    *reinterpret_cast<half8*>(o + 2 * a.ctot) = hi;
+    if constexpr (TWO) {
+      *reinterpret_cast<half8*>(o + a.ctot) = hi;
+    } else {
+      *reinterpret_cast<half8*>(o + a.ctot) = lo;
+      *reinterpret_cast<half8*>(o + 2 * a.ctot) = hi;
+    }
   }
 }
 
@@ -252,6 +259,23 @@ extern "C" int sm_split3_f16(const void* x, int x_is_f32, int64_t rows, int chan
     hipLaunchKernelGGL(split3_kernel<true>, dim3((unsigned)g), dim3(256), 0, sm_hip_stream(stream), a);
   else
     hipLaunchKernelGGL(split3_kernel<false>, dim3((unsigned)g), dim3(256), 0, sm_hip_stream(stream), a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_split2_f16(const void* x_bf16, int64_t rows, int channels, int in_cstride, void* y, int ctot, int coff,
+                             sm_stream_t stream) {
+  if (!x_bf16 || !y) return SM_ERR_BAD_ARG;
+  if (rows < 1 || channels < 8 || channels % 8 || in_cstride % 8 || in_cstride < channels || ctot % 8 || coff % 8 ||
+      coff + channels > ctot)
+    return SM_ERR_BAD_SHAPE;
+  SplitArgs a;
+  a.x = x_bf16, a.y = (uint16_t*)y, a.rows = rows, a.c8 = channels / 8, a.in_cs = in_cstride, a.out_cs = 2 * ctot;
+  a.ctot = ctot, a.coff = coff;
+  const long long n = rows * a.c8;
+  long long g = (n + 255) / 256;
+  if (g > 256 * 32) g = 256 * 32;
+  hipLaunchKernelGGL((split3_kernel<false, true>), dim3((unsigned)g), dim3(256), 0, sm_hip_stream(stream), a);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -57,6 +57,7 @@ _FUSE_BOTTLENECK = 1
 _CHAIN_CONV1 = 1               # layer1 tails also compute the next block's conv1 (2: not behind the fused shortcut; 3: layer2 too)
 _FUSE_SHORTCUT = 2             # the shortcut conv inside the fused tail: 1 = layer1.0, 2 = + layer2.0
 _PAIR_1X1 = False              # layer3's conv3 + next conv1 as one launch (sm_conv1x1_pair): bit-identical, no faster
+_X3_TOWER0_TWO_TERMS = True    # x3 plan: the first tower convs on [hi | hi] of the bf16 FPN outputs (two half products per element)
 _LATENCY_1X1 = ()              # stage widths whose 1x1 convs keep the latency-shaped plan inside pipelined slots: neutral
 _RELU_COPY_P7 = True           # relu(P6) as its own tensor instead of the input-ReLU loader for P7
 _SMALLCO_CONV = True           # 3x3 convs with <= 32 couts on csrc/conv3x3_smallco.hip
@@ -105,7 +106,8 @@ class _Conv:
         self.mode = mode or ("f32" if getattr(eng, "precision", "bf16") == "f32" else "bf16")
         # exact-f32 plan (parity mode): f32 operands on v_mfma_f32_32x32x2_f32, every conv output f32
         self.f32 = self.mode in ("f32", "f32x3")            # f32 tensors in HBM: csrc/conv_f32.hip
-        self.x3 = self.mode == "x3"
+        self.x3 = self.mode in ("x3", "x2")                  # "x2": the two-term form for inputs whose low half is zero
+        self.xterms = 2 if self.mode == "x2" else 3
         self.x3w = self.mode == "x3w"                        # FeatureAlign in the x3 plan on the LDS-window kernel
         acc_scale = 0.0
         if self.x3w:
@@ -131,10 +133,10 @@ class _Conv:
         elif self.x3:
             if offset is not None or residual is not None or cin_pad is not None or ci % 8 != 0:
                 raise NotImplementedError("x3 convs: plain convolutions over 8-aligned channel counts")
-            cin = 3 * ci
-            assert in_cstride == cin, "x3 convs read the [hi | lo | hi] split tensor (3 * cin channels)"
+            cin = self.xterms * ci
+            assert in_cstride == cin, "x3 convs read the [hi | lo | hi] split tensor (3 * cin channels; x2: [hi | hi])"
             self.x3_scale = getattr(self, "_x3_scale", None) or H.x3_weight_scale([w])
-            self.w, co_pad = H.prep_conv_weight_x3(w.to(dev), self.x3_scale)
+            self.w, co_pad = H.prep_conv_weight_x3(w.to(dev), self.x3_scale, self.xterms)
             flags |= _lib.SM_CONV_F16 | (0 if flags & _lib.SM_CONV_OUT_X3 else SM_CONV_OUT_F32)
             acc_scale = 1.0 / self.x3_scale
         else:
@@ -157,7 +159,7 @@ class _Conv:
         # their own kernel (round 4, csrc/conv3x3_smallco.hip: one wave per 2 x 32-position tile, weights straight from L2)
         self.smallco = False
         if (not self.f32 and offset is None and residual is None and _SMALLCO_CONV and k == 3 and stride == 1
-                and pad == 1 and co <= 32 and co % 8 == 0 and ci % 32 == 0 and cin == (3 * ci if self.x3 else ci)
+                and pad == 1 and co <= 32 and co % 8 == 0 and ci % 32 == 0 and cin == (3 * ci if self.x3 else ci) and self.mode != "x2"
                 and getattr(self, "_patch_groups", 1) == 1 and not (self.x3 and (flags & _lib.SM_CONV_OUT_X3))):
             ds = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, 32, k, stride, pad, in_cstride,
                                   out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0, scale_nch, level_scale,
@@ -193,7 +195,7 @@ class _Conv:
                                (small_co or pl["fill"] >= _PATCH_MIN_FILL or pl["makespan"] <= 1.0)))
                         and (small_co or co * 4 >= 3 * ((co + 255) // 256 * 256))):
                     self.patch = True
-                    self.w, _ = (H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale, pad_co) if self.x3
+                    self.w, _ = (H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale, pad_co, self.xterms) if self.x3
                                  else H.prep_conv_weight_patch(w.to(dev), pad_co))
                     self.desc = dp
         # 128-cout x 256-position patch tiles (round 4) for single-level 3x3 convs whose position count gives too few 256-cout
@@ -221,7 +223,7 @@ class _Conv:
             pl = H.conv_plan(self.desc)
             if pl["split_k"] > 1:
                 self.ws = torch.empty(pl["workspace_bytes"], dtype=torch.uint8, device=dev)
-        kin = 3 if (self.x3 or self.mode in ("f32x3", "x3w")) else 1   # MFMA work: three half products per element product
+        kin = self.xterms if self.x3 else (3 if self.mode in ("f32x3", "x3w") else 1)   # MFMA work: half products per element product
         self.flops = 2.0 * sum(batch * h * ww for h, ww in out_sizes) * co * ci * k * k
         self.mfma_flops = self.flops * kin
         # algorithmic HBM bytes: x read once + y written once (+ residual read) + weights
@@ -325,14 +327,14 @@ class _GroupedConv(_Conv):
                  out_row0, out_cstride, flags=0, mode=None):
         G = len(ws)
         self._patch_groups = G
-        if mode == "x3":
+        if mode in ("x3", "x2"):
             self._x3_scale = H.x3_weight_scale(ws)              # one accumulator scale per launch: shared by the groups
         _Conv.__init__(self, eng, name, ws[0], biases[0], batch, in_sizes, in_row0, x, in_cstride, 1, 1, y, out_row0,
                        out_cstride, flags=flags, mode=mode)
         dev = eng.device
         if self.x3:
-            prep = (lambda w: H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale)[0]) if self.patch else \
-                (lambda w: H.prep_conv_weight_x3(w.to(dev), self.x3_scale)[0])
+            prep = (lambda w: H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale, terms=self.xterms)[0]) if self.patch else \
+                (lambda w: H.prep_conv_weight_x3(w.to(dev), self.x3_scale, self.xterms)[0])
         else:
             prep = (lambda w: H.prep_conv_weight_patch(w.to(dev))[0]) if self.patch else \
                 (lambda w: H.prep_conv_weight(w.to(dev), in_cstride)[0])
@@ -895,8 +897,15 @@ class SipMaskEngine:
         par = lambda n: sd[n].float().to(dev).contiguous()
         TF = _lib_flag("SM_CONV_DBG_TILE256") | _lib_flag("SM_CONV_DBG_HAND_PLACED")
         # head input: the FPN pyramid as [hi | lo | hi] (bf16 rows of the bf16 backbone, or the caller's f32 features)
-        self.pyr_x3 = torch.empty(rows, 768, dtype=F16, device=dev)
-        self._add("split:pyr", lambda: H.split3_f16(self.pyr, self.pyr_x3, 256))
+        # A bf16 pyramid (the bf16 backbone's) has no low half: [hi | hi] against weights [hi | lo] is the same sum without its
+        # zero term -- the first tower launch does 2/3 of the MFMA work (round 5).  f32 features (for_head) keep three terms.
+        two = _X3_TOWER0_TWO_TERMS and self.pyr.dtype == torch.bfloat16
+        pyr_w = 512 if two else 768
+        self.pyr_x3 = torch.empty(rows, pyr_w, dtype=F16, device=dev)
+        if two:
+            self._add("split:pyr", lambda: H.split2_f16(self.pyr, self.pyr_x3, 256))
+        else:
+            self._add("split:pyr", lambda: H.split3_f16(self.pyr, self.pyr_x3, 256))
 
         relu = 0 if self.flag_norm else SM_CONV_RELU
         x, xg = self.pyr_x3, 0
@@ -904,9 +913,11 @@ class SipMaskEngine:
         for i in range(ncls):                         # cls + reg tower convs of one depth = ONE grouped launch
             y = torch.empty(2 * rows, 256, dtype=f32, device=dev)
             names = ["cls_convs.%d" % i, "reg_convs.%d" % i]
+            first2 = two and i == 0
             c = self._add_conv(_GroupedConv(self, "head.tower%d" % i, [sd[h + n + ".conv.weight"] for n in names],
-                                            [sd.get(h + n + ".conv.bias") for n in names], B, sizes, row0, x, xg, 768, y,
-                                            rows, row0, 256, flags=TF | relu, mode="x3"))
+                                            [sd.get(h + n + ".conv.bias") for n in names], B, sizes, row0, x, xg,
+                                            pyr_w if first2 else 768, y, rows, row0, 256, flags=TF | relu,
+                                            mode="x2" if first2 else "x3"))
             if self.flag_norm:
                 c.gn_stats = stats2
             nxt = torch.empty(2 * rows, 768, dtype=F16, device=dev)

@@ -64,18 +64,19 @@ def x3_weight_scale(ws):
     return 2.0 ** math.floor(math.log2(4096.0 / m)) if m > 0 and math.isfinite(m) else 1.0
 
 
-def _x3_halves(w, scale):
+def _x3_halves(w, scale, terms=3):
     """w * scale as two binary16 halves along the input-channel axis in the order that pairs with activations laid out
-    [hi | lo | hi]: [w_hi | w_hi | w_lo]  =>  x_hi*w_hi + x_lo*w_hi + x_hi*w_lo."""
+    [hi | lo | hi]: [w_hi | w_hi | w_lo]  =>  x_hi*w_hi + x_lo*w_hi + x_hi*w_lo.  terms=2: [w_hi | w_lo] against
+    activations [hi | hi] whose low half is zero (bf16 sources, split2_f16): the same sum without its zero term."""
     ws = w.float() * scale
     hi = ws.to(F16)
     lo = (ws - hi.float()).to(F16)
-    return torch.cat([hi, hi, lo], 1)                     # [co, 3*ci, kh, kw] binary16 values
+    return torch.cat([hi, hi, lo] if terms == 3 else [hi, lo], 1)      # [co, terms*ci, kh, kw] binary16 values
 
 
-def prep_conv_weight_x3(w, scale):
-    """[co,ci,kh,kw] float -> binary16 [cout_pad][Kp], K order (kh,kw,3*ci) for sm_conv2d with SM_CONV_F16"""
-    w3 = _x3_halves(w, scale)
+def prep_conv_weight_x3(w, scale, terms=3):
+    """[co,ci,kh,kw] float -> binary16 [cout_pad][Kp], K order (kh,kw,terms*ci) for sm_conv2d with SM_CONV_F16"""
+    w3 = _x3_halves(w, scale, terms)
     co, ci3, kh, kw = w3.shape
     assert ci3 % 8 == 0
     tile = cout_tile(co)
@@ -87,9 +88,9 @@ def prep_conv_weight_x3(w, scale):
     return out.contiguous(), co_pad
 
 
-def prep_conv_weight_patch_x3(w, scale, co_pad=None):
-    """[co,ci,3,3] float -> binary16 [cout_pad][3*ci/32][9][32] for sm_conv3x3_patch with SM_CONV_F16"""
-    w3 = _x3_halves(w, scale)
+def prep_conv_weight_patch_x3(w, scale, co_pad=None, terms=3):
+    """[co,ci,3,3] float -> binary16 [cout_pad][terms*ci/32][9][32] for sm_conv3x3_patch with SM_CONV_F16"""
+    w3 = _x3_halves(w, scale, terms)
     co, ci3, kh, kw = w3.shape
     assert (kh, kw) == (3, 3) and ci3 % 64 == 0
     co_pad = co_pad or (co + 255) // 256 * 256
@@ -154,6 +155,20 @@ def split3_f16(x, y, channels=None, ctot=None, coff=0):
     lib = _lib.load()
     _lib.check(lib.sm_split3_f16(_lib.ptr(x), int(x.dtype == torch.float32), x.shape[0], channels, x.stride(0), _lib.ptr(y),
                                  ctot, coff, _lib.stream_ptr()), "sm_split3_f16")
+    return y
+
+
+def split2_f16(x, y, channels=None, ctot=None, coff=0):
+    """x: bf16 rows [rows, >= channels] -> y binary16 [rows, 2*ctot]: [hi | hi] (sm_split2_f16: the two-term operand of a source
+    whose low half is zero)"""
+    _lib.require_cuda(x, y)
+    channels = channels or x.shape[1]
+    ctot = ctot or channels
+    if x.dtype != BF16 or y.dtype != F16 or y.shape[1] != 2 * ctot or y.shape[0] != x.shape[0]:
+        raise ValueError("split2_f16: bf16 rows in, binary16 [rows, 2*ctot] out")
+    lib = _lib.load()
+    _lib.check(lib.sm_split2_f16(_lib.ptr(x), x.shape[0], channels, x.stride(0), _lib.ptr(y), ctot, coff, _lib.stream_ptr()),
+               "sm_split2_f16")
     return y
 
 

@@ -108,6 +108,90 @@ def test_x3_conv_matches_f64_conv_of_f32_operands(kernel):
             torch.testing.assert_close(st[:, l, :, 1], (r8 * r8).sum(-1), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("kernel", ["igemm", "patch"])
+def test_two_term_conv_on_bf16_rows_equals_the_three_term_conv(kernel):
+    """Round 5: a bf16 source has no low half, so [hi | hi] x [w_hi | w_lo] (sm_split2_f16 + prep(..., terms=2): 2/3 of the MFMA
+    work) must give what [hi | lo | hi] x [w_hi | w_hi | w_lo] gives -- the same f32 accumulation without the products that are
+    zero.  Grouped launch with shared input and fused GroupNorm statistics, as the x3 plan's first tower launch runs it."""
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    B, C, G = 2, 256, 2
+    sizes = [(40, 66), (20, 33), (5, 9)] if kernel != "patch" else [(100, 168), (50, 84), (25, 42)]
+    lv = H.Levels(B, sizes)
+    xs = [(torch.randn(B, C, h, w, generator=g) * 1.7).to(torch.bfloat16) for h, w in sizes]
+    ws = [torch.randn(C, C, 3, 3, generator=g) * 0.03 for _ in range(G)]
+    bias = torch.stack([torch.randn(C, generator=g) for _ in range(G)]).to(dev).contiguous()
+    rows = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, C) for x in xs]).contiguous().to(dev)
+    scale = H.x3_weight_scale(ws)
+    outs = {}
+    for terms in (3, 2):
+        xq = torch.empty(lv.rows, terms * C, dtype=torch.float16, device=dev)
+        (H.split3_f16 if terms == 3 else H.split2_f16)(rows, xq)
+        if terms == 2:
+            # hi == the bf16 value wherever binary16 has it (normals: >= 2^-14; subnormals keep multiples of 2^-24)
+            hi_f, x_f = xq[:, :C].float(), rows.float()
+            assert torch.equal(xq[:, :C], xq[:, C:]) and float((hi_f - x_f).abs().max()) <= 2.0 ** -25
+            assert torch.equal(hi_f[x_f.abs() >= 2.0 ** -14], x_f[x_f.abs() >= 2.0 ** -14])
+        if kernel == "patch":
+            packed = [H.prep_conv_weight_patch_x3(w.to(dev), scale, terms=terms)[0] for w in ws]
+            co_pad = 256
+        else:
+            pk = [H.prep_conv_weight_x3(w.to(dev), scale, terms) for w in ws]
+            co_pad, packed = pk[0][1], [p[0] for p in pk]
+        wq = torch.stack(packed).contiguous()
+        S = 2 * B * len(sizes) * (C // 8)
+        d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, terms * C, C, co_pad, 3, 1, 1, terms * C, C,
+                             flags=_lib.SM_CONV_F16 | _lib.SM_CONV_OUT_F32, ngroups=G, x_group_rows=0, y_group_rows=lv.rows,
+                             w_group_stride=packed[0].numel(), bias_group_stride=C, gn_group_stride=S, acc_scale=1.0 / scale)
+        y = torch.zeros(G * lv.rows, C, dtype=torch.float32, device=dev)
+        stats = torch.zeros(G * S, dtype=torch.int64, device=dev)
+        if kernel == "patch":
+            assert H.conv3x3_patch_supported(d)
+            H.conv3x3_patch(d, xq, wq, bias, y, stats)
+        else:
+            H.conv2d_gn_stats(d, xq, None, wq, bias, None, y, stats)
+        torch.cuda.synchronize()
+        outs[terms] = (y, stats)
+    y3, y2 = outs[3][0], outs[2][0]
+    # (a bf16 value below 2^-17 can leave a low half of one binary16 ulp, 2^-24: nothing a randn draw of this size contains)
+    assert float((y3 - y2).abs().max()) <= 1e-6 * float(y3.abs().max())
+    assert float((y3 != y2).float().mean()) < 1e-3
+    ref = F.conv2d(xs[0].double(), ws[1].double(), bias[1].cpu().double(), 1, 1)
+    h, w = sizes[0]
+    got = y2[lv.rows:lv.rows + B * h * w].view(B, h, w, C).permute(0, 3, 1, 2).cpu().double()
+    assert float((got - ref).abs().max()) / float(ref.abs().max()) < 4e-6
+
+
+def test_x3_plan_first_tower_launch_runs_two_terms_on_the_bf16_pyramid(head_case, monkeypatch):
+    """The x3 plan's first tower launch reads the bf16 FPN outputs as [hi | hi] (mode "x2"); switched back to three terms
+    the head outputs and detections do not move (<= 1e-6 of the tensor's largest value); a head-only plan fed f32 features
+    keeps three terms."""
+    import sipmask_amd.engine as E
+    from sipmask_amd.engine import SipMaskEngine
+    sd = head_case["sd"]
+    img = torch.randn(2, 3, 192, 256, generator=torch.Generator().manual_seed(4)).cuda()
+    res = {}
+    for two in (True, False):
+        monkeypatch.setattr(E, "_X3_TOWER0_TWO_TERMS", two)
+        eng = SipMaskEngine(sd, 2, (192, 256), 50, precision="head_x3")
+        t0 = [c for c in eng.convs if c.name == "head.tower0"][0]
+        assert t0.mode == ("x2" if two else "x3") and t0.mfma_flops == t0.flops * (2 if two else 3)
+        assert all(c.mode != "x2" for c in eng.convs if c.name != "head.tower0")
+        r = eng.run(img)
+        torch.cuda.synchronize()
+        res[two] = (eng.cls_cof.clone(), eng.reg_out.clone(), {k: v.clone() for k, v in r.items()})
+    for a, b in zip(res[True][:2], res[False][:2]):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    for k in ("ndet", "det_labels", "idxs_keep"):
+        assert torch.equal(res[True][2][k], res[False][2][k]), k
+    sizes = [(24, 32), (12, 16), (6, 8), (3, 4), (2, 2)]
+    hsd = {k: v for k, v in sd.items() if k.startswith("bbox_head.")}
+    monkeypatch.setattr(E, "_X3_TOWER0_TWO_TERMS", True)
+    heng = SipMaskEngine.for_head(hsd, 2, sizes, img_shape=(192, 256, 3), precision="head_x3")
+    assert all(c.mode != "x2" for c in heng.convs)
+
+
 def test_x3_small_cout_and_1x1_convs():
     """the head's other x3 launches: 1x1 over 3*768 channels (sip_mask_lat0), 3x3 to 32 couts (sip_mask_lat) and to 8
     couts with per-level Scale on 4 of them (fcos_reg + centerness), ReLU, bias -- f32 out, within 4e-6 of float64"""
