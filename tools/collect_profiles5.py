@@ -80,6 +80,7 @@ js = {
 json.dump(js, open(os.path.join(DST, "r05_pmc_tower_conv.json"), "w"), indent=1)
 for src, dst in (("step_breakdown.txt", "r05_step_breakdown_hip_events.txt"),
                  ("step_breakdown_x3.txt", "r05_step_breakdown_hip_events_head_x3.txt"),
+                 ("step_breakdown_ssd.txt", "r05_step_breakdown_hip_events_ssd544.txt"),
                  ("kernel_stats_step.csv", "r05_rocprofv3_kernel_stats_step.csv"),
                  ("kernel_stats_step_x3.csv", "r05_rocprofv3_kernel_stats_step_head_x3.csv"),
                  ("kernel_stats_tower_only.csv", "r05_rocprofv3_kernel_stats_tower_only.csv"),
@@ -92,12 +93,14 @@ for src, dst in (("step_breakdown.txt", "r05_step_breakdown_hip_events.txt"),
     if os.path.exists(os.path.join(SRC, src)):
         shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
 lines = {}
-for n in ("r50_driver_args", "r50", "r50_tiny_boxes", "r50_x3", "eval_shapes"):
+for n in ("r50_driver_args", "r50", "r50_tiny_boxes", "r50_x3", "eval_shapes", "ssd"):
     j = last_json(os.path.join(SRC, "bench_%s.json" % n))
     if j:
         lines[n] = j
 json.dump(lines, open(os.path.join(DST, "r05_bench_lines.json"), "w"), indent=1)
 print(json.dumps(js, indent=1))
+if lines.get("ssd"):
+    json.dump(lines["ssd"], open(os.path.join(DST, "r05_bench_line_ssd544.json"), "w"), indent=1)
 dl = lines.get("r50_driver_args")
 if dl:
     json.dump(dl, open(os.path.join(DST, "r05_bench_line_driver_args.json"), "w"), indent=1)

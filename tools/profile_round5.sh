@@ -16,6 +16,7 @@ timeout 300 python $R/bench.py --no-cpu-baseline --extras-budget 45 --breakdown 
 timeout 300 python $R/bench.py --no-cpu-baseline --extras-budget 45 --det-boxes tiny > $OUT/bench_r50_tiny_boxes.json 2> $OUT/bench_r50_tiny.err
 timeout 300 python $R/bench.py --precision head_x3 --no-cpu-baseline --extras-budget 30 --breakdown $OUT/step_breakdown_x3.txt > $OUT/bench_r50_x3.json 2> $OUT/bench_r50_x3.err
 timeout 300 python $R/bench.py --config eval_shapes > $OUT/bench_eval_shapes.json 2> $OUT/bench_eval_shapes.err
+timeout 300 python $R/bench.py --config ssd --cpu-budget 8 --breakdown $OUT/step_breakdown_ssd.txt > $OUT/bench_ssd.json 2> $OUT/bench_ssd.err
 timeout -k 5 300 rocprofv3 --kernel-trace -d $OUT/step -o step -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extras --no-graph > $OUT/step.log 2>&1
 python $R/tools/prof_stats.py $OUT/step $OUT/kernel_stats_step.csv 5 > /dev/null
 timeout -k 5 300 rocprofv3 --kernel-trace -d $OUT/stepx3 -o stepx3 -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extras --no-graph --precision head_x3 > $OUT/stepx3.log 2>&1
@@ -34,4 +35,4 @@ timeout 300 python tools/deform_fwd_bench.py 4 0.0,1.0,2.0,4.0 > $OUT/deform_fwd
 timeout 300 python tools/deform_bwd_bench.py > $OUT/deform_bwd_microbench.txt 2>&1
 timeout 600 python tools/parity_baseline.py --plan pipelined --precision bf16 --out $OUT/parity_r50_b4_bf16.json > $OUT/parity_bf16.log 2>&1
 timeout 600 python tools/parity_baseline.py --plan pipelined --precision head_x3 --out $OUT/parity_r50_b4_x3.json > $OUT/parity_x3.log 2>&1
-find $OUT -name "*counter_collection.csv" | head -3; tail -c 300 $OUT/tower.log; for f in r50_driver_args r50 r50_tiny_boxes r50_x3 eval_shapes; do cut -c1-160 $OUT/bench_$f.json; done
+find $OUT -name "*counter_collection.csv" | head -3; tail -c 300 $OUT/tower.log; for f in r50_driver_args r50 r50_tiny_boxes r50_x3 eval_shapes ssd; do cut -c1-160 $OUT/bench_$f.json; done
