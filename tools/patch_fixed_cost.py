@@ -51,6 +51,29 @@ def main():
         fl = 2.0 * G * lv.rows * CO * cin * 9
         res.append((cin, ms))
         print("cin %4d  pairs %d  %.4f ms  %7.1f TFLOP/s   blocks %s" % (cin, cin // 64, ms, fl / ms / 1e9, pl.get("blocks", pl)))
+    # the epilogue's share: the cin = 256 launch without the fused GroupNorm statistics (no butterflies, LDS / global atomics,
+    # barriers, and no zero-fill launch in front), interleaved with the full launch
+    cin = 256
+    x = (torch.randn(lv.rows, cin, device=dev) * 0.5).to(torch.bfloat16)
+    ws = [torch.randn(CO, cin, 3, 3, device=dev) / (9 * cin) ** 0.5 for _ in range(G)]
+    wq = torch.stack([H.prep_conv_weight_patch(w)[0] for w in ws]).contiguous()
+    bias = torch.randn(G, CO, device=dev)
+    S = 2 * B * len(sizes) * (CO // 8)
+    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, cin, CO, 256, 3, 1, 1, cin, CO, ngroups=G, x_group_rows=0,
+                         y_group_rows=lv.rows, w_group_stride=wq[0].numel(), bias_group_stride=CO, gn_group_stride=S)
+    y = torch.empty(G * lv.rows, CO, dtype=torch.bfloat16, device=dev)
+    stats = torch.zeros(G * S, dtype=torch.int64, device=dev)
+    for rep in range(3):
+        for name, st in (("with statistics", stats), ("without", None)):
+            for _ in range(3):
+                H.conv3x3_patch(d, x, wq, bias, y, st)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.iters):
+                H.conv3x3_patch(d, x, wq, bias, y, st)
+            e1.record()
+            torch.cuda.synchronize()
+            print("cin 256 %-16s %.4f ms" % (name, e0.elapsed_time(e1) / args.iters))
     xs = np.array([c // 64 for c, _ in res], float)
     ys = np.array([m for _, m in res])
     k, b = np.polyfit(xs, ys, 1)
