@@ -1283,7 +1283,24 @@ def main():
         if STUB:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:     # bind the communicator to this rank's GPU up front (no "guessing device ID" in the first barrier)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # RCCL prints a five-line version banner on STDOUT when the first communicator is created; stdout carries the
+            # one JSON line of the contract and nothing else, so fd 1 points at stderr while that happens
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.barrier()
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                try:       # the banner is printf'ed into libc's buffer: flush it while fd 1 still points at stderr
+                    import ctypes
+                    ctypes.CDLL(None).fflush(None)
+                except Exception:
+                    pass
+                os.dup2(saved, 1)
+                os.close(saved)
         assert dist.get_world_size() == world
     if STUB:
         out = run_stub(args, rank, world)
