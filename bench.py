@@ -1323,6 +1323,7 @@ def main():
             line["diag_skip"] = os.environ["SIPMASK_DIAG_SKIP"]
             line["value_with_launches_skipped"], line["value"] = line["value"], None
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1 or os.environ.get("SIPMASK_FORCE_DIST") == "1":
         import torch.distributed as dist
         dist.destroy_process_group()
