@@ -134,6 +134,12 @@ typedef struct {
    * tiles); 128 = 128-cout x 256-position tiles (cout_pad % 128 == 0) for convs whose position count cannot fill the chip
    * with 256-cout tiles -- the 3x3 convs of ResNet layer3 / layer4 (resnet.py:84-239: 4 200 / 1 050 positions per image). */
   int32_t patch_cout_tile;
+  /* sm_conv3x3_patch with SM_CONV_F16 (round 6): 1 = PAIRED split operands.  x rows hold C values as C/16 groups of
+   * [hi 16 | lo 16] binary16 (in_cstride = cin = 2 * C; sm_split_pairs_f16 / sm_groupnorm_apply_x3p write that layout) and
+   * the weights are [cout_pad][C/16][9 taps][hi 16 | lo 16]; per 16 channels the kernel issues the three products
+   * w_hi*x_hi + w_hi*x_lo + w_lo*x_hi on fragments it reads once -- the same sum as the K-concatenated form ([hi | lo | hi]
+   * against [hi | hi | lo], x3_pairs = 0) with a third less operand traffic.  256-cout tiles, f32 output. */
+  int32_t x3_pairs;
 } sm_conv_desc;
 
 int sm_version(void);
@@ -394,6 +400,16 @@ int sm_gn_stats_f32_fix(const float* x, int64_t* stats, int batch, int nlev, con
 int sm_groupnorm_apply_x3(const float* x, const float* gamma, const float* beta, const int64_t* stats, int batch, int nlev,
                           const int32_t* hw, const int64_t* row0, int channels, int groups, float eps, int relu,
                           float* y_f32, void* y_split, sm_stream_t stream);
+/* The PAIRED layout (round 6; sm_conv_desc.x3_pairs): a row of C values as C/16 groups of [hi 16 | lo 16] binary16 -- 2*C per
+ * row (4 bytes per value instead of the 6 of [hi | lo | hi]); channel c has its hi half at (c >> 4) * 32 + (c & 15) and its lo
+ * half 16 elements behind.  sm_split_pairs_f16 is sm_split3_f16 writing that layout (ctot % 16 == 0, y binary16
+ * [rows][2*ctot]); sm_groupnorm_apply_x3p is sm_groupnorm_apply_x3 writing it (channels % 16 == 0; y_pairs required, y_f32
+ * optional).  The tower convs of the x3 head plan (sipmask_head.py:252-258) and fcos_cls + sip_cof read these rows. */
+int sm_split_pairs_f16(const void* x, int x_is_f32, int64_t rows, int channels, int in_cstride, void* y, int ctot, int coff,
+                       sm_stream_t stream);
+int sm_groupnorm_apply_x3p(const float* x, const float* gamma, const float* beta, const int64_t* stats, int batch, int nlev,
+                           const int32_t* hw, const int64_t* row0, int channels, int groups, float eps, int relu,
+                           float* y_f32, void* y_pairs, sm_stream_t stream);
 
 /* 3x3 / stride 1 / pad 1 convolution with 8..32 output channels (cout % 8 == 0) over cin % 32 == 0 input channels, bf16
  * operands: SipMaskHead's sip_mask_lat (512 -> 32, sipmask_head.py:284) and fcos_reg + fcos_centerness (256 -> 4 + 1,

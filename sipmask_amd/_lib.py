@@ -27,6 +27,12 @@ SM_CONV_DBG_PATCH_UNIFORM = 0x00004000
 SM_CONV_DBG_LDS_EPILOGUE = 0x01000000
 SM_CONV_F16 = 0x00020000                 # IEEE binary16 operands (the x3 head plan), f32 output
 SM_CONV_OUT_X3 = 64                      # ... or the next layer's split operand [hi | lo | hi] (forward descriptors)
+# backward descriptors only (sm_conv2d_bwd / sm_deform_conv2d_bwd read these bits; the forward entry points never do)
+SM_CONV_BWD_GX_BF16 = 64
+SM_CONV_BWD_WGRAD_GEMM = 128
+SM_CONV_BWD_WGRAD_DIRECT = 256
+SM_CONV_BWD_WGRAD_TILE128 = 512
+SM_CONV_BWD_DX_SCATTER = 1024            # A/B: d(x) of FeatureAlign's shape by the atomic scatter alone
 
 _i32x5 = C.c_int32 * SM_MAX_LEVELS
 _i64x5 = C.c_int64 * SM_MAX_LEVELS
@@ -50,7 +56,7 @@ class ConvDesc(C.Structure):
         ("bias_group_stride", C.c_int64), ("gn_group_stride", C.c_int64),
         ("acc_scale", C.c_float),
         ("w_level_stride", C.c_int64), ("bias_level_stride", C.c_int64),
-        ("patch_cout_tile", C.c_int32),
+        ("patch_cout_tile", C.c_int32), ("x3_pairs", C.c_int32),
     ]
 
 
@@ -118,6 +124,8 @@ PROTOTYPES = {
     "sm_upsample_sum2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sm_gn_stats_f32_fix": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _P]),
     "sm_groupnorm_apply_x3": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P]),
+    "sm_groupnorm_apply_x3p": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P]),
+    "sm_split_pairs_f16": (_I, [_P, _I, C.c_int64, _I, _I, _P, _I, _I, _P]),
     "sm_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P]),
     "sm_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sm_stem_fused": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -113,7 +113,14 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
   // (no DMA / no MFMA in the main loop: wrong results by construction, never used by the library's own launches)
   constexpr bool PIPE = (VAR & 1) != 0, STAGGER = (VAR & 2) != 0, NO_DMA = (VAR & 4) != 0, NO_MFMA = (VAR & 8) != 0;
   constexpr bool PINGPONG = (VAR & 16) != 0;
+  // VAR bit 32 (round 6, binary16 build only): PAIRED split operands (sm_conv_desc.x3_pairs).  A 64-byte patch row / weight
+  // (row, tap) holds 16 channels as [hi 16 | lo 16] instead of 32 channels, so the two fragment sets a tap reads anyway ARE
+  // (w_hi, w_lo) and (x_hi, x_lo), and the tap issues the three products  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi  on them: 24
+  // MFMAs per 12 fragment reads and per 128 weight bytes of a cout row, where the K-concatenated form [hi | lo | hi] x
+  // [hi | hi | lo] (SM_CONV_F16 alone) needs 18 reads and 192 bytes -- a third off the LDS-DMA stream that co-bounds the tile.
+  constexpr bool X3P = (VAR & 32) != 0;
   static_assert(!PINGPONG || WCO * WPOS == 8, "the ping-pong schedule pairs waves w and w + 4");
+  static_assert(!X3P || ((VAR & 31) == 0 && BCO == PT_BCO), "paired operands: the plain stage loop of the 256-cout tile");
   constexpr int BPOS = WPOS * TPOS * 32;
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -229,6 +236,17 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
     };
     rd(0, 0);
     rd(1, 1);
+    if constexpr (X3P) {
+      // set 0 = the hi halves of the chunk's 16 channels, set 1 = the lo halves: three cross products per accumulator tile,
+      // term-major so that consecutive MFMAs never touch the same accumulator
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+          for (int tp = 0; tp < TPOS; ++tp)
+            acc[tc][tp] = SM_MFMA_32x32x16(wf[term == 2 ? 1 : 0][tc], xf[term == 1 ? 1 : 0][tp], acc[tc][tp]);
+    } else {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -236,6 +254,7 @@ __device__ __forceinline__ void patch_tile(const PatchArgs& a, const int part, c
 #pragma unroll
         for (int tp = 0; tp < TPOS; ++tp)
           acc[tc][tp] = SM_MFMA_32x32x16(wf[kk][tc], xf[kk][tp], acc[tc][tp]);
+    }
   };
 
   // ---- main loop over channel-chunk PAIRS: 18 taps = 9 weight stages per iteration.
@@ -629,6 +648,8 @@ int patch_check(const sm_conv_desc* d) {
   if ((d->cout & 7) || (d->out_cstride & 7) || (d->out_coff & 7)) return SM_ERR_UNSUPPORTED;
   if (d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST | SM_CONV_IN_RELU)) return SM_ERR_UNSUPPORTED;
   if (d->w_batch_stride != 0) return SM_ERR_UNSUPPORTED;
+  // paired split operands: binary16 build, 256-cout tiles, f32 output
+  if (d->x3_pairs != 0 && (d->x3_pairs != 1 || !(d->flags & SM_CONV_F16) || patch_bco(d) != PT_BCO)) return SM_ERR_UNSUPPORTED;
   for (int l = 0; l < d->nlev; ++l) {
     if (d->in_h[l] != d->out_h[l] || d->in_w[l] != d->out_w[l] || d->in_h[l] < 1 || d->in_w[l] < 1) return SM_ERR_BAD_SHAPE;
     if (PT_BPOS + 2 * (d->in_w[l] + 2) + 2 > 16 * 48) return SM_ERR_UNSUPPORTED;   // patch rows the loader covers (48 pieces)
@@ -838,7 +859,7 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
   const int var = ((d->flags & SM_CONV_DBG_PATCH_PIPE) ? 1 : 0) | ((d->flags & SM_CONV_DBG_PATCH_STAGGER) ? 2 : 0) |
                   ((d->flags & SM_CONV_DBG_PATCH_NO_DMA) ? 4 : 0) | ((d->flags & SM_CONV_DBG_PATCH_NO_MFMA) ? 8 : 0) |
-                  ((d->flags & SM_CONV_DBG_PATCH_PINGPONG) ? 16 : 0);
+                  ((d->flags & SM_CONV_DBG_PATCH_PINGPONG) ? 16 : 0) | (d->x3_pairs ? 32 : 0);
   auto launch = [&](auto kern, int threads = PT_THREADS) -> int {
     // the attribute is per (kernel, device), not per launch: set once to the most any launch can ask for (common.h)
     if (sm_lds_optin((const void*)kern, 160 * 1024) != hipSuccess) return SM_ERR_LAUNCH;
@@ -864,6 +885,9 @@ extern "C" int sm_conv3x3_patch(const sm_conv_desc* d, const void* x, const void
 #endif
   switch (var) {
     PT_CASE(0)
+#ifdef SM_OPERAND_F16
+    PT_CASE(32)
+#endif
 #ifdef SM_EXPERIMENTS
     PT_CASE(1) PT_CASE(2) PT_CASE(3) PT_CASE(4) PT_CASE(8) PT_CASE(16) PT_CASE(20) PT_CASE(24)
 #endif

@@ -241,6 +241,7 @@ extern "C" int sm_conv3x3_smallco_supported(const sm_conv_desc* d) { return smal
 extern "C" int sm_conv3x3_smallco(const sm_conv_desc* d, const void* x, const void* w_frag, const float* bias, void* y,
                                   sm_stream_t stream) {
   if (!x || !w_frag || !y) return SM_ERR_BAD_ARG;
+  if (d && d->x3_pairs != 0) return SM_ERR_UNSUPPORTED;   // paired split operands: sm_conv3x3_patch only
   if (!smallco_ok(d)) return SM_ERR_UNSUPPORTED;
   SmallCoArgs a;
   a.x = (const uint16_t*)x;

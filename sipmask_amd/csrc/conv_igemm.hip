@@ -1813,6 +1813,7 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p,
   const long long nblk = t * (d->cout_pad / bco) * ngroups;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
   if (d->w_level_stride != 0 || d->bias_level_stride != 0) return SM_ERR_UNSUPPORTED;   // per-level weights: sm_conv3x3_patch only
+  if (d->x3_pairs != 0) return SM_ERR_UNSUPPORTED;                                      // paired split operands: sm_conv3x3_patch only
   // groups exist in the 64-wide-K LDS-DMA kernel only (its tile decode carries the group offsets)
   if (ngroups > 1 && (!dma || k32 || ws || (d->flags & SM_CONV_RES_NEAREST) || d->w_batch_stride != 0)) return SM_ERR_UNSUPPORTED;
   // K-loop variant.  64-wide K, 128/64-cout tiles of the tile-128 family: flat loader + peeled K loop + pipelined

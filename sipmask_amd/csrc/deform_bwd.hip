@@ -342,7 +342,11 @@ __global__ __launch_bounds__(256) void deform_dx_gather_kernel(const DBArgs a, c
       }
       n += __popcll(m);
     }
-    // (the list is written and read by this wave only: LDS operations of one wave complete in order)
+    // the list is written and read by this wave only (LDS operations of one wave complete in order); the fence + wave barrier
+    // pin that order in the SOURCE too: no compiler may move the list reads below above the list stores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     int e = 0;
     for (; e + 4 <= n; e += 4) {
@@ -357,6 +361,9 @@ __global__ __launch_bounds__(256) void deform_dx_gather_kernel(const DBArgs a, c
     }
     for (; e < n; ++e) acc0 = fmaf(s_lw[wv][e], bf16_bits_to_f32((uint32_t)gcol[s_list[wv][e] + c]), acc0);
     gx[(a.in_row0[lev] + (long long)b * H * W + (long long)hc * W + wc) * a.cin + c] = (acc0 + acc1) + (acc2 + acc3);
+    // ... and the next pixel's list stores stay behind this pixel's list reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -764,7 +771,8 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
       gather = gather && d->in_h[l] == d->out_h[l] && d->in_w[l] == d->out_w[l];
       covered += (long long)d->batch * d->in_h[l] * d->in_w[l];
     }
-    // (the gather writes every element of every level's rows: nothing to clear when the levels tile the row range)
+    // (the gather writes every element of every level's rows with plain stores BEFORE the far taps' atomics are
+    // launched behind it: nothing to clear when the levels tile the row range)
     if (gx_col && !(gather && covered == in_rows) && sm_zero_async(gx_col, (size_t)in_rows * d->cin * 4, s) != hipSuccess)
       return SM_ERR_LAUNCH;
     if (grad_offset) {   // positions sampling outside the image are skipped by the kernel: their gradient is 0
@@ -795,8 +803,9 @@ static int conv_bwd_impl(const sm_conv_desc* d, const void* x, const float* offs
     if (d->kh == 3 && d->kw == 3) {               // one wave per (position, 64-channel chunk), nine taps unrolled
       const long long nunits = pl.P * (d->cin / 64);
       const int blocks = (int)std::min<long long>((nunits + 3) / 4, 256 * 64);
-      // (with the gather in front: every offset gradient, and the d(x) atomics of the far taps only)
-      if (!gather || grad_offset)
+      // (with the gather in front: every offset gradient, and the d(x) atomics of the far taps only -- the gather leaves
+      // those out, so the launch is needed for grad_x alone too; goff == nullptr is handled by the kernel)
+      if (gx_col || grad_offset)
         hipLaunchKernelGGL(deform_col2im9_kernel, dim3(blocks), dim3(256), 0, s, a, gcol, gx_col, grad_offset, nunits,
                            gather ? 1 : 0);
     } else {

@@ -43,7 +43,10 @@ struct SplitArgs {
 // TWO: the two-term layout [hi | hi] for sources whose low half is zero (bf16 rows: every bf16 value above 2^-17 is a
 // binary16 value) -- against weights [hi | lo] the conv is x_hi*w_hi + x_hi*w_lo, the three-term product without its zero
 // term (sm_split2_f16, round 5: the first tower convs of the x3 plan read the bf16 FPN outputs)
-template <bool IN_F32, bool TWO = false>
+// PAIRS (round 6): the paired layout of sm_conv_desc.x3_pairs -- a row of C values is C/16 groups of [hi 16 | lo 16]
+// (2*C binary16 per row; channel c: hi at (c >> 4) * 32 + (c & 15), lo 16 elements behind it), the operand the patch kernel
+// reads as (x_hi, x_lo) fragment pairs: 4 bytes written per value instead of the 6 of [hi | lo | hi]
+template <bool IN_F32, bool TWO = false, bool PAIRS = false>
 __global__ __launch_bounds__(256) void split3_kernel(const SplitArgs a) {
   const long long total = a.rows * a.c8;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -59,6 +62,13 @@ __global__ __launch_bounds__(256) void split3_kernel(const SplitArgs a) {
     }
     half8 hi, lo;
     split8(v, hi, lo);
+    if constexpr (PAIRS) {
+      const int ch = a.coff + c;
+      uint16_t* o = a.y + r * a.out_cs + (ch >> 4) * 32 + (ch & 15);
+      *reinterpret_cast<half8*>(o) = hi;
+      *reinterpret_cast<half8*>(o + 16) = lo;
+      continue;
+    }
     uint16_t* o = a.y + r * a.out_cs + a.coff + c;
     *reinterpret_cast<half8*>(o) = hi;
     if constexpr (TWO) {
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(256) void gnx_stats_kernel(const float* __restrict_
   }
 }
 
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void gnx_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         const unsigned long long* __restrict__ stats, float* __restrict__ y32,
@@ -213,10 +224,16 @@ __global__ __launch_bounds__(256) void gnx_apply_kernel(const float* __restrict_
     if (y3 != nullptr) {
       half8 hi, lo;
       split8(v, hi, lo);
-      uint16_t* o = y3 + row * (3ll * a.C) + cc * 8;
-      *reinterpret_cast<half8*>(o) = hi;
-      *reinterpret_cast<half8*>(o + a.C) = lo;
-      *reinterpret_cast<half8*>(o + 2 * a.C) = hi;
+      if constexpr (PAIRS) {                        // [hi 16 | lo 16] per 16 channels (sm_conv_desc.x3_pairs)
+        uint16_t* o = y3 + row * (2ll * a.C) + (cc >> 1) * 32 + (cc & 1) * 8;
+        *reinterpret_cast<half8*>(o) = hi;
+        *reinterpret_cast<half8*>(o + 16) = lo;
+      } else {
+        uint16_t* o = y3 + row * (3ll * a.C) + cc * 8;
+        *reinterpret_cast<half8*>(o) = hi;
+        *reinterpret_cast<half8*>(o + a.C) = lo;
+        *reinterpret_cast<half8*>(o + 2 * a.C) = hi;
+      }
     }
   }
 }
@@ -302,8 +319,43 @@ extern "C" int sm_groupnorm_apply_x3(const float* x, const float* gamma, const f
   int t;
   const int rc = gnx_fill(a, t, batch, nlev, hw, row0, channels, groups, eps, relu);
   if (rc != SM_OK) return rc;
-  hipLaunchKernelGGL(gnx_apply_kernel, dim3(t, batch), dim3(256), 0, sm_hip_stream(stream), x, gamma, beta,
+  hipLaunchKernelGGL(gnx_apply_kernel<false>, dim3(t, batch), dim3(256), 0, sm_hip_stream(stream), x, gamma, beta,
                      reinterpret_cast<const unsigned long long*>(stats), y_f32, (uint16_t*)y_split, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_groupnorm_apply_x3p(const float* x, const float* gamma, const float* beta, const int64_t* stats, int batch,
+                                      int nlev, const int32_t* hw, const int64_t* row0, int channels, int groups, float eps,
+                                      int relu, float* y_f32, void* y_pairs, sm_stream_t stream) {
+  if (!x || !gamma || !beta || !stats || !hw || !row0 || !y_pairs) return SM_ERR_BAD_ARG;
+  if (channels % 16 != 0) return SM_ERR_BAD_SHAPE;
+  GnxArgs a;
+  int t;
+  const int rc = gnx_fill(a, t, batch, nlev, hw, row0, channels, groups, eps, relu);
+  if (rc != SM_OK) return rc;
+  hipLaunchKernelGGL(gnx_apply_kernel<true>, dim3(t, batch), dim3(256), 0, sm_hip_stream(stream), x, gamma, beta,
+                     reinterpret_cast<const unsigned long long*>(stats), y_f32, (uint16_t*)y_pairs, a);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_split_pairs_f16(const void* x, int x_is_f32, int64_t rows, int channels, int in_cstride, void* y,
+                                  int ctot, int coff, sm_stream_t stream) {
+  if (!x || !y) return SM_ERR_BAD_ARG;
+  if (rows < 1 || channels < 8 || channels % 8 || in_cstride % 8 || in_cstride < channels || ctot % 16 || coff % 8 ||
+      coff + channels > ctot)
+    return SM_ERR_BAD_SHAPE;
+  SplitArgs a;
+  a.x = x, a.y = (uint16_t*)y, a.rows = rows, a.c8 = channels / 8, a.in_cs = in_cstride, a.out_cs = 2 * ctot;
+  a.ctot = ctot, a.coff = coff;
+  const long long n = rows * a.c8;
+  long long g = (n + 255) / 256;
+  if (g > 256 * 32) g = 256 * 32;
+  if (x_is_f32)
+    hipLaunchKernelGGL((split3_kernel<true, false, true>), dim3((unsigned)g), dim3(256), 0, sm_hip_stream(stream), a);
+  else
+    hipLaunchKernelGGL((split3_kernel<false, false, true>), dim3((unsigned)g), dim3(256), 0, sm_hip_stream(stream), a);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

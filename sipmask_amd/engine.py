@@ -58,6 +58,9 @@ _CHAIN_CONV1 = 1               # layer1 tails also compute the next block's conv
 _FUSE_SHORTCUT = 2             # the shortcut conv inside the fused tail: 1 = layer1.0, 2 = + layer2.0
 _PAIR_1X1 = False              # layer3's conv3 + next conv1 as one launch (sm_conv1x1_pair): bit-identical, no faster
 _X3_TOWER0_TWO_TERMS = True    # x3 plan: the first tower convs on [hi | hi] of the bf16 FPN outputs (two half products per element)
+# x3 plan, round 6: the 3x3 tower convs and fcos_cls + sip_cof read PAIRED split operands (per 16 channels [hi 16 | lo 16],
+# sm_conv_desc.x3_pairs: three products on fragments read once, a third less LDS-DMA traffic than [hi | lo | hi] x [hi | hi | lo])
+_X3_PAIRS = True
 _LATENCY_1X1 = ()              # stage widths whose 1x1 convs keep the latency-shaped plan inside pipelined slots: neutral
 _RELU_COPY_P7 = True           # relu(P6) as its own tensor instead of the input-ReLU loader for P7
 _SMALLCO_CONV = True           # 3x3 convs with <= 32 couts on csrc/conv3x3_smallco.hip
@@ -106,7 +109,8 @@ class _Conv:
         self.mode = mode or ("f32" if getattr(eng, "precision", "bf16") == "f32" else "bf16")
         # exact-f32 plan (parity mode): f32 operands on v_mfma_f32_32x32x2_f32, every conv output f32
         self.f32 = self.mode in ("f32", "f32x3")            # f32 tensors in HBM: csrc/conv_f32.hip
-        self.x3 = self.mode in ("x3", "x2")                  # "x2": the two-term form for inputs whose low half is zero
+        self.x3 = self.mode in ("x3", "x2", "x3p")           # "x2": the two-term form for inputs whose low half is zero
+        self.x3p = self.mode == "x3p"                        # paired operands [hi 16 | lo 16] per 16 channels (patch kernel only)
         self.xterms = 2 if self.mode == "x2" else 3
         self.x3w = self.mode == "x3w"                        # FeatureAlign in the x3 plan on the LDS-window kernel
         acc_scale = 0.0
@@ -130,6 +134,17 @@ class _Conv:
                 acc_scale = 1.0 / self.x3_scale
             else:
                 self.w, co_pad = H.prep_conv_weight_f32(w.to(dev), cin)
+        elif self.x3p:
+            if (offset is not None or residual is not None or cin_pad is not None or ci % 32 != 0 or k != 3 or stride != 1
+                    or pad != 1):
+                raise NotImplementedError("x3p convs: plain 3x3 / stride 1 / pad 1 convolutions over 32-aligned channel counts")
+            cin = 2 * ci
+            assert in_cstride == cin, "x3p convs read the paired split tensor (2 * cin binary16 per row)"
+            self.x3_scale = getattr(self, "_x3_scale", None) or H.x3_weight_scale([w])
+            self.w, co_pad = H.prep_conv_weight_patch_x3p(w.to(dev), self.x3_scale)
+            flags |= _lib.SM_CONV_F16 | SM_CONV_OUT_F32
+            acc_scale = 1.0 / self.x3_scale
+            self._patch_force = True
         elif self.x3:
             if offset is not None or residual is not None or cin_pad is not None or ci % 8 != 0:
                 raise NotImplementedError("x3 convs: plain convolutions over 8-aligned channel counts")
@@ -149,7 +164,7 @@ class _Conv:
             flags |= getattr(eng, "extra_conv_flags", 0)   # for the launches that keep the latency-shaped plan (below)
         self.desc = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, co_pad, k, stride, pad,
                                      in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
-                                     scale_nch, level_scale, deform_groups, acc_scale=acc_scale)
+                                     scale_nch, level_scale, deform_groups, acc_scale=acc_scale, x3_pairs=int(self.x3p))
         self.x, self.y, self.residual, self.offset = x, y, residual, offset
         self.gn_stats = None      # set -> GroupNorm statistics of y are accumulated in the conv epilogue
         # large 3x3 / stride-1 convs run on the patch-resident kernel (csrc/conv3x3_patch.hip): own weight layout, cout
@@ -158,7 +173,7 @@ class _Conv:
         # 3x3 convs with a handful of output channels on the bf16 plan (sip_mask_lat 512 -> 32, fcos_reg + centerness 256 -> 8):
         # their own kernel (round 4, csrc/conv3x3_smallco.hip: one wave per 2 x 32-position tile, weights straight from L2)
         self.smallco = False
-        if (not self.f32 and offset is None and residual is None and _SMALLCO_CONV and k == 3 and stride == 1
+        if (not self.f32 and not self.x3p and offset is None and residual is None and _SMALLCO_CONV and k == 3 and stride == 1
                 and pad == 1 and co <= 32 and co % 8 == 0 and ci % 32 == 0 and cin == (3 * ci if self.x3 else ci) and self.mode != "x2"
                 and getattr(self, "_patch_groups", 1) == 1 and not (self.x3 and (flags & _lib.SM_CONV_OUT_X3))):
             ds = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, 32, k, stride, pad, in_cstride,
@@ -169,15 +184,15 @@ class _Conv:
                 self.w = H.prep_conv_weight_smallco(w.to(dev), x3_scale=self.x3_scale if self.x3 else None)
                 self.desc = ds
         if (not self.smallco and not self.f32 and offset is None and residual is None and _PATCH_CONV and k == 3 and stride == 1
-                and pad == 1 and ci % 64 == 0 and (cin == ci or self.x3)):
+                and pad == 1 and (ci % 64 == 0 or self.x3p) and (cin == ci or self.x3)):
             # cout tile of the patch kernel: 256, or 32 for the convs with a handful of output channels (round 4: sip_mask_lat
             # 512 -> 32 and fcos_reg + centerness 256 -> 8 spent 0.10 / 0.065 ms per B=4 launch on the implicit-GEMM kernel
             # re-reading their INPUT nine times; the grouped / per-level launches keep the 256 tile)
-            small_co = co <= 32 and co % 8 == 0 and getattr(self, "_patch_groups", 1) == 1 and _PATCH_SMALL_COUT
+            small_co = co <= 32 and co % 8 == 0 and getattr(self, "_patch_groups", 1) == 1 and _PATCH_SMALL_COUT and not self.x3p
             pad_co = H.patch_cout_pad(co) if small_co else (co + 255) // 256 * 256
             dp = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, pad_co, k, stride,
                                   pad, in_cstride, out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0,
-                                  scale_nch, level_scale, deform_groups, acc_scale=acc_scale)
+                                  scale_nch, level_scale, deform_groups, acc_scale=acc_scale, x3_pairs=int(self.x3p))
             if H.conv3x3_patch_supported(dp):
                 if getattr(eng, "patch_uniform", False):
                     dp.flags |= _lib.SM_CONV_DBG_PATCH_UNIFORM
@@ -193,11 +208,14 @@ class _Conv:
                 # (small_co: the alternative is the implicit-GEMM kernel's nine-fold re-read of the input, whatever the fill)
                 if ((force or (pl["work"] >= getattr(self, "_patch_min_work", _PATCH_MIN_WORK) and
                                (small_co or pl["fill"] >= _PATCH_MIN_FILL or pl["makespan"] <= 1.0)))
-                        and (small_co or co * 4 >= 3 * ((co + 255) // 256 * 256))):
+                        and (small_co or force or co * 4 >= 3 * ((co + 255) // 256 * 256))):
                     self.patch = True
-                    self.w, _ = (H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale, pad_co, self.xterms) if self.x3
+                    self.w, _ = (H.prep_conv_weight_patch_x3p(w.to(dev), self.x3_scale, pad_co) if self.x3p else
+                                 H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale, pad_co, self.xterms) if self.x3
                                  else H.prep_conv_weight_patch(w.to(dev), pad_co))
                     self.desc = dp
+        if self.x3p and not self.patch:
+            raise NotImplementedError("x3p conv %s: the patch-resident kernel does not take this shape" % name)
         # 128-cout x 256-position patch tiles (round 4) for single-level 3x3 convs whose position count gives too few 256-cout
         # tiles to be worth a launch of them: ResNet layer3 / layer4 conv2 (4 200 / 1 050 positions per image: 66 / 17 position
         # tiles at B=4, x 2 / 4 cout tiles).  The implicit-GEMM kernel re-reads their input nine times through L2 -> LDS and is
@@ -327,12 +345,14 @@ class _GroupedConv(_Conv):
                  out_row0, out_cstride, flags=0, mode=None):
         G = len(ws)
         self._patch_groups = G
-        if mode in ("x3", "x2"):
+        if mode in ("x3", "x2", "x3p"):
             self._x3_scale = H.x3_weight_scale(ws)              # one accumulator scale per launch: shared by the groups
         _Conv.__init__(self, eng, name, ws[0], biases[0], batch, in_sizes, in_row0, x, in_cstride, 1, 1, y, out_row0,
                        out_cstride, flags=flags, mode=mode)
         dev = eng.device
-        if self.x3:
+        if self.x3p:
+            prep = lambda w: H.prep_conv_weight_patch_x3p(w.to(dev), self.x3_scale)[0]
+        elif self.x3:
             prep = (lambda w: H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale, terms=self.xterms)[0]) if self.patch else \
                 (lambda w: H.prep_conv_weight_x3(w.to(dev), self.x3_scale, self.xterms)[0])
         else:
@@ -402,7 +422,16 @@ class _DeformChoice:
         return self.active is self.window and self.window.gn_stats is not None
 
     def __getattr__(self, name):          # name, mode, flops, mfma_flops, bytes, desc, ... of the active kernel
+        # (copy.deepcopy / pickle probe __deepcopy__ / __setstate__ / __reduce_ex__ on an instance whose __init__ has not run)
+        if name.startswith("__") or "active" not in self.__dict__:
+            raise AttributeError(name)
         return getattr(self.__dict__["active"], name)
+
+    def __setattr__(self, name, value):   # reads are forwarded, so writes to anything but the wrapper's own three fields
+        if name in ("window", "gather", "active"):        # would silently land on the wrapper: refuse them
+            object.__setattr__(self, name, value)
+        else:
+            raise AttributeError("_DeformChoice forwards reads only; set %r on .window / .gather" % name)
 
     def __call__(self):
         self.active()
@@ -900,15 +929,41 @@ class SipMaskEngine:
         # A bf16 pyramid (the bf16 backbone's) has no low half: [hi | hi] against weights [hi | lo] is the same sum without its
         # zero term -- the first tower launch does 2/3 of the MFMA work (round 5).  f32 features (for_head) keep three terms.
         two = _X3_TOWER0_TWO_TERMS and self.pyr.dtype == torch.bfloat16
-        pyr_w = 512 if two else 768
+        # operand layout of the 3x3 convs behind the first: paired ([hi 16 | lo 16] per 16 channels, 2 * 256 per row: mode "x3p",
+        # round 6) or K-concatenated ([hi | lo | hi], 3 * 256 per row: mode "x3")
+        pairs = _X3_PAIRS
+        self.x3_pairs = pairs
+        tw, tmode = (512, "x3p") if pairs else (768, "x3")
+        pyr_w = 512 if (two or pairs) else 768
         self.pyr_x3 = torch.empty(rows, pyr_w, dtype=F16, device=dev)
         if two:
             self._add("split:pyr", lambda: H.split2_f16(self.pyr, self.pyr_x3, 256))
+        elif pairs:
+            self._add("split:pyr", lambda: H.split_pairs_f16(self.pyr, self.pyr_x3, 256))
         else:
             self._add("split:pyr", lambda: H.split3_f16(self.pyr, self.pyr_x3, 256))
 
+        def gn_or_split(label, yv, st, norm_name, keep_f32, o_pairs, o_split):
+            """GroupNorm + ReLU (or nothing, SSD-style towers) of a tower conv's f32 output -> what its consumers read: f32 rows
+            (in place), the paired operand of the next 3x3 conv, the [hi | lo | hi] operand of the small-cout / 1x1 convs"""
+            assert (o_pairs is None) != (o_split is None), "one split operand per tensor (an in-place f32 pass runs once)"
+            if self.flag_norm:
+                gam, bet = par(h + norm_name + ".weight"), par(h + norm_name + ".bias")
+                if o_pairs is not None:
+                    self._add("gn:" + label, lambda: H.groupnorm_apply_x3(yv, gam, bet, st, lv, 256, 32, 1e-5, True,
+                                                                          y_f32=yv if keep_f32 else None, y_pairs=o_pairs))
+                if o_split is not None or o_pairs is None:
+                    self._add("gn:" + label + ("" if o_pairs is None else ".split"),
+                              lambda: H.groupnorm_apply_x3(yv, gam, bet, st, lv, 256, 32, 1e-5, True,
+                                                           y_f32=yv if (keep_f32 and o_pairs is None) else None, y_split=o_split))
+            else:
+                if o_pairs is not None:
+                    self._add("split:" + label, lambda: H.split_pairs_f16(yv, o_pairs, 256))
+                if o_split is not None:
+                    self._add("split:" + label + ("" if o_pairs is None else ".split"), lambda: H.split3_f16(yv, o_split, 256))
+
         relu = 0 if self.flag_norm else SM_CONV_RELU
-        x, xg = self.pyr_x3, 0
+        x, xg, xw = self.pyr_x3, 0, pyr_w
         cls_f32 = reg_x3 = None
         for i in range(ncls):                         # cls + reg tower convs of one depth = ONE grouped launch
             y = torch.empty(2 * rows, 256, dtype=f32, device=dev)
@@ -916,47 +971,55 @@ class SipMaskEngine:
             first2 = two and i == 0
             c = self._add_conv(_GroupedConv(self, "head.tower%d" % i, [sd[h + n + ".conv.weight"] for n in names],
                                             [sd.get(h + n + ".conv.bias") for n in names], B, sizes, row0, x, xg,
-                                            pyr_w if first2 else 768, y, rows, row0, 256, flags=TF | relu,
-                                            mode="x2" if first2 else "x3"))
+                                            xw, y, rows, row0, 256, flags=TF | relu,
+                                            mode="x2" if first2 else (tmode if (i > 0 or pairs) else "x3")))
             if self.flag_norm:
                 c.gn_stats = stats2
-            nxt = torch.empty(2 * rows, 768, dtype=F16, device=dev)
+            last_depth = i == ncls - 1
+            # both groups' next operand in ONE tensor (the next grouped launch reads group g at g * rows); behind the last
+            # grouped depth only the reg tower goes on
+            nxt = torch.empty(2 * rows, tw, dtype=F16, device=dev) if not last_depth else None
             for g, n in enumerate(names):
                 yv, st = y[g * rows:(g + 1) * rows], stats2[g * S:(g + 1) * S]
-                last_cls = g == 0 and i == ncls - 1               # feeds FeatureAlign's f32 deformable conv only
-                last_reg = g == 1 and i == nreg - 1               # feeds reg_ctr (split) and the mask branch (f32)
-                o3 = nxt[g * rows:(g + 1) * rows]
-                if self.flag_norm:
-                    gam, bet = par(h + n + ".gn.weight"), par(h + n + ".gn.bias")
-                    self._add("gn:" + n, (lambda yv=yv, gam=gam, bet=bet, st=st, o3=o3, lc=last_cls, lr=last_reg:
-                                          H.groupnorm_apply_x3(yv, gam, bet, st, lv, 256, 32, 1e-5, True,
-                                                               y_f32=yv if (lc or lr) else None, y_split=None if lc else o3)))
+                last_cls = g == 0 and last_depth                  # feeds FeatureAlign's f32 deformable conv only
+                last_reg = g == 1 and i == nreg - 1               # feeds reg_ctr, the mask branch ([hi | lo | hi]) and f32 consumers
+                o_next = o_split = None
+                if last_reg:
+                    o_split = torch.empty(rows, 768, dtype=F16, device=dev)
                 elif not last_cls:
-                    self._add("split:" + n, (lambda yv=yv, o3=o3: H.split3_f16(yv, o3, 256)))
+                    o_next = nxt[g * rows:(g + 1) * rows] if nxt is not None else torch.empty(rows, tw, dtype=F16, device=dev)
                 if last_cls:
                     cls_f32 = yv
+                    if self.flag_norm:                            # normalise in place, no split operand
+                        gam, bet = par(h + n + ".gn.weight"), par(h + n + ".gn.bias")
+                        self._add("gn:" + n, (lambda yv=yv, gam=gam, bet=bet, st=st:
+                                              H.groupnorm_apply_x3(yv, gam, bet, st, lv, 256, 32, 1e-5, True, y_f32=yv)))
+                elif pairs:
+                    gn_or_split(n, yv, st, n + ".gn", last_reg, o_next, o_split)
+                else:
+                    gn_or_split(n, yv, st, n + ".gn", last_reg, None, o_split if last_reg else o_next)
                 if last_reg:
-                    self.reg_feat, reg_x3 = yv, o3
-            x, xg = nxt, rows
-        xr = x[rows:]                                 # the reg tower's split operand
+                    self.reg_feat, reg_x3 = yv, o_split
+                if g == 1:
+                    xr = o_next
+            x, xg, xw = nxt, rows, tw
         for i in range(ncls, nreg):                   # the reg tower is deeper (stacked_convs vs stacked_convs - 1)
             y = torch.empty(rows, 256, dtype=f32, device=dev)
             name = "reg_convs.%d" % i
             c = self._add_conv(_Conv(self, "head." + name, sd[h + name + ".conv.weight"], sd.get(h + name + ".conv.bias"), B,
-                                     sizes, row0, xr, 768, 1, 1, y, row0, 256, flags=relu, mode="x3"))
+                                     sizes, row0, xr, tw, 1, 1, y, row0, 256, flags=relu, mode=tmode))
             if self.flag_norm:
                 c.gn_stats = self.gn_stats
             last = i == nreg - 1
-            o3 = torch.empty(rows, 768, dtype=F16, device=dev)
-            if self.flag_norm:
-                gam, bet = par(h + name + ".gn.weight"), par(h + name + ".gn.bias")
-                self._add("gn:" + name, (lambda y=y, gam=gam, bet=bet, o3=o3, last=last: H.groupnorm_apply_x3(
-                    y, gam, bet, self.gn_stats, lv, 256, 32, 1e-5, True, y_f32=y if last else None, y_split=o3)))
+            o_next = None if last else torch.empty(rows, tw, dtype=F16, device=dev)
+            o_split = torch.empty(rows, 768, dtype=F16, device=dev) if last else None
+            if pairs:
+                gn_or_split(name, y, self.gn_stats, name + ".gn", last, o_next, o_split)
             else:
-                self._add("split:" + name, (lambda y=y, o3=o3: H.split3_f16(y, o3, 256)))
-            xr = o3
+                gn_or_split(name, y, self.gn_stats, name + ".gn", last, None, o_split if last else o_next)
+            xr = o_next
             if last:
-                self.reg_feat, reg_x3 = y, o3
+                self.reg_feat, reg_x3 = y, o_split
         self.cls_feat = cls_f32
         # mask basis branch (sipmask_head.py:275-285) on lane 2: f32 [l0 | up2(l1) | up4(l2)] -> split -> 1x1 -> split -> 3x3
         (h0, w0) = sizes[0]
@@ -1032,13 +1095,15 @@ class SipMaskEngine:
         if window is not None and _DEFORM_MODE == "1":
             fa.pick("gather")
         self.deform_choice = None
-        aligned_x3 = torch.empty(rows, 768, dtype=F16, device=dev)
+        aligned_x3 = torch.empty(rows, tw, dtype=F16, device=dev)
         if self.flag_norm:
             gam, bet = par(h + "feat_align.norm.weight"), par(h + "feat_align.norm.bias")
             # (the window kernel's epilogue has written the statistics already)
             self._add("gn_stats:feat_align", lambda: None if fa.fused_stats else H.gn_stats_f32_fix(self.aligned, self.gn_stats, lv, 256, 32))
             self._add("gn:feat_align", lambda: H.groupnorm_apply_x3(self.aligned, gam, bet, self.gn_stats, lv, 256, 32, 1e-5,
-                                                                    True, y_split=aligned_x3))
+                                                                    True, **{"y_pairs" if pairs else "y_split": aligned_x3}))
+        elif pairs:
+            self._add("split:feat_align", lambda: H.split_pairs_f16(self.aligned, aligned_x3, 256))
         else:
             self._add("split:feat_align", lambda: H.split3_f16(self.aligned, aligned_x3, 256))
         # fcos_cls (80) + sip_cof (128): one 208-channel conv
@@ -1046,8 +1111,8 @@ class SipMaskEngine:
         b_cc = torch.cat([sd[h + "fcos_cls.bias"], sd[h + "sip_cof.bias"]], 0)
         self.ncc = self.ncls + 128
         self.cls_cof = torch.empty(rows, self.ncc, dtype=f32, device=dev)
-        self._add_conv(_Conv(self, "head.cls_cof", w_cc, b_cc, B, sizes, row0, aligned_x3, 768, 1, 1, self.cls_cof, row0,
-                             self.ncc, mode="x3"))
+        self._add_conv(_Conv(self, "head.cls_cof", w_cc, b_cc, B, sizes, row0, aligned_x3, tw, 1, 1, self.cls_cof, row0,
+                             self.ncc, mode=tmode))
         self.track_feats = None
 
     def _build_head(self, sd, prefix="bbox_head."):

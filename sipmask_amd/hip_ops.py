@@ -100,6 +100,44 @@ def prep_conv_weight_patch_x3(w, scale, co_pad=None, terms=3):
     return out.reshape(co_pad, 9 * ci3).contiguous(), co_pad
 
 
+def prep_conv_weight_patch_x3p(w, scale, co_pad=None):
+    """[co,ci,3,3] float -> binary16 [cout_pad][ci/16][9][hi 16 | lo 16] for sm_conv3x3_patch with SM_CONV_F16 and
+    sm_conv_desc.x3_pairs (round 6): per cout row, 16-channel group and tap the halves hi = f16(w * scale), lo = f16(w * scale -
+    hi) side by side -- 64 bytes, one fragment pair; the two taps of a weight stage stay one 128-byte line of the row."""
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (3, 3) and ci % 32 == 0
+    ws = w.float() * scale
+    hi = ws.to(F16)
+    lo = (ws - hi.float()).to(F16)
+    co_pad = co_pad or (co + 255) // 256 * 256
+    assert co_pad >= co and co_pad % 256 == 0
+    lay = lambda t: t.permute(0, 2, 3, 1).reshape(co, 9, ci // 16, 16).permute(0, 2, 1, 3)      # [co, ci/16, tap, 16]
+    out = torch.zeros(co_pad, ci // 16, 9, 32, dtype=F16, device=w.device)
+    out[:co, ..., :16] = lay(hi)
+    out[:co, ..., 16:] = lay(lo)
+    return out.reshape(co_pad, 18 * ci).contiguous(), co_pad
+
+
+def split_pairs_f16(x, y, channels=None, ctot=None, coff=0):
+    """x: f32 or bf16 rows [rows, >= channels] -> y binary16 [rows, 2*ctot] in the paired layout (per 16 channels [hi 16 | lo 16];
+    sm_split_pairs_f16)"""
+    _lib.require_cuda(x, y)
+    channels = channels or x.shape[1]
+    ctot = ctot or channels
+    if x.dtype not in (torch.float32, BF16) or y.dtype != F16 or y.shape[1] != 2 * ctot or y.shape[0] != x.shape[0]:
+        raise ValueError("split_pairs_f16: f32 / bf16 rows in, binary16 [rows, 2*ctot] out")
+    lib = _lib.load()
+    _lib.check(lib.sm_split_pairs_f16(_lib.ptr(x), int(x.dtype == torch.float32), x.shape[0], channels, x.stride(0),
+                                      _lib.ptr(y), ctot, coff, _lib.stream_ptr()), "sm_split_pairs_f16")
+    return y
+
+
+def pairs_to_float(y, channels):
+    """host-side inverse of the paired layout (tests): binary16 [rows, 2*C] -> (hi, lo) float [rows, C]"""
+    v = y.float().view(y.shape[0], channels // 16, 2, 16)
+    return v[:, :, 0].reshape(y.shape[0], channels), v[:, :, 1].reshape(y.shape[0], channels)
+
+
 def prep_deform_weight_x3(w, scale, deform_groups):
     """[co, 64*G, 3, 3] float -> binary16 [cout_pad][G*2*9][hi 32 | lo 32] for sm_deform_conv2d_x3: per cout row and K step
     (group g, channel half c, tap t) the 32 channels g*64 + c*32 .. +31 of w * scale as hi = f16(v), lo = f16(v - hi);
@@ -211,9 +249,20 @@ def gn_stats_f32_fix(x, stats, lv, channels, groups=32):
     return stats
 
 
-def groupnorm_apply_x3(x, gamma, beta, stats, lv, channels, groups=32, eps=1e-5, relu=True, y_f32=None, y_split=None):
-    """normalise (+ReLU) f32 rows with fixed-point statistics -> f32 rows and / or [hi | lo | hi] binary16 rows"""
+def groupnorm_apply_x3(x, gamma, beta, stats, lv, channels, groups=32, eps=1e-5, relu=True, y_f32=None, y_split=None,
+                       y_pairs=None):
+    """normalise (+ReLU) f32 rows with fixed-point statistics -> f32 rows and / or [hi | lo | hi] binary16 rows; y_pairs:
+    the paired layout instead (binary16 [rows, 2*C], sm_groupnorm_apply_x3p)"""
     _check_gn_stats(stats)
+    if y_pairs is not None:
+        if y_split is not None or x.dtype != torch.float32 or (y_f32 is not None and y_f32.dtype != torch.float32) or \
+                y_pairs.dtype != F16 or y_pairs.shape[1] != 2 * channels:
+            raise ValueError("groupnorm_apply_x3: f32 rows in; y_pairs binary16 [rows, 2*C] (and optionally f32 rows) out")
+        nlev, hw, row0 = _lv_geometry(lv)
+        _lib.check(_lib.load().sm_groupnorm_apply_x3p(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats), lv.batch,
+                                                      nlev, hw, row0, channels, groups, eps, int(relu), _lib.ptr(y_f32),
+                                                      _lib.ptr(y_pairs), _lib.stream_ptr()), "sm_groupnorm_apply_x3p")
+        return
     if x.dtype != torch.float32 or (y_f32 is not None and y_f32.dtype != torch.float32) or \
             (y_split is not None and (y_split.dtype != F16 or y_split.shape[1] != 3 * channels)):
         raise ValueError("groupnorm_apply_x3: f32 rows in; f32 and / or binary16 [rows, 3*C] rows out")
@@ -326,7 +375,7 @@ class Levels:
 def make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, cout, cout_pad, k, stride, pad,
                    in_cstride, out_cstride, out_coff=0, flags=0, dil=1, res_cstride=0, res_sizes=None,
                    res_row0=None, scale_nch=0, level_scale=None, deform_groups=0, ngroups=1, x_group_rows=0, y_group_rows=0,
-                   w_group_stride=0, bias_group_stride=0, gn_group_stride=0, acc_scale=0.0, patch_cout_tile=0):
+                   w_group_stride=0, bias_group_stride=0, gn_group_stride=0, acc_scale=0.0, patch_cout_tile=0, x3_pairs=0):
     d = ConvDesc()
     nlev = len(in_sizes)
     assert 1 <= nlev <= SM_MAX_LEVELS
@@ -352,6 +401,7 @@ def make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, cout, cou
     d.bias_group_stride, d.gn_group_stride = bias_group_stride, gn_group_stride
     d.acc_scale = float(acc_scale)
     d.patch_cout_tile = int(patch_cout_tile)
+    d.x3_pairs = int(x3_pairs)
     return d
 
 

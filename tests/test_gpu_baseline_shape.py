@@ -66,20 +66,53 @@ def test_bf16_plan_at_baseline_shape():
 
 
 def test_bf16_pipelined_plan_at_baseline_shape():
-    """the default object of bench.py: a slot of the PipelinedPlan (SipMask.prepare(in_flight=3)) at BASELINE's shape, held to
-    the bounds of the bf16 plan above"""
+    """the default object of bench.py: a slot of the PipelinedPlan (SipMask.prepare(in_flight=3)) at BASELINE's shape.  Bounds =
+    1.5 x what the plan measures (profiles/r05_parity_r50_b4_bf16_pipelined.json: backbone / FPN stages <= 1.14 %, head outputs
+    <= 2.3 % from the image and <= 1.1 % on identical features, mask logits 2.9 % / 1.3 %, 90-93 / 95-98 of 100 detections in
+    common), so that a regression of the timed plan cannot hide inside a loose tolerance (VERDICT r5 weak #2)."""
     _need_gpu()
     import parity_baseline as PB
-    rep = PB.run(50, 4, "bf16", features_too=False, verbose=False, plan="pipelined")
+    rep = PB.run(50, 4, "bf16", features_too=True, verbose=False, plan="pipelined")
     assert rep["steps_in_flight"] == 3 and rep["rerun_bit_identical"]
+    img, feat = rep["image"], rep["features"]
+    for k in ("C2", "C3", "C4", "C5", "P3", "P4", "P5", "P6", "P7"):
+        assert img[k]["rel_fro"] < 0.017, (k, img[k])
+    for k in ("cls_logits", "bbox_pred", "centerness", "cof", "basis"):
+        assert img[k]["rel_fro"] < 0.035, (k, img[k])
+        assert feat[k]["rel_fro"] < 0.017, (k, feat[k])
+    assert img["mask_logits"]["rel_fro"] < 0.044, img["mask_logits"]
+    assert feat["mask_logits"]["rel_fro"] < 0.0195 and feat["mask_logits"]["max_abs"] < 1.0, feat["mask_logits"]
+    for d in rep["detections"]:
+        assert d["ndet_engine"] == d["ndet_oracle"] == 100 and d["common"] >= 85, d
+    for d in rep["features_detections"]:
+        assert d["ndet_engine"] == d["ndet_oracle"] == 100 and d["common"] >= 92, d
+
+
+def test_head_x3_pipelined_plan_at_baseline_shape():
+    """THE OBJECT bench.py's `parity_plan` / `parity_pairs[head_x3]` times: a slot of det.prepare(4, ..., precision="head_x3",
+    in_flight=3), and its head-only twin built like that slot (SipMaskEngine.for_head(..., pipelined=True)) fed the oracle's
+    fp32 FPN features -- north_star's "outputs match the reference head on identical inputs": mask logits within 1e-3
+    ABSOLUTE (logits reach +-29.8), every head output within 1e-4 of its largest value, the 100 detections of every image
+    the oracle's IN THE ORACLE'S ORDER, boxes within 5e-3 px.  From the image the bf16 backbone's rounding dominates and the
+    bf16 plan's (tightened) stage bounds apply.  (sipmask_head.py:241-287, 609-633.)"""
+    _need_gpu()
+    import parity_baseline as PB
+    rep = PB.run(50, 4, "head_x3", features_too=True, verbose=False, plan="pipelined")
+    assert rep["steps_in_flight"] == 3 and rep["rerun_bit_identical"]
+    feat = rep["features"]
+    assert feat["mask_logits"]["max_abs"] <= 1e-3, feat["mask_logits"]
+    assert feat["mask_logits"]["cof_max_abs"] <= 1e-4, feat["mask_logits"]
+    for k in ("cls_logits", "bbox_pred", "centerness", "cof", "basis"):
+        assert feat[k]["max_abs"] <= 1e-4 * feat[k]["ref_max_abs"], (k, feat[k])
+    for d in rep["features_detections"]:
+        assert d["ndet_engine"] == d["ndet_oracle"] == d["common"] and d["same_order"], d
+        assert d["common_box_max_abs"] <= 5e-3, d
     img = rep["image"]
     for k in ("C2", "C3", "C4", "C5", "P3", "P4", "P5", "P6", "P7"):
-        assert img[k]["rel_fro"] < 0.02, (k, img[k])
+        assert img[k]["rel_fro"] < 0.017, (k, img[k])
     for k in ("cls_logits", "bbox_pred", "centerness", "cof", "basis"):
-        assert img[k]["rel_fro"] < 0.04, (k, img[k])
-    assert img["mask_logits"]["rel_fro"] < 0.05
-    for d in rep["detections"]:
-        assert d["ndet_engine"] > 0 and d["ndet_oracle"] > 0 and d["common"] >= 80, d
+        assert img[k]["rel_fro"] < 0.035, (k, img[k])
+    assert img["mask_logits"]["rel_fro"] < 0.044, img["mask_logits"]
 
 
 def test_head_x3_plan_at_baseline_shape():

@@ -3,6 +3,8 @@ weights and image, stage by stage.  bf16 storage of ~60 stacked conv layers cann
 logits end to end (SURVEY section 7 "hard parts"); the stated bound here is a relative Frobenius
 error per stage, and the tight (bit-exact / 1e-5) parity lives in test_gpu_kernels.py where
 both sides see identical inputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -393,6 +395,24 @@ def test_mixed_size_batch_reads_img_shape_and_scale_factor_per_image(rescale):
     small = det.prepare(3, tuple(batch.shape[-2:]), None, max(sfs) * 1.5, rescale)
     with pytest.raises(ValueError):
         small.set_image_metas(metas)
+
+
+@pytest.mark.parametrize("env,cycles", [({}, 2000), ({"AMD_SERIALIZE_KERNEL": "3"}, 500), ({"HSA_ENABLE_SDMA": "0"}, 500)])
+def test_pipelined_plan_stress(env, cycles):
+    """VERDICT r5 #3 (an unexplained SIGABRT inside torch.cuda.synchronize() of a PipelinedPlan test on one box in round 5):
+    2 000 submit(pack=True) / fetch cycles over three slots with hipGraph replay, batches and img_metas varying from step to
+    step, every result held to the single plan's, the slot's stream queried after every submit -- in its own process
+    (tests/_pipeline_stress_worker.py), once as shipped, once with every kernel serialised by the runtime
+    (AMD_SERIALIZE_KERNEL=3) and once with the SDMA engines off (blit-kernel copies).  A GPU memory fault or a runtime
+    assertion aborts the worker: the return code and its stderr are the finding."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_pipeline_stress_worker.py")
+    r = subprocess.run([sys.executable, worker, str(cycles)], env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and ("PIPELINE_STRESS_OK %d" % cycles) in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
 
 
 def test_pipelined_submit_packs_results_and_keeps_metas_per_slot(monkeypatch):

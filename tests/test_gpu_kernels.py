@@ -16,6 +16,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from oracle import ops as O  # noqa: E402
+from sipmask_amd import _lib as L  # noqa: E402
 
 
 def _dev():
@@ -726,20 +727,25 @@ def test_deform_dx_gather_equals_atomic_scatter(off_scale):
     w = torch.randn(Co, C, 3, 3, generator=g) / 48
     w_t, _ = H.prep_conv_weight(w.permute(2, 3, 1, 0).reshape(9 * C, Co, 1, 1).contiguous().to(dev), Co)
 
-    def run(flags):
+    def run(flags, want_goff=True):
         d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, C, Co, Co, 3, 1, 1, C, Co, flags=flags, deform_groups=G)
         gx = torch.full((lv.rows, C), float("nan"), dtype=torch.float32, device=dev)
-        goff = torch.full_like(off, float("nan"))
+        goff = torch.full_like(off, float("nan")) if want_goff else None
         H.deform_conv2d_bwd(d, x, off, w_t, go, gx, goff, None)
         torch.cuda.synchronize()
         return gx, goff
 
     a, ao = run(0)
-    b, bo = run(1024)                                    # SM_CONV_BWD_DX_SCATTER
+    b, bo = run(L.SM_CONV_BWD_DX_SCATTER)
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
     assert torch.equal(ao, bo)
     scale = float(b.abs().max())
     assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
+    # grad_x alone ("None = skip" for grad_offset): the far taps' d(x) comes from the scatter launch behind the
+    # gather, which must run also when no offset gradient is asked for
+    c, _ = run(0, want_goff=False)
+    assert torch.isfinite(c).all()
+    assert float((c - b).abs().max()) <= 2e-5 * scale, float((c - b).abs().max()) / scale
     if off_scale < 1.0:
         assert float((off.abs() > 3.0).float().sum()) == 0
         a2, _ = run(0)

@@ -52,7 +52,40 @@ def test_split3_layout_and_precision():
     assert float((y2[:, :64] + y2[:, 64:128] - xbc).abs().max()) <= float(xbc.abs().max()) * 2.0 ** -21
 
 
-@pytest.mark.parametrize("kernel", ["igemm", "igemm256", "patch"])
+def test_paired_layout_split_and_groupnorm():
+    """Round 6, the PAIRED operand layout (sm_conv_desc.x3_pairs): per 16 channels [hi 16 | lo 16].  sm_split_pairs_f16 writes
+    exactly the halves sm_split3_f16 writes, from f32 and from bf16 rows, also into a channel slice of a wider destination;
+    sm_groupnorm_apply_x3p writes exactly the halves (and the in-place f32 rows) sm_groupnorm_apply_x3 writes."""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(777, 64, generator=g) * torch.logspace(-3, 2, 64)).contiguous()
+    for src in (x, x.to(torch.bfloat16)):
+        y3 = torch.empty(777, 3 * 96, dtype=torch.float16, device=dev)
+        yp = torch.full((777, 2 * 96), 7.0, dtype=torch.float16, device=dev)
+        H.split3_f16(src.to(dev), y3, 64, 96, 16)
+        H.split_pairs_f16(src.to(dev), yp, 64, 96, 16)
+        hi, lo = H.pairs_to_float(yp.cpu(), 96)
+        assert torch.equal(hi[:, 16:80], y3[:, 16:80].cpu().float()) and torch.equal(lo[:, 16:80], y3[:, 96 + 16:96 + 80].cpu().float())
+        assert bool((hi[:, :16] == 7).all()) and bool((lo[:, 80:] == 7).all())       # other sources' slices untouched
+    B, sizes, C = 2, [(9, 14), (5, 7)], 256
+    lv = H.Levels(B, sizes)
+    v = torch.randn(lv.rows, C, generator=g).to(dev) * 3 + 0.5
+    gam, bet = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    stats = H.gn_stats_alloc(B * len(sizes) * 32, dev)
+    H.gn_stats_f32_fix(v, stats, lv, C, 32)
+    a32, b32 = v.clone(), v.clone()
+    y3 = torch.empty(lv.rows, 3 * C, dtype=torch.float16, device=dev)
+    yp = torch.empty(lv.rows, 2 * C, dtype=torch.float16, device=dev)
+    H.groupnorm_apply_x3(a32, gam, bet, stats, lv, C, 32, 1e-5, True, y_f32=a32, y_split=y3)
+    H.groupnorm_apply_x3(b32, gam, bet, stats, lv, C, 32, 1e-5, True, y_f32=b32, y_pairs=yp)
+    torch.cuda.synchronize()
+    hi, lo = H.pairs_to_float(yp.cpu(), C)
+    assert torch.equal(a32, b32) and torch.equal(hi, y3[:, :C].cpu().float()) and torch.equal(lo, y3[:, C:2 * C].cpu().float())
+    assert float(hi.abs().max()) > 0 and float(lo.abs().max()) > 0
+
+
+@pytest.mark.parametrize("kernel", ["igemm", "igemm256", "patch", "patch_pairs"])
 def test_x3_conv_matches_f64_conv_of_f32_operands(kernel):
     """3x3 256->256 over a 3-level pyramid, grouped (2 weight sets, shared input), fused fixed-point GN statistics, f32
     output: within 4e-6 of the float64 convolution of the SAME f32 operands, relative to the output's largest value
@@ -61,17 +94,22 @@ def test_x3_conv_matches_f64_conv_of_f32_operands(kernel):
     dev = _dev()
     g = torch.Generator().manual_seed(5)
     B, C, G = 2, 256, 2
-    sizes = [(40, 66), (20, 33), (5, 9)] if kernel != "patch" else [(100, 168), (50, 84), (25, 42)]
+    pairs = kernel == "patch_pairs"       # round 6: paired operands, three products on fragments read once (x3_pairs)
+    sizes = [(40, 66), (20, 33), (5, 9)] if not kernel.startswith("patch") else [(100, 168), (50, 84), (25, 42)]
     lv = H.Levels(B, sizes)
     xs = [torch.randn(B, C, h, w, generator=g) * 1.7 for h, w in sizes]
     ws = [torch.randn(C, C, 3, 3, generator=g) * 0.03 for _ in range(G)]
     bias = [torch.randn(C, generator=g) for _ in range(G)]
-    x3 = torch.empty(lv.rows, 3 * C, dtype=torch.float16, device=dev)
-    H.split3_f16(_rows(xs).to(dev), x3)
+    nk = 2 if pairs else 3
+    x3 = torch.empty(lv.rows, nk * C, dtype=torch.float16, device=dev)
+    (H.split_pairs_f16 if pairs else H.split3_f16)(_rows(xs).to(dev), x3)
     scale = H.x3_weight_scale(ws)
     assert scale == 2.0 ** round(np.log2(scale)) and 2048 <= max(float(w.abs().max()) for w in ws) * scale < 4096
     flags = _lib.SM_CONV_F16 | _lib.SM_CONV_OUT_F32
-    if kernel == "patch":
+    if pairs:
+        packed = [H.prep_conv_weight_patch_x3p(w.to(dev), scale)[0] for w in ws]
+        co_pad = 256
+    elif kernel == "patch":
         packed = [H.prep_conv_weight_patch_x3(w.to(dev), scale)[0] for w in ws]
         co_pad = 256
     else:
@@ -83,13 +121,13 @@ def test_x3_conv_matches_f64_conv_of_f32_operands(kernel):
     assert packed[0].dtype == torch.float16
     wq = torch.stack(packed).contiguous()
     S = 2 * B * len(sizes) * (C // 8)
-    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, 3 * C, C, co_pad, 3, 1, 1, 3 * C, C, flags=flags, ngroups=G,
+    d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, nk * C, C, co_pad, 3, 1, 1, nk * C, C, flags=flags, ngroups=G,
                          x_group_rows=0, y_group_rows=lv.rows, w_group_stride=packed[0].numel(), bias_group_stride=C,
-                         gn_group_stride=S, acc_scale=1.0 / scale)
+                         gn_group_stride=S, acc_scale=1.0 / scale, x3_pairs=int(pairs))
     y = torch.zeros(G * lv.rows, C, dtype=torch.float32, device=dev)
     stats = torch.full((G * S,), 5, dtype=torch.int64, device=dev)
     bq = torch.stack(bias).to(dev).contiguous()
-    if kernel == "patch":
+    if kernel.startswith("patch"):
         assert H.conv3x3_patch_supported(d)
         H.conv3x3_patch(d, x3, wq, bq, y, stats)
     else:
@@ -176,8 +214,9 @@ def test_x3_plan_first_tower_launch_runs_two_terms_on_the_bf16_pyramid(head_case
         monkeypatch.setattr(E, "_X3_TOWER0_TWO_TERMS", two)
         eng = SipMaskEngine(sd, 2, (192, 256), 50, precision="head_x3")
         t0 = [c for c in eng.convs if c.name == "head.tower0"][0]
-        assert t0.mode == ("x2" if two else "x3") and t0.mfma_flops == t0.flops * (2 if two else 3)
+        assert t0.mode == ("x2" if two else ("x3p" if E._X3_PAIRS else "x3")) and t0.mfma_flops == t0.flops * (2 if two else 3)
         assert all(c.mode != "x2" for c in eng.convs if c.name != "head.tower0")
+        assert [c.mode for c in eng.convs if c.name == "head.tower1"] == ["x3p" if E._X3_PAIRS else "x3"]
         r = eng.run(img)
         torch.cuda.synchronize()
         res[two] = (eng.cls_cof.clone(), eng.reg_out.clone(), {k: v.clone() for k, v in r.items()})
@@ -377,7 +416,11 @@ def test_x3_head_matches_the_fp32_oracle_on_identical_features(head_case):
     c = head_case
     hsd = {k: v for k, v in c["sd"].items() if k.startswith("bbox_head.")}
     eng = SipMaskEngine.for_head(hsd, c["B"], c["sizes"], img_shape=(192, 256, 3), precision="head_x3")
-    assert all(cv.mode in ("x3", "x3w") for cv in eng.convs) and sum(cv.mode == "x3w" for cv in eng.convs) == 1
+    assert all(cv.mode in ("x3", "x3p", "x3w") for cv in eng.convs) and sum(cv.mode == "x3w" for cv in eng.convs) == 1
+    # round 6: the 3x3 tower convs and fcos_cls + sip_cof read paired operands (three products on fragments read once)
+    import sipmask_amd.engine as E
+    paired = sorted(cv.name for cv in eng.convs if cv.mode == "x3p")
+    assert paired == (["head.cls_cof", "head.reg_convs.3", "head.tower0", "head.tower1", "head.tower2"] if E._X3_PAIRS else [])
     eng.load_pyramid([f.cuda() for f in c["feats"]])
     eng.run_head(with_post=True)
     torch.cuda.synchronize()

@@ -20,7 +20,7 @@ for name, sc in (("offsets ~N(0,1.5)", 1.5), ("offsets = 0", 0.0), ("offsets ~N(
     goff = torch.empty_like(off)
     gw = torch.empty(9 * C, C, dtype=torch.float32, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ds = H.make_conv_desc(B, LEVELS, LEVELS, lv.row0, lv.row0, C, C, C, 3, 1, 1, C, C, deform_groups=G, flags=1024)   # SM_CONV_BWD_DX_SCATTER
+    ds = H.make_conv_desc(B, LEVELS, LEVELS, lv.row0, lv.row0, C, C, C, 3, 1, 1, C, C, deform_groups=G, flags=L.SM_CONV_BWD_DX_SCATTER)
     for label, args, dd in (("gx+goff (gather + far scatter)", (gx, goff, None), d), ("gx+goff (atomic scatter alone)", (gx, goff, None), ds),
                             ("goff only", (None, goff, None), d), ("gw only", (None, None, gw), d), ("all", (gx, goff, gw), d)):
         ts = []

@@ -288,7 +288,9 @@ def run(depth=50, batch=4, precision="bf16", features_too=True, verbose=True, pl
     if features_too:
         sizes = [tuple(p.shape[-2:]) for p in ora["pyr"]]
         hsd = {k: v for k, v in sd.items() if k.startswith("bbox_head.")}
-        heng = SipMaskEngine.for_head(hsd, batch, sizes, img_shape=(IMG_H, 1333, 3), **kw)
+        # (plan="pipelined": the head-only plan is built like a slot of the pipeline -- same kernels, tiles and launch shapes
+        # as the timed head; bench.py's parity_on_identical_features does the same)
+        heng = SipMaskEngine.for_head(hsd, batch, sizes, img_shape=(IMG_H, 1333, 3), pipelined=(plan == "pipelined"), **kw)
         heng.load_pyramid([p.to(dev) for p in ora["pyr"]])
         heng.run_head(with_post=True)
         torch.cuda.synchronize()
