@@ -579,6 +579,14 @@ int sm_pairs_select(const sm_det_desc* d, float pre_nms_thresh, const float* cls
                     float* boxes, float* scores, float* cofs, int32_t* lvl_cnt, int32_t* ncand, void* workspace,
                     sm_stream_t stream);
 
+/* Evaluation-workload injection (no reference counterpart; bench.py --det-boxes): ONE launch that, while *flag != 0,
+ * overwrites x1, y1, x2, y2 of the n kept detections det [n][det_stride] (f32; the score in column 4 is kept) with set
+ * ((*counter + 1) % nsets) of sets [nsets][n][4] and advances *counter.  Labels, kept indices and coefficients stay the
+ * detector's: mask assembly and RLE then see an evaluation run's box sizes behind a random-weight detector.  counter and
+ * flag are device memory, so the launch can sit inside a captured graph. */
+int sm_det_boxes_override(float* det, int det_stride, const float* sets, int nsets, int n, int32_t* counter,
+                          const uint8_t* flag, sm_stream_t stream);
+
 /* Single-class greedy NMS with the reference op's contract, nms_cuda.nms:
  * dets f32 [n][5] -> keep i64 [<=n] ascending original indices, *nkeep (device).
  * M/mmdet/ops/nms/src/nms_kernel.cu:71-139.  workspace: sm_nms_workspace(n) bytes. */

@@ -126,6 +126,7 @@ PROTOTYPES = {
     "sm_groupnorm_apply_x3": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P]),
     "sm_groupnorm_apply_x3p": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P]),
     "sm_split_pairs_f16": (_I, [_P, _I, C.c_int64, _I, _I, _P, _I, _I, _P]),
+    "sm_det_boxes_override": (_I, [_P, _I, _P, _I, _I, _P, _P, _P]),
     "sm_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _P]),
     "sm_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sm_stem_fused": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -1189,6 +1189,35 @@ extern "C" int sm_fast_nms(const float* boxes, const float* scores, const float*
   return SM_OK;
 }
 
+// ---------------------------------------------------------------- evaluation-workload injection (bench.py --det-boxes)
+// One launch: while *flag != 0, overwrite x1, y1, x2, y2 of the kept detections det [n][det_stride] with set (*counter % nsets)
+// of `sets` [nsets][n][4] and advance the counter; scores (column 4), labels, kept indices and coefficients stay the
+// detector's.  Random-weight detections are tiny boxes; an evaluation run's are not -- this gives mask assembly / RLE the
+// rectangles of a real one without touching the detector.  Capture-safe (counter and flag live on the device).
+namespace {
+__global__ __launch_bounds__(256) void det_boxes_override_kernel(float* __restrict__ det, int det_stride,
+                                                                 const float* __restrict__ sets, int nsets, int n,
+                                                                 int* __restrict__ counter, const unsigned char* __restrict__ flag) {
+  const int c = *counter;                         // every thread reads the old value ...
+  const bool on = *flag != 0;
+  __syncthreads();
+  if (threadIdx.x == 0) *counter = c + 1;         // ... before one thread advances it
+  if (!on) return;
+  const float* src = sets + (long long)((c + 1) % nsets) * n * 4;
+  for (int i = threadIdx.x; i < n * 4; i += blockDim.x) det[(long long)(i >> 2) * det_stride + (i & 3)] = src[i];
+}
+}  // namespace
+
+extern "C" int sm_det_boxes_override(float* det, int det_stride, const float* sets, int nsets, int n, int32_t* counter,
+                                     const uint8_t* flag, sm_stream_t stream) {
+  if (!det || !sets || !counter || !flag) return SM_ERR_BAD_ARG;
+  if (det_stride < 4 || nsets < 1 || n < 1) return SM_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(det_boxes_override_kernel, dim3(1), dim3(256), 0, sm_hip_stream(stream), det, det_stride, sets, nsets, n,
+                     counter, flag);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
 extern "C" int64_t sm_nms_workspace(int n) { (void)n; return 16; }
 
 extern "C" int sm_nms(const float* dets, int n, float iou_thr, int64_t* keep, int32_t* nkeep, void* workspace,

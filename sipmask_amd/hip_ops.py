@@ -272,6 +272,19 @@ def groupnorm_apply_x3(x, gamma, beta, stats, lv, channels, groups=32, eps=1e-5,
                                                  _lib.ptr(y_split), _lib.stream_ptr()), "sm_groupnorm_apply_x3")
 
 
+def det_boxes_override(det, sets, counter, flag):
+    """det [..., n, >= 4] f32 (a contiguous detection table), sets [nsets, ..., n, 4] f32, counter int32 [1], flag bool / uint8
+    scalar, all on the device: one launch of sm_det_boxes_override (evaluation-workload injection, bench.py --det-boxes)"""
+    _lib.require_cuda(det, sets, counter, flag)
+    n = det.numel() // det.shape[-1]
+    if (det.dtype != torch.float32 or sets.dtype != torch.float32 or not det.is_contiguous() or not sets.is_contiguous()
+            or sets.shape[-1] != 4 or sets.numel() != sets.shape[0] * n * 4 or counter.dtype != torch.int32
+            or flag.element_size() != 1):
+        raise ValueError("det_boxes_override: det [.., n, k >= 4] f32, sets [nsets, .., n, 4] f32, int32 counter, 1-byte flag")
+    _lib.check(_lib.load().sm_det_boxes_override(_lib.ptr(det), det.shape[-1], _lib.ptr(sets), sets.shape[0], n,
+                                                 _lib.ptr(counter), _lib.ptr(flag), _lib.stream_ptr()), "sm_det_boxes_override")
+
+
 def conv3x3_patch_supported(desc):
     return bool(_lib.load().sm_conv3x3_patch_supported(C.byref(desc)))
 

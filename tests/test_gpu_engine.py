@@ -397,14 +397,16 @@ def test_mixed_size_batch_reads_img_shape_and_scale_factor_per_image(rescale):
         small.set_image_metas(metas)
 
 
-@pytest.mark.parametrize("env,cycles", [({}, 2000), ({"AMD_SERIALIZE_KERNEL": "3"}, 500), ({"HSA_ENABLE_SDMA": "0"}, 500)])
+@pytest.mark.parametrize("env,cycles", [({}, 2000), ({"AMD_SERIALIZE_KERNEL": "3"}, 500), ({"HSA_ENABLE_SDMA": "0"}, 500),
+                                        ({"SIPMASK_STRESS_POISON": "1"}, 500)])
 def test_pipelined_plan_stress(env, cycles):
     """VERDICT r5 #3 (an unexplained SIGABRT inside torch.cuda.synchronize() of a PipelinedPlan test on one box in round 5):
     2 000 submit(pack=True) / fetch cycles over three slots with hipGraph replay, batches and img_metas varying from step to
     step, every result held to the single plan's, the slot's stream queried after every submit -- in its own process
     (tests/_pipeline_stress_worker.py), once as shipped, once with every kernel serialised by the runtime
-    (AMD_SERIALIZE_KERNEL=3) and once with the SDMA engines off (blit-kernel copies).  A GPU memory fault or a runtime
-    assertion aborts the worker: the return code and its stderr are the finding."""
+    (AMD_SERIALIZE_KERNEL=3), once with the SDMA engines off (blit-kernel copies) and once with every uninitialised buffer of
+    the pipeline's plans poisoned (0x7f bytes: results must not depend on what an allocation held before).  A GPU memory
+    fault or a runtime assertion aborts the worker: the return code and its stderr are the finding."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import subprocess
