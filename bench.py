@@ -458,7 +458,9 @@ def run_inference(args, rank, world, dev):
     run_all = lambda: plan.run(img)
     if args.tower_only:      # the dominant kernel of the SAME plan the breakdown below times, alone and back to back
         eng.run(eng_img)
-        tower = [c for c in eng.convs if c.name.startswith("head.cls_convs") or c.name.startswith("head.tower")][0]
+        towers_ = [c for c in eng.convs if c.name.startswith("head.cls_convs") or c.name.startswith("head.tower")]
+        # (head_x3: the SECOND tower launch -- three half products on paired operands; the first reads the bf16 pyramid on two)
+        tower = towers_[1] if (args.precision == "head_x3" and len(towers_) > 1) else towers_[0]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
             tower()
@@ -471,6 +473,7 @@ def run_inference(args, rank, world, dev):
         print(json.dumps({"kernel": tower.name, "plan_batch": eng.batch, "patch_kernel": bool(getattr(tower, "patch", False)),
                           "launches": args.tower_only, "ms_per_launch": round(ms, 4),
                           "tflops": round(tower.flops / ms / 1e9, 1), "gflop": round(tower.flops / 1e9, 2),
+                          "mfma_tflops": round(getattr(tower, "mfma_flops", tower.flops) / ms / 1e9, 1), "mode": tower.mode,
                           "algorithmic_mb": round(tower.bytes / 1e6, 1)}))
         return None
 
@@ -689,14 +692,15 @@ def run_inference(args, rank, world, dev):
     # committed rocprofv3 summary of the same kernel/shape (profiles/), per launch
     traffic, traffic_src = None, None
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[0-9]_pmc_tower_conv.json")))     # the latest round's passes
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[0-9]_pmc_tower_conv%s.json" % ("_head_x3" if x3 else ""))))     # the latest round's passes
     pmc_file = cands[-1] if cands else ""
     pmc = json.load(open(pmc_file)) if pmc_file else None
-    if pmc and pmc.get("plan_batch") == eng.batch and pmc.get("launch") == towers[0].name and args.precision == "bf16":
-        # (the PMC passes were taken on the bf16 plan's launch; the split-precision launch reads three 16-bit planes of
-        # every input channel and writes f32 -- its traffic was not collected: null)
+    if pmc and pmc.get("plan_batch") == eng.batch and pmc.get("launch") in [c.name for c in towers] and args.precision in ("bf16", "head_x3"):
+        # (bf16: the PMC passes ran on the plan's first tower launch; head_x3: on the SECOND -- paired operands, three half
+        # products -- whose operand bytes differ from the first's two-term launch: the figure is that launch's)
         traffic = round(pmc["hbm_bytes_per_launch"] / 1e6, 1)
-        traffic_src = "profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), MB per launch" % os.path.basename(pmc_file)
+        traffic_src = "profiles/%s (launch %s; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), MB per launch" % (
+            os.path.basename(pmc_file), pmc.get("launch"))
     if args.breakdown and rank == 0:
         with open(args.breakdown, "w") as f:
             f.write("# per-step HIP event times (ms), eager launches, plan batch %d, mean of %d\n" % (eng.batch, reps))
