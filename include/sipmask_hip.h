@@ -134,11 +134,13 @@ typedef struct {
    * tiles); 128 = 128-cout x 256-position tiles (cout_pad % 128 == 0) for convs whose position count cannot fill the chip
    * with 256-cout tiles -- the 3x3 convs of ResNet layer3 / layer4 (resnet.py:84-239: 4 200 / 1 050 positions per image). */
   int32_t patch_cout_tile;
-  /* sm_conv3x3_patch with SM_CONV_F16 (round 6): 1 = PAIRED split operands.  x rows hold C values as C/16 groups of
-   * [hi 16 | lo 16] binary16 (in_cstride = cin = 2 * C; sm_split_pairs_f16 / sm_groupnorm_apply_x3p write that layout) and
-   * the weights are [cout_pad][C/16][9 taps][hi 16 | lo 16]; per 16 channels the kernel issues the three products
-   * w_hi*x_hi + w_hi*x_lo + w_lo*x_hi on fragments it reads once -- the same sum as the K-concatenated form ([hi | lo | hi]
-   * against [hi | hi | lo], x3_pairs = 0) with a third less operand traffic.  256-cout tiles, f32 output. */
+  /* With SM_CONV_F16 (round 6): 1 = PAIRED split operands.  x rows hold C values as C/16 groups of [hi 16 | lo 16] binary16
+   * (in_cstride = cin = 2 * C; sm_split_pairs_f16 / sm_groupnorm_apply_x3p / sm_upsample_sum2(out_x3 = 2) write that layout)
+   * and the weights carry the same pairing along their input-channel axis (sm_conv3x3_patch: [cout_pad][C/16][9 taps][hi 16 |
+   * lo 16]; sm_conv2d: [cout_pad][K = (kh, kw, 2 * C)]; sm_conv3x3_smallco: its fragment order over 2 * C channels); per 16
+   * channels the kernels issue the three products w_hi*x_hi + w_hi*x_lo + w_lo*x_hi on fragments they read once -- the same
+   * sum as the K-concatenated form ([hi | lo | hi] against [hi | hi | lo], x3_pairs = 0) with a third less operand traffic.
+   * sm_conv3x3_patch (256-cout tiles), sm_conv3x3_smallco, sm_conv2d on its 32-wide-K kernel (K <= 1152); f32 output. */
   int32_t x3_pairs;
 } sm_conv_desc;
 
@@ -392,7 +394,8 @@ int sm_upsample_bilinear_x3(const float* x, void* y, int batch, int h, int w, in
  * 4; a1 on h0/2 x w0/2, a2 on h0/4 x w0/4, all rows of c channels).  sip_mask_lat0 by linearity: the 1x1 conv over
  * [l0 | up2(l1) | up4(l2)] (sipmask_head.py:275-283) = W0.l0 + up2(W1.l1) + up4(W2.l2), so the three products run at their own
  * resolutions and this adds the coarse ones.  is_f32 = 0: a1, a2, out bf16, a0 NULL (out is the RES_ADD residual of the l0
- * conv); is_f32 = 1: a0 (or NULL), a1, a2 f32, out f32 rows or -- out_x3 -- the split layout of sm_split3_f16 (3*c channels). */
+ * conv); is_f32 = 1: a0 (or NULL), a1, a2 f32, out f32 rows or -- out_x3 = 1 -- the split layout of sm_split3_f16 (3*c channels)
+ * or -- out_x3 = 2, round 6 -- the paired layout of sm_split_pairs_f16 (2*c per row, c % 16 == 0). */
 int sm_upsample_sum2(const float* a0, const void* a1, const void* a2, int is_f32, int batch, int h0, int w0, int c, int relu,
                      int out_x3, void* out, sm_stream_t stream);
 int sm_gn_stats_f32_fix(const float* x, int64_t* stats, int batch, int nlev, const int32_t* hw, const int64_t* row0,

@@ -56,7 +56,10 @@ __device__ __forceinline__ void wait_vm() {
 // F16: the operands are IEEE binary16 (SM_CONV_F16: the x3 head plan's split tensors [hi | lo | hi] x [hi | hi | lo] -- the
 // kernel never interprets the 16-bit payloads it moves, only the MFMA differs)
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-template <bool F16>
+// PAIRS (F16 only, round 6; sm_conv_desc.x3_pairs): a 32-element slice is 16 channels as [hi 16 | lo 16], so the two fragment
+// halves of a tap are (x_hi, x_lo) / (w_hi, w_lo) and the tap issues w_hi*x_hi + w_hi*x_lo + w_lo*x_hi -- two thirds of the
+// slices, patch bytes and weight loads of the K-concatenated operand [hi | lo | hi] x [hi | hi | lo] for the same products
+template <bool F16, bool PAIRS = false>
 __global__ __launch_bounds__(64, 2) void conv3x3_smallco_kernel(const SmallCoArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // SC_RING x SC_BUF
   typedef __attribute__((address_space(3))) void lds_void;
@@ -134,6 +137,21 @@ __global__ __launch_bounds__(64, 2) void conv3x3_smallco_kernel(const SmallCoArg
     const unsigned bb = (unsigned)((sl % SC_RING) * SC_BUF);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
+      if constexpr (PAIRS) {
+        bf16x8 xh[SC_TR], xl[SC_TR];
+#pragma unroll
+        for (int tp = 0; tp < SC_TR; ++tp) {
+          xh[tp] = *reinterpret_cast<const bf16x8*>(smem + bb + baddr[tp][tap]);
+          xl[tp] = *reinterpret_cast<const bf16x8*>(smem + bb + (baddr[tp][tap] ^ 32u));
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int tp = 0; tp < SC_TR; ++tp)
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wcur[tap * 2 + (term == 2 ? 1 : 0)]),
+                                                             __builtin_bit_cast(half8, term == 1 ? xl[tp] : xh[tp]), acc[tp], 0, 0, 0);
+        continue;
+      }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 xf[SC_TR];
@@ -227,6 +245,7 @@ bool smallco_ok(const sm_conv_desc* d) {
   if (d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST | SM_CONV_IN_RELU | SM_CONV_OUT_X3)) return false;
   if ((d->flags & SM_CONV_F16) && !(d->flags & SM_CONV_OUT_F32)) return false;
   if (d->ngroups > 1 || d->w_batch_stride != 0 || d->w_level_stride != 0 || d->deform_groups > 0) return false;
+  if (d->x3_pairs != 0 && (d->x3_pairs != 1 || !(d->flags & SM_CONV_F16))) return false;     // paired operands: binary16 only
   const int calign = (d->flags & SM_CONV_OUT_F32) ? 4 : 8;        // 16-byte stores
   if (d->out_cstride % calign != 0 || d->out_coff % calign != 0 || d->out_coff + d->cout > d->out_cstride) return false;
   for (int l = 0; l < d->nlev; ++l)
@@ -241,7 +260,6 @@ extern "C" int sm_conv3x3_smallco_supported(const sm_conv_desc* d) { return smal
 extern "C" int sm_conv3x3_smallco(const sm_conv_desc* d, const void* x, const void* w_frag, const float* bias, void* y,
                                   sm_stream_t stream) {
   if (!x || !w_frag || !y) return SM_ERR_BAD_ARG;
-  if (d && d->x3_pairs != 0) return SM_ERR_UNSUPPORTED;   // paired split operands: sm_conv3x3_patch only
   if (!smallco_ok(d)) return SM_ERR_UNSUPPORTED;
   SmallCoArgs a;
   a.x = (const uint16_t*)x;
@@ -274,7 +292,9 @@ extern "C" int sm_conv3x3_smallco(const sm_conv_desc* d, const void* x, const vo
   a.flags = d->flags;
   a.scale_nch = d->scale_nch;
   a.acc_scale = (d->acc_scale == 0.f) ? 1.f : d->acc_scale;
-  if (d->flags & SM_CONV_F16)
+  if ((d->flags & SM_CONV_F16) && d->x3_pairs)
+    hipLaunchKernelGGL((conv3x3_smallco_kernel<true, true>), dim3((unsigned)nt), dim3(64), SC_RING * SC_BUF, sm_hip_stream(stream), a);
+  else if (d->flags & SM_CONV_F16)
     hipLaunchKernelGGL(conv3x3_smallco_kernel<true>, dim3((unsigned)nt), dim3(64), SC_RING * SC_BUF, sm_hip_stream(stream), a);
   else
     hipLaunchKernelGGL(conv3x3_smallco_kernel<false>, dim3((unsigned)nt), dim3(64), SC_RING * SC_BUF, sm_hip_stream(stream), a);

@@ -76,6 +76,7 @@ struct ConvKArgs {
   int ksplit;
   float* part;
   long long part_rows;   // rows of one partial slab
+  int x3_pairs;          // binary16 build, 32-wide K steps: a K step is one group [hi 16 | lo 16] (sm_conv_desc.x3_pairs)
 };
 
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
@@ -1152,7 +1153,10 @@ __global__ __launch_bounds__(64 * WCO * WPOS * (1 + PROD), (WCO * WPOS == 4) ? 2
 // s_barrier per K step instead of __syncthreads (which drains the DMA queue).  Meant for the launches whose blocks are all
 // resident at once (the 1x1 convs of layer3: 16 800 positions, 8 / 32 K steps); bit-identical, -14..-18 % on those two launches
 // alone, -0.5 % (3 stages) / -3 % (4) on the pipelined step: profiles/r05_conv_ring_ab.txt, DESIGN section 6.
-template <int WCO, int WPOS, int TCO, int TPOS, int MINB = 4, int OPT = 0, bool RESPF = false, int NST = 2>
+// X3P (binary16 build, round 6): paired split operands -- a K step is one [hi 16 | lo 16] group of 16 channels and issues the
+// three cross products on the fragments it reads once (sm_conv_desc.x3_pairs).  A template parameter, not a runtime branch:
+// two loop bodies that both update the accumulators made hipcc spill 238 registers in the 128 x 128 tile.
+template <int WCO, int WPOS, int TCO, int TPOS, int MINB = 4, int OPT = 0, bool RESPF = false, int NST = 2, bool X3P = false>
 __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a) {
   constexpr int BCO = WCO * TCO * 32;
   constexpr int BPOS = WPOS * TPOS * 32;
@@ -1279,6 +1283,37 @@ __global__ __launch_bounds__(256, MINB) void conv_dma32_kernel(const ConvKArgs a
   const int xrow_off = BCO * 64 + (wpos * TPOS * 32 + l31) * 64;
   auto compute = [&](int buf) {
     const unsigned char* S = smem + buf * STAGE;
+    if constexpr (X3P) {     // hi halves in slots 0-1 of the 64-byte row, lo halves in slots 2-3
+      const int s0 = (khalf ^ rsw) * 16, s1 = ((2 + khalf) ^ rsw) * 16;
+      frag8 wh[TCO], xh[TPOS];
+#pragma unroll
+      for (int t = 0; t < TCO; ++t) wh[t] = *reinterpret_cast<const frag8*>(S + wrow_off + t * 32 * 64 + s0);
+#pragma unroll
+      for (int t = 0; t < TPOS; ++t) xh[t] = *reinterpret_cast<const frag8*>(S + xrow_off + t * 32 * 64 + s0);
+      {
+        frag8 xl[TPOS];
+#pragma unroll
+        for (int t = 0; t < TPOS; ++t) xl[t] = *reinterpret_cast<const frag8*>(S + xrow_off + t * 32 * 64 + s1);
+#pragma unroll
+        for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+          for (int tp = 0; tp < TPOS; ++tp) acc[tc][tp] = SM_MFMA_32x32x16(wh[tc], xh[tp], acc[tc][tp]);
+#pragma unroll
+        for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+          for (int tp = 0; tp < TPOS; ++tp) acc[tc][tp] = SM_MFMA_32x32x16(wh[tc], xl[tp], acc[tc][tp]);
+      }
+      {
+        frag8 wl[TCO];
+#pragma unroll
+        for (int t = 0; t < TCO; ++t) wl[t] = *reinterpret_cast<const frag8*>(S + wrow_off + t * 32 * 64 + s1);
+#pragma unroll
+        for (int tc = 0; tc < TCO; ++tc)
+#pragma unroll
+          for (int tp = 0; tp < TPOS; ++tp) acc[tc][tp] = SM_MFMA_32x32x16(wl[tc], xh[tp], acc[tc][tp]);
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int slot = ((kk * 2 + khalf) ^ rsw) * 16;
@@ -1813,7 +1848,7 @@ int plan_conv(const sm_conv_desc* d, bool deform, bool with_gn, sm_conv_plan* p,
   const long long nblk = t * (d->cout_pad / bco) * ngroups;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SM_ERR_BAD_SHAPE;
   if (d->w_level_stride != 0 || d->bias_level_stride != 0) return SM_ERR_UNSUPPORTED;   // per-level weights: sm_conv3x3_patch only
-  if (d->x3_pairs != 0) return SM_ERR_UNSUPPORTED;                                      // paired split operands: sm_conv3x3_patch only
+  if (d->x3_pairs != 0 && !(d->flags & SM_CONV_F16)) return SM_ERR_UNSUPPORTED;         // paired split operands: binary16 only
   // groups exist in the 64-wide-K LDS-DMA kernel only (its tile decode carries the group offsets)
   if (ngroups > 1 && (!dma || k32 || ws || (d->flags & SM_CONV_RES_NEAREST) || d->w_batch_stride != 0)) return SM_ERR_UNSUPPORTED;
   // K-loop variant.  64-wide K, 128/64-cout tiles of the tile-128 family: flat loader + peeled K loop + pipelined
@@ -1874,6 +1909,12 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   if (DEFORM || !plan.lds_dma || !(d->flags & (SM_CONV_OUT_F32 | SM_CONV_OUT_X3)) ||
       (d->flags & (SM_CONV_RES_ADD | SM_CONV_RES_NEAREST)))
     return SM_ERR_UNSUPPORTED;
+  if (d->x3_pairs != 0) {
+    // paired split operands on this kernel family: the 32-wide-K loop without the experiments build's pipelined variant (one
+    // K step = one [hi 16 | lo 16] group; sip_mask_lat0's 1x1 convs), plain launches
+    if (d->x3_pairs != 1 || plan.k_step != 32 || plan.k_loop != 0 || (d->cin & 31) || d->ngroups > 1 || plan.split_k > 1)
+      return SM_ERR_UNSUPPORTED;
+  }
   if (d->flags & SM_CONV_OUT_X3) {                  // written by the register epilogue only (8 couts per lane, 16-byte stores)
     if ((d->flags & SM_CONV_DBG_LDS_EPILOGUE) || (d->cout & 7) || (d->out_cstride % 24) || (d->out_coff & 7) || gn_stats ||
         d->out_cstride < 3 * d->cout || plan.split_k > 1)
@@ -1958,6 +1999,7 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   a.ksplit = S;
   a.part = (float*)workspace;
   a.part_rows = (long long)d->batch * d->out_h[0] * d->out_w[0];
+  a.x3_pairs = d->x3_pairs;
   a.ngroups = d->ngroups > 1 ? d->ngroups : 1;
   a.tpg = t * a.ntn;
   a.x_grows = d->x_group_rows;
@@ -2013,6 +2055,18 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
     else if (o3 && bco == 32) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 1, 4, 3>));
     else if (bco == 128 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 4, 2>));
     else
+#endif
+#ifdef SM_OPERAND_F16
+    if (d->x3_pairs) {
+      if (bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2, 4, 0, false, 2, true>));
+      else if (bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1, 4, 0, false, 2, true>));
+      else if (bco == 64 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 2, 4, 0, false, 2, true>));
+      else if (bco == 64 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<1, 4, 2, 1, 4, 0, false, 2, true>));
+      else if (bco == 64 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 1, 1, 4, 0, false, 2, true>));
+      else if (bco == 32 && bpos == 256) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 2, 4, 0, false, 2, true>));
+      else if (bco == 32) SM_LAUNCH((conv_dma32_kernel<1, 4, 1, 1, 4, 0, false, 2, true>));
+      else return SM_ERR_UNSUPPORTED;
+    } else
 #endif
     if (bco == 128 && bpos == 128) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 2>));
     else if (bco == 128 && bpos == 64) SM_LAUNCH((conv_dma32_kernel<2, 2, 2, 1>));

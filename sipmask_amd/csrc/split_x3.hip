@@ -367,7 +367,8 @@ extern "C" int sm_split_pairs_f16(const void* x, int x_is_f32, int64_t rows, int
 // kernel adds the two coarse ones onto the fine grid:   out = [relu](a0 + up2(a1) + up4(a2))
 //   F32 = false: a1, a2 bf16 rows, a0 absent, out bf16 rows (the residual of the l0 conv: bias / ReLU in its epilogue);
 //   F32 = true : a0 (optional), a1, a2 f32 rows, out f32 rows or the split layout [hi | lo | hi] of sm_split3_f16.
-template <bool F32, bool X3OUT>
+//   X3OUT = 2 (round 6): the paired layout [hi 16 | lo 16] per 16 channels (sm_split_pairs_f16), 2 * C per row.
+template <bool F32, int X3OUT>
 __global__ __launch_bounds__(256) void upsample_sum2_kernel(const void* __restrict__ a0v, const void* __restrict__ a1v,
                                                             const void* __restrict__ a2v, void* __restrict__ outv, int B, int H0,
                                                             int W0, int C, int relu) {
@@ -423,7 +424,13 @@ __global__ __launch_bounds__(256) void upsample_sum2_kernel(const void* __restri
 #pragma unroll
       for (int e = 0; e < 8; ++e) r[e] = fmaxf(r[e], 0.f);
     }
-    if constexpr (X3OUT) {
+    if constexpr (X3OUT == 2) {
+      half8 hi, lo;
+      split8(r, hi, lo);
+      uint16_t* o = (uint16_t*)outv + orow * (2ll * C) + (cc >> 1) * 32 + (cc & 1) * 8;
+      *reinterpret_cast<half8*>(o) = hi;
+      *reinterpret_cast<half8*>(o + 16) = lo;
+    } else if constexpr (X3OUT == 1) {
       half8 hi, lo;
       split8(r, hi, lo);
       uint16_t* o = (uint16_t*)outv + orow * (3ll * C) + cc * 8;
@@ -449,12 +456,15 @@ extern "C" int sm_upsample_sum2(const float* a0, const void* a1, const void* a2,
   long long g = (n + 255) / 256;
   if (g > 256 * 32) g = 256 * 32;
   hipStream_t s = sm_hip_stream(stream);
+  if (out_x3 == 2 && (c & 15)) return SM_ERR_BAD_SHAPE;
   if (!is_f32)
-    hipLaunchKernelGGL((upsample_sum2_kernel<false, false>), dim3((unsigned)g), dim3(256), 0, s, nullptr, a1, a2, out, batch, h0, w0, c, relu);
+    hipLaunchKernelGGL((upsample_sum2_kernel<false, 0>), dim3((unsigned)g), dim3(256), 0, s, nullptr, a1, a2, out, batch, h0, w0, c, relu);
+  else if (out_x3 == 2)
+    hipLaunchKernelGGL((upsample_sum2_kernel<true, 2>), dim3((unsigned)g), dim3(256), 0, s, a0, a1, a2, out, batch, h0, w0, c, relu);
   else if (out_x3)
-    hipLaunchKernelGGL((upsample_sum2_kernel<true, true>), dim3((unsigned)g), dim3(256), 0, s, a0, a1, a2, out, batch, h0, w0, c, relu);
+    hipLaunchKernelGGL((upsample_sum2_kernel<true, 1>), dim3((unsigned)g), dim3(256), 0, s, a0, a1, a2, out, batch, h0, w0, c, relu);
   else
-    hipLaunchKernelGGL((upsample_sum2_kernel<true, false>), dim3((unsigned)g), dim3(256), 0, s, a0, a1, a2, out, batch, h0, w0, c, relu);
+    hipLaunchKernelGGL((upsample_sum2_kernel<true, 0>), dim3((unsigned)g), dim3(256), 0, s, a0, a1, a2, out, batch, h0, w0, c, relu);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -135,16 +135,17 @@ class _Conv:
             else:
                 self.w, co_pad = H.prep_conv_weight_f32(w.to(dev), cin)
         elif self.x3p:
-            if (offset is not None or residual is not None or cin_pad is not None or ci % 32 != 0 or k != 3 or stride != 1
-                    or pad != 1):
-                raise NotImplementedError("x3p convs: plain 3x3 / stride 1 / pad 1 convolutions over 32-aligned channel counts")
+            if offset is not None or residual is not None or cin_pad is not None or ci % 16 != 0 or stride != 1:
+                raise NotImplementedError("x3p convs: plain stride-1 convolutions over 16-aligned channel counts")
             cin = 2 * ci
             assert in_cstride == cin, "x3p convs read the paired split tensor (2 * cin binary16 per row)"
             self.x3_scale = getattr(self, "_x3_scale", None) or H.x3_weight_scale([w])
-            self.w, co_pad = H.prep_conv_weight_patch_x3p(w.to(dev), self.x3_scale)
+            # three kernels take paired operands: the patch-resident 3x3 kernel (256-cout tiles), the small-cout 3x3 kernel and
+            # the implicit-GEMM kernel's 32-wide-K loop (1x1 convs); the weights below are the last one's, replaced further down
+            self.w, co_pad = H.prep_conv_weight_x3p(w.to(dev), self.x3_scale)
             flags |= _lib.SM_CONV_F16 | SM_CONV_OUT_F32
             acc_scale = 1.0 / self.x3_scale
-            self._patch_force = True
+            self._patch_force = k == 3 and pad == 1 and co > 32
         elif self.x3:
             if offset is not None or residual is not None or cin_pad is not None or ci % 8 != 0:
                 raise NotImplementedError("x3 convs: plain convolutions over 8-aligned channel counts")
@@ -173,18 +174,19 @@ class _Conv:
         # 3x3 convs with a handful of output channels on the bf16 plan (sip_mask_lat 512 -> 32, fcos_reg + centerness 256 -> 8):
         # their own kernel (round 4, csrc/conv3x3_smallco.hip: one wave per 2 x 32-position tile, weights straight from L2)
         self.smallco = False
-        if (not self.f32 and not self.x3p and offset is None and residual is None and _SMALLCO_CONV and k == 3 and stride == 1
-                and pad == 1 and co <= 32 and co % 8 == 0 and ci % 32 == 0 and cin == (3 * ci if self.x3 else ci) and self.mode != "x2"
+        if (not self.f32 and offset is None and residual is None and _SMALLCO_CONV and k == 3 and stride == 1
+                and pad == 1 and co <= 32 and co % 8 == 0 and (ci % 32 == 0 or self.x3p)
+                and cin == (2 * ci if self.x3p else (3 * ci if self.x3 else ci)) and self.mode != "x2"
                 and getattr(self, "_patch_groups", 1) == 1 and not (self.x3 and (flags & _lib.SM_CONV_OUT_X3))):
             ds = H.make_conv_desc(batch, in_sizes, out_sizes, in_row0, out_row0, cin, co, 32, k, stride, pad, in_cstride,
                                   out_cstride, out_coff, flags, 1, res_cstride, res_sizes, res_row0, scale_nch, level_scale,
-                                  deform_groups, acc_scale=acc_scale)
+                                  deform_groups, acc_scale=acc_scale, x3_pairs=int(self.x3p))
             if H.conv3x3_smallco_supported(ds):
                 self.smallco = True
-                self.w = H.prep_conv_weight_smallco(w.to(dev), x3_scale=self.x3_scale if self.x3 else None)
+                self.w = H.prep_conv_weight_smallco(w.to(dev), x3_scale=self.x3_scale if self.x3 else None, pairs=self.x3p)
                 self.desc = ds
         if (not self.smallco and not self.f32 and offset is None and residual is None and _PATCH_CONV and k == 3 and stride == 1
-                and pad == 1 and (ci % 64 == 0 or self.x3p) and (cin == ci or self.x3)):
+                and pad == 1 and (ci % 64 == 0 or (self.x3p and ci % 32 == 0)) and (cin == ci or self.x3)):
             # cout tile of the patch kernel: 256, or 32 for the convs with a handful of output channels (round 4: sip_mask_lat
             # 512 -> 32 and fcos_reg + centerness 256 -> 8 spent 0.10 / 0.065 ms per B=4 launch on the implicit-GEMM kernel
             # re-reading their INPUT nine times; the grouped / per-level launches keep the 256 tile)
@@ -214,8 +216,8 @@ class _Conv:
                                  H.prep_conv_weight_patch_x3(w.to(dev), self.x3_scale, pad_co, self.xterms) if self.x3
                                  else H.prep_conv_weight_patch(w.to(dev), pad_co))
                     self.desc = dp
-        if self.x3p and not self.patch:
-            raise NotImplementedError("x3p conv %s: the patch-resident kernel does not take this shape" % name)
+        if self.x3p and k == 3 and not (self.patch or self.smallco):
+            raise NotImplementedError("x3p conv %s: neither 3x3 kernel with paired operands takes this shape" % name)
         # 128-cout x 256-position patch tiles (round 4) for single-level 3x3 convs whose position count gives too few 256-cout
         # tiles to be worth a launch of them: ResNet layer3 / layer4 conv2 (4 200 / 1 050 positions per image: 66 / 17 position
         # tiles at B=4, x 2 / 4 cout tiles).  The implicit-GEMM kernel re-reads their input nine times through L2 -> LDS and is
@@ -984,8 +986,8 @@ class SipMaskEngine:
                 last_cls = g == 0 and last_depth                  # feeds FeatureAlign's f32 deformable conv only
                 last_reg = g == 1 and i == nreg - 1               # feeds reg_ctr, the mask branch ([hi | lo | hi]) and f32 consumers
                 o_next = o_split = None
-                if last_reg:
-                    o_split = torch.empty(rows, 768, dtype=F16, device=dev)
+                if last_reg:       # read by reg_ctr and sip_mask_lat0's convs: the plan's operand layout (paired, or [hi | lo | hi])
+                    o_split = torch.empty(rows, tw, dtype=F16, device=dev)
                 elif not last_cls:
                     o_next = nxt[g * rows:(g + 1) * rows] if nxt is not None else torch.empty(rows, tw, dtype=F16, device=dev)
                 if last_cls:
@@ -995,7 +997,7 @@ class SipMaskEngine:
                         self._add("gn:" + n, (lambda yv=yv, gam=gam, bet=bet, st=st:
                                               H.groupnorm_apply_x3(yv, gam, bet, st, lv, 256, 32, 1e-5, True, y_f32=yv)))
                 elif pairs:
-                    gn_or_split(n, yv, st, n + ".gn", last_reg, o_next, o_split)
+                    gn_or_split(n, yv, st, n + ".gn", last_reg, o_split if last_reg else o_next, None)
                 else:
                     gn_or_split(n, yv, st, n + ".gn", last_reg, None, o_split if last_reg else o_next)
                 if last_reg:
@@ -1012,9 +1014,9 @@ class SipMaskEngine:
                 c.gn_stats = self.gn_stats
             last = i == nreg - 1
             o_next = None if last else torch.empty(rows, tw, dtype=F16, device=dev)
-            o_split = torch.empty(rows, 768, dtype=F16, device=dev) if last else None
+            o_split = torch.empty(rows, tw, dtype=F16, device=dev) if last else None     # reg_ctr's / sip_mask_lat0's operand
             if pairs:
-                gn_or_split(name, y, self.gn_stats, name + ".gn", last, o_next, o_split)
+                gn_or_split(name, y, self.gn_stats, name + ".gn", last, o_split if last else o_next, None)
             else:
                 gn_or_split(name, y, self.gn_stats, name + ".gn", last, None, o_split if last else o_next)
             xr = o_next
@@ -1026,10 +1028,15 @@ class SipMaskEngine:
         n0 = B * h0 * w0
         # [l0 | up2(l1) | up4(l2)] written straight as the split operand of sip_mask_lat0 (768 channels -> 3 x 768 halves),
         # and that 1x1 conv writes ITS output as the split operand of sip_mask_lat (SM_CONV_OUT_X3): no f32 round trips
-        lat0_x3 = torch.empty(n0, 3 * 512, dtype=F16, device=dev)
         w_l0 = sd[h + "sip_mask_lat0.weight"]
         exact_grids = all(sizes[l][0] * 2 ** l == h0 and sizes[l][1] * 2 ** l == w0 for l in range(3)) and h0 % 4 == 0 and w0 % 4 == 0
         self.lat0_by_linearity = _LAT0_LINEAR and tuple(w_l0.shape) == (512, 768, 1, 1) and exact_grids
+        # sip_mask_lat's operand: paired like the towers' when the branch runs by linearity (round 6: the 1x1 convs on the
+        # implicit-GEMM kernel's paired 32-wide-K loop, sm_upsample_sum2 writing pairs, sip_mask_lat on the small-cout kernel's
+        # paired instantiation); the concatenating fallback keeps [hi | lo | hi] end to end
+        lat_pairs = pairs and self.lat0_by_linearity
+        lw, lmode = (2, "x3p") if lat_pairs else (3, "x3")
+        lat0_x3 = torch.empty(n0, lw * 512, dtype=F16, device=dev)
         if self.lat0_by_linearity:
             # sip_mask_lat0 by linearity (see _build_head): three x3 convs on the levels' split operands (reg_x3 holds all
             # levels), f32 outputs; sm_upsample_sum2 adds them on the fine grid in f32, applies the ReLU and writes the split
@@ -1038,7 +1045,7 @@ class SipMaskEngine:
             for l in (1, 2, 0):
                 self._add_conv(_Conv(self, "head.sip_mask_lat0" + ("" if l == 0 else ".l%d" % l),
                                      w_l0[:, 256 * l:256 * (l + 1)].contiguous(), sd[h + "sip_mask_lat0.bias"] if l == 0 else None,
-                                     B, [sizes[l]], [row0[l]], reg_x3, 768, 1, 0, outs[l], [0], 512, mode="x3"), 2)
+                                     B, [sizes[l]], [row0[l]], reg_x3, tw, 1, 0, outs[l], [0], 512, mode=tmode), 2)
             self._add("up:sum2", lambda: H.upsample_sum2(outs[0], outs[1], outs[2], lat0_x3, B, h0, w0, 512, relu=True), 2)
         else:
             cat_x3 = torch.empty(n0, 3 * 768, dtype=F16, device=dev)
@@ -1052,7 +1059,7 @@ class SipMaskEngine:
                                  flags=SM_CONV_RELU | _lib.SM_CONV_OUT_X3, mode="x3"), 2)
         self.basis_lo = torch.empty(n0, 32, dtype=f32, device=dev)
         self._add_conv(_Conv(self, "head.sip_mask_lat", sd[h + "sip_mask_lat.weight"], sd[h + "sip_mask_lat.bias"], B,
-                             [(h0, w0)], [0], lat0_x3, 3 * 512, 1, 1, self.basis_lo, [0], 32, flags=SM_CONV_RELU, mode="x3"), 2)
+                             [(h0, w0)], [0], lat0_x3, lw * 512, 1, 1, self.basis_lo, [0], 32, flags=SM_CONV_RELU, mode=lmode), 2)
         self.hm, self.wm = 4 * h0, 4 * w0
         self._basis = None
         self._basis_h0w0 = (h0, w0)
@@ -1064,9 +1071,9 @@ class SipMaskEngine:
         b_rc = torch.cat([sd[h + "fcos_reg.bias"], sd[h + "fcos_centerness.bias"], torch.zeros_like(sd[h + "fcos_reg.bias"][:3])], 0)
         scales = [float(sd[h + "scales.%d.scale" % i]) for i in range(len(lv))]
         self.reg_out = torch.zeros(rows, 8, dtype=f32, device=dev)
-        c = self._add_conv(_Conv(self, "head.reg_ctr", w_rc, b_rc, B, sizes, row0, reg_x3, 768, 1, 1, self.reg_out, row0, 8,
+        c = self._add_conv(_Conv(self, "head.reg_ctr", w_rc, b_rc, B, sizes, row0, reg_x3, tw, 1, 1, self.reg_out, row0, 8,
                                  flags=(_lib.SM_CONV_RELU_NCH if self.benchmark else 0), scale_nch=4, level_scale=scales,
-                                 mode="x3"))
+                                 mode=tmode))
         c.flops, c.mfma_flops = c.flops * 5 / 8, c.mfma_flops * 5 / 8      # the 3 zero channels are not work (FLOP accounting)
         # FeatureAlign: offsets (f32 1x1 of the box prediction) -> deformable conv in exact f32 -> GN + ReLU -> split
         self.w_off = sd[h + "feat_align.conv_offset.weight"].float().view(72, 4).to(dev).contiguous()

@@ -74,6 +74,32 @@ def _x3_halves(w, scale, terms=3):
     return torch.cat([hi, hi, lo] if terms == 3 else [hi, lo], 1)      # [co, terms*ci, kh, kw] binary16 values
 
 
+def _x3_pairs_channels(w, scale):
+    """w * scale as binary16 halves PAIRED along the input-channel axis: [co, 2*ci, kh, kw] with, per 16 channels, the 16 hi
+    halves followed by the 16 lo halves -- the weight side of sm_conv_desc.x3_pairs (activations: sm_split_pairs_f16)"""
+    co, ci, kh, kw = w.shape
+    assert ci % 16 == 0
+    ws = w.float() * scale
+    hi = ws.to(F16)
+    lo = (ws - hi.float()).to(F16)
+    g = lambda t: t.reshape(co, ci // 16, 1, 16, kh, kw)
+    return torch.cat([g(hi), g(lo)], 2).reshape(co, 2 * ci, kh, kw)
+
+
+def prep_conv_weight_x3p(w, scale):
+    """[co,ci,kh,kw] float -> binary16 [cout_pad][Kp], K order (kh, kw, 2*ci paired) for sm_conv2d with SM_CONV_F16 and
+    sm_conv_desc.x3_pairs (its 32-wide-K kernel: one K step = one [hi 16 | lo 16] group)"""
+    w2 = _x3_pairs_channels(w, scale)
+    co, ci2, kh, kw = w2.shape
+    tile = cout_tile(co)
+    co_pad = (co + tile - 1) // tile * tile
+    k = kh * kw * ci2
+    kp = (k + 63) // 64 * 64
+    out = torch.zeros(co_pad, kp, dtype=F16, device=w.device)
+    out[:co, :k] = w2.permute(0, 2, 3, 1).reshape(co, k)
+    return out.contiguous(), co_pad
+
+
 def prep_conv_weight_x3(w, scale, terms=3):
     """[co,ci,kh,kw] float -> binary16 [cout_pad][Kp], K order (kh,kw,terms*ci) for sm_conv2d with SM_CONV_F16"""
     w3 = _x3_halves(w, scale, terms)
@@ -226,10 +252,11 @@ def upsample_sum2(a0, a1, a2, out, batch, h0, w0, c, relu=False):
     lib = _lib.load()
     _lib.require_cuda(a1, a2, out)
     is_f32 = a1.dtype == torch.float32
-    out_x3 = out.dtype == torch.float16
+    # binary16 out: [hi | lo | hi] (3 * c columns) or the paired layout (2 * c columns, sm_split_pairs_f16)
+    out_x3 = 0 if out.dtype != torch.float16 else (2 if out.shape[1] == 2 * c else 1)
     assert a1.dtype == a2.dtype and (a0 is None or a0.dtype == torch.float32)
     assert a1.shape == (batch * (h0 // 2) * (w0 // 2), c) and a2.shape == (batch * (h0 // 4) * (w0 // 4), c)
-    assert out.shape == (batch * h0 * w0, 3 * c if out_x3 else c) and out.is_contiguous()
+    assert out.shape == (batch * h0 * w0, (c, 3 * c, 2 * c)[out_x3]) and out.is_contiguous()
     _lib.check(lib.sm_upsample_sum2(_lib.ptr(a0), _lib.ptr(a1), _lib.ptr(a2), int(is_f32), batch, h0, w0, c, int(relu),
                                     int(out_x3), _lib.ptr(out), _lib.stream_ptr()), "sm_upsample_sum2")
     return out
@@ -343,13 +370,13 @@ def conv3x3_smallco_tiles(desc):
     return sum(desc.batch * -(-desc.in_h[l] // 2) * -(-desc.in_w[l] // 32) for l in range(desc.nlev))
 
 
-def prep_conv_weight_smallco(w, x3_scale=None):
+def prep_conv_weight_smallco(w, x3_scale=None, pairs=False):
     """[co <= 32, ci % 32 == 0, 3, 3] -> the A fragments of sm_conv3x3_smallco: bf16 [ci / 32][9][2][64][8] with
     lane = 32 * khalf + cout row (rows >= co zero) and channel = 32 * slice + 16 * half + 8 * khalf + e.
     x3_scale: the split-precision operand instead -- binary16 fragments of [w_hi | w_hi | w_lo] * scale over 3 * ci channels
     (SM_CONV_F16; pairs with activations laid out [hi | lo | hi])."""
-    if x3_scale is not None:
-        w = _x3_halves(w, x3_scale).float()
+    if x3_scale is not None:      # (pairs: 2 * ci channels, per 16 of them [hi 16 | lo 16] -- sm_conv_desc.x3_pairs)
+        w = (_x3_pairs_channels(w, x3_scale) if pairs else _x3_halves(w, x3_scale)).float()
     co, ci, kh, kw = w.shape
     if kh != 3 or kw != 3 or co > 32 or ci % 32 != 0:
         raise ValueError("sm_conv3x3_smallco: 3x3, cout <= 32, cin % 32 == 0")

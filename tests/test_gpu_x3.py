@@ -273,6 +273,75 @@ def test_x3_small_cout_and_1x1_convs():
         H.conv2d(d, x3, wq, None, None, y)
 
 
+def test_paired_operands_on_the_1x1_and_small_cout_kernels():
+    """Round 6: sm_conv_desc.x3_pairs beyond the patch kernel -- sm_conv2d's 32-wide-K kernel (sip_mask_lat0's 1x1 convs by
+    linearity, 256 -> 512), sm_conv3x3_smallco (sip_mask_lat 512 -> 32; fcos_reg + centerness 256 -> 5 with per-level Scale
+    over three levels) and sm_upsample_sum2 writing the paired layout: every conv within 4e-6 of float64 and within 2e-6 of the
+    K-concatenated launch it replaces; the up-sum's halves bit-equal to the [hi | lo | hi] output's."""
+    from sipmask_amd import hip_ops as H, _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(17)
+    B = 2
+    F16F = _lib.SM_CONV_F16 | _lib.SM_CONV_OUT_F32
+    for (ci, co, k, sizes, relu, nch) in [(256, 512, 1, [(25, 40)], False, 0), (512, 32, 3, [(25, 40)], True, 0),
+                                          (256, 5, 3, [(20, 33), (10, 17), (5, 9)], False, 4)]:
+        lv = H.Levels(B, sizes)
+        xs = [torch.randn(B, ci, h, w, generator=g).abs() for h, w in sizes]
+        wt = torch.randn(co, ci, k, k, generator=g) * (0.5 / (ci * k * k) ** 0.5)
+        bias = torch.randn(co, generator=g)
+        lscale = [1.0 + 0.25 * l for l in range(len(sizes))]
+        scale = H.x3_weight_scale([wt])
+        cs = (co + 7) // 8 * 8
+        outs = {}
+        for pairs in (False, True):
+            nk = 2 if pairs else 3
+            xq = torch.empty(lv.rows, nk * ci, dtype=torch.float16, device=dev)
+            (H.split_pairs_f16 if pairs else H.split3_f16)(_rows(xs).to(dev), xq)
+            y = torch.zeros(lv.rows, cs, dtype=torch.float32, device=dev)
+            kw = dict(flags=F16F | (_lib.SM_CONV_RELU if relu else 0), scale_nch=nch, level_scale=lscale, acc_scale=1.0 / scale,
+                      x3_pairs=int(pairs))
+            if k == 1:
+                wq, co_pad = (H.prep_conv_weight_x3p if pairs else H.prep_conv_weight_x3)(wt.to(dev), scale)
+                d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, nk * ci, co, co_pad, 1, 1, 0, nk * ci, cs, **kw)
+                assert H.conv_plan(d)["k_step"] == 32
+                H.conv2d(d, xq, wq, bias.to(dev), None, y)
+            else:
+                wpad = torch.cat([wt, torch.zeros(cs - co, ci, 3, 3)]) if cs != co else wt
+                bpad = torch.cat([bias, torch.zeros(cs - co)]) if cs != co else bias
+                wq = H.prep_conv_weight_smallco(wpad.to(dev), x3_scale=scale, pairs=pairs)
+                d = H.make_conv_desc(B, sizes, sizes, lv.row0, lv.row0, nk * ci, cs, 32, 3, 1, 1, nk * ci, cs, **kw)
+                assert H.conv3x3_smallco_supported(d)
+                H.conv3x3_smallco(d, xq, wq, bpad.to(dev), y)
+            torch.cuda.synchronize()
+            outs[pairs] = y
+        top = 0.0
+        for l, (h, w) in enumerate(sizes):
+            ref = F.conv2d(xs[l].double(), wt.double(), bias.double(), 1, k // 2)
+            if nch:
+                ref[:, :nch] *= lscale[l]
+            if relu:
+                ref = ref.clamp_min(0)
+            got = outs[True][lv.row0[l]:lv.row0[l] + B * h * w, :co].view(B, h, w, co).permute(0, 3, 1, 2).cpu().double()
+            top = max(top, float(ref.abs().max()))
+            err = float((got - ref).abs().max()) / float(ref.abs().max())
+            assert err < 4e-6, (ci, co, k, l, err)
+        assert float((outs[True] - outs[False]).abs().max()) <= 2e-6 * top, (ci, co, k)
+    # a bf16-plan descriptor (no SM_CONV_F16) must refuse the field
+    d.flags = _lib.SM_CONV_OUT_F32
+    assert not H.conv3x3_smallco_supported(d)
+    # sm_upsample_sum2 with the paired output
+    h0, w0, C = 24, 40, 512
+    n0, n1, n2 = B * h0 * w0, B * (h0 // 2) * (w0 // 2), B * (h0 // 4) * (w0 // 4)
+    a0, a1, a2 = (torch.randn(n, C, generator=g).to(dev) for n in (n0, n1, n2))
+    o3 = torch.empty(n0, 3 * C, dtype=torch.float16, device=dev)
+    op = torch.empty(n0, 2 * C, dtype=torch.float16, device=dev)
+    H.upsample_sum2(a0, a1, a2, o3, B, h0, w0, C, relu=True)
+    H.upsample_sum2(a0, a1, a2, op, B, h0, w0, C, relu=True)
+    torch.cuda.synchronize()
+    hi, lo = H.pairs_to_float(op.cpu(), C)
+    assert torch.equal(hi, o3[:, :C].cpu().float()) and torch.equal(lo, o3[:, C:2 * C].cpu().float())
+
+
 def test_fused_split_producers():
     """the two producers that write a split operand directly: sm_upsample_bilinear_x3 (the mask branch's [l0 | up2(l1) |
     up4(l2)] concatenation) and the SM_CONV_OUT_X3 epilogue (sip_mask_lat0 -> sip_mask_lat without an f32 round trip);
@@ -422,7 +491,9 @@ def test_x3_head_matches_the_fp32_oracle_on_identical_features(head_case):
     # round 6: the 3x3 tower convs and fcos_cls + sip_cof read paired operands (three products on fragments read once)
     import sipmask_amd.engine as E
     paired = sorted(cv.name for cv in eng.convs if cv.mode == "x3p")
-    assert paired == (["head.cls_cof", "head.reg_convs.3", "head.tower0", "head.tower1", "head.tower2"] if E._X3_PAIRS else [])
+    assert paired == (["head.cls_cof", "head.reg_convs.3", "head.reg_ctr", "head.sip_mask_lat", "head.sip_mask_lat0",
+                       "head.sip_mask_lat0.l1", "head.sip_mask_lat0.l2", "head.tower0", "head.tower1", "head.tower2"]
+                      if E._X3_PAIRS else [])
     eng.load_pyramid([f.cuda() for f in c["feats"]])
     eng.run_head(with_post=True)
     torch.cuda.synchronize()
