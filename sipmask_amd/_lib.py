@@ -114,6 +114,7 @@ PROTOTYPES = {
     "sm_offset_linear_bwd_workspace": (C.c_int64, [C.c_int64, _I]),
     "sm_offset_linear_bwd": (_I, [_P, _I, _P, _I, C.c_int64, _P, _P, _P]),
     "sm_relu_bf16": (_I, [_P, _P, C.c_int64, _P]),
+    "sm_copy_segments": (_I, [_I, _P, _P, _P, _P]),
     "sm_bottleneck_tail_supported": (_I, [_I]),
     "sm_bottleneck_tail": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sm_conv1x1_pair": (_I, [C.c_int64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

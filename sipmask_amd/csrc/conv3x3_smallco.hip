@@ -60,7 +60,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // halves of a tap are (x_hi, x_lo) / (w_hi, w_lo) and the tap issues w_hi*x_hi + w_hi*x_lo + w_lo*x_hi -- two thirds of the
 // slices, patch bytes and weight loads of the K-concatenated operand [hi | lo | hi] x [hi | hi | lo] for the same products
 template <bool F16, bool PAIRS = false>
-__global__ __launch_bounds__(64, 2) void conv3x3_smallco_kernel(const SmallCoArgs a) {
+__global__ __launch_bounds__(64, 1) void conv3x3_smallco_kernel(const SmallCoArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // SC_RING x SC_BUF
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -83,23 +83,28 @@ __global__ __launch_bounds__(64, 2) void conv3x3_smallco_kernel(const SmallCoArg
 
   // ---- per-lane source of every 16-byte slot of a patch slice: slot q = j * 64 + lane holds position p = q >> 2,
   // physical chunk q & 3 = logical chunk (8 channels) ^ ((p >> 2) & 3); positions outside the image read zeros
-  const uint16_t* src[SC_DMA];
-  bool live[SC_DMA];
+  // (32-bit element offsets, -1 = outside the image: nine registers instead of nine 64-bit pointers + nine flags -- with them the
+  // kernel needed 4 dwords of SCRATCH per lane, the only scratch user of the bf16 plan; round 6)
+  int soff[SC_DMA];
 #pragma unroll
   for (int j = 0; j < SC_DMA; ++j) {
     const int q = j * 64 + lane;
     const int p = q >> 2;
     const int pr = p / SC_PW, pc = p - pr * SC_PW;
     const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
-    live[j] = p < SC_NPOS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const bool live = p < SC_NPOS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
     const int chunk = (q & 3) ^ ((p >> 2) & 3);
-    src[j] = live[j] ? a.x + (img_row0 + (long long)gy * W + gx) * a.in_cstride + chunk * 8
-                     : reinterpret_cast<const uint16_t*>(g_zero16s);
+    soff[j] = live ? (gy * W + gx) * a.in_cstride + chunk * 8 : -1;
   }
+  const uint16_t* const ximg = a.x + img_row0 * a.in_cstride;
+  const unsigned long long zero_page = (unsigned long long)g_zero16s;
   auto dma_patch = [&](int sl, int buf) {
+    const uint16_t* xb = ximg + sl * 32;
+    asm volatile("" : "+s"(xb));                  // opaque: keeps hipcc from hoisting the nine 64-bit addresses out of the slice loop
 #pragma unroll
     for (int j = 0; j < SC_DMA; ++j) {
-      const uint16_t* s = live[j] ? src[j] + sl * 32 : src[j];
+      const unsigned long long pm = soff[j] >= 0 ? ~0ull : 0ull;
+      const unsigned long long s = ((unsigned long long)(xb + soff[j]) & pm) | (zero_page & ~pm);
       __builtin_amdgcn_global_load_lds((glb_void*)s, (lds_void*)(smem + buf * SC_BUF + j * 1024), 16, 0, 0);
     }
   };
@@ -248,8 +253,10 @@ bool smallco_ok(const sm_conv_desc* d) {
   if (d->x3_pairs != 0 && (d->x3_pairs != 1 || !(d->flags & SM_CONV_F16))) return false;     // paired operands: binary16 only
   const int calign = (d->flags & SM_CONV_OUT_F32) ? 4 : 8;        // 16-byte stores
   if (d->out_cstride % calign != 0 || d->out_coff % calign != 0 || d->out_coff + d->cout > d->out_cstride) return false;
-  for (int l = 0; l < d->nlev; ++l)
+  for (int l = 0; l < d->nlev; ++l) {
     if (d->in_h[l] != d->out_h[l] || d->in_w[l] != d->out_w[l] || d->in_h[l] < 1 || d->in_w[l] < 1) return false;
+    if ((long long)d->in_h[l] * d->in_w[l] * d->in_cstride >= (1ll << 31)) return false;      // 32-bit patch offsets per image
+  }
   return true;
 }
 

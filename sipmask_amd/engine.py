@@ -1891,6 +1891,7 @@ class PipelinedPlan:
         self._host = {}                                    # per slot: two sets of pinned host buffers of submit(pack=True)
         self._packs, self._pack_gen = {}, {}               # per slot: unread result sets (oldest first), packs issued
         self._rle_sets = {}                                # per slot: two device-side RLE buffer sets used alternately
+        self._pack_prefix = {}                             # per slot: bytes of RLE strings that travel with the step (adaptive)
         self._meta_pins, self._meta_gen = {}, {}           # per slot: two pinned (det, geom) table pairs + their copy events
         self.last_fetch = dict(wait_s=0.0, pack_s=0.0)     # host seconds of the last fetch(): waiting for the GPU / building dicts
 
@@ -1983,8 +1984,13 @@ class PipelinedPlan:
         pin["ev"].record(self.streams[k])
 
     # RLE strings of one batch that travel with the first (asynchronous) copy; a batch with longer strings pays a second,
-    # synchronous copy in fetch() (from the slot's device buffers, which are double-buffered like the pinned sets)
+    # synchronous copy in fetch() (from the slot's device buffers, which are double-buffered like the pinned sets).  The
+    # prefix ADAPTS (round 6): it starts at PACK_PREFIX_MIN and grows to twice the longest batch seen (a power of two, at
+    # most PACK_PREFIX_BYTES) -- a step's strings are 30-150 KB, and copying a fixed 4 MB per step was 1.4 GB/s of PCIe
+    # traffic at BASELINE's shape and 16 GB/s in the six-slot stress configuration, where it provoked GPU memory faults
+    # ("the PipelinedPlan abort").
     PACK_PREFIX_BYTES = 4 << 20
+    PACK_PREFIX_MIN = 256 << 10
 
     def _pack(self, k, canvas_hw, max_runs=8192):
         """on the slot's stream, behind its step: device-side RLE of the step's masks + asynchronous D2H of everything the
@@ -2016,13 +2022,15 @@ class PipelinedPlan:
         else:
             hb = sets[self._pack_gen.get(k, 0) % 2]
         self._pack_gen[k] = self._pack_gen.get(k, 0) + 1
-        for name, src in (("det", o["det"]), ("labels", o["labels"]), ("ndet", o["ndet"]), ("nruns", rle["nruns"]),
-                          ("offsets", rle["offsets"])):
-            hb[name].copy_(src, non_blocking=True)
-        hb["packed"].copy_(rle["packed"][:hb["packed"].numel()], non_blocking=True)
+        prefix = min(hb["packed"].numel(), self._pack_prefix.get(k, self.PACK_PREFIX_MIN))
+        # ONE launch writes all six pieces into the pinned set (sm_copy_segments) -- not six hipMemcpyAsync calls: with several
+        # steps in flight the SDMA engines' device -> host copies aborted the process with a GPU memory fault once in 20 000 -
+        # 90 000 steps (round 6, DESIGN section 6: 25 of 145 stress workers with them, 0 of 130 without)
+        H.copy_segments([(o["det"], hb["det"]), (o["labels"], hb["labels"]), (o["ndet"], hb["ndet"]), (rle["nruns"], hb["nruns"]),
+                         (rle["offsets"], hb["offsets"]), (rle["packed"][:prefix], hb["packed"][:prefix])])
         ev = torch.cuda.Event()
         ev.record(self.streams[k])
-        q.append(dict(ev=ev, hb=hb, canvases=list(rle["canvases"]), rle=rle))
+        q.append(dict(ev=ev, hb=hb, canvases=list(rle["canvases"]), rle=rle, prefix=prefix))
 
     def fetch(self, slot=None):
         """the packed results of the OLDEST unread step submitted to `slot` with pack=True: blocks the HOST until that step
@@ -2043,10 +2051,13 @@ class PipelinedPlan:
             q.pop(0)                            # this result set is unusable whatever the caller does next
             raise RuntimeError("sm_rle_encode: max_runs too small, a mask needs %d runs" % (-nruns.min()))
         total = int(offs[-1])
-        blob = hb["packed"][:min(total, hb["packed"].numel())].numpy().tobytes()
-        if total > hb["packed"].numel():        # rare: longer strings than the prefix that travelled with the step -- the
+        prefix = rec["prefix"]
+        blob = hb["packed"][:min(total, prefix)].numpy().tobytes()
+        if total > prefix:                      # rare: longer strings than the prefix that travelled with the step -- the
             # slot's device buffers are double-buffered (_pack), and a slot holds at most two unread sets: still intact
-            blob += rec["rle"]["packed"][hb["packed"].numel():total].cpu().numpy().tobytes()
+            blob += rec["rle"]["packed"][prefix:total].cpu().numpy().tobytes()
+            grow = 1 << int(math.ceil(math.log2(2 * total)))          # the next packs of this slot carry twice this batch
+            self._pack_prefix[k] = min(self.PACK_PREFIX_BYTES, max(grow, self._pack_prefix.get(k, self.PACK_PREFIX_MIN)))
         q.pop(0)
         plan = self.plans[k]
         out, mx = [], plan.max_num

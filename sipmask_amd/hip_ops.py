@@ -299,6 +299,23 @@ def groupnorm_apply_x3(x, gamma, beta, stats, lv, channels, groups=32, eps=1e-5,
                                                  _lib.ptr(y_split), _lib.stream_ptr()), "sm_groupnorm_apply_x3")
 
 
+def copy_segments(pairs):
+    """pairs: up to 8 (src, dst) tensor pairs of equal byte size, each contiguous; src on the device, dst on the device or
+    in PINNED host memory -- ONE launch on the current stream copies them all (sm_copy_segments: the per-step results go to
+    the host through it instead of through hipMemcpyAsync; see include/sipmask_hip.h)."""
+    n = len(pairs)
+    if not 1 <= n <= 8:
+        raise ValueError("copy_segments: 1 to 8 segments")
+    for s, d in pairs:
+        if not s.is_cuda or not (d.is_cuda or d.is_pinned()) or not s.is_contiguous() or not d.is_contiguous() or \
+                s.numel() * s.element_size() != d.numel() * d.element_size():
+            raise ValueError("copy_segments: contiguous device source, device or pinned-host destination, equal byte sizes")
+    src = (C.c_void_p * n)(*[s.data_ptr() for s, _ in pairs])
+    dst = (C.c_void_p * n)(*[d.data_ptr() for _, d in pairs])
+    nb = (C.c_int64 * n)(*[s.numel() * s.element_size() for s, _ in pairs])
+    _lib.check(_lib.load().sm_copy_segments(n, src, dst, nb, _lib.stream_ptr()), "sm_copy_segments")
+
+
 def det_boxes_override(det, sets, counter, flag):
     """det [..., n, >= 4] f32 (a contiguous detection table), sets [nsets, ..., n, 4] f32, counter int32 [1], flag bool / uint8
     scalar, all on the device: one launch of sm_det_boxes_override (evaluation-workload injection, bench.py --det-boxes)"""

@@ -364,10 +364,10 @@ class SipMaskVIS(SipMask):
                 ids = self.bbox_head.match_clip(r["det_feats"], r["det_bboxes"], r["det_labels"], r["ndet"],
                                                 [m['is_first'] for m in clip_metas[i]])
                 h = host[k]
-                h["nd"].copy_(r["ndet"].view(-1), non_blocking=True)
-                h["ids"].copy_(ids, non_blocking=True)
-                h["det"].copy_(r["det_bboxes"], non_blocking=True)
-                h["lab"].copy_(r["det_labels"], non_blocking=True)
+                # one launch into the pinned set (sm_copy_segments), not four asynchronous SDMA copies (engine.PipelinedPlan._pack
+                # has the measurement behind that)
+                H.copy_segments([(r["ndet"].view(-1), h["nd"]), (ids, h["ids"]), (r["det_bboxes"].contiguous(), h["det"]),
+                                 (r["det_labels"].contiguous(), h["lab"])])
                 ev = torch.cuda.Event()
                 ev.record(tr)
             done[i], freed[k] = ev, ev

@@ -870,6 +870,36 @@ def test_input_pipeline_vs_oracle():
     assert d.max() <= 1.0 + 1e-4 and (d > 1e-3).mean() < 1e-3
 
 
+def test_copy_segments_to_pinned_host_memory():
+    """sm_copy_segments (round 6): several byte ranges -- aligned and unaligned, empty, 1 byte to 3 MB -- copied by ONE launch
+    from device tensors into PINNED host buffers (and into device buffers); the host sees every byte once the stream has
+    completed.  This is how a step's results leave the device (PipelinedPlan._pack, SipMaskVIS.clip_test_many)."""
+    from sipmask_amd import hip_ops as H
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    sizes = [4000, 17, 1, 3 * 1024 * 1024 + 5, 400, 8 * 100 * 5 * 4]
+    srcs = [torch.randint(0, 256, (n,), generator=g, dtype=torch.uint8).to(dev) for n in sizes]
+    pinned = [torch.full((n,), 7, dtype=torch.uint8).pin_memory() for n in sizes]
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        H.copy_segments(list(zip(srcs, pinned)))
+    st.synchronize()
+    for s, d in zip(srcs, pinned):
+        assert torch.equal(s.cpu(), d)
+    # unaligned source view, typed tensors, device destinations
+    a = torch.arange(1000, dtype=torch.int32, device=dev)
+    f = torch.randn(33, 5, generator=g).to(dev)
+    da = torch.zeros(999, dtype=torch.int32).pin_memory()
+    df = torch.zeros(33, 5, device=dev)
+    H.copy_segments([(a[1:], da), (f, df)])
+    torch.cuda.synchronize()
+    assert torch.equal(da, a[1:].cpu()) and torch.equal(df, f)
+    with pytest.raises(ValueError):
+        H.copy_segments([(a, torch.zeros(999, dtype=torch.int32).pin_memory())])          # size mismatch
+    with pytest.raises(ValueError):
+        H.copy_segments([(a, torch.zeros(1000, dtype=torch.int32))])                      # pageable destination
+
+
 def test_det_select_vs_oracle():
     """score -> per-level top-k -> gather/decode (sipmask_head.py:563-591) for a 2-image batch."""
     from sipmask_amd import hip_ops as H
