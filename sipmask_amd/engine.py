@@ -2025,7 +2025,7 @@ class PipelinedPlan:
         prefix = min(hb["packed"].numel(), self._pack_prefix.get(k, self.PACK_PREFIX_MIN))
         # ONE launch writes all six pieces into the pinned set (sm_copy_segments) -- not six hipMemcpyAsync calls: with several
         # steps in flight the SDMA engines' device -> host copies aborted the process with a GPU memory fault once in 20 000 -
-        # 90 000 steps (round 6, DESIGN section 6: 25 of 145 stress workers with them, 0 of 130 without)
+        # 90 000 steps (round 6, DESIGN section 6: 27 of 199 stress workers with them, 0 of 130 without)
         H.copy_segments([(o["det"], hb["det"]), (o["labels"], hb["labels"]), (o["ndet"], hb["ndet"]), (rle["nruns"], hb["nruns"]),
                          (rle["offsets"], hb["offsets"]), (rle["packed"][:prefix], hb["packed"][:prefix])])
         ev = torch.cuda.Event()

@@ -410,7 +410,7 @@ def test_pipelined_plan_stress(env, cycles):
     in the configuration that reproduced the fault fastest (six slots of one 128 x 160 image: ~1 worker in 5 died of
     "Memory access fault by GPU node ... Reason: Unknown" within 4 000 cycles).
     The cause (tools/fault_rate.sh): the six hipMemcpyAsync device -> pinned-host copies behind every step,
-    executed by the SDMA engines while other steps were in flight -- 25 of 145 workers died with them, 0 of 130 without them
+    executed by the SDMA engines while other steps were in flight -- 27 of 199 workers died with them, 0 of 130 without them
     (results left on the device, or HSA_ENABLE_SDMA=0).  The results now leave the device through ONE kernel launch that
     writes the pinned buffers (sm_copy_segments): 0 of 40 workers of the reproducing configuration died."""
     if not torch.cuda.is_available():
