@@ -599,9 +599,11 @@ def test_detector_forward_train_vs_oracle():
     HIP autograd ops, against torch-CPU autograd through the oracle.
     (1) backbone + FPN in isolation: a fixed random linear functional of the 5 FPN outputs, so the gradients depend
         on the forward only linearly -- every checked parameter within cosine > 0.995 / relative error < 0.1;
-    (2) the full training graph: loss values within 3 %; parameter gradients only sanity-bounded (cosine > 0.9):
-        on this untrained, gain-calibrated random net the head's logits differ by 5-15 % between the bf16 pipeline
-        and the f32 oracle (test_gpu_engine.py), and the loss gradients inherit that."""
+    (2) the full training graph, bounds = 1.5 x measured (round 6): loss_cls / loss_bbox / loss_centerness within 0.7 %
+        (measured <= 0.45 %), loss_mask 2.7 % (1.73 %); the checked HEAD gradients cosine >= 0.9975 / error <= 8.1 % (measured
+        0.9986 / 5.4 %), neck 0.985 / 21.5 %, trunk 0.925 / 47.5 % -- except layer2.0.conv1, the one tensor that flips between
+        two outcomes (comment below; wiring bound).  The same step at BASELINE's shape, where this noise averages out, is held to
+        cosine >= 0.9985 for EVERY tensor: tests/test_gpu_baseline_configs.py."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from oracle import loss as OL
@@ -620,7 +622,9 @@ def test_detector_forward_train_vs_oracle():
         return {k: (v.detach().cpu().clone().requires_grad_(True) if k in pnames else v.detach().cpu().clone())
                 for k, v in det.state_dict().items()}
 
-    def compare(names, osd, min_cos, max_err):
+    dump = os.environ.get("SIPMASK_TEST_DUMP")
+
+    def compare(names, osd, min_cos, max_err, tag=""):
         params = dict(det.named_parameters())
         bad = []
         for name in names:
@@ -629,6 +633,9 @@ def test_detector_forward_train_vs_oracle():
             got = got.cpu().float()
             err = float((got - ref).norm() / ref.norm())
             cos = float((got * ref).sum() / (got.norm() * ref.norm() + 1e-30))
+            if dump:
+                with open(dump + ".train_small", "a") as f:
+                    f.write("%s %-50s err %.4f cos %.5f\n" % (tag, name, err, cos))
             if err > max_err or cos < min_cos:
                 bad.append((name, round(err, 3), round(cos, 4)))
         assert not bad, bad
@@ -710,14 +717,22 @@ def test_detector_forward_train_vs_oracle():
     loss = det.forward_train(img.cuda(), metas, [b.cuda() for b in gtb], [l.cuda() for l in gtl], gt_masks=gtm)
     for k in loss:
         a, b = float(loss[k].detach()), float(oloss[k].detach())
-        assert abs(a - b) <= 3e-2 * max(1.0, abs(b)), (k, a, b)
+        if dump:
+            with open(dump + ".train_small", "a") as f:
+                f.write("loss %-16s hip %.6f oracle %.6f rel %.5f\n" % (k, a, b, abs(a - b) / max(1.0, abs(b))))
+        # 1.5 x measured (round 6, three runs, identical to five digits: bbox 0.45 %, cls 0.13 %, centerness 0.01 %, mask 1.73 %)
+        assert abs(a - b) <= (2.7e-2 if k == "loss_mask" else 7e-3) * max(1.0, abs(b)), (k, a, b)
     sum(loss.values()).backward()
     # the trunk under the full loss: the same two-outcome tensor as in (1) (layer2.0.conv1: 0.925 / 0.40, one run in six
     # 0.8997 / 0.462 -- seen again in round 4), so the same wiring bound; what the composed backward is HELD to is
     # test_backbone_fpn_backward_vs_same_rounding_emulation (noise-floor bound per tensor)
-    compare(trunk, osd, 0.85, 0.55)
+    compare(("backbone.layer2.0.conv1.weight",), osd, 0.85, 0.55, "full_trunk")
+    # every other checked trunk / neck tensor: 1.5 x measured (worst: layer2.0.downsample 0.315 / 0.951, neck <= 0.143 / >= 0.990)
+    compare([n for n in trunk if n.startswith("backbone.") and n != "backbone.layer2.0.conv1.weight"], osd, 0.925, 0.475, "full_trunk")
+    compare([n for n in trunk if n.startswith("neck.")], osd, 0.985, 0.215, "full_trunk")
+    # the head, behind at most the FPN's bf16 rounding: 1.5 x measured (worst: feat_align.conv_offset 0.054 / 0.9986)
     compare(("bbox_head.cls_convs.0.conv.weight", "bbox_head.reg_convs.3.gn.weight", "bbox_head.sip_cof.weight",
-             "bbox_head.feat_align.conv_offset.weight", "bbox_head.sip_mask_lat0.weight"), osd, 0.9, 0.5)
+             "bbox_head.feat_align.conv_offset.weight", "bbox_head.sip_mask_lat0.weight"), osd, 0.9975, 0.081, "full_head")
 
 
 def test_fcos_target_kernel_vs_tensor_formulation():
