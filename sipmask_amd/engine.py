@@ -945,24 +945,18 @@ class SipMaskEngine:
         else:
             self._add("split:pyr", lambda: H.split3_f16(self.pyr, self.pyr_x3, 256))
 
-        def gn_or_split(label, yv, st, norm_name, keep_f32, o_pairs, o_split):
-            """GroupNorm + ReLU (or nothing, SSD-style towers) of a tower conv's f32 output -> what its consumers read: f32 rows
-            (in place), the paired operand of the next 3x3 conv, the [hi | lo | hi] operand of the small-cout / 1x1 convs"""
-            assert (o_pairs is None) != (o_split is None), "one split operand per tensor (an in-place f32 pass runs once)"
+        def gn_or_split(label, yv, st, norm_name, keep_f32, out):
+            """GroupNorm + ReLU (or nothing: SSD-style towers, whose ReLU is the conv's) of a tower conv's f32 output -> the
+            operand its consumers read, in the plan's layout (paired, or [hi | lo | hi]); keep_f32: also f32 rows, in place"""
+            key = "y_pairs" if pairs else "y_split"
             if self.flag_norm:
                 gam, bet = par(h + norm_name + ".weight"), par(h + norm_name + ".bias")
-                if o_pairs is not None:
-                    self._add("gn:" + label, lambda: H.groupnorm_apply_x3(yv, gam, bet, st, lv, 256, 32, 1e-5, True,
-                                                                          y_f32=yv if keep_f32 else None, y_pairs=o_pairs))
-                if o_split is not None or o_pairs is None:
-                    self._add("gn:" + label + ("" if o_pairs is None else ".split"),
-                              lambda: H.groupnorm_apply_x3(yv, gam, bet, st, lv, 256, 32, 1e-5, True,
-                                                           y_f32=yv if (keep_f32 and o_pairs is None) else None, y_split=o_split))
+                self._add("gn:" + label, lambda: H.groupnorm_apply_x3(yv, gam, bet, st, lv, 256, 32, 1e-5, True,
+                                                                      y_f32=yv if keep_f32 else None, **{key: out}))
+            elif pairs:
+                self._add("split:" + label, lambda: H.split_pairs_f16(yv, out, 256))
             else:
-                if o_pairs is not None:
-                    self._add("split:" + label, lambda: H.split_pairs_f16(yv, o_pairs, 256))
-                if o_split is not None:
-                    self._add("split:" + label + ("" if o_pairs is None else ".split"), lambda: H.split3_f16(yv, o_split, 256))
+                self._add("split:" + label, lambda: H.split3_f16(yv, out, 256))
 
         relu = 0 if self.flag_norm else SM_CONV_RELU
         x, xg, xw = self.pyr_x3, 0, pyr_w
@@ -985,25 +979,21 @@ class SipMaskEngine:
                 yv, st = y[g * rows:(g + 1) * rows], stats2[g * S:(g + 1) * S]
                 last_cls = g == 0 and last_depth                  # feeds FeatureAlign's f32 deformable conv only
                 last_reg = g == 1 and i == nreg - 1               # feeds reg_ctr, the mask branch ([hi | lo | hi]) and f32 consumers
-                o_next = o_split = None
-                if last_reg:       # read by reg_ctr and sip_mask_lat0's convs: the plan's operand layout (paired, or [hi | lo | hi])
-                    o_split = torch.empty(rows, tw, dtype=F16, device=dev)
-                elif not last_cls:
-                    o_next = nxt[g * rows:(g + 1) * rows] if nxt is not None else torch.empty(rows, tw, dtype=F16, device=dev)
                 if last_cls:
                     cls_f32 = yv
                     if self.flag_norm:                            # normalise in place, no split operand
                         gam, bet = par(h + n + ".gn.weight"), par(h + n + ".gn.bias")
                         self._add("gn:" + n, (lambda yv=yv, gam=gam, bet=bet, st=st:
                                               H.groupnorm_apply_x3(yv, gam, bet, st, lv, 256, 32, 1e-5, True, y_f32=yv)))
-                elif pairs:
-                    gn_or_split(n, yv, st, n + ".gn", last_reg, o_split if last_reg else o_next, None)
-                else:
-                    gn_or_split(n, yv, st, n + ".gn", last_reg, None, o_split if last_reg else o_next)
+                    continue
+                # the operand of what reads this tensor: the next tower conv (both groups in `nxt`), or -- behind the reg tower's
+                # last conv -- reg_ctr and sip_mask_lat0's convs, which also read the f32 rows
+                out = nxt[g * rows:(g + 1) * rows] if nxt is not None else torch.empty(rows, tw, dtype=F16, device=dev)
+                gn_or_split(n, yv, st, n + ".gn", last_reg, out)
                 if last_reg:
-                    self.reg_feat, reg_x3 = yv, o_split
-                if g == 1:
-                    xr = o_next
+                    self.reg_feat, reg_x3 = yv, out
+                else:
+                    xr = out
             x, xg, xw = nxt, rows, tw
         for i in range(ncls, nreg):                   # the reg tower is deeper (stacked_convs vs stacked_convs - 1)
             y = torch.empty(rows, 256, dtype=f32, device=dev)
@@ -1013,15 +1003,11 @@ class SipMaskEngine:
             if self.flag_norm:
                 c.gn_stats = self.gn_stats
             last = i == nreg - 1
-            o_next = None if last else torch.empty(rows, tw, dtype=F16, device=dev)
-            o_split = torch.empty(rows, tw, dtype=F16, device=dev) if last else None     # reg_ctr's / sip_mask_lat0's operand
-            if pairs:
-                gn_or_split(name, y, self.gn_stats, name + ".gn", last, o_split if last else o_next, None)
-            else:
-                gn_or_split(name, y, self.gn_stats, name + ".gn", last, None, o_split if last else o_next)
-            xr = o_next
+            out = torch.empty(rows, tw, dtype=F16, device=dev)       # the next reg conv's operand; behind the last: reg_ctr's / sip_mask_lat0's
+            gn_or_split(name, y, self.gn_stats, name + ".gn", last, out)
+            xr = out
             if last:
-                self.reg_feat, reg_x3 = y, o_split
+                self.reg_feat, reg_x3 = y, out
         self.cls_feat = cls_f32
         # mask basis branch (sipmask_head.py:275-285) on lane 2: f32 [l0 | up2(l1) | up4(l2)] -> split -> 1x1 -> split -> 3x3
         (h0, w0) = sizes[0]
