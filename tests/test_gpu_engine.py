@@ -423,6 +423,40 @@ def test_pipelined_plan_stress(env, cycles):
     assert r.returncode == 0 and ("PIPELINE_STRESS_OK %d" % cycles) in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
 
 
+def test_pipelined_pack_prefix_adapts_and_long_batches_fall_back(monkeypatch):
+    """PipelinedPlan.fetch with RLE strings longer than the prefix that travelled with the step (round 6: the prefix starts
+    small and adapts): the rest comes from the slot's double-buffered device strings by a second copy, the slot's next packs
+    carry twice the batch seen, and every RLE dict equals the single plan's."""
+    import sipmask_amd.engine as E
+    from sipmask_amd.synthetic import build_synthetic_detector
+    monkeypatch.setattr(E, "_SPLIT_K", False)
+    monkeypatch.setattr(E.PipelinedPlan, "PACK_PREFIX_MIN", 64)          # bytes: every batch of this test is longer
+    det = build_synthetic_detector(50, seed=0)
+    with torch.no_grad():
+        det.bbox_head.fcos_cls.bias.fill_(-2.0)
+    g = torch.Generator().manual_seed(29)
+    H_, W_ = 192, 256
+    batches = [torch.randn(2, 3, H_, W_, generator=g).cuda() for _ in range(3)]
+    one = det.prepare(2, (H_, W_), (H_, W_, 3), lanes=1)
+    want = []
+    for b in batches:
+        r = one.run(b)
+        torch.cuda.synchronize()
+        want.append(one.encode_rle((H_, W_)))
+    assert sum(len(x["counts"]) for w in want for img in w for x in img) > 3 * 64
+    pipe = det.prepare(2, (H_, W_), (H_, W_, 3), in_flight=2)
+    seen = []
+    for rep in range(3):
+        for bi, b in enumerate(batches):
+            k = pipe.submit(b, pack=True, canvas_hw=(H_, W_))
+            res = pipe.fetch(k)
+            for img in range(2):
+                assert res[img][2] == want[bi][img], (rep, bi, img)
+            seen.append(dict(pipe._pack_prefix))
+    assert seen[0] and all(v >= 128 and (v & (v - 1)) == 0 for v in seen[-1].values())      # grown, a power of two
+    assert seen[-1] == seen[-4]                                                            # and settled
+
+
 def test_pipelined_submit_packs_results_and_keeps_metas_per_slot(monkeypatch):
     """PipelinedPlan.submit(img, img_metas, pack=True) / fetch (round 4):
     (1) result packing behind every step on the slot's stream (sm_mask_rects + sm_rle_encode + asynchronous copies into
