@@ -76,7 +76,6 @@ struct ConvKArgs {
   int ksplit;
   float* part;
   long long part_rows;   // rows of one partial slab
-  int x3_pairs;          // binary16 build, 32-wide K steps: a K step is one group [hi 16 | lo 16] (sm_conv_desc.x3_pairs)
 };
 
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
@@ -1999,7 +1998,6 @@ int launch_conv(const sm_conv_desc* d, const void* x, const float* offset, const
   a.ksplit = S;
   a.part = (float*)workspace;
   a.part_rows = (long long)d->batch * d->out_h[0] * d->out_w[0];
-  a.x3_pairs = d->x3_pairs;
   a.ngroups = d->ngroups > 1 ? d->ngroups : 1;
   a.tpg = t * a.ntn;
   a.x_grows = d->x_group_rows;

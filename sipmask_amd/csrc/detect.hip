@@ -37,7 +37,7 @@ __device__ void block_bitonic_desc(unsigned long long* a, int P, bool in_lds = t
   bool cross = true;      // the data this step reads may have been written by another wave
   for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      if (stride >= 128 || cross) __syncthreads();
+      if (stride >= 128 || cross) sm_syncthreads_flat();      // (`a` may be a generic pointer: common.h)
       else {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -54,7 +54,7 @@ __device__ void block_bitonic_desc(unsigned long long* a, int P, bool in_lds = t
       }
     }
   }
-  __syncthreads();
+  sm_syncthreads_flat();
 }
 
 // Exact top-k of keys[0..n) for one block of TK_THREADS threads.  Result: sm.sel[0..k) sorted
@@ -439,7 +439,7 @@ __device__ int block_greedy_nms(const unsigned long long* keys, int n, float thr
       const unsigned long long row = __ballot(hit);
       if (lane == 0) sm.rowm[t] = row;
     }
-    __syncthreads();
+    sm_syncthreads_flat();
     // (c) scalar resolve + (d) append, by wave 0 alone (the 64 dependent steps are serial anyway; 16 waves doing them
     // redundantly only fought for the issue slots of the 4 SIMDs)
     if (wv == 0) {
@@ -458,7 +458,7 @@ __device__ int block_greedy_nms(const unsigned long long* keys, int n, float thr
       }
       if (lane == 0) sm.nkept = nkept + __popcll(am);
     }
-    __syncthreads();
+    sm_syncthreads_flat();
     nkept = sm.nkept;
   }
   return nkept;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __r
   const float* ct = ctr + (long long)b * a.kmax;
   const float4* bx = reinterpret_cast<const float4*>(boxes) + (long long)b * a.kmax;
   if (tid == 0) sm.n = 0;
-  __syncthreads();
+  sm_syncthreads_flat();
   // 0. how many candidates pass the raw class score threshold (bbox_nms.py:111)?  decides LDS vs global scratch
   {
     unsigned int cnt = 0;
@@ -518,9 +518,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __r
     for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
     if (lane == 0 && cnt) atomicAdd(&sm.n, cnt);
   }
-  __syncthreads();
+  sm_syncthreads_flat();
   const int n = (int)sm.n;
-  __syncthreads();
+  sm_syncthreads_flat();
   int32_t* outk = cls_keep + ((long long)b * a.C + c) * a.kmax;
   if (n == 0) {
     if (tid == 0) cls_cnt[b * a.C + c] = 0;
@@ -532,9 +532,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __r
   int slot = -1;
   if (a.heavy_slots > 0 && n > a.heavy_min) {
     if (tid == 0) sm.nkept = atomicAdd(a.heavy_cnt, 1);
-    __syncthreads();
+    sm_syncthreads_flat();
     slot = sm.nkept < a.heavy_slots ? sm.nkept : -1;
-    __syncthreads();
+    sm_syncthreads_flat();
   }
   if (tid == 0) sm.n = 0;
   const bool in_lds = slot >= 0 ? (size_t)P * 8 <= (size_t)a.P_lds * 28 : P <= a.P_lds;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __r
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws);
   float4* kept_box = reinterpret_cast<float4*>(ws + cap * 8);
   uint32_t* kept_idx = reinterpret_cast<uint32_t*>(ws + cap * 24);
-  __syncthreads();
+  sm_syncthreads_flat();
   // 1. compaction of candidates with raw class score > thr.  The order of insertion is irrelevant: the sort key
   //    (score, index) is a total order.
   for (int base = 0; base < K; base += NMS_THREADS) {
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(const float* __r
     }
   }
   for (int i = n + tid; i < P; i += NMS_THREADS) keys[i] = 0ull;
-  __syncthreads();
+  sm_syncthreads_flat();
   // 2. sort (score desc, index asc)
   block_bitonic_desc(keys, P, in_lds);
   if (slot >= 0) {   // hand the sorted class over: boxes + indices in score order

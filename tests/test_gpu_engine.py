@@ -399,20 +399,25 @@ def test_mixed_size_batch_reads_img_shape_and_scale_factor_per_image(rescale):
 
 @pytest.mark.parametrize("env,cycles", [({}, 2000), ({"AMD_SERIALIZE_KERNEL": "3"}, 500), ({"HSA_ENABLE_SDMA": "0"}, 500),
                                         ({"SIPMASK_STRESS_POISON": "1"}, 500),
-                                        ({"SIPMASK_STRESS_DEPTH": "6", "SIPMASK_STRESS_SHAPE": "128,160,1"}, 4000)])
+                                        ({"SIPMASK_STRESS_DEPTH": "6", "SIPMASK_STRESS_SHAPE": "128,160,1"}, 4000),
+                                        ({"SIPMASK_STRESS_SHAPE": "192,256,4", "SIPMASK_STRESS_BURST": "6000"}, 24)])
 def test_pipelined_plan_stress(env, cycles):
     """VERDICT r5 #3 (an unexplained SIGABRT inside torch.cuda.synchronize() of a PipelinedPlan test on one box in round 5) --
     ROOT-CAUSED in round 6 with this test as the reproducer.  Thousands of submit(pack=True) / fetch cycles over the slots of a
     PipelinedPlan with hipGraph replay, batches and img_metas varying from step to step, every result held to the single
     plan's, the slot's stream queried after every submit -- in its own process (tests/_pipeline_stress_worker.py): as shipped,
     with every kernel serialised by the runtime (AMD_SERIALIZE_KERNEL=3), with the SDMA engines off, with every
-    uninitialised buffer of the plans poisoned (0x7f bytes: results must not depend on what an allocation held before), and
-    in the configuration that reproduced the fault fastest (six slots of one 128 x 160 image: ~1 worker in 5 died of
-    "Memory access fault by GPU node ... Reason: Unknown" within 4 000 cycles).
-    The cause (tools/fault_rate.sh): the six hipMemcpyAsync device -> pinned-host copies behind every step,
-    executed by the SDMA engines while other steps were in flight -- 27 of 199 workers died with them, 0 of 130 without them
-    (results left on the device, or HSA_ENABLE_SDMA=0).  The results now leave the device through ONE kernel launch that
-    writes the pinned buffers (sm_copy_segments): 0 of 40 workers of the reproducing configuration died."""
+    uninitialised buffer of the plans poisoned (0x7f bytes: results must not depend on what an allocation held before), in the
+    configuration that reproduced the first cause fastest (six slots of one 128 x 160 image) and in the one that reproduces
+    the second (four 192 x 256 images per step, 6 000 steps submitted back to back).
+    Two causes, both "Memory access fault by GPU node ... Reason: Unknown" followed by SIGABRT:
+    (1) a barrier race in nms_class_kernel's bitonic sort -- its keys are reached through a generic pointer, hipcc emits
+    flat_store and leaves the next step's s_barrier without a wait, so beside another step's LDS traffic a padding key could
+    end up among the valid ones and its candidate index 0xffffffff sent a load 64 GB past the boxes: 8 of 8 workers of the
+    last variant died within 3 000 steps, 0 of 6 in 10 000 with sm_syncthreads_flat() (profiles/r06_pipeline_nms_sort_race.txt);
+    (2) the six hipMemcpyAsync device -> pinned-host copies behind every step, executed by the SDMA engines while other steps
+    were in flight, raised the rate in the six-slot configuration from 0 of 130 workers to 27 of 199; the results now leave
+    the device through ONE kernel launch that writes the pinned buffers (sm_copy_segments): 0 of 40."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import subprocess
