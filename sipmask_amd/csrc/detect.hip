@@ -39,6 +39,7 @@ __device__ void block_bitonic_desc(unsigned long long* a, int P, bool in_lds = t
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       if (stride >= 128 || cross) sm_syncthreads_flat();      // (`a` may be a generic pointer: common.h)
       else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // flat stores of the step before (generic `a`), same wave
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
