@@ -357,8 +357,7 @@ int sm_relu_bf16(const void* x, void* y, int64_t n, sm_stream_t stream);
 /* nseg <= SM_COPY_MAX_SEGS byte ranges copied by ONE launch: dst[i][0 .. bytes[i]) = src[i][...].  Meant for the per-step
  * results (sipmask_head.py:645-662 returns them per batch; M/mmdet/apis/test.py:12-72 collects them): the destinations are
  * pinned host buffers (hipHostMalloc: GPU-addressable), so the step's boxes / labels / counts / RLE strings reach the host
- * through a kernel on the step's stream instead of six hipMemcpyAsync calls on the SDMA engines -- which, with several
- * steps in flight, aborted the process with a GPU memory fault once in 20 000 - 90 000 steps on ROCm 7.2.
+ * through ONE kernel launch on the step's stream instead of six hipMemcpyAsync calls.
  * src / dst / bytes are HOST arrays (read during the call). */
 #define SM_COPY_MAX_SEGS 8
 int sm_copy_segments(int nseg, const void* const* src, void* const* dst, const int64_t* bytes, sm_stream_t stream);

@@ -618,10 +618,8 @@ extern "C" int sm_relu_bf16(const void* x, void* y, int64_t n, sm_stream_t strea
 /* ---- results to the host without the runtime's asynchronous copy path (round 6) ------------------------------------
  * Up to SM_COPY_MAX_SEGS (source, destination, bytes) segments copied by ONE kernel launch; the destinations are
  * pinned (hipHostMalloc) host buffers, which the GPU addresses directly.  What it replaces: six hipMemcpyAsync
- * device -> pinned-host calls behind every step (boxes, labels, counts, run counts, string offsets, string prefix).  With
- * several steps in flight on their own streams those copies, executed by the SDMA engines, aborted the process with a GPU
- * memory fault about once in 20 000 - 90 000 steps (ROCm 7.2 on this platform): 27 of 199 stress workers
- * with them, 0 of 130 without them or with HSA_ENABLE_SDMA=0.  A kernel's stores to coherent host memory are visible to the
+ * device -> pinned-host calls behind every step (boxes, labels, counts, run counts, string offsets, string prefix): one host
+ * call on the submit path of a pipelined step instead of six.  A kernel's stores to coherent host memory are visible to the
  * host once the launch has completed (the event the caller records behind it). */
 namespace {
 struct CopySegs {

@@ -1973,8 +1973,7 @@ class PipelinedPlan:
     # synchronous copy in fetch() (from the slot's device buffers, which are double-buffered like the pinned sets).  The
     # prefix ADAPTS (round 6): it starts at PACK_PREFIX_MIN and grows to twice the longest batch seen (a power of two, at
     # most PACK_PREFIX_BYTES) -- a step's strings are 30-150 KB, and copying a fixed 4 MB per step was 1.4 GB/s of PCIe
-    # traffic at BASELINE's shape and 16 GB/s in the six-slot stress configuration, where it provoked GPU memory faults
-    # ("the PipelinedPlan abort").
+    # traffic at BASELINE's shape and 16 GB/s in the six-slot stress configuration.
     PACK_PREFIX_BYTES = 4 << 20
     PACK_PREFIX_MIN = 256 << 10
 
@@ -2009,9 +2008,10 @@ class PipelinedPlan:
             hb = sets[self._pack_gen.get(k, 0) % 2]
         self._pack_gen[k] = self._pack_gen.get(k, 0) + 1
         prefix = min(hb["packed"].numel(), self._pack_prefix.get(k, self.PACK_PREFIX_MIN))
-        # ONE launch writes all six pieces into the pinned set (sm_copy_segments) -- not six hipMemcpyAsync calls: with several
-        # steps in flight the SDMA engines' device -> host copies aborted the process with a GPU memory fault once in 20 000 -
-        # 90 000 steps (round 6, DESIGN section 6: 27 of 199 stress workers with them, 0 of 130 without)
+        # ONE launch writes all six pieces into the pinned set (sm_copy_segments) instead of six hipMemcpyAsync calls: one
+        # host call per step on the submit path.  (Round 6 first blamed those copies for the pipeline's rare GPU memory fault --
+        # with them the six-slot stress configuration faulted ten times as often -- until the cause turned out to be a barrier
+        # race in the NMS sort, whose window their traffic widened: DESIGN section 6.)
         H.copy_segments([(o["det"], hb["det"]), (o["labels"], hb["labels"]), (o["ndet"], hb["ndet"]), (rle["nruns"], hb["nruns"]),
                          (rle["offsets"], hb["offsets"]), (rle["packed"][:prefix], hb["packed"][:prefix])])
         ev = torch.cuda.Event()

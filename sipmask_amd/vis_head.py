@@ -364,8 +364,7 @@ class SipMaskVIS(SipMask):
                 ids = self.bbox_head.match_clip(r["det_feats"], r["det_bboxes"], r["det_labels"], r["ndet"],
                                                 [m['is_first'] for m in clip_metas[i]])
                 h = host[k]
-                # one launch into the pinned set (sm_copy_segments), not four asynchronous SDMA copies (engine.PipelinedPlan._pack
-                # has the measurement behind that)
+                # one launch into the pinned set (sm_copy_segments) instead of four asynchronous copies (as engine.PipelinedPlan._pack)
                 H.copy_segments([(r["ndet"].view(-1), h["nd"]), (ids, h["ids"]), (r["det_bboxes"].contiguous(), h["det"]),
                                  (r["det_labels"].contiguous(), h["lab"])])
                 ev = torch.cuda.Event()

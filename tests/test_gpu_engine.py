@@ -408,16 +408,16 @@ def test_pipelined_plan_stress(env, cycles):
     plan's, the slot's stream queried after every submit -- in its own process (tests/_pipeline_stress_worker.py): as shipped,
     with every kernel serialised by the runtime (AMD_SERIALIZE_KERNEL=3), with the SDMA engines off, with every
     uninitialised buffer of the plans poisoned (0x7f bytes: results must not depend on what an allocation held before), in the
-    configuration that reproduced the first cause fastest (six slots of one 128 x 160 image) and in the one that reproduces
-    the second (four 192 x 256 images per step, 6 000 steps submitted back to back).
-    Two causes, both "Memory access fault by GPU node ... Reason: Unknown" followed by SIGABRT:
-    (1) a barrier race in nms_class_kernel's bitonic sort -- its keys are reached through a generic pointer, hipcc emits
-    flat_store and leaves the next step's s_barrier without a wait, so beside another step's LDS traffic a padding key could
-    end up among the valid ones and its candidate index 0xffffffff sent a load 64 GB past the boxes: 8 of 8 workers of the
-    last variant died within 3 000 steps, 0 of 6 in 10 000 with sm_syncthreads_flat() (profiles/r06_pipeline_nms_sort_race.txt);
-    (2) the six hipMemcpyAsync device -> pinned-host copies behind every step, executed by the SDMA engines while other steps
-    were in flight, raised the rate in the six-slot configuration from 0 of 130 workers to 27 of 199; the results now leave
-    the device through ONE kernel launch that writes the pinned buffers (sm_copy_segments): 0 of 40."""
+    configuration in which the fault was first bisected (six slots of one 128 x 160 image) and in the one that reproduces it
+    in every run (four 192 x 256 images per step, 6 000 steps submitted back to back).
+    The cause ("Memory access fault by GPU node ... Reason: Unknown", then SIGABRT): a barrier race in
+    nms_class_kernel's bitonic sort -- its keys are reached through a generic pointer, hipcc emits flat_store and leaves the
+    next step's s_barrier without a wait, so beside another step's LDS traffic a padding key could end up among the valid
+    ones and its candidate index 0xffffffff sent a load 64 GB past the boxes: 8 of 8 workers of the last variant died within
+    3 000 steps, 0 of 6 in 10 000 with sm_syncthreads_flat() (profiles/r06_pipeline_nms_sort_race.txt).  (A first bisection
+    had blamed the six hipMemcpyAsync device -> pinned-host copies behind every step -- 27 of 199 workers of the six-slot
+    variant died with them, 0 of 130 without; with the sort fixed the same copies give 0 of 24: they had widened the
+    race's window.  They are one sm_copy_segments launch now for the host calls it saves.)"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import subprocess
