@@ -82,7 +82,12 @@ def barriers_with_flat_stores_in_flight(body):
     return sorted(bad)
 
 
-@pytest.mark.parametrize("src", ["detect.hip", "rle.hip"])
+_DEFAULT = ["detect.hip", "rle.hip"]
+# SIPMASK_LINT_ALL=1: every source of the library (the scan DESIGN.md section 6 reports; several minutes of hipcc)
+_SOURCES = (sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")) if os.environ.get("SIPMASK_LINT_ALL") == "1" else _DEFAULT)
+
+
+@pytest.mark.parametrize("src", _SOURCES)
 def test_no_barrier_with_flat_lds_stores_in_flight(src, tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -97,7 +102,8 @@ def test_no_barrier_with_flat_lds_stores_in_flight(src, tmp_path):
         seen += 1
         for k in barriers_with_flat_stores_in_flight(body):
             bad.append((name, k, body[max(0, k - 6):k + 1]))
-    assert seen > 0, "the lint no longer sees a kernel with flat stores and barriers in %s: retire or retarget it" % src
+    if src in _DEFAULT:
+        assert seen > 0, "the lint no longer sees a kernel with flat stores and barriers in %s: retire or retarget it" % src
     assert not bad, "s_barrier with flat stores possibly in flight:\n" + "\n".join("%s @%d: %s" % b for b in bad)
 
 
